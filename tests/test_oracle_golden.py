@@ -1,0 +1,141 @@
+"""Pin the CPU oracle (oracle/fmk_oracle.c) against fixtures produced by the reference itself.
+
+CPU-only.  Integer outputs must be bit-exact; float64 outputs are sequential restatements of
+the same arithmetic, so they are checked for exact equality too except where NumPy evaluates
+through BLAS/libm paths we cannot reproduce bit-for-bit (stated per assert).
+"""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+
+def test_time_indexer_golden(orc):
+    d = G.load("time_indexer")
+    for c in G.cases(d):
+        ts = d[f"{c}__ts"] if f"{c}__ts" in d else G.synth_from(orc, d[f"{c}__synth"])[0]
+        clock, idx = orc._time_bar_indexer(ts, float(d[f"{c}__interval"]))
+        np.testing.assert_array_equal(clock, d[f"{c}__clock"], err_msg=c)
+        np.testing.assert_array_equal(idx, d[f"{c}__idx"], err_msg=c)
+
+
+def test_threshold_indexers_golden(orc):
+    d = G.load("threshold_indexers")
+    ts, px, am, sd = G.synth_from(orc, d["synth"])
+    for k, want in d.items():
+        kind, _, thr = k.partition("_")
+        if kind == "tick":
+            got = orc._tick_bar_indexer(ts, int(thr))
+        elif kind == "vol32":
+            got = orc._volume_bar_indexer(am, float(thr))
+        elif kind == "dol32":
+            got = orc._dollar_bar_indexer(px, am, float(thr))
+        elif kind == "vol64":
+            got = orc._volume_bar_indexer(d["r_am"], float(thr))
+        elif kind == "dol64":
+            got = orc._dollar_bar_indexer(d["r_px"], d["r_am"], float(thr))
+        else:
+            continue
+        np.testing.assert_array_equal(got, want, err_msg=k)
+    np.testing.assert_array_equal(orc._dollar_bar_indexer(d["big_px"], d["big_am"], 100.0), d["big_dol_100"])
+    np.testing.assert_array_equal(orc._volume_bar_indexer(d["big_am"], 10.0), d["big_vol_10"])
+
+
+REDUCER_CASES = ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37", "sparse_t60"]
+
+
+@pytest.mark.parametrize("case", REDUCER_CASES)
+def test_ohlcv_golden(orc, case):
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    got = orc.comp_bar_ohlcv(px, am, d[f"{case}__ci"])
+    for k, g in zip(G.OHLCV_KEYS, got):
+        np.testing.assert_array_equal(g, d[f"{case}__ohlcv_{k}"], err_msg=f"{case}:{k}")
+        assert g.dtype == d[f"{case}__ohlcv_{k}"].dtype, k
+
+
+@pytest.mark.parametrize("case", [c for c in REDUCER_CASES if c != "sparse_t60"])
+def test_directional_golden(orc, case):
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    got = orc.comp_bar_directional_features(px, am, d[f"{case}__ci"], sd)
+    for k, g in zip(G.DIR_KEYS, got):
+        np.testing.assert_array_equal(g, d[f"{case}__dir_{k}"], err_msg=f"{case}:{k}")
+        assert g.dtype == d[f"{case}__dir_{k}"].dtype, k
+
+
+@pytest.mark.parametrize("case", [c for c in REDUCER_CASES if c != "sparse_t60"])
+def test_footprints_golden(orc, case):
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    ci = d[f"{case}__ci"]
+    off, flat, bar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, d[f"{case}__ohlcv_low"],
+                                                 d[f"{case}__ohlcv_high"], 3.0)
+    np.testing.assert_array_equal(off, d[f"{case}__fp_offsets"])
+    for k in G.FP_LIST_KEYS:
+        np.testing.assert_array_equal(flat[k].astype(d[f"{case}__fp_{k}"].dtype), d[f"{case}__fp_{k}"],
+                                      err_msg=f"{case}:{k}")
+    for k in G.FP_BAR_KEYS:
+        want = d[f"{case}__fp_{k}"]
+        if k == "vp_skew":
+            # sum((p - vwap) * v) / sum(v) is identically 0 in exact arithmetic: the reference value
+            # is rounding noise of a BLAS dot product -> absolute tolerance scaled by the level index.
+            np.testing.assert_allclose(bar[k], want, rtol=0, atol=1e-6, err_msg=f"{case}:{k}")
+        else:
+            np.testing.assert_array_equal(bar[k], want, err_msg=f"{case}:{k}")
+
+
+def test_footprint_features_golden(orc):
+    d = G.load("footprint_features")
+    for c in G.cases(d):
+        bi, si, run, cot, sk, gi = orc.comp_footprint_features(d[f"{c}__lv"], d[f"{c}__b"], d[f"{c}__s"], 1.5)
+        np.testing.assert_array_equal(bi, d[f"{c}__bi"], err_msg=c)
+        np.testing.assert_array_equal(si, d[f"{c}__si"], err_msg=c)
+        wrun, wcot, wsk, wgi = d[f"{c}__scalars"]
+        assert run == int(wrun) and cot == int(wcot), c
+        assert gi == wgi, (c, gi, wgi)                 # float32 pairwise order pinned bit-exactly
+        assert abs(sk - wsk) <= 1e-9 * 2000, (c, sk, wsk)   # rounding noise, see above
+
+
+def test_ticklevel_golden(orc):
+    d = G.load("ticklevel")
+    ts, px, am, sd = G.synth_from(orc, d["synth"])
+    for w in (1e-6, 0.5, 5.0, 60.0):
+        for lg in (0, 1):
+            got = orc.comp_lagged_returns(ts, px, w, bool(lg))
+            want = d[f"ret_{w}_{lg}"]
+            if lg:   # libm log vs NumPy's SIMD log: <=1 ulp apart
+                G.assert_f64_close(got, want, rtol=1e-12, what=f"ret {w} log")
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+            else:
+                np.testing.assert_array_equal(got, want, err_msg=f"ret {w}")
+    np.testing.assert_array_equal(orc.comp_lagged_returns(d["small_ts"], d["small_px"], 2.0, False),
+                                  d["small_ret_2.0_0"])
+    r = orc.comp_lagged_returns(ts, px, 5.0, True)
+    r = d["ret_5.0_1"]   # use the reference's returns so exp/log ulp noise does not stack
+    for hl in (1.0, 30.0, 600.0):
+        G.assert_f64_close(orc.ewmst(ts, r, hl), d[f"ewmst_{hl}"], rtol=1e-11, what=f"ewmst {hl}")
+        G.assert_f64_close(orc.ewmst_mean0(ts, r, hl), d[f"ewmst0_{hl}"], rtol=1e-11, what=f"ewmst0 {hl}")
+    rn = r.copy()
+    rn[1000:1010] = np.nan
+    G.assert_f64_close(orc.ewmst(ts, rn, 30.0), d["ewmst_nan_30.0"], rtol=1e-11, what="ewmst nan")
+    for span in (2, 20, 500):
+        G.assert_f64_close(orc.ewms(rn, span), d[f"ewms_{span}"], rtol=1e-11, what=f"ewms {span}")
+    for win, smp in ((2, 1), (50, 1), (50, 0)):
+        G.assert_f64_close(orc.realized_vol(rn, win, bool(smp)), d[f"rv_{win}_{smp}"], rtol=1e-12,
+                           what=f"rv {win}")
+
+
+def test_tick_size_golden(orc):
+    d = G.load("tick_size")
+    _, px, _, _ = G.synth_from(orc, d["synth"])
+    assert orc.comp_price_tick_size(px) == float(d["synth_tick"])
+    for c in G.cases(d):
+        assert orc.comp_price_tick_size(d[f"{c}__px"]) == float(d[f"{c}__tick"]), c
+
+
+def test_trade_size_golden(orc):
+    d = G.load("trade_size")
+    got = orc.comp_bar_trade_size_features(d["am"], d["theta"], d["ci"], 5.0)
+    for k, g in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], got):
+        G.assert_f32_close(g, d[k], what=k, max_ulp=1, max_frac=0.01)
