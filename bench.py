@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- ticks/sec aggregated to 1-minute time bars on N x MI355X.
+
+Workload (BASELINE.json configs[1], per GPU): 1e9 synthetic ticks (generated on the
+device, resident in HBM) -> `TimeBarKit(period=60s).build_ohlcv()` semantics: bar clock + close
+indices (_time_bar_indexer), OHLC/volume/VWAP/trade count (comp_bar_ohlcv) and the median trade
+size.  One "step" = one full pass of that path over the resident columns; outputs stay on the device.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): rank r holds ticks [r*n, (r+1)*n) of ONE
+global stream (weak scaling); the bar that straddles a shard boundary is stitched by a single RCCL
+neighbour send/recv of the trailing partial bar's raw ticks (finmlkit_amd/dist.py).
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement); `roofline` describes the
+dominant kernel (k_bar_ohlcv: 12 algorithmic B/tick), `cpu_baseline` the scalar C oracle on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ticks", type=int, default=1_000_000_000, help="ticks per GPU")
+    ap.add_argument("--interval", type=float, default=60.0)
+    ap.add_argument("--no-median", action="store_true", help="skip the median trade size (not the reference path)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="ticks of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the sharded code path (torch.distributed/RCCL init, planning, halo logic) even with 1 rank")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Scalar C oracle (oracle/fmk_oracle.c, 1 thread) on a bounded sample of the same workload."""
+    if args.cpu_sample <= 0:
+        return None
+    from oracle import oracle as orc
+    orc.build()
+    m = min(args.cpu_sample, args.ticks)
+    ts, px, am, sd = orc.synth(args.seed, 0, m)
+    t0 = time.perf_counter()
+    clock, ci = orc._time_bar_indexer(ts, args.interval)
+    orc.comp_bar_ohlcv(px, am, ci, want_median=not args.no_median)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "ticks/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} ticks of the same synthetic stream, time-bar indexer + comp_bar_ohlcv"
+                      f"{'' if args.no_median else ' + median'} (oracle/fmk_oracle.c, gcc -O2, 1 thread), {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ["FMK_DEVICE"] = str(local_rank)
+
+    comm = None
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch   # imported BEFORE libfmk_hip.so so both share one HIP runtime (same SONAME)
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from finmlkit_amd.dist import Comm
+        comm = Comm(torch.device("cuda", local_rank))
+
+    import numpy as np
+    from finmlkit_amd import _ffi, engine
+    from finmlkit_amd._ffi import DeviceArray, Event, c_f64, c_i64
+    import ctypes as C
+
+    ctx = _ffi.default_context()
+    n = args.ticks
+    free, total = ctx.mem_info()
+    need = n * 21 + (1 << 30)
+    if need > free:
+        n = int((free - (2 << 30)) // 21)
+        if rank == 0:
+            print(f"[bench] reducing ticks/GPU to {n} (free HBM {free / 2**30:.1f} GiB)", file=sys.stderr)
+    HALO = 1 << 22 if use_dist else 0     # headroom in front of every column for the neighbour's halo
+    trades = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, headroom=HALO)
+    ctx.sync()
+
+    want_median = not args.no_median
+    state = {}
+
+    def clock_of(t0, t1):
+        ne, e0, d = c_i64(), c_i64(), c_i64()
+        _ffi.check(_ffi.lib().fmk_time_bar_clock(c_i64(t0), c_i64(t1), c_f64(args.interval), C.byref(ne),
+                                                 C.byref(e0), C.byref(d)))
+        return ne.value, e0.value, d.value
+
+    def ensure_buffers(ne):
+        if state.get("cap", 0) < ne:
+            cap = ne + 1024
+            state["cap"] = cap
+            state["clock"] = DeviceArray(ctx, cap, np.int64)
+            state["idx"] = DeviceArray(ctx, cap, np.int64)
+            state["out"] = trades.alloc_ohlcv(cap, want_median)
+
+    if use_dist:
+        import torch
+        dev = f"cuda:{local_rank}"
+        tcols = [torch.as_tensor(b, device=dev) for b in trades._backing]   # zero-copy views of our buffers
+        one = DeviceArray(ctx, 1, np.int64)
+
+    def step(ev=None):
+        if not use_dist:
+            t0, t1 = trades.first_last_ts()
+            ne, e0, d = clock_of(t0, t1)
+            ensure_buffers(ne)
+            t = trades
+        else:
+            f, l = trades.first_last_ts()
+            allfl = comm.all_gather_i64([f, l])
+            gne, ge0, gd = clock_of(allfl[0][0], allfl[-1][1])
+            from finmlkit_amd.dist import halo_lengths, plan_edges
+            plans = plan_edges([a[0] for a in allfl], gne, ge0, gd)
+            my = plans[rank]
+            # local close index of my last edge = first tick of the halo I send to the right neighbour
+            ctx.call("fmk_time_bar_indexer_dev", trades.ts.p, c_i64(n), c_i64(ge0 + my.hi * gd), c_i64(gd),
+                     c_i64(1), None, one.p)
+            c_last = int(one.to_host()[0])
+            send_h, recv_h = halo_lengths(comm, n, c_last)
+            if recv_h > HALO:
+                raise RuntimeError(f"halo {recv_h} exceeds headroom {HALO}")
+            send = [tc[HALO + c_last: HALO + n] for tc in tcols] if send_h else []
+            recv = [tc[HALO - recv_h: HALO] for tc in tcols] if recv_h else []
+            comm.neighbour_exchange(send, recv)
+            torch.cuda.current_stream().synchronize()
+            t = trades.with_halo(recv_h)
+            ne, e0, d = my.hi - my.lo + 1, ge0 + my.lo * gd, gd
+            ensure_buffers(ne)
+        clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
+        out = state["out"]
+        if ev:
+            ev[0].record()
+        t.bar_ohlcv(ci, want_median=False, out=out)
+        if ev:
+            ev[1].record()
+        if want_median:
+            t.bar_median(ci, out["median_trade_size"])
+        if ev:
+            ev[2].record()
+        state["n_bars"] = ne - 1
+        return ne - 1
+
+    def barrier():
+        ctx.sync()
+        if comm:
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(Event(ctx), Event(ctx), Event(ctx)) for _ in range(args.steps)]
+    barrier()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t_start
+
+    if comm:
+        import torch
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        nb_all = comm.all_gather_i64([state["n_bars"]])
+        n_bars_total = sum(x[0] for x in nb_all)
+    else:
+        n_bars_total = state["n_bars"]
+
+    k_ms = [e[0].elapsed_ms(e[1]) for e in events]
+    m_ms = [e[1].elapsed_ms(e[2]) for e in events] if want_median else [0.0]
+    avg_k_ms = sum(k_ms) / len(k_ms)
+    nb = state["n_bars"]
+    # algorithmic bytes of ONE k_bar_ohlcv launch: price f64 + amount f32 read once per tick,
+    # close_idx read once and 60 B written per bar (DESIGN.md "roofline")
+    alg_bytes = n * 12 + nb * 60 + (nb + 1) * 8
+    achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_ticks = n * world
+        line = {
+            "metric": "ticks/sec aggregated to bars",
+            "value": total_ticks * args.steps / elapsed,
+            "unit": "ticks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: {n:.3g} synthetic ticks/GPU -> {args.interval:g}s time bars: clock+close indices, "
+                            f"OHLC/volume/VWAP/trades{'' if args.no_median else ' + median trade size'}",
+                "ticks_per_gpu": n, "n_bars_total": n_bars_total, "interval_s": args.interval,
+                "parallelism": f"time-range shards x{world}, 1 neighbour halo exchange" if use_dist else "1 GPU",
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_bar_ohlcv<f32 amount>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
+                         "median_kernel_ms": sum(m_ms) / len(m_ms)},
+        }
+        if world == 1:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if comm:
+        import torch.distributed as dist
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

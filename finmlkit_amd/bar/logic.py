@@ -1,0 +1,81 @@
+"""Bar close-index builders: drop-in for finmlkit/bar/logic.py, computed on the MI355X.
+
+Same names, arguments, return values and error behaviour as the reference functions; each
+call uploads its NumPy inputs, runs the HIP kernels of csrc/fmk_indexers.hip /
+csrc/fmk_threshold.hip through the C ABI and downloads the result.  For device-resident
+pipelines use finmlkit_amd.engine.DeviceTrades instead (no PCIe traffic per call).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+import numpy as np
+from numpy.typing import NDArray
+
+from .. import _ffi
+from .._ffi import DeviceArray, c_f64, c_i64, ptr
+
+
+def _time_bar_indexer(timestamps: NDArray[np.int64], interval_seconds: float
+                      ) -> Tuple[NDArray[np.int64], NDArray[np.int64]]:
+    """Reference: finmlkit/bar/logic.py:12-51.  Returns (bar_clock, bar_close_indices)."""
+    ctx = _ffi.default_context()
+    ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    ne = c_i64()
+    ctx.call("fmk_time_bar_indexer", ptr(ts), c_i64(len(ts)), c_f64(interval_seconds), None, None, c_i64(0),
+             C.byref(ne))
+    clock = np.empty(ne.value, np.int64)
+    idx = np.empty(ne.value, np.int64)
+    ctx.call("fmk_time_bar_indexer", ptr(ts), c_i64(len(ts)), c_f64(interval_seconds), ptr(clock), ptr(idx),
+             c_i64(ne.value), C.byref(ne))
+    return clock, idx
+
+
+def _tick_bar_indexer(timestamps: NDArray[np.int64], threshold: int) -> NDArray[np.int64]:
+    """Reference: finmlkit/bar/logic.py:54-84 (returns an int64 array instead of a numba List)."""
+    ctx = _ffi.default_context()
+    m = c_i64()
+    ctx.call("fmk_tick_bar_indexer_dev", c_i64(len(timestamps)), c_i64(int(threshold)), None, c_i64(0),
+             C.byref(m))
+    out = DeviceArray(ctx, m.value, np.int64)
+    ctx.call("fmk_tick_bar_indexer_dev", c_i64(len(timestamps)), c_i64(int(threshold)), out.p, c_i64(m.value),
+             C.byref(m))
+    return out.to_host()
+
+
+def _threshold_indexer(fn, cols, n, threshold):
+    ctx = _ffi.default_context()
+    m, unc = c_i64(), c_i64()
+    ctx.call(fn, *cols, c_i64(n), c_f64(threshold), None, c_i64(0), C.byref(m), C.byref(unc))
+    out = DeviceArray(ctx, m.value, np.int64)
+    ctx.call(fn, *cols, c_i64(n), c_f64(threshold), out.p, c_i64(m.value), C.byref(m), C.byref(unc))
+    return out.to_host()
+
+
+def _volume_bar_indexer(volumes: NDArray, threshold: float) -> NDArray[np.int64]:
+    """Reference: finmlkit/bar/logic.py:87-115."""
+    ctx = _ffi.default_context()
+    v, f64 = _ffi.amount_array(volumes)
+    dv = DeviceArray.from_host(ctx, v)
+    return _threshold_indexer("fmk_volume_bar_indexer_dev", (dv.p, C.c_int(f64)), len(v), threshold)
+
+
+def _dollar_bar_indexer(prices: NDArray[np.float64], volumes: NDArray, threshold: float) -> NDArray[np.int64]:
+    """Reference: finmlkit/bar/logic.py:118-149."""
+    ctx = _ffi.default_context()
+    p = np.ascontiguousarray(prices, dtype=np.float64)
+    v, f64 = _ffi.amount_array(volumes)
+    dp = DeviceArray.from_host(ctx, p)
+    dv = DeviceArray.from_host(ctx, v)
+    return _threshold_indexer("fmk_dollar_bar_indexer_dev", (dp.p, dv.p, C.c_int(f64)), len(v), threshold)
+
+
+def _imbalance_bar_indexer(timestamps, prices, volumes, threshold):
+    """Reference stub: finmlkit/bar/logic.py:224-241."""
+    raise NotImplementedError("Imbalance bar indexer is not implemented yet.")
+
+
+def _run_bar_indexer(timestamps, prices, volumes, threshold):
+    """Reference stub: finmlkit/bar/logic.py:244-261."""
+    raise NotImplementedError("Run bar indexer is not implemented yet.")

@@ -1,0 +1,221 @@
+// fmk_api.hip -- context, memory, timing and error plumbing of libfmk_hip.so.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "fmk_common.h"
+
+static char g_err[512] = "";
+
+int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int fmk_abi_version(void) { return FMK_ABI_VERSION; }
+
+const char *fmk_last_error(const fmk_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int fmk_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fmk_set_error(nullptr, FMK_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return FMK_OK;
+}
+
+int fmk_ctx_create(int device, fmk_ctx **out)
+{
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fmk_set_error(nullptr, FMK_E_NODEVICE,
+                             "no HIP device (hipGetDeviceCount: %s, count=%d); libfmk_hip has no CPU fallback",
+                             hipGetErrorString(e), n);
+    if (device < 0 || device >= n)
+        return fmk_set_error(nullptr, FMK_E_ARG, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return fmk_set_error(nullptr, FMK_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fmk_set_error(nullptr, FMK_E_NODEVICE, "device %d is %s; this library carries gfx950 code only",
+                             device, prop.gcnArchName);
+    fmk_ctx *c = (fmk_ctx *)calloc(1, sizeof(fmk_ctx));
+    if (!c) return fmk_set_error(nullptr, FMK_E_NOMEM, "calloc");
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e2 = (x);                                                               \
+        if (e2 != hipSuccess) {                                                            \
+            fmk_set_error(nullptr, FMK_E_HIP, "%s: %s", #x, hipGetErrorString(e2));        \
+            free(c);                                                                       \
+            return FMK_E_HIP;                                                              \
+        }                                                                                  \
+    } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+    CK(hipHostMalloc((void **)&c->h_mail, 64 * sizeof(int64_t), hipHostMallocDefault));
+    CK(hipMalloc((void **)&c->d_mail, 64 * sizeof(int64_t)));
+#undef CK
+    *out = c;
+    return FMK_OK;
+}
+
+int fmk_ctx_destroy(fmk_ctx *ctx)
+{
+    if (!ctx) return FMK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipFree(ctx->d_mail);
+    (void)hipHostFree(ctx->h_mail);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return FMK_OK;
+}
+
+int fmk_ctx_sync(fmk_ctx *ctx)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FMK_OK;
+}
+
+void *fmk_ctx_stream(fmk_ctx *ctx) { return (void *)ctx->stream; }
+
+int fmk_alloc(fmk_ctx *ctx, size_t bytes, void **dptr)
+{
+    *dptr = nullptr;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 16;
+    FMK_HIP(ctx, hipMalloc(dptr, bytes));
+    return FMK_OK;
+}
+
+int fmk_free(fmk_ctx *ctx, void *dptr)
+{
+    if (!dptr) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FMK_HIP(ctx, hipFree(dptr));
+    return FMK_OK;
+}
+
+int fmk_memset(fmk_ctx *ctx, void *dptr, int value, size_t bytes)
+{
+    if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_h2d(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_d2h(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_d2d(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_mem_info(fmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return FMK_OK;
+}
+
+int fmk_timer_start(fmk_ctx *ctx)
+{
+    FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_timer_stop(fmk_ctx *ctx, double *elapsed_ms)
+{
+    FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}
+
+int fmk_event_create(fmk_ctx *ctx, void **event)
+{
+    hipEvent_t e;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipEventCreate(&e));
+    *event = (void *)e;
+    return FMK_OK;
+}
+
+int fmk_event_destroy(fmk_ctx *ctx, void *event)
+{
+    if (event) FMK_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+    return FMK_OK;
+}
+
+int fmk_event_record(fmk_ctx *ctx, void *event)
+{
+    FMK_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return FMK_OK;
+}
+
+int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms)
+{
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}
+
+}  // extern "C"
+
+int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) FMK_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + (bytes >> 2) + 4096;
+        FMK_HIP(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return FMK_OK;
+}

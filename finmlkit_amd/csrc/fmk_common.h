@@ -1,0 +1,128 @@
+// fmk_common.h -- shared host/device helpers of the gfx950 tick->bar engine.
+// gfx950 only: wave = 64 lanes everywhere, no portability shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fmk.h"
+
+#define FMK_WAVE 64
+
+struct fmk_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    char err[512];
+    // grow-on-demand device scratch (scan partials, flags)
+    void *scratch;
+    size_t scratch_bytes;
+    // small pinned host mailbox for flags / counters read back from the device
+    int64_t *h_mail;   // 64 x int64
+    int64_t *d_mail;   // 64 x int64
+    int n_cu;
+};
+
+int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);
+int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out);
+
+#define FMK_HIP(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fmk_set_error((ctx), e__ == hipErrorOutOfMemory ? FMK_E_NOMEM : FMK_E_HIP, \
+                                 "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                                 __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define FMK_TRY(expr)                   \
+    do {                                \
+        int rc__ = (expr);              \
+        if (rc__ != FMK_OK) return rc__; \
+    } while (0)
+
+#define FMK_LAUNCH_CHECK(ctx) FMK_HIP(ctx, hipGetLastError())
+
+static inline int64_t fmk_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int fmk_lane() { return threadIdx.x & 63; }
+
+// Make a wave-uniform 64-bit value provably uniform (SGPR pair) for the compiler.
+__device__ __forceinline__ int64_t fmk_uniform(int64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int fmk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename T>
+__device__ __forceinline__ T fmk_wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double fmk_wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double fmk_wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int64_t fmk_wave_max(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int64_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ int64_t fmk_wave_min(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int64_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+// inclusive scan across the 64 lanes (Kogge-Stone, 6 steps)
+template <typename T>
+__device__ __forceinline__ T fmk_wave_iscan(T v)
+{
+    const int lane = fmk_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T w = __shfl_up(v, o, 64);
+        if (lane >= o) v += w;
+    }
+    return v;
+}
+
+// amount column element j as float64 (float32 -> float64 is exact)
+template <bool F64>
+__device__ __forceinline__ double fmk_amt(const void *p, int64_t j)
+{
+    if constexpr (F64) return ((const double *)p)[j];
+    else return (double)((const float *)p)[j];
+}
+
+// Python negative-index wrap of the reference (prices[-1] when close_idx[0] == -1)
+__device__ __forceinline__ int64_t fmk_wrap(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
+
+// splitmix64-style counter hash shared with oracle/fmk_oracle.c (orc_mix64)
+__host__ __device__ __forceinline__ uint64_t fmk_mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+#endif  // __HIPCC__

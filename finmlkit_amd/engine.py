@@ -1,0 +1,199 @@
+"""Device-resident tick->bar pipeline (no PCIe traffic between stages).
+
+`DeviceTrades` holds the four trade columns in HBM; the methods enqueue the HIP kernels of
+csrc/ on the context's stream through the *_dev entry points of include/fmk.h and return
+`DeviceArray`s.  The NumPy drop-in functions of finmlkit_amd.bar / finmlkit_amd.feature and
+bench.py are thin layers over this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (DIRECTIONAL_FIELDS, FOOTPRINT_BAR_FIELDS, FOOTPRINT_FLAT_FIELDS, Context, DeviceArray,
+                   DirectionalOut, FootprintOut, c_f64, c_i64, c_vp)
+
+DENSE_GAP_MOD = 100_000_000          # mean gap 50 ms, no empty 1-min bar
+SPARSE_GAP_MOD = 500_000_000_000     # "sparse" variant: exercises empty bars
+
+OHLCV_FIELDS = [("open", np.float64), ("high", np.float64), ("low", np.float64), ("close", np.float64),
+                ("volume", np.float32), ("vwap", np.float64), ("trades", np.int64),
+                ("median_trade_size", np.float64)]
+
+
+class DeviceTrades:
+    """Trade columns resident in HBM: ts int64 ns, price f64, amount f32|f64, side int8."""
+
+    def __init__(self, ctx: Context, ts: DeviceArray, price: DeviceArray, amount: DeviceArray,
+                 side: Optional[DeviceArray]):
+        self.ctx, self.ts, self.price, self.amount, self.side = ctx, ts, price, amount, side
+        self.n = price.n
+        self.amount_is_f64 = int(amount.dtype == np.float64)
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_numpy(cls, ts, price, amount, side=None, ctx: Optional[Context] = None) -> "DeviceTrades":
+        ctx = ctx or _ffi.default_context()
+        am, _ = _ffi.amount_array(amount)
+        return cls(ctx,
+                   DeviceArray.from_host(ctx, np.ascontiguousarray(ts, dtype=np.int64)),
+                   DeviceArray.from_host(ctx, np.ascontiguousarray(price, dtype=np.float64)),
+                   DeviceArray.from_host(ctx, am),
+                   None if side is None else DeviceArray.from_host(ctx, np.ascontiguousarray(side, dtype=np.int8)))
+
+    @classmethod
+    def synth(cls, n: int, seed: int = 42, first: int = 0, gap_mod: int = DENSE_GAP_MOD,
+              ctx: Optional[Context] = None, headroom: int = 0) -> "DeviceTrades":
+        """Ticks [first, first+n) of the synthetic stream, generated on the device.
+
+        `headroom` reserves that many elements *in front* of every column (multi-GPU halo)."""
+        ctx = ctx or _ffi.default_context()
+        cols = [DeviceArray(ctx, n + headroom, dt) for dt in (np.int64, np.float64, np.float32, np.int8)]
+        v = [c.view(headroom, n) for c in cols]
+        ctx.call("fmk_synth_trades_dev", C.c_uint64(seed), c_i64(first), c_i64(n), C.c_uint64(gap_mod),
+                 v[0].p, v[1].p, v[2].p, v[3].p)
+        t = cls(ctx, *v)
+        t._backing = cols
+        t._headroom = headroom
+        return t
+
+    def with_halo(self, k: int) -> "DeviceTrades":
+        """View that also covers the k elements in front of the shard (already filled by the caller)."""
+        assert k <= getattr(self, "_headroom", 0)
+        h = self._headroom
+        cols = [b.view(h - k, self.n + k) for b in self._backing]
+        t = DeviceTrades(self.ctx, *cols)
+        t._backing, t._headroom = self._backing, h - k
+        return t
+
+    def to_numpy(self):
+        return (self.ts.to_host(), self.price.to_host(), self.amount.to_host(),
+                None if self.side is None else self.side.to_host())
+
+    # ------------------------------------------------------------------ indexers
+    def first_last_ts(self) -> Tuple[int, int]:
+        a = self.ts.view(0, 1).to_host()[0]
+        b = self.ts.view(self.n - 1, 1).to_host()[0]
+        return int(a), int(b)
+
+    def time_bar_index(self, interval_seconds: float, clock_params=None,
+                       out: Optional[Tuple[DeviceArray, DeviceArray]] = None) -> Tuple[DeviceArray, DeviceArray]:
+        """_time_bar_indexer (logic.py:12-51) -> (bar_clock, bar_close_indices) on the device.
+
+        `out` = preallocated (clock, idx) buffers with capacity >= n_edges (views of them are returned)."""
+        if clock_params is None:
+            t0, t1 = self.first_last_ts()
+            ne, e0, d = c_i64(), c_i64(), c_i64()
+            _ffi.check(_ffi.lib().fmk_time_bar_clock(c_i64(t0), c_i64(t1), c_f64(interval_seconds),
+                                                     C.byref(ne), C.byref(e0), C.byref(d)))
+            clock_params = (ne.value, e0.value, d.value)
+        ne, e0, d = clock_params
+        if out is not None:
+            clock, idx = out[0].view(0, ne), out[1].view(0, ne)
+        else:
+            clock = DeviceArray(self.ctx, ne, np.int64)
+            idx = DeviceArray(self.ctx, ne, np.int64)
+        self.ctx.call("fmk_time_bar_indexer_dev", self.ts.p, c_i64(self.n), c_i64(e0), c_i64(d), c_i64(ne),
+                      clock.p, idx.p)
+        return clock, idx
+
+    def tick_bar_index(self, threshold: int) -> DeviceArray:
+        m = c_i64()
+        self.ctx.call("fmk_tick_bar_indexer_dev", c_i64(self.n), c_i64(int(threshold)), None, c_i64(0), C.byref(m))
+        out = DeviceArray(self.ctx, m.value, np.int64)
+        self.ctx.call("fmk_tick_bar_indexer_dev", c_i64(self.n), c_i64(int(threshold)), out.p, c_i64(m.value),
+                      C.byref(m))
+        return out
+
+    def _threshold_index(self, fn, cols, threshold) -> DeviceArray:
+        m, unc = c_i64(), c_i64()
+        self.ctx.call(fn, *cols, c_i64(self.n), c_f64(threshold), None, c_i64(0), C.byref(m), C.byref(unc))
+        out = DeviceArray(self.ctx, m.value, np.int64)
+        self.ctx.call(fn, *cols, c_i64(self.n), c_f64(threshold), out.p, c_i64(m.value), C.byref(m), C.byref(unc))
+        self.last_uncertified = unc.value
+        return out
+
+    def volume_bar_index(self, threshold: float) -> DeviceArray:
+        return self._threshold_index("fmk_volume_bar_indexer_dev", (self.amount.p, C.c_int(self.amount_is_f64)),
+                                     threshold)
+
+    def dollar_bar_index(self, threshold: float) -> DeviceArray:
+        return self._threshold_index("fmk_dollar_bar_indexer_dev",
+                                     (self.price.p, self.amount.p, C.c_int(self.amount_is_f64)), threshold)
+
+    def gather_ts(self, close_idx: DeviceArray) -> DeviceArray:
+        out = DeviceArray(self.ctx, close_idx.n, np.int64)
+        self.ctx.call("fmk_gather_i64_dev", self.ts.p, c_i64(self.n), close_idx.p, c_i64(close_idx.n), out.p)
+        return out
+
+    # ------------------------------------------------------------------ reducers
+    def alloc_ohlcv(self, n_bars: int, want_median: bool = True) -> Dict[str, DeviceArray]:
+        return {k: DeviceArray(self.ctx, n_bars, dt) for k, dt in OHLCV_FIELDS
+                if want_median or k != "median_trade_size"}
+
+    def bar_ohlcv(self, close_idx: DeviceArray, want_median: bool = True,
+                  out: Optional[Dict[str, DeviceArray]] = None) -> Dict[str, DeviceArray]:
+        """comp_bar_ohlcv (base.py:306-407) on device-resident columns."""
+        nb = close_idx.n - 1
+        out = out or self.alloc_ohlcv(max(nb, 0), want_median)
+        med = out["median_trade_size"].p if (want_median and "median_trade_size" in out) else None
+        self.ctx.call("fmk_comp_bar_ohlcv_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64),
+                      c_i64(self.n), close_idx.p, c_i64(close_idx.n), out["open"].p, out["high"].p,
+                      out["low"].p, out["close"].p, out["volume"].p, out["vwap"].p, out["trades"].p, med)
+        return out
+
+    def bar_median(self, close_idx: DeviceArray, out: DeviceArray) -> DeviceArray:
+        self.ctx.call("fmk_comp_bar_median_dev", self.amount.p, C.c_int(self.amount_is_f64), c_i64(self.n),
+                      close_idx.p, c_i64(close_idx.n), out.p)
+        return out
+
+    def bar_directional(self, close_idx: DeviceArray) -> Tuple[Dict[str, DeviceArray], DeviceArray]:
+        """comp_bar_directional_features (base.py:409-546); second value: device count of bars without a
+        signed tick (the reference raises ZeroDivisionError for those)."""
+        nb = close_idx.n - 1
+        out = {k: DeviceArray(self.ctx, nb, dt) for k, dt in DIRECTIONAL_FIELDS}
+        st = DirectionalOut(**{k: out[k].ptr for k in out})
+        nz = DeviceArray(self.ctx, 1, np.int64)
+        nz.zero()
+        self.ctx.call("fmk_comp_bar_directional_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64),
+                      c_i64(self.n), close_idx.p, c_i64(close_idx.n), self.side.p, C.byref(st), nz.p)
+        return out, nz
+
+    def bar_footprints(self, close_idx: DeviceArray, lows: DeviceArray, highs: DeviceArray,
+                       price_tick_size: float, imbalance_factor: float = 3.0):
+        """comp_bar_footprints (base.py:615-850) in CSR form -> (level_offsets, flat, per_bar, n_bad)."""
+        nb = close_idx.n - 1
+        off = DeviceArray(self.ctx, nb + 1, np.int64)
+        tot, mx = c_i64(), c_i64()
+        self.ctx.call("fmk_comp_bar_footprints_size_dev", lows.p, highs.p, c_i64(nb), c_f64(price_tick_size),
+                      off.p, C.byref(tot), C.byref(mx))
+        flat = {k: DeviceArray(self.ctx, tot.value, dt) for k, dt in FOOTPRINT_FLAT_FIELDS}
+        bar = {k: DeviceArray(self.ctx, nb, dt) for k, dt in FOOTPRINT_BAR_FIELDS}
+        st = FootprintOut(**{k: v.ptr for k, v in {**flat, **bar}.items()})
+        bad = DeviceArray(self.ctx, 1, np.int64)
+        bad.zero()
+        self.ctx.call("fmk_comp_bar_footprints_fill_dev", self.price.p, self.amount.p,
+                      C.c_int(self.amount_is_f64), c_i64(self.n), close_idx.p, c_i64(close_idx.n), self.side.p,
+                      c_f64(price_tick_size), lows.p, c_f64(imbalance_factor), off.p, c_i64(mx.value),
+                      C.byref(st), bad.p)
+        return off, flat, bar, bad
+
+    # ------------------------------------------------------------------ tick-level features
+    def lagged_returns(self, window_sec: float, is_log: bool, close: Optional[DeviceArray] = None) -> DeviceArray:
+        out = DeviceArray(self.ctx, self.n, np.float64)
+        self.ctx.call("fmk_comp_lagged_returns_dev", self.ts.p, (close or self.price).p, c_i64(self.n),
+                      c_f64(window_sec), C.c_int(bool(is_log)), out.p)
+        return out
+
+    def ewmst(self, y: DeviceArray, half_life: float, sigma_floor: float = 1e-12, mean0: bool = False) -> DeviceArray:
+        out = DeviceArray(self.ctx, self.n, np.float64)
+        self.ctx.call("fmk_ewmst_dev", self.ts.p, y.p, c_i64(self.n), c_f64(half_life), c_f64(sigma_floor),
+                      C.c_int(bool(mean0)), out.p)
+        return out
+
+
+def to_host(d: Dict[str, DeviceArray]) -> Dict[str, np.ndarray]:
+    return {k: v.to_host() for k, v in d.items()}

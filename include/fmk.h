@@ -1,0 +1,202 @@
+/*
+ * fmk.h -- C ABI of libfmk_hip.so, the MI355X (gfx950) tick->bar engine.
+ *
+ * This is the drop-in boundary for the hot path of quantscious/finmlkit
+ * (tick arrays -> bar close indices -> per-bar OHLCV / order-flow / footprint,
+ * plus the tick-level volatility loops).  The reference has no FFI of its own:
+ * its boundary is "a module-level Python function over contiguous 1-D NumPy
+ * arrays" (finmlkit/bar/logic.py, finmlkit/bar/base.py:306-850,
+ * finmlkit/feature/core/{utils,volatility}.py).  Each entry point below
+ * replaces exactly one of those functions; the ctypes binding a maintainer
+ * would add is shown in INTEGRATION.md and shipped in finmlkit_amd/_ffi.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types.
+ *   - every function returns an int status (FMK_OK == 0, negative = error);
+ *     fmk_last_error() gives the text.  The Python shim maps the codes to
+ *     the exception types the reference raises (see FMK_E_* below).
+ *   - *_dev functions take DEVICE pointers and enqueue on the context's HIP
+ *     stream without synchronising (fmk_ctx_sync to wait).  The functions
+ *     without the suffix take HOST pointers (the NumPy drop-in): they upload,
+ *     run the same kernels, download and synchronise.
+ *   - `amount` columns may be float32 (the reference's preprocessed dtype,
+ *     data_model.py:332-342) or float64: `amount_is_f64` selects.
+ *   - close-index arrays follow the reference: n_idx = n_bars + 1 entries,
+ *     entry 0 is the "open" edge (may be -1), bar i covers ticks
+ *     close_idx[i]+1 .. close_idx[i+1] inclusive (base.py:364,377).
+ *   - the caller owns every buffer; the library keeps no host pointer after
+ *     a call returns.
+ *   - there is NO CPU fallback: without a usable HIP device fmk_ctx_create
+ *     fails with FMK_E_NODEVICE.
+ */
+#ifndef FMK_H
+#define FMK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMK_OK 0
+#define FMK_E_ARG (-1)      /* ValueError (base.py:332-335, utils.py:33-34, ...) */
+#define FMK_E_CAPACITY (-2) /* caller buffer too small (two-phase protocol misuse) */
+#define FMK_E_LEVEL (-3)    /* ValueError "Invalid price level index" (base.py:719) */
+#define FMK_E_ZERODIV (-4)  /* ZeroDivisionError (base.py:536: bar without signed tick) */
+#define FMK_E_NOMEM (-5)    /* MemoryError */
+#define FMK_E_HIP (-6)      /* RuntimeError: HIP runtime failure, see fmk_last_error */
+#define FMK_E_NODEVICE (-7) /* RuntimeError: no gfx950 device / HIP runtime unusable */
+
+#define FMK_ABI_VERSION 1
+
+typedef struct fmk_ctx fmk_ctx;
+
+/* ---- context, memory, timing --------------------------------------------------------- */
+int fmk_abi_version(void);
+int fmk_device_count(int *count);
+int fmk_ctx_create(int device, fmk_ctx **out);
+int fmk_ctx_destroy(fmk_ctx *ctx);
+int fmk_ctx_sync(fmk_ctx *ctx);
+/* hipStream_t of the context (for interop with other HIP users, e.g. RCCL). */
+void *fmk_ctx_stream(fmk_ctx *ctx);
+/* Text of the last error on this context (ctx == NULL: last context-less error). */
+const char *fmk_last_error(const fmk_ctx *ctx);
+
+int fmk_alloc(fmk_ctx *ctx, size_t bytes, void **dptr);
+int fmk_free(fmk_ctx *ctx, void *dptr);
+int fmk_memset(fmk_ctx *ctx, void *dptr, int value, size_t bytes);
+int fmk_h2d(fmk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* sync */
+int fmk_d2h(fmk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* sync */
+int fmk_d2d(fmk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* async */
+int fmk_mem_info(fmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+
+/* hipEvent timer on the context stream: ms between start and stop (stop syncs). */
+int fmk_timer_start(fmk_ctx *ctx);
+int fmk_timer_stop(fmk_ctx *ctx, double *elapsed_ms);
+/* Non-blocking event pairs (per-kernel timing inside a timed region): record on the context
+ * stream, read the elapsed time after fmk_ctx_sync. */
+int fmk_event_create(fmk_ctx *ctx, void **event);
+int fmk_event_destroy(fmk_ctx *ctx, void *event);
+int fmk_event_record(fmk_ctx *ctx, void *event);
+int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms);
+
+/* ---- synthetic tick stream (same definition as oracle/orc_synth) ----- */
+/* Writes ticks [first, first+n) of stream `seed` into device columns (any may be NULL). */
+int fmk_synth_trades_dev(fmk_ctx *ctx, uint64_t seed, int64_t first, int64_t n, uint64_t gap_mod,
+                         int64_t *d_ts, double *d_price, float *d_amount, int8_t *d_side);
+
+/* ---- bar indexers: finmlkit/bar/logic.py ---------------------------------------------- */
+/* _time_bar_indexer (logic.py:12-51).  fmk_time_bar_clock is pure host arithmetic: the
+ * float64 clock of logic.py:30-39 as NumPy evaluates it -> edge k = first_edge + k*delta. */
+int fmk_time_bar_clock(int64_t ts_first, int64_t ts_last, double interval_seconds,
+                       int64_t *n_edges, int64_t *first_edge, int64_t *delta);
+/* Fills d_clock[n_edges] and d_close_idx[n_edges] (searchsorted(ts, clock, 'right') - 1). */
+int fmk_time_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, int64_t n, int64_t first_edge,
+                             int64_t delta, int64_t n_edges, int64_t *d_clock,
+                             int64_t *d_close_idx);
+/* Host flavour, two-phase: call with clock == NULL to get *n_edges, then with buffers. */
+int fmk_time_bar_indexer(fmk_ctx *ctx, const int64_t *ts, int64_t n, double interval_seconds,
+                         int64_t *clock, int64_t *close_idx, int64_t capacity, int64_t *n_edges);
+
+/* _tick_bar_indexer (logic.py:54-84): closed form.  *n_idx receives the number of close
+ * indices (first is 0); d_close_idx may be NULL to query the count only. */
+int fmk_tick_bar_indexer_dev(fmk_ctx *ctx, int64_t n, int64_t threshold, int64_t *d_close_idx,
+                             int64_t capacity, int64_t *n_idx);
+/* _volume_bar_indexer (logic.py:87-115) and _dollar_bar_indexer (logic.py:118-149).
+ * Two-phase: d_close_idx == NULL -> count only.  *n_uncertified (may be NULL) receives the
+ * number of close decisions whose margin to the threshold was below the floating-point
+ * reordering bound (see DESIGN.md "threshold bars"); 0 means certified bit-identical. */
+int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                               double threshold, int64_t *d_close_idx, int64_t capacity,
+                               int64_t *n_idx, int64_t *n_uncertified);
+int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                               int amount_is_f64, int64_t n, double threshold,
+                               int64_t *d_close_idx, int64_t capacity, int64_t *n_idx,
+                               int64_t *n_uncertified);
+/* d_out[i] = d_in[idx[i]] for int64 (close_ts = timestamps[close_indices], kit.py:66). */
+int fmk_gather_i64_dev(fmk_ctx *ctx, const int64_t *d_in, int64_t n_in, const int64_t *d_idx,
+                       int64_t n_idx, int64_t *d_out);
+
+/* ---- per-bar reducers: finmlkit/bar/base.py ------------------------------------------- */
+/* comp_bar_ohlcv (base.py:306-407).  d_median may be NULL (skip the order statistic). */
+int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                           int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                           int64_t n_idx, double *d_open, double *d_high, double *d_low,
+                           double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades,
+                           double *d_median);
+/* The order statistic alone (np.median of the bar's trade sizes, base.py:373-403). */
+int fmk_comp_bar_median_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                            const int64_t *d_close_idx, int64_t n_idx, double *d_median);
+int fmk_comp_bar_ohlcv(fmk_ctx *ctx, const double *price, const void *amount, int amount_is_f64,
+                       int64_t n, const int64_t *close_idx, int64_t n_idx, double *open_,
+                       double *high, double *low, double *close_, float *volume, double *vwap,
+                       int64_t *trades, double *median);
+
+/* comp_bar_directional_features (base.py:409-546).  Outputs in the reference's tuple order.
+ * d_n_zero_div (device int64, may be NULL) counts bars without a signed tick, for which the
+ * reference raises ZeroDivisionError; their mean_spread is written as NaN.  The host flavour
+ * returns FMK_E_ZERODIV in that case (outputs are still filled). */
+typedef struct fmk_directional_out {
+    int64_t *ticks_buy, *ticks_sell;
+    float *volume_buy, *volume_sell, *dollars_buy, *dollars_sell;
+    float *mean_spread, *max_spread;
+    int64_t *cum_ticks_min, *cum_ticks_max;
+    float *cum_volumes_min, *cum_volumes_max, *cum_dollars_min, *cum_dollars_max;
+} fmk_directional_out;
+int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                 int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                                 int64_t n_idx, const int8_t *d_side,
+                                 const fmk_directional_out *d_out, int64_t *d_n_zero_div);
+int fmk_comp_bar_directional(fmk_ctx *ctx, const double *price, const void *amount,
+                             int amount_is_f64, int64_t n, const int64_t *close_idx,
+                             int64_t n_idx, const int8_t *side, const fmk_directional_out *out);
+
+/* comp_bar_footprints + comp_footprint_features (base.py:615-850), CSR output.
+ * Phase 1: level_offsets[n_bars+1] from the bars' lows/highs (exclusive scan of
+ *          int(round(high/tick)) - int(round(low/tick)) + 1); *total_levels and *max_levels
+ *          are returned to the host (synchronises).
+ * Phase 2: fills the flat per-level arrays (length total_levels) and the per-bar arrays. */
+typedef struct fmk_footprint_out {
+    int32_t *price_levels;   /* flat [total_levels] */
+    float *buy_volumes, *sell_volumes;
+    int32_t *buy_ticks, *sell_ticks;
+    uint8_t *buy_imbalances, *sell_imbalances;   /* numpy bool */
+    uint16_t *buy_imbalances_sum, *sell_imbalances_sum;   /* per bar [n_bars] */
+    int32_t *cot_price_levels;
+    int16_t *imb_max_run_signed;
+    double *vp_skew, *vp_gini;
+} fmk_footprint_out;
+int fmk_comp_bar_footprints_size_dev(fmk_ctx *ctx, const double *d_bar_lows,
+                                     const double *d_bar_highs, int64_t n_bars,
+                                     double price_tick_size, int64_t *d_level_offsets,
+                                     int64_t *total_levels, int64_t *max_levels);
+int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                     int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                                     int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                                     const double *d_bar_lows, double imbalance_factor,
+                                     const int64_t *d_level_offsets, int64_t max_levels,
+                                     const fmk_footprint_out *d_out, int64_t *d_n_bad_level);
+/* Host flavour, two-phase: out == NULL -> fills level_offsets only. */
+int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amount,
+                            int amount_is_f64, int64_t n, const int64_t *close_idx, int64_t n_idx,
+                            const int8_t *side, double price_tick_size, const double *bar_lows,
+                            const double *bar_highs, double imbalance_factor,
+                            int64_t *level_offsets, const fmk_footprint_out *out);
+
+/* ---- tick-level feature loops: finmlkit/feature/core ---------------------------------- */
+/* comp_lagged_returns (core/utils.py:12-64). */
+int fmk_comp_lagged_returns_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_close,
+                                int64_t n, double return_window_sec, int is_log, double *d_out);
+int fmk_comp_lagged_returns(fmk_ctx *ctx, const int64_t *ts, const double *close_, int64_t n,
+                            double return_window_sec, int is_log, double *out);
+/* ewmst / ewmst_mean0 (core/volatility.py:139-219, 72-136). */
+int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n,
+                  double half_life, double sigma_floor, int mean0, double *d_out);
+int fmk_ewmst(fmk_ctx *ctx, const int64_t *ts, const double *y, int64_t n, double half_life,
+              double sigma_floor, int mean0, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMK_H */

@@ -1,0 +1,121 @@
+"""GPU parity: synthetic generator, time-bar indexer, comp_bar_ohlcv (+ median) vs the CPU oracle
+and the reference-generated golden fixtures.  All calls go through the C ABI (libfmk_hip.so)."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from finmlkit_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("first,n,gap", [(0, 10_000, 100_000_000), (12_345, 70_001, 100_000_000),
+                                         (0, 5_000, 500_000_000_000), (1_000_003, 4097, 100_000_000)])
+def test_synth_matches_oracle(eng, orc, first, n, gap):
+    t = eng.DeviceTrades.synth(n, seed=42, first=first, gap_mod=gap)
+    ts, px, am, sd = t.to_numpy()
+    ots, opx, oam, osd = orc.synth(42, first, n, gap)
+    np.testing.assert_array_equal(ts, ots)
+    np.testing.assert_array_equal(px, opx)
+    np.testing.assert_array_equal(am, oam)
+    np.testing.assert_array_equal(sd, osd)
+
+
+def test_time_indexer_golden(eng, orc):
+    from finmlkit_amd.bar.logic import _time_bar_indexer
+    d = G.load("time_indexer")
+    for c in G.cases(d):
+        ts = d[f"{c}__ts"] if f"{c}__ts" in d else G.synth_from(orc, d[f"{c}__synth"])[0]
+        clock, idx = _time_bar_indexer(ts, float(d[f"{c}__interval"]))
+        np.testing.assert_array_equal(clock, d[f"{c}__clock"], err_msg=c)
+        np.testing.assert_array_equal(idx, d[f"{c}__idx"], err_msg=c)
+
+
+def test_tick_indexer_golden(eng, orc):
+    from finmlkit_amd.bar.logic import _tick_bar_indexer
+    d = G.load("threshold_indexers")
+    ts = np.zeros(int(d["synth"][2]), np.int64)
+    for k, want in d.items():
+        if k.startswith("tick_"):
+            np.testing.assert_array_equal(_tick_bar_indexer(ts, int(k[5:])), want, err_msg=k)
+    for n, thr in [(1, 1), (1, 5), (5, 5), (6, 5), (4, 5), (10, 0), (10, -3)]:
+        np.testing.assert_array_equal(_tick_bar_indexer(np.zeros(n, np.int64), thr),
+                                      orc._tick_bar_indexer(np.zeros(n, np.int64), thr), err_msg=f"{n},{thr}")
+
+
+def _check_ohlcv(got, want, what):
+    o, h, l, c, vol, vwap, tr, med = want
+    np.testing.assert_array_equal(got["trades"], tr, err_msg=what)
+    for k, w in (("open", o), ("high", h), ("low", l), ("close", c)):
+        np.testing.assert_array_equal(got[k], w, err_msg=f"{what}:{k}")       # selections: bit-exact
+    G.assert_f32_close(got["volume"], vol, what=f"{what}:volume")
+    G.assert_f64_close(got["vwap"], vwap, rtol=1e-9, what=f"{what}:vwap")
+    np.testing.assert_array_equal(got["median_trade_size"], med, err_msg=f"{what}:median")   # order statistic
+
+
+@pytest.mark.parametrize("case", ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37",
+                                  "sparse_t60"])
+def test_ohlcv_golden(eng, orc, case):
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    ci = d[f"{case}__ci"]
+    t = eng.DeviceTrades.from_numpy(np.zeros(len(px), np.int64), px, am, sd)
+    from finmlkit_amd._ffi import DeviceArray
+    got = eng.to_host(t.bar_ohlcv(DeviceArray.from_host(t.ctx, ci)))
+    want = tuple(d[f"{case}__ohlcv_{k}"] for k in G.OHLCV_KEYS)
+    _check_ohlcv(got, want, case)
+    assert got["volume"].dtype == np.float32 and got["trades"].dtype == np.int64
+
+
+@pytest.mark.parametrize("n,interval,f64", [(300_000, 60.0, False), (300_000, 1.0, False), (300_000, 3600.0, False),
+                                            (200_000, 86400.0, True), (100_000, 0.25, True)])
+def test_ohlcv_vs_oracle_synth(eng, orc, n, interval, f64):
+    ts, px, am, sd = orc.synth(7, 0, n)
+    if f64:
+        am = np.random.default_rng(1).lognormal(-1, 1.3, n)       # non-dyadic float64 amounts
+    t = eng.DeviceTrades.from_numpy(ts, px, am, sd)
+    clock, ci = t.time_bar_index(interval)
+    oclock, oci = orc._time_bar_indexer(ts, interval)
+    np.testing.assert_array_equal(ci.to_host(), oci)
+    np.testing.assert_array_equal(clock.to_host(), oclock)
+    got = eng.to_host(t.bar_ohlcv(ci))
+    _check_ohlcv(got, orc.comp_bar_ohlcv(px, am, oci), f"n={n} iv={interval}")
+
+
+def test_ohlcv_big_bar_and_edge_counts(eng, orc):
+    """Bars longer than the register-resident median path (2048 / 1024 ticks), 1..130-tick bars, NaN amount."""
+    rng = np.random.default_rng(3)
+    n = 40_000
+    px = 100 + np.cumsum(rng.integers(-2, 3, n)) * 0.01
+    for dt in (np.float32, np.float64):
+        am = rng.lognormal(0, 1, n).astype(dt)
+        cuts = [-1, 0, 1, 3, 66, 130, 131 + 2047, 131 + 2047 + 2048, 131 + 2047 + 2048 + 2049, 20_000, 20_000, n - 1]
+        ci = np.array(cuts, dtype=np.int64)
+        t = eng.DeviceTrades.from_numpy(np.zeros(n, np.int64), px, am)
+        from finmlkit_amd._ffi import DeviceArray
+        got = eng.to_host(t.bar_ohlcv(DeviceArray.from_host(t.ctx, ci)))
+        _check_ohlcv(got, orc.comp_bar_ohlcv(px, am, ci), f"edge {dt}")
+    am = rng.lognormal(0, 1, n).astype(np.float32)
+    am[5] = np.nan
+    t = eng.DeviceTrades.from_numpy(np.zeros(n, np.int64), px, am)
+    got = eng.to_host(t.bar_ohlcv(DeviceArray.from_host(t.ctx, np.array([-1, 99, 199], dtype=np.int64))))
+    assert np.isnan(got["median_trade_size"][0]) and not np.isnan(got["median_trade_size"][1])
+
+
+def test_ohlcv_host_flavour_and_errors(eng, orc):
+    from finmlkit_amd.bar.base import comp_bar_ohlcv
+    ts, px, am, sd = orc.synth(11, 0, 50_000)
+    _, ci = orc._time_bar_indexer(ts, 30.0)
+    got = comp_bar_ohlcv(px, am, ci)
+    want = orc.comp_bar_ohlcv(px, am, ci)
+    _check_ohlcv(dict(zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], got)),
+                 want, "host")
+    with pytest.raises(ValueError, match="same length"):
+        comp_bar_ohlcv(px, am[:-1], ci)
+    with pytest.raises(ValueError, match="at least two"):
+        comp_bar_ohlcv(px, am, ci[:1])
