@@ -120,3 +120,123 @@ int fmk_comp_bar_ohlcv(fmk_ctx *ctx, const double *price, const void *amount, in
 }
 
 }  // extern "C"
+
+extern "C" {
+
+int fmk_comp_bar_directional(fmk_ctx *ctx, const double *price, const void *amount, int amount_is_f64, int64_t n,
+                             const int64_t *close_idx, int64_t n_idx, const int8_t *side,
+                             const fmk_directional_out *out)
+{
+    if (n_idx < 2)
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    const int64_t nb = n_idx - 1;
+    DevBag bag(ctx);
+    double *d_p;
+    void *d_a;
+    int64_t *d_ci, *d_nz;
+    int8_t *d_s;
+    FMK_TRY(bag.up(price, n, &d_p));
+    FMK_TRY(bag.up_amount(amount, amount_is_f64, n, &d_a));
+    FMK_TRY(bag.up(close_idx, n_idx, &d_ci));
+    FMK_TRY(bag.up(side, n, &d_s));
+    FMK_TRY(bag.out(1, &d_nz));
+    FMK_TRY(fmk_memset(ctx, d_nz, 0, 8));
+    fmk_directional_out d;
+    int64_t **di[] = {&d.ticks_buy, &d.ticks_sell, &d.cum_ticks_min, &d.cum_ticks_max};
+    float **df[] = {&d.volume_buy, &d.volume_sell, &d.dollars_buy, &d.dollars_sell, &d.mean_spread, &d.max_spread,
+                    &d.cum_volumes_min, &d.cum_volumes_max, &d.cum_dollars_min, &d.cum_dollars_max};
+    for (auto p : di) FMK_TRY(bag.out(nb, p));
+    for (auto p : df) FMK_TRY(bag.out(nb, p));
+    FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_p, d_a, amount_is_f64, n, d_ci, n_idx, d_s, &d, d_nz));
+    FMK_TRY(down(ctx, out->ticks_buy, d.ticks_buy, nb));
+    FMK_TRY(down(ctx, out->ticks_sell, d.ticks_sell, nb));
+    FMK_TRY(down(ctx, out->volume_buy, d.volume_buy, nb));
+    FMK_TRY(down(ctx, out->volume_sell, d.volume_sell, nb));
+    FMK_TRY(down(ctx, out->dollars_buy, d.dollars_buy, nb));
+    FMK_TRY(down(ctx, out->dollars_sell, d.dollars_sell, nb));
+    FMK_TRY(down(ctx, out->mean_spread, d.mean_spread, nb));
+    FMK_TRY(down(ctx, out->max_spread, d.max_spread, nb));
+    FMK_TRY(down(ctx, out->cum_ticks_min, d.cum_ticks_min, nb));
+    FMK_TRY(down(ctx, out->cum_ticks_max, d.cum_ticks_max, nb));
+    FMK_TRY(down(ctx, out->cum_volumes_min, d.cum_volumes_min, nb));
+    FMK_TRY(down(ctx, out->cum_volumes_max, d.cum_volumes_max, nb));
+    FMK_TRY(down(ctx, out->cum_dollars_min, d.cum_dollars_min, nb));
+    FMK_TRY(down(ctx, out->cum_dollars_max, d.cum_dollars_max, nb));
+    int64_t nz = 0;
+    FMK_TRY(fmk_d2h(ctx, &nz, d_nz, 8));
+    if (nz > 0)   // base.py:536: current_cum_spread / (buy + sell) with buy + sell == 0
+        return fmk_set_error(ctx, FMK_E_ZERODIV, "division by zero: %lld bar(s) without a signed tick", (long long)nz);
+    return FMK_OK;
+}
+
+int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amount, int amount_is_f64, int64_t n,
+                            const int64_t *close_idx, int64_t n_idx, const int8_t *side, double price_tick_size,
+                            const double *bar_lows, const double *bar_highs, double imbalance_factor,
+                            int64_t *level_offsets, const fmk_footprint_out *out)
+{
+    if (n_idx < 2)
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    const int64_t nb = n_idx - 1;
+    DevBag bag(ctx);
+    double *d_lo, *d_hi;
+    int64_t *d_off;
+    FMK_TRY(bag.up(bar_lows, nb, &d_lo));
+    FMK_TRY(bag.up(bar_highs, nb, &d_hi));
+    FMK_TRY(bag.out(nb + 1, &d_off));
+    int64_t total = 0, maxl = 0;
+    FMK_TRY(fmk_comp_bar_footprints_size_dev(ctx, d_lo, d_hi, nb, price_tick_size, d_off, &total, &maxl));
+    FMK_TRY(down(ctx, level_offsets, d_off, nb + 1));
+    if (!out) return FMK_OK;
+    double *d_p;
+    void *d_a;
+    int64_t *d_ci, *d_bad;
+    int8_t *d_s;
+    FMK_TRY(bag.up(price, n, &d_p));
+    FMK_TRY(bag.up_amount(amount, amount_is_f64, n, &d_a));
+    FMK_TRY(bag.up(close_idx, n_idx, &d_ci));
+    FMK_TRY(bag.up(side, n, &d_s));
+    FMK_TRY(bag.out(1, &d_bad));
+    FMK_TRY(fmk_memset(ctx, d_bad, 0, 8));
+    fmk_footprint_out d;
+    FMK_TRY(bag.out(total, &d.price_levels));
+    FMK_TRY(bag.out(total, &d.buy_volumes));
+    FMK_TRY(bag.out(total, &d.sell_volumes));
+    FMK_TRY(bag.out(total, &d.buy_ticks));
+    FMK_TRY(bag.out(total, &d.sell_ticks));
+    FMK_TRY(bag.out(total, &d.buy_imbalances));
+    FMK_TRY(bag.out(total, &d.sell_imbalances));
+    FMK_TRY(bag.out(nb, &d.buy_imbalances_sum));
+    FMK_TRY(bag.out(nb, &d.sell_imbalances_sum));
+    FMK_TRY(bag.out(nb, &d.cot_price_levels));
+    FMK_TRY(bag.out(nb, &d.imb_max_run_signed));
+    FMK_TRY(bag.out(nb, &d.vp_skew));
+    FMK_TRY(bag.out(nb, &d.vp_gini));
+    FMK_TRY(fmk_memset(ctx, d.buy_imbalances_sum, 0, 2 * (size_t)nb));
+    FMK_TRY(fmk_memset(ctx, d.sell_imbalances_sum, 0, 2 * (size_t)nb));
+    FMK_TRY(fmk_memset(ctx, d.cot_price_levels, 0, 4 * (size_t)nb));
+    FMK_TRY(fmk_memset(ctx, d.imb_max_run_signed, 0, 2 * (size_t)nb));
+    FMK_TRY(fmk_memset(ctx, d.vp_skew, 0, 8 * (size_t)nb));
+    FMK_TRY(fmk_memset(ctx, d.vp_gini, 0, 8 * (size_t)nb));
+    FMK_TRY(fmk_comp_bar_footprints_fill_dev(ctx, d_p, d_a, amount_is_f64, n, d_ci, n_idx, d_s, price_tick_size, d_lo,
+                                             imbalance_factor, d_off, maxl, &d, d_bad));
+    FMK_TRY(down(ctx, out->price_levels, d.price_levels, total));
+    FMK_TRY(down(ctx, out->buy_volumes, d.buy_volumes, total));
+    FMK_TRY(down(ctx, out->sell_volumes, d.sell_volumes, total));
+    FMK_TRY(down(ctx, out->buy_ticks, d.buy_ticks, total));
+    FMK_TRY(down(ctx, out->sell_ticks, d.sell_ticks, total));
+    FMK_TRY(down(ctx, out->buy_imbalances, d.buy_imbalances, total));
+    FMK_TRY(down(ctx, out->sell_imbalances, d.sell_imbalances, total));
+    FMK_TRY(down(ctx, out->buy_imbalances_sum, d.buy_imbalances_sum, nb));
+    FMK_TRY(down(ctx, out->sell_imbalances_sum, d.sell_imbalances_sum, nb));
+    FMK_TRY(down(ctx, out->cot_price_levels, d.cot_price_levels, nb));
+    FMK_TRY(down(ctx, out->imb_max_run_signed, d.imb_max_run_signed, nb));
+    FMK_TRY(down(ctx, out->vp_skew, d.vp_skew, nb));
+    FMK_TRY(down(ctx, out->vp_gini, d.vp_gini, nb));
+    int64_t bad = 0;
+    FMK_TRY(fmk_d2h(ctx, &bad, d_bad, 8));
+    if (bad > 0)   // base.py:719
+        return fmk_set_error(ctx, FMK_E_LEVEL, "Something went wrong! Invalid price level index!");
+    return FMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""GPU parity: comp_bar_directional_features and comp_bar_footprints (+ comp_footprint_features)
+vs the CPU oracle and the reference-generated golden fixtures, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+INT_DIR = {"ticks_buy", "ticks_sell", "cum_ticks_min", "cum_ticks_max"}
+
+
+def _check_dir(got, want, what):
+    for k, g, w in zip(G.DIR_KEYS, got, want):
+        assert g.dtype == w.dtype, (what, k)
+        if k in INT_DIR:
+            np.testing.assert_array_equal(g, w, err_msg=f"{what}:{k}")
+        else:
+            G.assert_f32_close(g, w, what=f"{what}:{k}")
+
+
+@pytest.mark.parametrize("case", ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37"])
+def test_directional_golden(orc, case):
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    got = comp_bar_directional_features(px, am, d[f"{case}__ci"], sd)
+    _check_dir(got, tuple(d[f"{case}__dir_{k}"] for k in G.DIR_KEYS), case)
+
+
+@pytest.mark.parametrize("n,interval,f64,zeros", [(300_000, 60.0, False, False), (200_000, 1.0, True, True),
+                                                  (300_000, 7200.0, True, False)])
+def test_directional_vs_oracle(orc, n, interval, f64, zeros):
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    ts, px, am, sd = orc.synth(5, 0, n)
+    rng = np.random.default_rng(9)
+    if f64:
+        am = rng.lognormal(-1, 1.3, n)
+    if zeros:
+        sd = sd.copy()
+        sd[rng.random(n) < 0.1] = 0
+    _, ci = orc._time_bar_indexer(ts, interval)
+    want = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    empty = np.diff(ci) <= 0
+    if np.isnan(want[6]).any():
+        with pytest.raises(ZeroDivisionError):
+            comp_bar_directional_features(px, am, ci, sd)
+    else:
+        _check_dir(comp_bar_directional_features(px, am, ci, sd), want, f"n={n} iv={interval}")
+
+
+def test_directional_zero_division(orc):
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    ts, px, am, sd = orc.synth(42, 0, 5_000, 500_000_000_000)       # sparse stream: empty bars
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    with pytest.raises(ZeroDivisionError):
+        comp_bar_directional_features(px, am, ci, sd)
+
+
+def _check_fp(off, flat, bar, woff, wflat, wbar, what):
+    np.testing.assert_array_equal(off, woff, err_msg=what)
+    for k in G.FP_LIST_KEYS:
+        np.testing.assert_array_equal(flat[k].astype(wflat[k].dtype), wflat[k], err_msg=f"{what}:{k}")
+    for k in G.FP_BAR_KEYS:
+        if k == "vp_skew":    # identically 0 in exact arithmetic: rounding noise of the reference's dot product
+            np.testing.assert_allclose(bar[k], wbar[k], rtol=0, atol=1e-6, err_msg=f"{what}:{k}")
+        else:
+            np.testing.assert_array_equal(bar[k], wbar[k], err_msg=f"{what}:{k}")
+
+
+@pytest.mark.parametrize("case", ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37"])
+def test_footprints_golden(orc, case):
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    off, flat, bar = comp_bar_footprints_csr(px, am, d[f"{case}__ci"], sd, 0.01, d[f"{case}__ohlcv_low"],
+                                             d[f"{case}__ohlcv_high"], 3.0)
+    _check_fp(off, flat, bar, d[f"{case}__fp_offsets"], {k: d[f"{case}__fp_{k}"] for k in G.FP_LIST_KEYS},
+              {k: d[f"{case}__fp_{k}"] for k in G.FP_BAR_KEYS}, case)
+
+
+@pytest.mark.parametrize("n,interval,dtype,tick,mult", [(300_000, 60.0, np.float32, 0.01, 3.0),
+                                                        (300_000, 3600.0, np.float32, 0.01, 1.5),
+                                                        (150_000, 10.0, np.float64, 0.01, 2.0),
+                                                        (100_000, 900.0, np.float32, 0.002, 3.0)])
+def test_footprints_vs_oracle(orc, n, interval, dtype, tick, mult):
+    """Non-dyadic amounts: float32 level sums are order-sensitive -> checks the tick-ordered accumulation.
+    tick=0.002 widens the bars beyond 128 / 512 levels (all LDS size classes)."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    ts, px, am, sd = orc.synth(13, 0, n)
+    rng = np.random.default_rng(4)
+    am = rng.lognormal(-1, 1.3, n).astype(dtype)
+    sd = sd.copy()
+    sd[rng.random(n) < 0.03] = 0
+    _, ci = orc._time_bar_indexer(ts, interval)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], mult)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], mult)
+    _check_fp(off, flat, bar, woff, wflat, wbar, f"n={n} iv={interval}")
+
+
+def test_footprints_reference_shape_and_errors(orc):
+    from finmlkit_amd.bar.base import comp_bar_footprints
+    ts, px, am, sd = orc.synth(3, 0, 20_000)
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    got = comp_bar_footprints(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    want = orc.comp_bar_footprints(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    assert len(got) == 13 and len(got[0]) == len(ci) - 1
+    for g, w in zip(got[:7], want[:7]):
+        for a, b in zip(g, w):
+            np.testing.assert_array_equal(a, b)
+            assert a.dtype == b.dtype
+    assert got[5][0].dtype == np.bool_
+    # lows too high -> a tick falls outside the level range -> the reference's ValueError
+    with pytest.raises(ValueError, match="Invalid price level index"):
+        comp_bar_footprints(px, am, ci, sd, 0.01, o[2] + 0.05, o[1] + 0.05, 3.0)
