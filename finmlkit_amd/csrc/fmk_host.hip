@@ -239,4 +239,34 @@ int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amoun
     return FMK_OK;
 }
 
+int fmk_comp_lagged_returns(fmk_ctx *ctx, const int64_t *ts, const double *close_, int64_t n,
+                            double return_window_sec, int is_log, double *out)
+{
+    if (!(return_window_sec > 0))
+        return fmk_set_error(ctx, FMK_E_ARG, "The return window must be greater than zero.");
+    if (n <= 0) return FMK_OK;
+    DevBag bag(ctx);
+    int64_t *d_ts;
+    double *d_c, *d_o;
+    FMK_TRY(bag.up(ts, n, &d_ts));
+    FMK_TRY(bag.up(close_, n, &d_c));
+    FMK_TRY(bag.out(n, &d_o));
+    FMK_TRY(fmk_comp_lagged_returns_dev(ctx, d_ts, d_c, n, return_window_sec, is_log, d_o));
+    return down(ctx, out, d_o, n);
+}
+
+int fmk_ewmst(fmk_ctx *ctx, const int64_t *ts, const double *y, int64_t n, double half_life, double sigma_floor,
+              int mean0, double *out)
+{
+    if (n <= 0) return FMK_OK;
+    DevBag bag(ctx);
+    int64_t *d_ts;
+    double *d_y, *d_o;
+    FMK_TRY(bag.up(ts, n, &d_ts));
+    FMK_TRY(bag.up(y, n, &d_y));
+    FMK_TRY(bag.out(n, &d_o));
+    FMK_TRY(fmk_ewmst_dev(ctx, d_ts, d_y, n, half_life, sigma_floor, mean0, d_o));
+    return down(ctx, out, d_o, n);
+}
+
 }  // extern "C"

@@ -1,0 +1,203 @@
+// fmk_threshold.hip -- _volume_bar_indexer / _dollar_bar_indexer (finmlkit/bar/logic.py:87-149).
+//
+// Both are sequential recurrences with a data-dependent reset (volume: cum = 0) or carry
+// (dollar: cum -= threshold) -- the position of every close depends on all earlier ones.
+// ROUND-1 IMPLEMENTATION (correct first, see DESIGN.md "threshold bars" for the parallel
+// hierarchical-jump design that replaces it): ONE wave walks the stream in 1024-tick chunks.
+//   * lane l owns 16 consecutive ticks: sequential float64 prefix inside the lane, 6-step wave
+//     scan of the lane totals -> cum at every tick of the chunk in ~30 wave instructions.
+//   * the first tick with cum >= threshold is found with one ballot; reset/carry is applied by
+//     re-basing the chunk's prefix values (no re-scan), so a chunk costs O(1 + closes in chunk).
+//   * the next chunk's loads are issued before the current one is processed (software prefetch:
+//     the single wave has no neighbours to hide HBM latency behind).
+// The in-chunk sums are tree+lane ordered instead of strictly sequential; a close decision whose
+// margin |cum - threshold| is below 1e-11*threshold is counted in n_uncertified (0 = every
+// decision is provably the reference's; amounts that sum exactly, like the synthetic dyadic
+// stream, are always certified).
+// A parallel reduction first bounds the number of closes (sum/threshold + 2) so the result can be
+// written in one pass; the two-phase C-ABI call (count, then fill) reuses the cached result.
+#include <math.h>
+
+#include "fmk_common.h"
+
+#define TH_ITEMS 16
+#define TH_CHUNK (64 * TH_ITEMS)
+
+template <bool AF64, bool DOLLAR>
+__device__ __forceinline__ void th_load(const double *price, const void *amount, int64_t n, int64_t i0,
+                                        double (&d)[TH_ITEMS])
+{
+#pragma unroll
+    for (int k = 0; k < TH_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        double v = 0.0;
+        if (i < n) {
+            v = fmk_amt<AF64>(amount, i);
+            if constexpr (DOLLAR) v = price[i] * v;      // rounded product, like the reference
+        }
+        d[k] = v;
+    }
+}
+
+template <bool AF64, bool DOLLAR>
+__global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict__ price,
+                                                        const void *__restrict__ amount, int64_t n, double thr,
+                                                        int64_t *__restrict__ out, int64_t cap,
+                                                        int64_t *__restrict__ result /*[2]: count, uncertified*/)
+{
+    const int lane = fmk_lane();
+    int64_t m = 0, unc = 0;
+    if (lane == 0 && cap > 0) out[0] = 0;       // logic.py:104 / 138
+    m = 1;
+    double cin = 0.0;                            // cum carried into the chunk
+    const double tol = 1e-11 * fabs(thr);
+    double cur[TH_ITEMS], nxt[TH_ITEMS];
+    th_load<AF64, DOLLAR>(price, amount, n, (int64_t)lane * TH_ITEMS, cur);
+    for (int64_t base = 0; base < n; base += TH_CHUNK) {
+        if (base + TH_CHUNK < n)
+            th_load<AF64, DOLLAR>(price, amount, n, base + TH_CHUNK + (int64_t)lane * TH_ITEMS, nxt);
+        // inclusive prefix inside the lane, exclusive prefix across lanes
+        double s[TH_ITEMS];
+        s[0] = cur[0];
+#pragma unroll
+        for (int k = 1; k < TH_ITEMS; ++k) s[k] = s[k - 1] + cur[k];
+        const double inc = fmk_wave_iscan(s[TH_ITEMS - 1]);
+        const double ex = inc - s[TH_ITEMS - 1];
+        const double chunk_total = __shfl(inc, 63, 64);
+        const int64_t i0 = base + (int64_t)lane * TH_ITEMS;
+        double off = 0.0;                         // chunk-prefix value at the last close in this chunk
+        int64_t last_close = base == 0 ? 0 : base - 1;   // ticks <= last_close cannot close (tick 0 never does)
+        for (;;) {
+            int kk = TH_ITEMS;
+            double ck = 0.0;
+            bool frag = false;
+#pragma unroll
+            for (int k = TH_ITEMS - 1; k >= 0; --k) {
+                const int64_t i = i0 + k;
+                const double c = cin + ((ex + s[k]) - off);
+                const bool live = i > last_close && i < n;
+                if (live && c >= thr) { kk = k; ck = c; }
+                frag |= live && fabs(c - thr) <= tol;
+            }
+            const uint64_t hit = __ballot(kk < TH_ITEMS);
+            if (hit == 0) {
+                unc += __popcll(__ballot(frag));
+                break;
+            }
+            const int l0 = __ffsll((unsigned long long)hit) - 1;
+            const int k0 = __shfl(kk, l0, 64);
+            const double c0 = __shfl(ck, l0, 64);
+            const int64_t ic = base + (int64_t)l0 * TH_ITEMS + k0;
+            // fragile decisions up to and including the close
+            unc += __popcll(__ballot(frag && i0 <= ic)) > 0 ? 1 : 0;
+            if (lane == 0 && m < cap) out[m] = ic;
+            ++m;
+            // re-base: prefix value of the chunk at the close
+            double pk = 0.0;
+#pragma unroll
+            for (int k = 0; k < TH_ITEMS; ++k) pk = (k == k0) ? ex + s[k] : pk;
+            off = __shfl(pk, l0, 64);
+            cin = DOLLAR ? c0 - thr : 0.0;        // logic.py:147 carry / logic.py:113 reset
+            last_close = ic;
+        }
+        cin = cin + (chunk_total - off);
+#pragma unroll
+        for (int k = 0; k < TH_ITEMS; ++k) cur[k] = nxt[k];
+    }
+    if (lane == 0) { result[0] = m; result[1] = unc; }
+}
+
+// sum of the (dollar) volumes: bounds the number of closes
+template <bool AF64, bool DOLLAR>
+__global__ __launch_bounds__(256) void k_threshold_total(const double *__restrict__ price,
+                                                         const void *__restrict__ amount, int64_t n, double *acc)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = fabs(fmk_amt<AF64>(amount, i));
+        if constexpr (DOLLAR) v = fabs(price[i]) * v;
+        s += v;
+    }
+    s = fmk_wave_sum(s);
+    if (fmk_lane() == 0) atomicAdd(acc, s);
+}
+
+struct ThCache {
+    const void *amount;
+    const double *price;
+    int64_t n;
+    double thr;
+    int kind, is_f64;
+    int64_t count, unc;
+    int64_t *dbuf;
+    int64_t cap;
+    fmk_ctx *ctx;
+};
+static ThCache g_cache = {nullptr, nullptr, 0, 0.0, -1, 0, 0, 0, nullptr, 0, nullptr};
+
+template <bool DOLLAR>
+static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
+                  int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    ThCache &c = g_cache;
+    const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
+                     c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf;
+    if (!(hit && d_close_idx)) {
+        // bound the number of closes
+        double *d_acc = (double *)ctx->d_mail;
+        FMK_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, ctx->stream));
+        const unsigned blocks = (unsigned)(fmk_ceil_div(n, 256 * 16) < ctx->n_cu * 16 ? fmk_ceil_div(n, 256 * 16)
+                                                                                      : ctx->n_cu * 16);
+        if (is_f64) k_threshold_total<true, DOLLAR><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, n, d_acc);
+        else k_threshold_total<false, DOLLAR><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, n, d_acc);
+        FMK_LAUNCH_CHECK(ctx);
+        double total = 0.0;
+        FMK_HIP(ctx, hipMemcpyAsync(&total, d_acc, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int64_t bound = n;
+        if (thr > 0 && total / thr + 2.0 < (double)n) bound = (int64_t)(total / thr) + 2;
+        if (bound < 1) bound = 1;
+        if (c.dbuf && c.cap < bound) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
+        if (!c.dbuf) {
+            FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)bound * 8));
+            c.cap = bound;
+        }
+        int64_t *d_res = ctx->d_mail + 8;
+        if (is_f64)
+            k_threshold_index<true, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
+        else
+            k_threshold_index<false, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 16, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = thr; c.kind = (int)DOLLAR;
+        c.is_f64 = is_f64; c.count = ctx->h_mail[0]; c.unc = ctx->h_mail[1];
+        if (c.count > c.cap) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: internal bound exceeded");
+    }
+    *n_idx = c.count;
+    if (n_unc) *n_unc = c.unc;
+    if (!d_close_idx) return FMK_OK;
+    if (capacity < c.count) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: capacity %lld < %lld",
+                                                 (long long)capacity, (long long)c.count);
+    FMK_HIP(ctx, hipMemcpyAsync(d_close_idx, c.dbuf, (size_t)c.count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    c.ctx = nullptr;    // one-shot cache: the inputs may change behind the same pointers
+    return FMK_OK;
+}
+
+extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                                          double threshold, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx,
+                                          int64_t *n_uncertified)
+{
+    return th_run<false>(ctx, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
+                         n_uncertified);
+}
+
+extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                          int amount_is_f64, int64_t n, double threshold, int64_t *d_close_idx,
+                                          int64_t capacity, int64_t *n_idx, int64_t *n_uncertified)
+{
+    return th_run<true>(ctx, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
+                        n_uncertified);
+}

@@ -1,0 +1,36 @@
+"""Drop-in for the tick-level estimators of finmlkit/feature/core/volatility.py on the MI355X.
+
+Only the time-decay estimators that run on the raw tick frame are on the hot path (SURVEY.md 8a
+row 10): `ewmst` and `ewmst_mean0`.  The bar-level indicators of that module are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from numpy.typing import NDArray
+
+from ... import _ffi
+from ..._ffi import c_f64, c_i64, ptr
+
+
+def _ewmst(timestamps, y, half_life, sigma_floor, mean0):
+    ctx = _ffi.default_context()
+    ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    yy = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty(len(yy), np.float64)
+    ctx.call("fmk_ewmst", ptr(ts), ptr(yy), c_i64(len(yy)), c_f64(half_life), c_f64(sigma_floor),
+             C.c_int(int(mean0)), ptr(out))
+    return out
+
+
+def ewmst(timestamps: NDArray[np.int64], y: NDArray[np.float64], half_life: float,
+          sigma_floor: float = 1e-12) -> NDArray[np.float64]:
+    """Reference: finmlkit/feature/core/volatility.py:139-219 (unbiased time-decay EWMA std)."""
+    return _ewmst(timestamps, y, half_life, sigma_floor, False)
+
+
+def ewmst_mean0(timestamps: NDArray[np.int64], y: NDArray[np.float64], half_life: float,
+                sigma_floor: float = 1e-12) -> NDArray[np.float64]:
+    """Reference: finmlkit/feature/core/volatility.py:72-136 (zero-mean variant)."""
+    return _ewmst(timestamps, y, half_life, sigma_floor, True)

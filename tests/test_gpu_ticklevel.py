@@ -1,0 +1,68 @@
+"""GPU parity: comp_lagged_returns and ewmst / ewmst_mean0 vs goldens and the CPU oracle (C ABI)."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9     # north-star float tolerance
+
+
+def _nan_pattern_equal(a, b, what):
+    assert np.array_equal(np.isnan(a), np.isnan(b)), f"{what}: NaN pattern"
+    assert np.array_equal(np.isinf(a), np.isinf(b)), f"{what}: inf pattern"
+
+
+def test_lagged_returns_golden(orc):
+    from finmlkit_amd.feature.core.utils import comp_lagged_returns
+    d = G.load("ticklevel")
+    ts, px, am, sd = G.synth_from(orc, d["synth"])
+    for w in (1e-6, 0.5, 5.0, 60.0):
+        for lg in (0, 1):
+            got = comp_lagged_returns(ts, px, w, bool(lg))
+            want = d[f"ret_{w}_{lg}"]
+            _nan_pattern_equal(got, want, f"ret {w} {lg}")
+            if lg:
+                G.assert_f64_close(got, want, rtol=1e-12, what=f"ret {w} log")   # device log vs NumPy log: <=1 ulp
+            else:
+                np.testing.assert_array_equal(got, want, err_msg=f"ret {w}")     # one IEEE division: bit-exact
+    np.testing.assert_array_equal(comp_lagged_returns(d["small_ts"], d["small_px"], 2.0, False),
+                                  d["small_ret_2.0_0"])
+    with pytest.raises(ValueError, match="greater than zero"):
+        comp_lagged_returns(ts, px, 0.0, False)
+
+
+@pytest.mark.parametrize("n,w", [(500_000, 1.0), (500_000, 300.0), (200_000, 1e-7), (100_000, 1e5)])
+def test_lagged_returns_vs_oracle(orc, n, w):
+    from finmlkit_amd.feature.core.utils import comp_lagged_returns
+    ts, px, am, sd = orc.synth(21, 0, n)
+    got = comp_lagged_returns(ts, px, w, False)
+    np.testing.assert_array_equal(got, orc.comp_lagged_returns(ts, px, w, False))
+
+
+def test_ewmst_golden(orc):
+    from finmlkit_amd.feature.core.volatility import ewmst, ewmst_mean0
+    d = G.load("ticklevel")
+    ts, px, am, sd = G.synth_from(orc, d["synth"])
+    r = d["ret_5.0_1"]
+    for hl in (1.0, 30.0, 600.0):
+        G.assert_f64_close(ewmst(ts, r, hl), d[f"ewmst_{hl}"], rtol=RTOL, what=f"ewmst {hl}")
+        G.assert_f64_close(ewmst_mean0(ts, r, hl), d[f"ewmst0_{hl}"], rtol=RTOL, what=f"ewmst0 {hl}")
+    rn = r.copy()
+    rn[1000:1010] = np.nan
+    G.assert_f64_close(ewmst(ts, rn, 30.0), d["ewmst_nan_30.0"], rtol=RTOL, what="ewmst nan")
+
+
+@pytest.mark.parametrize("n,hl,mean0", [(1_000_000, 60.0, False), (1_000_000, 0.5, False), (700_001, 3600.0, True),
+                                        (5, 10.0, False), (1, 10.0, False), (2049, 10.0, True)])
+def test_ewmst_vs_oracle(orc, n, hl, mean0):
+    from finmlkit_amd.feature.core.volatility import ewmst, ewmst_mean0
+    ts, px, am, sd = orc.synth(8, 0, n)
+    rng = np.random.default_rng(0)
+    y = rng.normal(0, 1e-4, n)
+    y[rng.random(n) < 0.01] = np.nan
+    y[:min(n, 40)] = np.nan                     # leading NaNs like real lagged returns
+    f_gpu, f_cpu = (ewmst_mean0, orc.ewmst_mean0) if mean0 else (ewmst, orc.ewmst)
+    got, want = f_gpu(ts, y, hl), f_cpu(ts, y, hl)
+    G.assert_f64_close(got, want, rtol=RTOL, what=f"ewmst n={n} hl={hl}")
