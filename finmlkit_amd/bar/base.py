@@ -1,19 +1,166 @@
-"""Per-bar reducers: drop-in for the module-level functions of finmlkit/bar/base.py:306-850.
+"""Bar builder base class + per-bar reducers: drop-in for finmlkit/bar/base.py.
 
-Same names, positional arguments, output tuples, dtypes and exceptions as the reference; the
-arithmetic runs in the HIP kernels of csrc/ through the host-pointer flavour of the C ABI.
+* `BarBuilderBase` (reference :24-300): same public surface (`build_ohlcv`,
+  `build_directional_features`, `build_footprints`, `bar_close_indices`, `bar_close_timestamps`,
+  abstract `_comp_bar_close`) and the same DataFrame / FootprintData schemas.  The trade columns are
+  uploaded to HBM ONCE per builder and every `build_*` runs on the resident copy.
+* module-level reducers (reference :306-850): same names, positional arguments, output tuples, dtypes
+  and exceptions, computed by the HIP kernels of csrc/ through the host-pointer C ABI.
 """
 from __future__ import annotations
 
 import ctypes as C
+import io
+import logging
+from abc import ABC, abstractmethod
+from typing import Optional, Tuple
 
 import numpy as np
+import pandas as pd
 from numpy.typing import NDArray
 
 from .. import _ffi
-from .._ffi import c_i64, ptr
+from .._ffi import DeviceArray, c_f64, c_i64, ptr
+from .data_model import FootprintData, TradesData
+from .utils import comp_price_tick_size
+
+logger = logging.getLogger(__name__)
 
 
+class BarBuilderBase(ABC):
+    """Template for bar samplers: subclasses decide where bars close (`_comp_bar_close`), the base class
+    aggregates ticks between closes.  Mirrors finmlkit.bar.base.BarBuilderBase."""
+
+    def __init__(self, trades: TradesData):
+        self.trades_df = trades.data
+        self._close_ts: Optional[NDArray[np.int64]] = None
+        self._close_indices: Optional[NDArray[np.int64]] = None
+        self._highs: Optional[NDArray[np.float64]] = None
+        self._lows: Optional[NDArray[np.float64]] = None
+        self._dev = None           # engine.DeviceTrades (lazy)
+        self._d_close_idx = None   # DeviceArray mirror of _close_indices
+
+    def __str__(self) -> str:
+        members = "\n".join(f"{k}: {v}" for k, v in self.__dict__.items() if not k.startswith("_d"))
+        buf = io.StringIO()
+        try:
+            self.trades_df.info(buf=buf)
+            info = buf.getvalue()
+        except Exception:
+            info = "<unavailable>"
+        return f"Class: {self.__class__.__name__} with members:\n{members}\nRaw trades data:\n{info}"
+
+    # ------------------------------------------------------------------ device residency
+    def _device(self):
+        """Upload timestamp / price / amount (/ side) once; later builds reuse the HBM copy."""
+        if self._dev is None:
+            from ..engine import DeviceTrades
+            df = self.trades_df
+            side = df["side"].values.astype(np.int8) if "side" in df.columns else None
+            self._dev = DeviceTrades.from_numpy(df["timestamp"].astype(np.int64).values, df["price"].values,
+                                                df["amount"].values, side)
+        return self._dev
+
+    @abstractmethod
+    def _comp_bar_close(self) -> Tuple[NDArray[np.int64], NDArray[np.int64]]:
+        """Return (close timestamps, close indices), first entry = open edge (reference base.py:92-99)."""
+
+    def _set_bar_close(self):
+        if self._close_ts is None and self._close_indices is None:
+            logger.info("Calculating bar close tick indices and timestamps...")
+            self._close_ts, self._close_indices = self._comp_bar_close()
+        if self._d_close_idx is None:
+            self._d_close_idx = DeviceArray.from_host(self._device().ctx,
+                                                      np.ascontiguousarray(self._close_indices, dtype=np.int64))
+
+    @property
+    def bar_close_indices(self) -> Optional[NDArray[np.int64]]:
+        if self._close_indices is None:
+            self._set_bar_close()
+        return self._close_indices[1:]
+
+    @property
+    def bar_close_timestamps(self) -> Optional[NDArray[np.int64]]:
+        if self._close_ts is None:
+            self._set_bar_close()
+        return self._close_ts[1:]
+
+    def _check_indices(self):
+        if len(self._close_indices) < 2:
+            raise ValueError("Bar close indices must contain at least two elements.")
+
+    # ------------------------------------------------------------------ builders
+    def build_ohlcv(self) -> pd.DataFrame:
+        """OHLCV + VWAP + trade count + median trade size per bar (reference base.py:132-169)."""
+        from ..engine import to_host
+        self._set_bar_close()
+        self._check_indices()
+        o = to_host(self._device().bar_ohlcv(self._d_close_idx))
+        self._highs, self._lows = o["high"], o["low"]
+        df = pd.DataFrame({
+            "timestamp": self.bar_close_timestamps,
+            "open": o["open"], "high": o["high"], "low": o["low"], "close": o["close"], "volume": o["volume"],
+            "trades": o["trades"], "median_trade_size": o["median_trade_size"], "vwap": o["vwap"],
+        })
+        df["timestamp"] = pd.to_datetime(df["timestamp"], unit="ns")
+        df.set_index("timestamp", inplace=True)
+        if hasattr(self, "interval"):
+            df.index.freq = pd.Timedelta(seconds=self.interval)
+        return df
+
+    def build_directional_features(self) -> pd.DataFrame:
+        """Order-flow features per bar (reference base.py:171-212)."""
+        from ..engine import to_host
+        self._set_bar_close()
+        self._check_indices()
+        if "side" not in self.trades_df.columns:
+            raise KeyError("side")
+        dev = self._device()
+        out, nz = dev.bar_directional(self._d_close_idx)
+        d = to_host(out)
+        if int(nz.to_host()[0]) > 0:     # reference: cum_spread / (buy + sell) with no signed tick (base.py:536)
+            raise ZeroDivisionError("division by zero")
+        df = pd.DataFrame({"timestamp": self.bar_close_timestamps})
+        for k in ("ticks_buy", "ticks_sell", "volume_buy", "volume_sell", "dollars_buy", "dollars_sell",
+                  "mean_spread", "max_spread", "cum_ticks_min", "cum_ticks_max"):
+            df[k] = d[k]
+        df["cum_volume_min"], df["cum_volume_max"] = d["cum_volumes_min"], d["cum_volumes_max"]
+        df["cum_dollars_min"], df["cum_dollars_max"] = d["cum_dollars_min"], d["cum_dollars_max"]
+        df["timestamp"] = pd.to_datetime(df["timestamp"], unit="ns")
+        df.set_index("timestamp", inplace=True)
+        return df
+
+    def build_trade_size_features(self, theta, theta_mult: float = 5.0) -> pd.DataFrame:
+        """Reference base.py:214-245 -- first "next" row of SURVEY.md 8(f), not part of round 1."""
+        raise NotImplementedError("comp_bar_trade_size_features is scheduled after the hot-path rows (SURVEY 8f)")
+
+    def build_footprints(self, price_tick_size=None, imbalance_factor=3.0) -> FootprintData:
+        """Per-bar price-level footprints + imbalance statistics (reference base.py:247-300)."""
+        from ..engine import to_host
+        self._set_bar_close()
+        self._check_indices()
+        if self._highs is None or self._lows is None:
+            self.build_ohlcv()
+        if price_tick_size is None:
+            price_tick_size = comp_price_tick_size(self.trades_df["price"].values)
+        logger.info(f"Price tick size is set to: {price_tick_size}")
+        if "side" not in self.trades_df.columns:
+            raise KeyError("side")
+        dev = self._device()
+        lows = DeviceArray.from_host(dev.ctx, self._lows)
+        highs = DeviceArray.from_host(dev.ctx, self._highs)
+        off, flat, bar, bad = dev.bar_footprints(self._d_close_idx, lows, highs, price_tick_size, imbalance_factor)
+        if int(bad.to_host()[0]) > 0:
+            raise ValueError("Something went wrong! Invalid price level index!")
+        fp = FootprintData.from_csr(self.bar_close_timestamps, price_tick_size, off.to_host(), to_host(flat),
+                                    to_host(bar))
+        fp.cast_to_numba_list()
+        return fp
+
+
+# --------------------------------------------------------------------------------------------
+# CORE FUNCTIONS (NumPy in / NumPy out)
+# --------------------------------------------------------------------------------------------
 def comp_bar_ohlcv(prices: NDArray[np.float64], volumes: NDArray, bar_close_indices: NDArray[np.int64]):
     """Reference: finmlkit/bar/base.py:306-407.
 
@@ -70,7 +217,7 @@ def comp_bar_footprints_csr(prices, amounts, bar_close_indices, trade_sides, pri
     nb = len(ci) - 1
     off = np.empty(nb + 1, np.int64)
     args = (ptr(p), ptr(v), C.c_int(f64), c_i64(len(p)), ptr(ci), c_i64(len(ci)), ptr(sd),
-            _ffi.c_f64(price_tick_size), ptr(lo), ptr(hi), _ffi.c_f64(imbalance_factor), ptr(off))
+            c_f64(price_tick_size), ptr(lo), ptr(hi), c_f64(imbalance_factor), ptr(off))
     ctx.call("fmk_comp_bar_footprints", *args, None)
     tot = int(off[-1])
     flat = {k: np.empty(tot, dt) for k, dt in _ffi.FOOTPRINT_FLAT_FIELDS}
@@ -95,3 +242,27 @@ def comp_bar_footprints(prices, amounts, bar_close_indices, trade_sides, price_t
             split(flat["buy_imbalances"].view(np.bool_)), split(flat["sell_imbalances"].view(np.bool_)),
             bar["buy_imbalances_sum"], bar["sell_imbalances_sum"], bar["cot_price_levels"],
             bar["imb_max_run_signed"], bar["vp_skew"], bar["vp_gini"])
+
+
+def comp_footprint_features(price_levels, buy_volumes, sell_volumes, imbalance_multiplier):
+    """Reference: finmlkit/bar/base.py:755-850, for ONE bar's level arrays.
+
+    Evaluated by the same device code as comp_bar_footprints: the level profile is replayed as a
+    synthetic one-bar tick stream (one buy and one sell tick per level carrying that level's volume)."""
+    lv = np.ascontiguousarray(price_levels, dtype=np.int32)
+    b = np.ascontiguousarray(buy_volumes, dtype=np.float32)
+    s = np.ascontiguousarray(sell_volumes, dtype=np.float32)
+    L = len(lv)
+    if L == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    if np.any(np.diff(lv) != 1):
+        raise ValueError("comp_footprint_features: price_levels must be consecutive integers")
+    px = np.repeat(lv.astype(np.float64), 2)                 # tick size 1.0: level == price
+    am = np.stack([b, s], axis=1).reshape(-1)
+    sd = np.tile(np.array([1, -1], dtype=np.int8), L)
+    ci = np.array([-1, 2 * L - 1], dtype=np.int64)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 1.0, np.array([float(lv[0])]),
+                                             np.array([float(lv[-1])]), imbalance_multiplier)
+    return (flat["buy_imbalances"].view(np.bool_), flat["sell_imbalances"].view(np.bool_),
+            int(bar["imb_max_run_signed"][0]), np.int32(bar["cot_price_levels"][0]), float(bar["vp_skew"][0]),
+            float(bar["vp_gini"][0]))

@@ -1,0 +1,87 @@
+"""Concrete bar kits: drop-in for finmlkit/bar/kit.py (same constructors, same `build_*` results).
+
+Each kit only decides where bars close; the close indices are computed on the MI355X from the
+builder's resident trade columns (BarBuilderBase._device) and handed to the shared reducers.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Tuple
+
+import numpy as np
+import pandas as pd
+from numpy.typing import NDArray
+
+from .base import BarBuilderBase
+from .data_model import TradesData
+
+logger = logging.getLogger(__name__)
+
+
+class TimeBarKit(BarBuilderBase):
+    """Fixed-interval time bars (reference kit.py:12-35)."""
+
+    def __init__(self, trades: TradesData, period: pd.Timedelta):
+        super().__init__(trades)
+        self.interval = period.total_seconds()
+        logger.info(f"Time bar builder initialized with interval: {self.interval} seconds.")
+
+    def _comp_bar_close(self) -> Tuple[NDArray[np.int64], NDArray[np.int64]]:
+        clock, idx = self._device().time_bar_index(self.interval)
+        self._d_close_idx = idx
+        return clock.to_host(), idx.to_host()
+
+
+class _ThresholdKit(BarBuilderBase):
+    def _close_from(self, d_idx) -> Tuple[NDArray[np.int64], NDArray[np.int64]]:
+        self._d_close_idx = d_idx
+        close_ts = self._device().gather_ts(d_idx).to_host()      # timestamps[close_indices] (kit.py:66)
+        return close_ts, d_idx.to_host()
+
+
+class TickBarKit(_ThresholdKit):
+    """Every `tick_count_thrs`-th trade closes a bar (reference kit.py:38-67)."""
+
+    def __init__(self, trades: TradesData, tick_count_thrs: int):
+        super().__init__(trades)
+        self.tick_count_thrs = tick_count_thrs
+        logger.info(f"Tick bar builder initialized with tick count: {tick_count_thrs}.")
+
+    def _comp_bar_close(self):
+        return self._close_from(self._device().tick_bar_index(self.tick_count_thrs))
+
+
+class VolumeBarKit(_ThresholdKit):
+    """Cumulative traded volume >= `volume_ths` closes a bar (reference kit.py:70-101)."""
+
+    def __init__(self, trades: TradesData, volume_ths: float):
+        super().__init__(trades)
+        self.volume_ths = volume_ths
+        logger.info(f"Volume bar builder initialized with volume: {volume_ths}.")
+
+    def _comp_bar_close(self):
+        return self._close_from(self._device().volume_bar_index(self.volume_ths))
+
+
+class DollarBarKit(_ThresholdKit):
+    """Cumulative price*volume >= `dollar_thrs` closes a bar, excess carried over (reference kit.py:104-137)."""
+
+    def __init__(self, trades: TradesData, dollar_thrs: float):
+        super().__init__(trades)
+        self.dollar_thrs = dollar_thrs
+        logger.info(f"Dollar bar builder initialized with dollar amount: {dollar_thrs}.")
+
+    def _comp_bar_close(self):
+        return self._close_from(self._device().dollar_bar_index(self.dollar_thrs))
+
+
+class CUSUMBarKit(BarBuilderBase):
+    """Reference kit.py:140-181.  Third "next" row of SURVEY.md 8(f) (needs the tick-level sigma first);
+    not part of the round-1 hot path."""
+
+    def __init__(self, trades: TradesData, sigma, sigma_floor: float = 5e-4, sigma_mult: float = 2.):
+        super().__init__(trades)
+        self.lambda_mult, self._sigma, self.sigma_floor = sigma_mult, sigma, sigma_floor
+
+    def _comp_bar_close(self):
+        raise NotImplementedError("CUSUM bars are scheduled after the hot-path rows (SURVEY.md 8f rank 3)")

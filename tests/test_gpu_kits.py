@@ -1,0 +1,125 @@
+"""GPU: the TradesData / *BarKit / Compose surface end to end (the path a finmlkit user calls),
+checked against the CPU oracle."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+N = 120_000
+
+
+@pytest.fixture(scope="module")
+def stream(orc):
+    return orc.synth(42, 0, N)
+
+
+@pytest.fixture(scope="module")
+def trades(stream):
+    from finmlkit_amd.bar.data_model import TradesData
+    ts, px, am, sd = stream
+    return TradesData(ts, px, am, np.arange(N), side=sd)
+
+
+def test_time_bar_kit_ohlcv(orc, stream, trades):
+    from finmlkit_amd.bar.kit import TimeBarKit
+    ts, px, am, sd = stream
+    kit = TimeBarKit(trades, pd.Timedelta(minutes=1))
+    df = kit.build_ohlcv()
+    clock, ci = orc._time_bar_indexer(ts, 60.0)
+    o = orc.comp_bar_ohlcv(px, am, ci)
+    assert list(df.columns) == ["open", "high", "low", "close", "volume", "trades", "median_trade_size", "vwap"]
+    assert df.index.name == "timestamp" and df.index.freq == pd.Timedelta(seconds=60)
+    np.testing.assert_array_equal(df.index.values.astype(np.int64), clock[1:])        # close-timestamp convention
+    np.testing.assert_array_equal(kit.bar_close_indices, ci[1:])
+    np.testing.assert_array_equal(kit.bar_close_timestamps, clock[1:])
+    for k, w in zip(["open", "high", "low", "close"], o[:4]):
+        np.testing.assert_array_equal(df[k].values, w)
+    np.testing.assert_array_equal(df["trades"].values, o[6])
+    np.testing.assert_array_equal(df["median_trade_size"].values, o[7])
+    G.assert_f32_close(df["volume"].values, o[4], what="volume")
+    G.assert_f64_close(df["vwap"].values, o[5], rtol=1e-9, what="vwap")
+    assert df["volume"].dtype == np.float32 and df["trades"].dtype == np.int64
+
+
+def test_time_bar_kit_directional_and_footprints(orc, stream, trades):
+    from finmlkit_amd.bar.data_model import FootprintData
+    from finmlkit_amd.bar.kit import TimeBarKit
+    ts, px, am, sd = stream
+    kit = TimeBarKit(trades, pd.Timedelta(minutes=5))
+    _, ci = orc._time_bar_indexer(ts, 300.0)
+    d = kit.build_directional_features()
+    want = orc.comp_bar_directional_features(px, am, ci, sd)
+    cols = ["ticks_buy", "ticks_sell", "volume_buy", "volume_sell", "dollars_buy", "dollars_sell", "mean_spread",
+            "max_spread", "cum_ticks_min", "cum_ticks_max", "cum_volume_min", "cum_volume_max", "cum_dollars_min",
+            "cum_dollars_max"]
+    assert list(d.columns) == cols
+    for c, w in zip(cols, want):
+        if w.dtype == np.int64:
+            np.testing.assert_array_equal(d[c].values, w, err_msg=c)
+        else:
+            G.assert_f32_close(d[c].values, w, what=c)
+    fp = kit.build_footprints()                 # tick size inferred from the prices (0.01), ohlcv built on demand
+    assert isinstance(fp, FootprintData) and fp.price_tick == pytest.approx(0.01) and len(fp) == len(ci) - 1
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, fp.price_tick, o[2], o[1], 3.0)
+    np.testing.assert_array_equal(fp.level_offsets, woff)
+    for k in G.FP_LIST_KEYS:
+        np.testing.assert_array_equal(np.concatenate(getattr(fp, k)).astype(wflat[k].dtype), wflat[k], err_msg=k)
+    for k in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
+        np.testing.assert_array_equal(getattr(fp, k), wbar[k], err_msg=k)
+    assert isinstance(fp.price_levels, list) and len(fp.get_df()) == woff[-1]
+
+
+def test_threshold_kits(orc, stream, trades):
+    from finmlkit_amd.bar.kit import DollarBarKit, TickBarKit, VolumeBarKit
+    ts, px, am, sd = stream
+    for kit, ci in ((TickBarKit(trades, 250), orc._tick_bar_indexer(ts, 250)),
+                    (VolumeBarKit(trades, 1500.0), orc._volume_bar_indexer(am, 1500.0)),
+                    (DollarBarKit(trades, 2.5e7), orc._dollar_bar_indexer(px, am, 2.5e7))):
+        df = kit.build_ohlcv()
+        o = orc.comp_bar_ohlcv(px, am, ci)
+        np.testing.assert_array_equal(kit.bar_close_indices, ci[1:])
+        np.testing.assert_array_equal(df.index.values.astype(np.int64), ts[ci][1:])   # close_ts = timestamps[idx]
+        np.testing.assert_array_equal(df["trades"].values, o[6])
+        np.testing.assert_array_equal(df["close"].values, o[3])
+        assert not hasattr(kit, "interval")
+
+
+def test_compose_return_ewmst(orc, stream, trades):
+    """QuickStart flow: Compose(ReturnT(5s, log, 'price'), EWMST(1 min))(trades.data)."""
+    from finmlkit_amd.feature.transforms import EWMST, Compose, ReturnT
+    ts, px, am, sd = stream
+    pipe = Compose(ReturnT(pd.Timedelta(seconds=5), is_log=True, input_col="price"), EWMST(pd.Timedelta(minutes=1)))
+    out = pipe(trades.data)
+    assert out.name == "price_ret5.0s_ewms60.0s" and out.index.equals(trades.data.index)
+    r = orc.comp_lagged_returns(ts, px, 5.0, True)
+    G.assert_f64_close(out.values, orc.ewmst(ts, r, 60.0), rtol=1e-9, what="compose")
+
+
+def test_footprint_features_function(orc):
+    from finmlkit_amd.bar.base import comp_footprint_features
+    d = G.load("footprint_features")
+    for c in G.cases(d):
+        bi, si, run, cot, sk, gi = comp_footprint_features(d[f"{c}__lv"], d[f"{c}__b"], d[f"{c}__s"], 1.5)
+        np.testing.assert_array_equal(bi, d[f"{c}__bi"], err_msg=c)
+        np.testing.assert_array_equal(si, d[f"{c}__si"], err_msg=c)
+        wrun, wcot, wsk, wgi = d[f"{c}__scalars"]
+        assert run == int(wrun) and cot == int(wcot), c
+        assert gi == wgi, (c, gi, wgi)                      # float32 pairwise summation order, bit-exact
+        assert abs(sk - wsk) <= 2e-6, (c, sk, wsk)          # rounding noise of an identically-zero quantity
+
+
+def test_errors_match_reference(orc, trades):
+    from finmlkit_amd.bar.base import comp_bar_ohlcv
+    from finmlkit_amd.bar.data_model import TradesData
+    from finmlkit_amd.bar.kit import CUSUMBarKit, TimeBarKit
+    with pytest.raises(ValueError, match="same length"):
+        comp_bar_ohlcv(np.zeros(3), np.zeros(2), np.array([0, 1]))
+    t2 = TradesData(trades.data["timestamp"].values, trades.data["price"].values, trades.data["amount"].values)
+    with pytest.raises(KeyError):
+        TimeBarKit(t2, pd.Timedelta(minutes=1)).build_directional_features()
+    with pytest.raises(NotImplementedError):
+        CUSUMBarKit(trades, np.zeros(N)).build_ohlcv()
