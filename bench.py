@@ -24,6 +24,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+# note of MI355X_MICROARCH.md + WRITE_SIZE), see profiles/; None until measured for the current kernel.
+TRAFFIC = None
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -86,7 +89,7 @@ def main():
 
     import numpy as np
     from finmlkit_amd import _ffi, engine
-    from finmlkit_amd._ffi import DeviceArray, Event, c_f64, c_i64
+    from finmlkit_amd._ffi import DeviceArray, c_f64, c_i64
     import ctypes as C
 
     ctx = _ffi.default_context()
@@ -124,7 +127,7 @@ def main():
         tcols = [torch.as_tensor(b, device=dev) for b in trades._backing]   # zero-copy views of our buffers
         one = DeviceArray(ctx, 1, np.int64)
 
-    def step(ev=None):
+    def step():
         if not use_dist:
             t0, t1 = trades.first_last_ts()
             ne, e0, d = clock_of(t0, t1)
@@ -153,15 +156,8 @@ def main():
             ensure_buffers(ne)
         clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
         out = state["out"]
-        if ev:
-            ev[0].record()
-        t.bar_ohlcv(ci, want_median=False, out=out)
-        if ev:
-            ev[1].record()
-        if want_median:
-            t.bar_median(ci, out["median_trade_size"])
-        if ev:
-            ev[2].record()
+        # comp_bar_ohlcv incl. the median trade size: ONE fused kernel for bars <= 1408 ticks (dominant)
+        t.bar_ohlcv(ci, want_median=want_median, out=out)
         state["n_bars"] = ne - 1
         return ne - 1
 
@@ -172,13 +168,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [(Event(ctx), Event(ctx), Event(ctx)) for _ in range(args.steps)]
+    ctx.call("fmk_profile_enable", C.c_int(1))      # HIP-event pair around every dominant-kernel launch
     barrier()
     t_start = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step()
     barrier()
     elapsed = time.perf_counter() - t_start
+    kms = (C.c_double * 64)()
+    kn = C.c_int()
+    ctx.call("fmk_profile_read", kms, C.c_int(64), C.byref(kn))
+    ctx.call("fmk_profile_enable", C.c_int(0))
 
     if comm:
         import torch
@@ -190,13 +190,12 @@ def main():
     else:
         n_bars_total = state["n_bars"]
 
-    k_ms = [e[0].elapsed_ms(e[1]) for e in events]
-    m_ms = [e[1].elapsed_ms(e[2]) for e in events] if want_median else [0.0]
+    k_ms = [kms[i] for i in range(kn.value)]
     avg_k_ms = sum(k_ms) / len(k_ms)
     nb = state["n_bars"]
-    # algorithmic bytes of ONE k_bar_ohlcv launch: price f64 + amount f32 read once per tick,
-    # close_idx read once and 60 B written per bar (DESIGN.md "roofline")
-    alg_bytes = n * 12 + nb * 60 + (nb + 1) * 8
+    # algorithmic bytes of ONE launch of the dominant kernel: price f64 + amount f32 read once per tick,
+    # close_idx read once and 60 (+8 with the median) B written per bar (DESIGN.md "roofline")
+    alg_bytes = n * 12 + nb * (68 if want_median else 60) + (nb + 1) * 8
     achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
 
     if rank == 0:
@@ -220,10 +219,11 @@ def main():
                 "ticks_per_gpu": n, "n_bars_total": n_bars_total, "interval_s": args.interval,
                 "parallelism": f"time-range shards x{world}, 1 neighbour halo exchange" if use_dist else "1 GPU",
             },
-            "roofline": {"bound": "hbm", "kernel": "k_bar_ohlcv<f32 amount>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
-                         "median_kernel_ms": sum(m_ms) / len(m_ms)},
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_bar_ohlcv_small<f32 amount, 22 chunks, %s>" % ("fused median" if want_median else "no median"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": TRAFFIC, "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
+                         "launches_timed": len(k_ms)},
         }
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -203,6 +203,33 @@ int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms)
     return FMK_OK;
 }
 
+int fmk_profile_enable(fmk_ctx *ctx, int on)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->kev[0][0])
+        for (int i = 0; i < 64; ++i) {
+            FMK_HIP(ctx, hipEventCreate(&ctx->kev[i][0]));
+            FMK_HIP(ctx, hipEventCreate(&ctx->kev[i][1]));
+        }
+    ctx->profile_on = on;
+    ctx->profile_n = 0;
+    return FMK_OK;
+}
+
+int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count)
+{
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = ctx->profile_n < 64 ? ctx->profile_n : 64;
+    if (n > capacity) n = capacity;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        FMK_HIP(ctx, hipEventElapsedTime(&t, ctx->kev[i][0], ctx->kev[i][1]));
+        ms[i] = (double)t;
+    }
+    *count = n;
+    return FMK_OK;
+}
+
 }  // extern "C"
 
 int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out)

@@ -23,6 +23,9 @@ struct fmk_ctx {
     int64_t *h_mail;   // 64 x int64
     int64_t *d_mail;   // 64 x int64
     int n_cu;
+    // per-launch timing of the dominant kernel (fmk_profile_enable)
+    int profile_on, profile_n;
+    hipEvent_t kev[64][2];
 };
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);

@@ -2,29 +2,76 @@
 //
 // Layout: price f64[N], amount f32|f64[N], close_idx i64[B+1] resident in HBM.
 // One 64-lane wave owns one bar (bars are contiguous tick ranges, so the wave streams
-// 512 B (price) + 256 B (amount) fully coalesced per load instruction, four independent
-// loads in flight per lane), keeps hi/lo/sum(vol)/sum(price*vol) in registers and folds them
-// with a 6-step xor butterfly when the bar ends.  No LDS, no atomics, no MFMA: the kernel is
-// bounded by HBM read bandwidth, 12 B/tick (f32 amounts) + 60 B/bar written.
+// 512 B (price) + 256 B (amount) fully coalesced per load instruction), keeps
+// hi/lo/sum(vol)/sum(price*vol) in registers and folds them with a 6-step xor butterfly when the
+// bar ends.  No atomics, no MFMA: bounded by HBM read bandwidth, 12 B/tick (f32 amounts) +
+// 8 B/bar read + 60..68 B/bar written.
 //
-// The median trade size (base.py:403) is a second kernel, see fmk_median.hip.
+// Two kernels:
+//   k_bar_ohlcv_small  bars of <= 64*NCH ticks (NCH = 22 -> 1408 ticks: every 1-minute bar of the
+//                      benchmark stream).  ALL loads of the bar are issued up front (one HBM round
+//                      trip per bar instead of one per unrolled batch), and -- when the median trade
+//                      size is requested (base.py:403) -- the amounts that are already in registers
+//                      feed the exact order-statistic search of fmk_median.h directly: the amount
+//                      column is read ONCE for OHLCV + median.
+//   k_bar_ohlcv        any bar length (unroll-4 streaming loop); with min_cnt > 0 it only takes the
+//                      bars the small kernel skipped.  Long bars get their median from k_bar_median.
 //
 // Floating point: price*volume is rounded before it is added (-ffp-contract=off), exactly
 // like the reference; the per-bar float64 sums are accumulated lane-strided and then
 // tree-reduced, i.e. in a different order than the reference's sequential loop
-// (|rel. diff| ~ 1e-16, the north-star tolerance is 1e-9).
+// (|rel. diff| ~ 1e-16, the north-star tolerance is 1e-9).  Both kernels use the same order.
 #include <math.h>
+#include <stdlib.h>
 
 #include "fmk_common.h"
+#include "fmk_median.h"
+
+#define FMK_SMALL_NCH 22
+
+int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
+                      int64_t min_cnt, double *d_median);
+
+struct OhlcvOut {
+    double *open, *high, *low, *close;
+    float *vol;
+    double *vwap;
+    int64_t *trades;
+    double *median;
+};
+
+__device__ __forceinline__ void ohlcv_empty(const OhlcvOut &o, int64_t b, const double *price, int64_t e, int64_t n)
+{
+    // empty bar (base.py:352-361): previous close, Python-style negative wrap of prices[end]
+    double p = price[fmk_wrap(e, n)];
+    o.open[b] = p; o.high[b] = p; o.low[b] = p; o.close[b] = p;
+    o.vol[b] = 0.f; o.vwap[b] = 0.0; o.trades[b] = 0;
+    if (o.median) o.median[b] = 0.0;
+}
+
+__device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const double *price, int64_t start,
+                                             int64_t e, double hi, double lo, double tv, double td, int lane)
+{
+    hi = fmk_wave_max(hi);
+    lo = fmk_wave_min(lo);
+    tv = fmk_wave_sum(tv);
+    td = fmk_wave_sum(td);
+    if (lane == 0) {
+        o.open[b] = price[start];
+        o.close[b] = price[e];
+        o.high[b] = hi;
+        o.low[b] = lo;
+        o.vol[b] = (float)tv;
+        o.vwap[b] = tv > 0.0 ? td / tv : 0.0;   // base.py:398
+        o.trades[b] = e - start + 1;
+    }
+}
 
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ price,
                                                    const void *__restrict__ amount,
                                                    const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                   double *__restrict__ o_open, double *__restrict__ o_high,
-                                                   double *__restrict__ o_low, double *__restrict__ o_close,
-                                                   float *__restrict__ o_vol, double *__restrict__ o_vwap,
-                                                   int64_t *__restrict__ o_trades)
+                                                   int64_t min_cnt, OhlcvOut o)
 {
     const int lane = fmk_lane();
     const int wpb = blockDim.x >> 6;
@@ -33,12 +80,9 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
-        if (e <= s) {   // empty bar (base.py:352-361): previous close, Python-style negative wrap
-            if (lane == 0) {
-                double p = price[fmk_wrap(e, n)];
-                o_open[b] = p; o_high[b] = p; o_low[b] = p; o_close[b] = p;
-                o_vol[b] = 0.f; o_vwap[b] = 0.0; o_trades[b] = 0;
-            }
+        if (min_cnt > 0 && e - s <= min_cnt) continue;      // the small-bar kernel owns this one
+        if (e <= s) {
+            if (lane == 0) ohlcv_empty(o, b, price, e, n);
             continue;
         }
         const int64_t start = s + 1;
@@ -62,18 +106,75 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
             lo = fmin(lo, p0);
             tv += a0; td += p0 * a0;
         }
-        hi = fmk_wave_max(hi);
-        lo = fmk_wave_min(lo);
-        tv = fmk_wave_sum(tv);
-        td = fmk_wave_sum(td);
-        if (lane == 0) {
-            o_open[b] = price[start];
-            o_close[b] = price[e];
-            o_high[b] = hi;
-            o_low[b] = lo;
-            o_vol[b] = (float)tv;
-            o_vwap[b] = tv > 0.0 ? td / tv : 0.0;   // base.py:398
-            o_trades[b] = e - s;
+        ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
+    }
+}
+
+template <bool AF64, int NCH, bool MEDIAN>
+__global__ __launch_bounds__(256) void k_bar_ohlcv_small(const double *__restrict__ price,
+                                                         const void *__restrict__ amount,
+                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                         OhlcvOut o)
+{
+    typedef MedKey<AF64> MK;
+    typedef typename MK::K K;     // raw bit pattern type of one amount
+    __shared__ K sbuf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t cnt = e - s;
+        if (cnt > 64 * NCH) continue;                        // long bar: generic kernels
+        if (cnt <= 0) {
+            if (lane == 0) ohlcv_empty(o, b, price, e, n);
+            continue;
+        }
+        const int64_t start = s + 1;
+        // ---- issue every load of the bar: branch-free, offsets clamped to the bar's last tick (chunks
+        //      past the end re-read that one element: same cache line, no extra HBM traffic)
+        const double *pb = price + start;                    // wave-uniform bases + 32-bit lane offsets
+        const K *ab = (const K *)amount + start;
+        const unsigned last = (unsigned)(cnt - 1);
+        double p[NCH];
+        K araw[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            unsigned idx = (unsigned)(c * 64 + lane);
+            idx = idx < last ? idx : last;
+            p[c] = pb[idx];
+            araw[c] = ab[idx];
+        }
+        // ---- OHLCV accumulation, same per-lane order as k_bar_ohlcv
+        double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+        MedBar<AF64, NCH> bar;
+        bool nan = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool valid = (unsigned)(c * 64 + lane) <= last;
+            double a;
+            if constexpr (AF64) a = __longlong_as_double((long long)araw[c]);
+            else a = (double)__uint_as_float(araw[c]);
+            hi = fmax(hi, p[c]);                             // clamped duplicates cannot change max/min
+            lo = fmin(lo, p[c]);
+            const double pa = p[c] * a;
+            tv += valid ? a : 0.0;
+            td += valid ? pa : 0.0;
+            if constexpr (MEDIAN) {
+                const K key = valid ? MK::tokey(araw[c]) : MK::MAXK;
+                nan |= valid && MK::is_nan(key);
+                bar.key[c] = key;
+            }
+        }
+        ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
+        if constexpr (MEDIAN) {
+            bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+            double m = NAN;                                   // np.median propagates NaN
+            if (__ballot(nan) == 0) m = med_search<AF64, NCH>(bar, sbuf[wib]);
+            if (lane == 0) o.median[b] = m;
         }
     }
 }
@@ -87,6 +188,31 @@ static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
     return (unsigned)blocks;
 }
 
+template <bool AF64>
+static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n,
+                        const OhlcvOut &o, int variant)
+{
+    const unsigned grid = ohlcv_grid(ctx, nb);
+    const int slot = ctx->profile_on ? (ctx->profile_n++ & 63) : -1;     // time the dominant launch only
+    if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][0], ctx->stream));
+    if (variant == 0) {   // generic streaming kernel only (+ stand-alone median)
+        k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, o);
+        FMK_LAUNCH_CHECK(ctx);
+        if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
+        if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, o.median);
+        return FMK_OK;
+    }
+    // small bars: all loads up front (+ fused median); long bars: generic kernels on the rest
+    if (o.median) k_bar_ohlcv_small<AF64, FMK_SMALL_NCH, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, o);
+    else k_bar_ohlcv_small<AF64, FMK_SMALL_NCH, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, o);
+    FMK_LAUNCH_CHECK(ctx);
+    if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
+    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 64 * FMK_SMALL_NCH, o);
+    FMK_LAUNCH_CHECK(ctx);
+    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 64 * FMK_SMALL_NCH, o.median);
+    return FMK_OK;
+}
+
 extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
                                       int amount_is_f64, int64_t n, const int64_t *d_close_idx, int64_t n_idx,
                                       double *d_open, double *d_high, double *d_low, double *d_close,
@@ -97,15 +223,12 @@ extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_ohlcv: empty price array");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;
-    const unsigned grid = ohlcv_grid(ctx, nb);
-    if (amount_is_f64)
-        k_bar_ohlcv<true><<<grid, 256, 0, ctx->stream>>>(d_price, d_amount, d_close_idx, nb, n, d_open, d_high,
-                                                        d_low, d_close, d_volume, d_vwap, d_trades);
-    else
-        k_bar_ohlcv<false><<<grid, 256, 0, ctx->stream>>>(d_price, d_amount, d_close_idx, nb, n, d_open, d_high,
-                                                         d_low, d_close, d_volume, d_vwap, d_trades);
-    FMK_LAUNCH_CHECK(ctx);
-    if (d_median) return fmk_comp_bar_median_dev(ctx, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_median);
-    return FMK_OK;
+    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median};
+    static int variant = -1;   // developer knob: FMK_OHLCV_VARIANT=0 forces the generic kernels
+    if (variant < 0) {
+        const char *v = getenv("FMK_OHLCV_VARIANT");
+        variant = v ? atoi(v) : 1;
+    }
+    return amount_is_f64 ? ohlcv_launch<true>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant)
+                         : ohlcv_launch<false>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant);
 }
-

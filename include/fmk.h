@@ -80,6 +80,11 @@ int fmk_event_create(fmk_ctx *ctx, void **event);
 int fmk_event_destroy(fmk_ctx *ctx, void *event);
 int fmk_event_record(fmk_ctx *ctx, void *event);
 int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms);
+/* Per-launch timing of the dominant kernel (k_bar_ohlcv_small / k_bar_ohlcv of comp_bar_ohlcv):
+ * while enabled, every fmk_comp_bar_ohlcv_dev call brackets that ONE kernel launch with a HIP event
+ * pair on the context stream (ring of 64).  fmk_profile_read synchronises and returns the durations. */
+int fmk_profile_enable(fmk_ctx *ctx, int on);
+int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count);
 
 /* ---- synthetic tick stream (same definition as oracle/orc_synth) ----- */
 /* Writes ticks [first, first+n) of stream `seed` into device columns (any may be NULL). */
