@@ -50,15 +50,38 @@ extern "C" int fmk_time_bar_clock(int64_t ts_first, int64_t ts_last, double inte
     return FMK_OK;
 }
 
+// Two-level search.  A coarse sample ts[j*4096] (N/4096 entries, L2-resident) is gathered first; every
+// clock edge then bisects the sample (cache hits) and finishes inside one 4096-tick window (32 KB):
+// ~8 HBM-latency probes per edge instead of ~20.
+#define TB_COARSE_SHIFT 12
+
+__global__ __launch_bounds__(256) void k_time_bar_coarse(const int64_t *__restrict__ ts, int64_t n,
+                                                         int64_t *__restrict__ coarse, int64_t m)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) coarse[j] = ts[j << TB_COARSE_SHIFT];
+}
+
 // one thread per clock edge: close_idx[k] = searchsorted(ts, edge_k, side='right') - 1
 __global__ __launch_bounds__(256) void k_time_bar_index(const int64_t *__restrict__ ts, int64_t n, int64_t e0,
-                                                        int64_t d, int64_t ne, int64_t *__restrict__ clock,
+                                                        int64_t d, int64_t ne, const int64_t *__restrict__ coarse,
+                                                        int64_t m, int64_t *__restrict__ clock,
                                                         int64_t *__restrict__ idx)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ne) return;
     int64_t edge = e0 + k * d;
-    int64_t lo = 0, hi = n;
+    // number of sample points <= edge
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (coarse[mid] <= edge) lo = mid + 1; else hi = mid;
+    }
+    // ts[(lo-1)*4096] <= edge < ts[lo*4096]  ->  the answer lies in that window
+    int64_t wlo = lo == 0 ? 0 : ((lo - 1) << TB_COARSE_SHIFT) + 1;
+    int64_t whi = lo == 0 ? 0 : (lo << TB_COARSE_SHIFT);
+    if (whi > n) whi = n;
+    lo = wlo; hi = whi;
     while (lo < hi) {
         int64_t mid = lo + ((hi - lo) >> 1);
         if (ts[mid] <= edge) lo = mid + 1; else hi = mid;
@@ -73,8 +96,15 @@ extern "C" int fmk_time_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, int64
     if (n <= 0 || n_edges < 0) return fmk_set_error(ctx, FMK_E_ARG, "time_bar_indexer: empty input");
     if (n_edges == 0) return FMK_OK;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t m = fmk_ceil_div(n, (int64_t)1 << TB_COARSE_SHIFT);
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, (size_t)m * 8, &scr));
+    int64_t *coarse = (int64_t *)scr;
+    k_time_bar_coarse<<<(unsigned)fmk_ceil_div(m, 256), 256, 0, ctx->stream>>>(d_ts, n, coarse, m);
+    FMK_LAUNCH_CHECK(ctx);
     k_time_bar_index<<<(unsigned)fmk_ceil_div(n_edges, 256), 256, 0, ctx->stream>>>(d_ts, n, first_edge, delta,
-                                                                                   n_edges, d_clock, d_close_idx);
+                                                                                   n_edges, coarse, m, d_clock,
+                                                                                   d_close_idx);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }

@@ -1,15 +1,20 @@
-// fmk_median.h -- exact per-bar order statistics (shared by fmk_median.hip and the fused small-bar kernel of fmk_ohlcv.hip).
-// See fmk_median.hip for the algorithm description.
+// fmk_median.h -- exact per-bar order statistics (shared by fmk_median.hip and the fused small-bar
+// kernel of fmk_ohlcv.hip).  See fmk_median.hip for the algorithm description.
 #pragma once
 #include <math.h>
 
 #include "fmk_common.h"
 
+// Order-preserving map float bits -> unsigned ("key").  Every non-NaN float maps into
+// [key(-inf), key(+inf)]; NaNs map outside that interval, so a bar contains a NaN iff the
+// min/max of its keys leaves it -- no per-element NaN test is needed.
 template <bool AF64> struct MedKey;
 template <> struct MedKey<false> {
     typedef uint32_t K;
     static constexpr int BITS = 32;
     static constexpr K MAXK = 0xFFFFFFFFu;
+    static constexpr K KEY_NEG_INF = 0x007FFFFFu;   // ~0xFF800000
+    static constexpr K KEY_POS_INF = 0xFF800000u;   // 0x7F800000 | sign
     __device__ static __forceinline__ K tokey(K u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
     __device__ static __forceinline__ K load(const void *p, int64_t j) { return tokey(((const uint32_t *)p)[j]); }
     __device__ static __forceinline__ double value(K k)
@@ -17,27 +22,19 @@ template <> struct MedKey<false> {
         uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
         return (double)__uint_as_float(u);
     }
-    __device__ static __forceinline__ bool is_nan(K k)
-    {
-        uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-        return (u & 0x7FFFFFFFu) > 0x7F800000u;
-    }
 };
 template <> struct MedKey<true> {
     typedef uint64_t K;
     static constexpr int BITS = 64;
     static constexpr K MAXK = 0xFFFFFFFFFFFFFFFFull;
+    static constexpr K KEY_NEG_INF = 0x000FFFFFFFFFFFFFull;
+    static constexpr K KEY_POS_INF = 0xFFF0000000000000ull;
     __device__ static __forceinline__ K tokey(K u) { return (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
     __device__ static __forceinline__ K load(const void *p, int64_t j) { return tokey(((const uint64_t *)p)[j]); }
     __device__ static __forceinline__ double value(K k)
     {
         uint64_t u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
         return __longlong_as_double((long long)u);
-    }
-    __device__ static __forceinline__ bool is_nan(K k)
-    {
-        uint64_t u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-        return (u & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull;
     }
 };
 
@@ -76,8 +73,10 @@ __device__ __forceinline__ K med_bitonic64(K v, int lane)
     return v;
 }
 
-// Abstract access to the bar's keys: NREG > 0 -> register file, NREG == 0 -> re-read from memory.
-template <bool AF64, int NREG>
+// The bar's keys.  NREG > 0: register file, key[r] of lane l is tick r*64+l, unused slots hold the
+// sentinel MAXK.  EXACT: the bar has exactly NREG chunks, so only register NREG-1 can hold sentinels.
+// NREG == 0: keys are re-read from memory on every pass (bars too long for the register file).
+template <bool AF64, int NREG, bool EXACT = false>
 struct MedBar {
     typedef MedKey<AF64> MK;
     typedef typename MK::K K;
@@ -86,34 +85,27 @@ struct MedBar {
     int64_t start, cnt;
     int lane;
 
-    __device__ __forceinline__ bool load_all()   // returns "any NaN in my lane"
+    __device__ __forceinline__ void load_all()
     {
-        bool nan = false;
         if constexpr (NREG > 0) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
                 int64_t j = (int64_t)r * 64 + lane;
-                K k = MK::MAXK;
-                if (j < cnt) {
-                    k = MK::load(amount, start + j);
-                    nan |= MK::is_nan(k);
-                }
-                key[r] = k;
+                key[r] = j < cnt ? MK::load(amount, start + j) : MK::MAXK;
             }
-        } else {
-            for (int64_t j = lane; j < cnt; j += 64) nan |= MK::is_nan(MK::load(amount, start + j));
         }
-        return nan;
     }
+    __device__ __forceinline__ bool maybe_invalid(int r) const { return !EXACT || r == NREG - 1; }
     __device__ __forceinline__ void minmax(K &mn, K &mx)
     {
         K a = MK::MAXK, b = 0;
         if constexpr (NREG > 0) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
-                bool valid = (int64_t)r * 64 + lane < cnt;
-                a = key[r] < a ? key[r] : a;
-                b = (valid && key[r] > b) ? key[r] : b;
+                const K k = key[r];
+                a = k < a ? k : a;
+                if (maybe_invalid(r)) b = (k != MK::MAXK && k > b) ? k : b;
+                else b = k > b ? k : b;
             }
         } else {
             for (int64_t j = lane; j < cnt; j += 64) {
@@ -146,10 +138,9 @@ struct MedBar {
         if constexpr (NREG > 0) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
-                bool valid = (int64_t)r * 64 + lane < cnt;
-                K k = key[r];
+                const K k = key[r];
                 a = (k <= pivot && k > a) ? k : a;
-                b = (valid && k > pivot && k < b) ? k : b;
+                b = (k > pivot && k < b) ? k : b;      // a sentinel can only "win" when no real key is > pivot
             }
         } else {
             for (int64_t j = lane; j < cnt; j += 64) {
@@ -189,10 +180,10 @@ struct MedBar {
     }
 };
 
-// The search itself; bar.key[] (register path) must already hold the keys (sentinel MAXK in unused
-// slots) and the bar must be NaN-free.
-template <bool AF64, int NREG>
-__device__ __forceinline__ double med_search(MedBar<AF64, NREG> &bar, typename MedKey<AF64>::K *buf)
+// The search itself; bar.key[] (register path) must already hold the keys.  Returns np.median of the
+// bar's amounts (NaN if any amount is NaN, like NumPy).
+template <bool AF64, int NREG, bool EXACT>
+__device__ __forceinline__ double med_search(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf)
 {
     typedef MedKey<AF64> MK;
     typedef typename MK::K K;
@@ -201,8 +192,9 @@ __device__ __forceinline__ double med_search(MedBar<AF64, NREG> &bar, typename M
     const int64_t k1 = (cnt - 1) >> 1, k2 = cnt >> 1;   // the two middle ranks (equal when cnt is odd)
     K mn, mx;
     bar.minmax(mn, mx);
+    if (mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF) return NAN;     // a NaN amount: np.median propagates it
     // invariant: count(key <= lo) = clo <= k1  and  count(key <= hi) = chi > k2
-    K lo = mn - 1, hi = mx;     // mn >= 1 for every non-NaN float key
+    K lo = mn - 1, hi = mx;
     int64_t clo = 0, chi = cnt;
     K v1, v2;
     for (;;) {
@@ -236,9 +228,8 @@ template <bool AF64, int NREG>
 __device__ __forceinline__ double med_select(const void *amount, int64_t start, int64_t cnt, int lane,
                                              typename MedKey<AF64>::K *buf)
 {
-    MedBar<AF64, NREG> bar;
+    MedBar<AF64, NREG, false> bar;
     bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
-    bool nan = bar.load_all();
-    if (__ballot(nan) != 0) return NAN;    // np.median propagates NaN
-    return med_search<AF64, NREG>(bar, buf);
+    bar.load_all();
+    return med_search<AF64, NREG, false>(bar, buf);
 }

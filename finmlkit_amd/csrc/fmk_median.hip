@@ -22,8 +22,9 @@
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amount,
                                                     const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt,
-                                                    double *__restrict__ o_median)
+                                                    const int *__restrict__ go, double *__restrict__ o_median)
 {
+    if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
     const int lane = fmk_lane();
@@ -57,16 +58,16 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, double *d_median)
+                      int64_t min_cnt, const int *d_go, double *d_median)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (amount_is_f64)
-        k_bar_median<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_median);
+        k_bar_median<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
     else
-        k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_median);
+        k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -78,5 +79,5 @@ extern "C" int fmk_comp_bar_median_dev(fmk_ctx *ctx, const void *d_amount, int a
     if (n_idx < 2)
         return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    return fmk_median_launch(ctx, d_amount, amount_is_f64, d_close_idx, n_idx - 1, 0, d_median);
+    return fmk_median_launch(ctx, d_amount, amount_is_f64, d_close_idx, n_idx - 1, 0, nullptr, d_median);
 }

@@ -30,7 +30,7 @@
 #define FMK_SMALL_NCH 22
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, double *d_median);
+                      int64_t min_cnt, const int *d_go, double *d_median);
 
 struct OhlcvOut {
     double *open, *high, *low, *close;
@@ -71,8 +71,9 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ price,
                                                    const void *__restrict__ amount,
                                                    const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                   int64_t min_cnt, OhlcvOut o)
+                                                   int64_t min_cnt, const int *__restrict__ go, OhlcvOut o)
 {
+    if (go && *go == 0) return;                              // the small-bar kernel saw no long bar
     const int lane = fmk_lane();
     const int wpb = blockDim.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + fmk_uniform((int)(threadIdx.x >> 6));
@@ -110,71 +111,98 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
     }
 }
 
-template <bool AF64, int NCH, bool MEDIAN>
-__global__ __launch_bounds__(256) void k_bar_ohlcv_small(const double *__restrict__ price,
-                                                         const void *__restrict__ amount,
-                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                         OhlcvOut o)
+// One bar of <= 64*NCH ticks.  EXACT: the bar has exactly NCH chunks, so chunks 0..NCH-2 are full and
+// need neither index clamping nor predication.
+template <bool AF64, int NCH, bool EXACT, bool MEDIAN>
+__device__ __forceinline__ void small_bar(const double *__restrict__ price, const void *__restrict__ amount,
+                                          int64_t b, int64_t start, int64_t e, int64_t cnt, int lane,
+                                          typename MedKey<AF64>::K *buf, const OhlcvOut &o)
 {
     typedef MedKey<AF64> MK;
     typedef typename MK::K K;     // raw bit pattern type of one amount
+    // ---- issue every load of the bar: branch-free; offsets of possibly-partial chunks are clamped to the
+    //      bar's last tick (re-reads one element of a line that is fetched anyway: no extra HBM traffic)
+    const double *pb = price + start;                    // wave-uniform bases + 32-bit lane offsets
+    const K *ab = (const K *)amount + start;
+    const unsigned last = (unsigned)(cnt - 1);
+    double p[NCH];
+    K araw[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        unsigned idx = (unsigned)(c * 64 + lane);
+        if (!EXACT || c == NCH - 1) idx = idx < last ? idx : last;
+        p[c] = pb[idx];
+        araw[c] = ab[idx];
+    }
+    // ---- OHLCV accumulation, same per-lane order as k_bar_ohlcv
+    double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+    MedBar<AF64, NCH, EXACT> bar;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        double a;
+        if constexpr (AF64) a = __longlong_as_double((long long)araw[c]);
+        else a = (double)__uint_as_float(araw[c]);
+        hi = fmax(hi, p[c]);                             // clamped duplicates cannot change max/min
+        lo = fmin(lo, p[c]);
+        const double pa = p[c] * a;
+        if (!EXACT || c == NCH - 1) {
+            const bool valid = (unsigned)(c * 64 + lane) <= last;
+            tv += valid ? a : 0.0;
+            td += valid ? pa : 0.0;
+            if constexpr (MEDIAN) bar.key[c] = valid ? MK::tokey(araw[c]) : MK::MAXK;
+        } else {
+            tv += a;
+            td += pa;
+            if constexpr (MEDIAN) bar.key[c] = MK::tokey(araw[c]);
+        }
+    }
+    ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
+    if constexpr (MEDIAN) {
+        bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+        const double m = med_search<AF64, NCH, EXACT>(bar, buf);
+        if (lane == 0) o.median[b] = m;
+    }
+}
+
+template <bool AF64, bool MEDIAN>
+__global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__restrict__ price,
+                                                            const void *__restrict__ amount,
+                                                            const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                            int *__restrict__ saw_long, OhlcvOut o)
+{
+    typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    K *buf = sbuf[wib];
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t cnt = e - s;
-        if (cnt > 64 * NCH) continue;                        // long bar: generic kernels
+        if (cnt > 64 * FMK_SMALL_NCH) {                      // long bar: left to the generic kernels
+            if (lane == 0) atomicOr(saw_long, 1);
+            continue;
+        }
         if (cnt <= 0) {
             if (lane == 0) ohlcv_empty(o, b, price, e, n);
             continue;
         }
         const int64_t start = s + 1;
-        // ---- issue every load of the bar: branch-free, offsets clamped to the bar's last tick (chunks
-        //      past the end re-read that one element: same cache line, no extra HBM traffic)
-        const double *pb = price + start;                    // wave-uniform bases + 32-bit lane offsets
-        const K *ab = (const K *)amount + start;
-        const unsigned last = (unsigned)(cnt - 1);
-        double p[NCH];
-        K araw[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            unsigned idx = (unsigned)(c * 64 + lane);
-            idx = idx < last ? idx : last;
-            p[c] = pb[idx];
-            araw[c] = ab[idx];
-        }
-        // ---- OHLCV accumulation, same per-lane order as k_bar_ohlcv
-        double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
-        MedBar<AF64, NCH> bar;
-        bool nan = false;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const bool valid = (unsigned)(c * 64 + lane) <= last;
-            double a;
-            if constexpr (AF64) a = __longlong_as_double((long long)araw[c]);
-            else a = (double)__uint_as_float(araw[c]);
-            hi = fmax(hi, p[c]);                             // clamped duplicates cannot change max/min
-            lo = fmin(lo, p[c]);
-            const double pa = p[c] * a;
-            tv += valid ? a : 0.0;
-            td += valid ? pa : 0.0;
-            if constexpr (MEDIAN) {
-                const K key = valid ? MK::tokey(araw[c]) : MK::MAXK;
-                nan |= valid && MK::is_nan(key);
-                bar.key[c] = key;
-            }
-        }
-        ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
-        if constexpr (MEDIAN) {
-            bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
-            double m = NAN;                                   // np.median propagates NaN
-            if (__ballot(nan) == 0) m = med_search<AF64, NCH>(bar, sbuf[wib]);
-            if (lane == 0) o.median[b] = m;
+        const int nch = (int)((cnt + 63) >> 6);
+        // exact-size code for the chunk counts a ~1200-tick (1-minute) bar takes, size classes below
+        switch (nch) {
+        case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 21: small_bar<AF64, 21, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        default:
+            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else small_bar<AF64, FMK_SMALL_NCH, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
         }
     }
 }
@@ -196,20 +224,25 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     const int slot = ctx->profile_on ? (ctx->profile_n++ & 63) : -1;     // time the dominant launch only
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][0], ctx->stream));
     if (variant == 0) {   // generic streaming kernel only (+ stand-alone median)
-        k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, o);
+        k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);
         FMK_LAUNCH_CHECK(ctx);
         if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
-        if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, o.median);
+        if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, nullptr, o.median);
         return FMK_OK;
     }
     // small bars: all loads up front (+ fused median); long bars: generic kernels on the rest
-    if (o.median) k_bar_ohlcv_small<AF64, FMK_SMALL_NCH, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, o);
-    else k_bar_ohlcv_small<AF64, FMK_SMALL_NCH, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, o);
+    // launch bounds measured on MI355X: forcing >4 waves/SIMD on the fused-median kernel makes the compiler
+    // serialise the up-front loads (2.7 ms -> 3.5..4.3 ms at N = 1e9); 4 waves/SIMD (102 VGPRs) is the optimum.
+    int *saw_long = (int *)(ctx->d_mail + 16);               // set by the small kernel iff a long bar exists
+    FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+    if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+    else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
-    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 64 * FMK_SMALL_NCH, o);
+    // long bars (if any): the generic kernels exit at once when the flag is clear
+    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 64 * FMK_SMALL_NCH, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
-    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 64 * FMK_SMALL_NCH, o.median);
+    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 64 * FMK_SMALL_NCH, saw_long, o.median);
     return FMK_OK;
 }
 

@@ -75,9 +75,13 @@ class DeviceTrades:
 
     # ------------------------------------------------------------------ indexers
     def first_last_ts(self) -> Tuple[int, int]:
-        a = self.ts.view(0, 1).to_host()[0]
-        b = self.ts.view(self.n - 1, 1).to_host()[0]
-        return int(a), int(b)
+        """timestamps[0], timestamps[-1] (what the reference reads from its host array, logic.py:33-36);
+        fetched from the device once per trade set and cached -- the columns are immutable."""
+        if getattr(self, "_first_last", None) is None:
+            a = self.ts.view(0, 1).to_host()[0]
+            b = self.ts.view(self.n - 1, 1).to_host()[0]
+            self._first_last = (int(a), int(b))
+        return self._first_last
 
     def time_bar_index(self, interval_seconds: float, clock_params=None,
                        out: Optional[Tuple[DeviceArray, DeviceArray]] = None) -> Tuple[DeviceArray, DeviceArray]:
