@@ -9,13 +9,14 @@
 //     previous chunk's lane 63 (first chunk: tick start-1 with the reference's Python negative-
 //     index wrap, base.py:485-500).
 //   * min/max of the running signed tick/volume/dollar imbalance: 6-step inclusive wave scan of
-//     the signed contributions per chunk + wave-uniform carry; every lane tracks min/max of its
+//     the signed contributions per chunk on the DPP path (fmk_dpp.h, no LDS round trips) + wave-uniform carry; every lane tracks min/max of its
 //     own prefix values, folded at the end of the bar.
 // The float64 prefix values are tree-summed (not the reference's sequential order): the float32
 // outputs are identical except for a ~1e-8 chance of a 1-ulp flip (see tests/_golden.py).
 #include <math.h>
 
 #include "fmk_common.h"
+#include "fmk_dpp.h"
 
 struct DirOut {
     int64_t *ticks_buy, *ticks_sell;
@@ -55,22 +56,26 @@ __global__ __launch_bounds__(256) void k_bar_directional(const double *__restric
             prev_price = price[fmk_wrap(start - 1, n)];
             prev_side = cnt > 1 ? (int)side[fmk_wrap(start - 1, n)] : 0;    // base.py:485-488
         }
+        // software pipeline: the loads of chunk c+1 are in flight while chunk c is processed
+        double p_n = 0, a_n = 0;
+        int sd_n = 0;
+        if (start + lane <= e) { p_n = price[start + lane]; a_n = fmk_amt<AF64>(amount, start + lane); sd_n = side[start + lane]; }
         for (int64_t j0 = start; j0 <= e; j0 += 64) {
             const int64_t j = j0 + lane;
             const bool valid = j <= e;
-            double p = 0, a = 0;
-            int sd = 0;
-            if (valid) { p = price[j]; a = fmk_amt<AF64>(amount, j); sd = side[j]; }
-            double pp = __shfl_up(p, 1, 64);
-            int ps = __shfl_up(sd, 1, 64);
-            if (lane == 0) { pp = prev_price; ps = prev_side; }
+            const double p = p_n, a = a_n;
+            const int sd = sd_n;
+            p_n = 0; a_n = 0; sd_n = 0;
+            if (j + 64 <= e) { p_n = price[j + 64]; a_n = fmk_amt<AF64>(amount, j + 64); sd_n = side[j + 64]; }
+            const double pp = fmk_dpp_shift_up1(p, prev_price);      // lane 0: last tick of the previous chunk
+            const int ps = fmk_dpp_shift_up1(sd, prev_side);
             if (valid && sd != ps) {                           // base.py:495-500
                 double sp = fabs(p - pp);
                 mxs = fmax(mxs, sp);
                 cs += sp;
             }
-            prev_price = __shfl(p, 63, 64);
-            prev_side = __shfl(sd, 63, 64);
+            prev_price = fmk_last_lane(p);
+            prev_side = fmk_last_lane(sd);
             const bool buy = valid && sd == 1, sell = valid && sd == -1;
             const double pv = p * a;
             if (buy) { vb += a; db += pv; }
@@ -80,9 +85,9 @@ __global__ __launch_bounds__(256) void k_bar_directional(const double *__restric
             const int t = (int)buy - (int)sell;
             const double sv = buy ? a : (sell ? -a : 0.0);
             const double sdol = buy ? pv : (sell ? -pv : 0.0);
-            const int it = fmk_wave_iscan(t);
-            const double iv = fmk_wave_iscan(sv);
-            const double id = fmk_wave_iscan(sdol);
+            const int it = fmk_dpp_iscan(t, 0, FmkOpAdd());
+            const double iv = fmk_dpp_iscan(sv, 0.0, FmkOpAdd());
+            const double id = fmk_dpp_iscan(sdol, 0.0, FmkOpAdd());
             if (t != 0) {                                       // base.py:518-527: signed ticks only
                 const int64_t ct = carry_t + it;
                 const double cv = carry_v + iv, cd = carry_d + id;
@@ -90,16 +95,17 @@ __global__ __launch_bounds__(256) void k_bar_directional(const double *__restric
                 vmin = fmin(vmin, cv); vmax = fmax(vmax, cv);
                 dmin = fmin(dmin, cd); dmax = fmax(dmax, cd);
             }
-            carry_t += __shfl(it, 63, 64);
-            carry_v += __shfl(iv, 63, 64);
-            carry_d += __shfl(id, 63, 64);
+            carry_t += fmk_last_lane(it);
+            carry_v += fmk_last_lane(iv);
+            carry_d += fmk_last_lane(id);
         }
-        vb = fmk_wave_sum(vb); vs = fmk_wave_sum(vs);
-        db = fmk_wave_sum(db); ds = fmk_wave_sum(ds);
-        cs = fmk_wave_sum(cs); mxs = fmk_wave_max(mxs);
-        tmin = fmk_wave_min(tmin); tmax = fmk_wave_max(tmax);
-        vmin = fmk_wave_min(vmin); vmax = fmk_wave_max(vmax);
-        dmin = fmk_wave_min(dmin); dmax = fmk_wave_max(dmax);
+        vb = fmk_dpp_reduce(vb, 0.0, FmkOpAdd()); vs = fmk_dpp_reduce(vs, 0.0, FmkOpAdd());
+        db = fmk_dpp_reduce(db, 0.0, FmkOpAdd()); ds = fmk_dpp_reduce(ds, 0.0, FmkOpAdd());
+        cs = fmk_dpp_reduce(cs, 0.0, FmkOpAdd()); mxs = fmk_dpp_reduce(mxs, 0.0, FmkOpMax());
+        tmin = fmk_dpp_reduce(tmin, (int64_t)1000000000LL, FmkOpMin());
+        tmax = fmk_dpp_reduce(tmax, (int64_t)-1000000000LL, FmkOpMax());
+        vmin = fmk_dpp_reduce(vmin, 1e9, FmkOpMin()); vmax = fmk_dpp_reduce(vmax, -1e9, FmkOpMax());
+        dmin = fmk_dpp_reduce(dmin, 1e9, FmkOpMin()); dmax = fmk_dpp_reduce(dmax, -1e9, FmkOpMax());
         if (lane == 0) {
             o.ticks_buy[b] = tb; o.ticks_sell[b] = tsell;
             o.volume_buy[b] = (float)vb; o.volume_sell[b] = (float)vs;

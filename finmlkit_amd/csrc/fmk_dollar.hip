@@ -1,0 +1,361 @@
+// fmk_dollar.hip -- _dollar_bar_indexer (finmlkit/bar/logic.py:118-149), parallel closed form.
+//
+// Reference recurrence (sequential):   cum += p_i*v_i ; if cum >= thr: close at i, cum -= thr.
+// With D_i = sum_{k<=i} d_k (d_k = fl(p_k*v_k), the same rounded product the reference adds),
+// M_i = floor(D_i / thr) and K_i = number of closes among ticks 1..i, the recurrence is
+//     K_0 = 0,  K_i = min(K_{i-1} + 1, M_i)        (at most one close per tick, tick 0 never closes)
+// whose solution is  K_i = i + min_{0<=j<=i} G_j  with G_0 = 0, G_j = M_j - j :  a prefix-MIN scan.
+// Tick i closes iff G_i >= min_{j<i} G_j, and K_i is directly its slot in the output array -- no
+// stream compaction pass.  Everything is a scan:
+//   k_dl_tile_sums   tile sums of d in double-double (two-sum, ~2^-104 relative: "exact")
+//   k_dl_scan_dd     exclusive scan of the tile sums (one block)
+//   k_dl_tile_min    per tile: D_i -> M_i -> G_i, tile minimum
+//   k_dl_scan_min    exclusive prefix-min of the tile minima (one block)
+//   k_dl_emit        per tile: recompute G_i, running min, write out[K_i] = i
+// Traffic: price 8 + amount 4 B/tick, three times (sum, min, emit) + 8 B per close.
+//
+// Exact arithmetic vs the reference's float64 running sum: the reference's `cum` carries its own
+// rounding drift (<= (i+1)*2^-52*thr after i adds, the carry never resets it).  A decision is
+// reported in n_uncertified when the exact cum lies within that bound (or 1e-11*thr) of the threshold;
+// 0 means the close indices are provably the reference's.
+#include <math.h>
+#include <stdlib.h>
+
+#include "fmk_common.h"
+
+struct DD { double hi, lo; };
+
+__device__ __forceinline__ DD dd_make(double a) { return DD{a, 0.0}; }
+__device__ __forceinline__ DD dd_fast2(double s, double e) { double h = s + e; return DD{h, e - (h - s)}; }
+__device__ __forceinline__ DD dd_add(DD x, double y)
+{
+    double s = x.hi + y, bb = s - x.hi;
+    double e = (x.hi - (s - bb)) + (y - bb);
+    e += x.lo;
+    return dd_fast2(s, e);
+}
+__device__ __forceinline__ DD dd_add(DD x, DD y)
+{
+    double s = x.hi + y.hi, bb = s - x.hi;
+    double e = (x.hi - (s - bb)) + (y.hi - bb);
+    double t = x.lo + y.lo, tb = t - x.lo;
+    double f = (x.lo - (t - tb)) + (y.lo - tb);
+    e += t;
+    DD r = dd_fast2(s, e);
+    r.lo += f;
+    return dd_fast2(r.hi, r.lo);
+}
+__device__ __forceinline__ DD dd_shfl_up(DD v, int d) { return DD{__shfl_up(v.hi, d, 64), __shfl_up(v.lo, d, 64)}; }
+
+// floor(D / thr) for D >= 0 in double-double; *frag receives the distance of D/thr to the nearest
+// integer boundary in units of thr (for the certification count)
+__device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_dist)
+{
+    double q = floor(D.hi / thr);
+    double p = q * thr, e = fma(q, thr, -p);          // q*thr = p + e exactly
+    double r = (D.hi - p) + (D.lo - e);
+    while (r < 0.0) { q -= 1.0; r += thr; }
+    while (r >= thr) { q += 1.0; r -= thr; }
+    *frac_dist = fmin(r, thr - r) / thr;
+    return (int64_t)q;
+}
+
+#define DL_THREADS 256
+#define DL_ITEMS 8
+#define DL_TILE (DL_THREADS * DL_ITEMS)
+
+template <bool AF64>
+__device__ __forceinline__ double dl_d(const double *price, const void *amount, int64_t i)
+{
+    return price[i] * fmk_amt<AF64>(amount, i);       // rounded once, like prices[i] * volumes[i]
+}
+
+// block-wide inclusive scan of DD thread totals; returns this thread's EXCLUSIVE prefix and the block total
+__device__ __forceinline__ DD dl_block_exclusive(DD mine, DD *lds /*[4]*/, DD *total)
+{
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    DD inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        DD o = dd_shfl_up(inc, d);
+        if (lane >= d) inc = dd_add(o, inc);
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    DD pre = dd_make(0.0);
+    for (int k = 0; k < w; ++k) pre = dd_add(pre, lds[k]);
+    DD tot = lds[0];
+    for (int k = 1; k < 4; ++k) tot = dd_add(tot, lds[k]);
+    *total = tot;
+    DD prev = dd_shfl_up(inc, 1);
+    if (lane == 0) prev = dd_make(0.0);
+    __syncthreads();
+    return dd_add(pre, prev);
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__restrict__ price,
+                                                             const void *__restrict__ amount, int64_t n,
+                                                             DD *__restrict__ tile_sum, int *__restrict__ bad)
+{
+    __shared__ DD lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+    DD s = dd_make(0.0);
+    bool neg = false;
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k)
+        if (i0 + k < n) {
+            const double d = dl_d<AF64>(price, amount, i0 + k);
+            neg |= !(d >= 0.0);                      // negative or NaN increment: outside the closed form
+            s = dd_add(s, d);
+        }
+    if (__ballot(neg) != 0 && fmk_lane() == 0) atomicOr(bad, 1);
+    DD tot;
+    (void)dl_block_exclusive(s, lds, &tot);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+// exclusive scan in place (one block)
+__global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t, int64_t m)
+{
+    __shared__ DD lds[4];
+    __shared__ DD run_s;
+    if (threadIdx.x == 0) run_s = dd_make(0.0);
+    __syncthreads();
+    for (int64_t b = 0; b < m; b += DL_THREADS) {
+        const int64_t i = b + threadIdx.x;
+        DD v = i < m ? t[i] : dd_make(0.0);
+        DD tot;
+        DD ex = dl_block_exclusive(v, lds, &tot);
+        DD run = run_s;
+        if (i < m) t[i] = dd_add(run, ex);
+        __syncthreads();
+        if (threadIdx.x == 0) run_s = dd_add(run, tot);
+        __syncthreads();
+    }
+}
+
+// G_i for the 8 ticks of this thread (G_0 = 0); returns the number of fragile ticks
+template <bool AF64>
+__device__ __forceinline__ int dl_thread_G(const double *price, const void *amount, int64_t n, double thr,
+                                           const DD *tile_base, DD *lds, int64_t (&G)[DL_ITEMS])
+{
+    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+    double d[DL_ITEMS];
+    DD s = dd_make(0.0);
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k) {
+        d[k] = i0 + k < n ? dl_d<AF64>(price, amount, i0 + k) : 0.0;
+        s = dd_add(s, d[k]);
+    }
+    DD tot;
+    DD ex = dl_block_exclusive(s, lds, &tot);
+    DD D = dd_add(tile_base[blockIdx.x], ex);
+    int frag = 0;
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        D = dd_add(D, d[k]);
+        G[k] = INT64_MAX;                 // neutral for min beyond the end
+        if (i < n) {
+            double fd;
+            const int64_t M = dd_floor_div(D, thr, &fd);
+            G[k] = i == 0 ? 0 : M - i;
+            const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16);
+            frag += (i > 0 && fd <= tol);
+        }
+    }
+    return frag;
+}
+
+__device__ __forceinline__ int64_t dl_block_min(int64_t v, int64_t *lds4)
+{
+    v = fmk_wave_min(v);
+    if (fmk_lane() == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int64_t r = lds4[0];
+    for (int k = 1; k < 4; ++k) r = lds4[k] < r ? lds4[k] : r;
+    __syncthreads();
+    return r;
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_tile_min(const double *__restrict__ price,
+                                                            const void *__restrict__ amount, int64_t n, double thr,
+                                                            const DD *__restrict__ tile_base,
+                                                            int64_t *__restrict__ tile_min)
+{
+    __shared__ DD lds[4];
+    __shared__ int64_t lmin[4];
+    int64_t G[DL_ITEMS];
+    (void)dl_thread_G<AF64>(price, amount, n, thr, tile_base, lds, G);
+    int64_t m = G[0];
+#pragma unroll
+    for (int k = 1; k < DL_ITEMS; ++k) m = G[k] < m ? G[k] : m;
+    m = dl_block_min(m, lmin);
+    if (threadIdx.x == 0) tile_min[blockIdx.x] = m;
+}
+
+// exclusive prefix-min in place (one block); result[0] = overall minimum
+__global__ __launch_bounds__(1024) void k_dl_scan_min(int64_t *__restrict__ t, int64_t m, int64_t *result)
+{
+    __shared__ int64_t ws[16];
+    __shared__ int64_t run;
+    if (threadIdx.x == 0) run = INT64_MAX;
+    __syncthreads();
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    for (int64_t b = 0; b < m; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        int64_t v = i < m ? t[i] : INT64_MAX;
+        int64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int64_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc = o < inc ? o : inc;
+        }
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        int64_t pre = run;
+        for (int k = 0; k < w; ++k) pre = ws[k] < pre ? ws[k] : pre;
+        int64_t prev = __shfl_up(inc, 1, 64);
+        if (lane == 0) prev = INT64_MAX;
+        const int64_t ex = prev < pre ? prev : pre;
+        if (i < m) t[i] = ex;
+        __syncthreads();
+        if (threadIdx.x == 1023) run = inc < pre ? inc : pre;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) result[0] = run;
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict__ price,
+                                                        const void *__restrict__ amount, int64_t n, double thr,
+                                                        const DD *__restrict__ tile_base,
+                                                        const int64_t *__restrict__ tile_premin,
+                                                        int64_t *__restrict__ out, int64_t cap,
+                                                        unsigned long long *n_frag)
+{
+    __shared__ DD lds[4];
+    __shared__ int64_t wmin[4];
+    int64_t G[DL_ITEMS];
+    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, lds, G);
+    // exclusive prefix-min over the block in tick order: thread-local then across threads
+    int64_t tmin = G[0];
+#pragma unroll
+    for (int k = 1; k < DL_ITEMS; ++k) tmin = G[k] < tmin ? G[k] : tmin;
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    int64_t inc = tmin;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = o < inc ? o : inc;
+    }
+    if (lane == 63) wmin[w] = inc;
+    __syncthreads();
+    int64_t pre = tile_premin[blockIdx.x];           // min of all G before this tile (INT64_MAX for tile 0)
+    for (int k = 0; k < w; ++k) pre = wmin[k] < pre ? wmin[k] : pre;
+    int64_t prev = __shfl_up(inc, 1, 64);
+    if (lane == 0) prev = INT64_MAX;
+    int64_t mex = prev < pre ? prev : pre;           // min_{j < first tick of this thread} G_j
+    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        if (i < n) {
+            if (i >= 1 && G[k] >= mex) {             // close: K_i = i + mex is its slot
+                const int64_t slot = i + mex;
+                if (slot < cap) out[slot] = i;
+            }
+            mex = G[k] < mex ? G[k] : mex;
+        }
+    }
+    if (i0 == 0 && cap > 0) out[0] = 0;              // logic.py:138
+    int f = (int)fmk_wave_sum(frag);
+    if (lane == 0 && f) atomicAdd(n_frag, (unsigned long long)f);
+}
+
+struct DlCache {
+    fmk_ctx *ctx;
+    const void *amount;
+    const double *price;
+    int64_t n;
+    double thr;
+    int is_f64;
+    int64_t count, unc;
+    int64_t *dbuf;
+    int64_t cap;
+};
+static DlCache g_dl = {nullptr, nullptr, nullptr, 0, 0.0, 0, 0, 0, nullptr, 0};
+
+template <bool AF64>
+static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, double thr, DlCache &c)
+{
+    const int64_t tiles = fmk_ceil_div(n, DL_TILE);
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, (size_t)tiles * (sizeof(DD) + 8) + 64, &scr));
+    DD *tsum = (DD *)scr;
+    int64_t *tmin = (int64_t *)(tsum + tiles);
+    int64_t *d_res = ctx->d_mail + 24;
+    int *d_bad = (int *)(ctx->d_mail + 26);
+    FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad);
+    FMK_LAUNCH_CHECK(ctx);
+    k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(tsum, tiles);
+    FMK_LAUNCH_CHECK(ctx);
+    k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, tmin);
+    FMK_LAUNCH_CHECK(ctx);
+    k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(tmin, tiles, d_res);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((int)ctx->h_mail[1] != 0) return 1;          // negative / NaN increments: caller falls back to the serial walk
+    const int64_t gmin = ctx->h_mail[0] < 0 ? ctx->h_mail[0] : 0;     // G_0 = 0 is part of every prefix
+    c.count = (n - 1) + gmin + 1;                                       // K_{n-1} closes + the leading 0
+    if (c.dbuf && c.cap < c.count) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
+    if (!c.dbuf) { FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.count * 8)); c.cap = c.count; }
+    unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 25);
+    FMK_HIP(ctx, hipMemsetAsync(d_frag, 0, 8, ctx->stream));
+    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, tmin, c.dbuf, c.cap, d_frag);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c.unc = ctx->h_mail[0];
+    return FMK_OK;
+}
+
+int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
+                         double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
+
+extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                          int amount_is_f64, int64_t n, double threshold, int64_t *d_close_idx,
+                                          int64_t capacity, int64_t *n_idx, int64_t *n_uncertified)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
+    // the closed form needs thr > 0 and non-negative increments; anything else takes the serial walk
+    if (!(threshold > 0.0) || getenv("FMK_THRESHOLD_SERIAL"))
+        return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
+                                    n_idx, n_uncertified);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    DlCache &c = g_dl;
+    const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
+                     c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
+    if (!hit) {
+        int rc = amount_is_f64 ? dl_run<true>(ctx, d_price, d_amount, n, threshold, c)
+                               : dl_run<false>(ctx, d_price, d_amount, n, threshold, c);
+        if (rc == 1)
+            return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
+                                        n_idx, n_uncertified);
+        if (rc) return rc;
+        c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
+    }
+    *n_idx = c.count;
+    if (n_uncertified) *n_uncertified = c.unc;
+    if (!d_close_idx) return FMK_OK;
+    if (capacity < c.count) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: capacity %lld < %lld",
+                                                 (long long)capacity, (long long)c.count);
+    FMK_HIP(ctx, hipMemcpyAsync(d_close_idx, c.dbuf, (size_t)c.count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    c.ctx = nullptr;     // one-shot cache: the inputs may change behind the same pointers
+    return FMK_OK;
+}

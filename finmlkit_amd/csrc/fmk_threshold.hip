@@ -186,18 +186,13 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
     return FMK_OK;
 }
 
-extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
-                                          double threshold, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx,
-                                          int64_t *n_uncertified)
+// Serial walk, shared entry for both bar types (also the fallback of the parallel algorithms for
+// inputs outside their domain: thr <= 0, negative increments, bars longer than the jump tables).
+int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
+                         double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc)
 {
-    return th_run<false>(ctx, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
-                         n_uncertified);
+    return dollar ? th_run<true>(ctx, d_price, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc)
+                  : th_run<false>(ctx, nullptr, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc);
 }
 
-extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
-                                          int amount_is_f64, int64_t n, double threshold, int64_t *d_close_idx,
-                                          int64_t capacity, int64_t *n_idx, int64_t *n_uncertified)
-{
-    return th_run<true>(ctx, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
-                        n_uncertified);
-}
+// (the extern "C" entry points live in fmk_volume.hip / fmk_dollar.hip)

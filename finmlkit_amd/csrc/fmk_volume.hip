@@ -1,0 +1,372 @@
+// fmk_volume.hip -- _volume_bar_indexer (finmlkit/bar/logic.py:87-115), parallel jump tables.
+//
+// Reference recurrence (sequential):   cum += v_i ; if cum >= thr: close at i, cum = 0   (RESET).
+// Because of the reset, the state after a close is only the POSITION of that close: the bar that starts
+// after a close at tick j ends at nxt(j) = min{ j' > j : sum(v[j+1..j']) >= thr }, and the closes are
+// the orbit c_1, nxt(c_1), nxt(nxt(c_1)), ...  -- a pointer chain of B links.  Chains started from
+// different ticks do not merge, so the chain cannot be guessed; it CAN be composed hierarchically:
+//
+//   level 0  (k_vol_level0, one workgroup per block of S ticks, S >= longest bar):
+//            prefix sums of the block + S ticks of look-ahead in LDS; nxt(j) for EVERY tick j of the
+//            block by bisection in LDS; pointer doubling in LDS turns nxt into
+//            E0[j] = first chain node >= end of the block, C0[j] = chain nodes inside the block.
+//   level k  (k_vol_level_up): a block of S*2^k ticks is two blocks of level k-1.  The chain enters any
+//            block within its first S ticks (S >= longest bar), so a table over those S entry ticks is
+//            enough:  E^k[i] = E^{k-1}_right[ E^{k-1}_left[i] ],  C^k = C_left + C_right.   O(N/2^k) work.
+//   top-down (k_vol_descend): the root block's entry is the first close c_1; every block hands its entry
+//            to the left child and E_left[entry] (+ the close count so far) to the right child.
+//   emit     (k_vol_emit): every level-0 block walks its <= S/bar-length chain nodes and writes them to
+//            their final output slots.
+// Total work O(N) + 2*log2(N/S) tiny launches; no sequential pass over the stream.
+//
+// Arithmetic: bar sums are differences of block-local float64 prefix sums (not the reference's
+// sequential sum from the bar start); a candidate decision within 1e-11*thr of the threshold is counted
+// in n_uncertified (0 => provably the reference's indices; always 0 for exactly-summable amounts such as
+// the dyadic synthetic stream).  Domain: thr > 0, v >= 0, bars <= 2048 ticks, N < 2^31 -- anything else
+// falls back to the serial walk of fmk_threshold.hip.
+#include <math.h>
+#include <stdlib.h>
+
+#include "fmk_common.h"
+
+#define VOL_END 0xFFFFFFFFu
+#define VOL_THREADS 256
+
+int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
+                         double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
+
+// status word bits
+#define VOL_ST_OVERFLOW 1   // a bar is longer than S ticks
+#define VOL_ST_BAD 2        // negative / NaN volume
+
+template <bool AF64, int S>
+__global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restrict__ amount, int64_t n, double thr,
+                                                            uint32_t *__restrict__ nxt, uint32_t *__restrict__ E0,
+                                                            uint32_t *__restrict__ C0, uint32_t *__restrict__ root,
+                                                            int *__restrict__ status,
+                                                            unsigned long long *__restrict__ n_frag)
+{
+    constexpr int PER = 2 * S / VOL_THREADS;          // prefix elements per thread
+    constexpr int EPT = S / VOL_THREADS;              // table entries per thread
+    __shared__ double Lp[2 * S + 1];                  // Lp[i] = sum of the first i ticks from the block start
+    __shared__ uint32_t Eb[S], Cb[S];
+    __shared__ double wtot[4];
+    const int64_t bs = (int64_t)blockIdx.x * S;       // first tick of the block
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    // ---- block-local prefix sums over [bs, bs + 2S)
+    double loc[PER];
+    double run = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int64_t j = bs + (int64_t)tid * PER + k;
+        double v = 0.0;
+        if (j < n) { v = fmk_amt<AF64>(amount, j); bad |= !(v >= 0.0); }
+        run += v;
+        loc[k] = run;
+    }
+    double inc = fmk_wave_iscan(run);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    double pre = __shfl_up(inc, 1, 64);               // exclusive prefix of the thread totals
+    if (lane == 0) pre = 0.0;
+    {
+        double wp = 0.0;
+        for (int q = 0; q < w; ++q) wp += wtot[q];
+        pre = wp + pre;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) Lp[tid * PER + k + 1] = pre + loc[k];
+    if (tid == 0) Lp[0] = 0.0;
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);
+    __syncthreads();
+    // ---- nxt(j) for every tick of the block: smallest m > i+1 with Lp[m] - Lp[i+1] >= thr
+    const int64_t remain = n - bs;                                  // ticks available from the block start
+    const int mmax = (int)(remain < 2 * S ? remain : 2 * S);        // Lp[0..mmax] are valid
+    const double tol = 1e-11 * thr;
+    int frag = 0;
+    for (int q = 0; q < EPT; ++q) {
+        const int i = q * VOL_THREADS + tid;                        // tick bs + i
+        uint32_t nx = VOL_END, cc = 0;
+        if (i < remain) {
+            cc = 1;
+            const double target = Lp[i + 1] + thr;
+            int lo = i + 2, hi = i + 1 + S;                          // close tick = bs + m - 1 in (j, j + S]
+            if (hi > mmax) hi = mmax;
+            if (lo <= hi && Lp[hi] >= target) {
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (Lp[mid] >= target) hi = mid; else lo = mid + 1;
+                }
+                nx = (uint32_t)(bs + lo - 1);
+                // an exact hit (difference 0) is a certain decision, not a fragile one: it is what
+                // exactly-summable amounts produce, and a measure-zero coincidence otherwise
+                const double over = Lp[lo] - target, under = target - Lp[lo - 1];
+                frag += (over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol);
+            } else if (i + 1 + S <= mmax) {
+                atomicOr(status, VOL_ST_OVERFLOW);                   // no close within S ticks although data remains
+            } else if (hi >= lo) {
+                frag += target - Lp[hi] <= tol;
+            }
+        }
+        Eb[i] = nx;
+        Cb[i] = cc;
+        nxt[bs + i] = nx;
+    }
+    // first bar (block 0): tick 0 is counted but cannot close -> first j >= 1 with P_j >= thr
+    if (blockIdx.x == 0 && tid == 0) {
+        uint32_t r = VOL_END;
+        int lo = 2, hi = mmax < S ? mmax : S;           // keeps the root inside the first S ticks
+        if (lo <= hi && Lp[hi] >= thr) {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (Lp[mid] >= thr) hi = mid; else lo = mid + 1;
+            }
+            r = (uint32_t)(lo - 1);
+        } else if (S <= mmax) {
+            atomicOr(status, VOL_ST_OVERFLOW);
+        }
+        *root = r;
+    }
+    __syncthreads();
+    // ---- pointer doubling inside the block: E -> first node >= block end, C -> nodes inside the block
+    const uint32_t bend = (uint32_t)(bs + S);
+    for (;;) {
+        uint32_t e2[EPT], c2[EPT];
+        int changed = 0;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = q * VOL_THREADS + tid;
+            const uint32_t e = Eb[i];
+            e2[q] = e;
+            c2[q] = Cb[i];
+            if (e != VOL_END && e < bend) {
+                const int i2 = (int)(e - (uint32_t)bs);
+                e2[q] = Eb[i2];
+                c2[q] += Cb[i2];
+                changed = 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = q * VOL_THREADS + tid;
+            Eb[i] = e2[q];
+            Cb[i] = c2[q];
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = q * VOL_THREADS + tid;
+        E0[bs + i] = Eb[i];
+        C0[bs + i] = Cb[i];
+    }
+    frag = (int)fmk_wave_sum(frag);
+    if (lane == 0 && frag) atomicAdd(n_frag, (unsigned long long)frag);
+}
+
+// tables of level k from level k-1: one thread per (block, entry)
+template <int S>
+__global__ __launch_bounds__(256) void k_vol_level_up(const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
+                                                      int64_t nblk_prev, int64_t span_prev /* ticks per prev block */,
+                                                      uint32_t *__restrict__ Ek, uint32_t *__restrict__ Ck,
+                                                      int64_t nblk, int *__restrict__ status)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * S) return;
+    const int64_t b = t / S;
+    const int i = (int)(t % S);
+    const int64_t left = 2 * b, right = 2 * b + 1;
+    uint32_t x = Ep[left * S + i];
+    uint32_t c = Cp[left * S + i];
+    if (x != VOL_END && right < nblk_prev) {
+        const int64_t i2 = (int64_t)x - right * span_prev;
+        if (i2 < 0 || i2 >= S) { atomicOr(status, VOL_ST_OVERFLOW); x = VOL_END; }
+        else {
+            c += Cp[right * S + i2];
+            x = Ep[right * S + i2];
+        }
+    }
+    Ek[t] = x;
+    Ck[t] = c;
+}
+
+// entries / output offsets of level k-1 from level k
+template <int S>
+__global__ __launch_bounds__(256) void k_vol_descend(const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
+                                                     int64_t nblk_k, int64_t span_prev,
+                                                     const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
+                                                     int64_t nblk_prev, uint32_t *__restrict__ ent_p,
+                                                     int64_t *__restrict__ off_p)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk_k) return;
+    const uint32_t e = ent_k[b];
+    const int64_t o = off_k[b];
+    const int64_t left = 2 * b, right = 2 * b + 1;
+    ent_p[left] = e;
+    off_p[left] = o;
+    if (right < nblk_prev) {
+        uint32_t x = VOL_END;
+        int64_t oo = o;
+        if (e != VOL_END) {
+            const int64_t i = (int64_t)e - left * span_prev;       // entry lies in the left child's first S ticks
+            if (i >= 0 && i < S) {
+                x = Ep[left * S + i];
+                oo = o + Cp[left * S + i];
+            } else {
+                x = e;                                              // (cannot happen when S >= longest bar)
+            }
+        }
+        ent_p[right] = x;
+        off_p[right] = oo;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_vol_emit(const uint32_t *__restrict__ ent0, const int64_t *__restrict__ off0,
+                                                  int64_t nblk0, const uint32_t *__restrict__ nxt,
+                                                  int64_t *__restrict__ out, int64_t cap)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && cap > 0) out[0] = 0;                              // logic.py:104
+    if (b >= nblk0) return;
+    uint32_t j = ent0[b];
+    int64_t o = off0[b];
+    const uint64_t bend = (uint64_t)(b + 1) * S;
+    while (j != VOL_END && (uint64_t)j < bend) {
+        if (o < cap) out[o] = (int64_t)j;
+        ++o;
+        j = nxt[j];
+    }
+}
+
+struct VolCache {
+    fmk_ctx *ctx;
+    const void *amount;
+    int64_t n;
+    double thr;
+    int is_f64;
+    int64_t count, unc;
+    int64_t *dbuf;
+    int64_t cap;
+    void *work;
+    size_t work_bytes;
+};
+static VolCache g_vol = {nullptr, nullptr, 0, 0.0, 0, 0, 0, nullptr, 0, nullptr, 0};
+
+// returns FMK_OK, 1 (=> use the serial fallback) or an error
+template <bool AF64, int S>
+static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c)
+{
+    const int64_t nblk0 = fmk_ceil_div(n, S);
+    // levels: nblk[k] = ceil(nblk0 / 2^k) until 1
+    int64_t nblk[64];
+    int K = 0;
+    nblk[0] = nblk0;
+    while (nblk[K] > 1) { nblk[K + 1] = (nblk[K] + 1) / 2; ++K; }
+    // workspace layout (uint32 tables + per-level entry/offset arrays)
+    size_t tbl = 0;
+    for (int k = 0; k <= K; ++k) tbl += (size_t)nblk[k] * S;
+    size_t ents = 0;
+    for (int k = 0; k <= K; ++k) ents += (size_t)nblk[k];
+    const size_t bytes = ((size_t)nblk0 * S + 2 * tbl) * 4 + ents * (4 + 8) + 256;
+    if (c.work_bytes < bytes) {
+        if (c.work) FMK_HIP(ctx, hipFree(c.work));
+        c.work = nullptr; c.work_bytes = 0;
+        FMK_HIP(ctx, hipMalloc(&c.work, bytes));
+        c.work_bytes = bytes;
+    }
+    uint32_t *nxt = (uint32_t *)c.work;
+    uint32_t *Eall = nxt + (size_t)nblk0 * S;
+    uint32_t *Call = Eall + tbl;
+    int64_t *offall = (int64_t *)(Call + tbl);
+    uint32_t *entall = (uint32_t *)(offall + ents);
+    uint32_t *E[64], *C[64], *ent[64];
+    int64_t *off[64];
+    {
+        size_t to = 0, eo = 0;
+        for (int k = 0; k <= K; ++k) {
+            E[k] = Eall + to; C[k] = Call + to; to += (size_t)nblk[k] * S;
+            ent[k] = entall + eo; off[k] = offall + eo; eo += (size_t)nblk[k];
+        }
+    }
+    int *d_status = (int *)(ctx->d_mail + 32);
+    uint32_t *d_root = (uint32_t *)(ctx->d_mail + 33);
+    unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 34);
+    FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 24, ctx->stream));
+    k_vol_level0<AF64, S><<<(unsigned)nblk0, VOL_THREADS, 0, ctx->stream>>>(a, n, thr, nxt, E[0], C[0], d_root,
+                                                                            d_status, d_frag);
+    FMK_LAUNCH_CHECK(ctx);
+    for (int k = 1; k <= K; ++k) {
+        const int64_t tot = nblk[k] * S;
+        k_vol_level_up<S><<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
+            E[k - 1], C[k - 1], nblk[k - 1], (int64_t)S << (k - 1), E[k], C[k], nblk[k], d_status);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    // root entry + total count
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 32, 24, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int status = (int)(ctx->h_mail[0] & 0xFFFFFFFF);
+    const uint32_t root = (uint32_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
+    c.unc = ctx->h_mail[2];
+    if (status) return 1;
+    int64_t closes = 0;
+    if (root != VOL_END) {
+        if ((int64_t)root >= S) return 1;
+        uint32_t cnt = 0;
+        FMK_HIP(ctx, hipMemcpyAsync(&cnt, C[K] + root, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        closes = cnt;
+    }
+    c.count = closes + 1;
+    if (c.dbuf && c.cap < c.count) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
+    if (!c.dbuf) { FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.count * 8)); c.cap = c.count; }
+    // top-down
+    const int64_t one = 1;
+    FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int k = K; k >= 1; --k) {
+        k_vol_descend<S><<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+            ent[k], off[k], nblk[k], (int64_t)S << (k - 1), E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1]);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    k_vol_emit<S><<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(ent[0], off[0], nblk0, nxt, c.dbuf,
+                                                                               c.cap);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FMK_OK;
+}
+
+extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                                          double threshold, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx,
+                                          int64_t *n_uncertified)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
+    const bool serial = !(threshold > 0.0) || n >= ((int64_t)1 << 31) - 4096 || getenv("FMK_THRESHOLD_SERIAL");
+    if (serial)
+        return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
+                                    n_idx, n_uncertified);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    VolCache &c = g_vol;
+    const bool hit = c.ctx == ctx && c.amount == d_amount && c.n == n && c.thr == threshold &&
+                     c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
+    if (!hit) {
+        int rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
+                               : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
+        if (rc == 1)     // bar longer than the table span, or negative volumes
+            return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
+                                        n_idx, n_uncertified);
+        if (rc) return rc;
+        c.ctx = ctx; c.amount = d_amount; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
+    }
+    *n_idx = c.count;
+    if (n_uncertified) *n_uncertified = c.unc;
+    if (!d_close_idx) return FMK_OK;
+    if (capacity < c.count) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: capacity %lld < %lld",
+                                                 (long long)capacity, (long long)c.count);
+    FMK_HIP(ctx, hipMemcpyAsync(d_close_idx, c.dbuf, (size_t)c.count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    c.ctx = nullptr;     // one-shot cache: the inputs may change behind the same pointers
+    return FMK_OK;
+}

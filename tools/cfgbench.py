@@ -69,10 +69,10 @@ def main():
         vthr = float(np.median(dv["volume"][:-1])) / 2000.0
         dthr = vthr * float(np.median(dv["close"]))
         ms, vci = timed(ctx, lambda: t.volume_bar_index(vthr), 1)
-        emit("volume_bar_indexer (round-1 serial)", ms, 4, threshold=vthr, n_bars=vci.n - 1,
+        emit("volume_bar_indexer (parallel jump tables)", ms, 4, threshold=vthr, n_bars=vci.n - 1,
              uncertified=t.last_uncertified)
         ms, dci2 = timed(ctx, lambda: t.dollar_bar_index(dthr), 1)
-        emit("dollar_bar_indexer (round-1 serial)", ms, 12, threshold=dthr, n_bars=dci2.n - 1,
+        emit("dollar_bar_indexer (parallel closed form)", ms, 12, threshold=dthr, n_bars=dci2.n - 1,
              uncertified=t.last_uncertified)
         vout = t.alloc_ohlcv(vci.n - 1, True)
         ms, _ = timed(ctx, lambda: t.bar_ohlcv(vci, True, out=vout), args.reps)
