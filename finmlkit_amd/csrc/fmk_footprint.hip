@@ -6,17 +6,23 @@
 // per-bar level counts, phase 1) + flat per-level arrays, filled by one wave per bar (phase 2):
 //
 //   * the bar's dense level histogram lives in the wave's slice of LDS:
-//       vol[2L] f32 (buy/sell interleaved), cnt[2L] i32, tag[2L] u32          = 24 B / level
+//       vol[2L] f32 (buy/sell interleaved), cnt[2L] i32, aux[2L]              = 24 B / level
 //   * ticks stream in 64-tick chunks (price 512 B + amount 256 B + side 64 B per load, coalesced,
-//     13 B/tick); level = int(round(price/tick)) - int(round(low/tick)) (round-half-even, exact
-//     float64 division like the reference, base.py:688-703).
-//   * tick counts: LDS integer atomics (order-free).
-//   * volumes: the reference rounds to float32 on EVERY add, in tick order (base.py:713-717), so
-//     the sum is order-sensitive.  Within a chunk, lanes that hit the same (level, side) key are
-//     serialised in lane (= tick) order: each round every pending lane does ds_min(tag[key], lane),
-//     the winner (lowest lane per key) applies its add non-atomically and re-arms the tag.  Rounds =
-//     max multiplicity of a key in the chunk; distinct keys proceed in parallel.  Result: bit-exact
-//     float32 level volumes for ANY input, not only for exactly-summable amounts.
+//     software-pipelined; 13 B/tick).  level = int(round(price/tick)) - int(round(low/tick)) with
+//     round-half-even like the reference (base.py:688-703); the per-tick quotient is one multiply by
+//     1/tick, with the exact division as a guarded fallback when the product is within 1e-15 (rel.)
+//     of a half-integer, so the rounded level is always the reference's.
+//   * the reference rounds the level volume to float32 on EVERY add, in tick order (base.py:713-717),
+//     so the sum is order-sensitive in general.  Two ways to get its bits:
+//       - exact path: if all amounts of the bar are non-negative multiples of 2^q and the bar's total
+//         is < 2^(24+q), every partial sum is exactly representable and the order cannot matter.  The
+//         amounts are then accumulated as integer units with LDS integer atomics (ds_add_u32; the
+//         float atomic ds_add_f32 measured ~25x slower) and converted back at the end.  The certificate
+//         is evaluated from the data of the bar itself; q is remembered per wave.
+//       - ordered path (any input): per chunk the lanes are grouped by (level, side) key with a
+//         ballot loop; inside a group the running float32 value is passed from the lane of rank t-1 to
+//         rank t by a lane gather (tick order), the first lane starts from LDS and the last one stores.
+//         Distinct keys proceed in parallel, no atomics.
 //   * comp_footprint_features runs on the LDS histogram: diagonal imbalance flags (float32 product
 //     like NumPy: float32 array * Python float), longest signed run, first argmax (COT), and the
 //     float32 sums total / gini with NumPy's pairwise summation order reproduced exactly
@@ -26,8 +32,12 @@
 // Bars are binned by level count so that the common narrow bars run at high occupancy:
 // L<=128 (3 KB LDS/wave), <=512 (12 KB), <=2048 (48 KB, one wave per workgroup).
 #include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "fmk_common.h"
+#include "fmk_dpp.h"
 #include "fmk_scan.h"
 
 struct FpOut {
@@ -43,9 +53,20 @@ struct FpOut {
 static_assert(sizeof(FpOut) == sizeof(fmk_footprint_out), "ABI struct mismatch");
 
 #define FP_MAX_LEVELS 2048
+#define FP_Q_UNKNOWN 0x7FFFFFFF
 
 // int(round(x)) with Python's round-half-even == rint() in the default rounding mode
 __device__ __forceinline__ int64_t fp_level(double price, double tick) { return (int64_t)rint(price / tick); }
+// Same value with one multiply instead of a float64 division on the per-tick path: price*(1/tick) and
+// price/tick differ by <= 3.3e-16 relative, so rint() can only disagree when the quotient is that close
+// to a half-integer -- in that (rare, divergent) case the exact division decides.
+__device__ __forceinline__ int64_t fp_level(double price, double tick, double inv_tick)
+{
+    const double q = price * inv_tick;
+    const double r = rint(q);
+    if (0.5 - fabs(q - r) <= fabs(q) * 1e-15) return (int64_t)rint(price / tick);
+    return (int64_t)r;
+}
 
 // ---------------------------------------------------------------------------------------
 // phase 1: level counts per bar -> exclusive scan
@@ -147,6 +168,144 @@ __device__ __forceinline__ float fp_pairwise_f32(const float *a, int n, int lane
 }
 
 // ---------------------------------------------------------------------------------------
+// histogram accumulation
+// ---------------------------------------------------------------------------------------
+// lowest set bit of |a| as a power-of-two exponent (INT_MAX for 0, INT_MIN for inf/NaN)
+__device__ __forceinline__ int fp_lowbit_exp(float a)
+{
+    const uint32_t u = __float_as_uint(a) & 0x7FFFFFFFu;
+    if (u == 0) return 0x7FFFFFFF;
+    const int ex = (int)(u >> 23);
+    const uint32_t mant = u & 0x7FFFFFu;
+    if (ex == 255) return (int)0x80000000;
+    if (ex == 0) return -149 + __builtin_ctz(mant);
+    return ex - 150 + __builtin_ctz(mant | 0x800000u);
+}
+__device__ __forceinline__ int fp_lowbit_exp(double a)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(a) & 0x7FFFFFFFFFFFFFFFull;
+    if (u == 0) return 0x7FFFFFFF;
+    const int ex = (int)(u >> 52);
+    const uint64_t mant = u & 0xFFFFFFFFFFFFFull;
+    if (ex == 2047) return (int)0x80000000;
+    if (ex == 0) return -1074 + __builtin_ctzll(mant);
+    return ex - 1075 + __builtin_ctzll(mant | (1ull << 52));
+}
+
+struct FpStats {
+    int lbmin;       // min lowest-set-bit exponent over the accumulated amounts (FP_Q_UNKNOWN if all zero)
+    double atot;     // sum of |amount|
+    bool units_ok;   // exact path only: every amount was a non-negative multiple of 2^q below 2^31 units
+    bool bad;        // a tick fell outside the level range (base.py:719)
+};
+
+// One pass over the bar's ticks [s+1, e].
+//   EXACT  : vol[] is used as uint32 units of 2^q, updated with integer LDS atomics (order-free).
+//   !EXACT : vol[] holds float32 running sums updated in tick order (group / rank / lane-gather chains).
+template <bool AF64, bool EXACT>
+__device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ price, const void *__restrict__ amount,
+                                                 const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low,
+                                                 int L, double tick, double inv_tick, int lane, float *vol, int *cnt,
+                                                 int q)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    unsigned *units = (unsigned *)vol;
+    int lbmin = FP_Q_UNKNOWN;
+    double atot = 0.0;
+    bool bad = false, units_ok = true;
+    // software pipeline: the loads of chunk c+1 are in flight while chunk c is processed
+    double p_n = 0.0;
+    AmtT a_n = 0;
+    int sd_n = 0;
+    if (s + 1 + lane <= e) {
+        p_n = price[s + 1 + lane];
+        a_n = ((const AmtT *)amount)[s + 1 + lane];
+        sd_n = side[s + 1 + lane];
+    }
+    for (int64_t j0 = s + 1; j0 <= e; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const double p = p_n;
+        const AmtT a = a_n;
+        const int sd = sd_n;
+        if (j + 64 <= e) {
+            p_n = price[j + 64];
+            a_n = ((const AmtT *)amount)[j + 64];
+            sd_n = side[j + 64];
+        }
+        bool pending = false;
+        int key = -1;
+        if (j <= e) {
+            const int64_t lvl = fp_level(p, tick, inv_tick) - low;    // base.py:700-707
+            if (lvl < 0 || lvl >= L) bad = true;                      // base.py:719
+            else if (sd == 1 || sd == -1) {
+                pending = true;
+                key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
+                const int lb = fp_lowbit_exp(a);
+                lbmin = lb < lbmin ? lb : lbmin;
+                atot += fabs((double)a);
+            }
+        }
+        if constexpr (EXACT) {
+            if (pending) {
+                const double u = ldexp((double)a, -q);                // exact scaling
+                const bool ok = u >= 0.0 && u < 2147483648.0 && u == rint(u);
+                units_ok &= ok;
+                if (ok) atomicAdd(&units[key], (unsigned)u);
+                atomicAdd(&cnt[key], 1);
+            }
+            continue;
+        }
+        // ---- group the pending lanes by key: every lane learns the lane mask of its key
+        uint64_t grp = 0;
+        for (uint64_t rem = __ballot(pending); rem != 0;) {
+            const int leader = __ffsll((unsigned long long)rem) - 1;
+            const int k = __builtin_amdgcn_readlane(key, leader);
+            const uint64_t m = __ballot(key == k);                    // non-pending lanes carry key -1
+            if (key == k) grp = m;
+            rem &= ~m;
+        }
+        // ---- float32 accumulation in tick (= lane) order inside every key group: the first lane of a
+        //      group starts from the LDS value, the lane of rank t takes the running value of rank t-1
+        //      by a lane gather, the last lane stores.
+        const uint64_t below = grp & (((uint64_t)1 << lane) - 1);
+        const int rank = __popcll(below);
+        const int gsize = __popcll(grp);
+        const int prev_lane = rank > 0 ? 63 - __clzll((unsigned long long)below) : lane;
+        float acc = 0.f;
+        if (pending && rank == 0) {
+            acc = vol[key];
+            if constexpr (AF64) acc = (float)((double)acc + a);       // f32 element += f64 amount
+            else acc = acc + a;
+            cnt[key] += gsize;                                        // one writer per key: no atomic
+        }
+        const int rounds = fmk_dpp_reduce(gsize, 0, FmkOpMax());
+        for (int t = 1; t < rounds; ++t) {
+            const float v = __shfl(acc, prev_lane, 64);
+            if (pending && rank == t) {
+                if constexpr (AF64) acc = (float)((double)v + a);
+                else acc = v + a;
+            }
+        }
+        if (pending && rank == gsize - 1) vol[key] = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+    FpStats st;
+    st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
+    st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    st.units_ok = __ballot(!units_ok) == 0;
+    st.bad = __ballot(bad) != 0;
+    __builtin_amdgcn_wave_barrier();
+    return st;
+}
+
+// every float32 add of a bar with these statistics is exact at quantum 2^q
+__device__ __forceinline__ bool fp_certified(const FpStats &st, int q)
+{
+    if (st.lbmin == FP_Q_UNKNOWN) return true;                 // only zeros
+    return st.units_ok && q <= st.lbmin && q >= -149 && q <= 100 && st.atot < ldexp(1.0, 24 + q);
+}
+
+// ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
 template <bool AF64>
@@ -156,7 +315,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const int64_t *__restrict__ ci, int64_t nb, double tick,
                                                         const double *__restrict__ lows, float m32,
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
-                                                        FpOut o, unsigned long long *n_bad)
+                                                        FpOut o, unsigned long long *n_bad, int force_ordered)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
@@ -166,10 +325,12 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     unsigned char *mine = smem + (size_t)wib * per_wave;
     float *vol = (float *)mine;                                   // [2*lmax]  buy = 2l, sell = 2l+1
     int *cnt = (int *)(mine + (size_t)lmax * 8);                  // [2*lmax]
-    unsigned *tag = (unsigned *)(mine + (size_t)lmax * 16);       // [2*lmax]
+    float *aux = (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
     int *stk = (int *)(mine + (size_t)lmax * 24);                 // 64 ints
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    const double inv_tick = 1.0 / tick;
+    int wq = FP_Q_UNKNOWN;        // quantum exponent the previous bar of this wave certified with
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t base = fmk_uniform(off[b]);
         const int L = (int)fmk_uniform(off[b + 1] - base);
@@ -177,48 +338,51 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t low = fp_level(lows[b], tick);
-        for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; tag[k] = 0xFFFFFFFFu; }
+        for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
         __builtin_amdgcn_wave_barrier();
-        bool bad = false;
-        for (int64_t j0 = s + 1; j0 <= e; j0 += 64) {
-            const int64_t j = j0 + lane;
-            bool pending = false;
-            int key = 0;
-            float a32 = 0.f;
-            double a64 = 0.0;
-            if (j <= e) {
-                const int sd = side[j];
-                const int64_t lvl = fp_level(price[j], tick) - low;       // base.py:700-707
-                if (lvl < 0 || lvl >= L) bad = true;                      // base.py:719
-                else if (sd == 1 || sd == -1) {
-                    pending = true;
-                    key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
-                    if constexpr (AF64) a64 = ((const double *)amount)[j];
-                    else a32 = ((const float *)amount)[j];
+        // Exact path first (with the quantum that worked for the previous bar); when its certificate
+        // fails the bar's own statistics give the right quantum for one retry, else the ordered path runs.
+        FpStats st;
+        bool done = false;
+        if (!force_ordered && wq != FP_Q_UNKNOWN) {
+            st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
+            done = fp_certified(st, wq);
+            if (!done) {
+                for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
+                __builtin_amdgcn_wave_barrier();
+                const int q2 = st.lbmin;
+                FpStats probe = st;
+                probe.units_ok = true;
+                if (q2 != FP_Q_UNKNOWN && q2 != (int)0x80000000 && fp_certified(probe, q2)) {
+                    st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, q2);
+                    done = fp_certified(st, q2);
+                    if (done) wq = q2;
+                    else {
+                        for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
-            if (pending) atomicAdd(&cnt[key], 1);
-            // tick-ordered float32 accumulation: lowest pending lane per key wins each round
-            while (__ballot(pending) != 0) {
-                if (pending) atomicMin(&tag[key], (unsigned)lane);
-                __builtin_amdgcn_wave_barrier();
-                const bool win = pending && tag[key] == (unsigned)lane;
-                if (win) {
-                    float h = vol[key];
-                    if constexpr (AF64) h = (float)((double)h + a64);     // f32 element += f64 amount
-                    else h = h + a32;
-                    vol[key] = h;
-                    tag[key] = 0xFFFFFFFFu;
-                    pending = false;
-                }
+            if (done) {       // units -> float32 (exact)
+                unsigned *units = (unsigned *)vol;
+                const int qq = wq;
+                for (int k = lane; k < 2 * L; k += 64) vol[k] = ldexpf((float)units[k], qq);
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (__ballot(bad) != 0 && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
+        if (!done) {
+            st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
+            // remember a usable quantum for the next bar (if this bar would have certified)
+            FpStats probe = st;
+            probe.units_ok = true;
+            const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 && fp_certified(probe, st.lbmin);
+            wq = usable ? st.lbmin : FP_Q_UNKNOWN;
+        }
+        if (st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
         __builtin_amdgcn_wave_barrier();
 
         // ---- pass A: write the level rows, total[l] = buy + sell (float32), argmax, vwap numerator
-        float *tot = (float *)tag;                 // tag area is free now: tot[0..L)
+        float *tot = aux;
         float best = -INFINITY;
         int best_i = 0x7FFFFFFF;
         double num = 0.0;
@@ -243,7 +407,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         }
         if (best_i == 0x7FFFFFFF) best_i = 0;      // all-NaN / empty guard: np.argmax -> 0
-        num = fmk_wave_sum(num);
+        num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
         __builtin_amdgcn_wave_barrier();
         const float total = fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()
         const bool stats = total > 0.f && L > 0;                         // base.py:836
@@ -274,7 +438,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             bsum += __popcll(__ballot(bi));
             ssum += __popcll(__ballot(si));
         }
-        skew = fmk_wave_sum(skew);
+        skew = fmk_dpp_reduce(skew, 0.0, FmkOpAdd());
         __builtin_amdgcn_wave_barrier();
         double gini = 0.0;
         if (stats) gini = (double)(1.0f - fp_pairwise_f32(q2, L, lane, stk));   // base.py:847-848 (float32)
@@ -304,13 +468,15 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
                      double tick, const double *lows, float m32, const int64_t *off, int lmin, int lmax, int wpb,
                      const FpOut &o, unsigned long long *n_bad)
 {
+    static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
+    if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
     const size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256);
     int64_t blocks = fmk_ceil_div(nb, wpb);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     k_bar_footprints<AF64><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32, off,
-                                                                            lmin, lmax, o, n_bad);
+                                                                            lmin, lmax, o, n_bad, force_ordered);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
