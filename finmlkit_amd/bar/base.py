@@ -131,8 +131,19 @@ class BarBuilderBase(ABC):
         return df
 
     def build_trade_size_features(self, theta, theta_mult: float = 5.0) -> pd.DataFrame:
-        """Reference base.py:214-245 -- first "next" row of SURVEY.md 8(f), not part of round 1."""
-        raise NotImplementedError("comp_bar_trade_size_features is scheduled after the hot-path rows (SURVEY 8f)")
+        """Relative mean / 95th-percentile trade size, block share and size Gini per bar
+        (reference base.py:214-245)."""
+        self._set_bar_close()
+        self._check_indices()
+        nb = len(self._close_indices) - 1
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if len(theta) != nb:
+            raise ValueError("Theta should match the the number of bars (len(bar_close_indices) - 1).")
+        out = self._device().bar_trade_size(self._d_close_idx, theta, theta_mult)
+        df = pd.DataFrame({"timestamp": self.bar_close_timestamps, **out})
+        df["timestamp"] = pd.to_datetime(df["timestamp"], unit="ns")
+        df.set_index("timestamp", inplace=True)
+        return df
 
     def build_footprints(self, price_tick_size=None, imbalance_factor=3.0) -> FootprintData:
         """Per-bar price-level footprints + imbalance statistics (reference base.py:247-300)."""
@@ -200,6 +211,25 @@ def comp_bar_directional_features(prices: NDArray[np.float64], volumes: NDArray,
     ctx.call("fmk_comp_bar_directional", ptr(p), ptr(v), C.c_int(f64), c_i64(len(p)), ptr(ci), c_i64(len(ci)),
              ptr(sd), C.byref(st))
     return tuple(outs[k] for k, _ in _ffi.DIRECTIONAL_FIELDS)
+
+
+def comp_bar_trade_size_features(amounts: NDArray, theta: NDArray[np.float64], bar_close_indices: NDArray[np.int64],
+                                 theta_mult: float):
+    """Reference: finmlkit/bar/base.py:549-612.
+
+    Returns float32 arrays (mean_size_rel, size_95_rel, pct_block, size_gini); NaN where the reference
+    leaves NaN (empty bar, theta == 0, zero total volume)."""
+    ctx = _ffi.default_context()
+    v, f64 = _ffi.amount_array(amounts)
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    ci = np.ascontiguousarray(bar_close_indices, dtype=np.int64)
+    if len(th) != len(ci) - 1:
+        raise ValueError("Theta should match the the number of bars (len(bar_close_indices) - 1).")
+    nb = len(ci) - 1
+    outs = tuple(np.empty(nb, np.float32) for _ in range(4))
+    ctx.call("fmk_comp_bar_trade_size", ptr(v), C.c_int(f64), c_i64(len(v)), ptr(th), ptr(ci), c_i64(len(ci)),
+             c_f64(theta_mult), *[ptr(o) for o in outs])
+    return outs
 
 
 def comp_bar_footprints_csr(prices, amounts, bar_close_indices, trade_sides, price_tick_size, bar_lows,

@@ -239,6 +239,30 @@ int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amoun
     return FMK_OK;
 }
 
+int fmk_comp_bar_trade_size(fmk_ctx *ctx, const void *amount, int amount_is_f64, int64_t n, const double *theta,
+                            const int64_t *close_idx, int64_t n_idx, double theta_mult, float *mean_size_rel,
+                            float *size_95_rel, float *pct_block, float *size_gini)
+{
+    if (n_idx < 2)
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    const int64_t nb = n_idx - 1;
+    DevBag bag(ctx);
+    void *d_a;
+    double *d_th;
+    int64_t *d_ci;
+    float *d_o[4];
+    FMK_TRY(bag.up_amount(amount, amount_is_f64, n, &d_a));
+    FMK_TRY(bag.up(theta, nb, &d_th));
+    FMK_TRY(bag.up(close_idx, n_idx, &d_ci));
+    for (int k = 0; k < 4; ++k) FMK_TRY(bag.out(nb, &d_o[k]));
+    FMK_TRY(fmk_comp_bar_trade_size_dev(ctx, d_a, amount_is_f64, n, d_th, d_ci, n_idx, theta_mult, d_o[0], d_o[1],
+                                        d_o[2], d_o[3]));
+    FMK_TRY(down(ctx, mean_size_rel, d_o[0], nb));
+    FMK_TRY(down(ctx, size_95_rel, d_o[1], nb));
+    FMK_TRY(down(ctx, pct_block, d_o[2], nb));
+    return down(ctx, size_gini, d_o[3], nb);
+}
+
 int fmk_comp_lagged_returns(fmk_ctx *ctx, const int64_t *ts, const double *close_, int64_t n,
                             double return_window_sec, int is_log, double *out)
 {

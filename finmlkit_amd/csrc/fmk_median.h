@@ -180,23 +180,23 @@ struct MedBar {
     }
 };
 
-// The search itself; bar.key[] (register path) must already hold the keys.  Returns np.median of the
-// bar's amounts (NaN if any amount is NaN, like NumPy).
+// Exact order statistics of ranks k1 <= k2 <= k1+1 (0-based) of the bar's keys; bar.key[] (register
+// path) must already hold the keys.  Returns false when the bar contains a NaN (keys outside [-inf, +inf]).
 template <bool AF64, int NREG, bool EXACT>
-__device__ __forceinline__ double med_search(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf)
+__device__ __forceinline__ bool med_rank_pair(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf,
+                                              int64_t k1, int64_t k2, typename MedKey<AF64>::K &v1,
+                                              typename MedKey<AF64>::K &v2)
 {
     typedef MedKey<AF64> MK;
     typedef typename MK::K K;
     const int lane = bar.lane;
     const int64_t cnt = bar.cnt;
-    const int64_t k1 = (cnt - 1) >> 1, k2 = cnt >> 1;   // the two middle ranks (equal when cnt is odd)
     K mn, mx;
     bar.minmax(mn, mx);
-    if (mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF) return NAN;     // a NaN amount: np.median propagates it
+    if (mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF) return false;
     // invariant: count(key <= lo) = clo <= k1  and  count(key <= hi) = chi > k2
     K lo = mn - 1, hi = mx;
     int64_t clo = 0, chi = cnt;
-    K v1, v2;
     for (;;) {
         if (chi - clo <= 64) {
             // <= 64 candidates in (lo, hi]: compact -> sort across lanes -> read the ranks
@@ -215,11 +215,22 @@ __device__ __forceinline__ double med_search(MedBar<AF64, NREG, EXACT> &bar, typ
         int64_t c = bar.count_le(pivot);
         if (c > k2) { hi = pivot; chi = c; }
         else if (c <= k1) { lo = pivot; clo = c; }
-        else {   // k1 < c <= k2: the pivot separates the two middle ranks
+        else {   // k1 < c <= k2: the pivot separates the two ranks
             bar.split(pivot, v1, v2);
             break;
         }
     }
+    return true;
+}
+
+// np.median of the bar's amounts (NaN if any amount is NaN, like NumPy).
+template <bool AF64, int NREG, bool EXACT>
+__device__ __forceinline__ double med_search(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf)
+{
+    typedef MedKey<AF64> MK;
+    typename MK::K v1, v2;
+    const int64_t cnt = bar.cnt;
+    if (!med_rank_pair<AF64, NREG, EXACT>(bar, buf, (cnt - 1) >> 1, cnt >> 1, v1, v2)) return NAN;
     // np.median: mean of the two middle elements == (a + b) / 2.0 ; odd count: the middle one
     return (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
 }

@@ -1,0 +1,128 @@
+// fmk_tradesize.hip -- comp_bar_trade_size_features (finmlkit/bar/base.py:549-612) on gfx950.
+// First "next" row of SURVEY.md 8(f): same bar segments, reuses the exact order-statistic search of
+// fmk_median.h for np.percentile(amounts_bar, 95).
+//
+// One wave per bar, three passes over the bar's amounts (the 2nd/3rd hit L2; bars of <= 2048 ticks keep
+// their keys in registers for the percentile):
+//   pass 1  sum, block volume (amounts > theta*theta_mult)            -> mean_size_rel, pct_block
+//   select  ranks floor(0.95(n-1)) and +1, NumPy 'linear' interpolation -> size_95_rel
+//   pass 3  sum (a/total)^2                                            -> size_gini
+// Arithmetic is float64 throughout and the results are rounded once to float32.  For float64 amounts
+// this is the reference's arithmetic up to summation order; for float32 amounts the reference (both its
+// NumPy and its Numba mode) accumulates the sums in float32, which this kernel deliberately does not
+// reproduce -- the float64 sums are the more accurate value and differ by ~1e-7 relative (documented
+// tolerance in tests/test_gpu_next.py).
+#include <math.h>
+
+#include "fmk_median.h"
+
+template <bool AF64, int NREG>
+__device__ __forceinline__ double ts_percentile95(const void *amount, int64_t start, int64_t cnt, int lane,
+                                                  typename MedKey<AF64>::K *buf)
+{
+    typedef MedKey<AF64> MK;
+    MedBar<AF64, NREG, false> bar;
+    bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+    bar.load_all();
+    // NumPy 'linear' method: virtual index (n-1)*q, neighbours floor and floor+1 (clipped), _lerp
+    const double vidx = (double)(cnt - 1) * 0.95;
+    const double fl = floor(vidx);
+    const int64_t k1 = (int64_t)fl;
+    const int64_t k2 = k1 + 1 < cnt ? k1 + 1 : cnt - 1;
+    typename MK::K v1, v2;
+    if (!med_rank_pair<AF64, NREG, false>(bar, buf, k1, k2, v1, v2)) return NAN;
+    const double a = MK::value(v1), b = MK::value(v2);
+    const double t = vidx - fl;
+    // float32 inputs: NumPy subtracts the two float32 neighbours in float32 before promoting
+    const double d = AF64 ? b - a : (double)((float)b - (float)a);
+    double r = a + d * t;
+    if (t >= 0.5) r = b - d * (1.0 - t);
+    if (d == 0.0) r = a;
+    return r;
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__ amount,
+                                                        const double *__restrict__ theta,
+                                                        const int64_t *__restrict__ ci, int64_t nb, double theta_mult,
+                                                        float *__restrict__ o_mean, float *__restrict__ o_p95,
+                                                        float *__restrict__ o_pct, float *__restrict__ o_gini)
+{
+    typedef typename MedKey<AF64>::K K;
+    __shared__ K sbuf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    K *buf = sbuf[wib];
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t cnt = e - s;
+        const int64_t start = s + 1;
+        float mean_rel = NAN, p95_rel = NAN, pct = NAN, gini = NAN;      // base.py:576-579
+        const double th = theta[b];
+        if (cnt > 0 && th != 0.0) {                                      // base.py:586-587
+            const double thr = th * theta_mult;
+            double sum = 0.0, block = 0.0;
+            for (int64_t j = lane; j < cnt; j += 64) {
+                const double a = fmk_amt<AF64>(amount, start + j);
+                sum += a;
+                if (a > thr) block += a;
+            }
+            sum = fmk_wave_sum(sum);
+            block = fmk_wave_sum(block);
+            mean_rel = (float)log1p((sum / (double)cnt) / thr);
+            const int nreg = (int)((cnt + 63) >> 6);
+            double p95;
+            if (cnt > 64 * 32) p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
+            else if (nreg <= 4) p95 = ts_percentile95<AF64, 4>(amount, start, cnt, lane, buf);
+            else if (nreg <= 12) p95 = ts_percentile95<AF64, 12>(amount, start, cnt, lane, buf);
+            else if (nreg <= 20) p95 = ts_percentile95<AF64, 20>(amount, start, cnt, lane, buf);
+            else if constexpr (!AF64) p95 = ts_percentile95<AF64, 32>(amount, start, cnt, lane, buf);
+            else if (nreg <= 24) p95 = ts_percentile95<AF64, 24>(amount, start, cnt, lane, buf);
+            else p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
+            p95_rel = (float)log1p(p95 / thr);
+            if (sum != 0.0) {                                            // base.py:597-598
+                pct = (float)(block / sum);
+                if (cnt == 1) gini = 0.f;
+                else {
+                    double sq = 0.0;
+                    for (int64_t j = lane; j < cnt; j += 64) {
+                        const double q = fmk_amt<AF64>(amount, start + j) / sum;
+                        sq += q * q;
+                    }
+                    gini = (float)(1.0 - fmk_wave_sum(sq));
+                }
+            }
+        }
+        if (lane == 0) { o_mean[b] = mean_rel; o_p95[b] = p95_rel; o_pct[b] = pct; o_gini[b] = gini; }
+    }
+}
+
+extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                                           const double *d_theta, const int64_t *d_close_idx, int64_t n_idx,
+                                           double theta_mult, float *d_mean_size_rel, float *d_size_95_rel,
+                                           float *d_pct_block, float *d_size_gini)
+{
+    (void)n;
+    if (n_idx < 2)
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nb = n_idx - 1;
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 64;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (amount_is_f64)
+        k_bar_trade_size<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb,
+                                                                          theta_mult, d_mean_size_rel, d_size_95_rel,
+                                                                          d_pct_block, d_size_gini);
+    else
+        k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb,
+                                                                           theta_mult, d_mean_size_rel, d_size_95_rel,
+                                                                           d_pct_block, d_size_gini);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}

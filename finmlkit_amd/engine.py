@@ -154,6 +154,17 @@ class DeviceTrades:
                       close_idx.p, c_i64(close_idx.n), out.p)
         return out
 
+    def bar_trade_size(self, close_idx: DeviceArray, theta, theta_mult: float = 5.0) -> Dict[str, np.ndarray]:
+        """comp_bar_trade_size_features (base.py:549-612) -> host float32 arrays keyed like the reference's
+        DataFrame columns."""
+        nb = close_idx.n - 1
+        th = DeviceArray.from_host(self.ctx, np.ascontiguousarray(theta, dtype=np.float64))
+        keys = ("mean_size_rel", "size_95_rel", "pct_block", "size_gini")
+        out = {k: DeviceArray(self.ctx, nb, np.float32) for k in keys}
+        self.ctx.call("fmk_comp_bar_trade_size_dev", self.amount.p, C.c_int(self.amount_is_f64), c_i64(self.n), th.p,
+                      close_idx.p, c_i64(close_idx.n), c_f64(theta_mult), *[out[k].p for k in keys])
+        return {k: v.to_host() for k, v in out.items()}
+
     def bar_directional(self, close_idx: DeviceArray) -> Tuple[Dict[str, DeviceArray], DeviceArray]:
         """comp_bar_directional_features (base.py:409-546); second value: device count of bars without a
         signed tick (the reference raises ZeroDivisionError for those)."""

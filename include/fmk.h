@@ -189,6 +189,18 @@ int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amoun
                             const double *bar_highs, double imbalance_factor,
                             int64_t *level_offsets, const fmk_footprint_out *out);
 
+/* comp_bar_trade_size_features (base.py:549-612).  theta[n_bars] float64;
+ * outputs float32[n_bars]: mean_size_rel, size_95_rel, pct_block, size_gini (NaN where the reference
+ * leaves NaN: empty bar, theta == 0, zero total volume). */
+int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
+                                const double *d_theta, const int64_t *d_close_idx, int64_t n_idx,
+                                double theta_mult, float *d_mean_size_rel, float *d_size_95_rel,
+                                float *d_pct_block, float *d_size_gini);
+int fmk_comp_bar_trade_size(fmk_ctx *ctx, const void *amount, int amount_is_f64, int64_t n,
+                            const double *theta, const int64_t *close_idx, int64_t n_idx,
+                            double theta_mult, float *mean_size_rel, float *size_95_rel,
+                            float *pct_block, float *size_gini);
+
 /* ---- tick-level feature loops: finmlkit/feature/core ---------------------------------- */
 /* comp_lagged_returns (core/utils.py:12-64). */
 int fmk_comp_lagged_returns_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_close,

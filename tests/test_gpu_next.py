@@ -1,0 +1,63 @@
+"""GPU parity of the first "next" row: comp_bar_trade_size_features."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
+
+
+def test_trade_size_golden_f64():
+    """float64 amounts: the reference's arithmetic up to summation order -> float32 results within 1 ulp."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    d = G.load("trade_size")
+    got = comp_bar_trade_size_features(d["am"], d["theta"], d["ci"], 5.0)
+    for k, g in zip(KEYS, got):
+        assert g.dtype == np.float32
+        G.assert_f32_close(g, d[k], what=k, max_ulp=1, max_frac=0.02)
+    assert np.isnan(got[0][3]) and np.isnan(got[3][3])          # theta == 0 -> NaN row
+
+
+@pytest.mark.parametrize("n,interval", [(300_000, 60.0), (300_000, 1.0), (200_000, 3600.0)])
+def test_trade_size_vs_oracle(orc, n, interval):
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    ts, px, am, sd = orc.synth(19, 0, n)
+    am64 = np.random.default_rng(2).lognormal(-1, 1.2, n)
+    _, ci = orc._time_bar_indexer(ts, interval)
+    theta = np.full(len(ci) - 1, float(np.median(am64)))
+    want = orc.comp_bar_trade_size_features(am64, theta, ci, 5.0)
+    got = comp_bar_trade_size_features(am64, theta, ci, 5.0)
+    for k, g, w in zip(KEYS, got, want):
+        G.assert_f32_close(g, w, what=f"{k} iv={interval}", max_ulp=1, max_frac=0.02)
+    # float32 amounts: the reference accumulates its sums in float32 (NumPy pairwise / Numba sequential);
+    # the kernel sums in float64 -> agree to float32 summation accuracy only
+    theta32 = np.full(len(ci) - 1, float(np.median(am)))
+    want = orc.comp_bar_trade_size_features(am, theta32, ci, 5.0)
+    got = comp_bar_trade_size_features(am, theta32, ci, 5.0)
+    for k, g, w in zip(KEYS, got, want):
+        assert np.array_equal(np.isnan(g), np.isnan(w)), k
+        np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-6, equal_nan=True, err_msg=k)
+
+
+def test_trade_size_kit_and_errors(orc):
+    import pandas as pd
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    from finmlkit_amd.bar.data_model import TradesData
+    from finmlkit_amd.bar.kit import TickBarKit
+    n = 50_000
+    ts, px, am, sd = orc.synth(4, 0, n)
+    am64 = am.astype(np.float64) * 1.37
+    kit = TickBarKit(TradesData(ts, px, am64, np.arange(n), side=sd), 500)
+    ci = orc._tick_bar_indexer(ts, 500)
+    theta = np.full(len(ci) - 1, 1.0)
+    df = kit.build_trade_size_features(theta, theta_mult=3.0)
+    assert list(df.columns) == KEYS and len(df) == len(ci) - 1
+    want = orc.comp_bar_trade_size_features(am64, theta, ci, 3.0)
+    for k, w in zip(KEYS, want):
+        G.assert_f32_close(df[k].values, w, what=k, max_ulp=1, max_frac=0.02)
+    with pytest.raises(ValueError, match="Theta should match"):
+        comp_bar_trade_size_features(am64, theta[:-1], ci, 3.0)
+    with pytest.raises(ValueError, match="Theta should match"):
+        kit.build_trade_size_features(theta[:-1])
