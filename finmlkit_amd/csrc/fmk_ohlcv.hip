@@ -8,7 +8,7 @@
 // 8 B/bar read + 60..68 B/bar written.
 //
 // Two kernels:
-//   k_bar_ohlcv_small  bars of <= 64*NCH ticks (NCH = 22 -> 1408 ticks: every 1-minute bar of the
+//   k_bar_ohlcv_small  bars of <= 64*NCH ticks (up to 21 chunks = 1344 ticks: every 1-minute bar of the
 //                      benchmark stream).  ALL loads of the bar are issued up front (one HBM round
 //                      trip per bar instead of one per unrolled batch), and -- when the median trade
 //                      size is requested (base.py:403) -- the amounts that are already in registers
@@ -27,7 +27,7 @@
 #include "fmk_common.h"
 #include "fmk_median.h"
 
-#define FMK_SMALL_NCH 22
+#define FMK_SMALL_NCH 21
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median);
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
         const int nch = (int)((cnt + 63) >> 6);
         // exact-size code for the chunk counts a ~1200-tick (1-minute) bar takes, size classes below
         switch (nch) {
+        case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
         case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
         case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
         case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
             if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
             else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
             else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else small_bar<AF64, FMK_SMALL_NCH, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
         }
     }
 }
