@@ -24,9 +24,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-# note of MI355X_MICROARCH.md + WRITE_SIZE), see profiles/; None until measured for the current kernel.
-TRAFFIC = None
+# HBM bytes per tick / per bar of the dominant kernel from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), measured at N = 1e9,
+# B = 833323 on the default workload: profiles/r01_bench_cfg2_pmc_traffic.csv (1.2102e10 read + 6.82e7 written).
+# Reported per launch, scaled to the run's N/B; null for non-default workloads (not measured).
+PMC_READ_BYTES_PER_TICK = 1.2102e10 / 1e9
+PMC_WRITE_BYTES_PER_BAR = 6.8171e7 / 833323
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -220,9 +223,11 @@ def main():
                 "parallelism": f"time-range shards x{world}, 1 neighbour halo exchange" if use_dist else "1 GPU",
             },
             "roofline": {"bound": "hbm",
-                         "kernel": "k_bar_ohlcv_small<f32 amount, 22 chunks, %s>" % ("fused median" if want_median else "no median"),
+                         "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC, "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
+                         "traffic": (PMC_READ_BYTES_PER_TICK * n + PMC_WRITE_BYTES_PER_BAR * nb)
+                         if (want_median and args.interval == 60.0) else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
                          "launches_timed": len(k_ms)},
         }
         if world == 1:
