@@ -126,41 +126,32 @@ def main():
 
     if use_dist:
         import torch
+        from finmlkit_amd.dist import ShardedTimeBars
         dev = f"cuda:{local_rank}"
         tcols = [torch.as_tensor(b, device=dev) for b in trades._backing]   # zero-copy views of our buffers
-        one = DeviceArray(ctx, 1, np.int64)
+        shard = ShardedTimeBars(trades, rank, world, args.interval, want_median)
 
     def step():
-        if not use_dist:
-            t0, t1 = trades.first_last_ts()
-            ne, e0, d = clock_of(t0, t1)
-            ensure_buffers(ne)
-            t = trades
-        else:
-            f, l = trades.first_last_ts()
-            allfl = comm.all_gather_i64([f, l])
-            gne, ge0, gd = clock_of(allfl[0][0], allfl[-1][1])
-            from finmlkit_amd.dist import halo_lengths, plan_edges
-            plans = plan_edges([a[0] for a in allfl], gne, ge0, gd)
-            my = plans[rank]
-            # local close index of my last edge = first tick of the halo I send to the right neighbour
-            ctx.call("fmk_time_bar_indexer_dev", trades.ts.p, c_i64(n), c_i64(ge0 + my.hi * gd), c_i64(gd),
-                     c_i64(1), None, one.p)
-            c_last = int(one.to_host()[0])
-            send_h, recv_h = halo_lengths(comm, n, c_last)
+        if use_dist:
+            # all-gather (first, last) timestamp -> global clock + edge plan; the bars that need no halo are
+            # enqueued right away and run while the halo lengths and the halo itself travel
+            send_h = shard.launch_local(comm.all_gather_i64(list(shard.span())))
+            allh = comm.all_gather_i64([send_h])
+            recv_h = allh[rank - 1][0] if rank > 0 else 0
             if recv_h > HALO:
                 raise RuntimeError(f"halo {recv_h} exceeds headroom {HALO}")
-            send = [tc[HALO + c_last: HALO + n] for tc in tcols] if send_h else []
+            send = [tc[HALO + shard.send_start: HALO + n] for tc in tcols] if send_h else []
             recv = [tc[HALO - recv_h: HALO] for tc in tcols] if recv_h else []
-            comm.neighbour_exchange(send, recv)
+            comm.neighbour_exchange(send, recv)                 # one RCCL send/recv batch per neighbour pair
             torch.cuda.current_stream().synchronize()
-            t = trades.with_halo(recv_h)
-            ne, e0, d = my.hi - my.lo + 1, ge0 + my.lo * gd, gd
-            ensure_buffers(ne)
-        clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
-        out = state["out"]
-        # comp_bar_ohlcv incl. the median trade size: ONE fused kernel for bars <= 1408 ticks (dominant)
-        t.bar_ohlcv(ci, want_median=want_median, out=out)
+            state["n_bars"] = shard.finish(recv_h)              # the bar straddling the left boundary
+            return state["n_bars"]
+        t0, t1 = trades.first_last_ts()
+        ne, e0, d = clock_of(t0, t1)
+        ensure_buffers(ne)
+        clock, ci = trades.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
+        # comp_bar_ohlcv incl. the median trade size: ONE fused kernel for bars <= 1344 ticks (dominant)
+        trades.bar_ohlcv(ci, want_median=want_median, out=state["out"])
         state["n_bars"] = ne - 1
         return ne - 1
 

@@ -93,6 +93,92 @@ class Comm:
                 w.wait()
 
 
+class ShardedTimeBars:
+    """One rank's side of a sharded `TimeBarKit.build_ohlcv()` step, split into phases.
+
+    The exchange between the phases is the caller's: RCCL in bench.py, an in-process device copy between
+    virtual ranks in tests/test_gpu_dist.py.  Phases of one step:
+
+      span()                 -> (first, last) timestamp of the shard            [all-gather #1]
+      launch_local(all_span) -> halo length this rank sends right               [all-gather #2, halo send/recv]
+                                (global clock + edge plan, local close indices, and -- already enqueued on the
+                                context's stream, overlapping the exchange -- every bar that needs no halo)
+      finish(recv_h)         -> number of bars; the bar straddling the left boundary is reduced from
+                                [halo | shard] by the same kernels.
+
+    `trades` must have been created with headroom (engine.DeviceTrades.synth(..., headroom=H)); the halo lands in
+    backing[H - recv_h : H], the halo sent right is backing[H + send_start : H + n].
+    """
+
+    def __init__(self, trades, rank: int, world: int, interval_seconds: float, want_median: bool = True):
+        import numpy as np
+        from ._ffi import DeviceArray
+        self.t, self.rank, self.world = trades, rank, world
+        self.interval, self.want_median = float(interval_seconds), want_median
+        self.ctx = trades.ctx
+        self.headroom = trades._headroom
+        self._np, self._DA = np, DeviceArray
+        self._cap = 0
+        self._ci0 = DeviceArray(self.ctx, 2, np.int64)
+        self.clock = self.idx = self.out = None
+        self.plan = None
+        self.send_start = trades.n
+
+    def span(self) -> Tuple[int, int]:
+        return self.t.first_last_ts()
+
+    def _ensure(self, ne: int):
+        if self._cap < ne:
+            self._cap = ne + 1024
+            self._clock = self._DA(self.ctx, self._cap, self._np.int64)
+            self._idx = self._DA(self.ctx, self._cap, self._np.int64)
+            self._out = self.t.alloc_ohlcv(self._cap, self.want_median)
+
+    def launch_local(self, all_span: Sequence[Sequence[int]]) -> int:
+        import ctypes as C
+        from . import _ffi
+        from ._ffi import c_f64, c_i64
+        ne, e0, d = c_i64(), c_i64(), c_i64()
+        _ffi.check(_ffi.lib().fmk_time_bar_clock(c_i64(int(all_span[0][0])), c_i64(int(all_span[-1][1])),
+                                                 c_f64(self.interval), C.byref(ne), C.byref(e0), C.byref(d)))
+        self.gclock = (ne.value, e0.value, d.value)
+        self.plan = plan_edges([int(a[0]) for a in all_span], *self.gclock)[self.rank]
+        my = self.plan
+        n_edges = my.hi - my.lo + 1
+        self._ensure(n_edges)
+        self.e_lo = e0.value + my.lo * d.value
+        # close indices of my edges in LOCAL coordinates (entry 0 is -1 on ranks > 0: the open edge lies left)
+        self.clock, self.idx = self.t.time_bar_index(self.interval, clock_params=(n_edges, self.e_lo, d.value),
+                                                     out=(self._clock, self._idx))
+        self.out = {k: v.view(0, n_edges - 1) for k, v in self._out.items()}
+        last = self.rank + 1 == self.world
+        # one 8-byte read-back; it also orders this step's halo receive after the previous step's kernels
+        c_last = int(self.idx.view(n_edges - 1, 1).to_host()[0])
+        if last:
+            c_last = self.t.n
+        self.send_start = c_last
+        # bars that need no halo: all of them on rank 0, bars 1.. elsewhere (their ticks are local and the
+        # halo only prepends, so local coordinates are valid)
+        if self.rank == 0:
+            self.t.bar_ohlcv(self.idx, want_median=self.want_median, out=self.out)
+        elif n_edges > 2:
+            self.t.bar_ohlcv(self.idx.view(1), want_median=self.want_median,
+                             out={k: v.view(1) for k, v in self.out.items()})
+        return 0 if last else self.t.n - c_last
+
+    def finish(self, recv_h: int) -> int:
+        from ._ffi import c_i64
+        if self.rank > 0:
+            if recv_h < 1 or recv_h > self.headroom:
+                raise RuntimeError(f"rank {self.rank}: halo of {recv_h} ticks (headroom {self.headroom})")
+            th = self.t.with_halo(recv_h)
+            # [open edge, first close] in [halo | shard] coordinates: the open edge is the halo's first tick
+            self.ctx.call("fmk_time_bar_indexer_dev", th.ts.p, c_i64(th.n), c_i64(self.e_lo), c_i64(self.gclock[2]),
+                          c_i64(2), None, self._ci0.p)
+            th.bar_ohlcv(self._ci0, want_median=self.want_median, out={k: v.view(0, 1) for k, v in self.out.items()})
+        return self.plan.n_bars
+
+
 def halo_lengths(comm: Comm, n_local: int, close_of_last_edge: int) -> Tuple[int, int]:
     """(halo I send, halo I receive).  The halo is ticks [close_of_last_edge, n_local)."""
     send = n_local - close_of_last_edge if comm.rank + 1 < comm.world else 0

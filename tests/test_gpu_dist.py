@@ -1,0 +1,69 @@
+"""GPU: the sharded time-bar step of finmlkit_amd/dist.py (what bench.py runs at --gpus N > 1), driven with W
+virtual ranks on ONE device: the halo travels by a device copy instead of RCCL, everything else -- global clock,
+edge plan, local index, interior bars before the halo arrives, boundary bar from [halo | shard] -- is the code
+the real ranks execute.  The concatenated per-rank outputs must equal one un-sharded run, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HALO = 1 << 16
+KEYS = ["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"]
+
+
+def _run_sharded(engine, dist, ctx, world, n, gap_mod, interval, want_median=True, steps=1):
+    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, gap_mod=gap_mod, ctx=ctx, headroom=HALO)
+              for r in range(world)]
+    ranks = [dist.ShardedTimeBars(t, r, world, interval, want_median) for r, t in enumerate(shards)]
+    for _ in range(steps):                                     # a second step reuses the buffers
+        spans = [list(s.span()) for s in ranks]                # all-gather #1
+        send_h = [s.launch_local(spans) for s in ranks]        # all-gather #2
+        for r in range(1, world):                              # the halo: left rank's tail -> my headroom
+            h = send_h[r - 1]
+            assert 1 <= h <= HALO
+            for src, dst in zip(shards[r - 1]._backing, shards[r]._backing):
+                s = src.view(HALO + ranks[r - 1].send_start, h)
+                d = dst.view(HALO - h, h)
+                ctx.call("fmk_d2d", d.p, s.p, C.c_size_t(s.nbytes))
+        assert send_h[-1] == 0
+        nb = [s.finish(send_h[r - 1] if r else 0) for r, s in enumerate(ranks)]
+    out = {k: np.concatenate([s.out[k].to_host()[:b] for s, b in zip(ranks, nb)]) for k in KEYS if want_median or k != KEYS[-1]}
+    clock = np.concatenate([ranks[0].clock.to_host()[:1]] + [s.clock.to_host()[1:b + 1] for s, b in zip(ranks, nb)])
+    return clock, out
+
+
+@pytest.mark.parametrize("world,n,sparse,interval", [(2, 400_000, False, 60.0), (3, 250_000, False, 60.0),
+                                                    (4, 100_000, False, 300.0), (2, 300_000, True, 60.0),
+                                                    (8, 60_000, False, 60.0)])
+def test_virtual_ranks_match_unsharded(orc, world, n, sparse, interval):
+    from finmlkit_amd import _ffi, dist, engine
+    ctx = _ffi.default_context()
+    gap = engine.SPARSE_GAP_MOD if sparse else engine.DENSE_GAP_MOD
+    clock, got = _run_sharded(engine, dist, ctx, world, n, gap, interval, steps=2)
+    whole = engine.DeviceTrades.synth(world * n, seed=42, gap_mod=gap, ctx=ctx)
+    wclock, wci = whole.time_bar_index(interval)
+    want = engine.to_host(whole.bar_ohlcv(wci))
+    np.testing.assert_array_equal(clock, wclock.to_host())
+    for k in KEYS:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)   # same kernels, same ticks -> identical
+    # and against the oracle (vwap: tree vs sequential order)
+    ts, px, am, sd = orc.synth(42, 0, world * n, gap)
+    oclk, oci = orc._time_bar_indexer(ts, interval)
+    np.testing.assert_array_equal(clock, oclk)
+    for k, w in zip(KEYS, orc.comp_bar_ohlcv(px, am, oci)):
+        if k == "vwap":
+            np.testing.assert_allclose(got[k], w, rtol=1e-9)
+        else:
+            np.testing.assert_array_equal(got[k], w, err_msg=k)
+
+
+def test_shard_without_complete_bar_is_rejected():
+    from finmlkit_amd import _ffi, dist, engine
+    ctx = _ffi.default_context()
+    shards = [engine.DeviceTrades.synth(500, seed=1, first=r * 500, ctx=ctx, headroom=HALO) for r in range(2)]
+    ranks = [dist.ShardedTimeBars(t, r, 2, 3600.0) for r, t in enumerate(shards)]
+    spans = [list(s.span()) for s in ranks]
+    with pytest.raises(ValueError, match="complete bar close"):
+        ranks[1].launch_local(spans)
