@@ -293,4 +293,27 @@ int fmk_ewmst(fmk_ctx *ctx, const int64_t *ts, const double *y, int64_t n, doubl
     return down(ctx, out, d_o, n);
 }
 
+int fmk_ewms(fmk_ctx *ctx, const double *y, int64_t n, int64_t span, double *out)
+{
+    if (n <= 0) return FMK_OK;
+    DevBag bag(ctx);
+    double *d_y, *d_o;
+    FMK_TRY(bag.up(y, n, &d_y));
+    FMK_TRY(bag.out(n, &d_o));
+    FMK_TRY(fmk_ewms_dev(ctx, d_y, n, span, d_o));
+    return down(ctx, out, d_o, n);
+}
+
+int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, int is_sample, double *out)
+{
+    if (window < 1) return fmk_set_error(ctx, FMK_E_ARG, "window must be at least 1");
+    if (n <= 0) return FMK_OK;
+    DevBag bag(ctx);
+    double *d_r, *d_o;
+    FMK_TRY(bag.up(r, n, &d_r));
+    FMK_TRY(bag.out(n, &d_o));
+    FMK_TRY(fmk_realized_vol_dev(ctx, d_r, n, window, is_sample, d_o));
+    return down(ctx, out, d_o, n);
+}
+
 }  // extern "C"

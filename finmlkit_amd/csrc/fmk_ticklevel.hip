@@ -165,18 +165,30 @@ __device__ __forceinline__ EwMap ew_compose(const EwMap &f, const EwMap &g)
     return r;
 }
 
-// the reference's per-tick update as a map (volatility.py:176-201 / 110-124)
-template <bool MEAN0>
+// MODE 0: ewmst (volatility.py:139-219)   1: ewmst_mean0 (:72-136)   2: ewms (:9-69; fixed alpha, no timestamps --
+// `half_life` then carries one_minus_alpha and the four states are Sw, Sw2, Sy, Sy2)
+// the reference's per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52)
+template <int MODE>
 __device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y, double half_life)
 {
+    const bool nan = isnan(y);
+    EwMap m;
+    if constexpr (MODE == 2) {
+        const double om = half_life;
+        m.a = om;
+        m.a2 = om * om;
+        m.bV = nan ? 0.0 : 1.0;
+        m.bV2 = nan ? 0.0 : 1.0;
+        m.bSy = nan ? 0.0 : y;
+        m.bSyy = nan ? 0.0 : y * y;
+        return m;
+    }
     const double dt = (double)(t_cur - t_prev) / 1e9;
     const double alpha = 1.0 - exp(-dt / half_life);
     const double om = 1.0 - alpha;
-    const bool nan = isnan(y);
-    EwMap m;
     m.a = om;
     m.a2 = om * om;
-    if constexpr (MEAN0) {
+    if constexpr (MODE == 1) {
         m.bV = nan ? 0.0 : alpha;            // V  (weights) : decays only on NaN
         m.bV2 = 0.0;
         m.bSy = 0.0;
@@ -191,15 +203,23 @@ __device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y
 }
 
 // sequentially apply one tick to a state, in the reference's exact operation order
-template <bool MEAN0>
+template <int MODE>
 __device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, double &Syy, int64_t t_prev, int64_t t_cur,
                                         double y, double half_life)
 {
+    const bool nan = isnan(y);
+    if constexpr (MODE == 2) {
+        const double om = half_life, w = nan ? 0.0 : 1.0;
+        V = om * V + w;
+        V2 = (om * om) * V2 + w;
+        if (nan) { Sy = om * Sy; Syy = om * Syy; }
+        else { Sy = om * Sy + y; Syy = om * Syy + y * y; }
+        return;
+    }
     const double dt = (double)(t_cur - t_prev) / 1e9;
     const double alpha = 1.0 - exp(-dt / half_life);
     const double om = 1.0 - alpha;
-    const bool nan = isnan(y);
-    if constexpr (MEAN0) {
+    if constexpr (MODE == 1) {
         if (nan) { Syy = om * Syy; V = om * V; }
         else { Syy = alpha * (y * y) + om * Syy; V = alpha + om * V; }
     } else {
@@ -210,10 +230,18 @@ __device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, doubl
     }
 }
 
-template <bool MEAN0>
+template <int MODE>
 __device__ __forceinline__ double ew_sigma(double V, double V2, double Sy, double Syy, double sigma_floor)
 {
-    if constexpr (MEAN0) {
+    if constexpr (MODE == 2) {                    // volatility.py:54-67
+        if (!(V > 0.0)) return NAN;
+        const double mean = Sy / V;
+        const double den = V - (V2 / V);
+        if (!(den > 0.0)) return NAN;
+        double var = (Syy / V - mean * mean) * V / den;
+        if (!(var > 0.0)) var = isnan(var) ? var : 0.0;
+        return sqrt(var);
+    } else if constexpr (MODE == 1) {
         double var = V > 0.0 ? Syy / V : NAN;     // volatility.py:127-133
         if (var < 0.0) var = 0.0;
         double s = sqrt(var);
@@ -282,7 +310,7 @@ __device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, con
         const int e = r * EW_THREADS + threadIdx.x;          // element of the tile
         const int64_t i = base + e;
         const int slot = (e >> 3) * 9 + (e & 7);
-        s_ts[slot] = i < n ? ts[i] : 0;
+        s_ts[slot] = (ts && i < n) ? ts[i] : 0;
         s_y[slot] = i < n ? y[i] : 0.0;
     }
     __syncthreads();
@@ -294,13 +322,13 @@ __device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, con
     const int64_t i0 = base + (int64_t)threadIdx.x * EW_ITEMS;
     int64_t tp = 0;
     if (threadIdx.x > 0) tp = s_ts[(threadIdx.x - 1) * 9 + 7];
-    else if (i0 >= 1 && i0 - 1 < n) tp = ts[i0 - 1];
+    else if (ts && i0 >= 1 && i0 - 1 < n) tp = ts[i0 - 1];
     *tprev0 = tp;
 }
 
 #define EW_LDS_ELEMS (EW_THREADS * 9)
 
-template <bool MEAN0>
+template <int MODE>
 __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], const double (&yl)[EW_ITEMS],
                                                int64_t tprev0, int64_t n, double half_life)
 {
@@ -310,8 +338,8 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k) {
         const int64_t i = i0 + k;
-        if (i >= 1 && i < n) {
-            m = ew_compose(m, ew_tick<MEAN0>(tprev, tl[k], yl[k], half_life));
+        if (i >= (MODE == 2 ? 0 : 1) && i < n) {          // ewms has no skipped first tick
+            m = ew_compose(m, ew_tick<MODE>(tprev, tl[k], yl[k], half_life));
             tprev = tl[k];
         } else if (i == 0 && n > 0) {
             tprev = tl[k];
@@ -320,7 +348,7 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
     return m;
 }
 
-template <bool MEAN0>
+template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__restrict__ ts,
                                                              const double *__restrict__ y, int64_t n,
                                                              double half_life, EwMap *__restrict__ tile_map)
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__re
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
     ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
-    EwMap m = ew_thread_map<MEAN0>(tl, yl, tprev0, n, half_life);
+    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life);
     EwMap tot;
     (void)ew_block_exclusive(m, lds, &tot);
     if (threadIdx.x == 0) tile_map[blockIdx.x] = tot;
@@ -380,7 +408,7 @@ static int ew_scan_maps(fmk_ctx *ctx, EwMap *maps, int64_t m, EwMap *work)
     return FMK_OK;
 }
 
-template <bool MEAN0>
+template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
                                                          int64_t n, double half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
     ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
-    EwMap m = ew_thread_map<MEAN0>(tl, yl, tprev0, n, half_life);
+    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life);
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     ex = ew_compose(tile_pre[blockIdx.x], ex);
@@ -406,10 +434,10 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
         const int64_t i = i0 + k;
         res[k] = NAN;                                              // volatility.py:174 (out[0])
         if (i >= n) continue;
-        if (i == 0) { tprev = tl[k]; continue; }
-        ew_step<MEAN0>(V, V2, Sy, Syy, tprev, tl[k], yl[k], half_life);
+        if (MODE != 2 && i == 0) { tprev = tl[k]; continue; }
+        ew_step<MODE>(V, V2, Sy, Syy, tprev, tl[k], yl[k], half_life);
         tprev = tl[k];
-        res[k] = ew_sigma<MEAN0>(V, V2, Sy, Syy, sigma_floor);
+        res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
     }
     // coalesced store through the (now free) LDS tile
     __syncthreads();
@@ -425,10 +453,10 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     }
 }
 
-extern "C" int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
-                             double sigma_floor, int mean0, double *d_out)
+template <int MODE>
+static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
+                  double sigma_floor, double *d_out)
 {
-    if (n <= 0) return FMK_OK;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t tiles = fmk_ceil_div(n, EW_TILE);
     // tile maps + the (geometrically shrinking) group maps of the hierarchical scan
@@ -441,14 +469,332 @@ extern "C" int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_
     FMK_TRY(fmk_scratch(ctx, (size_t)(tiles + work_maps + 2) * sizeof(EwMap), &scr));
     EwMap *tm = (EwMap *)scr;
     EwMap *work = tm + tiles;
-    if (mean0) k_ew_tile_maps<true><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, tm);
-    else k_ew_tile_maps<false><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, tm);
+    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, tm);
     FMK_LAUNCH_CHECK(ctx);
     FMK_TRY(ew_scan_maps(ctx, tm, tiles, work));
-    if (mean0)
-        k_ew_apply<true><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_out);
-    else
-        k_ew_apply<false><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_out);
+    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_out);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
+extern "C" int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
+                             double sigma_floor, int mean0, double *d_out)
+{
+    if (n <= 0) return FMK_OK;
+    return mean0 ? ew_run<1>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out)
+                 : ew_run<0>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out);
+}
+
+__global__ void k_fill_nan(double *out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = NAN;
+}
+
+/* ewms (volatility.py:9-69): fixed-alpha exponentially weighted std, alpha = 2/(span+1); span <= 1 -> all NaN */
+extern "C" int fmk_ewms_dev(fmk_ctx *ctx, const double *d_y, int64_t n, int64_t span, double *d_out)
+{
+    if (n <= 0) return FMK_OK;
+    if (span <= 1) {
+        FMK_HIP(ctx, hipSetDevice(ctx->device));
+        k_fill_nan<<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_out, n);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
+    const double alpha = 2.0 / ((double)span + 1.0);
+    return ew_run<2>(ctx, nullptr, d_y, n, 1.0 - alpha, 0.0, d_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// realized_vol (volatility.py:256-286): out[i] = sqrt(nansum(r[i-W+1..i]^2) / (valid - is_sample)), NaN unless
+// valid > 1 and i >= W-1.
+//
+// Rolling sums WITHOUT subtraction (a prefix-sum difference would cancel: one outlier return in the prefix destroys
+// the digits of a quiet window): the index axis is cut into segments of length W aligned at multiples of W; a
+// window [s, i] of length W covers a suffix of s's segment and a prefix of i's segment, so
+//     sum = suffix_in_segment[s] + prefix_in_segment[i]        (just prefix[i] when s starts a segment)
+// -- only additions of non-negative terms, relative error a few ulp like the reference's pairwise sum.
+// W <= RV_MAX_W: one kernel, the region [tile - (W-1), tile end) staged in LDS, both segmented scans in LDS/registers
+// (8 B/tick read + 8 written).  Larger W: segment scans through global scratch (one block per segment).
+// ---------------------------------------------------------------------------------------
+#define RV_THREADS 256
+#define RV_C 25                                  // region elements per thread (odd: conflict-free ds_read_b64)
+#define RV_R (RV_THREADS * RV_C)                 // 6400 region elements: 51200 B of squares + 12800 B of counts
+#define RV_MAX_W 2048
+
+// exclusive carry of a segmented sum across the block's threads, in thread order (REV = false) or reversed.
+// (s, f) = my chunk's aggregate: f = chunk contains a segment boundary, s = sum of the elements after (before,
+// when reversed) the last boundary -- or of the whole chunk if there is none.
+template <bool REV>
+__device__ __forceinline__ double rv_block_carry(double s, int f, double *w_s, int *w_f)
+{
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double os = REV ? __shfl_down(s, d, 64) : __shfl_up(s, d, 64);
+        const int of = REV ? __shfl_down(f, d, 64) : __shfl_up(f, d, 64);
+        const bool has = REV ? (lane + d < 64) : (lane >= d);
+        if (has) {
+            if (!f) s = os + s;
+            f |= of;
+        }
+    }
+    if (lane == (REV ? 0 : 63)) { w_s[w] = s; w_f[w] = f; }
+    __syncthreads();
+    // carry entering my wave
+    double cs = 0.0;
+    if (!REV) { for (int k = 0; k < w; ++k) cs = w_f[k] ? w_s[k] : cs + w_s[k]; }
+    else { for (int k = 3; k > w; --k) cs = w_f[k] ? w_s[k] : cs + w_s[k]; }
+    // neighbour lane's inclusive value
+    double ps = REV ? __shfl_down(s, 1, 64) : __shfl_up(s, 1, 64);
+    int pf = REV ? __shfl_down(f, 1, 64) : __shfl_up(f, 1, 64);
+    if (lane == (REV ? 63 : 0)) { ps = 0.0; pf = 0; }
+    __syncthreads();
+    return pf ? ps : cs + ps;
+}
+
+__global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__restrict__ r, int64_t n, int64_t W,
+                                                             int is_sample, int64_t T, double *__restrict__ out)
+{
+    __shared__ double s_sq[RV_R];
+    __shared__ unsigned short s_cnt[RV_R];
+    __shared__ double w_s[4];
+    __shared__ int w_f[4];
+    __shared__ int w_c[4];
+    const int tid = threadIdx.x, lane = fmk_lane(), wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const int64_t g0 = base - (W - 1);                 // global index of region element 0 (may be negative)
+    const int R = (int)(T + W - 1);                    // <= RV_R
+    for (int e = tid; e < RV_R; e += RV_THREADS) {
+        const int64_t g = g0 + e;
+        double v = NAN;
+        if (e < R && g >= 0 && g < n) v = r[g];
+        const bool ok = !isnan(v);
+        s_sq[e] = ok ? v * v : 0.0;
+        s_cnt[e] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int e0 = tid * RV_C;
+    double sq[RV_C], pre[RV_C];
+    int cn[RV_C];
+#pragma unroll
+    for (int k = 0; k < RV_C; ++k) { sq[k] = s_sq[e0 + k]; cn[k] = s_cnt[e0 + k]; }
+    int64_t m0 = (g0 + e0) % W;                        // position of my first element inside its segment
+    if (m0 < 0) m0 += W;
+    // ---- forward: prefix inside the segment
+    double run = 0.0;
+    int f = 0, csum = 0;
+    {
+        int64_t m = m0;
+#pragma unroll
+        for (int k = 0; k < RV_C; ++k) {
+            if (m == 0) { run = 0.0; f = 1; }
+            run += sq[k];
+            pre[k] = run;
+            csum += cn[k];
+            cn[k] = csum;                              // inclusive count inside my chunk
+            if (++m == W) m = 0;
+        }
+    }
+    const double cf = rv_block_carry<false>(run, f, w_s, w_f);
+    {
+        int64_t m = m0;
+        bool open = true;                              // no segment start seen yet -> the carry applies
+#pragma unroll
+        for (int k = 0; k < RV_C; ++k) {
+            if (m == 0) open = false;
+            if (open) pre[k] = cf + pre[k];
+            if (++m == W) m = 0;
+        }
+    }
+    // ---- plain inclusive count scan across threads
+    int cinc = csum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(cinc, d, 64);
+        if (lane >= d) cinc += o;
+    }
+    if (lane == 63) w_c[wv] = cinc;
+    __syncthreads();
+    int cbase = cinc - csum;
+    for (int k = 0; k < wv; ++k) cbase += w_c[k];
+    // ---- backward: suffix inside the segment (segment END at m == W-1)
+    double suf[RV_C];
+    run = 0.0;
+    f = 0;
+    {
+        int64_t m = m0 + RV_C - 1;
+        m %= W;
+#pragma unroll
+        for (int k = RV_C - 1; k >= 0; --k) {
+            if (m == W - 1) { run = 0.0; f = 1; }
+            run += sq[k];
+            suf[k] = run;
+            if (--m < 0) m = W - 1;
+        }
+    }
+    const double cb = rv_block_carry<true>(run, f, w_s, w_f);
+    {
+        int64_t m = (m0 + RV_C - 1) % W;
+        bool open = true;
+#pragma unroll
+        for (int k = RV_C - 1; k >= 0; --k) {
+            if (m == W - 1) open = false;
+            if (open) suf[k] = cb + suf[k];
+            if (--m < 0) m = W - 1;
+        }
+    }
+    // publish suffix sums + inclusive counts (every thread has its chunk in registers by now)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RV_C; ++k) { s_sq[e0 + k] = suf[k]; s_cnt[e0 + k] = (unsigned short)(cbase + cn[k]); }
+    __syncthreads();
+    double res[RV_C];
+    {
+        int64_t m = m0;
+#pragma unroll
+        for (int k = 0; k < RV_C; ++k) {
+            const int e = e0 + k;
+            const int es = e - (int)(W - 1);            // region element of the window start
+            double o = NAN;
+            if (es >= 0 && g0 + es >= 0) {              // i >= W-1
+                const double sum = (m == W - 1) ? pre[k] : s_sq[es] + pre[k];
+                const int valid = (cbase + cn[k]) - (es > 0 ? (int)s_cnt[es - 1] : 0);
+                if (valid > 1) o = sqrt(sum / (double)(is_sample ? valid - 1 : valid));
+            }
+            res[k] = o;
+            if (++m == W) m = 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RV_C; ++k) s_sq[e0 + k] = res[k];
+    __syncthreads();
+    for (int e = (int)(W - 1) + tid; e < R; e += RV_THREADS) {
+        const int64_t i = g0 + e;
+        if (i < n) out[i] = s_sq[e];
+    }
+}
+
+// ---- W > RV_MAX_W: per-segment scans through global scratch ------------------------------------------
+#define RVG_ITEMS 4
+#define RVG_CHUNK (RV_THREADS * RVG_ITEMS)
+
+// block-wide inclusive scan of (double, int) over RVG_CHUNK elements held RVG_ITEMS per thread (blocked layout);
+// returns totals through *ts / *tc
+__device__ __forceinline__ void rvg_scan(double (&v)[RVG_ITEMS], int (&c)[RVG_ITEMS], double *w_s, int *w_c,
+                                         double *ts, int *tc)
+{
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 1; k < RVG_ITEMS; ++k) { v[k] += v[k - 1]; c[k] += c[k - 1]; }
+    double s = v[RVG_ITEMS - 1];
+    int q = c[RVG_ITEMS - 1];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double os = __shfl_up(s, d, 64);
+        const int oq = __shfl_up(q, d, 64);
+        if (lane >= d) { s += os; q += oq; }
+    }
+    if (lane == 63) { w_s[w] = s; w_c[w] = q; }
+    __syncthreads();
+    double bs = __shfl_up(s, 1, 64);                  // exclusive prefix by shift, never by subtraction
+    if (lane == 0) bs = 0.0;
+    int bq = q - c[RVG_ITEMS - 1];
+    double tot = 0.0;
+    int totc = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < w) { bs += w_s[k]; bq += w_c[k]; }
+        tot += w_s[k];
+        totc += w_c[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RVG_ITEMS; ++k) { v[k] += bs; c[k] += bq; }
+    *ts = tot;
+    *tc = totc;
+}
+
+// one block per segment [b*W, min(n, (b+1)*W)): prefix (REV = false) or suffix (REV = true) sums of r^2 and of the
+// valid flags inside the segment
+template <bool REV>
+__global__ __launch_bounds__(RV_THREADS) void k_rv_segment_scan(const double *__restrict__ r, int64_t n, int64_t W,
+                                                                double *__restrict__ sums, int *__restrict__ cnts)
+{
+    __shared__ double w_s[4];
+    __shared__ int w_c[4];
+    const int64_t lo = (int64_t)blockIdx.x * W, hi = (lo + W < n) ? lo + W : n;
+    const int64_t len = hi - lo;
+    double carry = 0.0;
+    int ccarry = 0;
+    for (int64_t c0 = 0; c0 < len; c0 += RVG_CHUNK) {
+        double v[RVG_ITEMS];
+        int c[RVG_ITEMS];
+        int64_t idx[RVG_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RVG_ITEMS; ++k) {
+            const int64_t p = c0 + (int64_t)threadIdx.x * RVG_ITEMS + k;       // position along the scan direction
+            idx[k] = p < len ? (REV ? hi - 1 - p : lo + p) : -1;
+            const double x = idx[k] >= 0 ? r[idx[k]] : NAN;
+            const bool ok = !isnan(x);
+            v[k] = ok ? x * x : 0.0;
+            c[k] = ok ? 1 : 0;
+        }
+        double ts;
+        int tc;
+        rvg_scan(v, c, w_s, w_c, &ts, &tc);
+#pragma unroll
+        for (int k = 0; k < RVG_ITEMS; ++k)
+            if (idx[k] >= 0) { sums[idx[k]] = carry + v[k]; cnts[idx[k]] = ccarry + c[k]; }
+        carry += ts;
+        ccarry += tc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rv_combine(const double *__restrict__ pre, const int *__restrict__ cpre,
+                                                    const double *__restrict__ suf, const int *__restrict__ csuf,
+                                                    int64_t n, int64_t W, int is_sample, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double o = NAN;
+    const int64_t s = i - W + 1;
+    if (s >= 0) {
+        const bool whole = (s % W) == 0;
+        const double sum = whole ? pre[i] : suf[s] + pre[i];
+        const int valid = whole ? cpre[i] : csuf[s] + cpre[i];
+        if (valid > 1) o = sqrt(sum / (double)(is_sample ? valid - 1 : valid));
+    }
+    out[i] = o;
+}
+
+extern "C" int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, int64_t window, int is_sample,
+                                    double *d_out)
+{
+    if (window < 1) return fmk_set_error(ctx, FMK_E_ARG, "window must be at least 1");
+    if (n <= 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    if (window > n) {                                   // no full window anywhere
+        k_fill_nan<<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_out, n);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
+    if (window <= RV_MAX_W) {
+        const int64_t T = RV_R - (window - 1);
+        k_realized_vol<<<(unsigned)fmk_ceil_div(n, T), RV_THREADS, 0, ctx->stream>>>(d_r, n, window, is_sample, T, d_out);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, (size_t)n * 24 + 64, &scr));
+    double *pre = (double *)scr, *suf = pre + n;
+    int *cpre = (int *)(suf + n), *csuf = cpre + n;
+    const int64_t segs = fmk_ceil_div(n, window);
+    k_rv_segment_scan<false><<<(unsigned)segs, RV_THREADS, 0, ctx->stream>>>(d_r, n, window, pre, cpre);
+    FMK_LAUNCH_CHECK(ctx);
+    k_rv_segment_scan<true><<<(unsigned)segs, RV_THREADS, 0, ctx->stream>>>(d_r, n, window, suf, csuf);
+    FMK_LAUNCH_CHECK(ctx);
+    k_rv_combine<<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(pre, cpre, suf, csuf, n, window, is_sample, d_out);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }

@@ -209,6 +209,16 @@ class DeviceTrades:
                       C.c_int(bool(mean0)), out.p)
         return out
 
+    def ewms(self, y: DeviceArray, span: int) -> DeviceArray:
+        out = DeviceArray(self.ctx, y.n, np.float64)
+        self.ctx.call("fmk_ewms_dev", y.p, c_i64(y.n), c_i64(int(span)), out.p)
+        return out
+
+    def realized_vol(self, r: DeviceArray, window: int, is_sample: bool) -> DeviceArray:
+        out = DeviceArray(self.ctx, r.n, np.float64)
+        self.ctx.call("fmk_realized_vol_dev", r.p, c_i64(r.n), c_i64(int(window)), C.c_int(bool(is_sample)), out.p)
+        return out
+
 
 def to_host(d: Dict[str, DeviceArray]) -> Dict[str, np.ndarray]:
     return {k: v.to_host() for k, v in d.items()}

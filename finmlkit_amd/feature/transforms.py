@@ -1,4 +1,4 @@
-"""The tick-level transforms of the hot path: `ReturnT`, `EWMST` (+ `Compose`).
+"""The tick-level transforms of the hot path: `ReturnT`, `EWMST`, `RealizedVolatility` (+ `Compose`).
 
 Counterparts of finmlkit/feature/transforms.py:89-117 (ReturnT), :308-332 (EWMST) and the
 pipeline part of finmlkit/feature/kit.py:Compose (:630-720), enough to run the QuickStart flow
@@ -13,7 +13,7 @@ import numpy as np
 import pandas as pd
 
 from .core.utils import comp_lagged_returns
-from .core.volatility import ewmst
+from .core.volatility import ewmst, realized_vol
 
 
 class SISOTransform:
@@ -80,6 +80,19 @@ class EWMST(SISOTransform):
 
     def _hip(self, x):
         res = ewmst(self._get_timestamps(x), self._prepare_input_nb(x), self.half_life_sec)
+        return self._prepare_output_nb(x.index, res)
+
+
+class RealizedVolatility(SISOTransform):
+    """Rolling realised volatility of a return series (reference transforms.py:449-491)."""
+
+    def __init__(self, window: int, is_sample: bool = False, input_col: str = "ret"):
+        super().__init__(input_col, f"rv{window}")
+        self.window = window
+        self.is_sample = is_sample
+
+    def _hip(self, x):
+        res = realized_vol(self._prepare_input_nb(x).astype(np.float64), self.window, self.is_sample)
         return self._prepare_output_nb(x.index, res)
 
 

@@ -66,3 +66,60 @@ def test_ewmst_vs_oracle(orc, n, hl, mean0):
     f_gpu, f_cpu = (ewmst_mean0, orc.ewmst_mean0) if mean0 else (ewmst, orc.ewmst)
     got, want = f_gpu(ts, y, hl), f_cpu(ts, y, hl)
     G.assert_f64_close(got, want, rtol=RTOL, what=f"ewmst n={n} hl={hl}")
+
+
+def test_ewms_and_realized_vol_golden(orc):
+    from finmlkit_amd.feature.core.volatility import ewms, realized_vol
+    d = G.load("ticklevel")
+    rn = d["ret_5.0_1"].copy()
+    rn[1000:1010] = np.nan
+    for span in (2, 20, 500):
+        G.assert_f64_close(ewms(rn, span), d[f"ewms_{span}"], rtol=RTOL, what=f"ewms {span}")
+    for win, smp in ((2, 1), (50, 1), (50, 0)):
+        G.assert_f64_close(realized_vol(rn, win, bool(smp)), d[f"rv_{win}_{smp}"], rtol=1e-12, what=f"rv {win}")
+
+
+@pytest.mark.parametrize("n,span", [(1_000_000, 50), (300_001, 2), (4097, 100_000), (3, 5), (1000, 1), (1000, 0)])
+def test_ewms_vs_oracle(orc, n, span):
+    from finmlkit_amd.feature.core.volatility import ewms
+    rng = np.random.default_rng(span)
+    y = rng.normal(1e-5, 1e-4, n)
+    y[rng.random(n) < 0.02] = np.nan
+    y[:min(n, 3)] = np.nan
+    G.assert_f64_close(ewms(y, span), orc.ewms(y, span), rtol=RTOL, what=f"ewms n={n} span={span}")
+
+
+@pytest.mark.parametrize("n,window,sample", [(1_000_000, 100, True), (500_000, 1, False), (500_000, 2, True),
+                                             (300_000, 4096, False), (300_000, 2048, True), (300_000, 2047, False), (300_000, 6399, True),
+                                             (250_000, 4097, True), (200_000, 50_001, False), (6400, 6400, True),
+                                             (6401, 3, True), (12_801, 2049, False), (10, 11, True), (2, 2, False),
+                                             (777, 777, True)])
+def test_realized_vol_vs_oracle(orc, n, window, sample):
+    """Both code paths (LDS kernel for window <= 2048, segment scans beyond) incl. tile / segment edge sizes; one
+    huge outlier must not disturb the quiet windows around it (no prefix-sum cancellation)."""
+    from finmlkit_amd.feature.core.volatility import realized_vol
+    rng = np.random.default_rng(window)
+    r = rng.normal(0, 1e-5, n)
+    r[rng.random(n) < 0.03] = np.nan
+    if n > 1000:
+        r[n // 3] = 25.0                            # outlier: r^2 = 625 next to 1e-10
+        r[n // 2: n // 2 + 2 * min(window, n // 4)] = np.nan      # a run of NaNs longer than the window
+    got, want = realized_vol(r, window, sample), orc.realized_vol(r, window, sample)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    G.assert_f64_close(got, want, rtol=1e-12, what=f"rv n={n} w={window}")
+
+
+def test_realized_vol_errors_and_transform(orc):
+    import pandas as pd
+    from finmlkit_amd.feature.core.volatility import realized_vol
+    from finmlkit_amd.feature.transforms import RealizedVolatility
+    with pytest.raises(ValueError):
+        realized_vol(np.zeros(10), 0, True)
+    n = 20_000
+    ts, px, am, sd = orc.synth(5, 0, n)
+    r = np.diff(np.log(px), prepend=np.nan)
+    df = pd.DataFrame({"ret": r}, index=pd.to_datetime(ts))
+    tr = RealizedVolatility(30, is_sample=True)
+    out = tr(df)
+    assert out.name == "ret_rv30" and len(out) == n
+    G.assert_f64_close(out.values, orc.realized_vol(r, 30, True), rtol=1e-12, what="rv transform")
