@@ -1,0 +1,529 @@
+// fmk_barflow.hip -- order-flow features (comp_bar_directional_features, base.py:409-546) on LDS tiles, and the
+// cfg-4 FUSED pass: order-flow + footprints (comp_bar_footprints + comp_footprint_features, base.py:615-850) from
+// ONE read of price / amount / side (13 B/tick), on gfx950.
+//
+// Tiles.  A bar is streamed in tiles of up to 512 ticks: coalesced loads (price 512 B, amount 256 B, side 64 B per
+// instruction) -> LDS, stored TRANSPOSED so that lane k owns r = 1, 2, 4 or 8 CONSECUTIVE ticks (rows padded
+// r -> r+1: conflict-free ds_read_b64).
+//
+// Directional walk (bf_dir_tile).  Every lane walks its r ticks sequentially: running signed tick / volume /
+// dollar sums, their local min / max, buy / sell sums and the spread terms are plain register updates (previous tick
+// = previous loop iteration; the first tick of a lane reads the previous lane's last tick from LDS).  ONE wave scan
+// of the lane totals per tile (DPP, fmk_dpp.h) turns the local extrema into bar-level ones:
+//     min over the lane's ticks of (carry + exclusive lane prefix + local running sum).
+// The first version scanned every 64-tick chunk (3 scans per chunk); this schedule scans once per 512 ticks.
+//
+// k_bar_dir  : one wave per bar, directional only (fmk_comp_bar_directional_dev).
+// k_bar_flow2: TWO waves per bar sharing the tile -- both load it (alternate chunks, next tile's loads in flight
+//              while the current one is processed, double-buffered LDS, one s_barrier per tile), then wave 0 runs the
+//              directional walk while wave 1 feeds the footprint histogram (exact integer-unit path or tick-ordered
+//              float32 path, see fmk_footprint.hip) -- the two ALU / LDS-atomic bound halves run on different SIMDs
+//              and HBM is read once.  Bars wider than 128 levels get their footprint from k_bar_footprints afterwards.
+// float64 sums are combined in (lane-sequential, then tree) order: float32 outputs identical to the reference
+// except for rare 1-ulp flips on exact ties (tests/_golden.py).
+#include "fmk_footprint.h"
+
+struct FlowDirOut {
+    int64_t *ticks_buy, *ticks_sell;
+    float *volume_buy, *volume_sell, *dollars_buy, *dollars_sell;
+    float *mean_spread, *max_spread;
+    int64_t *cum_ticks_min, *cum_ticks_max;
+    float *cum_volumes_min, *cum_volumes_max, *cum_dollars_min, *cum_dollars_max;
+};
+static_assert(sizeof(FlowDirOut) == sizeof(fmk_directional_out), "ABI struct mismatch");
+
+#define BF_SLOTS 576                    // 64 rows x (8 + 1 pad)
+#define BF_INIT_MIN 1000000000          // base.py:459-464
+#define BF_INIT_MAX (-1000000000)
+#define BF_FUSED_LMAX 128               // widest footprint the fused kernel keeps in LDS next to the tiles
+
+struct FlowDir {                        // per-lane accumulators of one bar
+    double vb, vs, db, ds, cs, mxs;
+    double vmin, vmax, dmin, dmax;
+    int tmin, tmax, nbuy, nsell;
+    // wave-uniform
+    int carry_t;
+    double carry_v, carry_d;
+    double prev_price;
+    int prev_side;
+};
+
+__device__ __forceinline__ void bf_dir_init(FlowDir &d)
+{
+    d.vb = d.vs = d.db = d.ds = d.cs = d.mxs = 0.0;
+    d.vmin = d.dmin = 1e9; d.vmax = d.dmax = -1e9;       // base.py:461-464
+    d.tmin = BF_INIT_MIN; d.tmax = BF_INIT_MAX;
+    d.nbuy = d.nsell = 0;
+    d.carry_t = 0; d.carry_v = d.carry_d = 0.0;
+    d.prev_price = 0.0; d.prev_side = 0;
+}
+
+// slot of tick t of a tile whose lanes own r = 1 << lr consecutive ticks
+__device__ __forceinline__ int bf_slot(int t, int lr) { return (t >> lr) * ((1 << lr) + 1) + (t & ((1 << lr) - 1)); }
+
+// tile shape for `rem` remaining ticks: lanes own 1 << lr ticks, the tile holds tn of them
+__device__ __forceinline__ void bf_shape(int64_t rem, int &lr, int &tn)
+{
+    lr = rem > 256 ? 3 : (rem > 128 ? 2 : (rem > 64 ? 1 : 0));
+    tn = (int)(rem < ((int64_t)64 << lr) ? rem : ((int64_t)64 << lr));
+}
+
+// directional walk over one LDS tile (tn ticks, lanes own r = 1 << lr consecutive ones)
+template <typename AmtT>
+__device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const double *sP, const AmtT *sA, const int8_t *sS,
+                                            FlowDir &d)
+{
+    const int r = 1 << lr;
+    const int row = lane * (r + 1);
+    double pp = d.prev_price;
+    int ps = d.prev_side;
+    if (lane > 0) { pp = sP[row - 2]; ps = sS[row - 2]; }          // previous lane's last tick (row - 1 is its pad)
+    int rt = 0, ltmin = 0x7FFFFFFF, ltmax = (int)0x80000000;
+    double rv = 0.0, rd = 0.0, lvmin = INFINITY, lvmax = -INFINITY, ldmin = INFINITY, ldmax = -INFINITY;
+    for (int i = 0; i < r; ++i) {
+        const bool valid = lane * r + i < tn;
+        const double p = sP[row + i];
+        const double av = (double)sA[row + i];
+        const int sd = sS[row + i];
+        if (valid && sd != ps) {                             // base.py:495-500
+            const double sp = fabs(p - pp);
+            d.mxs = fmax(d.mxs, sp);
+            d.cs += sp;
+        }
+        pp = p; ps = sd;
+        const bool buy = valid && sd == 1, sell = valid && sd == -1;
+        const double pv = p * av;
+        if (buy) { d.vb += av; d.db += pv; d.nbuy += 1; }
+        if (sell) { d.vs += av; d.ds += pv; d.nsell += 1; }
+        if (buy || sell) {                                   // base.py:518-527: signed ticks only
+            rt += buy ? 1 : -1;
+            rv += buy ? av : -av;
+            rd += buy ? pv : -pv;
+            ltmin = rt < ltmin ? rt : ltmin; ltmax = rt > ltmax ? rt : ltmax;
+            lvmin = fmin(lvmin, rv); lvmax = fmax(lvmax, rv);
+            ldmin = fmin(ldmin, rd); ldmax = fmax(ldmax, rd);
+        }
+    }
+    // lane totals -> exclusive prefixes (one scan set per tile); local extrema -> bar extrema
+    const int it = fmk_dpp_iscan(rt, 0, FmkOpAdd());
+    const double iv = fmk_dpp_iscan(rv, 0.0, FmkOpAdd());
+    const double id = fmk_dpp_iscan(rd, 0.0, FmkOpAdd());
+    const int et = fmk_dpp_shift_up1(it, 0);
+    const double ev = fmk_dpp_shift_up1(iv, 0.0), ed = fmk_dpp_shift_up1(id, 0.0);
+    if (ltmin != 0x7FFFFFFF) {
+        const int bt = d.carry_t + et;
+        const double bv = d.carry_v + ev, bd = d.carry_d + ed;
+        d.tmin = bt + ltmin < d.tmin ? bt + ltmin : d.tmin;
+        d.tmax = bt + ltmax > d.tmax ? bt + ltmax : d.tmax;
+        d.vmin = fmin(d.vmin, bv + lvmin); d.vmax = fmax(d.vmax, bv + lvmax);
+        d.dmin = fmin(d.dmin, bd + ldmin); d.dmax = fmax(d.dmax, bd + ldmax);
+    }
+    d.carry_t += fmk_last_lane(it);
+    d.carry_v += fmk_last_lane(iv);
+    d.carry_d += fmk_last_lane(id);
+    const int last = bf_slot(tn - 1, lr);
+    d.prev_price = __longlong_as_double(fmk_uniform((int64_t)__double_as_longlong(sP[last])));
+    d.prev_side = fmk_uniform((int)sS[last]);
+}
+
+// fold the lanes and write the 14 per-bar outputs
+__device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int lane, const FlowDir &d,
+                                            unsigned long long *n_zero_div)
+{
+    const double vb = fmk_dpp_reduce(d.vb, 0.0, FmkOpAdd()), vs = fmk_dpp_reduce(d.vs, 0.0, FmkOpAdd());
+    const double db = fmk_dpp_reduce(d.db, 0.0, FmkOpAdd()), ds = fmk_dpp_reduce(d.ds, 0.0, FmkOpAdd());
+    const double cs = fmk_dpp_reduce(d.cs, 0.0, FmkOpAdd()), mxs = fmk_dpp_reduce(d.mxs, 0.0, FmkOpMax());
+    const int tb = fmk_dpp_reduce(d.nbuy, 0, FmkOpAdd()), tsell = fmk_dpp_reduce(d.nsell, 0, FmkOpAdd());
+    const int tmin = fmk_dpp_reduce(d.tmin, BF_INIT_MIN, FmkOpMin());
+    const int tmax = fmk_dpp_reduce(d.tmax, BF_INIT_MAX, FmkOpMax());
+    const double vmin = fmk_dpp_reduce(d.vmin, 1e9, FmkOpMin()), vmax = fmk_dpp_reduce(d.vmax, -1e9, FmkOpMax());
+    const double dmin = fmk_dpp_reduce(d.dmin, 1e9, FmkOpMin()), dmax = fmk_dpp_reduce(d.dmax, -1e9, FmkOpMax());
+    if (lane == 0) {
+        o.ticks_buy[b] = tb; o.ticks_sell[b] = tsell;
+        o.volume_buy[b] = (float)vb; o.volume_sell[b] = (float)vs;
+        o.dollars_buy[b] = (float)db; o.dollars_sell[b] = (float)ds;
+        o.max_spread[b] = (float)mxs;
+        if (tb + tsell == 0) {       // reference: ZeroDivisionError (base.py:536)
+            o.mean_spread[b] = NAN;
+            if (n_zero_div) atomicAdd(n_zero_div, 1ULL);
+        } else {
+            o.mean_spread[b] = (float)(cs / (double)(tb + tsell));
+        }
+        o.cum_ticks_min[b] = tmin; o.cum_ticks_max[b] = tmax;
+        o.cum_volumes_min[b] = (float)vmin; o.cum_volumes_max[b] = (float)vmax;
+        o.cum_dollars_min[b] = (float)dmin; o.cum_dollars_max[b] = (float)dmax;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// directional only: one wave per bar
+// ---------------------------------------------------------------------------------------
+template <bool AF64>
+__global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ price, const void *__restrict__ amount,
+                                                 const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                 int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    __shared__ double s_p[4][BF_SLOTS];
+    __shared__ AmtT s_a[4][BF_SLOTS];
+    __shared__ int8_t s_s[4][640];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    double *sP = s_p[wib];
+    AmtT *sA = s_a[wib];
+    int8_t *sS = s_s[wib];
+    const AmtT *am = (const AmtT *)amount;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t start = s + 1;
+        FlowDir d;
+        bf_dir_init(d);
+        if (e > s) {
+            d.prev_price = price[fmk_wrap(start - 1, n)];
+            d.prev_side = e - s > 1 ? (int)side[fmk_wrap(start - 1, n)] : 0;    // base.py:485-488
+        }
+        int64_t j0 = start, rem = e - s;
+        while (rem > 0) {
+            int lr, tn;
+            bf_shape(rem, lr, tn);
+            // uniform base pointer + 32-bit lane offset: one address VGPR for all chunks.  No register prefetch of
+            // the next tile: the other waves of the SIMD cover the load latency (keeps the kernel at 4 waves/SIMD).
+            const double *pb = price + j0;
+            const AmtT *ab = am + j0;
+            const int8_t *sb = side + j0;
+            double pr[8];
+            AmtT ar[8];
+            int sr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pr[c] = 0.0; ar[c] = 0; sr[c] = 0;
+                const int t = c * 64 + lane;
+                if (c < (1 << lr) && t < tn) { pr[c] = pb[t]; ar[c] = ab[t]; sr[c] = sb[t]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < (1 << lr)) {
+                    const int sl = bf_slot(c * 64 + lane, lr);
+                    sP[sl] = pr[c]; sA[sl] = ar[c]; sS[sl] = (int8_t)sr[c];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf_dir_tile<AmtT>(lane, lr, tn, sP, sA, sS, d);
+            __builtin_amdgcn_wave_barrier();
+            j0 += tn;
+            rem -= tn;
+        }
+        bf_dir_emit(o, b, lane, d, n_zero_div);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// footprint histogram update from one LDS tile, in chunk (= tick) order
+// ---------------------------------------------------------------------------------------
+struct FpLane {          // per-lane statistics of one sweep (see FpStats)
+    int lbmin;
+    double atot;
+    bool units_ok, bad;
+};
+
+template <bool AF64>
+__device__ __forceinline__ void bf_fp_tile(int mode, int lane, int lr, int tn, const double *sP, const void *sA_,
+                                           const int8_t *sS, int64_t low, int L, double tick, double inv_tick, float *vol,
+                                           int *cnt, int q, FpLane &f)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    const AmtT *sA = (const AmtT *)sA_;
+    unsigned *units = (unsigned *)vol;
+    const int r = 1 << lr;
+    for (int c = 0; c < r; ++c) {
+        const int t = c * 64 + lane;
+        const int sl = bf_slot(t, lr);
+        const double p = sP[sl];
+        const AmtT a = sA[sl];
+        const int sd = sS[sl];
+        bool pending = false;
+        int key = -1;
+        if (t < tn) {
+            const int64_t lvl = fp_level(p, tick, inv_tick) - low;    // base.py:700-707
+            if (lvl < 0 || lvl >= L) f.bad = true;                    // base.py:719
+            else if (sd == 1 || sd == -1) {
+                pending = true;
+                key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
+                const int lb = fp_lowbit_exp(a);
+                f.lbmin = lb < f.lbmin ? lb : f.lbmin;
+                f.atot += fabs((double)a);
+            }
+        }
+        if (mode == 1) {                                              // exact integer units of 2^q, order-free
+            if (pending) {
+                const double u = ldexp((double)a, -q);
+                const bool ok = u >= 0.0 && u < 2147483648.0 && u == rint(u);
+                f.units_ok &= ok;
+                if (ok) atomicAdd(&units[key], (unsigned)u);
+                atomicAdd(&cnt[key], 1);
+            }
+            continue;
+        }
+        // tick-ordered float32: group the pending lanes by key, chain the running value in lane order
+        uint64_t grp = 0;
+        for (uint64_t remm = __ballot(pending); remm != 0;) {
+            const int leader = __ffsll((unsigned long long)remm) - 1;
+            const int k = __builtin_amdgcn_readlane(key, leader);
+            const uint64_t m = __ballot(key == k);                    // non-pending lanes carry key -1
+            if (key == k) grp = m;
+            remm &= ~m;
+        }
+        const uint64_t below = grp & (((uint64_t)1 << lane) - 1);
+        const int rank = __popcll(below);
+        const int gsize = __popcll(grp);
+        const int prev_lane = rank > 0 ? 63 - __clzll((unsigned long long)below) : lane;
+        float acc = 0.f;
+        if (pending && rank == 0) {
+            acc = vol[key];
+            if constexpr (AF64) acc = (float)((double)acc + a);       // f32 element += f64 amount
+            else acc = acc + a;
+            cnt[key] += gsize;                                        // one writer per key: no atomic
+        }
+        const int rounds = fmk_dpp_reduce(gsize, 0, FmkOpMax());
+        for (int k = 1; k < rounds; ++k) {
+            const float v = __shfl(acc, prev_lane, 64);
+            if (pending && rank == k) {
+                if constexpr (AF64) acc = (float)((double)v + a);
+                else acc = v + a;
+            }
+        }
+        if (pending && rank == gsize - 1) vol[key] = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// fused: two waves per bar (wave 0 directional, wave 1 footprints) on shared, double-buffered tiles
+// ---------------------------------------------------------------------------------------
+template <bool AF64>
+__global__ __launch_bounds__(128, 8) void k_bar_flow2(const double *__restrict__ price, const void *__restrict__ amount,
+                                                      const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                      int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
+                                                      double tick, const double *__restrict__ lows, float m32,
+                                                      const int64_t *__restrict__ off, FpOut fo,
+                                                      unsigned long long *n_bad, int force_ordered)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    __shared__ double s_p[2][BF_SLOTS];
+    __shared__ AmtT s_a[2][BF_SLOTS];
+    __shared__ int8_t s_s[2][640];
+    __shared__ __attribute__((aligned(16))) unsigned char s_hist[BF_FUSED_LMAX * 24 + 256];
+    __shared__ int s_ctrl[2];
+    const int lane = fmk_lane();
+    const int role = fmk_uniform((int)(threadIdx.x >> 6));          // 0: directional, 1: footprints
+    const AmtT *am = (const AmtT *)amount;
+    float *vol = (float *)s_hist;                                     // [2*lmax]  buy = 2l, sell = 2l+1
+    int *cnt = (int *)(s_hist + BF_FUSED_LMAX * 8);                   // [2*lmax]
+    float *aux = (float *)(s_hist + BF_FUSED_LMAX * 16);              // [2*lmax]
+    int *stk = (int *)(s_hist + BF_FUSED_LMAX * 24);                  // 64 ints
+    const double inv_tick = 1.0 / tick;
+    int wq = FP_Q_UNKNOWN;        // quantum exponent the previous bar certified with (footprint wave)
+    int buf = 0;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t start = s + 1;
+        const int64_t base = fmk_uniform(off[b]);
+        const int L = (int)fmk_uniform(off[b + 1] - base);
+        const bool fp_this = L > 0 && L <= BF_FUSED_LMAX;            // wider bars: k_bar_footprints afterwards
+        FlowDir d;
+        bf_dir_init(d);
+        int64_t low = 0;
+        int mode = 0, qcur = wq;
+        bool retried = false;
+        if (role == 0) {
+            if (e > s) {
+                d.prev_price = price[fmk_wrap(start - 1, n)];
+                d.prev_side = e - s > 1 ? (int)side[fmk_wrap(start - 1, n)] : 0;    // base.py:485-488
+            }
+        } else if (fp_this) {
+            low = fp_level(lows[b], tick);
+            for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
+            __builtin_amdgcn_wave_barrier();
+            mode = (!force_ordered && wq != FP_Q_UNKNOWN) ? 1 : 2;
+        }
+        bool first_sweep = true;
+        for (;;) {                                                   // sweeps over the bar (block-uniform count)
+            FpLane f;
+            f.lbmin = FP_Q_UNKNOWN; f.atot = 0.0; f.units_ok = true; f.bad = false;
+            int64_t j0 = start, rem = e - s;
+            int lr, tn;
+            bf_shape(rem, lr, tn);
+            double pr[4];
+            AmtT ar[4];
+            int sr[4];
+            // my half of the first tile (chunks role, role + 2, ...)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pr[i] = 0.0; ar[i] = 0; sr[i] = 0;
+                const int c = 2 * i + role;
+                const int t = c * 64 + lane;
+                if (rem > 0 && c < (1 << lr) && t < tn) { pr[i] = (price + j0)[t]; ar[i] = (am + j0)[t]; sr[i] = (side + j0)[t]; }
+            }
+            while (rem > 0) {
+                double *sP = s_p[buf];
+                AmtT *sA = s_a[buf];
+                int8_t *sS = s_s[buf];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 2 * i + role;
+                    if (c < (1 << lr)) {
+                        const int sl = bf_slot(c * 64 + lane, lr);
+                        sP[sl] = pr[i]; sA[sl] = ar[i]; sS[sl] = (int8_t)sr[i];
+                    }
+                }
+                __syncthreads();          // tile visible to both waves; everybody is done with the other buffer
+                const int64_t j0n = j0 + tn, remn = rem - tn;
+                int lrn, tnn;
+                bf_shape(remn, lrn, tnn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                        // next tile's loads fly during the walk below
+                    pr[i] = 0.0; ar[i] = 0; sr[i] = 0;
+                    const int c = 2 * i + role;
+                    const int t = c * 64 + lane;
+                    if (remn > 0 && c < (1 << lrn) && t < tnn) { pr[i] = (price + j0n)[t]; ar[i] = (am + j0n)[t]; sr[i] = (side + j0n)[t]; }
+                }
+                if (role == 0) {
+                    if (first_sweep) bf_dir_tile<AmtT>(lane, lr, tn, sP, sA, sS, d);
+                } else if (mode != 0) {
+                    bf_fp_tile<AF64>(mode, lane, lr, tn, sP, sA, sS, low, L, tick, inv_tick, vol, cnt, qcur, f);
+                }
+                buf ^= 1;
+                j0 = j0n; rem = remn; lr = lrn; tn = tnn;
+            }
+            // ---- end of sweep: the footprint wave decides whether the bar needs another one
+            int again = 0;
+            if (role == 1 && mode != 0) {
+                FpStats st;
+                st.lbmin = fmk_dpp_reduce(f.lbmin, FP_Q_UNKNOWN, FmkOpMin());
+                st.atot = fmk_dpp_reduce(f.atot, 0.0, FmkOpAdd());
+                st.units_ok = __ballot(!f.units_ok) == 0;
+                st.bad = __ballot(f.bad) != 0;
+                if (mode == 2) {
+                    // remember a usable quantum for the next bar (if this bar would have certified)
+                    FpStats probe = st;
+                    probe.units_ok = true;
+                    const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 && fp_certified(probe, st.lbmin);
+                    wq = usable ? st.lbmin : FP_Q_UNKNOWN;
+                } else if (fp_certified(st, qcur)) {                 // units -> float32 (exact)
+                    wq = qcur;
+                    unsigned *units = (unsigned *)vol;
+                    for (int k = lane; k < 2 * L; k += 64) vol[k] = ldexpf((float)units[k], qcur);
+                } else {
+                    // the bar's own statistics give the right quantum for ONE exact retry, else the ordered sweep
+                    for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
+                    const int q2 = st.lbmin;
+                    FpStats probe = st;
+                    probe.units_ok = true;
+                    if (!retried && q2 != FP_Q_UNKNOWN && q2 != (int)0x80000000 && fp_certified(probe, q2)) { qcur = q2; retried = true; }
+                    else mode = 2;
+                    again = 1;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!again && st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
+                if (lane == 0) s_ctrl[0] = again;
+            } else if (role == 1 && lane == 0) {
+                s_ctrl[0] = 0;
+            }
+            __syncthreads();
+            again = s_ctrl[0];
+            __syncthreads();
+            first_sweep = false;
+            if (!again) break;
+        }
+        if (role == 0) bf_dir_emit(o, b, lane, d, n_zero_div);
+        else if (fp_this) fp_emit_bar(fo, b, base, L, low, BF_FUSED_LMAX, m32, lane, vol, cnt, aux, stk);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                            int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                                            int64_t n_idx, const int8_t *d_side, const fmk_directional_out *d_out,
+                                            int64_t *d_n_zero_div)
+{
+    if (n_idx < 2)
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_directional: bad arguments");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nb = n_idx - 1;
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 64;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    FlowDirOut o;
+    memcpy(&o, d_out, sizeof(o));
+    if (amount_is_f64)
+        k_bar_dir<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                                 (unsigned long long *)d_n_zero_div);
+    else
+        k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                                  (unsigned long long *)d_n_zero_div);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
+extern "C" int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                                       int64_t n, const int64_t *d_close_idx, int64_t n_idx, double price_tick_size,
+                                       double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                                       double *d_vwap, int64_t *d_trades, double *d_median, int64_t *d_level_offsets,
+                                       int64_t *total_levels, int64_t *max_levels)
+{
+    FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
+                                   d_close, d_volume, d_vwap, d_trades, d_median));
+    return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets,
+                                            total_levels, max_levels);
+}
+
+extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                                       int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
+                                       const fmk_directional_out *d_dir, int64_t *d_n_zero_div, double price_tick_size,
+                                       const double *d_bar_lows, double imbalance_factor,
+                                       const int64_t *d_level_offsets, int64_t max_levels,
+                                       const fmk_footprint_out *d_fp, int64_t *d_n_bad_level)
+{
+    if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n <= 0 || !d_side || !d_dir || !d_fp) return fmk_set_error(ctx, FMK_E_ARG, "bars_fused: bad arguments");
+    if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
+    if (max_levels > FP_MAX_LEVELS)
+        return fmk_set_error(ctx, FMK_E_CAPACITY,
+                             "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
+                             (long long)max_levels, FP_MAX_LEVELS);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nb = n_idx - 1;
+    FlowDirOut o;
+    memcpy(&o, d_dir, sizeof(o));
+    FpOut fo;
+    memcpy(&fo, d_fp, sizeof(fo));
+    const float m32 = (float)imbalance_factor;   // float32 array * Python float -> float32 (NEP 50)
+    static int force_ordered = -1;               // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
+    if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
+    int64_t blocks = nb;
+    const int64_t cap = (int64_t)ctx->n_cu * 128;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (amount_is_f64)
+        k_bar_flow2<true><<<(unsigned)blocks, 128, 0, ctx->stream>>>(
+            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, price_tick_size,
+            d_bar_lows, m32, d_level_offsets, fo, (unsigned long long *)d_n_bad_level, force_ordered);
+    else
+        k_bar_flow2<false><<<(unsigned)blocks, 128, 0, ctx->stream>>>(
+            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, price_tick_size,
+            d_bar_lows, m32, d_level_offsets, fo, (unsigned long long *)d_n_bad_level, force_ordered);
+    FMK_LAUNCH_CHECK(ctx);
+    if (max_levels > BF_FUSED_LMAX)              // footprints of the wide bars (> 128 levels): streaming kernel
+        return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, nb, d_side,
+                                           price_tick_size, d_bar_lows, m32, d_level_offsets, BF_FUSED_LMAX, max_levels,
+                                           d_fp, d_n_bad_level);
+    return FMK_OK;
+}

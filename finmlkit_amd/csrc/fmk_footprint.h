@@ -1,0 +1,227 @@
+// fmk_footprint.h -- device helpers shared by the footprint kernels (fmk_footprint.hip, fmk_barflow.hip):
+// level rounding, NumPy's pairwise float32 summation, the exactness certificate of the integer-unit path and
+// comp_footprint_features on the per-wave LDS histogram (finmlkit/bar/base.py:615-850).
+#ifndef FMK_FOOTPRINT_H
+#define FMK_FOOTPRINT_H
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "fmk_common.h"
+#include "fmk_dpp.h"
+
+struct FpOut {
+    int32_t *price_levels;
+    float *buy_volumes, *sell_volumes;
+    int32_t *buy_ticks, *sell_ticks;
+    uint8_t *buy_imbalances, *sell_imbalances;
+    uint16_t *buy_imbalances_sum, *sell_imbalances_sum;
+    int32_t *cot_price_levels;
+    int16_t *imb_max_run_signed;
+    double *vp_skew, *vp_gini;
+};
+static_assert(sizeof(FpOut) == sizeof(fmk_footprint_out), "ABI struct mismatch");
+
+#define FP_MAX_LEVELS 2048
+#define FP_Q_UNKNOWN 0x7FFFFFFF
+
+// int(round(x)) with Python's round-half-even == rint() in the default rounding mode
+__device__ __forceinline__ int64_t fp_level(double price, double tick) { return (int64_t)rint(price / tick); }
+// Same value with one multiply instead of a float64 division on the per-tick path: price*(1/tick) and
+// price/tick differ by <= 3.3e-16 relative, so rint() can only disagree when the quotient is that close
+// to a half-integer -- in that (rare, divergent) case the exact division decides.
+__device__ __forceinline__ int64_t fp_level(double price, double tick, double inv_tick)
+{
+    const double q = price * inv_tick;
+    const double r = rint(q);
+    if (0.5 - fabs(q - r) <= fabs(q) * 1e-15) return (int64_t)rint(price / tick);
+    return (int64_t)r;
+}
+
+// ---------------------------------------------------------------------------------------
+// NumPy pairwise float32 sum over an LDS array, evaluated by the whole wave (uniform result)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fp_pw_leaf(const float *a, int n, int lane)
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    const int nm = n - (n & 7);
+    float r = 0.f;
+    if (lane < 8) {
+        r = a[lane];
+        for (int i = 8 + lane; i < nm; i += 8) r += a[i];
+    }
+    float t = r + __shfl_down(r, 1, 64);     // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
+    float u = t + __shfl_down(t, 2, 64);     // lanes 0,4
+    float res = __shfl(u, 0, 64) + __shfl(u, 4, 64);
+    for (int i = nm; i < n; ++i) res += a[i];
+    return res;
+}
+
+// stk: per-wave LDS scratch of 4*16 ints (explicit recursion stack: off, len, phase, left)
+__device__ __forceinline__ float fp_pairwise_f32(const float *a, int n, int lane, int *stk)
+{
+    if (n <= 128) return fp_pw_leaf(a, n, lane);
+    int *s_off = stk, *s_len = stk + 16, *s_ph = stk + 32;
+    float *s_left = (float *)(stk + 48);
+    int sp = 1;
+    if (lane == 0) { s_off[0] = 0; s_len[0] = n; s_ph[0] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    float ret = 0.f;
+    bool have = false;
+    while (sp > 0) {
+        const int top = sp - 1;
+        const int off = fmk_uniform(s_off[top]), len = fmk_uniform(s_len[top]), ph = fmk_uniform(s_ph[top]);
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (!have) {
+            if (len <= 128) { ret = fp_pw_leaf(a + off, len, lane); have = true; --sp; }
+            else {
+                if (lane == 0) { s_off[sp] = off; s_len[sp] = n2; s_ph[sp] = 0; }
+                ++sp;
+            }
+        } else {
+            if (ph == 0) {
+                if (lane == 0) { s_left[top] = ret; s_ph[top] = 1; s_off[sp] = off + n2; s_len[sp] = len - n2; s_ph[sp] = 0; }
+                ++sp;
+                have = false;
+            } else {
+                ret = __builtin_bit_cast(float, fmk_uniform(__builtin_bit_cast(int, s_left[top]))) + ret;
+                --sp;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------
+// histogram accumulation
+// ---------------------------------------------------------------------------------------
+// lowest set bit of |a| as a power-of-two exponent (INT_MAX for 0, INT_MIN for inf/NaN)
+__device__ __forceinline__ int fp_lowbit_exp(float a)
+{
+    const uint32_t u = __float_as_uint(a) & 0x7FFFFFFFu;
+    if (u == 0) return 0x7FFFFFFF;
+    const int ex = (int)(u >> 23);
+    const uint32_t mant = u & 0x7FFFFFu;
+    if (ex == 255) return (int)0x80000000;
+    if (ex == 0) return -149 + __builtin_ctz(mant);
+    return ex - 150 + __builtin_ctz(mant | 0x800000u);
+}
+__device__ __forceinline__ int fp_lowbit_exp(double a)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(a) & 0x7FFFFFFFFFFFFFFFull;
+    if (u == 0) return 0x7FFFFFFF;
+    const int ex = (int)(u >> 52);
+    const uint64_t mant = u & 0xFFFFFFFFFFFFFull;
+    if (ex == 2047) return (int)0x80000000;
+    if (ex == 0) return -1074 + __builtin_ctzll(mant);
+    return ex - 1075 + __builtin_ctzll(mant | (1ull << 52));
+}
+
+struct FpStats {
+    int lbmin;       // min lowest-set-bit exponent over the accumulated amounts (FP_Q_UNKNOWN if all zero)
+    double atot;     // sum of |amount|
+    bool units_ok;   // exact path only: every amount was a non-negative multiple of 2^q below 2^31 units
+    bool bad;        // a tick fell outside the level range (base.py:719)
+};
+
+// every float32 add of a bar with these statistics is exact at quantum 2^q
+__device__ __forceinline__ bool fp_certified(const FpStats &st, int q)
+{
+    if (st.lbmin == FP_Q_UNKNOWN) return true;                 // only zeros
+    return st.units_ok && q <= st.lbmin && q >= -149 && q <= 100 && st.atot < ldexp(1.0, 24 + q);
+}
+
+// Level rows + comp_footprint_features (base.py:755-850) of ONE bar from the wave's LDS histogram:
+//   vol[2L] float32 (buy = 2l, sell = 2l+1), cnt[2L], aux[2*lmax] scratch, stk[64] ints.  `base` = CSR row offset.
+__device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t base, int L, int64_t low, int lmax,
+                                            float m32, int lane, float *vol, int *cnt, float *aux, int *stk)
+{
+    // ---- pass A: write the level rows, total[l] = buy + sell (float32), argmax, vwap numerator
+    float *tot = aux;
+    float best = -INFINITY;
+    int best_i = 0x7FFFFFFF;
+    double num = 0.0;
+    for (int l = lane; l < L; l += 64) {
+        const float bv = vol[2 * l], sv = vol[2 * l + 1];
+        const int bc = cnt[2 * l], sc = cnt[2 * l + 1];
+        o.price_levels[base + l] = (int32_t)(low + l);
+        o.buy_volumes[base + l] = bv;
+        o.sell_volumes[base + l] = sv;
+        o.buy_ticks[base + l] = bc;
+        o.sell_ticks[base + l] = sc;
+        const float t = bv + sv;                                     // base.py:822
+        tot[l] = t;
+        if (t > best) { best = t; best_i = l; }                      // first argmax within my lanes
+        num += (double)(low + l) * (double)t;
+    }
+    // first argmax across lanes (ties -> lowest index)
+#pragma unroll
+    for (int x = 32; x > 0; x >>= 1) {
+        float ob = __shfl_xor(best, x, 64);
+        int oi = __shfl_xor(best_i, x, 64);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (best_i == 0x7FFFFFFF) best_i = 0;      // all-NaN / empty guard: np.argmax -> 0
+    num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
+    __builtin_amdgcn_wave_barrier();
+    const float total = fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()
+    const bool stats = total > 0.f && L > 0;                         // base.py:836
+    const double vwap = stats ? num / (double)total : 0.0;
+
+    // ---- pass B: imbalance flags, run signs, skew, q^2
+    int *sign = cnt;                           // cnt area is free now: sign[0..L), q2 at cnt + lmax
+    float *q2 = (float *)(cnt + lmax);
+    unsigned bsum = 0, ssum = 0;
+    double skew = 0.0;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        const int l = l0 + lane;
+        bool bi = false, si = false;
+        if (l < L) {
+            const float bv = vol[2 * l], sv = vol[2 * l + 1];
+            if (l < L - 1) si = sv > vol[2 * (l + 1)] * m32;          // base.py:797
+            if (l >= 1) bi = bv > vol[2 * (l - 1) + 1] * m32;         // base.py:798
+            o.buy_imbalances[base + l] = bi;
+            o.sell_imbalances[base + l] = si;
+            sign[l] = bi ? 1 : (si ? -1 : 0);
+            const float t = tot[l];
+            if (stats) {
+                skew += ((double)(low + l) - vwap) * (double)t;
+                const float q = t / total;
+                q2[l] = q * q;
+            }
+        }
+        bsum += __popcll(__ballot(bi));
+        ssum += __popcll(__ballot(si));
+    }
+    skew = fmk_dpp_reduce(skew, 0.0, FmkOpAdd());
+    __builtin_amdgcn_wave_barrier();
+    double gini = 0.0;
+    if (stats) gini = (double)(1.0f - fp_pairwise_f32(q2, L, lane, stk));   // base.py:847-848 (float32)
+    // ---- longest signed run (base.py:801-819), sequential over the levels
+    if (lane == 0) {
+        int max_run = 0, max_sign = 0, run = 0, run_sign = 0;
+        for (int l = 0; l < L; ++l) {
+            const int sg = sign[l];
+            if (sg != 0 && sg == run_sign) run += 1;
+            else if (sg != 0) { run = 1; run_sign = sg; }
+            else { run = 0; run_sign = 0; }
+            if (run > max_run) { max_run = run; max_sign = run_sign; }
+        }
+        o.buy_imbalances_sum[b] = (uint16_t)bsum;
+        o.sell_imbalances_sum[b] = (uint16_t)ssum;
+        o.cot_price_levels[b] = (int32_t)(low + best_i);
+        o.imb_max_run_signed[b] = (int16_t)(max_run * max_sign);
+        o.vp_skew[b] = stats ? skew / (double)total : 0.0;
+        o.vp_gini[b] = gini;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+#endif

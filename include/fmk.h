@@ -201,6 +201,25 @@ int fmk_comp_bar_trade_size(fmk_ctx *ctx, const void *amount, int amount_is_f64,
                             double theta_mult, float *mean_size_rel, float *size_95_rel,
                             float *pct_block, float *size_gini);
 
+/* ---- cfg 4: time bars + order-flow + footprints, fused ----------------------------------
+ * Two phases like comp_bar_footprints (the CSR row count must reach the caller's allocator):
+ *   size: comp_bar_ohlcv (incl. median when d_median != NULL) + the footprint level offsets from the
+ *         lows/highs it just produced (12 B/tick);
+ *   fill: comp_bar_directional_features + comp_bar_footprints + comp_footprint_features in ONE pass over
+ *         price/amount/side (13 B/tick) -- base.py:409-546, 615-850.
+ * Replaces BarBuilderBase.build_ohlcv + build_directional_features + build_footprints (base.py:126-300)
+ * called back to back (38 B/tick as three reducers). */
+int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, double price_tick_size,
+                            double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                            double *d_vwap, int64_t *d_trades, double *d_median, int64_t *d_level_offsets,
+                            int64_t *total_levels, int64_t *max_levels);
+int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
+                            const fmk_directional_out *d_dir, int64_t *d_n_zero_div, double price_tick_size,
+                            const double *d_bar_lows, double imbalance_factor, const int64_t *d_level_offsets,
+                            int64_t max_levels, const fmk_footprint_out *d_fp, int64_t *d_n_bad_level);
+
 /* ---- tick-level feature loops: finmlkit/feature/core ---------------------------------- */
 /* comp_lagged_returns (core/utils.py:12-64). */
 int fmk_comp_lagged_returns_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_close,

@@ -1,0 +1,114 @@
+"""GPU parity of the cfg-4 fused path (fmk_bars_fused_size_dev / fmk_bars_fused_fill_dev): OHLCV, then order-flow +
+footprints from ONE read of price/amount/side by the two-waves-per-bar kernel.  Checked against the CPU oracle, the
+reference-generated goldens and the separate reducers (same arithmetic -> identical bits)."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+from tests.test_gpu_features import INT_DIR, _check_dir, _check_fp
+
+pytestmark = pytest.mark.gpu
+
+OHLCV_KEYS = ["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"]
+
+
+def _fused(px, am, sd, ci, tick=0.01, imb=3.0):
+    from finmlkit_amd import engine
+    t = engine.DeviceTrades.from_numpy(np.zeros(len(px), np.int64), px, am, sd)
+    cid = engine.DeviceArray.from_host(t.ctx, np.ascontiguousarray(ci, dtype=np.int64))
+    o, d, nz, off, flat, bar, bad = t.bars_fused(cid, tick, imb)
+    return (t, cid, engine.to_host(o), engine.to_host(d), int(nz.to_host()[0]), off.to_host(), engine.to_host(flat),
+            engine.to_host(bar), int(bad.to_host()[0]))
+
+
+def _check_all(orc, px, am, sd, ci, what, tick=0.01):
+    t, cid, o, d, nz, off, flat, bar, bad = _fused(px, am, sd, ci, tick)
+    assert bad == 0
+    want_o = orc.comp_bar_ohlcv(px, am, ci)
+    for k, w in zip(OHLCV_KEYS, want_o):
+        if k == "vwap":
+            G.assert_f64_close(o[k], w, rtol=1e-9, what=f"{what}:vwap")
+        else:
+            np.testing.assert_array_equal(o[k], w, err_msg=f"{what}:{k}")
+    want_d = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    assert nz == int(np.isnan(want_d[6]).sum())
+    _check_dir(tuple(d[k] for k in G.DIR_KEYS), want_d, what)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, want_o[2], want_o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, what)
+    # the separate reducers run the same arithmetic: bit-identical
+    from finmlkit_amd import engine
+    d2, _ = t.bar_directional(cid)
+    for k, v in engine.to_host(d2).items():
+        np.testing.assert_array_equal(d[k], v, err_msg=f"{what}: fused vs separate {k}")
+    lows = engine.DeviceArray.from_host(t.ctx, o["low"])
+    highs = engine.DeviceArray.from_host(t.ctx, o["high"])
+    off2, flat2, bar2, _ = t.bar_footprints(cid, lows, highs, tick, 3.0)
+    np.testing.assert_array_equal(off, off2.to_host())
+    for k, v in {**engine.to_host(flat2), **engine.to_host(bar2)}.items():
+        got = flat[k] if k in flat else bar[k]
+        np.testing.assert_array_equal(got, v, err_msg=f"{what}: fused vs separate {k}")
+
+
+@pytest.mark.parametrize("case", ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37"])
+def test_fused_golden(orc, case):
+    d = G.load("reducers")
+    px, am, sd = G.reducer_stream(orc, d, case)
+    ci = d[f"{case}__ci"]
+    t, cid, o, dr, nz, off, flat, bar, bad = _fused(px, am, sd, ci)
+    assert bad == 0 and nz == 0
+    _check_dir(tuple(dr[k] for k in G.DIR_KEYS), tuple(d[f"{case}__dir_{k}"] for k in G.DIR_KEYS), case)
+    _check_fp(off, flat, bar, d[f"{case}__fp_offsets"], {k: d[f"{case}__fp_{k}"] for k in G.FP_LIST_KEYS},
+              {k: d[f"{case}__fp_{k}"] for k in G.FP_BAR_KEYS}, case)
+    np.testing.assert_array_equal(o["low"], d[f"{case}__ohlcv_low"])
+
+
+@pytest.mark.parametrize("n,interval,amounts,zeros", [
+    (400_000, 60.0, "dyadic", False),        # exact integer-unit footprint path
+    (300_000, 60.0, "lognormal32", False),   # float32 amounts with inexact sums: tick-ordered path
+    (200_000, 60.0, "f64", True),            # float64 amounts, unsigned ticks
+    (300_000, 1.0, "dyadic", True),          # tiny bars (1, 2, 4 ticks per lane tiles), unsigned ticks
+    (300_000, 7200.0, "dyadic", False),      # long bars: many tiles, > 128 levels -> streaming footprint kernel
+    (150_000, 7200.0, "lognormal32", False),
+    (100_000, 3.0, "mixed", False),          # dyadic with a few inexact amounts: exact -> retry / ordered switches
+    (130, 60.0, "dyadic", False), (1, 60.0, "dyadic", False),
+])
+def test_fused_vs_oracle(orc, n, interval, amounts, zeros):
+    ts, px, am, sd = orc.synth(17, 0, n)
+    rng = np.random.default_rng(3)
+    if amounts == "lognormal32":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    elif amounts == "f64":
+        am = rng.lognormal(-1, 1.2, n)
+    elif amounts == "mixed":
+        am = am.copy()
+        am[rng.random(n) < 0.002] = np.float32(0.3)
+    if zeros:
+        sd = sd.copy()
+        sd[rng.random(n) < 0.1] = 0
+    if n > 1:
+        _, ci = orc._time_bar_indexer(ts, interval)
+    else:
+        ci = np.array([-1, 0], dtype=np.int64)
+    _check_all(orc, px, am, sd, ci, f"n={n} iv={interval} {amounts}")
+
+
+def test_fused_sparse_stream_empty_bars(orc):
+    ts, px, am, sd = orc.synth(42, 0, 20_000, orc.SPARSE_GAP_MOD)
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    assert (np.diff(ci) == 0).any()
+    _check_all(orc, px, am, sd, ci, "sparse")
+
+
+def test_fused_bad_level_and_errors(orc):
+    from finmlkit_amd import _ffi
+    ts, px, am, sd = orc.synth(2, 0, 50_000)
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    with pytest.raises(ValueError):
+        _fused(px, am, sd, ci[:1])
+    with pytest.raises(ValueError):
+        _fused(px, am, sd, ci, tick=0.0)
+    # a coarser tick than the data's: levels stay inside [low, high], nothing is flagged
+    t, cid, o, d, nz, off, flat, bar, bad = _fused(px, am, sd, ci, tick=0.05)
+    assert bad == 0
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.05, o["low"], o["high"], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, "tick 0.05")
