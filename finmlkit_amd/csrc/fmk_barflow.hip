@@ -1,6 +1,5 @@
 // fmk_barflow.hip -- order-flow features (comp_bar_directional_features, base.py:409-546) on LDS tiles, and the
-// cfg-4 FUSED pass: order-flow + footprints (comp_bar_footprints + comp_footprint_features, base.py:615-850) from
-// ONE read of price / amount / side (13 B/tick), on gfx950.
+// cfg-4 entry points (OHLCV -> order-flow + footprints), on gfx950.
 //
 // Tiles.  A bar is streamed in tiles of up to 512 ticks: coalesced loads (price 512 B, amount 256 B, side 64 B per
 // instruction) -> LDS, stored TRANSPOSED so that lane k owns r = 1, 2, 4 or 8 CONSECUTIVE ticks (rows padded
@@ -13,12 +12,10 @@
 //     min over the lane's ticks of (carry + exclusive lane prefix + local running sum).
 // The first version scanned every 64-tick chunk (3 scans per chunk); this schedule scans once per 512 ticks.
 //
-// k_bar_dir  : one wave per bar, directional only (fmk_comp_bar_directional_dev).
-// k_bar_flow2: TWO waves per bar sharing the tile -- both load it (alternate chunks, next tile's loads in flight
-//              while the current one is processed, double-buffered LDS, one s_barrier per tile), then wave 0 runs the
-//              directional walk while wave 1 feeds the footprint histogram (exact integer-unit path or tick-ordered
-//              float32 path, see fmk_footprint.hip) -- the two ALU / LDS-atomic bound halves run on different SIMDs
-//              and HBM is read once.  Bars wider than 128 levels get their footprint from k_bar_footprints afterwards.
+// k_bar_dir: one wave per bar (fmk_comp_bar_directional_dev).  The other waves of the SIMD cover the load latency
+// of a tile; a register-prefetch pipeline across tiles and bars was measured and is not faster (3.13 vs 3.05 ms at
+// 1e9 ticks): the kernel is VALU-bound (~106 VALU instructions per 64 ticks), not latency-bound.
+// The cfg-4 entry points (fmk_bars_fused_size_dev / _fill_dev) live here as well.
 // float64 sums are combined in (lane-sequential, then tree) order: float32 outputs identical to the reference
 // except for rare 1-ulp flips on exact ties (tests/_golden.py).
 #include "fmk_footprint.h"
@@ -35,7 +32,6 @@ static_assert(sizeof(FlowDirOut) == sizeof(fmk_directional_out), "ABI struct mis
 #define BF_SLOTS 576                    // 64 rows x (8 + 1 pad)
 #define BF_INIT_MIN 1000000000          // base.py:459-464
 #define BF_INIT_MAX (-1000000000)
-#define BF_FUSED_LMAX 128               // widest footprint the fused kernel keeps in LDS next to the tiles
 
 struct FlowDir {                        // per-lane accumulators of one bar
     double vb, vs, db, ds, cs, mxs;
@@ -68,6 +64,22 @@ __device__ __forceinline__ void bf_shape(int64_t rem, int &lr, int &tn)
     tn = (int)(rem < ((int64_t)64 << lr) ? rem : ((int64_t)64 << lr));
 }
 
+// v_min_f64 / v_max_f64 without the canonicalising v_max_f64 x, x, x the compiler puts in front of fmin / fmax on loop
+// carried values (5 extra VALU instructions per tick in a VALU-bound loop).  Operands here are sums / earlier
+// min-max results, never signalling NaNs; a quiet NaN operand is ignored exactly like fmin / fmax do.
+__device__ __forceinline__ double bf_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double bf_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // directional walk over one LDS tile (tn ticks, lanes own r = 1 << lr consecutive ones)
 template <typename AmtT>
 __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const double *sP, const AmtT *sA, const int8_t *sS,
@@ -87,7 +99,7 @@ __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const doub
         const int sd = sS[row + i];
         if (valid && sd != ps) {                             // base.py:495-500
             const double sp = fabs(p - pp);
-            d.mxs = fmax(d.mxs, sp);
+            d.mxs = bf_max(d.mxs, sp);
             d.cs += sp;
         }
         pp = p; ps = sd;
@@ -100,8 +112,8 @@ __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const doub
             rv += buy ? av : -av;
             rd += buy ? pv : -pv;
             ltmin = rt < ltmin ? rt : ltmin; ltmax = rt > ltmax ? rt : ltmax;
-            lvmin = fmin(lvmin, rv); lvmax = fmax(lvmax, rv);
-            ldmin = fmin(ldmin, rd); ldmax = fmax(ldmax, rd);
+            lvmin = bf_min(lvmin, rv); lvmax = bf_max(lvmax, rv);
+            ldmin = bf_min(ldmin, rd); ldmax = bf_max(ldmax, rd);
         }
     }
     // lane totals -> exclusive prefixes (one scan set per tile); local extrema -> bar extrema
@@ -203,10 +215,13 @@ __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ pric
                 const int t = c * 64 + lane;
                 if (c < (1 << lr) && t < tn) { pr[c] = pb[t]; ar[c] = ab[t]; sr[c] = sb[t]; }
             }
+            // slot(c * 64 + lane) is linear in c: one multiply-add per chunk instead of shift / mask / multiply
+            const int slot0 = bf_slot(lane, lr);
+            const int cstride = (64 >> lr) * ((1 << lr) + 1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (c < (1 << lr)) {
-                    const int sl = bf_slot(c * 64 + lane, lr);
+                    const int sl = slot0 + c * cstride;
                     sP[sl] = pr[c]; sA[sl] = ar[c]; sS[sl] = (int8_t)sr[c];
                 }
             }
@@ -217,230 +232,6 @@ __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ pric
             rem -= tn;
         }
         bf_dir_emit(o, b, lane, d, n_zero_div);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// footprint histogram update from one LDS tile, in chunk (= tick) order
-// ---------------------------------------------------------------------------------------
-struct FpLane {          // per-lane statistics of one sweep (see FpStats)
-    int lbmin;
-    double atot;
-    bool units_ok, bad;
-};
-
-template <bool AF64>
-__device__ __forceinline__ void bf_fp_tile(int mode, int lane, int lr, int tn, const double *sP, const void *sA_,
-                                           const int8_t *sS, int64_t low, int L, double tick, double inv_tick, float *vol,
-                                           int *cnt, int q, FpLane &f)
-{
-    typedef typename std::conditional<AF64, double, float>::type AmtT;
-    const AmtT *sA = (const AmtT *)sA_;
-    unsigned *units = (unsigned *)vol;
-    const int r = 1 << lr;
-    for (int c = 0; c < r; ++c) {
-        const int t = c * 64 + lane;
-        const int sl = bf_slot(t, lr);
-        const double p = sP[sl];
-        const AmtT a = sA[sl];
-        const int sd = sS[sl];
-        bool pending = false;
-        int key = -1;
-        if (t < tn) {
-            const int64_t lvl = fp_level(p, tick, inv_tick) - low;    // base.py:700-707
-            if (lvl < 0 || lvl >= L) f.bad = true;                    // base.py:719
-            else if (sd == 1 || sd == -1) {
-                pending = true;
-                key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
-                const int lb = fp_lowbit_exp(a);
-                f.lbmin = lb < f.lbmin ? lb : f.lbmin;
-                f.atot += fabs((double)a);
-            }
-        }
-        if (mode == 1) {                                              // exact integer units of 2^q, order-free
-            if (pending) {
-                const double u = ldexp((double)a, -q);
-                const bool ok = u >= 0.0 && u < 2147483648.0 && u == rint(u);
-                f.units_ok &= ok;
-                if (ok) atomicAdd(&units[key], (unsigned)u);
-                atomicAdd(&cnt[key], 1);
-            }
-            continue;
-        }
-        // tick-ordered float32: group the pending lanes by key, chain the running value in lane order
-        uint64_t grp = 0;
-        for (uint64_t remm = __ballot(pending); remm != 0;) {
-            const int leader = __ffsll((unsigned long long)remm) - 1;
-            const int k = __builtin_amdgcn_readlane(key, leader);
-            const uint64_t m = __ballot(key == k);                    // non-pending lanes carry key -1
-            if (key == k) grp = m;
-            remm &= ~m;
-        }
-        const uint64_t below = grp & (((uint64_t)1 << lane) - 1);
-        const int rank = __popcll(below);
-        const int gsize = __popcll(grp);
-        const int prev_lane = rank > 0 ? 63 - __clzll((unsigned long long)below) : lane;
-        float acc = 0.f;
-        if (pending && rank == 0) {
-            acc = vol[key];
-            if constexpr (AF64) acc = (float)((double)acc + a);       // f32 element += f64 amount
-            else acc = acc + a;
-            cnt[key] += gsize;                                        // one writer per key: no atomic
-        }
-        const int rounds = fmk_dpp_reduce(gsize, 0, FmkOpMax());
-        for (int k = 1; k < rounds; ++k) {
-            const float v = __shfl(acc, prev_lane, 64);
-            if (pending && rank == k) {
-                if constexpr (AF64) acc = (float)((double)v + a);
-                else acc = v + a;
-            }
-        }
-        if (pending && rank == gsize - 1) vol[key] = acc;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// fused: two waves per bar (wave 0 directional, wave 1 footprints) on shared, double-buffered tiles
-// ---------------------------------------------------------------------------------------
-template <bool AF64>
-__global__ __launch_bounds__(128, 8) void k_bar_flow2(const double *__restrict__ price, const void *__restrict__ amount,
-                                                      const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
-                                                      int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
-                                                      double tick, const double *__restrict__ lows, float m32,
-                                                      const int64_t *__restrict__ off, FpOut fo,
-                                                      unsigned long long *n_bad, int force_ordered)
-{
-    typedef typename std::conditional<AF64, double, float>::type AmtT;
-    __shared__ double s_p[2][BF_SLOTS];
-    __shared__ AmtT s_a[2][BF_SLOTS];
-    __shared__ int8_t s_s[2][640];
-    __shared__ __attribute__((aligned(16))) unsigned char s_hist[BF_FUSED_LMAX * 24 + 256];
-    __shared__ int s_ctrl[2];
-    const int lane = fmk_lane();
-    const int role = fmk_uniform((int)(threadIdx.x >> 6));          // 0: directional, 1: footprints
-    const AmtT *am = (const AmtT *)amount;
-    float *vol = (float *)s_hist;                                     // [2*lmax]  buy = 2l, sell = 2l+1
-    int *cnt = (int *)(s_hist + BF_FUSED_LMAX * 8);                   // [2*lmax]
-    float *aux = (float *)(s_hist + BF_FUSED_LMAX * 16);              // [2*lmax]
-    int *stk = (int *)(s_hist + BF_FUSED_LMAX * 24);                  // 64 ints
-    const double inv_tick = 1.0 / tick;
-    int wq = FP_Q_UNKNOWN;        // quantum exponent the previous bar certified with (footprint wave)
-    int buf = 0;
-    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const int64_t s = fmk_uniform(ci[b]);
-        const int64_t e = fmk_uniform(ci[b + 1]);
-        const int64_t start = s + 1;
-        const int64_t base = fmk_uniform(off[b]);
-        const int L = (int)fmk_uniform(off[b + 1] - base);
-        const bool fp_this = L > 0 && L <= BF_FUSED_LMAX;            // wider bars: k_bar_footprints afterwards
-        FlowDir d;
-        bf_dir_init(d);
-        int64_t low = 0;
-        int mode = 0, qcur = wq;
-        bool retried = false;
-        if (role == 0) {
-            if (e > s) {
-                d.prev_price = price[fmk_wrap(start - 1, n)];
-                d.prev_side = e - s > 1 ? (int)side[fmk_wrap(start - 1, n)] : 0;    // base.py:485-488
-            }
-        } else if (fp_this) {
-            low = fp_level(lows[b], tick);
-            for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
-            __builtin_amdgcn_wave_barrier();
-            mode = (!force_ordered && wq != FP_Q_UNKNOWN) ? 1 : 2;
-        }
-        bool first_sweep = true;
-        for (;;) {                                                   // sweeps over the bar (block-uniform count)
-            FpLane f;
-            f.lbmin = FP_Q_UNKNOWN; f.atot = 0.0; f.units_ok = true; f.bad = false;
-            int64_t j0 = start, rem = e - s;
-            int lr, tn;
-            bf_shape(rem, lr, tn);
-            double pr[4];
-            AmtT ar[4];
-            int sr[4];
-            // my half of the first tile (chunks role, role + 2, ...)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pr[i] = 0.0; ar[i] = 0; sr[i] = 0;
-                const int c = 2 * i + role;
-                const int t = c * 64 + lane;
-                if (rem > 0 && c < (1 << lr) && t < tn) { pr[i] = (price + j0)[t]; ar[i] = (am + j0)[t]; sr[i] = (side + j0)[t]; }
-            }
-            while (rem > 0) {
-                double *sP = s_p[buf];
-                AmtT *sA = s_a[buf];
-                int8_t *sS = s_s[buf];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 2 * i + role;
-                    if (c < (1 << lr)) {
-                        const int sl = bf_slot(c * 64 + lane, lr);
-                        sP[sl] = pr[i]; sA[sl] = ar[i]; sS[sl] = (int8_t)sr[i];
-                    }
-                }
-                __syncthreads();          // tile visible to both waves; everybody is done with the other buffer
-                const int64_t j0n = j0 + tn, remn = rem - tn;
-                int lrn, tnn;
-                bf_shape(remn, lrn, tnn);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {                        // next tile's loads fly during the walk below
-                    pr[i] = 0.0; ar[i] = 0; sr[i] = 0;
-                    const int c = 2 * i + role;
-                    const int t = c * 64 + lane;
-                    if (remn > 0 && c < (1 << lrn) && t < tnn) { pr[i] = (price + j0n)[t]; ar[i] = (am + j0n)[t]; sr[i] = (side + j0n)[t]; }
-                }
-                if (role == 0) {
-                    if (first_sweep) bf_dir_tile<AmtT>(lane, lr, tn, sP, sA, sS, d);
-                } else if (mode != 0) {
-                    bf_fp_tile<AF64>(mode, lane, lr, tn, sP, sA, sS, low, L, tick, inv_tick, vol, cnt, qcur, f);
-                }
-                buf ^= 1;
-                j0 = j0n; rem = remn; lr = lrn; tn = tnn;
-            }
-            // ---- end of sweep: the footprint wave decides whether the bar needs another one
-            int again = 0;
-            if (role == 1 && mode != 0) {
-                FpStats st;
-                st.lbmin = fmk_dpp_reduce(f.lbmin, FP_Q_UNKNOWN, FmkOpMin());
-                st.atot = fmk_dpp_reduce(f.atot, 0.0, FmkOpAdd());
-                st.units_ok = __ballot(!f.units_ok) == 0;
-                st.bad = __ballot(f.bad) != 0;
-                if (mode == 2) {
-                    // remember a usable quantum for the next bar (if this bar would have certified)
-                    FpStats probe = st;
-                    probe.units_ok = true;
-                    const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 && fp_certified(probe, st.lbmin);
-                    wq = usable ? st.lbmin : FP_Q_UNKNOWN;
-                } else if (fp_certified(st, qcur)) {                 // units -> float32 (exact)
-                    wq = qcur;
-                    unsigned *units = (unsigned *)vol;
-                    for (int k = lane; k < 2 * L; k += 64) vol[k] = ldexpf((float)units[k], qcur);
-                } else {
-                    // the bar's own statistics give the right quantum for ONE exact retry, else the ordered sweep
-                    for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
-                    const int q2 = st.lbmin;
-                    FpStats probe = st;
-                    probe.units_ok = true;
-                    if (!retried && q2 != FP_Q_UNKNOWN && q2 != (int)0x80000000 && fp_certified(probe, q2)) { qcur = q2; retried = true; }
-                    else mode = 2;
-                    again = 1;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (!again && st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
-                if (lane == 0) s_ctrl[0] = again;
-            } else if (role == 1 && lane == 0) {
-                s_ctrl[0] = 0;
-            }
-            __syncthreads();
-            again = s_ctrl[0];
-            __syncthreads();
-            first_sweep = false;
-            if (!again) break;
-        }
-        if (role == 0) bf_dir_emit(o, b, lane, d, n_zero_div);
-        else if (fp_this) fp_emit_bar(fo, b, base, L, low, BF_FUSED_LMAX, m32, lane, vol, cnt, aux, stk);
     }
 }
 
@@ -457,12 +248,12 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_directional: bad arguments");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;
+    FlowDirOut o;
+    memcpy(&o, d_out, sizeof(o));
     int64_t blocks = fmk_ceil_div(nb, 4);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    FlowDirOut o;
-    memcpy(&o, d_out, sizeof(o));
     if (amount_is_f64)
         k_bar_dir<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                  (unsigned long long *)d_n_zero_div);
@@ -499,31 +290,14 @@ extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, cons
         return fmk_set_error(ctx, FMK_E_CAPACITY,
                              "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
                              (long long)max_levels, FP_MAX_LEVELS);
-    FMK_HIP(ctx, hipSetDevice(ctx->device));
-    const int64_t nb = n_idx - 1;
-    FlowDirOut o;
-    memcpy(&o, d_dir, sizeof(o));
-    FpOut fo;
-    memcpy(&fo, d_fp, sizeof(fo));
-    const float m32 = (float)imbalance_factor;   // float32 array * Python float -> float32 (NEP 50)
-    static int force_ordered = -1;               // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
-    if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
-    int64_t blocks = nb;
-    const int64_t cap = (int64_t)ctx->n_cu * 128;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    if (amount_is_f64)
-        k_bar_flow2<true><<<(unsigned)blocks, 128, 0, ctx->stream>>>(
-            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, price_tick_size,
-            d_bar_lows, m32, d_level_offsets, fo, (unsigned long long *)d_n_bad_level, force_ordered);
-    else
-        k_bar_flow2<false><<<(unsigned)blocks, 128, 0, ctx->stream>>>(
-            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, price_tick_size,
-            d_bar_lows, m32, d_level_offsets, fo, (unsigned long long *)d_n_bad_level, force_ordered);
-    FMK_LAUNCH_CHECK(ctx);
-    if (max_levels > BF_FUSED_LMAX)              // footprints of the wide bars (> 128 levels): streaming kernel
-        return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, nb, d_side,
-                                           price_tick_size, d_bar_lows, m32, d_level_offsets, BF_FUSED_LMAX, max_levels,
-                                           d_fp, d_n_bad_level);
-    return FMK_OK;
+    // Two kernels back to back.  In-kernel fusion was built and measured twice (one wave doing both halves on a
+    // shared LDS tile: 11.2 ms; two waves per bar, one per half, on double-buffered tiles: 10.3 ms at 1e9 ticks)
+    // against 3.0 + 3.7 ms for the two kernels below: both halves are VALU-bound (~106 and ~161 VALU instructions
+    // per 64 ticks), not HBM-bound, so sharing the 13 B/tick read buys nothing while the merged register / LDS
+    // footprint halves the occupancy.  DESIGN.md section 3 has the counters.
+    FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
+                                         d_n_zero_div));
+    return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
+                                       price_tick_size, d_bar_lows, (float)imbalance_factor, d_level_offsets, 0,
+                                       max_levels, d_fp, d_n_bad_level);
 }
