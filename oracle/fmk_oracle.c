@@ -22,6 +22,9 @@
  *
  * Citations are relative to /root/reference/.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -348,9 +351,22 @@ int orc_comp_bar_ohlcv(const double *prices, const void *volumes, int is_f64, in
         int64_t cnt = close_idx[i + 1] - close_idx[i];
         if (cnt > maxcnt) maxcnt = cnt;
     }
-    double *scratch = median ? (double *)malloc(sizeof(double) * (size_t)maxcnt) : NULL;
-    if (median && !scratch) return ORC_E_NOMEM;
+    /* Bars are independent (the reference runs them under numba.prange, base.py:349): with ORC_THREADS > 1 in the
+     * environment the bar loop is an OpenMP parallel-for -- the arithmetic inside a bar is untouched, so results do
+     * not depend on the thread count.  Used by bench.py's cpu_baseline on all host cores. */
+    int nthreads = 1;
+    { const char *e = getenv("ORC_THREADS"); if (e && atoi(e) > 1) nthreads = atoi(e); }
+    double *scratch_all = median ? (double *)malloc(sizeof(double) * (size_t)maxcnt * (size_t)nthreads) : NULL;
+    if (median && !scratch_all) return ORC_E_NOMEM;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
     for (int64_t i = 0; i < nb; ++i) {
+#ifdef _OPENMP
+        double *scratch = scratch_all ? scratch_all + (size_t)omp_get_thread_num() * (size_t)maxcnt : NULL;
+#else
+        double *scratch = scratch_all;
+#endif
         int64_t start = close_idx[i], end = close_idx[i + 1];
         if (start == end) {                          /* base.py:352-361 */
             double p = prices[orc_wrap(end, n)];
@@ -378,7 +394,7 @@ int orc_comp_bar_ohlcv(const double *prices, const void *volumes, int is_f64, in
         trades[i] = cnt;
         if (median) median[i] = cnt > 0 ? orc_median(scratch, cnt) : 0.0;
     }
-    free(scratch);
+    free(scratch_all);
     return ORC_OK;
 }
 
