@@ -1,9 +1,11 @@
 """Host-side containers of the bar path: `TradesData` and `FootprintData`.
 
 Same constructor arguments, attributes and column schema as finmlkit/bar/data_model.py
-(TradesData :121-252, FootprintData :775-1058) for everything the bar builders touch.  What is
-NOT here (out of scope): the one-off preprocessing pipeline
-(`preprocess=True`: id-sort, split-trade merge, tick-rule side inference) and the HDF5 store.
+(TradesData :121-252, FootprintData :775-1058) for everything the bar builders touch, including the
+`preprocess=True` pipeline (:236-246, 296-400): unit conversion, id sort + integrity report and the
+re-sort stay pandas (host), the two sequential loops -- split-trade merge and tick-rule side
+inference -- run on the MI355X (finmlkit_amd.bar.utils).  Not here (out of scope):
+the HDF5 store.
 """
 from __future__ import annotations
 
@@ -15,7 +17,9 @@ import numpy as np
 import pandas as pd
 from numpy.typing import NDArray
 
-from .utils import footprint_to_dataframe
+from .utils import comp_trade_side_vector, footprint_to_dataframe, merge_split_trades
+
+_NS_PER_UNIT = {"s": 1_000_000_000, "ms": 1_000_000, "us": 1_000, "ns": 1}
 
 
 class TradesData:
@@ -33,11 +37,6 @@ class TradesData:
             raise TypeError("is_buyer_maker must be None or np.ndarray")
         if side is not None and not isinstance(side, np.ndarray):
             raise TypeError("side must be None or np.ndarray")
-        if preprocess:
-            raise NotImplementedError(
-                "TradesData(preprocess=True) (id sort, split-trade merge, tick-rule sides) is a one-off "
-                "sequential preprocessing step outside the MI355X hot path; preprocess once with finmlkit "
-                "and construct TradesData(..., side=..., preprocess=False).")
         self._start_date = self._end_date = None
         self._data = pd.DataFrame({"timestamp": ts, "price": px, "amount": qty, "id": id})
         self.is_buyer_maker = is_buyer_maker
@@ -48,6 +47,15 @@ class TradesData:
         self.missing_pct = 0
         self.data_ok = None
         self.discontinuities = []
+        if preprocess:                               # data_model.py:236-246 of the reference
+            if id is None:
+                raise ValueError("id is required if preprocess is True")
+            self._convert_timestamps_to_ns()
+            self._sort_trades()
+            self._merge_trades()
+            self._apply_timestamp_resolution(proc_res)
+            if "side" not in self._data.columns:
+                self._data["side"] = comp_trade_side_vector(self._data["price"].values)
         if dt_index is not None:
             self._data.set_index(dt_index, inplace=True)
         else:
@@ -79,6 +87,62 @@ class TradesData:
     @property
     def orig_timestamp_unit(self) -> str:
         return self._orig_timestamp_unit
+
+    # ------------------------------------------------------------------ preprocess=True pipeline
+    def _convert_timestamps_to_ns(self) -> None:
+        unit = self._orig_timestamp_unit
+        if unit not in _NS_PER_UNIT:
+            raise ValueError(f"Invalid timestamp format! Must be one of: {', '.join(_NS_PER_UNIT)}")
+        self._data["timestamp"] = np.multiply(self._data["timestamp"].values, _NS_PER_UNIT[unit], dtype=np.int64)
+
+    def _validate_data(self) -> None:
+        """Report gaps in the (sorted, unique) trade ids; gaps that also span more than a minute are recorded in
+        `discontinuities` and clear `data_ok` (reference data_model.py:253-293)."""
+        ids = self._data["id"].values
+        gaps = np.flatnonzero(np.diff(ids) > 1)
+        if len(gaps) == 0:
+            return
+        ts = self._data["timestamp"].values
+        missing = (ids[gaps + 1] - ids[gaps] - 1).astype(np.int64)
+        for g, miss in zip(gaps, missing):
+            before, after = pd.to_datetime(int(ts[g]), unit="ns"), pd.to_datetime(int(ts[g + 1]), unit="ns")
+            if after - before > pd.Timedelta(minutes=1):
+                self.data_ok = False
+                self.discontinuities.append({"start_id": int(ids[g]), "end_id": int(ids[g + 1]),
+                                             "missing_ids": int(miss), "pre_gap_time": before,
+                                             "post_gap_time": after, "time_interval": after - before})
+        self.missing_pct = int(missing.sum()) / len(self._data) * 100
+
+    def _sort_trades(self) -> None:
+        self.data_ok = True
+        self.discontinuities = []
+        self._data.sort_values(by=["id"], inplace=True)
+        self._data.reset_index(drop=True, inplace=True)
+        if self._data["id"].duplicated().any():
+            self._data.drop_duplicates(subset="id", keep="first", inplace=True)
+            self.data_ok = False
+        self._validate_data()
+        if not self._data["timestamp"].is_monotonic_increasing:
+            self._data.sort_values(by=["timestamp", "id"], inplace=True)
+        self._data.reset_index(drop=True, inplace=True)
+
+    def _merge_trades(self) -> None:
+        """Split-trade merge on the device; like the reference the merged frame has no `id` column and
+        `is_buyer_maker` is used as given (data_model.py:324-342)."""
+        ts, px, am, side = merge_split_trades(self._data["timestamp"].values.astype(np.int64),
+                                              self._data["price"].values.astype(np.float64),
+                                              self._data["amount"].values.astype(np.float32), self.is_buyer_maker)
+        self._data = pd.DataFrame({"timestamp": ts, "price": px, "amount": am})
+        if self.is_buyer_maker is not None:
+            self._data["side"] = side
+
+    def _apply_timestamp_resolution(self, proc_res: Optional[str]) -> None:
+        if proc_res and proc_res != self._orig_timestamp_unit:
+            if proc_res not in _NS_PER_UNIT:
+                raise ValueError(f"Invalid processing resolution: {proc_res}. Must be one of: "
+                                 f"{', '.join(_NS_PER_UNIT)}")
+            res = _NS_PER_UNIT[proc_res]
+            self._data["timestamp"] = (self._data["timestamp"] // res) * res
 
     def _infer_timestamp_unit(self) -> str:
         max_ts = self._data["timestamp"].max()

@@ -1,12 +1,52 @@
-"""Host-side helpers of the bar builders (the counterparts of finmlkit/bar/utils.py that the hot
-path actually calls).  Pure NumPy on at most 10k samples / on already-reduced bar data."""
+"""Helpers of the bar builders (the counterparts of finmlkit/bar/utils.py that the path calls): the
+tick-size estimate (pure NumPy on at most 10k samples), the footprint DataFrame view, and the two loops
+of `TradesData(preprocess=True)` -- `merge_split_trades`, `comp_trade_side_vector` -- on the MI355X."""
 from __future__ import annotations
 
 import math
+from typing import Optional
 
 import numpy as np
 import pandas as pd
 from numpy.typing import NDArray
+
+
+def merge_split_trades(timestamps: NDArray[np.int64], prices: NDArray[np.float64], amounts: NDArray[np.float32],
+                       is_buyer_maker: Optional[NDArray[np.bool_]]):
+    """Merge split trades: same timestamp, maker flag and price (|dp| < 1e-8 against the merged trade's
+    first price); amounts summed in float32 in trade order.  Reference: finmlkit/bar/utils.py:263-329.
+
+    -> (timestamps, prices, amounts float32, side int8) -- side is an empty array without `is_buyer_maker`."""
+    import ctypes as C
+
+    from .. import _ffi
+    from .._ffi import c_i64, ptr
+    ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    px = np.ascontiguousarray(prices, dtype=np.float64)
+    am = np.ascontiguousarray(amounts, dtype=np.float32)
+    n = len(ts)
+    if not (len(px) == len(am) == n) or n == 0:
+        raise ValueError("timestamps, prices and amounts must be non-empty arrays of one length")
+    ibm = None if is_buyer_maker is None else np.ascontiguousarray(is_buyer_maker, dtype=np.uint8)
+    o_ts, o_px, o_am = np.empty(n, np.int64), np.empty(n, np.float64), np.empty(n, np.float32)
+    o_sd = np.empty(n if ibm is not None else 0, np.int8)
+    m = c_i64()
+    _ffi.default_context().call("fmk_merge_split_trades", ptr(ts), ptr(px), ptr(am), None if ibm is None else ptr(ibm),
+                                c_i64(n), ptr(o_ts), ptr(o_px), ptr(o_am), ptr(o_sd) if ibm is not None else None,
+                                c_i64(n), C.byref(m))
+    k = m.value
+    return o_ts[:k], o_px[:k], o_am[:k], (o_sd[:k] if ibm is not None else np.empty(0, dtype=np.int8))
+
+
+def comp_trade_side_vector(prices: NDArray[np.float64]) -> NDArray[np.int8]:
+    """Tick rule: +1 / -1 after an up / down move larger than 1e-12, else the previous side; side[0] = 0.
+    Reference: finmlkit/bar/utils.py:26-46."""
+    from .. import _ffi
+    from .._ffi import c_i64, ptr
+    px = np.ascontiguousarray(prices, dtype=np.float64)
+    out = np.empty(len(px), np.int8)
+    _ffi.default_context().call("fmk_comp_trade_side_vector", ptr(px), c_i64(len(px)), ptr(out))
+    return out
 
 
 def comp_price_tick_size(prices: NDArray[np.float64]) -> float:

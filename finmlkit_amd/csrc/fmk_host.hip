@@ -316,4 +316,51 @@ int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, i
     return down(ctx, out, d_o, n);
 }
 
+int fmk_merge_split_trades(fmk_ctx *ctx, const int64_t *ts, const double *price, const float *amount,
+                           const uint8_t *is_buyer_maker, int64_t n, int64_t *out_ts, double *out_price,
+                           float *out_amount, int8_t *out_side, int64_t capacity, int64_t *n_merged)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "merge_split_trades: empty input");
+    DevBag bag(ctx);
+    int64_t *d_ts, *d_ots = nullptr;
+    double *d_p, *d_op = nullptr;
+    float *d_a, *d_oa = nullptr;
+    uint8_t *d_m = nullptr;
+    int8_t *d_os = nullptr;
+    FMK_TRY(bag.up(ts, n, &d_ts));
+    FMK_TRY(bag.up(price, n, &d_p));
+    FMK_TRY(bag.up(amount, n, &d_a));
+    if (is_buyer_maker) FMK_TRY(bag.up(is_buyer_maker, n, &d_m));
+    if (out_ts) {
+        FMK_TRY(bag.out(n, &d_ots));
+        FMK_TRY(bag.out(n, &d_op));
+        FMK_TRY(bag.out(n, &d_oa));
+        if (out_side && is_buyer_maker) FMK_TRY(bag.out(n, &d_os));
+    }
+    int64_t m = 0;
+    FMK_TRY(fmk_merge_split_trades_dev(ctx, d_ts, d_p, d_a, d_m, n, d_ots, d_op, d_oa, d_os, out_ts ? n : 0, &m));
+    if (n_merged) *n_merged = m;
+    if (!out_ts) return FMK_OK;
+    if (capacity < m)
+        return fmk_set_error(ctx, FMK_E_CAPACITY, "merge_split_trades: %lld merged trades, capacity %lld", (long long)m,
+                             (long long)capacity);
+    FMK_TRY(down(ctx, out_ts, d_ots, m));
+    FMK_TRY(down(ctx, out_price, d_op, m));
+    FMK_TRY(down(ctx, out_amount, d_oa, m));
+    if (d_os) FMK_TRY(down(ctx, out_side, d_os, m));
+    return FMK_OK;
+}
+
+int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int8_t *out)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "comp_trade_side_vector: empty input");
+    DevBag bag(ctx);
+    double *d_p;
+    int8_t *d_o;
+    FMK_TRY(bag.up(price, n, &d_p));
+    FMK_TRY(bag.out(n, &d_o));
+    FMK_TRY(fmk_comp_trade_side_vector_dev(ctx, d_p, n, d_o));
+    return down(ctx, out, d_o, n);
+}
+
 }  // extern "C"

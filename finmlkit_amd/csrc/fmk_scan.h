@@ -11,7 +11,7 @@
 #define FMK_SCAN_ROWS 16
 #define FMK_SCAN_TILE (FMK_SCAN_THREADS * FMK_SCAN_ROWS)
 
-__global__ __launch_bounds__(FMK_SCAN_THREADS) void k_scan_tile_sums(const int64_t *__restrict__ in, int64_t n,
+static __global__ __launch_bounds__(FMK_SCAN_THREADS) void k_scan_tile_sums(const int64_t *__restrict__ in, int64_t n,
                                                                      int64_t *__restrict__ tile_sum)
 {
     __shared__ int64_t sw[4];
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(FMK_SCAN_THREADS) void k_scan_tile_sums(const int64
 }
 
 // exclusive scan in place; total written to *total
-__global__ __launch_bounds__(1024) void k_scan_tile_scan(int64_t *t, int64_t m, int64_t *total)
+static __global__ __launch_bounds__(1024) void k_scan_tile_scan(int64_t *t, int64_t m, int64_t *total)
 {
     __shared__ int64_t ws[16];
     __shared__ int64_t run;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void k_scan_tile_scan(int64_t *t, int64_t m, 
 }
 
 // out[j] = tile_off[tile] + exclusive prefix within the tile; out[n] = total when j == n-1 is seen
-__global__ __launch_bounds__(FMK_SCAN_THREADS) void k_scan_apply(const int64_t *__restrict__ in, int64_t n,
+static __global__ __launch_bounds__(FMK_SCAN_THREADS) void k_scan_apply(const int64_t *__restrict__ in, int64_t n,
                                                                  const int64_t *__restrict__ tile_off,
                                                                  int64_t *__restrict__ out)
 {

@@ -240,6 +240,21 @@ int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, int64_t win
                          double *d_out);
 int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, int is_sample, double *out);
 
+/* ---- TradesData(preprocess=True) loops: finmlkit/bar/utils.py ("next" rank 4) ------------ */
+/* merge_split_trades (bar/utils.py:263-329): trades with the head's timestamp, maker flag and price (|dp| < 1e-8)
+ * are merged, amounts summed in float32 in trade order; side = -1 if is_buyer_maker else 1 (is_buyer_maker may be
+ * NULL: no side output).  *n_merged receives the number of merged trades; pass out_ts == NULL to only count.
+ * FMK_E_CAPACITY when capacity < *n_merged. */
+int fmk_merge_split_trades_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const float *d_amount,
+                               const uint8_t *d_is_buyer_maker, int64_t n, int64_t *d_out_ts, double *d_out_price,
+                               float *d_out_amount, int8_t *d_out_side, int64_t capacity, int64_t *n_merged);
+int fmk_merge_split_trades(fmk_ctx *ctx, const int64_t *ts, const double *price, const float *amount,
+                           const uint8_t *is_buyer_maker, int64_t n, int64_t *out_ts, double *out_price,
+                           float *out_amount, int8_t *out_side, int64_t capacity, int64_t *n_merged);
+/* comp_trade_side_vector (bar/utils.py:26-46): tick rule, side[0] = 0. */
+int fmk_comp_trade_side_vector_dev(fmk_ctx *ctx, const double *d_price, int64_t n, int8_t *d_out);
+int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -845,3 +845,44 @@ int orc_comp_price_tick_size(const double *prices, int64_t n, double *out)
     *out = (double)tick / scale;
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ */
+/* "Next" rank 4: the loops of TradesData(preprocess=True)              */
+/* merge_split_trades       finmlkit/bar/utils.py:263-329              */
+/* comp_trade_side_vector   finmlkit/bar/utils.py:26-46 (+ :10-23)     */
+/* ------------------------------------------------------------------ */
+int64_t orc_merge_split_trades(const int64_t *ts, const double *prices, const float *amounts,
+                               const uint8_t *is_buyer_maker, int64_t n,
+                               int64_t *o_ts, double *o_px, float *o_am, int8_t *o_side)
+{
+    if (n <= 0) return ORC_E_ARG;
+    int64_t m = 0;
+    o_ts[0] = ts[0]; o_px[0] = prices[0]; o_am[0] = amounts[0];
+    int head_maker = is_buyer_maker ? (is_buyer_maker[0] != 0) : 0;
+    if (is_buyer_maker) o_side[0] = head_maker ? -1 : 1;
+    for (int64_t i = 1; i < n; ++i) {
+        int same = ts[i] == o_ts[m] && fabs(prices[i] - o_px[m]) < 1e-8;          /* utils.py:300-301 */
+        if (is_buyer_maker) same = same && ((is_buyer_maker[i] != 0) == head_maker);   /* utils.py:303-304 */
+        if (same) {
+            o_am[m] = o_am[m] + amounts[i];                                        /* float32 += float32 */
+        } else {
+            ++m;
+            o_ts[m] = ts[i]; o_px[m] = prices[i]; o_am[m] = amounts[i];
+            if (is_buyer_maker) { head_maker = is_buyer_maker[i] != 0; o_side[m] = head_maker ? -1 : 1; }
+        }
+    }
+    return m + 1;
+}
+
+int orc_comp_trade_side_vector(const double *prices, int64_t n, int8_t *out)
+{
+    if (n <= 0) return ORC_E_ARG;
+    int prev = 0;
+    out[0] = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double dp = prices[i] - prices[i - 1];
+        if (fabs(dp) > 1e-12) prev = dp > 0 ? 1 : (dp < 0 ? -1 : 0);             /* np.sign(dp) */
+        out[i] = (int8_t)prev;
+    }
+    return ORC_OK;
+}

@@ -265,6 +265,78 @@ def gen_tick_size():
     save("tick_size", d)
 
 
+def split_trade_stream(seed, n, tick=0.01, second_resolution=False):
+    """Raw (un-merged) trades: bursts sharing a timestamp, partly at one price / maker flag."""
+    rng = np.random.default_rng(seed)
+    burst = rng.geometric(0.45, n)                       # trades per timestamp
+    ts = np.repeat(1_700_000_000_000_000_000 + np.cumsum(rng.integers(1, 50_000_000, n)), burst)[:n]
+    if second_resolution:
+        ts = ts // 1_000_000_000 * 1_000_000_000
+    step = rng.choice([-1, 0, 0, 0, 1], n)               # mostly unchanged price inside a burst
+    px = (2_700_000 + np.cumsum(step)) * tick
+    am = ((1 + rng.integers(0, 4096, n)) * 2.0 ** -10).astype(np.float32)
+    am[rng.random(n) < 0.3] = np.float32(0.1)            # inexact float32 sums: the += order matters
+    ibm = rng.random(n) < 0.5
+    ibm[1:][rng.random(n - 1) < 0.6] = False             # correlate flags so that runs exist
+    return ts.astype(np.int64), px, am, ibm
+
+
+def gen_preprocess():
+    d = {}
+    for name, seed, n, sec in (("a", 1, 5000, False), ("b", 2, 5000, True), ("c", 3, 300, False)):
+        ts, px, am, ibm = split_trade_stream(seed, n, second_resolution=sec)
+        for k, v in (("ts", ts), ("px", px), ("am", am), ("ibm", ibm)):
+            d[f"{name}__{k}"] = v
+        for tag, flag in (("side", ibm), ("noside", None)):
+            mts, mpx, mam, msd = rutils.merge_split_trades(ts, px, am, flag)
+            d[f"{name}__{tag}_ts"], d[f"{name}__{tag}_px"], d[f"{name}__{tag}_am"] = mts, mpx, mam
+            d[f"{name}__{tag}_sd"] = np.asarray(msd, dtype=np.int8)
+        d[f"{name}__tickrule"] = rutils.comp_trade_side_vector(px)
+    # prices closer than the 1e-8 merge tolerance / the 1e-12 tick-rule epsilon, compared against the HEAD
+    px = np.array([1.0, 1.0 + 6e-9, 1.0 + 1.2e-8, 1.0 + 1.8e-8, 1.0 + 1.8e-8, 2.0, 2.0 + 5e-13, 2.0 + 2e-12, 2.0])
+    ts = np.full(len(px), 1_700_000_000_000_000_000, dtype=np.int64)
+    am = np.full(len(px), 0.1, dtype=np.float32)
+    ibm = np.zeros(len(px), dtype=bool)
+    mts, mpx, mam, msd = rutils.merge_split_trades(ts, px, am, ibm)
+    d["eps__px"], d["eps__ts"], d["eps__am"], d["eps__ibm"] = px, ts, am, ibm
+    d["eps__side_ts"], d["eps__side_px"], d["eps__side_am"], d["eps__side_sd"] = mts, mpx, mam, np.asarray(msd, np.int8)
+    d["eps__tickrule"] = rutils.comp_trade_side_vector(px)
+    save("preprocess", d)
+
+
+def gen_tradesdata():
+    """TradesData(preprocess=True) end to end (data_model.py:236-246): raw exchange-style rows in millisecond
+    timestamps, shuffled, with duplicated ids and an id gap longer than a minute."""
+    from finmlkit.bar.data_model import TradesData
+    d = {}
+    for name, seed, with_maker, proc_res in (("mk", 11, True, None), ("tr", 12, False, "ms"), ("sec", 13, True, "s")):
+        ts_ns, px, am, ibm = split_trade_stream(seed, 4000)
+        ts_ms = ts_ns // 1_000_000
+        ids = np.arange(len(ts_ms), dtype=np.int64) + 1000
+        ids[2500:] += 40                                   # 40 missing ids ...
+        ts_ms[2500:] += 120_000                            # ... across a two-minute hole
+        rng = np.random.default_rng(seed)
+        perm = rng.permutation(len(ids))
+        dup = rng.choice(len(ids), 25, replace=False)      # duplicated rows
+        order = np.concatenate([perm, dup])
+        raw = {"ts": ts_ms[order], "px": px[order], "qty": am[order].astype(np.float64), "id": ids[order]}
+        maker = ibm[order] if with_maker else None
+        t = TradesData(raw["ts"].copy(), raw["px"].copy(), raw["qty"].copy(), raw["id"].copy(),
+                       is_buyer_maker=None if maker is None else maker.copy(), preprocess=True, proc_res=proc_res)
+        for k, v in raw.items():
+            d[f"{name}__raw_{k}"] = v
+        if maker is not None:
+            d[f"{name}__raw_maker"] = maker
+        d[f"{name}__proc_res"] = np.array(proc_res or "")
+        for col in ("timestamp", "price", "amount", "side"):
+            d[f"{name}__out_{col}"] = t.data[col].values
+        d[f"{name}__data_ok"] = np.array(bool(t.data_ok))
+        d[f"{name}__missing_pct"] = np.float64(t.missing_pct)
+        d[f"{name}__n_disc"] = np.int64(len(t.discontinuities))
+        d[f"{name}__unit"] = np.array(t.orig_timestamp_unit)
+    save("tradesdata", d)
+
+
 if __name__ == "__main__":
     gen_time_indexer()
     gen_threshold_indexers()
@@ -273,3 +345,5 @@ if __name__ == "__main__":
     gen_trade_size()
     gen_ticklevel()
     gen_tick_size()
+    gen_preprocess()
+    gen_tradesdata()

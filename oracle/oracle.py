@@ -305,3 +305,28 @@ def comp_price_tick_size(prices):
     out = C.c_double()
     _check(lib().orc_comp_price_tick_size(_p(p), _i64(len(p)), C.byref(out)))
     return out.value
+
+
+def merge_split_trades(timestamps, prices, amounts, is_buyer_maker):
+    """bar/utils.py:263-329 -> (ts, price, amount float32, side int8 | empty)."""
+    ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    px = np.ascontiguousarray(prices, dtype=np.float64)
+    am = np.ascontiguousarray(amounts, dtype=np.float32)
+    n = len(ts)
+    ibm = None if is_buyer_maker is None else np.ascontiguousarray(is_buyer_maker, dtype=np.uint8)
+    o_ts, o_px, o_am = np.empty(n, np.int64), np.empty(n, np.float64), np.empty(n, np.float32)
+    o_sd = np.empty(n, np.int8)
+    fn = lib().orc_merge_split_trades
+    fn.restype = C.c_int64
+    m = fn(_p(ts), _p(px), _p(am), _p(ibm), _i64(n), _p(o_ts), _p(o_px), _p(o_am), _p(o_sd))
+    if m < 0:
+        _check(int(m))
+    return o_ts[:m], o_px[:m], o_am[:m], (o_sd[:m] if ibm is not None else np.empty(0, dtype=np.int8))
+
+
+def comp_trade_side_vector(prices):
+    """bar/utils.py:26-46 (tick rule)."""
+    px = np.ascontiguousarray(prices, dtype=np.float64)
+    out = np.empty(len(px), np.int8)
+    _check(lib().orc_comp_trade_side_vector(_p(px), _i64(len(px)), _p(out)))
+    return out

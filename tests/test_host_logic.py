@@ -37,8 +37,8 @@ def test_tradesdata_type_errors():
         TradesData(a, [1.0], a.astype(float))
     with pytest.raises(TypeError, match="side must be"):
         TradesData(a, a.astype(float), a.astype(float), side=[1, 1, 1])
-    with pytest.raises(NotImplementedError):
-        TradesData(a, a.astype(float), a.astype(float), a, preprocess=True)
+    with pytest.raises(ValueError, match="id is required"):
+        TradesData(a, a.astype(float), a.astype(float), preprocess=True)
 
 
 def test_timestamp_unit_inference():

@@ -139,3 +139,19 @@ def test_trade_size_golden(orc):
     got = orc.comp_bar_trade_size_features(d["am"], d["theta"], d["ci"], 5.0)
     for k, g in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], got):
         G.assert_f32_close(g, d[k], what=k, max_ulp=1, max_frac=0.01)
+
+
+def test_preprocess_loops_golden(orc):
+    """merge_split_trades / comp_trade_side_vector (bar/utils.py:263-329, 26-46) incl. the head-relative 1e-8 rule."""
+    d = G.load("preprocess")
+    for name in ("a", "b", "c", "eps"):
+        ts, px, am, ibm = (d[f"{name}__{k}"] for k in ("ts", "px", "am", "ibm"))
+        for tag, flag in (("side", ibm), ("noside", None)):
+            if f"{name}__{tag}_ts" not in d:
+                continue
+            got = orc.merge_split_trades(ts, px, am, flag)
+            for g, k in zip(got, ("ts", "px", "am", "sd")):
+                w = d[f"{name}__{tag}_{k}"]
+                assert g.dtype == w.dtype, (name, tag, k)
+                np.testing.assert_array_equal(g, w, err_msg=f"{name} {tag} {k}")
+        np.testing.assert_array_equal(orc.comp_trade_side_vector(px), d[f"{name}__tickrule"])
