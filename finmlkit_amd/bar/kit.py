@@ -14,6 +14,7 @@ from numpy.typing import NDArray
 
 from .base import BarBuilderBase
 from .data_model import TradesData
+from .logic import _cusum_bar_indexer
 
 logger = logging.getLogger(__name__)
 
@@ -76,12 +77,19 @@ class DollarBarKit(_ThresholdKit):
 
 
 class CUSUMBarKit(BarBuilderBase):
-    """Reference kit.py:140-181.  Third "next" row of SURVEY.md 8(f) (needs the tick-level sigma first);
-    not part of the round-1 hot path."""
+    """Symmetric CUSUM bars with an adaptive threshold sigma_mult * sigma (reference kit.py:140-181)."""
 
     def __init__(self, trades: TradesData, sigma, sigma_floor: float = 5e-4, sigma_mult: float = 2.):
         super().__init__(trades)
         self.lambda_mult, self._sigma, self.sigma_floor = sigma_mult, sigma, sigma_floor
+        logger.info(f"CUSUM Bar builder initialized with: sigma multiplier={sigma_mult}.")
 
     def _comp_bar_close(self):
-        raise NotImplementedError("CUSUM bars are scheduled after the hot-path rows (SURVEY.md 8f rank 3)")
+        timestamps = self.trades_df["timestamp"].astype(np.int64).values
+        prices = self.trades_df["price"].values
+        close_indices = _cusum_bar_indexer(timestamps, prices, self._sigma, self.sigma_floor, self.lambda_mult)
+        return timestamps[close_indices], close_indices
+
+    def get_sigma(self):
+        """The (forward-filled) sigma at the close indices (reference kit.py:176-181)."""
+        return self._sigma[self.bar_close_indices]

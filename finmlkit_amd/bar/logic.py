@@ -79,3 +79,26 @@ def _imbalance_bar_indexer(timestamps, prices, volumes, threshold):
 def _run_bar_indexer(timestamps, prices, volumes, threshold):
     """Reference stub: finmlkit/bar/logic.py:244-261."""
     raise NotImplementedError("Run bar indexer is not implemented yet.")
+
+
+def _cusum_bar_indexer(timestamps: NDArray[np.int64], prices: NDArray[np.float64], sigma: NDArray[np.float64],
+                       sigma_floor: float, sigma_mult: float) -> NDArray[np.int64]:
+    """Symmetric CUSUM filter on log price changes (reference logic.py:152-221): a bar closes when the positive /
+    negative cumulative sum reaches +-max(sigma_mult * sigma[i], sigma_floor) at a tick that is not followed by a
+    same-timestamp tick.  Like the reference, NaNs of `sigma` are forward-filled IN PLACE from its first valid entry,
+    whose index opens the result.  Parallel-in-time fixed point on the device (csrc/fmk_cusum.hip)."""
+    import ctypes as C
+    ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    px = np.ascontiguousarray(prices, dtype=np.float64)
+    if not (len(px) == len(sigma) == len(ts)) or len(px) == 0:
+        raise ValueError("Prices, timestamps, and sigma arrays must have the same length.")
+    sg = sigma if (isinstance(sigma, np.ndarray) and sigma.dtype == np.float64 and sigma.flags["C_CONTIGUOUS"]
+                   and sigma.flags["WRITEABLE"]) else np.array(sigma, dtype=np.float64)
+    n = len(px)
+    out = np.empty(n, np.int64)
+    m = c_i64()
+    _ffi.default_context().call("fmk_cusum_bar_indexer", ptr(ts), ptr(px), ptr(sg), c_i64(n), c_f64(sigma_floor),
+                                c_f64(sigma_mult), ptr(out), c_i64(n), C.byref(m))
+    if sg is not sigma and isinstance(sigma, np.ndarray) and sigma.flags["WRITEABLE"]:
+        sigma[...] = sg                                   # keep the in-place fill visible to the caller
+    return out[:m.value].copy()

@@ -1,0 +1,275 @@
+// fmk_cusum.hip -- _cusum_bar_indexer (finmlkit/bar/logic.py:152-221) on gfx950.
+//
+// The reference is one sequential loop with a two-component state
+//     s_pos = max(0, s_pos + r_i),  s_neg = min(0, s_neg + r_i),   r_i = log(p_i / p_{i-1})
+// and a reset of ONE side when it crosses +-lambda_i at a tick that is not followed by a same-timestamp tick.
+// Because only one side resets, the state after a close is not a function of the close position alone (unlike the
+// volume bars), so there is no pointer chain to compose.  What the recursion does have is FORGETTING: the max / min
+// clamps and the resets erase the memory of the incoming state after a few hundred ticks.  That makes it a good
+// fit for a parallel-in-time fixed point:
+//     round 0 : every chunk of C ticks is simulated from the state (0, 0)             -> out_0[k]
+//     round r : chunk k is simulated from out_{r-1}[k-1]                               -> out_r[k]
+//     stop when out_r == out_{r-1} (bitwise): every chunk then started from the true state of its predecessor,
+//     i.e. the chunks reproduce the sequential loop exactly (chunk 0 is exact from round 0 on, so at most K rounds;
+//     on real streams 2-4).
+// One THREAD owns one chunk and runs the reference loop verbatim (same operations, same order), so the decisions are
+// the reference's; a final pass with the converged states writes the close indices at their scanned offsets.
+// The sigma forward-fill (logic.py:176-189, done IN PLACE like the reference) is a "last non-NaN" scan.
+#include <math.h>
+
+#include "fmk_common.h"
+#include "fmk_scan.h"
+
+#define CS_CHUNK 2048          // ticks per thread
+#define CS_THREADS 64
+
+// ---------------------------------------------------------------------------------------
+// sigma forward fill + first non-NaN index
+// ---------------------------------------------------------------------------------------
+#define FF_THREADS 256
+#define FF_ITEMS 8
+#define FF_TILE (FF_THREADS * FF_ITEMS)
+
+// last non-NaN value of the block's threads in thread order (NaN: none): exclusive value + block aggregate
+__device__ __forceinline__ double ff_block_exclusive(double mine, double *lds /*[4]*/, double *block_total)
+{
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    double inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(inc, d, 64);
+        if (lane >= d && isnan(inc)) inc = o;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    double pre = NAN;
+    for (int k = 0; k < w; ++k) pre = isnan(lds[k]) ? pre : lds[k];
+    double tot = NAN;
+    for (int k = 0; k < 4; ++k) tot = isnan(lds[k]) ? tot : lds[k];
+    *block_total = tot;
+    double prev = __shfl_up(inc, 1, 64);
+    if (lane == 0) prev = NAN;
+    __syncthreads();
+    return isnan(prev) ? pre : prev;
+}
+
+__global__ __launch_bounds__(FF_THREADS) void k_ff_tile(const double *__restrict__ x, int64_t n,
+                                                        double *__restrict__ tile_last,
+                                                        unsigned long long *first_valid)
+{
+    __shared__ double lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * FF_TILE + (int64_t)threadIdx.x * FF_ITEMS;
+    double last = NAN;
+    int64_t first = -1;
+#pragma unroll
+    for (int k = 0; k < FF_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        if (i < n) {
+            const double v = x[i];
+            if (!isnan(v)) { last = v; if (first < 0) first = i; }
+        }
+    }
+    if (first >= 0) atomicMin(first_valid, (unsigned long long)first);
+    double tot;
+    (void)ff_block_exclusive(last, lds, &tot);
+    if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
+}
+
+// one block: tile_last[t] := last non-NaN aggregate among tiles < t (exclusive), in place
+__global__ __launch_bounds__(1024) void k_ff_scan_tiles(double *tile_last, int64_t tiles)
+{
+    __shared__ double ws[16];
+    __shared__ double run;
+    if (threadIdx.x == 0) run = NAN;
+    __syncthreads();
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    for (int64_t b = 0; b < tiles; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const double v = i < tiles ? tile_last[i] : NAN;
+        double inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double o = __shfl_up(inc, d, 64);
+            if (lane >= d && isnan(inc)) inc = o;
+        }
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        double pre = run;
+        for (int k = 0; k < w; ++k) pre = isnan(ws[k]) ? pre : ws[k];
+        double prev = __shfl_up(inc, 1, 64);
+        if (lane == 0) prev = NAN;
+        if (i < tiles) tile_last[i] = isnan(prev) ? pre : prev;
+        __syncthreads();
+        if (threadIdx.x == 1023) run = isnan(inc) ? pre : inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(FF_THREADS) void k_ff_apply(double *__restrict__ x, int64_t n,
+                                                         const double *__restrict__ tile_pre)
+{
+    __shared__ double lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * FF_TILE + (int64_t)threadIdx.x * FF_ITEMS;
+    double v[FF_ITEMS];
+    double last = NAN;
+#pragma unroll
+    for (int k = 0; k < FF_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        v[k] = i < n ? x[i] : NAN;
+        last = isnan(v[k]) ? last : v[k];
+    }
+    double tot;
+    double cur = ff_block_exclusive(last, lds, &tot);
+    if (isnan(cur)) cur = tile_pre[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < FF_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        if (isnan(v[k])) { if (i < n && !isnan(cur)) x[i] = cur; }     // logic.py:187-189 (only after the first valid)
+        else cur = v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// chunk simulation
+// ---------------------------------------------------------------------------------------
+struct CsState { double sp, sn; };
+
+// One thread = one chunk [lo, hi) of the reference loop (logic.py:199-219), verbatim.
+//   in      : states to start from (in[k-1] for chunk k; chunk 0 starts from (0, 0)); nullptr: all (0, 0)
+//   out     : state at the end of the chunk
+//   changed : number of chunks whose `out` differs from `prev_out` (nullptr: not compared)
+//   closes  : nullptr, or the output array -- chunk k writes at closes[offsets[k] + ...]
+__global__ __launch_bounds__(CS_THREADS) void k_cusum_chunks(const int64_t *__restrict__ ts,
+                                                             const double *__restrict__ price,
+                                                             const double *__restrict__ sigma, int64_t n, int64_t first,
+                                                             int64_t chunks, double sigma_floor, double sigma_mult,
+                                                             const CsState *__restrict__ in, CsState *__restrict__ out,
+                                                             const CsState *__restrict__ prev_out,
+                                                             int64_t *__restrict__ counts,
+                                                             unsigned long long *changed,
+                                                             const int64_t *__restrict__ offsets,
+                                                             int64_t *__restrict__ closes)
+{
+    const int64_t k = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x;
+    if (k >= chunks) return;
+    const int64_t lo = first + 1 + k * CS_CHUNK;
+    const int64_t hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
+    double sp = 0.0, sn = 0.0;
+    if (in && k > 0) { sp = in[k - 1].sp; sn = in[k - 1].sn; }
+    int64_t cnt = 0;
+    int64_t w = closes ? offsets[k] : 0;
+    double pprev = price[lo - 1];
+    int64_t tcur = ts[lo];
+    for (int64_t i = lo; i < hi; ++i) {
+        const double p = price[i];
+        const double ret = log(p / pprev);                       // logic.py:200
+        pprev = p;
+        const double a = sp + ret, b = sn + ret;
+        sp = a > 0.0 ? a : 0.0;                                   // max(0.0, s_pos + ret): NaN -> 0.0
+        sn = b < 0.0 ? b : 0.0;                                   // min(0.0, s_neg + ret)
+        const int64_t tnext = i + 1 < n ? ts[i + 1] : 0;
+        const bool block = i + 1 < n && tcur == tnext;            // logic.py:206-209: inside a same-timestamp block
+        tcur = tnext;
+        if (block) continue;
+        double lam = sigma_mult * sigma[i];
+        lam = sigma_floor > lam ? sigma_floor : lam;              // max(lam, floor): a NaN lam stays NaN
+        if (sp >= lam) { if (closes) closes[w++] = i; ++cnt; sp = 0.0; }
+        else if (sn <= -lam) { if (closes) closes[w++] = i; ++cnt; sn = 0.0; }
+    }
+    if (out) {
+        out[k].sp = sp; out[k].sn = sn;
+        if (changed && prev_out) {
+            const bool same = __double_as_longlong(prev_out[k].sp) == __double_as_longlong(sp) &&
+                              __double_as_longlong(prev_out[k].sn) == __double_as_longlong(sn);
+            if (!same) atomicAdd(changed, 1ULL);
+        }
+    }
+    if (counts) counts[k] = cnt;
+}
+
+__global__ void k_cusum_first(int64_t *closes, int64_t first) { closes[0] = first; }
+
+extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma,
+                                         int64_t n, double sigma_floor, double sigma_mult, int64_t *d_out,
+                                         int64_t capacity, int64_t *n_out, int64_t *n_rounds)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Prices, timestamps, and sigma arrays must have the same length.");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    // ---- forward fill of sigma (in place) + first non-NaN index
+    const int64_t tiles = fmk_ceil_div(n, FF_TILE);
+    const int64_t max_chunks = fmk_ceil_div(n, CS_CHUNK) + 1;
+    const size_t scan_bytes = (((size_t)fmk_ceil_div(max_chunks, FMK_SCAN_TILE) + 1) * 8 + 255) & ~(size_t)255;
+    const size_t st_bytes = ((size_t)max_chunks * sizeof(CsState) + 255) & ~(size_t)255;
+    const size_t cnt_bytes = ((size_t)(max_chunks + 1) * 8 + 255) & ~(size_t)255;
+    const size_t ff_bytes = ((size_t)tiles * 8 + 255) & ~(size_t)255;
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, scan_bytes + 2 * st_bytes + cnt_bytes + ff_bytes, &scr));
+    char *base = (char *)scr + scan_bytes;
+    CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes);
+    int64_t *counts = (int64_t *)(base + 2 * st_bytes);
+    double *tile_last = (double *)(base + 2 * st_bytes + cnt_bytes);
+    unsigned long long *d_first = (unsigned long long *)ctx->d_mail;
+    unsigned long long *d_changed = d_first + 1;
+    const unsigned long long big = ~0ULL;
+    FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
+    k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first);
+    FMK_LAUNCH_CHECK(ctx);
+    k_ff_scan_tiles<<<1, 1024, 0, ctx->stream>>>(tile_last, tiles);
+    FMK_LAUNCH_CHECK(ctx);
+    k_ff_apply<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t first = ctx->h_mail[0];
+    if ((unsigned long long)first == big) first = 0;              // all NaN: logic.py:178 keeps index 0
+
+    // ---- parallel-in-time fixed point over the chunks of ticks first+1 .. n-1
+    const int64_t m = n - (first + 1);
+    const int64_t chunks = m > 0 ? fmk_ceil_div(m, CS_CHUNK) : 0;
+    int64_t rounds = 0;
+    int64_t total = 0;
+    if (chunks > 0) {
+        const unsigned blocks = (unsigned)fmk_ceil_div(chunks, CS_THREADS);
+        CsState *cur = st_a, *prev = st_b;
+        k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
+                                                              sigma_mult, nullptr, cur, nullptr, counts, nullptr, nullptr,
+                                                              nullptr);
+        FMK_LAUNCH_CHECK(ctx);
+        rounds = 1;
+        for (;;) {
+            CsState *t = cur; cur = prev; prev = t;               // prev = states of the last round
+            FMK_HIP(ctx, hipMemsetAsync(d_changed, 0, 8, ctx->stream));
+            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
+                                                                  sigma_mult, prev, cur, prev, counts, d_changed, nullptr,
+                                                                  nullptr);
+            FMK_LAUNCH_CHECK(ctx);
+            ++rounds;
+            FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_mail[1] == 0) break;                       // fixed point: every chunk started from the truth
+            if (rounds > chunks + 2) return fmk_set_error(ctx, FMK_E_HIP, "cusum: fixed point did not converge");
+        }
+        // counts -> offsets (+1 for the opening entry), total
+        FMK_TRY(fmk_exclusive_scan_i64(ctx, counts, counts, chunks, true));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], counts + chunks, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        total = ctx->h_mail[2];
+        if (d_out) {
+            if (capacity < total + 1)
+                return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(total + 1),
+                                     (long long)capacity);
+            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
+                                                                  sigma_mult, cur, nullptr, nullptr, nullptr, nullptr, counts,
+                                                                  d_out + 1);
+            FMK_LAUNCH_CHECK(ctx);
+        }
+    }
+    if (d_out) {
+        if (capacity < 1) return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: capacity 0");
+        k_cusum_first<<<1, 1, 0, ctx->stream>>>(d_out, first);   // logic.py:193: the first valid trade opens bar 0
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    if (n_out) *n_out = total + 1;
+    if (n_rounds) *n_rounds = rounds;
+    return FMK_OK;
+}

@@ -363,4 +363,26 @@ int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int
     return down(ctx, out, d_o, n);
 }
 
+int fmk_cusum_bar_indexer(fmk_ctx *ctx, const int64_t *ts, const double *price, double *sigma, int64_t n,
+                          double sigma_floor, double sigma_mult, int64_t *out, int64_t capacity, int64_t *n_out)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Prices, timestamps, and sigma arrays must have the same length.");
+    DevBag bag(ctx);
+    int64_t *d_ts, *d_o = nullptr;
+    double *d_p, *d_s;
+    FMK_TRY(bag.up(ts, n, &d_ts));
+    FMK_TRY(bag.up(price, n, &d_p));
+    FMK_TRY(bag.up((const double *)sigma, n, &d_s));
+    if (out) FMK_TRY(bag.out(n, &d_o));
+    int64_t m = 0;
+    FMK_TRY(fmk_cusum_bar_indexer_dev(ctx, d_ts, d_p, d_s, n, sigma_floor, sigma_mult, d_o, out ? n : 0, &m, nullptr));
+    if (n_out) *n_out = m;
+    FMK_TRY(down(ctx, sigma, (const double *)d_s, n));          // the reference forward-fills sigma in place
+    if (!out) return FMK_OK;
+    if (capacity < m)
+        return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)m,
+                             (long long)capacity);
+    return down(ctx, out, (const int64_t *)d_o, m);
+}
+
 }  // extern "C"

@@ -240,6 +240,16 @@ int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, int64_t win
                          double *d_out);
 int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, int is_sample, double *out);
 
+/* ---- CUSUM bars: finmlkit/bar/logic.py:152-221 ("next" rank 3) ------------------------------ */
+/* _cusum_bar_indexer: sigma is forward-filled IN PLACE from its first non-NaN entry (like the reference); the
+ * result starts with that entry's index, then one index per close.  d_out == NULL: count only (*n_out).
+ * *n_rounds (may be NULL): rounds the parallel-in-time fixed point needed.  FMK_E_CAPACITY: capacity < *n_out. */
+int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma, int64_t n,
+                              double sigma_floor, double sigma_mult, int64_t *d_out, int64_t capacity,
+                              int64_t *n_out, int64_t *n_rounds);
+int fmk_cusum_bar_indexer(fmk_ctx *ctx, const int64_t *ts, const double *price, double *sigma, int64_t n,
+                          double sigma_floor, double sigma_mult, int64_t *out, int64_t capacity, int64_t *n_out);
+
 /* ---- TradesData(preprocess=True) loops: finmlkit/bar/utils.py ("next" rank 4) ------------ */
 /* merge_split_trades (bar/utils.py:263-329): trades with the head's timestamp, maker flag and price (|dp| < 1e-8)
  * are merged, amounts summed in float32 in trade order; side = -1 if is_buyer_maker else 1 (is_buyer_maker may be

@@ -304,6 +304,34 @@ def gen_preprocess():
     save("preprocess", d)
 
 
+def gen_cusum():
+    """_cusum_bar_indexer (logic.py:152-221): EWM sigma with leading / interior NaNs, constant sigma, same-timestamp
+    print blocks (a close cannot happen inside one), floor-dominated thresholds."""
+    d = {}
+    ts, px, am, sd = orc.synth(42, 0, 20_000)
+    rng = np.random.default_rng(7)
+    px = 100.0 * np.exp(np.cumsum(rng.normal(0, 2e-4, len(ts))))          # returns large enough to trigger closes
+    tsb = ts.copy()
+    blk = rng.random(len(ts)) < 0.25
+    tsb[1:][blk[1:]] = 0
+    tsb = np.maximum.accumulate(tsb)                                       # 25 % of the ticks repeat the timestamp
+    r = rfutils.comp_lagged_returns(tsb, px, 5.0, True)
+    sig = rvol.ewmst(tsb, r, 60.0)
+    sig[3000:3040] = np.nan                                                # interior NaNs are forward-filled
+    cases = {"ewm": (tsb, px, sig, 5e-4, 2.0), "ewm_lowfloor": (tsb, px, sig, 1e-6, 1.5),
+             "const": (ts, px, np.full(len(ts), 1e-3), 5e-4, 2.0),
+             "allnan": (ts[:500], px[:500], np.full(500, np.nan), 5e-4, 2.0),
+             "floor": (ts, px, np.full(len(ts), 1e-9), 2e-3, 2.0)}
+    for name, (t_, p_, s_, fl, mult) in cases.items():
+        s_in = s_.copy()
+        idx = np.array(rlogic._cusum_bar_indexer(t_, p_, s_in, fl, mult), dtype=np.int64)
+        d[f"{name}__ts"], d[f"{name}__px"], d[f"{name}__sigma"] = t_, p_, s_
+        d[f"{name}__params"] = np.array([fl, mult])
+        d[f"{name}__idx"] = idx
+        d[f"{name}__sigma_filled"] = s_in
+    save("cusum", d)
+
+
 def gen_tradesdata():
     """TradesData(preprocess=True) end to end (data_model.py:236-246): raw exchange-style rows in millisecond
     timestamps, shuffled, with duplicated ids and an id gap longer than a minute."""
@@ -347,3 +375,4 @@ if __name__ == "__main__":
     gen_tick_size()
     gen_preprocess()
     gen_tradesdata()
+    gen_cusum()

@@ -132,7 +132,7 @@ def _dollar_bar_indexer(prices, volumes, threshold):
                       _f64(threshold))
 
 
-def _cusum_bar_indexer(timestamps, prices, sigma, sigma_floor, sigma_mult):
+def _cusum_bar_indexer(timestamps, prices, sigma, sigma_floor, sigma_mult, return_sigma=False):
     ts = np.ascontiguousarray(timestamps, dtype=np.int64)
     p = np.ascontiguousarray(prices, dtype=np.float64)
     s1 = np.array(sigma, dtype=np.float64)
@@ -142,7 +142,7 @@ def _cusum_bar_indexer(timestamps, prices, sigma, sigma_floor, sigma_mult):
     s2 = np.array(sigma, dtype=np.float64)
     lib().orc_cusum_bar_indexer(_p(ts), _p(p), _p(s2), _i64(len(p)), _f64(sigma_floor),
                                 _f64(sigma_mult), _p(out), _i64(m))
-    return out
+    return (out, s2) if return_sigma else out          # s2: sigma forward-filled like the reference does in place
 
 
 # ---------------------------------------------------------------- reducers

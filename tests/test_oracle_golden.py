@@ -155,3 +155,14 @@ def test_preprocess_loops_golden(orc):
                 assert g.dtype == w.dtype, (name, tag, k)
                 np.testing.assert_array_equal(g, w, err_msg=f"{name} {tag} {k}")
         np.testing.assert_array_equal(orc.comp_trade_side_vector(px), d[f"{name}__tickrule"])
+
+
+def test_cusum_indexer_golden(orc):
+    """_cusum_bar_indexer (logic.py:152-221): indices and the in-place sigma forward fill."""
+    d = G.load("cusum")
+    for name in ("ewm", "ewm_lowfloor", "const", "allnan", "floor"):
+        fl, mult = d[f"{name}__params"]
+        got, filled = orc._cusum_bar_indexer(d[f"{name}__ts"], d[f"{name}__px"], d[f"{name}__sigma"], fl, mult,
+                                             return_sigma=True)
+        np.testing.assert_array_equal(got, d[f"{name}__idx"], err_msg=name)
+        np.testing.assert_array_equal(filled, d[f"{name}__sigma_filled"], err_msg=name)
