@@ -12,8 +12,13 @@
 //     stop when out_r == out_{r-1} (bitwise): every chunk then started from the true state of its predecessor,
 //     i.e. the chunks reproduce the sequential loop exactly (chunk 0 is exact from round 0 on, so at most K rounds;
 //     on real streams 2-4).
-// One THREAD owns one chunk and runs the reference loop verbatim (same operations, same order), so the decisions are
-// the reference's; a final pass with the converged states writes the close indices at their scanned offsets.
+// One THREAD owns one chunk and runs the reference loop (same operations, same order), so the decisions are the
+// reference's; a final pass with the converged states writes the close indices at their scanned offsets.  The loop
+// inputs (log return, threshold / "cannot close" marker) are computed once and stored chunk-transposed so that
+// every round streams 16 B/tick fully coalesced; a chunk whose incoming state did not change is skipped.
+// Cost model: rounds ~ (ticks the state remembers) / CS_CHUNK.  Thresholds that are reached every few hundred ticks
+// converge in 2-4 rounds; thresholds that are almost never reached (one close per 10^5 ticks: the clamps rarely bind)
+// need hundreds of rounds -- still exact, but then the method has no advantage over the sequential loop.
 // The sigma forward-fill (logic.py:176-189, done IN PLACE like the reference) is a "last non-NaN" scan.
 #include <math.h>
 
@@ -134,47 +139,89 @@ __global__ __launch_bounds__(FF_THREADS) void k_ff_apply(double *__restrict__ x,
 // ---------------------------------------------------------------------------------------
 struct CsState { double sp, sn; };
 
-// One thread = one chunk [lo, hi) of the reference loop (logic.py:199-219), verbatim.
+// Per-tick inputs of the loop, computed ONCE and stored chunk-TRANSPOSED (element j of chunk k at [j * chunks + k]) so
+// that the one-thread-per-chunk simulation below reads fully coalesced 512 B per wave and per array:
+//   ret[t] = log(p_i / p_{i-1})                                             (logic.py:200)
+//   lam[t] = max(sigma_mult * sigma_i, sigma_floor), NaN inside a same-timestamp print block (logic.py:206-211):
+//            a NaN threshold can never be reached, which is exactly "this tick cannot close a bar"
+// for tick i = first + 1 + t, t = k * CS_CHUNK + j.  64 x 64 tiles through LDS (coalesced on both sides).
+__global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ ts, const double *__restrict__ price,
+                                                    const double *__restrict__ sigma, int64_t n, int64_t first,
+                                                    int64_t m, int64_t chunks, double sigma_floor, double sigma_mult,
+                                                    double *__restrict__ t_ret, double *__restrict__ t_lam)
+{
+    __shared__ double s_r[64][65];
+    __shared__ double s_l[64][65];
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    const int j0 = (int)blockIdx.y * 64;
+    const int col = threadIdx.x & 63, row4 = threadIdx.x >> 6;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = rr * 4 + row4;                                   // chunk inside the tile
+        const int64_t t = (k0 + row) * CS_CHUNK + j0 + col;
+        double r = 0.0, lam = NAN;
+        if (k0 + row < chunks && t < m) {
+            const int64_t i = first + 1 + t;
+            r = log(price[i] / price[i - 1]);
+            const bool block = i + 1 < n && ts[i] == ts[i + 1];
+            if (!block) {
+                lam = sigma_mult * sigma[i];
+                lam = sigma_floor > lam ? sigma_floor : lam;             // max(lam, floor): a NaN lam stays NaN
+            }
+        }
+        s_r[row][col] = r;
+        s_l[row][col] = lam;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 16; ++rr) {
+        const int jrow = rr * 4 + row4;                                  // tick inside the chunk
+        const int64_t k = k0 + col;
+        if (k < chunks) {
+            t_ret[(int64_t)(j0 + jrow) * chunks + k] = s_r[col][jrow];
+            t_lam[(int64_t)(j0 + jrow) * chunks + k] = s_l[col][jrow];
+        }
+    }
+}
+
+// One thread = one chunk of the reference loop (logic.py:199-219), same operations in the same order.
 //   in      : states to start from (in[k-1] for chunk k; chunk 0 starts from (0, 0)); nullptr: all (0, 0)
-//   out     : state at the end of the chunk
-//   changed : number of chunks whose `out` differs from `prev_out` (nullptr: not compared)
+//   last_in : the state chunk k was simulated from in the previous round -- unchanged input => unchanged output,
+//             the chunk is skipped (on real streams most chunks converge after 2-3 rounds)
+//   changed : number of chunks whose `out` differs from `prev_out`
 //   closes  : nullptr, or the output array -- chunk k writes at closes[offsets[k] + ...]
-__global__ __launch_bounds__(CS_THREADS) void k_cusum_chunks(const int64_t *__restrict__ ts,
-                                                             const double *__restrict__ price,
-                                                             const double *__restrict__ sigma, int64_t n, int64_t first,
-                                                             int64_t chunks, double sigma_floor, double sigma_mult,
+__global__ __launch_bounds__(CS_THREADS) void k_cusum_chunks(const double *__restrict__ t_ret,
+                                                             const double *__restrict__ t_lam, int64_t m,
+                                                             int64_t first, int64_t chunks,
                                                              const CsState *__restrict__ in, CsState *__restrict__ out,
                                                              const CsState *__restrict__ prev_out,
-                                                             int64_t *__restrict__ counts,
-                                                             unsigned long long *changed,
+                                                             CsState *__restrict__ last_in,
+                                                             int64_t *__restrict__ counts, unsigned long long *changed,
                                                              const int64_t *__restrict__ offsets,
                                                              int64_t *__restrict__ closes)
 {
     const int64_t k = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x;
     if (k >= chunks) return;
-    const int64_t lo = first + 1 + k * CS_CHUNK;
-    const int64_t hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
     double sp = 0.0, sn = 0.0;
     if (in && k > 0) { sp = in[k - 1].sp; sn = in[k - 1].sn; }
+    if (prev_out && last_in && !closes) {
+        const bool same_in = __double_as_longlong(last_in[k].sp) == __double_as_longlong(sp) &&
+                             __double_as_longlong(last_in[k].sn) == __double_as_longlong(sn);
+        if (same_in) { out[k] = prev_out[k]; return; }                   // counts[k] already holds this result
+    }
+    if (last_in) { last_in[k].sp = sp; last_in[k].sn = sn; }
+    const int64_t t0 = k * CS_CHUNK;
+    const int len = (int)(m - t0 < CS_CHUNK ? m - t0 : CS_CHUNK);
     int64_t cnt = 0;
     int64_t w = closes ? offsets[k] : 0;
-    double pprev = price[lo - 1];
-    int64_t tcur = ts[lo];
-    for (int64_t i = lo; i < hi; ++i) {
-        const double p = price[i];
-        const double ret = log(p / pprev);                       // logic.py:200
-        pprev = p;
+    const double *pr = t_ret + k, *pl = t_lam + k;
+#pragma unroll 8
+    for (int j = 0; j < len; ++j) {
+        const double ret = pr[(int64_t)j * chunks];
+        const double lam = pl[(int64_t)j * chunks];
         const double a = sp + ret, b = sn + ret;
         sp = a > 0.0 ? a : 0.0;                                   // max(0.0, s_pos + ret): NaN -> 0.0
         sn = b < 0.0 ? b : 0.0;                                   // min(0.0, s_neg + ret)
-        const int64_t tnext = i + 1 < n ? ts[i + 1] : 0;
-        const bool block = i + 1 < n && tcur == tnext;            // logic.py:206-209: inside a same-timestamp block
-        tcur = tnext;
-        if (block) continue;
-        double lam = sigma_mult * sigma[i];
-        lam = sigma_floor > lam ? sigma_floor : lam;              // max(lam, floor): a NaN lam stays NaN
-        if (sp >= lam) { if (closes) closes[w++] = i; ++cnt; sp = 0.0; }
-        else if (sn <= -lam) { if (closes) closes[w++] = i; ++cnt; sn = 0.0; }
+        if (sp >= lam) { if (closes) closes[w++] = first + 1 + t0 + j; ++cnt; sp = 0.0; }
+        else if (sn <= -lam) { if (closes) closes[w++] = first + 1 + t0 + j; ++cnt; sn = 0.0; }
     }
     if (out) {
         out[k].sp = sp; out[k].sn = sn;
@@ -195,21 +242,25 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Prices, timestamps, and sigma arrays must have the same length.");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    // ---- forward fill of sigma (in place) + first non-NaN index
+    // ---- scratch layout: [scan tile sums | states a, b, last_in | counts | forward-fill tiles | ret^T | lam^T]
     const int64_t tiles = fmk_ceil_div(n, FF_TILE);
     const int64_t max_chunks = fmk_ceil_div(n, CS_CHUNK) + 1;
     const size_t scan_bytes = (((size_t)fmk_ceil_div(max_chunks, FMK_SCAN_TILE) + 1) * 8 + 255) & ~(size_t)255;
     const size_t st_bytes = ((size_t)max_chunks * sizeof(CsState) + 255) & ~(size_t)255;
     const size_t cnt_bytes = ((size_t)(max_chunks + 1) * 8 + 255) & ~(size_t)255;
     const size_t ff_bytes = ((size_t)tiles * 8 + 255) & ~(size_t)255;
+    const size_t tr_bytes = ((size_t)max_chunks * CS_CHUNK * 8 + 255) & ~(size_t)255;
     void *scr;
-    FMK_TRY(fmk_scratch(ctx, scan_bytes + 2 * st_bytes + cnt_bytes + ff_bytes, &scr));
+    FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes, &scr));
     char *base = (char *)scr + scan_bytes;
-    CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes);
-    int64_t *counts = (int64_t *)(base + 2 * st_bytes);
-    double *tile_last = (double *)(base + 2 * st_bytes + cnt_bytes);
+    CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes), *last_in = (CsState *)(base + 2 * st_bytes);
+    int64_t *counts = (int64_t *)(base + 3 * st_bytes);
+    double *tile_last = (double *)(base + 3 * st_bytes + cnt_bytes);
+    double *t_ret = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes);
+    double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + tr_bytes);
     unsigned long long *d_first = (unsigned long long *)ctx->d_mail;
     unsigned long long *d_changed = d_first + 1;
+    // ---- forward fill of sigma (in place) + first non-NaN index
     const unsigned long long big = ~0ULL;
     FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
     k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first);
@@ -229,19 +280,21 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     int64_t rounds = 0;
     int64_t total = 0;
     if (chunks > 0) {
+        const dim3 pg((unsigned)fmk_ceil_div(chunks, 64), CS_CHUNK / 64);
+        k_cusum_prep<<<pg, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, t_ret,
+                                                 t_lam);
+        FMK_LAUNCH_CHECK(ctx);
         const unsigned blocks = (unsigned)fmk_ceil_div(chunks, CS_THREADS);
         CsState *cur = st_a, *prev = st_b;
-        k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
-                                                              sigma_mult, nullptr, cur, nullptr, counts, nullptr, nullptr,
-                                                              nullptr);
+        k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(t_ret, t_lam, m, first, chunks, nullptr, cur, nullptr, last_in,
+                                                              counts, nullptr, nullptr, nullptr);
         FMK_LAUNCH_CHECK(ctx);
         rounds = 1;
         for (;;) {
             CsState *t = cur; cur = prev; prev = t;               // prev = states of the last round
             FMK_HIP(ctx, hipMemsetAsync(d_changed, 0, 8, ctx->stream));
-            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
-                                                                  sigma_mult, prev, cur, prev, counts, d_changed, nullptr,
-                                                                  nullptr);
+            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(t_ret, t_lam, m, first, chunks, prev, cur, prev, last_in,
+                                                                  counts, d_changed, nullptr, nullptr);
             FMK_LAUNCH_CHECK(ctx);
             ++rounds;
             FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -258,9 +311,8 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
             if (capacity < total + 1)
                 return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(total + 1),
                                      (long long)capacity);
-            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, chunks, sigma_floor,
-                                                                  sigma_mult, cur, nullptr, nullptr, nullptr, nullptr, counts,
-                                                                  d_out + 1);
+            k_cusum_chunks<<<blocks, CS_THREADS, 0, ctx->stream>>>(t_ret, t_lam, m, first, chunks, cur, nullptr, nullptr,
+                                                                  nullptr, nullptr, nullptr, counts, d_out + 1);
             FMK_LAUNCH_CHECK(ctx);
         }
     }
