@@ -179,6 +179,37 @@ class ShardedTimeBars:
         return self.plan.n_bars
 
 
+    def features(self, recv_h: int, price_tick_size: float, imbalance_factor: float = 3.0):
+        """cfg 4 on the shard (after `finish`): order-flow + footprints of this rank's bars through the same
+        kernels as one GPU -- interior bars in local coordinates, the boundary bar from [halo | shard].
+
+        -> (directional dict, level_counts int64[B], flat dict, per-bar dict) as host arrays in bar order.  The
+        spread columns of the global stream's very first bar use the reference's wrap-around tick prices[-1]
+        (base.py:485-500), which on rank 0 is the last tick of the SHARD: undefined across shards, as in the
+        single-GPU path it is "the last tick of whatever array is passed"."""
+        np = self._np
+        from .engine import to_host
+        parts = []
+        n_edges = self.plan.n_bars + 1
+        if self.rank > 0:
+            th = self.t.with_halo(recv_h)
+            parts.append(th.bars_fused(self._ci0, price_tick_size, imbalance_factor, want_median=False))
+            if n_edges > 2:
+                parts.append(self.t.bars_fused(self.idx.view(1), price_tick_size, imbalance_factor, want_median=False))
+        else:
+            parts.append(self.t.bars_fused(self.idx, price_tick_size, imbalance_factor, want_median=False))
+        ds, lv, fl, pb = [], [], [], []
+        for o, d, nz, off, flat, bar, bad in parts:
+            if int(bad.to_host()[0]):
+                raise ValueError("Something went wrong! Invalid price level index!")
+            ds.append(to_host(d))
+            lv.append(np.diff(off.to_host()))
+            fl.append(to_host(flat))
+            pb.append(to_host(bar))
+        cat = lambda dicts: {k: np.concatenate([x[k] for x in dicts]) for k in dicts[0]}
+        return cat(ds), np.concatenate(lv), cat(fl), cat(pb)
+
+
 def halo_lengths(comm: Comm, n_local: int, close_of_last_edge: int) -> Tuple[int, int]:
     """(halo I send, halo I receive).  The halo is ticks [close_of_last_edge, n_local)."""
     send = n_local - close_of_last_edge if comm.rank + 1 < comm.world else 0
