@@ -385,4 +385,36 @@ int fmk_cusum_bar_indexer(fmk_ctx *ctx, const int64_t *ts, const double *price, 
     return down(ctx, out, (const int64_t *)d_o, m);
 }
 
+int fmk_volume_profile_rolling(fmk_ctx *ctx, const int64_t *bar_ts, const double *highs, const double *lows,
+                               const int64_t *level_offsets, const int32_t *price_levels, const float *buy_volumes,
+                               const float *sell_volumes, int64_t n_bars, int64_t first_bar, int64_t window_ns,
+                               int64_t n_bins, double price_tick, double va_pct, int32_t *poc, int32_t *hva, int32_t *lva,
+                               float *pct)
+{
+    if (n_bars <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Input arrays should have the same length and be non-empty.");
+    const int64_t nl = level_offsets[n_bars];
+    DevBag bag(ctx);
+    int64_t *d_ts, *d_off;
+    double *d_hi, *d_lo;
+    int32_t *d_pl, *d_poc, *d_hva, *d_lva;
+    float *d_b, *d_s, *d_pct;
+    FMK_TRY(bag.up(bar_ts, n_bars, &d_ts));
+    FMK_TRY(bag.up(highs, n_bars, &d_hi));
+    FMK_TRY(bag.up(lows, n_bars, &d_lo));
+    FMK_TRY(bag.up(level_offsets, n_bars + 1, &d_off));
+    FMK_TRY(bag.up(price_levels, nl, &d_pl));
+    FMK_TRY(bag.up(buy_volumes, nl, &d_b));
+    FMK_TRY(bag.up(sell_volumes, nl, &d_s));
+    FMK_TRY(bag.out(n_bars, &d_poc));
+    FMK_TRY(bag.out(n_bars, &d_hva));
+    FMK_TRY(bag.out(n_bars, &d_lva));
+    FMK_TRY(bag.out(n_bars, &d_pct));
+    FMK_TRY(fmk_volume_profile_rolling_dev(ctx, d_ts, d_hi, d_lo, d_off, d_pl, d_b, d_s, n_bars, first_bar, window_ns,
+                                           n_bins, price_tick, va_pct, d_poc, d_hva, d_lva, d_pct));
+    FMK_TRY(down(ctx, poc, (const int32_t *)d_poc, n_bars));
+    FMK_TRY(down(ctx, hva, (const int32_t *)d_hva, n_bars));
+    FMK_TRY(down(ctx, lva, (const int32_t *)d_lva, n_bars));
+    return down(ctx, pct, (const float *)d_pct, n_bars);
+}
+
 }  // extern "C"

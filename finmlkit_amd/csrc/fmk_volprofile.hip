@@ -1,0 +1,247 @@
+// fmk_volprofile.hip -- volume_profile_rolling (finmlkit/feature/core/volume.py:403-456) on
+// gfx950: rolling-window aggregation of the CSR footprints, optional bucketing, POC / value area, share of volume
+// above the POC.  Direct consumer of the footprint kernel's output (no ragged Python lists).
+//
+// One wave per output bar i:
+//   window [s, e) of bars by two binary searches on the bar timestamps (aggregate_footprint :158-166);
+//   level range from min(lows) / max(highs) of the window, rounded half-even like Python's round();
+//   the window's dense level histogram lives in the wave's LDS slice; the bars of the window are added ONE AFTER THE
+//   OTHER (lanes across the levels of a bar, which are distinct), i.e. every level sees its float32 adds in the
+//   reference's order (:196-200);
+//   bucket_price_levels (:206-275): one lane per bin adds its levels in level order (float32);
+//   comp_poc_hva_lva (:278-369): NumPy-pairwise float32 total, first argmax, the value-area walk by lane 0 with
+//   float64 scalars (Numba-typed semantics); calc_volume_percentage_above_poc (:372-400).
+#include "fmk_footprint.h"
+
+#define VP_MAX_LEVELS 8192
+
+__device__ __forceinline__ int64_t vp_lower(const int64_t *a, int64_t n, int64_t key)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int64_t vp_upper(const int64_t *a, int64_t n, int64_t key)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// window of bar i and its level range; uniform results
+__device__ __forceinline__ void vp_window(const int64_t *ts, const double *highs, const double *lows, int64_t nb, int64_t i,
+                                          int64_t window_ns, double tick, int lane, int64_t &s, int64_t &e,
+                                          int64_t &minl, int64_t &maxl)
+{
+    const int64_t end_ts = ts[i];
+    s = vp_lower(ts, nb, end_ts - window_ns);
+    e = vp_upper(ts, nb, end_ts);
+    if (s == e) s = s - 1 > 0 ? s - 1 : 0;                       // volume.py:164-166
+    double mn = INFINITY, mx = -INFINITY;
+    for (int64_t t = s + lane; t < e; t += 64) { mn = fmin(mn, lows[t]); mx = fmax(mx, highs[t]); }
+    mn = fmk_dpp_reduce(mn, (double)INFINITY, FmkOpMin());
+    mx = fmk_dpp_reduce(mx, (double)-INFINITY, FmkOpMax());
+    minl = (int64_t)rint(mn / tick);                             // int(round(x / price_tick)), half-even
+    maxl = (int64_t)rint(mx / tick);
+}
+
+__global__ __launch_bounds__(256) void k_vp_max_levels(const int64_t *__restrict__ ts, const double *__restrict__ highs,
+                                                       const double *__restrict__ lows, int64_t nb, int64_t first,
+                                                       int64_t window_ns, double tick, unsigned long long *max_levels)
+{
+    const int lane = fmk_lane();
+    const int64_t i = first + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nb) return;
+    int64_t s, e, minl, maxl;
+    vp_window(ts, highs, lows, nb, i, window_ns, tick, lane, s, e, minl, maxl);
+    const int64_t L = maxl - minl + 1;
+    if (lane == 0 && L > 0) atomicMax(max_levels, (unsigned long long)L);
+}
+
+// status bits written to *status
+#define VP_BAD_LEVEL 1      // a footprint level outside its window's range
+#define VP_ONE_LEVEL 2      // bucketing a window that spans a single level (the reference raises there)
+
+__global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restrict__ ts, const double *__restrict__ highs,
+                                                        const double *__restrict__ lows,
+                                                        const int64_t *__restrict__ off,
+                                                        const int32_t *__restrict__ levels,
+                                                        const float *__restrict__ buy, const float *__restrict__ sell,
+                                                        int64_t nb, int64_t first, int64_t window_ns, int64_t n_bins,
+                                                        double tick, double va_pct, int cap, int32_t *__restrict__ poc,
+                                                        int32_t *__restrict__ hva, int32_t *__restrict__ lva,
+                                                        float *__restrict__ pct, unsigned int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;
+    const size_t per_wave = (size_t)(cap + 8) * 8 + 256;
+    float *ab = (float *)(smem + (size_t)wib * per_wave);        // [cap + 8] buy sums, later totals
+    float *as = ab + (cap + 8);                                   // [cap + 8] sell sums, later binned volumes
+    int *stk = (int *)(as + (cap + 8));                           // 64 ints (pairwise-sum stack)
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t i = first + (int64_t)blockIdx.x * wpb + wib; i < nb; i += nwaves) {
+        int64_t s, e, minl, maxl;
+        vp_window(ts, highs, lows, nb, i, window_ns, tick, lane, s, e, minl, maxl);
+        const int64_t Ll = maxl - minl + 1;
+        if (Ll < 1 || Ll > cap) { if (lane == 0) atomicOr(status, VP_BAD_LEVEL); continue; }
+        const int L = (int)Ll;
+        for (int k = lane; k < L; k += 64) { ab[k] = 0.f; as[k] = 0.f; }
+        __builtin_amdgcn_wave_barrier();
+        // ---- aggregate_footprint: bars in order, lanes across the (distinct) levels of a bar
+        bool bad = false;
+        for (int64_t t = s; t < e; ++t) {
+            const int64_t r0 = fmk_uniform(off[t]), r1 = fmk_uniform(off[t + 1]);
+            for (int64_t r = r0 + lane; r < r1; r += 64) {
+                const int64_t idx = (int64_t)levels[r] - minl;
+                if (idx < 0 || idx >= L) { bad = true; continue; }
+                ab[idx] += buy[r];                                // float32 += float32, one add per level per bar
+                as[idx] += sell[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VP_BAD_LEVEL);
+        for (int k = lane; k < L; k += 64) ab[k] = ab[k] + as[k];  // total_volumes = buy + sell (float32)
+        __builtin_amdgcn_wave_barrier();
+        // ---- bucket_price_levels
+        float *vol = ab;
+        int np_ = L;
+        int64_t bw = 1, nbk = 0;
+        if (n_bins >= 0) {
+            const int64_t range = maxl - minl;
+            bw = range / n_bins;
+            if (bw < 1) bw = 1;
+            if (bw % 2 == 0) bw += 1;
+            const int64_t n_edges = (range + bw + bw - 1) / bw;   // len(arange(min, max + bw, bw))
+            nbk = n_edges - 1;
+            if (n_edges < 2) { if (lane == 0) atomicOr(status, VP_ONE_LEVEL); continue; }
+            np_ = (int)(nbk + ((range / bw >= nbk) ? 1 : 0));     // + leftover bin iff the last level falls past the bins
+            for (int b = lane; b < np_; b += 64) {
+                const int64_t k0 = (int64_t)b * bw;
+                const int64_t k1 = (b == nbk) ? L : (k0 + bw < L ? k0 + bw : L);
+                float acc = 0.f;
+                for (int64_t k = k0; k < k1; ++k) acc += ab[k];   // float32 adds in level order (volume.py:262-270)
+                as[b] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            vol = as;
+        }
+        // ---- comp_poc_hva_lva
+        const float total = fp_pairwise_f32(vol, np_, lane, stk);
+        float best = -INFINITY;
+        int best_i = 0x7FFFFFFF;
+        for (int k = lane; k < np_; k += 64) {
+            const float v = vol[k];
+            if (v > best) { best = v; best_i = k; }
+        }
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            const float ob = __shfl_xor(best, x, 64);
+            const int oi = __shfl_xor(best_i, x, 64);
+            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+        }
+        if (best_i == 0x7FFFFFFF) best_i = 0;                     // all-NaN guard: np.argmax -> 0
+        if (lane == 0) {
+            const int n = np_;
+            auto pl = [&](int k) -> int32_t {
+                if (n_bins < 0) return (int32_t)(minl + k);
+                if (k < nbk) return (int32_t)(minl + (int64_t)k * bw + (bw - 1) / 2);     // (e_k + e_k+1 - 1) // 2
+                return (int32_t)maxl;
+            };
+            const int pi = best_i;
+            const int32_t poc_price = pl(pi);
+            const double va_thrs = (double)total * (va_pct / 100.0);
+            double cum = vol[pi];
+            int32_t hv = poc_price, lv = poc_price;
+            int up = pi + 1, down = pi - 1;
+            double cu = 0.0, cd = 0.0;
+            if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+            if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+            while (cum < va_thrs) {
+                if (cu > cd) {
+                    cum += cu;
+                    hv = pl(up + 1 < n - 1 ? up + 1 : n - 1);
+                    up += 2;
+                    cu = -1.0;
+                    if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+                } else if (cu < cd) {
+                    cum += cd;
+                    lv = pl(down - 1 > 0 ? down - 1 : 0);
+                    down -= 2;
+                    cd = -1.0;
+                    if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+                } else if (cu == cd && cd != -1.0) {
+                    cum += cu + cd;
+                    hv = pl(up + 1 < n - 1 ? up + 1 : n - 1);
+                    lv = pl(down - 1 > 0 ? down - 1 : 0);
+                    up += 2; down -= 2;
+                    cu = -1.0;
+                    if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+                    cd = -1.0;
+                    if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+                } else break;                                      // the reference's "stuck in loop" exit
+            }
+            float p = 0.f;
+            if (total > 0.f) {                                     // calc_volume_percentage_above_poc
+                double above = 0.0;
+                for (int k = 0; k < n; ++k) if (pl(k) > poc_price) above += (double)vol[k];
+                if (above > 0.0) p = (float)(above / (double)total);
+            }
+            poc[i] = poc_price; hva[i] = hv; lva[i] = lv; pct[i] = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar_ts, const double *d_highs,
+                                              const double *d_lows, const int64_t *d_level_offsets,
+                                              const int32_t *d_price_levels, const float *d_buy_volumes,
+                                              const float *d_sell_volumes, int64_t n_bars, int64_t first_bar,
+                                              int64_t window_ns, int64_t n_bins, double price_tick, double va_pct,
+                                              int32_t *d_poc, int32_t *d_hva, int32_t *d_lva, float *d_pct)
+{
+    if (n_bars <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Input arrays should have the same length and be non-empty.");
+    if (!(price_tick > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick must be > 0");
+    if (n_bins == 0) return fmk_set_error(ctx, FMK_E_ZERODIV, "integer division or modulo by zero");   // range // n_bins
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipMemsetAsync(d_poc, 0, (size_t)n_bars * 4, ctx->stream));
+    FMK_HIP(ctx, hipMemsetAsync(d_hva, 0, (size_t)n_bars * 4, ctx->stream));
+    FMK_HIP(ctx, hipMemsetAsync(d_lva, 0, (size_t)n_bars * 4, ctx->stream));
+    FMK_HIP(ctx, hipMemsetAsync(d_pct, 0, (size_t)n_bars * 4, ctx->stream));
+    if (first_bar >= n_bars) return FMK_OK;
+    unsigned long long *d_max = (unsigned long long *)ctx->d_mail;
+    unsigned int *d_status = (unsigned int *)(d_max + 1);
+    FMK_HIP(ctx, hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    const int64_t work = n_bars - first_bar;
+    k_vp_max_levels<<<(unsigned)fmk_ceil_div(work, 4), 256, 0, ctx->stream>>>(d_bar_ts, d_highs, d_lows, n_bars, first_bar,
+                                                                             window_ns, price_tick, d_max);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t max_levels = ctx->h_mail[0];
+    if (max_levels > VP_MAX_LEVELS)
+        return fmk_set_error(ctx, FMK_E_CAPACITY, "volume_profile_rolling: a window spans %lld price levels; this build "
+                             "supports <= %d", (long long)max_levels, VP_MAX_LEVELS);
+    int cap = 1024, wpb = 4;
+    if (max_levels > 1024) { cap = max_levels > 4096 ? 8192 : 4096; wpb = 1; }
+    const size_t smem = (size_t)wpb * ((size_t)(cap + 8) * 8 + 256);
+    if (smem > 64 * 1024)
+        FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_volume_profile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int64_t blocks = fmk_ceil_div(work, wpb);
+    const int64_t capb = (int64_t)ctx->n_cu * 32;
+    if (blocks > capb) blocks = capb;
+    k_volume_profile<<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(d_bar_ts, d_highs, d_lows, d_level_offsets,
+                                                                       d_price_levels, d_buy_volumes, d_sell_volumes, n_bars,
+                                                                       first_bar, window_ns, n_bins, price_tick, va_pct, cap,
+                                                                       d_poc, d_hva, d_lva, d_pct, d_status);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned st = (unsigned)(ctx->h_mail[1] & 0xFFFFFFFF);
+    if (st & VP_BAD_LEVEL) return fmk_set_error(ctx, FMK_E_LEVEL, "volume_profile_rolling: footprint level outside its window");
+    if (st & VP_ONE_LEVEL)
+        return fmk_set_error(ctx, FMK_E_LEVEL, "volume_profile_rolling: a window spans a single price level; it cannot be "
+                             "bucketed (the reference raises a broadcast ValueError here)");
+    return FMK_OK;
+}

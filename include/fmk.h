@@ -240,6 +240,24 @@ int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, int64_t win
                          double *d_out);
 int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, int is_sample, double *out);
 
+/* ---- rolling volume profile: finmlkit/feature/core/volume.py:133-456 ("next" rank 2) --------- */
+/* volume_profile_rolling on CSR footprints (level_offsets[n_bars+1] + flat level arrays, the layout
+ * fmk_comp_bar_footprints produces).  first_bar = searchsorted(bar_ts, bar_ts[0] + window_ns) (volume.py:432):
+ * earlier bars keep 0.  n_bins < 0: no bucketing (n_bins=None).  Outputs: POC / HVA / LVA in tick units (int32) and
+ * the share of volume above the POC (float32).  FMK_E_LEVEL: a level outside its window, or a single-level window
+ * with bucketing (the reference raises); FMK_E_ZERODIV: n_bins == 0; FMK_E_CAPACITY: a window wider than 8192
+ * levels. */
+int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar_ts, const double *d_highs, const double *d_lows,
+                                   const int64_t *d_level_offsets, const int32_t *d_price_levels,
+                                   const float *d_buy_volumes, const float *d_sell_volumes, int64_t n_bars,
+                                   int64_t first_bar, int64_t window_ns, int64_t n_bins, double price_tick,
+                                   double va_pct, int32_t *d_poc, int32_t *d_hva, int32_t *d_lva, float *d_pct);
+int fmk_volume_profile_rolling(fmk_ctx *ctx, const int64_t *bar_ts, const double *highs, const double *lows,
+                               const int64_t *level_offsets, const int32_t *price_levels, const float *buy_volumes,
+                               const float *sell_volumes, int64_t n_bars, int64_t first_bar, int64_t window_ns,
+                               int64_t n_bins, double price_tick, double va_pct, int32_t *poc, int32_t *hva,
+                               int32_t *lva, float *pct);
+
 /* ---- CUSUM bars: finmlkit/bar/logic.py:152-221 ("next" rank 3) ------------------------------ */
 /* _cusum_bar_indexer: sigma is forward-filled IN PLACE from its first non-NaN entry (like the reference); the
  * result starts with that entry's index, then one index per close.  d_out == NULL: count only (*n_out).

@@ -886,3 +886,140 @@ int orc_comp_trade_side_vector(const double *prices, int64_t n, int8_t *out)
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ */
+/* "Next" rank 2: rolling volume profile                               */
+/* finmlkit/feature/core/volume.py: aggregate_footprint :133-203,      */
+/* bucket_price_levels :206-275, comp_poc_hva_lva :278-369,            */
+/* calc_volume_percentage_above_poc :372-400, volume_profile_rolling   */
+/* :403-456.  Footprints in CSR form (off[B+1] + flat level arrays).   */
+/* Typed (Numba) semantics: float32 arrays, float64 scalars.           */
+/* ORC_E_LEVEL: a window spans ONE price level with bucketing on -- the */
+/* reference (pure-Python mode) raises a broadcast ValueError there.    */
+/* ------------------------------------------------------------------ */
+static int64_t orc_lower_i64(const int64_t *a, int64_t n, int64_t key)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+static int64_t orc_upper_i64(const int64_t *a, int64_t n, int64_t key)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* comp_poc_hva_lva + calc_volume_percentage_above_poc on one profile */
+static void orc_poc_hva_lva(const int32_t *pl, const float *vol, int64_t n, double va_pct,
+                            int32_t *poc, int32_t *hva, int32_t *lva, float *pct)
+{
+    float total = orc_pairwise_f32(vol, n);                       /* np.sum(float32 array) */
+    int64_t pi = 0;
+    for (int64_t k = 1; k < n; ++k) if (vol[k] > vol[pi]) pi = k; /* first argmax */
+    int32_t poc_price = pl[pi];
+    double va_thrs = (double)total * (va_pct / 100.0);
+    double cum = vol[pi];
+    int32_t hv = poc_price, lv = poc_price;
+    int64_t up = pi + 1, down = pi - 1;
+    double cu = 0.0, cd = 0.0;
+    if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+    if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+    while (cum < va_thrs) {
+        if (cu > cd) {
+            cum += cu;
+            hv = pl[up + 1 < n - 1 ? up + 1 : n - 1];
+            up += 2;
+            cu = -1.0;
+            if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+        } else if (cu < cd) {
+            cum += cd;
+            lv = pl[down - 1 > 0 ? down - 1 : 0];
+            down -= 2;
+            cd = -1.0;
+            if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+        } else if (cu == cd && cd != -1.0) {
+            cum += cu + cd;
+            hv = pl[up + 1 < n - 1 ? up + 1 : n - 1];
+            lv = pl[down - 1 > 0 ? down - 1 : 0];
+            up += 2; down -= 2;
+            cu = -1.0;
+            if (up < n) { cu = vol[up]; if (up + 1 < n) cu += vol[up + 1]; }
+            cd = -1.0;
+            if (down >= 0) { cd = vol[down]; if (down - 1 >= 0) cd += vol[down - 1]; }
+        } else break;                                              /* "BUG! Stuck in loop" branch */
+    }
+    *poc = poc_price; *hva = hv; *lva = lv;
+    float p = 0.0f;
+    if (total > 0.0f) {
+        double above = 0.0;
+        for (int64_t k = 0; k < n; ++k) if (pl[k] > poc_price) above += vol[k];
+        if (above > 0.0) p = (float)(above / (double)total);
+    }
+    *pct = p;
+}
+
+int orc_volume_profile_rolling(const int64_t *ts, const double *highs, const double *lows,
+                               const int64_t *off, const int32_t *levels, const float *buy, const float *sell,
+                               int64_t nb, int64_t window_ns, int64_t n_bins, double tick, double va_pct,
+                               int32_t *poc, int32_t *hva, int32_t *lva, float *pct)
+{
+    if (nb <= 0) return ORC_E_ARG;
+    for (int64_t i = 0; i < nb; ++i) { poc[i] = hva[i] = lva[i] = 0; pct[i] = 0.0f; }
+    int64_t first = orc_lower_i64(ts, nb, ts[0] + window_ns);
+    for (int64_t i = first; i < nb; ++i) {
+        int64_t end_ts = ts[i], start_ts = end_ts - window_ns;
+        int64_t s = orc_lower_i64(ts, nb, start_ts), e = orc_upper_i64(ts, nb, end_ts);
+        if (s == e) s = s - 1 > 0 ? s - 1 : 0;
+        double mn = lows[s], mx = highs[s];
+        for (int64_t t = s + 1; t < e; ++t) { if (lows[t] < mn) mn = lows[t]; if (highs[t] > mx) mx = highs[t]; }
+        int64_t minl = (int64_t)nearbyint(mn / tick), maxl = (int64_t)nearbyint(mx / tick);
+        int64_t L = maxl - minl + 1;
+        if (L < 1) return ORC_E_ARG;
+        float *ab = (float *)calloc((size_t)L, sizeof(float)), *as = (float *)calloc((size_t)L, sizeof(float));
+        float *tot = (float *)malloc(sizeof(float) * (size_t)(L + 1));
+        int32_t *pl = (int32_t *)malloc(sizeof(int32_t) * (size_t)(L + 1));
+        if (!ab || !as || !tot || !pl) { free(ab); free(as); free(tot); free(pl); return ORC_E_NOMEM; }
+        for (int64_t t = s; t < e; ++t)
+            for (int64_t r = off[t]; r < off[t + 1]; ++r) {
+                int64_t idx = (int64_t)levels[r] - minl;            /* searchsorted on a dense arange */
+                if (idx < 0 || idx >= L) { free(ab); free(as); free(tot); free(pl); return ORC_E_LEVEL; }
+                ab[idx] += buy[r];
+                as[idx] += sell[r];
+            }
+        int64_t np_ = L;
+        for (int64_t k = 0; k < L; ++k) { tot[k] = ab[k] + as[k]; pl[k] = (int32_t)(minl + k); }
+        if (n_bins >= 0) {                                         /* bucket_price_levels */
+            if (n_bins == 0) { free(ab); free(as); free(tot); free(pl); return ORC_E_ZERODIV; }
+            int64_t range = maxl - minl;
+            int64_t bw = range / n_bins;                           /* non-negative: floor == trunc */
+            if (bw < 1) bw = 1;
+            if (bw % 2 == 0) bw += 1;
+            int64_t n_edges = (maxl + bw - minl + bw - 1) / bw;    /* len(arange(min, max + bw, bw)) */
+            int64_t nbk = n_edges - 1;
+            if (n_edges < 2) { free(ab); free(as); free(tot); free(pl); return ORC_E_LEVEL; }
+            /* bin of level v: (#edges <= v) - 1 = min((v - min) / bw, nbk) */
+            float *bv = (float *)calloc((size_t)(nbk + 1), sizeof(float));
+            int32_t *bp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nbk + 1));
+            if (!bv || !bp) { free(bv); free(bp); free(ab); free(as); free(tot); free(pl); return ORC_E_NOMEM; }
+            for (int64_t k = 0; k < nbk; ++k) {
+                int64_t e0 = minl + k * bw, e1 = e0 + bw;
+                int64_t ssum = e0 + e1 - 1;
+                bp[k] = (int32_t)(ssum >= 0 ? ssum / 2 : -((-ssum + 1) / 2));      /* floor division */
+            }
+            bp[nbk] = (int32_t)maxl;
+            for (int64_t k = 0; k < L; ++k) {
+                int64_t b = k / bw;
+                if (b > nbk) b = nbk;
+                bv[b] += tot[k];
+            }
+            /* volume.py:244-252: the extra "leftover" bin exists iff the LAST level falls past the last full bin */
+            np_ = nbk + ((range / bw >= nbk) ? 1 : 0);
+            for (int64_t k = 0; k < np_; ++k) { tot[k] = bv[k]; pl[k] = bp[k]; }
+            free(bv); free(bp);
+        }
+        orc_poc_hva_lva(pl, tot, np_, va_pct, &poc[i], &hva[i], &lva[i], &pct[i]);
+        free(ab); free(as); free(tot); free(pl);
+    }
+    return ORC_OK;
+}

@@ -332,6 +332,34 @@ def gen_cusum():
     save("cusum", d)
 
 
+def gen_volume_profile():
+    """volume_profile_rolling (feature/core/volume.py:403-456) on footprints of the synthetic stream.  Amounts are
+    multiples of 2^-4 so that every float32 sum on the way is exact (typed and pure-Python semantics coincide)."""
+    from finmlkit.feature.core import volume as rvolume
+    from numba.typed import List as NList
+    d = {}
+    n = 60_000
+    ts, px, _, sd = orc.synth(42, 0, n)
+    rng = np.random.default_rng(5)
+    am = (rng.integers(1, 65, n) * 2.0 ** -4).astype(np.float32)
+    for name, interval, window, n_bins in (("m1_w30", 60.0, 1800.0, 27), ("m1_w5_nobins", 60.0, 300.0, None),
+                                           ("s10_w120_b5", 10.0, 120.0, 5), ("m1_w30_b200", 60.0, 1800.0, 200)):
+        clock, ci = orc._time_bar_indexer(ts, interval)
+        o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+        off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+        nb = len(ci) - 1
+        split = lambda a: NList([a[off[i]:off[i + 1]] for i in range(nb)])
+        bar_ts = clock[1:]
+        poc, hva, lva, pct = rvolume.volume_profile_rolling(bar_ts, o[1], o[2], split(flat["price_levels"]),
+                                                            split(flat["buy_volumes"]), split(flat["sell_volumes"]),
+                                                            window, n_bins, 0.01, 68.34)
+        d[f"{name}__params"] = np.array([interval, window, -1 if n_bins is None else n_bins, 68.34])
+        d[f"{name}__poc"], d[f"{name}__hva"], d[f"{name}__lva"], d[f"{name}__pct"] = poc, hva, lva, pct
+    d["synth"] = np.array([42, 0, n, orc.DENSE_GAP_MOD], dtype=np.int64)
+    d["amount"] = am
+    save("volume_profile", d)
+
+
 def gen_tradesdata():
     """TradesData(preprocess=True) end to end (data_model.py:236-246): raw exchange-style rows in millisecond
     timestamps, shuffled, with duplicated ids and an id gap longer than a minute."""
@@ -376,3 +404,4 @@ if __name__ == "__main__":
     gen_preprocess()
     gen_tradesdata()
     gen_cusum()
+    gen_volume_profile()

@@ -330,3 +330,22 @@ def comp_trade_side_vector(prices):
     out = np.empty(len(px), np.int8)
     _check(lib().orc_comp_trade_side_vector(_p(px), _i64(len(px)), _p(out)))
     return out
+
+
+def volume_profile_rolling(ts, highs, lows, level_offsets, price_levels, buy_volumes, sell_volumes, window_size_sec,
+                           n_bins=None, price_tick=None, va_pct=68.34):
+    """feature/core/volume.py:403-456 on CSR footprints -> (poc, hva, lva int32, pct_above_poc float32)."""
+    t = np.ascontiguousarray(ts, dtype=np.int64)
+    hi = np.ascontiguousarray(highs, dtype=np.float64)
+    lo = np.ascontiguousarray(lows, dtype=np.float64)
+    off = np.ascontiguousarray(level_offsets, dtype=np.int64)
+    pl = np.ascontiguousarray(price_levels, dtype=np.int32)
+    bv = np.ascontiguousarray(buy_volumes, dtype=np.float32)
+    sv = np.ascontiguousarray(sell_volumes, dtype=np.float32)
+    nb = len(t)
+    poc, hva, lva = (np.zeros(nb, np.int32) for _ in range(3))
+    pct = np.zeros(nb, np.float32)
+    _check(lib().orc_volume_profile_rolling(_p(t), _p(hi), _p(lo), _p(off), _p(pl), _p(bv), _p(sv), _i64(nb),
+                                            _i64(int(window_size_sec * 1e9)), _i64(-1 if n_bins is None else n_bins),
+                                            _f64(price_tick), _f64(va_pct), _p(poc), _p(hva), _p(lva), _p(pct)))
+    return poc, hva, lva, pct

@@ -1,0 +1,82 @@
+"""GPU parity of the rolling volume profile ("next" rank 2): VolumePro / volume_profile_rolling vs reference-generated
+goldens and the CPU oracle."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import _golden as G
+from tests.test_oracle_golden import _vp_inputs
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("poc", "hva", "lva", "pct")
+
+
+def test_volume_profile_golden(orc):
+    from finmlkit_amd.feature.core.volume import volume_profile_rolling, volume_profile_rolling_csr
+    d = G.load("volume_profile")
+    for name in ("m1_w30", "m1_w5_nobins", "s10_w120_b5", "m1_w30_b200"):
+        bts, hi, lo, off, flat, window, nbins, va = _vp_inputs(orc, d, name)
+        got = volume_profile_rolling_csr(bts, hi, lo, off, flat["price_levels"], flat["buy_volumes"],
+                                         flat["sell_volumes"], window, nbins, 0.01, va)
+        for g, k in zip(got, KEYS):
+            assert g.dtype == d[f"{name}__{k}"].dtype
+            np.testing.assert_array_equal(g, d[f"{name}__{k}"], err_msg=f"{name}:{k}")
+        split = lambda a: [a[off[i]:off[i + 1]] for i in range(len(off) - 1)]          # the reference's ragged form
+        got2 = volume_profile_rolling(bts, hi, lo, split(flat["price_levels"]), split(flat["buy_volumes"]),
+                                      split(flat["sell_volumes"]), window, nbins, 0.01, va)
+        for a, b in zip(got, got2):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,interval,window,nbins,inexact", [(600_000, 60.0, 1800.0, 27, False),
+                                                             (600_000, 60.0, 1800.0, 27, True),
+                                                             (400_000, 5.0, 60.0, None, True),
+                                                             (400_000, 60.0, 14_400.0, 11, True),     # > 1024 levels/window
+                                                             (300_000, 1.0, 30.0, 3, False)])
+def test_volume_profile_vs_oracle(orc, n, interval, window, nbins, inexact):
+    from finmlkit_amd.feature.core.volume import volume_profile_rolling_csr
+    ts, px, am, sd = orc.synth(23, 0, n)
+    if inexact:
+        am = np.random.default_rng(1).lognormal(-1, 1.0, n).astype(np.float32)    # float32 sums round: order matters
+    clock, ci = orc._time_bar_indexer(ts, interval)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    args = (clock[1:], o[1], o[2], off, flat["price_levels"], flat["buy_volumes"], flat["sell_volumes"], window, nbins,
+            0.01, 68.34)
+    want = orc.volume_profile_rolling(*args)
+    got = volume_profile_rolling_csr(*args)
+    for g, w, k in zip(got, want, KEYS):
+        np.testing.assert_array_equal(g, w, err_msg=k)
+    assert (want[0] != 0).sum() > 10
+
+
+def test_volumepro_on_kit_output_and_errors(orc):
+    from finmlkit_amd.bar.data_model import TradesData
+    from finmlkit_amd.bar.kit import TimeBarKit
+    from finmlkit_amd.feature.core.volume import VolumePro, volume_profile_rolling_csr
+    n = 300_000
+    ts, px, am, sd = orc.synth(3, 0, n)
+    kit = TimeBarKit(TradesData(ts, px, am, np.arange(n), side=sd), pd.Timedelta(seconds=60))
+    bars = kit.build_ohlcv()
+    fp = kit.build_footprints(price_tick_size=0.01)
+    vp = VolumePro(pd.Timedelta(minutes=20), n_bins=15)
+    poc, hva, lva, pct = vp.compute(bars, fp)
+    want = orc.volume_profile_rolling(fp.bar_timestamps, bars.high.values, bars.low.values, fp.level_offsets,
+                                      fp.flat["price_levels"], fp.flat["buy_volumes"], fp.flat["sell_volumes"],
+                                      1200.0, 15, 0.01, 68.34)
+    first = int(np.flatnonzero(want[0])[0])
+    assert np.isnan(poc[:first]).all() and not np.isnan(poc[first:]).any()
+    np.testing.assert_array_equal(poc[first:], want[0][first:] * 0.01)
+    np.testing.assert_array_equal(hva[first:], want[1][first:] * 0.01)
+    np.testing.assert_array_equal(lva[first:], want[2][first:] * 0.01)
+    np.testing.assert_array_equal(pct, want[3])
+    assert np.all(lva[first:] <= poc[first:]) and np.all(poc[first:] <= hva[first:])
+    # a slice loses the CSR view and goes through the ragged-list path: same numbers
+    t0, t1 = pd.to_datetime(fp.bar_timestamps[40], unit="ns"), pd.to_datetime(fp.bar_timestamps[120], unit="ns")
+    bts, poc_r, hva_r, lva_r, pct_r = vp.compute_range(bars, fp, t0, t1)
+    assert bts[-1] == fp.bar_timestamps[120] and len(poc_r) == len(bts)
+    with pytest.raises(ZeroDivisionError):
+        volume_profile_rolling_csr(fp.bar_timestamps, bars.high.values, bars.low.values, fp.level_offsets,
+                                   fp.flat["price_levels"], fp.flat["buy_volumes"], fp.flat["sell_volumes"], 1200.0, 0,
+                                   0.01)

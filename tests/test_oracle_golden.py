@@ -166,3 +166,25 @@ def test_cusum_indexer_golden(orc):
                                              return_sigma=True)
         np.testing.assert_array_equal(got, d[f"{name}__idx"], err_msg=name)
         np.testing.assert_array_equal(filled, d[f"{name}__sigma_filled"], err_msg=name)
+
+
+def _vp_inputs(orc, d, name):
+    ts, px, _, sd = G.synth_from(orc, d["synth"])
+    am = d["amount"]
+    interval, window, nbins, va = d[f"{name}__params"]
+    clock, ci = orc._time_bar_indexer(ts, interval)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    return clock[1:], o[1], o[2], off, flat, window, (None if nbins < 0 else int(nbins)), va
+
+
+def test_volume_profile_rolling_golden(orc):
+    """volume_profile_rolling (feature/core/volume.py:403-456): bucketed / raw levels, wide and narrow windows."""
+    d = G.load("volume_profile")
+    for name in ("m1_w30", "m1_w5_nobins", "s10_w120_b5", "m1_w30_b200"):
+        bts, hi, lo, off, flat, window, nbins, va = _vp_inputs(orc, d, name)
+        got = orc.volume_profile_rolling(bts, hi, lo, off, flat["price_levels"], flat["buy_volumes"],
+                                         flat["sell_volumes"], window, nbins, 0.01, va)
+        for g, k in zip(got, ("poc", "hva", "lva", "pct")):
+            assert g.dtype == d[f"{name}__{k}"].dtype
+            np.testing.assert_array_equal(g, d[f"{name}__{k}"], err_msg=f"{name}:{k}")
