@@ -286,10 +286,10 @@ extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, cons
     if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     if (n <= 0 || !d_side || !d_dir || !d_fp) return fmk_set_error(ctx, FMK_E_ARG, "bars_fused: bad arguments");
     if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
-    if (max_levels > FP_MAX_LEVELS)
+    if (max_levels > FP_MAX_LEVELS_GLOBAL)
         return fmk_set_error(ctx, FMK_E_CAPACITY,
                              "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
-                             (long long)max_levels, FP_MAX_LEVELS);
+                             (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
     // Two kernels back to back.  In-kernel fusion was built and measured twice (one wave doing both halves on a
     // shared LDS tile: 11.2 ms; two waves per bar, one per half, on double-buffered tiles: 10.3 ms at 1e9 ticks)
     // against 3.0 + 3.7 ms for the two kernels below: both halves are VALU-bound (~106 and ~161 VALU instructions

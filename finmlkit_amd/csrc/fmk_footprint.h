@@ -23,7 +23,8 @@ struct FpOut {
 };
 static_assert(sizeof(FpOut) == sizeof(fmk_footprint_out), "ABI struct mismatch");
 
-#define FP_MAX_LEVELS 2048
+#define FP_MAX_LEVELS 2048                 // widest bar whose histogram lives in LDS
+#define FP_MAX_LEVELS_GLOBAL (1 << 24)     // wider bars: histogram in global scratch (one wave per bar)
 #define FP_Q_UNKNOWN 0x7FFFFFFF
 
 // int(round(x)) with Python's round-half-even == rint() in the default rounding mode
@@ -204,16 +205,54 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     __builtin_amdgcn_wave_barrier();
     double gini = 0.0;
     if (stats) gini = (double)(1.0f - fp_pairwise_f32(q2, L, lane, stk));   // base.py:847-848 (float32)
-    // ---- longest signed run (base.py:801-819), sequential over the levels
-    if (lane == 0) {
-        int max_run = 0, max_sign = 0, run = 0, run_sign = 0;
-        for (int l = 0; l < L; ++l) {
+    // ---- longest signed run (base.py:801-819).  The reference scans the levels once; here every lane scans a
+    //      contiguous segment (prefix run, first-longest run inside, run state at its end) and the 64 summaries
+    //      are folded in segment order -- same result, incl. "the FIRST run of maximal length wins".
+    int p_len = 0, p_sign = 0, s_len = 0, s_sign = 0, b_len = 0, b_sign = 0, n_seg = 0;
+    {
+        const int seg = (L + 63) / 64;
+        const int l0 = lane * seg;
+        const int l1 = l0 + seg < L ? l0 + seg : L;
+        n_seg = l1 > l0 ? l1 - l0 : 0;
+        int run = 0, rs = 0;
+        bool in_prefix = true;
+        for (int l = l0; l < l1; ++l) {
             const int sg = sign[l];
-            if (sg != 0 && sg == run_sign) run += 1;
-            else if (sg != 0) { run = 1; run_sign = sg; }
-            else { run = 0; run_sign = 0; }
-            if (run > max_run) { max_run = run; max_sign = run_sign; }
+            if (sg != 0 && sg == rs) run += 1;
+            else if (sg != 0) { run = 1; rs = sg; }
+            else { run = 0; rs = 0; }
+            if (in_prefix) {
+                if (l == l0) { if (sg == 0) in_prefix = false; else { p_sign = sg; p_len = 1; } }
+                else if (sg == p_sign) p_len += 1;
+                else in_prefix = false;
+            }
+            if (run > b_len) { b_len = run; b_sign = rs; }
         }
+        s_len = run; s_sign = rs;
+    }
+    int max_run = 0, max_sign = 0;
+    {
+        int run = 0, run_sign = 0;
+        for (int k = 0; k < 64; ++k) {
+            const int n_k = __builtin_amdgcn_readlane(n_seg, k);
+            if (n_k == 0) break;                                   // segments are filled from lane 0 upwards
+            const int pl = __builtin_amdgcn_readlane(p_len, k), ps = __builtin_amdgcn_readlane(p_sign, k);
+            if (pl == n_k) {                                       // the whole segment is one signed run
+                if (ps == run_sign) run += pl; else { run = pl; run_sign = ps; }
+                if (run > max_run) { max_run = run; max_sign = run_sign; }
+            } else {
+                if (pl > 0) {
+                    const int cand = ps == run_sign ? run + pl : pl;
+                    if (cand > max_run) { max_run = cand; max_sign = ps; }
+                }
+                const int bl = __builtin_amdgcn_readlane(b_len, k), bs = __builtin_amdgcn_readlane(b_sign, k);
+                if (bl > max_run) { max_run = bl; max_sign = bs; }
+                run = __builtin_amdgcn_readlane(s_len, k);
+                run_sign = __builtin_amdgcn_readlane(s_sign, k);
+            }
+        }
+    }
+    if (lane == 0) {
         o.buy_imbalances_sum[b] = (uint16_t)bsum;
         o.sell_imbalances_sum[b] = (uint16_t)ssum;
         o.cot_price_levels[b] = (int32_t)(low + best_i);

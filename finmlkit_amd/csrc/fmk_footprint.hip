@@ -182,14 +182,18 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const int64_t *__restrict__ ci, int64_t nb, double tick,
                                                         const double *__restrict__ lows, float m32,
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
-                                                        FpOut o, unsigned long long *n_bad, int force_ordered)
+                                                        FpOut o, unsigned long long *n_bad, int force_ordered,
+                                                        unsigned char *gscratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const size_t per_wave = (size_t)lmax * 24 + 256;
-    unsigned char *mine = smem + (size_t)wib * per_wave;
+    // the wave's histogram: LDS for the three narrow classes, a slice of global scratch for bars wider than 2048
+    // levels (same code through generic pointers; a wave's own stores are visible to its later loads)
+    unsigned char *mine = gscratch ? gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave
+                                   : smem + (size_t)wib * per_wave;
     float *vol = (float *)mine;                                   // [2*lmax]  buy = 2l, sell = 2l+1
     int *cnt = (int *)(mine + (size_t)lmax * 8);                  // [2*lmax]
     float *aux = (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
@@ -259,13 +263,27 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
 {
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
-    const size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256);
+    size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256);
     int64_t blocks = fmk_ceil_div(nb, wpb);
-    const int64_t cap = (int64_t)ctx->n_cu * 64;
+    int64_t cap = (int64_t)ctx->n_cu * 64;
+    unsigned char *gscratch = nullptr;
+    if (lmax > FP_MAX_LEVELS) {
+        // wide bars: one wave per workgroup, histogram in global scratch (<= 8 GB in total, >= 16 waves)
+        const size_t per_wave = (size_t)lmax * 24 + 256;
+        cap = (int64_t)(((size_t)8 << 30) / per_wave);
+        if (cap < 16) cap = 16;
+        if (cap > (int64_t)ctx->n_cu * 8) cap = (int64_t)ctx->n_cu * 8;
+        if (blocks > cap) blocks = cap;
+        void *scr;
+        FMK_TRY(fmk_scratch(ctx, per_wave * (size_t)blocks + 256, &scr));
+        gscratch = (unsigned char *)scr;
+        smem = 0;
+    }
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     k_bar_footprints<AF64><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32, off,
-                                                                            lmin, lmax, o, n_bad, force_ordered);
+                                                                            lmin, lmax, o, n_bad, force_ordered,
+                                                                            gscratch);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -279,10 +297,10 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
 {
     if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_footprints: bad arguments");
-    if (max_levels > FP_MAX_LEVELS)
+    if (max_levels > FP_MAX_LEVELS_GLOBAL)
         return fmk_set_error(ctx, FMK_E_CAPACITY,
                              "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
-                             (long long)max_levels, FP_MAX_LEVELS);
+                             (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, (float)imbalance_factor, d_level_offsets, 0,
@@ -298,10 +316,10 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     FpOut o;
     memcpy(&o, d_out, sizeof(o));
     unsigned long long *bad = (unsigned long long *)d_n_bad_level;
-    static const int LMAX[3] = {128, 512, 2048};
-    static const int WPB[3] = {4, 4, 1};
+    const int LMAX[4] = {128, 512, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
+    static const int WPB[4] = {4, 4, 1, 1};
     int lmin = 0;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         if (LMAX[k] > lmin_start) {
             int rc = amount_is_f64

@@ -13,7 +13,8 @@
 //   float64 scalars (Numba-typed semantics); calc_volume_percentage_above_poc (:372-400).
 #include "fmk_footprint.h"
 
-#define VP_MAX_LEVELS 8192
+#define VP_MAX_LEVELS 8192                  // widest window whose histogram lives in LDS
+#define VP_MAX_LEVELS_GLOBAL (1 << 24)      // wider windows: histogram in global scratch
 
 __device__ __forceinline__ int64_t vp_lower(const int64_t *a, int64_t n, int64_t key)
 {
@@ -70,14 +71,17 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
                                                         int64_t nb, int64_t first, int64_t window_ns, int64_t n_bins,
                                                         double tick, double va_pct, int cap, int32_t *__restrict__ poc,
                                                         int32_t *__restrict__ hva, int32_t *__restrict__ lva,
-                                                        float *__restrict__ pct, unsigned int *status)
+                                                        float *__restrict__ pct, unsigned int *status,
+                                                        unsigned char *gscratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const size_t per_wave = (size_t)(cap + 8) * 8 + 256;
-    float *ab = (float *)(smem + (size_t)wib * per_wave);        // [cap + 8] buy sums, later totals
+    unsigned char *mine = gscratch ? gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave   // very wide windows
+                                   : smem + (size_t)wib * per_wave;
+    float *ab = (float *)mine;                                    // [cap + 8] buy sums, later totals
     float *as = ab + (cap + 8);                                   // [cap + 8] sell sums, later binned volumes
     int *stk = (int *)(as + (cap + 8));                           // 64 ints (pairwise-sum stack)
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
@@ -220,21 +224,34 @@ extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t max_levels = ctx->h_mail[0];
-    if (max_levels > VP_MAX_LEVELS)
+    if (max_levels > VP_MAX_LEVELS_GLOBAL)
         return fmk_set_error(ctx, FMK_E_CAPACITY, "volume_profile_rolling: a window spans %lld price levels; this build "
-                             "supports <= %d", (long long)max_levels, VP_MAX_LEVELS);
+                             "supports <= %d", (long long)max_levels, VP_MAX_LEVELS_GLOBAL);
     int cap = 1024, wpb = 4;
     if (max_levels > 1024) { cap = max_levels > 4096 ? 8192 : 4096; wpb = 1; }
-    const size_t smem = (size_t)wpb * ((size_t)(cap + 8) * 8 + 256);
+    if (max_levels > VP_MAX_LEVELS) cap = (int)max_levels;
+    size_t smem = (size_t)wpb * ((size_t)(cap + 8) * 8 + 256);
+    int64_t blocks = fmk_ceil_div(work, wpb);
+    int64_t capb = (int64_t)ctx->n_cu * 32;
+    unsigned char *gscratch = nullptr;
+    if (max_levels > VP_MAX_LEVELS) {                             // histogram in global scratch (<= 8 GB, >= 16 waves)
+        const size_t per_wave = smem;
+        capb = (int64_t)(((size_t)8 << 30) / per_wave);
+        if (capb < 16) capb = 16;
+        if (capb > (int64_t)ctx->n_cu * 8) capb = (int64_t)ctx->n_cu * 8;
+        if (blocks > capb) blocks = capb;
+        void *scr;
+        FMK_TRY(fmk_scratch(ctx, per_wave * (size_t)blocks + 256, &scr));
+        gscratch = (unsigned char *)scr;
+        smem = 0;
+    }
     if (smem > 64 * 1024)
         FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_volume_profile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    int64_t blocks = fmk_ceil_div(work, wpb);
-    const int64_t capb = (int64_t)ctx->n_cu * 32;
     if (blocks > capb) blocks = capb;
     k_volume_profile<<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(d_bar_ts, d_highs, d_lows, d_level_offsets,
                                                                        d_price_levels, d_buy_volumes, d_sell_volumes, n_bars,
                                                                        first_bar, window_ns, n_bins, price_tick, va_pct, cap,
-                                                                       d_poc, d_hva, d_lva, d_pct, d_status);
+                                                                       d_poc, d_hva, d_lva, d_pct, d_status, gscratch);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));

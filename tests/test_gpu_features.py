@@ -115,3 +115,20 @@ def test_footprints_reference_shape_and_errors(orc):
     # lows too high -> a tick falls outside the level range -> the reference's ValueError
     with pytest.raises(ValueError, match="Invalid price level index"):
         comp_bar_footprints(px, am, ci, sd, 0.01, o[2] + 0.05, o[1] + 0.05, 3.0)
+
+
+@pytest.mark.parametrize("tick,interval,amounts", [(0.0001, 60.0, "dyadic"), (0.0001, 600.0, "lognormal"),
+                                                  (0.00001, 3600.0, "dyadic")])
+def test_footprints_wide_bars_global_histogram(orc, tick, interval, amounts):
+    """Bars wider than 2048 levels (a fine tick on a coarse price grid): histogram in global scratch, same results."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    n = 150_000
+    ts, px, am, sd = orc.synth(31, 0, n)
+    if amounts == "lognormal":
+        am = np.random.default_rng(4).lognormal(-1, 1.0, n).astype(np.float32)
+    _, ci = orc._time_bar_indexer(ts, interval)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
+    assert np.diff(woff).max() > 2048
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, f"wide tick={tick}")

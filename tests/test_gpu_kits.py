@@ -121,5 +121,5 @@ def test_errors_match_reference(orc, trades):
     t2 = TradesData(trades.data["timestamp"].values, trades.data["price"].values, trades.data["amount"].values)
     with pytest.raises(KeyError):
         TimeBarKit(t2, pd.Timedelta(minutes=1)).build_directional_features()
-    with pytest.raises(NotImplementedError):
-        CUSUMBarKit(trades, np.zeros(N)).build_ohlcv()
+    with pytest.raises(ValueError, match="at least two elements"):      # a huge floor: no close at all
+        CUSUMBarKit(trades, np.zeros(N), sigma_floor=10.0).build_ohlcv()

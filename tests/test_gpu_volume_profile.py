@@ -29,21 +29,22 @@ def test_volume_profile_golden(orc):
             np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,interval,window,nbins,inexact", [(600_000, 60.0, 1800.0, 27, False),
-                                                             (600_000, 60.0, 1800.0, 27, True),
-                                                             (400_000, 5.0, 60.0, None, True),
-                                                             (400_000, 60.0, 14_400.0, 11, True),     # > 1024 levels/window
-                                                             (300_000, 1.0, 30.0, 3, False)])
-def test_volume_profile_vs_oracle(orc, n, interval, window, nbins, inexact):
+@pytest.mark.parametrize("n,interval,window,nbins,inexact,tick", [
+    (600_000, 60.0, 1800.0, 27, False, 0.01), (600_000, 60.0, 1800.0, 27, True, 0.01),
+    (400_000, 5.0, 60.0, None, True, 0.01),
+    (400_000, 60.0, 14_400.0, 11, True, 0.01),          # > 1024 levels per window: one wave per workgroup
+    (300_000, 1.0, 30.0, 3, False, 0.01),
+    (500_000, 600.0, 7200.0, 27, True, 0.0001)])        # > 8192 levels per window: histogram in global scratch
+def test_volume_profile_vs_oracle(orc, n, interval, window, nbins, inexact, tick):
     from finmlkit_amd.feature.core.volume import volume_profile_rolling_csr
     ts, px, am, sd = orc.synth(23, 0, n)
     if inexact:
         am = np.random.default_rng(1).lognormal(-1, 1.0, n).astype(np.float32)    # float32 sums round: order matters
     clock, ci = orc._time_bar_indexer(ts, interval)
     o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
-    off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
     args = (clock[1:], o[1], o[2], off, flat["price_levels"], flat["buy_volumes"], flat["sell_volumes"], window, nbins,
-            0.01, 68.34)
+            tick, 68.34)
     want = orc.volume_profile_rolling(*args)
     got = volume_profile_rolling_csr(*args)
     for g, w, k in zip(got, want, KEYS):
