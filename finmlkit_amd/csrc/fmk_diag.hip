@@ -1,0 +1,44 @@
+// fmk_diag.hip -- calibration probe for the roofline figures of DESIGN.md: achievable read-only HBM bandwidth of a
+// plain streaming kernel on this part (the tick reducers are read streams; the guide's ~6.3 TB/s ceiling is a COPY).
+// Not used by any product path.
+#include "fmk_common.h"
+
+// variant 0: 16 B per lane per load (dwordx4), variant 1: 8 B per lane (dwordx2, what the reducers issue per price)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_diag_read(const uint4 *__restrict__ p, int64_t n16, unsigned long long *sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    if (VEC == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+            const uint4 v = p[i];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    } else {
+        const uint2 *q = (const uint2 *)p;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n16; i += stride) {
+            const uint2 v = q[i];
+            acc ^= v.x ^ v.y;
+        }
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);        // practically never: keeps the loads alive
+}
+
+extern "C" int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
+                                       double *elapsed_ms)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n16 = (int64_t)(bytes / 16);
+    const unsigned blocks = (unsigned)(ctx->n_cu * (blocks_per_cu > 0 ? blocks_per_cu : 8));
+    unsigned long long *sink = (unsigned long long *)(ctx->d_mail + 60);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (variant == 0) k_diag_read<0><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
+    else k_diag_read<1><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}

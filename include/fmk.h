@@ -283,6 +283,12 @@ int fmk_merge_split_trades(fmk_ctx *ctx, const int64_t *ts, const double *price,
 int fmk_comp_trade_side_vector_dev(fmk_ctx *ctx, const double *d_price, int64_t n, int8_t *d_out);
 int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int8_t *out);
 
+/* ---- diagnostics ------------------------------------------------------------------------ */
+/* Read-only streaming bandwidth probe (tools/readbw.py): calibrates the HBM ceiling quoted in DESIGN.md.
+ * variant 0: 16 B loads per lane, 1: 8 B loads per lane.  Not used by any product path. */
+int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
+                            double *elapsed_ms);
+
 #ifdef __cplusplus
 }
 #endif
