@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
 static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
-    int64_t cap = (int64_t)ctx->n_cu * 64;   // grid-stride beyond this
+    static int per_cu = -1;                  // developer knob: FMK_OHLCV_BLOCKS_PER_CU (workgroups per CU in the grid)
+    if (per_cu < 0) { const char *v = getenv("FMK_OHLCV_BLOCKS_PER_CU"); per_cu = v ? atoi(v) : 64; }
+    int64_t cap = (int64_t)ctx->n_cu * per_cu;   // grid-stride beyond this
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
