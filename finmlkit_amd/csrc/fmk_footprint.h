@@ -132,6 +132,10 @@ struct FpStats {
     bool bad;        // a tick fell outside the level range (base.py:719)
 };
 
+// exact (integer-unit) sweep: st.atot counts UNITS of 2^q; every amount was a whole non-negative number of units and
+// every partial sum stays below 2^24 units, so each float32 add of the reference is exact whatever its order
+__device__ __forceinline__ bool fp_certified_units(const FpStats &st) { return st.units_ok && st.atot < 16777216.0; }
+
 // every float32 add of a bar with these statistics is exact at quantum 2^q
 __device__ __forceinline__ bool fp_certified(const FpStats &st, int q)
 {
@@ -210,7 +214,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     //      are folded in segment order -- same result, incl. "the FIRST run of maximal length wins".
     int p_len = 0, p_sign = 0, s_len = 0, s_sign = 0, b_len = 0, b_sign = 0, n_seg = 0;
     {
-        const int seg = (L + 63) / 64;
+        int seg = (L + 63) / 64;
+        if (seg < 16) seg = 16;                                        // narrow bars: few segments, short fold
         const int l0 = lane * seg;
         const int l1 = l0 + seg < L ? l0 + seg : L;
         n_seg = l1 > l0 ? l1 - l0 : 0;

@@ -114,9 +114,11 @@ __device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ pric
             else if (sd == 1 || sd == -1) {
                 pending = true;
                 key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
-                const int lb = fp_lowbit_exp(a);
-                lbmin = lb < lbmin ? lb : lbmin;
-                atot += fabs((double)a);
+                if constexpr (!EXACT) {                               // statistics that pick the quantum of later bars
+                    const int lb = fp_lowbit_exp(a);
+                    lbmin = lb < lbmin ? lb : lbmin;
+                    atot += fabs((double)a);
+                }
             }
         }
         if constexpr (EXACT) {
@@ -124,7 +126,7 @@ __device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ pric
                 const double u = ldexp((double)a, -q);                // exact scaling
                 const bool ok = u >= 0.0 && u < 2147483648.0 && u == rint(u);
                 units_ok &= ok;
-                if (ok) atomicAdd(&units[key], (unsigned)u);
+                if (ok) { atomicAdd(&units[key], (unsigned)u); atot += u; }    // atot: units (fp_certified_units)
                 atomicAdd(&cnt[key], 1);
             }
             continue;
@@ -211,33 +213,21 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         const int64_t low = fp_level(lows[b], tick);
         for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
         __builtin_amdgcn_wave_barrier();
-        // Exact path first (with the quantum that worked for the previous bar); when its certificate
-        // fails the bar's own statistics give the right quantum for one retry, else the ordered path runs.
+        // Exact path first (with the quantum that worked for the previous bar); when its certificate fails the
+        // tick-ordered path runs.
         FpStats st;
         bool done = false;
         if (!force_ordered && wq != FP_Q_UNKNOWN) {
             st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
-            done = fp_certified(st, wq);
-            if (!done) {
-                for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
-                __builtin_amdgcn_wave_barrier();
-                const int q2 = st.lbmin;
-                FpStats probe = st;
-                probe.units_ok = true;
-                if (q2 != FP_Q_UNKNOWN && q2 != (int)0x80000000 && fp_certified(probe, q2)) {
-                    st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, q2);
-                    done = fp_certified(st, q2);
-                    if (done) wq = q2;
-                    else {
-                        for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
+            done = fp_certified_units(st);
             if (done) {       // units -> float32 (exact)
                 unsigned *units = (unsigned *)vol;
                 const int qq = wq;
                 for (int k = lane; k < 2 * L; k += 64) vol[k] = ldexpf((float)units[k], qq);
+                __builtin_amdgcn_wave_barrier();
+            } else {          // finer or larger amounts than the quantum in use: tick-ordered sweep, which also
+                              // measures the quantum for the following bars
+                for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
                 __builtin_amdgcn_wave_barrier();
             }
         }
