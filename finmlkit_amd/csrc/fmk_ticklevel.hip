@@ -412,6 +412,7 @@ template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
                                                          int64_t n, double half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
+                                                         const double *__restrict__ state_in,
                                                          double *__restrict__ out)
 {
     __shared__ EwMap lds[4];
@@ -424,8 +425,13 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     ex = ew_compose(tile_pre[blockIdx.x], ex);
-    // state entering my first tick (initial state is all-zero, so state = b parts of the prefix map)
+    // state entering my first tick: the prefix map applied to the initial state (all-zero unless this is a shard
+    // of a longer series: then the state the earlier shards leave behind, fmk_ewmst_shard_*)
     double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
+    if (state_in) {
+        V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
+        Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
+    }
     int64_t tprev = tprev0;
     const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
     double res[EW_ITEMS];
@@ -453,9 +459,28 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     }
 }
 
+// composition of all tile maps in order (ONE block): the map of the whole series, x -> a*x + b per state
+__global__ __launch_bounds__(EW_THREADS) void k_ew_total(const EwMap *__restrict__ maps, int64_t m, double *out6)
+{
+    __shared__ EwMap lds[4];
+    EwMap run = ew_identity();
+    for (int64_t b = 0; b < m; b += EW_THREADS) {
+        const int64_t i = b + threadIdx.x;
+        EwMap v = i < m ? maps[i] : ew_identity();
+        EwMap tot;
+        (void)ew_block_exclusive(v, lds, &tot);
+        run = ew_compose(run, tot);
+    }
+    if (threadIdx.x == 0) {
+        out6[0] = run.a; out6[1] = run.a2; out6[2] = run.bV; out6[3] = run.bV2; out6[4] = run.bSy; out6[5] = run.bSyy;
+    }
+}
+
+// d_map_out != nullptr: only the map of the series is produced (6 doubles on the device); else the outputs,
+// starting from d_state_in (4 doubles on the device, nullptr = zeros)
 template <int MODE>
 static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
-                  double sigma_floor, double *d_out)
+                  double sigma_floor, double *d_out, const double *d_state_in = nullptr, double *d_map_out = nullptr)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t tiles = fmk_ceil_div(n, EW_TILE);
@@ -471,8 +496,14 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     EwMap *work = tm + tiles;
     k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, tm);
     FMK_LAUNCH_CHECK(ctx);
+    if (d_map_out) {
+        k_ew_total<<<1, EW_THREADS, 0, ctx->stream>>>(tm, tiles, d_map_out);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
     FMK_TRY(ew_scan_maps(ctx, tm, tiles, work));
-    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_out);
+    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_state_in,
+                                                                     d_out);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -483,6 +514,29 @@ extern "C" int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_
     if (n <= 0) return FMK_OK;
     return mean0 ? ew_run<1>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out)
                  : ew_run<0>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out);
+}
+
+/* Shards of one series (multi-GPU): tick 0 of the arrays is the LAST tick of the previous shard (it only provides the
+ * previous timestamp; rank 0 passes its own arrays, whose tick 0 the reference skips anyway).
+ *   fmk_ewmst_shard_map_dev  : the affine map (a, a2, bV, bV2, bSy, bSyy) of ticks 1..n-1 -> d_map_out[6] (device)
+ *   fmk_ewmst_shard_apply_dev: outputs for ticks 1..n-1 starting from d_state_in[4] = (V, V2, Sy, Syy) (device);
+ *                              d_out[0] = NaN.
+ * The caller composes the maps of the earlier shards (x -> a*x + b, in shard order) into its incoming state. */
+extern "C" int fmk_ewmst_shard_map_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
+                                       int mean0, double *d_map_out)
+{
+    if (n <= 0 || !d_map_out) return fmk_set_error(ctx, FMK_E_ARG, "ewmst_shard_map: bad arguments");
+    return mean0 ? ew_run<1>(ctx, d_ts, d_y, n, half_life, 0.0, nullptr, nullptr, d_map_out)
+                 : ew_run<0>(ctx, d_ts, d_y, n, half_life, 0.0, nullptr, nullptr, d_map_out);
+}
+
+extern "C" int fmk_ewmst_shard_apply_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n,
+                                         double half_life, double sigma_floor, int mean0, const double *d_state_in,
+                                         double *d_out)
+{
+    if (n <= 0) return FMK_OK;
+    return mean0 ? ew_run<1>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out, d_state_in)
+                 : ew_run<0>(ctx, d_ts, d_y, n, half_life, sigma_floor, d_out, d_state_in);
 }
 
 __global__ void k_fill_nan(double *out, int64_t n)

@@ -210,6 +210,83 @@ class ShardedTimeBars:
         return cat(ds), np.concatenate(lv), cat(fl), cat(pb)
 
 
+class ShardedTickLevel:
+    """Tick-level volatility loops on a shard of one stream: `comp_lagged_returns` needs the left
+    neighbour's ticks of the last `window` seconds (raw-tick halo, same mechanism as the bars), `ewmst` is a scan over
+    affine maps, so a shard needs (a) its left neighbour's last tick for the first time step and (b) the state the
+    earlier shards leave behind = their maps composed in shard order (one all-gather of 6 doubles per rank).
+
+    Phases, exchange supplied by the caller (RCCL / gloo / in-process copy in tests):
+      returns_send_start(next_first_ts, window) -> first local tick the RIGHT neighbour needs        [halo send/recv]
+      lagged_returns(recv_h, window, is_log)     -> returns of [halo | shard] (device, h + n values; local part = [h:])
+      set_left_value(r_ext, recv_h, y_left)      -> plant the left neighbour's LAST return in front of the local part
+      ewmst_map(r_ext, recv_h, half_life)        -> this shard's map (6 doubles)                      [all-gather]
+      ewmst(r_ext, recv_h, maps_of_lower_ranks, half_life) -> local sigma (device, n values)
+    """
+
+    def __init__(self, trades, rank: int, world: int):
+        import numpy as np
+        from ._ffi import DeviceArray
+        self.t, self.rank, self.world, self.ctx = trades, rank, world, trades.ctx
+        self._np, self._DA = np, DeviceArray
+
+    def returns_send_start(self, next_first_ts: int, window_sec: float) -> int:
+        """Index of the first local tick the right neighbour needs: one tick before `next_first_ts - window`."""
+        from ._ffi import c_i64
+        one = self._DA(self.ctx, 1, self._np.int64)
+        edge = int(next_first_ts) - int(window_sec * 1e9) - 1024            # float64 timestamps: 256 ns granularity
+        self.ctx.call("fmk_time_bar_indexer_dev", self.t.ts.p, c_i64(self.t.n), c_i64(edge), c_i64(1), c_i64(1), None,
+                      one.p)
+        idx = int(one.to_host()[0])                                          # last tick <= edge
+        if idx < 0:
+            raise ValueError(f"rank {self.rank}: the return window is longer than the shard; use fewer ranks")
+        return idx
+
+    def lagged_returns(self, recv_h: int, window_sec: float, is_log: bool):
+        th = self.t.with_halo(recv_h) if recv_h else self.t
+        return th.lagged_returns(window_sec, is_log)
+
+    def set_left_value(self, r_ext, recv_h: int, y_left: float):
+        import ctypes as C
+        v = self._np.array([y_left], dtype=self._np.float64)
+        self.ctx.call("fmk_h2d", r_ext.view(recv_h - 1, 1).p, v.ctypes.data_as(C.c_void_p), C.c_size_t(8))
+
+    def _ext(self, r_ext, recv_h: int):
+        if self.rank == 0:
+            return self.t.ts, r_ext
+        return self.t.with_halo(1).ts, r_ext.view(recv_h - 1, self.t.n + 1)
+
+    def ewmst_map(self, r_ext, recv_h: int, half_life: float, mean0: bool = False):
+        import ctypes as C
+        from ._ffi import c_f64, c_i64
+        ts, y = self._ext(r_ext, recv_h)
+        m = self._DA(self.ctx, 6, self._np.float64)
+        self.ctx.call("fmk_ewmst_shard_map_dev", ts.p, y.p, c_i64(y.n), c_f64(half_life), C.c_int(bool(mean0)), m.p)
+        return m.to_host()
+
+    @staticmethod
+    def incoming_state(maps_of_lower_ranks):
+        """(V, V2, Sy, Syy) after the lower ranks: their maps x -> a*x + b applied in order to the zero state."""
+        V = V2 = Sy = Syy = 0.0
+        for a, a2, bV, bV2, bSy, bSyy in maps_of_lower_ranks:
+            V, V2, Sy, Syy = a * V + bV, a2 * V2 + bV2, a * Sy + bSy, a * Syy + bSyy
+        return V, V2, Sy, Syy
+
+    def ewmst(self, r_ext, recv_h: int, maps_of_lower_ranks, half_life: float, sigma_floor: float = 1e-12,
+              mean0: bool = False):
+        import ctypes as C
+        from ._ffi import c_f64, c_i64
+        ts, y = self._ext(r_ext, recv_h)
+        out = self._DA(self.ctx, y.n, self._np.float64)
+        st = None
+        if self.rank > 0:
+            st = self._DA.from_host(self.ctx, self._np.array(self.incoming_state(maps_of_lower_ranks), dtype=self._np.float64))
+        self.ctx.call("fmk_ewmst_shard_apply_dev", ts.p, y.p, c_i64(y.n), c_f64(half_life), c_f64(sigma_floor),
+                      C.c_int(bool(mean0)), None if st is None else st.p, out.p)
+        self.ctx.sync()                                                       # `st` must outlive the kernel
+        return out if self.rank == 0 else out.view(1, self.t.n)
+
+
 def halo_lengths(comm: Comm, n_local: int, close_of_last_edge: int) -> Tuple[int, int]:
     """(halo I send, halo I receive).  The halo is ticks [close_of_last_edge, n_local)."""
     send = n_local - close_of_last_edge if comm.rank + 1 < comm.world else 0

@@ -231,6 +231,13 @@ int fmk_ewmst_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
                   double half_life, double sigma_floor, int mean0, double *d_out);
 int fmk_ewmst(fmk_ctx *ctx, const int64_t *ts, const double *y, int64_t n, double half_life,
               double sigma_floor, int mean0, double *out);
+/* Shards of ONE series across GPUs: tick 0 of the arrays is the last tick of the previous shard
+ * (rank 0: its own first tick).  _map: affine map (a, a2, bV, bV2, bSy, bSyy) of ticks 1..n-1 -> d_map_out[6];
+ * _apply: outputs from the incoming state d_state_in[4] = (V, V2, Sy, Syy) (device pointers; NULL = zeros). */
+int fmk_ewmst_shard_map_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
+                            int mean0, double *d_map_out);
+int fmk_ewmst_shard_apply_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t n, double half_life,
+                              double sigma_floor, int mean0, const double *d_state_in, double *d_out);
 /* ewms (core/volatility.py:9-69): fixed alpha = 2/(span+1); span <= 1 -> all NaN. */
 int fmk_ewms_dev(fmk_ctx *ctx, const double *d_y, int64_t n, int64_t span, double *d_out);
 int fmk_ewms(fmk_ctx *ctx, const double *y, int64_t n, int64_t span, double *out);

@@ -101,3 +101,38 @@ def test_virtual_ranks_features_match_unsharded(world, n, interval):
         np.testing.assert_array_equal(np.concatenate([p[2][k] for p in parts]), w, err_msg=k)
     for k, w in wbar.items():
         np.testing.assert_array_equal(np.concatenate([p[3][k] for p in parts]), w, err_msg=k)
+
+
+@pytest.mark.parametrize("world,n,window,half_life,mean0", [(3, 300_000, 5.0, 60.0, False), (4, 150_000, 60.0, 5.0, True),
+                                                          (2, 200_001, 0.5, 600.0, False)])
+def test_virtual_ranks_tick_level_features(world, n, window, half_life, mean0):
+    """Sharded comp_lagged_returns (raw-tick halo of one window) and ewmst (maps of the lower ranks -> incoming state)
+    == the un-sharded run: returns bit-identical, sigma within the float tolerance (different composition order)."""
+    from finmlkit_amd import _ffi, dist, engine
+    ctx = _ffi.default_context()
+    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, ctx=ctx, headroom=HALO) for r in range(world)]
+    tl = [dist.ShardedTickLevel(t, r, world) for r, t in enumerate(shards)]
+    firsts = [t.first_last_ts()[0] for t in shards]
+    start = [tl[r].returns_send_start(firsts[r + 1], window) for r in range(world - 1)]
+    recv = [0] + [n - s for s in start]
+    for r in range(1, world):
+        h = recv[r]
+        assert 1 <= h <= HALO
+        for src, dst in zip(shards[r - 1]._backing, shards[r]._backing):
+            s_, d_ = src.view(HALO + start[r - 1], h), dst.view(HALO - h, h)
+            ctx.call("fmk_d2d", d_.p, s_.p, C.c_size_t(s_.nbytes))
+    r_ext = [tl[r].lagged_returns(recv[r], window, True) for r in range(world)]
+    whole = engine.DeviceTrades.synth(world * n, seed=42, ctx=ctx)
+    wr = whole.lagged_returns(window, True)
+    want_r = wr.to_host()
+    for r in range(world):
+        np.testing.assert_array_equal(r_ext[r].to_host()[recv[r]:], want_r[r * n:(r + 1) * n], err_msg=f"returns rank {r}")
+    for r in range(1, world):                                   # the left neighbour's last return (8 bytes)
+        tl[r].set_left_value(r_ext[r], recv[r], float(r_ext[r - 1].view(r_ext[r - 1].n - 1, 1).to_host()[0]))
+    maps = [tl[r].ewmst_map(r_ext[r], recv[r], half_life, mean0) for r in range(world)]
+    want_s = whole.ewmst(wr, half_life, mean0=mean0).to_host()
+    for r in range(world):
+        got = tl[r].ewmst(r_ext[r], recv[r], maps[:r], half_life, mean0=mean0).to_host()
+        w = want_s[r * n:(r + 1) * n]
+        assert got.shape == w.shape and np.array_equal(np.isnan(got), np.isnan(w)), f"rank {r}"
+        np.testing.assert_allclose(got, w, rtol=1e-9, atol=0, equal_nan=True, err_msg=f"sigma rank {r}")
