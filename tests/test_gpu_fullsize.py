@@ -143,3 +143,52 @@ def test_threshold_bars_full_size(big, prefix, orc):
             o = engine.to_host(t.bar_ohlcv(engine.DeviceArray.from_host(t.ctx, ci), want_median=False))
             v = o["volume"].astype(np.float64)
             assert np.all(v >= vthr - 4.0) and np.all(v < vthr + 4.0)       # reset bars: thr <= vol(+tick 0 rule) < thr + max tick
+
+
+def test_cusum_and_volume_profile_full_size(big, prefix, orc):
+    """The "next" rows at 1e9 ticks: CUSUM closes are causal (prefix parity with the sequential oracle on the same
+    sigma), the rolling volume profile satisfies its ordering invariants on 8e5 bars and equals the oracle on a prefix."""
+    import ctypes as C
+    from finmlkit_amd._ffi import DeviceArray, c_f64, c_i64
+    engine, t, n = big
+    ts, px, am, sd = prefix
+    r = t.lagged_returns(5.0, True)
+    sg = t.ewmst(r, 60.0)
+    del r
+    sigma_prefix = sg.view(0, PREFIX).to_host()
+    m, rounds = c_i64(), c_i64()
+    t.ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sg.p, c_i64(n), c_f64(1e-5), c_f64(2.0), None, c_i64(0),
+               C.byref(m), C.byref(rounds))
+    out = DeviceArray(t.ctx, m.value, np.int64)
+    t.ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sg.p, c_i64(n), c_f64(1e-5), c_f64(2.0), out.p,
+               c_i64(m.value), C.byref(m), C.byref(rounds))
+    ci = out.to_host()
+    del sg, out
+    assert rounds.value <= 16 and np.all(np.diff(ci) > 0) and ci[-1] < n
+    want = orc._cusum_bar_indexer(ts, px, sigma_prefix, 1e-5, 2.0)
+    k = int(np.searchsorted(ci, PREFIX - 1, side="left"))           # the tick PREFIX-1 has no successor in the prefix run
+    assert k > 1000
+    np.testing.assert_array_equal(ci[:k], want[:k])
+    # ---- rolling volume profile over all one-minute bars
+    clock, cid = t.time_bar_index(60.0)
+    o, d, nz, off, flat, bar, bad = t.bars_fused(cid, 0.01, 3.0, want_median=False)
+    nb = cid.n - 1
+    bts = clock.view(1, nb)
+    window_ns = 1800 * 10**9
+    first = int(np.searchsorted(bts.to_host(), int(bts.view(0, 1).to_host()[0]) + window_ns))
+    outs = [DeviceArray(t.ctx, nb, np.int32) for _ in range(3)] + [DeviceArray(t.ctx, nb, np.float32)]
+    t.ctx.call("fmk_volume_profile_rolling_dev", bts.p, o["high"].p, o["low"].p, off.p, flat["price_levels"].p,
+               flat["buy_volumes"].p, flat["sell_volumes"].p, c_i64(nb), c_i64(first), c_i64(window_ns), c_i64(27),
+               c_f64(0.01), c_f64(68.34), *[x.p for x in outs])
+    poc, hva, lva, pct = (x.to_host() for x in outs)
+    assert np.all(poc[:first] == 0) and np.all(poc[first:] > 0)
+    assert np.all(lva[first:] <= poc[first:]) and np.all(poc[first:] <= hva[first:])
+    assert np.all((pct >= 0) & (pct <= 1))
+    kb = 2000                                                          # oracle on the first 2000 bars (causal windows)
+    offh = off.view(0, kb + 1).to_host()
+    nl = int(offh[-1])
+    w = orc.volume_profile_rolling(bts.view(0, kb).to_host(), o["high"].view(0, kb).to_host(), o["low"].view(0, kb).to_host(),
+                                   offh, flat["price_levels"].view(0, nl).to_host(), flat["buy_volumes"].view(0, nl).to_host(),
+                                   flat["sell_volumes"].view(0, nl).to_host(), 1800.0, 27, 0.01, 68.34)
+    for g, ww, name in zip((poc, hva, lva, pct), w, ("poc", "hva", "lva", "pct")):
+        np.testing.assert_array_equal(g[:kb], ww, err_msg=name)
