@@ -137,6 +137,11 @@ def main():
         dev = f"cuda:{local_rank}"
         tcols = [torch.as_tensor(b, device=dev) for b in trades._backing]   # zero-copy views of our buffers
         shard = ShardedTimeBars(trades, rank, world, args.interval, want_median)
+        # connection setup (not a step): RCCL builds its point-to-point channels on first use -- seconds, once
+        ping = torch.zeros(1, dtype=torch.int64, device=dev)
+        pong = torch.zeros(1, dtype=torch.int64, device=dev)
+        comm.neighbour_exchange([ping], [pong])
+        torch.cuda.current_stream().synchronize()
 
     def step():
         if use_dist:
@@ -230,6 +235,10 @@ def main():
         }
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
+        try:
+            C.CDLL(None).fflush(None)        # RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer: keep the
+        except OSError:                      # JSON line the LAST line of stdout
+            pass
         print(json.dumps(line), flush=True)
     if comm:
         import torch.distributed as dist
