@@ -30,7 +30,9 @@
 //     vp_skew is mathematically 0 (rounding noise in the reference) and is evaluated in float64.
 //
 // Bars are binned by level count so that the common narrow bars run at high occupancy:
-// L<=128 (3 KB LDS/wave), <=512 (12 KB), <=2048 (48 KB, one wave per workgroup).
+// L<=128 (3 KB LDS/wave), <=512 (12 KB), <=2048 (48 KB, one wave per workgroup); bars wider than that (a fine
+// tick on a volatile hour: 10^4-10^5 levels) run the same code with the histogram in a per-wave slice of global
+// scratch instead of LDS (generic pointers; slow but unlimited up to 2^24 levels).
 #include "fmk_footprint.h"
 #include "fmk_scan.h"
 
