@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <map>
+#include <unordered_map>
+
 #include "fmk_common.h"
 
 static char g_err[512] = "";
@@ -15,6 +18,8 @@ int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+static void fmk_pool_destroy(fmk_ctx *ctx);
 
 extern "C" {
 
@@ -82,6 +87,7 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    fmk_pool_destroy(ctx);
     (void)hipFree(ctx->d_mail);
     (void)hipHostFree(ctx->h_mail);
     (void)hipEventDestroy(ctx->ev0);
@@ -100,12 +106,79 @@ int fmk_ctx_sync(fmk_ctx *ctx)
 
 void *fmk_ctx_stream(fmk_ctx *ctx) { return (void *)ctx->stream; }
 
+// ---------------------------------------------------------------------------------------
+// Caching allocator.  Everything the library enqueues runs on the context's ONE stream, so a block that is freed
+// and handed out again is reused in stream order: no synchronisation is needed, and hipMalloc / hipFree (milliseconds
+// for the multi-GB per-tick outputs) leave the steady state of a pipeline.  Blocks are matched by size (a cached
+// block may be up to 1/8 larger than the request); when hipMalloc fails the cache is flushed and the call retried.
+// FMK_POOL=0 in the environment disables caching.  Buffers that OTHER streams touch (the halo exchange of bench.py)
+// must simply stay allocated while those streams use them -- as with any allocator.
+// ---------------------------------------------------------------------------------------
+struct FmkPool {
+    std::multimap<size_t, void *> free_blocks;      // size -> block
+    std::unordered_map<void *, size_t> live;        // block -> size (everything handed out)
+    size_t cached_bytes = 0;
+    bool enabled = true;
+};
+
+static FmkPool *fmk_pool(fmk_ctx *ctx)
+{
+    if (!ctx->pool) {
+        FmkPool *p = new FmkPool();
+        const char *v = getenv("FMK_POOL");
+        if (v && atoi(v) == 0) p->enabled = false;
+        ctx->pool = p;
+    }
+    return (FmkPool *)ctx->pool;
+}
+
+static void fmk_pool_flush(fmk_ctx *ctx)
+{
+    FmkPool *p = fmk_pool(ctx);
+    if (p->free_blocks.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : p->free_blocks) (void)hipFree(kv.second);
+    p->free_blocks.clear();
+    p->cached_bytes = 0;
+}
+
+static void fmk_pool_destroy(fmk_ctx *ctx)
+{
+    if (!ctx->pool) return;
+    fmk_pool_flush(ctx);
+    delete (FmkPool *)ctx->pool;
+    ctx->pool = nullptr;
+}
+
 int fmk_alloc(fmk_ctx *ctx, size_t bytes, void **dptr)
 {
     *dptr = nullptr;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     if (bytes == 0) bytes = 16;
-    FMK_HIP(ctx, hipMalloc(dptr, bytes));
+    bytes = (bytes + 255) & ~(size_t)255;
+    FmkPool *p = fmk_pool(ctx);
+    if (p->enabled) {
+        auto it = p->free_blocks.lower_bound(bytes);
+        if (it != p->free_blocks.end() && it->first <= bytes + (bytes >> 3)) {
+            *dptr = it->second;
+            p->live[*dptr] = it->first;
+            p->cached_bytes -= it->first;
+            p->free_blocks.erase(it);
+            return FMK_OK;
+        }
+    }
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory && !p->free_blocks.empty()) {
+        (void)hipGetLastError();
+        fmk_pool_flush(ctx);
+        e = hipMalloc(dptr, bytes);
+    }
+    if (e != hipSuccess) {
+        *dptr = nullptr;
+        return fmk_set_error(ctx, e == hipErrorOutOfMemory ? FMK_E_NOMEM : FMK_E_HIP, "hipMalloc(%zu) failed: %s", bytes,
+                             hipGetErrorString(e));
+    }
+    p->live[*dptr] = bytes;
     return FMK_OK;
 }
 
@@ -113,8 +186,22 @@ int fmk_free(fmk_ctx *ctx, void *dptr)
 {
     if (!dptr) return FMK_OK;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FMK_HIP(ctx, hipFree(dptr));
+    FmkPool *p = fmk_pool(ctx);
+    auto it = p->live.find(dptr);
+    if (it == p->live.end()) {                       // not ours (or double free): fall back to the plain path
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FMK_HIP(ctx, hipFree(dptr));
+        return FMK_OK;
+    }
+    const size_t bytes = it->second;
+    p->live.erase(it);
+    if (!p->enabled) {
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FMK_HIP(ctx, hipFree(dptr));
+        return FMK_OK;
+    }
+    p->free_blocks.emplace(bytes, dptr);
+    p->cached_bytes += bytes;
     return FMK_OK;
 }
 
@@ -154,6 +241,7 @@ int fmk_mem_info(fmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    if (ctx->pool) *free_bytes += ((FmkPool *)ctx->pool)->cached_bytes;     // cached blocks are available memory
     return FMK_OK;
 }
 

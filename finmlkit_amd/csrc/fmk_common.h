@@ -26,6 +26,9 @@ struct fmk_ctx {
     // per-launch timing of the dominant kernel (fmk_profile_enable)
     int profile_on, profile_n;
     hipEvent_t kev[64][2];
+    // stream-ordered caching allocator behind fmk_alloc / fmk_free (fmk_api.hip): freed blocks are kept and handed
+    // out again to later requests of (almost) the same size -- no hipMalloc / hipFree / synchronisation per call
+    void *pool;
 };
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);

@@ -15,7 +15,7 @@ struct DevBag {
     ~DevBag()
     {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs) (void)fmk_free(ctx, p);      // back to the context's caching allocator
     }
     int alloc(size_t bytes, void **out)
     {
