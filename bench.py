@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-median", action="store_true", help="skip the median trade size (not the reference path)")
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="ticks of the CPU-baseline sample (0: skip)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational cfg 3 / cfg 4 timings")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded code path (torch.distributed/RCCL init, planning, halo logic) even with 1 rank")
     return ap.parse_args()
@@ -70,6 +71,45 @@ def cpu_baseline(args):
             "sample": f"first {m} ticks of the same synthetic stream, time-bar indexer + comp_bar_ohlcv"
                       f"{'' if args.no_median else ' + median'} (oracle/fmk_oracle.c, gcc -O2 -fopenmp, bars split over "
                       f"{cores} threads): {dtn:.2f} s; 1 thread: {dt1:.2f} s = {m / dt1:.3g} ticks/s"}
+
+
+def other_configs(trades, ctx, args):
+    """Informational, AFTER the timed region and outside `value`: one pass each of BASELINE.json configs[2] (volume +
+    dollar bar indices, data-derived thresholds) and configs[3] (time bars + order-flow + footprints) on the same
+    resident columns, host wall time incl. the size/fill phases.  Never raises: a failure is reported as a string."""
+    import numpy as np
+    out = {}
+
+    def timed(fn, reps=3):
+        best = None
+        for _ in range(reps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            ctx.sync()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+            del r
+        return best
+
+    try:
+        n = trades.n
+        clock, ci = trades.time_bar_index(args.interval)
+        o = trades.bar_ohlcv(ci, want_median=False)
+        vol_total = float(o["volume"].to_host().astype(np.float64).sum())
+        span_days = (trades.first_last_ts()[1] - trades.first_last_ts()[0]) / 86400e9
+        vthr = vol_total / max(span_days, 1e-9) / 2000.0                 # QuickStart: daily volume / 2000
+        dthr = vthr * float(np.median(o["close"].to_host()))
+        del o
+        out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr))
+        out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
+        out["cfg3_n_volume_bars"] = int(trades.volume_bar_index(vthr).n)
+        out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
+        out["cfg4_bytes_per_tick"] = 38
+        out["note"] = f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`"
+    except Exception as e:                                               # noqa: BLE001 -- informational only
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def main():
@@ -235,6 +275,8 @@ def main():
         }
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
+            if not args.no_extras:
+                line["other_configs"] = other_configs(trades, ctx, args)
         try:
             C.CDLL(None).fflush(None)        # RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer: keep the
         except OSError:                      # JSON line the LAST line of stdout
