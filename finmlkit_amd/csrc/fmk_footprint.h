@@ -40,6 +40,16 @@ __device__ __forceinline__ int64_t fp_level(double price, double tick, double in
     return (int64_t)r;
 }
 
+// 32-bit flavour for the per-tick path (price levels are int32 in the output arrays, base.py:675): a level beyond
+// +-2^31 saturates and is then reported as out of range like any other tick outside [low, high]
+__device__ __forceinline__ int fp_level32(double price, double tick, double inv_tick)
+{
+    const double q = price * inv_tick;
+    double r = rint(q);
+    if (0.5 - fabs(q - r) <= fabs(q) * 1e-15) r = rint(price / tick);
+    return (int)r;
+}
+
 // ---------------------------------------------------------------------------------------
 // NumPy pairwise float32 sum over an LDS array, evaluated by the whole wave (uniform result)
 // ---------------------------------------------------------------------------------------

@@ -108,19 +108,18 @@ __device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ pric
             a_n = ((const AmtT *)amount)[j + 64];
             sd_n = side[j + 64];
         }
-        bool pending = false;
-        int key = -1;
-        if (j <= e) {
-            const int64_t lvl = fp_level(p, tick, inv_tick) - low;    // base.py:700-707
-            if (lvl < 0 || lvl >= L) bad = true;                      // base.py:719
-            else if (sd == 1 || sd == -1) {
-                pending = true;
-                key = (int)lvl * 2 + (sd == 1 ? 0 : 1);
-                if constexpr (!EXACT) {                               // statistics that pick the quantum of later bars
-                    const int lb = fp_lowbit_exp(a);
-                    lbmin = lb < lbmin ? lb : lbmin;
-                    atot += fabs((double)a);
-                }
+        // branch-light: levels are int32 in the output, so 32-bit level arithmetic; one unsigned compare for the range
+        const bool in_bar = j <= e;
+        const int lvl = fp_level32(p, tick, inv_tick) - (int)low;     // base.py:700-707
+        const bool inside = (unsigned)lvl < (unsigned)L;
+        bad |= in_bar && !inside;                                     // base.py:719
+        const bool pending = in_bar && inside && (sd == 1 || sd == -1);
+        const int key = pending ? lvl * 2 + (sd == 1 ? 0 : 1) : -1;
+        if constexpr (!EXACT) {                                       // statistics that pick the quantum of later bars
+            if (pending) {
+                const int lb = fp_lowbit_exp(a);
+                lbmin = lb < lbmin ? lb : lbmin;
+                atot += fabs((double)a);
             }
         }
         if constexpr (EXACT) {
@@ -179,7 +178,7 @@ __device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ pric
 // ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
-template <bool AF64>
+template <bool AF64, bool GLOBAL>
 __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict__ price,
                                                         const void *__restrict__ amount,
                                                         const int8_t *__restrict__ side,
@@ -194,10 +193,11 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const size_t per_wave = (size_t)lmax * 24 + 256;
-    // the wave's histogram: LDS for the three narrow classes, a slice of global scratch for bars wider than 2048
-    // levels (same code through generic pointers; a wave's own stores are visible to its later loads)
-    unsigned char *mine = gscratch ? gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave
-                                   : smem + (size_t)wib * per_wave;
+    // the wave's histogram: LDS for the three narrow classes (LDS-typed pointers: ds_add / ds_read), a slice of global
+    // scratch for bars wider than 2048 levels (same code; a wave's own stores are visible to its later loads)
+    unsigned char *mine;
+    if constexpr (GLOBAL) mine = gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave;
+    else mine = smem + (size_t)wib * per_wave;
     float *vol = (float *)mine;                                   // [2*lmax]  buy = 2l, sell = 2l+1
     int *cnt = (int *)(mine + (size_t)lmax * 8);                  // [2*lmax]
     float *aux = (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
@@ -273,9 +273,14 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     }
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    k_bar_footprints<AF64><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32, off,
-                                                                            lmin, lmax, o, n_bad, force_ordered,
-                                                                            gscratch);
+    if (gscratch)
+        k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32, off,
+                                                                                   lmin, lmax, o, n_bad, force_ordered,
+                                                                                   gscratch);
+    else
+        k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32,
+                                                                                       off, lmin, lmax, o, n_bad,
+                                                                                       force_ordered, nullptr);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
