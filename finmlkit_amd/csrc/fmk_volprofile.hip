@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_vp_max_levels(const int64_t *__restrict
 #define VP_BAD_LEVEL 1      // a footprint level outside its window's range
 #define VP_ONE_LEVEL 2      // bucketing a window that spans a single level (the reference raises there)
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restrict__ ts, const double *__restrict__ highs,
                                                         const double *__restrict__ lows,
                                                         const int64_t *__restrict__ off,
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const size_t per_wave = (size_t)(cap + 8) * 8 + 256;
-    unsigned char *mine = gscratch ? gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave   // very wide windows
-                                   : smem + (size_t)wib * per_wave;
+    unsigned char *mine;                                          // LDS-typed unless the window is very wide
+    if constexpr (GLOBAL) mine = gscratch + ((size_t)blockIdx.x * wpb + wib) * per_wave;
+    else mine = smem + (size_t)wib * per_wave;
     float *ab = (float *)mine;                                    // [cap + 8] buy sums, later totals
     float *as = ab + (cap + 8);                                   // [cap + 8] sell sums, later binned volumes
     int *stk = (int *)(as + (cap + 8));                           // 64 ints (pairwise-sum stack)
@@ -246,12 +248,17 @@ extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar
         smem = 0;
     }
     if (smem > 64 * 1024)
-        FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_volume_profile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_volume_profile<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
     if (blocks > capb) blocks = capb;
-    k_volume_profile<<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(d_bar_ts, d_highs, d_lows, d_level_offsets,
-                                                                       d_price_levels, d_buy_volumes, d_sell_volumes, n_bars,
-                                                                       first_bar, window_ns, n_bins, price_tick, va_pct, cap,
-                                                                       d_poc, d_hva, d_lva, d_pct, d_status, gscratch);
+    if (gscratch)
+        k_volume_profile<true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(
+            d_bar_ts, d_highs, d_lows, d_level_offsets, d_price_levels, d_buy_volumes, d_sell_volumes, n_bars, first_bar,
+            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, gscratch);
+    else
+        k_volume_profile<false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(
+            d_bar_ts, d_highs, d_lows, d_level_offsets, d_price_levels, d_buy_volumes, d_sell_volumes, n_bars, first_bar,
+            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, nullptr);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
