@@ -48,7 +48,10 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
 {
     constexpr int PER = 2 * S / VOL_THREADS;          // prefix elements per thread
     constexpr int EPT = S / VOL_THREADS;              // table entries per thread
-    __shared__ double Lp[2 * S + 1];                  // Lp[i] = sum of the first i ticks from the block start
+    // Lp[i] = sum of the first i ticks from the block start, stored PADDED (one slot per 8): thread t later probes
+    // around element 8t + (bar length), i.e. with a lane stride of 8 doubles -- unpadded that is a 16-way bank conflict
+#define LP(i) Lp[(i) + ((i) >> 3)]
+    __shared__ double Lp[2 * S + 1 + (2 * S + 1) / 8 + 1];
     __shared__ uint32_t Eb[S], Cb[S];
     __shared__ double wtot[4];
     const int64_t bs = (int64_t)blockIdx.x * S;       // first tick of the block
@@ -76,51 +79,67 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
         pre = wp + pre;
     }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) Lp[tid * PER + k + 1] = pre + loc[k];
-    if (tid == 0) Lp[0] = 0.0;
+    for (int k = 0; k < PER; ++k) LP(tid * PER + k + 1) = pre + loc[k];
+    if (tid == 0) LP(0) = 0.0;
     if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);
     __syncthreads();
-    // ---- nxt(j) for every tick of the block: smallest m > i+1 with Lp[m] - Lp[i+1] >= thr
+    // ---- nxt(j) for every tick of the block: smallest m > i+1 with Lp[m] - Lp[i+1] >= thr.
+    //      Thread t owns the EPT CONSECUTIVE ticks i = t*EPT + q: nxt is non-decreasing in i, so after one bisection
+    //      for its first tick the thread only walks forward (amortised ~1 probe per tick instead of log2(2S) = 12).
     const int64_t remain = n - bs;                                  // ticks available from the block start
     const int mmax = (int)(remain < 2 * S ? remain : 2 * S);        // Lp[0..mmax] are valid
     const double tol = 1e-11 * thr;
     int frag = 0;
+    int carry_lo = 0;                                               // m of the previous tick of this thread
     for (int q = 0; q < EPT; ++q) {
-        const int i = q * VOL_THREADS + tid;                        // tick bs + i
+        const int i = tid * EPT + q;                                // tick bs + i
         uint32_t nx = VOL_END, cc = 0;
         if (i < remain) {
             cc = 1;
-            const double target = Lp[i + 1] + thr;
+            const double target = LP(i + 1) + thr;
             int lo = i + 2, hi = i + 1 + S;                          // close tick = bs + m - 1 in (j, j + S]
             if (hi > mmax) hi = mmax;
-            if (lo <= hi && Lp[hi] >= target) {
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (Lp[mid] >= target) hi = mid; else lo = mid + 1;
+            if (lo <= hi && LP(hi) >= target) {
+                if (q > 0 && carry_lo >= lo) {
+                    // monotone: the answer is >= the previous tick's; walk forward from there
+                    lo = carry_lo;
+                    while (lo < hi && LP(lo) < target) ++lo;
+                } else {
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (LP(mid) >= target) hi = mid; else lo = mid + 1;
+                    }
                 }
+                carry_lo = lo;
                 nx = (uint32_t)(bs + lo - 1);
                 // an exact hit (difference 0) is a certain decision, not a fragile one: it is what
                 // exactly-summable amounts produce, and a measure-zero coincidence otherwise
-                const double over = Lp[lo] - target, under = target - Lp[lo - 1];
+                const double over = LP(lo) - target, under = target - LP(lo - 1);
                 frag += (over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol);
             } else if (i + 1 + S <= mmax) {
                 atomicOr(status, VOL_ST_OVERFLOW);                   // no close within S ticks although data remains
-            } else if (hi >= lo) {
-                frag += target - Lp[hi] <= tol;
+                carry_lo = 0;
+            } else {
+                if (hi >= lo) frag += target - LP(hi) <= tol;
+                carry_lo = 0;
             }
         }
         Eb[i] = nx;
         Cb[i] = cc;
-        nxt[bs + i] = nx;
+    }
+    __syncthreads();
+    for (int q = 0; q < EPT; ++q) {                                  // coalesced copy of the chain links
+        const int i = q * VOL_THREADS + tid;
+        nxt[bs + i] = Eb[i];
     }
     // first bar (block 0): tick 0 is counted but cannot close -> first j >= 1 with P_j >= thr
     if (blockIdx.x == 0 && tid == 0) {
         uint32_t r = VOL_END;
         int lo = 2, hi = mmax < S ? mmax : S;           // keeps the root inside the first S ticks
-        if (lo <= hi && Lp[hi] >= thr) {
+        if (lo <= hi && LP(hi) >= thr) {
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (Lp[mid] >= thr) hi = mid; else lo = mid + 1;
+                if (LP(mid) >= thr) hi = mid; else lo = mid + 1;
             }
             r = (uint32_t)(lo - 1);
         } else if (S <= mmax) {
