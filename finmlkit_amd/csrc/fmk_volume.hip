@@ -51,9 +51,14 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     // Lp[i] = sum of the first i ticks from the block start, stored PADDED (one slot per 8): thread t later probes
     // around element 8t + (bar length), i.e. with a lane stride of 8 doubles -- unpadded that is a 16-way bank conflict
 #define LP(i) Lp[(i) + ((i) >> 3)]
-    __shared__ double Lp[2 * S + 1 + (2 * S + 1) / 8 + 1];
-    __shared__ uint32_t Eb[S], Cb[S];
-    __shared__ double wtot[4];
+    // dynamic LDS (S = 2048: 53 KB, S = 4096: 106 KB -- the larger table span is the fallback for streams whose
+    // longest bar exceeds 2048 ticks): [Lp | Eb | Cb | wtot]
+    constexpr int LPN = 2 * S + 1 + (2 * S + 1) / 8 + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char vol_smem[];
+    double *Lp = (double *)vol_smem;
+    uint32_t *Eb = (uint32_t *)(vol_smem + (size_t)LPN * 8);
+    uint32_t *Cb = Eb + S;
+    double *wtot = (double *)(Cb + S);
     const int64_t bs = (int64_t)blockIdx.x * S;       // first tick of the block
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
     // ---- block-local prefix sums over [bs, bs + 2S)
@@ -315,8 +320,14 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     uint32_t *d_root = (uint32_t *)(ctx->d_mail + 33);
     unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 34);
     FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 24, ctx->stream));
-    k_vol_level0<AF64, S><<<(unsigned)nblk0, VOL_THREADS, 0, ctx->stream>>>(a, n, thr, nxt, E[0], C[0], d_root,
-                                                                            d_status, d_frag);
+    {
+        constexpr size_t lds = (size_t)(2 * S + 1 + (2 * S + 1) / 8 + 1) * 8 + (size_t)S * 8 + 64;
+        if (lds > 64 * 1024)
+            FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vol_level0<AF64, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds));
+        k_vol_level0<AF64, S><<<(unsigned)nblk0, VOL_THREADS, lds, ctx->stream>>>(a, n, thr, nxt, E[0], C[0], d_root,
+                                                                                  d_status, d_frag);
+    }
     FMK_LAUNCH_CHECK(ctx);
     for (int k = 1; k <= K; ++k) {
         const int64_t tot = nblk[k] * S;
@@ -374,6 +385,9 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
     if (!hit) {
         int rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
+        if (rc == 1)     // a bar longer than 2048 ticks: retry with the 4096-tick table span (one workgroup per CU)
+            rc = amount_is_f64 ? vol_run<true, 4096>(ctx, d_amount, n, threshold, c)
+                               : vol_run<false, 4096>(ctx, d_amount, n, threshold, c);
         if (rc == 1)     // bar longer than the table span, or negative volumes
             return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                         n_idx, n_uncertified);
