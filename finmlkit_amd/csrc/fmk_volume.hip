@@ -96,6 +96,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     const double tol = 1e-11 * thr;
     int frag = 0;
     int carry_lo = 0;                                               // m of the previous tick of this thread
+    bool ovf = false;
     for (int q = 0; q < EPT; ++q) {
         const int i = tid * EPT + q;                                // tick bs + i
         uint32_t nx = VOL_END, cc = 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                 const double over = LP(lo) - target, under = target - LP(lo - 1);
                 frag += (over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol);
             } else if (i + 1 + S <= mmax) {
-                atomicOr(status, VOL_ST_OVERFLOW);                   // no close within S ticks although data remains
+                ovf = true;                                          // no close within S ticks although data remains
                 carry_lo = 0;
             } else {
                 if (hi >= lo) frag += target - LP(hi) <= tol;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
         Eb[i] = nx;
         Cb[i] = cc;
     }
+    if (__ballot(ovf) != 0 && lane == 0) atomicOr(status, VOL_ST_OVERFLOW);   // one atomic per wave, not per tick
     __syncthreads();
     for (int q = 0; q < EPT; ++q) {                                  // coalesced copy of the chain links
         const int i = q * VOL_THREADS + tid;
@@ -341,6 +343,7 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     const int status = (int)(ctx->h_mail[0] & 0xFFFFFFFF);
     const uint32_t root = (uint32_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
     c.unc = ctx->h_mail[2];
+    if (status & VOL_ST_BAD) return 2;              // negative / NaN volumes: only the serial walk reproduces those
     if (status) return 1;
     int64_t closes = 0;
     if (root != VOL_END) {
@@ -369,6 +372,203 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     return FMK_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Long bars (> 4096 ticks): the jump tables cannot span them, but long bars are FEW (<= N/4096), so the chain is simply
+// walked -- with the whole wave searching for each next close:
+//   k_vc_prefix : block-local inclusive prefix sums Lp[j] (2048-tick blocks, float64) + block totals
+//   k_vc_scan   : exclusive scan of the block totals in double-double -> Bb[0..nblk]
+//   k_vc_chase  : ONE wave; per close: 64 block ends at a time (Bb) locate the block of the crossing, 64 probes 32
+//                 ticks apart locate the 32-tick range, 32 probes the tick: ~4 dependent loads per close instead of one
+//                 per tick.  sum(c+1..m) = (Bb[blk(m)] - Bb[blk(c)]) + (Lp[m] - Lp[c]).
+// Decisions within (1e-11 + 2^-52 * bar length) * thr of the threshold are counted as uncertified, as in the tables.
+// ---------------------------------------------------------------------------------------
+#define VC_BLOCK 2048
+struct VcDD { double hi, lo; };
+__device__ __forceinline__ VcDD vc_two_sum(double a, double b) { double s = a + b, bb = s - a; return VcDD{s, (a - (s - bb)) + (b - bb)}; }
+__device__ __forceinline__ VcDD vc_add(VcDD x, VcDD y)
+{
+    VcDD s = vc_two_sum(x.hi, y.hi);
+    s.lo += x.lo + y.lo;
+    const double h = s.hi + s.lo;
+    return VcDD{h, s.lo - (h - s.hi)};
+}
+__device__ __forceinline__ double vc_diff(VcDD a, VcDD b)      // a - b rounded to double
+{
+    VcDD d = vc_two_sum(a.hi, -b.hi);
+    return d.hi + (d.lo + (a.lo - b.lo));
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(256) void k_vc_prefix(const void *__restrict__ amount, int64_t n, double *__restrict__ Lp,
+                                                   double *__restrict__ totals)
+{
+    __shared__ double wtot[4];
+    const int64_t bs = (int64_t)blockIdx.x * VC_BLOCK;
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    double loc[8], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t j = bs + (int64_t)tid * 8 + k;
+        run += j < n ? fmk_amt<AF64>(amount, j) : 0.0;
+        loc[k] = run;
+    }
+    const double inc = fmk_wave_iscan(run);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    double pre = __shfl_up(inc, 1, 64);
+    if (lane == 0) pre = 0.0;
+    for (int q = 0; q < w; ++q) pre += wtot[q];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t j = bs + (int64_t)tid * 8 + k;
+        if (j < n) Lp[j] = pre + loc[k];
+    }
+    if (tid == 255) totals[blockIdx.x] = pre + loc[7];
+}
+
+// Bb[k] = sum of totals[0..k) in double-double, k = 0..m (one block, 8 records per thread and round)
+__global__ __launch_bounds__(256) void k_vc_scan(const double *__restrict__ totals, int64_t m, VcDD *__restrict__ Bb)
+{
+    __shared__ VcDD lds[4];
+    __shared__ VcDD run_s;
+    if (threadIdx.x == 0) run_s = VcDD{0.0, 0.0};
+    __syncthreads();
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    for (int64_t b = 0; b < m; b += 2048) {
+        const int64_t i0 = b + (int64_t)threadIdx.x * 8;
+        VcDD loc[8], s = VcDD{0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            loc[k] = s;
+            if (i0 + k < m) s = vc_add(s, VcDD{totals[i0 + k], 0.0});
+        }
+        VcDD inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const VcDD o = VcDD{__shfl_up(inc.hi, d, 64), __shfl_up(inc.lo, d, 64)};
+            if (lane >= d) inc = vc_add(o, inc);
+        }
+        if (lane == 63) lds[w] = inc;
+        __syncthreads();
+        VcDD pre = run_s;
+        for (int q = 0; q < w; ++q) pre = vc_add(pre, lds[q]);
+        VcDD prev = VcDD{__shfl_up(inc.hi, 1, 64), __shfl_up(inc.lo, 1, 64)};
+        if (lane == 0) prev = VcDD{0.0, 0.0};
+        const VcDD base = vc_add(pre, prev);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < m) Bb[i0 + k] = vc_add(base, loc[k]);
+        __syncthreads();
+        if (threadIdx.x == 255) run_s = vc_add(pre, inc);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Bb[m] = run_s;
+}
+
+__global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
+                                                 int64_t nblk, double thr, int64_t *__restrict__ closes, int64_t cap,
+                                                 int64_t *__restrict__ result /* [0] count, [1] uncertified */)
+{
+    const int lane = fmk_lane();
+    int64_t c = -1, cnt = 0, unc = 0;
+    if (cap > 0 && lane == 0) closes[0] = 0;
+    cnt = 1;                                                       // the opening entry (logic.py:104)
+    for (;;) {
+        const double Lc = c >= 0 ? Lp[c] : 0.0;
+        const int64_t bc = c >= 0 ? c / VC_BLOCK : 0;
+        const VcDD Bc = Bb[bc];
+        // ---- block of the crossing: first b >= bc with sum(c+1 .. end of b) >= thr
+        int64_t bstar = -1;
+        for (int64_t b0 = bc; b0 < nblk && bstar < 0; b0 += 64) {
+            const int64_t b = b0 + lane;
+            bool hit = false;
+            if (b < nblk) hit = vc_diff(Bb[b + 1], Bc) - Lc >= thr;
+            const uint64_t m = __ballot(hit);
+            if (m) bstar = b0 + (__ffsll((unsigned long long)m) - 1);
+        }
+        if (bstar < 0) break;                                      // the remaining ticks do not fill a bar
+        const VcDD Bs = Bb[bstar];
+        const double off = vc_diff(Bs, Bc) - Lc;                   // sum(c+1 .. m) = off + Lp[m] for m in block bstar
+        const int64_t lo = bstar == bc ? (c + 1 > 1 ? c + 1 : 1) : bstar * VC_BLOCK;      // tick 0 cannot close
+        const int64_t hi = (bstar + 1) * VC_BLOCK - 1 < n - 1 ? (bstar + 1) * VC_BLOCK - 1 : n - 1;
+        // ---- 64 probes, 32 ticks apart
+        int64_t pr = lo + 31 + (int64_t)lane * 32;
+        if (pr > hi) pr = hi;
+        const uint64_t m1 = __ballot(off + Lp[pr] >= thr);
+        const int f = m1 ? __ffsll((unsigned long long)m1) - 1 : 63;   // the block end qualifies (lane 63 probes it)
+        const int64_t top = __shfl(pr, f, 64);
+        int64_t q = top - 31 + lane;
+        if (q < lo) q = lo;
+        const bool in = lane < 32;
+        const double sq = off + Lp[q];
+        const uint64_t m2 = __ballot(in && sq >= thr);
+        const int g = m2 ? __ffsll((unsigned long long)m2) - 1 : 31;   // lane 31 probes `top`
+        const int64_t mclose = __shfl(q, g, 64);
+        const double s_at = __shfl(sq, g, 64);
+        // ---- certification
+        const double tol = (1e-11 + 2.3e-16 * (double)(mclose - c)) * thr;
+        const double over = s_at - thr;
+        double under = INFINITY;
+        if (mclose - 1 >= lo) under = thr - (off + Lp[mclose - 1]);
+        if ((over > 0.0 && over <= tol) || under <= tol) ++unc;
+        if (cnt < cap && lane == 0) closes[cnt] = mclose;
+        ++cnt;
+        c = mclose;
+    }
+    if (lane == 0) { result[0] = cnt; result[1] = unc; }
+}
+
+// total_only: stop after the prefix / scan and return the stream's total volume through *total (used to decide whether
+// the 4096-tick tables are worth trying before the chain walk)
+template <bool AF64>
+static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c, bool total_only, double *total)
+{
+    const int64_t nblk = fmk_ceil_div(n, VC_BLOCK);
+    const size_t lp_bytes = ((size_t)n * 8 + 255) & ~(size_t)255;
+    const size_t tot_bytes = ((size_t)nblk * 8 + 255) & ~(size_t)255;
+    const size_t bb_bytes = ((size_t)(nblk + 1) * sizeof(VcDD) + 255) & ~(size_t)255;
+    const size_t bytes = lp_bytes + tot_bytes + bb_bytes + 256;
+    if (c.work_bytes < bytes) {
+        if (c.work) FMK_HIP(ctx, hipFree(c.work));
+        c.work = nullptr; c.work_bytes = 0;
+        FMK_HIP(ctx, hipMalloc(&c.work, bytes));
+        c.work_bytes = bytes;
+    }
+    double *Lp = (double *)c.work;
+    double *totals = (double *)((char *)c.work + lp_bytes);
+    VcDD *Bb = (VcDD *)((char *)c.work + lp_bytes + tot_bytes);
+    int64_t *d_res = ctx->d_mail + 44;
+    k_vc_prefix<AF64><<<(unsigned)nblk, 256, 0, ctx->stream>>>(a, n, Lp, totals);
+    FMK_LAUNCH_CHECK(ctx);
+    k_vc_scan<<<1, 256, 0, ctx->stream>>>(totals, nblk, Bb);
+    FMK_LAUNCH_CHECK(ctx);
+    if (total_only) {
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], &Bb[nblk].hi, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(total, &ctx->h_mail[6], 8);
+        return FMK_OK;
+    }
+    int64_t cap = c.dbuf ? c.cap : 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!c.dbuf) {
+            cap = n / 4096 + 1024;
+            if (attempt == 1) cap = c.count;
+            FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)cap * 8));
+            c.cap = cap;
+        }
+        k_vc_chase<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, c.dbuf, c.cap, d_res);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], d_res, 16, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        c.count = ctx->h_mail[6];
+        c.unc = ctx->h_mail[7];
+        if (c.count <= c.cap) return FMK_OK;
+        FMK_HIP(ctx, hipFree(c.dbuf));                              // more closes than expected: exact size, once more
+        c.dbuf = nullptr;
+    }
+    return fmk_set_error(ctx, FMK_E_HIP, "volume chase: capacity");
+}
+
 extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
                                           double threshold, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx,
                                           int64_t *n_uncertified)
@@ -385,9 +585,22 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
     if (!hit) {
         int rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
-        if (rc == 1)     // a bar longer than 2048 ticks: retry with the 4096-tick table span (one workgroup per CU)
-            rc = amount_is_f64 ? vol_run<true, 4096>(ctx, d_amount, n, threshold, c)
-                               : vol_run<false, 4096>(ctx, d_amount, n, threshold, c);
+        if (rc == 1) {
+            // a bar longer than 2048 ticks.  Mean bar length from the total volume decides the next tier: the
+            // 4096-tick tables (one workgroup per CU, ~0.2 s at 1e9 ticks) only when the bars are short enough on average
+            double total = 0.0;
+            int rc2 = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &total)
+                                    : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &total);
+            if (rc2) return rc2;
+            const double mean_len = total > 0.0 ? (double)n * threshold / total : 1e300;
+            if (mean_len < 3000.0)
+                rc = amount_is_f64 ? vol_run<true, 4096>(ctx, d_amount, n, threshold, c)
+                                   : vol_run<false, 4096>(ctx, d_amount, n, threshold, c);
+            if (rc == 1)     // few, long bars: walk the chain with wave-parallel searches
+                rc = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, false, nullptr)
+                                   : vol_chase<false>(ctx, d_amount, n, threshold, c, false, nullptr);
+        }
+        if (rc == 2) rc = 1;
         if (rc == 1)     // bar longer than the table span, or negative volumes
             return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                         n_idx, n_uncertified);

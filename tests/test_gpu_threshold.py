@@ -36,8 +36,8 @@ def test_threshold_vs_oracle(orc, n, f64):
     if f64:
         am = np.random.default_rng(6).lognormal(-1, 1.3, n)
     mean_v = float(np.mean(am))
-    # 3000 ticks/bar: beyond the 2048-tick table span -> the 4096-tick tables; 400 000: the serial walk
-    for bar_ticks in (3, 50, 1200, 3000, 400_000):
+    # 3000 ticks/bar: beyond the 2048-tick table span -> the 4096-tick tables; longer: wave-parallel chain walk
+    for bar_ticks in (3, 50, 1200, 3000, 5000, 70_000, 400_000, 10**9):
         vthr = mean_v * bar_ticks
         np.testing.assert_array_equal(_volume_bar_indexer(am, vthr), orc._volume_bar_indexer(am, vthr),
                                       err_msg=f"vol {bar_ticks}")
