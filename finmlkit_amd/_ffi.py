@@ -131,6 +131,10 @@ class Context:
     def call(self, name, *args, allow=()):
         return check(getattr(lib(), name)(self._h, *args), self._h, allow=allow)
 
+    def trim(self):
+        """Give back everything the context caches between calls (scratch, allocator free lists, indexer buffers)."""
+        self.call("fmk_ctx_trim")
+
     def sync(self):
         self.call("fmk_ctx_sync")
 

@@ -20,6 +20,7 @@ int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...)
 }
 
 static void fmk_pool_destroy(fmk_ctx *ctx);
+static void fmk_pool_flush(fmk_ctx *ctx);
 
 extern "C" {
 
@@ -88,12 +89,27 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     fmk_pool_destroy(ctx);
+    fmk_volume_trim(ctx->device);
+    fmk_dollar_trim(ctx->device);
+    fmk_threshold_trim(ctx->device);
     (void)hipFree(ctx->d_mail);
     (void)hipHostFree(ctx->h_mail);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
+    return FMK_OK;
+}
+
+int fmk_ctx_trim(fmk_ctx *ctx)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    fmk_pool_flush(ctx);
+    fmk_volume_trim(ctx->device);
+    fmk_dollar_trim(ctx->device);
+    fmk_threshold_trim(ctx->device);
     return FMK_OK;
 }
 

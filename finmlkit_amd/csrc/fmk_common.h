@@ -33,6 +33,10 @@ struct fmk_ctx {
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);
 int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out);
+// per-device result / work caches of the threshold indexers (released by fmk_ctx_trim and fmk_ctx_destroy)
+void fmk_volume_trim(int device);
+void fmk_dollar_trim(int device);
+void fmk_threshold_trim(int device);
 
 // fmk_footprint.hip: footprint fill launches for the level classes wider than `lmin_start` (0: all bars)
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,

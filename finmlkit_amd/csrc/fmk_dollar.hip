@@ -304,7 +304,14 @@ struct DlCache {
     int64_t *dbuf;
     int64_t cap;
 };
-static DlCache g_dl = {nullptr, nullptr, nullptr, 0, 0.0, 0, 0, 0, nullptr, 0};
+static DlCache g_dl[16];       // per device
+
+void fmk_dollar_trim(int device)
+{
+    DlCache &c = g_dl[device & 15];
+    if (c.dbuf) (void)hipFree(c.dbuf);
+    c = DlCache();
+}
 
 template <bool AF64>
 static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, double thr, DlCache &c)
@@ -356,7 +363,7 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    DlCache &c = g_dl;
+    DlCache &c = g_dl[ctx->device & 15];
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {

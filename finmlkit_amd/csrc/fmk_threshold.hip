@@ -133,7 +133,15 @@ struct ThCache {
     int64_t cap;
     fmk_ctx *ctx;
 };
-static ThCache g_cache = {nullptr, nullptr, 0, 0.0, -1, 0, 0, 0, nullptr, 0, nullptr};
+static ThCache g_cache[16];    // per device
+
+void fmk_threshold_trim(int device)
+{
+    ThCache &c = g_cache[device & 15];
+    if (c.dbuf) (void)hipFree(c.dbuf);
+    c = ThCache();
+    c.kind = -1;
+}
 
 template <bool DOLLAR>
 static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
@@ -141,7 +149,7 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    ThCache &c = g_cache;
+    ThCache &c = g_cache[ctx->device & 15];
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
                      c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf;
     if (!(hit && d_close_idx)) {

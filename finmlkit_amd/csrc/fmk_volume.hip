@@ -280,7 +280,15 @@ struct VolCache {
     void *work;
     size_t work_bytes;
 };
-static VolCache g_vol = {nullptr, nullptr, 0, 0.0, 0, 0, 0, nullptr, 0, nullptr, 0};
+static VolCache g_vol[16];     // per device: the buffers live in that device's memory
+
+void fmk_volume_trim(int device)
+{
+    VolCache &c = g_vol[device & 15];
+    if (c.dbuf) (void)hipFree(c.dbuf);
+    if (c.work) (void)hipFree(c.work);
+    c = VolCache();
+}
 
 // returns FMK_OK, 1 (=> use the serial fallback) or an error
 template <bool AF64, int S>
@@ -579,7 +587,7 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    VolCache &c = g_vol;
+    VolCache &c = g_vol[ctx->device & 15];
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {

@@ -58,6 +58,9 @@ int fmk_device_count(int *count);
 int fmk_ctx_create(int device, fmk_ctx **out);
 int fmk_ctx_destroy(fmk_ctx *ctx);
 int fmk_ctx_sync(fmk_ctx *ctx);
+/* Release everything the context keeps between calls: scratch, the caching allocator's free blocks, the work
+ * buffers of the threshold indexers (up to ~20 B/tick).  For long-lived processes; never required. */
+int fmk_ctx_trim(fmk_ctx *ctx);
 /* hipStream_t of the context (for interop with other HIP users, e.g. RCCL). */
 void *fmk_ctx_stream(fmk_ctx *ctx);
 /* Text of the last error on this context (ctx == NULL: last context-less error). */

@@ -119,3 +119,24 @@ def test_ohlcv_host_flavour_and_errors(eng, orc):
         comp_bar_ohlcv(px, am[:-1], ci)
     with pytest.raises(ValueError, match="at least two"):
         comp_bar_ohlcv(px, am, ci[:1])
+
+
+def test_context_trim_releases_cached_memory():
+    """fmk_ctx_trim: scratch, allocator free lists and the indexers' work buffers go back to the device."""
+    from finmlkit_amd import _ffi, engine
+    ctx = _ffi.default_context()
+    n = 20_000_000
+    t = engine.DeviceTrades.synth(n, seed=3, ctx=ctx)
+    ci = t.volume_bar_index(500.0)
+    r = t.lagged_returns(5.0, True)
+    del r, ci
+    ctx.trim()
+    free0, total = ctx.mem_info()
+    r = t.lagged_returns(5.0, True)          # 160 MB, cached by the allocator after the del
+    del r
+    ci = t.volume_bar_index(500.0)
+    free1, _ = ctx.mem_info()                # cached blocks count as free; the indexer's work buffers do not
+    ctx.trim()
+    free2, _ = ctx.mem_info()
+    assert free2 >= free1 and free2 >= free0 - (64 << 20)
+    np.testing.assert_array_equal(t.volume_bar_index(500.0).to_host(), ci.to_host())     # still works after a trim
