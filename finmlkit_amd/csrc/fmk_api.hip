@@ -89,9 +89,9 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     fmk_pool_destroy(ctx);
-    fmk_volume_trim(ctx->device);
-    fmk_dollar_trim(ctx->device);
-    fmk_threshold_trim(ctx->device);
+    fmk_volume_trim(ctx);
+    fmk_dollar_trim(ctx);
+    fmk_threshold_trim(ctx);
     (void)hipFree(ctx->d_mail);
     (void)hipHostFree(ctx->h_mail);
     (void)hipEventDestroy(ctx->ev0);
@@ -107,9 +107,9 @@ int fmk_ctx_trim(fmk_ctx *ctx)
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
     fmk_pool_flush(ctx);
-    fmk_volume_trim(ctx->device);
-    fmk_dollar_trim(ctx->device);
-    fmk_threshold_trim(ctx->device);
+    fmk_volume_trim(ctx);
+    fmk_dollar_trim(ctx);
+    fmk_threshold_trim(ctx);
     return FMK_OK;
 }
 

@@ -29,14 +29,16 @@ struct fmk_ctx {
     // stream-ordered caching allocator behind fmk_alloc / fmk_free (fmk_api.hip): freed blocks are kept and handed
     // out again to later requests of (almost) the same size -- no hipMalloc / hipFree / synchronisation per call
     void *pool;
+    // result / work caches of the threshold indexers (fmk_volume / fmk_dollar / fmk_threshold .hip), one per context
+    void *idx_cache[3];
 };
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);
 int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out);
-// per-device result / work caches of the threshold indexers (released by fmk_ctx_trim and fmk_ctx_destroy)
-void fmk_volume_trim(int device);
-void fmk_dollar_trim(int device);
-void fmk_threshold_trim(int device);
+// per-context result / work caches of the threshold indexers (released by fmk_ctx_trim and fmk_ctx_destroy)
+void fmk_volume_trim(fmk_ctx *ctx);
+void fmk_dollar_trim(fmk_ctx *ctx);
+void fmk_threshold_trim(fmk_ctx *ctx);
 
 // fmk_footprint.hip: footprint fill launches for the level classes wider than `lmin_start` (0: all bars)
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,

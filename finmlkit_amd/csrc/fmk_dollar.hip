@@ -304,13 +304,19 @@ struct DlCache {
     int64_t *dbuf;
     int64_t cap;
 };
-static DlCache g_dl[16];       // per device
-
-void fmk_dollar_trim(int device)
+static DlCache &dl_cache(fmk_ctx *ctx)       // one per context (slot 1), created on first use
 {
-    DlCache &c = g_dl[device & 15];
-    if (c.dbuf) (void)hipFree(c.dbuf);
-    c = DlCache();
+    if (!ctx->idx_cache[1]) ctx->idx_cache[1] = new DlCache();
+    return *(DlCache *)ctx->idx_cache[1];
+}
+
+void fmk_dollar_trim(fmk_ctx *ctx)
+{
+    DlCache *c = (DlCache *)ctx->idx_cache[1];
+    if (!c) return;
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    delete c;
+    ctx->idx_cache[1] = nullptr;
 }
 
 template <bool AF64>
@@ -363,7 +369,7 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    DlCache &c = g_dl[ctx->device & 15];
+    DlCache &c = dl_cache(ctx);
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {

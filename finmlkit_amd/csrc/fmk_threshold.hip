@@ -133,14 +133,19 @@ struct ThCache {
     int64_t cap;
     fmk_ctx *ctx;
 };
-static ThCache g_cache[16];    // per device
-
-void fmk_threshold_trim(int device)
+static ThCache &th_cache(fmk_ctx *ctx)       // one per context (slot 2), created on first use
 {
-    ThCache &c = g_cache[device & 15];
-    if (c.dbuf) (void)hipFree(c.dbuf);
-    c = ThCache();
-    c.kind = -1;
+    if (!ctx->idx_cache[2]) { ThCache *c = new ThCache(); c->kind = -1; ctx->idx_cache[2] = c; }
+    return *(ThCache *)ctx->idx_cache[2];
+}
+
+void fmk_threshold_trim(fmk_ctx *ctx)
+{
+    ThCache *c = (ThCache *)ctx->idx_cache[2];
+    if (!c) return;
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    delete c;
+    ctx->idx_cache[2] = nullptr;
 }
 
 template <bool DOLLAR>
@@ -149,7 +154,7 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    ThCache &c = g_cache[ctx->device & 15];
+    ThCache &c = th_cache(ctx);
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
                      c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf;
     if (!(hit && d_close_idx)) {

@@ -280,14 +280,20 @@ struct VolCache {
     void *work;
     size_t work_bytes;
 };
-static VolCache g_vol[16];     // per device: the buffers live in that device's memory
-
-void fmk_volume_trim(int device)
+static VolCache &vol_cache(fmk_ctx *ctx)     // one per context (slot 0), created on first use
 {
-    VolCache &c = g_vol[device & 15];
-    if (c.dbuf) (void)hipFree(c.dbuf);
-    if (c.work) (void)hipFree(c.work);
-    c = VolCache();
+    if (!ctx->idx_cache[0]) ctx->idx_cache[0] = new VolCache();
+    return *(VolCache *)ctx->idx_cache[0];
+}
+
+void fmk_volume_trim(fmk_ctx *ctx)
+{
+    VolCache *c = (VolCache *)ctx->idx_cache[0];
+    if (!c) return;
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    if (c->work) (void)hipFree(c->work);
+    delete c;
+    ctx->idx_cache[0] = nullptr;
 }
 
 // returns FMK_OK, 1 (=> use the serial fallback) or an error
@@ -587,7 +593,7 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    VolCache &c = g_vol[ctx->device & 15];
+    VolCache &c = vol_cache(ctx);
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {
