@@ -13,10 +13,9 @@ INT_DIR = {"ticks_buy", "ticks_sell", "cum_ticks_min", "cum_ticks_max"}
 def _check_dir(got, want, what):
     for k, g, w in zip(G.DIR_KEYS, got, want):
         assert g.dtype == w.dtype, (what, k)
-        if k in INT_DIR:
-            np.testing.assert_array_equal(g, w, err_msg=f"{what}:{k}")
-        else:
-            G.assert_f32_close(g, w, what=f"{what}:{k}")
+        # float32 columns too: bars whose float64 sums sit within rounding noise of a float32 tie are redone in the
+        # reference's tick order on the device, so every output is bit-identical
+        np.testing.assert_array_equal(g, w, err_msg=f"{what}:{k}")
 
 
 @pytest.mark.parametrize("case", ["syn_t60", "syn_t1", "syn_tick100", "syn_vol2048", "rnd_t120", "rnd_tick37"])

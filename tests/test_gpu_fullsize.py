@@ -113,10 +113,7 @@ def test_directional_and_footprints_full_size(big, prefix, orc):
     for key, w in zip(G.DIR_KEYS, want):
         # bar 0 starts at tick 0: its spread terms use the reference's wrap-around tick prices[-1], which is
         # the LAST tick of whatever array is passed (1e9 ticks here, the prefix in the oracle) -> skip bar 0
-        if w.dtype == np.int64:
-            np.testing.assert_array_equal(d[key][1:k], w[1:], err_msg=key)
-        else:
-            G.assert_f32_close(d[key][1:k], w[1:], what=key)
+        np.testing.assert_array_equal(d[key][1:k], w[1:], err_msg=key)          # float32 columns bit-identical too
     oo = orc.comp_bar_ohlcv(px, am, oci[:k + 1], want_median=False)
     woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, oci[:k + 1], sd, 0.01, oo[2], oo[1], 3.0)
     np.testing.assert_array_equal(offh[:k + 1], woff)
