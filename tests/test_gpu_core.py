@@ -53,7 +53,7 @@ def _check_ohlcv(got, want, what):
     np.testing.assert_array_equal(got["trades"], tr, err_msg=what)
     for k, w in (("open", o), ("high", h), ("low", l), ("close", c)):
         np.testing.assert_array_equal(got[k], w, err_msg=f"{what}:{k}")       # selections: bit-exact
-    G.assert_f32_close(got["volume"], vol, what=f"{what}:volume")
+    np.testing.assert_array_equal(got["volume"], vol, err_msg=f"{what}:volume")
     G.assert_f64_close(got["vwap"], vwap, rtol=1e-9, what=f"{what}:vwap")
     np.testing.assert_array_equal(got["median_trade_size"], med, err_msg=f"{what}:median")   # order statistic
 

@@ -50,7 +50,7 @@ def test_quickstart_flow(orc):
     dirf = kit.build_directional_features()
     wd = orc.comp_bar_directional_features(p, a, ci, s)
     np.testing.assert_array_equal(dirf["ticks_buy"].values, wd[0])
-    G.assert_f32_close(dirf["volume_buy"].values, wd[2], what="volume_buy")
+    np.testing.assert_array_equal(dirf["volume_buy"].values, wd[2], err_msg="volume_buy")
     fp = kit.build_footprints(price_tick_size=0.01)
     woff, wflat, wbar = orc.comp_bar_footprints_csr(p, a, ci, s, 0.01, want[2], want[1], 3.0)
     np.testing.assert_array_equal(fp.level_offsets, woff)
