@@ -20,6 +20,7 @@
 // noise of a float32 rounding tie are redone in tick order (k_bar_dir_redo), so the float32 outputs are the
 // reference's bit for bit.
 #include "fmk_footprint.h"
+#include "fmk_f32tie.h"
 
 struct FlowDirOut {
     int64_t *ticks_buy, *ticks_sell;
@@ -139,20 +140,6 @@ __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const doub
     d.prev_side = fmk_uniform((int)sS[last]);
 }
 
-// Is the float64 value s so close to a float32 rounding boundary that a perturbation of `bound` could change
-// (float)s?  (distance of s to the midpoint between the two neighbouring float32 values)
-__device__ __forceinline__ bool bf_near_tie(double s, double bound)
-{
-    const float f = (float)s;
-    const double af = fabs((double)f);
-    if (!(af > 1e-30) || isinf(f)) return false;                 // 0, denormal range, inf, NaN: nothing to flip
-    const int ex = ilogb(af);
-    const double up = ldexp(1.0, ex - 23);                       // float32 spacing above |f|
-    const double down = af == ldexp(1.0, ex) ? 0.5 * up : up;    // ... and below (a power of two sits on a binade edge)
-    const double half = 0.5 * (fabs(s) >= af ? up : down);
-    return half - fabs(fabs(s) - af) <= bound;
-}
-
 // The float32 sums of ONE bar in the reference's tick order (base.py:466-546), for the few bars whose float64 sums
 // land within rounding noise of a float32 tie, where the tree-ordered sums of the wave could round the other way.
 // A sequential float64 sum cannot be re-associated, but its TERMS can be prepared in parallel and the seven sums are
@@ -238,10 +225,10 @@ __device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int 
     // k_bar_dir_redo.  All operands are wave-uniform, so the decision is too.
     const double eps = 4.6e-16 * (double)(e - start + 2);                    // 2 x len x 2^-52, a safe over-estimate
     const double mean = tb + tsell == 0 ? 0.0 : cs / (double)(tb + tsell);
-    const bool tie = bf_near_tie(vb, eps * vb) || bf_near_tie(vs, eps * vs) || bf_near_tie(db, eps * db) ||
-                     bf_near_tie(ds, eps * ds) || bf_near_tie(mean, 2.0 * eps * mean) ||
-                     bf_near_tie(vmin, eps * (vb + vs)) || bf_near_tie(vmax, eps * (vb + vs)) ||
-                     bf_near_tie(dmin, eps * (db + ds)) || bf_near_tie(dmax, eps * (db + ds));
+    const bool tie = fmk_near_f32_tie(vb, eps * vb) || fmk_near_f32_tie(vs, eps * vs) || fmk_near_f32_tie(db, eps * db) ||
+                     fmk_near_f32_tie(ds, eps * ds) || fmk_near_f32_tie(mean, 2.0 * eps * mean) ||
+                     fmk_near_f32_tie(vmin, eps * (vb + vs)) || fmk_near_f32_tie(vmax, eps * (vb + vs)) ||
+                     fmk_near_f32_tie(dmin, eps * (db + ds)) || fmk_near_f32_tie(dmax, eps * (db + ds));
     if (tie && lane == 0) redo[32 + atomicAdd(redo, 1ULL)] = (unsigned long long)b;
     if (lane == 0) {
         o.ticks_buy[b] = tb; o.ticks_sell[b] = tsell;

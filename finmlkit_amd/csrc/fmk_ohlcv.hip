@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "fmk_common.h"
+#include "fmk_f32tie.h"
 #include "fmk_median.h"
 
 #define FMK_SMALL_NCH 21
@@ -38,6 +39,9 @@ struct OhlcvOut {
     double *vwap;
     int64_t *trades;
     double *median;
+    // float64 amounts only (null otherwise; last member so the other kernarg offsets do not move): redo list of the bars
+    // whose volume sum sits within summation-order noise of a float32 rounding boundary (fmk_f32tie.h)
+    unsigned long long *vol_redo;
 };
 
 __device__ __forceinline__ void ohlcv_empty(const OhlcvOut &o, int64_t b, const double *price, int64_t e, int64_t n)
@@ -49,6 +53,7 @@ __device__ __forceinline__ void ohlcv_empty(const OhlcvOut &o, int64_t b, const 
     if (o.median) o.median[b] = 0.0;
 }
 
+template <bool AF64>
 __device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const double *price, int64_t start,
                                              int64_t e, double hi, double lo, double tv, double td, int lane)
 {
@@ -64,6 +69,44 @@ __device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const
         o.vol[b] = (float)tv;
         o.vwap[b] = tv > 0.0 ? td / tv : 0.0;   // base.py:398
         o.trades[b] = e - start + 1;
+        // float32 amounts: 24-bit terms, so the float64 sum of a bar is exact in any order (as long as the amounts of a
+        // bar span less than 2^29 in magnitude) and (float)tv is the reference's value.  float64 amounts: the order
+        // matters in the last bits; bars that close to a float32 tie are redone in tick order by k_bar_vol_redo.
+        if constexpr (AF64) {
+            if (o.vol_redo && fmk_near_f32_tie(tv, fmk_f32tie_eps(e - start + 1) * fabs(tv)))
+                o.vol_redo[32 + atomicAdd(o.vol_redo, 1ULL)] = (unsigned long long)b;
+        }
+    }
+}
+
+// float64 amounts: `volume` of the listed bars as the reference adds it (base.py:377-398: one float64 accumulator in
+// tick order, cast once).  One wave per bar: 64 amounts per coalesced load into an LDS row, lane 0 adds them in order.
+__global__ __launch_bounds__(256) void k_bar_vol_redo(const double *__restrict__ amount, const int64_t *__restrict__ ci,
+                                                      float *__restrict__ vol,
+                                                      const unsigned long long *__restrict__ redo)
+{
+    __shared__ double s_row[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t count = (int64_t)redo[0];
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wib; i < count; i += nwaves) {
+        const int64_t b = fmk_uniform((int64_t)redo[32 + i]);
+        const int64_t start = fmk_uniform(ci[b]) + 1, e = fmk_uniform(ci[b + 1]);
+        double tv = 0.0;
+        double v = start + lane <= e ? amount[start + lane] : 0.0;
+        for (int64_t j0 = start; j0 <= e; j0 += 64) {
+            s_row[wib][lane] = v;                               // lanes past the bar hold 0.0: x + 0.0 == x
+            const int64_t jn = j0 + 64 + lane;
+            v = jn <= e ? amount[jn] : 0.0;                     // next chunk in flight while lane 0 adds
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+#pragma unroll 16
+                for (int k = 0; k < 64; ++k) tv += s_row[wib][k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) vol[b] = (float)tv;
     }
 }
 
@@ -107,7 +150,7 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
             lo = fmin(lo, p0);
             tv += a0; td += p0 * a0;
         }
-        ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
+        ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
     }
 }
 
@@ -156,7 +199,7 @@ __device__ __forceinline__ void small_bar(const double *__restrict__ price, cons
             if constexpr (MEDIAN) bar.key[c] = MK::tokey(araw[c]);
         }
     }
-    ohlcv_finish(o, b, price, start, e, hi, lo, tv, td, lane);
+    ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
     if constexpr (MEDIAN) {
         bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
         const double m = med_search<AF64, NCH, EXACT>(bar, buf);
@@ -221,15 +264,24 @@ static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 
 template <bool AF64>
 static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n,
-                        const OhlcvOut &o, int variant)
+                        const OhlcvOut &o_in, int variant)
 {
+    OhlcvOut o = o_in;
     const unsigned grid = ohlcv_grid(ctx, nb);
+    if (AF64) {   // redo list of near-tie volume sums (fmk_f32tie.h); nothing else here uses the context scratch
+        FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 8, (void **)&o.vol_redo));
+        FMK_HIP(ctx, hipMemsetAsync(o.vol_redo, 0, 8, ctx->stream));
+    }
     const int slot = ctx->profile_on ? (ctx->profile_n++ & 63) : -1;     // time the dominant launch only
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][0], ctx->stream));
     if (variant == 0) {   // generic streaming kernel only (+ stand-alone median)
         k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);
         FMK_LAUNCH_CHECK(ctx);
         if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
+        if (AF64) {
+            k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
+            FMK_LAUNCH_CHECK(ctx);
+        }
         if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, nullptr, o.median);
         return FMK_OK;
     }
@@ -245,6 +297,10 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     // long bars (if any): the generic kernels exit at once when the flag is clear
     k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 64 * FMK_SMALL_NCH, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
+    if (AF64) {
+        k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
+        FMK_LAUNCH_CHECK(ctx);
+    }
     if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 64 * FMK_SMALL_NCH, saw_long, o.median);
     return FMK_OK;
 }
@@ -259,7 +315,7 @@ extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_ohlcv: empty price array");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;
-    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median};
+    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median, nullptr};
     static int variant = -1;   // developer knob: FMK_OHLCV_VARIANT=0 forces the generic kernels
     if (variant < 0) {
         const char *v = getenv("FMK_OHLCV_VARIANT");

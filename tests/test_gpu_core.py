@@ -140,3 +140,47 @@ def test_context_trim_releases_cached_memory():
     free2, _ = ctx.mem_info()
     assert free2 >= free1 and free2 >= free0 - (64 << 20)
     np.testing.assert_array_equal(t.volume_bar_index(500.0).to_host(), ci.to_host())     # still works after a trim
+
+
+def _tie_bars(rng, nb, L, hi):
+    """nb bars of L ticks, amounts = milli-lots * 0.001 as float64, the last tick of every bar chosen so that the exact
+    bar total is an odd multiple of 0.125 inside [2^21, 2^22): exactly half-way between two float32 values."""
+    m = rng.integers(1, hi, size=(nb, L))
+    tot = m[:, :-1].sum(axis=1)
+    target = ((tot + hi // 2) // 250) * 250 + 125
+    m[:, -1] = target - tot
+    total = m.sum(axis=1)
+    assert (m[:, -1] > 0).all() and (total % 250 == 125).all()
+    assert (total >= 2**21 * 1000).all() and (total < 2**22 * 1000).all()
+    return m.reshape(-1).astype(np.float64) * 0.001
+
+
+@pytest.mark.parametrize("kind,nb,L", [("random", 60_000, 2048), ("ties_long", 20_000, 2048), ("ties_small", 20_000, 1024)])
+def test_ohlcv_volume_f64_decimal_lots_exact(orc, kind, nb, L):
+    """float64 amounts on a decimal lot grid (multiples of 0.001): per-bar sums of 2-4 million land on float32 rounding
+    ties (odd multiples of 0.125), where the ORDER of the float64 additions decides the float32 result -- and the
+    reference's sequential order is the less accurate one (it drifts off the tie, a tree sum stays on it).  `volume`
+    must still be the reference's sequential sum (base.py:377-398) bit for bit.  "random": ties by chance (1 bar in
+    60 000 differed before the tick-order redo); "ties_*": every bar total is an exact tie, through the long-bar
+    kernel (2048 ticks) and the small-bar kernel (1024 ticks)."""
+    from finmlkit_amd.bar.base import comp_bar_ohlcv
+    rng = np.random.default_rng(7)
+    if kind == "random":
+        am = rng.integers(1, 2_000_000, size=nb * L).astype(np.float64) * 0.001
+    else:
+        am = _tie_bars(rng, nb, L, 3_000_000 if L == 2048 else 6_000_000)
+    am = np.concatenate([[1.0], am])                         # tick 0 is the open edge of bar 0
+    px = 100.0 + 0.01 * rng.integers(0, 500, size=am.size)
+    ci = L * np.arange(nb + 1, dtype=np.int64)
+    want = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    got = comp_bar_ohlcv(px, am, ci)
+    if kind != "random":            # the input does what it says: a tree-ordered sum rounds the other way on ~half the bars
+        x = am[1:].reshape(nb, L)
+        t = x.reshape(nb, L // 64, 64).sum(axis=1)
+        while t.shape[1] > 1:
+            t = t[:, ::2] + t[:, 1::2]
+        assert (t[:, 0].astype(np.float32) != want[4]).sum() > nb // 4
+    bad = np.nonzero(got[4] != want[4])[0]
+    assert bad.size == 0, f"{bad.size} of {nb} bars differ in float32 volume, first {bad[:5]}: " \
+                          f"{got[4][bad[:5]]} vs {want[4][bad[:5]]}"
+    np.testing.assert_array_equal(got[6], want[6])
