@@ -226,7 +226,12 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t cnt = e - s;
         if (cnt > 64 * FMK_SMALL_NCH) {                      // long bar: left to the generic kernels
-            if (lane == 0) atomicOr(saw_long, 1);
+            // The flag only ever becomes 1: look first (shared reads do not serialise), store if still clear.  An
+            // atomicOr per long bar serialises on the one address (measured: 100 000 long bars -> 1.13 ms in this
+            // otherwise idle kernel, 11 ns each).  No state is kept across bars: a wave-uniform "already raised" bit
+            // made the register allocator park scalars in VGPR lanes throughout the small_bar bodies.
+            if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         if (cnt <= 0) {
