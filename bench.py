@@ -26,10 +26,13 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes per tick / per bar of the dominant kernel from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), measured at N = 1e9,
-# B = 833323 on the default workload: profiles/r01_bench_cfg2_pmc_traffic.csv (1.2102e10 read + 6.82e7 written).
-# Reported per launch, scaled to the run's N/B; null for non-default workloads (not measured).
-PMC_READ_BYTES_PER_TICK = 1.2102e10 / 1e9
-PMC_WRITE_BYTES_PER_BAR = 6.8171e7 / 833323
+# B = 833323 on the default workload: profiles/r01_bench_cfg2_pmc_traffic.csv, pass 2 (1.20997e10 read + 6.8026e7
+# written).  Counters cannot be collected inside a normal run, so roofline.traffic is that OFFLINE measurement of the same
+# kernel scaled to the run's N/B (roofline.traffic_source says so); null for non-default workloads (not measured).
+PMC_READ_BYTES_PER_TICK = 1.20997e10 / 1e9
+PMC_WRITE_BYTES_PER_BAR = 6.8026e7 / 833323
+PMC_SOURCE = ("offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at commit 2d41fbb "
+              "(profiles/r01_bench_cfg2_pmc_traffic.csv), scaled to this run's ticks and bars; not collected in this run")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -270,6 +273,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (PMC_READ_BYTES_PER_TICK * n + PMC_WRITE_BYTES_PER_BAR * nb)
                          if (want_median and args.interval == 60.0) else None,
+                         "traffic_source": PMC_SOURCE if (want_median and args.interval == 60.0) else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
                          "launches_timed": len(k_ms)},
         }
