@@ -203,8 +203,8 @@ def comp_bar_directional_features(prices: NDArray[np.float64], volumes: NDArray,
     v, f64 = _ffi.amount_array(volumes)
     ci = np.ascontiguousarray(bar_close_indices, dtype=np.int64)
     sd = np.ascontiguousarray(trade_sides, dtype=np.int8)
-    if len(ci) < 2:
-        raise ValueError("Bar close indices must contain at least two elements.")
+    # no length check on bar_close_indices in the reference (only comp_bar_ohlcv has one, base.py:334-335): one element
+    # -> zero bars, empty outputs; none -> NumPy's "negative dimensions are not allowed" from the allocation below
     nb = len(ci) - 1
     outs = {k: np.empty(nb, dt) for k, dt in _ffi.DIRECTIONAL_FIELDS}
     st = _ffi.DirectionalOut(**{k: a.ctypes.data for k, a in outs.items()})
@@ -242,16 +242,16 @@ def comp_bar_footprints_csr(prices, amounts, bar_close_indices, trade_sides, pri
     sd = np.ascontiguousarray(trade_sides, dtype=np.int8)
     lo = np.ascontiguousarray(bar_lows, dtype=np.float64)
     hi = np.ascontiguousarray(bar_highs, dtype=np.float64)
-    if len(ci) < 2:
-        raise ValueError("Bar close indices must contain at least two elements.")
+    # like the reference (base.py:615-752): no length check; one element -> zero bars -> empty lists / arrays
+    # (tests/bars/test_comp_bar_footprints.py::test_comp_bar_footprints_empty_bar of the reference)
     nb = len(ci) - 1
+    bar = {k: np.empty(nb, dt) for k, dt in _ffi.FOOTPRINT_BAR_FIELDS}     # nb == -1: NumPy's ValueError
     off = np.empty(nb + 1, np.int64)
     args = (ptr(p), ptr(v), C.c_int(f64), c_i64(len(p)), ptr(ci), c_i64(len(ci)), ptr(sd),
             c_f64(price_tick_size), ptr(lo), ptr(hi), c_f64(imbalance_factor), ptr(off))
     ctx.call("fmk_comp_bar_footprints", *args, None)
     tot = int(off[-1])
     flat = {k: np.empty(tot, dt) for k, dt in _ffi.FOOTPRINT_FLAT_FIELDS}
-    bar = {k: np.empty(nb, dt) for k, dt in _ffi.FOOTPRINT_BAR_FIELDS}
     st = _ffi.FootprintOut(**{k: a.ctypes.data for k, a in {**flat, **bar}.items()})
     ctx.call("fmk_comp_bar_footprints", *args, C.byref(st))
     return off, flat, bar

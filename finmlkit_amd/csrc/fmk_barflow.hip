@@ -337,8 +337,8 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
                                             int64_t n_idx, const int8_t *d_side, const fmk_directional_out *d_out,
                                             int64_t *d_n_zero_div)
 {
-    if (n_idx < 2)
-        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n_idx == 1) return FMK_OK;   // zero bars (base.py:409-546 has no length check, unlike comp_bar_ohlcv)
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_directional: bad arguments");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;

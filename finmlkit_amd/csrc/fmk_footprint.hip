@@ -58,7 +58,15 @@ extern "C" int fmk_comp_bar_footprints_size_dev(fmk_ctx *ctx, const double *d_ba
                                                 int64_t n_bars, double price_tick_size, int64_t *d_level_offsets,
                                                 int64_t *total_levels, int64_t *max_levels)
 {
-    if (n_bars < 1) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n_bars == 0) {   // zero bars (base.py:615-752 has no length check): one offset, no levels
+        FMK_HIP(ctx, hipSetDevice(ctx->device));
+        FMK_HIP(ctx, hipMemsetAsync(d_level_offsets, 0, 8, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (total_levels) *total_levels = 0;
+        if (max_levels) *max_levels = 0;
+        return FMK_OK;
+    }
+    if (n_bars < 0) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long *d_max = (unsigned long long *)ctx->d_mail;
@@ -292,7 +300,8 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
                                                 const int64_t *d_level_offsets, int64_t max_levels,
                                                 const fmk_footprint_out *d_out, int64_t *d_n_bad_level)
 {
-    if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n_idx == 1) return FMK_OK;   // zero bars: nothing to fill
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_footprints: bad arguments");
     if (max_levels > FP_MAX_LEVELS_GLOBAL)
         return fmk_set_error(ctx, FMK_E_CAPACITY,

@@ -127,8 +127,10 @@ int fmk_comp_bar_directional(fmk_ctx *ctx, const double *price, const void *amou
                              const int64_t *close_idx, int64_t n_idx, const int8_t *side,
                              const fmk_directional_out *out)
 {
-    if (n_idx < 2)
-        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    // base.py:409-546 has no length check on bar_close_indices (only comp_bar_ohlcv has, base.py:334-335): one element
+    // means zero bars and empty outputs (the reference's tests use that for comp_bar_footprints)
+    if (n_idx == 1) return FMK_OK;
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     const int64_t nb = n_idx - 1;
     DevBag bag(ctx);
     double *d_p;
@@ -174,8 +176,10 @@ int fmk_comp_bar_footprints(fmk_ctx *ctx, const double *price, const void *amoun
                             const double *bar_lows, const double *bar_highs, double imbalance_factor,
                             int64_t *level_offsets, const fmk_footprint_out *out)
 {
-    if (n_idx < 2)
-        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    // base.py:615-752 has no length check: one element = zero bars = empty outputs
+    // (reference test tests/bars/test_comp_bar_footprints.py::test_comp_bar_footprints_empty_bar)
+    if (n_idx == 1) { if (level_offsets) level_offsets[0] = 0; return FMK_OK; }
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     const int64_t nb = n_idx - 1;
     DevBag bag(ctx);
     double *d_lo, *d_hi;
@@ -243,8 +247,8 @@ int fmk_comp_bar_trade_size(fmk_ctx *ctx, const void *amount, int amount_is_f64,
                             const int64_t *close_idx, int64_t n_idx, double theta_mult, float *mean_size_rel,
                             float *size_95_rel, float *pct_block, float *size_gini)
 {
-    if (n_idx < 2)
-        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n_idx == 1) return FMK_OK;   // base.py:549-612 checks theta's length only: zero bars, empty outputs
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     const int64_t nb = n_idx - 1;
     DevBag bag(ctx);
     void *d_a;

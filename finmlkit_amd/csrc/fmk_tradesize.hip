@@ -44,8 +44,8 @@ __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t st
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__ amount,
                                                         const double *__restrict__ theta,
-                                                        const int64_t *__restrict__ ci, int64_t nb, double theta_mult,
-                                                        float *__restrict__ o_mean, float *__restrict__ o_p95,
+                                                        const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                        double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
                                                         float *__restrict__ o_pct, float *__restrict__ o_gini)
 {
     typedef typename MedKey<AF64>::K K;
@@ -58,8 +58,13 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
     K *buf = sbuf[wib];
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t s = fmk_uniform(ci[b]);
-        const int64_t e = fmk_uniform(ci[b + 1]);
-        const int64_t cnt = e - s;
+        const int64_t e_raw = fmk_uniform(ci[b + 1]);
+        // The reference takes the bar as a SLICE, amounts[start:end + 1] (base.py:590): an end index past the array is
+        // clamped, not an error (its own test_block_volume passes end == len(amounts)).  The empty-bar guard
+        // (start > end, base.py:584) looks at the raw indices; a slice left empty by the clamp gives mean([]) = NaN and
+        // a zero total -> the same all-NaN row.
+        const int64_t e = e_raw < n - 1 ? e_raw : n - 1;
+        const int64_t cnt = e_raw - s > 0 ? e - s : 0;
         const int64_t start = s + 1;
         float mean_rel = NAN, p95_rel = NAN, pct = NAN, gini = NAN;      // base.py:576-579
         const double th = theta[b];
@@ -106,9 +111,8 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
                                            double theta_mult, float *d_mean_size_rel, float *d_size_95_rel,
                                            float *d_pct_block, float *d_size_gini)
 {
-    (void)n;
-    if (n_idx < 2)
-        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n_idx == 1) return FMK_OK;   // zero bars (base.py:549-612 checks theta's length only)
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;
     int64_t blocks = fmk_ceil_div(nb, 4);
@@ -116,11 +120,11 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (amount_is_f64)
-        k_bar_trade_size<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb,
+        k_bar_trade_size<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                           theta_mult, d_mean_size_rel, d_size_95_rel,
                                                                           d_pct_block, d_size_gini);
     else
-        k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb,
+        k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
                                                                            d_pct_block, d_size_gini);
     FMK_LAUNCH_CHECK(ctx);

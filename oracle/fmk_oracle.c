@@ -15,10 +15,23 @@
  * a float32 there) -- the golden fixtures in tests/golden are generated on
  * such inputs; see oracle/gen_golden.py and DESIGN.md "Oracle pinning".
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
- * here against fixtures produced by importing the reference itself
- * (oracle/gen_golden.py) and against the known-answer vectors the
- * reference's own tests hold (re-expressed in tests/test_reference_cases.py).
+ * Parity status: PINNED, two ways.
+ * (1) tests/test_oracle_golden.py checks every function here against fixtures
+ *     produced by importing the reference itself on synthetic inputs
+ *     (oracle/gen_golden.py -> the .npz files under tests/golden).
+ * (2) tests/test_refcalls_oracle.py replays every call the reference's OWN
+ *     tests make to these functions: oracle/record_reference_tests.py runs the
+ *     12 test files of SURVEY.md 8c (112 tests, all passing) against the
+ *     reference with the path's functions wrapped and stores arguments +
+ *     results of the 129 calls (tests/golden/reference_test_calls.npz); 117
+ *     replay here, 12 have no C counterpart (listed with reasons in the test).
+ * Until (2) existed this header claimed a pin against the reference's
+ * known-answer tests that had not been built; building it found two
+ * deviations, both fixed here and in the HIP path: a one-element
+ * bar_close_indices means zero bars for every reducer except comp_bar_ohlcv
+ * (the reference has the length check only there), and
+ * comp_bar_trade_size_features takes bars as slices, so an end index past the
+ * array is clamped (this file used to read past the array instead).
  *
  * Citations are relative to /root/reference/.
  */
@@ -414,7 +427,8 @@ int orc_comp_bar_directional(const double *prices, const void *volumes, int is_f
                              float *cum_volumes_min, float *cum_volumes_max,
                              float *cum_dollars_min, float *cum_dollars_max)
 {
-    if (n_idx < 2) return ORC_E_ARG;
+    if (n_idx == 1) return ORC_OK;                   /* zero bars: base.py:409-546 has no length check */
+    if (n_idx < 1) return ORC_E_ARG;
     const float *vf = (const float *)volumes;
     const double *vd = (const double *)volumes;
     int64_t nb = n_idx - 1;
@@ -472,8 +486,8 @@ int orc_comp_bar_trade_size(const void *amounts, int is_f64, int64_t n, const do
                             float *mean_size_rel, float *size_95_rel, float *pct_block,
                             float *size_gini)
 {
-    (void)n;
-    if (n_idx < 2) return ORC_E_ARG;
+    if (n_idx == 1) return ORC_OK;                   /* zero bars: base.py:549-612 checks theta's length only */
+    if (n_idx < 1) return ORC_E_ARG;
     const float *vf = (const float *)amounts;
     const double *vd = (const double *)amounts;
     int64_t nb = n_idx - 1;
@@ -489,10 +503,14 @@ int orc_comp_bar_trade_size(const void *amounts, int is_f64, int64_t n, const do
     for (int64_t i = 0; i < nb; ++i) {
         mean_size_rel[i] = size_95_rel[i] = pct_block[i] = size_gini[i] = NAN;
         int64_t start = close_idx[i] + 1, end = close_idx[i + 1];
-        if (start > end) continue;
+        if (start > end) continue;                   /* base.py:584, on the raw indices */
         if (theta[i] == 0.0) continue;
         double thr = theta[i] * theta_mult;
+        /* base.py:590 takes a SLICE, amounts[start:end + 1]: an end past the array is clamped (the reference's own
+         * test_block_volume passes end == len(amounts)); a slice left empty gives mean([]) = NaN and total 0 -> NaN row */
+        if (end > n - 1) end = n - 1;
         int64_t cnt = end - start + 1;
+        if (cnt <= 0) continue;
         /* np.mean / .sum over the slice: pairwise in the slice dtype
          * (float32 slices use a float32 pairwise sum, mean divides in
          * float32 -- NumPy semantics of the reference's CI mode). */
@@ -610,7 +628,10 @@ int orc_comp_bar_footprints(const double *prices, const void *amounts, int is_f6
                             int32_t *cot, int16_t *max_run, double *vp_skew, double *vp_gini)
 {
     (void)n;
-    if (n_idx < 2) return ORC_E_ARG;
+    /* base.py:615-752 has no length check on bar_close_indices: one element = zero bars = empty outputs
+     * (pinned by the reference's tests/bars/test_comp_bar_footprints.py::test_comp_bar_footprints_empty_bar) */
+    if (n_idx == 1) { if (level_offsets) level_offsets[0] = 0; return ORC_OK; }
+    if (n_idx < 1) return ORC_E_ARG;
     const float *vf = (const float *)amounts;
     const double *vd = (const double *)amounts;
     int64_t nb = n_idx - 1;

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Record every call the REFERENCE'S OWN tests make to the functions of the hot path as data.
+
+Runs in the build container only (needs /root/reference; the GPU box has neither it nor this script's output path).
+The reference's test files for the path are executed by pytest against the reference itself (pure-Python mode through
+oracle/shim, the semantics of the reference's CI: .github/workflows/ci.yml:36-39), with the path's functions wrapped in
+their defining modules BEFORE collection, so that the test modules' `from finmlkit... import f` bind the wrappers.  Each
+call is stored with deep-copied arguments and its result or exception, tagged with the reference test that made it and
+with whether that test passed -- the recorded answers are therefore values the reference's own assertions accepted.
+
+Nothing of the reference's source is stored: tests/golden/reference_test_calls.npz holds arrays + a JSON manifest
+(function name, encoded arguments / result, citing test id).  tests/test_refcalls_oracle.py replays the calls through
+the oracle (CPU), tests/test_gpu_refcalls.py through the HIP path.
+
+    python oracle/record_reference_tests.py
+"""
+import copy
+import importlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "shim"))
+sys.dont_write_bytecode = True
+
+import numpy as np   # noqa: E402
+import pytest        # noqa: E402
+
+# module -> functions of the path (bar/logic.py, bar/base.py, bar/utils.py, feature/core/{utils,volatility,volume}.py)
+TARGETS = {
+    "finmlkit.bar.logic": ["_time_bar_indexer", "_tick_bar_indexer", "_volume_bar_indexer", "_dollar_bar_indexer",
+                           "_cusum_bar_indexer"],
+    "finmlkit.bar.base": ["comp_bar_ohlcv", "comp_bar_directional_features", "comp_bar_footprints",
+                          "comp_footprint_features", "comp_bar_trade_size_features"],
+    "finmlkit.bar.utils": ["comp_trade_side_vector", "comp_price_tick_size", "merge_split_trades",
+                           "footprint_to_dataframe"],
+    "finmlkit.feature.core.utils": ["comp_lagged_returns"],
+    "finmlkit.feature.core.volatility": ["ewms", "ewmst", "ewmst_mean0", "realized_vol"],
+    "finmlkit.feature.core.volume": ["volume_profile_rolling", "calc_volume_percentage_above_poc"],
+}
+# the reference's test files that pin the path
+TEST_FILES = [
+    "tests/bars/test_time_bar_indexer.py", "tests/bars/test_comp_ohlcv.py",
+    "tests/bars/test_comp_bar_directional_features.py", "tests/bars/test_comp_bar_footprints.py",
+    "tests/bars/test_footprint_features.py", "tests/bars/test_bar_builder_footprints.py",
+    "tests/bars/test_bar_trade_size_features.py", "tests/bars/test_utils.py",
+    "tests/features/test_compute_returns.py", "tests/features/test_realized_volatility.py",
+    "tests/features/test_ewms.py", "tests/features/test_volume_profile_rolling.py",
+]
+
+ARRAYS = {}
+CALLS = []
+STATE = {"test": None, "depth": 0}
+
+
+def enc(v):
+    """value -> JSON-able description; arrays go to ARRAYS"""
+    if v is None or isinstance(v, (bool, str)):
+        return {"t": "py", "v": v}
+    if isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_)):
+        return {"t": "int", "v": int(v), "np": type(v).__name__ if isinstance(v, np.generic) else None}
+    if isinstance(v, (np.bool_,)):
+        return {"t": "py", "v": bool(v)}
+    if isinstance(v, (float, np.floating)):
+        return {"t": "float", "v": repr(float(v)), "np": type(v).__name__ if isinstance(v, np.generic) else None}
+    if isinstance(v, np.ndarray):
+        if v.dtype == object:
+            return {"t": "list", "kind": "objarray", "v": [enc(x) for x in v.tolist()]}
+        key = "a%d" % len(ARRAYS)
+        ARRAYS[key] = np.array(v, copy=True)
+        return {"t": "nd", "k": key}
+    if isinstance(v, tuple):
+        return {"t": "list", "kind": "tuple", "v": [enc(x) for x in v]}
+    if isinstance(v, list):            # includes the shim's numba.typed.List
+        return {"t": "list", "kind": "list", "v": [enc(x) for x in v]}
+    try:
+        import pandas as pd
+        if isinstance(v, pd.Timedelta):
+            return {"t": "timedelta_ns", "v": int(v.value)}
+        if isinstance(v, pd.DataFrame):
+            return {"t": "df", "columns": [str(c) for c in v.columns], "index": enc(index_values(v.index)),
+                    "index_kind": type(v.index).__name__, "index_names": [None if n is None else str(n) for n in v.index.names],
+                    "index_level_kinds": [type(v.index.get_level_values(i)).__name__ for i in range(v.index.nlevels)],
+                    "cols": [enc(v[c].to_numpy()) for c in v.columns]}
+        if isinstance(v, pd.Series):
+            return {"t": "series", "name": None if v.name is None else str(v.name), "index": enc(index_values(v.index)),
+                    "index_kind": type(v.index).__name__, "values": enc(v.to_numpy())}
+        if isinstance(v, pd.Index):
+            return {"t": "list", "kind": "pandas:" + type(v).__name__, "v": [enc(index_values(v))]}
+    except ImportError:
+        pass
+    return {"t": "opaque", "v": type(v).__module__ + "." + type(v).__name__}
+
+
+def index_values(ix):
+    """index -> plain array(s): datetimes as int64 ns, a MultiIndex as one array per level"""
+    import pandas as pd
+    if isinstance(ix, pd.MultiIndex):
+        return [index_values(ix.get_level_values(i)) for i in range(ix.nlevels)]
+    if isinstance(ix, pd.DatetimeIndex):
+        return ix.asi8.copy()
+    a = ix.to_numpy()
+    return a.astype(str) if a.dtype == object else a
+
+
+def wrap_transform(cls, methods=("__call__", "_pd", "_nb")):
+    """record a transform at the transform level: plain constructor attributes, input, which entry was used
+    (reference: feature/base.py:226-260, __call__ routes to _pd / _nb; the reference's tests also call _pd / _nb
+    directly), output.  Outermost entry only; independent of the function-level records."""
+    tstate = {"depth": 0}
+
+    def make(mname, orig):
+        def call(self, x, *a, **kw):
+            if tstate["depth"] > 0:
+                return orig(self, x, *a, **kw)
+            attrs = {k: enc(v) for k, v in vars(self).items() if isinstance(v, (bool, int, float, str, type(None)))}
+            for k in ("requires", "produces"):
+                try:
+                    attrs[k] = enc(list(getattr(self, k)))
+                except Exception:          # noqa: BLE001
+                    pass
+            rec = {"fn": cls.__name__ + "." + mname, "module": cls.__module__, "test": STATE["test"],
+                   "kind": "transform", "attrs": attrs, "args": [enc(copy.deepcopy(x))],
+                   "kwargs": {k: enc(v) for k, v in kw.items()}}
+            tstate["depth"] += 1
+            try:
+                out = orig(self, x, *a, **kw)
+            except Exception as e:         # noqa: BLE001
+                rec["raises"] = {"type": type(e).__name__, "msg": str(e)}
+                CALLS.append(rec)
+                raise
+            finally:
+                tstate["depth"] -= 1
+            rec["result"] = enc(out)
+            CALLS.append(rec)
+            return out
+        call.__name__ = mname
+        return call
+    for mname in methods:
+        if hasattr(cls, mname):
+            setattr(cls, mname, make(mname, getattr(cls, mname)))
+
+
+def wrap(modname, name, fn):
+    def recorder(*args, **kwargs):
+        if STATE["depth"] > 0:                      # a path function calling another one: record the outer call only
+            return fn(*args, **kwargs)
+        rec = {"fn": name, "module": modname, "test": STATE["test"],
+               "args": [enc(copy.deepcopy(a)) for a in args],
+               "kwargs": {k: enc(copy.deepcopy(v)) for k, v in kwargs.items()}}
+        STATE["depth"] += 1
+        try:
+            out = fn(*args, **kwargs)
+        except Exception as e:                       # noqa: BLE001 -- the exception IS the recorded behaviour
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e)}
+            CALLS.append(rec)
+            raise
+        finally:
+            STATE["depth"] -= 1
+        rec["result"] = enc(out)
+        CALLS.append(rec)
+        return out
+    recorder.__name__ = name
+    recorder.__wrapped__ = fn
+    return recorder
+
+
+class Plugin:
+    def __init__(self):
+        self.outcome = {}
+
+    def pytest_runtest_setup(self, item):
+        STATE["test"] = item.nodeid
+
+    def pytest_runtest_logreport(self, report):
+        if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+            self.outcome[report.nodeid] = report.outcome
+
+    def pytest_runtest_teardown(self, item):
+        STATE["test"] = None
+
+
+def main():
+    for modname, names in TARGETS.items():
+        mod = importlib.import_module(modname)
+        for n in names:
+            if not hasattr(mod, n):
+                print("missing in reference:", modname, n)
+                continue
+            orig = getattr(mod, n)
+            w = wrap(modname, n, orig)
+            setattr(mod, n, w)
+            # package __init__ chains import everything up front: modules that did `from x import f` already hold the
+            # original -- rebind those names too
+            for m in list(sys.modules.values()):
+                if m is None or not getattr(m, "__name__", "").startswith("finmlkit"):
+                    continue
+                for attr, val in list(vars(m).items()):
+                    if val is orig:
+                        setattr(m, attr, w)
+    import finmlkit.feature.transforms as T
+    wrap_transform(T.RealizedVolatility)      # three of its four reference tests use backend="pd" only
+    plug = Plugin()
+    os.chdir(REF)
+    rc = pytest.main(["-q", "-p", "no:cacheprovider", "-x" if False else "-q", "--no-header", "--rootdir", REF,
+                      "-o", "addopts=", *TEST_FILES], plugins=[plug])
+    os.chdir(ROOT)
+    for c in CALLS:
+        c["test_outcome"] = plug.outcome.get(c["test"], "unknown")
+        if c["test"]:
+            c["test"] = c["test"].replace(REF + "/", "")
+    manifest = {"generator": "oracle/record_reference_tests.py", "reference_test_files": TEST_FILES,
+                "pytest_exit_code": int(rc), "n_tests": len(plug.outcome),
+                "n_tests_passed": sum(1 for v in plug.outcome.values() if v == "passed"),
+                "tests_not_passed": sorted(k for k, v in plug.outcome.items() if v != "passed"),
+                "calls": CALLS}
+    out = os.path.join(ROOT, "tests", "golden", "reference_test_calls.npz")
+    np.savez_compressed(out, __manifest__=np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8), **ARRAYS)
+    by_fn = {}
+    for c in CALLS:
+        by_fn[c["fn"]] = by_fn.get(c["fn"], 0) + 1
+    print("tests run %d, passed %d; calls recorded %d, arrays %d -> %s (%.1f KiB)" % (
+        manifest["n_tests"], manifest["n_tests_passed"], len(CALLS), len(ARRAYS), out, os.path.getsize(out) / 1024))
+    for k in sorted(by_fn):
+        print("  %-36s %d" % (k, by_fn[k]))
+    print("calls that raise:", sum(1 for c in CALLS if "raises" in c),
+          sorted({c["raises"]["type"] for c in CALLS if "raises" in c}))
+    opaque = [c["fn"] for c in CALLS if '"opaque"' in json.dumps(c)]
+    print("calls with an argument / result the encoder could not store:", len(opaque), sorted(set(opaque)))
+    silent = sorted(t.replace(REF + "/", "") for t in plug.outcome if t not in {c["test"] for c in CALLS}
+                    and t.replace(REF + "/", "") not in {c["test"] for c in CALLS})
+    manifest_silent = silent
+    print("reference tests that made NO recorded call (%d):" % len(silent))
+    for t in silent:
+        print("   ", t)
+    if manifest["tests_not_passed"]:
+        print("not passed under the reference itself:", manifest["tests_not_passed"])
+
+
+if __name__ == "__main__":
+    main()
