@@ -21,10 +21,10 @@
  *     (oracle/gen_golden.py -> the .npz files under tests/golden).
  * (2) tests/test_refcalls_oracle.py replays every call the reference's OWN
  *     tests make to these functions: oracle/record_reference_tests.py runs the
- *     12 test files of SURVEY.md 8c (112 tests, all passing) against the
+ *     14 reference test files that touch the path (116 tests) against the
  *     reference with the path's functions wrapped and stores arguments +
- *     results of the 129 calls (tests/golden/reference_test_calls.npz); 117
- *     replay here, 12 have no C counterpart (listed with reasons in the test).
+ *     results of the 160 calls (tests/golden/reference_test_calls.npz); 130
+ *     replay here, 30 have no C counterpart (listed with reasons in the test).
  * Until (2) existed this header claimed a pin against the reference's
  * known-answer tests that had not been built; building it found two
  * deviations, both fixed here and in the HIP path: a one-element

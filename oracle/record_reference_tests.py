@@ -50,6 +50,9 @@ TEST_FILES = [
     "tests/bars/test_bar_trade_size_features.py", "tests/bars/test_utils.py",
     "tests/features/test_compute_returns.py", "tests/features/test_realized_volatility.py",
     "tests/features/test_ewms.py", "tests/features/test_volume_profile_rolling.py",
+    # TradesData (row f4: the preprocess pipeline) and the five kits' _comp_bar_close; parts of these files need PyTables,
+    # which the image lacks: such tests are listed as not passed with their reason, the calls made before are kept
+    "tests/bars/test_data_model.py", "tests/bars/test_data_model_io_kit.py",
 ]
 
 ARRAYS = {}
@@ -73,6 +76,8 @@ def enc(v):
         key = "a%d" % len(ARRAYS)
         ARRAYS[key] = np.array(v, copy=True)
         return {"t": "nd", "k": key}
+    if isinstance(v, dict):
+        return {"t": "dict", "v": {str(k): enc(x) for k, x in v.items()}}
     if isinstance(v, tuple):
         return {"t": "list", "kind": "tuple", "v": [enc(x) for x in v]}
     if isinstance(v, list):            # includes the shim's numba.typed.List
@@ -145,6 +150,49 @@ def wrap_transform(cls, methods=("__call__", "_pd", "_nb")):
             setattr(cls, mname, make(mname, getattr(cls, mname)))
 
 
+def wrap_objects():
+    """object-level records: TradesData(...) -> its .data frame (or the exception), and <Kit>(trades, ...)._comp_bar_close()
+    -> (close timestamps, close indices), the kit's trades given as the index of the TradesData record it was built on"""
+    import finmlkit.bar.data_model as DM
+    import finmlkit.bar.kit as KIT
+    init = DM.TradesData.__init__
+
+    def td_init(self, *args, **kwargs):
+        rec = {"fn": "TradesData", "module": DM.__name__, "test": STATE["test"], "kind": "tradesdata",
+               "args": [enc(copy.deepcopy(a)) for a in args], "kwargs": {k: enc(copy.deepcopy(v)) for k, v in kwargs.items()}}
+        try:
+            init(self, *args, **kwargs)
+        except Exception as e:                       # noqa: BLE001
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e)}
+            CALLS.append(rec)
+            raise
+        rec["result"] = enc({"data": self.data.copy(), "orig_timestamp_unit": self.orig_timestamp_unit})
+        self._rec_index = len(CALLS)
+        CALLS.append(rec)
+    DM.TradesData.__init__ = td_init
+
+    for cname in ("TimeBarKit", "TickBarKit", "VolumeBarKit", "DollarBarKit", "CUSUMBarKit"):
+        cls = getattr(KIT, cname)
+
+        def patch(cls=cls, cname=cname):
+            kinit, close = cls.__init__, cls._comp_bar_close
+
+            def kit_init(self, trades, *args, **kwargs):
+                self._rec_ctor = {"trades": getattr(trades, "_rec_index", None),
+                                  "args": [enc(copy.deepcopy(a)) for a in args],
+                                  "kwargs": {k: enc(copy.deepcopy(v)) for k, v in kwargs.items()}}
+                kinit(self, trades, *args, **kwargs)
+
+            def kit_close(self):
+                out = close(self)
+                CALLS.append({"fn": cname + "._comp_bar_close", "module": KIT.__name__, "test": STATE["test"],
+                              "kind": "kit", "ctor": getattr(self, "_rec_ctor", None), "args": [], "kwargs": {},
+                              "result": enc(out)})
+                return out
+            cls.__init__, cls._comp_bar_close = kit_init, kit_close
+        patch()
+
+
 def wrap(modname, name, fn):
     def recorder(*args, **kwargs):
         if STATE["depth"] > 0:                      # a path function calling another one: record the outer call only
@@ -172,6 +220,7 @@ def wrap(modname, name, fn):
 class Plugin:
     def __init__(self):
         self.outcome = {}
+        self.reason = {}
 
     def pytest_runtest_setup(self, item):
         STATE["test"] = item.nodeid
@@ -179,6 +228,9 @@ class Plugin:
     def pytest_runtest_logreport(self, report):
         if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
             self.outcome[report.nodeid] = report.outcome
+            if report.outcome != "passed":
+                txt = getattr(report, "longreprtext", "") or ""
+                self.reason[report.nodeid] = (txt.strip().splitlines() or ["?"])[-1][:300]
 
     def pytest_runtest_teardown(self, item):
         STATE["test"] = None
@@ -204,6 +256,7 @@ def main():
                         setattr(m, attr, w)
     import finmlkit.feature.transforms as T
     wrap_transform(T.RealizedVolatility)      # three of its four reference tests use backend="pd" only
+    wrap_objects()
     plug = Plugin()
     os.chdir(REF)
     rc = pytest.main(["-q", "-p", "no:cacheprovider", "-x" if False else "-q", "--no-header", "--rootdir", REF,
@@ -216,7 +269,8 @@ def main():
     manifest = {"generator": "oracle/record_reference_tests.py", "reference_test_files": TEST_FILES,
                 "pytest_exit_code": int(rc), "n_tests": len(plug.outcome),
                 "n_tests_passed": sum(1 for v in plug.outcome.values() if v == "passed"),
-                "tests_not_passed": sorted(k for k, v in plug.outcome.items() if v != "passed"),
+                "tests_not_passed": {k.replace(REF + "/", ""): plug.reason.get(k, "?")
+                                     for k, v in sorted(plug.outcome.items()) if v != "passed"},
                 "calls": CALLS}
     out = os.path.join(ROOT, "tests", "golden", "reference_test_calls.npz")
     np.savez_compressed(out, __manifest__=np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8), **ARRAYS)

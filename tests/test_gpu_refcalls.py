@@ -23,11 +23,20 @@ def _realized_volatility(attrs, frame, kwargs):
 
 
 def test_hip_path_replays_reference_test_calls():
-    from finmlkit_amd.bar import base, logic, utils
+    from finmlkit_amd.bar import base, kit, logic, utils
+    from finmlkit_amd.bar.data_model import TradesData
     from finmlkit_amd.feature.core import utils as futils
     from finmlkit_amd.feature.core import volatility, volume
     table = {
         "_time_bar_indexer": logic._time_bar_indexer,
+        "_tick_bar_indexer": logic._tick_bar_indexer,
+        "_volume_bar_indexer": logic._volume_bar_indexer,
+        "_dollar_bar_indexer": logic._dollar_bar_indexer,
+        "_cusum_bar_indexer": logic._cusum_bar_indexer,
+        "TradesData": TradesData,
+        "TimeBarKit._comp_bar_close": kit.TimeBarKit, "TickBarKit._comp_bar_close": kit.TickBarKit,
+        "VolumeBarKit._comp_bar_close": kit.VolumeBarKit, "DollarBarKit._comp_bar_close": kit.DollarBarKit,
+        "CUSUMBarKit._comp_bar_close": kit.CUSUMBarKit,
         "comp_bar_ohlcv": base.comp_bar_ohlcv,
         "comp_bar_directional_features": base.comp_bar_directional_features,
         "comp_bar_footprints": base.comp_bar_footprints,
@@ -47,4 +56,4 @@ def test_hip_path_replays_reference_test_calls():
         "RealizedVolatility._nb": _realized_volatility,
     }
     done, skipped = R.replay(table, SKIP)
-    assert done == 125 and skipped == {"calc_volume_percentage_above_poc": 4}, (done, skipped)    # of 129 recorded calls
+    assert done == 156 and skipped == {"calc_volume_percentage_above_poc": 4}, (done, skipped)    # of 160 recorded calls

@@ -9,6 +9,10 @@ SKIP = {
     "footprint_to_dataframe": "pandas shaping of the footprint lists, host code of the package (bar/utils.py)",
     "RealizedVolatility._pd": "transform class, package level (feature/transforms.py)",
     "RealizedVolatility._nb": "transform class, package level (feature/transforms.py)",
+    "TradesData": "class-level host logic of the package (bar/data_model.py); its merge / side loops ARE replayed below",
+    "TimeBarKit._comp_bar_close": "kit classes, package level (bar/kit.py); their indexers ARE replayed below",
+    "TickBarKit._comp_bar_close": "kit class", "VolumeBarKit._comp_bar_close": "kit class",
+    "DollarBarKit._comp_bar_close": "kit class", "CUSUMBarKit._comp_bar_close": "kit class",
     "calc_volume_percentage_above_poc": "not a stand-alone function here: evaluated inside orc_volume_profile_rolling "
                                         "with the POC it computes itself; the recorded calls pass an arbitrary POC",
 }
@@ -30,6 +34,10 @@ def _vpr_from_lists(orc):
 def test_oracle_replays_reference_test_calls(orc):
     table = {
         "_time_bar_indexer": orc._time_bar_indexer,
+        "_tick_bar_indexer": orc._tick_bar_indexer,
+        "_volume_bar_indexer": orc._volume_bar_indexer,
+        "_dollar_bar_indexer": orc._dollar_bar_indexer,
+        "_cusum_bar_indexer": orc._cusum_bar_indexer,
         "comp_bar_ohlcv": orc.comp_bar_ohlcv,
         "comp_bar_directional_features": orc.comp_bar_directional_features,
         "comp_bar_footprints": orc.comp_bar_footprints,
@@ -44,6 +52,9 @@ def test_oracle_replays_reference_test_calls(orc):
         "volume_profile_rolling": _vpr_from_lists(orc),
     }
     done, skipped = R.replay(table, SKIP)
-    # 129 recorded calls (from all 112 tests of the 12 reference test files): 117 replayed, 12 documented skips
-    assert done == 117 and skipped == {"footprint_to_dataframe": 1, "RealizedVolatility._pd": 6, "RealizedVolatility._nb": 1,
-                                       "calc_volume_percentage_above_poc": 4}, (done, skipped)
+    # 160 recorded calls (from all 116 tests of the 14 reference test files): 130 replayed, 30 documented skips
+    assert done == 130 and skipped == {"footprint_to_dataframe": 1, "RealizedVolatility._pd": 6, "RealizedVolatility._nb": 1,
+                                       "calc_volume_percentage_above_poc": 4, "TradesData": 13,
+                                       "TimeBarKit._comp_bar_close": 1, "TickBarKit._comp_bar_close": 1,
+                                       "VolumeBarKit._comp_bar_close": 1, "DollarBarKit._comp_bar_close": 1,
+                                       "CUSUMBarKit._comp_bar_close": 1}, (done, skipped)
