@@ -22,6 +22,14 @@ def _time_bar_indexer(timestamps: NDArray[np.int64], interval_seconds: float
     """Reference: finmlkit/bar/logic.py:12-51.  Returns (bar_clock, bar_close_indices)."""
     ctx = _ffi.default_context()
     ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    if interval_seconds < 0:
+        # logic.py:33-39 with a negative step: np.arange(start, last + I + 1, I) is empty whenever the stream spans more
+        # than |I| (edge sweep: the reference returns two empty arrays); anything else is not supported
+        I = interval_seconds * 1e9
+        clock = np.arange(float(ts[0]) // I * I, np.ceil(ts[-1] / I) * I + I + 1, I, dtype=np.int64) if len(ts) else None
+        if clock is not None and len(clock) == 0:
+            return np.empty(0, np.int64), np.empty(0, np.int64)
+        raise ValueError("interval_seconds must be positive")
     ne = c_i64()
     ctx.call("fmk_time_bar_indexer", ptr(ts), c_i64(len(ts)), c_f64(interval_seconds), None, None, c_i64(0),
              C.byref(ne))
@@ -35,6 +43,8 @@ def _time_bar_indexer(timestamps: NDArray[np.int64], interval_seconds: float
 def _tick_bar_indexer(timestamps: NDArray[np.int64], threshold: int) -> NDArray[np.int64]:
     """Reference: finmlkit/bar/logic.py:54-84 (returns an int64 array instead of a numba List)."""
     ctx = _ffi.default_context()
+    if len(timestamps) == 0:                       # logic.py:54-84: the list starts as [0] and the loop does not run
+        return np.zeros(1, np.int64)
     m = c_i64()
     ctx.call("fmk_tick_bar_indexer_dev", c_i64(len(timestamps)), c_i64(int(threshold)), None, c_i64(0),
              C.byref(m))
@@ -90,8 +100,16 @@ def _cusum_bar_indexer(timestamps: NDArray[np.int64], prices: NDArray[np.float64
     import ctypes as C
     ts = np.ascontiguousarray(timestamps, dtype=np.int64)
     px = np.ascontiguousarray(prices, dtype=np.float64)
-    if not (len(px) == len(sigma) == len(ts)) or len(px) == 0:
+    # logic.py:174-175 is the CHAINED comparison len(prices) != len(sigma) != len(timestamps): it raises only when both
+    # inequalities hold; otherwise n = len(prices) and longer sigma / timestamps are read up to n (oracle/edge_sweep.py)
+    if len(px) != len(sigma) and len(sigma) != len(ts):
         raise ValueError("Prices, timestamps, and sigma arrays must have the same length.")
+    if len(px) == 0:
+        return np.zeros(1, np.int64)                # the list starts with first_non_nan_idx = 0, the loop does not run
+    if len(ts) < len(px) or len(sigma) < len(px):   # the reference indexes past the shorter array here
+        raise ValueError("timestamps / sigma shorter than prices")
+    ts = np.ascontiguousarray(ts[:len(px)])
+    sigma = sigma[:len(px)]                         # a view: the forward fill below still lands in the caller's array
     sg = sigma if (isinstance(sigma, np.ndarray) and sigma.dtype == np.float64 and sigma.flags["C_CONTIGUOUS"]
                    and sigma.flags["WRITEABLE"]) else np.array(sigma, dtype=np.float64)
     n = len(px)

@@ -62,10 +62,13 @@ __device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const
     tv = fmk_wave_sum(tv);
     td = fmk_wave_sum(td);
     if (lane == 0) {
-        o.open[b] = price[start];
+        // base.py:371-382 seeds high / low with the bar's first price and updates them with `>` / `<`: NaNs later in the
+        // bar lose every comparison (the fmax / fmin above), but a NaN FIRST price never loses one -> high = low = NaN
+        const double first = price[start];
+        o.open[b] = first;
         o.close[b] = price[e];
-        o.high[b] = hi;
-        o.low[b] = lo;
+        o.high[b] = first != first ? first : hi;
+        o.low[b] = first != first ? first : lo;
         o.vol[b] = (float)tv;
         o.vwap[b] = tv > 0.0 ? td / tv : 0.0;   // base.py:398
         o.trades[b] = e - start + 1;

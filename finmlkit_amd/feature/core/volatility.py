@@ -50,6 +50,8 @@ def realized_vol(r: NDArray[np.float64], window: int, is_sample: bool) -> NDArra
     """Reference: finmlkit/feature/core/volatility.py:256-286 (rolling sqrt(nansum(r^2) / (valid - is_sample)))."""
     ctx = _ffi.default_context()
     rr = np.ascontiguousarray(r, dtype=np.float64)
+    if int(window) == 0:                           # every window is empty: NaN everywhere (nothing to compute)
+        return np.full(len(rr), np.nan)
     out = np.empty(len(rr), np.float64)
     ctx.call("fmk_realized_vol", ptr(rr), c_i64(len(rr)), c_i64(int(window)), C.c_int(bool(is_sample)), ptr(out))
     return out

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Differential edge sweep: degenerate inputs of OUR choosing through the REFERENCE's functions of the hot path, recorded
+in the format of oracle/record_reference_tests.py -> tests/golden/edge_calls.npz, replayed through the oracle
+(tests/test_refcalls_oracle.py) and the HIP path (tests/test_gpu_refcalls.py).
+
+Why: the reference's own tests found two deviations the look-alike goldens had missed, both of the kind
+"this build assumed a validation / an indexing rule the reference does not have".  This sweep asks the reference directly
+about every such assumption: empty and one-element inputs, one-element / repeated / out-of-range bar indices, zero,
+negative and huge thresholds / windows / spans, NaNs, length mismatches.
+
+Build container only (imports /root/reference in its pure-Python CI mode through oracle/shim).  Cases whose behaviour
+exists only in that mode (an IndexError where compiled code would read out of bounds) are kept in the fixture but marked
+`python_mode_only`; the replays skip them and say how many.
+
+    python oracle/edge_sweep.py            # writes the fixture and prints reference-vs-oracle disagreements
+"""
+import copy
+import json
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "shim"))
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+
+import record_reference_tests as REC  # noqa: E402  (same directory: encoder + array store)
+
+f64 = lambda *x: np.array(x, dtype=np.float64)   # noqa: E731
+f32 = lambda *x: np.array(x, dtype=np.float32)   # noqa: E731
+i64 = lambda *x: np.array(x, dtype=np.int64)     # noqa: E731
+i8 = lambda *x: np.array(x, dtype=np.int8)       # noqa: E731
+NAN = float("nan")
+S = 1_000_000_000
+
+
+def cases():
+    """(function, args, kwargs, label)"""
+    ts6 = i64(0, 1 * S, 2 * S, 3 * S, 4 * S, 5 * S)
+    px6 = f64(100.0, 100.5, 100.5, 99.5, 100.0, 101.0)
+    am6 = f64(1.0, 2.0, 0.5, 4.0, 1.5, 3.0)
+    sd6 = i8(1, -1, -1, 1, 1, -1)
+    out = []
+    add = lambda fn, *a, label="", **k: out.append((fn, a, k, label))   # noqa: E731
+    # ---- indexers (bar/logic.py)
+    for iv in (1.0, 2.5, 0.5, 100.0):
+        add("_time_bar_indexer", ts6, iv, label=f"interval {iv}")
+    add("_time_bar_indexer", i64(7 * S), 1.0, label="one tick")
+    add("_time_bar_indexer", i64(), 1.0, label="no ticks")
+    add("_time_bar_indexer", ts6, 0.0, label="interval 0")
+    add("_time_bar_indexer", ts6, -1.0, label="interval < 0")
+    add("_time_bar_indexer", i64(S, S, S), 1.0, label="equal timestamps on an edge")
+    for thr in (1, 2, 6, 7, 0, -1):
+        add("_tick_bar_indexer", ts6, thr, label=f"threshold {thr}")
+    add("_tick_bar_indexer", i64(), 3, label="no ticks")
+    for thr in (1.0, 3.5, 12.0, 100.0, 0.0, -1.0, NAN):
+        add("_volume_bar_indexer", am6, thr, label=f"threshold {thr}")
+    add("_volume_bar_indexer", f64(), 1.0, label="no ticks")
+    add("_volume_bar_indexer", f64(0, 0, 0), 1.0, label="all-zero amounts")
+    add("_volume_bar_indexer", f64(1.0, NAN, 1.0, 1.0), 1.5, label="NaN amount")
+    add("_volume_bar_indexer", f32(1.0, 2.0, 0.5, 4.0), 2.0, label="float32 amounts")
+    for thr in (100.0, 350.0, 1e9, 0.0, -5.0):
+        add("_dollar_bar_indexer", px6, am6, thr, label=f"threshold {thr}")
+    add("_dollar_bar_indexer", f64(), f64(), 1.0, label="no ticks")
+    add("_dollar_bar_indexer", f64(100.0, NAN, 100.0), f64(1, 1, 1), 150.0, label="NaN price")
+    sig = f64(NAN, NAN, 0.001, 0.001, 0.002, 0.001)
+    add("_cusum_bar_indexer", ts6, px6, sig, 5e-4, 2.0, label="NaN prefix in sigma")
+    add("_cusum_bar_indexer", ts6, px6, np.full(6, NAN), 5e-4, 2.0, label="all-NaN sigma")
+    add("_cusum_bar_indexer", ts6, px6, np.full(6, 1e-9), 5e-4, 2.0, label="sigma below the floor")
+    add("_cusum_bar_indexer", ts6, px6, sig[:5], 5e-4, 2.0, label="sigma length mismatch")
+    # logic.py:174 is a CHAINED comparison (len(p) != len(s) != len(t)): it raises only if BOTH inequalities hold
+    add("_cusum_bar_indexer", ts6, px6[:5], np.full(6, 0.001), 5e-4, 2.0, label="prices shorter than sigma = timestamps")
+    add("_cusum_bar_indexer", ts6[:5], px6, np.full(6, 0.001), 5e-4, 2.0, label="timestamps shorter than prices = sigma")
+    add("_cusum_bar_indexer", ts6, px6, np.full(7, 0.001), 5e-4, 2.0, label="sigma longer than prices = timestamps")
+    add("_cusum_bar_indexer", i64(), f64(), f64(), 5e-4, 2.0, label="no ticks")
+    add("_cusum_bar_indexer", ts6[:1], px6[:1], sig[2:3], 5e-4, 2.0, label="one tick")
+    add("_cusum_bar_indexer", ts6, np.full(6, 100.0), np.full(6, 0.001), 5e-4, 2.0, label="flat prices")
+    # ---- per-bar reducers (bar/base.py)
+    CI = {"two bars": i64(-1, 2, 5), "open edge 0": i64(0, 3, 5), "empty bar inside": i64(-1, 2, 2, 5),
+          "one-tick bars": i64(-1, 0, 1, 2), "one element": i64(2), "no elements": i64(), "descending": i64(5, 2)}
+    for lab, ci in CI.items():
+        add("comp_bar_ohlcv", px6, am6, ci, label=lab)
+        add("comp_bar_directional_features", px6, am6, ci, sd6, label=lab)
+        if len(ci) >= 1:
+            add("comp_bar_trade_size_features", am6, np.full(max(len(ci) - 1, 0), 2.0), ci, 1.5, label=lab)
+    add("comp_bar_ohlcv", px6, np.zeros(6), i64(-1, 5), label="zero volume (vwap guard)")
+    add("comp_bar_ohlcv", f64(NAN, 100.0, 101.0, NAN, 99.0, 100.0), am6, i64(-1, 2, 5), label="NaN prices")
+    add("comp_bar_ohlcv", px6, am6.astype(np.float32), i64(-1, 2, 5), label="float32 amounts")
+    add("comp_bar_ohlcv", f64(), f64(), i64(-1, -1), label="no ticks, one empty bar")
+    add("comp_bar_directional_features", px6, am6, i64(-1, 2, 5), np.zeros(6, np.int8), label="no signed tick")
+    add("comp_bar_directional_features", px6, am6, i64(-1, 2, 5), i8(1, 1, 1, 0, 0, 0), label="second bar unsigned")
+    add("comp_bar_directional_features", px6, am6, i64(-1, 2, 2, 5), sd6, label="empty bar inside")
+    add("comp_bar_trade_size_features", am6, f64(2.0), i64(-1, 5), 1.5, label="one bar")
+    add("comp_bar_trade_size_features", am6, f64(2.0, 2.0), i64(-1, 5), 1.5, label="theta length mismatch")
+    add("comp_bar_trade_size_features", am6, f64(0.0, 2.0), i64(-1, 2, 5), 1.5, label="theta 0")
+    add("comp_bar_trade_size_features", np.zeros(6), f64(2.0), i64(-1, 5), 1.5, label="zero total volume")
+    add("comp_bar_trade_size_features", am6, f64(2.0, 2.0), i64(-1, 2, 9), 1.5, label="end past the array")
+    add("comp_bar_trade_size_features", am6, f64(2.0, 2.0), i64(-1, 7, 9), 1.5, label="start past the array")
+    add("comp_bar_trade_size_features", am6, f64(2.0), i64(3, 3), 1.5, label="empty bar")
+    add("comp_bar_trade_size_features", am6.astype(np.float32), f64(2.0, 2.0), i64(-1, 2, 5), 1.5, label="float32")
+    lo, hi = f64(100.0, 99.5), f64(100.5, 101.0)
+    for lab, kw in {"tick 0.5": dict(t=0.5, f=1.5), "tick 0.25": dict(t=0.25, f=3.0), "factor 0": dict(t=0.5, f=0.0)}.items():
+        add("comp_bar_footprints", px6, am6, i64(-1, 2, 5), sd6, kw["t"], lo, hi, kw["f"], label=lab)
+    add("comp_bar_footprints", px6, am6, i64(-1, 2, 2, 5), sd6, 0.5, f64(100.0, 100.5, 99.5), f64(100.5, 100.5, 101.0),
+        1.5, label="empty bar inside")
+    add("comp_bar_footprints", px6, am6, i64(-1, 5), sd6, 0.5, f64(100.0), f64(100.5), 1.5, label="highs below the prices")
+    add("comp_bar_footprints", px6, am6, i64(-1, 5), np.zeros(6, np.int8), 0.5, f64(99.5), f64(101.0), 1.5,
+        label="no signed tick")
+    for lab, (lv, b, s) in {"one level": ([100], [1.0], [2.0]), "all-zero volumes": ([1, 2, 3], [0, 0, 0], [0, 0, 0]),
+                            "buy only": ([1, 2, 3], [1, 5, 1], [0, 0, 0]), "ties for the POC": ([1, 2, 3], [2, 2, 2], [1, 1, 1]),
+                            "no levels": ([], [], [])}.items():
+        add("comp_footprint_features", np.array(lv, np.int32), np.array(b, np.float32), np.array(s, np.float32), 1.5, label=lab)
+    # ---- preprocessing (bar/utils.py)
+    add("comp_trade_side_vector", f64(), label="no ticks")
+    add("comp_trade_side_vector", f64(100.0), label="one tick")
+    add("comp_trade_side_vector", f64(100, 100, 100), label="flat")
+    add("comp_trade_side_vector", f64(100, 101, 101, 100, 100, NAN, 101), label="NaN inside")
+    add("comp_price_tick_size", f64(100.0), label="one price")
+    add("comp_price_tick_size", f64(100.0, 100.0, 100.0), label="identical prices")
+    add("comp_price_tick_size", f64(100.0, NAN, 100.5), label="NaN inside")
+    add("comp_price_tick_size", f64(0.00012, 0.00013, 0.00015), label="tiny prices")
+    bm = np.array([True, True, False, False])
+    add("merge_split_trades", i64(), f64(), f32(), np.array([], bool), label="no ticks")
+    add("merge_split_trades", i64(5), f64(1.0), f32(1.0), np.array([True]), label="one tick")
+    add("merge_split_trades", i64(1, 1, 1, 1), f64(1, 1, 2, 2), f32(1, 2, 3, 4), bm, label="one timestamp, two prices")
+    add("merge_split_trades", i64(1, 1, 1, 1), f64(1, 1, 1, 1), f32(1, 2, 3, 4), bm, label="side flips inside a group")
+    # ---- tick-level features (feature/core)
+    cl = f64(100, 101, 102, 101, 100, 99)
+    for w in (1, 2, 5, 6, 1000, 0.5):
+        add("comp_lagged_returns", ts6, cl, w, False, label=f"window {w}")
+    add("comp_lagged_returns", ts6, cl, -1, False, label="window < 0")
+    add("comp_lagged_returns", ts6, f64(100, 0, -1, 101, NAN, 99), 1, True, label="log of 0, < 0 and NaN")
+    add("comp_lagged_returns", i64(), f64(), 1, False, label="no ticks")
+    add("comp_lagged_returns", i64(3), f64(1.0), 1, False, label="one tick")
+    add("comp_lagged_returns", i64(1, 1, 1, 2), f64(1, 2, 3, 4), 1, False, label="equal timestamps")
+    y = f64(0.01, -0.02, NAN, 0.015, 0.0, -0.01)
+    for span in (1, 2, 10, 0, -3):
+        add("ewms", y, span, label=f"span {span}")
+    add("ewms", f64(), 5, label="no values")
+    add("ewms", np.full(4, NAN), 5, label="all NaN")
+    for hl in (1.0, 0.5, 1e-9, 0.0, -1.0, 1e12):
+        add("ewmst", ts6, y, hl, label=f"half life {hl}")
+        add("ewmst_mean0", ts6, y, hl, label=f"half life {hl}")
+    add("ewmst", i64(1, 1, 1, 2, 2, 3) * S, y, 1.0, label="equal timestamps")
+    add("ewmst", i64(), f64(), 1.0, label="no values")
+    add("ewmst", i64(S), f64(0.01), 1.0, label="one value")
+    for w in (1, 2, 3, 6, 7, 0, -1):
+        for smp in (True, False):
+            add("realized_vol", f64(0.01, -0.02, 0.005, 0.015, 0.0, -0.01), w, smp, label=f"window {w} sample {smp}")
+    add("realized_vol", y, 3, True, label="NaN inside")
+    add("realized_vol", f64(), 3, True, label="no values")
+    return out
+
+
+OOB = "pure-Python IndexError where compiled code reads out of bounds (undefined for a Numba user)"
+NOT_COMPARABLE = {
+    ("_time_bar_indexer", "no ticks"): OOB, ("_volume_bar_indexer", "no ticks"): OOB, ("_dollar_bar_indexer", "no ticks"): OOB,
+    ("_cusum_bar_indexer", "timestamps shorter than prices = sigma"): OOB,
+    ("comp_bar_ohlcv", "descending"): OOB, ("comp_bar_ohlcv", "no ticks, one empty bar"): OOB,
+    ("comp_trade_side_vector", "no ticks"): OOB, ("merge_split_trades", "no ticks"): OOB,
+    ("comp_lagged_returns", "no ticks"): OOB,
+    ("comp_bar_trade_size_features", "start past the array"):
+        "IndexError raised inside np.percentile for an empty slice (NumPy, pure-Python mode); this build: the NaN row",
+    ("comp_bar_directional_features", "second bar unsigned"):
+        "typed vs pure-Python semantics: np.float64 / 0 gives inf in Python mode; Numba's default error model raises "
+        "ZeroDivisionError for any bar without a signed tick, which is what this build does (not verifiable here: no Numba)",
+    ("comp_price_tick_size", "NaN inside"): "result comes from casting NaN to int64 and overflowing np.diff: garbage",
+    ("realized_vol", "window -1 sample True"): "artefact of negative indexing",
+    ("realized_vol", "window -1 sample False"): "artefact of negative indexing",
+}
+
+
+def main():
+    import importlib
+    mods = ["finmlkit.bar.logic", "finmlkit.bar.base", "finmlkit.bar.utils", "finmlkit.feature.core.utils",
+            "finmlkit.feature.core.volatility", "finmlkit.feature.core.volume"]
+    where = {}
+    for m in mods:
+        mod = importlib.import_module(m)
+        for n in dir(mod):
+            where.setdefault(n, (m, getattr(mod, n)))
+    calls = []
+    warnings.simplefilter("ignore")
+    np.seterr(all="ignore")
+    for fn, args, kwargs, label in cases():
+        modname, f = where[fn]
+        rec = {"fn": fn, "module": modname, "test": "oracle/edge_sweep.py::" + label, "label": label,
+               "args": [REC.enc(copy.deepcopy(a)) for a in args],
+               "kwargs": {k: REC.enc(copy.deepcopy(v)) for k, v in kwargs.items()}}
+        try:
+            rec["result"] = REC.enc(f(*copy.deepcopy(args), **copy.deepcopy(kwargs)))
+        except Exception as e:   # noqa: BLE001 -- the exception is the behaviour being recorded
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e)}
+        if (fn, label) in NOT_COMPARABLE:
+            rec["skip_reason"] = NOT_COMPARABLE[(fn, label)]
+        calls.append(rec)
+    assert {(c["fn"], c["label"]) for c in calls} >= set(NOT_COMPARABLE), "stale NOT_COMPARABLE entry"
+    # ---- compare with the oracle right here (informational; the tests are the gate)
+    from oracle import oracle as orc
+    from tests import _refcalls as R
+    table = {n: getattr(orc, n) for n in {c["fn"] for c in calls} if hasattr(orc, n)}
+    d = REC.ARRAYS
+    print("%-32s %-34s %-44s %s" % ("function", "case", "reference", "oracle"))
+    n_diff = 0
+    for c in calls:
+        args = [R.dec(a, d) for a in c["args"]]
+        kwargs = {k: R.dec(v, d) for k, v in c["kwargs"].items()}
+        ref = ("raises %s: %s" % (c["raises"]["type"], c["raises"]["msg"][:60])) if "raises" in c else "ok"
+        try:
+            got = table[c["fn"]](*args, **kwargs)
+            if "raises" in c:
+                mine = "returns"
+            else:
+                try:
+                    R.compare(c["fn"], got, R.dec(c["result"], d), "x")
+                    mine = "same"
+                except AssertionError as e:
+                    mine = "DIFFERENT: " + " ".join(str(e).split())[:90]
+        except Exception as e:   # noqa: BLE001
+            mine = "raises %s: %s" % (type(e).__name__, str(e)[:60])
+            if "raises" in c and c["raises"]["type"] == type(e).__name__ and c["raises"]["msg"] == str(e):
+                mine = "same"
+        if "raises" in c and mine.startswith("raises " + c["raises"]["type"] + ":"):
+            mine = "same"                                       # same exception type; message text is not a contract here
+        c["oracle_agrees"] = mine == "same"
+        if mine != "same" and "skip_reason" not in c:
+            n_diff += 1
+            print("%-32s %-34s %-44s %s" % (c["fn"], c["label"][:34], ref[:44], mine))
+    print("%d cases, %d marked not comparable, %d OTHER cases where the oracle differs from the reference" % (
+        len(calls), sum(1 for c in calls if "skip_reason" in c), n_diff))
+    manifest = {"generator": "oracle/edge_sweep.py", "tests_not_passed": {}, "n_tests": len(calls),
+                "n_tests_passed": len(calls), "calls": calls}
+    out = os.path.join(ROOT, "tests", "golden", "edge_calls.npz")
+    np.savez_compressed(out, __manifest__=np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8), **REC.ARRAYS)
+    print("->", out, "%.1f KiB" % (os.path.getsize(out) / 1024))
+
+
+if __name__ == "__main__":
+    main()

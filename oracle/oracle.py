@@ -96,6 +96,14 @@ def time_bar_clock(ts_first: int, ts_last: int, interval_seconds: float):
 
 def _time_bar_indexer(timestamps, interval_seconds):
     ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+    if interval_seconds < 0:
+        # logic.py:33-39 with a negative step: np.arange(start, last + I + 1, I) is empty whenever the stream spans more
+        # than |I| (edge sweep: the reference returns two empty arrays); anything else is not supported
+        I = interval_seconds * 1e9
+        clock = np.arange(float(ts[0]) // I * I, np.ceil(ts[-1] / I) * I + I + 1, I, dtype=np.int64) if len(ts) else None
+        if clock is not None and len(clock) == 0:
+            return np.empty(0, np.int64), np.empty(0, np.int64)
+        raise ValueError("interval_seconds must be positive")
     ne = C.c_int64()
     _check(lib().orc_time_bar_indexer(_p(ts), _i64(len(ts)), _f64(interval_seconds), None, None,
                                       _i64(0), C.byref(ne)))
@@ -117,6 +125,8 @@ def _two_phase(fn, *args):
 
 
 def _tick_bar_indexer(timestamps, threshold):
+    if len(timestamps) == 0:                       # logic.py:54-84: the list starts as [0] and the loop does not run
+        return np.zeros(1, np.int64)
     return _two_phase(lib().orc_tick_bar_indexer, _i64(len(timestamps)), _i64(threshold))
 
 
@@ -135,6 +145,17 @@ def _dollar_bar_indexer(prices, volumes, threshold):
 def _cusum_bar_indexer(timestamps, prices, sigma, sigma_floor, sigma_mult, return_sigma=False):
     ts = np.ascontiguousarray(timestamps, dtype=np.int64)
     p = np.ascontiguousarray(prices, dtype=np.float64)
+    # logic.py:174-175 is the CHAINED comparison len(prices) != len(sigma) != len(timestamps): it raises only when both
+    # inequalities hold; otherwise n = len(prices) and longer sigma / timestamps are read up to n (edge sweep)
+    if len(p) != len(sigma) and len(sigma) != len(ts):
+        raise ValueError("Prices, timestamps, and sigma arrays must have the same length.")
+    n = len(p)
+    if n == 0:
+        return (np.zeros(1, np.int64), np.array(sigma, dtype=np.float64)) if return_sigma else np.zeros(1, np.int64)
+    if len(ts) < n or len(sigma) < n:              # the reference indexes past the shorter array here
+        raise ValueError("timestamps / sigma shorter than prices")
+    ts = ts[:n]
+    sigma = np.asarray(sigma)[:n]
     s1 = np.array(sigma, dtype=np.float64)
     m = lib().orc_cusum_bar_indexer(_p(ts), _p(p), _p(s1), _i64(len(p)), _f64(sigma_floor),
                                     _f64(sigma_mult), None, _i64(0))
@@ -293,6 +314,8 @@ def ewms(y, span):
 
 def realized_vol(r, window, is_sample):
     rr = np.ascontiguousarray(r, dtype=np.float64)
+    if window == 0:                                # volatility.py:256-286: every window is empty -> NaN everywhere
+        return np.full(len(rr), np.nan)
     out = np.empty(len(rr), np.float64)
     _check(lib().orc_realized_vol(_p(rr), _i64(len(rr)), _i64(window), C.c_int(bool(is_sample)), _p(out)))
     return out

@@ -13,10 +13,12 @@ import numpy as np
 from tests import _golden as G
 
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_test_calls.npz")
+# degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py), same format
+EDGE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edge_calls.npz")
 
 
-def load():
-    d = np.load(PATH, allow_pickle=False)
+def load(path=PATH):
+    d = np.load(path, allow_pickle=False)
     return json.loads(bytes(d["__manifest__"]).decode()), d
 
 
@@ -81,6 +83,7 @@ POLICY = {
     "footprint_to_dataframe": "exact",
     "comp_lagged_returns": ("rtol", 1e-12),
     "ewms": ("rtol", 1e-9),
+    "ewmst": ("rtol", 1e-9), "ewmst_mean0": ("rtol", 1e-9),
     "realized_vol": ("rtol", 1e-9),
     "volume_profile_rolling": "exact",
     "_tick_bar_indexer": "exact", "_volume_bar_indexer": "exact", "_dollar_bar_indexer": "exact",
@@ -167,9 +170,11 @@ def compare(fn, got, want, what):
         rec(got, want, at(None), what)
 
 
-def replay(table, skip):
-    """-> (n_replayed, n_skipped_by_fn).  Asserts on the first mismatch, naming the citing reference test."""
-    man, d = load()
+def replay(table, skip, path=PATH, match_message=True):
+    """-> (n_replayed, n_skipped_by_fn).  Asserts on the first mismatch, naming the citing reference test.
+    Records carrying a `skip_reason` (edge sweep: behaviour that exists only in the reference's pure-Python mode, or is
+    garbage) are counted under "not comparable"."""
+    man, d = load(path)
     # the recorded answers come from tests that passed under the reference itself -- except tests that need PyTables
     # (absent from the image): those stop with pandas' ImportError in their HDF5 part; the calls they made before are kept
     assert all("ImportError" in why for why in man["tests_not_passed"].values()), man["tests_not_passed"]
@@ -177,6 +182,9 @@ def replay(table, skip):
     done, skipped = 0, {}
     for i, c in enumerate(man["calls"]):
         fn = c["fn"]
+        if "skip_reason" in c:
+            skipped["not comparable"] = skipped.get("not comparable", 0) + 1
+            continue
         if fn in skip:
             skipped[fn] = skipped.get(fn, 0) + 1
             continue
@@ -208,7 +216,8 @@ def replay(table, skip):
             try:
                 run()
             except exc as e:
-                assert str(e) == c["raises"]["msg"], f"{what}: message {str(e)!r} vs {c['raises']['msg']!r}"
+                if match_message:
+                    assert str(e) == c["raises"]["msg"], f"{what}: message {str(e)!r} vs {c['raises']['msg']!r}"
             else:
                 raise AssertionError(f"{what}: expected {c['raises']['type']}({c['raises']['msg']!r})")
         else:

@@ -75,6 +75,11 @@ def test_cusum_rounds_and_kit(orc):
     o = orc.comp_bar_ohlcv(px, am, want)
     np.testing.assert_array_equal(df["close"].values, o[3])
     np.testing.assert_array_equal(kit.get_sigma(), sigma[want[1:]])
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    # logic.py:174 is the chained comparison len(prices) != len(sigma) != len(timestamps): it raises only when BOTH
+    # inequalities hold (oracle/edge_sweep.py asked the reference) ...
     with pytest.raises(ValueError, match="same length"):
-        from finmlkit_amd.bar.logic import _cusum_bar_indexer
-        _cusum_bar_indexer(ts, px[:-1], sigma, 5e-4, 2.0)
+        _cusum_bar_indexer(ts, px, sigma[:-1].copy(), 5e-4, 2.0)
+    # ... and with prices shorter than sigma = timestamps it works on the first len(prices) ticks
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px[:-1], sigma.copy(), 5e-4, 2.0),
+                                  orc._cusum_bar_indexer(ts[:-1], px[:-1], sigma[:-1].copy(), 5e-4, 2.0))

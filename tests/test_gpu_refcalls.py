@@ -22,7 +22,7 @@ def _realized_volatility(attrs, frame, kwargs):
     return rv(frame)
 
 
-def test_hip_path_replays_reference_test_calls():
+def _table():
     from finmlkit_amd.bar import base, kit, logic, utils
     from finmlkit_amd.bar.data_model import TradesData
     from finmlkit_amd.feature.core import utils as futils
@@ -54,6 +54,18 @@ def test_hip_path_replays_reference_test_calls():
         # (HIP) backend here, the pandas recordings at the reference's own pd-vs-compiled tolerance (rtol 1e-10)
         "RealizedVolatility._pd": _realized_volatility,
         "RealizedVolatility._nb": _realized_volatility,
+        "ewmst": volatility.ewmst, "ewmst_mean0": volatility.ewmst_mean0,
     }
-    done, skipped = R.replay(table, SKIP)
+    return table
+
+
+def test_hip_path_replays_reference_test_calls():
+    done, skipped = R.replay(_table(), SKIP)
     assert done == 156 and skipped == {"calc_volume_percentage_above_poc": 4}, (done, skipped)    # of 160 recorded calls
+
+
+def test_hip_path_replays_edge_sweep():
+    """Degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py -> edge_calls.npz), replayed
+    through the package: results under the contract of DESIGN.md 5, exceptions by type."""
+    done, skipped = R.replay(_table(), SKIP, path=R.EDGE_PATH, match_message=False)
+    assert done == 137 and skipped == {"not comparable": 14}, (done, skipped)

@@ -113,8 +113,9 @@ def test_realized_vol_errors_and_transform(orc):
     import pandas as pd
     from finmlkit_amd.feature.core.volatility import realized_vol
     from finmlkit_amd.feature.transforms import RealizedVolatility
-    with pytest.raises(ValueError):
-        realized_vol(np.zeros(10), 0, True)
+    assert np.isnan(realized_vol(np.zeros(10), 0, True)).all()     # window 0: every window is empty (the reference: all NaN)
+    with pytest.raises(ValueError):                                # negative: the reference returns negative-index artefacts
+        realized_vol(np.zeros(10), -1, True)
     n = 20_000
     ts, px, am, sd = orc.synth(5, 0, n)
     r = np.diff(np.log(px), prepend=np.nan)

@@ -31,8 +31,8 @@ def _vpr_from_lists(orc):
     return call
 
 
-def test_oracle_replays_reference_test_calls(orc):
-    table = {
+def _table(orc):
+    return {
         "_time_bar_indexer": orc._time_bar_indexer,
         "_tick_bar_indexer": orc._tick_bar_indexer,
         "_volume_bar_indexer": orc._volume_bar_indexer,
@@ -50,11 +50,24 @@ def test_oracle_replays_reference_test_calls(orc):
         "ewms": orc.ewms,
         "realized_vol": orc.realized_vol,
         "volume_profile_rolling": _vpr_from_lists(orc),
+        "ewmst": orc.ewmst, "ewmst_mean0": orc.ewmst_mean0,
     }
-    done, skipped = R.replay(table, SKIP)
+
+
+def test_oracle_replays_reference_test_calls(orc):
+    done, skipped = R.replay(_table(orc), SKIP)
     # 160 recorded calls (from all 116 tests of the 14 reference test files): 130 replayed, 30 documented skips
     assert done == 130 and skipped == {"footprint_to_dataframe": 1, "RealizedVolatility._pd": 6, "RealizedVolatility._nb": 1,
                                        "calc_volume_percentage_above_poc": 4, "TradesData": 13,
                                        "TimeBarKit._comp_bar_close": 1, "TickBarKit._comp_bar_close": 1,
                                        "VolumeBarKit._comp_bar_close": 1, "DollarBarKit._comp_bar_close": 1,
                                        "CUSUMBarKit._comp_bar_close": 1}, (done, skipped)
+
+
+def test_oracle_replays_edge_sweep(orc):
+    """Degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py -> edge_calls.npz): empty and
+    one-element inputs, one-element / repeated bar indices, zero / negative / huge thresholds, windows, spans and half
+    lives, NaNs, length mismatches.  Exceptions are compared by type (NumPy-internal message texts are not a contract);
+    14 cases exist only in the reference's pure-Python mode or are garbage, and carry their reason in the fixture."""
+    done, skipped = R.replay(_table(orc), SKIP, path=R.EDGE_PATH, match_message=False)
+    assert done == 137 and skipped == {"not comparable": 14}, (done, skipped)
