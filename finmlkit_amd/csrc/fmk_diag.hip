@@ -42,3 +42,54 @@ extern "C" int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t b
     *elapsed_ms = (double)ms;
     return FMK_OK;
 }
+
+// Two columns read in lock-step (tools/placement.py): does the allocation-dependent step time of the bar reducers come
+// from the memory system seeing TWO concurrent streams (8 B and 4 B per element at the same index, two allocations), and
+// does the one-wave-per-bar walk (a wave streams `seg` contiguous elements, then jumps by the number of waves) matter?
+//   pattern 0: flat grid-stride over both columns      1: segment walk over both      2: segment walk over `a` only
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k_diag_read2(const uint2 *__restrict__ a, const unsigned *__restrict__ b, int64_t n,
+                                                    int seg, unsigned long long *sink)
+{
+    unsigned acc = 0;
+    if (PATTERN == 0) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const uint2 v = a[i];
+            acc ^= v.x ^ v.y ^ b[i];
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+        const int64_t nseg = n / seg;
+        for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+            const int64_t base = s * seg;
+            for (int j = lane; j < seg; j += 64) {
+                const uint2 v = a[base + j];
+                acc ^= v.x ^ v.y;
+                if (PATTERN == 1) acc ^= b[base + j];
+            }
+        }
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);
+}
+
+extern "C" int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
+                                         int blocks_per_cu, double *elapsed_ms)
+{
+    if (n <= 0 || seg <= 0 || pattern < 0 || pattern > 2) return fmk_set_error(ctx, FMK_E_ARG, "diag: bad arguments");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned blocks = (unsigned)(ctx->n_cu * (blocks_per_cu > 0 ? blocks_per_cu : 8));
+    unsigned long long *sink = (unsigned long long *)(ctx->d_mail + 60);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (pattern == 0) k_diag_read2<0><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
+    else if (pattern == 1) k_diag_read2<1><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
+    else k_diag_read2<2><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}

@@ -298,6 +298,11 @@ int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int
  * variant 0: 16 B loads per lane, 1: 8 B loads per lane.  Not used by any product path. */
 int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
                             double *elapsed_ms);
+/* Two columns read in lock-step (tools/placement.py): 8 B elements of d_a8 and 4 B elements of d_b4 at the same index.
+ * pattern 0: flat grid-stride; 1: each wave streams `seg` contiguous elements of both, then jumps by the number of waves
+ * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only.  Not used by any product path. */
+int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
+                              int blocks_per_cu, double *elapsed_ms);
 
 #ifdef __cplusplus
 }
