@@ -245,7 +245,8 @@ int fmk_ewmst_shard_apply_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d
 int fmk_ewms_dev(fmk_ctx *ctx, const double *d_y, int64_t n, int64_t span, double *d_out);
 int fmk_ewms(fmk_ctx *ctx, const double *y, int64_t n, int64_t span, double *out);
 /* realized_vol (core/volatility.py:256-286): rolling sqrt(nansum(r^2)/(valid - is_sample)) over `window`
- * elements; NaN where fewer than 2 valid returns or before the first full window.  FMK_E_ARG: window < 1. */
+ * elements; NaN where fewer than 2 valid returns or before the first full window.  FMK_E_ARG: window < 1 (the host
+ * layer answers window == 0 itself: all NaN, like the reference; negative windows stay rejected). */
 int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, int64_t window, int is_sample,
                          double *d_out);
 int fmk_realized_vol(fmk_ctx *ctx, const double *r, int64_t n, int64_t window, int is_sample, double *out);

@@ -15,7 +15,7 @@
  * a float32 there) -- the golden fixtures in tests/golden are generated on
  * such inputs; see oracle/gen_golden.py and DESIGN.md "Oracle pinning".
  *
- * Parity status: PINNED, two ways.
+ * Parity status: PINNED, three ways.
  * (1) tests/test_oracle_golden.py checks every function here against fixtures
  *     produced by importing the reference itself on synthetic inputs
  *     (oracle/gen_golden.py -> the .npz files under tests/golden).
@@ -25,6 +25,9 @@
  *     reference with the path's functions wrapped and stores arguments +
  *     results of the 160 calls (tests/golden/reference_test_calls.npz); 130
  *     replay here, 30 have no C counterpart (listed with reasons in the test).
+ * (3) tests/test_refcalls_oracle.py also replays oracle/edge_sweep.py's 151
+ *     degenerate inputs put to the reference (tests/golden/edge_calls.npz):
+ *     137 comparable, 14 marked with the reason they are not.
  * Until (2) existed this header claimed a pin against the reference's
  * known-answer tests that had not been built; building it found two
  * deviations, both fixed here and in the HIP path: a one-element
