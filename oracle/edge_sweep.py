@@ -170,9 +170,62 @@ NOT_COMPARABLE = {
         "typed vs pure-Python semantics: np.float64 / 0 gives inf in Python mode; Numba's default error model raises "
         "ZeroDivisionError for any bar without a signed tick, which is what this build does (not verifiable here: no Numba)",
     ("comp_price_tick_size", "NaN inside"): "result comes from casting NaN to int64 and overflowing np.diff: garbage",
+    ("TradesData", "no trades, preprocess"): OOB + " -- inside merge_split_trades, as in its function-level case",
     ("realized_vol", "window -1 sample True"): "artefact of negative indexing",
     ("realized_vol", "window -1 sample False"): "artefact of negative indexing",
 }
+
+
+def builtin_base(e):
+    """nearest builtin exception class (NumPy raises private subclasses, e.g. UFuncTypeError(TypeError))"""
+    import builtins
+    return next(c.__name__ for c in type(e).__mro__ if hasattr(builtins, c.__name__))
+
+
+def tradesdata_cases():
+    """(args, kwargs, label) for TradesData(...) (bar/data_model.py:120-190): unit inference and conversion, proc_res
+    rounding, sorting, split-trade merging, side inference / given sides, dtypes, degenerate sizes"""
+    base_ms = 1_700_000_000_000
+    ts_ms = np.array([base_ms + d for d in (0, 0, 0, 5, 5, 1200, 1200, 3000)], dtype=np.int64)
+    px = np.array([100.0, 100.0, 100.5, 100.5, 100.5, 100.0, 99.5, 99.5])
+    qty = np.array([1.0, 2.0, 0.5, 4.0, 1.5, 3.0, 0.25, 2.0])
+    ids = np.arange(8, dtype=np.int64)
+    bm = np.array([True, True, False, False, False, True, True, False])
+    out = []
+    add = lambda *a, label, **k: out.append((a, k, label))   # noqa: E731
+    for unit, mul in (("s", None), ("ms", 1), ("us", 1000), ("ns", 1_000_000)):
+        ts = (ts_ms // 1000) if mul is None else ts_ms * mul
+        add(ts, px, qty, ids, preprocess=True, label=f"inferred unit {unit}, preprocess")
+        add(ts, px, qty, ids, timestamp_unit=unit, preprocess=True, label=f"explicit unit {unit}, preprocess")
+        add(ts, px, qty, ids, label=f"inferred unit {unit}, raw")
+    for res in ("ms", "s", "us", "ns", "min"):
+        add(ts_ms * 1000 + np.arange(8) * 7, px, qty, ids, preprocess=True, proc_res=res, label=f"us stamps, proc_res {res}")
+    add(ts_ms, px, qty, ids, preprocess=True, proc_res="ms", label="proc_res equal to the unit")
+    perm = np.array([3, 0, 7, 1, 5, 2, 6, 4])
+    add(ts_ms[perm], px[perm], qty[perm], ids[perm], preprocess=True, label="unsorted input")
+    add(ts_ms, px, qty, ids, is_buyer_maker=bm, preprocess=True, label="is_buyer_maker given")
+    add(ts_ms, px, qty, ids, side=np.where(bm, -1, 1).astype(np.int8), preprocess=True, label="side given")
+    add(ts_ms, px, qty, ids, is_buyer_maker=bm, side=np.where(bm, -1, 1).astype(np.int8), preprocess=True,
+        label="side and is_buyer_maker given")
+    add(ts_ms, px, qty.astype(np.float32), ids, preprocess=True, label="float32 amounts")
+    add(ts_ms, px.astype(np.float32), qty, ids, preprocess=True, label="float32 prices")
+    add(ts_ms.astype(np.float64), px, qty, ids, preprocess=True, label="float64 timestamps")
+    add(ts_ms, px, qty, preprocess=True, label="preprocess without ids")
+    add(ts_ms, px, qty, label="raw, no ids")
+    add(ts_ms[:1], px[:1], qty[:1], ids[:1], preprocess=True, label="one trade")
+    add(ts_ms[:0], px[:0], qty[:0], ids[:0], preprocess=True, label="no trades, preprocess")
+    add(ts_ms[:0], px[:0], qty[:0], ids[:0], label="no trades, raw")
+    add(ts_ms, px[:7], qty, ids, label="price array shorter")
+    add(np.full(8, base_ms), np.full(8, 100.0), qty, ids, preprocess=True, label="one timestamp, one price")
+    add(np.full(8, base_ms), px, qty, ids, preprocess=True, label="one timestamp, several prices")
+    add(ts_ms, np.full(8, 100.0), qty, ids, preprocess=True, label="flat prices (side inference)")
+    add(ts_ms, px, qty, ids, preprocess=True, name="XBT", label="name given")
+    import pandas as pd
+    add(ts_ms, px, qty, ids, dt_index=pd.date_range("2024-01-01", periods=8, freq="s"), label="dt_index given, raw")
+    add(np.array([5, 6, 7], dtype=np.int64), px[:3], qty[:3], ids[:3], label="tiny timestamps (unit inference fails?)")
+    add(ts_ms, px, qty, ids, timestamp_unit="h", preprocess=True, label="unsupported unit")
+    add(ts_ms, px, qty, ids, preprocess=True, proc_res="fortnight", label="unsupported proc_res")
+    return out
 
 
 def main():
@@ -195,11 +248,27 @@ def main():
         try:
             rec["result"] = REC.enc(f(*copy.deepcopy(args), **copy.deepcopy(kwargs)))
         except Exception as e:   # noqa: BLE001 -- the exception is the behaviour being recorded
-            rec["raises"] = {"type": type(e).__name__, "msg": str(e)}
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
         if (fn, label) in NOT_COMPARABLE:
             rec["skip_reason"] = NOT_COMPARABLE[(fn, label)]
         calls.append(rec)
-    assert {(c["fn"], c["label"]) for c in calls} >= set(NOT_COMPARABLE), "stale NOT_COMPARABLE entry"
+    assert {(c["fn"], c["label"]) for c in calls} >= {k for k in NOT_COMPARABLE if k[0] != "TradesData"}, "stale entry"
+    import finmlkit.bar.data_model as DM
+    for args, kwargs, label in tradesdata_cases():
+        rec = {"fn": "TradesData", "module": DM.__name__, "test": "oracle/edge_sweep.py::" + label, "label": label,
+               "kind": "tradesdata", "args": [REC.enc(copy.deepcopy(a)) for a in args],
+               "kwargs": {k: REC.enc(copy.deepcopy(v)) for k, v in kwargs.items()}}
+        try:
+            td = DM.TradesData(*copy.deepcopy(args), **copy.deepcopy(kwargs))
+            rec["result"] = REC.enc({"data": td.data.copy(), "orig_timestamp_unit": td.orig_timestamp_unit})
+        except Exception as e:   # noqa: BLE001
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
+        if ("TradesData", label) in NOT_COMPARABLE:
+            rec["skip_reason"] = NOT_COMPARABLE[("TradesData", label)]
+        calls.append(rec)
+    n_td = sum(1 for c in calls if c.get("kind") == "tradesdata")
+    print("TradesData cases: %d (%d raise: %s)" % (n_td, sum(1 for c in calls if c.get("kind") == "tradesdata" and "raises" in c),
+          sorted({c["raises"]["type"] + ": " + c["raises"]["msg"][:50] for c in calls if c.get("kind") == "tradesdata" and "raises" in c})))
     # ---- compare with the oracle right here (informational; the tests are the gate)
     from oracle import oracle as orc
     from tests import _refcalls as R
@@ -208,6 +277,8 @@ def main():
     print("%-32s %-34s %-44s %s" % ("function", "case", "reference", "oracle"))
     n_diff = 0
     for c in calls:
+        if c.get("kind") == "tradesdata":              # class-level host logic: the package replays it on the GPU box
+            continue
         args = [R.dec(a, d) for a in c["args"]]
         kwargs = {k: R.dec(v, d) for k, v in c["kwargs"].items()}
         ref = ("raises %s: %s" % (c["raises"]["type"], c["raises"]["msg"][:60])) if "raises" in c else "ok"

@@ -34,6 +34,10 @@ def dec(e, d):
         return np.array(d[e["k"]])
     if t == "list":
         v = [dec(x, d) for x in e["v"]]
+        if e["kind"].startswith("pandas:"):            # an Index argument: datetimes were stored as int64 ns
+            import pandas as pd
+            return pd.DatetimeIndex(np.asarray(v[0], dtype="datetime64[ns]")) if e["kind"] == "pandas:DatetimeIndex" \
+                else pd.Index(v[0])
         return tuple(v) if e["kind"] == "tuple" else v
     if t == "dict":
         return {k: dec(x, d) for k, x in e["v"].items()}
@@ -212,7 +216,7 @@ def replay(table, skip, path=PATH, match_message=True):
             run = lambda: call(*args, **kwargs)                            # noqa: E731
         if "raises" in c:
             import builtins
-            exc = getattr(builtins, c["raises"]["type"])
+            exc = getattr(builtins, c["raises"]["type"], None) or getattr(builtins, c["raises"]["base"])
             try:
                 run()
             except exc as e:

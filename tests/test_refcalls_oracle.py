@@ -70,4 +70,4 @@ def test_oracle_replays_edge_sweep(orc):
     lives, NaNs, length mismatches.  Exceptions are compared by type (NumPy-internal message texts are not a contract);
     14 cases exist only in the reference's pure-Python mode or are garbage, and carry their reason in the fixture."""
     done, skipped = R.replay(_table(orc), SKIP, path=R.EDGE_PATH, match_message=False)
-    assert done == 137 and skipped == {"not comparable": 14}, (done, skipped)
+    assert done == 137 and skipped == {"not comparable": 15, "TradesData": 38}, (done, skipped)    # of 190 calls
