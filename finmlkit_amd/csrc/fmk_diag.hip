@@ -93,3 +93,46 @@ extern "C" int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const v
     *elapsed_ms = (double)ms;
     return FMK_OK;
 }
+
+// Dependent-access latency seen by ONE wave (tools/hoplat.py): hop h reads `loads` coalesced 512 B rows starting at
+// element pos of an 8-byte array, then moves pos by `stride` elements plus a value-dependent 0 (so the next address
+// depends on the data).  Reports shader cycles per hop.  What the volume chain walk pays per close.
+__global__ __launch_bounds__(64) void k_diag_hops(const double *__restrict__ buf, int64_t n, int64_t stride, int loads, int hops,
+                                                  long long *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    int64_t pos = 0;
+    double acc = 0.0;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int h = 0; h < hops; ++h) {
+        double v = 0.0;
+        for (int k = 0; k < loads; ++k) v += buf[pos + k * 64 + lane];
+        // lane 0's value decides the next position: always + stride for this data (zeros), but the hardware cannot know
+        const double first = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)((unsigned long long)__double_as_longlong(v) >> 32)) << 32));
+        acc += v;
+        pos += stride + (first > 1e300 ? 1 : 0);
+        if (pos + loads * 64 >= n) pos = 0;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { out[0] = t1 - t0; out[1] = (long long)acc; }
+}
+
+extern "C" int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t stride, int loads, int hops,
+                                    double *cycles_per_hop, double *elapsed_ms)
+{
+    if (n <= 0 || stride <= 0 || loads < 1 || loads > 16 || hops < 1) return fmk_set_error(ctx, FMK_E_ARG, "diag: bad arguments");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    long long *d_out = (long long *)(ctx->d_mail + 56);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    k_diag_hops<<<1, 64, 0, ctx->stream>>>((const double *)d_buf, n, stride, loads, hops, d_out);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[8], d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *cycles_per_hop = (double)ctx->h_mail[8] / hops;
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}
+

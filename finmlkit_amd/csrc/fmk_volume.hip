@@ -389,14 +389,18 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
 // ---------------------------------------------------------------------------------------
 // Long bars (> 4096 ticks): the jump tables cannot span them, but long bars are FEW (<= N/4096), so the chain is simply
 // walked -- with the whole wave searching for each next close:
-//   k_vc_prefix : block-local inclusive prefix sums Lp[j] (2048-tick blocks, float64) + block totals
-//   k_vc_scan   : exclusive scan of the block totals in double-double -> Bb[0..nblk]
-//   k_vc_chase  : ONE wave; per close: 64 block ends at a time (Bb) locate the block of the crossing, 64 probes 32
-//                 ticks apart locate the 32-tick range, 32 probes the tick: ~4 dependent loads per close instead of one
-//                 per tick.  sum(c+1..m) = (Bb[blk(m)] - Bb[blk(c)]) + (Lp[m] - Lp[c]).
+//   k_vc_prefix   : inclusive prefix sums Lp[j] inside 512-tick blocks (float64) + block totals, one wave per block
+//   k_vc_wgtotals, k_vc_scan, k_vc_expand : exclusive double-double scan of the block totals -> Bb[0..nblk]
+//                   (serial scan over N/2048 workgroup totals, expanded to the N/512 blocks in parallel)
+//   k_vc_chase    : ONE wave; per close: 64 block totals (requested one close ahead) locate the block of the crossing,
+//                   8 coalesced loads of that block's 512 prefixes locate the tick.  sum(c+1..m) = (Bb[blk(m)] -
+//                   Bb[blk(c)]) + (Lp[m] - Lp[c]).  ~1.6 us per close; the cost model behind the design is measured
+//                   (tools/hoplat.py: a dependent load instruction of a lone wave costs 600-770 cycles, and several in a
+//                   row do not overlap) -- see the kernel's comment.  Build with -DVC_TIMING for cycles per phase.
 // Decisions within (1e-11 + 2^-52 * bar length) * thr of the threshold are counted as uncertified, as in the tables.
 // ---------------------------------------------------------------------------------------
-#define VC_BLOCK 2048
+#define VC_BLOCK 512                    // ticks per prefix block: 64 lanes x 8 consecutive ticks resolve a crossing in ONE round
+#define VC_WG_TICKS 2048                // ticks per workgroup of k_vc_prefix (4 waves x 64 lanes x 8): one block per wave
 struct VcDD { double hi, lo; };
 __device__ __forceinline__ VcDD vc_two_sum(double a, double b) { double s = a + b, bb = s - a; return VcDD{s, (a - (s - bb)) + (b - bb)}; }
 __device__ __forceinline__ VcDD vc_add(VcDD x, VcDD y)
@@ -412,32 +416,31 @@ __device__ __forceinline__ double vc_diff(VcDD a, VcDD b)      // a - b rounded 
     return d.hi + (d.lo + (a.lo - b.lo));
 }
 
+// one wave per 512-tick block: lane l owns ticks 8l .. 8l+7 of the block; Lp = inclusive prefix inside the block
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_vc_prefix(const void *__restrict__ amount, int64_t n, double *__restrict__ Lp,
                                                    double *__restrict__ totals)
 {
-    __shared__ double wtot[4];
-    const int64_t bs = (int64_t)blockIdx.x * VC_BLOCK;
-    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    const int64_t blk = (int64_t)blockIdx.x * (VC_WG_TICKS / VC_BLOCK) + w;
+    const int64_t bs = blk * VC_BLOCK;
+    if (bs >= n) return;
     double loc[8], run = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int64_t j = bs + (int64_t)tid * 8 + k;
+        const int64_t j = bs + (int64_t)lane * 8 + k;
         run += j < n ? fmk_amt<AF64>(amount, j) : 0.0;
         loc[k] = run;
     }
     const double inc = fmk_wave_iscan(run);
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
     double pre = __shfl_up(inc, 1, 64);
     if (lane == 0) pre = 0.0;
-    for (int q = 0; q < w; ++q) pre += wtot[q];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int64_t j = bs + (int64_t)tid * 8 + k;
+        const int64_t j = bs + (int64_t)lane * 8 + k;
         if (j < n) Lp[j] = pre + loc[k];
     }
-    if (tid == 255) totals[blockIdx.x] = pre + loc[7];
+    if (lane == 63) totals[blk] = pre + loc[7];
 }
 
 // Bb[k] = sum of totals[0..k) in double-double, k = 0..m (one block, 8 records per thread and round)
@@ -479,69 +482,208 @@ __global__ __launch_bounds__(256) void k_vc_scan(const double *__restrict__ tota
     if (threadIdx.x == 0) Bb[m] = run_s;
 }
 
+// Bb[4w + i] = BW[w] + sum of the first i block totals of workgroup w (double-double): the serial scan runs over the
+// N/2048 workgroup totals only, this expands it to the N/512 prefix blocks in parallel
+__global__ __launch_bounds__(256) void k_vc_expand(const double *__restrict__ totals, const VcDD *__restrict__ BW, int64_t nwg,
+                                                   int64_t nblk, VcDD *__restrict__ Bb)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nwg) return;
+    if (w == nwg) { Bb[nblk] = BW[nwg]; return; }
+    VcDD run = BW[w];
+    constexpr int R = VC_WG_TICKS / VC_BLOCK;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int64_t b = w * R + i;
+        if (b < nblk) { Bb[b] = run; run = vc_add(run, VcDD{totals[b], 0.0}); }
+    }
+}
+
+// workgroup totals from the block totals (4 per workgroup)
+__global__ __launch_bounds__(256) void k_vc_wgtotals(const double *__restrict__ totals, int64_t nblk, int64_t nwg,
+                                                     double *__restrict__ wg)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwg) return;
+    constexpr int R = VC_WG_TICKS / VC_BLOCK;
+    double t = 0.0;                       // <= 2048 amounts: the same float64 sum the 2048-tick version formed per workgroup
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (w * R + i < nblk) t += totals[w * R + i];
+    wg[w] = t;
+}
+
+// value of lane `src` (wave-uniform index) for all lanes: v_readlane, no LDS round trip (__shfl compiles to ds_bpermute)
+__device__ __forceinline__ double vc_lane(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
                                                  int64_t nblk, double thr, int64_t *__restrict__ closes, int64_t cap,
                                                  int64_t *__restrict__ result /* [0] count, [1] uncertified */)
 {
+    // One wave, bound by its own dependent instruction chain, not by memory (measured with a cycle counter per phase at
+    // 5000-tick bars: ~3900 cycles per close whether the crossing was located by 64 + 32 scattered probes, by 8 loads of 8
+    // consecutive ticks per lane, or by 8 coalesced loads, cold or warmed by a helper wave; the ISA showed why: every
+    // __shfl with a run-time lane is two ds_bpermute + wait, ~100 cycles each for a lone wave).  Hence:
+    //   * all broadcasts use v_readlane: their source lanes come from ballots and are wave-uniform;
+    //   * the in-block round is 8 COALESCED loads (instruction k: lane l reads tick 64k + l of the block); prefix sums do
+    //     not decrease (v >= 0), so the crossing is the first (k, lane) in that order;
+    //   * the block totals for the NEXT close are requested as soon as this close's block is known (their addresses only
+    //     need bstar), so that round overlaps the in-block round;
+    //   * values the wave already holds are carried, never re-loaded or recomputed from sums (Lp[c], Bb[blk(c)],
+    //     Bb[bstar], Lp[close - 1]): every comparison sees the operands a plain re-load would see.
     const int lane = fmk_lane();
     int64_t c = -1, cnt = 0, unc = 0;
     if (cap > 0 && lane == 0) closes[0] = 0;
     cnt = 1;                                                       // the opening entry (logic.py:104)
+    int64_t bc = 0;
+    VcDD Bc = Bb[0];
+    double Lc = 0.0;
+    bool long_bars = false;
+    // window of block totals starting at block `wb`: lane l holds Bb[wb + l + 1]
+    int64_t wb = 0;
+    VcDD win = (wb + lane < nblk) ? Bb[wb + lane + 1] : VcDD{0.0, 0.0};
+#ifdef VC_TIMING
+    long long tA = 0, tB = 0, tC = 0, t0 = 0, t1 = 0, iters = 0;
+#define VC_T(x) x = __builtin_readcyclecounter()
+#else
+#define VC_T(x)
+#endif
     for (;;) {
-        const double Lc = c >= 0 ? Lp[c] : 0.0;
-        const int64_t bc = c >= 0 ? c / VC_BLOCK : 0;
-        const VcDD Bc = Bb[bc];
-        // ---- block of the crossing: first b >= bc with sum(c+1 .. end of b) >= thr
+        VC_T(t0);
+        // ---- block of the crossing: first b >= bc with sum(c+1 .. end of b) >= thr.  `win` covers [wb, wb + 64), wb == bc
         int64_t bstar = -1;
-        for (int64_t b0 = bc; b0 < nblk && bstar < 0; b0 += 64) {
+        VcDD Bs = Bc, Bfirst = Bc;                                 // Bfirst = Bb[b0]
+        int64_t bfrom = bc;
+        if (long_bars) {
+            // bars of more than 64 blocks: one gather 64 blocks apart finds the group of 64 that holds the crossing
+            // (one load instruction per 4096 blocks instead of one per 64)
+            for (;;) {
+                int64_t pb = bfrom + 64 * (int64_t)(lane + 1);     // group l ends before block pb
+                if (pb > nblk) pb = nblk;
+                const VcDD x = Bb[pb];
+                const uint64_t mg = __ballot(vc_diff(x, Bc) - Lc >= thr);
+                if (mg) {
+                    const int fg = __ffsll((unsigned long long)mg) - 1;
+                    if (fg > 0) {
+                        Bfirst = VcDD{vc_lane(x.hi, fg - 1), vc_lane(x.lo, fg - 1)};       // Bb[bfrom + 64 * fg]
+                        bfrom += 64 * (int64_t)fg;
+                    }
+                    break;
+                }
+                if (bfrom + 64 * 64 >= nblk) { bfrom = nblk; break; }                       // nothing left crosses
+                Bfirst = VcDD{vc_lane(x.hi, 63), vc_lane(x.lo, 63)};
+                bfrom += 64 * 64;
+            }
+        }
+        for (int64_t b0 = bfrom; b0 < nblk && bstar < 0; b0 += 64) {
             const int64_t b = b0 + lane;
-            bool hit = false;
-            if (b < nblk) hit = vc_diff(Bb[b + 1], Bc) - Lc >= thr;
+            VcDD nb = win;
+            if (b0 != wb) nb = (b < nblk) ? Bb[b + 1] : VcDD{0.0, 0.0};
+            const bool hit = b < nblk && vc_diff(nb, Bc) - Lc >= thr;
             const uint64_t m = __ballot(hit);
-            if (m) bstar = b0 + (__ffsll((unsigned long long)m) - 1);
+            if (m) {
+                const int f0 = __ffsll((unsigned long long)m) - 1;
+                bstar = b0 + f0;
+                const int src = f0 > 0 ? f0 - 1 : 0;
+                const VcDD prev = VcDD{vc_lane(nb.hi, src), vc_lane(nb.lo, src)};
+                Bs = f0 > 0 ? prev : Bfirst;                       // Bb[bstar]
+            } else {
+                Bfirst = VcDD{vc_lane(nb.hi, 63), vc_lane(nb.lo, 63)};            // Bb[b0 + 64]
+            }
         }
         if (bstar < 0) break;                                      // the remaining ticks do not fill a bar
-        const VcDD Bs = Bb[bstar];
+        // request the next close's window now: it starts at bstar whatever tick of the block closes
+        wb = bstar;
+        win = (wb + lane < nblk) ? Bb[wb + lane + 1] : VcDD{0.0, 0.0};
+#ifdef VC_TIMING
+        VC_T(t1); tA += t1 - t0; t0 = t1; ++iters;
+#endif
         const double off = vc_diff(Bs, Bc) - Lc;                   // sum(c+1 .. m) = off + Lp[m] for m in block bstar
-        const int64_t lo = bstar == bc ? (c + 1 > 1 ? c + 1 : 1) : bstar * VC_BLOCK;      // tick 0 cannot close
-        const int64_t hi = (bstar + 1) * VC_BLOCK - 1 < n - 1 ? (bstar + 1) * VC_BLOCK - 1 : n - 1;
-        // ---- 64 probes, 32 ticks apart
-        int64_t pr = lo + 31 + (int64_t)lane * 32;
-        if (pr > hi) pr = hi;
-        const uint64_t m1 = __ballot(off + Lp[pr] >= thr);
-        const int f = m1 ? __ffsll((unsigned long long)m1) - 1 : 63;   // the block end qualifies (lane 63 probes it)
-        const int64_t top = __shfl(pr, f, 64);
-        int64_t q = top - 31 + lane;
-        if (q < lo) q = lo;
-        const bool in = lane < 32;
-        const double sq = off + Lp[q];
-        const uint64_t m2 = __ballot(in && sq >= thr);
-        const int g = m2 ? __ffsll((unsigned long long)m2) - 1 : 31;   // lane 31 probes `top`
-        const int64_t mclose = __shfl(q, g, 64);
-        const double s_at = __shfl(sq, g, 64);
+        const int64_t bstart = bstar * VC_BLOCK;
+        const int64_t lo = bstar == bc ? (c + 1 > 1 ? c + 1 : 1) : bstart;                  // tick 0 cannot close
+        const int64_t hi = bstart + VC_BLOCK - 1 < n - 1 ? bstart + VC_BLOCK - 1 : n - 1;
+        // ---- ONE round inside the block, 8 coalesced loads
+        double lv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t j = bstart + k * 64 + lane;
+            lv[k] = j <= hi ? Lp[j] : 0.0;
+        }
+        // first (k, lane) whose prefix crosses: 8 ballots, all scalar work
+        int kk = -1, g = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t j = bstart + k * 64 + lane;
+            const uint64_t mk = __ballot(j >= lo && j <= hi && off + lv[k] >= thr);
+            if (kk < 0 && mk) { kk = k; g = __ffsll((unsigned long long)mk) - 1; }
+        }
+        int64_t mclose;
+        if (kk < 0) {
+            // the block was chosen because its END crosses (double-double test); plain doubles may round it just below
+            mclose = hi;
+            kk = (int)((hi - bstart) >> 6);
+            g = (int)((hi - bstart) & 63);
+        } else {
+            mclose = bstart + (int64_t)kk * 64 + g;
+        }
+        // Lp[mclose] and Lp[mclose - 1]: lane g (or g - 1) of load kk, or lane 63 of load kk - 1 -- kk is wave-uniform
+        double cur = lv[0], prv = 0.0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k == kk) { cur = lv[k]; prv = lv[k - 1]; }
+        const double l_at = vc_lane(cur, g);
+        const double l_before = g > 0 ? vc_lane(cur, g - 1) : vc_lane(prv, 63);
+        const double s_at = off + l_at;
+#ifdef VC_TIMING
+        VC_T(t1); tB += t1 - t0; t0 = t1;
+#endif
         // ---- certification
         const double tol = (1e-11 + 2.3e-16 * (double)(mclose - c)) * thr;
         const double over = s_at - thr;
         double under = INFINITY;
-        if (mclose - 1 >= lo) under = thr - (off + Lp[mclose - 1]);
+        if (mclose - 1 >= lo) under = thr - (off + l_before);       // mclose - 1 >= lo >= block start: inside this block
         if ((over > 0.0 && over <= tol) || under <= tol) ++unc;
         if (cnt < cap && lane == 0) closes[cnt] = mclose;
         ++cnt;
+        long_bars = bstar - bc >= 64;      // beyond one 64-block window; the next bar is probably as long as this one
         c = mclose;
+        bc = bstar;
+        Bc = Bs;
+        Lc = l_at;
+#ifdef VC_TIMING
+        VC_T(t1); tC += t1 - t0;
+#endif
     }
+#ifdef VC_TIMING
+    if (lane == 0) printf("vc_chase timing: closes %lld  cycles/close: block search %.0f  in-block %.0f  certify+store %.0f\n",
+                          iters, (double)tA / iters, (double)tB / iters, (double)tC / iters);
+#endif
     if (lane == 0) { result[0] = cnt; result[1] = unc; }
 }
 
 // total_only: stop after the prefix / scan and return the stream's total volume through *total (used to decide whether
 // the 4096-tick tables are worth trying before the chain walk)
 template <bool AF64>
-static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c, bool total_only, double *total)
+static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c, bool total_only, double *total,
+                     bool have_prefix = false, int64_t sample = 0)
 {
+    // sample > 0: prefix + total over the first `sample` ticks only (tier estimate); have_prefix: the full prefix of an
+    // earlier total_only call in this same entry-point call is still in c.work
+    if (sample > 0 && sample < n) n = sample;
     const int64_t nblk = fmk_ceil_div(n, VC_BLOCK);
     const size_t lp_bytes = ((size_t)n * 8 + 255) & ~(size_t)255;
     const size_t tot_bytes = ((size_t)nblk * 8 + 255) & ~(size_t)255;
     const size_t bb_bytes = ((size_t)(nblk + 1) * sizeof(VcDD) + 255) & ~(size_t)255;
-    const size_t bytes = lp_bytes + tot_bytes + bb_bytes + 256;
+    const int64_t nwg_all = fmk_ceil_div(n, VC_WG_TICKS);
+    const size_t wg_bytes = ((size_t)nwg_all * 8 + 255) & ~(size_t)255;
+    const size_t bw_bytes = ((size_t)(nwg_all + 1) * sizeof(VcDD) + 255) & ~(size_t)255;
+    const size_t bytes = lp_bytes + tot_bytes + bb_bytes + wg_bytes + bw_bytes + 256;
     if (c.work_bytes < bytes) {
         if (c.work) FMK_HIP(ctx, hipFree(c.work));
         c.work = nullptr; c.work_bytes = 0;
@@ -551,11 +693,19 @@ static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCach
     double *Lp = (double *)c.work;
     double *totals = (double *)((char *)c.work + lp_bytes);
     VcDD *Bb = (VcDD *)((char *)c.work + lp_bytes + tot_bytes);
+    double *wgt = (double *)((char *)c.work + lp_bytes + tot_bytes + bb_bytes);
+    VcDD *BW = (VcDD *)((char *)c.work + lp_bytes + tot_bytes + bb_bytes + wg_bytes);
     int64_t *d_res = ctx->d_mail + 44;
-    k_vc_prefix<AF64><<<(unsigned)nblk, 256, 0, ctx->stream>>>(a, n, Lp, totals);
-    FMK_LAUNCH_CHECK(ctx);
-    k_vc_scan<<<1, 256, 0, ctx->stream>>>(totals, nblk, Bb);
-    FMK_LAUNCH_CHECK(ctx);
+    if (!have_prefix) {
+        k_vc_prefix<AF64><<<(unsigned)fmk_ceil_div(n, VC_WG_TICKS), 256, 0, ctx->stream>>>(a, n, Lp, totals);
+        FMK_LAUNCH_CHECK(ctx);
+        // serial double-double scan over the N/2048 workgroup totals, expanded to the N/512 blocks in parallel
+        const int64_t nwg = fmk_ceil_div(n, VC_WG_TICKS);
+        k_vc_wgtotals<<<(unsigned)fmk_ceil_div(nwg, 256), 256, 0, ctx->stream>>>(totals, nblk, nwg, wgt);
+        k_vc_scan<<<1, 256, 0, ctx->stream>>>(wgt, nwg, BW);
+        k_vc_expand<<<(unsigned)fmk_ceil_div(nwg + 1, 256), 256, 0, ctx->stream>>>(totals, BW, nwg, nblk, Bb);
+        FMK_LAUNCH_CHECK(ctx);
+    }
     if (total_only) {
         FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], &Bb[nblk].hi, 8, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -597,22 +747,41 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {
-        int rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
+        // Tier by mean bar length.  A sample of the head of the stream (prefix + total of the first 2^19 ticks: two tiny
+        // launches and one read-back) decides whether the 2048-tick tables are worth building at all -- at 1e9 ticks a
+        // doomed attempt costs 27 ms.  A misleading sample only costs time: every tier still reports overflow.
+        double est_total = 0.0;
+        const int64_t ns = n < ((int64_t)1 << 19) ? n : ((int64_t)1 << 19);
+        int rcs = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &est_total, false, ns)
+                                : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &est_total, false, ns);
+        if (rcs) return rcs;
+        const double est_len = est_total > 0.0 ? (double)ns * threshold / est_total : 1e300;
+        int rc = 1;
+        if (est_len < 1800.0)
+            rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
         if (rc == 1) {
-            // a bar longer than 2048 ticks.  Mean bar length from the total volume decides the next tier: the
-            // 4096-tick tables (one workgroup per CU, ~0.2 s at 1e9 ticks) only when the bars are short enough on average
+            // a bar longer than 2048 ticks (or expected).  The exact mean bar length from the total volume decides: the
+            // 4096-tick tables (one workgroup per CU) only when the bars are short enough on average
             double total = 0.0;
             int rc2 = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &total)
                                     : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &total);
             if (rc2) return rc2;
             const double mean_len = total > 0.0 ? (double)n * threshold / total : 1e300;
-            if (mean_len < 3000.0)
+            bool prefix_ok = true;          // the table tiers build in c.work too: after one of them the prefix is gone
+            if (est_len >= 1800.0 && mean_len < 1400.0) {    // the sample misled: short bars after all
+                prefix_ok = false;
+                rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
+                                   : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
+            }
+            if (rc == 1 && mean_len < 3000.0) {
+                prefix_ok = false;
                 rc = amount_is_f64 ? vol_run<true, 4096>(ctx, d_amount, n, threshold, c)
                                    : vol_run<false, 4096>(ctx, d_amount, n, threshold, c);
-            if (rc == 1)     // few, long bars: walk the chain with wave-parallel searches
-                rc = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, false, nullptr)
-                                   : vol_chase<false>(ctx, d_amount, n, threshold, c, false, nullptr);
+            }
+            if (rc == 1)     // few, long bars: walk the chain with wave-parallel searches (total pass's prefix if still there)
+                rc = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, false, nullptr, prefix_ok)
+                                   : vol_chase<false>(ctx, d_amount, n, threshold, c, false, nullptr, prefix_ok);
         }
         if (rc == 2) rc = 1;
         if (rc == 1)     // bar longer than the table span, or negative volumes

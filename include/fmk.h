@@ -304,6 +304,10 @@ int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int v
  * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only.  Not used by any product path. */
 int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
                               int blocks_per_cu, double *elapsed_ms);
+/* Dependent-access latency of one wave (tools/hoplat.py): `hops` hops of `loads` coalesced 512 B rows, the next address
+ * depending on the data read; shader cycles per hop.  Not used by any product path. */
+int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t stride, int loads, int hops,
+                         double *cycles_per_hop, double *elapsed_ms);
 
 #ifdef __cplusplus
 }
