@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "fmk_common.h"
+#include "fmk_pairwise.h"
 #include "fmk_dpp.h"
 
 struct FpOut {
@@ -50,64 +51,10 @@ __device__ __forceinline__ int fp_level32(double price, double tick, double inv_
     return (int)r;
 }
 
-// ---------------------------------------------------------------------------------------
-// NumPy pairwise float32 sum over an LDS array, evaluated by the whole wave (uniform result)
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float fp_pw_leaf(const float *a, int n, int lane)
-{
-    if (n < 8) {
-        float r = 0.f;
-        for (int i = 0; i < n; ++i) r += a[i];
-        return r;
-    }
-    const int nm = n - (n & 7);
-    float r = 0.f;
-    if (lane < 8) {
-        r = a[lane];
-        for (int i = 8 + lane; i < nm; i += 8) r += a[i];
-    }
-    float t = r + __shfl_down(r, 1, 64);     // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
-    float u = t + __shfl_down(t, 2, 64);     // lanes 0,4
-    float res = __shfl(u, 0, 64) + __shfl(u, 4, 64);
-    for (int i = nm; i < n; ++i) res += a[i];
-    return res;
-}
-
-// stk: per-wave LDS scratch of 4*16 ints (explicit recursion stack: off, len, phase, left)
+// NumPy pairwise float32 sum over an LDS array (fmk_pairwise.h holds the wave-level algorithm)
 __device__ __forceinline__ float fp_pairwise_f32(const float *a, int n, int lane, int *stk)
 {
-    if (n <= 128) return fp_pw_leaf(a, n, lane);
-    int *s_off = stk, *s_len = stk + 16, *s_ph = stk + 32;
-    float *s_left = (float *)(stk + 48);
-    int sp = 1;
-    if (lane == 0) { s_off[0] = 0; s_len[0] = n; s_ph[0] = 0; }
-    __builtin_amdgcn_wave_barrier();
-    float ret = 0.f;
-    bool have = false;
-    while (sp > 0) {
-        const int top = sp - 1;
-        const int off = fmk_uniform(s_off[top]), len = fmk_uniform(s_len[top]), ph = fmk_uniform(s_ph[top]);
-        int n2 = len / 2;
-        n2 -= n2 % 8;
-        if (!have) {
-            if (len <= 128) { ret = fp_pw_leaf(a + off, len, lane); have = true; --sp; }
-            else {
-                if (lane == 0) { s_off[sp] = off; s_len[sp] = n2; s_ph[sp] = 0; }
-                ++sp;
-            }
-        } else {
-            if (ph == 0) {
-                if (lane == 0) { s_left[top] = ret; s_ph[top] = 1; s_off[sp] = off + n2; s_len[sp] = len - n2; s_ph[sp] = 0; }
-                ++sp;
-                have = false;
-            } else {
-                ret = __builtin_bit_cast(float, fmk_uniform(__builtin_bit_cast(int, s_left[top]))) + ret;
-                --sp;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    return ret;
+    return fmk_pairwise_f32([a](int i) { return a[i]; }, n, lane, stk);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "fmk_median.h"
+#include "fmk_pairwise.h"
 
 template <bool AF64, int NREG>
 __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t start, int64_t cnt, int lane,
@@ -24,17 +25,29 @@ __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t st
     MedBar<AF64, NREG, false> bar;
     bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
     bar.load_all();
-    // NumPy 'linear' method: virtual index (n-1)*q, neighbours floor and floor+1 (clipped), _lerp
-    const double vidx = (double)(cnt - 1) * 0.95;
+    // NumPy 'linear' method: virtual index (n-1)*q IN THE ARRAY'S DTYPE, neighbours floor and floor+1 (clipped), _lerp
+    const double vidx = AF64 ? (double)(cnt - 1) * 0.95 : (double)((float)(cnt - 1) * (95.0f / 100.0f));
     const double fl = floor(vidx);
-    const int64_t k1 = (int64_t)fl;
+    const int64_t k1 = (int64_t)fl < cnt - 1 ? (int64_t)fl : cnt - 1;
     const int64_t k2 = k1 + 1 < cnt ? k1 + 1 : cnt - 1;
     typename MK::K v1, v2;
     if (!med_rank_pair<AF64, NREG, false>(bar, buf, k1, k2, v1, v2)) return NAN;
     const double a = MK::value(v1), b = MK::value(v2);
+    if constexpr (!AF64) {
+        // float32 amounts: NumPy 2.2 does EVERY step of np.percentile in the array's dtype -- q = 95 / float32(100), the
+        // virtual index float32(n - 1) * q, the weight, the difference and both interpolation forms (oracle: orc_percentile_f32,
+        // validated bit for bit against np.percentile).  The reference's slices are float32 after TradesData's merge.
+        const float q32 = 95.0f / 100.0f;
+        const float vi = (float)(cnt - 1) * q32;
+        if (vi >= (float)(cnt - 1)) return b;            // k2 is clipped to the last element
+        const float t32 = vi - floorf(vi);
+        const float a32 = (float)a, b32 = (float)b, d32 = b32 - a32;
+        float r32 = a32 + d32 * t32;
+        if (t32 >= 0.5f) r32 = b32 - d32 * (1.0f - t32);
+        return (double)r32;
+    }
     const double t = vidx - fl;
-    // float32 inputs: NumPy subtracts the two float32 neighbours in float32 before promoting
-    const double d = AF64 ? b - a : (double)((float)b - (float)a);
+    const double d = b - a;
     double r = a + d * t;
     if (t >= 0.5) r = b - d * (1.0 - t);
     if (d == 0.0) r = a;
@@ -50,6 +63,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
 {
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
+    __shared__ int s_stk[4][64];                 // recursion stack of the pairwise float32 sums (float32 amounts)
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
@@ -78,7 +92,21 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             }
             sum = fmk_wave_sum(sum);
             block = fmk_wave_sum(block);
-            mean_rel = (float)log1p((sum / (double)cnt) / thr);
+            double mean = sum / (double)cnt;
+            // float32 amounts (what TradesData's merge produces): the reference's np.mean / .sum() of the float32 slice are
+            // NumPy PAIRWISE float32 sums and the mean divides in float32 (base.py:591-596 in NumPy semantics; oracle:
+            // orc_pairwise_f32, 0 ulp against the reference's kit frames).  `sum` then is that rounded total.
+            float tf = 0.f;
+            const bool f32_rule = !AF64 && cnt <= FMK_PW_MAX_N;
+            if constexpr (!AF64) {
+                if (f32_rule) {
+                    const float *af = (const float *)amount + start;
+                    tf = fmk_pairwise_f32([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
+                    mean = (double)(tf / (float)cnt);
+                    sum = (double)tf;
+                }
+            }
+            mean_rel = (float)log1p(mean / thr);
             const int nreg = (int)((cnt + 63) >> 6);
             double p95;
             if (cnt > 64 * 32) p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
@@ -92,7 +120,13 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             if (sum != 0.0) {                                            // base.py:597-598
                 pct = (float)(block / sum);
                 if (cnt == 1) gini = 0.f;
-                else {
+                else if (f32_rule) {
+                    // 1 - sum((a / total)^2) with float32 quotients, squares and pairwise sum (base.py:609)
+                    const float *af = (const float *)amount + start;
+                    const float t32 = tf;
+                    gini = 1.0f - fmk_pairwise_f32([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
+                                                   s_stk[wib]);
+                } else {
                     double sq = 0.0;
                     for (int64_t j = lane; j < cnt; j += 64) {
                         const double q = fmk_amt<AF64>(amount, start + j) / sum;

@@ -228,6 +228,91 @@ def tradesdata_cases():
     return out
 
 
+FP_FIELDS = ("bar_timestamps", "price_tick", "price_levels", "buy_volumes", "sell_volumes", "buy_ticks", "sell_ticks",
+             "buy_imbalances", "sell_imbalances", "cot_price_levels", "sell_imbalances_sum", "buy_imbalances_sum",
+             "imb_max_run_signed", "vp_skew", "vp_gini")
+
+
+def api_stream(n=4000, seed=3):
+    """a small trade tape: ms stamps with repeats, prices on a 0.5 grid, dyadic amounts (typed and pure-Python float
+    semantics agree on them), ids"""
+    rng = np.random.default_rng(seed)
+    ts = 1_700_000_000_000 + np.cumsum(rng.integers(0, 40, size=n))
+    px = 100.0 + 0.5 * np.cumsum(rng.integers(-1, 2, size=n))
+    qty = rng.integers(1, 33, size=n) * 0.25
+    return ts.astype(np.int64), px.astype(np.float64), qty.astype(np.float64), np.arange(n, dtype=np.int64)
+
+
+def api_records():
+    """object-level records made with the reference's own classes: every build_* of the five kits on one TradesData,
+    the ReturnT / EWMST / RealizedVolatility transforms and their composition, VolumePro.compute"""
+    import pandas as pd
+    import finmlkit.bar.data_model as DM
+    import finmlkit.bar.kit as KIT
+    import finmlkit.feature.transforms as T
+    from finmlkit.feature.core.volume import VolumePro
+    from finmlkit.feature.kit import Compose
+    ts, px, qty, ids = api_stream()
+    td_args = {"args": [REC.enc(a) for a in (ts, px, qty, ids)], "kwargs": {"preprocess": REC.enc(True)}}
+    td = DM.TradesData(ts.copy(), px.copy(), qty.copy(), ids.copy(), preprocess=True)
+    n = len(td.data)
+    out = []
+
+    def fp_dict(fp):
+        return {k: getattr(fp, k) for k in FP_FIELDS}
+
+    kits = [("TimeBarKit", (pd.Timedelta(seconds=10),), {}), ("TickBarKit", (), {"tick_count_thrs": 50}),
+            ("VolumeBarKit", (), {"volume_ths": 200.0}), ("DollarBarKit", (), {"dollar_thrs": 20000.0}),
+            ("CUSUMBarKit", (np.full(n, 1e-3),), {})]
+    first = {}
+    for cname, cargs, ckw in kits:
+        kit = getattr(KIT, cname)(td, *copy.deepcopy(cargs), **copy.deepcopy(ckw))
+        ohlcv = kit.build_ohlcv()
+        nb = len(ohlcv)
+        theta = np.full(nb, float(np.median(qty)))
+        for method, margs, mkw in (("build_ohlcv", (), {}), ("build_directional_features", (), {}),
+                                   ("build_trade_size_features", (theta,), {"theta_mult": 3.0}),
+                                   ("build_footprints", (), {"price_tick_size": 0.5, "imbalance_factor": 2.0})):
+            rec = {"fn": cname + "." + method, "kind": "kit_build", "test": "oracle/edge_sweep.py::api " + cname,
+                   "label": "api " + cname + "." + method, "module": KIT.__name__, "trades": td_args,
+                   "ctor": {"args": [REC.enc(a) for a in cargs], "kwargs": {k: REC.enc(v) for k, v in ckw.items()}},
+                   "method": method, "args": [REC.enc(a) for a in margs], "kwargs": {k: REC.enc(v) for k, v in mkw.items()}}
+            try:
+                res = getattr(kit, method)(*copy.deepcopy(margs), **copy.deepcopy(mkw))
+                if method == "build_footprints":
+                    if cname == "TimeBarKit":
+                        first["fp"], first["bars"] = res, ohlcv
+                    res = fp_dict(res)
+                rec["result"] = REC.enc(res)
+            except Exception as e:   # noqa: BLE001
+                rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
+            out.append(rec)
+    frame = td.data
+    for label, make in (("ReturnT 5s log", lambda: T.ReturnT(pd.Timedelta(seconds=5), is_log=True, input_col="price")),
+                        ("ReturnT 1s", lambda: T.ReturnT(pd.Timedelta(seconds=1), is_log=False, input_col="price")),
+                        ("Compose ReturnT EWMST", lambda: Compose(T.ReturnT(pd.Timedelta(seconds=5), is_log=True, input_col="price"),
+                                                                  T.EWMST(pd.Timedelta(seconds=60)))),
+                        ("Compose ReturnT RealizedVolatility", lambda: Compose(T.ReturnT(pd.Timedelta(seconds=1), is_log=True, input_col="price"),
+                                                                               T.RealizedVolatility(30, is_sample=True)))):
+        rec = {"fn": "transform:" + label, "kind": "api_transform", "test": "oracle/edge_sweep.py::api " + label,
+               "label": "api " + label, "module": T.__name__, "trades": td_args, "args": [], "kwargs": {}}
+        try:
+            rec["result"] = REC.enc(make()(frame))
+        except Exception as e:   # noqa: BLE001
+            rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
+        out.append(rec)
+    rec = {"fn": "VolumePro.compute", "kind": "api_volumepro", "test": "oracle/edge_sweep.py::api VolumePro",
+           "label": "api VolumePro.compute", "module": "finmlkit.feature.core.volume", "trades": td_args, "args": [],
+           "kwargs": {"window_size_ns": REC.enc(int(pd.Timedelta(seconds=60).value)), "n_bins": REC.enc(9),
+                      "va_pct": REC.enc(68.34)}}
+    try:
+        rec["result"] = REC.enc(VolumePro(pd.Timedelta(seconds=60), n_bins=9).compute(first["bars"], first["fp"]))
+    except Exception as e:   # noqa: BLE001
+        rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
+    out.append(rec)
+    return out
+
+
 def main():
     import importlib
     mods = ["finmlkit.bar.logic", "finmlkit.bar.base", "finmlkit.bar.utils", "finmlkit.feature.core.utils",
@@ -266,6 +351,10 @@ def main():
         if ("TradesData", label) in NOT_COMPARABLE:
             rec["skip_reason"] = NOT_COMPARABLE[("TradesData", label)]
         calls.append(rec)
+    api = api_records()
+    calls.extend(api)
+    print("API-level records: %d (%d raise: %s)" % (len(api), sum(1 for c in api if "raises" in c),
+          [c["label"] + " -> " + c["raises"]["type"] + ": " + c["raises"]["msg"][:60] for c in api if "raises" in c]))
     n_td = sum(1 for c in calls if c.get("kind") == "tradesdata")
     print("TradesData cases: %d (%d raise: %s)" % (n_td, sum(1 for c in calls if c.get("kind") == "tradesdata" and "raises" in c),
           sorted({c["raises"]["type"] + ": " + c["raises"]["msg"][:50] for c in calls if c.get("kind") == "tradesdata" and "raises" in c})))
@@ -277,7 +366,7 @@ def main():
     print("%-32s %-34s %-44s %s" % ("function", "case", "reference", "oracle"))
     n_diff = 0
     for c in calls:
-        if c.get("kind") == "tradesdata":              # class-level host logic: the package replays it on the GPU box
+        if c.get("kind") in ("tradesdata", "kit_build", "api_transform", "api_volumepro"):   # class level: GPU replay only
             continue
         args = [R.dec(a, d) for a in c["args"]]
         kwargs = {k: R.dec(v, d) for k, v in c["kwargs"].items()}

@@ -81,6 +81,12 @@ def enc(v):
     if isinstance(v, tuple):
         return {"t": "list", "kind": "tuple", "v": [enc(x) for x in v]}
     if isinstance(v, list):            # includes the shim's numba.typed.List
+        if len(v) >= 16 and all(isinstance(x, np.ndarray) and x.ndim == 1 and x.dtype == v[0].dtype and x.dtype != object
+                                for x in v):
+            # a long ragged list of same-typed 1-D arrays (per-bar footprint levels): values + offsets, two archive members
+            off = np.zeros(len(v) + 1, np.int64)
+            np.cumsum([len(x) for x in v], out=off[1:])
+            return {"t": "ragged", "values": enc(np.concatenate(v) if off[-1] else np.zeros(0, v[0].dtype)), "offsets": enc(off)}
         return {"t": "list", "kind": "list", "v": [enc(x) for x in v]}
     try:
         import pandas as pd

@@ -39,6 +39,9 @@ def dec(e, d):
             return pd.DatetimeIndex(np.asarray(v[0], dtype="datetime64[ns]")) if e["kind"] == "pandas:DatetimeIndex" \
                 else pd.Index(v[0])
         return tuple(v) if e["kind"] == "tuple" else v
+    if t == "ragged":
+        vals, off = dec(e["values"], d), dec(e["offsets"], d)
+        return [vals[off[i]:off[i + 1]] for i in range(len(off) - 1)]
     if t == "dict":
         return {k: dec(x, d) for k, x in e["v"].items()}
     if t == "timedelta_ns":
@@ -93,6 +96,13 @@ POLICY = {
     "_tick_bar_indexer": "exact", "_volume_bar_indexer": "exact", "_dollar_bar_indexer": "exact",
     "_cusum_bar_indexer": "exact",
     "TradesData": "exact",
+    # API level (oracle/edge_sweep.py api_records): DataFrames / FootprintData attributes of the kits, transforms, VolumePro
+    "build_ohlcv": {"vwap": ("rtol", 1e-9), None: "exact"},
+    "build_directional_features": "exact",
+    "build_trade_size_features": "exact",      # float32 amounts after the merge: NumPy's float32 trees, reproduced exactly
+    "build_footprints": {"vp_skew": ("atol", 1e-6), None: "exact"},
+    "api_transform": ("rtol", 1e-9),
+    "VolumePro.compute": "exact",
     "TimeBarKit._comp_bar_close": "exact", "TickBarKit._comp_bar_close": "exact", "VolumeBarKit._comp_bar_close": "exact",
     "DollarBarKit._comp_bar_close": "exact", "CUSUMBarKit._comp_bar_close": "exact",
     # the reference's own agreement between its pandas and its compiled backend (test_realized_volatility.py:25)
@@ -121,6 +131,7 @@ def _cmp_array(got, want, pol, what):
 
 def compare(fn, got, want, what):
     pol = POLICY[fn]
+    named = isinstance(pol, dict) and any(isinstance(k, str) for k in pol)      # per column / attribute name
 
     def at(i):
         return pol.get(i, pol[None]) if isinstance(pol, dict) else pol
@@ -146,12 +157,12 @@ def compare(fn, got, want, what):
                                                   np.asarray(wp.index.get_level_values(i)), err_msg=f"{path}: index {i}")
                 for c in wp.columns:
                     assert g[c].dtype == wp[c].dtype, f"{path}.{c}: dtype {g[c].dtype} vs {wp[c].dtype}"
-                    _cmp_array(g[c].to_numpy(), wp[c].to_numpy(), p, f"{path}.{c}")
+                    _cmp_array(g[c].to_numpy(), wp[c].to_numpy(), pol.get(c, pol[None]) if named else p, f"{path}.{c}")
             return
         if isinstance(w, dict):
             assert sorted(g) == sorted(w), f"{path}: keys {sorted(g)} vs {sorted(w)}"
             for k in w:
-                rec(g[k], w[k], p, f"{path}.{k}")
+                rec(g[k], w[k], pol.get(k, pol[None]) if named else p, f"{path}.{k}")
             return
         if isinstance(w, (tuple, list)):
             assert len(g) == len(w), f"{path}: length {len(g)} vs {len(w)}"
@@ -166,7 +177,9 @@ def compare(fn, got, want, what):
             return
         assert g == w, f"{path}: {g!r} vs {w!r}"
 
-    if isinstance(want, tuple) and isinstance(pol, dict):
+    if named:
+        rec(got, want, pol[None], what)
+    elif isinstance(want, tuple) and isinstance(pol, dict):
         assert len(got) == len(want), f"{what}: length {len(got)} vs {len(want)}"
         for i, (g, w) in enumerate(zip(got, want)):
             rec(g, w, at(i), f"{what}[{i}]")
@@ -192,6 +205,12 @@ def replay(table, skip, path=PATH, match_message=True):
         if fn in skip:
             skipped[fn] = skipped.get(fn, 0) + 1
             continue
+        kind_key = {"kit_build": "api:kit_build", "api_transform": "api:transform", "api_volumepro": "api:volumepro"}.get(c.get("kind"))
+        if kind_key:
+            if kind_key in skip:
+                skipped[kind_key] = skipped.get(kind_key, 0) + 1
+                continue
+            fn = kind_key
         assert fn in table, f"recorded function {fn} has neither a replay nor a documented skip"
         args = [dec(a, d) for a in c["args"]]
         kwargs = {k: dec(v, d) for k, v in c["kwargs"].items()}
@@ -205,6 +224,9 @@ def replay(table, skip, path=PATH, match_message=True):
                 obj = call(*args, **kwargs)
                 built[i] = obj
                 return {"data": obj.data, "orig_timestamp_unit": obj.orig_timestamp_unit}
+        elif c.get("kind") in ("kit_build", "api_transform", "api_volumepro"):
+            def run(c=c, call=call):
+                return call(c, lambda e: dec(e, d))
         elif c.get("kind") == "kit":
             def run(c=c, call=call):
                 ctor = c["ctor"]
@@ -225,6 +247,8 @@ def replay(table, skip, path=PATH, match_message=True):
             else:
                 raise AssertionError(f"{what}: expected {c['raises']['type']}({c['raises']['msg']!r})")
         else:
-            compare(fn, run(), dec(c["result"], d), what)
+            pfn = {"kit_build": c.get("method"), "api_transform": "api_transform", "api_volumepro": "VolumePro.compute"}.get(
+                c.get("kind"), fn)
+            compare(pfn, run(), dec(c["result"], d), what)
         done += 1
     return done, skipped

@@ -31,14 +31,13 @@ def test_trade_size_vs_oracle(orc, n, interval):
     got = comp_bar_trade_size_features(am64, theta, ci, 5.0)
     for k, g, w in zip(KEYS, got, want):
         G.assert_f32_close(g, w, what=f"{k} iv={interval}", max_ulp=1, max_frac=0.02)
-    # float32 amounts: the reference accumulates its sums in float32 (NumPy pairwise / Numba sequential);
-    # the kernel sums in float64 -> agree to float32 summation accuracy only
+    # float32 amounts (what TradesData's merge produces): the reference's mean / total / Gini sums are NumPy pairwise float32
+    # sums and its percentile interpolates in float32; the kernel follows the same trees (fmk_pairwise.h) -> bit-identical
     theta32 = np.full(len(ci) - 1, float(np.median(am)))
     want = orc.comp_bar_trade_size_features(am, theta32, ci, 5.0)
     got = comp_bar_trade_size_features(am, theta32, ci, 5.0)
     for k, g, w in zip(KEYS, got, want):
-        assert np.array_equal(np.isnan(g), np.isnan(w)), k
-        np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-6, equal_nan=True, err_msg=k)
+        np.testing.assert_array_equal(g, w, err_msg=k)
 
 
 def test_trade_size_kit_and_errors(orc):

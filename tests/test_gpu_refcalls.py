@@ -22,6 +22,57 @@ def _realized_volatility(attrs, frame, kwargs):
     return rv(frame)
 
 
+FP_FIELDS = ("bar_timestamps", "price_tick", "price_levels", "buy_volumes", "sell_volumes", "buy_ticks", "sell_ticks",
+             "buy_imbalances", "sell_imbalances", "cot_price_levels", "sell_imbalances_sum", "buy_imbalances_sum",
+             "imb_max_run_signed", "vp_skew", "vp_gini")
+_TD = {}
+
+
+def _api_trades(c, dec):
+    """the package's TradesData for the (shared) recorded constructor arguments of the API-level records"""
+    from finmlkit_amd.bar.data_model import TradesData
+    key = c["trades"]["args"][0]["k"]
+    if key not in _TD:
+        _TD[key] = TradesData(*[dec(a) for a in c["trades"]["args"]], **{k: dec(v) for k, v in c["trades"]["kwargs"].items()})
+    return _TD[key]
+
+
+def _api_kit_build(c, dec):
+    from finmlkit_amd.bar import kit
+    cname, method = c["fn"].split(".")
+    k = getattr(kit, cname)(_api_trades(c, dec), *[dec(a) for a in c["ctor"]["args"]],
+                            **{n: dec(v) for n, v in c["ctor"]["kwargs"].items()})
+    out = getattr(k, method)(*[dec(a) for a in c["args"]], **{n: dec(v) for n, v in c["kwargs"].items()})
+    if method == "build_footprints":
+        out = {f: getattr(out, f) for f in FP_FIELDS}
+    return out
+
+
+def _api_transform(c, dec):
+    import pandas as pd
+    from finmlkit_amd.feature.transforms import Compose, EWMST, RealizedVolatility, ReturnT
+    make = {
+        "ReturnT 5s log": lambda: ReturnT(pd.Timedelta(seconds=5), is_log=True, input_col="price"),
+        "ReturnT 1s": lambda: ReturnT(pd.Timedelta(seconds=1), is_log=False, input_col="price"),
+        "Compose ReturnT EWMST": lambda: Compose(ReturnT(pd.Timedelta(seconds=5), is_log=True, input_col="price"),
+                                                 EWMST(pd.Timedelta(seconds=60))),
+        "Compose ReturnT RealizedVolatility": lambda: Compose(ReturnT(pd.Timedelta(seconds=1), is_log=True, input_col="price"),
+                                                              RealizedVolatility(30, is_sample=True)),
+    }[c["fn"].split(":", 1)[1]]
+    return make()(_api_trades(c, dec).data)
+
+
+def _api_volumepro(c, dec):
+    import pandas as pd
+    from finmlkit_amd.bar.kit import TimeBarKit
+    from finmlkit_amd.feature.core.volume import VolumePro
+    k = TimeBarKit(_api_trades(c, dec), pd.Timedelta(seconds=10))
+    bars = k.build_ohlcv()
+    fp = k.build_footprints(price_tick_size=0.5, imbalance_factor=2.0)
+    kw = {n: dec(v) for n, v in c["kwargs"].items()}
+    return VolumePro(pd.Timedelta(kw["window_size_ns"], unit="ns"), n_bins=kw["n_bins"], va_pct=kw["va_pct"]).compute(bars, fp)
+
+
 def _table():
     from finmlkit_amd.bar import base, kit, logic, utils
     from finmlkit_amd.bar.data_model import TradesData
@@ -55,6 +106,8 @@ def _table():
         "RealizedVolatility._pd": _realized_volatility,
         "RealizedVolatility._nb": _realized_volatility,
         "ewmst": volatility.ewmst, "ewmst_mean0": volatility.ewmst_mean0,
+        # API level: the kits' build_* frames / FootprintData, transform classes, VolumePro.compute (edge sweep)
+        "api:kit_build": _api_kit_build, "api:transform": _api_transform, "api:volumepro": _api_volumepro,
     }
     return table
 
@@ -68,4 +121,5 @@ def test_hip_path_replays_edge_sweep():
     """Degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py -> edge_calls.npz), replayed
     through the package: results under the contract of DESIGN.md 5, exceptions by type."""
     done, skipped = R.replay(_table(), SKIP, path=R.EDGE_PATH, match_message=False)
-    assert done == 175 and skipped == {"not comparable": 15}, (done, skipped)    # 137 function calls + 39 TradesData(...)
+    # 137 function calls + 38 TradesData(...) + 25 API-level records (20 kit builds, 4 transforms, VolumePro.compute)
+    assert done == 200 and skipped == {"not comparable": 15}, (done, skipped)
