@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
 {
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
-    __shared__ int s_stk[4][64];                 // recursion stack of the pairwise float32 sums (float32 amounts)
+    __shared__ __attribute__((aligned(8))) int s_stk[4][FMK_PW_STK_F64];      // recursion stack of the pairwise sums
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
@@ -85,25 +85,51 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
         if (cnt > 0 && th != 0.0) {                                      // base.py:586-587
             const double thr = th * theta_mult;
             double sum = 0.0, block = 0.0;
-            for (int64_t j = lane; j < cnt; j += 64) {
-                const double a = fmk_amt<AF64>(amount, start + j);
-                sum += a;
-                if (a > thr) block += a;
+            if constexpr (AF64) {
+                // block_volume += amount runs in tick order in the reference (base.py:600-603) and float64 addition is not
+                // associative: the (few) amounts above the threshold are added one by one, in order, by the whole wave
+                for (int64_t j0 = 0; j0 < cnt; j0 += 64) {
+                    const int64_t j = j0 + lane;
+                    const double a = j < cnt ? fmk_amt<AF64>(amount, start + j) : 0.0;
+                    sum += a;
+                    uint64_t m = __ballot(j < cnt && a > thr);
+                    while (m) {
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        const int64_t bits = __double_as_longlong(a);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, l);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((uint64_t)bits >> 32), l);
+                        block += __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+                    }
+                }
+                sum = fmk_wave_sum(sum);
+            } else {
+                for (int64_t j = lane; j < cnt; j += 64) {
+                    const double a = fmk_amt<AF64>(amount, start + j);
+                    sum += a;
+                    if (a > thr) block += a;                // float32 amounts: the float64 sum is exact in any order
+                }
+                sum = fmk_wave_sum(sum);
+                block = fmk_wave_sum(block);
             }
-            sum = fmk_wave_sum(sum);
-            block = fmk_wave_sum(block);
             double mean = sum / (double)cnt;
             // float32 amounts (what TradesData's merge produces): the reference's np.mean / .sum() of the float32 slice are
             // NumPy PAIRWISE float32 sums and the mean divides in float32 (base.py:591-596 in NumPy semantics; oracle:
             // orc_pairwise_f32, 0 ulp against the reference's kit frames).  `sum` then is that rounded total.
+            // float64 amounts: the same trees in float64 (np.mean / .sum() of a float64 slice are pairwise too).
             float tf = 0.f;
-            const bool f32_rule = !AF64 && cnt <= FMK_PW_MAX_N;
-            if constexpr (!AF64) {
-                if (f32_rule) {
+            const bool np_rule = cnt <= FMK_PW_MAX_N;       // longer bars than the explicit stack holds: tree-ordered sums
+            const bool f32_rule = !AF64 && np_rule;
+            if (np_rule) {
+                if constexpr (!AF64) {
                     const float *af = (const float *)amount + start;
-                    tf = fmk_pairwise_f32([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
+                    tf = fmk_pairwise([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
                     mean = (double)(tf / (float)cnt);
                     sum = (double)tf;
+                } else {
+                    const double *ad = (const double *)amount + start;
+                    sum = fmk_pairwise([ad](int i) { return ad[i]; }, (int)cnt, lane, s_stk[wib]);
+                    mean = sum / (double)cnt;
                 }
             }
             mean_rel = (float)log1p(mean / thr);
@@ -124,8 +150,13 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
                     // 1 - sum((a / total)^2) with float32 quotients, squares and pairwise sum (base.py:609)
                     const float *af = (const float *)amount + start;
                     const float t32 = tf;
-                    gini = 1.0f - fmk_pairwise_f32([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
-                                                   s_stk[wib]);
+                    gini = 1.0f - fmk_pairwise([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
+                                               s_stk[wib]);
+                } else if (np_rule) {
+                    const double *ad = (const double *)amount + start;
+                    const double td = sum;
+                    gini = (float)(1.0 - fmk_pairwise([ad, td](int i) { const double q = ad[i] / td; return q * q; }, (int)cnt, lane,
+                                                       s_stk[wib]));
                 } else {
                     double sq = 0.0;
                     for (int64_t j = lane; j < cnt; j += 64) {

@@ -74,7 +74,7 @@ def to_pandas(v):
 
 
 # ---- comparison ---------------------------------------------------------------------------------
-# float policy per function: "exact" | ("rtol", r) | "ulp32"; per result position where the positions differ
+# float policy per function: "exact" | ("rtol", r) | ("atol", a); per result position / column where they differ
 POLICY = {
     "_time_bar_indexer": "exact",
     "comp_bar_ohlcv": {5: ("rtol", 1e-9), None: "exact"},        # vwap: float64 sums in tree order
@@ -83,7 +83,7 @@ POLICY = {
     # of a BLAS dot product -> the absolute tolerance of tests/test_gpu_features.py / test_oracle_golden.py
     "comp_bar_footprints": {11: ("atol", 1e-6), None: "exact"},
     "comp_footprint_features": {4: ("atol", 1e-6), None: "exact"},
-    "comp_bar_trade_size_features": "ulp32",
+    "comp_bar_trade_size_features": "exact",
     "comp_price_tick_size": "exact",
     "comp_trade_side_vector": "exact",
     "merge_split_trades": "exact",
@@ -121,9 +121,7 @@ def _cmp_array(got, want, pol, what):
         np.testing.assert_array_equal(got, want, err_msg=what)
         return
     assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern"
-    if pol == "ulp32":
-        G.assert_f32_close(got.astype(np.float32), want.astype(np.float32), what=what, max_ulp=1, max_frac=1.0)
-    elif pol[0] == "atol":
+    if pol[0] == "atol":
         np.testing.assert_allclose(got, want, rtol=0, atol=pol[1], equal_nan=True, err_msg=what)
     else:
         np.testing.assert_allclose(got, want, rtol=pol[1], atol=1e-300, equal_nan=True, err_msg=what)

@@ -10,13 +10,13 @@ KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
 
 
 def test_trade_size_golden_f64():
-    """float64 amounts: the reference's arithmetic up to summation order -> float32 results within 1 ulp."""
+    """float64 amounts: NumPy's pairwise trees, percentile rule and the tick-ordered block sum reproduced -> bit-exact."""
     from finmlkit_amd.bar.base import comp_bar_trade_size_features
     d = G.load("trade_size")
     got = comp_bar_trade_size_features(d["am"], d["theta"], d["ci"], 5.0)
     for k, g in zip(KEYS, got):
         assert g.dtype == np.float32
-        G.assert_f32_close(g, d[k], what=k, max_ulp=1, max_frac=0.02)
+        np.testing.assert_array_equal(g, d[k], err_msg=k)
     assert np.isnan(got[0][3]) and np.isnan(got[3][3])          # theta == 0 -> NaN row
 
 
@@ -30,7 +30,7 @@ def test_trade_size_vs_oracle(orc, n, interval):
     want = orc.comp_bar_trade_size_features(am64, theta, ci, 5.0)
     got = comp_bar_trade_size_features(am64, theta, ci, 5.0)
     for k, g, w in zip(KEYS, got, want):
-        G.assert_f32_close(g, w, what=f"{k} iv={interval}", max_ulp=1, max_frac=0.02)
+        np.testing.assert_array_equal(g, w, err_msg=f"{k} iv={interval}")
     # float32 amounts (what TradesData's merge produces): the reference's mean / total / Gini sums are NumPy pairwise float32
     # sums and its percentile interpolates in float32; the kernel follows the same trees (fmk_pairwise.h) -> bit-identical
     theta32 = np.full(len(ci) - 1, float(np.median(am)))
@@ -55,7 +55,7 @@ def test_trade_size_kit_and_errors(orc):
     assert list(df.columns) == KEYS and len(df) == len(ci) - 1
     want = orc.comp_bar_trade_size_features(am64, theta, ci, 3.0)
     for k, w in zip(KEYS, want):
-        G.assert_f32_close(df[k].values, w, what=k, max_ulp=1, max_frac=0.02)
+        np.testing.assert_array_equal(df[k].values, w, err_msg=k)
     with pytest.raises(ValueError, match="Theta should match"):
         comp_bar_trade_size_features(am64, theta[:-1], ci, 3.0)
     with pytest.raises(ValueError, match="Theta should match"):

@@ -138,7 +138,7 @@ def test_trade_size_golden(orc):
     d = G.load("trade_size")
     got = orc.comp_bar_trade_size_features(d["am"], d["theta"], d["ci"], 5.0)
     for k, g in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], got):
-        G.assert_f32_close(g, d[k], what=k, max_ulp=1, max_frac=0.01)
+        np.testing.assert_array_equal(g, d[k], err_msg=k)     # pairwise sums, NumPy's percentile rule: bit-exact
 
 
 def test_preprocess_loops_golden(orc):
