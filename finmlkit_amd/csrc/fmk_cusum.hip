@@ -236,6 +236,146 @@ __global__ __launch_bounds__(CS_THREADS) void k_cusum_chunks(const double *__res
 
 __global__ void k_cusum_first(int64_t *closes, int64_t first) { closes[0] = first; }
 
+// ---------------------------------------------------------------------------------------
+// Sparse phase.  Thresholds that are rarely reached (the reference's default sigma_floor = 5e-4 on a quiet tape: one
+// close per 2.4e5 ticks on the synthetic stream) leave long stretches in which neither clamp binds, so the truth
+// advances ONE chunk per dense round (1059 rounds = 1.1 s at N = 1e9) while every interior chunk of such a stretch is
+// recomputed from a still-wrong input in every round: O(N x rounds) work.  With S = exit states and last_in = the input
+// a chunk was computed from, chunk k is CONSISTENT iff last_in[k] == S[k-1]; a HEAD is an inconsistent chunk whose
+// predecessor is consistent -- one per dependency chain.  After two dense rounds, if heads are few:
+//   k_cusum_mark : lists the heads;
+//   k_cusum_walk : one WAVE per head recomputes ret / lam from the original, contiguous columns (same expressions, same
+//                  device log => the same bits), walks the chunk with wave-uniform scalars and follows its run: on into
+//                  chunk k + 1 while that is not another head and was not computed from the exit state just produced.
+// Every chunk of a run is recomputed once per launch by exactly one wave: O(N) work, critical path = the longest chain.
+// The fixed point is "no heads".  The first inconsistent chunk of the stream is always a head with a final predecessor, so
+// it becomes right: the loop ends within `chunks` launches; a torn read of a neighbour that is being rewritten only
+// produces an input the next mark pass rejects.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cs_same(CsState a, CsState b)
+{
+    return __double_as_longlong(a.sp) == __double_as_longlong(b.sp) && __double_as_longlong(a.sn) == __double_as_longlong(b.sn);
+}
+
+__global__ __launch_bounds__(256) void k_cusum_mark(const CsState *__restrict__ S, const CsState *__restrict__ last_in,
+                                                    int64_t chunks, unsigned char *__restrict__ active,
+                                                    int *__restrict__ list, unsigned long long *count)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= chunks) return;
+    bool act = false;                                      // chunk 0 always starts from (0, 0): consistent
+    if (k > 0 && !cs_same(S[k - 1], last_in[k])) act = k == 1 || cs_same(S[k - 2], last_in[k - 1]);    // ... and k - 1 consistent
+    active[k] = act ? 1 : 0;
+    if (act) list[atomicAdd(count, 1ULL)] = (int)k;
+}
+
+__device__ __forceinline__ double cs_lane(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ ts, const double *__restrict__ price,
+                                                    const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
+                                                    int64_t chunks, double sigma_floor, double sigma_mult,
+                                                    CsState *S, CsState *last_in, int64_t *counts,
+                                                    const unsigned char *__restrict__ active, const int *__restrict__ list,
+                                                    int64_t n_list, int max_steps)
+{
+    // 64 ticks at a time: all lanes compute ret / lam (the expressions of k_cusum_prep) into two LDS rows, then lane 0 alone
+    // walks them in its own vector registers, branch-free (selects instead of if / else: the same values as the loop of
+    // k_cusum_chunks).  A first version walked with wave-uniform scalars through v_readlane and scalar branches: 18
+    // instructions but ~540 cycles per tick -- every tick went VGPR -> SGPR -> VALU -> VCC -> branch.
+    __shared__ double s_r[4][64], s_l[4][64];
+    const int lane = fmk_lane();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * 4 + wib;
+    if (w >= n_list) return;
+    int64_t k = fmk_uniform((int64_t)list[w]);
+    for (int step = 0; step < max_steps; ++step) {
+        CsState in = S[k - 1];                                          // k >= 1 on every path
+        in.sp = cs_lane(in.sp, 0); in.sn = cs_lane(in.sn, 0);           // one consistent copy for the whole wave
+        double sp = in.sp, sn = in.sn;
+        const int64_t t0 = k * CS_CHUNK;
+        const int len = (int)(m - t0 < CS_CHUNK ? m - t0 : CS_CHUNK);
+        int64_t cnt = 0;
+        // raw inputs of a group of 64 ticks, all five loads issued together and one group ahead: loaded one after the other
+        // and only when needed (price -> log, then ts, then sigma) a group cost three memory round trips, ~10 us
+        double c_p = 1.0, c_pm = 1.0, c_sg = 0.0;
+        int64_t c_ts = 0, c_tsn = 1;
+        auto fetch = [&](int j0, double &p, double &pm, double &sg, int64_t &tsi, int64_t &tsn) {
+            int64_t i = first + 1 + t0 + j0 + lane;
+            if (i > n - 1) i = n - 1;                                   // lanes past the chunk: any valid address
+            p = price[i]; pm = price[i - 1]; sg = sigma[i]; tsi = ts[i];
+            tsn = ts[i + 1 < n ? i + 1 : i];
+        };
+        fetch(0, c_p, c_pm, c_sg, c_ts, c_tsn);
+#ifdef CS_TIMING
+        long long tA = 0, tB = 0, t0c = __builtin_readcyclecounter(), t1c;
+#endif
+        for (int j0 = 0; j0 < len; j0 += 64) {
+            const int64_t t = t0 + j0 + lane;
+            double n_p = 1.0, n_pm = 1.0, n_sg = 0.0;
+            int64_t n_ts = 0, n_tsn = 1;
+            if (j0 + 64 < len) fetch(j0 + 64, n_p, n_pm, n_sg, n_ts, n_tsn);
+            double r = 0.0, lam = NAN;
+            if (j0 + lane < len) {                                      // the expressions of k_cusum_prep
+                const int64_t i = first + 1 + t;
+                r = log(c_p / c_pm);
+                const bool block = i + 1 < n && c_ts == c_tsn;
+                if (!block) {
+                    lam = sigma_mult * c_sg;
+                    lam = sigma_floor > lam ? sigma_floor : lam;
+                }
+            }
+            c_p = n_p; c_pm = n_pm; c_sg = n_sg; c_ts = n_ts; c_tsn = n_tsn;
+            s_r[wib][lane] = r;
+            s_l[wib][lane] = lam;
+            __builtin_amdgcn_wave_barrier();
+#ifdef CS_TIMING
+            t1c = __builtin_readcyclecounter(); tA += t1c - t0c; t0c = t1c;
+#endif
+            const int lim = len - j0 < 64 ? len - j0 : 64;
+            if (lane == 0) {
+#pragma unroll 8
+                for (int q = 0; q < lim; ++q) {                         // the loop of k_cusum_chunks, as selects
+                    const double ret = s_r[wib][q], lm = s_l[wib][q];
+                    const double a = sp + ret, b = sn + ret;
+                    sp = a > 0.0 ? a : 0.0;
+                    sn = b < 0.0 ? b : 0.0;
+                    const bool cp = sp >= lm;
+                    const bool cn = !cp && sn <= -lm;
+                    cnt += (cp || cn) ? 1 : 0;
+                    sp = cp ? 0.0 : sp;
+                    sn = cn ? 0.0 : sn;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef CS_TIMING
+            t1c = __builtin_readcyclecounter(); tB += t1c - t0c; t0c = t1c;
+#endif
+        }
+#ifdef CS_TIMING
+        if (lane == 0 && w == 0 && step == 0) printf("cusum walk, one chunk of %d ticks: compute r/lam %lld cycles, lane-0 walk %lld cycles\n", len, tA, tB);
+#endif
+        sp = cs_lane(sp, 0); sn = cs_lane(sn, 0);
+        if (lane == 0) {
+            last_in[k] = in;
+            counts[k] = cnt;
+            S[k].sp = sp; S[k].sn = sn;
+        }
+        // follow the run: on into chunk k + 1 unless it is another wave's head or was computed from exactly this exit state
+        if (k + 1 >= chunks || active[k + 1]) break;
+        const CsState nin = last_in[k + 1];
+        const double nsp = cs_lane(nin.sp, 0), nsn = cs_lane(nin.sn, 0);
+        if (__double_as_longlong(nsp) == __double_as_longlong(sp) && __double_as_longlong(nsn) == __double_as_longlong(sn)) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        ++k;
+    }
+}
+
 extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma,
                                          int64_t n, double sigma_floor, double sigma_mult, int64_t *d_out,
                                          int64_t capacity, int64_t *n_out, int64_t *n_rounds)
@@ -251,13 +391,17 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     const size_t ff_bytes = ((size_t)tiles * 8 + 255) & ~(size_t)255;
     const size_t tr_bytes = ((size_t)max_chunks * CS_CHUNK * 8 + 255) & ~(size_t)255;
     void *scr;
-    FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes, &scr));
+    const size_t act_bytes = ((size_t)max_chunks + 255) & ~(size_t)255;
+    const size_t list_bytes = ((size_t)max_chunks * 4 + 255) & ~(size_t)255;
+    FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes + act_bytes + list_bytes, &scr));
     char *base = (char *)scr + scan_bytes;
     CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes), *last_in = (CsState *)(base + 2 * st_bytes);
     int64_t *counts = (int64_t *)(base + 3 * st_bytes);
     double *tile_last = (double *)(base + 3 * st_bytes + cnt_bytes);
     double *t_ret = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes);
     double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + tr_bytes);
+    unsigned char *active = (unsigned char *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes);
+    int *list = (int *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes + act_bytes);
     unsigned long long *d_first = (unsigned long long *)ctx->d_mail;
     unsigned long long *d_changed = d_first + 1;
     // ---- forward fill of sigma (in place) + first non-NaN index
@@ -301,6 +445,35 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
             FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->h_mail[1] == 0) break;                       // fixed point: every chunk started from the truth
             if (rounds > chunks + 2) return fmk_set_error(ctx, FMK_E_HIP, "cusum: fixed point did not converge");
+            if (rounds >= 2) {
+                // how many dependency chains are left?  (heads: inconsistent chunks with a consistent predecessor)
+                FMK_HIP(ctx, hipMemsetAsync(d_changed, 0, 8, ctx->stream));
+                k_cusum_mark<<<(unsigned)fmk_ceil_div(chunks, 256), 256, 0, ctx->stream>>>(cur, last_in, chunks, active, list,
+                                                                                           d_changed);
+                FMK_LAUNCH_CHECK(ctx);
+                FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
+                FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                int64_t n_list = ctx->h_mail[1];
+                // chunks a wave follows per launch: many walks start from inputs that are not final yet and are redone,
+                // so short legs waste little; measured at N = 1e9 in the slow regime: 4..16 within 3 %, 64: +30 %, 512: 3x
+                const int walk_steps = 8;
+                while (n_list > 0) {                              // sparse phase on the single state array `cur`
+                    k_cusum_walk<<<(unsigned)fmk_ceil_div(n_list, 4), 256, 0, ctx->stream>>>(
+                        d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, cur, last_in, counts, active,
+                        list, n_list, walk_steps);
+                    FMK_LAUNCH_CHECK(ctx);
+                    ++rounds;
+                    if (rounds > chunks + 2) return fmk_set_error(ctx, FMK_E_HIP, "cusum: fixed point did not converge");
+                    FMK_HIP(ctx, hipMemsetAsync(d_changed, 0, 8, ctx->stream));
+                    k_cusum_mark<<<(unsigned)fmk_ceil_div(chunks, 256), 256, 0, ctx->stream>>>(cur, last_in, chunks, active,
+                                                                                               list, d_changed);
+                    FMK_LAUNCH_CHECK(ctx);
+                    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
+                    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    n_list = ctx->h_mail[1];
+                }
+                break;
+            }
         }
         // counts -> offsets (+1 for the opening entry), total
         FMK_TRY(fmk_exclusive_scan_i64(ctx, counts, counts, chunks, true));
