@@ -135,6 +135,11 @@ class Context:
         """Give back everything the context caches between calls (scratch, allocator free lists, indexer buffers)."""
         self.call("fmk_ctx_trim")
 
+    def set_fast_threshold(self, on: bool):
+        """Volume / dollar indexers: True = return the parallel result even when some decisions are uncertified (counted,
+        each may differ from the reference by one tick); False (default) = such inputs are redone by the exact loop."""
+        self.call("fmk_ctx_set_fast_threshold", C.c_int(1 if on else 0))
+
     def sync(self):
         self.call("fmk_ctx_sync")
 

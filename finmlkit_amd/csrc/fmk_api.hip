@@ -320,6 +320,12 @@ int fmk_profile_enable(fmk_ctx *ctx, int on)
     return FMK_OK;
 }
 
+int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on)
+{
+    ctx->fast_threshold = on ? 1 : 0;
+    return FMK_OK;
+}
+
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count)
 {
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));

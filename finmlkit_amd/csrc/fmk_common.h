@@ -25,6 +25,9 @@ struct fmk_ctx {
     int n_cu;
     // per-launch timing of the dominant kernel (fmk_profile_enable)
     int profile_on, profile_n;
+    // threshold indexers: 0 (default) = inputs with uncertified decisions are redone by the exact sequential loop;
+    // 1 = return the parallel result with its n_uncertified (fmk_ctx_set_fast_threshold)
+    int fast_threshold;
     hipEvent_t kev[64][2];
     // stream-ordered caching allocator behind fmk_alloc / fmk_free (fmk_api.hip): freed blocks are kept and handed
     // out again to later requests of (almost) the same size -- no hipMalloc / hipFree / synchronisation per call

@@ -381,6 +381,13 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
     }
+    if (c.unc > 0 && !ctx->fast_threshold) {
+        // a sum within the reference's rounding drift of the threshold: only its own sequence of float64 operations
+        // decides like it does (fmk_threshold.hip: k_threshold_exact)
+        c.ctx = nullptr;
+        return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
+                                    n_uncertified);
+    }
     *n_idx = c.count;
     if (n_uncertified) *n_uncertified = c.unc;
     if (!d_close_idx) return FMK_OK;

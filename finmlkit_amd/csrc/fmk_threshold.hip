@@ -107,6 +107,55 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
     if (lane == 0) { result[0] = m; result[1] = unc; }
 }
 
+// The reference's loop, operation for operation (logic.py:107-113 / 141-147): cum = d_0; for i >= 1: cum += d_i; if
+// cum >= thr: close at i and cum = 0 (volume) or cum -= thr (dollar).  The float64 running sum carries its own rounding
+// drift -- for dollar bars it is never reset -- so when an exactly computed sum lands within that drift of the threshold
+// (n_uncertified of the parallel algorithms), only the same sequence of float64 operations reproduces the reference's
+// decision.  One wave: the 64 increments of a group are computed by the lanes (rounded product first, like the reference),
+// lane 0 adds them in tick order from LDS; the next group's loads are in flight meanwhile.  Tens of ns per tick: the
+// fallback of the NumPy-facing functions, not a path for 1e9 resident ticks (fmk_ctx_set_fast_threshold).
+template <bool AF64, bool DOLLAR>
+__global__ __launch_bounds__(64) void k_threshold_exact(const double *__restrict__ price, const void *__restrict__ amount,
+                                                        int64_t n, double thr, int64_t *__restrict__ out, int64_t cap,
+                                                        int64_t *__restrict__ result /*[2]: count, uncertified = 0*/)
+{
+    __shared__ double s_d[64];
+    const int lane = fmk_lane();
+    int64_t m = 1;
+    if (lane == 0 && cap > 0) out[0] = 0;        // logic.py:104 / 138
+    double cum = 0.0;
+    auto inc = [&](int64_t i) {
+        double v = 0.0;
+        if (i < n) {
+            v = fmk_amt<AF64>(amount, i);
+            if constexpr (DOLLAR) v = price[i] * v;
+        }
+        return v;
+    };
+    double cur = inc(lane);
+    for (int64_t base = 0; base < n; base += 64) {
+        const double nxt = inc(base + 64 + lane);
+        s_d[lane] = cur;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int lim = (int)(n - base < 64 ? n - base : 64);
+            for (int q = 0; q < lim; ++q) {
+                const int64_t i = base + q;
+                if (i == 0) { cum = s_d[0]; continue; }          // cum = volumes[0] (logic.py:107)
+                cum += s_d[q];
+                if (cum >= thr) {
+                    if (m < cap) out[m] = i;
+                    ++m;
+                    cum = DOLLAR ? cum - thr : 0.0;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+    }
+    if (lane == 0) { result[0] = m; result[1] = 0; }
+}
+
 // sum of the (dollar) volumes: bounds the number of closes
 template <bool AF64, bool DOLLAR>
 __global__ __launch_bounds__(256) void k_threshold_total(const double *__restrict__ price,
@@ -132,6 +181,7 @@ struct ThCache {
     int64_t *dbuf;
     int64_t cap;
     fmk_ctx *ctx;
+    int exact;
 };
 static ThCache &th_cache(fmk_ctx *ctx)       // one per context (slot 2), created on first use
 {
@@ -150,13 +200,13 @@ void fmk_threshold_trim(fmk_ctx *ctx)
 
 template <bool DOLLAR>
 static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
-                  int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc)
+                  int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc, int exact)
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     ThCache &c = th_cache(ctx);
     const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
-                     c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf;
+                     c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf && c.exact == exact;
     if (!(hit && d_close_idx)) {
         // bound the number of closes
         double *d_acc = (double *)ctx->d_mail;
@@ -178,7 +228,12 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
             c.cap = bound;
         }
         int64_t *d_res = ctx->d_mail + 8;
-        if (is_f64)
+        if (exact) {
+            if (is_f64)
+                k_threshold_exact<true, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
+            else
+                k_threshold_exact<false, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
+        } else if (is_f64)
             k_threshold_index<true, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
         else
             k_threshold_index<false, DOLLAR><<<1, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, c.dbuf, c.cap, d_res);
@@ -186,7 +241,7 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
         FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 16, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = thr; c.kind = (int)DOLLAR;
-        c.is_f64 = is_f64; c.count = ctx->h_mail[0]; c.unc = ctx->h_mail[1];
+        c.is_f64 = is_f64; c.count = ctx->h_mail[0]; c.unc = ctx->h_mail[1]; c.exact = exact;
         if (c.count > c.cap) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: internal bound exceeded");
     }
     *n_idx = c.count;
@@ -204,8 +259,9 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
 int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
                          double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc)
 {
-    return dollar ? th_run<true>(ctx, d_price, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc)
-                  : th_run<false>(ctx, nullptr, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc);
+    const int exact = !ctx->fast_threshold;      // default: the reference's float64 loop, operation for operation
+    return dollar ? th_run<true>(ctx, d_price, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc, exact)
+                  : th_run<false>(ctx, nullptr, d_amount, is_f64, n, thr, d_close_idx, capacity, n_idx, n_unc, exact);
 }
 
 // (the extern "C" entry points live in fmk_volume.hip / fmk_dollar.hip)

@@ -790,6 +790,11 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
     }
+    if (c.unc > 0 && !ctx->fast_threshold) {      // see fmk_dollar_bar_indexer_dev
+        c.ctx = nullptr;
+        return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
+                                    n_uncertified);
+    }
     *n_idx = c.count;
     if (n_uncertified) *n_uncertified = c.unc;
     if (!d_close_idx) return FMK_OK;

@@ -68,6 +68,7 @@ def main():
         dv = engine.to_host(t.bar_ohlcv(dci, False))
         vthr = float(np.median(dv["volume"][:-1])) / 2000.0
         dthr = vthr * float(np.median(dv["close"]))
+        ctx.set_fast_threshold(True)     # time the parallel algorithms; the uncertified counts are reported below
         ms, vci = timed(ctx, lambda: t.volume_bar_index(vthr), 1)
         emit("volume_bar_indexer (parallel jump tables)", ms, 4, threshold=vthr, n_bars=vci.n - 1,
              uncertified=t.last_uncertified)

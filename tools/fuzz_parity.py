@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Seeded randomized differential test of the HIP path against the oracle: random sizes (biased towards the kernels'
+internal boundaries: 64-tick chunks, the 17..21-chunk classes, 1344 / 2048 / 4096-tick limits, 512-tick tiles), bar
+structures (empty bars, a -1 open edge, one-tick and very long bars), dtypes, thresholds, windows, spans, half lives and
+NaN placements.  Every function is judged under the comparison policy of tests/_refcalls.py (the contract of DESIGN.md 5).
+    python tools/fuzz_parity.py [iterations] [seed]        prints every failure with the seed of its case; exit code 1 if any
+tests/test_gpu_fuzz.py runs a short fixed-seed campaign."""
+import os
+import sys
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from tests import _refcalls as R
+
+EDGES = [1, 2, 3, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024, 1025, 1087, 1088, 1089, 1343, 1344, 1345, 2047, 2048,
+         2049, 4095, 4096, 4097, 8191, 8192, 8193]
+
+
+def size(rng, hi=20000):
+    u = rng.random()
+    if u < 0.35:
+        return int(rng.choice(EDGES))
+    if u < 0.7:
+        return int(rng.integers(1, 400))
+    if u < 0.97:
+        return int(rng.integers(400, hi))
+    return int(rng.integers(hi, 12 * hi))
+
+
+def tape(rng, n):
+    """timestamps (ns, non-decreasing with repeats), prices on a 0.5 / 0.01 grid, amounts (dyadic float32, lognormal
+    float32 or lognormal float64), sides"""
+    gap = int(rng.choice([1, 1000, 10**6, 10**8]))
+    ts = 1_700_000_000_000_000_000 + np.cumsum(rng.integers(0, 3 * gap + 1, size=n)).astype(np.int64)
+    step = float(rng.choice([0.5, 0.01]))
+    px = 100.0 + step * np.cumsum(rng.integers(-2, 3, size=n))
+    px = np.maximum(px, step)
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        am = (rng.integers(1, 65, size=n) * 0.125).astype(np.float32)
+    elif kind == 1:
+        am = rng.lognormal(-1, 1.2, size=n).astype(np.float32)
+    else:
+        am = rng.lognormal(-1, 1.2, size=n)
+    sd = rng.choice(np.array([-1, 1, 1, -1, 0], dtype=np.int8), size=n)
+    return ts, px.astype(np.float64), am, sd
+
+
+def bars(rng, n):
+    """bar_close_indices over n ticks: strictly valid for the reference (ascending, within range), with repeats (empty
+    bars), sometimes a -1 open edge, bar lengths from one tick to everything"""
+    mode = rng.integers(0, 5)
+    first = -1 if rng.random() < 0.5 else int(rng.integers(0, max(1, min(n, 3))))
+    if mode == 0:
+        L = int(rng.choice(EDGES))
+        ci = np.arange(first, n, max(L, 1), dtype=np.int64)
+    elif mode == 1:
+        k = int(rng.integers(1, max(2, min(n, 200))))
+        ci = np.sort(rng.integers(first + 1, n, size=k)).astype(np.int64) if n - first - 1 > 0 else np.array([], np.int64)
+        ci = np.concatenate([[first], ci])
+    elif mode == 2:
+        ci = np.array([first, n - 1], dtype=np.int64)
+    elif mode == 3:
+        lens = rng.choice(np.array([1, 1, 2, 64, 65, 1200, 1344, 1345, 3000]), size=int(rng.integers(1, 40)))
+        ci = first + np.concatenate([[0], np.cumsum(lens)])
+        ci = ci[ci <= n - 1].astype(np.int64)
+    else:
+        ci = np.arange(first, n, dtype=np.int64)[: int(rng.integers(2, 300))]
+    if len(ci) < 2 or ci[-1] > n - 1:
+        ci = np.array([first, n - 1], dtype=np.int64)
+    if first >= n - 1:
+        ci = np.array([-1, n - 1], dtype=np.int64)
+    return ci
+
+
+def one_case(rng, orc, pkg, log):
+    n = size(rng)
+    ts, px, am, sd = tape(rng, n)
+    ci = bars(rng, n)
+    which = int(rng.integers(0, 14))
+    name = None
+    try:
+        if which == 0:
+            iv = float(rng.choice([1.0, 5.0, 60.0, 0.25, 3600.0]))
+            name = f"_time_bar_indexer n={n} iv={iv}"
+            R.compare("_time_bar_indexer", pkg["logic"]._time_bar_indexer(ts, iv), orc._time_bar_indexer(ts, iv), name)
+        elif which == 1:
+            thr = float(np.mean(am, dtype=np.float64)) * float(rng.choice([0.5, 3, 50, 700, 1500, 2500, 5000, 10**7]))
+            name = f"_volume_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
+            R.compare("_volume_bar_indexer", pkg["logic"]._volume_bar_indexer(am, thr), orc._volume_bar_indexer(am, thr), name)
+        elif which == 2:
+            thr = float(np.mean(am.astype(np.float64) * px)) * float(rng.choice([0.5, 3, 50, 700, 2500, 10**7]))
+            name = f"_dollar_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
+            R.compare("_dollar_bar_indexer", pkg["logic"]._dollar_bar_indexer(px, am, thr), orc._dollar_bar_indexer(px, am, thr), name)
+        elif which == 3:
+            p = px.copy()
+            if rng.random() < 0.3:
+                p[rng.integers(0, n, size=max(1, n // 50))] = np.nan
+                if rng.random() < 0.5 and len(ci) > 1:
+                    p[min(n - 1, ci[rng.integers(0, len(ci) - 1)] + 1)] = np.nan      # a bar's first price
+            name = f"comp_bar_ohlcv n={n} bars={len(ci) - 1} dtype={am.dtype}"
+            R.compare("comp_bar_ohlcv", pkg["base"].comp_bar_ohlcv(p, am, ci), orc.comp_bar_ohlcv(p, am, ci), name)
+        elif which == 4:
+            keep = np.ones(len(ci), bool)
+            keep[1:] = np.diff(ci) > 0                       # empty bars raise ZeroDivisionError in both: tested elsewhere
+            c2 = ci[keep]
+            s2 = sd.copy()
+            s2[s2 == 0] = 1
+            if len(c2) < 2:
+                return None
+            name = f"comp_bar_directional_features n={n} bars={len(c2) - 1} dtype={am.dtype}"
+            R.compare("comp_bar_directional_features", pkg["base"].comp_bar_directional_features(px, am, c2, s2),
+                      orc.comp_bar_directional_features(px, am, c2, s2), name)
+        elif which == 5:
+            o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+            tick = 0.5 if np.all(np.abs(px / 0.5 - np.round(px / 0.5)) < 1e-9) else 0.01
+            imb = float(rng.choice([1.5, 3.0, 0.0]))
+            name = f"comp_bar_footprints n={n} bars={len(ci) - 1} dtype={am.dtype} tick={tick}"
+            R.compare("comp_bar_footprints", pkg["base"].comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb),
+                      orc.comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb), name)
+        elif which == 6:
+            theta = np.full(len(ci) - 1, float(np.median(am)))
+            if rng.random() < 0.2:
+                theta[rng.integers(0, len(theta))] = 0.0
+            tm = float(rng.choice([1.0, 3.0, 5.0]))
+            name = f"comp_bar_trade_size_features n={n} bars={len(ci) - 1} dtype={am.dtype}"
+            R.compare("comp_bar_trade_size_features", pkg["base"].comp_bar_trade_size_features(am, theta, ci, tm),
+                      orc.comp_bar_trade_size_features(am, theta, ci, tm), name)
+        elif which == 7:
+            w = float(rng.choice([1e-6, 0.5, 1, 5, 60, 10**6]))
+            lg = bool(rng.integers(0, 2))
+            name = f"comp_lagged_returns n={n} w={w} log={lg}"
+            R.compare("comp_lagged_returns", pkg["futils"].comp_lagged_returns(ts, px, w, lg), orc.comp_lagged_returns(ts, px, w, lg), name)
+        elif which == 8:
+            y = rng.normal(0, 1e-3, size=n)
+            if rng.random() < 0.4:
+                y[rng.integers(0, n, size=max(1, n // 20))] = np.nan
+            span = int(rng.choice([2, 3, 10, 100, 5000]))
+            name = f"ewms n={n} span={span}"
+            R.compare("ewms", pkg["vol"].ewms(y, span), orc.ewms(y, span), name)
+        elif which == 9:
+            y = rng.normal(0, 1e-3, size=n)
+            if rng.random() < 0.4:
+                y[rng.integers(0, n, size=max(1, n // 20))] = np.nan
+            hl = float(rng.choice([1e-3, 1.0, 60.0, 10**5]))
+            fn = "ewmst" if rng.random() < 0.5 else "ewmst_mean0"
+            name = f"{fn} n={n} hl={hl}"
+            R.compare(fn, getattr(pkg["vol"], fn)(ts, y, hl), getattr(orc, fn)(ts, y, hl), name)
+        elif which == 10:
+            y = rng.normal(0, 1e-3, size=n)
+            if rng.random() < 0.4:
+                y[rng.integers(0, n, size=max(1, n // 20))] = np.nan
+            w = int(rng.choice([1, 2, 3, 20, 30, 64, 65, 1000, 2048, 2049, 5000]))
+            smp = bool(rng.integers(0, 2))
+            name = f"realized_vol n={n} w={w} sample={smp}"
+            R.compare("realized_vol", pkg["vol"].realized_vol(y, w, smp), orc.realized_vol(y, w, smp), name)
+        elif which == 11:
+            bm = rng.random(n) < 0.5
+            a32 = am.astype(np.float32)
+            name = f"merge_split_trades n={n}"
+            R.compare("merge_split_trades", pkg["utils"].merge_split_trades(ts, px, a32, bm), orc.merge_split_trades(ts, px, a32, bm), name)
+        elif which == 12:
+            name = f"comp_trade_side_vector n={n}"
+            R.compare("comp_trade_side_vector", pkg["utils"].comp_trade_side_vector(px), orc.comp_trade_side_vector(px), name)
+        else:
+            sig = np.abs(rng.normal(1e-3, 5e-4, size=n))
+            if rng.random() < 0.5:
+                sig[: int(rng.integers(0, min(n, 50)))] = np.nan
+            if rng.random() < 0.3:
+                sig[rng.integers(0, n, size=max(1, n // 30))] = np.nan
+            fl = float(rng.choice([1e-5, 5e-4, 1e-2]))
+            name = f"_cusum_bar_indexer n={n} floor={fl}"
+            R.compare("_cusum_bar_indexer", pkg["logic"]._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0),
+                      orc._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0), name)
+    except AssertionError as e:
+        return f"{name}: {' '.join(str(e).split())[:300]}"
+    except Exception as e:     # noqa: BLE001 -- a crash on one side only is a finding too
+        return f"{name}: {type(e).__name__}: {str(e)[:200]} | {traceback.format_exc().strip().splitlines()[-3][:160]}"
+    return None
+
+
+def campaign(iterations, seed, orc, verbose=True):
+    from finmlkit_amd.bar import base, logic, utils
+    from finmlkit_amd.feature.core import utils as futils
+    from finmlkit_amd.feature.core import volatility
+    pkg = {"base": base, "logic": logic, "utils": utils, "futils": futils, "vol": volatility}
+    fails = []
+    for it in range(iterations):
+        rng = np.random.default_rng([seed, it])
+        msg = one_case(rng, orc, pkg, verbose)
+        if msg:
+            fails.append(f"[seed {seed} case {it}] {msg}")
+            if verbose:
+                print(fails[-1], flush=True)
+    return fails
+
+
+if __name__ == "__main__":
+    from oracle import oracle as orc
+    its = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f = campaign(its, seed, orc)
+    print(f"{its} cases, seed {seed}: {len(f)} failures")
+    sys.exit(1 if f else 0)

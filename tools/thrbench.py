@@ -7,6 +7,7 @@ import numpy as np
 from finmlkit_amd import _ffi, engine
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 ctx = _ffi.default_context()
+ctx.set_fast_threshold(True)       # time the parallel algorithms; uncertified decisions are printed, not redone
 t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
 probe = engine.DeviceTrades.synth(1_000_000, seed=42, ctx=ctx)
 mean_v = float(probe.amount.to_host().astype(np.float64).mean())
@@ -25,6 +26,6 @@ for L in LENGTHS:
         ms = []
         for _ in range(3):
             ctx.timer_start(); ci = fn(thr); ms.append(ctx.timer_stop())
-        row.append("%s %8.2f ms (%9d bars)" % (kind, min(ms), ci.n - 1))
+        row.append("%s %8.2f ms (%9d bars, %d uncertified)" % (kind, min(ms), ci.n - 1, t.last_uncertified))
         del ci
     print("mean bar %8d ticks: %s" % (L, "   ".join(row)), flush=True)
