@@ -1,6 +1,6 @@
 """A short fixed-seed campaign of the randomized differential test (tools/fuzz_parity.py): the HIP path against the oracle
 on random sizes biased towards the kernels' internal boundaries, random bar structures, dtypes, thresholds, windows and NaN
-placements, every function under the comparison policy of tests/_refcalls.py.  12 000 cases over four seeds were run while
+placements, every function under the comparison policy of tests/_refcalls.py.  21 000 cases over eight seeds were run while
 round 1 was built (one failure: an uncertified dollar-bar decision, now redone by the exact loop)."""
 import pytest
 

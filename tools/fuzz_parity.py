@@ -3,7 +3,7 @@
 internal boundaries: 64-tick chunks, the 17..21-chunk classes, 1344 / 2048 / 4096-tick limits, 512-tick tiles), bar
 structures (empty bars, a -1 open edge, one-tick and very long bars), dtypes, thresholds, windows, spans, half lives and
 NaN placements.  Every function is judged under the comparison policy of tests/_refcalls.py (the contract of DESIGN.md 5).
-    python tools/fuzz_parity.py [iterations] [seed]        prints every failure with the seed of its case; exit code 1 if any
+    python tools/fuzz_parity.py [iterations] [seed] [hi]   prints every failure with the seed of its case; exit code 1 if any
 tests/test_gpu_fuzz.py runs a short fixed-seed campaign."""
 import os
 import sys
@@ -75,25 +75,49 @@ def bars(rng, n):
     return ci
 
 
-def one_case(rng, orc, pkg, log):
-    n = size(rng)
+def both(fn, got_thunk, want_thunk, name):
+    """compare under the policy of `fn`; the same kind of exception on both sides is agreement, on one side only a failure"""
+    ge = we = None
+    try:
+        got = got_thunk()
+    except Exception as e:      # noqa: BLE001
+        ge = e
+    try:
+        want = want_thunk()
+    except Exception as e:      # noqa: BLE001
+        we = e
+    if ge is None and we is None:
+        R.compare(fn, got, want, name)
+        return
+    if ge is not None and we is not None:
+        gb = [c.__name__ for c in type(ge).__mro__]
+        wb = [c.__name__ for c in type(we).__mro__]
+        assert "ValueError" in gb and "ValueError" in wb or type(ge) is type(we) or (set(gb) & set(wb)) - {"Exception", "BaseException", "object"}, \
+            f"{name}: package raises {type(ge).__name__}({ge}) but oracle {type(we).__name__}({we})"
+        return
+    side, e = ("package", ge) if ge is not None else ("oracle", we)
+    raise AssertionError(f"{name}: only the {side} raises {type(e).__name__}: {str(e)[:150]}")
+
+
+def one_case(rng, orc, pkg, log, hi=20000):
+    n = size(rng, hi)
     ts, px, am, sd = tape(rng, n)
     ci = bars(rng, n)
-    which = int(rng.integers(0, 14))
+    which = int(rng.integers(0, 17))
     name = None
     try:
         if which == 0:
             iv = float(rng.choice([1.0, 5.0, 60.0, 0.25, 3600.0]))
             name = f"_time_bar_indexer n={n} iv={iv}"
-            R.compare("_time_bar_indexer", pkg["logic"]._time_bar_indexer(ts, iv), orc._time_bar_indexer(ts, iv), name)
+            both("_time_bar_indexer", lambda: pkg["logic"]._time_bar_indexer(ts, iv), lambda: orc._time_bar_indexer(ts, iv), name)
         elif which == 1:
             thr = float(np.mean(am, dtype=np.float64)) * float(rng.choice([0.5, 3, 50, 700, 1500, 2500, 5000, 10**7]))
             name = f"_volume_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
-            R.compare("_volume_bar_indexer", pkg["logic"]._volume_bar_indexer(am, thr), orc._volume_bar_indexer(am, thr), name)
+            both("_volume_bar_indexer", lambda: pkg["logic"]._volume_bar_indexer(am, thr), lambda: orc._volume_bar_indexer(am, thr), name)
         elif which == 2:
             thr = float(np.mean(am.astype(np.float64) * px)) * float(rng.choice([0.5, 3, 50, 700, 2500, 10**7]))
             name = f"_dollar_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
-            R.compare("_dollar_bar_indexer", pkg["logic"]._dollar_bar_indexer(px, am, thr), orc._dollar_bar_indexer(px, am, thr), name)
+            both("_dollar_bar_indexer", lambda: pkg["logic"]._dollar_bar_indexer(px, am, thr), lambda: orc._dollar_bar_indexer(px, am, thr), name)
         elif which == 3:
             p = px.copy()
             if rng.random() < 0.3:
@@ -101,7 +125,7 @@ def one_case(rng, orc, pkg, log):
                 if rng.random() < 0.5 and len(ci) > 1:
                     p[min(n - 1, ci[rng.integers(0, len(ci) - 1)] + 1)] = np.nan      # a bar's first price
             name = f"comp_bar_ohlcv n={n} bars={len(ci) - 1} dtype={am.dtype}"
-            R.compare("comp_bar_ohlcv", pkg["base"].comp_bar_ohlcv(p, am, ci), orc.comp_bar_ohlcv(p, am, ci), name)
+            both("comp_bar_ohlcv", lambda: pkg["base"].comp_bar_ohlcv(p, am, ci), lambda: orc.comp_bar_ohlcv(p, am, ci), name)
         elif which == 4:
             keep = np.ones(len(ci), bool)
             keep[1:] = np.diff(ci) > 0                       # empty bars raise ZeroDivisionError in both: tested elsewhere
@@ -111,35 +135,36 @@ def one_case(rng, orc, pkg, log):
             if len(c2) < 2:
                 return None
             name = f"comp_bar_directional_features n={n} bars={len(c2) - 1} dtype={am.dtype}"
-            R.compare("comp_bar_directional_features", pkg["base"].comp_bar_directional_features(px, am, c2, s2),
-                      orc.comp_bar_directional_features(px, am, c2, s2), name)
+            both("comp_bar_directional_features", lambda: pkg["base"].comp_bar_directional_features(px, am, c2, s2),
+                 lambda: orc.comp_bar_directional_features(px, am, c2, s2), name)
         elif which == 5:
             o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
             tick = 0.5 if np.all(np.abs(px / 0.5 - np.round(px / 0.5)) < 1e-9) else 0.01
             imb = float(rng.choice([1.5, 3.0, 0.0]))
             name = f"comp_bar_footprints n={n} bars={len(ci) - 1} dtype={am.dtype} tick={tick}"
-            R.compare("comp_bar_footprints", pkg["base"].comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb),
-                      orc.comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb), name)
+            both("comp_bar_footprints", lambda: pkg["base"].comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb),
+                 lambda: orc.comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb), name)
         elif which == 6:
             theta = np.full(len(ci) - 1, float(np.median(am)))
             if rng.random() < 0.2:
                 theta[rng.integers(0, len(theta))] = 0.0
             tm = float(rng.choice([1.0, 3.0, 5.0]))
             name = f"comp_bar_trade_size_features n={n} bars={len(ci) - 1} dtype={am.dtype}"
-            R.compare("comp_bar_trade_size_features", pkg["base"].comp_bar_trade_size_features(am, theta, ci, tm),
-                      orc.comp_bar_trade_size_features(am, theta, ci, tm), name)
+            both("comp_bar_trade_size_features", lambda: pkg["base"].comp_bar_trade_size_features(am, theta, ci, tm),
+                 lambda: orc.comp_bar_trade_size_features(am, theta, ci, tm), name)
         elif which == 7:
             w = float(rng.choice([1e-6, 0.5, 1, 5, 60, 10**6]))
             lg = bool(rng.integers(0, 2))
             name = f"comp_lagged_returns n={n} w={w} log={lg}"
-            R.compare("comp_lagged_returns", pkg["futils"].comp_lagged_returns(ts, px, w, lg), orc.comp_lagged_returns(ts, px, w, lg), name)
+            both("comp_lagged_returns", lambda: pkg["futils"].comp_lagged_returns(ts, px, w, lg),
+                 lambda: orc.comp_lagged_returns(ts, px, w, lg), name)
         elif which == 8:
             y = rng.normal(0, 1e-3, size=n)
             if rng.random() < 0.4:
                 y[rng.integers(0, n, size=max(1, n // 20))] = np.nan
             span = int(rng.choice([2, 3, 10, 100, 5000]))
             name = f"ewms n={n} span={span}"
-            R.compare("ewms", pkg["vol"].ewms(y, span), orc.ewms(y, span), name)
+            both("ewms", lambda: pkg["vol"].ewms(y, span), lambda: orc.ewms(y, span), name)
         elif which == 9:
             y = rng.normal(0, 1e-3, size=n)
             if rng.random() < 0.4:
@@ -147,7 +172,7 @@ def one_case(rng, orc, pkg, log):
             hl = float(rng.choice([1e-3, 1.0, 60.0, 10**5]))
             fn = "ewmst" if rng.random() < 0.5 else "ewmst_mean0"
             name = f"{fn} n={n} hl={hl}"
-            R.compare(fn, getattr(pkg["vol"], fn)(ts, y, hl), getattr(orc, fn)(ts, y, hl), name)
+            both(fn, lambda: getattr(pkg["vol"], fn)(ts, y, hl), lambda: getattr(orc, fn)(ts, y, hl), name)
         elif which == 10:
             y = rng.normal(0, 1e-3, size=n)
             if rng.random() < 0.4:
@@ -155,15 +180,47 @@ def one_case(rng, orc, pkg, log):
             w = int(rng.choice([1, 2, 3, 20, 30, 64, 65, 1000, 2048, 2049, 5000]))
             smp = bool(rng.integers(0, 2))
             name = f"realized_vol n={n} w={w} sample={smp}"
-            R.compare("realized_vol", pkg["vol"].realized_vol(y, w, smp), orc.realized_vol(y, w, smp), name)
+            both("realized_vol", lambda: pkg["vol"].realized_vol(y, w, smp), lambda: orc.realized_vol(y, w, smp), name)
         elif which == 11:
             bm = rng.random(n) < 0.5
             a32 = am.astype(np.float32)
             name = f"merge_split_trades n={n}"
-            R.compare("merge_split_trades", pkg["utils"].merge_split_trades(ts, px, a32, bm), orc.merge_split_trades(ts, px, a32, bm), name)
+            both("merge_split_trades", lambda: pkg["utils"].merge_split_trades(ts, px, a32, bm), lambda: orc.merge_split_trades(ts, px, a32, bm), name)
         elif which == 12:
             name = f"comp_trade_side_vector n={n}"
-            R.compare("comp_trade_side_vector", pkg["utils"].comp_trade_side_vector(px), orc.comp_trade_side_vector(px), name)
+            both("comp_trade_side_vector", lambda: pkg["utils"].comp_trade_side_vector(px), lambda: orc.comp_trade_side_vector(px), name)
+        elif which == 14:
+            thr = int(rng.choice([1, 2, 7, 64, 1000, 10**9]))
+            name = f"_tick_bar_indexer n={n} thr={thr}"
+            both("_tick_bar_indexer", lambda: pkg["logic"]._tick_bar_indexer(ts, thr), lambda: orc._tick_bar_indexer(ts, thr), name)
+        elif which == 15:
+            # rolling volume profile over the footprints of time bars (the oracle's own OHLCV / footprints as inputs)
+            iv = float(rng.choice([1.0, 5.0, 60.0]))
+            clock, tci = orc._time_bar_indexer(ts, iv)
+            if len(tci) < 2 or len(tci) > 4000:
+                return None
+            o = orc.comp_bar_ohlcv(px, am, tci, want_median=False)
+            tick = 0.5 if np.all(np.abs(px / 0.5 - np.round(px / 0.5)) < 1e-9) else 0.01
+            off, flat, bar = orc.comp_bar_footprints_csr(px, am, tci, sd, tick, o[2], o[1], 3.0)
+            win = float(rng.choice([iv, 5 * iv, 30 * iv]))
+            nb = int(rng.choice([5, 27]))
+            name = f"volume_profile_rolling n={n} bars={len(tci) - 1} win={win} bins={nb}"
+            both("volume_profile_rolling",
+                 lambda: tuple(pkg["volume"].volume_profile_rolling_csr(clock[1:], o[1], o[2], off, flat["price_levels"],
+                                                                        flat["buy_volumes"], flat["sell_volumes"], win, nb, tick)),
+                 lambda: tuple(orc.volume_profile_rolling(clock[1:], o[1], o[2], off, flat["price_levels"], flat["buy_volumes"],
+                                                          flat["sell_volumes"], win, nb, tick)), name)
+        elif which == 16:
+            L = int(rng.integers(1, 300))
+            lv = (int(rng.integers(-50, 50)) + np.arange(L)).astype(np.int32)
+            b = (rng.integers(0, 40, size=L) * 0.25).astype(np.float32)
+            s_ = (rng.integers(0, 40, size=L) * 0.25).astype(np.float32)
+            if float(b.sum() + s_.sum()) == 0.0:
+                b[0] = 1.0
+            imb = float(rng.choice([1.5, 3.0]))
+            name = f"comp_footprint_features L={L}"
+            both("comp_footprint_features", lambda: pkg["base"].comp_footprint_features(lv, b, s_, imb),
+                 lambda: orc.comp_footprint_features(lv, b, s_, imb), name)
         else:
             sig = np.abs(rng.normal(1e-3, 5e-4, size=n))
             if rng.random() < 0.5:
@@ -172,8 +229,8 @@ def one_case(rng, orc, pkg, log):
                 sig[rng.integers(0, n, size=max(1, n // 30))] = np.nan
             fl = float(rng.choice([1e-5, 5e-4, 1e-2]))
             name = f"_cusum_bar_indexer n={n} floor={fl}"
-            R.compare("_cusum_bar_indexer", pkg["logic"]._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0),
-                      orc._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0), name)
+            both("_cusum_bar_indexer", lambda: pkg["logic"]._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0),
+                 lambda: orc._cusum_bar_indexer(ts, px, sig.copy(), fl, 2.0), name)
     except AssertionError as e:
         return f"{name}: {' '.join(str(e).split())[:300]}"
     except Exception as e:     # noqa: BLE001 -- a crash on one side only is a finding too
@@ -181,15 +238,15 @@ def one_case(rng, orc, pkg, log):
     return None
 
 
-def campaign(iterations, seed, orc, verbose=True):
+def campaign(iterations, seed, orc, verbose=True, hi=20000):
     from finmlkit_amd.bar import base, logic, utils
     from finmlkit_amd.feature.core import utils as futils
-    from finmlkit_amd.feature.core import volatility
-    pkg = {"base": base, "logic": logic, "utils": utils, "futils": futils, "vol": volatility}
+    from finmlkit_amd.feature.core import volatility, volume
+    pkg = {"base": base, "logic": logic, "utils": utils, "futils": futils, "vol": volatility, "volume": volume}
     fails = []
     for it in range(iterations):
         rng = np.random.default_rng([seed, it])
-        msg = one_case(rng, orc, pkg, verbose)
+        msg = one_case(rng, orc, pkg, verbose, hi)
         if msg:
             fails.append(f"[seed {seed} case {it}] {msg}")
             if verbose:
@@ -201,6 +258,7 @@ if __name__ == "__main__":
     from oracle import oracle as orc
     its = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    f = campaign(its, seed, orc)
-    print(f"{its} cases, seed {seed}: {len(f)} failures")
+    hi = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+    f = campaign(its, seed, orc, hi=hi)
+    print(f"{its} cases, seed {seed}, sizes up to {12 * hi}: {len(f)} failures")
     sys.exit(1 if f else 0)
