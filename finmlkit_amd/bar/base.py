@@ -172,6 +172,16 @@ class BarBuilderBase(ABC):
 # --------------------------------------------------------------------------------------------
 # CORE FUNCTIONS (NumPy in / NumPy out)
 # --------------------------------------------------------------------------------------------
+def _check_close_indices(ci: np.ndarray, n: int):
+    """The reducers index ticks ci[i] + 1 .. ci[i + 1] directly (base.py:349-391 and siblings).  An index at or past the end
+    of the arrays is an IndexError in the reference's Python mode and an out-of-bounds read under Numba; here it would be an
+    out-of-bounds DEVICE read, so the NumPy-facing functions refuse it.  -1 (first bar opens at tick 0) is the smallest
+    meaningful entry.  comp_bar_trade_size_features is exempt: it slices, and a slice clamps (base.py:590)."""
+    if len(ci) and (int(ci.max()) >= n or int(ci.min()) < -1):
+        bad = int(ci.max()) if int(ci.max()) >= n else int(ci.min())
+        raise IndexError(f"index {bad} is out of bounds for axis 0 with size {n}")
+
+
 def comp_bar_ohlcv(prices: NDArray[np.float64], volumes: NDArray, bar_close_indices: NDArray[np.int64]):
     """Reference: finmlkit/bar/base.py:306-407.
 
@@ -180,10 +190,11 @@ def comp_bar_ohlcv(prices: NDArray[np.float64], volumes: NDArray, bar_close_indi
         raise ValueError("Prices and volumes arrays must have the same length.")
     if len(bar_close_indices) < 2:
         raise ValueError("Bar close indices must contain at least two elements.")
-    ctx = _ffi.default_context()
     p = np.ascontiguousarray(prices, dtype=np.float64)
     v, f64 = _ffi.amount_array(volumes)
     ci = np.ascontiguousarray(bar_close_indices, dtype=np.int64)
+    _check_close_indices(ci, len(p))
+    ctx = _ffi.default_context()
     nb = len(ci) - 1
     o, h, l, c, vwap, med = (np.empty(nb, np.float64) for _ in range(6))
     vol = np.empty(nb, np.float32)
@@ -198,11 +209,12 @@ def comp_bar_directional_features(prices: NDArray[np.float64], volumes: NDArray,
     """Reference: finmlkit/bar/base.py:409-546.  Returns the same 14-tuple (dtypes included).
 
     Raises ZeroDivisionError, like the reference, when a bar has no signed tick (base.py:536)."""
-    ctx = _ffi.default_context()
     p = np.ascontiguousarray(prices, dtype=np.float64)
     v, f64 = _ffi.amount_array(volumes)
     ci = np.ascontiguousarray(bar_close_indices, dtype=np.int64)
     sd = np.ascontiguousarray(trade_sides, dtype=np.int8)
+    _check_close_indices(ci, len(p))
+    ctx = _ffi.default_context()
     # no length check on bar_close_indices in the reference (only comp_bar_ohlcv has one, base.py:334-335): one element
     # -> zero bars, empty outputs; none -> NumPy's "negative dimensions are not allowed" from the allocation below
     nb = len(ci) - 1
@@ -235,13 +247,14 @@ def comp_bar_trade_size_features(amounts: NDArray, theta: NDArray[np.float64], b
 def comp_bar_footprints_csr(prices, amounts, bar_close_indices, trade_sides, price_tick_size, bar_lows,
                             bar_highs, imbalance_factor):
     """CSR form of comp_bar_footprints: (level_offsets[B+1], flat per-level dict, per-bar dict)."""
-    ctx = _ffi.default_context()
     p = np.ascontiguousarray(prices, dtype=np.float64)
     v, f64 = _ffi.amount_array(amounts)
     ci = np.ascontiguousarray(bar_close_indices, dtype=np.int64)
     sd = np.ascontiguousarray(trade_sides, dtype=np.int8)
     lo = np.ascontiguousarray(bar_lows, dtype=np.float64)
     hi = np.ascontiguousarray(bar_highs, dtype=np.float64)
+    _check_close_indices(ci, len(p))
+    ctx = _ffi.default_context()
     # like the reference (base.py:615-752): no length check; one element -> zero bars -> empty lists / arrays
     # (tests/bars/test_comp_bar_footprints.py::test_comp_bar_footprints_empty_bar of the reference)
     nb = len(ci) - 1

@@ -125,3 +125,19 @@ def test_plan_edges():
     with pytest.raises(ValueError, match="complete bar"):
         plan_edges([1, 12, 14], ne, e0, d)                  # middle shard holds no edge
     assert plan_edges([5], ne, e0, d)[0].n_bars == 10
+
+
+def test_close_indices_out_of_range_are_refused_before_any_device_work():
+    """bar_close_indices at or past the end of the arrays (IndexError in the reference's Python mode, an out-of-bounds read
+    under Numba) must not reach the kernels; trade-size features are exempt (slice semantics).  Runs without a GPU."""
+    from finmlkit_amd.bar import base
+    px = np.arange(6, dtype=np.float64) + 100.0
+    am = np.ones(6)
+    sd = np.ones(6, np.int8)
+    for ci in (np.array([-1, 2, 6]), np.array([0, 9]), np.array([-2, 5])):
+        with pytest.raises(IndexError, match="out of bounds"):
+            base.comp_bar_ohlcv(px, am, ci)
+        with pytest.raises(IndexError, match="out of bounds"):
+            base.comp_bar_directional_features(px, am, ci, sd)
+        with pytest.raises(IndexError, match="out of bounds"):
+            base.comp_bar_footprints(px, am, ci, sd, 0.5, px[:len(ci) - 1], px[:len(ci) - 1], 3.0)
