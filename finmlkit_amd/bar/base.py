@@ -177,8 +177,10 @@ def _check_close_indices(ci: np.ndarray, n: int):
     of the arrays is an IndexError in the reference's Python mode and an out-of-bounds read under Numba; here it would be an
     out-of-bounds DEVICE read, so the NumPy-facing functions refuse it.  -1 (first bar opens at tick 0) is the smallest
     meaningful entry.  comp_bar_trade_size_features is exempt: it slices, and a slice clamps (base.py:590)."""
-    if len(ci) and (int(ci.max()) >= n or int(ci.min()) < -1):
-        bad = int(ci.max()) if int(ci.max()) >= n else int(ci.min())
+    if len(ci) < 2:
+        return                                   # no bars, nothing is indexed (one element: the reference returns empties)
+    if int(ci[1:].max()) >= n or int(ci.min()) < -1:
+        bad = int(ci[1:].max()) if int(ci[1:].max()) >= n else int(ci.min())
         raise IndexError(f"index {bad} is out of bounds for axis 0 with size {n}")
 
 

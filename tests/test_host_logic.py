@@ -134,6 +134,8 @@ def test_close_indices_out_of_range_are_refused_before_any_device_work():
     px = np.arange(6, dtype=np.float64) + 100.0
     am = np.ones(6)
     sd = np.ones(6, np.int8)
+    base._check_close_indices(np.array([0]), 0)          # one element = zero bars: nothing is indexed (the reference's
+    base._check_close_indices(np.array([7]), 3)          # test_comp_bar_footprints_empty_bar passes exactly that)
     for ci in (np.array([-1, 2, 6]), np.array([0, 9]), np.array([-2, 5])):
         with pytest.raises(IndexError, match="out of bounds"):
             base.comp_bar_ohlcv(px, am, ci)
