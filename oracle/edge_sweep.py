@@ -233,17 +233,20 @@ FP_FIELDS = ("bar_timestamps", "price_tick", "price_levels", "buy_volumes", "sel
              "imb_max_run_signed", "vp_skew", "vp_gini")
 
 
-def api_stream(n=4000, seed=3):
-    """a small trade tape: ms stamps with repeats, prices on a 0.5 grid, dyadic amounts (typed and pure-Python float
-    semantics agree on them), ids"""
+def api_stream(n=4000, seed=3, lognormal=False):
+    """a small trade tape: ms stamps with repeats, prices on a 0.5 grid, ids, and amounts that are either dyadic or
+    lognormal float64 -- for the latter the ORDER of the float64 additions matters (near-tie redo, pairwise trees, the
+    tick-ordered block sum).  The lognormal tape is given to TradesData WITHOUT preprocessing (sorted ns stamps, sides
+    supplied): the merge would cast the amounts to float32, and for non-exact float32 amounts the reference's pure-Python
+    mode (float32 accumulators under NEP 50) is a different function from its Numba mode (float64) -- not a usable truth"""
     rng = np.random.default_rng(seed)
     ts = 1_700_000_000_000 + np.cumsum(rng.integers(0, 40, size=n))
     px = 100.0 + 0.5 * np.cumsum(rng.integers(-1, 2, size=n))
-    qty = rng.integers(1, 33, size=n) * 0.25
+    qty = rng.lognormal(0.0, 1.1, size=n) if lognormal else rng.integers(1, 33, size=n) * 0.25
     return ts.astype(np.int64), px.astype(np.float64), qty.astype(np.float64), np.arange(n, dtype=np.int64)
 
 
-def api_records():
+def api_records(tape="dyadic"):
     """object-level records made with the reference's own classes: every build_* of the five kits on one TradesData,
     the ReturnT / EWMST / RealizedVolatility transforms and their composition, VolumePro.compute"""
     import pandas as pd
@@ -252,9 +255,20 @@ def api_records():
     import finmlkit.feature.transforms as T
     from finmlkit.feature.core.volume import VolumePro
     from finmlkit.feature.kit import Compose
-    ts, px, qty, ids = api_stream()
-    td_args = {"args": [REC.enc(a) for a in (ts, px, qty, ids)], "kwargs": {"preprocess": REC.enc(True)}}
-    td = DM.TradesData(ts.copy(), px.copy(), qty.copy(), ids.copy(), preprocess=True)
+    if tape == "dyadic":
+        ts, px, qty, ids = api_stream()
+        tag = "api "
+        td_args = {"args": [REC.enc(a) for a in (ts, px, qty, ids)], "kwargs": {"preprocess": REC.enc(True)}}
+        td = DM.TradesData(ts.copy(), px.copy(), qty.copy(), ids.copy(), preprocess=True)
+    else:
+        ts, px, qty, ids = api_stream(n=6000, seed=17, lognormal=True)
+        ts = ts * 1_000_000                                            # ns
+        side = np.random.default_rng(18).choice(np.array([-1, 1], dtype=np.int8), size=len(ts))
+        tag = "api[lognormal] "
+        td_args = {"args": [REC.enc(a) for a in (ts, px, qty, ids)],
+                   "kwargs": {"side": REC.enc(side), "timestamp_unit": REC.enc("ns"), "preprocess": REC.enc(False)}}
+        td = DM.TradesData(ts.copy(), px.copy(), qty.copy(), ids.copy(), side=side.copy(), timestamp_unit="ns", preprocess=False)
+        assert td.data["amount"].dtype == np.float64
     n = len(td.data)
     out = []
 
@@ -273,8 +287,8 @@ def api_records():
         for method, margs, mkw in (("build_ohlcv", (), {}), ("build_directional_features", (), {}),
                                    ("build_trade_size_features", (theta,), {"theta_mult": 3.0}),
                                    ("build_footprints", (), {"price_tick_size": 0.5, "imbalance_factor": 2.0})):
-            rec = {"fn": cname + "." + method, "kind": "kit_build", "test": "oracle/edge_sweep.py::api " + cname,
-                   "label": "api " + cname + "." + method, "module": KIT.__name__, "trades": td_args,
+            rec = {"fn": cname + "." + method, "kind": "kit_build", "test": "oracle/edge_sweep.py::" + tag + cname,
+                   "label": tag + cname + "." + method, "module": KIT.__name__, "trades": td_args,
                    "ctor": {"args": [REC.enc(a) for a in cargs], "kwargs": {k: REC.enc(v) for k, v in ckw.items()}},
                    "method": method, "args": [REC.enc(a) for a in margs], "kwargs": {k: REC.enc(v) for k, v in mkw.items()}}
             try:
@@ -294,15 +308,15 @@ def api_records():
                                                                   T.EWMST(pd.Timedelta(seconds=60)))),
                         ("Compose ReturnT RealizedVolatility", lambda: Compose(T.ReturnT(pd.Timedelta(seconds=1), is_log=True, input_col="price"),
                                                                                T.RealizedVolatility(30, is_sample=True)))):
-        rec = {"fn": "transform:" + label, "kind": "api_transform", "test": "oracle/edge_sweep.py::api " + label,
-               "label": "api " + label, "module": T.__name__, "trades": td_args, "args": [], "kwargs": {}}
+        rec = {"fn": "transform:" + label, "kind": "api_transform", "test": "oracle/edge_sweep.py::" + tag + label,
+               "label": tag + label, "module": T.__name__, "trades": td_args, "args": [], "kwargs": {}}
         try:
             rec["result"] = REC.enc(make()(frame))
         except Exception as e:   # noqa: BLE001
             rec["raises"] = {"type": type(e).__name__, "msg": str(e), "base": builtin_base(e)}
         out.append(rec)
-    rec = {"fn": "VolumePro.compute", "kind": "api_volumepro", "test": "oracle/edge_sweep.py::api VolumePro",
-           "label": "api VolumePro.compute", "module": "finmlkit.feature.core.volume", "trades": td_args, "args": [],
+    rec = {"fn": "VolumePro.compute", "kind": "api_volumepro", "test": "oracle/edge_sweep.py::" + tag + "VolumePro",
+           "label": tag + "VolumePro.compute", "module": "finmlkit.feature.core.volume", "trades": td_args, "args": [],
            "kwargs": {"window_size_ns": REC.enc(int(pd.Timedelta(seconds=60).value)), "n_bins": REC.enc(9),
                       "va_pct": REC.enc(68.34)}}
     try:
@@ -351,7 +365,7 @@ def main():
         if ("TradesData", label) in NOT_COMPARABLE:
             rec["skip_reason"] = NOT_COMPARABLE[("TradesData", label)]
         calls.append(rec)
-    api = api_records()
+    api = api_records() + api_records("lognormal")
     calls.extend(api)
     print("API-level records: %d (%d raise: %s)" % (len(api), sum(1 for c in api if "raises" in c),
           [c["label"] + " -> " + c["raises"]["type"] + ": " + c["raises"]["msg"][:60] for c in api if "raises" in c]))

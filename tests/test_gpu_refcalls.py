@@ -121,5 +121,6 @@ def test_hip_path_replays_edge_sweep():
     """Degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py -> edge_calls.npz), replayed
     through the package: results under the contract of DESIGN.md 5, exceptions by type."""
     done, skipped = R.replay(_table(), SKIP, path=R.EDGE_PATH, match_message=False)
-    # 137 function calls + 38 TradesData(...) + 25 API-level records (20 kit builds, 4 transforms, VolumePro.compute)
-    assert done == 200 and skipped == {"not comparable": 15}, (done, skipped)
+    # 137 function calls + 38 TradesData(...) + 50 API-level records on two tapes (40 kit builds, 8 transforms, 2 x
+    # VolumePro.compute); the second tape has lognormal float64 amounts: the order of the float64 additions matters there
+    assert done == 225 and skipped == {"not comparable": 15}, (done, skipped)
