@@ -38,13 +38,40 @@ int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const 
 // status word bits
 #define VOL_ST_OVERFLOW 1   // a bar is longer than S ticks
 #define VOL_ST_BAD 2        // negative / NaN volume
+#define VOL_ST_INEXACT 4    // an amount that is not a multiple of 2^-20 below 2^20: sums are not exact in float64
+
+// A decision whose margin is EXACTLY zero (sum == threshold in this file's evaluation order) is certain only when every sum
+// involved is exact in float64 -- then the reference's sequential sum is the same number.  That holds for streams of
+// multiples of 2^-20 below 2^20 with a threshold below 2^31 (bars and 8192-tick prefixes stay below 2^33: 53 bits), e.g.
+// the synthetic stream and integer lots.  For anything else (decimal lots: 100 x 0.1 is 9.99999999999998 summed in tick
+// order, 10.0 in other orders) an exact tie is as fragile as a near tie.  The kernels that read the amounts set
+// VOL_ST_INEXACT; ties are recorded as their own class (fragile byte 2) and count as fragile when the bit is set.
+__device__ __forceinline__ bool vol_amount_inexact(double v) { return !(v * 1048576.0 == rint(v * 1048576.0) && v < 1048576.0); }
+__device__ __forceinline__ void vol_flag(int *status, int bit)     // one atomic per kernel, not per wave
+{
+    if (!(__atomic_load_n(status, __ATOMIC_RELAXED) & bit)) atomicOr(status, bit);
+}
+__device__ __forceinline__ bool vol_ties_fragile(const int *status, double thr)
+{
+    return (__atomic_load_n(status, __ATOMIC_RELAXED) & VOL_ST_INEXACT) || !(thr < 2147483648.0);
+}
+
+// `fragile` (one byte per tick, may be null): the decision nxt(j) was within the certification margin.  Only decisions ON
+// THE CHAIN matter: their ordinals (decision q produces out[q]; q == count is the final "no further close") are appended
+// to `list` ([0] = how many, then the ordinals) for k_vol_verify.
+#define VOL_LIST_CAP 4096
+__device__ __forceinline__ void vol_list_append(int64_t *list, int64_t q)
+{
+    const unsigned long long pos = atomicAdd((unsigned long long *)list, 1ULL);
+    if (pos < VOL_LIST_CAP) list[1 + pos] = q;
+}
 
 template <bool AF64, int S>
 __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restrict__ amount, int64_t n, double thr,
                                                             uint32_t *__restrict__ nxt, uint32_t *__restrict__ E0,
                                                             uint32_t *__restrict__ C0, uint32_t *__restrict__ root,
-                                                            int *__restrict__ status,
-                                                            unsigned long long *__restrict__ n_frag)
+                                                            int *__restrict__ status, int *__restrict__ root_tie,
+                                                            unsigned char *__restrict__ fragile, int64_t *__restrict__ list)
 {
     constexpr int PER = 2 * S / VOL_THREADS;          // prefix elements per thread
     constexpr int EPT = S / VOL_THREADS;              // table entries per thread
@@ -64,12 +91,12 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     // ---- block-local prefix sums over [bs, bs + 2S)
     double loc[PER];
     double run = 0.0;
-    bool bad = false;
+    bool bad = false, inexact = false;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int64_t j = bs + (int64_t)tid * PER + k;
         double v = 0.0;
-        if (j < n) { v = fmk_amt<AF64>(amount, j); bad |= !(v >= 0.0); }
+        if (j < n) { v = fmk_amt<AF64>(amount, j); bad |= !(v >= 0.0); inexact |= vol_amount_inexact(v); }
         run += v;
         loc[k] = run;
     }
@@ -87,6 +114,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     for (int k = 0; k < PER; ++k) LP(tid * PER + k + 1) = pre + loc[k];
     if (tid == 0) LP(0) = 0.0;
     if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);
+    if (__ballot(inexact) != 0 && lane == 0) vol_flag(status, VOL_ST_INEXACT);
     __syncthreads();
     // ---- nxt(j) for every tick of the block: smallest m > i+1 with Lp[m] - Lp[i+1] >= thr.
     //      Thread t owns the EPT CONSECUTIVE ticks i = t*EPT + q: nxt is non-decreasing in i, so after one bisection
@@ -94,12 +122,12 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     const int64_t remain = n - bs;                                  // ticks available from the block start
     const int mmax = (int)(remain < 2 * S ? remain : 2 * S);        // Lp[0..mmax] are valid
     const double tol = 1e-11 * thr;
-    int frag = 0;
     int carry_lo = 0;                                               // m of the previous tick of this thread
     bool ovf = false;
     for (int q = 0; q < EPT; ++q) {
         const int i = tid * EPT + q;                                // tick bs + i
         uint32_t nx = VOL_END, cc = 0;
+        unsigned char frag = 0;                                      // 1: within the margin, 2: exact tie
         if (i < remain) {
             cc = 1;
             const double target = LP(i + 1) + thr;
@@ -118,26 +146,27 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                 }
                 carry_lo = lo;
                 nx = (uint32_t)(bs + lo - 1);
-                // an exact hit (difference 0) is a certain decision, not a fragile one: it is what
-                // exactly-summable amounts produce, and a measure-zero coincidence otherwise
                 const double over = LP(lo) - target, under = target - LP(lo - 1);
-                frag += (over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol);
+                frag = ((over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol)) ? 1 : (over == 0.0 ? 2 : 0);
             } else if (i + 1 + S <= mmax) {
                 ovf = true;                                          // no close within S ticks although data remains
                 carry_lo = 0;
             } else {
-                if (hi >= lo) frag += target - LP(hi) <= tol;
+                if (hi >= lo) frag = target - LP(hi) <= tol ? 1 : 0;
                 carry_lo = 0;
             }
         }
         Eb[i] = nx;
-        Cb[i] = cc;
-    }
+        Cb[i] = cc | ((uint32_t)frag << 30);                         // the class rides in the count until the copy below:
+    }                                                                // S = 2048 is 53.3 KB, exactly three workgroups per CU
     if (__ballot(ovf) != 0 && lane == 0) atomicOr(status, VOL_ST_OVERFLOW);   // one atomic per wave, not per tick
     __syncthreads();
     for (int q = 0; q < EPT; ++q) {                                  // coalesced copy of the chain links
         const int i = q * VOL_THREADS + tid;
         nxt[bs + i] = Eb[i];
+        const uint32_t cf = Cb[i];
+        fragile[bs + i] = (unsigned char)(cf >> 30);
+        Cb[i] = cf & 0x3FFFFFFFu;
     }
     // first bar (block 0): tick 0 is counted but cannot close -> first j >= 1 with P_j >= thr
     if (blockIdx.x == 0 && tid == 0) {
@@ -149,8 +178,13 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                 if (LP(mid) >= thr) hi = mid; else lo = mid + 1;
             }
             r = (uint32_t)(lo - 1);
+            const double over = LP(lo) - thr, under = thr - LP(lo - 1);       // decision 1 (the first bar)
+            if ((over > 0.0 && over <= tol) || (lo - 1 >= 2 && under <= tol)) vol_list_append(list, 1);
+            else if (over == 0.0) *root_tie = 1;        // k_vol_emit lists it when the stream is not exactly summable
         } else if (S <= mmax) {
             atomicOr(status, VOL_ST_OVERFLOW);
+        } else if (hi >= 1 && thr - LP(hi) <= tol) {
+            vol_list_append(list, 1);                   // the whole (short) stream comes within the margin of one bar
         }
         *root = r;
     }
@@ -188,21 +222,20 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
         E0[bs + i] = Eb[i];
         C0[bs + i] = Cb[i];
     }
-    frag = (int)fmk_wave_sum(frag);
-    if (lane == 0 && frag) atomicAdd(n_frag, (unsigned long long)frag);
 }
 
-// tables of level k from level k-1: one thread per (block, entry)
-template <int S>
-__global__ __launch_bounds__(256) void k_vol_level_up(const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
+// tables of level k from level k-1: one thread per (block, entry).  The table span S = 1 << ls is a run-time value: the
+// LDS tiers use 2048 / 4096, the global tier (below) whatever power of two covers the longest bar.
+__global__ __launch_bounds__(256) void k_vol_level_up(int ls, const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
                                                       int64_t nblk_prev, int64_t span_prev /* ticks per prev block */,
                                                       uint32_t *__restrict__ Ek, uint32_t *__restrict__ Ck,
                                                       int64_t nblk, int *__restrict__ status)
 {
+    const int64_t S = (int64_t)1 << ls;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nblk * S) return;
-    const int64_t b = t / S;
-    const int i = (int)(t % S);
+    const int64_t b = t >> ls;
+    const int64_t i = t & (S - 1);
     const int64_t left = 2 * b, right = 2 * b + 1;
     uint32_t x = Ep[left * S + i];
     uint32_t c = Cp[left * S + i];
@@ -219,13 +252,13 @@ __global__ __launch_bounds__(256) void k_vol_level_up(const uint32_t *__restrict
 }
 
 // entries / output offsets of level k-1 from level k
-template <int S>
-__global__ __launch_bounds__(256) void k_vol_descend(const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
+__global__ __launch_bounds__(256) void k_vol_descend(int ls, const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
                                                      int64_t nblk_k, int64_t span_prev,
                                                      const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
                                                      int64_t nblk_prev, uint32_t *__restrict__ ent_p,
                                                      int64_t *__restrict__ off_p)
 {
+    const int64_t S = (int64_t)1 << ls;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk_k) return;
     const uint32_t e = ent_k[b];
@@ -250,13 +283,17 @@ __global__ __launch_bounds__(256) void k_vol_descend(const uint32_t *__restrict_
     }
 }
 
-template <int S>
-__global__ __launch_bounds__(256) void k_vol_emit(const uint32_t *__restrict__ ent0, const int64_t *__restrict__ off0,
+__global__ __launch_bounds__(256) void k_vol_emit(int ls, const uint32_t *__restrict__ ent0, const int64_t *__restrict__ off0,
                                                   int64_t nblk0, const uint32_t *__restrict__ nxt,
-                                                  int64_t *__restrict__ out, int64_t cap)
+                                                  int64_t *__restrict__ out, int64_t cap,
+                                                  const unsigned char *__restrict__ fragile, int64_t *__restrict__ list,
+                                                  const int *__restrict__ status, const int *__restrict__ root_tie, double thr)
 {
+    const uint64_t S = (uint64_t)1 << ls;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ties = vol_ties_fragile(status, thr);
     if (b == 0 && cap > 0) out[0] = 0;                              // logic.py:104
+    if (b == 0 && root_tie && *root_tie && ties) vol_list_append(list, 1);
     if (b >= nblk0) return;
     uint32_t j = ent0[b];
     int64_t o = off0[b];
@@ -264,6 +301,8 @@ __global__ __launch_bounds__(256) void k_vol_emit(const uint32_t *__restrict__ e
     while (j != VOL_END && (uint64_t)j < bend) {
         if (o < cap) out[o] = (int64_t)j;
         ++o;
+        const unsigned char f = fragile[j];
+        if (f == 1 || (f == 2 && ties)) vol_list_append(list, o);
         j = nxt[j];
     }
 }
@@ -279,6 +318,9 @@ struct VolCache {
     int64_t cap;
     void *work;
     size_t work_bytes;
+    void *work2, *work3;          // global tier: chain links + fragile bytes, tables
+    size_t work2_bytes, work3_bytes;
+    int64_t *d_list;              // [1 + VOL_LIST_CAP] fragile decisions on the chain
 };
 static VolCache &vol_cache(fmk_ctx *ctx)     // one per context (slot 0), created on first use
 {
@@ -292,14 +334,21 @@ void fmk_volume_trim(fmk_ctx *ctx)
     if (!c) return;
     if (c->dbuf) (void)hipFree(c->dbuf);
     if (c->work) (void)hipFree(c->work);
+    if (c->work2) (void)hipFree(c->work2);
+    if (c->work3) (void)hipFree(c->work3);
+    if (c->d_list) (void)hipFree(c->d_list);
     delete c;
     ctx->idx_cache[0] = nullptr;
 }
 
-// returns FMK_OK, 1 (=> use the serial fallback) or an error
+static int vol_certify(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, double thr, VolCache &c);
+
+// returns FMK_OK, 1 (the next tier), 2 (negative / NaN amounts), 3 (a replayed decision disagrees: serial walk) or an error
 template <bool AF64, int S>
 static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c)
 {
+    constexpr int LS = 11;
+    static_assert(S == (1 << LS), "table span");
     const int64_t nblk0 = fmk_ceil_div(n, S);
     // levels: nblk[k] = ceil(nblk0 / 2^k) until 1
     int64_t nblk[64];
@@ -311,7 +360,9 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     for (int k = 0; k <= K; ++k) tbl += (size_t)nblk[k] * S;
     size_t ents = 0;
     for (int k = 0; k <= K; ++k) ents += (size_t)nblk[k];
-    const size_t bytes = ((size_t)nblk0 * S + 2 * tbl) * 4 + ents * (4 + 8) + 256;
+    const size_t bytes = ((size_t)nblk0 * S + 2 * tbl) * 4 + ents * (4 + 8) + 256 + (size_t)nblk0 * S;
+    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+    FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
     if (c.work_bytes < bytes) {
         if (c.work) FMK_HIP(ctx, hipFree(c.work));
         c.work = nullptr; c.work_bytes = 0;
@@ -323,6 +374,7 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     uint32_t *Call = Eall + tbl;
     int64_t *offall = (int64_t *)(Call + tbl);
     uint32_t *entall = (uint32_t *)(offall + ents);
+    unsigned char *fragile = (unsigned char *)(entall + ents);
     uint32_t *E[64], *C[64], *ent[64];
     int64_t *off[64];
     {
@@ -334,21 +386,21 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     }
     int *d_status = (int *)(ctx->d_mail + 32);
     uint32_t *d_root = (uint32_t *)(ctx->d_mail + 33);
-    unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 34);
-    FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 24, ctx->stream));
+    int *d_root_tie = (int *)(ctx->d_mail + 35);
+    FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 32, ctx->stream));
     {
         constexpr size_t lds = (size_t)(2 * S + 1 + (2 * S + 1) / 8 + 1) * 8 + (size_t)S * 8 + 64;
         if (lds > 64 * 1024)
             FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vol_level0<AF64, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds));
         k_vol_level0<AF64, S><<<(unsigned)nblk0, VOL_THREADS, lds, ctx->stream>>>(a, n, thr, nxt, E[0], C[0], d_root,
-                                                                                  d_status, d_frag);
+                                                                                  d_status, d_root_tie, fragile, c.d_list);
     }
     FMK_LAUNCH_CHECK(ctx);
     for (int k = 1; k <= K; ++k) {
         const int64_t tot = nblk[k] * S;
-        k_vol_level_up<S><<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
-            E[k - 1], C[k - 1], nblk[k - 1], (int64_t)S << (k - 1), E[k], C[k], nblk[k], d_status);
+        k_vol_level_up<<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
+            LS, E[k - 1], C[k - 1], nblk[k - 1], (int64_t)S << (k - 1), E[k], C[k], nblk[k], d_status);
         FMK_LAUNCH_CHECK(ctx);
     }
     // root entry + total count
@@ -356,9 +408,8 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int status = (int)(ctx->h_mail[0] & 0xFFFFFFFF);
     const uint32_t root = (uint32_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
-    c.unc = ctx->h_mail[2];
     if (status & VOL_ST_BAD) return 2;              // negative / NaN volumes: only the serial walk reproduces those
-    if (status) return 1;
+    if (status & VOL_ST_OVERFLOW) return 1;
     int64_t closes = 0;
     if (root != VOL_END) {
         if ((int64_t)root >= S) return 1;
@@ -375,15 +426,14 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int k = K; k >= 1; --k) {
-        k_vol_descend<S><<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
-            ent[k], off[k], nblk[k], (int64_t)S << (k - 1), E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1]);
+        k_vol_descend<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+            LS, ent[k], off[k], nblk[k], (int64_t)S << (k - 1), E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1]);
         FMK_LAUNCH_CHECK(ctx);
     }
-    k_vol_emit<S><<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(ent[0], off[0], nblk0, nxt, c.dbuf,
-                                                                               c.cap);
+    k_vol_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(LS, ent[0], off[0], nblk0, nxt, c.dbuf, c.cap,
+                                                                            fragile, c.d_list, d_status, d_root_tie, thr);
     FMK_LAUNCH_CHECK(ctx);
-    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FMK_OK;
+    return vol_certify(ctx, a, AF64 ? 1 : 0, n, thr, c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -419,19 +469,25 @@ __device__ __forceinline__ double vc_diff(VcDD a, VcDD b)      // a - b rounded 
 // one wave per 512-tick block: lane l owns ticks 8l .. 8l+7 of the block; Lp = inclusive prefix inside the block
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_vc_prefix(const void *__restrict__ amount, int64_t n, double *__restrict__ Lp,
-                                                   double *__restrict__ totals)
+                                                   double *__restrict__ totals, int *__restrict__ status)
 {
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
     const int64_t blk = (int64_t)blockIdx.x * (VC_WG_TICKS / VC_BLOCK) + w;
     const int64_t bs = blk * VC_BLOCK;
     if (bs >= n) return;
     double loc[8], run = 0.0;
+    bool bad = false, inexact = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int64_t j = bs + (int64_t)lane * 8 + k;
-        run += j < n ? fmk_amt<AF64>(amount, j) : 0.0;
+        const double v = j < n ? fmk_amt<AF64>(amount, j) : 0.0;
+        bad |= !(v >= 0.0);
+        inexact |= vol_amount_inexact(v);
+        run += v;
         loc[k] = run;
     }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);   // prefix sums must not decrease: serial walk instead
+    if (__ballot(inexact) != 0 && lane == 0) vol_flag(status, VOL_ST_INEXACT);
     const double inc = fmk_wave_iscan(run);
     double pre = __shfl_up(inc, 1, 64);
     if (lane == 0) pre = 0.0;
@@ -524,7 +580,8 @@ __device__ __forceinline__ double vc_lane(double v, int src)
 
 __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
                                                  int64_t nblk, double thr, int64_t *__restrict__ closes, int64_t cap,
-                                                 int64_t *__restrict__ result /* [0] count, [1] uncertified */)
+                                                 int64_t *__restrict__ result /* [0] count */, int64_t *__restrict__ list,
+                                                 const int *__restrict__ status)
 {
     // One wave, bound by its own dependent instruction chain, not by memory (measured with a cycle counter per phase at
     // 5000-tick bars: ~3900 cycles per close whether the crossing was located by 64 + 32 scattered probes, by 8 loads of 8
@@ -538,7 +595,8 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
     //   * values the wave already holds are carried, never re-loaded or recomputed from sums (Lp[c], Bb[blk(c)],
     //     Bb[bstar], Lp[close - 1]): every comparison sees the operands a plain re-load would see.
     const int lane = fmk_lane();
-    int64_t c = -1, cnt = 0, unc = 0;
+    int64_t c = -1, cnt = 0;
+    const bool ties = vol_ties_fragile(status, thr);
     if (cap > 0 && lane == 0) closes[0] = 0;
     cnt = 1;                                                       // the opening entry (logic.py:104)
     int64_t bc = 0;
@@ -597,7 +655,12 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
                 Bfirst = VcDD{vc_lane(nb.hi, 63), vc_lane(nb.lo, 63)};            // Bb[b0 + 64]
             }
         }
-        if (bstar < 0) break;                                      // the remaining ticks do not fill a bar
+        if (bstar < 0) {
+            // the remaining ticks do not fill a bar -- decision `cnt`, fragile when they come within the margin
+            const double rest = vc_diff(Bb[nblk], Bc) - Lc;
+            if (lane == 0 && thr - rest <= (1e-11 + 2.3e-16 * (double)(n - 1 - c)) * thr) vol_list_append(list, cnt);
+            break;
+        }
         // request the next close's window now: it starts at bstar whatever tick of the block closes
         wb = bstar;
         win = (wb + lane < nblk) ? Bb[wb + lane + 1] : VcDD{0.0, 0.0};
@@ -648,7 +711,7 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
         const double over = s_at - thr;
         double under = INFINITY;
         if (mclose - 1 >= lo) under = thr - (off + l_before);       // mclose - 1 >= lo >= block start: inside this block
-        if ((over > 0.0 && over <= tol) || under <= tol) ++unc;
+        if (lane == 0 && ((over > 0.0 && over <= tol) || under <= tol || (ties && over == 0.0))) vol_list_append(list, cnt);
         if (cnt < cap && lane == 0) closes[cnt] = mclose;
         ++cnt;
         long_bars = bstar - bc >= 64;      // beyond one 64-block window; the next bar is probably as long as this one
@@ -664,7 +727,7 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
     if (lane == 0) printf("vc_chase timing: closes %lld  cycles/close: block search %.0f  in-block %.0f  certify+store %.0f\n",
                           iters, (double)tA / iters, (double)tB / iters, (double)tC / iters);
 #endif
-    if (lane == 0) { result[0] = cnt; result[1] = unc; }
+    if (lane == 0) result[0] = cnt;
 }
 
 // total_only: stop after the prefix / scan and return the stream's total volume through *total (used to decide whether
@@ -696,8 +759,10 @@ static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCach
     double *wgt = (double *)((char *)c.work + lp_bytes + tot_bytes + bb_bytes);
     VcDD *BW = (VcDD *)((char *)c.work + lp_bytes + tot_bytes + bb_bytes + wg_bytes);
     int64_t *d_res = ctx->d_mail + 44;
+    int *d_bad = (int *)(ctx->d_mail + 40);
     if (!have_prefix) {
-        k_vc_prefix<AF64><<<(unsigned)fmk_ceil_div(n, VC_WG_TICKS), 256, 0, ctx->stream>>>(a, n, Lp, totals);
+        FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+        k_vc_prefix<AF64><<<(unsigned)fmk_ceil_div(n, VC_WG_TICKS), 256, 0, ctx->stream>>>(a, n, Lp, totals, d_bad);
         FMK_LAUNCH_CHECK(ctx);
         // serial double-double scan over the N/2048 workgroup totals, expanded to the N/512 blocks in parallel
         const int64_t nwg = fmk_ceil_div(n, VC_WG_TICKS);
@@ -708,8 +773,10 @@ static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCach
     }
     if (total_only) {
         FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], &Bb[nblk].hi, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[5], d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(total, &ctx->h_mail[6], 8);
+        if (ctx->h_mail[5] & VOL_ST_BAD) return 2;      // negative / NaN amounts: only the serial walk reproduces those
         return FMK_OK;
     }
     int64_t cap = c.dbuf ? c.cap : 0;
@@ -720,17 +787,412 @@ static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCach
             FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)cap * 8));
             c.cap = cap;
         }
-        k_vc_chase<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, c.dbuf, c.cap, d_res);
+        if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+        FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
+        k_vc_chase<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, c.dbuf, c.cap, d_res, c.d_list, d_bad);
         FMK_LAUNCH_CHECK(ctx);
-        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], d_res, 16, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[6], d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[5], d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_mail[5] & VOL_ST_BAD) return 2;
         c.count = ctx->h_mail[6];
-        c.unc = ctx->h_mail[7];
-        if (c.count <= c.cap) return FMK_OK;
+        if (c.count <= c.cap) return vol_certify(ctx, a, AF64 ? 1 : 0, n, thr, c);
         FMK_HIP(ctx, hipFree(c.dbuf));                              // more closes than expected: exact size, once more
         c.dbuf = nullptr;
     }
     return fmk_set_error(ctx, FMK_E_HIP, "volume chase: capacity");
+}
+
+// ---------------------------------------------------------------------------------------
+// Bars of ~3 000 .. ~60 000 ticks: GLOBAL jump tables.  The LDS tables stop at 4096 ticks and the chain walk pays ~1.4 us
+// per close (450 ms at 3 500-tick bars); in between, the same composition runs on tables in HBM:
+//   k_vg_nxt     nxt(j) for EVERY tick from the chase's prefix sums (Lp inside 512-tick blocks + double-double block
+//                bases Bb).  nxt is monotone in j, so the 512 source ticks of a wave land in a narrow destination window:
+//                the wave finds each tick's destination BLOCK from 64 block bases in LDS (one coalesced load per 32 768
+//                ticks of look-ahead), then stages each needed destination block (8 coalesced loads) in LDS and every lane
+//                searches it for its ticks (gallop + bisection, continuing from its previous tick's answer).
+//                ~N x (8 + 8 + 4) bytes of traffic, no dependent global chain.
+//   k_vg_level0  table span S = power of two >= the longest bar FROM ANY TICK (measured by k_vg_nxt).  Every tick follows
+//                the read-only links until they leave its S-block: S / bar length hops, 1-3 when S is chosen that tight.
+//   levels up, descent, emit: the kernels of the LDS tiers with S at run time.
+// Decisions within the certification margin are recorded per tick (one byte); k_vol_emit lists those ON THE CHAIN and
+// k_vol_verify replays exactly those bars with the reference's sequential float64 sum.
+// ---------------------------------------------------------------------------------------
+#define VG_DEND 0x7FFFFFFF              // destination block of a tick whose bar never closes
+// destination prefixes in LDS, padded one slot per 8 (a lane's probes sit ~8 doubles from its neighbour's: unpadded that is
+// an 8-way bank conflict); entries past the block's valid ticks hold +inf ("crossed"), 8 more slots for the local probe
+#define VG_SLP(i) s_lp[(i) + ((i) >> 3)]
+#define VG_SLP_DOUBLES (VC_BLOCK + 8 + (VC_BLOCK + 8) / 8 + 1)
+
+// first index in [0, 512] whose prefix crosses (512: none).  Prefixes do not decrease, so "crossed" is false..false
+// true..true: three rounds of 8 INDEPENDENT reads (strides 64, 8, 1) instead of 9 dependent bisection steps -- no loop,
+// no divergence, and nothing to go wrong on garbage input.
+__device__ __forceinline__ int vg_search(const double *s_lp, double b, double l0, double thr)
+{
+    int seg = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) seg += (b + (VG_SLP(64 * i + 63) - l0) >= thr) ? 0 : 1;
+    if (seg == 8) return VC_BLOCK;
+    const int b1 = 64 * seg;
+    int c2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c2 += (b + (VG_SLP(b1 + 8 * i + 7) - l0) >= thr) ? 0 : 1;
+    const int b2 = b1 + 8 * (c2 < 7 ? c2 : 7);
+    int c3 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c3 += (b + (VG_SLP(b2 + i) - l0) >= thr) ? 0 : 1;
+    return b2 + c3;
+}
+
+__global__ __launch_bounds__(256) void k_vg_nxt(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
+                                                int64_t nblk, double thr, uint32_t *__restrict__ nxt,
+                                                unsigned char *__restrict__ fragile, unsigned *__restrict__ maxlen)
+{
+    __shared__ double s_end_all[4][64];
+    __shared__ double s_lp_all[4][VG_SLP_DOUBLES];
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    double *s_end = s_end_all[w], *s_lp = s_lp_all[w];
+    const int64_t blk = (int64_t)blockIdx.x * 4 + w;
+    const int64_t bs = blk * VC_BLOCK;
+    if (bs >= n) return;                                          // waves are independent: wave barriers only
+    if (lane < 8) VG_SLP(VC_BLOCK + lane) = INFINITY;
+    const int64_t j0 = bs + (int64_t)lane * 8;                    // lane l owns ticks j0 .. j0 + 7
+    double lpj[8], dB[8];
+    int dblk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lpj[k] = j0 + k < n ? Lp[j0 + k] : 0.0;
+        dblk[k] = j0 + k < n ? -1 : VG_DEND;
+        dB[k] = 0.0;
+    }
+    const VcDD base = Bb[blk];
+    unsigned char frag[8];                                        // 1: within the margin, 2: exact tie
+#pragma unroll
+    for (int k = 0; k < 8; ++k) frag[k] = 0;
+    // ---- destination block of every tick: first d >= blk with sum(j+1 .. end of d) >= thr
+    double prev_end = 0.0;                                        // sum(block start of blk .. start of block b0)
+    for (int64_t r = 0;; ++r) {
+        const int64_t b0 = blk + 64 * r;
+        const int nv = (int)(nblk - b0 < 64 ? nblk - b0 : 64);
+        s_end[lane] = lane < nv ? vc_diff(Bb[b0 + lane + 1], base) : -INFINITY;
+        __builtin_amdgcn_wave_barrier();
+        const double last = s_end[nv - 1];
+        const bool more = b0 + 64 < nblk;
+        bool pending = false;
+        int lprev = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (dblk[k] != -1) continue;
+            if (last - lpj[k] >= thr) {
+                int lo = lprev, hi = nv - 1;
+                if (s_end[lo] - lpj[k] >= thr) hi = lo;             // the usual case after the lane's first tick: same block
+                else ++lo;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_end[mid] - lpj[k] >= thr) hi = mid; else lo = mid + 1;
+                }
+                dblk[k] = (int)(64 * r) + lo;
+                dB[k] = lo > 0 ? s_end[lo - 1] : prev_end;
+                lprev = lo;
+            } else if (more) {
+                pending = true;
+            } else {
+                // no further close: fragile if the rest of the stream comes within the margin of the threshold
+                dblk[k] = VG_DEND;
+                const double tol = (1e-11 + 2.3e-16 * (double)(n - 1 - (j0 + k))) * thr;
+                frag[k] = thr - (last - lpj[k]) <= tol ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!more || __ballot(pending) == 0) break;
+        prev_end = last;
+    }
+    // ---- inside the destination blocks, in ascending order, only those some tick needs
+    uint32_t res[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) res[k] = VOL_END;
+    int64_t wmax = 0;
+    int cur = -1;
+    for (;;) {
+        int mine = VG_DEND;
+#pragma unroll
+        for (int k = 7; k >= 0; --k)
+            if (dblk[k] > cur && dblk[k] < mine) mine = dblk[k];
+        cur = (int)fmk_wave_min((int64_t)mine);
+        if (cur == VG_DEND) break;
+        const int64_t ds = (blk + cur) * VC_BLOCK;
+        const int nvt = (int)(n - ds < VC_BLOCK ? n - ds : VC_BLOCK);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t = 64 * q + lane;
+            VG_SLP(t) = t < nvt ? Lp[ds + t] : INFINITY;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int iprev = 0;
+        bool have = false;                                         // a tick of this lane already answered in this block
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (dblk[k] != cur) continue;
+            const int64_t j = j0 + k;
+            const double b = dB[k], l0 = lpj[k];
+            int lo = cur == 0 ? lane * 8 + k + 1 : 0;              // m > j
+            if (iprev > lo) lo = iprev;                            // nxt does not decrease
+            int64_t m;
+            // one round of 8 reads from the previous tick's answer settles most ticks (nxt moves ~1 per tick); the lane's
+            // first tick of this block, and jumps past a large trade, take the three-round search
+            int hi;
+            {
+                int c = 8;
+                if (have) {
+                    c = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) c += (b + (VG_SLP(lo + i) - l0) >= thr) ? 0 : 1;
+                }
+                hi = lo + c;
+                if (c == 8) { hi = vg_search(s_lp, b, l0, thr); if (hi < lo) hi = lo; }
+            }
+            if (hi < nvt) {
+                iprev = hi;
+                m = ds + hi;
+                const double tol = (1e-11 + 2.3e-16 * (double)(m - j)) * thr;
+                const double over = b + (VG_SLP(hi) - l0) - thr;
+                double under = INFINITY;
+                if (m - 1 > j) under = thr - (hi > 0 ? b + (VG_SLP(hi - 1) - l0) : b - l0);
+                frag[k] = ((over > 0.0 && over <= tol) || under <= tol) ? 1 : (over == 0.0 ? 2 : 0);
+            } else {
+                // the block was chosen because its END crosses (double-double); plain doubles rounded it just below
+                m = ds + nvt < n ? ds + nvt : (int64_t)VOL_END;
+                frag[k] = 1;
+                iprev = nvt;
+            }
+            have = true;
+            res[k] = (uint32_t)m;
+            if (m != (int64_t)VOL_END && m - j > wmax) wmax = m - j;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j0 + 7 < n) {
+        uint4 *o = (uint4 *)(nxt + j0);
+        o[0] = make_uint4(res[0], res[1], res[2], res[3]);
+        o[1] = make_uint4(res[4], res[5], res[6], res[7]);
+        unsigned long long fb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb |= (unsigned long long)frag[k] << (8 * k);
+        *(unsigned long long *)(fragile + j0) = fb;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (j0 + k < n) { nxt[j0 + k] = res[k]; fragile[j0 + k] = frag[k]; }
+    }
+    wmax = fmk_wave_max(wmax);
+    if (lane == 0 && (unsigned)wmax > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)wmax);
+}
+
+// first close: tick 0 is counted but cannot close -> first m >= 1 with sum(0 .. m) >= thr (logic.py:104-108)
+__global__ __launch_bounds__(64) void k_vg_root(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
+                                                int64_t nblk, double thr, uint32_t *__restrict__ root,
+                                                int64_t *__restrict__ list, const int *__restrict__ status)
+{
+    const int lane = fmk_lane();
+    const bool ties = vol_ties_fragile(status, thr);
+    int64_t bstar = -1;
+    for (int64_t b0 = 0; b0 < nblk && bstar < 0; b0 += 64) {
+        const int64_t b = b0 + lane;
+        bool hit = false;
+        if (b < nblk) { const VcDD x = Bb[b + 1]; hit = x.hi + x.lo >= thr; }
+        const uint64_t mk = __ballot(hit);
+        if (mk) bstar = b0 + __ffsll((unsigned long long)mk) - 1;
+    }
+    if (bstar < 0) {
+        const VcDD t = Bb[nblk];
+        if (lane == 0) {
+            *root = VOL_END;
+            if (thr - (t.hi + t.lo) <= (1e-11 + 2.3e-16 * (double)n) * thr) vol_list_append(list, 1);
+        }
+        return;
+    }
+    const VcDD bb = Bb[bstar];
+    const double off = bb.hi + bb.lo;
+    const int64_t bstart = bstar * VC_BLOCK;
+    const int64_t lo = bstart > 1 ? bstart : 1;
+    const int64_t hi = bstart + VC_BLOCK - 1 < n - 1 ? bstart + VC_BLOCK - 1 : n - 1;
+    int64_t m = -1;
+    for (int k = 0; k < 8 && m < 0; ++k) {
+        const int64_t j = bstart + k * 64 + lane;
+        const uint64_t mk = __ballot(j >= lo && j <= hi && off + Lp[j <= hi ? j : hi] >= thr);
+        if (mk) m = bstart + k * 64 + __ffsll((unsigned long long)mk) - 1;
+    }
+    if (lane != 0) return;
+    bool fr = false;
+    if (m < 0) {
+        if (hi >= lo) { m = hi; fr = true; }                       // rounded just below at the block's end
+        else { *root = n > 1 ? 1u : VOL_END; if (n > 1) vol_list_append(list, 1); return; }   // one-tick block 0: let the replay decide
+    } else {
+        const double tol = (1e-11 + 2.3e-16 * (double)m) * thr;
+        const double over = off + Lp[m] - thr;
+        double under = INFINITY;
+        if (m - 1 >= lo) under = thr - (off + Lp[m - 1]);
+        else if (m - 1 >= 1) under = thr - off;                    // m is the first tick of its block
+        fr = (over > 0.0 && over <= tol) || under <= tol || (ties && over == 0.0);
+    }
+    *root = (uint32_t)m;
+    if (fr) vol_list_append(list, 1);
+}
+
+__global__ __launch_bounds__(256) void k_vg_level0(const uint32_t *__restrict__ nxt, int64_t n, int ls, int64_t total,
+                                                   uint32_t *__restrict__ E0, uint32_t *__restrict__ C0)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    if (j >= n) { E0[j] = VOL_END; C0[j] = 0; return; }
+    const uint64_t bend = (uint64_t)((j >> ls) + 1) << ls;
+    uint32_t e = nxt[j], c = 1;
+    while (e != VOL_END && (uint64_t)e < bend) { e = nxt[e]; ++c; }
+    E0[j] = e;
+    C0[j] = c;
+}
+
+// Replay of the listed decisions with the reference's own arithmetic (logic.py:104-113): cum = 0 after a close, += v in
+// tick order, close at the first cum >= thr.  Decision q starts after out[q - 1] (q == 1: at tick 0, which cannot close)
+// and must end at out[q] (q == count: nowhere).
+template <bool AF64>
+__global__ __launch_bounds__(64) void k_vol_verify(const void *__restrict__ amount, int64_t n, double thr,
+                                                   const int64_t *__restrict__ out, int64_t count,
+                                                   const int64_t *__restrict__ list, int *__restrict__ mismatch)
+{
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_items = list[0] < VOL_LIST_CAP ? list[0] : VOL_LIST_CAP;
+    if (item >= n_items) return;
+    const int64_t q = list[1 + item];
+    const int64_t start = q <= 1 ? 0 : out[q - 1] + 1;
+    const int64_t expect = q < count ? out[q] : -1;
+    const int64_t stop = expect >= 0 ? expect : n - 1;              // the replay may stop once it has passed the expected close
+    double cum = 0.0;
+    int64_t m = -1;
+    for (int64_t i = start; i <= stop; ++i) {
+        cum += fmk_amt<AF64>(amount, i);
+        if (i >= 1 && cum >= thr) { m = i; break; }
+    }
+    if (m != expect) atomicOr(mismatch, 1);
+}
+
+// certification of the listed decisions; returns FMK_OK with c.unc = 0 (all replayed and confirmed) or the raw count in
+// fast mode, or 3 (a replay disagrees / more fragile decisions than the list holds -> serial walk)
+static int vol_certify(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, double thr, VolCache &c)
+{
+    int *d_mis = (int *)(ctx->d_mail + 41);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[3], c.d_list, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t listed = ctx->h_mail[3];
+    c.unc = listed;
+    if (listed == 0 || ctx->fast_threshold) return FMK_OK;
+    if (listed > VOL_LIST_CAP) return 3;
+    FMK_HIP(ctx, hipMemsetAsync(d_mis, 0, 8, ctx->stream));
+    if (is_f64) k_vol_verify<true><<<(unsigned)fmk_ceil_div(listed, 64), 64, 0, ctx->stream>>>(a, n, thr, c.dbuf, c.count, c.d_list, d_mis);
+    else k_vol_verify<false><<<(unsigned)fmk_ceil_div(listed, 64), 64, 0, ctx->stream>>>(a, n, thr, c.dbuf, c.count, c.d_list, d_mis);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[3], d_mis, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_mail[3] & 1) return 3;
+    c.unc = 0;                                                      // every fragile decision replayed and confirmed
+    return FMK_OK;
+}
+
+static int vol_ensure(fmk_ctx *ctx, void **buf, size_t *have, size_t bytes)
+{
+    if (*have >= bytes) return FMK_OK;
+    if (*buf) FMK_HIP(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    FMK_HIP(ctx, hipMalloc(buf, bytes));
+    *have = bytes;
+    return FMK_OK;
+}
+
+// needs the full-stream prefix of a total_only vol_chase call in c.work.  Returns FMK_OK, 1 (not suitable: walk the chain)
+static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, double thr, VolCache &c, double mean_len)
+{
+    const int64_t nblk = fmk_ceil_div(n, VC_BLOCK);
+    const size_t lp_bytes = ((size_t)n * 8 + 255) & ~(size_t)255;
+    const size_t tot_bytes = ((size_t)nblk * 8 + 255) & ~(size_t)255;
+    const double *Lp = (const double *)c.work;
+    const VcDD *Bb = (const VcDD *)((char *)c.work + lp_bytes + tot_bytes);
+    const size_t nxt_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+    FMK_TRY(vol_ensure(ctx, &c.work2, &c.work2_bytes, nxt_bytes + (size_t)n + 256));
+    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+    uint32_t *nxt = (uint32_t *)c.work2;
+    unsigned char *fragile = (unsigned char *)c.work2 + nxt_bytes;
+    uint32_t *d_root = (uint32_t *)(ctx->d_mail + 36);
+    unsigned *d_maxlen = (unsigned *)(ctx->d_mail + 37);
+    int *d_status = (int *)(ctx->d_mail + 38);
+    FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 36, 0, 24, ctx->stream));
+    FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
+    k_vg_nxt<<<(unsigned)fmk_ceil_div(nblk, 4), 256, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, nxt, fragile, d_maxlen);
+    const int *d_pstat = (const int *)(ctx->d_mail + 40);          // status of the prefix pass (k_vc_prefix)
+    k_vg_root<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, d_root, c.d_list, d_pstat);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t root = (uint32_t)(ctx->h_mail[0] & 0xFFFFFFFFu);
+    const int64_t longest = (int64_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
+    int ls = 12;
+    while (((int64_t)1 << ls) < longest) ++ls;
+    const int64_t S = (int64_t)1 << ls;
+    // every tick walks S / bar-length links in k_vg_level0 (~2 ps per link at this parallelism: 3 ms at S / length = 1.6 and
+    // 1e9 ticks); the chain walk costs 1.4 us per CLOSE.  A quiet stretch that makes the longest bar 32 x the mean still
+    // leaves the tables far ahead; beyond that (or a span of more than 4M ticks) the chain is walked
+    if ((double)S > 32.0 * mean_len || ls > 22) return 1;
+    const int64_t nblk0 = fmk_ceil_div(n, S);
+    int64_t nb[64];
+    int K = 0;
+    nb[0] = nblk0;
+    while (nb[K] > 1) { nb[K + 1] = (nb[K] + 1) / 2; ++K; }
+    size_t tbl = 0, ents = 0;
+    for (int k = 0; k <= K; ++k) { tbl += (size_t)nb[k] * S; ents += (size_t)nb[k]; }
+    FMK_TRY(vol_ensure(ctx, &c.work3, &c.work3_bytes, 2 * tbl * 4 + ents * (4 + 8) + 256));
+    uint32_t *Eall = (uint32_t *)c.work3;
+    uint32_t *Call = Eall + tbl;
+    int64_t *offall = (int64_t *)(Call + tbl);
+    uint32_t *entall = (uint32_t *)(offall + ents);
+    uint32_t *E[64], *C[64], *ent[64];
+    int64_t *off[64];
+    {
+        size_t to = 0, eo = 0;
+        for (int k = 0; k <= K; ++k) {
+            E[k] = Eall + to; C[k] = Call + to; to += (size_t)nb[k] * S;
+            ent[k] = entall + eo; off[k] = offall + eo; eo += (size_t)nb[k];
+        }
+    }
+    k_vg_level0<<<(unsigned)fmk_ceil_div(nblk0 * S, 256), 256, 0, ctx->stream>>>(nxt, n, ls, nblk0 * S, E[0], C[0]);
+    FMK_LAUNCH_CHECK(ctx);
+    for (int k = 1; k <= K; ++k) {
+        k_vol_level_up<<<(unsigned)fmk_ceil_div(nb[k] * S, 256), 256, 0, ctx->stream>>>(
+            ls, E[k - 1], C[k - 1], nb[k - 1], S << (k - 1), E[k], C[k], nb[k], d_status);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    int64_t closes = 0;
+    if (root != VOL_END) {
+        if ((int64_t)root >= S) return 1;
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], C[K] + root, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_mail[1] & VOL_ST_OVERFLOW) return 1;
+        closes = (int64_t)(ctx->h_mail[0] & 0xFFFFFFFFu);
+    }
+    c.count = closes + 1;
+    if (c.dbuf && c.cap < c.count) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
+    if (!c.dbuf) { FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.count * 8)); c.cap = c.count; }
+    const int64_t one = 1;
+    FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int k = K; k >= 1; --k) {
+        k_vol_descend<<<(unsigned)fmk_ceil_div(nb[k], 256), 256, 0, ctx->stream>>>(
+            ls, ent[k], off[k], nb[k], S << (k - 1), E[k - 1], C[k - 1], nb[k - 1], ent[k - 1], off[k - 1]);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    k_vol_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(ls, ent[0], off[0], nblk0, nxt, c.dbuf, c.cap,
+                                                                            fragile, c.d_list, d_pstat, nullptr, thr);
+    FMK_LAUNCH_CHECK(ctx);
+    return vol_certify(ctx, a, is_f64, n, thr, c);
 }
 
 extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
@@ -754,19 +1216,21 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         const int64_t ns = n < ((int64_t)1 << 19) ? n : ((int64_t)1 << 19);
         int rcs = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &est_total, false, ns)
                                 : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &est_total, false, ns);
-        if (rcs) return rcs;
+        if (rcs && rcs != 2) return rcs;
         const double est_len = est_total > 0.0 ? (double)ns * threshold / est_total : 1e300;
         int rc = 1;
         if (est_len < 1800.0)
             rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
         if (rc == 1) {
-            // a bar longer than 2048 ticks (or expected).  The exact mean bar length from the total volume decides: the
-            // 4096-tick tables (one workgroup per CU) only when the bars are short enough on average
+            // a bar longer than 2048 ticks (or expected).  The exact mean bar length from the total volume decides the tier
             double total = 0.0;
             int rc2 = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &total)
                                     : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &total);
-            if (rc2) return rc2;
+            if (rc2 && rc2 != 2) return rc2;
+            if (rc2 == 2 || rcs == 2)
+                return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
+                                            n_idx, n_uncertified);
             const double mean_len = total > 0.0 ? (double)n * threshold / total : 1e300;
             bool prefix_ok = true;          // the table tiers build in c.work too: after one of them the prefix is gone
             if (est_len >= 1800.0 && mean_len < 1400.0) {    // the sample misled: short bars after all
@@ -774,17 +1238,23 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
                 rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                    : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
             }
-            if (rc == 1 && mean_len < 3000.0) {
-                prefix_ok = false;
-                rc = amount_is_f64 ? vol_run<true, 4096>(ctx, d_amount, n, threshold, c)
-                                   : vol_run<false, 4096>(ctx, d_amount, n, threshold, c);
+            // bars beyond the 2048-tick LDS tables: global tables up to ~64K ticks (26 ms at 1e9 ticks whatever the length;
+            // the 4096-tick LDS tables this used to try first cost 33 ms), the chain walk beyond
+            if (rc == 1 && mean_len < 65536.0 && !getenv("FMK_VOLUME_NO_GLOBAL")) {
+                if (!prefix_ok) {            // a table attempt overwrote the prefix of the total pass
+                    rc2 = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &total)
+                                        : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &total);
+                    if (rc2) return rc2;
+                    prefix_ok = true;
+                }
+                rc = vol_global_tables(ctx, d_amount, amount_is_f64, n, threshold, c, mean_len);
             }
             if (rc == 1)     // few, long bars: walk the chain with wave-parallel searches (total pass's prefix if still there)
                 rc = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, false, nullptr, prefix_ok)
                                    : vol_chase<false>(ctx, d_amount, n, threshold, c, false, nullptr, prefix_ok);
         }
-        if (rc == 2) rc = 1;
-        if (rc == 1)     // bar longer than the table span, or negative volumes
+        if (rc == 2 || rc == 3) rc = 1;
+        if (rc == 1)     // negative volumes, or a fragile decision whose replay disagrees
             return fmk_threshold_serial(ctx, 0, nullptr, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                         n_idx, n_uncertified);
         if (rc) return rc;

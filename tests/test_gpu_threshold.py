@@ -97,3 +97,117 @@ def test_threshold_knife_edge_is_exact_by_default(orc):
             assert np.array_equal(t.dollar_bar_index(dthr).to_host(), want) and t.last_uncertified == 0
     assert reported >= 4, f"the construction should put the last decision on the edge: {reported} of 8 inputs reported one"
     print("knife edge: uncertified reported for", reported, "of 8 inputs; the parallel result differed on", hits)
+
+
+@pytest.mark.parametrize("seed,sigma,f64,L", [(1, 1.0, True, 3500), (3, 0.5, False, 8000), (4, 2.5, True, 6000),
+                                             (5, 1.0, True, 20000), (6, 3.0, True, 12000), (7, 1.0, True, 40000)])
+def test_volume_bars_of_thousands_of_ticks_continuous_amounts(orc, seed, sigma, f64, L):
+    """Mean bar lengths between the LDS tables (<= 4096 ticks) and the chain walk: the global jump tables of
+    fmk_volume.hip (k_vg_nxt / k_vg_level0).  Lognormal amounts, so prefix-sum differences are NOT the reference's
+    sequential sums and the certification is live; whales (bars of one tick among the long ones); streams shorter than
+    one table span; a threshold that is some tick's sequential running sum to the last bit (decision 1 on a knife edge:
+    listed by the kernels, replayed by k_vol_verify, and redone serially when the replay disagrees)."""
+    from finmlkit_amd.bar.logic import _volume_bar_indexer
+    rng = np.random.default_rng(seed)
+    for n in (1_200_000, 70_001, 5_000):
+        am = rng.lognormal(0.0, sigma, n).astype(np.float64 if f64 else np.float32)
+        if seed == 6:
+            am[rng.integers(0, n, 20)] *= 5e4
+        thr = float(am.astype(np.float64).mean()) * L
+        edge = float(np.cumsum(am.astype(np.float64))[min(n - 1, L)])
+        for t in (thr, edge):
+            np.testing.assert_array_equal(_volume_bar_indexer(am, t), orc._volume_bar_indexer(am, t), err_msg=f"n={n} thr={t!r}")
+
+
+def test_volume_long_bars_negative_amounts_take_the_serial_walk(orc):
+    """Prefix sums must not decrease for any of the parallel tiers: a negative (or NaN) amount anywhere sends the input to
+    the serial walk, whatever the bar length (the prefix pass of the long-bar tiers used not to look)."""
+    from finmlkit_amd.bar.logic import _volume_bar_indexer
+    rng = np.random.default_rng(11)
+    for n, L in ((400_000, 5000), (400_000, 90_000), (3_000, 5000)):
+        am = rng.lognormal(0.0, 1.0, n)
+        am[n // 2] = -3.0 * am[n // 2] - 50.0
+        thr = float(np.abs(am).mean()) * L
+        np.testing.assert_array_equal(_volume_bar_indexer(am, thr), orc._volume_bar_indexer(am, thr), err_msg=f"n={n} L={L}")
+
+
+def test_volume_exact_mode_certifies_on_the_chain_only(orc):
+    """n_uncertified counts fragile decisions ON THE CHAIN OF CLOSES (those the result depends on), not over every tick's
+    hypothetical bar -- and the default mode replays exactly those with the reference's sequential sum.  For continuous
+    amounts the default therefore costs what the fast mode costs: it reports 0 after a confirmed replay."""
+    from finmlkit_amd import _ffi, engine
+    rng = np.random.default_rng(21)
+    n = 2_000_000
+    am = rng.lognormal(0.0, 1.0, n)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), am)
+    ctx = _ffi.default_context()
+    cs = np.cumsum(am)
+    for L in (90, 900, 3000, 9000, 150_000):
+        # thr = the sequential running sum at tick L: the first decision is an exact tie for the reference (it closes at L)
+        for thr in (float(am.mean()) * L, float(cs[L])):
+            want = orc._volume_bar_indexer(am, thr)
+            ctx.set_fast_threshold(True)
+            try:
+                fast = t.volume_bar_index(thr).to_host()
+                unc_fast = t.last_uncertified
+            finally:
+                ctx.set_fast_threshold(False)
+            exact = t.volume_bar_index(thr).to_host()
+            assert t.last_uncertified == 0
+            np.testing.assert_array_equal(exact, want, err_msg=f"L={L} thr={thr!r}")
+            if not np.array_equal(fast, want):
+                assert unc_fast > 0, f"L={L}: the parallel result differs from the reference without a reported decision"
+            if thr == float(cs[L]):
+                assert unc_fast >= 1, f"L={L}: the tie at tick {L} was not reported"
+            assert unc_fast < 50, f"L={L}: {unc_fast} fragile decisions on a chain of {len(want)} closes?"
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_volume_decimal_lots_round_threshold(orc, f64):
+    """Decimal lots with a round threshold: sums of 0.1, 0.2, ... hit the threshold EXACTLY in one summation order and
+    miss it by an ulp in another (100 x 0.1 is 9.99999999999998 in tick order).  An exact tie of the parallel evaluation
+    is therefore certain only for exactly-summable streams (multiples of 2^-20: the kernels check); here every such tie
+    must be listed and replayed -- on all tiers (bar lengths 50 .. 200 000 ticks)."""
+    from finmlkit_amd import _ffi, engine
+    from finmlkit_amd.bar.logic import _volume_bar_indexer
+    rng = np.random.default_rng(31)
+    n = 1_000_000
+    am = (rng.integers(1, 10, n) / 10.0).astype(np.float64 if f64 else np.float32)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), am)
+    ctx = _ffi.default_context()
+    reported = 0
+    for thr in (25.0, 500.0, 1500.0, 2500.0, 10_000.0, 100_000.0):
+        want = orc._volume_bar_indexer(am, thr)
+        np.testing.assert_array_equal(_volume_bar_indexer(am, thr), want, err_msg=f"thr={thr}")
+        ctx.set_fast_threshold(True)
+        try:
+            fast = t.volume_bar_index(thr).to_host()
+            unc = t.last_uncertified
+        finally:
+            ctx.set_fast_threshold(False)
+        reported += unc > 0
+        if not np.array_equal(fast, want):
+            assert unc > 0, f"thr={thr}: the parallel result differs from the reference without a reported decision"
+    if f64:
+        assert reported >= 3, f"exact ties of decimal lots should be reported: {reported} of 6 thresholds"
+
+
+def test_volume_integer_lots_ties_are_certain(orc):
+    """Integer (and dyadic) lots: every sum is exact in float64 in any order, an exact tie IS the reference's decision --
+    nothing is listed although a large share of the closes are exact hits."""
+    from finmlkit_amd import _ffi, engine
+    rng = np.random.default_rng(32)
+    n = 1_000_000
+    am = (rng.integers(1, 9, n) * 0.25).astype(np.float32)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), am)
+    ctx = _ffi.default_context()
+    for thr in (10.0, 1000.0, 4000.0, 9000.0, 300_000.0):
+        want = orc._volume_bar_indexer(am, thr)
+        ctx.set_fast_threshold(True)
+        try:
+            fast = t.volume_bar_index(thr).to_host()
+            unc = t.last_uncertified
+        finally:
+            ctx.set_fast_threshold(False)
+        np.testing.assert_array_equal(fast, want, err_msg=f"thr={thr}")
+        assert unc == 0, f"thr={thr}: {unc} decisions listed for an exactly-summable stream"
