@@ -20,9 +20,11 @@
 // Total work O(N) + 2*log2(N/S) tiny launches; no sequential pass over the stream.
 //
 // Arithmetic: bar sums are differences of block-local float64 prefix sums (not the reference's
-// sequential sum from the bar start); a candidate decision within 1e-11*thr of the threshold is counted
-// in n_uncertified (0 => provably the reference's indices; always 0 for exactly-summable amounts such as
-// the dyadic synthetic stream).  Domain: thr > 0, v >= 0, bars <= 2048 ticks, N < 2^31 -- anything else
+// sequential sum from the bar start).  Every decision gets a class per tick (0 certain, 1 within
+// (1e-11 + 2^-52 * length) * thr of the threshold, 2 exact tie); the emit pass lists the classes != 0 ON THE CHAIN
+// (ties only for streams that are not exactly summable), k_vol_verify replays those bars with the reference's sequential
+// sum, n_uncertified = 0 when all are confirmed.  Tiers by mean bar length: these LDS tables (S = 2048), the global
+// tables further down (to 64 K ticks), the chain walk (beyond).  Domain: thr > 0, v >= 0, N < 2^31 -- anything else
 // falls back to the serial walk of fmk_threshold.hip.
 #include <math.h>
 #include <stdlib.h>
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     // Lp[i] = sum of the first i ticks from the block start, stored PADDED (one slot per 8): thread t later probes
     // around element 8t + (bar length), i.e. with a lane stride of 8 doubles -- unpadded that is a 16-way bank conflict
 #define LP(i) Lp[(i) + ((i) >> 3)]
-    // dynamic LDS (S = 2048: 53 KB, S = 4096: 106 KB -- the larger table span is the fallback for streams whose
+    // dynamic LDS (S = 2048: 53.3 KB = exactly three workgroups per CU; S = 4096, 106 KB, was the tier for streams whose
     // longest bar exceeds 2048 ticks): [Lp | Eb | Cb | wtot]
     constexpr int LPN = 2 * S + 1 + (2 * S + 1) / 8 + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char vol_smem[];
