@@ -104,19 +104,25 @@ def other_configs(trades, ctx, args):
         vthr = vol_total / max(span_days, 1e-9) / 2000.0                 # QuickStart: daily volume / 2000
         dthr = vthr * float(np.median(o["close"].to_host()))
         del o
-        # the parallel indexers as such: decisions within the rounding drift of the reference's float64 running sum are
-        # counted, not redone by the exact sequential loop (the library's default; tens of ns per tick, not for 1e9 ticks)
-        ctx.set_fast_threshold(True)
+        # volume bars: the library's default (exact) mode -- fragile decisions on the chain of closes are replayed with the
+        # reference's sequential sum, so the count that comes back is 0 unless a replay disagreed
         out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr))
         out["cfg3_volume_uncertified"] = int(trades.last_uncertified)
-        out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
-        out["cfg3_dollar_uncertified"] = int(trades.last_uncertified)
         out["cfg3_n_volume_bars"] = int(trades.volume_bar_index(vthr).n)
-        ctx.set_fast_threshold(False)
+        # dollar bars: the parallel indexer as such.  Decisions within the rounding drift of the reference's float64 running
+        # sum (which never resets for dollar bars) are counted, not redone by the exact sequential loop (the default there;
+        # tens of ns per tick, not for 1e9 ticks)
+        ctx.set_fast_threshold(True)
+        try:
+            out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
+            out["cfg3_dollar_uncertified"] = int(trades.last_uncertified)
+        finally:
+            ctx.set_fast_threshold(False)
         out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
         out["cfg4_bytes_per_tick"] = 38
-        out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: parallel indexers with "
-                       "fmk_ctx_set_fast_threshold(1) -- each uncertified decision may differ from the reference by one tick")
+        out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume in the default exact "
+                       "mode; dollar with fmk_ctx_set_fast_threshold(1) -- each uncertified decision may differ from the "
+                       "reference by one tick")
     except Exception as e:                                               # noqa: BLE001 -- informational only
         out["error"] = f"{type(e).__name__}: {e}"
     return out

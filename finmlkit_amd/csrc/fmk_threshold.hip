@@ -62,7 +62,11 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
 #pragma unroll
         for (int k = 1; k < TH_ITEMS; ++k) s[k] = s[k - 1] + cur[k];
         const double inc = fmk_wave_iscan(s[TH_ITEMS - 1]);
-        const double ex = inc - s[TH_ITEMS - 1];
+        // the exclusive prefix comes from the previous lane, not from inc - s[last]: with a NaN (or inf) increment in this
+        // lane the subtraction would poison the lane's EARLIER ticks too, which the reference still closes on
+        // (tools/fuzz_volume.py seed 2 case 185)
+        double ex = __shfl_up(inc, 1, 64);
+        if (lane == 0) ex = 0.0;
         const double chunk_total = __shfl(inc, 63, 64);
         const int64_t i0 = base + (int64_t)lane * TH_ITEMS;
         double off = 0.0;                         // chunk-prefix value at the last close in this chunk

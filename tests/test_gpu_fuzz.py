@@ -20,3 +20,16 @@ def test_fuzz_sharded_fixed_seed():
     from tools.fuzz_sharded import sweep
     fails, ran = sweep(10, 20260928, verbose=False)
     assert ran >= 8 and not fails, "\n".join(fails[:5])
+
+
+@pytest.mark.parametrize("kind,seed", [("volume", 1), ("volume", 2), ("dollar", 1)])
+def test_fuzz_threshold_indexers_fixed_seed(orc, kind, seed):
+    """tools/fuzz_volume.py: streams up to 1e6 ticks of lognormal / decimal / integer / quarter lots, zeros, whales, NaN and
+    negative amounts or prices; thresholds as multiples of the mean (bar lengths 0.5 .. 3e5 ticks: every tier), round
+    numbers, some tick's running sum to the last bit, the total.  Exact mode equals the oracle with n_uncertified == 0; the
+    fast mode may only differ when it reports a decision.  (Seed 2 holds the NaN case that exposed the poisoned exclusive
+    prefix of the chunked serial walk.)"""
+    from tools.fuzz_volume import run
+    bad, reported, fast_diff = run(seed, 120, 1_000_000, kind, verbose=False)
+    assert bad == 0
+    print(f"{kind} seed {seed}: fast mode reported decisions in {reported} of 120 cases, differed from the reference in {fast_diff}")
