@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_threshold_exact(const double *__restrict
                                                         int64_t n, double thr, int64_t *__restrict__ out, int64_t cap,
                                                         int64_t *__restrict__ result /*[2]: count, uncertified = 0*/)
 {
-    __shared__ double s_d[64];
+    __shared__ __attribute__((aligned(16))) double s_d[64];
     const int lane = fmk_lane();
     int64_t m = 1;
     if (lane == 0 && cap > 0) out[0] = 0;        // logic.py:104 / 138
@@ -142,16 +142,56 @@ __global__ __launch_bounds__(64) void k_threshold_exact(const double *__restrict
         s_d[lane] = cur;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
+            // The chain cum -> add -> compare -> select is the whole cost (one lane, nothing to overlap it with), so it is kept
+            // to exactly those operations: 8 increments per LDS read, no branch per tick (a close is a select and a bit in
+            // `hits`), the closes are written after the group.  65 ns per tick with a load, a branch and a store inside the
+            // loop (tools/serialbench.py).
             const int lim = (int)(n - base < 64 ? n - base : 64);
-            for (int q = 0; q < lim; ++q) {
-                const int64_t i = base + q;
-                if (i == 0) { cum = s_d[0]; continue; }          // cum = volumes[0] (logic.py:107)
-                cum += s_d[q];
-                if (cum >= thr) {
-                    if (m < cap) out[m] = i;
-                    ++m;
-                    cum = DOLLAR ? cum - thr : 0.0;
+            uint64_t hits = 0;
+            if (base > 0 && lim == 64) {
+                // full groups: nothing but the chain.  The close bits go through the ballot into scalar registers (lane 0 is
+                // the only active lane), off the vector pipe and off the dependency chain; conditions on the tick index
+                // (first tick, end of the stream) would put a VALU -> SALU -> VALU round trip through VCC into every step
+#pragma unroll
+                for (int q8 = 0; q8 < 64; q8 += 8) {
+                    double d[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[k] = s_d[q8 + k];
+                    // speculate that none of these 8 ticks closes (bars are mostly longer than that): then the reference's
+                    // operations are just the 8 additions, in order -- one dependent instruction per tick, the compares hang
+                    // off the chain.  Only a batch with a close pays for the add -> compare -> select chain per tick.
+                    double sp[8];
+                    sp[0] = cum + d[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) sp[k] = sp[k - 1] + d[k];
+                    bool any = false;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) any |= sp[k] >= thr;
+                    if (__builtin_amdgcn_ballot_w64(any) == 0) { cum = sp[7]; continue; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        cum += d[k];
+                        const bool hit = cum >= thr;
+                        const double after = DOLLAR ? cum - thr : 0.0;     // logic.py:147 carry / logic.py:113 reset
+                        hits |= (uint64_t)(__builtin_amdgcn_ballot_w64(hit) & 1) << (q8 + k);
+                        cum = hit ? after : cum;
+                    }
                 }
+            } else {
+                for (int q = 0; q < lim; ++q) {
+                    if (base + q == 0) { cum = s_d[0]; continue; }          // cum = volumes[0] (logic.py:107); tick 0 cannot close
+                    cum += s_d[q];
+                    if (cum >= thr) {
+                        hits |= (uint64_t)1 << q;
+                        cum = DOLLAR ? cum - thr : 0.0;
+                    }
+                }
+            }
+            while (hits) {
+                const int q = __ffsll((unsigned long long)hits) - 1;
+                hits &= hits - 1;
+                if (m < cap) out[m] = base + q;
+                ++m;
             }
         }
         __builtin_amdgcn_wave_barrier();
