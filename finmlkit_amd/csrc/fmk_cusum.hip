@@ -21,6 +21,7 @@
 // need hundreds of rounds -- still exact, but then the method has no advantage over the sequential loop.
 // The sigma forward-fill (logic.py:176-189, done IN PLACE like the reference) is a "last non-NaN" scan.
 #include <math.h>
+#include <stdlib.h>
 
 #include "fmk_common.h"
 #include "fmk_scan.h"
@@ -284,11 +285,12 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
                                                     const unsigned char *__restrict__ active, const int *__restrict__ list,
                                                     int64_t n_list, int max_steps)
 {
-    // 64 ticks at a time: all lanes compute ret / lam (the expressions of k_cusum_prep) into two LDS rows, then lane 0 alone
+    // 256 ticks at a time: all lanes compute ret / lam (the expressions of k_cusum_prep) into two LDS rows, then lane 0 alone
     // walks them in its own vector registers, branch-free (selects instead of if / else: the same values as the loop of
     // k_cusum_chunks).  A first version walked with wave-uniform scalars through v_readlane and scalar branches: 18
     // instructions but ~540 cycles per tick -- every tick went VGPR -> SGPR -> VALU -> VCC -> branch.
-    __shared__ double s_r[4][64], s_l[4][64];
+    constexpr int G = 4;                                            // 64-tick rows per group
+    __shared__ __attribute__((aligned(16))) double s_r[4][64 * G], s_l[4][64 * G];
     const int lane = fmk_lane();
     const int wib = (int)(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * 4 + wib;
@@ -301,55 +303,85 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
         const int64_t t0 = k * CS_CHUNK;
         const int len = (int)(m - t0 < CS_CHUNK ? m - t0 : CS_CHUNK);
         int64_t cnt = 0;
-        // raw inputs of a group of 64 ticks, all five loads issued together and one group ahead: loaded one after the other
-        // and only when needed (price -> log, then ts, then sigma) a group cost three memory round trips, ~10 us
-        double c_p = 1.0, c_pm = 1.0, c_sg = 0.0;
-        int64_t c_ts = 0, c_tsn = 1;
-        auto fetch = [&](int j0, double &p, double &pm, double &sg, int64_t &tsi, int64_t &tsn) {
-            int64_t i = first + 1 + t0 + j0 + lane;
-            if (i > n - 1) i = n - 1;                                   // lanes past the chunk: any valid address
-            p = price[i]; pm = price[i - 1]; sg = sigma[i]; tsi = ts[i];
-            tsn = ts[i + 1 < n ? i + 1 : i];
+        // raw inputs of a group of 256 ticks (4 per lane), all twenty loads issued together and one group ahead.  Loaded one
+        // after the other and only when needed (price -> log, then ts, then sigma) a 64-tick group cost three memory round
+        // trips, ~10 us; with 64-tick groups prefetched one ahead the round trip (2-3 us) was still longer than the
+        // walk of a group once that had been shortened to ~1 us: 256 ticks per group balance the two.
+        double c_p[G], c_pm[G], c_sg[G];
+        int64_t c_ts[G], c_tsn[G];
+        auto fetch = [&](int j0, double (&p)[G], double (&pm)[G], double (&sg)[G], int64_t (&tsi)[G], int64_t (&tsn)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int64_t i = first + 1 + t0 + j0 + 64 * g + lane;
+                if (i > n - 1) i = n - 1;                               // lanes past the chunk: any valid address
+                p[g] = price[i]; pm[g] = price[i - 1]; sg[g] = sigma[i]; tsi[g] = ts[i];
+                tsn[g] = ts[i + 1 < n ? i + 1 : i];
+            }
         };
         fetch(0, c_p, c_pm, c_sg, c_ts, c_tsn);
 #ifdef CS_TIMING
         long long tA = 0, tB = 0, t0c = __builtin_readcyclecounter(), t1c;
 #endif
-        for (int j0 = 0; j0 < len; j0 += 64) {
-            const int64_t t = t0 + j0 + lane;
-            double n_p = 1.0, n_pm = 1.0, n_sg = 0.0;
-            int64_t n_ts = 0, n_tsn = 1;
-            if (j0 + 64 < len) fetch(j0 + 64, n_p, n_pm, n_sg, n_ts, n_tsn);
-            double r = 0.0, lam = NAN;
-            if (j0 + lane < len) {                                      // the expressions of k_cusum_prep
-                const int64_t i = first + 1 + t;
-                r = log(c_p / c_pm);
-                const bool block = i + 1 < n && c_ts == c_tsn;
-                if (!block) {
-                    lam = sigma_mult * c_sg;
-                    lam = sigma_floor > lam ? sigma_floor : lam;
+        for (int j0 = 0; j0 < len; j0 += 64 * G) {
+            double n_p[G], n_pm[G], n_sg[G];
+            int64_t n_ts[G], n_tsn[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { n_p[g] = 1.0; n_pm[g] = 1.0; n_sg[g] = 0.0; n_ts[g] = 0; n_tsn[g] = 1; }
+            if (j0 + 64 * G < len) fetch(j0 + 64 * G, n_p, n_pm, n_sg, n_ts, n_tsn);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int jj = j0 + 64 * g + lane;
+                double r = 0.0, lam = NAN;
+                if (jj < len) {                                         // the expressions of k_cusum_prep
+                    const int64_t i = first + 1 + t0 + jj;
+                    r = log(c_p[g] / c_pm[g]);
+                    const bool block = i + 1 < n && c_ts[g] == c_tsn[g];
+                    if (!block) {
+                        lam = sigma_mult * c_sg[g];
+                        lam = sigma_floor > lam ? sigma_floor : lam;
+                    }
                 }
+                s_r[wib][64 * g + lane] = r;
+                s_l[wib][64 * g + lane] = lam;
+                c_p[g] = n_p[g]; c_pm[g] = n_pm[g]; c_sg[g] = n_sg[g]; c_ts[g] = n_ts[g]; c_tsn[g] = n_tsn[g];
             }
-            c_p = n_p; c_pm = n_pm; c_sg = n_sg; c_ts = n_ts; c_tsn = n_tsn;
-            s_r[wib][lane] = r;
-            s_l[wib][lane] = lam;
             __builtin_amdgcn_wave_barrier();
 #ifdef CS_TIMING
             t1c = __builtin_readcyclecounter(); tA += t1c - t0c; t0c = t1c;
 #endif
-            const int lim = len - j0 < 64 ? len - j0 : 64;
+            const int lim = len - j0 < 64 * G ? len - j0 : 64 * G;
             if (lane == 0) {
-#pragma unroll 8
-                for (int q = 0; q < lim; ++q) {                         // the loop of k_cusum_chunks, as selects
-                    const double ret = s_r[wib][q], lm = s_l[wib][q];
-                    const double a = sp + ret, b = sn + ret;
-                    sp = a > 0.0 ? a : 0.0;
-                    sn = b < 0.0 ? b : 0.0;
-                    const bool cp = sp >= lm;
-                    const bool cn = !cp && sn <= -lm;
-                    cnt += (cp || cn) ? 1 : 0;
-                    sp = cp ? 0.0 : sp;
-                    sn = cn ? 0.0 : sn;
+                for (int q8 = 0; q8 < lim; q8 += 8) {
+                    const int nq = lim - q8 < 8 ? lim - q8 : 8;
+                    if (nq == 8) {
+                        // speculate that none of these 8 ticks closes (in this regime closes are thousands of ticks apart):
+                        // then the loop is add -> clamp per side and tick, the two sides are independent chains and the
+                        // compares hang off them.  Same operations, same order as the careful form below.
+                        double r8[8], l8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { r8[q] = s_r[wib][q8 + q]; l8[q] = s_l[wib][q8 + q]; }
+                        double p = sp, g2 = sn;
+                        bool any = false;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const double a = p + r8[q], b = g2 + r8[q];
+                            p = a > 0.0 ? a : 0.0;
+                            g2 = b < 0.0 ? b : 0.0;
+                            any |= (p >= l8[q]) | (g2 <= -l8[q]);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(any) == 0) { sp = p; sn = g2; continue; }
+                    }
+                    for (int q = q8; q < q8 + nq; ++q) {                // the loop of k_cusum_chunks, as selects
+                        const double ret = s_r[wib][q], lm = s_l[wib][q];
+                        const double a = sp + ret, b = sn + ret;
+                        sp = a > 0.0 ? a : 0.0;
+                        sn = b < 0.0 ? b : 0.0;
+                        const bool cp = sp >= lm;
+                        const bool cn = !cp && sn <= -lm;
+                        cnt += (cp || cn) ? 1 : 0;
+                        sp = cp ? 0.0 : sp;
+                        sn = cn ? 0.0 : sn;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -1100,12 +1100,18 @@ static int vol_certify(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, doubl
     return FMK_OK;
 }
 
+// workspace of the global tier (5 + 16 bytes per tick).  Returns 1 -- "use the next tier" -- when the device cannot
+// provide it: the chain walk needs no tables, and a full HBM is no reason to fail the call.
 static int vol_ensure(fmk_ctx *ctx, void **buf, size_t *have, size_t bytes)
 {
     if (*have >= bytes) return FMK_OK;
     if (*buf) FMK_HIP(ctx, hipFree(*buf));
     *buf = nullptr; *have = 0;
-    FMK_HIP(ctx, hipMalloc(buf, bytes));
+    if (hipMalloc(buf, bytes) != hipSuccess) {
+        (void)hipGetLastError();                                    // clear the sticky out-of-memory error
+        *buf = nullptr;
+        return 1;
+    }
     *have = bytes;
     return FMK_OK;
 }
