@@ -20,13 +20,15 @@
 // Total work O(N) + 2*log2(N/S) tiny launches; no sequential pass over the stream.
 //
 // Arithmetic: bar sums are differences of block-local float64 prefix sums (not the reference's
-// sequential sum from the bar start).  Every decision gets a class per tick (0 certain, 1 within
-// (1e-11 + 2^-52 * length) * thr of the threshold, 2 exact tie); the emit pass lists the classes != 0 ON THE CHAIN
-// (ties only for streams that are not exactly summable), k_vol_verify replays those bars with the reference's sequential
-// sum, n_uncertified = 0 when all are confirmed.  Tiers by mean bar length: these LDS tables (S = 2048), the global
-// tables further down (to 64 K ticks), the chain walk (beyond).  Domain: thr > 0, v >= 0, N < 2^31 -- anything else
-// falls back to the serial walk of fmk_threshold.hip.
+// sequential sum from the bar start).  Every decision gets a class (0 certain, 1 within (1e-11 + 2^-52 * length) * thr of
+// the threshold, 2 exact tie -- fragile unless the sums are exact in float64).  Exact mode (the default): a fragile decision
+// is settled by replaying its bar with the reference's sequential sum -- inline here, in a pass of its own in the global
+// tier, on the chain only (k_vol_emit's list -> k_vol_verify) for what remains; n_uncertified comes back 0.  Fast mode:
+// the classes are only counted, on the chain.  Tiers by mean bar length: these LDS tables (S = 2048), the global tables
+// further down (to 64 K ticks), the chain walk (beyond).  Domain: thr > 0, v >= 0, N < 2^31 -- anything else falls back
+// to the serial walk of fmk_threshold.hip.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "fmk_common.h"
@@ -61,7 +63,9 @@ __device__ __forceinline__ bool vol_ties_fragile(const int *status, double thr)
 // `fragile` (one byte per tick, may be null): the decision nxt(j) was within the certification margin.  Only decisions ON
 // THE CHAIN matter: their ordinals (decision q produces out[q]; q == count is the final "no further close") are appended
 // to `list` ([0] = how many, then the ordinals) for k_vol_verify.
-#define VOL_LIST_CAP 4096
+// capacity of the list (8 MB): each entry replays ONE bar, so the replay work is bounded by the stream length whatever the
+// count; decimal lots with a round threshold tie on a sizeable share of their bars (tests: 1e6 ticks, thr 25 -> thousands)
+#define VOL_LIST_CAP (1 << 20)
 __device__ __forceinline__ void vol_list_append(int64_t *list, int64_t q)
 {
     const unsigned long long pos = atomicAdd((unsigned long long *)list, 1ULL);
@@ -73,7 +77,8 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                                                             uint32_t *__restrict__ nxt, uint32_t *__restrict__ E0,
                                                             uint32_t *__restrict__ C0, uint32_t *__restrict__ root,
                                                             int *__restrict__ status, int *__restrict__ root_tie,
-                                                            unsigned char *__restrict__ fragile, int64_t *__restrict__ list)
+                                                            unsigned char *__restrict__ fragile, int64_t *__restrict__ list,
+                                                            int replay)
 {
     constexpr int PER = 2 * S / VOL_THREADS;          // prefix elements per thread
     constexpr int EPT = S / VOL_THREADS;              // table entries per thread
@@ -117,7 +122,21 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     if (tid == 0) LP(0) = 0.0;
     if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);
     if (__ballot(inexact) != 0 && lane == 0) vol_flag(status, VOL_ST_INEXACT);
-    __syncthreads();
+    // are exact ties of THIS block's decisions certain?  They involve only the block's own 2S ticks
+    const bool ties = __syncthreads_or(inexact ? 1 : 0) != 0 || !(thr < 2147483648.0);
+    // Exact mode (replay != 0): a fragile decision is settled on the spot by the reference's own computation for that bar --
+    // cum = 0, += v in tick order from the tick after j (logic.py:107-113) -- so the tables are built from links that are
+    // either certain by their margin or computed exactly.  Work: (fragile ticks) x (bar length) additions spread over all
+    // lanes; decimal lots with a round threshold tie on ~1/4 of their ticks, continuous amounts on ~1e-9 of them.
+    auto replay_from = [&](int64_t j, double cum, bool *too_long) -> uint32_t {
+        const int64_t lim = j + S < n - 1 ? j + S : n - 1;
+        for (int64_t t = j + 1; t <= lim; ++t) {
+            cum += fmk_amt<AF64>(amount, t);
+            if (cum >= thr) return (uint32_t)t;
+        }
+        if (lim < n - 1) *too_long = true;                          // no close within S ticks although data remains
+        return VOL_END;
+    };
     // ---- nxt(j) for every tick of the block: smallest m > i+1 with Lp[m] - Lp[i+1] >= thr.
     //      Thread t owns the EPT CONSECUTIVE ticks i = t*EPT + q: nxt is non-decreasing in i, so after one bisection
     //      for its first tick the thread only walks forward (amortised ~1 probe per tick instead of log2(2S) = 12).
@@ -150,11 +169,13 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                 nx = (uint32_t)(bs + lo - 1);
                 const double over = LP(lo) - target, under = target - LP(lo - 1);
                 frag = ((over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol)) ? 1 : (over == 0.0 ? 2 : 0);
+                if (replay && (frag == 1 || (frag == 2 && ties))) { nx = replay_from(bs + i, 0.0, &ovf); frag = 0; }
             } else if (i + 1 + S <= mmax) {
                 ovf = true;                                          // no close within S ticks although data remains
                 carry_lo = 0;
             } else {
                 if (hi >= lo) frag = target - LP(hi) <= tol ? 1 : 0;
+                if (replay && frag) { nx = replay_from(bs + i, 0.0, &ovf); frag = 0; }      // the rest of the stream: < S ticks
                 carry_lo = 0;
             }
         }
@@ -181,12 +202,21 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
             }
             r = (uint32_t)(lo - 1);
             const double over = LP(lo) - thr, under = thr - LP(lo - 1);       // decision 1 (the first bar)
-            if ((over > 0.0 && over <= tol) || (lo - 1 >= 2 && under <= tol)) vol_list_append(list, 1);
+            const bool near = (over > 0.0 && over <= tol) || (lo - 1 >= 2 && under <= tol);
+            if (replay) {
+                if (near || (over == 0.0 && ties)) {                // cum = volumes[0], then += from tick 1 (logic.py:107)
+                    bool too_long = false;
+                    r = replay_from(0, fmk_amt<AF64>(amount, 0), &too_long);
+                    if (too_long || (r != VOL_END && r >= (uint32_t)S)) atomicOr(status, VOL_ST_OVERFLOW);
+                }
+            } else if (near) vol_list_append(list, 1);
             else if (over == 0.0) *root_tie = 1;        // k_vol_emit lists it when the stream is not exactly summable
         } else if (S <= mmax) {
             atomicOr(status, VOL_ST_OVERFLOW);
         } else if (hi >= 1 && thr - LP(hi) <= tol) {
-            vol_list_append(list, 1);                   // the whole (short) stream comes within the margin of one bar
+            // the whole (short) stream comes within the margin of one bar
+            if (replay) { bool too_long = false; r = replay_from(0, fmk_amt<AF64>(amount, 0), &too_long); }
+            else vol_list_append(list, 1);
         }
         *root = r;
     }
@@ -363,7 +393,7 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     size_t ents = 0;
     for (int k = 0; k <= K; ++k) ents += (size_t)nblk[k];
     const size_t bytes = ((size_t)nblk0 * S + 2 * tbl) * 4 + ents * (4 + 8) + 256 + (size_t)nblk0 * S;
-    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, ((size_t)1 + VOL_LIST_CAP) * 8));
     FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
     if (c.work_bytes < bytes) {
         if (c.work) FMK_HIP(ctx, hipFree(c.work));
@@ -396,7 +426,8 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
             FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vol_level0<AF64, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds));
         k_vol_level0<AF64, S><<<(unsigned)nblk0, VOL_THREADS, lds, ctx->stream>>>(a, n, thr, nxt, E[0], C[0], d_root,
-                                                                                  d_status, d_root_tie, fragile, c.d_list);
+                                                                                  d_status, d_root_tie, fragile, c.d_list,
+                                                                                  ctx->fast_threshold ? 0 : 1);
     }
     FMK_LAUNCH_CHECK(ctx);
     for (int k = 1; k <= K; ++k) {
@@ -789,7 +820,7 @@ static int vol_chase(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCach
             FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)cap * 8));
             c.cap = cap;
         }
-        if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+        if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, ((size_t)1 + VOL_LIST_CAP) * 8));
         FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
         k_vc_chase<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, c.dbuf, c.cap, d_res, c.d_list, d_bad);
         FMK_LAUNCH_CHECK(ctx);
@@ -848,7 +879,8 @@ __device__ __forceinline__ int vg_search(const double *s_lp, double b, double l0
 
 __global__ __launch_bounds__(256) void k_vg_nxt(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
                                                 int64_t nblk, double thr, uint32_t *__restrict__ nxt,
-                                                unsigned char *__restrict__ fragile, unsigned *__restrict__ maxlen)
+                                                unsigned char *__restrict__ fragile, unsigned *__restrict__ maxlen,
+                                                const int *__restrict__ status, unsigned long long *__restrict__ n_fragile)
 {
     __shared__ double s_end_all[4][64];
     __shared__ double s_lp_all[4][VG_SLP_DOUBLES];
@@ -969,10 +1001,12 @@ __global__ __launch_bounds__(256) void k_vg_nxt(const double *__restrict__ Lp, c
             }
             have = true;
             res[k] = (uint32_t)m;
-            if (m != (int64_t)VOL_END && m - j > wmax) wmax = m - j;
         }
         __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (res[k] != VOL_END && (int64_t)res[k] - (j0 + k) > wmax) wmax = (int64_t)res[k] - (j0 + k);
     if (j0 + 7 < n) {
         uint4 *o = (uint4 *)(nxt + j0);
         o[0] = make_uint4(res[0], res[1], res[2], res[3]);
@@ -988,6 +1022,14 @@ __global__ __launch_bounds__(256) void k_vg_nxt(const double *__restrict__ Lp, c
     }
     wmax = fmk_wave_max(wmax);
     if (lane == 0 && (unsigned)wmax > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)wmax);
+    if ((blk & 63) == 0) {                                         // every 64th block: an estimate of the live fragile ticks
+        const bool ties = vol_ties_fragile(status, thr);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnt += (frag[k] == 1 || (frag[k] == 2 && ties)) ? 1 : 0;
+        cnt = (int)fmk_wave_sum(cnt);
+        if (lane == 0 && cnt) atomicAdd(n_fragile, (unsigned long long)cnt);
+    }
 }
 
 // first close: tick 0 is counted but cannot close -> first m >= 1 with sum(0 .. m) >= thr (logic.py:104-108)
@@ -1078,6 +1120,49 @@ __global__ __launch_bounds__(64) void k_vol_verify(const void *__restrict__ amou
     if (m != expect) atomicOr(mismatch, 1);
 }
 
+// Global tier, exact mode: every tick whose decision is fragile gets its link from the reference's own computation for
+// the bar that starts after it (cum = 0, += v in tick order, logic.py:107-113), BEFORE the tables are built -- the tables
+// then are exact by construction (k_vol_level0 does the same inline).  Thread 0 settles a listed first-bar decision too.
+// Work: (fragile ticks) x (bar length) additions side by side, measured ~4e-12 s each (tools/certbench.py decimal: tenth
+// lots tie on ~1/5 of their ticks); the host runs this pass only while that beats the serial walk's 19 ns per tick.
+// Two cheaper-looking schemes were built and measured first, both on the chain only: (1) replay the fragile decisions of
+// the emitted chain, patch the disagreeing links, rebuild -- each new stretch of chain has its own fragile decisions, half of
+// which change again, and a shifted chain needs ~10 bars to re-join: 819, 763, 771, 769 ... listed decisions per round, a
+// critical branching process; (2) let the thread that finds a disagreement follow the exact chain until it re-joins the
+// emitted one -- converges in one round, but the emitted chain is wrong at ~10 % of its bars, so the exact chain is almost
+// never on it and the thread walks the stream: 3.3 s for 2e7 ticks.
+template <bool AF64>
+__global__ __launch_bounds__(256) void k_vg_replay(const void *__restrict__ amount, int64_t n, double thr,
+                                                   uint32_t *__restrict__ nxt, unsigned char *__restrict__ fragile,
+                                                   const int *__restrict__ status, unsigned *__restrict__ maxlen,
+                                                   uint32_t *__restrict__ root, int64_t *__restrict__ list)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0 && list[0] > 0) {                                     // decision 1 was listed by k_vg_root
+        double cum = fmk_amt<AF64>(amount, 0);
+        uint32_t m = VOL_END;
+        for (int64_t t = 1; t < n; ++t) {
+            cum += fmk_amt<AF64>(amount, t);
+            if (cum >= thr) { m = (uint32_t)t; break; }
+        }
+        *root = m;
+        list[0] = 0;
+        if (m != VOL_END && m > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, m);
+    }
+    const unsigned char f = fragile[j];
+    if (!(f == 1 || (f == 2 && vol_ties_fragile(status, thr)))) return;
+    double cum = 0.0;
+    uint32_t m = VOL_END;
+    for (int64_t t = j + 1; t < n; ++t) {
+        cum += fmk_amt<AF64>(amount, t);
+        if (cum >= thr) { m = (uint32_t)t; break; }
+    }
+    nxt[j] = m;
+    fragile[j] = 0;
+    if (m != VOL_END && (unsigned)(m - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(m - j));
+}
+
 // certification of the listed decisions; returns FMK_OK with c.unc = 0 (all replayed and confirmed) or the raw count in
 // fast mode, or 3 (a replay disagrees / more fragile decisions than the list holds -> serial walk)
 static int vol_certify(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, double thr, VolCache &c)
@@ -1126,7 +1211,7 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     const VcDD *Bb = (const VcDD *)((char *)c.work + lp_bytes + tot_bytes);
     const size_t nxt_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
     FMK_TRY(vol_ensure(ctx, &c.work2, &c.work2_bytes, nxt_bytes + (size_t)n + 256));
-    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, (1 + VOL_LIST_CAP) * 8));
+    if (!c.d_list) FMK_HIP(ctx, hipMalloc((void **)&c.d_list, ((size_t)1 + VOL_LIST_CAP) * 8));
     uint32_t *nxt = (uint32_t *)c.work2;
     unsigned char *fragile = (unsigned char *)c.work2 + nxt_bytes;
     uint32_t *d_root = (uint32_t *)(ctx->d_mail + 36);
@@ -1134,12 +1219,27 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     int *d_status = (int *)(ctx->d_mail + 38);
     FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 36, 0, 24, ctx->stream));
     FMK_HIP(ctx, hipMemsetAsync(c.d_list, 0, 8, ctx->stream));
-    k_vg_nxt<<<(unsigned)fmk_ceil_div(nblk, 4), 256, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, nxt, fragile, d_maxlen);
     const int *d_pstat = (const int *)(ctx->d_mail + 40);          // status of the prefix pass (k_vc_prefix)
+    unsigned long long *d_nfrag = (unsigned long long *)(ctx->d_mail + 39);
+    FMK_HIP(ctx, hipMemsetAsync(d_nfrag, 0, 8, ctx->stream));
+    k_vg_nxt<<<(unsigned)fmk_ceil_div(nblk, 4), 256, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, nxt, fragile, d_maxlen, d_pstat,
+                                                                       d_nfrag);
     k_vg_root<<<1, 64, 0, ctx->stream>>>(Lp, Bb, n, nblk, thr, d_root, c.d_list, d_pstat);
     FMK_LAUNCH_CHECK(ctx);
-    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 32, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->fast_threshold) {
+        // exact mode: settle the fragile ticks before the tables are built -- while that is cheaper than the serial walk
+        const double est_fragile = (double)ctx->h_mail[3] * (nblk >= 64 ? 64.0 : (double)nblk);
+        if (est_fragile * mean_len > 4000.0 * (double)n) return 3;
+        if (is_f64) k_vg_replay<true><<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat,
+                                                                                              d_maxlen, d_root, c.d_list);
+        else k_vg_replay<false><<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat,
+                                                                                         d_maxlen, d_root, c.d_list);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 16, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const uint32_t root = (uint32_t)(ctx->h_mail[0] & 0xFFFFFFFFu);
     const int64_t longest = (int64_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
     int ls = 12;

@@ -88,10 +88,11 @@ int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms)
  * pair on the context stream (ring of 64).  fmk_profile_read synchronises and returns the durations. */
 /* Volume / dollar bar indexers: the parallel algorithms work on exactly computed sums and count the decisions that
  * land within the rounding drift of the reference's float64 running sum (n_uncertified).  on = 0 (default):
- * volume bars -- the fragile decisions on the chain of closes are replayed with the reference's sequential sum and
- * n_uncertified comes back 0 when all are confirmed (the usual case, at no measurable cost); a disagreeing replay, and
- * any uncertified dollar-bar input (the carried remainder never resets: no bar can be replayed alone), is redone by the
- * reference's own loop, operation for operation (one wave, tens of ns per tick: meant for host-array sizes).
+ * volume bars -- fragile decisions are settled by replaying their bar with the reference's sequential sum (every
+ * bar starts from 0, so it can be replayed alone) and n_uncertified comes back 0: at no measurable cost for continuous
+ * amounts, at (fragile ticks) x (bar length) additions for decimal lots with round thresholds; when that would cost more
+ * than it, and for any uncertified dollar-bar input (the carried remainder never resets: no bar can be replayed alone),
+ * the input is redone by the reference's own loop, operation for operation (one wave, 15-22 ns per tick).
  * on = 1: the parallel result is returned as is, each uncertified decision may differ from the reference by one tick
  * (resident pipelines of 1e9 ticks). */
 int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on);

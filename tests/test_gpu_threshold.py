@@ -211,3 +211,32 @@ def test_volume_integer_lots_ties_are_certain(orc):
             ctx.set_fast_threshold(False)
         np.testing.assert_array_equal(fast, want, err_msg=f"thr={thr}")
         assert unc == 0, f"thr={thr}: {unc} decisions listed for an exactly-summable stream"
+
+
+def test_volume_decimal_lots_many_ties_stay_on_the_parallel_path(orc):
+    """3e6 ticks of tenth lots, threshold 25: thousands of closes are exact ties of the parallel evaluation.  All of them are
+    listed and replayed (the list holds 2^20 decisions; each replays one bar) -- the result is the oracle's and the call
+    stays far below the serial walk's 15-22 ns per tick."""
+    import time
+    from finmlkit_amd import _ffi, engine
+    rng = np.random.default_rng(33)
+    n = 3_000_000
+    am = rng.integers(1, 10, n) / 10.0
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), am)
+    ctx = _ffi.default_context()
+    want = orc._volume_bar_indexer(am, 25.0)
+    ctx.set_fast_threshold(True)
+    try:
+        t.volume_bar_index(25.0)
+        listed = t.last_uncertified
+    finally:
+        ctx.set_fast_threshold(False)
+    assert listed > 4096, f"the construction should tie on thousands of closes: {listed}"
+    t.volume_bar_index(25.0); ctx.sync()
+    t0 = time.perf_counter()
+    got = t.volume_bar_index(25.0).to_host()
+    dt = time.perf_counter() - t0
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    assert dt < 0.02, f"{dt * 1e3:.1f} ms: the serial walk would take ~50 ms for {n} ticks"
+    print(f"{listed} tied or near-tied decisions of {len(want) - 1} closes replayed; {dt * 1e3:.2f} ms")

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Volume bar indexer on CONTINUOUS amounts (lognormal float64, where prefix-sum differences are not exact): time in the
 default exact mode (fragile decisions on the chain are replayed) against the fast mode, per tier, and against the oracle.
-usage: certbench.py [N] [L1,L2,...]"""
+With `decimal`, the amounts are tenth lots (0.1 .. 0.9) and the thresholds round numbers: exact ties on ~1/5 of the closes,
+each settled by an in-kernel replay of that bar in the exact mode.
+usage: certbench.py [N] [L1,L2,...] [lognormal|decimal]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,14 +12,15 @@ from oracle import oracle as orc
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
 LENGTHS = [int(float(x)) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 865, 1500, 2500, 5000, 30000, 200000]
+dist = sys.argv[3] if len(sys.argv) > 3 else "lognormal"
 rng = np.random.default_rng(5)
-am = rng.lognormal(0.0, 1.0, n)
+am = rng.lognormal(0.0, 1.0, n) if dist == "lognormal" else rng.integers(1, 10, n) / 10.0
 ctx = _ffi.default_context()
 t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), am, ctx=ctx)
 mean_v = float(am.mean())
-print(f"n={n} lognormal float64 amounts, mean {mean_v:.4f}")
+print(f"n={n} {dist} float64 amounts, mean {mean_v:.4f}")
 for L in LENGTHS:
-    thr = mean_v * L
+    thr = mean_v * L if dist == "lognormal" else float(round(mean_v * L))
     row = []
     res = {}
     for mode in ("exact", "fast"):
