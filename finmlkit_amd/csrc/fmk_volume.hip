@@ -1135,10 +1135,10 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_vg_replay(const void *__restrict__ amount, int64_t n, double thr,
                                                    uint32_t *__restrict__ nxt, unsigned char *__restrict__ fragile,
                                                    const int *__restrict__ status, unsigned *__restrict__ maxlen,
-                                                   uint32_t *__restrict__ root, int64_t *__restrict__ list)
+                                                   uint32_t *__restrict__ root, int64_t *__restrict__ list, int64_t n_threads)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= n_threads) return;                                      // n_threads = n, or 1: only the first decision
     if (j == 0 && list[0] > 0) {                                     // decision 1 was listed by k_vg_root
         double cum = fmk_amt<AF64>(amount, 0);
         uint32_t m = VOL_END;
@@ -1161,6 +1161,84 @@ __global__ __launch_bounds__(256) void k_vg_replay(const void *__restrict__ amou
     nxt[j] = m;
     fragile[j] = 0;
     if (m != VOL_END && (unsigned)(m - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(m - j));
+}
+
+// Few fragile ticks (continuous amounts: ~2e-11 x length^2 per tick) and long bars: a single thread replaying a 30 000-tick
+// bar runs at ~180 ns per tick (dependent, uncoalesced loads) and the whole pass waits for it.  So the live fragile ticks
+// are compacted (k_vg_fragile_list) and, when they fit the list, each gets a WAVE: coalesced loads of 64 ticks, lane 0 adds
+// them in tick order, 8 at a time on the assumption that none of them closes (the form of k_threshold_exact, ~20 ns per tick).
+#define VG_REPLAY_LIST_CAP 65536
+__global__ __launch_bounds__(256) void k_vg_fragile_list(const unsigned char *__restrict__ fragile, int64_t n, double thr,
+                                                         const int *__restrict__ status, uint32_t *__restrict__ ticks,
+                                                         unsigned long long *__restrict__ count)
+{
+    const bool ties = vol_ties_fragile(status, thr);
+    const int64_t j0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (j0 >= n) return;
+    if (j0 + 7 < n) {
+        const unsigned long long fb = *(const unsigned long long *)(fragile + j0);
+        if (fb == 0) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned f = (unsigned)(fb >> (8 * k)) & 0xFF;
+            if (f == 1 || (f == 2 && ties)) {
+                const unsigned long long pos = atomicAdd(count, 1ULL);
+                if (pos < VG_REPLAY_LIST_CAP) ticks[pos] = (uint32_t)(j0 + k);
+            }
+        }
+    } else {
+        for (int64_t j = j0; j < n; ++j) {
+            const unsigned f = fragile[j];
+            if (f == 1 || (f == 2 && ties)) {
+                const unsigned long long pos = atomicAdd(count, 1ULL);
+                if (pos < VG_REPLAY_LIST_CAP) ticks[pos] = (uint32_t)j;
+            }
+        }
+    }
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(64) void k_vg_replay_wave(const void *__restrict__ amount, int64_t n, double thr,
+                                                       uint32_t *__restrict__ nxt, unsigned char *__restrict__ fragile,
+                                                       const uint32_t *__restrict__ ticks, unsigned *__restrict__ maxlen)
+{
+    __shared__ __attribute__((aligned(16))) double s_v[64];
+    const int lane = fmk_lane();
+    const int64_t j = ticks[blockIdx.x];
+    double cum = 0.0;
+    int64_t m = -1;
+    double cur = j + 1 + lane < n ? fmk_amt<AF64>(amount, j + 1 + lane) : 0.0;
+    for (int64_t base = j + 1; base < n && m < 0; base += 64) {
+        const double nx = base + 64 + lane < n ? fmk_amt<AF64>(amount, base + 64 + lane) : 0.0;
+        s_v[lane] = cur;                                            // ticks past the end add 0.0: cum < thr stays
+        __builtin_amdgcn_wave_barrier();
+        int hit = -1;
+        if (lane == 0) {
+            for (int q8 = 0; q8 < 64 && hit < 0; q8 += 8) {
+                double d[8], sp[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = s_v[q8 + k];
+                sp[0] = cum + d[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) sp[k] = sp[k - 1] + d[k];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) any |= sp[k] >= thr;
+                if (!any) { cum = sp[7]; continue; }
+#pragma unroll
+                for (int k = 7; k >= 0; --k) if (sp[k] >= thr) hit = q8 + k;     // the first one (sums of v >= 0 do not decrease)
+            }
+        }
+        hit = __builtin_amdgcn_readfirstlane(hit);
+        if (hit >= 0) m = base + hit;
+        __builtin_amdgcn_wave_barrier();
+        cur = nx;
+    }
+    if (lane == 0) {
+        nxt[j] = m < 0 ? VOL_END : (uint32_t)m;
+        fragile[j] = 0;
+        if (m >= 0 && (unsigned)(m - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(m - j));
+    }
 }
 
 // certification of the listed decisions; returns FMK_OK with c.unc = 0 (all replayed and confirmed) or the raw count in
@@ -1232,10 +1310,27 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
         // exact mode: settle the fragile ticks before the tables are built -- while that is cheaper than the serial walk
         const double est_fragile = (double)ctx->h_mail[3] * (nblk >= 64 ? 64.0 : (double)nblk);
         if (est_fragile * mean_len > 4000.0 * (double)n) return 3;
-        if (is_f64) k_vg_replay<true><<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat,
-                                                                                              d_maxlen, d_root, c.d_list);
-        else k_vg_replay<false><<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat,
-                                                                                         d_maxlen, d_root, c.d_list);
+        int64_t few = -1;                                           // live fragile ticks when they fit the wave-replay list
+        if (est_fragile < (double)VG_REPLAY_LIST_CAP / 2) {
+            uint32_t *ticks = (uint32_t *)(c.d_list + 1 + VOL_LIST_CAP / 2);     // upper half of the chain list: unused until the emit
+            FMK_HIP(ctx, hipMemsetAsync(d_nfrag, 0, 8, ctx->stream));
+            k_vg_fragile_list<<<(unsigned)fmk_ceil_div(fmk_ceil_div(n, 8), 256), 256, 0, ctx->stream>>>(fragile, n, thr, d_pstat,
+                                                                                                      ticks, d_nfrag);
+            FMK_LAUNCH_CHECK(ctx);
+            FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[3], d_nfrag, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_mail[3] <= VG_REPLAY_LIST_CAP) few = ctx->h_mail[3];
+            if (few > 0) {
+                if (is_f64) k_vg_replay_wave<true><<<(unsigned)few, 64, 0, ctx->stream>>>(a, n, thr, nxt, fragile, ticks, d_maxlen);
+                else k_vg_replay_wave<false><<<(unsigned)few, 64, 0, ctx->stream>>>(a, n, thr, nxt, fragile, ticks, d_maxlen);
+            }
+        }
+        // thread per tick: whatever the wave pass did not take (everything when there are many), and a listed first decision
+        const int64_t n_thr = few >= 0 ? 1 : n;
+        if (is_f64) k_vg_replay<true><<<(unsigned)fmk_ceil_div(n_thr, 256), 256, 0, ctx->stream>>>(
+                        a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list, n_thr);
+        else k_vg_replay<false><<<(unsigned)fmk_ceil_div(n_thr, 256), 256, 0, ctx->stream>>>(
+                        a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list, n_thr);
         FMK_LAUNCH_CHECK(ctx);
         FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 16, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
