@@ -51,6 +51,32 @@ int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const 
 // order, 10.0 in other orders) an exact tie is as fragile as a near tie.  The kernels that read the amounts set
 // VOL_ST_INEXACT; ties are recorded as their own class (fragile byte 2) and count as fragile when the bit is set.
 __device__ __forceinline__ bool vol_amount_inexact(double v) { return !(v * 1048576.0 == rint(v * 1048576.0) && v < 1048576.0); }
+// The reference's loop for one bar (logic.py:107-113): cum += v[t] for t = from .. last in tick order, close at the first
+// cum >= thr (not before tick `min_close`: tick 0 cannot close).  Returns the close tick or -1.  Eight amounts are loaded
+// before they are added: with the exit test between a load and the next one, a lane had ONE load in flight and ran at
+// ~230 ns per tick.
+template <bool AF64>
+__device__ __forceinline__ int64_t vol_replay(const void *__restrict__ amount, int64_t from, int64_t last, double cum, double thr,
+                                              int64_t min_close)
+{
+    int64_t t = from;
+    for (; t + 7 <= last; t += 8) {
+        double d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = fmk_amt<AF64>(amount, t + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cum += d[k];
+            if (cum >= thr && t + k >= min_close) return t + k;
+        }
+    }
+    for (; t <= last; ++t) {
+        cum += fmk_amt<AF64>(amount, t);
+        if (cum >= thr && t >= min_close) return t;
+    }
+    return -1;
+}
+
 __device__ __forceinline__ void vol_flag(int *status, int bit)     // one atomic per kernel, not per wave
 {
     if (!(__atomic_load_n(status, __ATOMIC_RELAXED) & bit)) atomicOr(status, bit);
@@ -130,10 +156,8 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     // lanes; decimal lots with a round threshold tie on ~1/4 of their ticks, continuous amounts on ~1e-9 of them.
     auto replay_from = [&](int64_t j, double cum, bool *too_long) -> uint32_t {
         const int64_t lim = j + S < n - 1 ? j + S : n - 1;
-        for (int64_t t = j + 1; t <= lim; ++t) {
-            cum += fmk_amt<AF64>(amount, t);
-            if (cum >= thr) return (uint32_t)t;
-        }
+        const int64_t m = vol_replay<AF64>(amount, j + 1, lim, cum, thr, 1);
+        if (m >= 0) return (uint32_t)m;
         if (lim < n - 1) *too_long = true;                          // no close within S ticks although data remains
         return VOL_END;
     };
@@ -1111,19 +1135,14 @@ __global__ __launch_bounds__(64) void k_vol_verify(const void *__restrict__ amou
     const int64_t start = q <= 1 ? 0 : out[q - 1] + 1;
     const int64_t expect = q < count ? out[q] : -1;
     const int64_t stop = expect >= 0 ? expect : n - 1;              // the replay may stop once it has passed the expected close
-    double cum = 0.0;
-    int64_t m = -1;
-    for (int64_t i = start; i <= stop; ++i) {
-        cum += fmk_amt<AF64>(amount, i);
-        if (i >= 1 && cum >= thr) { m = i; break; }
-    }
+    const int64_t m = vol_replay<AF64>(amount, start, stop, 0.0, thr, 1);
     if (m != expect) atomicOr(mismatch, 1);
 }
 
 // Global tier, exact mode: every tick whose decision is fragile gets its link from the reference's own computation for
 // the bar that starts after it (cum = 0, += v in tick order, logic.py:107-113), BEFORE the tables are built -- the tables
 // then are exact by construction (k_vol_level0 does the same inline).  Thread 0 settles a listed first-bar decision too.
-// Work: (fragile ticks) x (bar length) additions side by side, measured ~4e-12 s each (tools/certbench.py decimal: tenth
+// Work: (fragile ticks) x (bar length) additions side by side, measured ~2.4e-12 s each (tools/certbench.py decimal: tenth
 // lots tie on ~1/5 of their ticks); the host runs this pass only while that beats the serial walk's 19 ns per tick.
 // Two cheaper-looking schemes were built and measured first, both on the chain only: (1) replay the fragile decisions of
 // the emitted chain, patch the disagreeing links, rebuild -- each new stretch of chain has its own fragile decisions, half of
@@ -1140,24 +1159,16 @@ __global__ __launch_bounds__(256) void k_vg_replay(const void *__restrict__ amou
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_threads) return;                                      // n_threads = n, or 1: only the first decision
     if (j == 0 && list[0] > 0) {                                     // decision 1 was listed by k_vg_root
-        double cum = fmk_amt<AF64>(amount, 0);
-        uint32_t m = VOL_END;
-        for (int64_t t = 1; t < n; ++t) {
-            cum += fmk_amt<AF64>(amount, t);
-            if (cum >= thr) { m = (uint32_t)t; break; }
-        }
+        const int64_t r = vol_replay<AF64>(amount, 1, n - 1, fmk_amt<AF64>(amount, 0), thr, 1);
+        const uint32_t m = r < 0 ? VOL_END : (uint32_t)r;
         *root = m;
         list[0] = 0;
         if (m != VOL_END && m > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, m);
     }
     const unsigned char f = fragile[j];
     if (!(f == 1 || (f == 2 && vol_ties_fragile(status, thr)))) return;
-    double cum = 0.0;
-    uint32_t m = VOL_END;
-    for (int64_t t = j + 1; t < n; ++t) {
-        cum += fmk_amt<AF64>(amount, t);
-        if (cum >= thr) { m = (uint32_t)t; break; }
-    }
+    const int64_t r = vol_replay<AF64>(amount, j + 1, n - 1, 0.0, thr, 1);
+    const uint32_t m = r < 0 ? VOL_END : (uint32_t)r;
     nxt[j] = m;
     fragile[j] = 0;
     if (m != VOL_END && (unsigned)(m - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(m - j));
@@ -1309,7 +1320,7 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     if (!ctx->fast_threshold) {
         // exact mode: settle the fragile ticks before the tables are built -- while that is cheaper than the serial walk
         const double est_fragile = (double)ctx->h_mail[3] * (nblk >= 64 ? 64.0 : (double)nblk);
-        if (est_fragile * mean_len > 4000.0 * (double)n) return 3;
+        if (est_fragile * mean_len > 7000.0 * (double)n) return 3;  // 2.4e-12 s per replayed addition against 19 ns per tick
         int64_t few = -1;                                           // live fragile ticks when they fit the wave-replay list
         if (est_fragile < (double)VG_REPLAY_LIST_CAP / 2) {
             uint32_t *ticks = (uint32_t *)(c.d_list + 1 + VOL_LIST_CAP / 2);     // upper half of the chain list: unused until the emit
