@@ -128,20 +128,22 @@ def test_threshold_bars_full_size(big, prefix, orc):
     ts, px, am, sd = prefix
     vthr = 1728.5                     # ~864 ticks per bar (median daily volume / 2000 of this stream)
     dthr = vthr * 10_000.0
-    # The PARALLEL indexers at full size: with the library's default, a dollar run with uncertified decisions (a few hundred
-    # of 1.16e6 at 1e9 ticks: the reference's float64 sum has drifted by ~1e-7 relative by then) would be redone by the exact
-    # sequential loop, ~60 s for 1e9 ticks.  Exactness of that fallback is tested at host-array sizes
-    # (test_gpu_threshold.py, tools/fuzz_parity.py); here the parallel result is checked on the prefix the oracle covers,
-    # where no decision is uncertified yet.
+    # Volume bars in the library's DEFAULT (exact) mode: fragile decisions are settled by replaying their bar, which costs
+    # nothing measurable here.  Dollar bars with the parallel indexer as such: with the default, a run with uncertified
+    # decisions (a few hundred of 1.16e6 at 1e9 ticks: the reference's float64 sum, which never resets, has drifted by ~1e-7
+    # relative by then) would be redone by the exact sequential loop, ~20 s for 1e9 ticks.  Exactness of that fallback is
+    # tested at host-array sizes (test_gpu_threshold.py, tools/fuzz_volume.py); here the parallel result is checked on the
+    # prefix the oracle covers, where no decision is uncertified yet.
+    _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr, ("volume",))
     t.ctx.set_fast_threshold(True)
     try:
-        _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr)
+        _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr, ("dollar",))
     finally:
         t.ctx.set_fast_threshold(False)
 
 
-def _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr):
-    for kind in ("volume", "dollar"):
+def _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr, kinds):
+    for kind in kinds:
         ci = (t.volume_bar_index(vthr) if kind == "volume" else t.dollar_bar_index(dthr)).to_host()
         want = orc._volume_bar_indexer(am, vthr) if kind == "volume" else orc._dollar_bar_indexer(px, am, dthr)
         assert ci[0] == 0 and np.all(np.diff(ci) > 0) and ci[-1] < n
