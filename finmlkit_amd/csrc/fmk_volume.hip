@@ -59,21 +59,34 @@ template <bool AF64>
 __device__ __forceinline__ int64_t vol_replay(const void *__restrict__ amount, int64_t from, int64_t last, double cum, double thr,
                                               int64_t min_close)
 {
+    // Every lane replays its own bar, so a wave's load touches 64 different lines and the pass runs at the rate the CU
+    // generates addresses (measured: 3.5e10 additions in 69 ms on 256 CUs = one lane-address per clock per CU).  Hence
+    // 16-byte loads -- 2 doubles or 4 floats per address -- and sixteen amounts in flight before the first is added.
+    constexpr int ELEM = AF64 ? 8 : 4;
     int64_t t = from;
-    for (; t + 7 <= last; t += 8) {
-        double d[8];
+    auto step = [&](double v, int64_t at) -> bool { cum += v; return cum >= thr && at >= min_close; };
+    for (; t <= last && (((uintptr_t)amount + (uintptr_t)t * ELEM) & 15) != 0; ++t)
+        if (step(fmk_amt<AF64>(amount, t), t)) return t;
+    for (; t + 15 <= last; t += 16) {
+        double d[16];
+        if constexpr (AF64) {
+            const double2 *p = (const double2 *)((const double *)amount + t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = fmk_amt<AF64>(amount, t + k);
+            for (int k = 0; k < 8; ++k) { const double2 x = p[k]; d[2 * k] = x.x; d[2 * k + 1] = x.y; }
+        } else {
+            const float4 *p = (const float4 *)((const float *)amount + t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            cum += d[k];
-            if (cum >= thr && t + k >= min_close) return t + k;
+            for (int k = 0; k < 4; ++k) {
+                const float4 x = p[k];
+                d[4 * k] = (double)x.x; d[4 * k + 1] = (double)x.y; d[4 * k + 2] = (double)x.z; d[4 * k + 3] = (double)x.w;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (step(d[k], t + k)) return t + k;
     }
-    for (; t <= last; ++t) {
-        cum += fmk_amt<AF64>(amount, t);
-        if (cum >= thr && t >= min_close) return t;
-    }
+    for (; t <= last; ++t)
+        if (step(fmk_amt<AF64>(amount, t), t)) return t;
     return -1;
 }
 
@@ -193,13 +206,11 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
                 nx = (uint32_t)(bs + lo - 1);
                 const double over = LP(lo) - target, under = target - LP(lo - 1);
                 frag = ((over > 0.0 && over <= tol) || (lo - 1 > i + 1 && under <= tol)) ? 1 : (over == 0.0 ? 2 : 0);
-                if (replay && (frag == 1 || (frag == 2 && ties))) { nx = replay_from(bs + i, 0.0, &ovf); frag = 0; }
             } else if (i + 1 + S <= mmax) {
                 ovf = true;                                          // no close within S ticks although data remains
                 carry_lo = 0;
             } else {
                 if (hi >= lo) frag = target - LP(hi) <= tol ? 1 : 0;
-                if (replay && frag) { nx = replay_from(bs + i, 0.0, &ovf); frag = 0; }      // the rest of the stream: < S ticks
                 carry_lo = 0;
             }
         }
@@ -208,13 +219,6 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     }                                                                // S = 2048 is 53.3 KB, exactly three workgroups per CU
     if (__ballot(ovf) != 0 && lane == 0) atomicOr(status, VOL_ST_OVERFLOW);   // one atomic per wave, not per tick
     __syncthreads();
-    for (int q = 0; q < EPT; ++q) {                                  // coalesced copy of the chain links
-        const int i = q * VOL_THREADS + tid;
-        nxt[bs + i] = Eb[i];
-        const uint32_t cf = Cb[i];
-        fragile[bs + i] = (unsigned char)(cf >> 30);
-        Cb[i] = cf & 0x3FFFFFFFu;
-    }
     // first bar (block 0): tick 0 is counted but cannot close -> first j >= 1 with P_j >= thr
     if (blockIdx.x == 0 && tid == 0) {
         uint32_t r = VOL_END;
@@ -243,6 +247,38 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
             else vol_list_append(list, 1);
         }
         *root = r;
+    }
+    __syncthreads();
+    if (replay) {
+        // ---- exact mode: the block's live fragile ticks, compacted (the prefix sums are dead now: their LDS holds the list)
+        //      and dealt out evenly -- replaying where they are found left 4 of 5 lanes idle, because ~1/5 of a decimal
+        //      stream's ticks are fragile but SOME lane of every wave is at every step (61 -> 18 ms per 2e8 ticks of tenth lots in 865-tick bars)
+        int *lcount = (int *)Lp;
+        unsigned short *llist = (unsigned short *)(lcount + 1);
+        if (tid == 0) *lcount = 0;
+        __syncthreads();
+        for (int q = 0; q < EPT; ++q) {
+            const int i = q * VOL_THREADS + tid;
+            const uint32_t cls = Cb[i] >> 30;
+            if (cls == 1 || (cls == 2 && ties)) llist[atomicAdd(lcount, 1)] = (unsigned short)i;
+        }
+        __syncthreads();
+        const int nlist = *lcount;
+        bool too_long = false;
+        for (int it = tid; it < nlist; it += VOL_THREADS) {
+            const int i = llist[it];
+            Eb[i] = replay_from(bs + i, 0.0, &too_long);
+            Cb[i] &= 0x3FFFFFFFu;
+        }
+        if (__ballot(too_long) != 0 && lane == 0) atomicOr(status, VOL_ST_OVERFLOW);
+        __syncthreads();
+    }
+    for (int q = 0; q < EPT; ++q) {                                  // coalesced copy of the chain links
+        const int i = q * VOL_THREADS + tid;
+        nxt[bs + i] = Eb[i];
+        const uint32_t cf = Cb[i];
+        fragile[bs + i] = (unsigned char)(cf >> 30);
+        Cb[i] = cf & 0x3FFFFFFFu;
     }
     __syncthreads();
     // ---- pointer doubling inside the block: E -> first node >= block end, C -> nodes inside the block
@@ -1142,7 +1178,7 @@ __global__ __launch_bounds__(64) void k_vol_verify(const void *__restrict__ amou
 // Global tier, exact mode: every tick whose decision is fragile gets its link from the reference's own computation for
 // the bar that starts after it (cum = 0, += v in tick order, logic.py:107-113), BEFORE the tables are built -- the tables
 // then are exact by construction (k_vol_level0 does the same inline).  Thread 0 settles a listed first-bar decision too.
-// Work: (fragile ticks) x (bar length) additions side by side, measured ~2.4e-12 s each (tools/certbench.py decimal: tenth
+// Work: (fragile ticks) x (bar length) additions side by side, measured ~7e-13 s each (tools/certbench.py decimal: tenth
 // lots tie on ~1/5 of their ticks); the host runs this pass only while that beats the serial walk's 19 ns per tick.
 // Two cheaper-looking schemes were built and measured first, both on the chain only: (1) replay the fragile decisions of
 // the emitted chain, patch the disagreeing links, rebuild -- each new stretch of chain has its own fragile decisions, half of
@@ -1154,24 +1190,50 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_vg_replay(const void *__restrict__ amount, int64_t n, double thr,
                                                    uint32_t *__restrict__ nxt, unsigned char *__restrict__ fragile,
                                                    const int *__restrict__ status, unsigned *__restrict__ maxlen,
-                                                   uint32_t *__restrict__ root, int64_t *__restrict__ list, int64_t n_threads)
+                                                   uint32_t *__restrict__ root, int64_t *__restrict__ list, int only_root)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_threads) return;                                      // n_threads = n, or 1: only the first decision
-    if (j == 0 && list[0] > 0) {                                     // decision 1 was listed by k_vg_root
+    // a block takes 2048 ticks: their live fragile ticks are compacted into LDS and dealt out evenly (see k_vol_level0:
+    // replaying them where they sit leaves most lanes idle)
+    __shared__ int lcount;
+    __shared__ unsigned short llist[2048];
+    const int tid = threadIdx.x;
+    const int64_t bs = (int64_t)blockIdx.x * 2048;
+    if (blockIdx.x == 0 && tid == 0 && list[0] > 0) {                // decision 1 was listed by k_vg_root
         const int64_t r = vol_replay<AF64>(amount, 1, n - 1, fmk_amt<AF64>(amount, 0), thr, 1);
         const uint32_t m = r < 0 ? VOL_END : (uint32_t)r;
         *root = m;
         list[0] = 0;
         if (m != VOL_END && m > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, m);
     }
-    const unsigned char f = fragile[j];
-    if (!(f == 1 || (f == 2 && vol_ties_fragile(status, thr)))) return;
-    const int64_t r = vol_replay<AF64>(amount, j + 1, n - 1, 0.0, thr, 1);
-    const uint32_t m = r < 0 ? VOL_END : (uint32_t)r;
-    nxt[j] = m;
-    fragile[j] = 0;
-    if (m != VOL_END && (unsigned)(m - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(m - j));
+    if (only_root) return;
+    if (tid == 0) lcount = 0;
+    __syncthreads();
+    const bool ties = vol_ties_fragile(status, thr);
+    const int64_t j0 = bs + (int64_t)tid * 8;
+    if (j0 + 7 < n) {
+        const unsigned long long fb = *(const unsigned long long *)(fragile + j0);
+        if (fb != 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned f = (unsigned)(fb >> (8 * k)) & 0xFF;
+                if (f == 1 || (f == 2 && ties)) llist[atomicAdd(&lcount, 1)] = (unsigned short)(tid * 8 + k);
+            }
+        }
+    } else {
+        for (int k = 0; k < 8 && j0 + k < n; ++k) {
+            const unsigned f = fragile[j0 + k];
+            if (f == 1 || (f == 2 && ties)) llist[atomicAdd(&lcount, 1)] = (unsigned short)(tid * 8 + k);
+        }
+    }
+    __syncthreads();
+    const int nlist = lcount;
+    for (int it = tid; it < nlist; it += 256) {
+        const int64_t j = bs + llist[it];
+        const int64_t r = vol_replay<AF64>(amount, j + 1, n - 1, 0.0, thr, 1);
+        nxt[j] = r < 0 ? VOL_END : (uint32_t)r;
+        fragile[j] = 0;
+        if (r >= 0 && (unsigned)(r - j) > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, (unsigned)(r - j));
+    }
 }
 
 // Few fragile ticks (continuous amounts: ~2e-11 x length^2 per tick) and long bars: a single thread replaying a 30 000-tick
@@ -1320,7 +1382,7 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     if (!ctx->fast_threshold) {
         // exact mode: settle the fragile ticks before the tables are built -- while that is cheaper than the serial walk
         const double est_fragile = (double)ctx->h_mail[3] * (nblk >= 64 ? 64.0 : (double)nblk);
-        if (est_fragile * mean_len > 7000.0 * (double)n) return 3;  // 2.4e-12 s per replayed addition against 19 ns per tick
+        if (est_fragile * mean_len > 24000.0 * (double)n) return 3; // 7e-13 s per replayed addition against 19 ns per tick
         int64_t few = -1;                                           // live fragile ticks when they fit the wave-replay list
         if (est_fragile < (double)VG_REPLAY_LIST_CAP / 2) {
             uint32_t *ticks = (uint32_t *)(c.d_list + 1 + VOL_LIST_CAP / 2);     // upper half of the chain list: unused until the emit
@@ -1337,11 +1399,12 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
             }
         }
         // thread per tick: whatever the wave pass did not take (everything when there are many), and a listed first decision
-        const int64_t n_thr = few >= 0 ? 1 : n;
-        if (is_f64) k_vg_replay<true><<<(unsigned)fmk_ceil_div(n_thr, 256), 256, 0, ctx->stream>>>(
-                        a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list, n_thr);
-        else k_vg_replay<false><<<(unsigned)fmk_ceil_div(n_thr, 256), 256, 0, ctx->stream>>>(
-                        a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list, n_thr);
+        const int only_root = few >= 0 ? 1 : 0;
+        const unsigned rblocks = only_root ? 1u : (unsigned)fmk_ceil_div(n, 2048);
+        if (is_f64) k_vg_replay<true><<<rblocks, 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list,
+                                                                        only_root);
+        else k_vg_replay<false><<<rblocks, 256, 0, ctx->stream>>>(a, n, thr, nxt, fragile, d_pstat, d_maxlen, d_root, c.d_list,
+                                                                   only_root);
         FMK_LAUNCH_CHECK(ctx);
         FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 36, 16, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
