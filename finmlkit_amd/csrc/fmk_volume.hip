@@ -34,7 +34,10 @@
 #include "fmk_common.h"
 
 #define VOL_END 0xFFFFFFFFu
-#define VOL_THREADS 256
+// threads per workgroup of k_vol_level0.  The workgroup's LDS (53.3 KB: three per CU) does not depend on it, so this sets
+// the waves per CU: 256 -> 12 waves, 14.6 ms per 1e9 ticks at 865-tick bars; 512 -> 24 waves, 11.8 ms; 1024 -> 32 waves
+// (two workgroups: the wave limit) but 19.6 ms -- barriers across 16 waves, and a thread's monotone walk covers 2 ticks
+#define VOL_THREADS 512
 
 int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
                          double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
