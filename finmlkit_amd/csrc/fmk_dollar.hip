@@ -12,7 +12,8 @@
 //   k_dl_tile_min    per tile: D_i -> M_i -> G_i, tile minimum
 //   k_dl_scan_min    exclusive prefix-min of the tile minima (one block)
 //   k_dl_emit        per tile: recompute G_i, running min, write out[K_i] = i
-// Traffic: price 8 + amount 4 B/tick, three times (sum, min, emit) + 8 B per close.
+// Traffic: price 8 + amount 4 B/tick, three times (sum, min, emit) + 8 B per close; all three passes load coalesced (the
+// two that scan in tick order hand the products to their owners through a padded LDS tile).
 //
 // Exact arithmetic vs the reference's float64 running sum: the reference's `cum` carries its own
 // rounding drift (<= (i+1)*2^-52*thr after i adds, the carry never resets it).  A decision is
@@ -99,16 +100,20 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
                                                              DD *__restrict__ tile_sum, int *__restrict__ bad)
 {
     __shared__ DD lds[4];
-    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+    // the tile's sum does not depend on the order of its terms (double-double: ~2^-104 relative), so the loads are COALESCED
+    // -- thread t takes ticks t, t + 256, ... of the tile; owning 8 consecutive ticks, as the scans below must, makes every
+    // load instruction touch 64 lines (2.7 TB/s instead of 5)
+    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x;
     DD s = dd_make(0.0);
     bool neg = false;
+    double d[DL_ITEMS];
 #pragma unroll
-    for (int k = 0; k < DL_ITEMS; ++k)
-        if (i0 + k < n) {
-            const double d = dl_d<AF64>(price, amount, i0 + k);
-            neg |= !(d >= 0.0);                      // negative or NaN increment: outside the closed form
-            s = dd_add(s, d);
-        }
+    for (int k = 0; k < DL_ITEMS; ++k) d[k] = i0 + k * DL_THREADS < n ? dl_d<AF64>(price, amount, i0 + k * DL_THREADS) : 0.0;
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k) {
+        neg |= !(d[k] >= 0.0);                       // negative or NaN increment: outside the closed form
+        s = dd_add(s, d[k]);
+    }
     if (__ballot(neg) != 0 && fmk_lane() == 0) atomicOr(bad, 1);
     DD tot;
     (void)dl_block_exclusive(s, lds, &tot);
@@ -149,18 +154,30 @@ template <bool AF64>
 __device__ __forceinline__ int dl_thread_G(const double *price, const void *amount, int64_t n, double thr,
                                            const DD *tile_base, DD *lds, int64_t (&G)[DL_ITEMS])
 {
-    const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+    // the thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order), but loading them that way makes every load
+    // instruction touch 64 lines: 2.8 TB/s.  So the tile is loaded coalesced (thread t: ticks t, t + 256, ...), the rounded
+    // products go through a padded LDS tile (one slot per 8: thread t then reads doubles 9t .. 9t + 7, conflict-free) and come
+    // back blocked.
+    __shared__ double stage[DL_TILE + DL_TILE / 8];
+    const int64_t t0 = (int64_t)blockIdx.x * DL_TILE;
+#pragma unroll
+    for (int k = 0; k < DL_ITEMS; ++k) {
+        const int idx = k * DL_THREADS + (int)threadIdx.x;
+        stage[idx + (idx >> 3)] = t0 + idx < n ? dl_d<AF64>(price, amount, t0 + idx) : 0.0;
+    }
+    __syncthreads();
     double d[DL_ITEMS];
     DD s = dd_make(0.0);
 #pragma unroll
     for (int k = 0; k < DL_ITEMS; ++k) {
-        d[k] = i0 + k < n ? dl_d<AF64>(price, amount, i0 + k) : 0.0;
+        d[k] = stage[(int)threadIdx.x * (DL_ITEMS + 1) + k];
         s = dd_add(s, d[k]);
     }
     DD tot;
     DD ex = dl_block_exclusive(s, lds, &tot);
     DD D = dd_add(tile_base[blockIdx.x], ex);
     int frag = 0;
+    const int64_t i0 = t0 + (int64_t)threadIdx.x * DL_ITEMS;
 #pragma unroll
     for (int k = 0; k < DL_ITEMS; ++k) {
         const int64_t i = i0 + k;

@@ -940,7 +940,7 @@ __device__ __forceinline__ int vg_search(const double *s_lp, double b, double l0
     return b2 + c3;
 }
 
-__global__ __launch_bounds__(256) void k_vg_nxt(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
+__global__ __launch_bounds__(256, 4) void k_vg_nxt(const double *__restrict__ Lp, const VcDD *__restrict__ Bb, int64_t n,
                                                 int64_t nblk, double thr, uint32_t *__restrict__ nxt,
                                                 unsigned char *__restrict__ fragile, unsigned *__restrict__ maxlen,
                                                 const int *__restrict__ status, unsigned long long *__restrict__ n_fragile)
