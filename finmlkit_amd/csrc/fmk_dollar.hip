@@ -64,6 +64,8 @@ __device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_d
 #define DL_THREADS 256
 #define DL_ITEMS 8
 #define DL_TILE (DL_THREADS * DL_ITEMS)
+#define DL_SEG_SHIFT 11                 // tiles per segment of the double-double scan: one round of k_dl_scan_dd
+#define DL_SEGM_SHIFT 13                // ... of the prefix-min scan: one round of k_dl_scan_min
 
 template <bool AF64>
 __device__ __forceinline__ double dl_d(const double *price, const void *amount, int64_t i)
@@ -122,10 +124,17 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
 
 // exclusive scan in place (one block; every thread owns 8 consecutive records per round, so the block-wide scan and
 // its barriers are paid once per 2048 records: 3.3 ms -> 0.4 ms for the 488 K tile sums of 1e9 ticks)
-__global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t, int64_t m)
+// Segmented: block s scans records [s * seg_len, (s + 1) * seg_len) on its own (exclusive WITHIN the segment) and leaves the
+// segment's total in seg_tot[s]; a second, one-block call scans the ~240 segment totals, and the consumers add their
+// segment's base.  As ONE block over all 488 K tile sums of 1e9 ticks this scan was 0.98 ms of the indexer's 11.
+__global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t_all, int64_t m_all, int64_t seg_len,
+                                                           DD *__restrict__ seg_tot)
 {
     __shared__ DD lds[4];
     __shared__ DD run_s;
+    const int64_t lo = (int64_t)blockIdx.x * seg_len;
+    DD *t = t_all + lo;
+    const int64_t m = m_all - lo < seg_len ? m_all - lo : seg_len;
     if (threadIdx.x == 0) run_s = dd_make(0.0);
     __syncthreads();
     for (int64_t b = 0; b < m; b += (int64_t)DL_THREADS * 8) {
@@ -147,12 +156,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t, i
         if (threadIdx.x == 0) run_s = dd_add(run_s, tot);
         __syncthreads();
     }
+    if (seg_tot && threadIdx.x == 0) seg_tot[blockIdx.x] = run_s;
 }
 
 // G_i for the 8 ticks of this thread (G_0 = 0); returns the number of fragile ticks
 template <bool AF64>
 __device__ __forceinline__ int dl_thread_G(const double *price, const void *amount, int64_t n, double thr,
-                                           const DD *tile_base, DD *lds, int64_t (&G)[DL_ITEMS])
+                                           const DD *tile_base, const DD *seg_base, DD *lds, int64_t (&G)[DL_ITEMS])
 {
     // the thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order), but loading them that way makes every load
     // instruction touch 64 lines: 2.8 TB/s.  So the tile is loaded coalesced (thread t: ticks t, t + 256, ...), the rounded
@@ -175,7 +185,7 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
     }
     DD tot;
     DD ex = dl_block_exclusive(s, lds, &tot);
-    DD D = dd_add(tile_base[blockIdx.x], ex);
+    DD D = dd_add(dd_add(seg_base[blockIdx.x >> DL_SEG_SHIFT], tile_base[blockIdx.x]), ex);
     int frag = 0;
     const int64_t i0 = t0 + (int64_t)threadIdx.x * DL_ITEMS;
 #pragma unroll
@@ -208,13 +218,13 @@ __device__ __forceinline__ int64_t dl_block_min(int64_t v, int64_t *lds4)
 template <bool AF64>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_min(const double *__restrict__ price,
                                                             const void *__restrict__ amount, int64_t n, double thr,
-                                                            const DD *__restrict__ tile_base,
+                                                            const DD *__restrict__ tile_base, const DD *__restrict__ seg_base,
                                                             int64_t *__restrict__ tile_min)
 {
     __shared__ DD lds[4];
     __shared__ int64_t lmin[4];
     int64_t G[DL_ITEMS];
-    (void)dl_thread_G<AF64>(price, amount, n, thr, tile_base, lds, G);
+    (void)dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G);
     int64_t m = G[0];
 #pragma unroll
     for (int k = 1; k < DL_ITEMS; ++k) m = G[k] < m ? G[k] : m;
@@ -223,10 +233,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_min(const double *__rest
 }
 
 // exclusive prefix-min in place (one block, 8 consecutive records per thread and round); result[0] = overall minimum
-__global__ __launch_bounds__(1024) void k_dl_scan_min(int64_t *__restrict__ t, int64_t m, int64_t *result)
+__global__ __launch_bounds__(1024) void k_dl_scan_min(int64_t *__restrict__ t_all, int64_t m_all, int64_t seg_len,
+                                                      int64_t *__restrict__ seg_min, int64_t *result)
 {
     __shared__ int64_t ws[16];
     __shared__ int64_t run;
+    const int64_t lo = (int64_t)blockIdx.x * seg_len;             // segmented like k_dl_scan_dd
+    int64_t *t = t_all + lo;
+    const int64_t m = m_all - lo < seg_len ? m_all - lo : seg_len;
     if (threadIdx.x == 0) run = INT64_MAX;
     __syncthreads();
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
@@ -260,21 +274,25 @@ __global__ __launch_bounds__(1024) void k_dl_scan_min(int64_t *__restrict__ t, i
         if (threadIdx.x == 1023) run = inc < pre ? inc : pre;
         __syncthreads();
     }
-    if (threadIdx.x == 0) result[0] = run;
+    if (threadIdx.x == 0) {
+        if (seg_min) seg_min[blockIdx.x] = run;
+        if (result) result[0] = run;
+    }
 }
 
 template <bool AF64>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict__ price,
                                                         const void *__restrict__ amount, int64_t n, double thr,
-                                                        const DD *__restrict__ tile_base,
+                                                        const DD *__restrict__ tile_base, const DD *__restrict__ seg_base,
                                                         const int64_t *__restrict__ tile_premin,
+                                                        const int64_t *__restrict__ seg_premin,
                                                         int64_t *__restrict__ out, int64_t cap,
                                                         unsigned long long *n_frag)
 {
     __shared__ DD lds[4];
     __shared__ int64_t wmin[4];
     int64_t G[DL_ITEMS];
-    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, lds, G);
+    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G);
     // exclusive prefix-min over the block in tick order: thread-local then across threads
     int64_t tmin = G[0];
 #pragma unroll
@@ -288,7 +306,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
     }
     if (lane == 63) wmin[w] = inc;
     __syncthreads();
-    int64_t pre = tile_premin[blockIdx.x];           // min of all G before this tile (INT64_MAX for tile 0)
+    int64_t pre = tile_premin[blockIdx.x];           // min of all G before this tile (INT64_MAX for tile 0):
+    const int64_t spre = seg_premin[blockIdx.x >> DL_SEGM_SHIFT];      // inside its segment, and of the segments before
+    pre = spre < pre ? spre : pre;
     for (int k = 0; k < w; ++k) pre = wmin[k] < pre ? wmin[k] : pre;
     int64_t prev = __shfl_up(inc, 1, 64);
     if (lane == 0) prev = INT64_MAX;
@@ -341,19 +361,24 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
 {
     const int64_t tiles = fmk_ceil_div(n, DL_TILE);
     void *scr;
-    FMK_TRY(fmk_scratch(ctx, (size_t)tiles * (sizeof(DD) + 8) + 64, &scr));
+    const int64_t gdd = fmk_ceil_div(tiles, (int64_t)1 << DL_SEG_SHIFT), gmn = fmk_ceil_div(tiles, (int64_t)1 << DL_SEGM_SHIFT);
+    FMK_TRY(fmk_scratch(ctx, (size_t)tiles * (sizeof(DD) + 8) + (size_t)gdd * sizeof(DD) + (size_t)gmn * 8 + 64, &scr));
     DD *tsum = (DD *)scr;
-    int64_t *tmin = (int64_t *)(tsum + tiles);
+    DD *segb = tsum + tiles;
+    int64_t *tmin = (int64_t *)(segb + gdd);
+    int64_t *segm = tmin + tiles;
     int64_t *d_res = ctx->d_mail + 24;
     int *d_bad = (int *)(ctx->d_mail + 26);
     FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad);
     FMK_LAUNCH_CHECK(ctx);
-    k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(tsum, tiles);
+    k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
+    k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(segb, gdd, gdd, nullptr);
     FMK_LAUNCH_CHECK(ctx);
-    k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, tmin);
+    k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin);
     FMK_LAUNCH_CHECK(ctx);
-    k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(tmin, tiles, d_res);
+    k_dl_scan_min<<<(unsigned)gmn, 1024, 0, ctx->stream>>>(tmin, tiles, (int64_t)1 << DL_SEGM_SHIFT, segm, nullptr);
+    k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(segm, gmn, gmn, nullptr, d_res);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -365,7 +390,7 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     if (!c.dbuf) { FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.count * 8)); c.cap = c.count; }
     unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 25);
     FMK_HIP(ctx, hipMemsetAsync(d_frag, 0, 8, ctx->stream));
-    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, tmin, c.dbuf, c.cap, d_frag);
+    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf, c.cap, d_frag);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));

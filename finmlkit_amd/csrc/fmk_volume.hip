@@ -562,7 +562,10 @@ __device__ __forceinline__ double vc_diff(VcDD a, VcDD b)      // a - b rounded 
     return d.hi + (d.lo + (a.lo - b.lo));
 }
 
-// one wave per 512-tick block: lane l owns ticks 8l .. 8l+7 of the block; Lp = inclusive prefix inside the block
+// one wave per 512-tick block; Lp = inclusive prefix inside the block.  The block is taken as 8 ROWS of 64 ticks -- row k is
+// ticks 64k .. 64k + 63, lane l holds tick 64k + l -- so every load and store is coalesced; each row gets a wave scan and the
+// rows chain through a running carry.  (Lanes owning 8 consecutive ticks made every load / store instruction touch 64
+// lines: 5.4 ms per 1e9 ticks for 12 GB.)
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_vc_prefix(const void *__restrict__ amount, int64_t n, double *__restrict__ Lp,
                                                    double *__restrict__ totals, int *__restrict__ status)
@@ -571,28 +574,26 @@ __global__ __launch_bounds__(256) void k_vc_prefix(const void *__restrict__ amou
     const int64_t blk = (int64_t)blockIdx.x * (VC_WG_TICKS / VC_BLOCK) + w;
     const int64_t bs = blk * VC_BLOCK;
     if (bs >= n) return;
-    double loc[8], run = 0.0;
+    double v[8];
     bool bad = false, inexact = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int64_t j = bs + (int64_t)lane * 8 + k;
-        const double v = j < n ? fmk_amt<AF64>(amount, j) : 0.0;
-        bad |= !(v >= 0.0);
-        inexact |= vol_amount_inexact(v);
-        run += v;
-        loc[k] = run;
+        const int64_t j = bs + 64 * k + lane;
+        v[k] = j < n ? fmk_amt<AF64>(amount, j) : 0.0;
+        bad |= !(v[k] >= 0.0);
+        inexact |= vol_amount_inexact(v[k]);
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);   // prefix sums must not decrease: serial walk instead
     if (__ballot(inexact) != 0 && lane == 0) vol_flag(status, VOL_ST_INEXACT);
-    const double inc = fmk_wave_iscan(run);
-    double pre = __shfl_up(inc, 1, 64);
-    if (lane == 0) pre = 0.0;
+    double carry = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int64_t j = bs + (int64_t)lane * 8 + k;
-        if (j < n) Lp[j] = pre + loc[k];
+        const double inc = carry + fmk_wave_iscan(v[k]);
+        const int64_t j = bs + 64 * k + lane;
+        if (j < n) Lp[j] = inc;
+        carry = __shfl(inc, 63, 64);
     }
-    if (lane == 63) totals[blk] = pre + loc[7];
+    if (lane == 0) totals[blk] = carry;
 }
 
 // Bb[k] = sum of totals[0..k) in double-double, k = 0..m (one block, 8 records per thread and round)
@@ -956,6 +957,9 @@ __global__ __launch_bounds__(256, 4) void k_vg_nxt(const double *__restrict__ Lp
     const int64_t j0 = bs + (int64_t)lane * 8;                    // lane l owns ticks j0 .. j0 + 7
     double lpj[8], dB[8];
     int dblk[8];
+    // (own prefixes: read blocked, 64 bytes per lane.  Loading them coalesced and handing them over through the padded tile,
+    // which paid off in the streaming passes of fmk_dollar.hip, was measured here and is slower -- 21.6 -> 23.2 ms: the lines
+    // were just written by k_vc_prefix, and the kernel is bound by its LDS searches, not by this load.)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         lpj[k] = j0 + k < n ? Lp[j0 + k] : 0.0;
