@@ -59,29 +59,50 @@ __device__ __forceinline__ double ff_block_exclusive(double mine, double *lds /*
     return isnan(prev) ? pre : prev;
 }
 
+// tile_last[b] = the tile's last non-NaN value (NaN: none); *first_valid = index of the stream's first non-NaN.
+// Only the LAST valid value of the tile is needed here, i.e. the value at the largest valid index: an argmax, so the loads are
+// coalesced (thread t: items t, t + 256, ...; its own last valid item is the one with the largest k).  The stream's first
+// valid index is an atomicMin that is attempted only when it would lower the current value: issued unconditionally it was one
+// same-address atomic per wave, 2 M of them at ~10 ns -- 22.5 ms for a kernel that reads 8 GB (now see profiles/).
 __global__ __launch_bounds__(FF_THREADS) void k_ff_tile(const double *__restrict__ x, int64_t n,
                                                         double *__restrict__ tile_last,
                                                         unsigned long long *first_valid)
 {
-    __shared__ double lds[4];
-    const int64_t i0 = (int64_t)blockIdx.x * FF_TILE + (int64_t)threadIdx.x * FF_ITEMS;
-    double last = NAN;
-    int64_t first = -1;
+    __shared__ double lds_v[4];
+    __shared__ int64_t lds_i[4];
+    const int64_t t0 = (int64_t)blockIdx.x * FF_TILE + (int64_t)threadIdx.x;
+    double v[FF_ITEMS];
 #pragma unroll
-    for (int k = 0; k < FF_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        if (i < n) {
-            const double v = x[i];
-            if (!isnan(v)) { last = v; if (first < 0) first = i; }
+    for (int k = 0; k < FF_ITEMS; ++k) v[k] = t0 + (int64_t)k * FF_THREADS < n ? x[t0 + (int64_t)k * FF_THREADS] : NAN;
+    double last = NAN;
+    int64_t last_i = -1, first = INT64_MAX;
+#pragma unroll
+    for (int k = 0; k < FF_ITEMS; ++k)
+        if (!isnan(v[k])) {
+            const int64_t i = t0 + (int64_t)k * FF_THREADS;
+            last = v[k]; last_i = i;                                 // k ascends: the thread's last valid item
+            if (first == INT64_MAX) first = i;
         }
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    first = fmk_wave_min(first);
+    if (lane == 0 && first != INT64_MAX && (unsigned long long)first < __atomic_load_n(first_valid, __ATOMIC_RELAXED))
+        atomicMin(first_valid, (unsigned long long)first);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {                               // value at the largest valid index of the wave
+        const int64_t oi = __shfl_xor(last_i, d, 64);
+        const double ov = __shfl_xor(last, d, 64);
+        if (oi > last_i) { last_i = oi; last = ov; }
     }
-    if (first >= 0) atomicMin(first_valid, (unsigned long long)first);
-    double tot;
-    (void)ff_block_exclusive(last, lds, &tot);
-    if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
+    if (lane == 0) { lds_v[w] = last; lds_i[w] = last_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bv = lds_v[0];
+        int64_t bi = lds_i[0];
+        for (int q = 1; q < 4; ++q) if (lds_i[q] > bi) { bi = lds_i[q]; bv = lds_v[q]; }
+        tile_last[blockIdx.x] = bi >= 0 ? bv : NAN;
+    }
 }
 
-// one block: tile_last[t] := last non-NaN aggregate among tiles < t (exclusive), in place
 __global__ __launch_bounds__(1024) void k_ff_scan_tiles(double *tile_last, int64_t tiles)
 {
     __shared__ double ws[16];
