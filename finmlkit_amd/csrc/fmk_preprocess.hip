@@ -133,17 +133,30 @@ __device__ __forceinline__ int sv_block_exclusive(int mine, int *lds /*[4]*/, in
 __global__ __launch_bounds__(SV_THREADS) void k_side_tile(const double *__restrict__ price, int64_t n,
                                                           int8_t *__restrict__ tile_last)
 {
-    __shared__ int lds[4];
-    const int64_t i0 = (int64_t)blockIdx.x * SV_TILE + (int64_t)threadIdx.x * SV_ITEMS;
-    int last = 0;
+    // the tile's LAST non-zero move = the move at the largest index that has one: an argmax, so the loads are coalesced
+    // (thread t: ticks t, t + 256, ...); 8 consecutive ticks per thread made every load instruction touch 64 lines
+    __shared__ int lds_m[4];
+    __shared__ int lds_i[4];
+    const int64_t t0 = (int64_t)blockIdx.x * SV_TILE + (int64_t)threadIdx.x;
+    int last = 0, last_i = -1;
 #pragma unroll
     for (int k = 0; k < SV_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        if (i < n) { const int m = sv_move(price, i); last = m != 0 ? m : last; }
+        const int64_t i = t0 + (int64_t)k * SV_THREADS;
+        if (i < n) { const int m = sv_move(price, i); if (m != 0) { last = m; last_i = k * SV_THREADS + (int)threadIdx.x; } }
     }
-    int tot;
-    (void)sv_block_exclusive(last, lds, &tot);
-    if (threadIdx.x == 0) tile_last[blockIdx.x] = (int8_t)tot;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int oi = __shfl_xor(last_i, d, 64), om = __shfl_xor(last, d, 64);
+        if (oi > last_i) { last_i = oi; last = om; }
+    }
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    if (lane == 0) { lds_m[w] = last; lds_i[w] = last_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int bm = lds_m[0], bi = lds_i[0];
+        for (int q = 1; q < 4; ++q) if (lds_i[q] > bi) { bi = lds_i[q]; bm = lds_m[q]; }
+        tile_last[blockIdx.x] = (int8_t)(bi >= 0 ? bm : 0);
+    }
 }
 
 // one block: tile_last[t] := last non-zero aggregate among tiles < t (exclusive), in place
@@ -180,13 +193,23 @@ __global__ __launch_bounds__(SV_THREADS) void k_side_apply(const double *__restr
                                                            const int8_t *__restrict__ tile_pre, int8_t *__restrict__ out)
 {
     __shared__ int lds[4];
+    // moves computed from COALESCED loads (thread t: ticks t, t + 256, ...), one byte each into an LDS tile, then every thread
+    // reads the 8 consecutive moves it owns as one 8-byte word: the fill below runs in tick order
+    __shared__ __attribute__((aligned(8))) signed char s_mv[SV_TILE];
+    const int64_t t0 = (int64_t)blockIdx.x * SV_TILE + (int64_t)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SV_ITEMS; ++k) {
+        const int64_t i = t0 + (int64_t)k * SV_THREADS;
+        s_mv[k * SV_THREADS + (int)threadIdx.x] = (signed char)(i < n ? sv_move(price, i) : 0);
+    }
+    __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * SV_TILE + (int64_t)threadIdx.x * SV_ITEMS;
+    const unsigned long long packed = *(const unsigned long long *)(s_mv + (int)threadIdx.x * SV_ITEMS);
     int mv[SV_ITEMS];
     int last = 0;
 #pragma unroll
     for (int k = 0; k < SV_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        mv[k] = i < n ? sv_move(price, i) : 0;
+        mv[k] = (int)(signed char)(packed >> (8 * k));
         last = mv[k] != 0 ? mv[k] : last;
     }
     int tot;
