@@ -28,7 +28,6 @@
 // further down (to 64 K ticks), the chain walk (beyond).  Domain: thr > 0, v >= 0, N < 2^31 -- anything else falls back
 // to the serial walk of fmk_threshold.hip.
 #include <math.h>
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "fmk_common.h"
