@@ -6,9 +6,11 @@ device, resident in HBM) -> `TimeBarKit(period=60s).build_ohlcv()` semantics: ba
 indices (_time_bar_indexer), OHLC/volume/VWAP/trade count (comp_bar_ohlcv) and the median trade
 size.  One "step" = one full pass of that path over the resident columns; outputs stay on the device.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): rank r holds ticks [r*n, (r+1)*n) of ONE
-global stream (weak scaling); the bar that straddles a shard boundary is stitched by a single RCCL
-neighbour send/recv of the trailing partial bar's raw ticks (finmlkit_amd/dist.py).
+N > 1 (launched by torch.distributed.run, one rank per GPU; only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are
+read from the environment -- PyTorch is never imported): rank r holds ticks [r*n, (r+1)*n) of ONE global stream (weak
+scaling); the bar that straddles a shard boundary is stitched by a single neighbour send/recv of the trailing partial
+bar's raw ticks per step: ncclSend/ncclRecv of librccl behind the C ABI (fmk_comm_*, csrc/fmk_comm.hip), on its own
+stream, ordered against the compute stream by events -- no host synchronisation inside a step (finmlkit_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement); `roofline` describes the
 dominant kernel (k_bar_ohlcv: 12 algorithmic B/tick), `cpu_baseline` the scalar C oracle on this host.
@@ -48,7 +50,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational cfg 3 / cfg 4 timings")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the sharded code path (torch.distributed/RCCL init, planning, halo logic) even with 1 rank")
+                    help="run the sharded step with 1 rank: RCCL communicator of size 1, the rank is its own neighbour "
+                         "(ncclSend/ncclRecv to self), plus the boundary-bar launches -- the per-step overhead of the "
+                         "multi-GPU path measured on one GPU")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
     return ap.parse_args()
 
 
@@ -141,17 +146,6 @@ def main():
 
     comm = None
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        import torch   # imported BEFORE libfmk_hip.so so both share one HIP runtime (same SONAME)
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from finmlkit_amd.dist import Comm
-        comm = Comm(torch.device("cuda", local_rank))
 
     import numpy as np
     from finmlkit_amd import _ffi, engine
@@ -166,9 +160,30 @@ def main():
         n = int((free - (2 << 30)) // 21)
         if rank == 0:
             print(f"[bench] reducing ticks/GPU to {n} (free HBM {free / 2**30:.1f} GiB)", file=sys.stderr)
-    HALO = 1 << 22 if use_dist else 0     # headroom in front of every column for the neighbour's halo
-    trades = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, headroom=HALO)
+    trades = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx)
     ctx.sync()
+
+    transport_note = None
+    if use_dist:
+        from finmlkit_amd.dist import Comm, ShardedTimeBars
+        # the ranks of this node meet in a shared-memory file named after the launcher (same parent pid + port on every
+        # rank); rank 0 creates it, it is unlinked as soon as every rank has attached
+        base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}_" \
+              f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+        path = os.path.join(base, f"fmk_comm_{key}")
+        transport = args.transport
+        try:
+            comm = Comm(ctx, rank, world, path, transport, self_loop=(world == 1))
+        except _ffi.FmkError as e:
+            if transport != "rccl":
+                raise
+            # RCCL could not initialise (every rank learns it in the rendezvous): the same step over the host-staged
+            # transport -- correct, slower, and SAID in the JSON line
+            transport_note = f"host-staged fallback: {e}"
+            print(f"[bench] rank {rank}: {transport_note}", file=sys.stderr)
+            comm = Comm(ctx, rank, world, path + ".host", "host", self_loop=(world == 1))
+            transport = "host"
 
     want_median = not args.no_median
     state = {}
@@ -188,31 +203,19 @@ def main():
             state["out"] = trades.alloc_ohlcv(cap, want_median)
 
     if use_dist:
-        import torch
-        from finmlkit_amd.dist import ShardedTimeBars
-        dev = f"cuda:{local_rank}"
-        tcols = [torch.as_tensor(b, device=dev) for b in trades._backing]   # zero-copy views of our buffers
-        shard = ShardedTimeBars(trades, rank, world, args.interval, want_median)
-        # connection setup (not a step): RCCL builds its point-to-point channels on first use -- seconds, once
-        ping = torch.zeros(1, dtype=torch.int64, device=dev)
-        pong = torch.zeros(1, dtype=torch.int64, device=dev)
-        comm.neighbour_exchange([ping], [pong])
-        torch.cuda.current_stream().synchronize()
+        # SET-UP, not a step: the plan (global clock, edge partition, halo lengths, boundary buffers) is a function of
+        # the immutable columns -- two host all-gathers, once.  The first exchange also builds RCCL's point-to-point
+        # channels (seconds, once).
+        shard = ShardedTimeBars(trades, rank, world, args.interval, want_median, self_loop=(world == 1)).setup(comm)
+        shard.step(comm)
+        ctx.sync()
+        comm.sync()
 
     def step():
         if use_dist:
-            # all-gather (first, last) timestamp -> global clock + edge plan; the bars that need no halo are
-            # enqueued right away and run while the halo lengths and the halo itself travel
-            send_h = shard.launch_local(comm.all_gather_i64(list(shard.span())))
-            allh = comm.all_gather_i64([send_h])
-            recv_h = allh[rank - 1][0] if rank > 0 else 0
-            if recv_h > HALO:
-                raise RuntimeError(f"halo {recv_h} exceeds headroom {HALO}")
-            send = [tc[HALO + shard.send_start: HALO + n] for tc in tcols] if send_h else []
-            recv = [tc[HALO - recv_h: HALO] for tc in tcols] if recv_h else []
-            comm.neighbour_exchange(send, recv)                 # one RCCL send/recv batch per neighbour pair
-            torch.cuda.current_stream().synchronize()
-            state["n_bars"] = shard.finish(recv_h)              # the bar straddling the left boundary
+            # one neighbour exchange (communicator's stream) || index + interior bars, then the boundary bar: enqueue
+            # only -- no read-back, no host wait, no allocation
+            state["n_bars"] = shard.step(comm)
             return state["n_bars"]
         t0, t1 = trades.first_last_ts()
         ne, e0, d = clock_of(t0, t1)
@@ -226,6 +229,7 @@ def main():
     def barrier():
         ctx.sync()
         if comm:
+            comm.sync()
             comm.barrier()
 
     for _ in range(args.warmup):
@@ -243,10 +247,7 @@ def main():
     ctx.call("fmk_profile_enable", C.c_int(0))
 
     if comm:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = max(x[0] for x in comm.all_gather_f64([elapsed]))      # MAX over ranks
         nb_all = comm.all_gather_i64([state["n_bars"]])
         n_bars_total = sum(x[0] for x in nb_all)
     else:
@@ -279,7 +280,9 @@ def main():
                 "workload": f"cfg2: {n:.3g} synthetic ticks/GPU -> {args.interval:g}s time bars: clock+close indices, "
                             f"OHLC/volume/VWAP/trades{'' if args.no_median else ' + median trade size'}",
                 "ticks_per_gpu": n, "n_bars_total": n_bars_total, "interval_s": args.interval,
-                "parallelism": f"time-range shards x{world}, 1 neighbour halo exchange" if use_dist else "1 GPU",
+                "parallelism": (f"time-range shards x{world}, 1 neighbour halo exchange per step "
+                                f"({'ncclSend/ncclRecv of librccl' if transport == 'rccl' else 'host-staged'} behind the "
+                                f"C ABI, no PyTorch{'; self-loop diagnostic' if world == 1 else ''})") if use_dist else "1 GPU",
             },
             "roofline": {"bound": "hbm",
                          "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
@@ -290,6 +293,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
                          "launches_timed": len(k_ms)},
         }
+        if transport_note:
+            line["config"]["transport_note"] = transport_note
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
             if not args.no_extras:
@@ -300,9 +305,8 @@ def main():
             pass
         print(json.dumps(line), flush=True)
     if comm:
-        import torch.distributed as dist
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfmk_hip.so")
 
 OK = 0
-E_ARG, E_CAPACITY, E_LEVEL, E_ZERODIV, E_NOMEM, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7
+E_ARG, E_CAPACITY, E_LEVEL, E_ZERODIV, E_NOMEM, E_HIP, E_NODEVICE, E_COMM = -1, -2, -3, -4, -5, -6, -7, -8
 
 c_i64 = C.c_int64
 c_f64 = C.c_double
@@ -207,12 +207,6 @@ class DeviceArray:
 
     def zero(self):
         self.ctx.call("fmk_memset", self.p, C.c_int(0), C.c_size_t(self.nbytes))
-
-    @property
-    def __cuda_array_interface__(self):
-        """Zero-copy view for torch.as_tensor(..., device='cuda') (RCCL halo exchange in bench.py)."""
-        return {"shape": (self.n,), "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2,
-                "strides": None}
 
     def free(self):
         if self._owned and self.ptr:

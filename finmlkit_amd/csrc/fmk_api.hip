@@ -162,7 +162,9 @@ static void fmk_pool_destroy(fmk_ctx *ctx)
 {
     if (!ctx->pool) return;
     fmk_pool_flush(ctx);
-    delete (FmkPool *)ctx->pool;
+    FmkPool *p = (FmkPool *)ctx->pool;
+    for (auto &kv : p->live) (void)hipFree(kv.first);        // blocks that outlive the context go with it
+    delete p;
     ctx->pool = nullptr;
 }
 
@@ -204,11 +206,9 @@ int fmk_free(fmk_ctx *ctx, void *dptr)
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FmkPool *p = fmk_pool(ctx);
     auto it = p->live.find(dptr);
-    if (it == p->live.end()) {                       // not ours (or double free): fall back to the plain path
-        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        FMK_HIP(ctx, hipFree(dptr));
-        return FMK_OK;
-    }
+    if (it == p->live.end())                         // not handed out by fmk_alloc, or freed twice: a raw hipFree here
+        return fmk_set_error(ctx, FMK_E_ARG,         // could release a block that sits in the free list (use after free)
+                             "fmk_free: %p is not a live block of this context (double free?)", dptr);
     const size_t bytes = it->second;
     p->live.erase(it);
     if (!p->enabled) {
@@ -224,6 +224,7 @@ int fmk_free(fmk_ctx *ctx, void *dptr)
 int fmk_memset(fmk_ctx *ctx, void *dptr, int value, size_t bytes)
 {
     if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return FMK_OK;
 }
@@ -249,6 +250,7 @@ int fmk_d2h(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
 int fmk_d2d(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return FMK_OK;
 }
@@ -263,12 +265,14 @@ int fmk_mem_info(fmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
 
 int fmk_timer_start(fmk_ctx *ctx)
 {
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return FMK_OK;
 }
 
 int fmk_timer_stop(fmk_ctx *ctx, double *elapsed_ms)
 {
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -294,6 +298,7 @@ int fmk_event_destroy(fmk_ctx *ctx, void *event)
 
 int fmk_event_record(fmk_ctx *ctx, void *event)
 {
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
     return FMK_OK;
 }
@@ -301,6 +306,7 @@ int fmk_event_record(fmk_ctx *ctx, void *event)
 int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms)
 {
     float ms = 0.f;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
     FMK_HIP(ctx, hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
     *elapsed_ms = (double)ms;

@@ -1,0 +1,553 @@
+// fmk_comm.hip -- the multi-GPU side of the time-bar path (BASELINE cfg 5): rank r holds a
+// contiguous tick range of one stream; the only data that crosses GPUs is the trailing partial bar of rank r, sent as
+// raw ticks to rank r+1 -- ONE neighbour send/recv per step, no collective on the data path.  The reference has no
+// distributed code (last row), so there is no reference interface to cite; the entry points are what a
+// maintainer binds next to the reducers ("multi-GPU").
+//
+// Two transports behind the same calls:
+//   FMK_COMM_RCCL  ncclSend / ncclRecv of librccl (dlopen'ed on first use: the single-GPU library has no RCCL
+//                  dependency), grouped into one launch per step on the communicator's own HIP stream, ordered against
+//                  the context's stream by events only -- no host synchronisation inside a step.
+//   FMK_COMM_HOST  host-staged: device -> ring buffer in the rendezvous segment -> device.  For the tests (two
+//                  processes on ONE GPU, or no GPU at all with ctx == NULL and host pointers) and as the fallback
+//                  bench.py reports when RCCL cannot initialise.
+// Ranks of one node meet in a shared-memory segment (a file the caller names; rank 0 creates it and unlinks it once
+// every rank has attached).  It carries the ncclUniqueId, the small host all-gathers of the set-up phase (timestamps,
+// halo lengths, timings) and the ring buffers of the host transport.  Every wait has a deadline: a missing peer is an
+// error code (FMK_E_COMM), never a hang.
+#include <dlfcn.h>
+#include <errno.h>
+#include <stdarg.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "fmk_common.h"
+
+namespace {
+
+constexpr uint64_t SEG_MAGIC = 0x464d4b434f4d4d32ULL;       // "FMKCOMM2"
+constexpr size_t GATHER_MAX = 4096;                         // bytes per rank and all-gather
+constexpr int MAX_WORLD = 64;
+
+struct alignas(64) RankSlot {
+    uint64_t gather_seq;                                    // generations this rank has published
+    uint64_t attached;
+    // ring buffer INTO this rank from its left neighbour (host transport)
+    uint64_t produced, consumed;                            // byte counters
+    char pad[32];
+};
+
+struct SegHeader {
+    uint64_t magic;                                         // written last by rank 0
+    uint64_t world, ring_bytes, total_bytes;
+    RankSlot slot[MAX_WORLD];
+};
+
+static inline size_t gather_off(int world, int parity, int rank)
+{
+    return sizeof(SegHeader) + ((size_t)parity * world + rank) * GATHER_MAX;
+}
+static inline size_t ring_off(int world, size_t ring_bytes, int rank)
+{
+    return sizeof(SegHeader) + (size_t)2 * world * GATHER_MAX + (size_t)rank * ring_bytes;
+}
+
+static double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static inline void relax(int &spins)
+{
+    if (++spins < 200) return;
+    if (spins < 2000) { sched_yield(); return; }
+    timespec ts{0, 50000};
+    nanosleep(&ts, nullptr);
+}
+
+// ---- librccl, resolved at run time -----------------------------------------------------------------------------------
+typedef struct { char internal[128]; } nccl_unique_id;      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void *nccl_comm;
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(nccl_unique_id *) = nullptr;
+    int (*CommInitRank)(nccl_comm *, int, nccl_unique_id, int) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+
+static const char *rccl_load()
+{
+    if (g_rccl.so) return nullptr;
+    static char msg[384];
+    const char *env = getenv("FMK_RCCL_LIB");
+    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *so = nullptr;
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        so = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (so) break;
+    }
+    if (!so) {
+        snprintf(msg, sizeof msg, "librccl not found (%s); set FMK_RCCL_LIB", dlerror());
+        return msg;
+    }
+#define SYM(field, name)                                                         \
+    do {                                                                         \
+        *(void **)(&g_rccl.field) = dlsym(so, name);                             \
+        if (!g_rccl.field) {                                                     \
+            snprintf(msg, sizeof msg, "librccl lacks %s", name);                 \
+            dlclose(so);                                                         \
+            return msg;                                                          \
+        }                                                                        \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.so = so;
+    return nullptr;
+}
+
+}  // namespace
+
+struct fmk_comm {
+    fmk_ctx *ctx;                   // may be NULL with the host transport (pointers are host pointers then)
+    int transport, rank, world, flags;
+    double timeout_s;
+    char *seg;                      // the mapped rendezvous segment
+    size_t seg_bytes, ring_bytes;
+    uint64_t gather_gen;
+    nccl_comm nccl;
+    hipStream_t stream;             // RCCL launches go here
+    hipEvent_t ev_ready, ev_done;   // ctx stream -> comm stream, comm stream -> ctx stream
+    int exchange_pending;
+    char err[512];
+};
+
+namespace {
+
+int comm_error(fmk_comm *c, int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    if (c->ctx) fmk_set_error(c->ctx, code, "%s", c->err);
+    else fmk_set_error(nullptr, code, "%s", c->err);
+    return code;
+}
+
+inline SegHeader *hdr(fmk_comm *c) { return (SegHeader *)c->seg; }
+
+#define NCCL_TRY(c, expr)                                                                                        \
+    do {                                                                                                         \
+        int r__ = (expr);                                                                                        \
+        if (r__ != 0) return comm_error((c), FMK_E_COMM, "%s: %s", #expr, g_rccl.GetErrorString(r__));           \
+    } while (0)
+#define COMM_HIP(c, expr)                                                                                        \
+    do {                                                                                                         \
+        hipError_t e__ = (expr);                                                                                 \
+        if (e__ != hipSuccess) return comm_error((c), FMK_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));       \
+    } while (0)
+
+int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
+{
+    const int world = c->world;
+    const size_t total = ring_off(world, ring_bytes, world);
+    const double deadline = now_s() + c->timeout_s;
+    int fd = -1;
+    if (c->rank == 0) {
+        fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
+        if (fd < 0 && errno == EEXIST) {                    // a leftover of a run that died: replace it
+            unlink(path);
+            fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
+        }
+        if (fd < 0) return comm_error(c, FMK_E_COMM, "rendezvous %s: %s", path, strerror(errno));
+        if (ftruncate(fd, (off_t)total) != 0) {
+            close(fd);
+            return comm_error(c, FMK_E_COMM, "rendezvous %s: ftruncate(%zu): %s", path, total, strerror(errno));
+        }
+    } else {
+        int spins = 0;
+        for (;;) {
+            fd = open(path, O_RDWR);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SegHeader)) break;
+                close(fd);
+                fd = -1;
+            }
+            if (now_s() > deadline)
+                return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s did not appear within %.0f s", c->rank, path,
+                                  c->timeout_s);
+            relax(spins);
+        }
+    }
+    size_t map_bytes = total;
+    if (c->rank != 0) {                                     // the creator's size wins (it is validated below)
+        struct stat st;
+        fstat(fd, &st);
+        if ((size_t)st.st_size < total) {
+            // the file exists but rank 0 has not sized it yet: wait for the full size
+            int spins = 0;
+            while ((size_t)st.st_size < total) {
+                if (now_s() > deadline) {
+                    close(fd);
+                    return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s has %zu bytes, expected %zu", c->rank, path,
+                                      (size_t)st.st_size, total);
+                }
+                relax(spins);
+                fstat(fd, &st);
+            }
+        }
+    }
+    void *m = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return comm_error(c, FMK_E_COMM, "mmap(%s): %s", path, strerror(errno));
+    c->seg = (char *)m;
+    c->seg_bytes = map_bytes;
+    c->ring_bytes = ring_bytes;
+    SegHeader *h = hdr(c);
+    if (c->rank == 0) {
+        h->world = (uint64_t)world;
+        h->ring_bytes = ring_bytes;
+        h->total_bytes = total;
+        __atomic_store_n(&h->magic, SEG_MAGIC, __ATOMIC_RELEASE);
+    } else {
+        int spins = 0;
+        while (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) != SEG_MAGIC) {
+            if (now_s() > deadline)
+                return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s was never initialised by rank 0", c->rank, path);
+            relax(spins);
+        }
+        if (h->world != (uint64_t)world || h->ring_bytes != ring_bytes)
+            return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s belongs to another job (world %llu, ring %llu)",
+                              c->rank, path, (unsigned long long)h->world, (unsigned long long)h->ring_bytes);
+    }
+    __atomic_store_n(&h->slot[c->rank].attached, 1, __ATOMIC_RELEASE);
+    return FMK_OK;
+}
+
+int gather(fmk_comm *c, const void *send, size_t bytes, void *recv)
+{
+    if (bytes > GATHER_MAX) return comm_error(c, FMK_E_ARG, "fmk_comm_allgather: %zu bytes per rank (max %zu)", bytes, GATHER_MAX);
+    SegHeader *h = hdr(c);
+    const uint64_t gen = ++c->gather_gen;
+    const int par = (int)(gen & 1);
+    // two generations of slots suffice: nobody can publish generation g+2 before everybody has read generation g,
+    // because publishing g+2 requires having completed g+1, which requires everybody to have published g+1, which a
+    // rank only does after it has read g
+    if (bytes) memcpy(c->seg + gather_off(c->world, par, c->rank), send, bytes);
+    __atomic_store_n(&h->slot[c->rank].gather_seq, gen, __ATOMIC_RELEASE);
+    const double deadline = now_s() + c->timeout_s;
+    for (int r = 0; r < c->world; ++r) {
+        int spins = 0;
+        while (__atomic_load_n(&h->slot[r].gather_seq, __ATOMIC_ACQUIRE) < gen) {
+            if (now_s() > deadline)
+                return comm_error(c, FMK_E_COMM, "rank %d: rank %d did not reach all-gather %llu within %.0f s", c->rank, r,
+                                  (unsigned long long)gen, c->timeout_s);
+            relax(spins);
+        }
+        if (bytes && recv) memcpy((char *)recv + (size_t)r * bytes, c->seg + gather_off(c->world, par, r), bytes);
+    }
+    return FMK_OK;
+}
+
+// copy between a (device or host) user buffer and the host ring
+int copy_in(fmk_comm *c, void *ring_dst, const void *user_src, size_t bytes)
+{
+    if (c->ctx) COMM_HIP(c, hipMemcpy(ring_dst, user_src, bytes, hipMemcpyDeviceToHost));
+    else memcpy(ring_dst, user_src, bytes);
+    return FMK_OK;
+}
+int copy_out(fmk_comm *c, void *user_dst, const void *ring_src, size_t bytes)
+{
+    if (c->ctx) COMM_HIP(c, hipMemcpy(user_dst, ring_src, bytes, hipMemcpyHostToDevice));
+    else memcpy(user_dst, ring_src, bytes);
+    return FMK_OK;
+}
+
+// Host-staged exchange: a byte stream per neighbour pair through the receiver's ring; sending and receiving make
+// progress alternately, so a message longer than the ring (or a rank that is its own neighbour) cannot deadlock.
+int host_exchange(fmk_comm *c, int n_cols, const void *const *send_ptrs, const size_t *send_bytes, void *const *recv_ptrs,
+                  const size_t *recv_bytes, int to, int from)
+{
+    SegHeader *h = hdr(c);
+    if (c->ctx) {
+        COMM_HIP(c, hipSetDevice(c->ctx->device));
+        COMM_HIP(c, hipStreamSynchronize(c->ctx->stream));  // the buffers are produced / consumed on that stream
+    }
+    const size_t cap = c->ring_bytes;
+    int sc = 0, rc = 0;
+    size_t so = 0, ro = 0;                                   // column, offset inside it
+    auto skip_empty = [&](int &col, const size_t *bytes) { while (col < n_cols && bytes[col] == 0) ++col; };
+    if (to < 0) sc = n_cols;
+    if (from < 0) rc = n_cols;
+    skip_empty(sc, send_bytes);
+    skip_empty(rc, recv_bytes);
+    RankSlot *out = to >= 0 ? &h->slot[to] : nullptr;
+    RankSlot *in = from >= 0 ? &h->slot[c->rank] : nullptr;
+    char *out_ring = to >= 0 ? c->seg + ring_off(c->world, cap, to) : nullptr;
+    char *in_ring = from >= 0 ? c->seg + ring_off(c->world, cap, c->rank) : nullptr;
+    double deadline = now_s() + c->timeout_s;
+    int spins = 0;
+    while (sc < n_cols || rc < n_cols) {
+        bool progressed = false;
+        if (sc < n_cols) {
+            const uint64_t prod = __atomic_load_n(&out->produced, __ATOMIC_RELAXED);
+            const uint64_t cons = __atomic_load_n(&out->consumed, __ATOMIC_ACQUIRE);
+            size_t room = cap - (size_t)(prod - cons);
+            if (room) {
+                size_t k = send_bytes[sc] - so;
+                if (k > room) k = room;
+                const size_t pos = (size_t)(prod % cap);
+                if (k > cap - pos) k = cap - pos;
+                FMK_TRY(copy_in(c, out_ring + pos, (const char *)send_ptrs[sc] + so, k));
+                __atomic_store_n(&out->produced, prod + k, __ATOMIC_RELEASE);
+                so += k;
+                if (so == send_bytes[sc]) { ++sc; so = 0; skip_empty(sc, send_bytes); }
+                progressed = true;
+            }
+        }
+        if (rc < n_cols) {
+            const uint64_t cons = __atomic_load_n(&in->consumed, __ATOMIC_RELAXED);
+            const uint64_t prod = __atomic_load_n(&in->produced, __ATOMIC_ACQUIRE);
+            size_t avail = (size_t)(prod - cons);
+            if (avail) {
+                size_t k = recv_bytes[rc] - ro;
+                if (k > avail) k = avail;
+                const size_t pos = (size_t)(cons % cap);
+                if (k > cap - pos) k = cap - pos;
+                FMK_TRY(copy_out(c, (char *)recv_ptrs[rc] + ro, in_ring + pos, k));
+                __atomic_store_n(&in->consumed, cons + k, __ATOMIC_RELEASE);
+                ro += k;
+                if (ro == recv_bytes[rc]) { ++rc; ro = 0; skip_empty(rc, recv_bytes); }
+                progressed = true;
+            }
+        }
+        if (progressed) {
+            spins = 0;
+            deadline = now_s() + c->timeout_s;
+        } else {
+            if (now_s() > deadline)
+                return comm_error(c, FMK_E_COMM, "rank %d: halo exchange stalled for %.0f s (neighbour gone?)", c->rank,
+                                  c->timeout_s);
+            relax(spins);
+        }
+    }
+    return FMK_OK;
+}
+
+int rccl_exchange(fmk_comm *c, int n_cols, const void *const *send_ptrs, const size_t *send_bytes, void *const *recv_ptrs,
+                  const size_t *recv_bytes, int to, int from)
+{
+    fmk_ctx *ctx = c->ctx;
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    // the communicator's stream starts after everything enqueued so far on the context's stream (the previous step's
+    // boundary kernel still reads the receive buffers) -- an event, not a host wait
+    COMM_HIP(c, hipEventRecord(c->ev_ready, ctx->stream));
+    COMM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    NCCL_TRY(c, g_rccl.GroupStart());
+    if (to >= 0)
+        for (int i = 0; i < n_cols; ++i)
+            if (send_bytes[i]) NCCL_TRY(c, g_rccl.Send(send_ptrs[i], send_bytes[i], /*ncclInt8*/ 0, to, c->nccl, c->stream));
+    if (from >= 0)
+        for (int i = 0; i < n_cols; ++i)
+            if (recv_bytes[i]) NCCL_TRY(c, g_rccl.Recv(recv_ptrs[i], recv_bytes[i], /*ncclInt8*/ 0, from, c->nccl, c->stream));
+    NCCL_TRY(c, g_rccl.GroupEnd());
+    COMM_HIP(c, hipEventRecord(c->ev_done, c->stream));
+    return FMK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fmk_comm_last_error(const fmk_comm *comm) { return comm ? comm->err : fmk_last_error(nullptr); }
+
+int fmk_comm_create(fmk_ctx *ctx, int transport, const char *rendezvous_path, int rank, int world, int flags,
+                    size_t ring_bytes, double timeout_s, fmk_comm **out)
+{
+    *out = nullptr;
+    if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
+        return fmk_set_error(ctx, FMK_E_ARG, "fmk_comm_create: rank %d of %d (at most %d ranks)", rank, world, MAX_WORLD);
+    if (transport != FMK_COMM_RCCL && transport != FMK_COMM_HOST)
+        return fmk_set_error(ctx, FMK_E_ARG, "fmk_comm_create: unknown transport %d", transport);
+    if (transport == FMK_COMM_RCCL && !ctx)
+        return fmk_set_error(ctx, FMK_E_ARG, "fmk_comm_create: the RCCL transport needs a context");
+    if (!rendezvous_path || !*rendezvous_path)
+        return fmk_set_error(ctx, FMK_E_ARG, "fmk_comm_create: no rendezvous path");
+    fmk_comm *c = (fmk_comm *)calloc(1, sizeof(fmk_comm));
+    if (!c) return fmk_set_error(ctx, FMK_E_NOMEM, "calloc");
+    c->ctx = ctx;
+    c->transport = transport;
+    c->rank = rank;
+    c->world = world;
+    c->flags = flags;
+    c->timeout_s = timeout_s > 0 ? timeout_s : 120.0;
+    if (ring_bytes == 0) ring_bytes = (size_t)1 << 20;
+    ring_bytes = (ring_bytes + 4095) & ~(size_t)4095;
+    if (transport == FMK_COMM_RCCL) ring_bytes = 4096;       // unused there
+    int rc = seg_attach(c, rendezvous_path, ring_bytes);
+    auto fail = [&](int code) {
+        if (ctx) fmk_set_error(ctx, code, "%s", c->err);
+        else fmk_set_error(nullptr, code, "%s", c->err);
+        fmk_comm_destroy(c);
+        return code;
+    };
+    if (rc != FMK_OK) return fail(rc);
+    nccl_unique_id id;
+    memset(&id, 0, sizeof id);
+    char why[384] = "";
+    int ok = 1;
+    if (transport == FMK_COMM_RCCL) {
+        const char *e = rccl_load();
+        if (e) { ok = 0; snprintf(why, sizeof why, "%s", e); }
+        if (ok && rank == 0) {
+            int r = g_rccl.GetUniqueId(&id);
+            if (r != 0) { ok = 0; snprintf(why, sizeof why, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r)); }
+        }
+    }
+    // everybody learns whether everybody can go on (a rank that cannot load librccl must not leave the others waiting
+    // inside ncclCommInitRank), and rank 0's id
+    struct { int ok; nccl_unique_id id; } mine, all[MAX_WORLD];
+    mine.ok = ok;
+    mine.id = id;
+    rc = gather(c, &mine, sizeof mine, all);
+    if (rc != FMK_OK) return fail(rc);
+    if (rank == 0) unlink(rendezvous_path);                  // everybody is attached: the name can go
+    for (int r = 0; r < world; ++r)
+        if (!all[r].ok) {
+            snprintf(c->err, sizeof c->err, "RCCL transport unavailable on rank %d%s%s", r, r == rank ? ": " : "",
+                     r == rank ? why : "");
+            return fail(FMK_E_COMM);
+        }
+    if (transport == FMK_COMM_RCCL) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            snprintf(c->err, sizeof c->err, "comm stream/events: %s", hipGetErrorString(e));
+            return fail(FMK_E_HIP);
+        }
+        int r = g_rccl.CommInitRank(&c->nccl, world, all[0].id, rank);
+        if (r != 0) {
+            c->nccl = nullptr;
+            snprintf(c->err, sizeof c->err, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
+            return fail(FMK_E_COMM);
+        }
+    }
+    *out = c;
+    return FMK_OK;
+}
+
+int fmk_comm_destroy(fmk_comm *c)
+{
+    if (!c) return FMK_OK;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->seg) munmap(c->seg, c->seg_bytes);
+    free(c);
+    return FMK_OK;
+}
+
+int fmk_comm_allgather(fmk_comm *c, const void *send, size_t bytes, void *recv) { return gather(c, send, bytes, recv); }
+
+int fmk_comm_barrier(fmk_comm *c) { return gather(c, nullptr, 0, nullptr); }
+
+int fmk_comm_halo_exchange_dev(fmk_comm *c, int n_cols, const void *const *send_ptrs, const size_t *send_bytes,
+                               void *const *recv_ptrs, const size_t *recv_bytes)
+{
+    if (n_cols < 0 || n_cols > 16) return comm_error(c, FMK_E_ARG, "fmk_comm_halo_exchange_dev: %d columns", n_cols);
+    const bool loop = (c->flags & FMK_COMM_SELF_LOOP) && c->world == 1;
+    const int to = loop ? 0 : (c->rank + 1 < c->world ? c->rank + 1 : -1);
+    const int from = loop ? 0 : (c->rank > 0 ? c->rank - 1 : -1);
+    if (to < 0 && from < 0) return FMK_OK;
+    if (c->transport == FMK_COMM_HOST)
+        return host_exchange(c, n_cols, send_ptrs, send_bytes, recv_ptrs, recv_bytes, to, from);
+    FMK_TRY(rccl_exchange(c, n_cols, send_ptrs, send_bytes, recv_ptrs, recv_bytes, to, from));
+    c->exchange_pending = 1;
+    return FMK_OK;
+}
+
+int fmk_comm_wait_dev(fmk_comm *c)
+{
+    if (c->transport != FMK_COMM_RCCL || !c->exchange_pending) return FMK_OK;
+    COMM_HIP(c, hipSetDevice(c->ctx->device));
+    COMM_HIP(c, hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));   // the context's stream continues after the exchange
+    c->exchange_pending = 0;
+    return FMK_OK;
+}
+
+int fmk_comm_sync(fmk_comm *c)
+{
+    if (c->stream) {
+        COMM_HIP(c, hipSetDevice(c->ctx->device));
+        COMM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return FMK_OK;
+}
+
+}  // extern "C"
+
+// ---- column helper of the sharded step: up to 8 small column slices copied by ONE launch ---------------------------
+struct FmkCopyCols {
+    const char *src[8];
+    char *dst[8];
+    unsigned long long bytes[8];
+};
+
+__global__ void k_copy_cols(FmkCopyCols c, int n_cols)
+{
+    const int col = blockIdx.y;
+    if (col >= n_cols) return;
+    const unsigned long long nb = c.bytes[col];
+    const char *s = c.src[col];
+    char *d = c.dst[col];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+extern "C" int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *const *dst, const size_t *bytes)
+{
+    if (n_cols < 0 || n_cols > 8) return fmk_set_error(ctx, FMK_E_ARG, "fmk_copy_cols_dev: %d columns (max 8)", n_cols);
+    FmkCopyCols c;
+    size_t mx = 0;
+    for (int i = 0; i < n_cols; ++i) {
+        c.src[i] = (const char *)src[i];
+        c.dst[i] = (char *)dst[i];
+        c.bytes[i] = bytes[i];
+        if (bytes[i] > mx) mx = bytes[i];
+    }
+    if (mx == 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bx = (mx + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    k_copy_cols<<<dim3((unsigned)bx, (unsigned)n_cols), 256, 0, ctx->stream>>>(c, n_cols);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}

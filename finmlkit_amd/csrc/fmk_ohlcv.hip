@@ -280,7 +280,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 8, (void **)&o.vol_redo));
         FMK_HIP(ctx, hipMemsetAsync(o.vol_redo, 0, 8, ctx->stream));
     }
-    const int slot = ctx->profile_on ? (ctx->profile_n++ & 63) : -1;     // time the dominant launch only
+    // time the dominant launch only (the one-bar boundary launch of a sharded step is not it)
+    const int slot = (ctx->profile_on && nb >= 64) ? (ctx->profile_n++ & 63) : -1;
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][0], ctx->stream));
     if (variant == 0) {   // generic streaming kernel only (+ stand-alone median)
         k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);

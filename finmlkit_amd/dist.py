@@ -9,10 +9,11 @@ empty-bar price, previous side/price of the first tick) to its right neighbour, 
 them to its shard.  Every bar is then reduced from raw ticks by exactly the kernels of the
 single-GPU path -> results identical to one GPU.  A bar is owned by the rank where it closes.
 
-Communication per step: two tiny all-gathers (first/last timestamp, halo length) and ONE
-point-to-point send/recv per neighbour pair (4 column slices, ~25 KB for 1-minute bars) --
-`torch.distributed` P2P, i.e. RCCL send/recv over a single xGMI link on the GPU box and gloo in
-the CPU tests.  No all-reduce, no ring.
+Communication: two tiny host all-gathers ONCE per trade set (first/last timestamp, halo length: the
+plan is a function of the immutable columns) and, per step, ONE point-to-point send/recv per
+neighbour pair (price + amount slices, ~15 KB for 1-minute bars) -- `ncclSend`/`ncclRecv` of librccl
+over a single xGMI link, called from csrc/fmk_comm.hip behind the C ABI (`fmk_comm_*`), ordered
+against the compute stream by events only.  No PyTorch, no all-reduce, no ring.
 
 The planning arithmetic is plain Python integers (exact); nothing here computes bar values.
 """
@@ -60,128 +61,234 @@ def plan_edges(first_ts: Sequence[int], n_edges: int, e0: int, d: int) -> List[E
 
 
 class Comm:
-    """Minimal wrapper over torch.distributed (nccl == RCCL on ROCm, gloo on CPU)."""
+    """One rank's handle on the node's ranks: `fmk_comm_*` of libfmk_hip.so (csrc/fmk_comm.hip) -- librccl's
+    ncclSend/ncclRecv on the communicator's own HIP stream (transport "rccl"), or host-staged through the rendezvous
+    segment (transport "host": tests, and with ctx=None plain host buffers).  No PyTorch anywhere.
 
-    def __init__(self, device=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.device = device if device is not None else torch.device("cpu")
+    `path` names the rendezvous file, the same string on every rank (rank 0 creates it, it is unlinked once all ranks
+    have attached).  The small all-gathers are for the SET-UP phase (host buffers, blocking); a step only calls
+    exchange() / wait(), which enqueue and return."""
+
+    def __init__(self, ctx, rank: int, world: int, path: str, transport: str = "rccl", self_loop: bool = False,
+                 ring_bytes: int = 0, timeout_s: float = 120.0):
+        import ctypes as C
+        from . import _ffi
+        self._C, self._ffi = C, _ffi
+        self.ctx, self.rank, self.world, self.transport = ctx, int(rank), int(world), transport
+        self._h = C.c_void_p()
+        kind = {"rccl": 0, "host": 1}[transport]
+        lib = _ffi.lib()
+        lib.fmk_comm_last_error.restype = C.c_char_p
+        lib.fmk_comm_last_error.argtypes = [C.c_void_p]
+        rc = lib.fmk_comm_create(ctx.handle if ctx is not None else None, C.c_int(kind), path.encode(), C.c_int(rank),
+                                 C.c_int(world), C.c_int(1 if self_loop else 0), C.c_size_t(ring_bytes),
+                                 C.c_double(timeout_s), C.byref(self._h))
+        _ffi.check(rc, ctx.handle if ctx is not None else None)
+
+    def _call(self, name, *args):
+        rc = getattr(self._ffi.lib(), name)(self._h, *args)
+        if rc != 0:
+            msg = self._ffi.lib().fmk_comm_last_error(self._h).decode(errors="replace")
+            if rc == self._ffi.E_ARG:
+                raise ValueError(msg)
+            raise self._ffi.FmkError(f"{name}: status {rc}: {msg}")
+
+    def _gather(self, vals, np_dtype):
+        import numpy as np
+        a = np.ascontiguousarray(vals, dtype=np_dtype)
+        out = np.empty((self.world, a.size), dtype=np_dtype)
+        self._call("fmk_comm_allgather", self._ffi.ptr(a), self._C.c_size_t(a.nbytes), self._ffi.ptr(out))
+        return out
 
     def all_gather_i64(self, vals: Sequence[int]) -> List[List[int]]:
-        t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=self.device)
-        out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        return [[int(x) for x in o.cpu().tolist()] for o in out]
+        import numpy as np
+        return [[int(x) for x in row] for row in self._gather(list(vals), np.int64)]
+
+    def all_gather_f64(self, vals: Sequence[float]) -> List[List[float]]:
+        import numpy as np
+        return [[float(x) for x in row] for row in self._gather(list(vals), np.float64)]
 
     def barrier(self):
-        if self.device.type == "cuda":
-            self.dist.barrier(device_ids=[self.device.index])
-        else:
-            self.dist.barrier()
+        """Host barrier over the ranks (callers synchronise their own stream first)."""
+        self._call("fmk_comm_barrier")
 
-    def neighbour_exchange(self, send_right: Sequence, recv_left: Sequence):
-        """Send `send_right` tensors to rank+1 and receive `recv_left` tensors from rank-1 (one batch)."""
-        ops = []
-        if self.rank + 1 < self.world:
-            ops += [self.dist.P2POp(self.dist.isend, t, self.rank + 1) for t in send_right]
-        if self.rank > 0:
-            ops += [self.dist.P2POp(self.dist.irecv, t, self.rank - 1) for t in recv_left]
-        if ops:
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()
+    def exchange(self, send: Sequence[Tuple[int, int]], recv: Sequence[Tuple[int, int]]):
+        """(pointer, bytes) column slices: `send` to rank+1, `recv` from rank-1 -- one ncclGroup (or one host-staged
+        round).  Both lists must have one entry per column; a side without a neighbour passes zero lengths."""
+        C = self._C
+        n = max(len(send), len(recv))
+        pad = lambda xs: list(xs) + [(0, 0)] * (n - len(xs))
+        send, recv = pad(send), pad(recv)
+        sp = (C.c_void_p * n)(*[p for p, _ in send])
+        sb = (C.c_size_t * n)(*[b for _, b in send])
+        rp = (C.c_void_p * n)(*[p for p, _ in recv])
+        rb = (C.c_size_t * n)(*[b for _, b in recv])
+        self._call("fmk_comm_halo_exchange_dev", C.c_int(n), sp, sb, rp, rb)
+
+    def wait(self):
+        """Make the context's stream wait (an event, not the host) for the exchange enqueued last."""
+        self._call("fmk_comm_wait_dev")
+
+    def sync(self):
+        self._call("fmk_comm_sync")
+
+    def close(self):
+        if self._h:
+            self._ffi.lib().fmk_comm_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedTimeBars:
-    """One rank's side of a sharded `TimeBarKit.build_ohlcv()` step, split into phases.
+    """One rank's side of a sharded `TimeBarKit.build_ohlcv()` step.
 
-    The exchange between the phases is the caller's: RCCL in bench.py, an in-process device copy between
-    virtual ranks in tests/test_gpu_dist.py.  Phases of one step:
+    SET-UP (host, once per trade set and interval -- every quantity is a function of the immutable columns, like
+    `DeviceTrades.first_last_ts`):
 
-      span()                 -> (first, last) timestamp of the shard            [all-gather #1]
-      launch_local(all_span) -> halo length this rank sends right               [all-gather #2, halo send/recv]
-                                (global clock + edge plan, local close indices, and -- already enqueued on the
-                                context's stream, overlapping the exchange -- every bar that needs no halo)
-      finish(recv_h)         -> number of bars; the bar straddling the left boundary is reduced from
-                                [halo | shard] by the same kernels.
+      span()                 -> (first, last) timestamp of the shard                     [all-gather #1]
+      make_plan(all_span)    -> halo length this rank sends right                        [all-gather #2]
+                                (global clock, edge plan, local close indices of the first and last edge)
+      set_halo(recv_h)       -> boundary buffers sized from the plan: [halo | head of the shard up to its first close]
 
-    `trades` must have been created with headroom (engine.DeviceTrades.synth(..., headroom=H)); the halo lands in
-    backing[H - recv_h : H], the halo sent right is backing[H + send_start : H + n].
+    STEP (device only: nothing below reads back, waits or allocates):
+
+      send_slices() / recv_slices()  the (pointer, bytes) lists of the one neighbour exchange
+      enqueue_interior()     local close indices + every bar that needs no halo (all of them on rank 0) -- enqueued
+                             while the halo travels on the communicator's stream
+      enqueue_boundary()     the bar straddling the left boundary, reduced from [halo | head] by the same kernels
+
+    `setup(comm)` / `step(comm)` run the phases over a `Comm`; tests/test_gpu_dist.py drives them with virtual ranks
+    and a device copy.  The raw ticks travel, not partial aggregates: every bar is reduced by the single-GPU kernels
+    from the same ticks in the same order, so the outputs are bit-identical to an un-sharded run.
     """
 
-    def __init__(self, trades, rank: int, world: int, interval_seconds: float, want_median: bool = True):
+    def __init__(self, trades, rank: int, world: int, interval_seconds: float, want_median: bool = True,
+                 with_side: bool = False, self_loop: bool = False):
         import numpy as np
         from ._ffi import DeviceArray
         self.t, self.rank, self.world = trades, rank, world
         self.interval, self.want_median = float(interval_seconds), want_median
+        self.with_side = with_side and trades.side is not None
+        self.self_loop = self_loop and world == 1
         self.ctx = trades.ctx
-        self.headroom = trades._headroom
         self._np, self._DA = np, DeviceArray
-        self._cap = 0
-        self._ci0 = DeviceArray(self.ctx, 2, np.int64)
         self.clock = self.idx = self.out = None
         self.plan = None
         self.send_start = trades.n
+        self.recv_h = 0
+        self._bnd = None
 
+    # ------------------------------------------------------------------ set-up
     def span(self) -> Tuple[int, int]:
         return self.t.first_last_ts()
 
-    def _ensure(self, ne: int):
-        if self._cap < ne:
-            self._cap = ne + 1024
-            self._clock = self._DA(self.ctx, self._cap, self._np.int64)
-            self._idx = self._DA(self.ctx, self._cap, self._np.int64)
-            self._out = self.t.alloc_ohlcv(self._cap, self.want_median)
+    def _cols(self, t):
+        cols = [t.price, t.amount]
+        if self.with_side:
+            cols.append(t.side)
+        return cols
 
-    def launch_local(self, all_span: Sequence[Sequence[int]]) -> int:
+    def make_plan(self, all_span: Sequence[Sequence[int]]) -> int:
         import ctypes as C
         from . import _ffi
         from ._ffi import c_f64, c_i64
+        np = self._np
         ne, e0, d = c_i64(), c_i64(), c_i64()
         _ffi.check(_ffi.lib().fmk_time_bar_clock(c_i64(int(all_span[0][0])), c_i64(int(all_span[-1][1])),
                                                  c_f64(self.interval), C.byref(ne), C.byref(e0), C.byref(d)))
         self.gclock = (ne.value, e0.value, d.value)
         self.plan = plan_edges([int(a[0]) for a in all_span], *self.gclock)[self.rank]
         my = self.plan
-        n_edges = my.hi - my.lo + 1
-        self._ensure(n_edges)
+        self.n_edges = my.hi - my.lo + 1
         self.e_lo = e0.value + my.lo * d.value
+        cap = self.n_edges + 1                                  # one spare output slot (self-loop diagnostic)
+        self._clock = self._DA(self.ctx, cap, np.int64)
+        self._idx = self._DA(self.ctx, cap, np.int64)
+        self._out = self.t.alloc_ohlcv(cap, self.want_median)
+        self.out = {k: v.view(0, self.n_edges - 1) for k, v in self._out.items()}
         # close indices of my edges in LOCAL coordinates (entry 0 is -1 on ranks > 0: the open edge lies left)
-        self.clock, self.idx = self.t.time_bar_index(self.interval, clock_params=(n_edges, self.e_lo, d.value),
+        self._index()
+        self.c_first = int(self.idx.view(1, 1).to_host()[0])     # read back ONCE, here
+        c_last = int(self.idx.view(self.n_edges - 1, 1).to_host()[0])
+        last = self.rank + 1 == self.world and not self.self_loop
+        self.send_start = self.t.n if last else c_last
+        return self.t.n - self.send_start
+
+    def set_halo(self, recv_h: int):
+        np = self._np
+        self.recv_h = int(recv_h)
+        if self.rank == 0 and not self.self_loop:
+            if recv_h:
+                raise RuntimeError("rank 0 has no left neighbour")
+            return
+        if recv_h < 1:
+            raise RuntimeError(f"rank {self.rank}: empty halo")
+        head = self.c_first + 1                                  # my ticks up to the first close
+        self._head = head
+        self._bnd = [self._DA(self.ctx, recv_h + head, c.dtype) for c in self._cols(self.t)]
+        # [open edge, first close] in [halo | head] coordinates: the halo's first tick is the open edge
+        self._ci0 = self._DA.from_host(self.ctx, np.array([0, recv_h + head - 1], dtype=np.int64))
+        from .engine import DeviceTrades
+        self._bt = DeviceTrades(self.ctx, None, self._bnd[0], self._bnd[1], self._bnd[2] if self.with_side else None)
+        slot = self.n_edges - 1 if self.self_loop else 0          # the diagnostic's extra bar goes to the spare slot
+        self._bout = {k: v.view(slot, 1) for k, v in self._out.items()}
+
+    def setup(self, comm: "Comm"):
+        """Both all-gathers of the set-up phase over `comm`; afterwards step(comm) can run any number of times."""
+        send_h = self.make_plan(comm.all_gather_i64(list(self.span())))
+        allh = comm.all_gather_i64([send_h])
+        self.set_halo(allh[self.rank - 1][0] if self.rank > 0 else (send_h if self.self_loop else 0))
+        return self
+
+    # ------------------------------------------------------------------ step
+    def send_slices(self) -> List[Tuple[int, int]]:
+        k = self.t.n - self.send_start
+        return [(c.ptr + self.send_start * c.dtype.itemsize, k * c.dtype.itemsize) for c in self._cols(self.t)]
+
+    def recv_slices(self) -> List[Tuple[int, int]]:
+        if self._bnd is None:
+            return [(0, 0) for _ in self._cols(self.t)]
+        return [(b.ptr, self.recv_h * b.dtype.itemsize) for b in self._bnd]
+
+    def _index(self):
+        self.clock, self.idx = self.t.time_bar_index(self.interval, clock_params=(self.n_edges, self.e_lo, self.gclock[2]),
                                                      out=(self._clock, self._idx))
-        self.out = {k: v.view(0, n_edges - 1) for k, v in self._out.items()}
-        last = self.rank + 1 == self.world
-        # one 8-byte read-back; it also orders this step's halo receive after the previous step's kernels
-        c_last = int(self.idx.view(n_edges - 1, 1).to_host()[0])
-        if last:
-            c_last = self.t.n
-        self.send_start = c_last
-        # bars that need no halo: all of them on rank 0, bars 1.. elsewhere (their ticks are local and the
-        # halo only prepends, so local coordinates are valid)
+
+    def enqueue_interior(self):
+        self._index()
+        # bars that need no halo: all of them on rank 0, bars 1.. elsewhere (their ticks are local)
         if self.rank == 0:
             self.t.bar_ohlcv(self.idx, want_median=self.want_median, out=self.out)
-        elif n_edges > 2:
+        elif self.n_edges > 2:
             self.t.bar_ohlcv(self.idx.view(1), want_median=self.want_median,
                              out={k: v.view(1) for k, v in self.out.items()})
-        return 0 if last else self.t.n - c_last
 
-    def finish(self, recv_h: int) -> int:
-        from ._ffi import c_i64
-        if self.rank > 0:
-            if recv_h < 1 or recv_h > self.headroom:
-                raise RuntimeError(f"rank {self.rank}: halo of {recv_h} ticks (headroom {self.headroom})")
-            th = self.t.with_halo(recv_h)
-            # [open edge, first close] in [halo | shard] coordinates: the open edge is the halo's first tick
-            self.ctx.call("fmk_time_bar_indexer_dev", th.ts.p, c_i64(th.n), c_i64(self.e_lo), c_i64(self.gclock[2]),
-                          c_i64(2), None, self._ci0.p)
-            th.bar_ohlcv(self._ci0, want_median=self.want_median, out={k: v.view(0, 1) for k, v in self.out.items()})
+    def enqueue_boundary(self) -> int:
+        import ctypes as C
+        if self._bnd is not None:
+            cols = self._cols(self.t)
+            n = len(cols)
+            src = (C.c_void_p * n)(*[c.ptr for c in cols])
+            dst = (C.c_void_p * n)(*[b.ptr + self.recv_h * b.dtype.itemsize for b in self._bnd])
+            nb = (C.c_size_t * n)(*[self._head * c.dtype.itemsize for c in cols])
+            self.ctx.call("fmk_copy_cols_dev", C.c_int(n), src, dst, nb)       # head of the shard behind the halo
+            self._bt.bar_ohlcv(self._ci0, want_median=self.want_median, out=self._bout)
         return self.plan.n_bars
 
+    def step(self, comm: "Comm") -> int:
+        comm.exchange(self.send_slices(), self.recv_slices())    # enqueued on the communicator's stream
+        self.enqueue_interior()                                   # overlaps the exchange
+        comm.wait()                                               # event: context stream after the exchange
+        return self.enqueue_boundary()
 
-    def features(self, recv_h: int, price_tick_size: float, imbalance_factor: float = 3.0):
-        """cfg 4 on the shard (after `finish`): order-flow + footprints of this rank's bars through the same
-        kernels as one GPU -- interior bars in local coordinates, the boundary bar from [halo | shard].
+    def features(self, price_tick_size: float, imbalance_factor: float = 3.0):
+        """cfg 4 on the shard (after a step with with_side=True): order-flow + footprints of this rank's bars through
+        the same kernels as one GPU -- interior bars in local coordinates, the boundary bar from [halo | head].
 
         -> (directional dict, level_counts int64[B], flat dict, per-bar dict) as host arrays in bar order.  The
         spread columns of the global stream's very first bar use the reference's wrap-around tick prices[-1]
@@ -190,11 +297,9 @@ class ShardedTimeBars:
         np = self._np
         from .engine import to_host
         parts = []
-        n_edges = self.plan.n_bars + 1
         if self.rank > 0:
-            th = self.t.with_halo(recv_h)
-            parts.append(th.bars_fused(self._ci0, price_tick_size, imbalance_factor, want_median=False))
-            if n_edges > 2:
+            parts.append(self._bt.bars_fused(self._ci0, price_tick_size, imbalance_factor, want_median=False))
+            if self.n_edges > 2:
                 parts.append(self.t.bars_fused(self.idx.view(1), price_tick_size, imbalance_factor, want_median=False))
         else:
             parts.append(self.t.bars_fused(self.idx, price_tick_size, imbalance_factor, want_median=False))
@@ -285,11 +390,3 @@ class ShardedTickLevel:
                       C.c_int(bool(mean0)), None if st is None else st.p, out.p)
         self.ctx.sync()                                                       # `st` must outlive the kernel
         return out if self.rank == 0 else out.view(1, self.t.n)
-
-
-def halo_lengths(comm: Comm, n_local: int, close_of_last_edge: int) -> Tuple[int, int]:
-    """(halo I send, halo I receive).  The halo is ticks [close_of_last_edge, n_local)."""
-    send = n_local - close_of_last_edge if comm.rank + 1 < comm.world else 0
-    allh = comm.all_gather_i64([send])
-    recv = allh[comm.rank - 1][0] if comm.rank > 0 else 0
-    return send, recv

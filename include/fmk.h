@@ -47,6 +47,7 @@ extern "C" {
 #define FMK_E_NOMEM (-5)    /* MemoryError */
 #define FMK_E_HIP (-6)      /* RuntimeError: HIP runtime failure, see fmk_last_error */
 #define FMK_E_NODEVICE (-7) /* RuntimeError: no gfx950 device / HIP runtime unusable */
+#define FMK_E_COMM (-8)     /* RuntimeError: multi-GPU rendezvous / RCCL failure or a peer that never arrived */
 
 #define FMK_ABI_VERSION 1
 
@@ -303,6 +304,36 @@ int fmk_merge_split_trades(fmk_ctx *ctx, const int64_t *ts, const double *price,
 /* comp_trade_side_vector (bar/utils.py:26-46): tick rule, side[0] = 0. */
 int fmk_comp_trade_side_vector_dev(fmk_ctx *ctx, const double *d_price, int64_t n, int8_t *d_out);
 int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int8_t *out);
+
+/* ---- multi-GPU: one neighbour halo exchange per step (BASELINE cfg 5) ------------------------
+ * The reference has no distributed code (last row); these entry points are new.  Rank r of `world` holds
+ * a contiguous tick range of one stream; the trailing partial bar of rank r travels as raw ticks to rank r+1.
+ * No PyTorch: librccl is dlopen'ed by fmk_comm_create(FMK_COMM_RCCL) and the ranks of the node meet in a shared-memory
+ * file (`rendezvous_path`, the same string on every rank; rank 0 creates it and unlinks it once all have attached).
+ * Every wait has a deadline (`timeout_s`, <= 0: 120 s): a missing peer is FMK_E_COMM, not a hang. */
+typedef struct fmk_comm fmk_comm;
+#define FMK_COMM_RCCL 0      /* ncclSend / ncclRecv over xGMI on the communicator's own stream */
+#define FMK_COMM_HOST 1      /* host-staged through the rendezvous segment; ctx may be NULL (host pointers) */
+#define FMK_COMM_SELF_LOOP 1 /* flags: with world == 1 the rank is its own left and right neighbour (diagnostic) */
+int fmk_comm_create(fmk_ctx *ctx, int transport, const char *rendezvous_path, int rank, int world, int flags,
+                    size_t ring_bytes /* host transport: bytes of each rank's receive ring, 0 = 1 MiB */,
+                    double timeout_s, fmk_comm **out);
+int fmk_comm_destroy(fmk_comm *comm);
+const char *fmk_comm_last_error(const fmk_comm *comm);
+/* Set-up phase, HOST buffers, blocking: `bytes` (<= 4096) from every rank, in rank order; barrier = empty gather. */
+int fmk_comm_allgather(fmk_comm *comm, const void *send, size_t bytes, void *recv);
+int fmk_comm_barrier(fmk_comm *comm);
+/* One exchange: column slice i of `send_*` goes to rank+1 (ignored on the last rank), `recv_*` arrives from rank-1
+ * (ignored on rank 0); sizes in bytes, zero-length columns allowed, both sides must agree on them.
+ * RCCL: enqueued as ONE ncclGroup on the communicator's stream, which first waits (event) for everything already
+ * enqueued on the context's stream; returns at once.  fmk_comm_wait_dev makes the context's stream wait (event) for
+ * that exchange -- kernels enqueued between the two calls overlap it.  HOST: synchronous, complete on return. */
+int fmk_comm_halo_exchange_dev(fmk_comm *comm, int n_cols, const void *const *send_ptrs, const size_t *send_bytes,
+                               void *const *recv_ptrs, const size_t *recv_bytes);
+int fmk_comm_wait_dev(fmk_comm *comm);
+int fmk_comm_sync(fmk_comm *comm); /* host wait for the communicator's stream (tear-down, tests) */
+/* Up to 8 small device column slices copied by one launch on the context's stream (boundary-bar assembly). */
+int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *const *dst, const size_t *bytes);
 
 /* ---- diagnostics ------------------------------------------------------------------------ */
 /* Read-only streaming bandwidth probe (tools/readbw.py): calibrates the HBM ceiling quoted in DESIGN.md.

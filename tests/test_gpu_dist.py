@@ -1,34 +1,51 @@
-"""GPU: the sharded time-bar step of finmlkit_amd/dist.py (what bench.py runs at --gpus N > 1), driven with W
-virtual ranks on ONE device: the halo travels by a device copy instead of RCCL, everything else -- global clock,
-edge plan, local index, interior bars before the halo arrives, boundary bar from [halo | shard] -- is the code
-the real ranks execute.  The concatenated per-rank outputs must equal one un-sharded run, bit for bit."""
+"""GPU: the sharded time-bar step of finmlkit_amd/dist.py (what bench.py runs at --gpus N > 1).
+
+* W *virtual ranks* on ONE device in one process: the halo travels by a device copy, everything else -- global clock,
+  edge plan, local index, interior bars, boundary bar from [halo | head of the shard] -- is the code the real ranks run.
+* W = 2 REAL processes on one device through the C entry points `fmk_comm_*` with the host-staged transport
+  (`ShardedTimeBars.setup(comm)` / `.step(comm)`, exactly bench.py's calls).
+* the RCCL transport with one rank that is its own neighbour (ncclSend / ncclRecv to self): librccl is loaded, a
+  communicator is built, the grouped exchange runs on the communicator's stream and the event ordering is exercised.
+The concatenated per-rank outputs must equal one un-sharded run, bit for bit."""
 import ctypes as C
+import multiprocessing as mp
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-HALO = 1 << 16
 KEYS = ["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"]
 
 
+def _copy_halo(ctx, left, right):
+    """What the exchange does between two virtual ranks: left.send_slices() -> right.recv_slices()."""
+    for (sp, sb), (rp, rb) in zip(left.send_slices(), right.recv_slices()):
+        assert sb == rb and sb > 0
+        ctx.call("fmk_d2d", C.c_void_p(rp), C.c_void_p(sp), C.c_size_t(sb))
+
+
+def _setup_virtual(dist, shards, interval, want_median=True, with_side=False):
+    world = len(shards)
+    ranks = [dist.ShardedTimeBars(t, r, world, interval, want_median, with_side=with_side) for r, t in enumerate(shards)]
+    spans = [list(s.span()) for s in ranks]                    # all-gather #1
+    send_h = [s.make_plan(spans) for s in ranks]               # all-gather #2
+    assert send_h[-1] == 0
+    for r, s in enumerate(ranks):
+        s.set_halo(send_h[r - 1] if r else 0)
+    return ranks
+
+
 def _run_sharded(engine, dist, ctx, world, n, gap_mod, interval, want_median=True, steps=1):
-    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, gap_mod=gap_mod, ctx=ctx, headroom=HALO)
-              for r in range(world)]
-    ranks = [dist.ShardedTimeBars(t, r, world, interval, want_median) for r, t in enumerate(shards)]
-    for _ in range(steps):                                     # a second step reuses the buffers
-        spans = [list(s.span()) for s in ranks]                # all-gather #1
-        send_h = [s.launch_local(spans) for s in ranks]        # all-gather #2
-        for r in range(1, world):                              # the halo: left rank's tail -> my headroom
-            h = send_h[r - 1]
-            assert 1 <= h <= HALO
-            for src, dst in zip(shards[r - 1]._backing, shards[r]._backing):
-                s = src.view(HALO + ranks[r - 1].send_start, h)
-                d = dst.view(HALO - h, h)
-                ctx.call("fmk_d2d", d.p, s.p, C.c_size_t(s.nbytes))
-        assert send_h[-1] == 0
-        nb = [s.finish(send_h[r - 1] if r else 0) for r, s in enumerate(ranks)]
+    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, gap_mod=gap_mod, ctx=ctx) for r in range(world)]
+    ranks = _setup_virtual(dist, shards, interval, want_median)
+    for _ in range(steps):                                     # a second step reuses every buffer
+        for r in range(1, world):
+            _copy_halo(ctx, ranks[r - 1], ranks[r])
+        for s in ranks:
+            s.enqueue_interior()
+        nb = [s.enqueue_boundary() for s in ranks]
     out = {k: np.concatenate([s.out[k].to_host()[:b] for s, b in zip(ranks, nb)]) for k in KEYS if want_median or k != KEYS[-1]}
     clock = np.concatenate([ranks[0].clock.to_host()[:1]] + [s.clock.to_host()[1:b + 1] for s, b in zip(ranks, nb)])
     return clock, out
@@ -62,11 +79,11 @@ def test_virtual_ranks_match_unsharded(orc, world, n, sparse, interval):
 def test_shard_without_complete_bar_is_rejected():
     from finmlkit_amd import _ffi, dist, engine
     ctx = _ffi.default_context()
-    shards = [engine.DeviceTrades.synth(500, seed=1, first=r * 500, ctx=ctx, headroom=HALO) for r in range(2)]
+    shards = [engine.DeviceTrades.synth(500, seed=1, first=r * 500, ctx=ctx) for r in range(2)]
     ranks = [dist.ShardedTimeBars(t, r, 2, 3600.0) for r, t in enumerate(shards)]
     spans = [list(s.span()) for s in ranks]
     with pytest.raises(ValueError, match="complete bar close"):
-        ranks[1].launch_local(spans)
+        ranks[1].make_plan(spans)
 
 
 @pytest.mark.parametrize("world,n,interval", [(3, 250_000, 60.0), (2, 300_000, 7200.0)])
@@ -74,19 +91,14 @@ def test_virtual_ranks_features_match_unsharded(world, n, interval):
     """cfg 4 on shards: order-flow + footprints of every rank's bars == the un-sharded run (same kernels, same ticks)."""
     from finmlkit_amd import _ffi, dist, engine
     ctx = _ffi.default_context()
-    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, ctx=ctx, headroom=HALO) for r in range(world)]
-    ranks = [dist.ShardedTimeBars(t, r, world, interval, True) for r, t in enumerate(shards)]
-    spans = [list(s.span()) for s in ranks]
-    send_h = [s.launch_local(spans) for s in ranks]
+    shards = [engine.DeviceTrades.synth(n, seed=42, first=r * n, ctx=ctx) for r in range(world)]
+    ranks = _setup_virtual(dist, shards, interval, True, with_side=True)
     for r in range(1, world):
-        h = send_h[r - 1]
-        for src, dst in zip(shards[r - 1]._backing, shards[r]._backing):
-            s_, d_ = src.view(HALO + ranks[r - 1].send_start, h), dst.view(HALO - h, h)
-            ctx.call("fmk_d2d", d_.p, s_.p, C.c_size_t(s_.nbytes))
-    recv = [send_h[r - 1] if r else 0 for r in range(world)]
-    for r, s in enumerate(ranks):
-        s.finish(recv[r])
-    parts = [s.features(recv[r], 0.01, 3.0) for r, s in enumerate(ranks)]
+        _copy_halo(ctx, ranks[r - 1], ranks[r])
+    for s in ranks:
+        s.enqueue_interior()
+        s.enqueue_boundary()
+    parts = [s.features(0.01, 3.0) for s in ranks]
     whole = engine.DeviceTrades.synth(world * n, seed=42, ctx=ctx)
     _, wci = whole.time_bar_index(interval)
     o, d, nz, off, flat, bar, bad = whole.bars_fused(wci, 0.01, 3.0, want_median=False)
@@ -106,6 +118,7 @@ def test_virtual_ranks_features_match_unsharded(world, n, interval):
 @pytest.mark.parametrize("world,n,window,half_life,mean0", [(3, 300_000, 5.0, 60.0, False), (4, 150_000, 60.0, 5.0, True),
                                                           (2, 200_001, 0.5, 600.0, False)])
 def test_virtual_ranks_tick_level_features(world, n, window, half_life, mean0):
+    HALO = 1 << 16
     """Sharded comp_lagged_returns (raw-tick halo of one window) and ewmst (maps of the lower ranks -> incoming state)
     == the un-sharded run: returns bit-identical, sigma within the float tolerance (different composition order)."""
     from finmlkit_amd import _ffi, dist, engine
@@ -136,3 +149,72 @@ def test_virtual_ranks_tick_level_features(world, n, window, half_life, mean0):
         w = want_s[r * n:(r + 1) * n]
         assert got.shape == w.shape and np.array_equal(np.isnan(got), np.isnan(w)), f"rank {r}"
         np.testing.assert_allclose(got, w, rtol=1e-9, atol=0, equal_nan=True, err_msg=f"sigma rank {r}")
+
+
+# ---- real processes, real C entry points ----------------------------------------------------------------------------
+def _proc_worker(rank, world, path, n, interval, out_dir, transport, steps):
+    os.environ["FMK_DEVICE"] = "0"                              # both ranks share the box's one GPU
+    from finmlkit_amd import _ffi, dist, engine
+    ctx = _ffi.default_context()
+    comm = dist.Comm(ctx, rank, world, path, transport, self_loop=(world == 1), ring_bytes=8192, timeout_s=120.0)
+    t = engine.DeviceTrades.synth(n, seed=42, first=rank * n, ctx=ctx)
+    shard = dist.ShardedTimeBars(t, rank, world, interval, True, self_loop=(world == 1)).setup(comm)
+    for _ in range(steps):
+        nb = shard.step(comm)
+    ctx.sync()
+    comm.sync()
+    res = {k: v.to_host()[:nb] for k, v in shard.out.items()}
+    res["clock"] = shard.clock.to_host()[:nb + 1]
+    if world == 1:                                              # the self-loop's extra bar sits in the spare slot
+        res["loop_trades"] = shard._out["trades"].view(nb, 1).to_host()
+        res["loop_expect"] = np.array([shard.recv_h - 1 + shard._head], dtype=np.int64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    comm.barrier()
+    comm.close()
+
+
+def _spawn(world, args):
+    mpx = mp.get_context("spawn")
+    procs = [mpx.Process(target=_proc_worker, args=(r, world) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("worker hung")
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+
+
+def _whole(world, n, interval):
+    from finmlkit_amd import _ffi, engine
+    ctx = _ffi.default_context()
+    whole = engine.DeviceTrades.synth(world * n, seed=42, ctx=ctx)
+    wclock, wci = whole.time_bar_index(interval)
+    return wclock.to_host(), engine.to_host(whole.bar_ohlcv(wci))
+
+
+@pytest.mark.parametrize("world,n,interval", [(2, 500_000, 60.0), (3, 200_000, 60.0)])
+def test_processes_host_transport_match_unsharded(tmp_path, world, n, interval):
+    _spawn(world, (str(tmp_path / "rdv"), n, interval, str(tmp_path), "host", 3))
+    parts = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(world)]
+    wclock, want = _whole(world, n, interval)
+    clock = np.concatenate([parts[0]["clock"][:1]] + [p["clock"][1:] for p in parts])
+    np.testing.assert_array_equal(clock, wclock)
+    for k in KEYS:
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), want[k], err_msg=k)
+
+
+def test_rccl_self_loop_one_rank(tmp_path):
+    """librccl behind the C ABI: communicator of size 1, ncclSend/ncclRecv to self on the communicator's stream, event
+    ordering against the context's stream; the rank's own bars are untouched and equal the un-sharded run, the extra
+    boundary bar made of [own tail | own head] has exactly the ticks it was given."""
+    n, interval = 600_000, 60.0
+    _spawn(1, (str(tmp_path / "rdv"), n, interval, str(tmp_path), "rccl", 4))
+    p = dict(np.load(tmp_path / "rank0.npz"))
+    wclock, want = _whole(1, n, interval)
+    np.testing.assert_array_equal(p["clock"], wclock)
+    for k in KEYS:
+        np.testing.assert_array_equal(p[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(p["loop_trades"], p["loop_expect"])
