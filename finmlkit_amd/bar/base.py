@@ -111,9 +111,8 @@ class BarBuilderBase(ABC):
     def build_directional_features(self) -> pd.DataFrame:
         """Order-flow features per bar (reference base.py:171-212)."""
         from ..engine import to_host
-        self._set_bar_close()
-        self._check_indices()
-        if "side" not in self.trades_df.columns:
+        self._set_bar_close()             # fewer than two close indices = no bars: empty frame (only comp_bar_ohlcv
+        if "side" not in self.trades_df.columns:          # checks for that in the reference, base.py:334-335)
             raise KeyError("side")
         dev = self._device()
         out, nz = dev.bar_directional(self._d_close_idx)
@@ -134,8 +133,7 @@ class BarBuilderBase(ABC):
         """Relative mean / 95th-percentile trade size, block share and size Gini per bar
         (reference base.py:214-245)."""
         self._set_bar_close()
-        self._check_indices()
-        nb = len(self._close_indices) - 1
+        nb = max(len(self._close_indices) - 1, 0)
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         if len(theta) != nb:
             raise ValueError("Theta should match the the number of bars (len(bar_close_indices) - 1).")
@@ -149,9 +147,8 @@ class BarBuilderBase(ABC):
         """Per-bar price-level footprints + imbalance statistics (reference base.py:247-300)."""
         from ..engine import to_host
         self._set_bar_close()
-        self._check_indices()
         if self._highs is None or self._lows is None:
-            self.build_ohlcv()
+            self.build_ohlcv()            # raises for fewer than two close indices, as the reference does here
         if price_tick_size is None:
             price_tick_size = comp_price_tick_size(self.trades_df["price"].values)
         logger.info(f"Price tick size is set to: {price_tick_size}")

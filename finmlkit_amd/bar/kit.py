@@ -85,10 +85,29 @@ class CUSUMBarKit(BarBuilderBase):
         logger.info(f"CUSUM Bar builder initialized with: sigma multiplier={sigma_mult}.")
 
     def _comp_bar_close(self):
-        timestamps = self.trades_df["timestamp"].astype(np.int64).values
-        prices = self.trades_df["price"].values
-        close_indices = _cusum_bar_indexer(timestamps, prices, self._sigma, self.sigma_floor, self.lambda_mult)
-        return timestamps[close_indices], close_indices
+        """`_cusum_bar_indexer` (logic.py:152-221) on the builder's RESIDENT timestamp / price columns: only sigma is
+        uploaded (and, forward-filled from its first valid entry, written back in place like the reference, :187-189)."""
+        import ctypes as C
+        from .._ffi import DeviceArray, c_f64, c_i64
+        dev = self._device()
+        n = dev.n
+        sigma = self._sigma
+        if not isinstance(sigma, np.ndarray) or len(sigma) != n or n == 0:
+            # length quirks of the reference's chained comparison (logic.py:174-175): the NumPy-level function has them
+            timestamps = self.trades_df["timestamp"].astype(np.int64).values
+            close_indices = _cusum_bar_indexer(timestamps, self.trades_df["price"].values, sigma, self.sigma_floor,
+                                               self.lambda_mult)
+            return timestamps[close_indices], close_indices
+        d_sigma = DeviceArray.from_host(dev.ctx, np.ascontiguousarray(sigma, dtype=np.float64))
+        m = c_i64()
+        args = (dev.ts.p, dev.price.p, d_sigma.p, c_i64(n), c_f64(self.sigma_floor), c_f64(self.lambda_mult))
+        d_all = DeviceArray(dev.ctx, n, np.int64)                   # at most one close per tick: one pass, no count phase
+        dev.ctx.call("fmk_cusum_bar_indexer_dev", *args, d_all.p, c_i64(n), C.byref(m), None)
+        d_idx = d_all.view(0, m.value)
+        if sigma.flags["WRITEABLE"]:
+            sigma[...] = d_sigma.to_host()                          # the in-place forward fill, visible to the caller
+        self._d_close_idx = d_idx
+        return dev.gather_ts(d_idx).to_host(), d_idx.to_host()      # timestamps[close_indices] (kit.py:172-174)
 
     def get_sigma(self):
         """The (forward-filled) sigma at the close indices (reference kit.py:176-181)."""

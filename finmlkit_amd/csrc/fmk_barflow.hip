@@ -399,6 +399,6 @@ extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, cons
     FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
                                          d_n_zero_div));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
-                                       price_tick_size, d_bar_lows, (float)imbalance_factor, d_level_offsets, 0,
+                                       price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
                                        max_levels, d_fp, d_n_bad_level);
 }

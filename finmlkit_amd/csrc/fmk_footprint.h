@@ -103,7 +103,7 @@ __device__ __forceinline__ bool fp_certified(const FpStats &st, int q)
 // Level rows + comp_footprint_features (base.py:755-850) of ONE bar from the wave's LDS histogram:
 //   vol[2L] float32 (buy = 2l, sell = 2l+1), cnt[2L], aux[2*lmax] scratch, stk[64] ints.  `base` = CSR row offset.
 __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t base, int L, int64_t low, int lmax,
-                                            float m32, int lane, float *vol, int *cnt, float *aux, int *stk)
+                                            double imb_mult, int lane, float *vol, int *cnt, float *aux, int *stk)
 {
     // ---- pass A: write the level rows, total[l] = buy + sell (float32), argmax, vwap numerator
     float *tot = aux;
@@ -147,8 +147,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         bool bi = false, si = false;
         if (l < L) {
             const float bv = vol[2 * l], sv = vol[2 * l + 1];
-            if (l < L - 1) si = sv > vol[2 * (l + 1)] * m32;          // base.py:797
-            if (l >= 1) bi = bv > vol[2 * (l - 1) + 1] * m32;         // base.py:798
+            if (l < L - 1) si = (double)sv > (double)vol[2 * (l + 1)] * imb_mult;         // base.py:797
+            if (l >= 1) bi = (double)bv > (double)vol[2 * (l - 1) + 1] * imb_mult;        // base.py:798
             o.buy_imbalances[base + l] = bi;
             o.sell_imbalances[base + l] = si;
             sign[l] = bi ? 1 : (si ? -1 : 0);

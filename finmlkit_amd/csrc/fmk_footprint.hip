@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const void *__restrict__ amount,
                                                         const int8_t *__restrict__ side,
                                                         const int64_t *__restrict__ ci, int64_t nb, double tick,
-                                                        const double *__restrict__ lows, float m32,
+                                                        const double *__restrict__ lows, double imb_mult,
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
                                                         FpOut o, unsigned long long *n_bad, int force_ordered,
                                                         unsigned char *gscratch)
@@ -252,13 +252,13 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
         __builtin_amdgcn_wave_barrier();
 
-        fp_emit_bar(o, b, base, L, low, lmax, m32, lane, vol, cnt, aux, stk);
+        fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk);
     }
 }
 
 template <bool AF64>
 static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t *sd, const int64_t *ci, int64_t nb,
-                     double tick, const double *lows, float m32, const int64_t *off, int lmin, int lmax, int wpb,
+                     double tick, const double *lows, double imb_mult, const int64_t *off, int lmin, int lmax, int wpb,
                      const FpOut &o, unsigned long long *n_bad)
 {
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
@@ -282,11 +282,11 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (gscratch)
-        k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32, off,
+        k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
                                                                                    gscratch);
     else
-        k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, m32,
+        k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr);
     FMK_LAUNCH_CHECK(ctx);
@@ -309,16 +309,17 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
                              (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
-                                       price_tick_size, d_bar_lows, (float)imbalance_factor, d_level_offsets, 0,
+                                       price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
                                        max_levels, d_out, d_n_bad_level);
 }
 
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
-                                const double *d_bar_lows, float m32, const int64_t *d_level_offsets, int lmin_start,
+                                const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level)
 {
-    // m32: float32 array * Python float -> float32 (NEP 50)
+    // imb_mult stays float64: array(float32) * float64 is float64 under Numba typing (the production path); NumPy 2 / NEP 50
+    // would round the product to float32 -- they differ only for inexact products (decimal lots), see oracle/fmk_oracle.c
     FpOut o;
     memcpy(&o, d_out, sizeof(o));
     unsigned long long *bad = (unsigned long long *)d_n_bad_level;
@@ -330,9 +331,9 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         if (LMAX[k] > lmin_start) {
             int rc = amount_is_f64
                          ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                           m32, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad)
+                                           imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad)
                          : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                            m32, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad);
+                                            imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad);
             if (rc) return rc;
         }
         lmin = LMAX[k];

@@ -271,3 +271,54 @@ extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar
                              "bucketed (the reference raises a broadcast ValueError here)");
     return FMK_OK;
 }
+
+
+// ---- calc_volume_percentage_above_poc (volume.py:367-391) as a stand-alone call ----------------------------------------
+// One wave: NumPy-pairwise float32 total (np.sum of a float32 array), then the reference's sequential `+=` over the levels
+// above the POC in float64 (Numba's type unification of `volume_above_poc = 0.0; += float32`), float64 quotient.
+__global__ __launch_bounds__(64) void k_pct_above_poc(const int32_t *__restrict__ levels, const float *__restrict__ vol,
+                                                      int n, int32_t poc_price, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(8))) int stk[FMK_PW_STK_F32];
+    const int lane = fmk_lane();
+    const float total = fmk_pairwise_f32([&](int i) { return vol[i]; }, n, lane, stk);
+    if (lane == 0) {
+        double r = 0.0;
+        if (total > 0.f) {
+            double above = 0.0;
+            for (int k = 0; k < n; ++k)
+                if (levels[k] > poc_price) above += (double)vol[k];
+            if (above > 0.0) r = above / (double)total;
+        }
+        *out = r;
+    }
+}
+
+extern "C" int fmk_calc_volume_percentage_above_poc_dev(fmk_ctx *ctx, const int32_t *d_price_levels, const float *d_volumes,
+                                                        int64_t n, int32_t poc_price, double *d_out)
+{
+    if (n < 0 || n > FMK_PW_MAX_N) return fmk_set_error(ctx, FMK_E_ARG, "calc_volume_percentage_above_poc: %lld levels", (long long)n);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    k_pct_above_poc<<<1, 64, 0, ctx->stream>>>(d_price_levels, d_volumes, (int)n, poc_price, d_out);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
+extern "C" int fmk_calc_volume_percentage_above_poc(fmk_ctx *ctx, const int32_t *price_levels, const float *volumes,
+                                                    int64_t n, int32_t poc_price, double *out)
+{
+    *out = 0.0;
+    if (n <= 0) return FMK_OK;                                  // np.sum of nothing is 0 -> 0.0 (volume.py:377-379)
+    void *d_l = nullptr, *d_v = nullptr, *d_o = nullptr;
+    int rc = fmk_alloc(ctx, (size_t)n * 4, &d_l);
+    if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)n * 4, &d_v);
+    if (rc == FMK_OK) rc = fmk_alloc(ctx, 8, &d_o);
+    if (rc == FMK_OK) rc = fmk_h2d(ctx, d_l, price_levels, (size_t)n * 4);
+    if (rc == FMK_OK) rc = fmk_h2d(ctx, d_v, volumes, (size_t)n * 4);
+    if (rc == FMK_OK) rc = fmk_calc_volume_percentage_above_poc_dev(ctx, (const int32_t *)d_l, (const float *)d_v, n, poc_price, (double *)d_o);
+    if (rc == FMK_OK) rc = fmk_d2h(ctx, out, d_o, 8);
+    if (d_l) fmk_free(ctx, d_l);
+    if (d_v) fmk_free(ctx, d_v);
+    if (d_o) fmk_free(ctx, d_o);
+    return rc;
+}

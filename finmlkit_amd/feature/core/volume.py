@@ -66,6 +66,19 @@ def volume_profile_rolling(ts, highs, lows, price_levels, buy_volumes, sell_volu
     return volume_profile_rolling_csr(ts, highs, lows, off, pl, bv, sv, window_size_sec, n_bins, price_tick, va_pct)
 
 
+def calc_volume_percentage_above_poc(price_levels: NDArray[np.int32], volumes: NDArray[np.float32], poc_price: int) -> float:
+    """Share (0..1) of the volume that sits on levels above `poc_price` (reference volume.py:367-391), on the device."""
+    pl = np.ascontiguousarray(price_levels, dtype=np.int32)
+    v = np.ascontiguousarray(volumes, dtype=np.float32)
+    if len(pl) != len(v):
+        raise IndexError(f"index {min(len(pl), len(v))} is out of bounds for axis 0 with size {min(len(pl), len(v))}")
+    out = c_f64()
+    import ctypes as C
+    _ffi.default_context().call("fmk_calc_volume_percentage_above_poc", ptr(pl), ptr(v), c_i64(len(pl)),
+                                C.c_int32(int(poc_price)), C.byref(out))
+    return out.value
+
+
 class VolumePro:
     """Rolling POC / value-area calculator (reference volume.py:12-131)."""
 

@@ -9,9 +9,13 @@ The other ~37 bar-level transforms of the reference are out of scope (SURVEY.md 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import pandas as pd
 
+from .. import _ffi
+from .._ffi import DeviceArray, c_f64, c_i64
 from .core.utils import comp_lagged_returns
 from .core.volatility import ewmst, realized_vol
 
@@ -54,6 +58,10 @@ class SISOTransform:
     def _hip(self, x):
         raise NotImplementedError
 
+    def _dev(self, ts, y):
+        """Device-resident form used by `Compose`: (DeviceArray timestamps, DeviceArray input) -> DeviceArray output."""
+        raise NotImplementedError
+
 
 class ReturnT(SISOTransform):
     """Lagged return over a time window on an irregular series (reference transforms.py:89-117)."""
@@ -69,6 +77,14 @@ class ReturnT(SISOTransform):
         res = comp_lagged_returns(self._get_timestamps(x), self._prepare_input_nb(x), self.window_sec, self.is_log)
         return self._prepare_output_nb(x.index, res)
 
+    def _dev(self, ts, y):
+        if self.window_sec <= 0:
+            raise ValueError("The return window must be greater than zero.")
+        out = DeviceArray(ts.ctx, y.n, np.float64)
+        ts.ctx.call("fmk_comp_lagged_returns_dev", ts.p, y.p, c_i64(y.n), c_f64(self.window_sec), C.c_int(bool(self.is_log)),
+                    out.p)
+        return out
+
 
 class EWMST(SISOTransform):
     """Time-decay exponentially weighted std (reference transforms.py:308-332)."""
@@ -82,6 +98,11 @@ class EWMST(SISOTransform):
         res = ewmst(self._get_timestamps(x), self._prepare_input_nb(x), self.half_life_sec)
         return self._prepare_output_nb(x.index, res)
 
+    def _dev(self, ts, y):
+        out = DeviceArray(ts.ctx, y.n, np.float64)
+        ts.ctx.call("fmk_ewmst_dev", ts.p, y.p, c_i64(y.n), c_f64(self.half_life_sec), c_f64(1e-12), C.c_int(0), out.p)
+        return out
+
 
 class RealizedVolatility(SISOTransform):
     """Rolling realised volatility of a return series (reference transforms.py:449-491)."""
@@ -94,6 +115,13 @@ class RealizedVolatility(SISOTransform):
     def _hip(self, x):
         res = realized_vol(self._prepare_input_nb(x).astype(np.float64), self.window, self.is_sample)
         return self._prepare_output_nb(x.index, res)
+
+    def _dev(self, ts, y):
+        out = DeviceArray(ts.ctx, y.n, np.float64)
+        if int(self.window) == 0:                      # every window is empty (core/volatility.py realized_vol)
+            return DeviceArray.from_host(ts.ctx, np.full(y.n, np.nan))
+        ts.ctx.call("fmk_realized_vol_dev", y.p, c_i64(y.n), c_i64(int(self.window)), C.c_int(bool(self.is_sample)), out.p)
+        return out
 
 
 class Compose(SISOTransform):
@@ -113,6 +141,16 @@ class Compose(SISOTransform):
         self._validate_input(x)
         if self.output_name in x.columns:
             return x[self.output_name]
+        if len(x) and not any(t.produces[0] in x.columns or (i and t.requires[0] in x.columns)
+                              for i, t in enumerate(self.transforms)):
+            # the chain stays in HBM: timestamps and the input column go up once, every intermediate series is a device
+            # buffer handed to the next kernel, only the last one comes back (the reference round-trips pandas objects)
+            ctx = _ffi.default_context()
+            ts = DeviceArray.from_host(ctx, self._get_timestamps(x))
+            cur = DeviceArray.from_host(ctx, np.ascontiguousarray(self.transforms[0]._prepare_input_nb(x), dtype=np.float64))
+            for t in self.transforms:
+                cur = t._dev(ts, cur)
+            return pd.Series(cur.to_host(), index=x.index, name=self.output_name)
         cur = None
         for i, t in enumerate(self.transforms):
             if t.produces[0] in x.columns:

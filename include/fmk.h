@@ -280,6 +280,13 @@ int fmk_volume_profile_rolling(fmk_ctx *ctx, const int64_t *bar_ts, const double
                                int64_t n_bins, double price_tick, double va_pct, int32_t *poc, int32_t *hva,
                                int32_t *lva, float *pct);
 
+/* calc_volume_percentage_above_poc (volume.py:367-391) on ONE profile: share of the volume on levels above `poc_price`
+ * (NumPy-pairwise float32 total, the levels above added in order in float64, float64 quotient = the Numba-typed function). */
+int fmk_calc_volume_percentage_above_poc_dev(fmk_ctx *ctx, const int32_t *d_price_levels, const float *d_volumes, int64_t n,
+                                             int32_t poc_price, double *d_out);
+int fmk_calc_volume_percentage_above_poc(fmk_ctx *ctx, const int32_t *price_levels, const float *volumes, int64_t n,
+                                         int32_t poc_price, double *out);
+
 /* ---- CUSUM bars: finmlkit/bar/logic.py:152-221 ("next" rank 3) ------------------------------ */
 /* _cusum_bar_indexer: sigma is forward-filled IN PLACE from its first non-NaN entry (like the reference); the
  * result starts with that entry's index, then one index per close.  d_out == NULL: count only (*n_out).

@@ -278,11 +278,18 @@ def api_records(tape="dyadic"):
     kits = [("TimeBarKit", (pd.Timedelta(seconds=10),), {}), ("TickBarKit", (), {"tick_count_thrs": 50}),
             ("VolumeBarKit", (), {"volume_ths": 200.0}), ("DollarBarKit", (), {"dollar_thrs": 20000.0}),
             ("CUSUMBarKit", (np.full(n, 1e-3),), {})]
+    if tape == "dyadic":
+        # a threshold no bar ever reaches: the kit's close indices are [0] -- only build_ohlcv (and build_footprints through
+        # it) checks for that (base.py:334-335); the other builders return empty frames
+        kits.append(("VolumeBarKit", (), {"volume_ths": 1e12}))
     first = {}
     for cname, cargs, ckw in kits:
         kit = getattr(KIT, cname)(td, *copy.deepcopy(cargs), **copy.deepcopy(ckw))
-        ohlcv = kit.build_ohlcv()
-        nb = len(ohlcv)
+        try:
+            ohlcv = kit.build_ohlcv()
+            nb = len(ohlcv)
+        except ValueError:
+            ohlcv, nb = None, 0
         theta = np.full(nb, float(np.median(qty)))
         for method, margs, mkw in (("build_ohlcv", (), {}), ("build_directional_features", (), {}),
                                    ("build_trade_size_features", (theta,), {"theta_mult": 3.0}),

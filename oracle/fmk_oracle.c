@@ -587,11 +587,14 @@ static void orc_footprint_features(const int32_t *levels, const float *buy, cons
                                    int *max_run_signed, int32_t *cot, double *skew, double *gini,
                                    float *tmpf, double *tmpd)
 {
-    float m32 = (float)mult;    /* float32 array * Python float stays float32 (NEP 50) */
+    /* array(float32) * float64 scalar: Numba's typed semantics (the production path) promote to float64, the product is
+     * exact to ~1e-16; NumPy >= 2 (NEP 50, the pure-Python mode the fixtures are recorded in) would round it to float32.
+     * The two differ only when the float32-rounded product crosses the other volume (decimal lots: 0.3f > 0.1f * 3.0 is
+     * False in float32 and True in float64); every recorded reference call has exact products, where they agree. */
     for (int64_t k = 0; k < L; ++k) buy_imb[k] = sell_imb[k] = 0;
     if (L > 1) {                                                    /* base.py:795-798 */
-        for (int64_t k = 0; k < L - 1; ++k) sell_imb[k] = sell[k] > buy[k + 1] * m32;
-        for (int64_t k = 1; k < L; ++k) buy_imb[k] = buy[k] > sell[k - 1] * m32;
+        for (int64_t k = 0; k < L - 1; ++k) sell_imb[k] = (double)sell[k] > (double)buy[k + 1] * mult;
+        for (int64_t k = 1; k < L; ++k) buy_imb[k] = (double)buy[k] > (double)sell[k - 1] * mult;
     }
     int max_run = 0, max_sign = 0, run = 0, run_sign = 0;           /* base.py:801-819 */
     for (int64_t k = 0; k < L; ++k) {
@@ -956,6 +959,10 @@ static int64_t orc_upper_i64(const int64_t *a, int64_t n, int64_t key)
     return lo;
 }
 
+/* calc_volume_percentage_above_poc, finmlkit/feature/core/volume.py:367-391, stand-alone (typed semantics: float32
+ * np.sum, float64 accumulator and quotient) */
+double orc_calc_volume_percentage_above_poc(const int32_t *pl, const float *vol, int64_t n, int32_t poc_price);
+
 /* comp_poc_hva_lva + calc_volume_percentage_above_poc on one profile */
 static void orc_poc_hva_lva(const int32_t *pl, const float *vol, int64_t n, double va_pct,
                             int32_t *poc, int32_t *hva, int32_t *lva, float *pct)
@@ -1068,4 +1075,15 @@ int orc_volume_profile_rolling(const int64_t *ts, const double *highs, const dou
         free(ab); free(as); free(tot); free(pl);
     }
     return ORC_OK;
+}
+
+
+double orc_calc_volume_percentage_above_poc(const int32_t *pl, const float *vol, int64_t n, int32_t poc_price)
+{
+    float total = orc_pairwise_f32(vol, n);                       /* volume.py:377 np.sum(volumes) */
+    if (!(total > 0.f)) return 0.0;                               /* :378-379 */
+    double above = 0.0;
+    for (int64_t k = 0; k < n; ++k) if (pl[k] > poc_price) above += vol[k];   /* :381-384 */
+    if (!(above > 0.0)) return 0.0;                               /* :387-388 */
+    return above / (double)total;                                 /* :390 */
 }

@@ -372,3 +372,12 @@ def volume_profile_rolling(ts, highs, lows, level_offsets, price_levels, buy_vol
                                             _i64(int(window_size_sec * 1e9)), _i64(-1 if n_bins is None else n_bins),
                                             _f64(price_tick), _f64(va_pct), _p(poc), _p(hva), _p(lva), _p(pct)))
     return poc, hva, lva, pct
+
+
+def calc_volume_percentage_above_poc(price_levels, volumes, poc_price):
+    """finmlkit/feature/core/volume.py:367-391."""
+    pl = np.ascontiguousarray(price_levels, dtype=np.int32)
+    v = np.ascontiguousarray(volumes, dtype=np.float32)
+    f = lib().orc_calc_volume_percentage_above_poc
+    f.restype = C.c_double
+    return float(f(_p(pl), _p(v), _i64(len(pl)), C.c_int32(int(poc_price))))

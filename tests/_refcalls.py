@@ -93,6 +93,9 @@ POLICY = {
     "ewmst": ("rtol", 1e-9), "ewmst_mean0": ("rtol", 1e-9),
     "realized_vol": ("rtol", 1e-9),
     "volume_profile_rolling": "exact",
+    # float64 accumulator / quotient of the Numba-typed function vs the recorded pure-Python float32 one (same split as
+    # VolumePro.compute's fourth output below): within 2 ulp(float32)
+    "calc_volume_percentage_above_poc": ("rtol", 2.4e-7),
     "_tick_bar_indexer": "exact", "_volume_bar_indexer": "exact", "_dollar_bar_indexer": "exact",
     "_cusum_bar_indexer": "exact",
     "TradesData": "exact",

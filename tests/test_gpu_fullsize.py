@@ -123,6 +123,50 @@ def test_directional_and_footprints_full_size(big, prefix, orc):
         np.testing.assert_array_equal(bar[key].to_host()[:k], wbar[key], err_msg=key)
 
 
+def test_cfg1_reference_vectors_at_full_size(big):
+    """BASELINE cfg 1 + cfg 2 tied together: the first bars of the 10^9-tick HIP run against the vectors the REFERENCE's
+    own `TimeBarKit(60 s).build_ohlcv()` produced from the first 10^7 ticks of the same stream (oracle/gen_cfg1.py,
+    tests/golden/cfg1_reference_timebars.npz) -- directly, no oracle in between.  All bars but the reference run's last
+    (which closes on that run's final, partial minute) consist of the same ticks in both runs.  Indices, counts, OHLC,
+    median and the float32 volume bit-exact; vwap <= 1e-9 relative (tree-ordered float64 sum)."""
+    engine, t, n = big
+    d = G.load("cfg1_reference_timebars")
+    assert n >= int(d["n_ohlcv"])
+    clock, ci = t.time_bar_index(60.0)
+    k = len(d["close_indices"]) - 2                                      # complete bars of the 10^7-tick run: 8330
+    assert k == 8330
+    np.testing.assert_array_equal(ci.view(0, k + 1).to_host(), d["close_indices"][:k + 1])
+    np.testing.assert_array_equal(clock.view(0, k + 1).to_host(), d["close_ts"][:k + 1])
+    o = t.bar_ohlcv(ci)
+    for key in ("open", "high", "low", "close", "volume", "trades", "median_trade_size"):
+        got, want = o[key].view(0, k).to_host(), d["ohlcv_col_" + key][:k]
+        assert got.dtype == want.dtype, key
+        np.testing.assert_array_equal(got, want, err_msg=key)
+    G.assert_f64_close(o["vwap"].view(0, k).to_host(), d["ohlcv_col_vwap"][:k], rtol=1e-9, what="vwap")
+    # order-flow + footprints (the reference's build_directional_features / build_footprints on the first 10^6 ticks)
+    kf = len(d["flow_close_indices"]) - 2
+    cif = ci.view(0, kf + 1)
+    dd, nz = t.bar_directional(cif)
+    for name in (str(c) for c in d["dir_columns"]):
+        mine = {"cum_volume_min": "cum_volumes_min", "cum_volume_max": "cum_volumes_max"}.get(name, name)
+        got, want = dd[mine].to_host(), d["dir_col_" + name][:kf]
+        if name in ("mean_spread", "max_spread"):                       # bar 0: wrap-around tick prices[-1] (DESIGN 5)
+            got, want = got[1:], want[1:]
+        assert got.dtype == want.dtype, name
+        np.testing.assert_array_equal(got, want, err_msg=name)
+    off, flat, bar, bad = t.bar_footprints(cif, o["low"].view(0, kf), o["high"].view(0, kf), 0.01, 3.0)
+    assert int(bad.to_host()[0]) == 0
+    offh = off.to_host()
+    np.testing.assert_array_equal(np.diff(offh), d["fp_n_levels"][:kf])
+    nl = int(offh[-1])
+    for key in G.FP_LIST_KEYS:
+        want = d["fp_" + key][:nl]
+        np.testing.assert_array_equal(flat[key].to_host().astype(want.dtype), want, err_msg=key)
+    for key in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
+        np.testing.assert_array_equal(bar[key].to_host(), d["fp_" + key][:kf], err_msg=key)
+    np.testing.assert_allclose(bar["vp_skew"].to_host(), d["fp_vp_skew"][:kf], atol=1e-6)
+
+
 def test_threshold_bars_full_size(big, prefix, orc):
     engine, t, n = big
     ts, px, am, sd = prefix

@@ -8,11 +8,7 @@ from tests import _refcalls as R
 
 pytestmark = pytest.mark.gpu
 
-SKIP = {
-    "calc_volume_percentage_above_poc": "not exported as a stand-alone function: the share above the POC is evaluated "
-                                        "inside k_volume_profile with the POC it finds itself; the recorded calls pass "
-                                        "an arbitrary POC.  The 4 volume_profile_rolling records cover the kernel.",
-}
+SKIP = {}
 
 
 def _realized_volatility(attrs, frame, kwargs):
@@ -101,6 +97,7 @@ def _table():
         "ewms": volatility.ewms,
         "realized_vol": volatility.realized_vol,
         "volume_profile_rolling": volume.volume_profile_rolling,
+        "calc_volume_percentage_above_poc": volume.calc_volume_percentage_above_poc,
         # the reference's tests call the two backends of the transform directly; both are replayed through the one
         # (HIP) backend here, the pandas recordings at the reference's own pd-vs-compiled tolerance (rtol 1e-10)
         "RealizedVolatility._pd": _realized_volatility,
@@ -114,13 +111,14 @@ def _table():
 
 def test_hip_path_replays_reference_test_calls():
     done, skipped = R.replay(_table(), SKIP)
-    assert done == 156 and skipped == {"calc_volume_percentage_above_poc": 4}, (done, skipped)    # of 160 recorded calls
+    assert done == 160 and skipped == {}, (done, skipped)    # every one of the 160 recorded calls
 
 
 def test_hip_path_replays_edge_sweep():
     """Degenerate inputs of our own through the reference's functions (oracle/edge_sweep.py -> edge_calls.npz), replayed
     through the package: results under the contract of DESIGN.md 5, exceptions by type."""
     done, skipped = R.replay(_table(), SKIP, path=R.EDGE_PATH, match_message=False)
-    # 137 function calls + 38 TradesData(...) + 50 API-level records on two tapes (40 kit builds, 8 transforms, 2 x
-    # VolumePro.compute); the second tape has lognormal float64 amounts: the order of the float64 additions matters there
-    assert done == 225 and skipped == {"not comparable": 15}, (done, skipped)
+    # 137 function calls + 38 TradesData(...) + 54 API-level records on two tapes (44 kit builds -- four of them on a kit
+    # whose threshold no bar reaches: close indices [0] --, 8 transforms, 2 x VolumePro.compute); the second tape has
+    # lognormal float64 amounts: the order of the float64 additions matters there
+    assert done == 229 and skipped == {"not comparable": 15}, (done, skipped)

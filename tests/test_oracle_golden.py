@@ -188,3 +188,43 @@ def test_volume_profile_rolling_golden(orc):
         for g, k in zip(got, ("poc", "hva", "lva", "pct")):
             assert g.dtype == d[f"{name}__{k}"].dtype
             np.testing.assert_array_equal(g, d[f"{name}__{k}"], err_msg=f"{name}:{k}")
+
+
+# ---- BASELINE cfg 1: 10^7 ticks -> 1-minute bars made by the reference's own TimeBarKit (oracle/gen_cfg1.py) ---------
+def test_cfg1_reference_timebars_ohlcv(orc):
+    d = G.load("cfg1_reference_timebars")
+    n = int(d["n_ohlcv"])
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, n)
+    clock, ci = orc._time_bar_indexer(ts, 60.0)
+    np.testing.assert_array_equal(clock, d["close_ts"])
+    np.testing.assert_array_equal(ci, d["close_indices"])
+    assert len(ci) - 1 == 8331
+    np.testing.assert_array_equal(d["ohlcv_index_ns"], clock[1:])                 # rows are labelled with the close edge
+    got = dict(zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"],
+                   orc.comp_bar_ohlcv(px, am, ci)))
+    assert list(d["ohlcv_columns"]) == ["open", "high", "low", "close", "volume", "trades", "median_trade_size", "vwap"]
+    for k, g in got.items():
+        w = d["ohlcv_col_" + k]
+        assert g.dtype == w.dtype, k
+        np.testing.assert_array_equal(g, w, err_msg=k)                            # sequential restatement: exact, vwap too
+
+
+def test_cfg1_reference_timebars_flow(orc):
+    d = G.load("cfg1_reference_timebars")
+    n = int(d["n_flow"])
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, n)
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    np.testing.assert_array_equal(ci, d["flow_close_indices"])
+    names = [str(c) for c in d["dir_columns"]]
+    assert len(names) == 14
+    for name, g in zip(names, orc.comp_bar_directional_features(px, am, ci, sd)):   # the frame keeps the tuple's order
+        np.testing.assert_array_equal(g, d["dir_col_" + name], err_msg=name)
+    off, flat, bar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, d["flow_ohlcv_col_low"], d["flow_ohlcv_col_high"], 3.0)
+    np.testing.assert_array_equal(np.diff(off), d["fp_n_levels"])
+    for k, v in flat.items():
+        np.testing.assert_array_equal(v.astype(d["fp_" + k].dtype), d["fp_" + k], err_msg=k)
+    for k, v in bar.items():
+        if k == "vp_skew":                                                        # rounding noise of a BLAS dot
+            np.testing.assert_allclose(v, d["fp_" + k], atol=1e-6)
+        else:
+            np.testing.assert_array_equal(v, d["fp_" + k], err_msg=k)

@@ -3,8 +3,7 @@ oracle/fmk_oracle.c to the known answers the reference's tests hold, beyond the 
 Fixture: tests/golden/reference_test_calls.npz (oracle/record_reference_tests.py)."""
 from tests import _refcalls as R
 
-# recorded functions the C oracle has no counterpart for (host-side pandas shaping / transform classes / a helper that
-# only exists inside the volume-profile loop); the package replays the first three on the GPU box
+# recorded functions the C oracle has no counterpart for (host-side pandas shaping / transform classes); the package replays the first three on the GPU box
 SKIP = {
     "footprint_to_dataframe": "pandas shaping of the footprint lists, host code of the package (bar/utils.py)",
     "RealizedVolatility._pd": "transform class, package level (feature/transforms.py)",
@@ -15,8 +14,6 @@ SKIP = {
     "DollarBarKit._comp_bar_close": "kit class", "CUSUMBarKit._comp_bar_close": "kit class",
     "api:kit_build": "kit classes' build_* frames: package level", "api:transform": "transform classes: package level",
     "api:volumepro": "VolumePro.compute: package level (its loop IS replayed at function level)",
-    "calc_volume_percentage_above_poc": "not a stand-alone function here: evaluated inside orc_volume_profile_rolling "
-                                        "with the POC it computes itself; the recorded calls pass an arbitrary POC",
 }
 
 
@@ -53,14 +50,15 @@ def _table(orc):
         "realized_vol": orc.realized_vol,
         "volume_profile_rolling": _vpr_from_lists(orc),
         "ewmst": orc.ewmst, "ewmst_mean0": orc.ewmst_mean0,
+        "calc_volume_percentage_above_poc": orc.calc_volume_percentage_above_poc,
     }
 
 
 def test_oracle_replays_reference_test_calls(orc):
     done, skipped = R.replay(_table(orc), SKIP)
-    # 160 recorded calls (from all 116 tests of the 14 reference test files): 130 replayed, 30 documented skips
-    assert done == 130 and skipped == {"footprint_to_dataframe": 1, "RealizedVolatility._pd": 6, "RealizedVolatility._nb": 1,
-                                       "calc_volume_percentage_above_poc": 4, "TradesData": 13,
+    # 160 recorded calls (from all 116 tests of the 14 reference test files): 134 replayed, 26 documented skips
+    assert done == 134 and skipped == {"footprint_to_dataframe": 1, "RealizedVolatility._pd": 6, "RealizedVolatility._nb": 1,
+                                       "TradesData": 13,
                                        "TimeBarKit._comp_bar_close": 1, "TickBarKit._comp_bar_close": 1,
                                        "VolumeBarKit._comp_bar_close": 1, "DollarBarKit._comp_bar_close": 1,
                                        "CUSUMBarKit._comp_bar_close": 1}, (done, skipped)
@@ -72,5 +70,5 @@ def test_oracle_replays_edge_sweep(orc):
     lives, NaNs, length mismatches.  Exceptions are compared by type (NumPy-internal message texts are not a contract);
     14 cases exist only in the reference's pure-Python mode or are garbage, and carry their reason in the fixture."""
     done, skipped = R.replay(_table(orc), SKIP, path=R.EDGE_PATH, match_message=False)
-    assert done == 137 and skipped == {"not comparable": 15, "TradesData": 38, "api:kit_build": 40, "api:transform": 8,
-                                       "api:volumepro": 2}, (done, skipped)    # of 240 records
+    assert done == 137 and skipped == {"not comparable": 15, "TradesData": 38, "api:kit_build": 44, "api:transform": 8,
+                                       "api:volumepro": 2}, (done, skipped)    # of 244 records
