@@ -50,7 +50,7 @@ __device__ __forceinline__ DD dd_shfl_up(DD v, int d) { return DD{__shfl_up(v.hi
 
 // floor(D / thr) for D >= 0 in double-double; *frag receives the distance of D/thr to the nearest
 // integer boundary in units of thr (for the certification count)
-__device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_dist)
+__device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_dist, double *rem = nullptr)
 {
     double q = floor(D.hi / thr);
     double p = q * thr, e = fma(q, thr, -p);          // q*thr = p + e exactly
@@ -58,6 +58,7 @@ __device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_d
     while (r < 0.0) { q -= 1.0; r += thr; }
     while (r >= thr) { q += 1.0; r -= thr; }
     *frac_dist = fmin(r, thr - r) / thr;
+    if (rem) *rem = r;                                // D - q*thr to ~1 ulp: the exact-arithmetic carry after a close
     return (int64_t)q;
 }
 
@@ -66,6 +67,7 @@ __device__ __forceinline__ int64_t dd_floor_div(DD D, double thr, double *frac_d
 #define DL_TILE (DL_THREADS * DL_ITEMS)
 #define DL_SEG_SHIFT 11                 // tiles per segment of the double-double scan: one round of k_dl_scan_dd
 #define DL_SEGM_SHIFT 13                // ... of the prefix-min scan: one round of k_dl_scan_min
+#define DL_EXTRA 16                     // spare output slots behind the closes of the closed form (fmk_dollar_exact.hip)
 
 template <bool AF64>
 __device__ __forceinline__ double dl_d(const double *price, const void *amount, int64_t i)
@@ -99,7 +101,8 @@ __device__ __forceinline__ DD dl_block_exclusive(DD mine, DD *lds /*[4]*/, DD *t
 template <bool AF64>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__restrict__ price,
                                                              const void *__restrict__ amount, int64_t n,
-                                                             DD *__restrict__ tile_sum, int *__restrict__ bad)
+                                                             DD *__restrict__ tile_sum, int *__restrict__ bad,
+                                                             unsigned long long *__restrict__ dmax_bits)
 {
     __shared__ DD lds[4];
     // the tile's sum does not depend on the order of its terms (double-double: ~2^-104 relative), so the loads are COALESCED
@@ -117,6 +120,16 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
         s = dd_add(s, d[k]);
     }
     if (__ballot(neg) != 0 && fmk_lane() == 0) atomicOr(bad, 1);
+    {   // largest increment of the stream (the exact tier of fmk_dollar_exact.hip needs d_max < thr): non-negative doubles
+        // order like their bit patterns; look first, a same-address atomic per wave is not free
+        double m = d[0];
+#pragma unroll
+        for (int k = 1; k < DL_ITEMS; ++k) m = fmax(m, d[k]);
+        m = fmk_wave_max(m);
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+        if (fmk_lane() == 0 && !neg && mb > __hip_atomic_load(dmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(dmax_bits, mb);
+    }
     DD tot;
     (void)dl_block_exclusive(s, lds, &tot);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
@@ -162,7 +175,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t_al
 // G_i for the 8 ticks of this thread (G_0 = 0); returns the number of fragile ticks
 template <bool AF64>
 __device__ __forceinline__ int dl_thread_G(const double *price, const void *amount, int64_t n, double thr,
-                                           const DD *tile_base, const DD *seg_base, DD *lds, int64_t (&G)[DL_ITEMS])
+                                           const DD *tile_base, const DD *seg_base, DD *lds, int64_t (&G)[DL_ITEMS],
+                                           double *rem = nullptr)
 {
     // the thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order), but loading them that way makes every load
     // instruction touch 64 lines: 2.8 TB/s.  So the tile is loaded coalesced (thread t: ticks t, t + 256, ...), the rounded
@@ -194,8 +208,9 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
         D = dd_add(D, d[k]);
         G[k] = INT64_MAX;                 // neutral for min beyond the end
         if (i < n) {
-            double fd;
-            const int64_t M = dd_floor_div(D, thr, &fd);
+            double fd, r;
+            const int64_t M = dd_floor_div(D, thr, &fd, &r);
+            if (rem) rem[k] = r;
             G[k] = i == 0 ? 0 : M - i;
             const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16);
             frag += (i > 0 && fd <= tol);
@@ -287,12 +302,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
                                                         const int64_t *__restrict__ tile_premin,
                                                         const int64_t *__restrict__ seg_premin,
                                                         int64_t *__restrict__ out, int64_t cap,
-                                                        unsigned long long *n_frag)
+                                                        unsigned long long *n_frag, int64_t *__restrict__ carry_k,
+                                                        double inv_ulp)
 {
     __shared__ DD lds[4];
     __shared__ int64_t wmin[4];
     int64_t G[DL_ITEMS];
-    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G);
+    double rem[DL_ITEMS];
+    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G, rem);
     // exclusive prefix-min over the block in tick order: thread-local then across threads
     int64_t tmin = G[0];
 #pragma unroll
@@ -320,7 +337,12 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
         if (i < n) {
             if (i >= 1 && G[k] >= mex) {             // close: K_i = i + mex is its slot
                 const int64_t slot = i + mex;
-                if (slot < cap) out[slot] = i;
+                if (slot < cap) {
+                    out[slot] = i;
+                    // exact-arithmetic carry after this close in units of ulp(thr) (D_i - M_i*thr: with d_max < thr there is
+                    // no backlog, M_i == K_i) -- the start state of the next bar's simulation in fmk_dollar_exact.hip
+                    carry_k[slot] = llrint(rem[k] * inv_ulp);
+                }
             }
             mex = G[k] < mex ? G[k] : mex;
         }
@@ -339,7 +361,9 @@ struct DlCache {
     int is_f64;
     int64_t count, unc;
     int64_t *dbuf;
+    int64_t *carry;      // carry_k per close, same capacity
     int64_t cap;
+    double dmax;
 };
 static DlCache &dl_cache(fmk_ctx *ctx)       // one per context (slot 1), created on first use
 {
@@ -352,6 +376,7 @@ void fmk_dollar_trim(fmk_ctx *ctx)
     DlCache *c = (DlCache *)ctx->idx_cache[1];
     if (!c) return;
     if (c->dbuf) (void)hipFree(c->dbuf);
+    if (c->carry) (void)hipFree(c->carry);
     delete c;
     ctx->idx_cache[1] = nullptr;
 }
@@ -369,8 +394,9 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     int64_t *segm = tmin + tiles;
     int64_t *d_res = ctx->d_mail + 24;
     int *d_bad = (int *)(ctx->d_mail + 26);
-    FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad);
+    unsigned long long *d_dmax = (unsigned long long *)(ctx->d_mail + 27);
+    FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 16, ctx->stream));
+    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax);
     FMK_LAUNCH_CHECK(ctx);
     k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
     k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(segb, gdd, gdd, nullptr);
@@ -381,16 +407,28 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(segm, gmn, gmn, nullptr, d_res);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((int)ctx->h_mail[1] != 0) return 1;          // negative / NaN increments: caller falls back to the serial walk
+    memcpy(&c.dmax, &ctx->h_mail[2], 8);
     const int64_t gmin = ctx->h_mail[0] < 0 ? ctx->h_mail[0] : 0;     // G_0 = 0 is part of every prefix
     c.count = (n - 1) + gmin + 1;                                       // K_{n-1} closes + the leading 0
-    if (c.dbuf && c.cap < c.count) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
-    if (!c.dbuf) { FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.count * 8)); c.cap = c.count; }
+    if (c.dbuf && c.cap < c.count + DL_EXTRA) {
+        FMK_HIP(ctx, hipFree(c.dbuf));
+        FMK_HIP(ctx, hipFree(c.carry));
+        c.dbuf = c.carry = nullptr;
+    }
+    if (!c.dbuf) {       // DL_EXTRA spare slots: the exact tier may find a few more closes at the end of the stream
+        c.cap = c.count + DL_EXTRA;
+        FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.cap * 8));
+        FMK_HIP(ctx, hipMalloc((void **)&c.carry, (size_t)c.cap * 8));
+    }
     unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 25);
     FMK_HIP(ctx, hipMemsetAsync(d_frag, 0, 8, ctx->stream));
-    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf, c.cap, d_frag);
+    int ex;
+    (void)frexp(thr, &ex);                                            // thr = m * 2^ex, m in [0.5, 1): ulp(thr) = 2^(ex - 53)
+    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf, c.count,
+                                                                     d_frag, c.carry, ldexp(1.0, 53 - ex));
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -400,6 +438,11 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
 
 int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
                          double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
+// fmk_dollar_exact.hip: the reference's float64 state at every bar start, reconstructed in parallel; rewrites the closes the
+// closed form got wrong in `close_idx` (capacity: count + DL_EXTRA).  *status: 0 = done (now exact), 1 = not applicable /
+// gave up (caller takes the serial walk).
+int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
+                     int64_t *d_close_idx, const int64_t *d_carry_k, int64_t *count, int *status);
 
 extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
                                           int amount_is_f64, int64_t n, double threshold, int64_t *d_close_idx,
@@ -423,12 +466,26 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
     }
-    if (c.unc > 0 && !ctx->fast_threshold) {
-        // a sum within the reference's rounding drift of the threshold: only its own sequence of float64 operations
-        // decides like it does (fmk_threshold.hip: k_threshold_exact)
-        c.ctx = nullptr;
-        return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
-                                    n_uncertified);
+    static int force_sim = -1;          // developer knob: FMK_DL_FORCE_EXACT_TIER=1 runs the exact tier on every input
+    if (force_sim < 0) { const char *v = getenv("FMK_DL_FORCE_EXACT_TIER"); force_sim = v ? atoi(v) : 0; }
+    if ((c.unc > 0 || force_sim) && !ctx->fast_threshold) {
+        // a sum within the reference's rounding drift of the threshold: only its own sequence of float64 operations decides
+        // like it does.  The exact tier reconstructs the reference's float64 state at every bar start (its rounding errors
+        // are a function of the bar's own ticks and of the carried state modulo 4 ulp(thr)) and replays the few fragile bars
+        // from it; streams it does not cover (an increment >= thr) take the serial walk (fmk_threshold.hip)
+        int status = 1;
+        if (c.dmax < threshold && !hit) {
+            int rc = fmk_dollar_exact(ctx, d_price, d_amount, amount_is_f64, n, threshold, c.dbuf, c.carry, &c.count, &status);
+            if (rc) { c.ctx = nullptr; return rc; }
+            if (status == 0) c.unc = 0;
+        } else if (hit) {
+            status = c.unc == 0 ? 0 : 1;
+        }
+        if (status != 0) {
+            c.ctx = nullptr;
+            return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
+                                        n_uncertified);
+        }
     }
     *n_idx = c.count;
     if (n_uncertified) *n_uncertified = c.unc;
