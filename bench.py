@@ -114,20 +114,29 @@ def other_configs(trades, ctx, args):
         out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr))
         out["cfg3_volume_uncertified"] = int(trades.last_uncertified)
         out["cfg3_n_volume_bars"] = int(trades.volume_bar_index(vthr).n)
-        # dollar bars: the parallel indexer as such.  Decisions within the rounding drift of the reference's float64 running
-        # sum (which never resets for dollar bars) are counted, not redone by the exact sequential loop (the default there;
-        # tens of ns per tick, not for 1e9 ticks)
+        # dollar bars, default (exact) mode as well: closed form + exact tier (csrc/fmk_dollar_exact.hip: the reference's
+        # float64 running sum reconstructed at every bar start, fragile bars replayed) -- n_uncertified comes back 0.  The
+        # closed form alone (fmk_ctx_set_fast_threshold(1)) is timed next to it with the count of decisions it cannot certify
+        out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
+        out["cfg3_dollar_uncertified"] = int(trades.last_uncertified)
+        out["cfg3_dollar_exact"] = out["cfg3_dollar_uncertified"] == 0
+        exact_idx = trades.dollar_bar_index(dthr)
+        out["cfg3_n_dollar_bars"] = int(exact_idx.n - 1)
         ctx.set_fast_threshold(True)
         try:
-            out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
-            out["cfg3_dollar_uncertified"] = int(trades.last_uncertified)
+            out["cfg3_dollar_closed_form_only_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
+            out["cfg3_dollar_closed_form_uncertified"] = int(trades.last_uncertified)
+            fast_idx = trades.dollar_bar_index(dthr)
+            out["cfg3_dollar_closes_differing_exact_vs_closed_form"] = (
+                int((fast_idx.to_host() != exact_idx.to_host()).sum()) if fast_idx.n == exact_idx.n else -1)
+            del fast_idx
         finally:
             ctx.set_fast_threshold(False)
+        del exact_idx
         out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
         out["cfg4_bytes_per_tick"] = 38
-        out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume in the default exact "
-                       "mode; dollar with fmk_ctx_set_fast_threshold(1) -- each uncertified decision may differ from the "
-                       "reference by one tick")
+        out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
+                       "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only
         out["error"] = f"{type(e).__name__}: {e}"
     return out

@@ -466,8 +466,9 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
     }
-    static int force_sim = -1;          // developer knob: FMK_DL_FORCE_EXACT_TIER=1 runs the exact tier on every input
-    if (force_sim < 0) { const char *v = getenv("FMK_DL_FORCE_EXACT_TIER"); force_sim = v ? atoi(v) : 0; }
+    // test knob (read per call): FMK_DL_FORCE_EXACT_TIER=1 runs the exact tier even when the closed form is already certain
+    const char *fv = getenv("FMK_DL_FORCE_EXACT_TIER");
+    const int force_sim = fv ? atoi(fv) : 0;
     if ((c.unc > 0 || force_sim) && !ctx->fast_threshold) {
         // a sum within the reference's rounding drift of the threshold: only its own sequence of float64 operations decides
         // like it does.  The exact tier reconstructs the reference's float64 state at every bar start (its rounding errors

@@ -22,13 +22,12 @@
 //  tabulated function (a real flip: the close moves by a tick) the bar becomes a constant in the scan and the scan is
 //  repeated -- a fixed point after (number of dependent flips + 1) rounds.  No decision is left uncertified.
 //
-//   k_dlx_bars      one thread per bar: four trajectories from (k~ - 1 + j)*u, flags, f = (base, kappa[4])
+//   k_dlx_bars      one lane per bar, loads by the wave: four trajectories from (k~ - 1 + j)*u, flags, f = (base, kappa[4])
 //   k_dlx_scan      compose the bars' functions (block = 1024 bars); phase 1 applies them: k_in per bar
 //   k_dlx_blocks    one wave walks the block aggregates
 //   k_dlx_resolve   one thread per flagged bar: the reference loop from k_in*u until it is back on a closed-form close
 //   k_dlx_commit    rewrite the closes of the bars whose replay differed
-// Cost at 1e9 ticks / 1.16e6 bars: one more read of price + amount by k_dlx_bars (a lane streams its own bar), the rest is
-// per-bar data.  Streams with an increment >= thr (a backlog of closes) are not covered: the caller takes the serial walk.
+// Cost at 1e9 ticks / 1.16e6 bars: one more read of price + amount by k_dlx_bars, the rest is per-bar data.  Streams with an increment >= thr (a backlog of closes) are not covered: the caller takes the serial walk.
 #include <math.h>
 #include <stdlib.h>
 
@@ -84,64 +83,124 @@ __device__ __forceinline__ double dlx_d(const double *price, const void *amount,
 
 __device__ __forceinline__ int64_t dlx_binade(double x) { return __double_as_longlong(x) >> 52; }   // sign + exponent
 
+#define DLX_T 32                         // ticks a lane takes per round
+#define DLX_R_MAX 8                      // bars per lane (strided by 64: evens out the bar lengths within a wave) -- as many
+                                         // as leave the chip >= 8192 workgroups: a wave is one long dependent loop
+
+// One LANE per bar -- the adds of a bar are a dependent chain -- but the loads are the wave's: a lane that streamed its own
+// bar would touch its own cache line with every load instruction (64 lines for 512 useful bytes; the first version of this
+// kernel took 31.6 ms at 1e9 ticks, 0.4 TB/s).  Per round every lane publishes the next DLX_T ticks it needs; the wave fetches
+// the 64 segments with coalesced loads (half a wave per 256-byte segment), forms the rounded products and parks them in LDS,
+// one padded row per lane; then every lane walks its own row.
 template <bool AF64>
-__global__ __launch_bounds__(256) void k_dlx_bars(const double *__restrict__ price, const void *__restrict__ amount, int64_t n,
+__global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ price, const void *__restrict__ amount, int64_t n,
                                                   double thr, double u, double inv_u, double m_rel, double m_abs,
                                                   const int64_t *__restrict__ ci, int64_t nb,
                                                   const int64_t *__restrict__ carry_k, DlxFn *__restrict__ fn,
                                                   int32_t *__restrict__ fidx, int32_t *__restrict__ owner,
-                                                  int64_t *__restrict__ flist, unsigned long long *__restrict__ n_flag)
+                                                  int64_t *__restrict__ flist, unsigned long long *__restrict__ n_flag,
+                                                  int bars_per_lane)
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nb) return;
-    const bool tail = b == nb;                       // ticks behind the last close: no function, but they must not close
-    const int64_t start = ci[b] + 1;
-    const int64_t end = tail ? n - 1 : ci[b + 1];
-    // how far the reference's state can be from a simulated trajectory at the end of this bar: its drift against exact
-    // arithmetic (3), the rounding of the exact carry to k~, the spread of the four trajectories and their parity wiggle
-    const double m = (double)(end + 2) * m_rel + m_abs;
-    int64_t kb = 0;
-    double c0, c1, c2, c3;
-    if (b == 0) {
-        c0 = c1 = c2 = c3 = dlx_d<AF64>(price, amount, 0);           // cum = prices[0] * volumes[0] (logic.py:140): known exactly
-    } else {
-        kb = carry_k[b] - 1;
-        if (kb < 0) kb = 0;
-        c0 = (double)kb * u; c1 = (double)(kb + 1) * u; c2 = (double)(kb + 2) * u; c3 = (double)(kb + 3) * u;
+    __shared__ double rows[2][64][DLX_T + 1];               // 2 waves x 16.9 KB
+    __shared__ int64_t s_pos[2][64], s_end[2][64];
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 2 + w;
+    const int64_t bar0 = wave * (64 * (int64_t)bars_per_lane) + lane;
+    int r = 0;
+    int64_t b = bar0, pos = 0, end = -1, kb = 0;
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, m = 0;
+    bool tail = false, flag = false, active = false;
+    auto open_bar = [&]() {                          // next bar of this lane, or none
+        for (;;) {
+            active = r < bars_per_lane && b <= nb;
+            if (!active) return;
+            tail = b == nb;
+            pos = ci[b] + 1;
+            end = tail ? n - 1 : ci[b + 1];
+            // how far the reference's state can be from a simulated trajectory at the end of this bar: its drift against
+            // exact arithmetic (3), the rounding of the exact carry to k~, the spread of the trajectories, their parity wiggle
+            m = (double)(end + 2) * m_rel + m_abs;
+            flag = false;
+            kb = 0;
+            if (b == 0) {
+                c0 = c1 = c2 = c3 = dlx_d<AF64>(price, amount, 0);   // cum = prices[0] * volumes[0] (logic.py:140): exact
+            } else {
+                kb = carry_k[b] - 1;
+                if (kb < 0) kb = 0;
+                c0 = (double)kb * u; c1 = (double)(kb + 1) * u; c2 = (double)(kb + 2) * u; c3 = (double)(kb + 3) * u;
+            }
+            if (pos <= end) return;
+            // an empty tail: nothing can close behind the last close
+            DlxFn f;
+            f.base = kb; f.kap[0] = kb; f.kap[1] = kb + 1; f.kap[2] = kb + 2; f.kap[3] = kb + 3;
+            fn[b] = f; owner[b] = (int32_t)b; fidx[b] = -1;
+            ++r; b += 64;
+        }
+    };
+    open_bar();
+    while (__ballot(active) != 0) {
+        s_pos[w][lane] = active ? pos : -1;
+        s_end[w][lane] = active ? end : -2;
+        __builtin_amdgcn_wave_barrier();
+        const int half = lane >> 5, j32 = lane & 31;
+#pragma unroll
+        for (int sgm = 0; sgm < 64; sgm += 2) {             // all 32 loads of the round in flight together
+            const int seg = sgm + half;
+            const int64_t p0 = s_pos[w][seg], e0 = s_end[w][seg];
+            const int64_t tick = p0 + j32;
+            double v = 0.0;
+            if (p0 >= 0 && tick <= e0) v = dlx_d<AF64>(price, amount, tick);
+            rows[w][seg][j32] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int cnt = 0;
+        if (active) cnt = (int)(end - pos + 1 < DLX_T ? end - pos + 1 : DLX_T);
+        const bool closes_here = active && !tail && pos + cnt - 1 == end;     // the closing add is the last tick of this round
+#pragma unroll 4
+        for (int j = 0; j < DLX_T; ++j) {
+            if (j < cnt) {
+                const double d = rows[w][lane][j];
+                c0 += d; c1 += d; c2 += d; c3 += d;
+                const double lo = c0 - m, hi = c3 + m;
+                bool bad = dlx_binade(lo) != dlx_binade(hi);     // the add must land in one binade for every possible state
+                if (closes_here && j == cnt - 1) bad |= !(lo >= thr);   // the closing add reaches the threshold for every state
+                else bad |= hi >= thr;                           // every other add stays below it
+                flag |= bad;
+            }
+        }
+        pos += cnt;
+        const bool finished = active && pos > end;
+        bool report = false;
+        if (finished) {
+            DlxFn f;
+            f.base = kb;
+            if (!tail) {
+                f.kap[0] = llrint((c0 - thr) * inv_u);           // cum - thr is exact and a multiple of u (1)
+                f.kap[1] = llrint((c1 - thr) * inv_u);
+                f.kap[2] = llrint((c2 - thr) * inv_u);
+                f.kap[3] = llrint((c3 - thr) * inv_u);
+                if (b == 0) f.base = DLX_CONST;                  // the first bar starts from a known state: a constant
+            } else {
+                f.kap[0] = kb; f.kap[1] = kb + 1; f.kap[2] = kb + 2; f.kap[3] = kb + 3;   // identity
+            }
+            fn[b] = f;
+            owner[b] = (int32_t)b;
+            report = flag;
+            if (!flag) fidx[b] = -1;
+        }
+        const uint64_t rep = __ballot(report);
+        if (rep) {                                               // one atomic per wave and round, not one per flagged bar
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(n_flag, (unsigned long long)__popcll(rep));
+            base = __shfl(base, 0, 64);
+            if (report) {
+                const int64_t fi = (int64_t)base + __popcll(rep & ((1ULL << lane) - 1));
+                flist[fi] = b;
+                fidx[b] = (int32_t)fi;
+            }
+        }
+        if (finished) { ++r; b += 64; open_bar(); }
     }
-    bool flag = false;
-    const int64_t last = tail ? end + 1 : end;       // interior ticks: [start, last)
-    for (int64_t i = start; i < last; ++i) {
-        const double d = dlx_d<AF64>(price, amount, i);
-        c0 += d; c1 += d; c2 += d; c3 += d;
-        const double lo = c0 - m, hi = c3 + m;
-        flag |= dlx_binade(lo) != dlx_binade(hi);    // the add must land in one binade for every possible state
-        flag |= hi >= thr;                           // ... and stay below the threshold
-    }
-    DlxFn f;
-    f.base = kb;
-    if (!tail) {
-        const double d = dlx_d<AF64>(price, amount, end);
-        c0 += d; c1 += d; c2 += d; c3 += d;
-        const double lo = c0 - m, hi = c3 + m;
-        flag |= dlx_binade(lo) != dlx_binade(hi);
-        flag |= !(lo >= thr);                        // the closing add must reach the threshold for every possible state
-        f.kap[0] = llrint((c0 - thr) * inv_u);       // cum - thr is exact and a multiple of u (1)
-        f.kap[1] = llrint((c1 - thr) * inv_u);
-        f.kap[2] = llrint((c2 - thr) * inv_u);
-        f.kap[3] = llrint((c3 - thr) * inv_u);
-        if (b == 0) f.base = DLX_CONST;              // the first bar starts from a known state: a constant
-    } else {
-        f.kap[0] = kb; f.kap[1] = kb + 1; f.kap[2] = kb + 2; f.kap[3] = kb + 3;     // identity
-    }
-    fn[b] = f;
-    owner[b] = (int32_t)b;
-    int32_t fi = -1;
-    if (flag) {
-        fi = (int32_t)atomicAdd(n_flag, 1ULL);
-        flist[fi] = b;
-    }
-    fidx[b] = fi;
 }
 
 // the function bar x contributes to the scan in this round
@@ -327,8 +386,11 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     (void)frexp(thr, &ex);
     if (!(thr > 0.0) || !isfinite(thr) || ex < -900 || ex > 900 || nb < 0 || nb + 1 >= (int64_t)INT32_MAX) return FMK_OK;
     const double u = ldexp(1.0, ex - 53), inv_u = ldexp(1.0, 53 - ex);
-    static double mscale = -1.0;                     // developer knob: FMK_DL_MARGIN_SCALE widens the margin -> more bars replayed
-    if (mscale < 0) { const char *v = getenv("FMK_DL_MARGIN_SCALE"); mscale = v ? atof(v) : 1.0; if (!(mscale >= 1.0)) mscale = 1.0; }
+    // test knob (read per call): FMK_DL_MARGIN_SCALE >= 1 widens the margin -> more bars are replayed (never fewer: exactness
+    // does not depend on it)
+    const char *mv = getenv("FMK_DL_MARGIN_SCALE");
+    double mscale = mv ? atof(mv) : 1.0;
+    if (!(mscale >= 1.0)) mscale = 1.0;
     const double m_rel = ldexp(thr, -52) * mscale, m_abs = 16.0 * u * mscale;
     const int64_t nbar = nb + 1;                     // + the tail
     const int64_t nblk = fmk_ceil_div(nbar, DLX_BLOCK_BARS);
@@ -338,7 +400,9 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     unsigned long long *cnt;
     int64_t n_flag = 0;
     int rounds = 0;
-    const unsigned gb = (unsigned)fmk_ceil_div(nbar, 256);
+    int bpl = (int)(nbar / ((int64_t)128 * 8192));
+    bpl = bpl < 1 ? 1 : (bpl > DLX_R_MAX ? DLX_R_MAX : bpl);
+    const unsigned gb = (unsigned)fmk_ceil_div(nbar, (int64_t)128 * bpl);
     DLX_TRY(fmk_alloc(ctx, (size_t)nbar * sizeof(DlxFn), &p_fn));
     DLX_TRY(fmk_alloc(ctx, (size_t)nbar * 4, &p_fidx));
     DLX_TRY(fmk_alloc(ctx, (size_t)nbar * 4, &p_owner));
@@ -350,11 +414,11 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     cnt = (unsigned long long *)p_cnt;               // [0] flagged bars, [1] changed, [2] gave up, [3] new count
     DLX_HIP(hipMemsetAsync(cnt, 0, 64, ctx->stream));
     if (is_f64)
-        k_dlx_bars<true><<<gb, 256, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
-                                                      (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt);
+        k_dlx_bars<true><<<gb, 128, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
+                                                      (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl);
     else
-        k_dlx_bars<false><<<gb, 256, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
-                                                       (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt);
+        k_dlx_bars<false><<<gb, 128, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
+                                                       (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl);
     DLX_HIP(hipGetLastError());
     DLX_HIP(hipMemcpyAsync(ctx->h_mail, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     DLX_HIP(hipStreamSynchronize(ctx->stream));
@@ -398,9 +462,8 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     }
 done:
     {
-        static int verbose = -1;
-        if (verbose < 0) { const char *v = getenv("FMK_DL_VERBOSE"); verbose = v ? atoi(v) : 0; }
-        if (verbose)
+        const char *vv = getenv("FMK_DL_VERBOSE");
+        if (vv && atoi(vv))
             fprintf(stderr, "[fmk_dollar_exact] n=%lld bars=%lld flagged=%lld rounds=%d status=%d rc=%d\n", (long long)n,
                     (long long)nb, (long long)n_flag, rounds + 1, *status, rc);
     }

@@ -240,3 +240,50 @@ def test_volume_decimal_lots_many_ties_stay_on_the_parallel_path(orc):
     assert t.last_uncertified == 0
     assert dt < 0.02, f"{dt * 1e3:.1f} ms: the serial walk would take ~50 ms for {n} ticks"
     print(f"{listed} tied or near-tied decisions of {len(want) - 1} closes replayed; {dt * 1e3:.2f} ms")
+
+
+@pytest.mark.parametrize("margin_scale", ["1", "1e5", "1e9"])
+def test_dollar_exact_tier_forced(orc, monkeypatch, margin_scale):
+    """csrc/fmk_dollar_exact.hip on inputs small enough for the oracle: forced (FMK_DL_FORCE_EXACT_TIER) so that it also runs
+    where the closed form is already certain, with its margin widened so that from a few to ALL bars are replayed from the
+    reconstructed float64 state.  Lognormal amounts (rounding in every add), decimal lots with a round threshold (exact ties
+    in exact arithmetic that the reference's running sum misses: real flips, more than one round), dyadic amounts, bars of 3
+    to 20 000 ticks, a threshold just below a power of two (the closing add lands in the next binade: state mod 4)."""
+    from finmlkit_amd import _ffi, engine
+    monkeypatch.setenv("FMK_DL_FORCE_EXACT_TIER", "1")
+    monkeypatch.setenv("FMK_DL_MARGIN_SCALE", margin_scale)
+    rng = np.random.default_rng(11)
+    n = 400_000
+    px = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=n)), 0.01)
+    streams = {
+        "lognormal64": rng.lognormal(-1.0, 1.0, n),
+        "lognormal32": rng.lognormal(-1.0, 1.0, n).astype(np.float32),
+        "tenths": rng.integers(1, 10, n) / 10.0,
+        "dyadic": (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32),
+    }
+    for name, am in streams.items():
+        mean = float(np.mean(am.astype(np.float64) * px))
+        for thr in (mean * 3.0, mean * 57.3, mean * 20_000.0, 4096.0 - 1e-9, 1000.0):
+            if float(np.max(am.astype(np.float64) * px)) >= thr:
+                continue                                   # an increment >= thr: not this tier (serial walk)
+            t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, am)
+            got = t.dollar_bar_index(thr).to_host()
+            assert t.last_uncertified == 0
+            np.testing.assert_array_equal(got, orc._dollar_bar_indexer(px, am, thr), err_msg=f"{name} thr={thr!r}")
+
+
+def test_dollar_exact_tier_end_of_stream(orc, monkeypatch):
+    """The last decision on a knife edge: the replay may find one close more or one fewer than the closed form."""
+    from finmlkit_amd import engine
+    monkeypatch.setenv("FMK_DL_FORCE_EXACT_TIER", "1")
+    rng = np.random.default_rng(3)
+    for n in (3 * 2731, 3 * 4099, 30_000):
+        px = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=n)), 0.01)
+        for am in (rng.lognormal(-1, 1.2, size=n), rng.integers(1, 10, n) / 10.0):
+            d = am * px
+            for thr in (float(np.mean(d)) * 3.0, float(np.sum(d)) / 100.0, float(np.cumsum(d)[n - 1]) / 7.0):
+                if float(np.max(d)) >= thr:
+                    continue
+                t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, am)
+                np.testing.assert_array_equal(t.dollar_bar_index(thr).to_host(), orc._dollar_bar_indexer(px, am, thr))
+                assert t.last_uncertified == 0
