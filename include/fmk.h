@@ -312,6 +312,24 @@ int fmk_merge_split_trades(fmk_ctx *ctx, const int64_t *ts, const double *price,
 int fmk_comp_trade_side_vector_dev(fmk_ctx *ctx, const double *d_price, int64_t n, int8_t *d_out);
 int fmk_comp_trade_side_vector(fmk_ctx *ctx, const double *price, int64_t n, int8_t *out);
 
+/* ---- TimeBarReader._resample: finmlkit/bar/io.py:890-950 ("next" rank 4, second half) --------------------------
+ * Bars -> coarser bars.  Group g covers the rows [seg[g], seg[g+1]) of the input frame (contiguous; the host computes the
+ * groups with pandas' own index.floor(timeframe)).  Per group: open = first / close = last non-NaN, high = max, low = min,
+ * volume = pandas' Kahan-compensated sum in the column's dtype (float32 stays float32), trades = integer sum,
+ * vwap = float32(sum(vwap * volume) / sum(volume)) with NumPy's dtype promotion of the product, median_trade_size =
+ * float32 of the trades-weighted median of the rows' medians (searchsorted(cumsum(w), total / 2, 'left')).
+ * o_valid[g] = 0 where every open of the group is NaN (the reference drops those rows, io.py:948). */
+int fmk_resample_bars_dev(fmk_ctx *ctx, const int64_t *d_seg, int64_t n_groups, const double *d_open, const double *d_high,
+                          const double *d_low, const double *d_close, const void *d_volume, int volume_is_f64,
+                          const int64_t *d_trades, const void *d_vwap, int vwap_is_f64, const double *d_median,
+                          double *d_o_open, double *d_o_high, double *d_o_low, double *d_o_close, void *d_o_volume,
+                          int64_t *d_o_trades, float *d_o_vwap, float *d_o_median, uint8_t *d_o_valid);
+int fmk_resample_bars(fmk_ctx *ctx, const int64_t *seg, int64_t n_groups, int64_t n_rows, const double *open,
+                      const double *high, const double *low, const double *close, const void *volume, int volume_is_f64,
+                      const int64_t *trades, const void *vwap, int vwap_is_f64, const double *median, double *o_open,
+                      double *o_high, double *o_low, double *o_close, void *o_volume, int64_t *o_trades, float *o_vwap,
+                      float *o_median, uint8_t *o_valid);
+
 /* ---- multi-GPU: one neighbour halo exchange per step (BASELINE cfg 5) ------------------------
  * The reference has no distributed code (last row); these entry points are new.  Rank r of `world` holds
  * a contiguous tick range of one stream; the trailing partial bar of rank r travels as raw ticks to rank r+1.

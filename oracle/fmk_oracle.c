@@ -1087,3 +1087,96 @@ double orc_calc_volume_percentage_above_poc(const int32_t *pl, const float *vol,
     if (!(above > 0.0)) return 0.0;                               /* :387-388 */
     return above / (double)total;                                 /* :390 */
 }
+
+
+/* ------------------------------------------------------------------ */
+/* TimeBarReader._resample, finmlkit/bar/io.py:890-950                  */
+/* Rows [seg[g], seg[g+1]) form group g (the caller groups by            */
+/* index.floor(timeframe), :913).  pandas' groupby sum is a Kahan-       */
+/* compensated sequential sum in the column dtype (pandas/_libs/         */
+/* groupby.pyx group_sum; verified in oracle/gen_resample.py).           */
+/* ------------------------------------------------------------------ */
+#define ORC_KAHAN(T, sum, comp, val)                     \
+    do {                                                 \
+        T v__ = (val);                                   \
+        if (v__ == v__) {                                \
+            T y__ = v__ - (comp);                        \
+            T t__ = (sum) + y__;                         \
+            (comp) = (t__ - (sum)) - y__;                \
+            if ((comp) != (comp)) (comp) = 0;            \
+            (sum) = t__;                                 \
+        }                                                \
+    } while (0)
+
+typedef struct { double size; double w; int64_t row; } orc_rs_pair;
+static int orc_rs_cmp(const void *a, const void *b)
+{
+    const orc_rs_pair *x = (const orc_rs_pair *)a, *y = (const orc_rs_pair *)b;
+    int xn = x->size != x->size, yn = y->size != y->size;
+    if (xn || yn) return xn - yn;                        /* NaN last (np.argsort) */
+    if (x->size < y->size) return -1;
+    if (x->size > y->size) return 1;
+    return (x->row > y->row) - (x->row < y->row);        /* any order among ties gives the same VALUE (io.py:937-946) */
+}
+
+int orc_resample_bars(const int64_t *seg, int64_t n_groups, const double *open, const double *high, const double *low,
+                      const double *close, const void *volume, int volume_is_f64, const int64_t *trades, const void *vwap,
+                      int vwap_is_f64, const double *median, double *o_open, double *o_high, double *o_low, double *o_close,
+                      void *o_volume, int64_t *o_trades, float *o_vwap, float *o_median, uint8_t *o_valid)
+{
+    for (int64_t g = 0; g < n_groups; ++g) {
+        int64_t s = seg[g], e = seg[g + 1];
+        double f_open = NAN, l_close = NAN, hi = NAN, lo = NAN;
+        int have = 0;
+        int64_t tr = 0;
+        float vs32 = 0, vc32 = 0, ps32 = 0, pc32 = 0;
+        double vs64 = 0, vc64 = 0, ps64 = 0, pc64 = 0;
+        for (int64_t i = s; i < e; ++i) {
+            if (!have && open[i] == open[i]) { f_open = open[i]; have = 1; }          /* "first" skips NaN (:918) */
+            if (close[i] == close[i]) l_close = close[i];                             /* "last" (:921) */
+            if (high[i] == high[i] && !(hi >= high[i])) hi = high[i];                 /* "max" / "min" skip NaN */
+            if (low[i] == low[i] && !(lo <= low[i])) lo = low[i];
+            tr += trades[i];                                                          /* :923 */
+            if (volume_is_f64) {
+                double v = ((const double *)volume)[i];
+                double w = vwap_is_f64 ? ((const double *)vwap)[i] : (double)((const float *)vwap)[i];
+                ORC_KAHAN(double, vs64, vc64, v);
+                ORC_KAHAN(double, ps64, pc64, w * v);                                 /* :929 */
+            } else if (vwap_is_f64) {
+                float v = ((const float *)volume)[i];
+                ORC_KAHAN(float, vs32, vc32, v);
+                ORC_KAHAN(double, ps64, pc64, ((const double *)vwap)[i] * (double)v); /* float64 * float32 -> float64 */
+            } else {
+                float v = ((const float *)volume)[i];
+                float p = ((const float *)vwap)[i] * v;                               /* float32 * float32 -> float32 */
+                ORC_KAHAN(float, vs32, vc32, v);
+                ORC_KAHAN(float, ps32, pc32, p);
+            }
+        }
+        o_open[g] = f_open; o_high[g] = hi; o_low[g] = lo; o_close[g] = l_close; o_trades[g] = tr;
+        if (volume_is_f64) { ((double *)o_volume)[g] = vs64; o_vwap[g] = (float)(ps64 / vs64); }
+        else if (vwap_is_f64) { ((float *)o_volume)[g] = vs32; o_vwap[g] = (float)(ps64 / (double)vs32); }
+        else { ((float *)o_volume)[g] = vs32; o_vwap[g] = ps32 / vs32; }
+        o_valid[g] = (uint8_t)have;
+        /* w_median (:933-946): argsort by size, cumsum of the float64 weights, first index with cum >= total * 0.5 */
+        float med = NAN;
+        if (e > s) {
+            orc_rs_pair *pr = (orc_rs_pair *)malloc((size_t)(e - s) * sizeof(orc_rs_pair));
+            if (!pr) return ORC_E_ARG;
+            for (int64_t i = s; i < e; ++i) { pr[i - s].size = median[i]; pr[i - s].w = (double)trades[i]; pr[i - s].row = i; }
+            qsort(pr, (size_t)(e - s), sizeof(orc_rs_pair), orc_rs_cmp);
+            double tot = 0.0;
+            for (int64_t i = 0; i < e - s; ++i) tot += pr[i].w;
+            double cutoff = tot * 0.5, cum = 0.0;
+            int64_t idx = e - s;                          /* searchsorted(..., 'left') past the end would raise; cannot: */
+            for (int64_t i = 0; i < e - s; ++i) {         /* cum[-1] >= cutoff whenever the weights are >= 0            */
+                cum += pr[i].w;
+                if (cum >= cutoff) { idx = i; break; }
+            }
+            if (idx < e - s) med = (float)pr[idx].size;
+            free(pr);
+        }
+        o_median[g] = med;
+    }
+    return ORC_OK;
+}

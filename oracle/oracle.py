@@ -381,3 +381,20 @@ def calc_volume_percentage_above_poc(price_levels, volumes, poc_price):
     f = lib().orc_calc_volume_percentage_above_poc
     f.restype = C.c_double
     return float(f(_p(pl), _p(v), _i64(len(pl)), C.c_int32(int(poc_price))))
+
+
+def resample_bars(seg, open_, high, low, close, volume, trades, vwap, median):
+    """TimeBarReader._resample (finmlkit/bar/io.py:890-950) on contiguous row groups [seg[g], seg[g+1])
+    -> (open, high, low, close, volume, trades, vwap f32, median f32, valid)."""
+    seg = np.ascontiguousarray(seg, dtype=np.int64)
+    G = len(seg) - 1
+    f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    o, h, l, c, m = f8(open_), f8(high), f8(low), f8(close), f8(median)
+    vol = np.ascontiguousarray(volume, dtype=np.float32 if np.asarray(volume).dtype == np.float32 else np.float64)
+    vw = np.ascontiguousarray(vwap, dtype=np.float32 if np.asarray(vwap).dtype == np.float32 else np.float64)
+    tr = np.ascontiguousarray(trades, dtype=np.int64)
+    out = [np.empty(G, np.float64) for _ in range(4)] + [np.empty(G, vol.dtype), np.empty(G, np.int64),
+                                                         np.empty(G, np.float32), np.empty(G, np.float32), np.empty(G, np.uint8)]
+    _check(lib().orc_resample_bars(_p(seg), _i64(G), _p(o), _p(h), _p(l), _p(c), _p(vol), C.c_int(vol.dtype == np.float64),
+                                   _p(tr), _p(vw), C.c_int(vw.dtype == np.float64), _p(m), *[_p(a) for a in out]))
+    return tuple(out)
