@@ -25,10 +25,12 @@
 #include <stdlib.h>
 
 #include "fmk_common.h"
+#include "fmk_dpp.h"
 #include "fmk_f32tie.h"
 #include "fmk_median.h"
 
 #define FMK_SMALL_NCH 21
+#define FMK_PACKED_MAX_MEAN 40          // mean ticks per bar up to which the packed schedule is used (float32 amounts)
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median);
@@ -259,6 +261,159 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed short bars (float32 amounts): the reference's other caller builds 1-SECOND bars (AddTimeBarH5, bar/io.py:484-485:
+// ~20 ticks per bar on the SURVEY 8(d) stream).  One wave per bar then uses 20 of 64 lanes and pays four cross-lane
+// butterflies plus a 64-lane sort per bar: 46 ms per 1e9 ticks, 0.34 TB/s (profiles/r02_short_bars_before.txt).  Here a
+// wave takes as many WHOLE consecutive bars as fit its 64 lanes (bar boundaries from close_idx, so every segment is
+// complete inside the chunk: no carries), one tick per lane:
+//   * head flags from the closes -> hi / lo / sum(vol) / sum(price*vol) by ONE segmented inclusive scan on the DPP path
+//     (fmk_dpp.h), four values riding the same flags;
+//   * the median by ONE 64-lane bitonic sort of (segment, key) pairs: a segment keeps its lane range, so its two middle
+//     keys sit at known lanes (steps of distance 1, 2 and 8 are DPP moves, the rest go through the crossbar);
+//   * the first lanes of the wave "own" the chunk's bars: they fetch their bar's totals from its last tick's lane and write
+//     all outputs coalesced.  Bars longer than 64 ticks are left to the generic kernels (flag `saw_long`).
+template <int J>
+__device__ __forceinline__ uint64_t pk_partner(uint64_t v)
+{
+    if constexpr (J == 1) return (uint64_t)fmk_dpp<0xB1, 0xF>((int64_t)0, (int64_t)v);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint64_t)fmk_dpp<0x4E, 0xF>((int64_t)0, (int64_t)v);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 8) return (uint64_t)fmk_dpp<0x128, 0xF>((int64_t)0, (int64_t)v);  // row_ror:8 == lane ^ 8
+    else {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, J, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(v >> 32), J, 64);
+        return ((uint64_t)hi << 32) | lo;
+    }
+}
+template <int K, int J>
+__device__ __forceinline__ uint64_t pk_cmpx(uint64_t v, int lane)
+{
+    const uint64_t w = pk_partner<J>(v);
+    const bool up = (lane & K) == 0, lower = (lane & J) == 0;
+    const uint64_t mn = w < v ? w : v, mx = w < v ? v : w;
+    return (lower == up) ? mn : mx;
+}
+__device__ __forceinline__ uint64_t pk_bitonic64(uint64_t v, int lane)
+{
+    v = pk_cmpx<2, 1>(v, lane);
+    v = pk_cmpx<4, 2>(v, lane); v = pk_cmpx<4, 1>(v, lane);
+    v = pk_cmpx<8, 4>(v, lane); v = pk_cmpx<8, 2>(v, lane); v = pk_cmpx<8, 1>(v, lane);
+    v = pk_cmpx<16, 8>(v, lane); v = pk_cmpx<16, 4>(v, lane); v = pk_cmpx<16, 2>(v, lane); v = pk_cmpx<16, 1>(v, lane);
+    v = pk_cmpx<32, 16>(v, lane); v = pk_cmpx<32, 8>(v, lane); v = pk_cmpx<32, 4>(v, lane); v = pk_cmpx<32, 2>(v, lane);
+    v = pk_cmpx<32, 1>(v, lane);
+    v = pk_cmpx<64, 32>(v, lane); v = pk_cmpx<64, 16>(v, lane); v = pk_cmpx<64, 8>(v, lane); v = pk_cmpx<64, 4>(v, lane);
+    v = pk_cmpx<64, 2>(v, lane); v = pk_cmpx<64, 1>(v, lane);
+    return v;
+}
+
+// one step of the segmented inclusive scan: f = "a segment head lies between the source lane (exclusive) and me (inclusive)"
+template <int CTRL, int MASK>
+__device__ __forceinline__ void pk_seg_step(double &hi, double &lo, double &tv, double &td, int &f)
+{
+    const double phi = fmk_dpp<CTRL, MASK>(-INFINITY, hi), plo = fmk_dpp<CTRL, MASK>(INFINITY, lo);
+    const double ptv = fmk_dpp<CTRL, MASK>(0.0, tv), ptd = fmk_dpp<CTRL, MASK>(0.0, td);
+    const int pf = fmk_dpp<CTRL, MASK>(0, f);
+    if (!f) { hi = fmax(phi, hi); lo = fmin(plo, lo); tv = ptv + tv; td = ptd + td; }
+    f |= pf;
+}
+
+template <bool MEDIAN>
+__global__ __launch_bounds__(256) void k_bar_ohlcv_packed(const double *__restrict__ price, const float *__restrict__ amount,
+                                                          const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                          int *__restrict__ saw_long, OhlcvOut o)
+{
+    typedef MedKey<false> MK;
+    __shared__ int64_t s_ci[4][66];
+    __shared__ int s_flag[4][64];
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t ngroups = (nb + 63) >> 6;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + w; g < ngroups; g += nwaves) {
+        const int64_t B0 = g * 64;
+        const int nbg = (int)(nb - B0 < 64 ? nb - B0 : 64);
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= nbg) s_ci[w][lane] = ci[B0 + lane];
+        if (lane == 0 && nbg == 64) s_ci[w][64] = ci[B0 + 64];
+        __builtin_amdgcn_wave_barrier();
+        int bl = 0;
+        while (bl < nbg) {
+            const int64_t s0 = s_ci[w][bl];
+            const int idx = bl + 1 + lane;
+            const bool valid = idx <= nbg;
+            const int64_t e_l = valid ? s_ci[w][idx] : INT64_MAX;
+            const int64_t s_l = valid ? s_ci[w][idx - 1] : 0;
+            const int m = __popcll(__ballot(valid && e_l - s0 <= 64));         // closes ascend: a prefix of the lanes
+            if (m == 0) {                                                        // a bar longer than the wave: generic kernels
+                if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bl += 1;
+                continue;
+            }
+            const int ntick = (int)(s_ci[w][bl + m] - s0);                       // ticks of the m bars
+            const bool owner = lane < m;
+            const int L = owner ? (int)(e_l - s_l) : 0;
+            const bool nonempty = owner && L > 0;
+            const int pos = nonempty ? (int)(e_l - s0 - 1) : 0;                  // lane of my bar's last tick
+            const int first_pos = nonempty ? (int)(s_l - s0) : 0;                // ... and of its first
+            const bool act = lane < ntick;
+            double p = 0.0;
+            uint32_t araw = 0;
+            if (ntick > 0) {
+                const int64_t t = s0 + 1 + (act ? lane : ntick - 1);             // idle lanes re-read the last tick's line
+                p = price[t];
+                araw = ((const uint32_t *)amount)[t];
+            }
+            s_flag[w][lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (nonempty) s_flag[w][pos] = 1;
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t tailmask = __ballot(act && s_flag[w][lane] != 0);
+            int f = (lane == 0 || ((tailmask >> (lane - 1)) & 1)) ? 1 : 0;       // head of a segment
+            const double a = (double)__uint_as_float(araw);
+            double hi = act ? p : -INFINITY, lo = act ? p : INFINITY, tv = act ? a : 0.0, td = act ? p * a : 0.0;
+            pk_seg_step<FMK_DPP_ROW_SHR(1), 0xF>(hi, lo, tv, td, f);
+            pk_seg_step<FMK_DPP_ROW_SHR(2), 0xF>(hi, lo, tv, td, f);
+            pk_seg_step<FMK_DPP_ROW_SHR(4), 0xF>(hi, lo, tv, td, f);
+            pk_seg_step<FMK_DPP_ROW_SHR(8), 0xF>(hi, lo, tv, td, f);
+            pk_seg_step<FMK_DPP_ROW_BCAST15, 0xA>(hi, lo, tv, td, f);
+            pk_seg_step<FMK_DPP_ROW_BCAST31, 0xC>(hi, lo, tv, td, f);
+            // the owners collect their bar: totals and close from its last tick's lane, open from its first
+            const double b_hi = __shfl(hi, pos, 64), b_lo = __shfl(lo, pos, 64);
+            const double b_tv = __shfl(tv, pos, 64), b_td = __shfl(td, pos, 64);
+            const double b_close = __shfl(p, pos, 64), b_open = __shfl(p, first_pos, 64);
+            double med = 0.0;
+            if constexpr (MEDIAN) {
+                const uint64_t seg = (uint64_t)__popcll(tailmask & lt_mask);
+                const uint64_t key = act ? ((seg << 32) | MK::tokey(araw)) : ~0ULL;
+                const uint32_t sk = (uint32_t)pk_bitonic64(key, lane);           // a segment keeps its lanes, sorted inside
+                const uint32_t v1 = (uint32_t)__shfl((int)sk, first_pos + ((L - 1) >> 1), 64);
+                const uint32_t v2 = (uint32_t)__shfl((int)sk, first_pos + (L >> 1), 64);
+                const uint32_t kmn = (uint32_t)__shfl((int)sk, first_pos, 64), kmx = (uint32_t)__shfl((int)sk, pos, 64);
+                if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
+                else med = (L & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
+            }
+            if (owner) {
+                const int64_t b = B0 + bl + lane;
+                if (nonempty) {
+                    o.open[b] = b_open;
+                    o.close[b] = b_close;
+                    o.high[b] = b_open != b_open ? b_open : b_hi;                // a NaN first price never loses (base.py:371-382)
+                    o.low[b] = b_open != b_open ? b_open : b_lo;
+                    o.vol[b] = (float)b_tv;
+                    o.vwap[b] = b_tv > 0.0 ? b_td / b_tv : 0.0;
+                    o.trades[b] = L;
+                    if constexpr (MEDIAN) o.median[b] = med;
+                } else {
+                    ohlcv_empty(o, b, price, e_l, n);
+                }
+            }
+            bl += m;
+        }
+    }
+}
+
 static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
@@ -299,18 +454,30 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     // serialise the up-front loads (2.7 ms -> 3.5..4.3 ms at N = 1e9); 4 waves/SIMD (102 VGPRs) is the optimum.
     int *saw_long = (int *)(ctx->d_mail + 16);               // set by the small kernel iff a long bar exists
     FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
-    if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+    // mean bar length (the tick array's length over the bars is an upper bound) picks the schedule: several whole bars per
+    // wave below FMK_PACKED_MAX_MEAN ticks per bar, one wave per bar above
+    static int packed_max = -1;              // developer knob: FMK_OHLCV_PACKED_MAX_MEAN (0 disables the packed schedule)
+    if (packed_max < 0) { const char *v = getenv("FMK_OHLCV_PACKED_MAX_MEAN"); packed_max = v ? atoi(v) : FMK_PACKED_MAX_MEAN; }
+    int64_t long_min = 64 * FMK_SMALL_NCH;
+    if (!AF64 && nb >= 64 && n / nb <= packed_max) {
+        int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 4);
+        const int64_t cap = (int64_t)ctx->n_cu * 64;
+        if (blocks > cap) blocks = cap;
+        if (!o.median) k_bar_ohlcv_packed<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        else k_bar_ohlcv_packed<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        long_min = 64;
+    } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
     // long bars (if any): the generic kernels exit at once when the flag is clear
-    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 64 * FMK_SMALL_NCH, saw_long, o);
+    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (AF64) {
         k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
         FMK_LAUNCH_CHECK(ctx);
     }
-    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 64 * FMK_SMALL_NCH, saw_long, o.median);
+    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median);
     return FMK_OK;
 }
 

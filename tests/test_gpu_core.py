@@ -184,3 +184,38 @@ def test_ohlcv_volume_f64_decimal_lots_exact(orc, kind, nb, L):
     assert bad.size == 0, f"{bad.size} of {nb} bars differ in float32 volume, first {bad[:5]}: " \
                           f"{got[4][bad[:5]]} vs {want[4][bad[:5]]}"
     np.testing.assert_array_equal(got[6], want[6])
+
+
+@pytest.mark.parametrize("seed,mean_len,with_nan", [(1, 3, False), (2, 8, False), (3, 20, True), (4, 33, False), (5, 39, True)])
+def test_packed_short_bars(orc, seed, mean_len, with_nan):
+    """The packed schedule of comp_bar_ohlcv (k_bar_ohlcv_packed: several whole bars per wave, float32 amounts, mean bar
+    length <= 40 ticks): random bar lengths 0 (empty) .. 64 .. 200 (left to the generic kernels), a -1 open edge, NaN
+    amounts (median NaN), a NaN first price (high = low = NaN), repeated closes; every output against the oracle."""
+    from finmlkit_amd import engine
+    rng = np.random.default_rng(seed)
+    nb = 5000
+    lens = rng.geometric(1.0 / mean_len, nb) - (rng.random(nb) < 0.15)        # some empty bars
+    lens = np.maximum(lens, 0)
+    lens[rng.integers(0, nb, 25)] = rng.integers(60, 70, 25)                  # around the wave's 64 lanes
+    lens[rng.integers(0, nb, 8)] = rng.integers(65, 200, 8)                   # longer than a wave
+    ci = np.concatenate([[-1], np.cumsum(lens) - 1]).astype(np.int64)
+    n = int(ci[-1]) + 1 + 17                                                  # some ticks behind the last close
+    px = 100.0 + 0.01 * np.cumsum(rng.integers(-3, 4, n))
+    am = rng.lognormal(-1.0, 1.0, n).astype(np.float32)
+    if with_nan:
+        am[rng.integers(0, n, 40)] = np.nan
+        px[ci[rng.integers(1, nb, 10)] + 1] = np.nan                          # NaN as some bars' first price
+        px[rng.integers(0, n, 20)] = np.nan
+    assert n / nb <= 40
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, am)
+    dci = engine.DeviceArray.from_host(t.ctx, ci)
+    for med in (True, False):
+        got = engine.to_host(t.bar_ohlcv(dci, want_median=med))
+        want = orc.comp_bar_ohlcv(px, am, ci, want_median=med)
+        for k, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], want):
+            if k == "median_trade_size" and not med:
+                continue
+            if k == "vwap":
+                np.testing.assert_allclose(got[k], w, rtol=1e-9, equal_nan=True, err_msg=k)
+            else:
+                np.testing.assert_array_equal(got[k], w, err_msg=f"{k} (median={med})")
