@@ -24,13 +24,15 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <utility>
+
 #include "fmk_common.h"
 #include "fmk_dpp.h"
 #include "fmk_f32tie.h"
 #include "fmk_median.h"
 
 #define FMK_SMALL_NCH 21
-#define FMK_PACKED_MAX_MEAN 40          // mean ticks per bar up to which the packed schedule is used (float32 amounts)
+#define FMK_PACKED_MAX_MEAN 48          // mean ticks per bar up to which the lane-per-bar schedule is used (float32 amounts)
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median);
@@ -262,75 +264,122 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Packed short bars (float32 amounts): the reference's other caller builds 1-SECOND bars (AddTimeBarH5, bar/io.py:484-485:
-// ~20 ticks per bar on the SURVEY 8(d) stream).  One wave per bar then uses 20 of 64 lanes and pays four cross-lane
-// butterflies plus a 64-lane sort per bar: 46 ms per 1e9 ticks, 0.34 TB/s (profiles/r02_short_bars_before.txt).  Here a
-// wave takes as many WHOLE consecutive bars as fit its 64 lanes (bar boundaries from close_idx, so every segment is
-// complete inside the chunk: no carries), one tick per lane:
-//   * head flags from the closes -> hi / lo / sum(vol) / sum(price*vol) by ONE segmented inclusive scan on the DPP path
-//     (fmk_dpp.h), four values riding the same flags;
-//   * the median by ONE 64-lane bitonic sort of (segment, key) pairs: a segment keeps its lane range, so its two middle
-//     keys sit at known lanes (steps of distance 1, 2 and 8 are DPP moves, the rest go through the crossbar);
-//   * the first lanes of the wave "own" the chunk's bars: they fetch their bar's totals from its last tick's lane and write
-//     all outputs coalesced.  Bars longer than 64 ticks are left to the generic kernels (flag `saw_long`).
-template <int J>
-__device__ __forceinline__ uint64_t pk_partner(uint64_t v)
+// Short bars (float32 amounts), one LANE per bar.  The reference's other caller builds 1-SECOND bars (AddTimeBarH5,
+// bar/io.py:484-485: ~20 ticks per bar on the SURVEY 8(d) stream).  One wave per bar then uses 20 of 64 lanes and pays four
+// cross-lane butterflies plus a 64-lane sort per bar: 46 ms per 1e9 ticks, 0.34 TB/s.  A first packed schedule (whole bars
+// side by side in the 64 lanes, one tick per lane, a segmented DPP scan of four values and one sort of (segment, key)
+// pairs) got 12.4 ms but still spent ~4.7 wave instructions per tick (profiles/r02_short_bars_before.txt).  This one spends
+// ~1: a wave takes the next <= 64 whole bars whose ticks fit its LDS tile; the tile is filled with coalesced loads (the bars
+// are one contiguous tick range); then lane l walks bar l's ticks in the tile -- max / min / sum(vol) / sum(price*vol) are
+// plain sequential register updates IN THE REFERENCE'S TICK ORDER (base.py:377-391: vwap comes out bit-identical, not just
+// within 1e-9) -- and sorts the bar's keys with a fixed compare-exchange network on its own registers (all lanes in
+// lockstep, two instructions per exchange, no cross-lane traffic at all).  Outputs are written coalesced, one bar per lane.
+// Bars longer than 64 ticks are left to the generic kernels (flag `saw_long`).
+#define LB_TILE 1024                     // ticks per wave tile: 8 KB prices + 4 KB amounts
+
+// bitonic sorting network on N registers of ONE lane; every index is a template constant, so the keys stay in VGPRs
+template <int I, int J, int K, int N>
+__device__ __forceinline__ void lb_ce(uint32_t (&r)[N])
 {
-    if constexpr (J == 1) return (uint64_t)fmk_dpp<0xB1, 0xF>((int64_t)0, (int64_t)v);        // quad_perm [1,0,3,2]
-    else if constexpr (J == 2) return (uint64_t)fmk_dpp<0x4E, 0xF>((int64_t)0, (int64_t)v);   // quad_perm [2,3,0,1]
-    else if constexpr (J == 8) return (uint64_t)fmk_dpp<0x128, 0xF>((int64_t)0, (int64_t)v);  // row_ror:8 == lane ^ 8
-    else {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, J, 64);
-        const uint32_t hi = (uint32_t)__shfl_xor((int)(v >> 32), J, 64);
-        return ((uint64_t)hi << 32) | lo;
+    constexpr int l = I ^ J;
+    if constexpr (l > I) {
+        const uint32_t a = r[I], b = r[l];
+        const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+        if constexpr ((I & K) == 0) { r[I] = mn; r[l] = mx; }
+        else { r[I] = mx; r[l] = mn; }
     }
 }
-template <int K, int J>
-__device__ __forceinline__ uint64_t pk_cmpx(uint64_t v, int lane)
+template <int J, int K, int N, int... I>
+__device__ __forceinline__ void lb_stage(uint32_t (&r)[N], std::integer_sequence<int, I...>)
 {
-    const uint64_t w = pk_partner<J>(v);
-    const bool up = (lane & K) == 0, lower = (lane & J) == 0;
-    const uint64_t mn = w < v ? w : v, mx = w < v ? v : w;
-    return (lower == up) ? mn : mx;
+    (lb_ce<I, J, K, N>(r), ...);
 }
-__device__ __forceinline__ uint64_t pk_bitonic64(uint64_t v, int lane)
+template <int J, int K, int N>
+__device__ __forceinline__ void lb_js(uint32_t (&r)[N])
 {
-    v = pk_cmpx<2, 1>(v, lane);
-    v = pk_cmpx<4, 2>(v, lane); v = pk_cmpx<4, 1>(v, lane);
-    v = pk_cmpx<8, 4>(v, lane); v = pk_cmpx<8, 2>(v, lane); v = pk_cmpx<8, 1>(v, lane);
-    v = pk_cmpx<16, 8>(v, lane); v = pk_cmpx<16, 4>(v, lane); v = pk_cmpx<16, 2>(v, lane); v = pk_cmpx<16, 1>(v, lane);
-    v = pk_cmpx<32, 16>(v, lane); v = pk_cmpx<32, 8>(v, lane); v = pk_cmpx<32, 4>(v, lane); v = pk_cmpx<32, 2>(v, lane);
-    v = pk_cmpx<32, 1>(v, lane);
-    v = pk_cmpx<64, 32>(v, lane); v = pk_cmpx<64, 16>(v, lane); v = pk_cmpx<64, 8>(v, lane); v = pk_cmpx<64, 4>(v, lane);
-    v = pk_cmpx<64, 2>(v, lane); v = pk_cmpx<64, 1>(v, lane);
+    lb_stage<J, K, N>(r, std::make_integer_sequence<int, N>{});
+    if constexpr (J > 1) lb_js<J / 2, K, N>(r);
+}
+template <int K, int N>
+__device__ __forceinline__ void lb_ks(uint32_t (&r)[N])
+{
+    lb_js<K / 2, K, N>(r);
+    if constexpr (K < N) lb_ks<K * 2, N>(r);
+}
+template <int N>
+__device__ __forceinline__ void lb_sort(uint32_t (&r)[N]) { lb_ks<2, N>(r); }
+
+template <int N, int... I>
+__device__ __forceinline__ uint32_t lb_pick_seq(const uint32_t (&r)[N], int idx, std::integer_sequence<int, I...>)
+{
+    uint32_t v = r[0];
+    ((v = idx == I ? r[I] : v), ...);
     return v;
 }
-
-// one step of the segmented inclusive scan: f = "a segment head lies between the source lane (exclusive) and me (inclusive)"
-template <int CTRL, int MASK>
-__device__ __forceinline__ void pk_seg_step(double &hi, double &lo, double &tv, double &td, int &f)
+template <int N>
+__device__ __forceinline__ uint32_t lb_pick(const uint32_t (&r)[N], int idx)
 {
-    const double phi = fmk_dpp<CTRL, MASK>(-INFINITY, hi), plo = fmk_dpp<CTRL, MASK>(INFINITY, lo);
-    const double ptv = fmk_dpp<CTRL, MASK>(0.0, tv), ptd = fmk_dpp<CTRL, MASK>(0.0, td);
-    const int pf = fmk_dpp<CTRL, MASK>(0, f);
-    if (!f) { hi = fmax(phi, hi); lo = fmin(plo, lo); tv = ptv + tv; td = ptd + td; }
-    f |= pf;
+    return lb_pick_seq<N>(r, idx, std::make_integer_sequence<int, N>{});
+}
+
+// One bar of L <= N ticks per lane (L == 0: idle lane): the reference's loop body (base.py:377-391) over the lane's slice of
+// the tile, eight ticks at a time (more loads in flight only cost registers: the LDS is next door), then the median from a
+// fixed N-key sorting network on the lane's own registers.
+template <bool MEDIAN, int N>
+__device__ __forceinline__ void lb_bar(const double *tp, const uint32_t *ta, int off, int L, double &hi, double &lo,
+                                       double &tv, double &td, double &med)
+{
+    typedef MedKey<false> MK;
+    uint32_t r[MEDIAN ? N : 1];
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        double p[8];
+        uint32_t raw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int at = j0 + q < L ? off + j0 + q : off;      // idle iterations re-read the bar's first tick
+            p[q] = tp[at];
+            raw[q] = ta[at];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = j0 + q < L;
+            const double a = (double)__uint_as_float(raw[q]);
+            if (in) {
+                hi = p[q] > hi ? p[q] : hi;                      // `>` / `<` like the reference: a NaN never wins
+                lo = p[q] < lo ? p[q] : lo;
+                tv += a;
+                td += p[q] * a;
+            }
+            if constexpr (MEDIAN) r[j0 + q] = in ? MK::tokey(raw[q]) : MK::MAXK;
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // keep the blocks apart: 8 ticks of loads live at a time
+    }
+    if constexpr (MEDIAN) {
+        lb_sort<N>(r);
+        const uint32_t v1 = lb_pick<N>(r, (L - 1) >> 1), v2 = lb_pick<N>(r, L >> 1);
+        const uint32_t kmx = lb_pick<N>(r, L > 0 ? L - 1 : 0), kmn = r[0];
+        if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
+        else med = (L & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
+    }
 }
 
 template <bool MEDIAN>
-__global__ __launch_bounds__(256) void k_bar_ohlcv_packed(const double *__restrict__ price, const float *__restrict__ amount,
-                                                          const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                          int *__restrict__ saw_long, OhlcvOut o)
+__global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restrict__ price, const float *__restrict__ amount,
+                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                         int *__restrict__ saw_long, OhlcvOut o)
 {
     typedef MedKey<false> MK;
-    __shared__ int64_t s_ci[4][66];
-    __shared__ int s_flag[4][64];
+    __shared__ double s_p[2][LB_TILE];
+    __shared__ uint32_t s_a[2][LB_TILE];
+    __shared__ int64_t s_ci[2][66];
     const int lane = fmk_lane();
     const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    double *tp = s_p[w];
+    uint32_t *ta = s_a[w];
     const int64_t ngroups = (nb + 63) >> 6;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const uint64_t lt_mask = (1ULL << lane) - 1;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + w; g < ngroups; g += nwaves) {
+    const int64_t nwaves = (int64_t)gridDim.x * 2;
+    for (int64_t g = (int64_t)blockIdx.x * 2 + w; g < ngroups; g += nwaves) {
         const int64_t B0 = g * 64;
         const int nbg = (int)(nb - B0 < 64 ? nb - B0 : 64);
         __builtin_amdgcn_wave_barrier();
@@ -344,68 +393,51 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv_packed(const double *__restri
             const bool valid = idx <= nbg;
             const int64_t e_l = valid ? s_ci[w][idx] : INT64_MAX;
             const int64_t s_l = valid ? s_ci[w][idx - 1] : 0;
-            const int m = __popcll(__ballot(valid && e_l - s0 <= 64));         // closes ascend: a prefix of the lanes
-            if (m == 0) {                                                        // a bar longer than the wave: generic kernels
+            const int m = __popcll(__ballot(valid && e_l - s0 <= LB_TILE));     // closes ascend: a prefix of the lanes
+            if (m == 0) {                                                        // one bar longer than the tile
                 if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                     __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bl += 1;
                 continue;
             }
-            const int ntick = (int)(s_ci[w][bl + m] - s0);                       // ticks of the m bars
+            const int ntick = (int)(s_ci[w][bl + m] - s0);                       // ticks of the m bars: (s0, s0 + ntick]
+            // ---- fill the tile: one contiguous range, coalesced
+            __builtin_amdgcn_wave_barrier();
+            const double *gp = price + s0 + 1;
+            const uint32_t *ga = (const uint32_t *)amount + s0 + 1;
+#pragma unroll 4
+            for (int j = lane; j < ntick; j += 64) {
+                tp[j] = gp[j];
+                ta[j] = ga[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- one lane per bar
             const bool owner = lane < m;
             const int L = owner ? (int)(e_l - s_l) : 0;
-            const bool nonempty = owner && L > 0;
-            const int pos = nonempty ? (int)(e_l - s0 - 1) : 0;                  // lane of my bar's last tick
-            const int first_pos = nonempty ? (int)(s_l - s0) : 0;                // ... and of its first
-            const bool act = lane < ntick;
-            double p = 0.0;
-            uint32_t araw = 0;
-            if (ntick > 0) {
-                const int64_t t = s0 + 1 + (act ? lane : ntick - 1);             // idle lanes re-read the last tick's line
-                p = price[t];
-                araw = ((const uint32_t *)amount)[t];
-            }
-            s_flag[w][lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (nonempty) s_flag[w][pos] = 1;
-            __builtin_amdgcn_wave_barrier();
-            const uint64_t tailmask = __ballot(act && s_flag[w][lane] != 0);
-            int f = (lane == 0 || ((tailmask >> (lane - 1)) & 1)) ? 1 : 0;       // head of a segment
-            const double a = (double)__uint_as_float(araw);
-            double hi = act ? p : -INFINITY, lo = act ? p : INFINITY, tv = act ? a : 0.0, td = act ? p * a : 0.0;
-            pk_seg_step<FMK_DPP_ROW_SHR(1), 0xF>(hi, lo, tv, td, f);
-            pk_seg_step<FMK_DPP_ROW_SHR(2), 0xF>(hi, lo, tv, td, f);
-            pk_seg_step<FMK_DPP_ROW_SHR(4), 0xF>(hi, lo, tv, td, f);
-            pk_seg_step<FMK_DPP_ROW_SHR(8), 0xF>(hi, lo, tv, td, f);
-            pk_seg_step<FMK_DPP_ROW_BCAST15, 0xA>(hi, lo, tv, td, f);
-            pk_seg_step<FMK_DPP_ROW_BCAST31, 0xC>(hi, lo, tv, td, f);
-            // the owners collect their bar: totals and close from its last tick's lane, open from its first
-            const double b_hi = __shfl(hi, pos, 64), b_lo = __shfl(lo, pos, 64);
-            const double b_tv = __shfl(tv, pos, 64), b_td = __shfl(td, pos, 64);
-            const double b_close = __shfl(p, pos, 64), b_open = __shfl(p, first_pos, 64);
+            const bool mine = owner && L > 0 && L <= 64;
+            const int off = mine ? (int)(s_l - s0) : 0;
+            const uint64_t longer = __ballot(owner && L > 64);                   // wave-long bars: generic kernels
+            if (longer && lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int Lw = mine ? L : 0;
+            const bool any_gt32 = __ballot(Lw > 32) != 0;
+            const double first = ntick > 0 ? tp[off] : 0.0;
+            double hi = first, lo = first, tv = 0.0, td = 0.0;                   // base.py:371-372: seeded with the first price
             double med = 0.0;
-            if constexpr (MEDIAN) {
-                const uint64_t seg = (uint64_t)__popcll(tailmask & lt_mask);
-                const uint64_t key = act ? ((seg << 32) | MK::tokey(araw)) : ~0ULL;
-                const uint32_t sk = (uint32_t)pk_bitonic64(key, lane);           // a segment keeps its lanes, sorted inside
-                const uint32_t v1 = (uint32_t)__shfl((int)sk, first_pos + ((L - 1) >> 1), 64);
-                const uint32_t v2 = (uint32_t)__shfl((int)sk, first_pos + (L >> 1), 64);
-                const uint32_t kmn = (uint32_t)__shfl((int)sk, first_pos, 64), kmx = (uint32_t)__shfl((int)sk, pos, 64);
-                if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
-                else med = (L & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
-            }
+            if (any_gt32) lb_bar<MEDIAN, 64>(tp, ta, off, Lw, hi, lo, tv, td, med);
+            else lb_bar<MEDIAN, 32>(tp, ta, off, Lw, hi, lo, tv, td, med);
             if (owner) {
                 const int64_t b = B0 + bl + lane;
-                if (nonempty) {
-                    o.open[b] = b_open;
-                    o.close[b] = b_close;
-                    o.high[b] = b_open != b_open ? b_open : b_hi;                // a NaN first price never loses (base.py:371-382)
-                    o.low[b] = b_open != b_open ? b_open : b_lo;
-                    o.vol[b] = (float)b_tv;
-                    o.vwap[b] = b_tv > 0.0 ? b_td / b_tv : 0.0;
+                if (mine) {
+                    o.open[b] = first;
+                    o.close[b] = tp[off + L - 1];
+                    o.high[b] = hi;
+                    o.low[b] = lo;
+                    o.vol[b] = (float)tv;
+                    o.vwap[b] = tv > 0.0 ? td / tv : 0.0;
                     o.trades[b] = L;
                     if constexpr (MEDIAN) o.median[b] = med;
-                } else {
+                } else if (L == 0) {
                     ohlcv_empty(o, b, price, e_l, n);
                 }
             }
@@ -455,16 +487,16 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     int *saw_long = (int *)(ctx->d_mail + 16);               // set by the small kernel iff a long bar exists
     FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
     // mean bar length (the tick array's length over the bars is an upper bound) picks the schedule: several whole bars per
-    // wave below FMK_PACKED_MAX_MEAN ticks per bar, one wave per bar above
+    // LANE below FMK_PACKED_MAX_MEAN ticks per bar (k_bar_ohlcv_lanes), one bar per wave above
     static int packed_max = -1;              // developer knob: FMK_OHLCV_PACKED_MAX_MEAN (0 disables the packed schedule)
     if (packed_max < 0) { const char *v = getenv("FMK_OHLCV_PACKED_MAX_MEAN"); packed_max = v ? atoi(v) : FMK_PACKED_MAX_MEAN; }
     int64_t long_min = 64 * FMK_SMALL_NCH;
     if (!AF64 && nb >= 64 && n / nb <= packed_max) {
-        int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 4);
-        const int64_t cap = (int64_t)ctx->n_cu * 64;
+        int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
+        const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
-        if (!o.median) k_bar_ohlcv_packed<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
-        else k_bar_ohlcv_packed<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        if (!o.median) k_bar_ohlcv_lanes<false><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        else k_bar_ohlcv_lanes<true><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         long_min = 64;
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
