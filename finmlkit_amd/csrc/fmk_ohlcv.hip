@@ -59,12 +59,16 @@ __device__ __forceinline__ void ohlcv_empty(const OhlcvOut &o, int64_t b, const 
 
 template <bool AF64>
 __device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const double *price, int64_t start,
-                                             int64_t e, double hi, double lo, double tv, double td, int lane)
+                                             int64_t e, double hi, double lo, double tv, double td, int lane,
+                                             bool sums_done = false)
 {
-    hi = fmk_wave_max(hi);
-    lo = fmk_wave_min(lo);
-    tv = fmk_wave_sum(tv);
-    td = fmk_wave_sum(td);
+    // DPP reductions (fmk_dpp.h): the four 6-step xor butterflies that stood here were 48 ds_bpermute round trips per bar
+    hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+    lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
+    if (!sums_done) {
+        tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
+        td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+    }
     if (lane == 0) {
         // base.py:371-382 seeds high / low with the bar's first price and updates them with `>` / `<`: NaNs later in the
         // bar lose every comparison (the fmax / fmin above), but a NaN FIRST price never loses one -> high = low = NaN
@@ -206,7 +210,27 @@ __device__ __forceinline__ void small_bar(const double *__restrict__ price, cons
             if constexpr (MEDIAN) bar.key[c] = MK::tokey(araw[c]);
         }
     }
-    ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
+    if constexpr (NCH == 1 && !AF64) {
+        // A bar of <= 64 ticks with float32 amounts gets the SAME sums whichever schedule serves it: k_bar_ohlcv_lanes adds in
+        // tick order (the reference's order), so this one does too -- lane k's product broadcast from a scalar register,
+        // k = 0 .. cnt-1.  Only reached when the stream's mean bar is long (few such bars) or there are < 64 bars: a result
+        // that depended on the mean bar length would make a sharded run differ from the un-sharded one in the last bit.
+        double tvs = 0.0, tds = 0.0;
+        const double a0 = (double)__uint_as_float(araw[0]);
+        for (int k = 0; k < (int)cnt; ++k) {
+            const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(p[0]), k);
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)__double_as_longlong(p[0]) >> 32), k);
+            const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(a0), k);
+            const uint32_t ahi = (uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)__double_as_longlong(a0) >> 32), k);
+            const double pk = __longlong_as_double((long long)(((uint64_t)phi << 32) | plo));
+            const double ak = __longlong_as_double((long long)(((uint64_t)ahi << 32) | alo));
+            tvs += ak;
+            tds += pk * ak;
+        }
+        ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tvs, tds, lane, true);
+    } else {
+        ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
+    }
     if constexpr (MEDIAN) {
         bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
         const double m = med_search<AF64, NCH, EXACT>(bar, buf);
@@ -275,7 +299,6 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
 // within 1e-9) -- and sorts the bar's keys with a fixed compare-exchange network on its own registers (all lanes in
 // lockstep, two instructions per exchange, no cross-lane traffic at all).  Outputs are written coalesced, one bar per lane.
 // Bars longer than 64 ticks are left to the generic kernels (flag `saw_long`).
-#define LB_TILE 1024                     // ticks per wave tile: 8 KB prices + 4 KB amounts
 
 // bitonic sorting network on N registers of ONE lane; every index is a template constant, so the keys stay in VGPRs
 template <int I, int J, int K, int N>
@@ -364,12 +387,13 @@ __device__ __forceinline__ void lb_bar(const double *tp, const uint32_t *ta, int
     }
 }
 
-template <bool MEDIAN>
+// LB_TILE ticks per wave tile (12 B each).  1024 (two waves: 24 KB per workgroup) beat 2048 at every bar length from 10 to 40
+// ticks (4.5 vs 4.8 .. 7.6 ms per 1e9 ticks): the waves a CU can hold matter more than filling all 64 lanes
+template <bool MEDIAN, int LB_TILE>
 __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restrict__ price, const float *__restrict__ amount,
                                                          const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                          int *__restrict__ saw_long, OhlcvOut o)
 {
-    typedef MedKey<false> MK;
     __shared__ double s_p[2][LB_TILE];
     __shared__ uint32_t s_a[2][LB_TILE];
     __shared__ int64_t s_ci[2][66];
@@ -495,8 +519,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
-        if (!o.median) k_bar_ohlcv_lanes<false><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
-        else k_bar_ohlcv_lanes<true><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        if (!o.median) k_bar_ohlcv_lanes<false, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        else k_bar_ohlcv_lanes<true, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         long_min = 64;
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
