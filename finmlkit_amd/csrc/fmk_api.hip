@@ -211,6 +211,11 @@ int fmk_free(fmk_ctx *ctx, void *dptr)
                              "fmk_free: %p is not a live block of this context (double free?)", dptr);
     const size_t bytes = it->second;
     p->live.erase(it);
+    for (int k = 0; k < 3; ++k)                      // result caches of the threshold indexers keyed on pointers into this block
+        for (int q = 0; q < 2; ++q) {
+            const char *key = (const char *)ctx->idx_key[k][q];
+            if (key && key >= (const char *)dptr && key < (const char *)dptr + bytes) ctx->idx_stale[k] = 1;
+        }
     if (!p->enabled) {
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         FMK_HIP(ctx, hipFree(dptr));

@@ -34,6 +34,10 @@ struct fmk_ctx {
     void *pool;
     // result / work caches of the threshold indexers (fmk_volume / fmk_dollar / fmk_threshold .hip), one per context
     void *idx_cache[3];
+    // the caches are keyed on device POINTERS (amount, price): when fmk_free gives a block back that holds such a key, the
+    // cache is marked stale, so a later allocation that recycles the address for other data cannot hit it
+    const void *idx_key[3][2];
+    int idx_stale[3];
 };
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);

@@ -455,7 +455,7 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     DlCache &c = dl_cache(ctx);
-    const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
+    const bool hit = c.ctx == ctx && !ctx->idx_stale[1] && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {
         int rc = amount_is_f64 ? dl_run<true>(ctx, d_price, d_amount, n, threshold, c)
@@ -465,6 +465,7 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
                                         n_idx, n_uncertified);
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
+        ctx->idx_key[1][0] = d_amount; ctx->idx_key[1][1] = d_price; ctx->idx_stale[1] = 0;
     }
     // test knob (read per call): FMK_DL_FORCE_EXACT_TIER=1 runs the exact tier even when the closed form is already certain
     const char *fv = getenv("FMK_DL_FORCE_EXACT_TIER");

@@ -249,7 +249,7 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     ThCache &c = th_cache(ctx);
-    const bool hit = c.ctx == ctx && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
+    const bool hit = c.ctx == ctx && !ctx->idx_stale[2] && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == thr &&
                      c.kind == (int)DOLLAR && c.is_f64 == is_f64 && c.dbuf && c.exact == exact;
     if (!(hit && d_close_idx)) {
         // bound the number of closes
@@ -285,6 +285,7 @@ static int th_run(fmk_ctx *ctx, const double *d_price, const void *d_amount, int
         FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 16, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = thr; c.kind = (int)DOLLAR;
+        ctx->idx_key[2][0] = d_amount; ctx->idx_key[2][1] = d_price; ctx->idx_stale[2] = 0;
         c.is_f64 = is_f64; c.count = ctx->h_mail[0]; c.unc = ctx->h_mail[1]; c.exact = exact;
         if (c.count > c.cap) return fmk_set_error(ctx, FMK_E_CAPACITY, "threshold indexer: internal bound exceeded");
     }

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
         // clamped, not an error (its own test_block_volume passes end == len(amounts)).  The empty-bar guard
         // (start > end, base.py:584) looks at the raw indices; a slice left empty by the clamp gives mean([]) = NaN and
         // a zero total -> the same all-NaN row.
-        const int64_t e = e_raw < n - 1 ? e_raw : n - 1;
-        const int64_t cnt = e_raw - s > 0 ? e - s : 0;
-        const int64_t start = s + 1;
+        // Python slice bounds: a negative start / stop wraps by n once and is then clamped to [0, n] -- a close index below -1
+        // must not become a read in front of the column (it selects the reference's wrapped, usually empty, slice)
+        int64_t start = s + 1, stop = e_raw + 1;
+        start = start < 0 ? (start + n > 0 ? start + n : 0) : (start < n ? start : n);
+        stop = stop < 0 ? (stop + n > 0 ? stop + n : 0) : (stop < n ? stop : n);
+        const int64_t cnt = (e_raw - s > 0 && stop > start) ? stop - start : 0;
         float mean_rel = NAN, p95_rel = NAN, pct = NAN, gini = NAN;      // base.py:576-579
         const double th = theta[b];
         if (cnt > 0 && th != 0.0) {                                      // base.py:586-587

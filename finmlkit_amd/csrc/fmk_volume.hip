@@ -181,7 +181,11 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     //      for its first tick the thread only walks forward (amortised ~1 probe per tick instead of log2(2S) = 12).
     const int64_t remain = n - bs;                                  // ticks available from the block start
     const int mmax = (int)(remain < 2 * S ? remain : 2 * S);        // Lp[0..mmax] are valid
-    const double tol = 1e-11 * thr;
+    // The decisions are differences of block-local prefix sums over up to 2S ticks: their own rounding (<= 2S * 2^-53 of the
+    // largest prefix, twice) must stay inside the margin even when that prefix dwarfs the threshold (one giant trade followed
+    // by small ones: an ulp of the prefix can exceed 1e-11 * thr and a decision that differs from the reference's sequential
+    // sum would be classed certain) -- hence the second term, 2^-40 = 2 * 4096 * 2^-53 of the block's last prefix
+    const double tol = 1e-11 * thr + 9.094947017729282e-13 * fabs(LP(mmax));
     int carry_lo = 0;                                               // m of the previous tick of this thread
     bool ovf = false;
     for (int q = 0; q < EPT; ++q) {
@@ -1489,7 +1493,7 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
                                     n_idx, n_uncertified);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     VolCache &c = vol_cache(ctx);
-    const bool hit = c.ctx == ctx && c.amount == d_amount && c.n == n && c.thr == threshold &&
+    const bool hit = c.ctx == ctx && !ctx->idx_stale[0] && c.amount == d_amount && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {
         // Tier by mean bar length.  A sample of the head of the stream (prefix + total of the first 2^19 ticks: two tiny
@@ -1542,6 +1546,7 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
                                         n_idx, n_uncertified);
         if (rc) return rc;
         c.ctx = ctx; c.amount = d_amount; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
+        ctx->idx_key[0][0] = d_amount; ctx->idx_key[0][1] = nullptr; ctx->idx_stale[0] = 0;
     }
     if (c.unc > 0 && !ctx->fast_threshold) {      // see fmk_dollar_bar_indexer_dev
         c.ctx = nullptr;

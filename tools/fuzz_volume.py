@@ -30,6 +30,8 @@ def amounts(rng, n):
         a = rng.random(n)
     else:                                                           # mostly zeros
         a = np.where(rng.random(n) < 0.02, rng.lognormal(0, 1, n), 0.0)
+    if rng.random() < 0.08 and n > 10:                              # a prefix that dwarfs the threshold: one ulp of it is more
+        a = a.astype(np.float64); a[rng.integers(0, n, 1 + n // 200000)] *= float(rng.choice([1e9, 1e12]))   # than 1e-11 * thr
     if rng.random() < 0.2 and n > 10:                               # whales
         a = a.copy(); a[rng.integers(0, n, max(1, n // 50000 + 1))] *= float(rng.choice([1e3, 1e5]))
     if rng.random() < 0.04 and n > 10:                              # outside the parallel domain
