@@ -76,6 +76,7 @@ int fmk_ctx_create(int device, fmk_ctx **out)
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
     CK(hipHostMalloc((void **)&c->h_mail, 64 * sizeof(int64_t), hipHostMallocDefault));
+    memset(c->h_mail, 0, 64 * sizeof(int64_t));
     CK(hipMalloc((void **)&c->d_mail, 64 * sizeof(int64_t)));
 #undef CK
     *out = c;
@@ -113,11 +114,24 @@ int fmk_ctx_trim(fmk_ctx *ctx)
     return FMK_OK;
 }
 
+// Kernels that wait for other workgroups inside a launch (the one-pass scans) bound their spins and, instead of hanging,
+// raise h_mail[40] (pinned host memory the device writes directly); it is looked at whenever the host waits for the stream.
+static int fmk_check_device_error(fmk_ctx *ctx)
+{
+    if (ctx->h_mail[40] != 0) {
+        const long long code = (long long)ctx->h_mail[40];
+        ctx->h_mail[40] = 0;
+        return fmk_set_error(ctx, FMK_E_HIP, "a one-pass scan kernel gave up waiting for another workgroup (code %lld); "
+                             "its output is not valid", code);
+    }
+    return FMK_OK;
+}
+
 int fmk_ctx_sync(fmk_ctx *ctx)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FMK_OK;
+    return fmk_check_device_error(ctx);
 }
 
 void *fmk_ctx_stream(fmk_ctx *ctx) { return (void *)ctx->stream; }
@@ -249,7 +263,7 @@ int fmk_d2h(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FMK_OK;
+    return fmk_check_device_error(ctx);
 }
 
 int fmk_d2d(fmk_ctx *ctx, void *dst, const void *src, size_t bytes)

@@ -165,6 +165,29 @@ __device__ __forceinline__ EwMap ew_compose(const EwMap &f, const EwMap &g)
     return r;
 }
 
+// the per-tick map of MODE 0 / 1 from the tick's alpha = 1 - exp(-dt / half_life)
+template <int MODE>
+__device__ __forceinline__ EwMap ew_tick_alpha(double alpha, double y)
+{
+    const bool nan = isnan(y);
+    EwMap m;
+    const double om = 1.0 - alpha;
+    m.a = om;
+    m.a2 = om * om;
+    if constexpr (MODE == 1) {
+        m.bV = nan ? 0.0 : alpha;            // V  (weights) : decays only on NaN
+        m.bV2 = 0.0;
+        m.bSy = 0.0;
+        m.bSyy = nan ? 0.0 : alpha * (y * y);   // U
+    } else {
+        m.bV = alpha;
+        m.bV2 = alpha * alpha;
+        m.bSy = nan ? 0.0 : alpha * y;
+        m.bSyy = nan ? 0.0 : alpha * y * y;
+    }
+    return m;
+}
+
 // MODE 0: ewmst (volatility.py:139-219)   1: ewmst_mean0 (:72-136)   2: ewms (:9-69; fixed alpha, no timestamps --
 // `half_life` then carries one_minus_alpha and the four states are Sw, Sw2, Sy, Sy2)
 // the reference's per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52)
@@ -185,21 +208,7 @@ __device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y
     }
     const double dt = (double)(t_cur - t_prev) / 1e9;
     const double alpha = 1.0 - exp(-dt / half_life);
-    const double om = 1.0 - alpha;
-    m.a = om;
-    m.a2 = om * om;
-    if constexpr (MODE == 1) {
-        m.bV = nan ? 0.0 : alpha;            // V  (weights) : decays only on NaN
-        m.bV2 = 0.0;
-        m.bSy = 0.0;
-        m.bSyy = nan ? 0.0 : alpha * (y * y);   // U
-    } else {
-        m.bV = alpha;
-        m.bV2 = alpha * alpha;
-        m.bSy = nan ? 0.0 : alpha * y;
-        m.bSyy = nan ? 0.0 : alpha * y * y;
-    }
-    return m;
+    return ew_tick_alpha<MODE>(alpha, y);
 }
 
 // sequentially apply one tick to a state, in the reference's exact operation order
@@ -459,6 +468,185 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE pass (ewmst / ewmst_mean0 / ewms): tile aggregates + decoupled look-back + apply in the same kernel, so ts and y are
+// read once (16 B/tick instead of 2 x 16) and exp() is evaluated once per tick (the per-tick decay factors stay in
+// registers between the map phase and the apply phase).  Inter-workgroup hand-off as the CDNA4 guide prescribes (Guideline
+// 16, form R2: the data IS the flag): a tile's aggregate map and, later, its inclusive prefix map are published as twelve
+// 8-byte {tag, 32-bit word} granules each with relaxed agent-scope stores; a consumer re-reads the twelve granules until
+// every tag matches -- no fences, no flags, nothing that depends on dispatch order or XCD placement.  Forward progress: the
+// grid is PERSISTENT (as many workgroups as the device can hold at once, each looping over tiles t, t + G, ...), so every
+// tile a workgroup waits for belongs to a resident workgroup that only ever waits for EARLIER tiles.  Spins are bounded: a
+// tile that never shows up raises a sticky error word in pinned host memory (reported by the next fmk_ctx_sync / fmk_d2h)
+// instead of hanging the device.
+typedef __attribute__((address_space(1))) unsigned long long ew_gu64;
+#define EW_GRAN 12                       // 6 doubles = 12 words
+#define EW_SPIN_LIMIT (1u << 22)
+
+__device__ __forceinline__ void ew_publish(unsigned long long *g, const EwMap &m, int lane)
+{
+    if (lane < EW_GRAN) {
+        const double d = lane < 2 ? m.a : lane < 4 ? m.a2 : lane < 6 ? m.bV : lane < 8 ? m.bV2 : lane < 10 ? m.bSy : m.bSyy;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+        const unsigned word = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store((ew_gu64 *)(g + lane), (1ULL << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// one sweep over the twelve granules: true when all tags are set; m (wave-uniform) is then the published map
+__device__ __forceinline__ bool ew_sweep(unsigned long long *g, EwMap &m, int lane)
+{
+    unsigned long long x = 1ULL << 32;
+    if (lane < EW_GRAN) x = __hip_atomic_load((ew_gu64 *)(g + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__ballot((x >> 32) != 1ULL) != 0) return false;
+    const unsigned w = (unsigned)x;
+    double d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)w, 2 * k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)w, 2 * k + 1);
+        d[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    m.a = d[0]; m.a2 = d[1]; m.bV = d[2]; m.bV2 = d[3]; m.bSy = d[4]; m.bSyy = d[5];
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__restrict__ ts, const double *__restrict__ y,
+                                                           int64_t n, double half_life, double sigma_floor,
+                                                           const double *__restrict__ state_in, double *__restrict__ out,
+                                                           unsigned long long *gran /*[tiles][2][EW_GRAN]*/, int64_t tiles,
+                                                           int64_t *err_word)
+{
+    __shared__ EwMap lds[4];
+    __shared__ EwMap s_excl;
+    __shared__ int64_t s_ts[EW_LDS_ELEMS];
+    __shared__ double s_y[EW_LDS_ELEMS];
+    const int lane = fmk_lane();
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t base = tile * EW_TILE;
+        // ---- coalesced tile load through LDS (ew_load_tile with an explicit tile index)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EW_ITEMS; ++r) {
+            const int e = r * EW_THREADS + threadIdx.x;
+            const int64_t i = base + e;
+            const int slot = (e >> 3) * 9 + (e & 7);
+            s_ts[slot] = (ts && i < n) ? ts[i] : 0;
+            s_y[slot] = i < n ? y[i] : 0.0;
+        }
+        __syncthreads();
+        int64_t tl[EW_ITEMS];
+        double yl[EW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) {
+            tl[k] = s_ts[threadIdx.x * 9 + k];
+            yl[k] = s_y[threadIdx.x * 9 + k];
+        }
+        const int64_t i0 = base + (int64_t)threadIdx.x * EW_ITEMS;
+        int64_t tprev0 = 0;
+        if (threadIdx.x > 0) tprev0 = s_ts[(threadIdx.x - 1) * 9 + 7];
+        else if (ts && i0 >= 1 && i0 - 1 < n) tprev0 = ts[i0 - 1];
+        // ---- per-tick maps (the decay factor of every tick is kept for the apply phase: one exp per tick)
+        EwMap m = ew_identity();
+        double al[EW_ITEMS];                                           // alpha of every tick (MODE 2: the fixed 1 - alpha)
+        {
+            int64_t tprev = tprev0;
+#pragma unroll
+            for (int k = 0; k < EW_ITEMS; ++k) {
+                const int64_t i = i0 + k;
+                al[k] = 0.0;
+                if (i >= (MODE == 2 ? 0 : 1) && i < n) {
+                    EwMap t;
+                    if constexpr (MODE == 2) {
+                        t = ew_tick<MODE>(tprev, tl[k], yl[k], half_life);
+                        al[k] = half_life;
+                    } else {
+                        const double dt = (double)(tl[k] - tprev) / 1e9;
+                        al[k] = 1.0 - exp(-dt / half_life);            // volatility.py:178-179, evaluated ONCE per tick
+                        t = ew_tick_alpha<MODE>(al[k], yl[k]);
+                    }
+                    m = ew_compose(m, t);
+                    tprev = tl[k];
+                } else if (i == 0 && n > 0) {
+                    tprev = tl[k];
+                }
+            }
+        }
+        EwMap tot;
+        EwMap ex = ew_block_exclusive(m, lds, &tot);
+        // ---- publish the aggregate, look back, publish the inclusive prefix (wave 0)
+        unsigned long long *g_agg = gran + (size_t)tile * 2 * EW_GRAN, *g_pre = g_agg + EW_GRAN;
+        if (threadIdx.x < 64) {
+            EwMap excl = ew_identity();
+            if (tile > 0) {
+                ew_publish(g_agg, tot, lane);
+                unsigned spins = 0;
+                for (int64_t j = tile - 1; j >= 0;) {
+                    unsigned long long *pj = gran + (size_t)j * 2 * EW_GRAN;
+                    EwMap got;
+                    if (ew_sweep(pj + EW_GRAN, got, lane)) { excl = ew_compose(got, excl); break; }     // inclusive prefix of j
+                    if (ew_sweep(pj, got, lane)) { excl = ew_compose(got, excl); --j; spins = 0; continue; }   // its aggregate
+                    if (++spins > EW_SPIN_LIMIT) {                           // never: report, do not hang
+                        if (lane == 0) *err_word = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            ew_publish(g_pre, ew_compose(excl, tot), lane);
+            if (lane == 0) s_excl = excl;
+        }
+        __syncthreads();
+        ex = ew_compose(s_excl, ex);
+        // ---- apply: the reference's update in its own operation order, from the state entering my first tick
+        double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
+        if (state_in) {
+            V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
+            Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
+        }
+        double res[EW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) {
+            const int64_t i = i0 + k;
+            res[k] = NAN;                                              // volatility.py:174 (out[0])
+            if (i >= n) continue;
+            if (MODE != 2 && i == 0) continue;
+            const bool nan = isnan(yl[k]);
+            const double yy = yl[k];
+            if constexpr (MODE == 2) {
+                const double o = al[k], wgt = nan ? 0.0 : 1.0;
+                V = o * V + wgt;
+                V2 = (o * o) * V2 + wgt;
+                if (nan) { Sy = o * Sy; Syy = o * Syy; }
+                else { Sy = o * Sy + yy; Syy = o * Syy + yy * yy; }
+            } else {
+                const double alpha = al[k], o = 1.0 - alpha;           // the operations of ew_step, minus its exp
+                if constexpr (MODE == 1) {
+                    if (nan) { Syy = o * Syy; V = o * V; }
+                    else { Syy = alpha * (yy * yy) + o * Syy; V = alpha + o * V; }
+                } else {
+                    V = alpha + o * V;
+                    V2 = alpha * alpha + (o * o) * V2;
+                    if (nan) { Sy = o * Sy; Syy = o * Syy; }
+                    else { Sy = alpha * yy + o * Sy; Syy = alpha * yy * yy + o * Syy; }
+                }
+            }
+            res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
+        }
+        // ---- coalesced store through the (now free) LDS tile
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) s_y[threadIdx.x * 9 + k] = res[k];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EW_ITEMS; ++r) {
+            const int e = r * EW_THREADS + threadIdx.x;
+            const int64_t i = base + e;
+            if (i < n) out[i] = s_y[(e >> 3) * 9 + (e & 7)];
+        }
+    }
+}
+
 // composition of all tile maps in order (ONE block): the map of the whole series, x -> a*x + b per state
 __global__ __launch_bounds__(EW_THREADS) void k_ew_total(const EwMap *__restrict__ maps, int64_t m, double *out6)
 {
@@ -491,6 +679,26 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         if (g <= 1) break;
     }
     void *scr;
+    static int two_pass = -1;                        // developer knob: FMK_EW_TWO_PASS=1 keeps the two-pass scan (A/B timing)
+    if (two_pass < 0) { const char *v = getenv("FMK_EW_TWO_PASS"); two_pass = v ? atoi(v) : 0; }
+    if (!d_map_out && !two_pass) {
+        // one pass: persistent grid, decoupled look-back over {tag, word} granules (zeroed before every launch)
+        const size_t gbytes = (size_t)tiles * 2 * EW_GRAN * 8;
+        FMK_TRY(fmk_scratch(ctx, gbytes, &scr));
+        FMK_HIP(ctx, hipMemsetAsync(scr, 0, gbytes, ctx->stream));
+        static int per_cu = 0;
+        if (!per_cu) {
+            int nbk = 0;
+            FMK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)k_ew_onepass<MODE>, EW_THREADS, 0));
+            per_cu = nbk > 0 ? nbk : 1;
+        }
+        int64_t grid = (int64_t)ctx->n_cu * per_cu;  // every workgroup resident at once: the look-back cannot starve
+        if (grid > tiles) grid = tiles;
+        k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, d_state_in, d_out,
+                                                                          (unsigned long long *)scr, tiles, ctx->h_mail + 40);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
     FMK_TRY(fmk_scratch(ctx, (size_t)(tiles + work_maps + 2) * sizeof(EwMap), &scr));
     EwMap *tm = (EwMap *)scr;
     EwMap *work = tm + tiles;
