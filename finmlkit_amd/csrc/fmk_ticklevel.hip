@@ -679,9 +679,15 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         if (g <= 1) break;
     }
     void *scr;
-    static int two_pass = -1;                        // developer knob: FMK_EW_TWO_PASS=1 keeps the two-pass scan (A/B timing)
-    if (two_pass < 0) { const char *v = getenv("FMK_EW_TWO_PASS"); two_pass = v ? atoi(v) : 0; }
-    if (!d_map_out && !two_pass) {
+    // MEASURED (round 2, 1e9 ticks, profiles/r02_ewmst_one_pass_vs_two_pass.txt): the one-pass kernel is correct (same suite)
+    // but SLOWER than the two passes -- ewmst 25.9 vs 16.0 ms, ewms 21.8 vs 9.7 ms.  With the persistent grid every
+    // "generation" of ~1000 tiles publishes its aggregates at the same time, and a tile's look-back then walks back ~sqrt(2 k)
+    // tiles, each step a dependent cross-XCD round trip of ~1.2 us: ~54 us per generation, which is the whole run time
+    // (the frontier of finished prefixes moves at ~19 tiles/us, the two passes need the equivalent of 30).  And the two passes are not
+    // bound by their 40 B/tick anyway: exp, four float64 divisions and a sqrt per tick keep k_ew_apply at 2.3 TB/s.
+    // The two-pass scan therefore stays the default; FMK_EW_ONE_PASS=1 (read per call) selects this kernel.
+    const char *opv = getenv("FMK_EW_ONE_PASS");
+    if (!d_map_out && opv && atoi(opv)) {
         // one pass: persistent grid, decoupled look-back over {tag, word} granules (zeroed before every launch)
         const size_t gbytes = (size_t)tiles * 2 * EW_GRAN * 8;
         FMK_TRY(fmk_scratch(ctx, gbytes, &scr));

@@ -124,3 +124,22 @@ def test_realized_vol_errors_and_transform(orc):
     out = tr(df)
     assert out.name == "ret_rv30" and len(out) == n
     G.assert_f64_close(out.values, orc.realized_vol(r, 30, True), rtol=1e-12, what="rv transform")
+
+
+def test_ewmst_one_pass_kernel_matches_two_pass(monkeypatch):
+    """k_ew_onepass (persistent grid, decoupled look-back, one exp per tick; kept behind FMK_EW_ONE_PASS because it measured
+    slower than the two-pass scan): same per-tick operations, so the outputs agree to reassociation noise of the prefix maps;
+    the sticky error word stays clear (no workgroup gave up waiting)."""
+    from finmlkit_amd import _ffi, engine
+    ctx = _ffi.default_context()
+    n = 3_000_001
+    t = engine.DeviceTrades.synth(n, seed=7, ctx=ctx)
+    r = t.lagged_returns(2.0, True)
+    want = {(hl, m0): t.ewmst(r, hl, mean0=m0).to_host() for hl in (5.0, 600.0) for m0 in (False, True)}
+    want_s = t.ewms(r, 50).to_host()
+    monkeypatch.setenv("FMK_EW_ONE_PASS", "1")
+    for (hl, m0), w in want.items():
+        got = t.ewmst(r, hl, mean0=m0).to_host()
+        np.testing.assert_allclose(got, w, rtol=1e-11, atol=0, equal_nan=True)
+    np.testing.assert_allclose(t.ewms(r, 50).to_host(), want_s, rtol=1e-11, atol=0, equal_nan=True)
+    ctx.sync()
