@@ -26,15 +26,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes per tick / per bar of the dominant kernel from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), measured at N = 1e9,
-# B = 833323 on the default workload: profiles/r01_bench_cfg2_pmc_traffic.csv, pass 2 (1.20997e10 read + 6.8026e7
-# written).  Counters cannot be collected inside a normal run, so roofline.traffic is that OFFLINE measurement of the same
-# kernel scaled to the run's N/B (roofline.traffic_source says so); null for non-default workloads (not measured).
-PMC_READ_BYTES_PER_TICK = 1.20997e10 / 1e9
-PMC_WRITE_BYTES_PER_BAR = 6.8026e7 / 833323
-PMC_SOURCE = ("offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at commit 2d41fbb "
-              "(profiles/r01_bench_cfg2_pmc_traffic.csv), scaled to this run's ticks and bars; not collected in this run")
+# HBM bytes per tick / per bar of the dominant kernel: counters cannot be collected inside a normal run, so roofline.traffic is an
+# OFFLINE rocprofv3 --pmc measurement of the same kernel, scaled to the run's ticks and bars (roofline.traffic_source says so).
+# The constants live in the tracked file profiles/traffic_constants.json (written by tools/pmc_summarize.py from the two counter
+# passes of tools/pmc_calibrate.sh, with the commit it was measured at and the FETCH_SIZE / WRITE_SIZE corrections calibrated in
+# the SAME passes on known byte counts at 16, 8 and 4 bytes per lane: profiles/r02_pmc_calibration.txt); null for other workloads.
+def _traffic_constants():
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_constants.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -270,6 +274,8 @@ def main():
     alg_bytes = n * 12 + nb * (68 if want_median else 60) + (nb + 1) * 8
     achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
 
+    tc = _traffic_constants()
+    tc_ok = bool(tc) and want_median and args.interval == 60.0 and tc.get("write_bytes_per_bar") is not None
     if rank == 0:
         total_ticks = n * world
         line = {
@@ -296,9 +302,11 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (PMC_READ_BYTES_PER_TICK * n + PMC_WRITE_BYTES_PER_BAR * nb)
-                         if (want_median and args.interval == 60.0) else None,
-                         "traffic_source": PMC_SOURCE if (want_median and args.interval == 60.0) else None,
+                         "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) if tc_ok else None,
+                         "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at commit "
+                                            f"{tc['commit']} (profiles/traffic_constants.json: FETCH_SIZE x{tc['fetch_size_correction']}, "
+                                            f"WRITE_SIZE x{tc['write_size_correction']}, calibrated on known byte counts in the same passes), "
+                                            f"scaled to this run's ticks and bars; not collected in this run") if tc_ok else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
                          "launches_timed": len(k_ms)},
         }

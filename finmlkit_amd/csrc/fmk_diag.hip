@@ -24,6 +24,21 @@ __global__ __launch_bounds__(256) void k_diag_read(const uint4 *__restrict__ p, 
     if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);        // practically never: keeps the loads alive
 }
 
+// variant 2: 4 B per lane (dword, what the reducers issue per float32 amount); variant 3: 8 B per lane STORES (calibration of
+// WRITE_SIZE on a known byte count; the buffer is overwritten with its own indices)
+__global__ __launch_bounds__(256) void k_diag_read4(const unsigned *__restrict__ p, int64_t n4, unsigned long long *sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) acc ^= p[i];
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);
+}
+__global__ __launch_bounds__(256) void k_diag_write8(unsigned long long *__restrict__ p, int64_t n8)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) p[i] = (unsigned long long)i;
+}
+
 extern "C" int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
                                        double *elapsed_ms)
 {
@@ -33,7 +48,9 @@ extern "C" int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t b
     unsigned long long *sink = (unsigned long long *)(ctx->d_mail + 60);
     FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (variant == 0) k_diag_read<0><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
-    else k_diag_read<1><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
+    else if (variant == 1) k_diag_read<1><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
+    else if (variant == 2) k_diag_read4<<<blocks, 256, 0, ctx->stream>>>((const unsigned *)d_buf, n16 * 4, sink);
+    else k_diag_write8<<<blocks, 256, 0, ctx->stream>>>((unsigned long long *)d_buf, n16 * 2);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));

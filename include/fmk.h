@@ -362,7 +362,9 @@ int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *co
 
 /* ---- diagnostics ------------------------------------------------------------------------ */
 /* Read-only streaming bandwidth probe (tools/readbw.py): calibrates the HBM ceiling quoted in DESIGN.md.
- * variant 0: 16 B loads per lane, 1: 8 B loads per lane.  Not used by any product path. */
+ * variant 0: 16 B loads per lane, 1: 8 B loads per lane, 2: 4 B loads per lane, 3: 8 B STORES per lane (the buffer is
+ * overwritten) -- the last three calibrate FETCH_SIZE / WRITE_SIZE for the access widths the reducers use
+ * (tools/pmc_calibrate.py).  Not used by any product path. */
 int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
                             double *elapsed_ms);
 /* Two columns read in lock-step (tools/placement.py): 8 B elements of d_a8 and 4 B elements of d_b4 at the same index.
