@@ -85,11 +85,34 @@ def cpu_baseline(args):
                       f"{cores} threads): {dtn:.2f} s; 1 thread: {dt1:.2f} s = {m / dt1:.3g} ticks/s"}
 
 
+def _time_resample(ctx, timed, clock1, o1, nb1):
+    """fmk_resample_bars_dev on resident 1-second bars (segments = floor(ts / 60 s) computed on the host from the clock)."""
+    import ctypes as C
+    import numpy as np
+    from finmlkit_amd._ffi import DeviceArray, c_i64
+    ts = clock1.to_host()[1:nb1 + 1]
+    key = ts // 60_000_000_000
+    seg = np.concatenate([[0], np.flatnonzero(np.diff(key)) + 1, [nb1]]).astype(np.int64)
+    G = len(seg) - 1
+    d_seg = DeviceArray.from_host(ctx, seg)
+    outs = [DeviceArray(ctx, G, dt) for dt in (np.float64, np.float64, np.float64, np.float64, np.float32, np.int64,
+                                               np.float32, np.float32, np.uint8)]
+    def run():
+        ctx.call("fmk_resample_bars_dev", d_seg.p, c_i64(G), o1["open"].p, o1["high"].p, o1["low"].p, o1["close"].p,
+                 o1["volume"].p, C.c_int(0), o1["trades"].p, o1["vwap"].p, C.c_int(1), o1["median_trade_size"].p,
+                 *[x.p for x in outs])
+        return None
+    return timed(run)
+
+
 def other_configs(trades, ctx, args):
     """Informational, AFTER the timed region and outside `value`: one pass each of BASELINE.json configs[2] (volume +
     dollar bar indices, data-derived thresholds) and configs[3] (time bars + order-flow + footprints) on the same
     resident columns, host wall time incl. the size/fill phases.  Never raises: a failure is reported as a string."""
+    import ctypes as C
     import numpy as np
+    from finmlkit_amd import engine
+    from finmlkit_amd._ffi import DeviceArray, c_i64
     out = {}
 
     def timed(fn, reps=3):
@@ -139,6 +162,20 @@ def other_configs(trades, ctx, args):
         del exact_idx
         out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
         out["cfg4_bytes_per_tick"] = 38
+        # the same pass on amounts with a full random float32 mantissa: the footprint level sums are then inexact in every
+        # order and every bar takes the tick-ordered accumulation (the synthetic stream's dyadic amounts all certify for the
+        # order-free integer path) -- real trade sizes are like that, so this is the number to expect on real data
+        am2 = DeviceArray(ctx, n, np.float32)
+        ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(args.seed), c_i64(n), am2.p)
+        t2 = engine.DeviceTrades(ctx, trades.ts, trades.price, am2, trades.side)
+        out["cfg4_full_mantissa_amounts_ms"] = timed(lambda: t2.bars_fused(ci, 0.01, 3.0))
+        del t2, am2
+        # TimeBarReader._resample: 1-second bars of the same stream (built here, not timed) -> 1-minute bars
+        clock1, ci1 = trades.time_bar_index(1.0)
+        o1 = trades.bar_ohlcv(ci1)
+        nb1 = ci1.n - 1
+        out["resample_1s_to_1min_ms"], out["resample_n_rows"] = _time_resample(ctx, timed, clock1, o1, nb1), nb1
+        del o1, clock1, ci1
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only

@@ -153,3 +153,26 @@ extern "C" int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, 
     return FMK_OK;
 }
 
+
+
+// Amounts with a full random 24-bit mantissa in [2^-7, 2): float32 sums of them are inexact in every order, like real trade
+// sizes (the synthetic stream's dyadic amounts make every footprint bar take the certified integer path).  bench.py times
+// cfg 4 on both.  Not used by any product path.
+__global__ __launch_bounds__(256) void k_diag_fill_amounts(uint64_t seed, int64_t n, float *__restrict__ amount)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = fmk_mix64(seed ^ (0xA5A5A5A5ULL + (uint64_t)i));
+        const uint32_t bits = (uint32_t)(h & 0x7FFFFFu) | ((120u + (uint32_t)((h >> 23) & 7u)) << 23);
+        amount[i] = __uint_as_float(bits);
+    }
+}
+
+extern "C" int fmk_diag_fill_amounts_dev(fmk_ctx *ctx, uint64_t seed, int64_t n, float *d_amount)
+{
+    if (n <= 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    k_diag_fill_amounts<<<(unsigned)(ctx->n_cu * 16), 256, 0, ctx->stream>>>(seed, n, d_amount);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
