@@ -93,6 +93,7 @@ POLICY = {
     "ewmst": ("rtol", 1e-9), "ewmst_mean0": ("rtol", 1e-9),
     "realized_vol": ("rtol", 1e-9),
     "volume_profile_rolling": "exact",
+    "resample_bars": "exact",                  # pandas' Kahan sums row by row: nothing is reassociated
     # float64 accumulator / quotient of the Numba-typed function vs the recorded pure-Python float32 one (same split as
     # VolumePro.compute's fourth output below): within 2 ulp(float32)
     "calc_volume_percentage_above_poc": ("rtol", 2.4e-7),

@@ -51,8 +51,19 @@ def tape(rng, n):
 def bars(rng, n):
     """bar_close_indices over n ticks: strictly valid for the reference (ascending, within range), with repeats (empty
     bars), sometimes a -1 open edge, bar lengths from one tick to everything"""
-    mode = rng.integers(0, 5)
+    mode = rng.integers(0, 6)
     first = -1 if rng.random() < 0.5 else int(rng.integers(0, max(1, min(n, 3))))
+    if mode == 5:
+        # many SHORT bars of random length (mean 2..45, some empty, a few around / beyond the 64 lanes of a wave): the
+        # one-lane-per-bar schedule of comp_bar_ohlcv (k_bar_ohlcv_lanes: >= 64 bars, mean <= 48 ticks per bar)
+        mean = float(rng.choice([2, 5, 12, 20, 31, 33, 45]))
+        lens = rng.geometric(1.0 / mean, size=max(2, int(n / mean) + 2))
+        lens[rng.random(len(lens)) < 0.1] = 0
+        lens[rng.random(len(lens)) < 0.02] = int(rng.choice([63, 64, 65, 130]))
+        ci = first + np.concatenate([[0], np.cumsum(lens)])
+        ci = ci[ci <= n - 1].astype(np.int64)
+        if len(ci) >= 2:
+            return ci
     if mode == 0:
         L = int(rng.choice(EDGES))
         ci = np.arange(first, n, max(L, 1), dtype=np.int64)
@@ -103,7 +114,7 @@ def one_case(rng, orc, pkg, log, hi=20000):
     n = size(rng, hi)
     ts, px, am, sd = tape(rng, n)
     ci = bars(rng, n)
-    which = int(rng.integers(0, 17))
+    which = int(rng.integers(0, 18))
     name = None
     try:
         if which == 0:
@@ -210,6 +221,36 @@ def one_case(rng, orc, pkg, log, hi=20000):
                                                                         flat["buy_volumes"], flat["sell_volumes"], win, nb, tick)),
                  lambda: tuple(orc.volume_profile_rolling(clock[1:], o[1], o[2], off, flat["price_levels"], flat["buy_volumes"],
                                                           flat["sell_volumes"], win, nb, tick)), name)
+        elif which == 13:
+            # TimeBarReader._resample: bars of a random fine interval (the oracle's own OHLCV) -> a coarser timeframe
+            import pandas as pd
+            iv = float(rng.choice([1.0, 2.0, 7.0, 60.0]))
+            clock, tci = orc._time_bar_indexer(ts, iv)
+            if len(tci) < 2 or len(tci) > 200000:
+                return None
+            a_in = am if rng.random() < 0.7 else am.astype(np.float32)
+            o = orc.comp_bar_ohlcv(px, a_in, tci)
+            df = pd.DataFrame(dict(zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], o)),
+                              index=pd.DatetimeIndex(clock[1:].astype("datetime64[ns]")))
+            if rng.random() < 0.3:
+                df["volume"] = df["volume"].astype(np.float64)
+            if rng.random() < 0.3:
+                df.loc[df.index[rng.random(len(df)) < 0.1], ["open", "high", "vwap", "median_trade_size"]] = np.nan
+            tf = str(rng.choice(["3s", "1min", "5min", "1h", "1D"]))
+            cols = ["open", "high", "low", "close", "volume", "trades", "vwap", "median_trade_size"]
+            name = f"resample n={n} rows={len(df)} {iv}s -> {tf} volume={df['volume'].dtype}"
+
+            def want():
+                codes, uniq = pd.factorize(df.index.floor(tf), sort=False)
+                seg = np.concatenate([[0], np.flatnonzero(np.diff(codes)) + 1, [len(df)]]).astype(np.int64)
+                r = orc.resample_bars(seg, *[df[c].values for c in cols])
+                keep = r[8].astype(bool)
+                return tuple(x[keep] for x in r[:8]) + (uniq.values.astype("datetime64[ns]").astype(np.int64)[keep],)
+
+            def got():
+                g = pkg["io"].resample_bars(df, tf)
+                return tuple(g[c].values for c in cols) + (g.index.values.astype("datetime64[ns]").astype(np.int64),)
+            both("resample_bars", got, want, name)
         elif which == 16:
             L = int(rng.integers(1, 300))
             lv = (int(rng.integers(-50, 50)) + np.arange(L)).astype(np.int32)
@@ -239,10 +280,10 @@ def one_case(rng, orc, pkg, log, hi=20000):
 
 
 def campaign(iterations, seed, orc, verbose=True, hi=20000):
-    from finmlkit_amd.bar import base, logic, utils
+    from finmlkit_amd.bar import base, io, logic, utils
     from finmlkit_amd.feature.core import utils as futils
     from finmlkit_amd.feature.core import volatility, volume
-    pkg = {"base": base, "logic": logic, "utils": utils, "futils": futils, "vol": volatility, "volume": volume}
+    pkg = {"base": base, "logic": logic, "utils": utils, "futils": futils, "vol": volatility, "volume": volume, "io": io}
     fails = []
     for it in range(iterations):
         rng = np.random.default_rng([seed, it])
