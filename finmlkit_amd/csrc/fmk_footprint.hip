@@ -183,6 +183,156 @@ __device__ __forceinline__ FpStats fp_accumulate(const double *__restrict__ pric
     return st;
 }
 
+// Same sweep, straight-line (LDS histograms only; round 2).  The loop above costs 161 VALU + 130 SALU instructions per 64
+// ticks (profiles/r01_flow_sq_counters.txt), most of it branches around `pending`, 64-bit index compares and, on the
+// tick-ordered path, the ballot loop that groups the lanes by key (one iteration per distinct key: ~20 per chunk).
+//   * no per-tick branch: one predicate per lane, the rare half-integer guard of the level rounding is a wave-uniform branch;
+//   * EXACT: amount -> units with v_ldexp / v_cvt and ONE compare for "whole, non-negative, below 2^31";
+//   * tick order WITHOUT grouping: a same-address LDS atomic with return hands out its old values in ascending lane order
+//     (checked on the device before first use, fp_lds_atomics_in_lane_order; tools/ldsorder_probe.hip), so
+//         rank = atomicAdd(&cnt[key], 1) - (cnt[key] before the chunk)
+//     is the tick order of the lane inside its (level, side) group, and round t lets the lanes of rank t do a plain
+//     read - add - write on vol[key]: distinct keys in a round, float32 adds of one key strictly in tick order.
+template <bool AF64, bool EXACT>
+__device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__ price, const void *__restrict__ amount,
+                                                      const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low,
+                                                      int L, double tick, double inv_tick, int lane, float *vol, int *cnt,
+                                                      int q)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    unsigned *units = (unsigned *)vol;
+    int lbmin = FP_Q_UNKNOWN;
+    double atot = 0.0;
+    bool bad = false, units_ok = true;
+    const int ilow = (int)low;
+    const double *pp = price + (s + 1);
+    const AmtT *ap = (const AmtT *)amount + (s + 1);
+    const int8_t *sp = side + (s + 1);
+    const int total = (int)(e - s);                                   // ticks of the bar (<= 2^31: one wave per bar)
+    double p_n = 0.0;
+    AmtT a_n = 0;
+    int sd_n = 0;
+    if (lane < total) { p_n = pp[lane]; a_n = ap[lane]; sd_n = sp[lane]; }
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        const int j = j0 + lane;
+        const double p = p_n;
+        const AmtT a = a_n;
+        const int sd = sd_n;
+        if (j + 64 < total) { p_n = pp[j + 64]; a_n = ap[j + 64]; sd_n = sp[j + 64]; }
+        const bool in_bar = j < total;
+        // level = int(round(price / tick)) - low (base.py:700-707): one multiply; the exact division decides the (rare) products
+        // within 1e-15 of a half-integer -- as a wave-uniform branch
+        const double qq = p * inv_tick;
+        double r = rint(qq);
+        if (__ballot(in_bar && 0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) != 0) {
+            if (0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) r = rint(p / tick);
+        }
+        const int lvl = (int)r - ilow;
+        const bool inside = (unsigned)lvl < (unsigned)L;
+        bad |= in_bar && !inside;                                     // base.py:719
+        const bool pending = in_bar && inside && (sd == 1 || sd == -1);
+        const int key = pending ? lvl * 2 + (sd < 0 ? 1 : 0) : 0;
+        if constexpr (EXACT) {
+            unsigned ui;
+            bool ok;
+            double ud;
+            if constexpr (AF64) {
+                ud = ldexp((double)a, -q);
+                ok = ud >= 0.0 && ud < 2147483648.0 && ud == rint(ud);
+                ui = ok ? (unsigned)ud : 0u;
+            } else {
+                const float u = ldexpf(a, -q);                        // exact scaling
+                ui = (unsigned)u;                                     // saturating convert, NaN -> 0
+                ok = (float)ui == u && u < 2147483648.f;              // whole, non-negative, below 2^31
+                ud = (double)u;
+            }
+            units_ok &= ok || !pending;
+            if (pending && ok) {
+                atomicAdd(&units[key], ui);
+                atomicAdd(&cnt[key], 1);
+                atot += ud;                                           // units (fp_certified_units)
+            }
+        } else {
+            if (pending) {                                            // statistics that pick the quantum of later bars
+                const int lb = fp_lowbit_exp(a);
+                lbmin = lb < lbmin ? lb : lbmin;
+                atot += fabs((double)a);
+            }
+            const int before = pending ? cnt[key] : 0;
+            __builtin_amdgcn_wave_barrier();
+            const int rank = pending ? atomicAdd(&cnt[key], 1) - before : -1;     // old values come in lane (= tick) order
+            const int rounds = fmk_dpp_reduce(rank, -1, FmkOpMax()) + 1;
+            for (int t = 0; t < rounds; ++t) {
+                if (rank == t) {
+                    const float v = vol[key];
+                    if constexpr (AF64) vol[key] = (float)((double)v + a);       // f32 element += f64 amount
+                    else vol[key] = v + a;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    FpStats st;
+    st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
+    st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    st.units_ok = __ballot(!units_ok) == 0;
+    st.bad = __ballot(bad) != 0;
+    __builtin_amdgcn_wave_barrier();
+    return st;
+}
+
+// Are same-address LDS atomics with return applied in ascending lane order?  (They are on gfx950; the tick-ordered sweep above
+// relies on it, so the device is ASKED once per process -- 7 access patterns x 64 repetitions x 64 waves -- and the ballot-loop
+// sweep stays the fallback.)
+__global__ __launch_bounds__(64) void k_fp_lds_order_probe(int *out_bad)
+{
+    __shared__ int slot[64];
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int pattern = 0; pattern < 7; ++pattern)
+        for (int rep = 0; rep < 64; ++rep) {
+            slot[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            int key;
+            switch (pattern) {
+            case 0: key = 0; break;
+            case 1: key = lane & 3; break;
+            case 2: key = lane >> 4; break;
+            case 3: key = (lane * 7 + rep + (int)blockIdx.x) % 5; break;
+            case 4: key = (lane ^ rep) & 7; break;
+            default: key = (int)(((unsigned)lane * 2654435761u) >> 27) % (1 + (rep + (int)blockIdx.x) % 9); break;
+            }
+            const bool act = pattern < 6 ? true : ((lane * 13 + rep) % 3 != 0);
+            int old = -1;
+            if (act) old = atomicAdd(&slot[key], 1);
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t am = __ballot(act);
+            int expect = 0;
+            for (int l = 0; l < 64; ++l) {
+                const int kl = __shfl(key, l, 64);
+                if (l < lane && ((am >> l) & 1) && kl == key) ++expect;
+            }
+            bad += act && old != expect;
+        }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicAdd(out_bad, 1);
+}
+
+static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
+{
+    static int known = -1;
+    if (known >= 0) return known;
+    const char *v = getenv("FMK_FP_BALLOT_GROUPS");                   // developer knob: 1 = use the ballot-loop sweep
+    if (v && atoi(v)) { known = 0; return known; }
+    int *d = (int *)(ctx->d_mail + 30);
+    if (hipMemsetAsync(d, 0, 4, ctx->stream) != hipSuccess) return 0;
+    k_fp_lds_order_probe<<<64, 64, 0, ctx->stream>>>(d);
+    int bad = 1;
+    if (hipMemcpyAsync(&bad, d, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+    known = bad == 0 ? 1 : 0;
+    return known;
+}
+
 // ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
@@ -194,7 +344,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const double *__restrict__ lows, double imb_mult,
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
                                                         FpOut o, unsigned long long *n_bad, int force_ordered,
-                                                        unsigned char *gscratch)
+                                                        unsigned char *gscratch, int lean)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
@@ -228,7 +378,11 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         FpStats st;
         bool done = false;
         if (!force_ordered && wq != FP_Q_UNKNOWN) {
-            st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
+            bool did = false;
+            if constexpr (!GLOBAL) {
+                if (lean) { st = fp_accumulate_lean<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq); did = true; }
+            }
+            if (!did) st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
             done = fp_certified_units(st);
             if (done) {       // units -> float32 (exact)
                 unsigned *units = (unsigned *)vol;
@@ -242,7 +396,11 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             }
         }
         if (!done) {
-            st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
+            bool did = false;
+            if constexpr (!GLOBAL) {
+                if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0); did = true; }
+            }
+            if (!did) st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
             // remember a usable quantum for the next bar (if this bar would have certified)
             FpStats probe = st;
             probe.units_ok = true;
@@ -284,11 +442,12 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if (gscratch)
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
-                                                                                   gscratch);
+                                                                                   gscratch, 0);
     else
         k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
-                                                                                       force_ordered, nullptr);
+                                                                                       force_ordered, nullptr,
+                                                                                       fp_lds_atomics_in_lane_order(ctx));
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
