@@ -21,6 +21,7 @@
 // reference's bit for bit.
 #include "fmk_footprint.h"
 #include "fmk_f32tie.h"
+#include "fmk_median.h"
 
 struct FlowDirOut {
     int64_t *ticks_buy, *ticks_sell;
@@ -330,6 +331,148 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// cfg 4, first half (round 2): comp_bar_ohlcv (+ median) INSIDE the directional kernel -- float32 amounts.
+// The tile loader already holds 8 strided ticks per lane in registers before it transposes them into LDS: max / min /
+// sum(vol) / sum(price*vol) over those registers cost ~5 VALU instructions per 64 ticks (every instruction covers 64 ticks),
+// and their bit patterns are the median's keys: up to three 512-tick tiles (1536 ticks) stay in 24 registers per lane and
+// feed the exact order-statistic search of fmk_median.h when the bar ends.  One read of price / amount / side (13 B/tick)
+// then serves build_ohlcv AND build_directional_features: cfg 4 reads 26 B/tick instead of 38, and the 2.2 ms OHLCV kernel
+// shrinks to ~0.8 ms of extra work here.  Bars longer than 1536 ticks get their median from k_bar_median (flag `saw_long`).
+// ---------------------------------------------------------------------------------------
+struct FlowOhlcvOut {
+    double *open, *high, *low, *close;
+    float *vol;
+    double *vwap;
+    int64_t *trades;
+    double *median;
+};
+#define BF_MED_TILES 3
+
+template <bool MEDIAN>
+__global__ __launch_bounds__(256) void k_bar_ohlcv_dir(const double *__restrict__ price, const float *__restrict__ amount,
+                                                       const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                       int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
+                                                       unsigned long long *redo, FlowOhlcvOut oo, int *saw_long)
+{
+    typedef MedKey<false> MK;
+    __shared__ double s_p[4][BF_SLOTS];
+    __shared__ float s_a[4][BF_SLOTS];
+    __shared__ int8_t s_s[4][640];
+    __shared__ uint32_t s_buf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    double *sP = s_p[wib];
+    float *sA = s_a[wib];
+    int8_t *sS = s_s[wib];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t start = s + 1;
+        FlowDir d;
+        bf_dir_init(d);
+        if (e > s) {
+            d.prev_price = price[fmk_wrap(start - 1, n)];
+            d.prev_side = e - s > 1 ? (int)side[fmk_wrap(start - 1, n)] : 0;    // base.py:485-488
+        }
+        double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+        MedBar<false, BF_MED_TILES * 8, false> bar;
+        if constexpr (MEDIAN) {
+#pragma unroll
+            for (int k = 0; k < BF_MED_TILES * 8; ++k) bar.key[k] = MK::MAXK;
+        }
+        int64_t j0 = start, rem = e - s;
+        // one tile: coalesced loads -> OHLCV partials (+ keys) from the registers -> transposed LDS tile -> directional walk
+        auto tile = [&](auto ti_c) {
+            constexpr int TI = decltype(ti_c)::value;                 // < BF_MED_TILES: the tile's keys are kept
+            int lr, tn;
+            bf_shape(rem, lr, tn);
+            const double *pb = price + j0;
+            const float *ab = amount + j0;
+            const int8_t *sb = side + j0;
+            double pr[8];
+            float ar[8];
+            int sr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pr[c] = 0.0; ar[c] = 0.f; sr[c] = 0;
+                const int t = c * 64 + lane;
+                if (c < (1 << lr) && t < tn) { pr[c] = pb[t]; ar[c] = ab[t]; sr[c] = sb[t]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bool valid = c < (1 << lr) && c * 64 + lane < tn;
+                const double a = (double)ar[c];
+                hi = valid ? fmax(hi, pr[c]) : hi;                    // NaN prices lose (base.py:380-383)
+                lo = valid ? fmin(lo, pr[c]) : lo;
+                tv += valid ? a : 0.0;
+                td += valid ? pr[c] * a : 0.0;
+                if constexpr (MEDIAN && TI < BF_MED_TILES) {
+                    if (valid) bar.key[TI * 8 + c] = MK::tokey(__float_as_uint(ar[c]));
+                }
+            }
+            const int slot0 = bf_slot(lane, lr);
+            const int cstride = (64 >> lr) * ((1 << lr) + 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < (1 << lr)) {
+                    const int sl = slot0 + c * cstride;
+                    sP[sl] = pr[c]; sA[sl] = ar[c]; sS[sl] = (int8_t)sr[c];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf_dir_tile<float>(lane, lr, tn, sP, sA, sS, d);
+            __builtin_amdgcn_wave_barrier();
+            j0 += tn;
+            rem -= tn;
+        };
+        if (rem > 0) tile(std::integral_constant<int, 0>{});
+        if (rem > 0) tile(std::integral_constant<int, 1>{});
+        if (rem > 0) tile(std::integral_constant<int, 2>{});
+        while (rem > 0) tile(std::integral_constant<int, BF_MED_TILES>{});
+        bf_dir_emit<float>(o, b, lane, d, n_zero_div, start, e, redo);
+        // ---- comp_bar_ohlcv (base.py:306-407)
+        const int64_t cnt = e - s;
+        if (cnt <= 0) {                                               // empty bar: previous close (base.py:352-361)
+            if (lane == 0) {
+                const double pz = price[fmk_wrap(e, n)];
+                oo.open[b] = pz; oo.high[b] = pz; oo.low[b] = pz; oo.close[b] = pz;
+                oo.vol[b] = 0.f; oo.vwap[b] = 0.0; oo.trades[b] = 0;
+                if (oo.median) oo.median[b] = 0.0;
+            }
+            continue;
+        }
+        hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+        lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
+        tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
+        td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+        if (lane == 0) {
+            const double first = price[start];
+            oo.open[b] = first;
+            oo.close[b] = price[e];
+            oo.high[b] = first != first ? first : hi;                 // a NaN first price never loses (base.py:371-382)
+            oo.low[b] = first != first ? first : lo;
+            oo.vol[b] = (float)tv;                                    // float32 amounts: exact in any order
+            oo.vwap[b] = tv > 0.0 ? td / tv : 0.0;                    // base.py:398
+            oo.trades[b] = cnt;
+        }
+        if constexpr (MEDIAN) {
+            if (cnt <= (int64_t)BF_MED_TILES * 512) {
+                bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+                const double m = med_search<false, BF_MED_TILES * 8, false>(bar, s_buf[wib]);
+                if (lane == 0) oo.median[b] = m;
+            } else if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // k_bar_median takes it
+            }
+        }
+    }
+}
+
+int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
+                      int64_t min_cnt, const int *d_go, double *d_median);
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
@@ -375,6 +518,58 @@ extern "C" int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, cons
                                    d_close, d_volume, d_vwap, d_trades, d_median));
     return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets,
                                             total_levels, max_levels);
+}
+
+// cfg 4 in two passes over the ticks (26 B/tick): this call = OHLCV (+ median) + order-flow features from ONE read, then the
+// CSR level counts; fmk_comp_bar_footprints_fill_dev is the second pass.  float64 amounts take the separate kernels.
+extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
+                                      const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                                      double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                                      double *d_vwap, int64_t *d_trades, double *d_median, const fmk_directional_out *d_dir,
+                                      int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
+                                      int64_t *max_levels)
+{
+    if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (n <= 0 || !d_side || !d_dir) return fmk_set_error(ctx, FMK_E_ARG, "bars_flow: bad arguments");
+    if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
+    static int separate = -1;              // developer knob: FMK_FLOW_SEPARATE=1 keeps the OHLCV kernel apart (A/B timing)
+    if (separate < 0) { const char *v = getenv("FMK_FLOW_SEPARATE"); separate = v ? atoi(v) : 0; }
+    if (amount_is_f64 || separate) {
+        FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
+                                       d_close, d_volume, d_vwap, d_trades, d_median));
+        FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
+                                             d_n_zero_div));
+    } else {
+        FMK_HIP(ctx, hipSetDevice(ctx->device));
+        const int64_t nb = n_idx - 1;
+        FlowDirOut o;
+        memcpy(&o, d_dir, sizeof(o));
+        FlowOhlcvOut oo{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median};
+        int64_t blocks = fmk_ceil_div(nb, 4);
+        const int64_t cap = (int64_t)ctx->n_cu * 64;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        unsigned long long *redo;
+        FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 8, (void **)&redo));
+        FMK_HIP(ctx, hipMemsetAsync(redo, 0, 8, ctx->stream));
+        int *saw_long = (int *)(ctx->d_mail + 16);
+        FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+        if (d_median)
+            k_bar_ohlcv_dir<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side, d_close_idx,
+                                                                           nb, n, o, (unsigned long long *)d_n_zero_div, redo, oo,
+                                                                           saw_long);
+        else
+            k_bar_ohlcv_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side, d_close_idx,
+                                                                            nb, n, o, (unsigned long long *)d_n_zero_div, redo, oo,
+                                                                            saw_long);
+        FMK_LAUNCH_CHECK(ctx);
+        const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
+        k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+        FMK_LAUNCH_CHECK(ctx);
+        if (d_median) FMK_TRY(fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, (int64_t)BF_MED_TILES * 512, saw_long, d_median));
+    }
+    return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
+                                            max_levels);
 }
 
 extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,

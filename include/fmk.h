@@ -234,6 +234,15 @@ int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_a
                             const double *d_bar_lows, double imbalance_factor, const int64_t *d_level_offsets,
                             int64_t max_levels, const fmk_footprint_out *d_fp, int64_t *d_n_bad_level);
 
+/* cfg 4 in TWO passes over the ticks (round 2; 26 B/tick): build_ohlcv + build_directional_features semantics from one read of
+ * price / amount / side (float32 amounts: one kernel; float64 amounts: the two kernels back to back), then the CSR level
+ * counts.  The second pass is fmk_comp_bar_footprints_fill_dev with the offsets and lows produced here. */
+int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
+                           const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                           double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume, double *d_vwap,
+                           int64_t *d_trades, double *d_median /* may be NULL */, const fmk_directional_out *d_dir,
+                           int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels, int64_t *max_levels);
+
 /* ---- tick-level feature loops: finmlkit/feature/core ---------------------------------- */
 /* comp_lagged_returns (core/utils.py:12-64). */
 int fmk_comp_lagged_returns_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_close,
