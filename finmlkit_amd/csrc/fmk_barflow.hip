@@ -336,8 +336,11 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
 // sum(vol) / sum(price*vol) over those registers cost ~5 VALU instructions per 64 ticks (every instruction covers 64 ticks),
 // and their bit patterns are the median's keys: up to three 512-tick tiles (1536 ticks) stay in 24 registers per lane and
 // feed the exact order-statistic search of fmk_median.h when the bar ends.  One read of price / amount / side (13 B/tick)
-// then serves build_ohlcv AND build_directional_features: cfg 4 reads 26 B/tick instead of 38, and the 2.2 ms OHLCV kernel
-// shrinks to ~0.8 ms of extra work here.  Bars longer than 1536 ticks get their median from k_bar_median (flag `saw_long`).
+// then serves build_ohlcv AND build_directional_features: cfg 4 reads 26 B/tick instead of 38.  MEASURED at 1e9 ticks
+// (tools/cfg4bench.py, profiles/r02_cfg4.txt): this kernel 5.7 ms at its natural 153 VGPRs (3 waves per SIMD), 5.3 ms held to
+// 128 (launch bounds, 68 B of scratch) -- against 2.31 + 2.95 ms for k_bar_ohlcv_small + k_bar_dir back to back: the SAME
+// time, a third fewer bytes.  The directional walk is VALU-bound, so a shared read buys bytes, not milliseconds.
+// Bars longer than 1536 ticks get their median from k_bar_median (flag `saw_long`).
 // ---------------------------------------------------------------------------------------
 struct FlowOhlcvOut {
     double *open, *high, *low, *close;
@@ -349,7 +352,7 @@ struct FlowOhlcvOut {
 #define BF_MED_TILES 3
 
 template <bool MEDIAN>
-__global__ __launch_bounds__(256) void k_bar_ohlcv_dir(const double *__restrict__ price, const float *__restrict__ amount,
+__global__ __launch_bounds__(256, 4) void k_bar_ohlcv_dir(const double *__restrict__ price, const float *__restrict__ amount,
                                                        const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                        int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
                                                        unsigned long long *redo, FlowOhlcvOut oo, int *saw_long)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""cfg 4 (bars_fused: OHLCV + order-flow + footprints) at N ticks, dyadic and full-mantissa amounts, host wall time best of 5.
+usage: cfg4bench.py [N]     (FMK_FLOW_SEPARATE=1: OHLCV kernel apart from the directional one)"""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from finmlkit_amd import _ffi, engine
+from finmlkit_amd._ffi import DeviceArray, c_i64
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
+ctx = _ffi.default_context()
+t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
+clock, ci = t.time_bar_index(60.0)
+am2 = DeviceArray(ctx, n, np.float32)
+ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(42), c_i64(n), am2.p)
+t2 = engine.DeviceTrades(ctx, t.ts, t.price, am2, t.side)
+for name, tr in (("dyadic amounts", t), ("full-mantissa amounts", t2)):
+    best = 1e9
+    for _ in range(5):
+        ctx.sync(); t0 = time.perf_counter(); r = tr.bars_fused(ci, 0.01, 3.0); ctx.sync()
+        best = min(best, (time.perf_counter() - t0) * 1e3); del r
+    print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms (separate={os.environ.get('FMK_FLOW_SEPARATE', '0')})", flush=True)
