@@ -37,6 +37,7 @@
 // the waves per CU: 256 -> 12 waves, 14.6 ms per 1e9 ticks at 865-tick bars; 512 -> 24 waves, 11.8 ms; 1024 -> 32 waves
 // (two workgroups: the wave limit) but 19.6 ms -- barriers across 16 waves, and a thread's monotone walk covers 2 ticks
 #define VOL_THREADS 512
+#define VOL_RADIX 16                    // blocks composed per table level (LDS tier)
 
 int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
                          double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
@@ -140,13 +141,37 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     double loc[PER];
     double run = 0.0;
     bool bad = false, inexact = false;
+    {
+        // the thread's PER consecutive amounts: ONE 16-byte load per four float32 (two float64) when the whole group lies inside
+        // the stream (block starts are multiples of S, so the group is 16-byte aligned whenever the column is) -- eight scalar
+        // loads with a 32-byte lane stride made every instruction touch 16 lines
+        const int64_t jb = bs + (int64_t)tid * PER;
+        double vv[PER];
+        const bool al16 = ((uintptr_t)amount & 15) == 0;
+        if (jb + PER <= n && al16) {
+            if constexpr (AF64) {
+                const double2 *q = (const double2 *)((const double *)amount + jb);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int64_t j = bs + (int64_t)tid * PER + k;
-        double v = 0.0;
-        if (j < n) { v = fmk_amt<AF64>(amount, j); bad |= !(v >= 0.0); inexact |= vol_amount_inexact(v); }
-        run += v;
-        loc[k] = run;
+                for (int k = 0; k < PER / 2; ++k) { const double2 t2 = q[k]; vv[2 * k] = t2.x; vv[2 * k + 1] = t2.y; }
+            } else {
+                const float4 *q = (const float4 *)((const float *)amount + jb);
+#pragma unroll
+                for (int k = 0; k < PER / 4; ++k) {
+                    const float4 t4 = q[k];
+                    vv[4 * k] = (double)t4.x; vv[4 * k + 1] = (double)t4.y; vv[4 * k + 2] = (double)t4.z; vv[4 * k + 3] = (double)t4.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) vv[k] = jb + k < n ? fmk_amt<AF64>(amount, jb + k) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const double v = vv[k];
+            if (jb + k < n) { bad |= !(v >= 0.0); inexact |= vol_amount_inexact(v); }
+            run += v;
+            loc[k] = run;
+        }
     }
     double inc = fmk_wave_iscan(run);
     if (lane == 63) wtot[w] = inc;
@@ -381,6 +406,64 @@ __global__ __launch_bounds__(256) void k_vol_descend(int ls, const uint32_t *__r
     }
 }
 
+// Radix-4 flavours (round 2): level q+1 composes FOUR blocks of level q.  Composing two at a time writes and re-reads a
+// table of N / 2^k entries at every one of the ~20 levels (8 B read + 8 B gathered + 8 B written per entry: 24 GB per 1e9
+// ticks, 4.2 of the indexer's 12.1 ms); four at a time writes N / 4^q entries with three dependent gathers each:
+// 13 GB, half the launches, and a third fewer tables to keep.  Measured at 1e9 ticks (cfg-3 threshold): radix 2 / 4 / 8 / 16 / 32 ->
+// 11.6 / 9.5 / 8.9 / 8.7 / 8.6 ms for the whole indexer; VOL_RADIX = 16 (the kernels take the radix as an argument).
+__global__ __launch_bounds__(256) void k_vol_level_up4(int ls, const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
+                                                       int64_t nblk_prev, int64_t span_prev, uint32_t *__restrict__ Ek,
+                                                       uint32_t *__restrict__ Ck, int64_t nblk, int *__restrict__ status,
+                                                       int radix)
+{
+    const int64_t S = (int64_t)1 << ls;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * S) return;
+    const int64_t b = t >> ls;
+    const int64_t i = t & (S - 1);
+    const int64_t c0 = (int64_t)radix * b;
+    uint32_t x = Ep[c0 * S + i];
+    uint32_t c = Cp[c0 * S + i];
+    for (int j = 1; j < radix; ++j) {
+        const int64_t child = c0 + j;
+        if (x == VOL_END || child >= nblk_prev) break;
+        const int64_t i2 = (int64_t)x - child * span_prev;           // the chain enters the next child in its first S ticks
+        if (i2 < 0 || i2 >= S) { atomicOr(status, VOL_ST_OVERFLOW); x = VOL_END; break; }
+        c += Cp[child * S + i2];
+        x = Ep[child * S + i2];
+    }
+    Ek[t] = x;
+    Ck[t] = c;
+}
+
+__global__ __launch_bounds__(256) void k_vol_descend4(int ls, const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
+                                                      int64_t nblk_k, int64_t span_prev, const uint32_t *__restrict__ Ep,
+                                                      const uint32_t *__restrict__ Cp, int64_t nblk_prev,
+                                                      uint32_t *__restrict__ ent_p, int64_t *__restrict__ off_p, int radix)
+{
+    const int64_t S = (int64_t)1 << ls;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk_k) return;
+    uint32_t e = ent_k[b];
+    int64_t o = off_k[b];
+    const int64_t c0 = (int64_t)radix * b;
+    ent_p[c0] = e;
+    off_p[c0] = o;
+    for (int j = 1; j < radix; ++j) {
+        const int64_t child = c0 + j;
+        if (child >= nblk_prev) break;
+        if (e != VOL_END) {
+            const int64_t i = (int64_t)e - (child - 1) * span_prev;  // the entry lies in the previous child's first S ticks
+            if (i >= 0 && i < S) {
+                o += Cp[(child - 1) * S + i];
+                e = Ep[(child - 1) * S + i];
+            }                                                        // (else: cannot happen when S >= longest bar)
+        }
+        ent_p[child] = e;
+        off_p[child] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_vol_emit(int ls, const uint32_t *__restrict__ ent0, const int64_t *__restrict__ off0,
                                                   int64_t nblk0, const uint32_t *__restrict__ nxt,
                                                   int64_t *__restrict__ out, int64_t cap,
@@ -448,11 +531,14 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     constexpr int LS = 11;
     static_assert(S == (1 << LS), "table span");
     const int64_t nblk0 = fmk_ceil_div(n, S);
-    // levels: nblk[k] = ceil(nblk0 / 2^k) until 1
-    int64_t nblk[64];
+    // levels: nblk[k] = ceil(nblk0 / R^k) until 1 (radix-R composition, k_vol_level_up4)
+    static int RAD = 0;                  // developer knob: FMK_VOL_RADIX (2..64, default VOL_RADIX)
+    if (!RAD) { const char *v = getenv("FMK_VOL_RADIX"); RAD = v ? atoi(v) : VOL_RADIX; if (RAD < 2 || RAD > 64) RAD = VOL_RADIX; }
+    int64_t nblk[64], spanq[64];
     int K = 0;
     nblk[0] = nblk0;
-    while (nblk[K] > 1) { nblk[K + 1] = (nblk[K] + 1) / 2; ++K; }
+    spanq[0] = S;
+    while (nblk[K] > 1) { nblk[K + 1] = (nblk[K] + RAD - 1) / RAD; spanq[K + 1] = spanq[K] * RAD; ++K; }
     // workspace layout (uint32 tables + per-level entry/offset arrays)
     size_t tbl = 0;
     for (int k = 0; k <= K; ++k) tbl += (size_t)nblk[k] * S;
@@ -498,8 +584,8 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     FMK_LAUNCH_CHECK(ctx);
     for (int k = 1; k <= K; ++k) {
         const int64_t tot = nblk[k] * S;
-        k_vol_level_up<<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
-            LS, E[k - 1], C[k - 1], nblk[k - 1], (int64_t)S << (k - 1), E[k], C[k], nblk[k], d_status);
+        k_vol_level_up4<<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
+            LS, E[k - 1], C[k - 1], nblk[k - 1], spanq[k - 1], E[k], C[k], nblk[k], d_status, RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     // root entry + total count
@@ -525,8 +611,8 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int k = K; k >= 1; --k) {
-        k_vol_descend<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
-            LS, ent[k], off[k], nblk[k], (int64_t)S << (k - 1), E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1]);
+        k_vol_descend4<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+            LS, ent[k], off[k], nblk[k], spanq[k - 1], E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1], RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     k_vol_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(LS, ent[0], off[0], nblk0, nxt, c.dbuf, c.cap,
@@ -1429,10 +1515,11 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     // leaves the tables far ahead; beyond that (or a span of more than 4M ticks) the chain is walked
     if ((double)S > 32.0 * mean_len || ls > 22) return 1;
     const int64_t nblk0 = fmk_ceil_div(n, S);
-    int64_t nb[64];
+    int64_t nb[64], spanq[64];
     int K = 0;
     nb[0] = nblk0;
-    while (nb[K] > 1) { nb[K + 1] = (nb[K] + 1) / 2; ++K; }
+    spanq[0] = S;
+    while (nb[K] > 1) { nb[K + 1] = (nb[K] + VOL_RADIX - 1) / VOL_RADIX; spanq[K + 1] = spanq[K] * VOL_RADIX; ++K; }   // radix-16 levels
     size_t tbl = 0, ents = 0;
     for (int k = 0; k <= K; ++k) { tbl += (size_t)nb[k] * S; ents += (size_t)nb[k]; }
     FMK_TRY(vol_ensure(ctx, &c.work3, &c.work3_bytes, 2 * tbl * 4 + ents * (4 + 8) + 256));
@@ -1452,8 +1539,8 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     k_vg_level0<<<(unsigned)fmk_ceil_div(nblk0 * S, 256), 256, 0, ctx->stream>>>(nxt, n, ls, nblk0 * S, E[0], C[0]);
     FMK_LAUNCH_CHECK(ctx);
     for (int k = 1; k <= K; ++k) {
-        k_vol_level_up<<<(unsigned)fmk_ceil_div(nb[k] * S, 256), 256, 0, ctx->stream>>>(
-            ls, E[k - 1], C[k - 1], nb[k - 1], S << (k - 1), E[k], C[k], nb[k], d_status);
+        k_vol_level_up4<<<(unsigned)fmk_ceil_div(nb[k] * S, 256), 256, 0, ctx->stream>>>(
+            ls, E[k - 1], C[k - 1], nb[k - 1], spanq[k - 1], E[k], C[k], nb[k], d_status, VOL_RADIX);
         FMK_LAUNCH_CHECK(ctx);
     }
     int64_t closes = 0;
@@ -1472,8 +1559,8 @@ static int vol_global_tables(fmk_ctx *ctx, const void *a, int is_f64, int64_t n,
     FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int k = K; k >= 1; --k) {
-        k_vol_descend<<<(unsigned)fmk_ceil_div(nb[k], 256), 256, 0, ctx->stream>>>(
-            ls, ent[k], off[k], nb[k], S << (k - 1), E[k - 1], C[k - 1], nb[k - 1], ent[k - 1], off[k - 1]);
+        k_vol_descend4<<<(unsigned)fmk_ceil_div(nb[k], 256), 256, 0, ctx->stream>>>(
+            ls, ent[k], off[k], nb[k], spanq[k - 1], E[k - 1], C[k - 1], nb[k - 1], ent[k - 1], off[k - 1], VOL_RADIX);
         FMK_LAUNCH_CHECK(ctx);
     }
     k_vol_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(ls, ent[0], off[0], nblk0, nxt, c.dbuf, c.cap,
