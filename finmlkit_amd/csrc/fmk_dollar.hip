@@ -303,7 +303,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
                                                         const int64_t *__restrict__ seg_premin,
                                                         int64_t *__restrict__ out, int64_t cap,
                                                         unsigned long long *n_frag, int64_t *__restrict__ carry_k,
-                                                        double inv_ulp)
+                                                        double inv_ulp, int simple, int64_t *__restrict__ last_M)
 {
     __shared__ DD lds[4];
     __shared__ int64_t wmin[4];
@@ -323,9 +323,22 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
     }
     if (lane == 63) wmin[w] = inc;
     __syncthreads();
-    int64_t pre = tile_premin[blockIdx.x];           // min of all G before this tile (INT64_MAX for tile 0):
-    const int64_t spre = seg_premin[blockIdx.x >> DL_SEGM_SHIFT];      // inside its segment, and of the segments before
-    pre = spre < pre ? spre : pre;
+    int64_t pre;                                     // min of all G before this tile (INT64_MAX for tile 0)
+    if (simple) {
+        // No increment reaches the threshold (d_max < thr): M grows by at most 1 per tick, so G_j = M_j - j never increases and
+        // the prefix-min IS the previous tick's value -- G at the tick before this tile, from the tile's own base prefix.  The
+        // whole minima pass (k_dl_tile_min + k_dl_scan_min: a third read of price and amount) is not needed: K_i = M_i.
+        pre = INT64_MAX;
+        if (blockIdx.x > 0) {
+            double fd;
+            const DD base = dd_add(seg_base[blockIdx.x >> DL_SEG_SHIFT], tile_base[blockIdx.x]);
+            pre = dd_floor_div(base, thr, &fd) - ((int64_t)blockIdx.x * DL_TILE - 1);
+        }
+    } else {
+        pre = tile_premin[blockIdx.x];
+        const int64_t spre = seg_premin[blockIdx.x >> DL_SEGM_SHIFT];  // inside its segment, and of the segments before
+        pre = spre < pre ? spre : pre;
+    }
     for (int k = 0; k < w; ++k) pre = wmin[k] < pre ? wmin[k] : pre;
     int64_t prev = __shfl_up(inc, 1, 64);
     if (lane == 0) prev = INT64_MAX;
@@ -345,6 +358,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
                 }
             }
             mex = G[k] < mex ? G[k] : mex;
+            if (simple && i == n - 1) *last_M = G[k] + i;    // closes of the whole stream = M_{n-1}
         }
     }
     if (i0 == 0 && cap > 0) out[0] = 0;              // logic.py:138
@@ -399,20 +413,41 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax);
     FMK_LAUNCH_CHECK(ctx);
     k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
-    k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(segb, gdd, gdd, nullptr);
+    DD *d_total = (DD *)(ctx->d_mail + 44);                            // sum of all increments (double-double)
+    k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(segb, gdd, gdd, d_total);
     FMK_LAUNCH_CHECK(ctx);
-    k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin);
-    FMK_LAUNCH_CHECK(ctx);
-    k_dl_scan_min<<<(unsigned)gmn, 1024, 0, ctx->stream>>>(tmin, tiles, (int64_t)1 << DL_SEGM_SHIFT, segm, nullptr);
-    k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(segm, gmn, gmn, nullptr, d_res);
-    FMK_LAUNCH_CHECK(ctx);
-    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    // what pass 1 learned: negative / NaN increments (-> serial walk), the largest increment, the total
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 4, d_total, 16, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if ((int)ctx->h_mail[1] != 0) return 1;          // negative / NaN increments: caller falls back to the serial walk
+    if ((int)ctx->h_mail[1] != 0) return 1;
     memcpy(&c.dmax, &ctx->h_mail[2], 8);
-    const int64_t gmin = ctx->h_mail[0] < 0 ? ctx->h_mail[0] : 0;     // G_0 = 0 is part of every prefix
-    c.count = (n - 1) + gmin + 1;                                       // K_{n-1} closes + the leading 0
+    static int force_minpass = -1;       // developer knob: FMK_DL_MIN_PASS=1 keeps the prefix-min pass for every input
+    if (force_minpass < 0) { const char *v = getenv("FMK_DL_MIN_PASS"); force_minpass = v ? atoi(v) : 0; }
+    const int simple = (c.dmax < thr && !force_minpass) ? 1 : 0;
+    if (!simple) {
+        k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin);
+        FMK_LAUNCH_CHECK(ctx);
+        k_dl_scan_min<<<(unsigned)gmn, 1024, 0, ctx->stream>>>(tmin, tiles, (int64_t)1 << DL_SEGM_SHIFT, segm, nullptr);
+        k_dl_scan_min<<<1, 1024, 0, ctx->stream>>>(segm, gmn, gmn, nullptr, d_res);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t gmin = ctx->h_mail[0] < 0 ? ctx->h_mail[0] : 0; // G_0 = 0 is part of every prefix
+        c.count = (n - 1) + gmin + 1;                                   // K_{n-1} closes + the leading 0
+    } else {
+        // two passes: the number of closes is M_{n-1} = floor(D_{n-1} / thr), from the double-double total (same arithmetic as
+        // dd_floor_div on the device; the emit pass reports the value it used and the two are compared)
+        double hi, lo;
+        memcpy(&hi, &ctx->h_mail[4], 8);
+        memcpy(&lo, &ctx->h_mail[5], 8);
+        double q = floor(hi / thr);
+        const double pq = q * thr, eq = fma(q, thr, -pq);
+        double r = (hi - pq) + (lo - eq);
+        while (r < 0.0) { q -= 1.0; r += thr; }
+        while (r >= thr) { q += 1.0; r -= thr; }
+        c.count = (int64_t)q + 1;
+    }
     if (c.dbuf && c.cap < c.count + DL_EXTRA) {
         FMK_HIP(ctx, hipFree(c.dbuf));
         FMK_HIP(ctx, hipFree(c.carry));
@@ -427,12 +462,24 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     FMK_HIP(ctx, hipMemsetAsync(d_frag, 0, 8, ctx->stream));
     int ex;
     (void)frexp(thr, &ex);                                            // thr = m * 2^ex, m in [0.5, 1): ulp(thr) = 2^(ex - 53)
-    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf, c.count,
-                                                                     d_frag, c.carry, ldexp(1.0, 53 - ex));
+    FMK_HIP(ctx, hipMemsetAsync(d_res, 0xFF, 8, ctx->stream));
+    k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf,
+                                                                     simple ? c.cap : c.count, d_frag, c.carry,
+                                                                     ldexp(1.0, 53 - ex), simple, d_res);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     c.unc = ctx->h_mail[0];
+    if (simple && ctx->h_mail[1] + 1 != c.count) {
+        // the device's D_{n-1} (segment base + tile base + in-tile prefix) and the host's total are the same sum in two
+        // association orders: they can only disagree about floor(D / thr) when D is within ~2^-100 of a multiple of thr
+        const int64_t dev = ctx->h_mail[1] + 1;
+        if (dev < 1 || dev > c.cap)
+            return fmk_set_error(ctx, FMK_E_HIP, "dollar indexer: %lld closes on the device, %lld from the total",
+                                 (long long)(dev - 1), (long long)(c.count - 1));
+        c.count = dev;
+    }
     return FMK_OK;
 }
 
