@@ -199,21 +199,48 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
     }
     DD tot;
     DD ex = dl_block_exclusive(s, lds, &tot);
-    DD D = dd_add(dd_add(seg_base[blockIdx.x >> DL_SEG_SHIFT], tile_base[blockIdx.x]), ex);
+    // (M, r) = floor and remainder of D / thr BEFORE the thread's first tick, from the double-double prefix: one division per
+    // thread.  Its 8 ticks then only add their increment to r and step M when r passes thr -- the exact-arithmetic form of the
+    // reference's loop.  r is a plain double: 8 additions lose <= 8 * 2^-53 * 2 thr, five orders of magnitude inside the
+    // 1e-11 * thr margin that flags a decision.  (A division, an fma and a double-double add per TICK stood here: the emit
+    // pass ran at 2.3 TB/s, VALU-bound.)
+    const DD D0 = dd_add(dd_add(seg_base[blockIdx.x >> DL_SEG_SHIFT], tile_base[blockIdx.x]), ex);
+    double fd0, r;
+    int64_t M = dd_floor_div(D0, thr, &fd0, &r);
     int frag = 0;
     const int64_t i0 = t0 + (int64_t)threadIdx.x * DL_ITEMS;
+    bool big = false;                      // an increment of this thread reaches the threshold (whale trades): per-tick division
 #pragma unroll
-    for (int k = 0; k < DL_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        D = dd_add(D, d[k]);
-        G[k] = INT64_MAX;                 // neutral for min beyond the end
-        if (i < n) {
-            double fd, r;
-            const int64_t M = dd_floor_div(D, thr, &fd, &r);
-            if (rem) rem[k] = r;
-            G[k] = i == 0 ? 0 : M - i;
-            const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16);
-            frag += (i > 0 && fd <= tol);
+    for (int k = 0; k < DL_ITEMS; ++k) big |= d[k] >= thr;
+    if (!big) {
+#pragma unroll
+        for (int k = 0; k < DL_ITEMS; ++k) {
+            const int64_t i = i0 + k;
+            G[k] = INT64_MAX;                 // neutral for min beyond the end
+            if (i < n) {
+                r += d[k];
+                if (r >= thr) { r -= thr; M += 1; }      // d < thr: at most one step per tick
+                if (rem) rem[k] = r;
+                G[k] = i == 0 ? 0 : M - i;
+                const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16) * thr;
+                frag += (i > 0 && fmin(r, thr - r) <= tol);
+            }
+        }
+    } else {
+        DD D = D0;
+#pragma unroll
+        for (int k = 0; k < DL_ITEMS; ++k) {
+            const int64_t i = i0 + k;
+            D = dd_add(D, d[k]);
+            G[k] = INT64_MAX;
+            if (i < n) {
+                double fd, rr;
+                const int64_t Mk = dd_floor_div(D, thr, &fd, &rr);
+                if (rem) rem[k] = rr;
+                G[k] = i == 0 ? 0 : Mk - i;
+                const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16);
+                frag += (i > 0 && fd <= tol);
+            }
         }
     }
     return frag;

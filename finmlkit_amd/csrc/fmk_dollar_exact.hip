@@ -83,14 +83,15 @@ __device__ __forceinline__ double dlx_d(const double *price, const void *amount,
 
 __device__ __forceinline__ int64_t dlx_binade(double x) { return __double_as_longlong(x) >> 52; }   // sign + exponent
 
-#define DLX_T 32                         // ticks a lane takes per round
+#define DLX_T 16                         // ticks a lane takes per round: 32 -> 16 -> 8 gave 5.7 / 3.5 / 4.6 ms at 1e9 ticks (the LDS rows
+                                         // of a wave shrink with it: 2 -> 4 -> 8 waves per SIMD, but twice the rounds each time)
 #define DLX_R_MAX 8                      // bars per lane (strided by 64: evens out the bar lengths within a wave) -- as many
                                          // as leave the chip >= 8192 workgroups: a wave is one long dependent loop
 
 // One LANE per bar -- the adds of a bar are a dependent chain -- but the loads are the wave's: a lane that streamed its own
 // bar would touch its own cache line with every load instruction (64 lines for 512 useful bytes; the first version of this
-// kernel took 31.6 ms at 1e9 ticks, 0.4 TB/s).  Per round every lane publishes the next DLX_T ticks it needs; the wave fetches
-// the 64 segments with coalesced loads (half a wave per 256-byte segment), forms the rounded products and parks them in LDS,
+// kernel took 31.6 ms at 1e9 ticks, 0.4 TB/s; this one 3.5).  Per round every lane publishes the next DLX_T ticks it needs; the wave fetches
+// the 64 segments with coalesced loads (a quarter wave per 128-byte segment), forms the rounded products and parks them in LDS,
 // one padded row per lane; then every lane walks its own row.
 template <bool AF64>
 __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ price, const void *__restrict__ amount, int64_t n,
@@ -139,12 +140,16 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
     };
     open_bar();
     while (__ballot(active) != 0) {
-        s_pos[w][lane] = active ? pos : -1;
+        // the window a lane asks for starts on a DLX_T-tick boundary (whole 128-byte lines of prices when the column is
+        // line-aligned): only the first round of a bar is partial.  Windows at the lane's exact position made the kernel fetch
+        // 19.75 GB for its 12 (2 x FETCH_SIZE); aligned: 12.4 GB (profiles/r02_dollar_two_pass.txt)
+        s_pos[w][lane] = active ? (pos & ~(int64_t)(DLX_T - 1)) : -1;
         s_end[w][lane] = active ? end : -2;
         __builtin_amdgcn_wave_barrier();
-        const int half = lane >> 5, j32 = lane & 31;
+        constexpr int SPI = 64 / DLX_T;                              // segments per load instruction
+        const int half = lane / DLX_T, j32 = lane & (DLX_T - 1);
 #pragma unroll
-        for (int sgm = 0; sgm < 64; sgm += 2) {             // all 32 loads of the round in flight together
+        for (int sgm = 0; sgm < 64; sgm += SPI) {           // all loads of the round in flight together
             const int seg = sgm + half;
             const int64_t p0 = s_pos[w][seg], e0 = s_end[w][seg];
             const int64_t tick = p0 + j32;
@@ -154,12 +159,13 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
         }
         __builtin_amdgcn_wave_barrier();
         int cnt = 0;
-        if (active) cnt = (int)(end - pos + 1 < DLX_T ? end - pos + 1 : DLX_T);
+        const int o = (int)(pos & (DLX_T - 1));                     // my first tick inside the window
+        if (active) cnt = (int)(end - pos + 1 < DLX_T - o ? end - pos + 1 : DLX_T - o);
         const bool closes_here = active && !tail && pos + cnt - 1 == end;     // the closing add is the last tick of this round
 #pragma unroll 4
         for (int j = 0; j < DLX_T; ++j) {
             if (j < cnt) {
-                const double d = rows[w][lane][j];
+                const double d = rows[w][lane][(o + j) & (DLX_T - 1)];
                 c0 += d; c1 += d; c2 += d; c3 += d;
                 const double lo = c0 - m, hi = c3 + m;
                 bool bad = dlx_binade(lo) != dlx_binade(hi);     // the add must land in one binade for every possible state
@@ -391,7 +397,7 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     const char *mv = getenv("FMK_DL_MARGIN_SCALE");
     double mscale = mv ? atof(mv) : 1.0;
     if (!(mscale >= 1.0)) mscale = 1.0;
-    const double m_rel = ldexp(thr, -52) * mscale, m_abs = 16.0 * u * mscale;
+    const double m_rel = ldexp(thr, -52) * mscale, m_abs = 64.0 * u * mscale;   // the carry k~ is good to a few units
     const int64_t nbar = nb + 1;                     // + the tail
     const int64_t nblk = fmk_ceil_div(nbar, DLX_BLOCK_BARS);
     void *p_fn = nullptr, *p_fidx = nullptr, *p_owner = nullptr, *p_flist = nullptr, *p_kin = nullptr, *p_blk = nullptr,
