@@ -88,6 +88,30 @@ def main():
     d["fp_price_tick"] = np.float64(fp.price_tick)
     print(f"directional + footprints: {N_FLOW} ticks -> {nb} bars in {time.time() - t0:.0f} s")
 
+    # ---- cfg 3 at the same size: the reference's own sequential indexers (bar/logic.py:87-149) on the first 10^7 ticks with
+    #      the thresholds the bench derives from the data (about one bar per 865 ticks), and on a lognormal float64 tape where
+    #      every addition rounds.  Only the close indices are stored.
+    import finmlkit.bar.logic as LG
+    t0 = time.time()
+    orc.build()
+    ts, px, am, sd = orc.synth(42, 0, N_OHLCV)
+    vthr, dthr = 1728.5, 17285000.0
+    d["cfg3_vthr"], d["cfg3_dthr"] = np.float64(vthr), np.float64(dthr)
+    d["cfg3_volume_close_indices"] = np.array(LG._volume_bar_indexer(am, vthr), dtype=np.int64)
+    d["cfg3_dollar_close_indices"] = np.array(LG._dollar_bar_indexer(px, am, dthr), dtype=np.int64)
+    rng = np.random.default_rng(2024)
+    m = 2_000_000
+    lam = rng.lognormal(-1.0, 1.2, m)
+    lpx = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=m)), 0.01)
+    d["cfg3_logn_seed"], d["cfg3_logn_n"] = np.int64(2024), np.int64(m)
+    lv, ld = float(np.mean(lam)) * 700.0, float(np.mean(lam * lpx)) * 700.0
+    d["cfg3_logn_vthr"], d["cfg3_logn_dthr"] = np.float64(lv), np.float64(ld)
+    d["cfg3_logn_volume_close_indices"] = np.array(LG._volume_bar_indexer(lam, lv), dtype=np.int64)
+    d["cfg3_logn_dollar_close_indices"] = np.array(LG._dollar_bar_indexer(lpx, lam, ld), dtype=np.int64)
+    print(f"volume / dollar indexers: {len(d['cfg3_volume_close_indices']) - 1} / {len(d['cfg3_dollar_close_indices']) - 1} bars on "
+          f"{N_OHLCV} ticks, {len(d['cfg3_logn_volume_close_indices']) - 1} / {len(d['cfg3_logn_dollar_close_indices']) - 1} on the "
+          f"lognormal tape, in {time.time() - t0:.0f} s")
+
     path = os.path.join(ROOT, "tests", "golden", "cfg1_reference_timebars.npz")
     np.savez_compressed(path, **d)
     print(f"{path}: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

@@ -52,3 +52,12 @@ def assert_f64_close(got, want, rtol=1e-9, what=""):
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
     np.testing.assert_allclose(got, want, rtol=rtol, atol=0.0, equal_nan=True, err_msg=what)
+
+
+def lognormal_tape(d):
+    """(amounts float64, prices) of the lognormal tape of cfg1_reference_timebars.npz (oracle/gen_cfg1.py: same draws)."""
+    rng = np.random.default_rng(int(d["cfg3_logn_seed"]))
+    m = int(d["cfg3_logn_n"])
+    lam = rng.lognormal(-1.0, 1.2, m)
+    lpx = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=m)), 0.01)
+    return lam, lpx

@@ -189,6 +189,30 @@ def test_threshold_bars_full_size(big, prefix, orc):
     print(f"dollar bars at {n:.3g} ticks: {int((exact != fast).sum())} closes differ between the exact tier and the closed form")
 
 
+def test_cfg3_reference_vectors(big, monkeypatch):
+    """cfg 3 against vectors the REFERENCE's own sequential indexers made (oracle/gen_cfg1.py): the closes of the 10^9-tick HIP
+    run that fall inside the first 10^7 ticks (threshold bars are causal), and the lognormal float64 tape in full -- default exact
+    mode, and the dollar tape once more forced through the exact tier with a wide margin (most bars replayed)."""
+    engine, t, n = big
+    d = G.load("cfg1_reference_timebars")
+    m = int(d["n_ohlcv"])
+    assert n >= m
+    for kind, thr, key in (("volume", float(d["cfg3_vthr"]), "cfg3_volume_close_indices"),
+                           ("dollar", float(d["cfg3_dthr"]), "cfg3_dollar_close_indices")):
+        ci = (t.volume_bar_index(thr) if kind == "volume" else t.dollar_bar_index(thr)).to_host()
+        assert t.last_uncertified == 0
+        k = int(np.searchsorted(ci, m, side="left"))
+        np.testing.assert_array_equal(ci[:k], d[key], err_msg=kind)
+    lam, lpx = G.lognormal_tape(d)
+    tape = engine.DeviceTrades.from_numpy(np.arange(len(lam), dtype=np.int64), lpx, lam)
+    np.testing.assert_array_equal(tape.volume_bar_index(float(d["cfg3_logn_vthr"])).to_host(), d["cfg3_logn_volume_close_indices"])
+    np.testing.assert_array_equal(tape.dollar_bar_index(float(d["cfg3_logn_dthr"])).to_host(), d["cfg3_logn_dollar_close_indices"])
+    monkeypatch.setenv("FMK_DL_FORCE_EXACT_TIER", "1")
+    monkeypatch.setenv("FMK_DL_MARGIN_SCALE", "1e6")
+    np.testing.assert_array_equal(tape.dollar_bar_index(float(d["cfg3_logn_dthr"])).to_host(), d["cfg3_logn_dollar_close_indices"])
+    assert tape.last_uncertified == 0
+
+
 def _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr, kinds):
     for kind in kinds:
         ci = (t.volume_bar_index(vthr) if kind == "volume" else t.dollar_bar_index(dthr)).to_host()

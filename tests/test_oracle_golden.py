@@ -228,3 +228,15 @@ def test_cfg1_reference_timebars_flow(orc):
             np.testing.assert_allclose(v, d["fp_" + k], atol=1e-6)
         else:
             np.testing.assert_array_equal(v, d["fp_" + k], err_msg=k)
+
+
+def test_cfg3_reference_threshold_indexers(orc):
+    """The reference's own sequential volume / dollar indexers (bar/logic.py:87-149) at 10^7 ticks of the bench stream and on a
+    2*10^6-tick lognormal float64 tape (every addition rounds; the dollar carry never resets): the oracle's close indices."""
+    d = G.load("cfg1_reference_timebars")
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n_ohlcv"]))
+    np.testing.assert_array_equal(orc._volume_bar_indexer(am, float(d["cfg3_vthr"])), d["cfg3_volume_close_indices"])
+    np.testing.assert_array_equal(orc._dollar_bar_indexer(px, am, float(d["cfg3_dthr"])), d["cfg3_dollar_close_indices"])
+    lam, lpx = G.lognormal_tape(d)
+    np.testing.assert_array_equal(orc._volume_bar_indexer(lam, float(d["cfg3_logn_vthr"])), d["cfg3_logn_volume_close_indices"])
+    np.testing.assert_array_equal(orc._dollar_bar_indexer(lpx, lam, float(d["cfg3_logn_dthr"])), d["cfg3_logn_dollar_close_indices"])
