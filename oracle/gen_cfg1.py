@@ -112,6 +112,21 @@ def main():
           f"{N_OHLCV} ticks, {len(d['cfg3_logn_volume_close_indices']) - 1} / {len(d['cfg3_logn_dollar_close_indices']) - 1} on the "
           f"lognormal tape, in {time.time() - t0:.0f} s")
 
+    # ---- the tick-level chain at 10^6 ticks through the reference's own loops: comp_lagged_returns (core/utils.py:12-64) ->
+    #      ewmst (core/volatility.py:139-219) -> _cusum_bar_indexer (bar/logic.py:152-221).  Every 97th value of the two
+    #      series (and their NaN counts) and all CUSUM close indices are stored.
+    from finmlkit.feature.core import utils as FU
+    from finmlkit.feature.core import volatility as FV
+    t0 = time.time()
+    ts, px, am, sd = orc.synth(42, 0, N_FLOW)
+    r = FU.comp_lagged_returns(ts, px, 5.0, True)
+    sg = FV.ewmst(ts, r, 60.0)
+    ci = np.array(LG._cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), dtype=np.int64)
+    d["tl_returns_97"], d["tl_sigma_97"] = r[::97].copy(), sg[::97].copy()
+    d["tl_returns_nan"], d["tl_sigma_nan"] = np.int64(np.isnan(r).sum()), np.int64(np.isnan(sg).sum())
+    d["tl_cusum_close_indices"] = ci
+    print(f"lagged returns -> ewmst -> CUSUM on {N_FLOW} ticks: {len(ci) - 1} bars, in {time.time() - t0:.0f} s")
+
     path = os.path.join(ROOT, "tests", "golden", "cfg1_reference_timebars.npz")
     np.savez_compressed(path, **d)
     print(f"{path}: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

@@ -143,3 +143,20 @@ def test_ewmst_one_pass_kernel_matches_two_pass(monkeypatch):
         np.testing.assert_allclose(got, w, rtol=1e-11, atol=0, equal_nan=True)
     np.testing.assert_allclose(t.ewms(r, 50).to_host(), want_s, rtol=1e-11, atol=0, equal_nan=True)
     ctx.sync()
+
+
+def test_tick_level_chain_reference_vectors(orc):
+    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer at 10^6 ticks against vectors made by the reference's own loops
+    (oracle/gen_cfg1.py): returns and sigma at every 97th tick within the north-star tolerance, NaN counts equal, and the
+    CUSUM closes -- an integer result fed by the device's own sigma -- identical."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    from finmlkit_amd.feature.core.utils import comp_lagged_returns
+    from finmlkit_amd.feature.core.volatility import ewmst
+    d = G.load("cfg1_reference_timebars")
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n_flow"]))
+    r = comp_lagged_returns(ts, px, 5.0, True)
+    sg = ewmst(ts, r, 60.0)
+    assert int(np.isnan(r).sum()) == int(d["tl_returns_nan"]) and int(np.isnan(sg).sum()) == int(d["tl_sigma_nan"])
+    G.assert_f64_close(r[::97], d["tl_returns_97"], rtol=1e-12, what="returns")
+    G.assert_f64_close(sg[::97], d["tl_sigma_97"], rtol=RTOL, what="sigma")
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), d["tl_cusum_close_indices"])

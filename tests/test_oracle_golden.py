@@ -240,3 +240,17 @@ def test_cfg3_reference_threshold_indexers(orc):
     lam, lpx = G.lognormal_tape(d)
     np.testing.assert_array_equal(orc._volume_bar_indexer(lam, float(d["cfg3_logn_vthr"])), d["cfg3_logn_volume_close_indices"])
     np.testing.assert_array_equal(orc._dollar_bar_indexer(lpx, lam, float(d["cfg3_logn_dthr"])), d["cfg3_logn_dollar_close_indices"])
+
+
+def test_tick_level_chain_reference_vectors(orc):
+    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer at 10^6 ticks, made by the reference's own loops (oracle/gen_cfg1.py):
+    returns bit-exact (one IEEE division / log), sigma to 1e-12 (libm exp), the CUSUM closes computed from the ORACLE's sigma
+    identical."""
+    d = G.load("cfg1_reference_timebars")
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n_flow"]))
+    r = orc.comp_lagged_returns(ts, px, 5.0, True)
+    sg = orc.ewmst(ts, r, 60.0)
+    assert int(np.isnan(r).sum()) == int(d["tl_returns_nan"]) and int(np.isnan(sg).sum()) == int(d["tl_sigma_nan"])
+    np.testing.assert_allclose(r[::97], d["tl_returns_97"], rtol=1e-15, atol=0, equal_nan=True)
+    np.testing.assert_allclose(sg[::97], d["tl_sigma_97"], rtol=1e-12, atol=0, equal_nan=True)
+    np.testing.assert_array_equal(orc._cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), d["tl_cusum_close_indices"])
