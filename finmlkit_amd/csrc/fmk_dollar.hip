@@ -15,6 +15,13 @@
 // Traffic: price 8 + amount 4 B/tick, three times (sum, min, emit) + 8 B per close; all three passes load coalesced (the
 // two that scan in tick order hand the products to their owners through a padded LDS tile).
 //
+// Two-pass form (the common case, chosen by dl_run from what pass 1 learned): k_dl_tile_sums also takes the largest
+// increment.  When it is below thr, M grows by at most 1 per tick, so G_j = M_j - j never increases, the running minimum
+// is simply the previous tick's G and K_i = M_i: k_dl_tile_min / k_dl_scan_min are skipped, the close count comes from the
+// double-double total on the host, and k_dl_emit ("simple") does ONE double-double division per thread and follows the
+// remainder incrementally (a thread whose own increments reach thr falls back to a division per tick).  24 B/tick.
+// The float64-drift replay that makes the result exact (default mode) lives in fmk_dollar_exact.hip.
+//
 // Exact arithmetic vs the reference's float64 running sum: the reference's `cum` carries its own
 // rounding drift (<= (i+1)*2^-52*thr after i adds, the carry never resets it).  A decision is
 // reported in n_uncertified when the exact cum lies within that bound (or 1e-11*thr) of the threshold;
