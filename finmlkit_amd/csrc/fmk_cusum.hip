@@ -429,6 +429,10 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
     }
 }
 
+int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const double *d_sigma, int64_t n,
+                         int64_t first, int64_t m, int64_t chunks, double sigma_floor, double sigma_mult, int64_t *d_out,
+                         int64_t capacity, int64_t *total, int64_t *visits, int *done);
+
 extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma,
                                          int64_t n, double sigma_floor, double sigma_mult, int64_t *d_out,
                                          int64_t capacity, int64_t *n_out, int64_t *n_rounds)
@@ -446,15 +450,9 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     void *scr;
     const size_t act_bytes = ((size_t)max_chunks + 255) & ~(size_t)255;
     const size_t list_bytes = ((size_t)max_chunks * 4 + 255) & ~(size_t)255;
-    FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes + act_bytes + list_bytes, &scr));
-    char *base = (char *)scr + scan_bytes;
-    CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes), *last_in = (CsState *)(base + 2 * st_bytes);
-    int64_t *counts = (int64_t *)(base + 3 * st_bytes);
-    double *tile_last = (double *)(base + 3 * st_bytes + cnt_bytes);
-    double *t_ret = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes);
-    double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + tr_bytes);
-    unsigned char *active = (unsigned char *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes);
-    int *list = (int *)(base + 3 * st_bytes + cnt_bytes + ff_bytes + 2 * tr_bytes + act_bytes);
+    // the forward fill only needs its tile array; the fixed point's 16 B/tick of scratch are requested when it runs
+    FMK_TRY(fmk_scratch(ctx, ff_bytes, &scr));
+    double *tile_last = (double *)scr;
     unsigned long long *d_first = (unsigned long long *)ctx->d_mail;
     unsigned long long *d_changed = d_first + 1;
     // ---- forward fill of sigma (in place) + first non-NaN index
@@ -476,7 +474,24 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     const int64_t chunks = m > 0 ? fmk_ceil_div(m, CS_CHUNK) : 0;
     int64_t rounds = 0;
     int64_t total = 0;
-    if (chunks > 0) {
+    int chain_done = 0;
+    if (chunks > 0)                                               // thresholds rarely reached: fmk_cusum_chain.hip
+        FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out, capacity,
+                                     &total, &rounds, &chain_done));
+    if (chain_done) {
+        if (d_out && capacity < total + 1)
+            return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(total + 1),
+                                 (long long)capacity);
+    } else if (chunks > 0) {
+        rounds = 0;
+        FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes + list_bytes, &scr));
+        char *base = (char *)scr + scan_bytes;
+        CsState *st_a = (CsState *)base, *st_b = (CsState *)(base + st_bytes), *last_in = (CsState *)(base + 2 * st_bytes);
+        int64_t *counts = (int64_t *)(base + 3 * st_bytes);
+        double *t_ret = (double *)(base + 3 * st_bytes + cnt_bytes);
+        double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + tr_bytes);
+        unsigned char *active = (unsigned char *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes);
+        int *list = (int *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes);
         const dim3 pg((unsigned)fmk_ceil_div(chunks, 64), CS_CHUNK / 64);
         k_cusum_prep<<<pg, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, t_ret,
                                                  t_lam);

@@ -299,7 +299,8 @@ int fmk_calc_volume_percentage_above_poc(fmk_ctx *ctx, const int32_t *price_leve
 /* ---- CUSUM bars: finmlkit/bar/logic.py:152-221 ("next" rank 3) ------------------------------ */
 /* _cusum_bar_indexer: sigma is forward-filled IN PLACE from its first non-NaN entry (like the reference); the
  * result starts with that entry's index, then one index per close.  d_out == NULL: count only (*n_out).
- * *n_rounds (may be NULL): rounds the parallel-in-time fixed point needed.  FMK_E_CAPACITY: capacity < *n_out. */
+ * *n_rounds (may be NULL): rounds the parallel-in-time fixed point needed (chunks opened, when the chain walk for rarely
+ * reached thresholds served the call).  FMK_E_CAPACITY: capacity < *n_out. */
 int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma, int64_t n,
                               double sigma_floor, double sigma_mult, int64_t *d_out, int64_t capacity,
                               int64_t *n_out, int64_t *n_rounds);
@@ -388,6 +389,11 @@ int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, 
  * depending on the data read; shader cycles per hop.  Not used by any product path. */
 int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t stride, int loads, int hops,
                          double *cycles_per_hop, double *elapsed_ms);
+
+/* Which tier the last fmk_cusum_bar_indexer[_dev] call of this process took (tests): *tier 1 = the chain walk of
+ * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
+ * 3 non-finite return, -1 not tried).  Not used by any product path. */
+int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
 
 #ifdef __cplusplus
 }

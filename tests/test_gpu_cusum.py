@@ -83,3 +83,73 @@ def test_cusum_rounds_and_kit(orc):
     # ... and with prices shorter than sigma = timestamps it works on the first len(prices) ticks
     np.testing.assert_array_equal(_cusum_bar_indexer(ts, px[:-1], sigma.copy(), 5e-4, 2.0),
                                   orc._cusum_bar_indexer(ts[:-1], px[:-1], sigma[:-1].copy(), 5e-4, 2.0))
+
+
+def _last_tier():
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    from finmlkit_amd._ffi import c_i64
+    t, o, s = c_i64(), c_i64(), c_i64()
+    _ffi.lib().fmk_diag_cusum_last(C.byref(t), C.byref(o), C.byref(s))
+    return t.value, o.value, s.value
+
+
+@pytest.mark.parametrize("n,vol,floor,mult,kind,same_ts", [
+    (3_000_000, 2e-6, 5e-4, 2.0, "ewm", 0.25),        # the reference's default floor on a quiet tape: a close per ~1e5 ticks
+    (3_000_000, 2e-6, 5e-4, 2.0, "const0", 0.0),      # sigma below the floor everywhere, no print blocks
+    (1_000_000, 2e-5, 5e-4, 2.0, "ewm", 0.5),         # a close every few thousand ticks
+    (300_000, 2e-4, 1e-6, 1.0, "ewm", 0.25),          # a close every few ticks: every chunk opened, dozens of restarts in each
+    (300_001, 2e-4, 0.05, 2.0, "const0", 0.1),        # never reached: the walk opens nothing
+    (4097, 2e-5, 5e-4, 2.0, "const0", 0.25),
+])
+def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind, same_ts):
+    """The chain walk for rarely reached thresholds (fmk_cusum_chain.hip), forced for every regime (no budget, no minimum
+    size): the same close indices as the sequential loop, and the tier must be the one that answered."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    ts, px = _stream(orc, n, 11, vol=vol, same_ts=same_ts)
+    if kind == "ewm":
+        r = orc.comp_lagged_returns(ts, px, 5.0, True)
+        sigma = orc.ewmst(ts, r, 60.0)
+        sigma[n // 3: n // 3 + 50] = np.nan
+    else:
+        sigma = np.full(n, 1e-7)
+        sigma[:5] = np.nan                                     # the loop starts after the first valid sigma
+    want, wfilled = orc._cusum_bar_indexer(ts, px, sigma, floor, mult, return_sigma=True)
+    s = sigma.copy()
+    got = _cusum_bar_indexer(ts, px, s, floor, mult)
+    tier, opened, status = _last_tier()
+    print(f"n {n}: {len(want) - 1} closes, tier {tier}, chunks opened {opened}, status {status}")
+    assert (tier, status) == (1, 0)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(s, wfilled)
+
+
+def test_cusum_chain_walk_falls_back(orc, monkeypatch):
+    """An uncertain decision (forced: margins scaled by 1e12), a non-finite return (a zero price) and a tape whose
+    thresholds are reached often (the budget of opened chunks) all hand the call to the fixed point: same result."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    n = 3_000_000
+    ts, px = _stream(orc, n, 13, vol=1e-6, same_ts=0.25)
+    sigma = np.full(n, 1e-7)
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    assert 5 < len(want) < 40
+    monkeypatch.setenv("FMK_CUSUM_MARGIN_SCALE", "1e12")
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0), want)
+    assert _last_tier()[0] == 0 and _last_tier()[2] == 2
+    monkeypatch.delenv("FMK_CUSUM_MARGIN_SCALE")
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0), want)
+    assert _last_tier()[0] == 1
+    # thresholds reached every few ticks: the sample's budget ends the walk
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 1e-5, 2.0)
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sigma.copy(), 1e-5, 2.0), want)
+    assert _last_tier()[0] == 0 and _last_tier()[2] == 1
+    # a zero price: log(0 / p) = -inf, log(p / 0) = +inf
+    px2 = px.copy()
+    px2[n // 2] = 0.0
+    with np.errstate(all="ignore"):
+        want = orc._cusum_bar_indexer(ts, px2, sigma.copy(), 5e-4, 2.0)
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px2, sigma.copy(), 5e-4, 2.0), want)
+    assert _last_tier()[0] == 0 and _last_tier()[2] == 3

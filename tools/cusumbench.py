@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """_cusum_bar_indexer at N ticks on the synthetic stream with an EWM sigma of 5 s log returns (the QuickStart flow):
-total time, rounds of the fixed point, closes, for two sigma floors: 1e-5 (thresholds reached every 6-210 ticks) and the
-reference kit's default 5e-4 (on this quiet tape the floor IS the threshold: one close per 2.4e5 ticks, the slow regime).
-usage: cusumbench.py [N]"""
+total time, rounds of the fixed point (or chunks opened by the chain walk), closes and the tier that answered, for a range
+of sigma floors from 1e-5 (thresholds reached every 6-210 ticks) to the reference kit's default 5e-4 (on this quiet tape
+the floor IS the threshold: one close per 2.4e5 ticks).  FMK_CUSUM_CHAIN=0 times the fixed point alone.
+usage: cusumbench.py [N] [floor ...]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from finmlkit_amd import _ffi, engine
 from finmlkit_amd._ffi import DeviceArray, c_i64, c_f64
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
+floors = [float(x) for x in sys.argv[2:]] or [1e-5, 5e-4]
 ctx = _ffi.default_context()
 t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
 ret = t.lagged_returns(5.0, True)
 sig = t.ewmst(ret, 60.0)
 del ret
 m, rounds = c_i64(), c_i64()
+tier, opened, status = c_i64(), c_i64(), c_i64()
 out = DeviceArray(ctx, n, np.int64)
-for floor in (1e-5, 5e-4):
+for floor in floors:
     for rep in range(3):
         ctx.timer_start()
         ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sig.p, c_i64(n), c_f64(floor), c_f64(2.0), out.p, c_i64(n),
                  C.byref(m), C.byref(rounds))
         ms = ctx.timer_stop()
-        print("sigma_floor %g: %.2f ms  rounds %d  closes %d" % (floor, ms, rounds.value, m.value), flush=True)
+        _ffi.lib().fmk_diag_cusum_last(C.byref(tier), C.byref(opened), C.byref(status))
+        print("sigma_floor %g: %.2f ms  rounds %d  closes %d  tier %d (walk: %d opened / events, status %d)  checksum %d" %
+              (floor, ms, rounds.value, m.value, tier.value, opened.value, status.value,
+               int(out.view(0, m.value).to_host().sum())), flush=True)
