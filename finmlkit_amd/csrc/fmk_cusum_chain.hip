@@ -176,8 +176,10 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
         atomicOr(&state->bad, 1);
 }
 
-__global__ void k_cc_init(CcState *st)
+__global__ void k_cc_init(CcState *st3, int64_t *flag)
 {
+    if (threadIdx.x == 0) *flag = 0;
+    CcState *st = st3 + threadIdx.x;                                  // positive side, negative side, joint
     st->chunk = 0; st->sp = 0.0; st->sn = 0.0; st->reset_p = 0; st->reset_n = 0; st->mag_p = 0.0; st->mag_n = 0.0;
     st->n_out = 0; st->visits = 0; st->status = CC_ST_DONE; st->bad = 0;
 }
@@ -219,9 +221,17 @@ __device__ __forceinline__ CcMap cc_map_exclusive(const CcMap &inc)
 __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                 const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                 int64_t chunk_limit, int64_t chunks, double sigma_floor, double sigma_mult,
-                                                const double *__restrict__ sums, CcState *state, int64_t visit_budget,
-                                                double margin_scale, int64_t *__restrict__ closes, int64_t capacity)
+                                                const double *__restrict__ sums, CcState *states, int64_t visit_budget,
+                                                double margin_scale, int joint, int64_t *__restrict__ lists, int64_t list_cap,
+                                                int64_t *__restrict__ closes, int64_t capacity)
 {
+    // joint != 0: one workgroup evaluates the loop as written (both sides, `if / elif`), closes -> closes[1 + ...].
+    // joint == 0: workgroup 0 follows the positive side alone, workgroup 1 the negative side alone (each side's state after
+    // its own close is 0 whatever the other side does, so the two chains are independent -- except that a positive close
+    // hides a negative one on the same tick; the caller merges the two lists and re-runs jointly if they ever share a tick).
+    const int side = joint ? 0 : (int)blockIdx.x + 1;
+    const bool do_p = side != 2, do_n = side != 1;
+    CcState *state = states + (joint ? 2 : (int)blockIdx.x);
     __shared__ double s_r[CC_CHUNK + CC_CHUNK / 32], s_l[CC_CHUNK + CC_CHUNK / 32];
     __shared__ int64_t s_cmd;                                           // chunk to open, -1: the walk is over
     const int lane = fmk_lane(), wv = (int)(threadIdx.x >> 6);
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     int64_t c = state->chunk;
     double sp = state->sp, sn = state->sn, mag_p = state->mag_p, mag_n = state->mag_n;
     int64_t reset_p = state->reset_p, reset_n = state->reset_n, n_out = state->n_out, visits = state->visits;
-    int status = state->bad ? CC_ST_BAD : CC_ST_DONE;
+    int status = states[0].bad ? CC_ST_BAD : CC_ST_DONE;              // k_cc_summary reports there
     const double eps = margin_scale * 8.881784197001252e-16;              // 2^-50
 
     auto load = [&](int64_t c0) -> CcSum {
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
             const int64_t t_end = (c + 64) * CC_CHUNK;
             const double mar_p = (double)(t_end - reset_p + 4096) * eps * mg_p;
             const double mar_n = (double)(t_end - reset_n + 4096) * eps * mg_n;
-            const bool cand = fmax(cur.Pp, in_p + cur.Qp) >= -mar_p || fmin(cur.Pn, in_n + cur.Qn) <= mar_n;
+            const bool cand = (do_p && fmax(cur.Pp, in_p + cur.Qp) >= -mar_p) || (do_n && fmin(cur.Pn, in_n + cur.Qn) <= mar_n);
             const unsigned long long cb = __builtin_amdgcn_ballot_w64(cand);
             mag_p = mg_p; mag_n = mg_n;                                   // incl. the chunks skipped on the way to a candidate
             if (cb == 0) {
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
             for (int q = 0; q < 32; ++q) {
                 ap = fmax(ap + rr[q], 0.0);                               // max(0.0, s_pos + ret), min(0.0, s_neg + ret)
                 an = fmin(an + rr[q], 0.0);
-                mask |= (ap - ll[q] >= -mp || an + ll[q] <= mq) ? 1u << q : 0u;
+                mask |= ((do_p && ap - ll[q] >= -mp) || (do_n && an + ll[q] <= mq)) ? 1u << q : 0u;
             }
             if (lane < dead) mask = 0;
             const unsigned long long eb = __builtin_amdgcn_ballot_w64(mask != 0);
@@ -376,11 +386,16 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
             for (int q = 0; q < 32; ++q)
                 if (q <= q0) { bp = fmax(bp + rr[q], 0.0); bn = fmin(bn + rr[q], 0.0); lamq = ll[q]; }
             const double dp = bp - lamq, dn = bn + lamq;
-            const int kind_l = dp >= mp ? 1 : (dp < -mp && dn <= -mq) ? 2 : 3;     // `if s_pos >= lam ... elif s_neg <= -lam`
+            // `if s_pos >= lam ... elif s_neg <= -lam`, each answer only when it is beyond the margin
+            const int kind_l = (do_p && dp >= mp) ? 1 : ((!do_p || dp < -mp) && do_n && dn <= -mq) ? 2 : 3;
             const int kind = __builtin_amdgcn_readlane(kind_l, fl);
             if (kind == 3) { status = CC_ST_UNCERTAIN; break; }
             const int j = 32 * fl + q0;
-            if (lane == 0) { if (closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + t0 + j; }
+            if (joint) { if (lane == 0 && closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + t0 + j; }
+            else {
+                if (n_out >= list_cap) { status = CC_ST_BUDGET; break; }
+                if (lane == 0) lists[(int64_t)(side - 1) * list_cap + n_out] = first + 1 + t0 + j;
+            }
             ++n_out; ++visits;                                            // an event costs about as much as opening a chunk
             sp = kind == 1 ? 0.0 : cc_bcast(bp, fl);                      // states after that tick, the closing side reset
             sn = kind == 2 ? 0.0 : cc_bcast(bn, fl);
@@ -410,6 +425,25 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     }
 }
 
+// the two sides' closes (each ascending) -> out[1 ..]; *coincide = 1 when a tick is in both
+__global__ __launch_bounds__(256) void k_cc_merge(const int64_t *__restrict__ lp, int64_t np, const int64_t *__restrict__ ln,
+                                                  int64_t nn, int64_t *__restrict__ out, int64_t capacity, int64_t *coincide)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np + nn) return;
+    const bool is_p = i < np;
+    const int64_t self = is_p ? i : i - np, v = is_p ? lp[self] : ln[self];
+    const int64_t *o = is_p ? ln : lp;
+    int64_t lo = 0, hi = is_p ? nn : np;                              // entries of the other list before v (ties: positive first)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const bool before = is_p ? o[mid] < v : o[mid] <= v;
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    if (is_p && lo < nn && ln[lo] == v) *coincide = 1;
+    if (out && 1 + self + lo < capacity) out[1 + self + lo] = v;
+}
+
 static int64_t g_cc_last[3];            // tier used by the last call (0 fixed point, 1 this one), chunks opened, walk status
 extern "C" int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status)
 {
@@ -436,34 +470,69 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     if (!(margin_scale > 0.0)) margin_scale = 1.0;
     g_cc_last[0] = 0; g_cc_last[1] = 0; g_cc_last[2] = -1;
     if (mode == 0 || chunks < min_chunks || chunks < 2) return FMK_OK;
+    v = getenv("FMK_CUSUM_CHAIN_JOINT");
+    const bool force_joint = v && atoi(v);                           // developer knob: the one-workgroup joint walk only
     void *scr;
     const size_t sum_bytes = (size_t)chunks * 8 * sizeof(double);
-    FMK_TRY(fmk_scratch(ctx, sum_bytes + 256, &scr));
+    // per-side close lists: a side that fills its list ends the tier like an exhausted budget
+    const int64_t list_cap = m < ((int64_t)1 << 22) ? m : ((int64_t)1 << 22);
+    const size_t list_bytes = (size_t)list_cap * 8;
+    FMK_TRY(fmk_scratch(ctx, sum_bytes + 2 * list_bytes + 512, &scr));
     double *sums = (double *)scr;
-    CcState *st = (CcState *)((char *)scr + sum_bytes);
-    k_cc_init<<<1, 1, 0, ctx->stream>>>(st);
+    int64_t *lists = (int64_t *)((char *)scr + sum_bytes);
+    struct CcHost { CcState st[3]; int64_t coincide; };
+    CcHost *dev = (CcHost *)((char *)scr + sum_bytes + 2 * list_bytes);
+    CcState *st = dev->st;
+    k_cc_init<<<1, 3, 0, ctx->stream>>>(st, &dev->coincide);
     FMK_LAUNCH_CHECK(ctx);
     // a sample first: the leading 2048 chunks with a budget of opened chunks that the slow regime never needs
     const int64_t sample = chunks < 2048 ? chunks : 2048;
     const int64_t sample_budget = mode == 2 ? INT64_MAX : 64 + sample / 32;
-    CcState h;
-    auto run = [&](int64_t lo, int64_t hi, int64_t budget) -> int {
-        k_cc_summary<<<(unsigned)fmk_ceil_div(hi - lo, 4), 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, lo, hi,
-                                                                                chunks, sigma_floor, sigma_mult, sums, st);
+    CcHost hh;
+    auto walk = [&](int joint, int64_t hi, int64_t budget) -> int {
+        k_cc_walk<<<joint ? 1 : 2, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor,
+                                                                        sigma_mult, sums, st, budget, margin_scale, joint, lists,
+                                                                        list_cap, d_out, d_out ? capacity : 0);
         FMK_LAUNCH_CHECK(ctx);
-        k_cc_walk<<<1, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor, sigma_mult, sums, st,
-                                            budget, margin_scale, d_out, d_out ? capacity : 0);
-        FMK_LAUNCH_CHECK(ctx);
-        FMK_HIP(ctx, hipMemcpyAsync(&h, st, sizeof(CcState), hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&hh, dev, sizeof(CcHost), hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return FMK_OK;
     };
-    FMK_TRY(run(0, sample, sample_budget));
-    if (h.status == CC_ST_DONE && sample < chunks) {
-        // ~6 us per opened chunk: allow twice the sample's rate, and never more than ~0.25 s of them
-        int64_t budget = mode == 2 ? INT64_MAX : 2 * (h.visits + 8) * fmk_ceil_div(chunks, sample);
+    auto summarize = [&](int64_t lo, int64_t hi) -> int {
+        k_cc_summary<<<(unsigned)fmk_ceil_div(hi - lo, 4), 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, lo, hi,
+                                                                                chunks, sigma_floor, sigma_mult, sums, st);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    };
+    const int j0 = force_joint ? 1 : 0;
+    auto worst = [&]() { return j0 ? hh.st[2].status : (hh.st[0].status ? hh.st[0].status : hh.st[1].status); };
+    auto spent = [&]() { return j0 ? hh.st[2].visits : (hh.st[0].visits > hh.st[1].visits ? hh.st[0].visits : hh.st[1].visits); };
+    FMK_TRY(summarize(0, sample));
+    FMK_TRY(walk(j0, sample, sample_budget));
+    int64_t budget = sample_budget;
+    if (worst() == CC_ST_DONE && sample < chunks) {
+        // ~3 us per opened chunk or event: allow twice the sample's rate, and never more than ~0.1 s of them
+        budget = mode == 2 ? INT64_MAX : 2 * (spent() + 8) * fmk_ceil_div(chunks, sample);
         if (mode != 2 && budget > 40000) budget = 40000;
-        FMK_TRY(run(sample, chunks, budget));
+        FMK_TRY(summarize(sample, chunks));
+        FMK_TRY(walk(j0, chunks, budget));
+    }
+    CcState h = hh.st[j0 ? 2 : 0];
+    h.status = worst(); h.visits = spent();
+    if (!j0 && h.status == CC_ST_DONE) {
+        const int64_t np = hh.st[0].n_out, nn = hh.st[1].n_out;
+        h.n_out = np + nn;
+        if (np + nn > 0) {
+            k_cc_merge<<<(unsigned)fmk_ceil_div(np + nn, 256), 256, 0, ctx->stream>>>(lists, np, lists + list_cap, nn, d_out,
+                                                                                    d_out ? capacity : 0, &dev->coincide);
+            FMK_LAUNCH_CHECK(ctx);
+            FMK_HIP(ctx, hipMemcpyAsync(&hh.coincide, &dev->coincide, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (hh.coincide) {                                        // a positive and a negative close on one tick: `elif`
+                FMK_TRY(walk(1, chunks, budget));
+                h = hh.st[2];
+            }
+        }
     }
     if (visits) *visits = h.visits;
     g_cc_last[1] = h.visits; g_cc_last[2] = h.status;

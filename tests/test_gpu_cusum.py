@@ -102,11 +102,14 @@ def _last_tier():
     (300_001, 2e-4, 0.05, 2.0, "const0", 0.1),        # never reached: the walk opens nothing
     (4097, 2e-5, 5e-4, 2.0, "const0", 0.25),
 ])
-def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind, same_ts):
+@pytest.mark.parametrize("joint", [0, 1])
+def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind, same_ts, joint):
     """The chain walk for rarely reached thresholds (fmk_cusum_chain.hip), forced for every regime (no budget, no minimum
-    size): the same close indices as the sequential loop, and the tier must be the one that answered."""
+    size), as two independent side chains + merge and as the one joint walk: the same close indices as the sequential loop,
+    and the tier must be the one that answered."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
     monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
     ts, px = _stream(orc, n, 11, vol=vol, same_ts=same_ts)
     if kind == "ewm":
@@ -153,3 +156,27 @@ def test_cusum_chain_walk_falls_back(orc, monkeypatch):
         want = orc._cusum_bar_indexer(ts, px2, sigma.copy(), 5e-4, 2.0)
     np.testing.assert_array_equal(_cusum_bar_indexer(ts, px2, sigma.copy(), 5e-4, 2.0), want)
     assert _last_tier()[0] == 0 and _last_tier()[2] == 3
+
+
+def test_cusum_chain_walk_positive_close_hides_negative(orc, monkeypatch):
+    """`if s_pos >= lam ... elif s_neg <= -lam` (logic.py:214-219): inside a same-timestamp block the price falls by 3.5
+    thresholds and recovers 2.2 of them on the block's last tick -- both sides are beyond their threshold there, only the
+    positive one closes and resets, the negative side closes one tick later.  The two independent side chains put a close of
+    each side on the same tick; the merge must notice and the joint walk must answer."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    n = 600_000
+    ts, px = _stream(orc, n, 17, vol=1e-6, same_ts=0.0)
+    lr = np.diff(np.log(px), prepend=np.log(px[0]))
+    for t in (200_000, 431_234):
+        ts[t - 1] = ts[t - 2]; ts[t] = ts[t - 2]                  # ticks t-2, t-1 cannot close, tick t can
+        assert ts[t + 1] > ts[t]
+        lr[t - 1] = -3.5e-3; lr[t] = 2.2e-3; lr[t + 1] = 0.0
+    px = 100.0 * np.exp(np.cumsum(lr))
+    sigma = np.full(n, 1e-7)
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 1e-3, 2.0)
+    for t in (200_000, 431_234):
+        assert t in want and t + 1 in want
+    got = _cusum_bar_indexer(ts, px, sigma.copy(), 1e-3, 2.0)
+    assert _last_tier()[0] == 1
+    np.testing.assert_array_equal(got, want)
