@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
                 const int last = left >= 64 ? 63 : (int)left - 1;
                 const double oB = cc_bcast(inc.B, last), oAp = cc_bcast(inc.Ap, last), oAn = cc_bcast(inc.An, last);
                 sp = fmax(oAp, sp + oB); sn = fmin(oAn, sn + oB);
-                c += 64;
+                c = left >= 64 ? c + 64 : chunk_limit;                    // (the next launch resumes at `c`)
 #ifdef CC_TIMING
                 ++nG;
 #endif
@@ -486,8 +486,13 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     k_cc_init<<<1, 3, 0, ctx->stream>>>(st, &dev->coincide);
     FMK_LAUNCH_CHECK(ctx);
     // a sample first: the leading 2048 chunks with a budget of opened chunks that the slow regime never needs
-    const int64_t sample = chunks < 2048 ? chunks : 2048;
-    const int64_t sample_budget = mode == 2 ? INT64_MAX : 64 + sample / 32;
+    v = getenv("FMK_CUSUM_CHAIN_SAMPLE");                              // developer knob: chunks of the sample phase
+    const int64_t sample_want = v && atoll(v) > 0 ? atoll(v) : 2048;
+    const int64_t sample = chunks < sample_want ? chunks : sample_want;
+    // Measured at 1e9 ticks (profiles/r02_cusum_chain.txt): the walk costs ~9 ms + 6 us per close, the fixed point 73 / 109 /
+    // 164 / 320 ms at 101 K / 25 K / 11 K / 4 K closes -- the walk wins below ~0.04 closes per chunk.
+    const double max_rate = 0.04;
+    const int64_t sample_budget = mode == 2 ? INT64_MAX : 32 + (int64_t)(max_rate * (double)sample);
     CcHost hh;
     auto walk = [&](int joint, int64_t hi, int64_t budget) -> int {
         k_cc_walk<<<joint ? 1 : 2, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor,
@@ -511,9 +516,14 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     FMK_TRY(walk(j0, sample, sample_budget));
     int64_t budget = sample_budget;
     if (worst() == CC_ST_DONE && sample < chunks) {
-        // ~3 us per opened chunk or event: allow twice the sample's rate, and never more than ~0.1 s of them
-        budget = mode == 2 ? INT64_MAX : 2 * (spent() + 8) * fmk_ceil_div(chunks, sample);
-        if (mode != 2 && budget > 40000) budget = 40000;
+        // the rest with three times the sample's rate as a safety net (an exhausted budget hands over to the fixed point)
+        budget = INT64_MAX;
+        if (mode != 2) {
+            const double rate = (double)(spent() + 1) / (double)sample;
+            budget = (int64_t)(3.0 * rate * (double)chunks) + 1000;
+            const int64_t cap = (int64_t)(2.0 * max_rate * (double)chunks) + 1000;
+            if (budget > cap) budget = cap;
+        }
         FMK_TRY(summarize(sample, chunks));
         FMK_TRY(walk(j0, chunks, budget));
     }

@@ -110,6 +110,7 @@ def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind,
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
     monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
     monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_SAMPLE", "50")         # two launches; the first ends inside a group of 64 chunks
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
     ts, px = _stream(orc, n, 11, vol=vol, same_ts=same_ts)
     if kind == "ewm":

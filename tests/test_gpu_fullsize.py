@@ -275,3 +275,41 @@ def test_cusum_and_volume_profile_full_size(big, prefix, orc):
                                    flat["sell_volumes"].view(0, nl).to_host(), 1800.0, 27, 0.01, 68.34)
     for g, ww, name in zip((poc, hva, lva, pct), w, ("poc", "hva", "lva", "pct")):
         np.testing.assert_array_equal(g[:kb], ww, err_msg=name)
+
+
+def test_cusum_default_floor_chain_walk_equals_fixed_point(big, prefix, orc, monkeypatch):
+    """CUSUMBarKit's default sigma_floor (5e-4; kit.py:147) on the 1e9-tick tape: a close per ~2.4e5 ticks, served by the
+    chain walk of fmk_cusum_chain.hip.  Its closes are those of the fixed point (the reference's loop operation for
+    operation: 0.3 s here) at two floors, and on the prefix those of the sequential oracle."""
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    from finmlkit_amd._ffi import DeviceArray, c_f64, c_i64
+    engine, t, n = big
+    ts, px, am, sd = prefix
+    r = t.lagged_returns(5.0, True)
+    sg = t.ewmst(r, 60.0)
+    del r
+    out = DeviceArray(t.ctx, 1 << 20, np.int64)
+    m, rounds, tier, opened, status = c_i64(), c_i64(), c_i64(), c_i64(), c_i64()
+
+    def run(floor):
+        t.ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sg.p, c_i64(n), c_f64(floor), c_f64(2.0), out.p,
+                   c_i64(out.n), C.byref(m), C.byref(rounds))
+        _ffi.lib().fmk_diag_cusum_last(C.byref(tier), C.byref(opened), C.byref(status))
+        return out.view(0, m.value).to_host().copy(), tier.value
+
+    for floor in (5e-4, 3e-4):
+        monkeypatch.setenv("FMK_CUSUM_CHAIN", "1")
+        got, used = run(floor)
+        if n >= 100_000_000:
+            assert used == 1, "the chain walk should serve this regime"
+        monkeypatch.setenv("FMK_CUSUM_CHAIN", "0")
+        want, used0 = run(floor)
+        assert used0 == 0
+        np.testing.assert_array_equal(got, want)
+        assert len(got) > n // 1_000_000
+    sigma_prefix = sg.view(0, PREFIX).to_host()
+    seq = orc._cusum_bar_indexer(ts, px, sigma_prefix, 3e-4, 2.0)
+    k = int(np.searchsorted(got, PREFIX - 1, side="left"))
+    assert k > 10
+    np.testing.assert_array_equal(got[:k], seq[:k])
