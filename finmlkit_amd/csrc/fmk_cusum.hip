@@ -3,8 +3,9 @@
 // The reference is one sequential loop with a two-component state
 //     s_pos = max(0, s_pos + r_i),  s_neg = min(0, s_neg + r_i),   r_i = log(p_i / p_{i-1})
 // and a reset of ONE side when it crosses +-lambda_i at a tick that is not followed by a same-timestamp tick.
-// Because only one side resets, the state after a close is not a function of the close position alone (unlike the
-// volume bars), so there is no pointer chain to compose.  What the recursion does have is FORGETTING: the max / min
+// Because only one side resets, the JOINT state after a close is not a function of the close position alone (unlike the
+// volume bars).  (Each side on its own is: fmk_cusum_chain.hip walks the two chains when thresholds are rarely reached and
+// hands every other call, and every decision it cannot certify, to this file.)  What the recursion does have is FORGETTING: the max / min
 // clamps and the resets erase the memory of the incoming state after a few hundred ticks.  That makes it a good
 // fit for a parallel-in-time fixed point:
 //     round 0 : every chunk of C ticks is simulated from the state (0, 0)             -> out_0[k]

@@ -11,12 +11,15 @@
 // Blocks compose associatively, so
 //   k_cc_summary : one wave per 2048-tick chunk reduces its ticks to {B, A+, P+, Q+, A-, P-, Q-, U = max |S_i|}
 //                  (coalesced loads, 8 consecutive ticks per lane through LDS, an ordered tree over the lanes): a stream pass;
-//   k_cc_walk    : ONE wave follows the chain: 64 chunk summaries per step (a scan of the exit maps gives every chunk its
+//   k_cc_walk    : one wave follows a chain: 64 chunk summaries per step (a scan of the exit maps gives every chunk its
 //                  incoming state, a ballot the first chunk that may close), and only such a chunk is opened: its ticks are
-//                  recomputed from the columns, every lane walks 32 of them with the reference's own operations from the
-//                  state the lane scan hands it, the first event is emitted, the side that closed restarts from 0 at the
-//                  next tick (ONLY that side resets -- logic.py:214-219 -- and a positive close hides a negative one on the
-//                  same tick: the walk evaluates `if / elif` as written).
+//                  recomputed from the columns (by the four waves of the workgroup), the walking wave takes 32 of them per
+//                  lane, runs the reference's own operations over them from the state the lane scan hands it, the first
+//                  event is emitted and the side that closed restarts from 0 at the next tick.
+//                  ONLY the side that closed resets (logic.py:214-219), so each side is a chain of its own: workgroup 0
+//                  walks the positive side, workgroup 1 the negative side, k_cc_merge interleaves the two lists.  The sides
+//                  couple in one place -- a positive close hides a negative one on the same tick (`if / elif`) -- so if the
+//                  lists share a tick the joint walk (both sides in one wave, `if / elif` as written) answers instead.
 // Arithmetic.  The block sums are not the reference's sequential float64 sum from the last reset, so every decision
 // carries a margin: (ticks since that side's reset + 4096) * 2^-50 * (largest magnitude the side's state or a block
 // prefix has reached since) -- 4x the worst-case distance between two float64 evaluation orders of the same recurrence plus
@@ -24,7 +27,7 @@
 // accepted only when it exceeds it by more than the margin; anything in between ends the tier (status UNCERTAIN) and the
 // caller runs the fixed point of fmk_cusum.hip, which is the reference's loop operation for operation.  Non-finite returns
 // (a price <= 0) are outside the algebra: status BAD, same fallback.  Expected uncertain decisions at 1e9 ticks: ~1e-2.
-// Cost: the summary pass (24 B/tick) + ~1 us per 64 chunks + ~6 us per opened chunk; the caller tries the first 2^22 ticks
+// Cost: the summary pass (24 B/tick, 7 ms per 1e9 ticks) + ~6 us per close (profiles/r02_cusum_chain.txt); the caller tries the first 2^22 ticks
 // with a small budget of opened chunks first, so a tape whose thresholds are reached often never pays for this tier.
 #include <math.h>
 #include <stdlib.h>
