@@ -250,7 +250,7 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ price, const void *__restrict__ amount,
                                                  const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                  int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
-                                                 unsigned long long *redo)
+                                                 unsigned long long *redo, const unsigned long long *only = nullptr)
 {
     typedef typename std::conditional<AF64, double, float>::type AmtT;
     __shared__ double s_p[4][BF_SLOTS];
@@ -264,7 +264,10 @@ __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ pric
     const AmtT *am = (const AmtT *)amount;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t b = wave0; b < nb; b += nwaves) {
+    // `only` (list mode: [0] = count, [32...] = bar numbers): the bars k_bar_dir_lanes left to this schedule
+    const int64_t todo = only ? (int64_t)only[0] : nb;
+    for (int64_t it = wave0; it < todo; it += nwaves) {
+        const int64_t b = only ? fmk_uniform((int64_t)only[32 + it]) : it;
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t start = s + 1;
@@ -327,6 +330,199 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
         const int64_t b = fmk_uniform((int64_t)redo[32 + i]);
         const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
         bf_dir_sequential<AmtT>(o, b, lane, s_rows[threadIdx.x >> 6], price, (const AmtT *)amount, side, s + 1, e, n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// directional only, ONE LANE PER BAR (round 2, float32 amounts): the schedule for streams of many moderate bars.
+// A wave takes 64 consecutive bars; lane l walks bar l tick by tick with the reference's own loop (base.py:476-546: same
+// operations, same order, float64 accumulators), so
+//   * there is nothing to scan or to combine across lanes (the wave-per-bar schedule above spends as many VALU instructions
+//     on its per-tile scans, tile shapes and carries as on the ticks: ~60 + ~45 per 64 ticks),
+//   * every float64 sum is the reference's sequential sum: no float32 tie test, no redo pass.
+// Memory.  The lanes' bars lie 1 200 ticks apart, so a lane's own loads would touch 64 lines per instruction.  Instead the
+// wave stages, per step, the 16-tick aligned block each lane is at: row r of the tile = 128 B of price, 64 B of amount, 16 B
+// of side of lane r's block, fetched by 16 / 8 / 4 fully coalesced instructions (16 / 8 / 4 lanes per row) into registers
+// ONE STEP AHEAD, written to LDS (rows padded 16 -> 17 elements: conflict-free per-lane reads) when the previous step's walk
+// is done.  Every 128-byte line is fetched once.
+// A step in which every live lane is inside its bar and has met a signed tick runs without per-tick predicates (~39 VALU
+// per tick-row); first / last steps of a bar run the predicated form.  Bars longer than `max_len` are left to k_bar_dir
+// (list mode): one long bar would hold its wave for ~75 us per 1e3 ticks.
+// ---------------------------------------------------------------------------------------
+#define DL_T 16
+#define DL_ROW 17
+#define DL_WAVES 2                      // 29.6 KB of LDS per workgroup: five per CU
+__global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *__restrict__ price, const float *__restrict__ amount,
+                                                       const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                       int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
+                                                       unsigned long long *long_list, int64_t max_len)
+{
+    __shared__ double s_p[DL_WAVES][64 * DL_ROW];
+    __shared__ float s_a[DL_WAVES][64 * DL_ROW];
+    __shared__ uint32_t s_s[DL_WAVES][64 * 5];                                // 16 side bytes + 4 of padding per row
+    __shared__ int64_t s_blk[DL_WAVES][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    double *sP = s_p[wib];
+    float *sA = s_a[wib];
+    uint32_t *sS = s_s[wib];
+    const signed char *sS8 = (const signed char *)sS;
+    int64_t *sB = s_blk[wib];
+    const int64_t nwaves = (int64_t)gridDim.x * DL_WAVES;
+    for (int64_t w = (int64_t)blockIdx.x * DL_WAVES + wib; w * 64 < nb; w += nwaves) {
+        const int64_t b = w * 64 + lane;
+        const bool has = b < nb;
+        const int64_t s = has ? ci[b] : 0, e = has ? ci[b + 1] : 0;
+        const int64_t len = e - s;
+        const bool is_long = has && len > max_len;
+        const unsigned long long lb = __builtin_amdgcn_ballot_w64(is_long);
+        if (lb) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(long_list, (unsigned long long)__builtin_popcountll(lb));
+            base = (unsigned long long)fmk_uniform((int64_t)base);
+            if (is_long) long_list[32 + base + __builtin_popcountll(lb & ((1ULL << lane) - 1))] = (unsigned long long)b;
+        }
+        const bool active = has && len > 0 && !is_long;
+        const int64_t start = s + 1;
+        const int64_t first_blk = start >> 4;
+        const int nsteps = active ? (int)((e >> 4) - first_blk + 1) : 0;
+        const int steps = fmk_dpp_reduce(nsteps, 0, FmkOpMax());
+        // the reference's accumulators (base.py:476-488)
+        double vb = 0.0, vs = 0.0, db = 0.0, ds = 0.0, cs = 0.0, mxs = 0.0, cv = 0.0, cd = 0.0;
+        double vmin = 1e9, vmax = -1e9, dmin = 1e9, dmax = -1e9;
+        int ct = 0, tmin = BF_INIT_MIN, tmax = BF_INIT_MAX, nbuy = 0, nsell = 0;
+        bool seen = false;                                             // a signed tick has updated the extrema
+        double pp = 0.0;
+        int ps = 0;
+        if (active) {
+            pp = price[fmk_wrap(s, n)];
+            ps = len > 1 ? (int)side[fmk_wrap(s, n)] : 0;              // base.py:485-488
+        }
+        double pr[16];
+        float2 ar[8];
+        uint32_t sr[4];
+        auto issue = [&](int step) {                                   // the blocks of `step` -> registers
+            sB[lane] = step < nsteps ? first_blk + step : (int64_t)-1;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t rb = sB[4 * k + (lane >> 4)];
+                int64_t idx = rb * DL_T + (lane & 15);
+                idx = idx < n ? idx : n - 1;
+                pr[k] = rb >= 0 ? price[idx] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t rb = sB[8 * k + (lane >> 3)];
+                const int64_t idx = rb * DL_T + (lane & 7) * 2;
+                float2 v = make_float2(0.f, 0.f);
+                if (rb >= 0) {
+                    if (idx + 1 < n) v = *(const float2 *)(amount + idx);
+                    else if (idx < n) v.x = amount[idx];
+                }
+                ar[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t rb = sB[16 * k + (lane >> 2)];
+                const int64_t idx = rb * DL_T + (lane & 3) * 4;
+                uint32_t v = 0;
+                if (rb >= 0) {
+                    if (idx + 3 < n) v = *(const uint32_t *)(side + idx);
+                    else
+                        for (int q = 0; q < 4; ++q)
+                            if (idx + q < n) v |= (uint32_t)(uint8_t)side[idx + q] << (8 * q);
+                }
+                sr[k] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (steps > 0) issue(0);
+        for (int step = 0; step < steps; ++step) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sP[(4 * k + (lane >> 4)) * DL_ROW + (lane & 15)] = pr[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int at = (8 * k + (lane >> 3)) * DL_ROW + (lane & 7) * 2;
+                sA[at] = ar[k].x; sA[at + 1] = ar[k].y;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sS[(16 * k + (lane >> 2)) * 5 + (lane & 3)] = sr[k];
+            __builtin_amdgcn_wave_barrier();
+            if (step + 1 < steps) issue(step + 1);
+            // ---- the lane's 16 ticks
+            const bool live = step < nsteps;
+            const int64_t blk0 = (first_blk + step) * DL_T;
+            int lo = 16, hi = -1;
+            if (live) {
+                lo = start > blk0 ? (int)(start - blk0) : 0;
+                hi = e - blk0 < 15 ? (int)(e - blk0) : 15;
+            }
+            const bool fast = __builtin_amdgcn_ballot_w64(live && !(lo == 0 && hi == 15 && seen)) == 0;
+            const double *rowP = sP + lane * DL_ROW;
+            const float *rowA = sA + lane * DL_ROW;
+            const signed char *rowS = sS8 + lane * 20;
+            if (fast) {
+                if (live) {
+#pragma unroll
+                for (int j = 0; j < DL_T; ++j) {
+                    const double p = rowP[j];
+                    const double a = (double)rowA[j];
+                    const int sd = (int)rowS[j];
+                    const double sp = sd != ps ? fabs(p - pp) : 0.0;   // base.py:495-500 (max / += of 0.0 change nothing)
+                    mxs = bf_max(mxs, sp);
+                    cs += sp;
+                    pp = p; ps = sd;
+                    const double pv = p * a;
+                    const bool buy = sd == 1, sell = sd == -1;
+                    vb += buy ? a : 0.0; db += buy ? pv : 0.0; nbuy += buy ? 1 : 0;
+                    vs += sell ? a : 0.0; ds += sell ? pv : 0.0; nsell += sell ? 1 : 0;
+                    const double sf = (double)sd;                      // -1, 0, +1: the signed terms are exact
+                    ct += sd; cv += sf * a; cd += sf * pv;
+                    tmin = ct < tmin ? ct : tmin; tmax = ct > tmax ? ct : tmax;    // an unsigned tick repeats a candidate
+                    vmin = bf_min(vmin, cv); vmax = bf_max(vmax, cv);
+                    dmin = bf_min(dmin, cd); dmax = bf_max(dmax, cd);
+                }
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < DL_T; ++j) {
+                    if (j < lo || j > hi) continue;
+                    const double p = rowP[j];
+                    const double a = (double)rowA[j];
+                    const int sd = (int)rowS[j];
+                    if (sd != ps) {
+                        const double sp = fabs(p - pp);
+                        mxs = bf_max(mxs, sp);
+                        cs += sp;
+                    }
+                    pp = p; ps = sd;
+                    const double pv = p * a;
+                    if (sd == 1) { nbuy += 1; vb += a; db += pv; ct += 1; cv += a; cd += pv; }
+                    else if (sd == -1) { nsell += 1; vs += a; ds += pv; ct -= 1; cv -= a; cd -= pv; }
+                    else continue;
+                    seen = true;
+                    tmin = ct < tmin ? ct : tmin; tmax = ct > tmax ? ct : tmax;
+                    vmin = bf_min(vmin, cv); vmax = bf_max(vmax, cv);
+                    dmin = bf_min(dmin, cd); dmax = bf_max(dmax, cd);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- one bar per lane: coalesced stores
+        const bool zero = has && !is_long && nbuy + nsell == 0;
+        const unsigned long long zb = __builtin_amdgcn_ballot_w64(zero);
+        if (zb && lane == 0 && n_zero_div) atomicAdd(n_zero_div, (unsigned long long)__builtin_popcountll(zb));
+        if (has && !is_long) {
+            o.ticks_buy[b] = nbuy; o.ticks_sell[b] = nsell;
+            o.volume_buy[b] = (float)vb; o.volume_sell[b] = (float)vs;
+            o.dollars_buy[b] = (float)db; o.dollars_sell[b] = (float)ds;
+            o.max_spread[b] = (float)mxs;
+            o.mean_spread[b] = nbuy + nsell == 0 ? NAN : (float)(cs / (double)(nbuy + nsell));
+            o.cum_ticks_min[b] = tmin; o.cum_ticks_max[b] = tmax;
+            o.cum_volumes_min[b] = (float)vmin; o.cum_volumes_max[b] = (float)vmax;
+            o.cum_dollars_min[b] = (float)dmin; o.cum_dollars_max[b] = (float)dmax;
+        }
     }
 }
 
@@ -495,9 +691,33 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     unsigned long long *redo;
-    FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 8, (void **)&redo));
+    FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 16, (void **)&redo));
     FMK_HIP(ctx, hipMemsetAsync(redo, 0, 8, ctx->stream));
     const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
+    // One lane per bar when there are enough moderate bars to fill the chip with 64-bar waves (developer knob
+    // FMK_DIR_LANES: 0 never, 2 whenever the layout allows it); float32 amounts, 8- / 4-byte aligned amount / side columns.
+    const char *lv = getenv("FMK_DIR_LANES");
+    const int lanes_mode = lv ? atoi(lv) : 1;
+    const bool lanes_ok = !amount_is_f64 && ((uintptr_t)d_amount & 7) == 0 && ((uintptr_t)d_side & 3) == 0;
+    // measured at 1e9 ticks (profiles/r02_dir_lanes.txt): 20-tick bars 66.5 -> 6.2 ms, 200-tick bars 7.6 -> 3.5 ms, 1 200-tick bars
+    // 3.44 vs 3.53 ms (the two schedules issue the same ~55-60 VALU instructions per 64 ticks there), 12 000-tick bars: wave per bar
+    const bool lanes_fit = nb >= (int64_t)ctx->n_cu * 64 * 4 && n / nb <= 1024;
+    if (lanes_ok && lanes_mode != 0 && (lanes_fit || lanes_mode == 2)) {
+        unsigned long long *long_list = redo + nb + 32;
+        FMK_HIP(ctx, hipMemsetAsync(long_list, 0, 8, ctx->stream));
+        int64_t lblocks = fmk_ceil_div(fmk_ceil_div(nb, 64), DL_WAVES);
+        const int64_t lcap = (int64_t)ctx->n_cu * 40;
+        if (lblocks > lcap) lblocks = lcap;
+        k_bar_dir_lanes<<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side, d_close_idx,
+                                                                             nb, n, o, (unsigned long long *)d_n_zero_div,
+                                                                             long_list, 8192);
+        FMK_LAUNCH_CHECK(ctx);
+        k_bar_dir<false><<<(unsigned)(blocks < 2048 ? blocks : 2048), 256, 0, ctx->stream>>>(
+            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, redo, long_list);
+        k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
     if (amount_is_f64) {
         k_bar_dir<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                  (unsigned long long *)d_n_zero_div, redo);
@@ -537,7 +757,10 @@ extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const
     if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
     static int separate = -1;              // developer knob: FMK_FLOW_SEPARATE=1 keeps the OHLCV kernel apart (A/B timing)
     if (separate < 0) { const char *v = getenv("FMK_FLOW_SEPARATE"); separate = v ? atoi(v) : 0; }
-    if (amount_is_f64 || separate) {
+    // short bars: the fused kernel is a wave-per-bar schedule; comp_bar_ohlcv and the order-flow features each have a
+    // several-bars-per-wave schedule of their own (k_bar_ohlcv_lanes, k_bar_dir_lanes)
+    const bool short_bars = n / (n_idx - 1) < 600;
+    if (amount_is_f64 || separate || short_bars) {
         FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
                                        d_close, d_volume, d_vwap, d_trades, d_median));
         FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,

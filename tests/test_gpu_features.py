@@ -48,6 +48,36 @@ def test_directional_vs_oracle(orc, n, interval, f64, zeros):
         _check_dir(comp_bar_directional_features(px, am, ci, sd), want, f"n={n} iv={interval}")
 
 
+@pytest.mark.parametrize("case", ["t60", "t1", "t7200", "volume", "sparse", "zeros", "tail"])
+def test_directional_lane_per_bar_schedule(orc, monkeypatch, case):
+    """k_bar_dir_lanes (one lane walks one bar in tick order; forced here, the library picks it for >= 64 K moderate bars):
+    non-dyadic float32 amounts, 20-tick to 9 000-tick bars in one call (bars beyond 8 192 ticks go to the wave-per-bar kernel
+    through the list), empty bars, unsigned ticks before a bar's first signed one, a stream that ends inside a 16-tick block."""
+    from finmlkit_amd import _ffi, engine
+    monkeypatch.setenv("FMK_DIR_LANES", "2")
+    n = 700_003 if case == "tail" else 600_000
+    gap = 400_000_000_000 if case == "sparse" else None
+    ts, px, am, sd = orc.synth(23, 0, n, gap) if gap else orc.synth(23, 0, n)
+    rng = np.random.default_rng(4)
+    am = rng.lognormal(-1, 1.3, n).astype(np.float32)
+    if case == "zeros":
+        sd = sd.copy()
+        sd[rng.random(n) < 0.3] = 0
+        sd[:40] = 0
+    if case == "volume":
+        ci = orc._volume_bar_indexer(am.astype(np.float64), float(am.mean()) * 300.0)
+        ci = np.concatenate([ci[:200], ci[260:]])                  # one bar of ~18 000 ticks among ~300-tick bars
+    else:
+        _, ci = orc._time_bar_indexer(ts, {"t1": 1.0, "t7200": 7200.0}.get(case, 60.0))
+    want = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    t = engine.DeviceTrades.from_numpy(ts, px, am, sd)
+    d, nz = t.bar_directional(_ffi.DeviceArray.from_host(t.ctx, ci))
+    got = tuple(d[k].to_host() for k in G.DIR_KEYS)
+    assert int(nz.to_host()[0]) == int(np.isnan(want[6]).sum())
+    for k, g, w in zip(G.DIR_KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=f"{case}:{k}")
+
+
 def test_directional_zero_division(orc):
     from finmlkit_amd.bar.base import comp_bar_directional_features
     ts, px, am, sd = orc.synth(42, 0, 5_000, 500_000_000_000)       # sparse stream: empty bars
