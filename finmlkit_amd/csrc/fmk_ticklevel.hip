@@ -188,6 +188,41 @@ __device__ __forceinline__ EwMap ew_tick_alpha(double alpha, double y)
     return m;
 }
 
+// alpha of one tick, volatility.py:178-179: dt = (t - t_prev) / 1e9; alpha = 1 - exp(-dt / half_life).  The two float64
+// divisions per tick are one multiplication by rate = -1 / (1e9 * half_life) (computed once on the host): the exponent differs
+// from the reference's by <= 3 ulp, exp by < 2e-16 absolute, the outputs by ~1e-13 relative (the contract is 1e-9; measured in
+// tests/test_gpu_ticklevel.py).  With the per-tick divisions, exp twice per tick in the apply pass and four IEEE divisions in
+// ew_sigma the two passes issued 126 + 310 VALU instructions per tick and were bound by them, not by their 40 B/tick.
+// For -1/16 < x <= 0 (a tick gap below half_life / 16: nearly every tick) 1 - exp(x) = -expm1(x) is a degree-10 Taylor
+// polynomial (next term < 5e-18 relative) -- 11 instructions instead of the ~45 of exp, in both passes.  It is also the better
+// number: the reference's 1 - exp(x) carries the rounding of exp(x) ~ 1 (1.1e-16 absolute, i.e. 1e-11 relative of a typical
+// alpha); the two evaluations agree to that 1.1e-16, the same distance as between two correctly working exp implementations.
+__device__ __forceinline__ double ew_alpha(int64_t t_prev, int64_t t_cur, double rate)
+{
+    const double x = (double)(t_cur - t_prev) * rate;
+    if (x > -0.0625 && x <= 0.0) {
+        double q = 1.0 / 3628800.0;
+        q = fma(q, x, 1.0 / 362880.0);
+        q = fma(q, x, 1.0 / 40320.0);
+        q = fma(q, x, 1.0 / 5040.0);
+        q = fma(q, x, 1.0 / 720.0);
+        q = fma(q, x, 1.0 / 120.0);
+        q = fma(q, x, 1.0 / 24.0);
+        q = fma(q, x, 1.0 / 6.0);
+        q = fma(q, x, 0.5);
+        return -fma(q * x, x, x);                                  // -(x + x^2 (1/2 + x/6 + ...))
+    }
+    return 1.0 - exp(x);
+}
+// 1 / x for a positive normal x, correctly rounded in practice: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double ew_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 // MODE 0: ewmst (volatility.py:139-219)   1: ewmst_mean0 (:72-136)   2: ewms (:9-69; fixed alpha, no timestamps --
 // `half_life` then carries one_minus_alpha and the four states are Sw, Sw2, Sy, Sy2)
 // the reference's per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52)
@@ -206,27 +241,23 @@ __device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y
         m.bSyy = nan ? 0.0 : y * y;
         return m;
     }
-    const double dt = (double)(t_cur - t_prev) / 1e9;
-    const double alpha = 1.0 - exp(-dt / half_life);
-    return ew_tick_alpha<MODE>(alpha, y);
+    return ew_tick_alpha<MODE>(ew_alpha(t_prev, t_cur, half_life), y);      // MODE 0 / 1: `half_life` carries the rate
 }
 
-// sequentially apply one tick to a state, in the reference's exact operation order
+// sequentially apply one tick to a state, in the reference's operation order; `alpha` is the tick's alpha (MODE 2: the fixed
+// 1 - alpha) as the map phase computed it -- exp is evaluated once per tick and pass
 template <int MODE>
-__device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, double &Syy, int64_t t_prev, int64_t t_cur,
-                                        double y, double half_life)
+__device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, double &Syy, double alpha, double y)
 {
     const bool nan = isnan(y);
     if constexpr (MODE == 2) {
-        const double om = half_life, w = nan ? 0.0 : 1.0;
+        const double om = alpha, w = nan ? 0.0 : 1.0;
         V = om * V + w;
         V2 = (om * om) * V2 + w;
         if (nan) { Sy = om * Sy; Syy = om * Syy; }
         else { Sy = om * Sy + y; Syy = om * Syy + y * y; }
         return;
     }
-    const double dt = (double)(t_cur - t_prev) / 1e9;
-    const double alpha = 1.0 - exp(-dt / half_life);
     const double om = 1.0 - alpha;
     if constexpr (MODE == 1) {
         if (nan) { Syy = om * Syy; V = om * V; }
@@ -239,29 +270,43 @@ __device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, doubl
     }
 }
 
+// x / v for positive normal v with r = ew_rcp(v): the product corrected by its exact remainder (Markstein's last step -- what the
+// hardware's own v_div_fmas sequence does, minus the range scaling these operands do not need).  The quotient is the correctly
+// rounded one, which matters here: e2 - mean * mean and V - V2 / V cancel to EXACTLY 0 for a window with one valid sample in the
+// reference, and "== 0" decides between 0.0 / NaN and a 1e-13 residue.  Three quotients by V share one reciprocal:
+// 5 + 3 x 3 instructions instead of three ~11-instruction IEEE divisions.
+__device__ __forceinline__ double ew_div(double x, double v, double r)
+{
+    const double q = x * r;
+    return fma(fma(-q, v, x), r, q);
+}
+
+// The reference's closing expressions (volatility.py:54-67 / 127-133 / 204-217).
 template <int MODE>
 __device__ __forceinline__ double ew_sigma(double V, double V2, double Sy, double Syy, double sigma_floor)
 {
     if constexpr (MODE == 2) {                    // volatility.py:54-67
         if (!(V > 0.0)) return NAN;
-        const double mean = Sy / V;
-        const double den = V - (V2 / V);
+        const double rV = ew_rcp(V);
+        const double mean = ew_div(Sy, V, rV);
+        const double den = V - ew_div(V2, V, rV);
         if (!(den > 0.0)) return NAN;
-        double var = (Syy / V - mean * mean) * V / den;
+        double var = ew_div((ew_div(Syy, V, rV) - mean * mean) * V, den, ew_rcp(den));
         if (!(var > 0.0)) var = isnan(var) ? var : 0.0;
         return sqrt(var);
     } else if constexpr (MODE == 1) {
-        double var = V > 0.0 ? Syy / V : NAN;     // volatility.py:127-133
+        double var = V > 0.0 ? ew_div(Syy, V, ew_rcp(V)) : NAN;     // volatility.py:127-133
         if (var < 0.0) var = 0.0;
         double s = sqrt(var);
         if (s < sigma_floor) s = sigma_floor;
         return s;
     } else {
         if (!(V > 0.0)) return NAN;               // volatility.py:204-217
-        const double mean = Sy / V, e2 = Syy / V;
+        const double rV = ew_rcp(V);
+        const double mean = ew_div(Sy, V, rV), e2 = ew_div(Syy, V, rV);
         const double var_raw = e2 - mean * mean;
-        const double denom = V - (V2 / V);
-        const double var = (denom > 0.0 && var_raw > 0.0) ? var_raw * (V / denom) : 0.0;
+        const double denom = V - ew_div(V2, V, rV);
+        const double var = (denom > 0.0 && var_raw > 0.0) ? var_raw * ew_div(V, denom, ew_rcp(denom)) : 0.0;
         double s = sqrt(var);
         if (s < sigma_floor) s = sigma_floor;
         return s;
@@ -337,9 +382,10 @@ __device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, con
 
 #define EW_LDS_ELEMS (EW_THREADS * 9)
 
+// al[k]: the tick's alpha (MODE 2: the fixed 1 - alpha), kept for the apply phase
 template <int MODE>
 __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], const double (&yl)[EW_ITEMS],
-                                               int64_t tprev0, int64_t n, double half_life)
+                                               int64_t tprev0, int64_t n, double half_life, double (&al)[EW_ITEMS])
 {
     const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
     EwMap m = ew_identity();
@@ -347,8 +393,13 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k) {
         const int64_t i = i0 + k;
+        al[k] = MODE == 2 ? half_life : 0.0;
         if (i >= (MODE == 2 ? 0 : 1) && i < n) {          // ewms has no skipped first tick
-            m = ew_compose(m, ew_tick<MODE>(tprev, tl[k], yl[k], half_life));
+            if constexpr (MODE == 2) m = ew_compose(m, ew_tick<MODE>(tprev, tl[k], yl[k], half_life));
+            else {
+                al[k] = ew_alpha(tprev, tl[k], half_life);
+                m = ew_compose(m, ew_tick_alpha<MODE>(al[k], yl[k]));
+            }
             tprev = tl[k];
         } else if (i == 0 && n > 0) {
             tprev = tl[k];
@@ -368,7 +419,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__re
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
     ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
-    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life);
+    double al[EW_ITEMS];
+    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
     EwMap tot;
     (void)ew_block_exclusive(m, lds, &tot);
     if (threadIdx.x == 0) tile_map[blockIdx.x] = tot;
@@ -430,7 +482,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
     ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
-    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life);
+    double al[EW_ITEMS];
+    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     ex = ew_compose(tile_pre[blockIdx.x], ex);
@@ -441,7 +494,6 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
         V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
         Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
     }
-    int64_t tprev = tprev0;
     const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
     double res[EW_ITEMS];
 #pragma unroll
@@ -449,9 +501,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
         const int64_t i = i0 + k;
         res[k] = NAN;                                              // volatility.py:174 (out[0])
         if (i >= n) continue;
-        if (MODE != 2 && i == 0) { tprev = tl[k]; continue; }
-        ew_step<MODE>(V, V2, Sy, Syy, tprev, tl[k], yl[k], half_life);
-        tprev = tl[k];
+        if (MODE != 2 && i == 0) continue;
+        ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
         res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
     }
     // coalesced store through the (now free) LDS tile
@@ -561,8 +612,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__rest
                         t = ew_tick<MODE>(tprev, tl[k], yl[k], half_life);
                         al[k] = half_life;
                     } else {
-                        const double dt = (double)(tl[k] - tprev) / 1e9;
-                        al[k] = 1.0 - exp(-dt / half_life);            // volatility.py:178-179, evaluated ONCE per tick
+                        al[k] = ew_alpha(tprev, tl[k], half_life);     // volatility.py:178-179, evaluated ONCE per tick
                         t = ew_tick_alpha<MODE>(al[k], yl[k]);
                     }
                     m = ew_compose(m, t);
@@ -671,6 +721,8 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
                   double sigma_floor, double *d_out, const double *d_state_in = nullptr, double *d_map_out = nullptr)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    // the kernels take the decay RATE for the time-stamped modes (ew_alpha), the fixed 1 - alpha for ewms
+    if (MODE != 2) half_life = -1.0 / (1e9 * half_life);
     const int64_t tiles = fmk_ceil_div(n, EW_TILE);
     // tile maps + the (geometrically shrinking) group maps of the hierarchical scan
     int64_t work_maps = 0;
