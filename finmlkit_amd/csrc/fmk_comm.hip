@@ -26,6 +26,9 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <thread>
+
 #include "fmk_common.h"
 
 namespace {
@@ -449,12 +452,81 @@ int fmk_comm_create(fmk_ctx *ctx, int transport, const char *rendezvous_path, in
             snprintf(c->err, sizeof c->err, "comm stream/events: %s", hipGetErrorString(e));
             return fail(FMK_E_HIP);
         }
-        int r = g_rccl.CommInitRank(&c->nccl, world, all[0].id, rank);
-        if (r != 0) {
-            c->nccl = nullptr;
-            snprintf(c->err, sizeof c->err, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
-            return fail(FMK_E_COMM);
+        // ncclCommInitRank and the first exchange are where a broken fabric shows (IPC handles, P2P mappings): both run under
+        // a deadline, and the ranks AGREE on the outcome before anyone returns -- a rank that came through must not be left
+        // waiting in a later ncclRecv for a neighbour that has already fallen back to the host transport.
+        struct Init { std::atomic<int> done{0}; int rc = 0; nccl_comm comm = nullptr; };
+        Init *init = new Init;                                    // leaked on purpose if the call never returns
+        const nccl_unique_id uid = all[0].id;
+        const int dev = ctx->device;
+        std::thread th([init, uid, world, rank, dev]() {
+            (void)hipSetDevice(dev);
+            init->rc = g_rccl.CommInitRank(&init->comm, world, uid, rank);
+            init->done.store(1, std::memory_order_release);
+        });
+        int my_ok = 1;
+        why[0] = 0;
+        {
+            const double deadline = now_s() + c->timeout_s;
+            int spins = 0;
+            while (!init->done.load(std::memory_order_acquire) && now_s() < deadline) relax(spins);
+            if (!init->done.load(std::memory_order_acquire)) {
+                th.detach();
+                my_ok = 0;
+                snprintf(why, sizeof why, "ncclCommInitRank(rank %d of %d) did not return within %.0f s", rank, world, c->timeout_s);
+            } else {
+                th.join();
+                if (init->rc != 0) {
+                    my_ok = 0;
+                    snprintf(why, sizeof why, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(init->rc));
+                } else c->nccl = init->comm;
+                delete init;
+            }
         }
+        // one 8-byte exchange with the neighbours the step will talk to
+        const bool loop = (flags & FMK_COMM_SELF_LOOP) && world == 1;
+        const int to = loop ? 0 : (rank + 1 < world ? rank + 1 : -1), from = loop ? 0 : (rank > 0 ? rank - 1 : -1);
+        void *probe = nullptr;
+        if (my_ok && (to >= 0 || from >= 0)) {
+            hipError_t e2 = hipMalloc(&probe, 16);
+            int r = 0;
+            if (e2 == hipSuccess) {
+                r = g_rccl.GroupStart();
+                if (!r && to >= 0) r = g_rccl.Send(probe, 8, 0, to, c->nccl, c->stream);
+                if (!r && from >= 0) r = g_rccl.Recv((char *)probe + 8, 8, 0, from, c->nccl, c->stream);
+                const int r2 = g_rccl.GroupEnd();
+                if (!r) r = r2;
+            }
+            if (e2 != hipSuccess || r != 0) {
+                my_ok = 0;
+                snprintf(why, sizeof why, "first RCCL exchange (rank %d): %s", rank,
+                         e2 != hipSuccess ? hipGetErrorString(e2) : g_rccl.GetErrorString(r));
+            } else {
+                const double deadline = now_s() + c->timeout_s;
+                int spins = 0;
+                hipError_t q;
+                while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady && now_s() < deadline) relax(spins);
+                if (q != hipSuccess) {
+                    my_ok = 0;
+                    snprintf(why, sizeof why, "first RCCL exchange (rank %d) %s", rank,
+                             q == hipErrorNotReady ? "did not complete in time" : hipGetErrorString(q));
+                }
+            }
+        }
+        int oks[MAX_WORLD];
+        rc = gather(c, &my_ok, sizeof my_ok, oks);
+        if (rc != FMK_OK) return fail(rc);
+        for (int r = 0; r < world; ++r)
+            if (!oks[r]) {
+                snprintf(c->err, sizeof c->err, "RCCL transport failed on rank %d%s%s", r, r == rank ? ": " : "", r == rank ? why : "");
+                // what may be stuck is left behind, not destroyed: ncclCommDestroy can wait for the peers, and a stream with an
+                // exchange that never completes cannot be synchronised (fmk_comm_destroy does both)
+                c->nccl = nullptr;
+                if (!my_ok) c->stream = nullptr;
+                if (my_ok && probe) (void)hipFree(probe);
+                return fail(FMK_E_COMM);
+            }
+        if (probe) (void)hipFree(probe);
     }
     *out = c;
     return FMK_OK;

@@ -218,3 +218,43 @@ def test_rccl_self_loop_one_rank(tmp_path):
     for k in KEYS:
         np.testing.assert_array_equal(p[k], want[k], err_msg=k)
     np.testing.assert_array_equal(p["loop_trades"], p["loop_expect"])
+
+
+def _rccl_pair_worker(rank, world, path, out_dir):
+    os.environ["FMK_DEVICE"] = "0"                              # two ranks on ONE device: RCCL refuses (or not) -- for both
+    from finmlkit_amd import _ffi, dist
+    ctx = _ffi.default_context()
+    outcome = "ok"
+    try:
+        comm = dist.Comm(ctx, rank, world, path, "rccl", ring_bytes=8192, timeout_s=25.0)
+        comm.barrier()
+        comm.close()
+    except _ffi.FmkError as e:
+        outcome = f"error: {e}"
+        # what bench.py does next: the same step over the host-staged transport, on every rank
+        comm = dist.Comm(ctx, rank, world, path + ".host", "host", ring_bytes=8192, timeout_s=25.0)
+        comm.barrier()
+        comm.close()
+    with open(os.path.join(out_dir, f"outcome{rank}.txt"), "w") as f:
+        f.write(outcome)
+
+
+def test_rccl_two_ranks_on_one_device_agree_on_the_outcome(tmp_path):
+    """Two processes ask for the RCCL transport on the box's single GPU.  Whatever librccl makes of that (it normally rejects
+    two ranks on one device), BOTH ranks must come out of fmk_comm_create the same way and within the deadline -- communicator
+    creation and the first exchange run under a watchdog and the ranks agree on the result before anyone returns -- so that
+    the host-staged fallback of bench.py is taken by all ranks or by none."""
+    mpx = mp.get_context("spawn")
+    procs = [mpx.Process(target=_rccl_pair_worker, args=(r, 2, str(tmp_path / "rdv"), str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank hung in the RCCL rendezvous")
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    outcomes = [open(tmp_path / f"outcome{r}.txt").read() for r in range(2)]
+    print("outcomes:", outcomes)
+    assert outcomes[0].startswith("ok") == outcomes[1].startswith("ok")
