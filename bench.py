@@ -176,6 +176,26 @@ def other_configs(trades, ctx, args):
         nb1 = ci1.n - 1
         out["resample_1s_to_1min_ms"], out["resample_n_rows"] = _time_resample(ctx, timed, clock1, o1, nb1), nb1
         del o1, clock1, ci1
+        # "next" rows: the QuickStart chain lagged returns -> ewmst -> CUSUM bars (CUSUMBarKit's default sigma_floor 5e-4: on this
+        # quiet tape a close per 2.4e5 ticks, served by the chain walk of fmk_cusum_chain.hip; 1e-5: a close per ~200 ticks, the
+        # fixed point), and the order-flow features on the 1-second bars of io.py:484 (one lane per bar)
+        ret = trades.lagged_returns(5.0, True)
+        out["lagged_returns_5s_ms"] = timed(lambda: trades.lagged_returns(5.0, True))
+        sig = trades.ewmst(ret, 60.0)
+        out["ewmst_60s_ms"] = timed(lambda: trades.ewmst(ret, 60.0))
+        del ret
+        cus = DeviceArray(ctx, 8_000_000 if n >= 1_000_000_000 else max(n, 16), np.int64)
+        m, rounds = c_i64(), c_i64()
+        for key, floor in (("cusum_default_floor_5e-4", 5e-4), ("cusum_floor_1e-5", 1e-5)):
+            def run(floor=floor):
+                ctx.call("fmk_cusum_bar_indexer_dev", trades.ts.p, trades.price.p, sig.p, c_i64(n), C.c_double(floor),
+                         C.c_double(2.0), cus.p, c_i64(cus.n), C.byref(m), C.byref(rounds))
+            out[key + "_ms"] = timed(run)
+            out[key + "_closes"] = int(m.value) - 1
+        del sig, cus
+        clock1, ci1 = trades.time_bar_index(1.0)
+        out["directional_1s_bars_ms"] = timed(lambda: trades.bar_directional(ci1))
+        del clock1, ci1
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only
