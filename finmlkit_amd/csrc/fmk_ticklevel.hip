@@ -188,30 +188,28 @@ __device__ __forceinline__ EwMap ew_tick_alpha(double alpha, double y)
     return m;
 }
 
-// alpha of one tick, volatility.py:178-179: dt = (t - t_prev) / 1e9; alpha = 1 - exp(-dt / half_life).  The two float64
-// divisions per tick are one multiplication by rate = -1 / (1e9 * half_life) (computed once on the host): the exponent differs
-// from the reference's by <= 3 ulp, exp by < 2e-16 absolute, the outputs by ~1e-13 relative (the contract is 1e-9; measured in
-// tests/test_gpu_ticklevel.py).  With the per-tick divisions, exp twice per tick in the apply pass and four IEEE divisions in
-// ew_sigma the two passes issued 126 + 310 VALU instructions per tick and were bound by them, not by their 40 B/tick.
-// For -1/16 < x <= 0 (a tick gap below half_life / 16: nearly every tick) 1 - exp(x) = -expm1(x) is a degree-10 Taylor
-// polynomial (next term < 5e-18 relative) -- 11 instructions instead of the ~45 of exp, in both passes.  It is also the better
-// number: the reference's 1 - exp(x) carries the rounding of exp(x) ~ 1 (1.1e-16 absolute, i.e. 1e-11 relative of a typical
-// alpha); the two evaluations agree to that 1.1e-16, the same distance as between two correctly working exp implementations.
-__device__ __forceinline__ double ew_alpha(int64_t t_prev, int64_t t_cur, double rate)
+// x / v for positive normal v with r = RN(1 / v): the product corrected by its exact remainder (Markstein's last step -- what
+// the hardware's own v_div_fmas sequence does, minus the range scaling these operands do not need): the correctly rounded
+// quotient, i.e. the IEEE division's result, in 3 instructions instead of ~11.
+__device__ __forceinline__ double ew_div(double x, double v, double r)
 {
-    const double x = (double)(t_cur - t_prev) * rate;
-    if (x > -0.0625 && x <= 0.0) {
-        double q = 1.0 / 3628800.0;
-        q = fma(q, x, 1.0 / 362880.0);
-        q = fma(q, x, 1.0 / 40320.0);
-        q = fma(q, x, 1.0 / 5040.0);
-        q = fma(q, x, 1.0 / 720.0);
-        q = fma(q, x, 1.0 / 120.0);
-        q = fma(q, x, 1.0 / 24.0);
-        q = fma(q, x, 1.0 / 6.0);
-        q = fma(q, x, 0.5);
-        return -fma(q * x, x, x);                                  // -(x + x^2 (1/2 + x/6 + ...))
-    }
+    const double q = x * r;
+    return fma(fma(-q, v, x), r, q);
+}
+
+// The time constant of MODE 0 / 1 with its correctly rounded reciprocal from the host (r == 0: an odd half life -- zero,
+// negative, non-finite, an all-ones significand -- takes the plain divisions); MODE 2: `hl` is the fixed 1 - alpha.
+struct EwHl { double hl, r; };
+
+// alpha of one tick, volatility.py:178-179: dt = (t - t_prev) / 1e9; alpha = 1 - exp(-dt / half_life) -- the reference's two
+// divisions as correctly rounded quotients (same bits), then the library exp.  Parity note: for gaps of nanoseconds against a
+// half life of seconds exp(x) is 1 - k * 2^-53 with a single-digit k and the reference's alpha carries a relative error of 1e-2
+// ... 1e-7; a MORE accurate alpha (a polynomial for -expm1 was tried: 11 instructions instead of exp's ~45) moves the outputs by
+// up to 4e-7 relative and fails the parity fuzz -- the reference's rounding is part of its result.
+__device__ __forceinline__ double ew_alpha(int64_t t_prev, int64_t t_cur, EwHl h)
+{
+    const double dt = ew_div((double)(t_cur - t_prev), 1e9, 1e-9);        // 1e-9 == RN(1 / 1e9)
+    const double x = h.r != 0.0 ? -ew_div(dt, h.hl, h.r) : -dt / h.hl;
     return 1.0 - exp(x);
 }
 // 1 / x for a positive normal x, correctly rounded in practice: v_rcp_f64 and two Newton steps
@@ -227,12 +225,12 @@ __device__ __forceinline__ double ew_rcp(double x)
 // `half_life` then carries one_minus_alpha and the four states are Sw, Sw2, Sy, Sy2)
 // the reference's per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52)
 template <int MODE>
-__device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y, double half_life)
+__device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y, EwHl half_life)
 {
     const bool nan = isnan(y);
     EwMap m;
     if constexpr (MODE == 2) {
-        const double om = half_life;
+        const double om = half_life.hl;
         m.a = om;
         m.a2 = om * om;
         m.bV = nan ? 0.0 : 1.0;
@@ -241,7 +239,7 @@ __device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y
         m.bSyy = nan ? 0.0 : y * y;
         return m;
     }
-    return ew_tick_alpha<MODE>(ew_alpha(t_prev, t_cur, half_life), y);      // MODE 0 / 1: `half_life` carries the rate
+    return ew_tick_alpha<MODE>(ew_alpha(t_prev, t_cur, half_life), y);
 }
 
 // sequentially apply one tick to a state, in the reference's operation order; `alpha` is the tick's alpha (MODE 2: the fixed
@@ -270,17 +268,9 @@ __device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, doubl
     }
 }
 
-// x / v for positive normal v with r = ew_rcp(v): the product corrected by its exact remainder (Markstein's last step -- what the
-// hardware's own v_div_fmas sequence does, minus the range scaling these operands do not need).  The quotient is the correctly
-// rounded one, which matters here: e2 - mean * mean and V - V2 / V cancel to EXACTLY 0 for a window with one valid sample in the
-// reference, and "== 0" decides between 0.0 / NaN and a 1e-13 residue.  Three quotients by V share one reciprocal:
-// 5 + 3 x 3 instructions instead of three ~11-instruction IEEE divisions.
-__device__ __forceinline__ double ew_div(double x, double v, double r)
-{
-    const double q = x * r;
-    return fma(fma(-q, v, x), r, q);
-}
-
+// The closing quotients use ew_div with ONE refined reciprocal per divisor (three quotients by V share it: 5 + 3 x 3 instructions
+// instead of three ~11-instruction IEEE divisions).  Correct rounding matters here: e2 - mean * mean and V - V2 / V cancel to
+// EXACTLY 0 for a window with one valid sample in the reference, and "== 0" decides between 0.0 / NaN and a 1e-13 residue.
 // The reference's closing expressions (volatility.py:54-67 / 127-133 / 204-217).
 template <int MODE>
 __device__ __forceinline__ double ew_sigma(double V, double V2, double Sy, double Syy, double sigma_floor)
@@ -385,7 +375,7 @@ __device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, con
 // al[k]: the tick's alpha (MODE 2: the fixed 1 - alpha), kept for the apply phase
 template <int MODE>
 __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], const double (&yl)[EW_ITEMS],
-                                               int64_t tprev0, int64_t n, double half_life, double (&al)[EW_ITEMS])
+                                               int64_t tprev0, int64_t n, EwHl half_life, double (&al)[EW_ITEMS])
 {
     const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
     EwMap m = ew_identity();
@@ -393,7 +383,7 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k) {
         const int64_t i = i0 + k;
-        al[k] = MODE == 2 ? half_life : 0.0;
+        al[k] = MODE == 2 ? half_life.hl : 0.0;
         if (i >= (MODE == 2 ? 0 : 1) && i < n) {          // ewms has no skipped first tick
             if constexpr (MODE == 2) m = ew_compose(m, ew_tick<MODE>(tprev, tl[k], yl[k], half_life));
             else {
@@ -411,7 +401,7 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__restrict__ ts,
                                                              const double *__restrict__ y, int64_t n,
-                                                             double half_life, EwMap *__restrict__ tile_map)
+                                                             EwHl half_life, EwMap *__restrict__ tile_map)
 {
     __shared__ EwMap lds[4];
     __shared__ int64_t s_ts[EW_LDS_ELEMS];
@@ -471,7 +461,7 @@ static int ew_scan_maps(fmk_ctx *ctx, EwMap *maps, int64_t m, EwMap *work)
 
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
-                                                         int64_t n, double half_life, double sigma_floor,
+                                                         int64_t n, EwHl half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
                                                          const double *__restrict__ state_in,
                                                          double *__restrict__ out)
@@ -563,7 +553,7 @@ __device__ __forceinline__ bool ew_sweep(unsigned long long *g, EwMap &m, int la
 
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__restrict__ ts, const double *__restrict__ y,
-                                                           int64_t n, double half_life, double sigma_floor,
+                                                           int64_t n, EwHl half_life, double sigma_floor,
                                                            const double *__restrict__ state_in, double *__restrict__ out,
                                                            unsigned long long *gran /*[tiles][2][EW_GRAN]*/, int64_t tiles,
                                                            int64_t *err_word)
@@ -610,7 +600,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__rest
                     EwMap t;
                     if constexpr (MODE == 2) {
                         t = ew_tick<MODE>(tprev, tl[k], yl[k], half_life);
-                        al[k] = half_life;
+                        al[k] = half_life.hl;
                     } else {
                         al[k] = ew_alpha(tprev, tl[k], half_life);     // volatility.py:178-179, evaluated ONCE per tick
                         t = ew_tick_alpha<MODE>(al[k], yl[k]);
@@ -722,7 +712,13 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     // the kernels take the decay RATE for the time-stamped modes (ew_alpha), the fixed 1 - alpha for ewms
-    if (MODE != 2) half_life = -1.0 / (1e9 * half_life);
+    // MODE 0 / 1: the half life with its correctly rounded reciprocal (ew_alpha); MODE 2: the fixed 1 - alpha
+    EwHl hl{half_life, 0.0};
+    if (MODE != 2 && half_life > 0.0 && half_life < 1e300 && half_life > 1e-300) {
+        unsigned long long bits;
+        memcpy(&bits, &half_life, 8);
+        if ((bits & 0xFFFFFFFFFFFFFULL) != 0xFFFFFFFFFFFFFULL) hl.r = 1.0 / half_life;
+    }
     const int64_t tiles = fmk_ceil_div(n, EW_TILE);
     // tile maps + the (geometrically shrinking) group maps of the hierarchical scan
     int64_t work_maps = 0;
@@ -752,7 +748,7 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         }
         int64_t grid = (int64_t)ctx->n_cu * per_cu;  // every workgroup resident at once: the look-back cannot starve
         if (grid > tiles) grid = tiles;
-        k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, d_state_in, d_out,
+        k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out,
                                                                           (unsigned long long *)scr, tiles, ctx->h_mail + 40);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
@@ -760,7 +756,7 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     FMK_TRY(fmk_scratch(ctx, (size_t)(tiles + work_maps + 2) * sizeof(EwMap), &scr));
     EwMap *tm = (EwMap *)scr;
     EwMap *work = tm + tiles;
-    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, tm);
+    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, tm);
     FMK_LAUNCH_CHECK(ctx);
     if (d_map_out) {
         k_ew_total<<<1, EW_THREADS, 0, ctx->stream>>>(tm, tiles, d_map_out);
@@ -768,7 +764,7 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         return FMK_OK;
     }
     FMK_TRY(ew_scan_maps(ctx, tm, tiles, work));
-    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, half_life, sigma_floor, tm, d_state_in,
+    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, tm, d_state_in,
                                                                      d_out);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;

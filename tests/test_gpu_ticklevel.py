@@ -164,13 +164,12 @@ def test_tick_level_chain_reference_vectors(orc):
 
 @pytest.mark.parametrize("hl", [0.05, 5.0, 600.0])
 def test_ewmst_deviation_from_the_sequential_loop(orc, hl):
-    """The device path replaces the reference's per-tick divisions by one multiplication (rate = -1 / (1e9 half_life)), 1 - exp(x)
-    by a polynomial for small |x| and the four divisions of the closing expression by correctly rounded reciprocal quotients
-    (fmk_ticklevel.hip: ew_alpha, ew_div), and it enters every tile through composed affine maps.  Contract 1e-9; observed:
+    """The device path computes every division of the reference as a correctly rounded reciprocal quotient (fmk_ticklevel.hip:
+    ew_div; same bits as the IEEE division) and enters every tile through composed affine maps.  Contract 1e-9; observed:
     99.9 % of the ticks within 1e-12, NaN positions and exact zeros identical.  The one place a larger RELATIVE figure shows up
-    is a sigma that is itself a cancellation residue (half_life 0.05 s: one tick at 1.1e-9 where its neighbours are 1e-6; both
-    builds, before and after the instruction diet, give 2.75e-9 there -- 3e-18 absolute), so the bound on the maximum is taken
-    against the series' typical magnitude (tools/ewdev.py prints the table)."""
+    is a sigma that is itself a cancellation residue (half_life 0.05 s: one tick at 1.1e-9 where its neighbours are 1e-6:
+    2.75e-9 there -- 3e-18 absolute), so the bound on the maximum is taken against the series' typical magnitude
+    (tools/ewdev.py prints the table)."""
     from finmlkit_amd.feature.core.volatility import ewmst, ewmst_mean0
     ts, px, am, sd = orc.synth(33, 0, 1_000_000)
     r = orc.comp_lagged_returns(ts, px, 2.0, True)
