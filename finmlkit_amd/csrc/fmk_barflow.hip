@@ -821,5 +821,5 @@ extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, cons
                                          d_n_zero_div));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
-                                       max_levels, d_fp, d_n_bad_level);
+                                       max_levels, d_fp, d_n_bad_level, n);
 }

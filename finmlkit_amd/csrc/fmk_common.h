@@ -51,7 +51,8 @@ void fmk_threshold_trim(fmk_ctx *ctx);
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
-                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level);
+                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
+                                int64_t n_ticks /* 0: unknown */);
 
 #define FMK_HIP(ctx, expr)                                                                   \
     do {                                                                                     \

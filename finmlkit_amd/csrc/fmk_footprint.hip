@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256) void k_fp_level_counts(const double *__restric
         if (L < 0) L = 0;
         counts[i] = L;
     }
+    // the atomic is attempted only when it would raise the current maximum: issued unconditionally it was one same-address
+    // atomic per wave -- 7.8e5 of them at ~10 ns for the 5e7 one-second bars of a 1e9-tick tape: 8.9 ms for a 1.2 GB pass
     int64_t m = fmk_wave_max(L);
-    if (fmk_lane() == 0 && m > 0) atomicMax(max_levels, (unsigned long long)m);
+    if (fmk_lane() == 0 && m > 0 && (unsigned long long)m > __atomic_load_n(max_levels, __ATOMIC_RELAXED))
+        atomicMax(max_levels, (unsigned long long)m);
 }
 
 extern "C" int fmk_comp_bar_footprints_size_dev(fmk_ctx *ctx, const double *d_bar_lows, const double *d_bar_highs,
@@ -344,7 +347,8 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const double *__restrict__ lows, double imb_mult,
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
                                                         FpOut o, unsigned long long *n_bad, int force_ordered,
-                                                        unsigned char *gscratch, int lean)
+                                                        unsigned char *gscratch, int lean,
+                                                        const unsigned long long *only = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
@@ -364,7 +368,10 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     const double inv_tick = 1.0 / tick;
     int wq = FP_Q_UNKNOWN;        // quantum exponent the previous bar of this wave certified with
-    for (int64_t b = wave0; b < nb; b += nwaves) {
+    // `only` (list mode: [0] = count, [32...] = bar numbers): the bars k_bar_footprints_lanes left to this schedule
+    const int64_t todo = only ? (int64_t)only[0] : nb;
+    for (int64_t it = wave0; it < todo; it += nwaves) {
+        const int64_t b = only ? fmk_uniform((int64_t)only[32 + it]) : it;
         const int64_t base = fmk_uniform(off[b]);
         const int L = (int)fmk_uniform(off[b + 1] - base);
         if (L <= lmin || L > lmax) continue;          // handled by another launch (or L == 0)
@@ -414,10 +421,245 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ONE LANE PER BAR (round 2, float32 amounts): footprints of streams of very short bars (1-second bars: ~20 ticks, 2-4
+// price levels).  The wave-per-bar kernel above spends a whole wave -- tile loads, histogram reset, the level passes of
+// fp_emit_bar with their wave scans -- on 20 ticks: 53.8 ms per 1e9 ticks of 1-second bars against 3.5 ms for 1-minute bars.
+// Here a wave takes 64 consecutive bars; lane l runs the reference's loops for bar l (base.py:700-719 over its ticks,
+// comp_footprint_features over its <= FL_MAXL levels) on a private histogram in its registers, so the float32 level sums are
+// added in tick order by construction and the level statistics are plain sequential code: NumPy's pairwise float32 sum degenerates to its n < 8 loop / its one 8-accumulator fold.  Ticks arrive like in
+// k_bar_dir_lanes (fmk_barflow.hip): per step the wave stages each lane's 16-tick aligned block, 16 / 8 / 4 coalesced load
+// instructions into registers one step ahead, LDS rows padded 16 -> 17.
+// Bars with more than FL_MAXL levels or more than `max_len` ticks go on a list for the wave-per-bar kernel (list mode).
+// ---------------------------------------------------------------------------------------
+#define FL_MAXL 8
+#define FL_T 16
+#define FL_ROW 17
+#define FL_WAVES 2
+__device__ __forceinline__ float fl_pairwise(const float (&a)[FL_MAXL], int n)      // np.sum of n <= 8 float32
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+__global__ __launch_bounds__(64 * FL_WAVES) void k_bar_footprints_lanes(const double *__restrict__ price,
+                                                                       const float *__restrict__ amount,
+                                                                       const int8_t *__restrict__ side,
+                                                                       const int64_t *__restrict__ ci, int64_t nb, double tick,
+                                                                       const double *__restrict__ lows, double imb_mult,
+                                                                       const int64_t *__restrict__ off, FpOut o,
+                                                                       unsigned long long *n_bad,
+                                                                       unsigned long long *__restrict__ grp_mask,
+                                                                       int64_t *__restrict__ grp_cnt, int64_t max_len)
+{
+    __shared__ double s_p[FL_WAVES][64 * FL_ROW];
+    __shared__ float s_a[FL_WAVES][64 * FL_ROW];
+    __shared__ uint32_t s_s[FL_WAVES][64 * 5];
+    __shared__ int64_t s_blk[FL_WAVES][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    double *sP = s_p[wib];
+    float *sA = s_a[wib];
+    uint32_t *sS = s_s[wib];
+    const signed char *sS8 = (const signed char *)sS;
+    int64_t *sB = s_blk[wib];
+    const int64_t nwaves = (int64_t)gridDim.x * FL_WAVES;
+    const double inv_tick = 1.0 / tick;
+    const int64_t last_tick = ci[nb];                                   // no bar reaches beyond it: the bound of every load
+    for (int64_t w = (int64_t)blockIdx.x * FL_WAVES + wib; w * 64 < nb; w += nwaves) {
+        const int64_t b = w * 64 + lane;
+        const bool has = b < nb;
+        const int64_t s = has ? ci[b] : 0, e = has ? ci[b + 1] : 0;
+        const int64_t base = has ? off[b] : 0;
+        const int64_t L64 = has ? off[b + 1] - base : 0;
+        const int64_t len = e - s;
+        const bool mine = has && L64 >= 1 && L64 <= FL_MAXL && len <= max_len;
+        const bool other = has && L64 >= 1 && !mine;                    // L == 0: no rows, nothing written (as the wave kernel)
+        // which of the 64 bars stay for the wave-per-bar kernel: one mask and one count per group, compacted into a list by a
+        // scan afterwards (k_fl_compact) -- an atomicAdd on one list counter per wave was 7.8e5 same-address atomics for 5e7 bars
+        const unsigned long long ob = __builtin_amdgcn_ballot_w64(other);
+        if (lane == 0) { grp_mask[w] = ob; grp_cnt[w] = __builtin_popcountll(ob); }
+        const int L = mine ? (int)L64 : 0;
+        const int ilow = mine ? (int)fp_level(lows[b], tick) : 0;
+        // the lane's histogram lives in REGISTERS (slot = 2 * level + side; 16 float32 sums, 16 counts): a tick updates it
+        // with 16 compare / select / add triples.  An LDS histogram ([slot][lane], read-modify-write per tick) was built
+        // first: two dependent LDS round trips per tick at 6 waves per CU -- 23 ms per 1e9 ticks of 1-second bars.
+        float hv[2 * FL_MAXL];
+        int hc[2 * FL_MAXL];
+#pragma unroll
+        for (int k = 0; k < 2 * FL_MAXL; ++k) { hv[k] = 0.f; hc[k] = 0; }
+        const bool active = mine && len > 0;
+        const int64_t start = s + 1;
+        const int64_t first_blk = start >> 4;
+        const int nsteps = active ? (int)((e >> 4) - first_blk + 1) : 0;
+        const int steps = fmk_dpp_reduce(nsteps, 0, FmkOpMax());
+        bool bad = false;
+        double pr[16];
+        float2 ar[8];
+        uint32_t sr[4];
+        auto issue = [&](int step) {                                   // the blocks of `step` -> registers
+            sB[lane] = step < nsteps ? first_blk + step : (int64_t)-1;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t rb = sB[4 * k + (lane >> 4)];
+                int64_t idx = rb * FL_T + (lane & 15);
+                idx = idx <= last_tick ? idx : last_tick;
+                pr[k] = rb >= 0 ? price[idx] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t rb = sB[8 * k + (lane >> 3)];
+                const int64_t idx = rb * FL_T + (lane & 7) * 2;
+                float2 v = make_float2(0.f, 0.f);
+                if (rb >= 0) {
+                    if (idx + 1 <= last_tick) v = *(const float2 *)(amount + idx);
+                    else if (idx <= last_tick) v.x = amount[idx];
+                }
+                ar[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t rb = sB[16 * k + (lane >> 2)];
+                const int64_t idx = rb * FL_T + (lane & 3) * 4;
+                uint32_t v = 0;
+                if (rb >= 0) {
+                    if (idx + 3 <= last_tick) v = *(const uint32_t *)(side + idx);
+                    else
+                        for (int q = 0; q < 4; ++q)
+                            if (idx + q <= last_tick) v |= (uint32_t)(uint8_t)side[idx + q] << (8 * q);
+                }
+                sr[k] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (steps > 0) issue(0);
+        for (int step = 0; step < steps; ++step) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sP[(4 * k + (lane >> 4)) * FL_ROW + (lane & 15)] = pr[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int at = (8 * k + (lane >> 3)) * FL_ROW + (lane & 7) * 2;
+                sA[at] = ar[k].x; sA[at + 1] = ar[k].y;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sS[(16 * k + (lane >> 2)) * 5 + (lane & 3)] = sr[k];
+            __builtin_amdgcn_wave_barrier();
+            if (step + 1 < steps) issue(step + 1);
+            if (step < nsteps) {                                       // base.py:700-719 over the lane's ticks of this block
+                const int64_t blk0 = (first_blk + step) * FL_T;
+                const int lo = start > blk0 ? (int)(start - blk0) : 0;
+                const int hi = e - blk0 < 15 ? (int)(e - blk0) : 15;
+                const double *rowP = sP + lane * FL_ROW;
+                const float *rowA = sA + lane * FL_ROW;
+                const signed char *rowS = sS8 + lane * 20;
+#pragma unroll 4
+                for (int j = 0; j < FL_T; ++j) {
+                    const bool valid = j >= lo && j <= hi;
+                    const double p = rowP[j];
+                    const int sd = (int)rowS[j];
+                    const float a = rowA[j];
+                    const int lvl = fp_level32(p, tick, inv_tick) - ilow;
+                    const bool inside = (unsigned)lvl < (unsigned)L;
+                    bad |= valid && !inside;                               // base.py:719
+                    const int slot = (valid && inside && (sd == 1 || sd == -1)) ? 2 * lvl + (sd < 0 ? 1 : 0) : -1;
+#pragma unroll
+                    for (int k = 0; k < 2 * FL_MAXL; ++k) {
+                        hv[k] += slot == k ? a : 0.f;                      // float32 +=, in tick order (x + 0.0f == x)
+                        hc[k] += slot == k ? 1 : 0;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const unsigned long long bb = __builtin_amdgcn_ballot_w64(bad);
+        if (bb && lane == 0 && n_bad) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bb));
+        if (!mine) continue;
+        // ---- level rows + comp_footprint_features (base.py:755-850), sequentially over the lane's L <= 8 levels
+        float bv[FL_MAXL], sv[FL_MAXL], tot[FL_MAXL];
+        float best = -INFINITY;
+        int best_i = 0;
+        double num = 0.0;
+#pragma unroll
+        for (int l = 0; l < FL_MAXL; ++l) {
+            bv[l] = 0.f; sv[l] = 0.f; tot[l] = 0.f;
+            if (l < L) {
+                bv[l] = hv[2 * l]; sv[l] = hv[2 * l + 1];
+                o.price_levels[base + l] = (int32_t)(ilow + l);
+                o.buy_volumes[base + l] = bv[l];
+                o.sell_volumes[base + l] = sv[l];
+                o.buy_ticks[base + l] = hc[2 * l];
+                o.sell_ticks[base + l] = hc[2 * l + 1];
+                tot[l] = bv[l] + sv[l];                                    // base.py:822
+                if (tot[l] > best) { best = tot[l]; best_i = l; }          // np.argmax: the first maximum
+                num += (double)(ilow + l) * (double)tot[l];
+            }
+        }
+        const float total = fl_pairwise(tot, L);
+        const bool stats = total > 0.f;                                    // base.py:836 (L >= 1 here)
+        const double vwap = stats ? num / (double)total : 0.0;
+        unsigned bsum = 0, ssum = 0;
+        double skew = 0.0;
+        float q2[FL_MAXL];
+        int max_run = 0, max_sign = 0, run = 0, run_sign = 0;
+#pragma unroll
+        for (int l = 0; l < FL_MAXL; ++l) {
+            q2[l] = 0.f;
+            if (l < L) {
+                const bool si = l < L - 1 && (double)sv[l] > (double)bv[l + 1 < FL_MAXL ? l + 1 : l] * imb_mult;   // base.py:797
+                const bool bi = l >= 1 && (double)bv[l] > (double)sv[l >= 1 ? l - 1 : 0] * imb_mult;              // base.py:798
+                o.buy_imbalances[base + l] = bi;
+                o.sell_imbalances[base + l] = si;
+                bsum += bi ? 1u : 0u; ssum += si ? 1u : 0u;
+                const int sg = bi ? 1 : (si ? -1 : 0);                     // base.py:801-819
+                if (sg != 0 && sg == run_sign) run += 1;
+                else if (sg != 0) { run = 1; run_sign = sg; }
+                else { run = 0; run_sign = 0; }
+                if (run > max_run) { max_run = run; max_sign = run_sign; }
+                if (stats) {
+                    skew += ((double)(ilow + l) - vwap) * (double)tot[l];
+                    const float q = tot[l] / total;
+                    q2[l] = q * q;
+                }
+            }
+        }
+        double gini = 0.0;
+        if (stats) gini = (double)(1.0f - fl_pairwise(q2, L));             // base.py:847-848 (float32)
+        o.buy_imbalances_sum[b] = (uint16_t)bsum;
+        o.sell_imbalances_sum[b] = (uint16_t)ssum;
+        o.cot_price_levels[b] = (int32_t)(ilow + best_i);
+        o.imb_max_run_signed[b] = (int16_t)(max_run * max_sign);
+        o.vp_skew[b] = stats ? skew / (double)total : 0.0;
+        o.vp_gini[b] = gini;
+    }
+}
+
+// list of the bars k_bar_footprints_lanes left over: rest[0] = count (from the scan's total), rest[32 + pos[g] + k] = the k-th
+// set bit of group g
+__global__ __launch_bounds__(256) void k_fl_compact(const unsigned long long *__restrict__ grp_mask,
+                                                    const int64_t *__restrict__ pos, int64_t groups,
+                                                    unsigned long long *__restrict__ rest)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) rest[0] = (unsigned long long)pos[groups];
+    if (g >= groups) return;
+    unsigned long long m = grp_mask[g];
+    int64_t at = 32 + pos[g];
+    while (m) {
+        const int bit = __builtin_ctzll(m);
+        rest[at++] = (unsigned long long)(g * 64 + bit);
+        m &= m - 1;
+    }
+}
+
 template <bool AF64>
 static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t *sd, const int64_t *ci, int64_t nb,
                      double tick, const double *lows, double imb_mult, const int64_t *off, int lmin, int lmax, int wpb,
-                     const FpOut &o, unsigned long long *n_bad)
+                     const FpOut &o, unsigned long long *n_bad, const unsigned long long *only = nullptr)
 {
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
@@ -442,12 +684,12 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if (gscratch)
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
-                                                                                   gscratch, 0);
+                                                                                   gscratch, 0, only);
     else
         k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
-                                                                                       fp_lds_atomics_in_lane_order(ctx));
+                                                                                       fp_lds_atomics_in_lane_order(ctx), only);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -469,13 +711,13 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
-                                       max_levels, d_out, d_n_bad_level);
+                                       max_levels, d_out, d_n_bad_level, n);
 }
 
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
-                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level)
+                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level, int64_t n_ticks)
 {
     // imb_mult stays float64: array(float32) * float64 is float64 under Numba typing (the production path); NumPy 2 / NEP 50
     // would round the product to float32 -- they differ only for inexact products (decimal lots), see oracle/fmk_oracle.c
@@ -484,18 +726,48 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     unsigned long long *bad = (unsigned long long *)d_n_bad_level;
     const int LMAX[4] = {128, 512, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
     static const int WPB[4] = {4, 4, 1, 1};
-    int lmin = 0;
-    for (int k = 0; k < 4; ++k) {
+    // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
+    // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
+    // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
+    unsigned long long *rest = nullptr;
+    {
+        const char *lv = getenv("FMK_FP_LANES");
+        const int mode = lv ? atoi(lv) : 1;
+        const bool ok = !amount_is_f64 && lmin_start == 0 && ((uintptr_t)d_amount & 7) == 0 && ((uintptr_t)d_side & 3) == 0;
+        const bool fit = n_ticks > 0 && nb >= (int64_t)ctx->n_cu * 64 * 4 && n_ticks / nb <= 64;
+        if (ok && mode != 0 && (fit || mode == 2)) {
+            const int64_t groups = fmk_ceil_div(nb, 64);
+            unsigned long long *grp_mask = nullptr;
+            int64_t *grp_cnt = nullptr;
+            FMK_TRY(fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest));
+            FMK_TRY(fmk_alloc(ctx, (size_t)groups * 8, (void **)&grp_mask));
+            FMK_TRY(fmk_alloc(ctx, (size_t)(groups + 1) * 8, (void **)&grp_cnt));
+            int64_t blocks = fmk_ceil_div(groups, FL_WAVES);
+            const int64_t cap = (int64_t)ctx->n_cu * 32;
+            if (blocks > cap) blocks = cap;
+            k_bar_footprints_lanes<<<(unsigned)blocks, 64 * FL_WAVES, 0, ctx->stream>>>(
+                d_price, (const float *)d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o,
+                bad, grp_mask, grp_cnt, 4096);
+            FMK_LAUNCH_CHECK(ctx);
+            FMK_TRY(fmk_exclusive_scan_i64(ctx, grp_cnt, grp_cnt, groups, true));
+            k_fl_compact<<<(unsigned)fmk_ceil_div(groups, 256), 256, 0, ctx->stream>>>(grp_mask, grp_cnt, groups, rest);
+            FMK_LAUNCH_CHECK(ctx);
+            (void)fmk_free(ctx, grp_mask);
+            (void)fmk_free(ctx, grp_cnt);
+        }
+    }
+    int lmin = 0, rc = FMK_OK;
+    for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         if (LMAX[k] > lmin_start) {
-            int rc = amount_is_f64
-                         ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                           imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad)
-                         : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                            imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad);
-            if (rc) return rc;
+            rc = amount_is_f64
+                     ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
+                                       imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest)
+                     : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
+                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest);
         }
         lmin = LMAX[k];
     }
-    return FMK_OK;
+    if (rest) (void)fmk_free(ctx, rest);                               // stream-ordered: the launches above are queued before it
+    return rc;
 }

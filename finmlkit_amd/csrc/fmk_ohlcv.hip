@@ -210,27 +210,12 @@ __device__ __forceinline__ void small_bar(const double *__restrict__ price, cons
             if constexpr (MEDIAN) bar.key[c] = MK::tokey(araw[c]);
         }
     }
-    if constexpr (NCH == 1 && !AF64) {
-        // A bar of <= 64 ticks with float32 amounts gets the SAME sums whichever schedule serves it: k_bar_ohlcv_lanes adds in
-        // tick order (the reference's order), so this one does too -- lane k's product broadcast from a scalar register,
-        // k = 0 .. cnt-1.  Only reached when the stream's mean bar is long (few such bars) or there are < 64 bars: a result
-        // that depended on the mean bar length would make a sharded run differ from the un-sharded one in the last bit.
-        double tvs = 0.0, tds = 0.0;
-        const double a0 = (double)__uint_as_float(araw[0]);
-        for (int k = 0; k < (int)cnt; ++k) {
-            const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(p[0]), k);
-            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)__double_as_longlong(p[0]) >> 32), k);
-            const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(a0), k);
-            const uint32_t ahi = (uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)__double_as_longlong(a0) >> 32), k);
-            const double pk = __longlong_as_double((long long)(((uint64_t)phi << 32) | plo));
-            const double ak = __longlong_as_double((long long)(((uint64_t)ahi << 32) | alo));
-            tvs += ak;
-            tds += pk * ak;
-        }
-        ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tvs, tds, lane, true);
-    } else {
-        ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
-    }
+    // A bar of <= 64 ticks gets the SAME sums whichever schedule serves it (a result that depended on the stream's mean bar
+    // length would make a sharded run differ from the un-sharded one in the last bit): both this kernel and k_bar_ohlcv_lanes add
+    // the 64 tick slots (0.0 beyond the bar) as the balanced binary tree of fmk_dpp_reduce -- ((x0+x1)+(x2+x3))+... in tick
+    // order.  (A first version made both add in the reference's sequential order; here that was a 64-step readlane loop per bar,
+    // 27 ms per 1e9 ticks of 60-tick bars.)
+    ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
     if constexpr (MEDIAN) {
         bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
         const double m = med_search<AF64, NCH, EXACT>(bar, buf);
@@ -345,25 +330,31 @@ __device__ __forceinline__ uint32_t lb_pick(const uint32_t (&r)[N], int idx)
     return lb_pick_seq<N>(r, idx, std::make_integer_sequence<int, N>{});
 }
 
-// One bar of L <= N ticks per lane (L == 0: idle lane): the reference's loop body (base.py:377-391) over the lane's slice of
-// the tile, eight ticks at a time (more loads in flight only cost registers: the LDS is next door), then the median from a
-// fixed N-key sorting network on the lane's own registers.
-template <bool MEDIAN, int N>
-__device__ __forceinline__ void lb_bar(const double *tp, const uint32_t *ta, int off, int L, double &hi, double &lo,
-                                       double &tv, double &td, double &med)
+// Block K (ticks 8K .. 8K+7) of a lane's bar: high / low, the eight tick slots' contribution to the two sums and the median
+// keys.  The sums are the balanced binary tree over the N tick slots in tick order (0.0 beyond the bar) -- the combining order
+// of fmk_dpp_reduce, which serves the same bar in the wave-per-bar kernels (small_bar<NCH = 1>): a tree over the block's 8
+// slots here, then a binary counter over the blocks (lv / ld: partial sums of 8, 16, 32 slots waiting for their right halves).
+// K is a template constant, so the counter is resolved at compile time.
+template <bool MEDIAN, int N, int K, int NR>
+__device__ __forceinline__ void lb_block(const double *tp, const uint32_t *ta, int off, int L, int Lmax, int zero_at, double &hi, double &lo,
+                                         double (&lv)[3], double (&ld)[3], double &tv, double &td, uint32_t (&r)[NR])
 {
     typedef MedKey<false> MK;
-    uint32_t r[MEDIAN ? N : 1];
-#pragma unroll
-    for (int j0 = 0; j0 < N; j0 += 8) {
+    constexpr int j0 = 8 * K;
+    double cv = 0.0, cd = 0.0;
+    // a block no bar of the wave reaches is skipped (0.0 contributions: x + 0.0 == x, the tree is unchanged).  The wave-uniform
+    // branch is also what keeps the blocks apart: as straight-line code the eight blocks were scheduled into one another and
+    // the kernel needed > 256 VGPRs.
+    if (j0 < Lmax) {
         double p[8];
         uint32_t raw[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int at = j0 + q < L ? off + j0 + q : off;      // idle iterations re-read the bar's first tick
+            const int at = j0 + q < L ? off + j0 + q : zero_at;  // idle iterations read the tile's zero slot: price 0, amount 0
             p[q] = tp[at];
             raw[q] = ta[at];
         }
+        double xv[8], xd[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const bool in = j0 + q < L;
@@ -371,13 +362,49 @@ __device__ __forceinline__ void lb_bar(const double *tp, const uint32_t *ta, int
             if (in) {
                 hi = p[q] > hi ? p[q] : hi;                      // `>` / `<` like the reference: a NaN never wins
                 lo = p[q] < lo ? p[q] : lo;
-                tv += a;
-                td += p[q] * a;
             }
+            xv[q] = a;                                           // 0.0 and 0.0 * 0.0 for the idle slots: no selects
+            xd[q] = p[q] * a;
             if constexpr (MEDIAN) r[j0 + q] = in ? MK::tokey(raw[q]) : MK::MAXK;
         }
-        __builtin_amdgcn_sched_barrier(0);                       // keep the blocks apart: 8 ticks of loads live at a time
+        cv = ((xv[0] + xv[1]) + (xv[2] + xv[3])) + ((xv[4] + xv[5]) + (xv[6] + xv[7]));
+        cd = ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+    } else if constexpr (MEDIAN) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[j0 + q] = MK::MAXK;
     }
+    constexpr int NB = N / 8;
+    if constexpr ((K & 1) == 0 && NB > 1) { lv[0] = cv; ld[0] = cd; }
+    else {
+        if constexpr (NB > 1) { cv = lv[0] + cv; cd = ld[0] + cd; }
+        if constexpr ((K & 2) == 0 && NB > 2) { lv[1] = cv; ld[1] = cd; }
+        else {
+            if constexpr (NB > 2) { cv = lv[1] + cv; cd = ld[1] + cd; }
+            if constexpr ((K & 4) == 0 && NB > 4) { lv[2] = cv; ld[2] = cd; }
+            else {
+                if constexpr (NB > 4) { cv = lv[2] + cv; cd = ld[2] + cd; }
+                tv = cv; td = cd;                                // K == NB - 1: the root
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                           // keep the blocks apart: 8 ticks of loads live at a time
+    asm volatile("" ::: "memory");                               // (the tree sums made the blocks independent: without a compiler
+                                                                 //  barrier all 64 ticks were loaded up front, 256 VGPRs)
+    if constexpr (K + 1 < NB) lb_block<MEDIAN, N, K + 1, NR>(tp, ta, off, L, Lmax, zero_at, hi, lo, lv, ld, tv, td, r);
+}
+
+// One bar of L <= N ticks per lane (L == 0: idle lane): the reference's loop body (base.py:377-391) over the lane's slice of
+// the tile, eight ticks at a time (more loads in flight only cost registers: the LDS is next door), then the median from a
+// fixed N-key sorting network on the lane's own registers.
+template <bool MEDIAN, int N>
+__device__ __forceinline__ void lb_bar(const double *tp, const uint32_t *ta, int off, int L, int zero_at, double &hi, double &lo,
+                                       double &tv, double &td, double &med)
+{
+    typedef MedKey<false> MK;
+    uint32_t r[MEDIAN ? N : 1];
+    double lv[3] = {0.0, 0.0, 0.0}, ld[3] = {0.0, 0.0, 0.0};
+    const int Lmax = fmk_dpp_reduce(L, 0, FmkOpMax());               // wave-uniform: the longest bar of the wave
+    lb_block<MEDIAN, N, 0, (MEDIAN ? N : 1)>(tp, ta, off, L, Lmax, zero_at, hi, lo, lv, ld, tv, td, r);
     if constexpr (MEDIAN) {
         lb_sort<N>(r);
         const uint32_t v1 = lb_pick<N>(r, (L - 1) >> 1), v2 = lb_pick<N>(r, L >> 1);
@@ -394,13 +421,14 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
                                                          const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                          int *__restrict__ saw_long, OhlcvOut o)
 {
-    __shared__ double s_p[2][LB_TILE];
-    __shared__ uint32_t s_a[2][LB_TILE];
+    __shared__ double s_p[2][LB_TILE + 2];                            // [LB_TILE]: the zero slot of idle iterations
+    __shared__ uint32_t s_a[2][LB_TILE + 2];
     __shared__ int64_t s_ci[2][66];
     const int lane = fmk_lane();
     const int w = fmk_uniform((int)(threadIdx.x >> 6));
     double *tp = s_p[w];
     uint32_t *ta = s_a[w];
+    if (lane == 0) { tp[LB_TILE] = 0.0; ta[LB_TILE] = 0u; }
     const int64_t ngroups = (nb + 63) >> 6;
     const int64_t nwaves = (int64_t)gridDim.x * 2;
     for (int64_t g = (int64_t)blockIdx.x * 2 + w; g < ngroups; g += nwaves) {
@@ -448,8 +476,8 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
             const double first = ntick > 0 ? tp[off] : 0.0;
             double hi = first, lo = first, tv = 0.0, td = 0.0;                   // base.py:371-372: seeded with the first price
             double med = 0.0;
-            if (any_gt32) lb_bar<MEDIAN, 64>(tp, ta, off, Lw, hi, lo, tv, td, med);
-            else lb_bar<MEDIAN, 32>(tp, ta, off, Lw, hi, lo, tv, td, med);
+            if (any_gt32) lb_bar<MEDIAN, 64>(tp, ta, off, Lw, LB_TILE, hi, lo, tv, td, med);
+            else lb_bar<MEDIAN, 32>(tp, ta, off, Lw, LB_TILE, hi, lo, tv, td, med);
             if (owner) {
                 const int64_t b = B0 + bl + lane;
                 if (mine) {

@@ -128,6 +128,33 @@ def test_footprints_vs_oracle(orc, n, interval, dtype, tick, mult):
     _check_fp(off, flat, bar, woff, wflat, wbar, f"n={n} iv={interval}")
 
 
+@pytest.mark.parametrize("case", ["t1", "t1_zeros", "t3_coarse", "t60", "sparse", "tail", "mult15"])
+def test_footprints_lane_per_bar_schedule(orc, monkeypatch, case):
+    """k_bar_footprints_lanes (one lane runs the reference's loops for one bar; forced here, the library picks it for >= 64 K
+    bars of <= 64 ticks on average): non-dyadic float32 amounts (the float32 level sums are order-sensitive), 1-second bars
+    with 1-8 levels, bars with more than 8 levels handed to the wave-per-bar kernel through the list (1-minute bars: all of
+    them), unsigned ticks, empty bars, a stream that ends inside a 16-tick block."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    monkeypatch.setenv("FMK_FP_LANES", "2")
+    n = 500_003 if case == "tail" else 400_000
+    ts, px, am, sd = orc.synth(29, 0, n, 300_000_000_000) if case == "sparse" else orc.synth(29, 0, n)
+    rng = np.random.default_rng(6)
+    am = rng.lognormal(-1, 1.3, n).astype(np.float32)
+    if case == "t1_zeros":
+        sd = sd.copy()
+        sd[rng.random(n) < 0.25] = 0
+    interval = {"t60": 60.0, "t3_coarse": 3.0}.get(case, 1.0)
+    tick = 0.05 if case == "t3_coarse" else 0.01
+    _, ci = orc._time_bar_indexer(ts, interval)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    mult = 1.5 if case == "mult15" else 3.0
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], mult)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], mult)
+    _check_fp(off, flat, bar, woff, wflat, wbar, case)
+    widths = np.diff(woff)
+    print(f"{case}: {len(widths)} bars, levels per bar: mean {widths.mean():.2f}, max {widths.max()}, > 8: {(widths > 8).mean():.1%}")
+
+
 def test_footprints_reference_shape_and_errors(orc):
     from finmlkit_amd.bar.base import comp_bar_footprints
     ts, px, am, sd = orc.synth(3, 0, 20_000)
