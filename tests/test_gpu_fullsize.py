@@ -313,3 +313,47 @@ def test_cusum_default_floor_chain_walk_equals_fixed_point(big, prefix, orc, mon
     k = int(np.searchsorted(got, PREFIX - 1, side="left"))
     assert k > 10
     np.testing.assert_array_equal(got[:k], seq[:k])
+
+
+def test_one_second_bars_full_size(big, prefix, orc):
+    """TimeBarKit(1 s) -- the reference's other caller (io.py:484) -- at 1e9 ticks: 5e7 bars of ~20 ticks.  The library takes its
+    lane-per-bar schedules here on its own (k_bar_ohlcv_lanes, k_bar_dir_lanes, k_bar_footprints_lanes + the wave kernels for the
+    bars they list); the outputs satisfy the row-sum identities over all bars and equal the oracle on the prefix, bit for bit."""
+    engine, t, n = big
+    ts, px, am, sd = prefix
+    _, ci = t.time_bar_index(1.0)
+    cih = ci.to_host()
+    o = t.bar_ohlcv(ci)
+    d, nz = t.bar_directional(ci)
+    d = engine.to_host(d)
+    trades = np.diff(cih)
+    assert int(nz.to_host()[0]) == int((trades == 0).sum())               # empty seconds: no signed tick
+    assert np.array_equal(d["ticks_buy"] + d["ticks_sell"], trades)
+    assert np.array_equal(o["trades"].to_host(), trades)
+    off, flat, bar, bad = t.bar_footprints(ci, o["low"], o["high"], 0.01, 3.0)
+    assert int(bad.to_host()[0]) == 0
+    offh = off.to_host()
+    starts = offh[:-1]
+    has = np.diff(offh) > 0
+    bt = np.add.reduceat(flat["buy_ticks"].to_host().astype(np.int64), np.minimum(starts, offh[-1] - 1))
+    assert np.array_equal(bt[has], d["ticks_buy"][has])
+    # --- prefix parity with the oracle
+    _, oci = orc._time_bar_indexer(ts, 1.0)
+    k = int(np.searchsorted(cih, PREFIX - 1, side="left")) - 1
+    assert k > 100_000
+    oo = orc.comp_bar_ohlcv(px, am, oci[:k + 1])
+    for key, w in zip(G.OHLCV_KEYS, oo):
+        got = o[{"median": "median_trade_size"}.get(key, key)].to_host()[:k]
+        if key == "vwap":
+            G.assert_f64_close(got, w, what="vwap")
+        else:
+            np.testing.assert_array_equal(got, w, err_msg=key)
+    want = orc.comp_bar_directional_features(px, am, oci[:k + 1], sd, raise_on_zero_div=False)
+    for key, w in zip(G.DIR_KEYS, want):
+        np.testing.assert_array_equal(d[key][1:k], w[1:], err_msg=key)    # bar 0: the wrap-around tick differs (see above)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, oci[:k + 1], sd, 0.01, oo[2], oo[1], 3.0)
+    np.testing.assert_array_equal(offh[:k + 1], woff)
+    for key in G.FP_LIST_KEYS:
+        np.testing.assert_array_equal(flat[key].view(0, int(woff[-1])).to_host().astype(wflat[key].dtype), wflat[key], err_msg=key)
+    for key in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
+        np.testing.assert_array_equal(bar[key].view(0, k).to_host(), wbar[key], err_msg=key)
