@@ -168,39 +168,47 @@ struct CsState { double sp, sn; };
 //   lam[t] = max(sigma_mult * sigma_i, sigma_floor), NaN inside a same-timestamp print block (logic.py:206-211):
 //            a NaN threshold can never be reached, which is exactly "this tick cannot close a bar"
 // for tick i = first + 1 + t, t = k * CS_CHUNK + j.  64 x 64 tiles through LDS (coalesced on both sides).
+#define CS_PREP_TJ 32           // ticks per tile: 64 chunks x 32 ticks, 33.8 KB of LDS -> four workgroups per CU (64 x 64 tiles, 66 KB:
+                                // two per CU, 16.7 ms per 1e9 ticks; 32: 12.1 ms; 16: 14.5 ms)
 __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                     const double *__restrict__ sigma, int64_t n, int64_t first,
                                                     int64_t m, int64_t chunks, double sigma_floor, double sigma_mult,
                                                     double *__restrict__ t_ret, double *__restrict__ t_lam)
 {
-    __shared__ double s_r[64][65];
-    __shared__ double s_l[64][65];
+    __shared__ double s_r[64][CS_PREP_TJ + 1];
+    __shared__ double s_l[64][CS_PREP_TJ + 1];
     const int64_t k0 = (int64_t)blockIdx.x * 64;
-    const int j0 = (int)blockIdx.y * 64;
-    const int col = threadIdx.x & 63, row4 = threadIdx.x >> 6;
-    for (int rr = 0; rr < 16; ++rr) {
-        const int row = rr * 4 + row4;                                   // chunk inside the tile
-        const int64_t t = (k0 + row) * CS_CHUNK + j0 + col;
-        double r = 0.0, lam = NAN;
-        if (k0 + row < chunks && t < m) {
-            const int64_t i = first + 1 + t;
-            r = log(price[i] / price[i - 1]);
-            const bool block = i + 1 < n && ts[i] == ts[i + 1];
-            if (!block) {
-                lam = sigma_mult * sigma[i];
-                lam = sigma_floor > lam ? sigma_floor : lam;             // max(lam, floor): a NaN lam stays NaN
+    const int j0 = (int)blockIdx.y * CS_PREP_TJ;
+    {
+        const int col = threadIdx.x & (CS_PREP_TJ - 1), row8 = threadIdx.x / CS_PREP_TJ;
+        constexpr int RP = 256 / CS_PREP_TJ;                            // rows per pass
+        for (int rr = 0; rr < 64 / RP; ++rr) {
+            const int row = rr * RP + row8;                             // chunk inside the tile
+            const int64_t t = (k0 + row) * CS_CHUNK + j0 + col;
+            double r = 0.0, lam = NAN;
+            if (k0 + row < chunks && t < m) {
+                const int64_t i = first + 1 + t;
+                r = log(price[i] / price[i - 1]);
+                const bool block = i + 1 < n && ts[i] == ts[i + 1];
+                if (!block) {
+                    lam = sigma_mult * sigma[i];
+                    lam = sigma_floor > lam ? sigma_floor : lam;         // max(lam, floor): a NaN lam stays NaN
+                }
             }
+            s_r[row][col] = r;
+            s_l[row][col] = lam;
         }
-        s_r[row][col] = r;
-        s_l[row][col] = lam;
     }
     __syncthreads();
-    for (int rr = 0; rr < 16; ++rr) {
-        const int jrow = rr * 4 + row4;                                  // tick inside the chunk
-        const int64_t k = k0 + col;
-        if (k < chunks) {
-            t_ret[(int64_t)(j0 + jrow) * chunks + k] = s_r[col][jrow];
-            t_lam[(int64_t)(j0 + jrow) * chunks + k] = s_l[col][jrow];
+    {
+        const int col = threadIdx.x & 63, jr4 = threadIdx.x >> 6;
+        for (int rr = 0; rr < CS_PREP_TJ / 4; ++rr) {
+            const int jrow = rr * 4 + jr4;                              // tick inside the tile
+            const int64_t k = k0 + col;
+            if (k < chunks) {
+                t_ret[(int64_t)(j0 + jrow) * chunks + k] = s_r[col][jrow];
+                t_lam[(int64_t)(j0 + jrow) * chunks + k] = s_l[col][jrow];
+            }
         }
     }
 }
@@ -493,7 +501,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
         double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + tr_bytes);
         unsigned char *active = (unsigned char *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes);
         int *list = (int *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes);
-        const dim3 pg((unsigned)fmk_ceil_div(chunks, 64), CS_CHUNK / 64);
+        const dim3 pg((unsigned)fmk_ceil_div(chunks, 64), CS_CHUNK / CS_PREP_TJ);
         k_cusum_prep<<<pg, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, t_ret,
                                                  t_lam);
         FMK_LAUNCH_CHECK(ctx);
