@@ -739,9 +739,14 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
             const int64_t groups = fmk_ceil_div(nb, 64);
             unsigned long long *grp_mask = nullptr;
             int64_t *grp_cnt = nullptr;
-            FMK_TRY(fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest));
-            FMK_TRY(fmk_alloc(ctx, (size_t)groups * 8, (void **)&grp_mask));
-            FMK_TRY(fmk_alloc(ctx, (size_t)(groups + 1) * 8, (void **)&grp_cnt));
+            int arc = fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest);
+            if (arc == FMK_OK) arc = fmk_alloc(ctx, (size_t)groups * 8, (void **)&grp_mask);
+            if (arc == FMK_OK) arc = fmk_alloc(ctx, (size_t)(groups + 1) * 8, (void **)&grp_cnt);
+            if (arc != FMK_OK) {
+                if (rest) (void)fmk_free(ctx, rest);
+                if (grp_mask) (void)fmk_free(ctx, grp_mask);
+                return arc;
+            }
             int64_t blocks = fmk_ceil_div(groups, FL_WAVES);
             const int64_t cap = (int64_t)ctx->n_cu * 32;
             if (blocks > cap) blocks = cap;
@@ -749,11 +754,12 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                 d_price, (const float *)d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o,
                 bad, grp_mask, grp_cnt, 4096);
             FMK_LAUNCH_CHECK(ctx);
-            FMK_TRY(fmk_exclusive_scan_i64(ctx, grp_cnt, grp_cnt, groups, true));
-            k_fl_compact<<<(unsigned)fmk_ceil_div(groups, 256), 256, 0, ctx->stream>>>(grp_mask, grp_cnt, groups, rest);
-            FMK_LAUNCH_CHECK(ctx);
+            arc = fmk_exclusive_scan_i64(ctx, grp_cnt, grp_cnt, groups, true);
+            if (arc == FMK_OK) k_fl_compact<<<(unsigned)fmk_ceil_div(groups, 256), 256, 0, ctx->stream>>>(grp_mask, grp_cnt, groups, rest);
             (void)fmk_free(ctx, grp_mask);
             (void)fmk_free(ctx, grp_cnt);
+            if (arc != FMK_OK) { (void)fmk_free(ctx, rest); return arc; }
+            FMK_LAUNCH_CHECK(ctx);
         }
     }
     int lmin = 0, rc = FMK_OK;
