@@ -87,6 +87,13 @@ __device__ __forceinline__ int64_t fmk_uniform(int64_t v)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ int fmk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane `src` (wave-uniform index) broadcast to the wave
+__device__ __forceinline__ int64_t fmk_readlane(int64_t v, int src)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
 template <typename T>
 __device__ __forceinline__ T fmk_wave_sum(T v)

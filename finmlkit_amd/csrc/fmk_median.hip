@@ -33,11 +33,8 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     K *buf = sbuf[wib];
-    for (int64_t b = wave0; b < nb; b += nwaves) {
-        const int64_t s = fmk_uniform(ci[b]);
-        const int64_t e = fmk_uniform(ci[b + 1]);
+    auto do_bar = [&](int64_t b, int64_t s, int64_t e) {
         const int64_t cnt = e - s;
-        if (cnt <= min_cnt && min_cnt > 0) continue;     // handled by the fused small-bar kernel
         double m = 0.0;
         if (cnt > 0) {
             const int64_t start = s + 1;
@@ -54,7 +51,26 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
             else m = med_select<AF64, 0>(amount, start, cnt, lane, buf);
         }
         if (lane == 0) o_median[b] = m;
+    };
+    if (min_cnt > 0) {
+        // the leftover pass of a small-bar kernel: 64 bars per step, one coalesced load of their close indices, then only the
+        // bars it left (longer than min_cnt) get the wave -- walking the bars one by one cost a dependent load per bar, 2.3 ms
+        // per 2.5e7 bars of which a few per cent were long
+        const int64_t ngroups = (nb + 63) >> 6;
+        for (int64_t g = wave0; g < ngroups; g += nwaves) {
+            const int64_t bl = g * 64 + lane;
+            int64_t s_l = 0, e_l = 0;
+            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(bl < nb && e_l - s_l > min_cnt);
+            while (todo) {
+                const int bit = fmk_uniform((int)__builtin_ctzll(todo));
+                todo &= todo - 1;
+                do_bar(g * 64 + bit, fmk_readlane(s_l, bit), fmk_readlane(e_l, bit));
+            }
+        }
+        return;
     }
+    for (int64_t b = wave0; b < nb; b += nwaves) do_bar(b, fmk_uniform(ci[b]), fmk_uniform(ci[b + 1]));
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,

@@ -32,7 +32,8 @@
 #include "fmk_median.h"
 
 #define FMK_SMALL_NCH 21
-#define FMK_PACKED_MAX_MEAN 48          // mean ticks per bar up to which the lane-per-bar schedule is used (float32 amounts)
+#define FMK_PACKED_MAX_MEAN 64          // mean ticks per bar up to which the lane-per-bar schedule is used (float32 amounts):
+                                        // at 60 ticks 9.8 vs 12.6 ms for the wave-per-bar kernel, at 80 ticks 18.6 vs 12.0 (1e9 ticks)
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median);
@@ -132,13 +133,10 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
     const int wpb = blockDim.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + fmk_uniform((int)(threadIdx.x >> 6));
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
-    for (int64_t b = wave0; b < nb; b += nwaves) {
-        const int64_t s = fmk_uniform(ci[b]);
-        const int64_t e = fmk_uniform(ci[b + 1]);
-        if (min_cnt > 0 && e - s <= min_cnt) continue;      // the small-bar kernel owns this one
+    auto do_bar = [&](int64_t b, int64_t s, int64_t e) {
         if (e <= s) {
             if (lane == 0) ohlcv_empty(o, b, price, e, n);
-            continue;
+            return;
         }
         const int64_t start = s + 1;
         double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
@@ -162,7 +160,25 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
             tv += a0; td += p0 * a0;
         }
         ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane);
+    };
+    if (min_cnt > 0) {
+        // the leftover pass of a small-bar kernel: 64 bars per step, one coalesced load of their close indices, then only the
+        // bars it left (longer than min_cnt) get the wave (walking the bars one by one cost a dependent load per bar)
+        const int64_t ngroups = (nb + 63) >> 6;
+        for (int64_t g = wave0; g < ngroups; g += nwaves) {
+            const int64_t bl = g * 64 + lane;
+            int64_t s_l = 0, e_l = 0;
+            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(bl < nb && e_l - s_l > min_cnt);
+            while (todo) {
+                const int bit = fmk_uniform((int)__builtin_ctzll(todo));
+                todo &= todo - 1;
+                do_bar(g * 64 + bit, fmk_readlane(s_l, bit), fmk_readlane(e_l, bit));
+            }
+        }
+        return;
     }
+    for (int64_t b = wave0; b < nb; b += nwaves) do_bar(b, fmk_uniform(ci[b]), fmk_uniform(ci[b + 1]));
 }
 
 // One bar of <= 64*NCH ticks.  EXACT: the bar has exactly NCH chunks, so chunks 0..NCH-2 are full and
