@@ -239,8 +239,12 @@ __device__ __forceinline__ void small_bar(const double *__restrict__ price, cons
     }
 }
 
-template <bool AF64, bool MEDIAN>
-__global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__restrict__ price,
+// MAXNCH: the longest bar the instantiation serves, in 64-tick chunks.  FMK_SMALL_NCH (21): the 1-minute-bar kernel, held to
+// four waves per SIMD by the 21-chunk class' registers.  4: streams of 65..256-tick bars -- one wave per bar pays a full memory
+// round trip per bar, so what matters there is how many bars a CU has in flight: without the long classes the kernel fits eight
+// waves per SIMD (1e9 ticks, ohlcv + median: 80-tick bars 12.0 -> 9.0 ms, 100-tick 9.9 -> 7.3, 200-tick 5.3 -> 4.1; equal at 240).
+template <bool AF64, bool MEDIAN, int MAXNCH = FMK_SMALL_NCH>
+__global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : 4)) void k_bar_ohlcv_small(const double *__restrict__ price,
                                                             const void *__restrict__ amount,
                                                             const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                             int *__restrict__ saw_long, OhlcvOut o)
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t cnt = e - s;
-        if (cnt > 64 * FMK_SMALL_NCH) {                      // long bar: left to the generic kernels
+        if (cnt > 64 * MAXNCH) {                             // long bar: left to the generic kernels
             // The flag only ever becomes 1: look first (shared reads do not serialise), store if still clear.  An
             // atomicOr per long bar serialises on the one address (measured: 100 000 long bars -> 1.13 ms in this
             // otherwise idle kernel, 11 ns each).  No state is kept across bars: a wave-uniform "already raised" bit
@@ -273,17 +277,22 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_small(const double *__rest
         const int64_t start = s + 1;
         const int nch = (int)((cnt + 63) >> 6);
         // exact-size code for the chunk counts a ~1200-tick (1-minute) bar takes, size classes below
-        switch (nch) {
-        case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 21: small_bar<AF64, 21, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        default:
+        if constexpr (MAXNCH <= 4) {
             if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+        } else {
+            switch (nch) {
+            case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 21: small_bar<AF64, 21, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            default:
+                if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+                else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+                else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+                else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            }
         }
     }
 }
@@ -559,6 +568,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     static int packed_max = -1;              // developer knob: FMK_OHLCV_PACKED_MAX_MEAN (0 disables the packed schedule)
     if (packed_max < 0) { const char *v = getenv("FMK_OHLCV_PACKED_MAX_MEAN"); packed_max = v ? atoi(v) : FMK_PACKED_MAX_MEAN; }
     int64_t long_min = 64 * FMK_SMALL_NCH;
+    static int mid_max = -1;                 // developer knob: FMK_OHLCV_MID_MAX_MEAN (0 disables the 65..256-tick instantiation)
+    if (mid_max < 0) { const char *v = getenv("FMK_OHLCV_MID_MAX_MEAN"); mid_max = v ? atoi(v) : 210; }
     if (!AF64 && nb >= 64 && n / nb <= packed_max) {
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
@@ -566,6 +577,14 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         if (!o.median) k_bar_ohlcv_lanes<false, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_lanes<true, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         long_min = 64;
+    } else if (n / nb <= mid_max) {
+        // streams of 65..256-tick bars: the instantiation without the long classes (eight waves per SIMD); longer bars are left
+        int64_t blocks = fmk_ceil_div(nb, 4);
+        const int64_t cap = (int64_t)ctx->n_cu * 128;
+        if (blocks > cap) blocks = cap;
+        if (!o.median) k_bar_ohlcv_small<AF64, false, 4><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+        else k_bar_ohlcv_small<AF64, true, 4><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+        long_min = 256;
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
