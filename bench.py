@@ -212,7 +212,9 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    os.environ["FMK_DEVICE"] = str(local_rank)
+    # developer switch for boxes with ONE GPU: every rank on device 0 (RCCL then refuses the communicator, all ranks agree on
+    # that in the rendezvous and the step runs over the host-staged transport) -- exercises the N > 1 flow end to end
+    os.environ["FMK_DEVICE"] = "0" if os.environ.get("FMK_BENCH_ONE_DEVICE") else str(local_rank)
 
     comm = None
     use_dist = world > 1 or args.force_dist
