@@ -401,7 +401,24 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
         double pr[16];
         float2 ar[8];
         uint32_t sr[4];
+        // every block of the wave's bars ends before the arrays do (all but the stream's last wave): no bound checks on the loads,
+        // idle rows re-read the wave's first block (28 loads per step: the checks were ~110 of a step's ~1000 VALU instructions)
+        const int64_t e_max = fmk_dpp_reduce(active ? e : (int64_t)0, (int64_t)0, FmkOpMax());
+        const bool safe = e_max + DL_T < n;
+        const int64_t blk_any = fmk_uniform(fmk_dpp_reduce(active ? first_blk : (int64_t)INT64_MAX, (int64_t)INT64_MAX, FmkOpMin()));
         auto issue = [&](int step) {                                   // the blocks of `step` -> registers
+            if (safe) {
+                sB[lane] = step < nsteps ? first_blk + step : blk_any;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pr[k] = price[sB[4 * k + (lane >> 4)] * DL_T + (lane & 15)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ar[k] = *(const float2 *)(amount + sB[8 * k + (lane >> 3)] * DL_T + (lane & 7) * 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sr[k] = *(const uint32_t *)(side + sB[16 * k + (lane >> 2)] * DL_T + (lane & 3) * 4);
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
             sB[lane] = step < nsteps ? first_blk + step : (int64_t)-1;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -475,10 +492,13 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
                     pp = p; ps = sd;
                     const double pv = p * a;
                     const bool buy = sd == 1, sell = sd == -1;
-                    vb += buy ? a : 0.0; db += buy ? pv : 0.0; nbuy += buy ? 1 : 0;
-                    vs += sell ? a : 0.0; ds += sell ? pv : 0.0; nsell += sell ? 1 : 0;
-                    const double sf = (double)sd;                      // -1, 0, +1: the signed terms are exact
-                    ct += sd; cv += sf * a; cd += sf * pv;
+                    // x += cond ? y : 0.0 as fma(1.0 or 0.0, y, x): the product is exact, so the one rounding is the addition's
+                    // (two instructions instead of two selects and an add); likewise the signed terms with sf = -1, 0, +1
+                    const double ib = buy ? 1.0 : 0.0, is = sell ? 1.0 : 0.0;
+                    vb = fma(ib, a, vb); db = fma(ib, pv, db); nbuy += buy ? 1 : 0;
+                    vs = fma(is, a, vs); ds = fma(is, pv, ds); nsell += sell ? 1 : 0;
+                    const double sf = (double)sd;
+                    ct += sd; cv = fma(sf, a, cv); cd = fma(sf, pv, cd);
                     tmin = ct < tmin ? ct : tmin; tmax = ct > tmax ? ct : tmax;    // an unsigned tick repeats a candidate
                     vmin = bf_min(vmin, cv); vmax = bf_max(vmax, cv);
                     dmin = bf_min(dmin, cd); dmax = bf_max(dmax, cd);
@@ -699,9 +719,10 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     const char *lv = getenv("FMK_DIR_LANES");
     const int lanes_mode = lv ? atoi(lv) : 1;
     const bool lanes_ok = !amount_is_f64 && ((uintptr_t)d_amount & 7) == 0 && ((uintptr_t)d_side & 3) == 0;
-    // measured at 1e9 ticks (profiles/r02_dir_lanes.txt): 20-tick bars 66.5 -> 6.2 ms, 200-tick bars 7.6 -> 3.5 ms, 1 200-tick bars
-    // 3.44 vs 3.53 ms (the two schedules issue the same ~55-60 VALU instructions per 64 ticks there), 12 000-tick bars: wave per bar
-    const bool lanes_fit = nb >= (int64_t)ctx->n_cu * 64 * 4 && n / nb <= 1024;
+    // measured at 1e9 ticks (profiles/r02_dir_lanes.txt): 20-tick bars 66.5 -> 5.5 ms, 200-tick bars 7.6 -> 3.0 ms, 1 200-tick bars
+    // 3.1-3.2 -> 2.98 ms (the lane schedule's loads without bound checks and its conditional sums as fma(1.0 or 0.0, y, x) put it
+    // ahead there too; before: 3.53), 12 000-tick bars: wave per bar
+    const bool lanes_fit = nb >= (int64_t)ctx->n_cu * 64 * 4 && n / nb <= 2048;
     if (lanes_ok && lanes_mode != 0 && (lanes_fit || lanes_mode == 2)) {
         unsigned long long *long_list = redo + nb + 32;
         FMK_HIP(ctx, hipMemsetAsync(long_list, 0, 8, ctx->stream));

@@ -11,7 +11,7 @@ ctx = _ffi.default_context()
 t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
 for iv in ivs:
     clock, ci = t.time_bar_index(iv)
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         os.environ["FMK_DIR_LANES"] = mode
         ms = []
         for _ in range(4):
