@@ -370,6 +370,36 @@ __device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, con
     *tprev0 = tp;
 }
 
+// The thread's 8 consecutive ticks straight from memory, 16 bytes per load (4 + 4 instructions; every 128-byte line is shared
+// by two lanes): no LDS.  The transposing tile of ew_load_tile costs 36.8 KB per workgroup -- four workgroups per CU -- and
+// these kernels are bound by the work they have in flight, not by how their loads coalesce: k_ew_tile_maps 5.5 -> 2.7 ms per 1e9
+// ticks (6.0 TB/s), k_ew_apply with direct 16-byte stores as well: see profiles/r02_ewmst_direct_loads.txt.
+__device__ __forceinline__ void ew_load_direct(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
+                                               int64_t (&tl)[EW_ITEMS], double (&yl)[EW_ITEMS], int64_t *tprev0)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    if (i0 + EW_ITEMS <= n) {
+        if (ts) {
+            const longlong2 *q = (const longlong2 *)(ts + i0);
+#pragma unroll
+            for (int k = 0; k < EW_ITEMS / 2; ++k) { const longlong2 v = q[k]; tl[2 * k] = v.x; tl[2 * k + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EW_ITEMS; ++k) tl[k] = 0;
+        }
+        const double2 *qy = (const double2 *)(y + i0);
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { const double2 v = qy[k]; yl[2 * k] = v.x; yl[2 * k + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) {
+            tl[k] = (ts && i0 + k < n) ? ts[i0 + k] : 0;
+            yl[k] = i0 + k < n ? y[i0 + k] : 0.0;
+        }
+    }
+    *tprev0 = (ts && i0 >= 1 && i0 - 1 < n) ? ts[i0 - 1] : 0;
+}
+
 #define EW_LDS_ELEMS (EW_THREADS * 9)
 
 // al[k]: the tick's alpha (MODE 2: the fixed 1 - alpha), kept for the apply phase
@@ -404,11 +434,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__re
                                                              EwHl half_life, EwMap *__restrict__ tile_map)
 {
     __shared__ EwMap lds[4];
-    __shared__ int64_t s_ts[EW_LDS_ELEMS];
-    __shared__ double s_y[EW_LDS_ELEMS];
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
-    ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
+    ew_load_direct(ts, y, n, tl, yl, &tprev0);
     double al[EW_ITEMS];
     EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
     EwMap tot;
@@ -467,11 +495,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
                                                          double *__restrict__ out)
 {
     __shared__ EwMap lds[4];
-    __shared__ int64_t s_ts[EW_LDS_ELEMS];
-    __shared__ double s_y[EW_LDS_ELEMS];
     int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
-    ew_load_tile(ts, y, n, s_ts, s_y, tl, yl, &tprev0);
+    ew_load_direct(ts, y, n, tl, yl, &tprev0);
     double al[EW_ITEMS];
     EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
     EwMap tot;
@@ -495,17 +521,15 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_apply(const int64_t *__restri
         ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
         res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
     }
-    // coalesced store through the (now free) LDS tile
-    __syncthreads();
+    // the thread's 8 results as four 16-byte stores
+    if (i0 + EW_ITEMS <= n) {
+        double2 *q = (double2 *)(out + i0);
 #pragma unroll
-    for (int k = 0; k < EW_ITEMS; ++k) s_y[threadIdx.x * 9 + k] = res[k];
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * EW_TILE;
+        for (int k = 0; k < EW_ITEMS / 2; ++k) q[k] = make_double2(res[2 * k], res[2 * k + 1]);
+    } else {
 #pragma unroll
-    for (int r = 0; r < EW_ITEMS; ++r) {
-        const int e = r * EW_THREADS + threadIdx.x;
-        const int64_t i = base + e;
-        if (i < n) out[i] = s_y[(e >> 3) * 9 + (e & 7)];
+        for (int k = 0; k < EW_ITEMS; ++k)
+            if (i0 + k < n) out[i0 + k] = res[k];
     }
 }
 
