@@ -185,25 +185,42 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
                                            const DD *tile_base, const DD *seg_base, DD *lds, int64_t (&G)[DL_ITEMS],
                                            double *rem = nullptr)
 {
-    // the thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order), but loading them that way makes every load
-    // instruction touch 64 lines: 2.8 TB/s.  So the tile is loaded coalesced (thread t: ticks t, t + 256, ...), the rounded
-    // products go through a padded LDS tile (one slot per 8: thread t then reads doubles 9t .. 9t + 7, conflict-free) and come
-    // back blocked.
-    __shared__ double stage[DL_TILE + DL_TILE / 8];
+    // The thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order) and loads them itself, 16 bytes per instruction (price
+    // 4 x double2, amount 2 x float4 / 4 x double2).  History: eight 8-byte loads per array made every instruction touch 64
+    // lines (2.8 TB/s); a coalesced load + padded LDS tile to hand the products to their owners fixed that at the price of 18 KB
+    // of LDS and two barriers per workgroup; the 16-byte loads need neither (the lesson of profiles/r02_ewmst_direct_loads.txt).
     const int64_t t0 = (int64_t)blockIdx.x * DL_TILE;
-#pragma unroll
-    for (int k = 0; k < DL_ITEMS; ++k) {
-        const int idx = k * DL_THREADS + (int)threadIdx.x;
-        stage[idx + (idx >> 3)] = t0 + idx < n ? dl_d<AF64>(price, amount, t0 + idx) : 0.0;
-    }
-    __syncthreads();
     double d[DL_ITEMS];
+    {
+        const int64_t j0 = t0 + (int64_t)threadIdx.x * DL_ITEMS;
+        const bool vec = j0 + DL_ITEMS <= n && ((uintptr_t)price & 15) == 0 && ((uintptr_t)amount & 15) == 0;
+        if (vec) {
+            double pp[DL_ITEMS], aa[DL_ITEMS];
+            const double2 *qp = (const double2 *)(price + j0);
+#pragma unroll
+            for (int k = 0; k < DL_ITEMS / 2; ++k) { const double2 v = qp[k]; pp[2 * k] = v.x; pp[2 * k + 1] = v.y; }
+            if constexpr (AF64) {
+                const double2 *qa = (const double2 *)((const double *)amount + j0);
+#pragma unroll
+                for (int k = 0; k < DL_ITEMS / 2; ++k) { const double2 v = qa[k]; aa[2 * k] = v.x; aa[2 * k + 1] = v.y; }
+            } else {
+                const float4 *qa = (const float4 *)((const float *)amount + j0);
+#pragma unroll
+                for (int k = 0; k < DL_ITEMS / 4; ++k) {
+                    const float4 v = qa[k];
+                    aa[4 * k] = (double)v.x; aa[4 * k + 1] = (double)v.y; aa[4 * k + 2] = (double)v.z; aa[4 * k + 3] = (double)v.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < DL_ITEMS; ++k) d[k] = pp[k] * aa[k];       // rounded once, like prices[i] * volumes[i]
+        } else {
+#pragma unroll
+            for (int k = 0; k < DL_ITEMS; ++k) d[k] = j0 + k < n ? dl_d<AF64>(price, amount, j0 + k) : 0.0;
+        }
+    }
     DD s = dd_make(0.0);
 #pragma unroll
-    for (int k = 0; k < DL_ITEMS; ++k) {
-        d[k] = stage[(int)threadIdx.x * (DL_ITEMS + 1) + k];
-        s = dd_add(s, d[k]);
-    }
+    for (int k = 0; k < DL_ITEMS; ++k) s = dd_add(s, d[k]);
     DD tot;
     DD ex = dl_block_exclusive(s, lds, &tot);
     // (M, r) = floor and remainder of D / thr BEFORE the thread's first tick, from the double-double prefix: one division per
