@@ -110,43 +110,54 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
                                                     int64_t chunk_lo, int64_t chunk_hi, int64_t chunks, double sigma_floor,
                                                     double sigma_mult, double *__restrict__ sums, CcState *state)
 {
-    __shared__ double s_r[4][CC_SUB + CC_SUB / 8], s_l[4][CC_SUB + CC_SUB / 8];
     const int lane = fmk_lane(), w = (int)(threadIdx.x >> 6);
     const int64_t k = chunk_lo + (int64_t)blockIdx.x * 4 + w;
     if (k >= chunk_hi) return;
     const int64_t t0 = k * CC_CHUNK;
     CcSum acc = cc_identity();
     bool bad = false;
+    typedef double cc_d2 __attribute__((ext_vector_type(2), aligned(8)));       // 16-byte loads on an 8-byte alignment promise
+    typedef long long cc_l2 __attribute__((ext_vector_type(2), aligned(8)));
     for (int sub = 0; sub < CC_CHUNK / CC_SUB; ++sub) {
-        double p[8], pm[8], sg[8];
-        int64_t a[8], b[8];
+        // the lane's 8 consecutive ticks straight from the columns (price, sigma, timestamp: 4 x 16 bytes each, plus the price
+        // before and the timestamp after them).  A first version loaded coalesced rows and handed them over through an LDS tile:
+        // 36 KB per workgroup, 7.0 ms per 1e9 ticks (profiles/r02_ewmst_direct_loads.txt has the same lesson).
+        const int64_t tq = t0 + sub * CC_SUB + 8 * lane;              // t of the lane's first tick
+        const int64_t i0 = first + 1 + tq;
+        double p[8], sg[8], pm0;
+        int64_t a[8], an;
+        if (i0 + 8 <= n - 1) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int64_t t = t0 + sub * CC_SUB + 64 * g + lane;
-            int64_t i = first + 1 + t;
-            if (i > n - 1) i = n - 1;
-            p[g] = price[i]; pm[g] = price[i - 1]; sg[g] = sigma[i]; a[g] = ts[i]; b[g] = ts[i + 1 < n ? i + 1 : i];
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int64_t t = t0 + sub * CC_SUB + 64 * g + lane;
-            double r = 0.0, lam = NAN;
-            if (t < m) {
-                cc_tick(p[g], pm[g], sg[g], a[g], b[g], first + 1 + t + 1 < n, sigma_floor, sigma_mult, &r, &lam);
-                bad |= !(fabs(r) < INFINITY);
+            for (int q = 0; q < 4; ++q) {
+                const cc_d2 vp = *(const cc_d2 *)(price + i0 + 2 * q);
+                const cc_d2 vs = *(const cc_d2 *)(sigma + i0 + 2 * q);
+                const cc_l2 vt = *(const cc_l2 *)(ts + i0 + 2 * q);
+                p[2 * q] = vp.x; p[2 * q + 1] = vp.y; sg[2 * q] = vs.x; sg[2 * q + 1] = vs.y; a[2 * q] = vt.x; a[2 * q + 1] = vt.y;
             }
-            const int j = 64 * g + lane;
-            s_r[w][j + (j >> 3)] = r;
-            s_l[w][j + (j >> 3)] = lam;
+            pm0 = price[i0 - 1];
+            an = ts[i0 + 8];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int64_t i = i0 + q;
+                if (i > n - 1) i = n - 1;
+                p[q] = price[i]; sg[q] = sigma[i]; a[q] = ts[i];
+            }
+            pm0 = price[(i0 - 1 > n - 1 ? n - 1 : i0 - 1)];
+            an = ts[(i0 + 8 > n - 1 ? n - 1 : i0 + 8)];
         }
-        __builtin_amdgcn_wave_barrier();
-        // the lane's 8 consecutive ticks
         CcSum me;
         {
             double S = 0.0, mn = INFINITY, mx = -INFINITY, U = 0.0, Pp = -INFINITY, Qp = -INFINITY, Pn = INFINITY, Qn = INFINITY;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const double r = s_r[w][9 * lane + q], lam = s_l[w][9 * lane + q];
+                double r = 0.0, lam = NAN;
+                if (tq + q < m) {
+                    const int64_t i = i0 + q;
+                    cc_tick(p[q], q == 0 ? pm0 : p[q > 0 ? q - 1 : 0], sg[q], a[q], q == 7 ? an : a[q < 7 ? q + 1 : 7], i + 1 < n,
+                            sigma_floor, sigma_mult, &r, &lam);
+                    bad |= !(fabs(r) < INFINITY);
+                }
                 S += r;
                 mn = fmin(mn, S); mx = fmax(mx, S);
                 U = fmax(U, fabs(S));
@@ -158,7 +169,6 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
             }
             me = CcSum{S, U, S - mn, Pp, Qp, S - mx, Pn, Qn};
         }
-        __builtin_amdgcn_wave_barrier();
         // ordered tree over the lanes: after step d, lanes that are multiples of 2d hold [lane, lane + 2d)
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
