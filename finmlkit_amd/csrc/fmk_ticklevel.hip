@@ -73,14 +73,18 @@ __global__ __launch_bounds__(256) void k_lagged_returns(const int64_t *__restric
     if (staged)
         for (int64_t k = threadIdx.x; k < len; k += 256) s_ts[k] = (double)ts[r0 + k];
     __syncthreads();
-    // 4 ticks per thread, processed in three unrolled phases so that the four LDS bisections, then the eight
-    // global loads, are in flight together (the loop is latency-, not bandwidth-bound)
+    // 4 CONSECUTIVE ticks per thread: the lag index is monotone in the tick, so only the first tick bisects the whole stage
+    // (~12 dependent LDS probes); each of the other three gallops forward from its predecessor's answer (2-4 probes).  (First
+    // version: ticks t, t + 256, ... per thread and four independent bisections -- 48 probes per thread, 7.9 ms per 1e9 ticks.)
     constexpr int PER = LR_TILE / 256;
+    const int64_t i0 = i_first + (int64_t)threadIdx.x * PER;
     int64_t lag[PER];
     bool live[PER];
+    int prev_lo = -1;                                    // staged offset of the previous tick's lag (-1: none yet)
+    bool have_prev = false;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int64_t i = i_first + threadIdx.x + 256 * k;
+        const int64_t i = i0 + k;
         lag[k] = -1;
         live[k] = false;
         if (i > i_last) continue;
@@ -92,10 +96,19 @@ __global__ __launch_bounds__(256) void k_lagged_returns(const int64_t *__restric
         // largest j with float64(ts[j]) <= target ; the reference needs 0 <= j < i
         if (staged) {
             int lo = -1, hi = (int)(i - r0);             // staged offsets; f(hi) false
+            if (have_prev && prev_lo >= 0) {
+                // ts is non-decreasing, so is the target: the answer is >= the previous tick's.  Gallop, then bisect.
+                lo = prev_lo;
+                int step = 1;
+                while (lo + step < hi && s_ts[lo + step] <= target) { lo += step; step <<= 1; }
+                hi = lo + step < hi ? lo + step : hi;
+            }
             while (hi - lo > 1) {
                 const int mid = lo + ((hi - lo) >> 1);
                 if (s_ts[mid] <= target) lo = mid; else hi = mid;
             }
+            prev_lo = lo;
+            have_prev = true;
             // lo == -1: nothing in the stage is <= target.  The stage starts at lag(first tick of the tile)
             // (or at tick 0), and lag is monotone, so this only happens when there is no lag at all.
             lag[k] = lo < 0 ? (r0 > 0 ? lr_search_global(ts, i, target) : -1) : r0 + lo;
@@ -104,22 +117,35 @@ __global__ __launch_bounds__(256) void k_lagged_returns(const int64_t *__restric
         }
     }
     double c1[PER], c0[PER];
+    const bool vec = i0 + PER - 1 <= i_last && ((uintptr_t)close & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    if (vec) {
+        const double2 *q = (const double2 *)(close + i0);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int64_t i = i_first + threadIdx.x + 256 * k;
-        c1[k] = 0.0; c0[k] = 0.0;
-        if (live[k] && lag[k] >= 0) { c1[k] = close[i]; c0[k] = close[lag[k]]; }
+        for (int k = 0; k < PER / 2; ++k) { const double2 v = q[k]; c1[2 * k] = v.x; c1[2 * k + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) c1[k] = i0 + k <= i_last ? close[i0 + k] : 0.0;
     }
 #pragma unroll
+    for (int k = 0; k < PER; ++k) c0[k] = (live[k] && lag[k] >= 0) ? close[lag[k]] : 0.0;
+    double res[PER];
+#pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int64_t i = i_first + threadIdx.x + 256 * k;
-        if (i > i_last) continue;
         double r = NAN;
         if (live[k] && lag[k] >= 0) {
             if (c0[k] != 0.0) r = is_log ? log(c1[k] / c0[k]) : c1[k] / c0[k] - 1.0;
             else r = INFINITY;                           // utils.py:57-60
         }
-        out[i] = r;
+        res[k] = r;
+    }
+    if (vec) {
+        double2 *q = (double2 *)(out + i0);
+#pragma unroll
+        for (int k = 0; k < PER / 2; ++k) q[k] = make_double2(res[2 * k], res[2 * k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (i0 + k <= i_last) out[i0 + k] = res[k];
     }
 }
 
