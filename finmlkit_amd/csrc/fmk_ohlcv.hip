@@ -244,7 +244,7 @@ __device__ __forceinline__ void small_bar(const double *__restrict__ price, cons
 // round trip per bar, so what matters there is how many bars a CU has in flight: without the long classes the kernel fits eight
 // waves per SIMD (1e9 ticks, ohlcv + median: 80-tick bars 12.0 -> 9.0 ms, 100-tick 9.9 -> 7.3, 200-tick 5.3 -> 4.1; equal at 240).
 template <bool AF64, bool MEDIAN, int MAXNCH = FMK_SMALL_NCH>
-__global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : 4)) void k_bar_ohlcv_small(const double *__restrict__ price,
+__global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : MAXNCH <= 10 ? 6 : 4)) void k_bar_ohlcv_small(const double *__restrict__ price,
                                                             const void *__restrict__ amount,
                                                             const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                             int *__restrict__ saw_long, OhlcvOut o)
@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : 4)) void k_bar_ohlcv_small(
         if constexpr (MAXNCH <= 4) {
             if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
             else small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+        } else if constexpr (MAXNCH <= 10) {
+            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
         } else {
             switch (nch) {
             case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
@@ -570,6 +574,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     int64_t long_min = 64 * FMK_SMALL_NCH;
     static int mid_max = -1;                 // developer knob: FMK_OHLCV_MID_MAX_MEAN (0 disables the 65..256-tick instantiation)
     if (mid_max < 0) { const char *v = getenv("FMK_OHLCV_MID_MAX_MEAN"); mid_max = v ? atoi(v) : 210; }
+    static int mid2_max = -1;                // FMK_OHLCV_MID2_MAX_MEAN: ... served by the <= 640-tick instantiation
+    if (mid2_max < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2_max = v ? atoi(v) : 600; }
     if (!AF64 && nb >= 64 && n / nb <= packed_max) {
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
@@ -585,6 +591,14 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         if (!o.median) k_bar_ohlcv_small<AF64, false, 4><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_small<AF64, true, 4><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         long_min = 256;
+    } else if (mid_max > 0 && n / nb <= mid2_max) {
+        // ... and of 257..640-tick bars: size classes up to 10 chunks (six waves per SIMD)
+        int64_t blocks = fmk_ceil_div(nb, 4);
+        const int64_t cap = (int64_t)ctx->n_cu * 96;
+        if (blocks > cap) blocks = cap;
+        if (!o.median) k_bar_ohlcv_small<AF64, false, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+        else k_bar_ohlcv_small<AF64, true, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+        long_min = 640;
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
