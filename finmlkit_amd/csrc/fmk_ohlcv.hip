@@ -278,14 +278,34 @@ __global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : MAXNCH <= 10 ? 6 : 4)) void
         const int nch = (int)((cnt + 63) >> 6);
         // exact-size code for the chunk counts a ~1200-tick (1-minute) bar takes, size classes below
         if constexpr (MAXNCH <= 4) {
-            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            switch (nch) {
+            case 1: small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 2: small_bar<AF64, 2, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 3: small_bar<AF64, 3, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            default: small_bar<AF64, 4, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            }
         } else if constexpr (MAXNCH <= 10) {
-            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            // exact-size code for every chunk count (full chunks need neither clamping nor predication)
+            switch (nch) {
+            case 1: small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 2: small_bar<AF64, 2, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 3: small_bar<AF64, 3, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 4: small_bar<AF64, 4, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 5: small_bar<AF64, 5, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 6: small_bar<AF64, 6, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 7: small_bar<AF64, 7, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 8: small_bar<AF64, 8, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 9: small_bar<AF64, 9, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            default: small_bar<AF64, 10, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            }
         } else {
             switch (nch) {
+            case 11: small_bar<AF64, 11, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 12: small_bar<AF64, 12, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 13: small_bar<AF64, 13, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 14: small_bar<AF64, 14, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 15: small_bar<AF64, 15, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+            case 16: small_bar<AF64, 16, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
             case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
             case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
             case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
