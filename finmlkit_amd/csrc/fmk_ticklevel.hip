@@ -404,18 +404,21 @@ __device__ __forceinline__ void ew_load_direct(const int64_t *__restrict__ ts, c
                                                int64_t (&tl)[EW_ITEMS], double (&yl)[EW_ITEMS], int64_t *tprev0)
 {
     const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    // 16-byte accesses on an 8-byte alignment promise: a shard's arrays start one tick before a 64-byte boundary
+    typedef long long ew_l2 __attribute__((ext_vector_type(2), aligned(8)));
+    typedef double ew_d2 __attribute__((ext_vector_type(2), aligned(8)));
     if (i0 + EW_ITEMS <= n) {
         if (ts) {
-            const longlong2 *q = (const longlong2 *)(ts + i0);
+            const ew_l2 *q = (const ew_l2 *)(ts + i0);
 #pragma unroll
-            for (int k = 0; k < EW_ITEMS / 2; ++k) { const longlong2 v = q[k]; tl[2 * k] = v.x; tl[2 * k + 1] = v.y; }
+            for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_l2 v = q[k]; tl[2 * k] = v.x; tl[2 * k + 1] = v.y; }
         } else {
 #pragma unroll
             for (int k = 0; k < EW_ITEMS; ++k) tl[k] = 0;
         }
-        const double2 *qy = (const double2 *)(y + i0);
+        const ew_d2 *qy = (const ew_d2 *)(y + i0);
 #pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) { const double2 v = qy[k]; yl[2 * k] = v.x; yl[2 * k + 1] = v.y; }
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_d2 v = qy[k]; yl[2 * k] = v.x; yl[2 * k + 1] = v.y; }
     } else {
 #pragma unroll
         for (int k = 0; k < EW_ITEMS; ++k) {
@@ -550,9 +553,10 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
     }
     // the thread's 8 results as four 16-byte stores
     if (i0 + EW_ITEMS <= n) {
-        double2 *q = (double2 *)(out + i0);
+        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
+        ew_d2s *q = (ew_d2s *)(out + i0);
 #pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) q[k] = make_double2(res[2 * k], res[2 * k + 1]);
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { ew_d2s v; v.x = res[2 * k]; v.y = res[2 * k + 1]; q[k] = v; }
     } else {
 #pragma unroll
         for (int k = 0; k < EW_ITEMS; ++k)
