@@ -161,7 +161,7 @@ def other_configs(trades, ctx, args):
             ctx.set_fast_threshold(False)
         del exact_idx
         out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
-        out["cfg4_bytes_per_tick"] = 26      # two passes of 13 B/tick: OHLCV + median + order-flow in one kernel, then the footprints
+        out["cfg4_bytes_per_tick"] = 30      # 13 (order flow + OHLC, one lane per bar) + 4 (median of the amounts) + 13 (footprints)
         # the same pass on amounts with a full random float32 mantissa: the footprint level sums are then inexact in every
         # order and every bar takes the tick-ordered accumulation (the synthetic stream's dyadic amounts all certify for the
         # order-free integer path) -- real trade sizes are like that, so this is the number to expect on real data

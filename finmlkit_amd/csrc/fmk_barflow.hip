@@ -352,10 +352,15 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
 #define DL_T 16
 #define DL_ROW 17
 #define DL_WAVES 2                      // 29.6 KB of LDS per workgroup: five per CU
+// OHLC: comp_bar_ohlcv's open / high / low / close / volume / vwap / trades (base.py:352-400) ride along -- the lane already holds
+// the tick's price and amount; six more instructions per tick, the reference's own sequential sums.  (Not the median trade size:
+// fmk_median_small_launch.)  Bars left on the list get theirs from k_bar_ohlcv (`any_long` is its go flag).
+struct DlOhlcOut { double *open, *high, *low, *close; float *vol; double *vwap; int64_t *trades; int *any_long; };
+template <bool OHLC>
 __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *__restrict__ price, const float *__restrict__ amount,
                                                        const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                        int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
-                                                       unsigned long long *long_list, int64_t max_len)
+                                                       unsigned long long *long_list, int64_t max_len, DlOhlcOut oo)
 {
     __shared__ double s_p[DL_WAVES][64 * DL_ROW];
     __shared__ float s_a[DL_WAVES][64 * DL_ROW];
@@ -381,6 +386,10 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
             if (lane == 0) base = atomicAdd(long_list, (unsigned long long)__builtin_popcountll(lb));
             base = (unsigned long long)fmk_uniform((int64_t)base);
             if (is_long) long_list[32 + base + __builtin_popcountll(lb & ((1ULL << lane) - 1))] = (unsigned long long)b;
+            if constexpr (OHLC) {
+                if (lane == 0 && __hip_atomic_load(oo.any_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(oo.any_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         const bool active = has && len > 0 && !is_long;
         const int64_t start = s + 1;
@@ -392,6 +401,8 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
         double vmin = 1e9, vmax = -1e9, dmin = 1e9, dmax = -1e9;
         int ct = 0, tmin = BF_INIT_MIN, tmax = BF_INIT_MAX, nbuy = 0, nsell = 0;
         bool seen = false;                                             // a signed tick has updated the extrema
+        double b_first = 0.0, b_hi = 0.0, b_lo = 0.0, b_tv = 0.0, b_td = 0.0;       // comp_bar_ohlcv's loop state (OHLC)
+        bool opened = false;
         double pp = 0.0;
         int ps = 0;
         if (active) {
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
                 lo = start > blk0 ? (int)(start - blk0) : 0;
                 hi = e - blk0 < 15 ? (int)(e - blk0) : 15;
             }
-            const bool fast = __builtin_amdgcn_ballot_w64(live && !(lo == 0 && hi == 15 && seen)) == 0;
+            const bool fast = __builtin_amdgcn_ballot_w64(live && !(lo == 0 && hi == 15 && seen && (!OHLC || opened))) == 0;
             const double *rowP = sP + lane * DL_ROW;
             const float *rowA = sA + lane * DL_ROW;
             const signed char *rowS = sS8 + lane * 20;
@@ -491,6 +502,12 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
                     cs += sp;
                     pp = p; ps = sd;
                     const double pv = p * a;
+                    if constexpr (OHLC) {                              // base.py:377-391 (every live lane has opened its bar)
+                        b_hi = p > b_hi ? p : b_hi;
+                        b_lo = p < b_lo ? p : b_lo;
+                        b_tv += a;
+                        b_td += pv;
+                    }
                     const bool buy = sd == 1, sell = sd == -1;
                     // x += cond ? y : 0.0 as fma(1.0 or 0.0, y, x): the product is exact, so the one rounding is the addition's
                     // (two instructions instead of two selects and an add); likewise the signed terms with sf = -1, 0, +1
@@ -518,6 +535,13 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
                     }
                     pp = p; ps = sd;
                     const double pv = p * a;
+                    if constexpr (OHLC) {
+                        if (!opened) { b_first = p; b_hi = p; b_lo = p; opened = true; }     // base.py:371-372
+                        if (p > b_hi) b_hi = p;
+                        if (p < b_lo) b_lo = p;
+                        b_tv += a;
+                        b_td += pv;
+                    }
                     if (sd == 1) { nbuy += 1; vb += a; db += pv; ct += 1; cv += a; cd += pv; }
                     else if (sd == -1) { nsell += 1; vs += a; ds += pv; ct -= 1; cv -= a; cd -= pv; }
                     else continue;
@@ -542,6 +566,19 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
             o.cum_ticks_min[b] = tmin; o.cum_ticks_max[b] = tmax;
             o.cum_volumes_min[b] = (float)vmin; o.cum_volumes_max[b] = (float)vmax;
             o.cum_dollars_min[b] = (float)dmin; o.cum_dollars_max[b] = (float)dmax;
+            if constexpr (OHLC) {
+                if (len > 0) {
+                    oo.open[b] = b_first; oo.close[b] = pp;            // pp: the price of the bar's last tick
+                    oo.high[b] = b_hi; oo.low[b] = b_lo;
+                    oo.vol[b] = (float)b_tv;
+                    oo.vwap[b] = b_tv > 0.0 ? b_td / b_tv : 0.0;       // base.py:398
+                    oo.trades[b] = len;
+                } else {                                               // empty bar: previous close (base.py:352-361)
+                    const double pz = price[fmk_wrap(e, n)];
+                    oo.open[b] = pz; oo.high[b] = pz; oo.low[b] = pz; oo.close[b] = pz;
+                    oo.vol[b] = 0.f; oo.vwap[b] = 0.0; oo.trades[b] = 0;
+                }
+            }
         }
     }
 }
@@ -729,9 +766,10 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
         int64_t lblocks = fmk_ceil_div(fmk_ceil_div(nb, 64), DL_WAVES);
         const int64_t lcap = (int64_t)ctx->n_cu * 40;
         if (lblocks > lcap) lblocks = lcap;
-        k_bar_dir_lanes<<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side, d_close_idx,
-                                                                             nb, n, o, (unsigned long long *)d_n_zero_div,
-                                                                             long_list, 8192);
+        k_bar_dir_lanes<false><<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side,
+                                                                                    d_close_idx, nb, n, o,
+                                                                                    (unsigned long long *)d_n_zero_div, long_list,
+                                                                                    8192, DlOhlcOut{});
         FMK_LAUNCH_CHECK(ctx);
         k_bar_dir<false><<<(unsigned)(blocks < 2048 ? blocks : 2048), 256, 0, ctx->stream>>>(
             d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, redo, long_list);
@@ -781,11 +819,48 @@ extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const
     // short bars: the fused kernel is a wave-per-bar schedule; comp_bar_ohlcv and the order-flow features each have a
     // several-bars-per-wave schedule of their own (k_bar_ohlcv_lanes, k_bar_dir_lanes)
     const bool short_bars = n / (n_idx - 1) < 600;
+    const char *flv = getenv("FMK_FLOW_LANES");
+    const int flow_lanes = flv ? atoi(flv) : 1;
     if (amount_is_f64 || separate || short_bars) {
         FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
                                        d_close, d_volume, d_vwap, d_trades, d_median));
         FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
                                              d_n_zero_div));
+    } else if (flow_lanes != 0 && ((uintptr_t)d_amount & 7) == 0 && ((uintptr_t)d_side & 3) == 0 &&
+               (flow_lanes == 2 || (n_idx - 1 >= (int64_t)ctx->n_cu * 64 * 4 && n / (n_idx - 1) <= 2048))) {
+        // Streams of many 600..2048-tick bars (1-minute bars): ONE lane per bar walks price / amount / side for the order-flow
+        // features AND open / high / low / close / volume / vwap (k_bar_dir_lanes<true>: 13 B/tick), the median trade size comes
+        // from the amounts alone (fmk_median_small_launch: 4 B/tick).  Measured against the fused wave-per-bar kernel below
+        // (k_bar_ohlcv_dir, 13 B/tick, VALU-bound): profiles/r02_cfg4.txt.  Developer knob FMK_FLOW_LANES: 0 never, 2 whenever the layout allows.
+        FMK_HIP(ctx, hipSetDevice(ctx->device));
+        const int64_t nb = n_idx - 1;
+        FlowDirOut o;
+        memcpy(&o, d_dir, sizeof(o));
+        unsigned long long *redo;
+        FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 16, (void **)&redo));
+        unsigned long long *long_list = redo + nb + 32;
+        int *any_long = (int *)(ctx->d_mail + 20);
+        FMK_HIP(ctx, hipMemsetAsync(redo, 0, 8, ctx->stream));
+        FMK_HIP(ctx, hipMemsetAsync(long_list, 0, 8, ctx->stream));
+        FMK_HIP(ctx, hipMemsetAsync(any_long, 0, sizeof(int), ctx->stream));
+        int64_t lblocks = fmk_ceil_div(fmk_ceil_div(nb, 64), DL_WAVES);
+        const int64_t lcap = (int64_t)ctx->n_cu * 40;
+        if (lblocks > lcap) lblocks = lcap;
+        DlOhlcOut oo{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, any_long};
+        k_bar_dir_lanes<true><<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side,
+                                                                                   d_close_idx, nb, n, o,
+                                                                                   (unsigned long long *)d_n_zero_div, long_list,
+                                                                                   8192, oo);
+        FMK_LAUNCH_CHECK(ctx);
+        int64_t blocks = fmk_ceil_div(nb, 4);
+        if (blocks > 2048) blocks = 2048;
+        k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                                   (unsigned long long *)d_n_zero_div, redo, long_list);
+        k_bar_dir_redo<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_TRY(fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, 8192, any_long, d_open, d_high, d_low,
+                                          d_close, d_volume, d_vwap, d_trades));
+        if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median));
     } else {
         FMK_HIP(ctx, hipSetDevice(ctx->device));
         const int64_t nb = n_idx - 1;

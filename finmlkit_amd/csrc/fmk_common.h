@@ -54,6 +54,12 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
                                 int64_t n_ticks /* 0: unknown */);
 
+// fmk_ohlcv.hip: pieces of comp_bar_ohlcv for cfg 4's first half (fmk_barflow.hip)
+int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,
+                              int64_t n, int64_t min_cnt, const int *go, double *d_open, double *d_high, double *d_low,
+                              double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades);
+int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median);
+
 #define FMK_HIP(ctx, expr)                                                                   \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \

@@ -322,6 +322,75 @@ __global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : MAXNCH <= 10 ? 6 : 4)) void
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The median trade size ALONE for bars of <= 64 * 21 ticks (float32 amounts): k_bar_ohlcv_small's amount loads, keys and
+// order-statistic search without the price column (4 B/tick).  For cfg 4's first half the order-flow kernel k_bar_dir_lanes walks
+// price / amount / side anyway and takes open / high / low / close / volume / vwap along for six instructions per tick; what it cannot
+// do in one lane is the median of 1 200 amounts.  Longer bars: k_bar_median through the flag, as after k_bar_ohlcv_small.
+template <int NCH>
+__device__ __forceinline__ void median_bar(const void *__restrict__ amount, int64_t b, int64_t start, int64_t cnt, int lane,
+                                           uint32_t *buf, double *__restrict__ o_median)
+{
+    typedef MedKey<false> MK;
+    const uint32_t *ab = (const uint32_t *)amount + start;
+    const unsigned last = (unsigned)(cnt - 1);
+    MedBar<false, NCH, true> bar;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        unsigned idx = (unsigned)(c * 64 + lane);
+        if (c == NCH - 1) idx = idx < last ? idx : last;
+        const uint32_t raw = ab[idx];
+        bar.key[c] = (c < NCH - 1 || (unsigned)(c * 64 + lane) <= last) ? MK::tokey(raw) : MK::MAXK;
+    }
+    bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+    const double m = med_search<false, NCH, true>(bar, buf);
+    if (lane == 0) o_median[b] = m;
+}
+
+__global__ __launch_bounds__(256) void k_bar_median_small(const float *__restrict__ amount, const int64_t *__restrict__ ci,
+                                                          int64_t nb, int *__restrict__ saw_long, double *__restrict__ o_median)
+{
+    __shared__ uint32_t sbuf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    uint32_t *buf = sbuf[wib];
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]);
+        const int64_t e = fmk_uniform(ci[b + 1]);
+        const int64_t cnt = e - s;
+        if (cnt > 64 * FMK_SMALL_NCH) {
+            if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (cnt <= 0) { if (lane == 0) o_median[b] = 0.0; continue; }     // base.py:352-361
+        const int64_t start = s + 1;
+        switch ((int)((cnt + 63) >> 6)) {
+#define FMK_MB(N) case N: median_bar<N>(amount, b, start, cnt, lane, buf, o_median); break;
+            FMK_MB(1) FMK_MB(2) FMK_MB(3) FMK_MB(4) FMK_MB(5) FMK_MB(6) FMK_MB(7) FMK_MB(8) FMK_MB(9) FMK_MB(10) FMK_MB(11)
+            FMK_MB(12) FMK_MB(13) FMK_MB(14) FMK_MB(15) FMK_MB(16) FMK_MB(17) FMK_MB(18) FMK_MB(19) FMK_MB(20)
+#undef FMK_MB
+        default: median_bar<21>(amount, b, start, cnt, lane, buf, o_median); break;
+        }
+    }
+}
+
+// median trade size of every bar, float32 amounts: the small-bar kernel + k_bar_median for the bars beyond its classes
+int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median)
+{
+    int *saw_long = (int *)(ctx->d_mail + 16);
+    FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 64;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    k_bar_median_small<<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, saw_long, d_median);
+    FMK_LAUNCH_CHECK(ctx);
+    return fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, 64 * FMK_SMALL_NCH, saw_long, d_median);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Short bars (float32 amounts), one LANE per bar.  The reference's other caller builds 1-SECOND bars (AddTimeBarH5,
 // bar/io.py:484-485: ~20 ticks per bar on the SURVEY 8(d) stream).  One wave per bar then uses 20 of 64 lanes and pays four
 // cross-lane butterflies plus a 64-lane sort per bar: 46 ms per 1e9 ticks, 0.34 TB/s.  A first packed schedule (whole bars
@@ -631,6 +700,19 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         FMK_LAUNCH_CHECK(ctx);
     }
     if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median);
+    return FMK_OK;
+}
+
+// comp_bar_ohlcv (without the median) for the bars longer than min_cnt that another kernel left behind (`go`: its flag)
+int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,
+                              int64_t n, int64_t min_cnt, const int *go, double *d_open, double *d_high, double *d_low,
+                              double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades)
+{
+    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, nullptr, nullptr};
+    const unsigned grid = ohlcv_grid(ctx, nb);
+    if (amount_is_f64) k_bar_ohlcv<true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
+    else k_bar_ohlcv<false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
+    FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
 

@@ -357,3 +357,32 @@ def test_one_second_bars_full_size(big, prefix, orc):
         np.testing.assert_array_equal(flat[key].view(0, int(woff[-1])).to_host().astype(wflat[key].dtype), wflat[key], err_msg=key)
     for key in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
         np.testing.assert_array_equal(bar[key].view(0, k).to_host(), wbar[key], err_msg=key)
+
+
+def test_cfg4_first_half_lane_schedule_full_size(big, prefix, orc):
+    """cfg 4 at 1e9 ticks, 1-minute bars: bars_fused takes k_bar_dir_lanes<OHLC> + the median-only kernel on its own.  Its OHLCV
+    equals build_ohlcv's (vwap to 1e-9: the lane adds in the reference's tick order, the wave kernel as a tree), its order-flow
+    columns the standalone reducer's, and everything the oracle's on the prefix."""
+    engine, t, n = big
+    ts, px, am, sd = prefix
+    _, ci = t.time_bar_index(60.0)
+    cih = ci.to_host()
+    o, d, nz, off, flat, bar, bad = t.bars_fused(ci, 0.01, 3.0)
+    o, d = engine.to_host(o), engine.to_host(d)
+    o2 = engine.to_host(t.bar_ohlcv(ci))
+    for k in o2:
+        if k == "vwap":
+            G.assert_f64_close(o[k], o2[k], what="vwap fused vs build_ohlcv")
+        else:
+            np.testing.assert_array_equal(o[k], o2[k], err_msg=k)
+    d2, _ = t.bar_directional(ci)
+    for k, v in engine.to_host(d2).items():
+        np.testing.assert_array_equal(d[k], v, err_msg=k)
+    _, oci = orc._time_bar_indexer(ts, 60.0)
+    k = int(np.searchsorted(cih, PREFIX - 1, side="left")) - 1
+    want = orc.comp_bar_ohlcv(px, am, oci[:k + 1])
+    for key, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], want):
+        if key == "vwap":
+            G.assert_f64_close(o[key][:k], w, what="vwap")
+        else:
+            np.testing.assert_array_equal(o[key][:k], w, err_msg=key)

@@ -72,7 +72,12 @@ def test_fused_golden(orc, case):
     (100_000, 3.0, "mixed", False),          # dyadic with a few inexact amounts: exact -> retry / ordered switches
     (130, 60.0, "dyadic", False), (1, 60.0, "dyadic", False),
 ])
-def test_fused_vs_oracle(orc, n, interval, amounts, zeros):
+@pytest.mark.parametrize("flow_lanes", ["1", "2"])
+def test_fused_vs_oracle(orc, monkeypatch, n, interval, amounts, zeros, flow_lanes):
+    """flow_lanes 2: the first half of cfg 4 through k_bar_dir_lanes<OHLC> + the median-only small-bar kernel whatever the number
+    of bars (the library takes that path for >= 65 536 bars of 600..2048 ticks on average; bars beyond 8 192 ticks go to the
+    wave-per-bar kernels by list / flag)."""
+    monkeypatch.setenv("FMK_FLOW_LANES", flow_lanes)
     ts, px, am, sd = orc.synth(17, 0, n)
     rng = np.random.default_rng(3)
     if amounts == "lognormal32":
@@ -92,7 +97,9 @@ def test_fused_vs_oracle(orc, n, interval, amounts, zeros):
     _check_all(orc, px, am, sd, ci, f"n={n} iv={interval} {amounts}")
 
 
-def test_fused_sparse_stream_empty_bars(orc):
+@pytest.mark.parametrize("flow_lanes", ["1", "2"])
+def test_fused_sparse_stream_empty_bars(orc, monkeypatch, flow_lanes):
+    monkeypatch.setenv("FMK_FLOW_LANES", flow_lanes)
     ts, px, am, sd = orc.synth(42, 0, 20_000, orc.SPARSE_GAP_MOD)
     _, ci = orc._time_bar_indexer(ts, 60.0)
     assert (np.diff(ci) == 0).any()
