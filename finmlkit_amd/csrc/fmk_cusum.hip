@@ -67,23 +67,26 @@ __device__ __forceinline__ double ff_block_exclusive(double mine, double *lds /*
 // same-address atomic per wave, 2 M of them at ~10 ns -- 22.5 ms for a kernel that reads 8 GB (now see profiles/).
 __global__ __launch_bounds__(FF_THREADS) void k_ff_tile(const double *__restrict__ x, int64_t n,
                                                         double *__restrict__ tile_last,
-                                                        unsigned long long *first_valid)
+                                                        unsigned long long *first_valid, int *__restrict__ tile_nan)
 {
     __shared__ double lds_v[4];
     __shared__ int64_t lds_i[4];
+    __shared__ int lds_c[4];
     const int64_t t0 = (int64_t)blockIdx.x * FF_TILE + (int64_t)threadIdx.x;
     double v[FF_ITEMS];
 #pragma unroll
     for (int k = 0; k < FF_ITEMS; ++k) v[k] = t0 + (int64_t)k * FF_THREADS < n ? x[t0 + (int64_t)k * FF_THREADS] : NAN;
     double last = NAN;
     int64_t last_i = -1, first = INT64_MAX;
+    int nan_cnt = 0;                                                 // NaNs of the tile (inside the array)
 #pragma unroll
-    for (int k = 0; k < FF_ITEMS; ++k)
+    for (int k = 0; k < FF_ITEMS; ++k) {
+        const int64_t i = t0 + (int64_t)k * FF_THREADS;
         if (!isnan(v[k])) {
-            const int64_t i = t0 + (int64_t)k * FF_THREADS;
             last = v[k]; last_i = i;                                 // k ascends: the thread's last valid item
             if (first == INT64_MAX) first = i;
-        }
+        } else if (i < n) ++nan_cnt;
+    }
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
     first = fmk_wave_min(first);
     if (lane == 0 && first != INT64_MAX && (unsigned long long)first < __atomic_load_n(first_valid, __ATOMIC_RELAXED))
@@ -94,13 +97,33 @@ __global__ __launch_bounds__(FF_THREADS) void k_ff_tile(const double *__restrict
         const double ov = __shfl_xor(last, d, 64);
         if (oi > last_i) { last_i = oi; last = ov; }
     }
-    if (lane == 0) { lds_v[w] = last; lds_i[w] = last_i; }
+    nan_cnt = fmk_wave_sum(nan_cnt);
+    if (lane == 0) { lds_v[w] = last; lds_i[w] = last_i; lds_c[w] = nan_cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double bv = lds_v[0];
         int64_t bi = lds_i[0];
         for (int q = 1; q < 4; ++q) if (lds_i[q] > bi) { bi = lds_i[q]; bv = lds_v[q]; }
         tile_last[blockIdx.x] = bi >= 0 ? bv : NAN;
+        tile_nan[blockIdx.x] = lds_c[0] + lds_c[1] + lds_c[2] + lds_c[3];
+    }
+}
+
+// total number of NaNs (one block): with the first valid index it tells whether there is anything to fill -- all NaNs lead
+// iff their number equals that index -- and the scan and the 8 GB apply pass are skipped when there is not (the usual case:
+// an EWM sigma is NaN at its first tick only)
+__global__ __launch_bounds__(1024) void k_ff_count(const int *__restrict__ tile_nan, int64_t tiles, long long *total)
+{
+    __shared__ long long ws[16];
+    long long acc = 0;
+    for (int64_t i = threadIdx.x; i < tiles; i += 1024) acc += tile_nan[i];
+    acc = fmk_wave_sum(acc);
+    if (fmk_lane() == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < 16; ++k) t += ws[k];
+        *total = t;
     }
 }
 
@@ -460,23 +483,30 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     const size_t act_bytes = ((size_t)max_chunks + 255) & ~(size_t)255;
     const size_t list_bytes = ((size_t)max_chunks * 4 + 255) & ~(size_t)255;
     // the forward fill only needs its tile array; the fixed point's 16 B/tick of scratch are requested when it runs
-    FMK_TRY(fmk_scratch(ctx, ff_bytes, &scr));
+    FMK_TRY(fmk_scratch(ctx, ff_bytes + (size_t)tiles * 4 + 256, &scr));
     double *tile_last = (double *)scr;
+    int *tile_nan = (int *)((char *)scr + ff_bytes);
     unsigned long long *d_first = (unsigned long long *)ctx->d_mail;
     unsigned long long *d_changed = d_first + 1;
     // ---- forward fill of sigma (in place) + first non-NaN index
     const unsigned long long big = ~0ULL;
     FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
-    k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first);
+    k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first, tile_nan);
     FMK_LAUNCH_CHECK(ctx);
-    k_ff_scan_tiles<<<1, 1024, 0, ctx->stream>>>(tile_last, tiles);
-    FMK_LAUNCH_CHECK(ctx);
-    k_ff_apply<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last);
+    k_ff_count<<<1, 1024, 0, ctx->stream>>>(tile_nan, tiles, (long long *)(ctx->d_mail + 2));
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], ctx->d_mail + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int64_t first = ctx->h_mail[0];
-    if ((unsigned long long)first == big) first = 0;              // all NaN: logic.py:178 keeps index 0
+    const bool all_nan = (unsigned long long)first == big;
+    if (!all_nan && ctx->h_mail[2] != first) {                    // NaNs after the first valid entry: fill them (logic.py:187-189)
+        k_ff_scan_tiles<<<1, 1024, 0, ctx->stream>>>(tile_last, tiles);
+        FMK_LAUNCH_CHECK(ctx);
+        k_ff_apply<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    if (all_nan) first = 0;                                       // all NaN: logic.py:178 keeps index 0
 
     // ---- parallel-in-time fixed point over the chunks of ticks first+1 .. n-1
     const int64_t m = n - (first + 1);
