@@ -108,7 +108,8 @@ __device__ __forceinline__ void cc_tick(double p, double pm, double sg, int64_t 
 __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                     const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                     int64_t chunk_lo, int64_t chunk_hi, int64_t chunks, double sigma_floor,
-                                                    double sigma_mult, double *__restrict__ sums, CcState *state)
+                                                    double sigma_mult, double *__restrict__ sums, double *__restrict__ subs,
+                                                    CcState *state)
 {
     const int lane = fmk_lane(), w = (int)(threadIdx.x >> 6);
     const int64_t k = chunk_lo + (int64_t)blockIdx.x * 4 + w;
@@ -178,6 +179,12 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
             o.An = cc_shfl_down(me.An, d); o.Pn = cc_shfl_down(me.Pn, d); o.Qn = cc_shfl_down(me.Qn, d);
             me = cc_compose(me, o);
         }
+        if (lane == 0) {                                      // the 512-tick sub-block's own summary (the walk opens sub-blocks)
+            const int64_t q = k * (CC_CHUNK / CC_SUB) + sub, nq = chunks * (CC_CHUNK / CC_SUB);
+            subs[0 * nq + q] = me.B; subs[1 * nq + q] = me.U;
+            subs[2 * nq + q] = me.Ap; subs[3 * nq + q] = me.Pp; subs[4 * nq + q] = me.Qp;
+            subs[5 * nq + q] = me.An; subs[6 * nq + q] = me.Pn; subs[7 * nq + q] = me.Qn;
+        }
         acc = cc_compose(acc, me);                            // meaningful on lane 0
     }
     if (lane == 0) {
@@ -201,7 +208,7 @@ __global__ void k_cc_init(CcState *st3, int64_t *flag)
 // the walk along the chain: wave 0 walks, the other waves of the workgroup only help to open a chunk
 // ---------------------------------------------------------------------------------------
 #define CC_PAD(j) ((j) + ((j) >> 5))
-#define CC_WALK_WAVES 4
+#define CC_WALK_WAVES 8
 struct CcMap { double B, Ap, An; };                                   // exit maps of the two sides: max(Ap, s + B), min(An, s + B)
 __device__ __forceinline__ CcMap cc_map_compose(const CcMap &l, const CcMap &r)
 {
@@ -234,7 +241,8 @@ __device__ __forceinline__ CcMap cc_map_exclusive(const CcMap &inc)
 __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                 const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                 int64_t chunk_limit, int64_t chunks, double sigma_floor, double sigma_mult,
-                                                const double *__restrict__ sums, CcState *states, int64_t visit_budget,
+                                                const double *__restrict__ sums, const double *__restrict__ subs,
+                                                CcState *states, int64_t visit_budget,
                                                 double margin_scale, int joint, int64_t *__restrict__ lists, int64_t list_cap,
                                                 int64_t *__restrict__ closes, int64_t capacity)
 {
@@ -245,19 +253,20 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     const int side = joint ? 0 : (int)blockIdx.x + 1;
     const bool do_p = side != 2, do_n = side != 1;
     CcState *state = states + (joint ? 2 : (int)blockIdx.x);
-    __shared__ double s_r[CC_CHUNK + CC_CHUNK / 32], s_l[CC_CHUNK + CC_CHUNK / 32];
-    __shared__ int64_t s_cmd;                                           // chunk to open, -1: the walk is over
+    __shared__ double s_r[CC_SUB + CC_SUB / 8], s_l[CC_SUB + CC_SUB / 8];
+    __shared__ int64_t s_cmd;                                           // sub-block (4 * chunk + sub) to open, -1: the walk is over
     const int lane = fmk_lane(), wv = (int)(threadIdx.x >> 6);
-    // r / lam of the chunk's rows wv, wv + 8, ... into LDS (all waves; the expressions of k_cusum_prep)
-    auto open_rows = [&](int64_t k) {
-        const int64_t t0 = k * CC_CHUNK;
-        const int len = (int)(m - t0 < CC_CHUNK ? m - t0 : CC_CHUNK);
-        constexpr int RW = CC_CHUNK / 64 / CC_WALK_WAVES;
+    // r / lam of the sub-block's rows wv, wv + WAVES, ... into LDS (all waves; the expressions of k_cusum_prep)
+    auto open_rows = [&](int64_t q) {
+        const int64_t tq = (q >> 2) * CC_CHUNK + (q & 3) * CC_SUB;      // t of the sub-block's first tick
+        const int64_t left = m - tq;
+        const int len = (int)(left < CC_SUB ? (left > 0 ? left : 0) : CC_SUB);
+        constexpr int RW = CC_SUB / 64 / CC_WALK_WAVES;
         double p[RW], pm[RW], sg[RW];
         int64_t a[RW], b[RW];
 #pragma unroll
         for (int g = 0; g < RW; ++g) {
-            int64_t i = first + 1 + t0 + 64 * (wv + CC_WALK_WAVES * g) + lane;
+            int64_t i = first + 1 + tq + 64 * (wv + CC_WALK_WAVES * g) + lane;
             if (i > n - 1) i = n - 1;
             p[g] = price[i]; pm[g] = price[i - 1]; sg[g] = sigma[i]; a[g] = ts[i]; b[g] = ts[i + 1 < n ? i + 1 : i];
         }
@@ -265,17 +274,17 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
         for (int g = 0; g < RW; ++g) {
             const int j = 64 * (wv + CC_WALK_WAVES * g) + lane;
             double r = 0.0, lam = NAN;
-            if (j < len) cc_tick(p[g], pm[g], sg[g], a[g], b[g], first + 1 + t0 + j + 1 < n, sigma_floor, sigma_mult, &r, &lam);
-            s_r[CC_PAD(j)] = r;
-            s_l[CC_PAD(j)] = lam;
+            if (j < len) cc_tick(p[g], pm[g], sg[g], a[g], b[g], first + 1 + tq + j + 1 < n, sigma_floor, sigma_mult, &r, &lam);
+            s_r[j + (j >> 3)] = r;
+            s_l[j + (j >> 3)] = lam;
         }
     };
-    if (wv != 0) {                                                      // helpers: two barriers per opened chunk
+    if (wv != 0) {                                                      // helpers: two barriers per opened sub-block
         for (;;) {
             __syncthreads();
-            const int64_t k = s_cmd;
-            if (k < 0) return;
-            open_rows(k);
+            const int64_t q = s_cmd;
+            if (q < 0) return;
+            open_rows(q);
             __syncthreads();
         }
     }
@@ -346,78 +355,115 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
         if (k < 0) { load_batch(c); CC_TICK(tG) continue; }
         CC_TICK(tG)
         // ---- open it
+        (void)U_k;
         sp = k_sp; sn = k_sn;
         c = k;
-        if (visits >= visit_budget) { status = CC_ST_BUDGET; break; }
-        ++visits;
         load_batch(k + 1);                                                // the groups after this chunk, behind the work below
         const int64_t t0 = k * CC_CHUNK;
-        if (lane == 0) s_cmd = k;
-        __syncthreads();
-        open_rows(k);
-        __syncthreads();
-        // the lane's 32 consecutive ticks, in registers for the passes below
-        double rr[32], ll[32];
-        const int j_lo = 32 * lane;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) { rr[q] = s_r[CC_PAD(j_lo + q)]; ll[q] = s_l[CC_PAD(j_lo + q)]; }
-        CC_TICK(tL)
-        // Ticks that are decided (up to and including an event) are neutralised: whole lanes through `dead`, the event's own
-        // lane by r = 0 / lam = NaN in its registers.  A block's minimum / maximum prefix includes the empty prefix here (mn,
-        // mx start at 0): that only adds "reset before the block's first tick" to the exit map, max(A, B, s + B), which is
-        // max(A, s + B) for every state the positive side can have (s >= 0; mirrored for the negative side) -- and it makes
-        // r = 0 ticks and dead lanes exact identities, so the passes need no per-tick predicates.
-        int dead = 0;
-        for (;;) {
-            // (1) each lane's exit map, scanned over the lanes
-            double S = 0.0, mn = 0.0, mx = 0.0;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) { S += rr[q]; mn = fmin(mn, S); mx = fmax(mx, S); }
-            CcMap me{S, S - mn, S - mx};
-            if (lane < dead) me = CcMap{0.0, 0.0, 0.0};
-            const CcMap lexc = cc_map_exclusive(cc_map_iscan(me));
-            const double lp = fmax(lexc.Ap, sp + lexc.B), ln = fmin(lexc.An, sn + lexc.B);   // states entering the lane's ticks
-            // (2a) the reference's loop over the lane's ticks: which ticks come within the margins of a threshold (or beyond)?
-            const double mp = (double)(t0 + CC_CHUNK - reset_p + 4096) * eps * mag_p;
-            const double mq = (double)(t0 + CC_CHUNK - reset_n + 4096) * eps * mag_n;
-            unsigned mask = 0;
-            double ap = lp, an = ln;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                ap = fmax(ap + rr[q], 0.0);                               // max(0.0, s_pos + ret), min(0.0, s_neg + ret)
-                an = fmin(an + rr[q], 0.0);
-                mask |= ((do_p && ap - ll[q] >= -mp) || (do_n && an + ll[q] <= mq)) ? 1u << q : 0u;
+        // The chunk's four 512-tick sub-blocks have summaries of their own (k_cc_summary): the same step as above over them finds
+        // the first sub-block that may close, and only that one is opened -- 8 ticks per lane instead of 32, 8 rows of log()
+        // instead of 32.  After its events the walk goes on over the remaining sub-blocks' summaries.
+        CcSum sb = cc_identity();
+        {
+            const int64_t nq = chunks * (CC_CHUNK / CC_SUB), q = k * (CC_CHUNK / CC_SUB) + lane;
+            if (lane < CC_CHUNK / CC_SUB)
+                sb = CcSum{subs[0 * nq + q], subs[1 * nq + q], subs[2 * nq + q], subs[3 * nq + q],
+                           subs[4 * nq + q], subs[5 * nq + q], subs[6 * nq + q], subs[7 * nq + q]};
+        }
+        int s_from = 0;                                                   // first sub-block not yet passed
+        while (s_from < CC_CHUNK / CC_SUB && status == CC_ST_DONE) {
+            CcMap mm{sb.B, sb.Ap, sb.An};
+            if (lane < s_from || lane >= CC_CHUNK / CC_SUB) mm = CcMap{0.0, -INFINITY, INFINITY};
+            const CcMap sinc = cc_map_iscan(mm);
+            const CcMap sexc = cc_map_exclusive(sinc);
+            const double si_p = fmax(sexc.Ap, sp + sexc.B), si_n = fmin(sexc.An, sn + sexc.B);   // states entering the sub-block
+            const bool mine = lane >= s_from && lane < CC_CHUNK / CC_SUB;
+            const double sg_p = fmax(mag_p, fmk_dpp_reduce(mine ? fabs(si_p) + 2.0 * sb.U : 0.0, 0.0, FmkOpMax()));
+            const double sg_n = fmax(mag_n, fmk_dpp_reduce(mine ? fabs(si_n) + 2.0 * sb.U : 0.0, 0.0, FmkOpMax()));
+            const double sm_p = (double)(t0 + CC_CHUNK - reset_p + 4096) * eps * sg_p;
+            const double sm_n = (double)(t0 + CC_CHUNK - reset_n + 4096) * eps * sg_n;
+            const bool scand = mine && ((do_p && fmax(sb.Pp, si_p + sb.Qp) >= -sm_p) || (do_n && fmin(sb.Pn, si_n + sb.Qn) <= sm_n));
+            const unsigned long long sc = __builtin_amdgcn_ballot_w64(scand);
+            mag_p = sg_p; mag_n = sg_n;
+            if (sc == 0) {                                                // the rest of the chunk passes without an event
+                const double oB = cc_bcast(sinc.B, CC_CHUNK / CC_SUB - 1), oAp = cc_bcast(sinc.Ap, CC_CHUNK / CC_SUB - 1);
+                const double oAn = cc_bcast(sinc.An, CC_CHUNK / CC_SUB - 1);
+                sp = fmax(oAp, sp + oB); sn = fmin(oAn, sn + oB);
+                break;
             }
-            if (lane < dead) mask = 0;
-            const unsigned long long eb = __builtin_amdgcn_ballot_w64(mask != 0);
-            if (eb == 0) { sp = cc_bcast(ap, 63); sn = cc_bcast(an, 63); break; }
-            // (2b) the first such tick: the states there (wave-uniform trip count: no predicates)
-            const int fl = __builtin_ctzll(eb);
-            const int q0 = __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)mask, fl));
-            double bp = lp, bn = ln, lamq = NAN;
+            const int sf = __builtin_ctzll(sc);
+            sp = cc_bcast(si_p, sf); sn = cc_bcast(si_n, sf);
+            const double U_s = cc_bcast(sb.U, sf);
+            if (visits >= visit_budget) { status = CC_ST_BUDGET; break; }
+            ++visits;
+            const int64_t ts0 = t0 + (int64_t)sf * CC_SUB;                // t of the sub-block's first tick
+            if (lane == 0) s_cmd = k * (CC_CHUNK / CC_SUB) + sf;
+            __syncthreads();
+            open_rows(k * (CC_CHUNK / CC_SUB) + sf);
+            __syncthreads();
+            // the lane's 8 consecutive ticks, in registers for the passes below
+            double rr[8], ll[8];
 #pragma unroll
-            for (int q = 0; q < 32; ++q)
-                if (q <= q0) { bp = fmax(bp + rr[q], 0.0); bn = fmin(bn + rr[q], 0.0); lamq = ll[q]; }
-            const double dp = bp - lamq, dn = bn + lamq;
-            // `if s_pos >= lam ... elif s_neg <= -lam`, each answer only when it is beyond the margin
-            const int kind_l = (do_p && dp >= mp) ? 1 : ((!do_p || dp < -mp) && do_n && dn <= -mq) ? 2 : 3;
-            const int kind = __builtin_amdgcn_readlane(kind_l, fl);
-            if (kind == 3) { status = CC_ST_UNCERTAIN; break; }
-            const int j = 32 * fl + q0;
-            if (joint) { if (lane == 0 && closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + t0 + j; }
-            else {
-                if (n_out >= list_cap) { status = CC_ST_BUDGET; break; }
-                if (lane == 0) lists[(int64_t)(side - 1) * list_cap + n_out] = first + 1 + t0 + j;
+            for (int q = 0; q < 8; ++q) { rr[q] = s_r[9 * lane + q]; ll[q] = s_l[9 * lane + q]; }
+            CC_TICK(tL)
+            // Ticks that are decided (up to and including an event) are neutralised: whole lanes through `dead`, the event's own
+            // lane by r = 0 / lam = NaN in its registers.  A block's minimum / maximum prefix includes the empty prefix here (mn,
+            // mx start at 0): that only adds "reset before the block's first tick" to the exit map, max(A, B, s + B), which is
+            // max(A, s + B) for every state the positive side can have (s >= 0; mirrored for the negative side) -- and it makes
+            // r = 0 ticks and dead lanes exact identities, so the passes need no per-tick predicates.
+            int dead = 0;
+            for (;;) {
+                // (1) each lane's exit map, scanned over the lanes
+                double S = 0.0, mn = 0.0, mx = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { S += rr[q]; mn = fmin(mn, S); mx = fmax(mx, S); }
+                CcMap me{S, S - mn, S - mx};
+                if (lane < dead) me = CcMap{0.0, 0.0, 0.0};
+                const CcMap lexc = cc_map_exclusive(cc_map_iscan(me));
+                const double lp = fmax(lexc.Ap, sp + lexc.B), ln = fmin(lexc.An, sn + lexc.B);   // states entering the lane's ticks
+                // (2a) the reference's loop over the lane's ticks: which ticks come within the margins of a threshold (or beyond)?
+                const double mp = (double)(ts0 + CC_SUB - reset_p + 4096) * eps * mag_p;
+                const double mq = (double)(ts0 + CC_SUB - reset_n + 4096) * eps * mag_n;
+                unsigned mask = 0;
+                double ap = lp, an = ln;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ap = fmax(ap + rr[q], 0.0);                           // max(0.0, s_pos + ret), min(0.0, s_neg + ret)
+                    an = fmin(an + rr[q], 0.0);
+                    mask |= ((do_p && ap - ll[q] >= -mp) || (do_n && an + ll[q] <= mq)) ? 1u << q : 0u;
+                }
+                if (lane < dead) mask = 0;
+                const unsigned long long eb = __builtin_amdgcn_ballot_w64(mask != 0);
+                if (eb == 0) { sp = cc_bcast(ap, 63); sn = cc_bcast(an, 63); break; }
+                // (2b) the first such tick: the states there (wave-uniform trip count: no predicates)
+                const int fl = __builtin_ctzll(eb);
+                const int q0 = __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)mask, fl));
+                double bp = lp, bn = ln, lamq = NAN;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q <= q0) { bp = fmax(bp + rr[q], 0.0); bn = fmin(bn + rr[q], 0.0); lamq = ll[q]; }
+                const double dp = bp - lamq, dn = bn + lamq;
+                // `if s_pos >= lam ... elif s_neg <= -lam`, each answer only when it is beyond the margin
+                const int kind_l = (do_p && dp >= mp) ? 1 : ((!do_p || dp < -mp) && do_n && dn <= -mq) ? 2 : 3;
+                const int kind = __builtin_amdgcn_readlane(kind_l, fl);
+                if (kind == 3) { status = CC_ST_UNCERTAIN; break; }
+                const int j = 8 * fl + q0;
+                if (joint) { if (lane == 0 && closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + ts0 + j; }
+                else {
+                    if (n_out >= list_cap) { status = CC_ST_BUDGET; break; }
+                    if (lane == 0) lists[(int64_t)(side - 1) * list_cap + n_out] = first + 1 + ts0 + j;
+                }
+                ++n_out; ++visits;                                        // an event costs about as much as opening a sub-block
+                sp = kind == 1 ? 0.0 : cc_bcast(bp, fl);                  // states after that tick, the closing side reset
+                sn = kind == 2 ? 0.0 : cc_bcast(bn, fl);
+                if (kind == 1) { reset_p = ts0 + j; mag_p = 2.0 * U_s; } else { reset_n = ts0 + j; mag_n = 2.0 * U_s; }
+                mag_p = fmax(mag_p, fabs(sp)); mag_n = fmax(mag_n, fabs(sn));
+                dead = fl;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q <= q0) { rr[q] = lane == fl ? 0.0 : rr[q]; ll[q] = lane == fl ? (double)NAN : ll[q]; }
             }
-            ++n_out; ++visits;                                            // an event costs about as much as opening a chunk
-            sp = kind == 1 ? 0.0 : cc_bcast(bp, fl);                      // states after that tick, the closing side reset
-            sn = kind == 2 ? 0.0 : cc_bcast(bn, fl);
-            if (kind == 1) { reset_p = t0 + j; mag_p = 2.0 * U_k; } else { reset_n = t0 + j; mag_n = 2.0 * U_k; }
-            mag_p = fmax(mag_p, fabs(sp)); mag_n = fmax(mag_n, fabs(sn));
-            dead = fl;
-#pragma unroll
-            for (int q = 0; q < 32; ++q)
-                if (q <= q0) { rr[q] = lane == fl ? 0.0 : rr[q]; ll[q] = lane == fl ? (double)NAN : ll[q]; }
+            s_from = sf + 1;
         }
         if (status != CC_ST_DONE) break;
         c = k + 1;
@@ -490,11 +536,13 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     // per-side close lists: a side that fills its list ends the tier like an exhausted budget
     const int64_t list_cap = m < ((int64_t)1 << 22) ? m : ((int64_t)1 << 22);
     const size_t list_bytes = (size_t)list_cap * 8;
-    FMK_TRY(fmk_scratch(ctx, sum_bytes + 2 * list_bytes + 512, &scr));
+    const size_t sub_bytes = sum_bytes * (CC_CHUNK / CC_SUB);
+    FMK_TRY(fmk_scratch(ctx, sum_bytes + sub_bytes + 2 * list_bytes + 512, &scr));
     double *sums = (double *)scr;
-    int64_t *lists = (int64_t *)((char *)scr + sum_bytes);
+    double *subs = (double *)((char *)scr + sum_bytes);
+    int64_t *lists = (int64_t *)((char *)scr + sum_bytes + sub_bytes);
     struct CcHost { CcState st[3]; int64_t coincide; };
-    CcHost *dev = (CcHost *)((char *)scr + sum_bytes + 2 * list_bytes);
+    CcHost *dev = (CcHost *)((char *)scr + sum_bytes + sub_bytes + 2 * list_bytes);
     CcState *st = dev->st;
     k_cc_init<<<1, 3, 0, ctx->stream>>>(st, &dev->coincide);
     FMK_LAUNCH_CHECK(ctx);
@@ -509,7 +557,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     CcHost hh;
     auto walk = [&](int joint, int64_t hi, int64_t budget) -> int {
         k_cc_walk<<<joint ? 1 : 2, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor,
-                                                                        sigma_mult, sums, st, budget, margin_scale, joint, lists,
+                                                                        sigma_mult, sums, subs, st, budget, margin_scale, joint, lists,
                                                                         list_cap, d_out, d_out ? capacity : 0);
         FMK_LAUNCH_CHECK(ctx);
         FMK_HIP(ctx, hipMemcpyAsync(&hh, dev, sizeof(CcHost), hipMemcpyDeviceToHost, ctx->stream));
@@ -518,7 +566,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     };
     auto summarize = [&](int64_t lo, int64_t hi) -> int {
         k_cc_summary<<<(unsigned)fmk_ceil_div(hi - lo, 4), 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, lo, hi,
-                                                                                chunks, sigma_floor, sigma_mult, sums, st);
+                                                                                chunks, sigma_floor, sigma_mult, sums, subs, st);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     };
