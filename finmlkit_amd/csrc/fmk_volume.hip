@@ -97,9 +97,14 @@ __device__ __forceinline__ void vol_flag(int *status, int bit)     // one atomic
 {
     if (!(__atomic_load_n(status, __ATOMIC_RELAXED) & bit)) atomicOr(status, bit);
 }
+// ... and the THRESHOLD has to be such a multiple too: the decisions compare a prefix with (earlier prefix + thr), and with
+// thr = 2840.5000000000005 (one ulp above a multiple of 1/8; found by tools/fuzz_parity.py seed 778 case 121) that sum rounds
+// to the grid -- a bar whose amounts add up to 2840.5 looked like an exact tie and closed, where the reference's
+// `cum >= thr` is false.
+__device__ __forceinline__ bool vol_thr_inexact(double thr) { return !(thr * 1048576.0 == rint(thr * 1048576.0) && thr < 2147483648.0); }
 __device__ __forceinline__ bool vol_ties_fragile(const int *status, double thr)
 {
-    return (__atomic_load_n(status, __ATOMIC_RELAXED) & VOL_ST_INEXACT) || !(thr < 2147483648.0);
+    return (__atomic_load_n(status, __ATOMIC_RELAXED) & VOL_ST_INEXACT) || vol_thr_inexact(thr);
 }
 
 // `fragile` (one byte per tick, may be null): the decision nxt(j) was within the certification margin.  Only decisions ON
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(VOL_THREADS) void k_vol_level0(const void *__restri
     if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VOL_ST_BAD);
     if (__ballot(inexact) != 0 && lane == 0) vol_flag(status, VOL_ST_INEXACT);
     // are exact ties of THIS block's decisions certain?  They involve only the block's own 2S ticks
-    const bool ties = __syncthreads_or(inexact ? 1 : 0) != 0 || !(thr < 2147483648.0);
+    const bool ties = __syncthreads_or(inexact ? 1 : 0) != 0 || vol_thr_inexact(thr);
     // Exact mode (replay != 0): a fragile decision is settled on the spot by the reference's own computation for that bar --
     // cum = 0, += v in tick order from the tick after j (logic.py:107-113) -- so the tables are built from links that are
     // either certain by their margin or computed exactly.  Work: (fragile ticks) x (bar length) additions spread over all

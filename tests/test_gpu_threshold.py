@@ -213,6 +213,25 @@ def test_volume_integer_lots_ties_are_certain(orc):
         assert unc == 0, f"thr={thr}: {unc} decisions listed for an exactly-summable stream"
 
 
+def test_volume_dyadic_lots_threshold_one_ulp_off_the_grid(orc):
+    """Dyadic lots whose bars add up to EXACTLY the grid value just below the threshold: prefix + thr rounds to the grid, so
+    the decision looks like an exact tie although the reference's `cum >= thr` is false (tools/fuzz_parity.py seed 778 case
+    121).  Ties count as certain only when the threshold is on the amounts' grid too.  All tiers: short, 4096-tick and
+    chain-walk bars."""
+    from finmlkit_amd.bar.logic import _volume_bar_indexer
+    rng = np.random.default_rng(33)
+    n = 600_000
+    am = (rng.integers(1, 65, n) * 0.125).astype(np.float32)
+    for base in (40.0, 2840.5, 12_000.25, 90_000.0):
+        for thr in (np.nextafter(base, np.inf), np.nextafter(base, -np.inf), base):
+            got = _volume_bar_indexer(am, float(thr))
+            want = orc._volume_bar_indexer(am, float(thr))
+            np.testing.assert_array_equal(got, want, err_msg=f"thr={thr!r}")
+    # the two neighbours of a grid value give different closes wherever a bar hits it exactly
+    up, dn = orc._volume_bar_indexer(am, float(np.nextafter(2840.5, np.inf))), orc._volume_bar_indexer(am, 2840.5)
+    assert not np.array_equal(up, dn)
+
+
 def test_volume_decimal_lots_many_ties_stay_on_the_parallel_path(orc):
     """3e6 ticks of tenth lots, threshold 25: thousands of closes are exact ties of the parallel evaluation.  All of them are
     listed and replayed (the list holds 2^20 decisions; each replays one bar) -- the result is the oracle's and the call
