@@ -48,6 +48,21 @@ def tape(rng, n):
     return ts, px.astype(np.float64), am, sd
 
 
+def knife_edge(rng, v, thr):
+    """one time in four: a threshold that some run of ticks reaches EXACTLY in the reference's summation order, or misses /
+    passes by one ulp (seed 778 case 121 of the first version met one by chance: a volume bar closed a tick early)"""
+    if rng.random() >= 0.25 or len(v) < 4:
+        return thr
+    a = int(rng.integers(0, len(v) - 2))
+    b = int(rng.integers(a + 2, min(len(v), a + 2 + int(rng.choice([3, 60, 900, 5000]))) + 1))
+    cum = 0.0
+    for x in v[a:b]:
+        cum += float(x)
+    if not (cum > 0.0 and np.isfinite(cum)):
+        return thr
+    return float(rng.choice([cum, np.nextafter(cum, np.inf), np.nextafter(cum, -np.inf)]))
+
+
 def bars(rng, n):
     """bar_close_indices over n ticks: strictly valid for the reference (ascending, within range), with repeats (empty
     bars), sometimes a -1 open edge, bar lengths from one tick to everything"""
@@ -123,11 +138,13 @@ def one_case(rng, orc, pkg, log, hi=20000):
             both("_time_bar_indexer", lambda: pkg["logic"]._time_bar_indexer(ts, iv), lambda: orc._time_bar_indexer(ts, iv), name)
         elif which == 1:
             thr = float(np.mean(am, dtype=np.float64)) * float(rng.choice([0.5, 3, 50, 700, 1500, 2500, 5000, 10**7]))
-            name = f"_volume_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
+            thr = knife_edge(rng, am.astype(np.float64), thr)
+            name = f"_volume_bar_indexer n={n} dtype={am.dtype} thr={thr!r}"
             both("_volume_bar_indexer", lambda: pkg["logic"]._volume_bar_indexer(am, thr), lambda: orc._volume_bar_indexer(am, thr), name)
         elif which == 2:
             thr = float(np.mean(am.astype(np.float64) * px)) * float(rng.choice([0.5, 3, 50, 700, 2500, 10**7]))
-            name = f"_dollar_bar_indexer n={n} dtype={am.dtype} thr={thr:g}"
+            thr = knife_edge(rng, am.astype(np.float64) * px, thr)
+            name = f"_dollar_bar_indexer n={n} dtype={am.dtype} thr={thr!r}"
             both("_dollar_bar_indexer", lambda: pkg["logic"]._dollar_bar_indexer(px, am, thr), lambda: orc._dollar_bar_indexer(px, am, thr), name)
         elif which == 3:
             p = px.copy()

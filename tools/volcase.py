@@ -18,6 +18,7 @@ ci = F.bars(rng, n)
 which = int(rng.integers(0, 18))
 assert which == 1, which
 thr = float(np.mean(am, dtype=np.float64)) * float(rng.choice([0.5, 3, 50, 700, 1500, 2500, 5000, 10**7]))
+thr = F.knife_edge(rng, am.astype(np.float64), thr)
 print(f"n={n} dtype={am.dtype} thr={thr!r} mean ticks/bar {thr / float(np.mean(am, dtype=np.float64)):g}")
 from oracle import oracle as orc
 from finmlkit_amd.bar import logic
