@@ -168,6 +168,10 @@ def one_case(rng, orc, pkg, log, hi=20000):
         elif which == 5:
             o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
             tick = 0.5 if np.all(np.abs(px / 0.5 - np.round(px / 0.5)) < 1e-9) else 0.01
+            if rng.random() < 0.4:
+                # coarser / finer price levels than the tape's grid: half of the prices then sit EXACTLY between two levels
+                # (round-half-to-even in the reference), or levels stay empty
+                tick *= float(rng.choice([2.0, 0.5, 4.0, 3.0]))
             imb = float(rng.choice([1.5, 3.0, 0.0]))
             name = f"comp_bar_footprints n={n} bars={len(ci) - 1} dtype={am.dtype} tick={tick}"
             both("comp_bar_footprints", lambda: pkg["base"].comp_bar_footprints(px, am, ci, sd, tick, o[2], o[1], imb),
