@@ -32,6 +32,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "fmk_common.h"
 #include "fmk_dpp.h"
 
@@ -52,6 +54,9 @@ struct CcState {                         // the walk's state between launches (d
     int64_t n_out;                       // closes emitted so far
     int64_t visits;                      // chunks opened so far
     int32_t status, bad;                 // CC_ST_*; bad: k_cc_summary saw a non-finite return
+    int64_t limit;                       // the walk of this state ends before this chunk (segments; otherwise no limit)
+    int64_t list_off, list_cap;          // where its closes go in the lists buffer
+    int32_t side, pad_;                  // 0: both sides jointly, 1: positive, 2: negative
 };
 
 __device__ __forceinline__ CcSum cc_identity()
@@ -196,19 +201,46 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
         atomicOr(&state->bad, 1);
 }
 
-__global__ void k_cc_init(CcState *st3, int64_t *flag)
+// states: [0] positive side, [1] negative side, [2 .. 2 + 2 (K - 1)) the later segments of the two sides (k_cc_ranges), then
+// the joint walk
+__global__ void k_cc_init(CcState *st, int n_states, int64_t list_cap, int64_t *flag)
 {
-    if (threadIdx.x == 0) *flag = 0;
-    CcState *st = st3 + threadIdx.x;                                  // positive side, negative side, joint
-    st->chunk = 0; st->sp = 0.0; st->sn = 0.0; st->reset_p = 0; st->reset_n = 0; st->mag_p = 0.0; st->mag_n = 0.0;
-    st->n_out = 0; st->visits = 0; st->status = CC_ST_DONE; st->bad = 0;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i == 0) *flag = 0;
+    if (i >= n_states) return;
+    CcState *q = st + i;
+    q->chunk = 0; q->sp = 0.0; q->sn = 0.0; q->reset_p = 0; q->reset_n = 0; q->mag_p = 0.0; q->mag_n = 0.0;
+    q->n_out = 0; q->visits = 0; q->status = CC_ST_DONE; q->bad = 0;
+    q->limit = i < 2 || i == n_states - 1 ? INT64_MAX : 0;           // segments are inactive until k_cc_ranges says otherwise
+    q->list_off = i == 1 ? list_cap : 0; q->list_cap = list_cap;
+    q->side = i == n_states - 1 ? 0 : i < 2 ? i + 1 : 0; q->pad_ = 0;
 }
 
 // ---------------------------------------------------------------------------------------
 // the walk along the chain: wave 0 walks, the other waves of the workgroup only help to open a chunk
 // ---------------------------------------------------------------------------------------
+// The reference's operations for one side from a tick where its state is exactly 0.0 (t_from: the first tick after a reset,
+// the start of the stream or of a segment) through t_to: s = max(0.0, s + ret) or min(0.0, s + ret), tick by tick.  The
+// wave computes 64 returns at a time; the fold over them is wave-uniform (~30 cycles per tick).
+#define CC_REPLAY_MAX ((int64_t)1 << 21)
+__device__ __forceinline__ double cc_replay(const double *__restrict__ price, int64_t first, int64_t t_from, int64_t t_to, bool positive)
+{
+    const int lane = fmk_lane();
+    double s = 0.0;
+    for (int64_t base = t_from; base <= t_to; base += 64) {
+        const int64_t t = base + lane, i = first + 1 + (t <= t_to ? t : t_to);
+        const double r = log(price[i] / price[i - 1]);
+        const int cnt = (int)(t_to - base + 1 < 64 ? t_to - base + 1 : 64);
+        for (int k = 0; k < cnt; ++k) {
+            const double rk = cc_bcast(r, k);
+            s = positive ? fmax(0.0, s + rk) : fmin(0.0, s + rk);
+        }
+    }
+    return s;
+}
+
 #define CC_PAD(j) ((j) + ((j) >> 5))
-#define CC_WALK_WAVES 8
+#define CC_WALK_WAVES 2
 struct CcMap { double B, Ap, An; };                                   // exit maps of the two sides: max(Ap, s + B), min(An, s + B)
 __device__ __forceinline__ CcMap cc_map_compose(const CcMap &l, const CcMap &r)
 {
@@ -242,17 +274,24 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
                                                 const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                 int64_t chunk_limit, int64_t chunks, double sigma_floor, double sigma_mult,
                                                 const double *__restrict__ sums, const double *__restrict__ subs,
-                                                CcState *states, int64_t visit_budget,
-                                                double margin_scale, int joint, int64_t *__restrict__ lists, int64_t list_cap,
+                                                CcState *states, const CcState *st0, int64_t visit_budget,
+                                                double margin_scale, int64_t *__restrict__ all_lists,
                                                 int64_t *__restrict__ closes, int64_t capacity)
 {
     // joint != 0: one workgroup evaluates the loop as written (both sides, `if / elif`), closes -> closes[1 + ...].
     // joint == 0: workgroup 0 follows the positive side alone, workgroup 1 the negative side alone (each side's state after
     // its own close is 0 whatever the other side does, so the two chains are independent -- except that a positive close
     // hides a negative one on the same tick; the caller merges the two lists and re-runs jointly if they ever share a tick).
-    const int side = joint ? 0 : (int)blockIdx.x + 1;
+    // Every workgroup has a state of its own (`states + blockIdx.x`): a side from the start, a later SEGMENT of a side (from a
+    // chunk boundary where k_cc_sync proved that the side's state no longer depends on the past), or the joint walk.
+    CcState *state = states + blockIdx.x;
+    const int side = state->side;
+    const int joint = side == 0;
     const bool do_p = side != 2, do_n = side != 1;
-    CcState *state = states + (joint ? 2 : (int)blockIdx.x);
+    if (state->limit < chunk_limit) chunk_limit = state->limit;
+    if (state->chunk >= chunk_limit) return;                            // (all waves: nothing to do, e.g. an unused segment)
+    int64_t *lists = all_lists + state->list_off;
+    const int64_t list_cap = state->list_cap;
     __shared__ double s_r[CC_SUB + CC_SUB / 8], s_l[CC_SUB + CC_SUB / 8];
     __shared__ int64_t s_cmd;                                           // sub-block (4 * chunk + sub) to open, -1: the walk is over
     const int lane = fmk_lane(), wv = (int)(threadIdx.x >> 6);
@@ -291,7 +330,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     int64_t c = state->chunk;
     double sp = state->sp, sn = state->sn, mag_p = state->mag_p, mag_n = state->mag_n;
     int64_t reset_p = state->reset_p, reset_n = state->reset_n, n_out = state->n_out, visits = state->visits;
-    int status = states[0].bad ? CC_ST_BAD : CC_ST_DONE;              // k_cc_summary reports there
+    int status = st0->bad ? CC_ST_BAD : CC_ST_DONE;                    // k_cc_summary reports there
     const double eps = margin_scale * 8.881784197001252e-16;              // 2^-50
 
     auto load = [&](int64_t c0) -> CcSum {
@@ -445,18 +484,41 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
                 const double dp = bp - lamq, dn = bn + lamq;
                 // `if s_pos >= lam ... elif s_neg <= -lam`, each answer only when it is beyond the margin
                 const int kind_l = (do_p && dp >= mp) ? 1 : ((!do_p || dp < -mp) && do_n && dn <= -mq) ? 2 : 3;
-                const int kind = __builtin_amdgcn_readlane(kind_l, fl);
-                if (kind == 3) { status = CC_ST_UNCERTAIN; break; }
+                int kind = __builtin_amdgcn_readlane(kind_l, fl);
                 const int j = 8 * fl + q0;
-                if (joint) { if (lane == 0 && closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + ts0 + j; }
-                else {
-                    if (n_out >= list_cap) { status = CC_ST_BUDGET; break; }
-                    if (lane == 0) lists[(int64_t)(side - 1) * list_cap + n_out] = first + 1 + ts0 + j;
+                if (kind == 3) {
+                    // Inside the margin: block sums cannot tell.  The side's state has been exactly 0.0 since its last reset,
+                    // so the reference's own sequence of operations from there gives its state at this tick bit for bit
+                    // (cc_replay), and `if s_pos >= lam ... elif s_neg <= -lam` is evaluated as written.  Tapes whose
+                    // log-prices sit on a lattice meet round floors EXACTLY (the synthetic one: s = 2.0000000000054e-05
+                    // against a floor of 2e-5, again and again); on others this is a once-in-1e11 event.
+                    const double lam_e = cc_bcast(lamq, fl);
+                    const int64_t te = ts0 + j;
+                    kind = 0;
+                    if (do_p) {
+                        if (te - reset_p >= CC_REPLAY_MAX) { status = CC_ST_UNCERTAIN; break; }
+                        if (cc_replay(price, first, reset_p, te, true) >= lam_e) kind = 1;
+                        visits += (te - reset_p) >> 10;                   // the budget also bounds the replayed ticks
+                    }
+                    if (kind == 0 && do_n) {
+                        if (te - reset_n >= CC_REPLAY_MAX) { status = CC_ST_UNCERTAIN; break; }
+                        if (cc_replay(price, first, reset_n, te, false) <= -lam_e) kind = 2;
+                        visits += (te - reset_n) >> 10;
+                    }
+                    ++visits;
                 }
-                ++n_out; ++visits;                                        // an event costs about as much as opening a sub-block
+                if (kind != 0) {
+                    if (joint) { if (lane == 0 && closes && 1 + n_out < capacity) closes[1 + n_out] = first + 1 + ts0 + j; }
+                    else {
+                        if (n_out >= list_cap) { status = CC_ST_BUDGET; break; }
+                        if (lane == 0) lists[n_out] = first + 1 + ts0 + j;
+                    }
+                    ++n_out; ++visits;                                    // an event costs about as much as opening a sub-block
+                }
                 sp = kind == 1 ? 0.0 : cc_bcast(bp, fl);                  // states after that tick, the closing side reset
                 sn = kind == 2 ? 0.0 : cc_bcast(bn, fl);
-                if (kind == 1) { reset_p = ts0 + j; mag_p = 2.0 * U_s; } else { reset_n = ts0 + j; mag_n = 2.0 * U_s; }
+                if (kind == 1) { reset_p = ts0 + j + 1; mag_p = 2.0 * U_s; }            // (first tick after the reset)
+                else if (kind == 2) { reset_n = ts0 + j + 1; mag_n = 2.0 * U_s; }
                 mag_p = fmax(mag_p, fabs(sp)); mag_n = fmax(mag_n, fabs(sn));
                 dead = fl;
 #pragma unroll
@@ -484,6 +546,122 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     }
 }
 
+// How often are the thresholds reached?  Sub-blocks (512 ticks) of the leading chunks in which a side closes even when it
+// enters with state 0 (P >= 0): a lower bound of the closes that needs no walk.  *count += such (sub-block, side) pairs.
+__global__ __launch_bounds__(256) void k_cc_rate(const double *__restrict__ subs, int64_t nq_all, int64_t nq, unsigned long long *count)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (q < nq) c = (subs[3 * nq_all + q] >= 0.0 ? 1 : 0) + (subs[6 * nq_all + q] <= 0.0 ? 1 : 0);
+    c = fmk_wave_sum(c);
+    if (fmk_lane() == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
+// ---------------------------------------------------------------------------------------
+// segments: chunk boundaries from which a side's chain does not depend on the past
+// ---------------------------------------------------------------------------------------
+// A side's state is forgotten whenever it is clamped to 0.0 (or closes).  Take a chunk boundary c.  Whatever happened before,
+// the positive state leaving chunk c - 1 is below  s* = max(A, B - Q)  of that chunk: a trajectory that did not close inside
+// it entered with s < min_i(lam_i - S_i) = -Q and leaves with max(A, s + B); one that did close restarted from 0 at its last
+// close and leaves with at most S_end - min S = A.  If now, over the chunks c, c + 1, ..., (1) no trajectory starting below
+// s* can close -- s* + max_i(S_i - lam_i) < 0 -- until (2) the one starting AT s* has been clamped -- s* + min_i S_i < 0 --
+// then every trajectory, the true one included, was clamped to exactly 0.0 in that window without a close, and from its own
+// clamp on it is BIT-identical to the trajectory that starts at the boundary with state 0.0 (float addition is monotone, so
+// that one, being the smallest, is 0.0 wherever a larger one is).  A walk started at such a boundary with state 0 therefore
+// emits the reference's closes, all of them, without knowing anything about the ticks before -- and the side's chain can
+// be walked by many workgroups at once.  Both inequalities carry the walk's margin (block sums against the reference's
+// sequential sums).  Mirrored for the negative side.  flags[side * chunks + c] = 1: boundary c is such a start.
+#define CC_SYNC_MAX 1024                                                // chunks a window may span
+__global__ __launch_bounds__(256) void k_cc_sync(const double *__restrict__ sums, int64_t chunks, int64_t lo, double margin_scale,
+                                                 unsigned char *__restrict__ flags)
+{
+    const int64_t c = lo + 1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= chunks) return;
+    auto load = [&](int64_t k) {
+        return CcSum{sums[0 * chunks + k], sums[1 * chunks + k], sums[2 * chunks + k], sums[3 * chunks + k],
+                     sums[4 * chunks + k], sums[5 * chunks + k], sums[6 * chunks + k], sums[7 * chunks + k]};
+    };
+    const double eps = margin_scale * 8.881784197001252e-16;              // 2^-50
+    const CcSum prev = load(c - 1);
+    double sp = fmax(prev.Ap, prev.B - prev.Qp), sn = fmin(prev.An, prev.B - prev.Qn);    // bounds of the states at the boundary
+    const double m0 = (double)(CC_CHUNK + 4096) * eps;
+    sp += m0 * (fabs(sp) + 2.0 * prev.U);
+    sn -= m0 * (fabs(sn) + 2.0 * prev.U);
+    int dp = sp < INFINITY ? 0 : 2, dn = sn > -INFINITY ? 0 : 2;          // 0 open, 1 proven, 2 failed
+    if (!(sp >= 0.0)) dp = 2;                                             // (NaN summaries: never)
+    if (!(sn <= 0.0)) dn = 2;
+    CcSum acc = cc_identity();
+    for (int64_t j = c; j < chunks && j < c + CC_SYNC_MAX && (dp == 0 || dn == 0); ++j) {
+        acc = cc_compose(acc, load(j));
+        const double ticks = (double)((j + 1 - c) * CC_CHUNK + 4096);
+        if (dp == 0) {
+            const double mar = ticks * eps * (sp + 2.0 * acc.U);
+            if (!(sp + acc.Qp < -mar)) dp = 2;                            // something may close before everything is clamped
+            else if (sp + (acc.B - acc.Ap) < -mar) dp = 1;                // min_i S_i = B - A
+        }
+        if (dn == 0) {
+            const double mar = ticks * eps * (-sn + 2.0 * acc.U);
+            if (!(sn + acc.Qn > mar)) dn = 2;
+            else if (sn + (acc.B - acc.An) > mar) dn = 1;                 // max_i S_i = B - A
+        }
+    }
+    flags[c] = dp == 1;
+    flags[chunks + c] = dn == 1;
+}
+
+// segment k (1 .. K - 1) of a side starts at the first such boundary in its nominal range [lo + k w, lo + (k + 1) w), if any
+__global__ __launch_bounds__(64) void k_cc_pick(const unsigned char *__restrict__ flags, int64_t chunks, int64_t lo, int K,
+                                                int64_t *__restrict__ starts)
+{
+    const int side = (int)blockIdx.x / (K - 1), k = 1 + (int)blockIdx.x % (K - 1), lane = fmk_lane();
+    const int64_t w = (chunks - lo) / K, a = lo + k * w, b = k == K - 1 ? chunks : a + w;
+    int64_t found = -1;
+    for (int64_t c0 = a; c0 < b && found < 0; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(c < b && flags[(int64_t)side * chunks + c] != 0);
+        if (hit) found = c0 + __builtin_ctzll(hit);
+    }
+    if (lane == 0) starts[side * K + k] = found;
+}
+
+// the segments' states: each runs from its start to the next segment's start
+__global__ void k_cc_ranges(const int64_t *__restrict__ starts, int K, int64_t chunks, CcState *st, int64_t list_cap,
+                            int64_t seg_base, int64_t seg_cap, int64_t *n_active)
+{
+    const int side = (int)threadIdx.x;
+    if (side >= 2) return;
+    int64_t next = chunks;
+    int active = 0;
+    for (int k = K - 1; k >= 1; --k) {
+        CcState *q = st + 2 + side * (K - 1) + (k - 1);
+        const int64_t a = starts[side * K + k];
+        q->side = side + 1;
+        q->list_off = seg_base + ((int64_t)side * (K - 1) + (k - 1)) * seg_cap; q->list_cap = seg_cap;
+        q->sp = 0.0; q->sn = 0.0; q->mag_p = 0.0; q->mag_n = 0.0; q->n_out = 0; q->visits = 0; q->status = CC_ST_DONE;
+        if (a >= 0) {
+            q->chunk = a; q->limit = next; q->reset_p = a * CC_CHUNK; q->reset_n = a * CC_CHUNK;
+            next = a; ++active;
+        } else { q->chunk = 0; q->limit = 0; q->reset_p = 0; q->reset_n = 0; }
+    }
+    st[side].limit = next;                                              // the side's first segment: from where the sample ended
+    atomicAdd((unsigned long long *)n_active, (unsigned long long)active);
+}
+
+// the segments' closes behind the first segment's, in order: the side's list
+__global__ __launch_bounds__(256) void k_cc_gather(const CcState *__restrict__ st, int K, int64_t *__restrict__ lists, int64_t list_cap)
+{
+    const int side = (int)blockIdx.x / (K - 1), k = 1 + (int)blockIdx.x % (K - 1);
+    const CcState *q = st + 2 + side * (K - 1) + (k - 1);
+    const int64_t cnt = q->n_out;
+    if (cnt == 0) return;
+    int64_t off = st[side].n_out;
+    for (int j = 1; j < k; ++j) off += st[2 + side * (K - 1) + (j - 1)].n_out;
+    const int64_t *src = lists + q->list_off;
+    int64_t *dst = lists + (int64_t)side * list_cap + off;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256)
+        if (off + i < list_cap) dst[i] = src[i];
+}
+
 // the two sides' closes (each ascending) -> out[1 ..]; *coincide = 1 when a tick is in both
 __global__ __launch_bounds__(256) void k_cc_merge(const int64_t *__restrict__ lp, int64_t np, const int64_t *__restrict__ ln,
                                                   int64_t nn, int64_t *__restrict__ out, int64_t capacity, int64_t *coincide)
@@ -503,12 +681,20 @@ __global__ __launch_bounds__(256) void k_cc_merge(const int64_t *__restrict__ lp
     if (out && 1 + self + lo < capacity) out[1 + self + lo] = v;
 }
 
-static int64_t g_cc_last[3];            // tier used by the last call (0 fixed point, 1 this one), chunks opened, walk status
+static int64_t g_cc_last[4];            // tier used by the last call (0 fixed point, 1 this one), chunks opened, walk status, segments
 extern "C" int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status)
 {
     if (tier) *tier = g_cc_last[0];
     if (opened) *opened = g_cc_last[1];
     if (status) *status = g_cc_last[2];
+    return FMK_OK;
+}
+
+static double g_cc_rate;                // sub-blocks per chunk and side of the leading chunks in which a close is certain
+extern "C" int fmk_diag_cusum_segments(int64_t *segments, double *rate)
+{
+    if (segments) *segments = g_cc_last[3];
+    if (rate) *rate = g_cc_rate;
     return FMK_OK;
 }
 
@@ -527,7 +713,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     v = getenv("FMK_CUSUM_MARGIN_SCALE");
     double margin_scale = v ? atof(v) : 1.0;
     if (!(margin_scale > 0.0)) margin_scale = 1.0;
-    g_cc_last[0] = 0; g_cc_last[1] = 0; g_cc_last[2] = -1;
+    g_cc_last[0] = 0; g_cc_last[1] = 0; g_cc_last[2] = -1; g_cc_last[3] = 0;
     if (mode == 0 || chunks < min_chunks || chunks < 2) return FMK_OK;
     v = getenv("FMK_CUSUM_CHAIN_JOINT");
     const bool force_joint = v && atoi(v);                           // developer knob: the one-workgroup joint walk only
@@ -537,31 +723,89 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     const int64_t list_cap = m < ((int64_t)1 << 22) ? m : ((int64_t)1 << 22);
     const size_t list_bytes = (size_t)list_cap * 8;
     const size_t sub_bytes = sum_bytes * (CC_CHUNK / CC_SUB);
-    FMK_TRY(fmk_scratch(ctx, sum_bytes + sub_bytes + 2 * list_bytes + 512, &scr));
+    // segments of the walk after the sample (k_cc_sync): developer knob FMK_CUSUM_CHAIN_SEGMENTS, 1 = one walk per side
+    v = getenv("FMK_CUSUM_CHAIN_SEGMENTS");
+    int K = v ? atoi(v) : 512;
+    if (K > 1024) K = 1024;
+    if (K < 1 || force_joint) K = 1;
+    const int n_states = 2 * K + 1, JOINT = 2 * K;                    // [pos, neg, later segments of pos, of neg, joint]
+    const size_t flag_bytes = ((size_t)2 * chunks + 15) & ~(size_t)15;
+    const size_t state_bytes = (sizeof(CcState) * n_states + 8 * (2 * K + 2) + 15) & ~(size_t)15;
+    FMK_TRY(fmk_scratch(ctx, sum_bytes + sub_bytes + 4 * list_bytes + flag_bytes + state_bytes + 512, &scr));
     double *sums = (double *)scr;
     double *subs = (double *)((char *)scr + sum_bytes);
-    int64_t *lists = (int64_t *)((char *)scr + sum_bytes + sub_bytes);
-    struct CcHost { CcState st[3]; int64_t coincide; };
-    CcHost *dev = (CcHost *)((char *)scr + sum_bytes + sub_bytes + 2 * list_bytes);
-    CcState *st = dev->st;
-    k_cc_init<<<1, 3, 0, ctx->stream>>>(st, &dev->coincide);
+    int64_t *lists = (int64_t *)((char *)scr + sum_bytes + sub_bytes);           // [2][list_cap] the sides, [2][list_cap] segments
+    unsigned char *flags = (unsigned char *)scr + sum_bytes + sub_bytes + 4 * list_bytes;
+    CcState *st = (CcState *)(flags + flag_bytes);
+    int64_t *d_coincide = (int64_t *)(st + n_states), *d_active = d_coincide + 1, *d_starts = d_coincide + 2;
+    struct CcHost { CcState st[3]; int64_t coincide; };              // host copy: [0] positive, [1] negative, [2] joint
+    k_cc_init<<<(unsigned)fmk_ceil_div(n_states, 64), 64, 0, ctx->stream>>>(st, n_states, list_cap, d_coincide);
     FMK_LAUNCH_CHECK(ctx);
-    // a sample first: the leading 2048 chunks with a budget of opened chunks that the slow regime never needs
-    v = getenv("FMK_CUSUM_CHAIN_SAMPLE");                              // developer knob: chunks of the sample phase
-    const int64_t sample_want = v && atoll(v) > 0 ? atoll(v) : 2048;
+    FMK_HIP(ctx, hipMemsetAsync(d_active, 0, 8, ctx->stream));
+    // Which tier?  Measured at 1e9 ticks (profiles/r02_cusum_chain.txt): the segmented walk costs ~8.5 ms + 8 ns per opened
+    // sub-block or event of the busier side, the fixed point 24 / 24 / 26 / 47 / 66 ms at 4.8 M / 2.4 M / 1.1 M / 398 K / 101 K
+    // closes -- the walk wins up to ~3 visits per chunk and side.  The rate is estimated from the sub-block summaries of the
+    // leading 2048 chunks (k_cc_rate: no walk, one small launch); the visit budgets below are the safety net for tapes whose
+    // beginning is not representative.
+    const double max_rate = 3.0, max_certain = 1.3;
+    v = getenv("FMK_CUSUM_CHAIN_SAMPLE");                              // developer knob (tests): walk this many leading chunks
+    const int64_t sample_want = v && atoll(v) > 0 ? atoll(v) : 0;      // in a launch of their own first (the walk resumes)
     const int64_t sample = chunks < sample_want ? chunks : sample_want;
-    // Measured at 1e9 ticks (profiles/r02_cusum_chain.txt): the walk costs ~9 ms + 6 us per close, the fixed point 73 / 109 /
-    // 164 / 320 ms at 101 K / 25 K / 11 K / 4 K closes -- the walk wins below ~0.04 closes per chunk.
-    const double max_rate = 0.04;
-    const int64_t sample_budget = mode == 2 ? INT64_MAX : 32 + (int64_t)(max_rate * (double)sample);
+    const int64_t lead = chunks < 2048 ? chunks : 2048;
     CcHost hh;
+    memset(&hh, 0, sizeof(hh));
+    auto fetch = [&]() -> int {
+        FMK_HIP(ctx, hipMemcpyAsync(&hh.st[0], st, 2 * sizeof(CcState), hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&hh.st[2], st + JOINT, sizeof(CcState), hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FMK_OK;
+    };
     auto walk = [&](int joint, int64_t hi, int64_t budget) -> int {
         k_cc_walk<<<joint ? 1 : 2, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor,
-                                                                        sigma_mult, sums, subs, st, budget, margin_scale, joint, lists,
-                                                                        list_cap, d_out, d_out ? capacity : 0);
+                                                                        sigma_mult, sums, subs, joint ? st + JOINT : st, st, budget,
+                                                                        margin_scale, lists, d_out, d_out ? capacity : 0);
         FMK_LAUNCH_CHECK(ctx);
-        FMK_HIP(ctx, hipMemcpyAsync(&hh, dev, sizeof(CcHost), hipMemcpyDeviceToHost, ctx->stream));
+        return fetch();
+    };
+    // the rest of the stream after the sample, each side in up to K segments that start where k_cc_sync proved independence
+    std::vector<CcState> hseg;
+    int64_t active = 0;
+    auto walk_segments = [&](int64_t lo, int64_t budget) -> int {
+        const unsigned nb = (unsigned)(2 * (K - 1));
+        k_cc_sync<<<(unsigned)fmk_ceil_div(chunks - lo - 1, 256), 256, 0, ctx->stream>>>(sums, chunks, lo, margin_scale, flags);
+        FMK_LAUNCH_CHECK(ctx);
+        k_cc_pick<<<nb, 64, 0, ctx->stream>>>(flags, chunks, lo, K, d_starts);
+        FMK_LAUNCH_CHECK(ctx);
+        k_cc_ranges<<<1, 64, 0, ctx->stream>>>(d_starts, K, chunks, st, list_cap, 2 * list_cap, (2 * list_cap) / (2 * (K - 1)), d_active);
+        FMK_LAUNCH_CHECK(ctx);
+        k_cc_walk<<<(unsigned)(2 * K), 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, chunks,
+                                                                            sigma_floor, sigma_mult, sums, subs, st, st, budget,
+                                                                            margin_scale, lists, d_out, d_out ? capacity : 0);
+        FMK_LAUNCH_CHECK(ctx);
+        hseg.resize((size_t)(2 * K));
+        FMK_HIP(ctx, hipMemcpyAsync(hseg.data(), st, sizeof(CcState) * 2 * K, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&active, d_active, 8, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // fold the segments into the two sides' records: counts add up, the worst status and the largest visit count stand
+        for (int side = 0; side < 2; ++side) {
+            CcState &h = hh.st[side];
+            h = hseg[(size_t)side];
+            int64_t tot = h.n_out, vis = h.visits;
+            for (int k = 1; k < K; ++k) {
+                const CcState &q = hseg[(size_t)(2 + side * (K - 1) + (k - 1))];
+                tot += q.n_out; vis += q.visits;
+                if (h.status == CC_ST_DONE && q.status != CC_ST_DONE) h.status = q.status;
+            }
+            if (tot > list_cap && h.status == CC_ST_DONE) h.status = CC_ST_BUDGET;
+            if (h.status == CC_ST_DONE && tot > h.n_out) {
+                // (one launch for both sides below)
+            }
+            h.n_out = tot; h.visits = vis;
+        }
+        if (hh.st[0].status == CC_ST_DONE && hh.st[1].status == CC_ST_DONE) {
+            k_cc_gather<<<nb, 256, 0, ctx->stream>>>(st, K, lists, list_cap);
+            FMK_LAUNCH_CHECK(ctx);
+        }
         return FMK_OK;
     };
     auto summarize = [&](int64_t lo, int64_t hi) -> int {
@@ -573,20 +817,31 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     const int j0 = force_joint ? 1 : 0;
     auto worst = [&]() { return j0 ? hh.st[2].status : (hh.st[0].status ? hh.st[0].status : hh.st[1].status); };
     auto spent = [&]() { return j0 ? hh.st[2].visits : (hh.st[0].visits > hh.st[1].visits ? hh.st[0].visits : hh.st[1].visits); };
-    FMK_TRY(summarize(0, sample));
-    FMK_TRY(walk(j0, sample, sample_budget));
-    int64_t budget = sample_budget;
+    FMK_TRY(summarize(0, lead));
+    g_cc_rate = -1.0;
+    if (mode != 2) {
+        unsigned long long cnt = 0;
+        FMK_HIP(ctx, hipMemsetAsync(d_starts, 0, 8, ctx->stream));
+        k_cc_rate<<<(unsigned)fmk_ceil_div(4 * lead, 256), 256, 0, ctx->stream>>>(subs, 4 * chunks, 4 * lead, (unsigned long long *)d_starts);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(&cnt, d_starts, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        g_cc_rate = (double)cnt / (2.0 * (double)lead);
+        if (g_cc_rate > max_certain) { g_cc_last[2] = CC_ST_BUDGET; return FMK_OK; }     // thresholds reached often: the fixed point
+    }
+    if (lead < chunks) FMK_TRY(summarize(lead, chunks));
+    const bool segmented = !j0 && K > 1 && chunks - sample >= 4 * (int64_t)K;
+    // budgets of opened sub-blocks + events + replayed ticks / 1024: four times the rate up to which the walk is chosen
+    int64_t budget = INT64_MAX, seg_budget = INT64_MAX;
+    if (mode != 2) {
+        budget = (int64_t)(4.0 * max_rate * (double)chunks) + 1000;
+        seg_budget = (int64_t)(4.0 * max_rate * (double)(chunks / K + 1)) + 256;
+    }
+    hh.st[0].status = hh.st[1].status = hh.st[2].status = CC_ST_DONE;
+    if (sample > 0) FMK_TRY(walk(j0, sample, budget));
     if (worst() == CC_ST_DONE && sample < chunks) {
-        // the rest with three times the sample's rate as a safety net (an exhausted budget hands over to the fixed point)
-        budget = INT64_MAX;
-        if (mode != 2) {
-            const double rate = (double)(spent() + 1) / (double)sample;
-            budget = (int64_t)(3.0 * rate * (double)chunks) + 1000;
-            const int64_t cap = (int64_t)(2.0 * max_rate * (double)chunks) + 1000;
-            if (budget > cap) budget = cap;
-        }
-        FMK_TRY(summarize(sample, chunks));
-        FMK_TRY(walk(j0, chunks, budget));
+        if (segmented) FMK_TRY(walk_segments(sample, seg_budget));
+        else FMK_TRY(walk(j0, chunks, budget));
     }
     CcState h = hh.st[j0 ? 2 : 0];
     h.status = worst(); h.visits = spent();
@@ -595,9 +850,9 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
         h.n_out = np + nn;
         if (np + nn > 0) {
             k_cc_merge<<<(unsigned)fmk_ceil_div(np + nn, 256), 256, 0, ctx->stream>>>(lists, np, lists + list_cap, nn, d_out,
-                                                                                    d_out ? capacity : 0, &dev->coincide);
+                                                                                    d_out ? capacity : 0, d_coincide);
             FMK_LAUNCH_CHECK(ctx);
-            FMK_HIP(ctx, hipMemcpyAsync(&hh.coincide, &dev->coincide, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipMemcpyAsync(&hh.coincide, d_coincide, 8, hipMemcpyDeviceToHost, ctx->stream));
             FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (hh.coincide) {                                        // a positive and a negative close on one tick: `elif`
                 FMK_TRY(walk(1, chunks, budget));
@@ -606,7 +861,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
         }
     }
     if (visits) *visits = h.visits;
-    g_cc_last[1] = h.visits; g_cc_last[2] = h.status;
+    g_cc_last[1] = h.visits; g_cc_last[2] = h.status; g_cc_last[3] = active;
     if (h.status != CC_ST_DONE) return FMK_OK;
     *total = h.n_out;
     *done = 1;

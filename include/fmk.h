@@ -394,6 +394,10 @@ int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t str
  * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
  * 3 non-finite return, -1 not tried).  Not used by any product path. */
 int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
+/* ... and into how many LATER segments that walk split the two sides' chains (0: each side walked in one piece); a segment
+ * starts at a chunk boundary from which the side's state provably does not depend on earlier ticks (k_cc_sync).  *rate: the
+ * estimate the tier was chosen by (512-tick sub-blocks per chunk and side of the leading chunks with a certain close; -1: none). */
+int fmk_diag_cusum_segments(int64_t *segments, double *rate);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,15 @@ def _last_tier():
     return t.value, o.value, s.value
 
 
+def _last_segments():
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    from finmlkit_amd._ffi import c_i64
+    k = c_i64()
+    _ffi.lib().fmk_diag_cusum_segments(C.byref(k), None)
+    return k.value
+
+
 @pytest.mark.parametrize("n,vol,floor,mult,kind,same_ts", [
     (3_000_000, 2e-6, 5e-4, 2.0, "ewm", 0.25),        # the reference's default floor on a quiet tape: a close per ~1e5 ticks
     (3_000_000, 2e-6, 5e-4, 2.0, "const0", 0.0),      # sigma below the floor everywhere, no print blocks
@@ -102,16 +111,18 @@ def _last_tier():
     (300_001, 2e-4, 0.05, 2.0, "const0", 0.1),        # never reached: the walk opens nothing
     (4097, 2e-5, 5e-4, 2.0, "const0", 0.25),
 ])
-@pytest.mark.parametrize("joint", [0, 1])
-def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind, same_ts, joint):
+@pytest.mark.parametrize("joint,segments", [(0, "128"), (0, "7"), (0, "1"), (1, "128")])
+def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind, same_ts, joint, segments):
     """The chain walk for rarely reached thresholds (fmk_cusum_chain.hip), forced for every regime (no budget, no minimum
-    size), as two independent side chains + merge and as the one joint walk: the same close indices as the sequential loop,
-    and the tier must be the one that answered."""
+    size), as two independent side chains + merge -- each side in one piece or in segments that start where its state
+    provably no longer depends on the past (k_cc_sync) -- and as the one joint walk: the same close indices as the
+    sequential loop, and the tier must be the one that answered."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
     monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
     monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
     monkeypatch.setenv("FMK_CUSUM_CHAIN_SAMPLE", "50")         # two launches; the first ends inside a group of 64 chunks
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_SEGMENTS", segments)
     ts, px = _stream(orc, n, 11, vol=vol, same_ts=same_ts)
     if kind == "ewm":
         r = orc.comp_lagged_returns(ts, px, 5.0, True)
@@ -124,15 +135,48 @@ def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind,
     s = sigma.copy()
     got = _cusum_bar_indexer(ts, px, s, floor, mult)
     tier, opened, status = _last_tier()
-    print(f"n {n}: {len(want) - 1} closes, tier {tier}, chunks opened {opened}, status {status}")
+    seg = _last_segments()
+    print(f"n {n}: {len(want) - 1} closes, tier {tier}, chunks opened {opened}, status {status}, later segments {seg}")
     assert (tier, status) == (1, 0)
+    if joint or segments == "1":
+        assert seg == 0
+    elif n >= 3_000_000:                                     # (a tape that closes every few hundred ticks has no such boundary)
+        assert seg > 0, "no segment started although the tape has thousands of chunk boundaries"
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(s, wfilled)
 
 
+@pytest.mark.parametrize("scale", ["1e9", "3e10"])
+@pytest.mark.parametrize("joint", [0, 1])
+def test_cusum_chain_walk_replays_what_its_margins_cannot_settle(orc, monkeypatch, scale, joint):
+    """Decisions inside the margin are settled by the reference's own sequence of operations from the side's last reset
+    (cc_replay).  Margins inflated by 1e9 / 3e10 put a share of the ticks near every close there -- also ticks that do NOT
+    close, after which the walk has to go on as if nothing happened -- on the lattice tape of the bench round floors do it
+    unaided (log-prices are multiples of a quantum: s == floor to the last bits)."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_SAMPLE", "50")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    monkeypatch.setenv("FMK_CUSUM_MARGIN_SCALE", scale)
+    n = 1_000_000
+    ts, px = _stream(orc, n, 19, vol=2e-5, same_ts=0.3)
+    r = orc.comp_lagged_returns(ts, px, 5.0, True)
+    sigma = orc.ewmst(ts, r, 60.0)
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    assert len(want) > 200
+    got = _cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    tier, opened, status = _last_tier()
+    print(f"scale {scale}: {len(want) - 1} closes, tier {tier}, opened + events + replays {opened}, status {status}")
+    assert (tier, status) == (1, 0)
+    assert opened > 2.2 * len(want)                                  # replays happened (each counts, beside open + event)
+    np.testing.assert_array_equal(got, want)
+
+
 def test_cusum_chain_walk_falls_back(orc, monkeypatch):
-    """An uncertain decision (forced: margins scaled by 1e12), a non-finite return (a zero price) and a tape whose
-    thresholds are reached often (the budget of opened chunks) all hand the call to the fixed point: same result."""
+    """Decisions that block sums cannot settle at every tick (forced: margins scaled by 1e12), a non-finite return (a zero
+    price) and a tape whose thresholds are reached often (the budget of opened chunks) all hand the call to the fixed point:
+    same result."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
     n = 3_000_000
@@ -142,7 +186,9 @@ def test_cusum_chain_walk_falls_back(orc, monkeypatch):
     assert 5 < len(want) < 40
     monkeypatch.setenv("FMK_CUSUM_MARGIN_SCALE", "1e12")
     np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0), want)
-    assert _last_tier()[0] == 0 and _last_tier()[2] == 2
+    # (every tick is "inside the margin" now: each is settled by replaying the side from its last reset, which the budget
+    #  of the sample phase ends after a hundred of them; a replay longer than 2^21 ticks would end it as "uncertain")
+    assert _last_tier()[0] == 0 and _last_tier()[2] in (1, 2)
     monkeypatch.delenv("FMK_CUSUM_MARGIN_SCALE")
     np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0), want)
     assert _last_tier()[0] == 1

@@ -26,6 +26,8 @@ for floor in floors:
                  C.byref(m), C.byref(rounds))
         ms = ctx.timer_stop()
         _ffi.lib().fmk_diag_cusum_last(C.byref(tier), C.byref(opened), C.byref(status))
-        print("sigma_floor %g: %.2f ms  rounds %d  closes %d  tier %d (walk: %d opened / events, status %d)  checksum %d" %
-              (floor, ms, rounds.value, m.value, tier.value, opened.value, status.value,
+        seg, rate = c_i64(), c_f64()
+        _ffi.lib().fmk_diag_cusum_segments(C.byref(seg), C.byref(rate))
+        print("sigma_floor %g: %.2f ms  rounds %d  closes %d  tier %d (walk: %d opened / events, status %d, %d later segments, rate %.3f)  checksum %d" %
+              (floor, ms, rounds.value, m.value, tier.value, opened.value, status.value, seg.value, rate.value,
                int(out.view(0, m.value).to_host().sum())), flush=True)

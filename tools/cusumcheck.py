@@ -25,7 +25,9 @@ def dev(mode):
     ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sig.p, c_i64(n), c_f64(floor), c_f64(2.0), out.p, c_i64(n),
              C.byref(m), C.byref(rounds))
     _ffi.lib().fmk_diag_cusum_last(C.byref(tier), C.byref(opened), C.byref(status))
-    return out.view(0, m.value).to_host().copy(), (tier.value, opened.value, status.value)
+    seg, rate = c_i64(), c_f64()
+    _ffi.lib().fmk_diag_cusum_segments(C.byref(seg), C.byref(rate))
+    return out.view(0, m.value).to_host().copy(), (tier.value, opened.value, status.value, seg.value)
 
 
 for floor in floors:
