@@ -109,6 +109,18 @@ __global__ __launch_bounds__(FF_THREADS) void k_ff_tile(const double *__restrict
     }
 }
 
+// The first non-NaN index when it lies in the stream's head (the usual sigma, an EWM, is NaN at its first ticks only): the
+// chain walk then reads sigma as it is, its summary pass reports a NaN it meets after that index, and only then -- or for the
+// fixed point -- is the full pass above run.  Saves the 8 GB read of k_ff_tile (1.5 ms per 1e9 ticks).
+__global__ __launch_bounds__(1024) void k_ff_head(const double *__restrict__ x, int64_t n_head, unsigned long long *first_valid)
+{
+    int64_t first = INT64_MAX;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n_head && first == INT64_MAX; i += (int64_t)gridDim.x * 1024)
+        if (!isnan(x[i])) first = i;
+    first = fmk_wave_min(first);
+    if (fmk_lane() == 0 && first != INT64_MAX) atomicMin(first_valid, (unsigned long long)first);
+}
+
 // total number of NaNs (one block): with the first valid index it tells whether there is anything to fill -- all NaNs lead
 // iff their number equals that index -- and the scan and the 8 GB apply pass are skipped when there is not (the usual case:
 // an EWM sigma is NaN at its first tick only)
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
 
 int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const double *d_sigma, int64_t n,
                          int64_t first, int64_t m, int64_t chunks, double sigma_floor, double sigma_mult, int64_t *d_out,
-                         int64_t capacity, int64_t *total, int64_t *visits, int *done);
+                         int64_t capacity, int64_t *total, int64_t *visits, int *done, int *nan_seen);
 
 extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, double *d_sigma,
                                          int64_t n, double sigma_floor, double sigma_mult, int64_t *d_out,
@@ -490,23 +502,46 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     unsigned long long *d_changed = d_first + 1;
     // ---- forward fill of sigma (in place) + first non-NaN index
     const unsigned long long big = ~0ULL;
-    FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
-    k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first, tile_nan);
-    FMK_LAUNCH_CHECK(ctx);
-    k_ff_count<<<1, 1024, 0, ctx->stream>>>(tile_nan, tiles, (long long *)(ctx->d_mail + 2));
-    FMK_LAUNCH_CHECK(ctx);
-    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], ctx->d_mail + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int64_t first = ctx->h_mail[0];
-    const bool all_nan = (unsigned long long)first == big;
-    if (!all_nan && ctx->h_mail[2] != first) {                    // NaNs after the first valid entry: fill them (logic.py:187-189)
-        k_ff_scan_tiles<<<1, 1024, 0, ctx->stream>>>(tile_last, tiles);
+    int64_t first = 0;
+    bool all_nan = false, filled = false;
+    auto full_fill = [&]() -> int {
+        FMK_TRY(fmk_scratch(ctx, ff_bytes + (size_t)tiles * 4 + 256, &scr));   // (the chain tier may have regrown the scratch)
+        tile_last = (double *)scr;
+        tile_nan = (int *)((char *)scr + ff_bytes);
+        FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
+        k_ff_tile<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last, d_first, tile_nan);
         FMK_LAUNCH_CHECK(ctx);
-        k_ff_apply<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last);
+        k_ff_count<<<1, 1024, 0, ctx->stream>>>(tile_nan, tiles, (long long *)(ctx->d_mail + 2));
         FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], ctx->d_mail + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        first = ctx->h_mail[0];
+        all_nan = (unsigned long long)first == big;
+        if (!all_nan && ctx->h_mail[2] != first) {                // NaNs after the first valid entry: fill them (logic.py:187-189)
+            k_ff_scan_tiles<<<1, 1024, 0, ctx->stream>>>(tile_last, tiles);
+            FMK_LAUNCH_CHECK(ctx);
+            k_ff_apply<<<(unsigned)tiles, FF_THREADS, 0, ctx->stream>>>(d_sigma, n, tile_last);
+            FMK_LAUNCH_CHECK(ctx);
+        }
+        if (all_nan) first = 0;                                   // all NaN: logic.py:178 keeps index 0
+        filled = true;
+        return FMK_OK;
+    };
+    {   // the first valid index from the head alone; NaNs after it are the summary pass's to report (k_ff_head)
+        const char *v = getenv("FMK_CUSUM_LAZY_FILL");             // developer knob: 0 = always run the full pass first
+        const int64_t n_head = n < ((int64_t)1 << 20) ? n : ((int64_t)1 << 20);
+        bool head_ok = false;
+        if (!(v && atoi(v) == 0)) {
+            FMK_HIP(ctx, hipMemcpyAsync(d_first, &big, 8, hipMemcpyHostToDevice, ctx->stream));
+            k_ff_head<<<16, 1024, 0, ctx->stream>>>(d_sigma, n_head, d_first);
+            FMK_LAUNCH_CHECK(ctx);
+            FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if ((unsigned long long)ctx->h_mail[0] != big) { first = ctx->h_mail[0]; head_ok = true; }
+        }
+        if (!head_ok) FMK_TRY(full_fill());
     }
-    if (all_nan) first = 0;                                       // all NaN: logic.py:178 keeps index 0
 
     // ---- parallel-in-time fixed point over the chunks of ticks first+1 .. n-1
     const int64_t m = n - (first + 1);
@@ -514,9 +549,17 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     int64_t rounds = 0;
     int64_t total = 0;
     int chain_done = 0;
-    if (chunks > 0)                                               // thresholds rarely reached: fmk_cusum_chain.hip
+    if (chunks > 0) {                                             // thresholds rarely reached: fmk_cusum_chain.hip
+        int nan_seen = 0;
         FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out, capacity,
-                                     &total, &rounds, &chain_done));
+                                     &total, &rounds, &chain_done, filled ? nullptr : &nan_seen));
+        if (!filled && !chain_done) {                             // sigma was read as it is: fill it now
+            FMK_TRY(full_fill());
+            if (nan_seen)                                         // ... the walk stopped for that NaN alone: once more
+                FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out,
+                                             capacity, &total, &rounds, &chain_done, nullptr));
+        }
+    } else if (!filled) FMK_TRY(full_fill());
     if (chain_done) {
         if (d_out && capacity < total + 1)
             return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(total + 1),

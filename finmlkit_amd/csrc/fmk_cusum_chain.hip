@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
     if (k >= chunk_hi) return;
     const int64_t t0 = k * CC_CHUNK;
     CcSum acc = cc_identity();
-    bool bad = false;
+    bool bad = false, nan_sigma = false;
     typedef double cc_d2 __attribute__((ext_vector_type(2), aligned(8)));       // 16-byte loads on an 8-byte alignment promise
     typedef long long cc_l2 __attribute__((ext_vector_type(2), aligned(8)));
     for (int sub = 0; sub < CC_CHUNK / CC_SUB; ++sub) {
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
                     cc_tick(p[q], q == 0 ? pm0 : p[q > 0 ? q - 1 : 0], sg[q], a[q], q == 7 ? an : a[q < 7 ? q + 1 : 7], i + 1 < n,
                             sigma_floor, sigma_mult, &r, &lam);
                     bad |= !(fabs(r) < INFINITY);
+                    nan_sigma |= sg[q] != sg[q];
                 }
                 S += r;
                 mn = fmin(mn, S); mx = fmax(mx, S);
@@ -197,8 +198,10 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
         sums[2 * chunks + k] = acc.Ap; sums[3 * chunks + k] = acc.Pp; sums[4 * chunks + k] = acc.Qp;
         sums[5 * chunks + k] = acc.An; sums[6 * chunks + k] = acc.Pn; sums[7 * chunks + k] = acc.Qn;
     }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0 && !__atomic_load_n(&state->bad, __ATOMIC_RELAXED))
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0 && !(__atomic_load_n(&state->bad, __ATOMIC_RELAXED) & 1))
         atomicOr(&state->bad, 1);
+    if (__builtin_amdgcn_ballot_w64(nan_sigma) != 0 && lane == 0 && !(__atomic_load_n(&state->bad, __ATOMIC_RELAXED) & 2))
+        atomicOr(&state->bad, 2);                                     // (matters only while sigma is not forward filled)
 }
 
 // states: [0] positive side, [1] negative side, [2 .. 2 + 2 (K - 1)) the later segments of the two sides (k_cc_ranges), then
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
                                                 const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                 int64_t chunk_limit, int64_t chunks, double sigma_floor, double sigma_mult,
                                                 const double *__restrict__ sums, const double *__restrict__ subs,
-                                                CcState *states, const CcState *st0, int64_t visit_budget,
+                                                CcState *states, const CcState *st0, int bad_mask, int64_t visit_budget,
                                                 double margin_scale, int64_t *__restrict__ all_lists,
                                                 int64_t *__restrict__ closes, int64_t capacity)
 {
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *_
     int64_t c = state->chunk;
     double sp = state->sp, sn = state->sn, mag_p = state->mag_p, mag_n = state->mag_n;
     int64_t reset_p = state->reset_p, reset_n = state->reset_n, n_out = state->n_out, visits = state->visits;
-    int status = st0->bad ? CC_ST_BAD : CC_ST_DONE;                    // k_cc_summary reports there
+    int status = (st0->bad & bad_mask) ? CC_ST_BAD : CC_ST_DONE;       // k_cc_summary reports there
     const double eps = margin_scale * 8.881784197001252e-16;              // 2^-50
 
     auto load = [&](int64_t c0) -> CcSum {
@@ -624,27 +627,27 @@ __global__ __launch_bounds__(64) void k_cc_pick(const unsigned char *__restrict_
     if (lane == 0) starts[side * K + k] = found;
 }
 
-// the segments' states: each runs from its start to the next segment's start
-__global__ void k_cc_ranges(const int64_t *__restrict__ starts, int K, int64_t chunks, CcState *st, int64_t list_cap,
-                            int64_t seg_base, int64_t seg_cap, int64_t *n_active)
+// the segments' states: each runs from its start to the next segment's start (one workgroup per side, thread k = segment k)
+__global__ __launch_bounds__(1024) void k_cc_ranges(const int64_t *__restrict__ starts, int K, int64_t chunks, CcState *st,
+                                                    int64_t list_cap, int64_t seg_base, int64_t seg_cap, int64_t *n_active)
 {
-    const int side = (int)threadIdx.x;
-    if (side >= 2) return;
-    int64_t next = chunks;
-    int active = 0;
-    for (int k = K - 1; k >= 1; --k) {
-        CcState *q = st + 2 + side * (K - 1) + (k - 1);
-        const int64_t a = starts[side * K + k];
-        q->side = side + 1;
-        q->list_off = seg_base + ((int64_t)side * (K - 1) + (k - 1)) * seg_cap; q->list_cap = seg_cap;
-        q->sp = 0.0; q->sn = 0.0; q->mag_p = 0.0; q->mag_n = 0.0; q->n_out = 0; q->visits = 0; q->status = CC_ST_DONE;
-        if (a >= 0) {
-            q->chunk = a; q->limit = next; q->reset_p = a * CC_CHUNK; q->reset_n = a * CC_CHUNK;
-            next = a; ++active;
-        } else { q->chunk = 0; q->limit = 0; q->reset_p = 0; q->reset_n = 0; }
+    const int side = (int)blockIdx.x, k = (int)threadIdx.x;
+    if (k >= K) return;
+    int64_t next = chunks;                                              // the first started segment after this one
+    for (int j = k + 1; j < K; ++j) {
+        const int64_t a = starts[side * K + j];
+        if (a >= 0) { next = a; break; }
     }
-    st[side].limit = next;                                              // the side's first segment: from where the sample ended
-    atomicAdd((unsigned long long *)n_active, (unsigned long long)active);
+    if (k == 0) { st[side].limit = next; return; }                      // the side's first segment: from where the stream starts
+    CcState *q = st + 2 + side * (K - 1) + (k - 1);
+    const int64_t a = starts[side * K + k];
+    q->side = side + 1;
+    q->list_off = seg_base + ((int64_t)side * (K - 1) + (k - 1)) * seg_cap; q->list_cap = seg_cap;
+    q->sp = 0.0; q->sn = 0.0; q->mag_p = 0.0; q->mag_n = 0.0; q->n_out = 0; q->visits = 0; q->status = CC_ST_DONE;
+    if (a >= 0) { q->chunk = a; q->limit = next; q->reset_p = a * CC_CHUNK; q->reset_n = a * CC_CHUNK; }
+    else { q->chunk = 0; q->limit = 0; q->reset_p = 0; q->reset_n = 0; }
+    const unsigned long long on = __builtin_amdgcn_ballot_w64(a >= 0);
+    if (fmk_lane() == (int)__builtin_ctzll(on | (1ULL << 63)) && on) atomicAdd((unsigned long long *)n_active, (unsigned long long)__builtin_popcountll(on));
 }
 
 // the segments' closes behind the first segment's, in order: the side's list
@@ -654,8 +657,13 @@ __global__ __launch_bounds__(256) void k_cc_gather(const CcState *__restrict__ s
     const CcState *q = st + 2 + side * (K - 1) + (k - 1);
     const int64_t cnt = q->n_out;
     if (cnt == 0) return;
-    int64_t off = st[side].n_out;
-    for (int j = 1; j < k; ++j) off += st[2 + side * (K - 1) + (j - 1)].n_out;
+    __shared__ int64_t s_part[4];
+    int64_t part = 0;                                                    // closes of the side's earlier segments
+    for (int j = 1 + (int)threadIdx.x; j < k; j += 256) part += st[2 + side * (K - 1) + (j - 1)].n_out;
+    part = fmk_wave_sum(part);
+    if (fmk_lane() == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const int64_t off = st[side].n_out + s_part[0] + s_part[1] + s_part[2] + s_part[3];
     const int64_t *src = lists + q->list_off;
     int64_t *dst = lists + (int64_t)side * list_cap + off;
     for (int64_t i = threadIdx.x; i < cnt; i += 256)
@@ -702,9 +710,12 @@ extern "C" int fmk_diag_cusum_segments(int64_t *segments, double *rate)
 // *done = 0 when the caller has to run the fixed point (thresholds reached often, an uncertain decision, a bad return).
 int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const double *d_sigma, int64_t n,
                          int64_t first, int64_t m, int64_t chunks, double sigma_floor, double sigma_mult, int64_t *d_out,
-                         int64_t capacity, int64_t *total, int64_t *visits, int *done)
+                         int64_t capacity, int64_t *total, int64_t *visits, int *done, int *nan_seen)
 {
+    // nan_seen != null: sigma has not been forward filled (fmk_cusum.hip) -- its first valid index is `first`, and a NaN after
+    // it (k_cc_summary reports one) ends the tier with *nan_seen = 1
     *done = 0;
+    if (nan_seen) *nan_seen = 0;
     // developer knobs, read per call: FMK_CUSUM_CHAIN = 0 (never) / 1 (default) / 2 (no budget of opened chunks)
     const char *v = getenv("FMK_CUSUM_CHAIN");
     const int mode = v ? atoi(v) : 1;
@@ -752,6 +763,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     const int64_t sample_want = v && atoll(v) > 0 ? atoll(v) : 0;      // in a launch of their own first (the walk resumes)
     const int64_t sample = chunks < sample_want ? chunks : sample_want;
     const int64_t lead = chunks < 2048 ? chunks : 2048;
+    const int bad_mask = nan_seen ? 3 : 1;
     CcHost hh;
     memset(&hh, 0, sizeof(hh));
     auto fetch = [&]() -> int {
@@ -762,7 +774,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     };
     auto walk = [&](int joint, int64_t hi, int64_t budget) -> int {
         k_cc_walk<<<joint ? 1 : 2, 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, hi, chunks, sigma_floor,
-                                                                        sigma_mult, sums, subs, joint ? st + JOINT : st, st, budget,
+                                                                        sigma_mult, sums, subs, joint ? st + JOINT : st, st, bad_mask, budget,
                                                                         margin_scale, lists, d_out, d_out ? capacity : 0);
         FMK_LAUNCH_CHECK(ctx);
         return fetch();
@@ -776,10 +788,10 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
         FMK_LAUNCH_CHECK(ctx);
         k_cc_pick<<<nb, 64, 0, ctx->stream>>>(flags, chunks, lo, K, d_starts);
         FMK_LAUNCH_CHECK(ctx);
-        k_cc_ranges<<<1, 64, 0, ctx->stream>>>(d_starts, K, chunks, st, list_cap, 2 * list_cap, (2 * list_cap) / (2 * (K - 1)), d_active);
+        k_cc_ranges<<<2, 1024, 0, ctx->stream>>>(d_starts, K, chunks, st, list_cap, 2 * list_cap, (2 * list_cap) / (2 * (K - 1)), d_active);
         FMK_LAUNCH_CHECK(ctx);
         k_cc_walk<<<(unsigned)(2 * K), 64 * CC_WALK_WAVES, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, chunks,
-                                                                            sigma_floor, sigma_mult, sums, subs, st, st, budget,
+                                                                            sigma_floor, sigma_mult, sums, subs, st, st, bad_mask, budget,
                                                                             margin_scale, lists, d_out, d_out ? capacity : 0);
         FMK_LAUNCH_CHECK(ctx);
         hseg.resize((size_t)(2 * K));
@@ -860,6 +872,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
             }
         }
     }
+    if (nan_seen && (hh.st[0].bad & 2)) *nan_seen = 1;
     if (visits) *visits = h.visits;
     g_cc_last[1] = h.visits; g_cc_last[2] = h.status; g_cc_last[3] = active;
     if (h.status != CC_ST_DONE) return FMK_OK;

@@ -173,6 +173,32 @@ def test_cusum_chain_walk_replays_what_its_margins_cannot_settle(orc, monkeypatc
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("lead,hole", [(1_100_000, None), (7, 1_234_567), (0, None), (2_000_000, None)])
+def test_cusum_sigma_is_filled_lazily(orc, monkeypatch, lead, hole):
+    """sigma is not forward filled before the chain walk: its first valid index comes from the head of the array (k_ff_head:
+    the first 2^20 entries, else the full pass), and a NaN after it is reported by the walk's summary pass, which then has the
+    array filled and starts over.  Leading NaNs beyond the head, a hole far inside, none at all, all NaN: closes and the
+    filled sigma as the reference leaves them (logic.py:178-189)."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    n = 2_000_000
+    ts, px = _stream(orc, n, 23, vol=2e-6, same_ts=0.25)
+    sigma = np.full(n, 1e-7)
+    sigma[:lead] = np.nan
+    if hole is not None:
+        sigma[hole: hole + 3] = np.nan
+        sigma[hole - 1] = 4e-4                                     # the filled value matters: lam = 2 * 4e-4 there
+    want, wfilled = orc._cusum_bar_indexer(ts, px, sigma, 5e-4, 2.0, return_sigma=True)
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("FMK_CUSUM_LAZY_FILL", lazy)
+        s = sigma.copy()
+        got = _cusum_bar_indexer(ts, px, s, 5e-4, 2.0)
+        np.testing.assert_array_equal(got, want, err_msg=f"lazy {lazy}")
+        np.testing.assert_array_equal(s, wfilled, err_msg=f"lazy {lazy}")
+        if lead < n:
+            assert _last_tier()[0] == 1
+
+
 def test_cusum_chain_walk_falls_back(orc, monkeypatch):
     """Decisions that block sums cannot settle at every tick (forced: margins scaled by 1e12), a non-finite return (a zero
     price) and a tape whose thresholds are reached often (the budget of opened chunks) all hand the call to the fixed point:

