@@ -156,6 +156,25 @@ __device__ __forceinline__ double fmk_amt(const void *p, int64_t j)
 // Python negative-index wrap of the reference (prices[-1] when close_idx[0] == -1)
 __device__ __forceinline__ int64_t fmk_wrap(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
 
+// log(p / pm) for tick returns (comp_lagged_returns utils.py, _cusum_bar_indexer logic.py:198): the quotient as the reference
+// rounds it, then its logarithm.  Prices a few ticks apart give x = p / pm within 2^-6 of 1, where f = x - 1 is exact and
+// log1p(f) = f + f^2 (-1/2 + f/3 - ... - f^10/12) needs twelve instructions: the last step adds a correction of at most
+// f / 128 to an exact f, so the result is within 0.51 ulp -- tools/logratio_check.c: the same double as glibc's log in all
+// but 4 of a million such quotients, and as often the correctly rounded value as glibc's.  The library log costs ~150
+// instructions per call, which made every kernel that takes tick returns VALU-bound (k_cc_summary 7.0 ms per 1e9 ticks for
+// a 24 B/tick read).  Anything else -- larger moves, zero, negative, non-finite -- goes to the library function.
+__device__ __noinline__ static double fmk_log_far(double x) { return log(x); }   // (not inlined: ~150 instructions, rarely run)
+__device__ __forceinline__ double fmk_log_ratio(double p, double pm)
+{
+    const double x = p / pm, f = x - 1.0;
+    if (!(fabs(f) <= 0.015625)) return fmk_log_far(x);
+    double q = -1.0 / 12.0;
+    q = fma(f, q, 1.0 / 11.0); q = fma(f, q, -1.0 / 10.0); q = fma(f, q, 1.0 / 9.0); q = fma(f, q, -1.0 / 8.0);
+    q = fma(f, q, 1.0 / 7.0); q = fma(f, q, -1.0 / 6.0); q = fma(f, q, 1.0 / 5.0); q = fma(f, q, -1.0 / 4.0);
+    q = fma(f, q, 1.0 / 3.0); q = fma(f, q, -0.5);
+    return fma(f * f, q, f);
+}
+
 // splitmix64-style counter hash shared with oracle/fmk_oracle.c (orc_mix64)
 __host__ __device__ __forceinline__ uint64_t fmk_mix64(uint64_t x)
 {

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ 
             double r = 0.0, lam = NAN;
             if (k0 + row < chunks && t < m) {
                 const int64_t i = first + 1 + t;
-                r = log(price[i] / price[i - 1]);
+                r = fmk_log_ratio(price[i], price[i - 1]);
                 const bool block = i + 1 < n && ts[i] == ts[i + 1];
                 if (!block) {
                     lam = sigma_mult * sigma[i];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
                 double r = 0.0, lam = NAN;
                 if (jj < len) {                                         // the expressions of k_cusum_prep
                     const int64_t i = first + 1 + t0 + jj;
-                    r = log(c_p[g] / c_pm[g]);
+                    r = fmk_log_ratio(c_p[g], c_pm[g]);
                     const bool block = i + 1 < n && c_ts[g] == c_tsn[g];
                     if (!block) {
                         lam = sigma_mult * c_sg[g];

@@ -98,13 +98,34 @@ __device__ __forceinline__ int64_t cc_bcast_i64(int64_t v, int src)
 __device__ __forceinline__ void cc_tick(double p, double pm, double sg, int64_t tsi, int64_t tsn, bool has_next,
                                         double sigma_floor, double sigma_mult, double *r, double *lam)
 {
-    *r = log(p / pm);
+    *r = fmk_log_ratio(p, pm);
     double l = NAN;
     if (!(has_next && tsi == tsn)) {
         l = sigma_mult * sg;
         l = sigma_floor > l ? sigma_floor : l;
     }
     *lam = l;
+}
+
+// ordered composition over the lanes on the DPP path (lane 63 ends up with lanes 0 .. 63 composed left to right; the order of
+// fmk_dpp_iscan).  The first version was a shuffle-down tree: 96 ds_bpermute per 512 ticks and their LDS round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ CcSum cc_sum_dpp(const CcSum &v)
+{
+    return CcSum{fmk_dpp<CTRL, ROW_MASK>(0.0, v.B), fmk_dpp<CTRL, ROW_MASK>(0.0, v.U),
+                 fmk_dpp<CTRL, ROW_MASK>((double)-INFINITY, v.Ap), fmk_dpp<CTRL, ROW_MASK>((double)-INFINITY, v.Pp),
+                 fmk_dpp<CTRL, ROW_MASK>((double)-INFINITY, v.Qp), fmk_dpp<CTRL, ROW_MASK>((double)INFINITY, v.An),
+                 fmk_dpp<CTRL, ROW_MASK>((double)INFINITY, v.Pn), fmk_dpp<CTRL, ROW_MASK>((double)INFINITY, v.Qn)};
+}
+__device__ __forceinline__ CcSum cc_sum_iscan(CcSum v)
+{
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_SHR(1), 0xF>(v), v);
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_SHR(2), 0xF>(v), v);
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_SHR(4), 0xF>(v), v);
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_SHR(8), 0xF>(v), v);
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_BCAST15, 0xA>(v), v);
+    v = cc_compose(cc_sum_dpp<FMK_DPP_ROW_BCAST31, 0xC>(v), v);
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -176,24 +197,16 @@ __global__ __launch_bounds__(256) void k_cc_summary(const int64_t *__restrict__ 
             }
             me = CcSum{S, U, S - mn, Pp, Qp, S - mx, Pn, Qn};
         }
-        // ordered tree over the lanes: after step d, lanes that are multiples of 2d hold [lane, lane + 2d)
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            CcSum o;
-            o.B = cc_shfl_down(me.B, d); o.U = cc_shfl_down(me.U, d);
-            o.Ap = cc_shfl_down(me.Ap, d); o.Pp = cc_shfl_down(me.Pp, d); o.Qp = cc_shfl_down(me.Qp, d);
-            o.An = cc_shfl_down(me.An, d); o.Pn = cc_shfl_down(me.Pn, d); o.Qn = cc_shfl_down(me.Qn, d);
-            me = cc_compose(me, o);
-        }
-        if (lane == 0) {                                      // the 512-tick sub-block's own summary (the walk opens sub-blocks)
+        me = cc_sum_iscan(me);                                // lane 63: the sub-block's 64 lane blocks composed in order
+        if (lane == 63) {                                     // the 512-tick sub-block's own summary (the walk opens sub-blocks)
             const int64_t q = k * (CC_CHUNK / CC_SUB) + sub, nq = chunks * (CC_CHUNK / CC_SUB);
             subs[0 * nq + q] = me.B; subs[1 * nq + q] = me.U;
             subs[2 * nq + q] = me.Ap; subs[3 * nq + q] = me.Pp; subs[4 * nq + q] = me.Qp;
             subs[5 * nq + q] = me.An; subs[6 * nq + q] = me.Pn; subs[7 * nq + q] = me.Qn;
         }
-        acc = cc_compose(acc, me);                            // meaningful on lane 0
+        acc = cc_compose(acc, me);                            // meaningful on lane 63
     }
-    if (lane == 0) {
+    if (lane == 63) {
         sums[0 * chunks + k] = acc.B; sums[1 * chunks + k] = acc.U;
         sums[2 * chunks + k] = acc.Ap; sums[3 * chunks + k] = acc.Pp; sums[4 * chunks + k] = acc.Qp;
         sums[5 * chunks + k] = acc.An; sums[6 * chunks + k] = acc.Pn; sums[7 * chunks + k] = acc.Qn;
@@ -232,7 +245,7 @@ __device__ __forceinline__ double cc_replay(const double *__restrict__ price, in
     double s = 0.0;
     for (int64_t base = t_from; base <= t_to; base += 64) {
         const int64_t t = base + lane, i = first + 1 + (t <= t_to ? t : t_to);
-        const double r = log(price[i] / price[i - 1]);
+        const double r = fmk_log_ratio(price[i], price[i - 1]);
         const int cnt = (int)(t_to - base + 1 < 64 ? t_to - base + 1 : 64);
         for (int k = 0; k < cnt; ++k) {
             const double rk = cc_bcast(r, k);
@@ -273,7 +286,7 @@ __device__ __forceinline__ CcMap cc_map_exclusive(const CcMap &inc)
                  fmk_dpp_shift_up1(inc.An, (double)INFINITY)};
 }
 
-__global__ __launch_bounds__(64 * CC_WALK_WAVES) void k_cc_walk(const int64_t *__restrict__ ts, const double *__restrict__ price,
+__global__ __launch_bounds__(64 * CC_WALK_WAVES, 2) void k_cc_walk(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                 const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                 int64_t chunk_limit, int64_t chunks, double sigma_floor, double sigma_mult,
                                                 const double *__restrict__ sums, const double *__restrict__ subs,

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_lagged_returns(const int64_t *__restric
     for (int k = 0; k < PER; ++k) {
         double r = NAN;
         if (live[k] && lag[k] >= 0) {
-            if (c0[k] != 0.0) r = is_log ? log(c1[k] / c0[k]) : c1[k] / c0[k] - 1.0;
+            if (c0[k] != 0.0) r = is_log ? fmk_log_ratio(c1[k], c0[k]) : c1[k] / c0[k] - 1.0;
             else r = INFINITY;                           // utils.py:57-60
         }
         res[k] = r;
