@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_cc_rate(const double *__restrict__ subs
 // emits the reference's closes, all of them, without knowing anything about the ticks before -- and the side's chain can
 // be walked by many workgroups at once.  Both inequalities carry the walk's margin (block sums against the reference's
 // sequential sums).  Mirrored for the negative side.  flags[side * chunks + c] = 1: boundary c is such a start.
-#define CC_SYNC_MAX 1024                                                // chunks a window may span
+#define CC_SYNC_MAX 96                                                  // chunks a window may span
 __global__ __launch_bounds__(256) void k_cc_sync(const double *__restrict__ sums, int64_t chunks, int64_t lo, double margin_scale,
                                                  unsigned char *__restrict__ flags)
 {
