@@ -892,6 +892,7 @@ extern "C" int fmk_ewms_dev(fmk_ctx *ctx, const double *d_y, int64_t n, int64_t 
 #define RV_C 25                                  // region elements per thread (odd: conflict-free ds_read_b64)
 #define RV_R (RV_THREADS * RV_C)                 // 6400 region elements: 51200 B of squares + 12800 B of counts
 #define RV_MAX_W 2048
+#define RV_SMALL_W 640
 
 // exclusive carry of a segmented sum across the block's threads, in thread order (REV = false) or reversed.
 // (s, f) = my chunk's aggregate: f = chunk contains a segment boundary, s = sum of the elements after (before,
@@ -924,19 +925,23 @@ __device__ __forceinline__ double rv_block_carry(double s, int f, double *w_s, i
     return pf ? ps : cs + ps;
 }
 
+// C = region elements per thread: 25 (64 KB of LDS, 249 VGPRs: two workgroups per CU) serves windows up to 2048; windows up to
+// RV_SMALL_W take C = 9 (23 KB, 110 VGPRs: four workgroups per CU; 1e9 ticks, W = 20: 8.9 -> 5.9 ms, W = 500: 10.0 -> ~7.5 ms with
+// 28 % of halo; C = 5 and C = 15 were measured too and are no better than their neighbours)
+template <int C>
 __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__restrict__ r, int64_t n, int64_t W,
                                                              int is_sample, int64_t T, double *__restrict__ out)
 {
-    __shared__ double s_sq[RV_R];
-    __shared__ unsigned short s_cnt[RV_R];
+    __shared__ double s_sq[(RV_THREADS * C)];
+    __shared__ unsigned short s_cnt[(RV_THREADS * C)];
     __shared__ double w_s[4];
     __shared__ int w_f[4];
     __shared__ int w_c[4];
     const int tid = threadIdx.x, lane = fmk_lane(), wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * T;
     const int64_t g0 = base - (W - 1);                 // global index of region element 0 (may be negative)
-    const int R = (int)(T + W - 1);                    // <= RV_R
-    for (int e = tid; e < RV_R; e += RV_THREADS) {
+    const int R = (int)(T + W - 1);                    // <= (RV_THREADS * C)
+    for (int e = tid; e < (RV_THREADS * C); e += RV_THREADS) {
         const int64_t g = g0 + e;
         double v = NAN;
         if (e < R && g >= 0 && g < n) v = r[g];
@@ -945,11 +950,11 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
         s_cnt[e] = ok ? 1 : 0;
     }
     __syncthreads();
-    const int e0 = tid * RV_C;
-    double sq[RV_C], pre[RV_C];
-    int cn[RV_C];
+    const int e0 = tid * C;
+    double sq[C], pre[C];
+    int cn[C];
 #pragma unroll
-    for (int k = 0; k < RV_C; ++k) { sq[k] = s_sq[e0 + k]; cn[k] = s_cnt[e0 + k]; }
+    for (int k = 0; k < C; ++k) { sq[k] = s_sq[e0 + k]; cn[k] = s_cnt[e0 + k]; }
     int64_t m0 = (g0 + e0) % W;                        // position of my first element inside its segment
     if (m0 < 0) m0 += W;
     // ---- forward: prefix inside the segment
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
     {
         int64_t m = m0;
 #pragma unroll
-        for (int k = 0; k < RV_C; ++k) {
+        for (int k = 0; k < C; ++k) {
             if (m == 0) { run = 0.0; f = 1; }
             run += sq[k];
             pre[k] = run;
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
         int64_t m = m0;
         bool open = true;                              // no segment start seen yet -> the carry applies
 #pragma unroll
-        for (int k = 0; k < RV_C; ++k) {
+        for (int k = 0; k < C; ++k) {
             if (m == 0) open = false;
             if (open) pre[k] = cf + pre[k];
             if (++m == W) m = 0;
@@ -990,14 +995,14 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
     int cbase = cinc - csum;
     for (int k = 0; k < wv; ++k) cbase += w_c[k];
     // ---- backward: suffix inside the segment (segment END at m == W-1)
-    double suf[RV_C];
+    double suf[C];
     run = 0.0;
     f = 0;
     {
-        int64_t m = m0 + RV_C - 1;
+        int64_t m = m0 + C - 1;
         m %= W;
 #pragma unroll
-        for (int k = RV_C - 1; k >= 0; --k) {
+        for (int k = C - 1; k >= 0; --k) {
             if (m == W - 1) { run = 0.0; f = 1; }
             run += sq[k];
             suf[k] = run;
@@ -1006,10 +1011,10 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
     }
     const double cb = rv_block_carry<true>(run, f, w_s, w_f);
     {
-        int64_t m = (m0 + RV_C - 1) % W;
+        int64_t m = (m0 + C - 1) % W;
         bool open = true;
 #pragma unroll
-        for (int k = RV_C - 1; k >= 0; --k) {
+        for (int k = C - 1; k >= 0; --k) {
             if (m == W - 1) open = false;
             if (open) suf[k] = cb + suf[k];
             if (--m < 0) m = W - 1;
@@ -1018,13 +1023,13 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
     // publish suffix sums + inclusive counts (every thread has its chunk in registers by now)
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RV_C; ++k) { s_sq[e0 + k] = suf[k]; s_cnt[e0 + k] = (unsigned short)(cbase + cn[k]); }
+    for (int k = 0; k < C; ++k) { s_sq[e0 + k] = suf[k]; s_cnt[e0 + k] = (unsigned short)(cbase + cn[k]); }
     __syncthreads();
-    double res[RV_C];
+    double res[C];
     {
         int64_t m = m0;
 #pragma unroll
-        for (int k = 0; k < RV_C; ++k) {
+        for (int k = 0; k < C; ++k) {
             const int e = e0 + k;
             const int es = e - (int)(W - 1);            // region element of the window start
             double o = NAN;
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_realized_vol(const double *__res
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RV_C; ++k) s_sq[e0 + k] = res[k];
+    for (int k = 0; k < C; ++k) s_sq[e0 + k] = res[k];
     __syncthreads();
     for (int e = (int)(W - 1) + tid; e < R; e += RV_THREADS) {
         const int64_t i = g0 + e;
@@ -1150,9 +1155,15 @@ extern "C" int fmk_realized_vol_dev(fmk_ctx *ctx, const double *d_r, int64_t n, 
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }
+    if (window <= RV_SMALL_W) {
+        const int64_t T = RV_THREADS * 9 - (window - 1);
+        k_realized_vol<9><<<(unsigned)fmk_ceil_div(n, T), RV_THREADS, 0, ctx->stream>>>(d_r, n, window, is_sample, T, d_out);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
     if (window <= RV_MAX_W) {
         const int64_t T = RV_R - (window - 1);
-        k_realized_vol<<<(unsigned)fmk_ceil_div(n, T), RV_THREADS, 0, ctx->stream>>>(d_r, n, window, is_sample, T, d_out);
+        k_realized_vol<RV_C><<<(unsigned)fmk_ceil_div(n, T), RV_THREADS, 0, ctx->stream>>>(d_r, n, window, is_sample, T, d_out);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }

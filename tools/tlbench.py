@@ -24,5 +24,5 @@ timed("lagged_returns 5s log", lambda: t.lagged_returns(5.0, True))
 timed("ewmst 60s", lambda: t.ewmst(r, 60.0))
 timed("ewmst_mean0 60s", lambda: t.ewmst(r, 60.0, mean0=True))
 timed("ewms span 100", lambda: t.ewms(r, 100))
-for w in (20, 1000, 4096, 100_000):
+for w in (20, 64, 100, 256, 500, 1000, 2048, 4096, 100_000):
     timed(f"realized_vol window {w}", lambda: t.realized_vol(r, w, True))
