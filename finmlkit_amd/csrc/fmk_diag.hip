@@ -24,6 +24,29 @@ __global__ __launch_bounds__(256) void k_diag_read(const uint4 *__restrict__ p, 
     if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);        // practically never: keeps the loads alive
 }
 
+// variants 4 / 5: the same two widths as NON-TEMPORAL loads (nt: the lines are not kept in L2 for reuse)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_diag_read_nt(const uint4 *__restrict__ p, int64_t n16, unsigned long long *sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    if (VEC == 0) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 *q = (const u4 *)p;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+            const u4 v = __builtin_nontemporal_load(q + i);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    } else {
+        const unsigned long long *q = (const unsigned long long *)p;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n16; i += stride) {
+            const unsigned long long v = __builtin_nontemporal_load(q + i);
+            acc ^= (unsigned)v ^ (unsigned)(v >> 32);
+        }
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);
+}
+
 // variant 2: 4 B per lane (dword, what the reducers issue per float32 amount); variant 3: 8 B per lane STORES (calibration of
 // WRITE_SIZE on a known byte count; the buffer is overwritten with its own indices)
 __global__ __launch_bounds__(256) void k_diag_read4(const unsigned *__restrict__ p, int64_t n4, unsigned long long *sink)
@@ -50,6 +73,8 @@ extern "C" int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t b
     if (variant == 0) k_diag_read<0><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
     else if (variant == 1) k_diag_read<1><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
     else if (variant == 2) k_diag_read4<<<blocks, 256, 0, ctx->stream>>>((const unsigned *)d_buf, n16 * 4, sink);
+    else if (variant == 4) k_diag_read_nt<0><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
+    else if (variant == 5) k_diag_read_nt<1><<<blocks, 256, 0, ctx->stream>>>((const uint4 *)d_buf, n16, sink);
     else k_diag_write8<<<blocks, 256, 0, ctx->stream>>>((unsigned long long *)d_buf, n16 * 2);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

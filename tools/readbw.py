@@ -9,7 +9,7 @@ ctx = _ffi.default_context()
 nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else 12_000_000_000
 buf = DeviceArray(ctx, nbytes // 8, np.int64)
 buf.zero(); ctx.sync()
-for variant, name in ((0, "16 B/lane"), (1, "8 B/lane")):
+for variant, name in ((0, "16 B/lane"), (1, "8 B/lane"), (4, "16 B nt"), (5, "8 B nt")):
     for bpc in (4, 8, 16, 32):
         ms = C.c_double()
         best = 1e9
