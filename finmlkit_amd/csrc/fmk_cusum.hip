@@ -197,28 +197,33 @@ __global__ __launch_bounds__(FF_THREADS) void k_ff_apply(double *__restrict__ x,
 // ---------------------------------------------------------------------------------------
 struct CsState { double sp, sn; };
 
-// Per-tick inputs of the loop, computed ONCE and stored chunk-TRANSPOSED (element j of chunk k at [j * chunks + k]) so
-// that the one-thread-per-chunk simulation below reads fully coalesced 512 B per wave and per array:
+// Per-tick inputs of the loop, computed ONCE and stored chunk-TRANSPOSED in blocks of 64 chunks -- element j of chunk k at
+// [((k >> 6) * CS_CHUNK + j) * 64 + (k & 63)] -- so that the one-thread-per-chunk simulation below streams 512 contiguous
+// bytes per wave, array and tick, one after the other:
 //   ret[t] = log(p_i / p_{i-1})                                             (logic.py:200)
 //   lam[t] = max(sigma_mult * sigma_i, sigma_floor), NaN inside a same-timestamp print block (logic.py:206-211):
 //            a NaN threshold can never be reached, which is exactly "this tick cannot close a bar"
-// for tick i = first + 1 + t, t = k * CS_CHUNK + j.  64 x 64 tiles through LDS (coalesced on both sides).
-#define CS_PREP_TJ 32           // ticks per tile: 64 chunks x 32 ticks, 33.8 KB of LDS -> four workgroups per CU (64 x 64 tiles, 66 KB:
-                                // two per CU, 16.7 ms per 1e9 ticks; 32: 12.1 ms; 16: 14.5 ms)
+// for tick i = first + 1 + t, t = k * CS_CHUNK + j.  Tiles of 32 chunks x 64 ticks through LDS: every wave instruction of the
+// read side takes 512 contiguous bytes of a column, the write side fills 256-byte halves of adjacent rows.  (The first layout,
+// [j * chunks + k] with 64 x 32 tiles, read 256-byte pieces 16 KB apart and wrote rows 3.9 MB apart: 12.3 ms per 1e9 ticks.)
+#define CS_PREP_TK 32           // chunks per tile
+#define CS_PREP_TJ 64           // ticks per tile: 33.3 KB of LDS -> four workgroups per CU
+__device__ __forceinline__ int64_t cs_tr_index(int64_t k, int j) { return (((k >> 6) * CS_CHUNK + j) << 6) + (k & 63); }
 __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                     const double *__restrict__ sigma, int64_t n, int64_t first,
                                                     int64_t m, int64_t chunks, double sigma_floor, double sigma_mult,
                                                     double *__restrict__ t_ret, double *__restrict__ t_lam)
 {
-    __shared__ double s_r[64][CS_PREP_TJ + 1];
-    __shared__ double s_l[64][CS_PREP_TJ + 1];
-    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    __shared__ double s_r[CS_PREP_TK][CS_PREP_TJ + 1];
+    __shared__ double s_l[CS_PREP_TK][CS_PREP_TJ + 1];
+    const int64_t k0 = (int64_t)blockIdx.x * CS_PREP_TK;
     const int j0 = (int)blockIdx.y * CS_PREP_TJ;
     {
-        const int col = threadIdx.x & (CS_PREP_TJ - 1), row8 = threadIdx.x / CS_PREP_TJ;
+        const int col = threadIdx.x & (CS_PREP_TJ - 1), row4 = threadIdx.x / CS_PREP_TJ;
         constexpr int RP = 256 / CS_PREP_TJ;                            // rows per pass
-        for (int rr = 0; rr < 64 / RP; ++rr) {
-            const int row = rr * RP + row8;                             // chunk inside the tile
+#pragma unroll
+        for (int rr = 0; rr < CS_PREP_TK / RP; ++rr) {
+            const int row = rr * RP + row4;                             // chunk inside the tile
             const int64_t t = (k0 + row) * CS_CHUNK + j0 + col;
             double r = 0.0, lam = NAN;
             if (k0 + row < chunks && t < m) {
@@ -236,13 +241,16 @@ __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ 
     }
     __syncthreads();
     {
-        const int col = threadIdx.x & 63, jr4 = threadIdx.x >> 6;
-        for (int rr = 0; rr < CS_PREP_TJ / 4; ++rr) {
-            const int jrow = rr * 4 + jr4;                              // tick inside the tile
+        const int col = threadIdx.x & (CS_PREP_TK - 1), jr8 = threadIdx.x / CS_PREP_TK;
+        constexpr int JP = 256 / CS_PREP_TK;                            // ticks per pass
+#pragma unroll
+        for (int rr = 0; rr < CS_PREP_TJ / JP; ++rr) {
+            const int jrow = rr * JP + jr8;                             // tick inside the tile
             const int64_t k = k0 + col;
             if (k < chunks) {
-                t_ret[(int64_t)(j0 + jrow) * chunks + k] = s_r[col][jrow];
-                t_lam[(int64_t)(j0 + jrow) * chunks + k] = s_l[col][jrow];
+                const int64_t at = cs_tr_index(k, j0 + jrow);
+                t_ret[at] = s_r[col][jrow];
+                t_lam[at] = s_l[col][jrow];
             }
         }
     }
@@ -278,11 +286,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_cusum_chunks(const double *__res
     const int len = (int)(m - t0 < CS_CHUNK ? m - t0 : CS_CHUNK);
     int64_t cnt = 0;
     int64_t w = closes ? offsets[k] : 0;
-    const double *pr = t_ret + k, *pl = t_lam + k;
+    const double *pr = t_ret + cs_tr_index(k, 0), *pl = t_lam + cs_tr_index(k, 0);
 #pragma unroll 8
     for (int j = 0; j < len; ++j) {
-        const double ret = pr[(int64_t)j * chunks];
-        const double lam = pl[(int64_t)j * chunks];
+        const double ret = pr[(int64_t)j * 64];
+        const double lam = pl[(int64_t)j * 64];
         const double a = sp + ret, b = sn + ret;
         sp = a > 0.0 ? a : 0.0;                                   // max(0.0, s_pos + ret): NaN -> 0.0
         sn = b < 0.0 ? b : 0.0;                                   // min(0.0, s_neg + ret)
@@ -490,7 +498,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
     const size_t st_bytes = ((size_t)max_chunks * sizeof(CsState) + 255) & ~(size_t)255;
     const size_t cnt_bytes = ((size_t)(max_chunks + 1) * 8 + 255) & ~(size_t)255;
     const size_t ff_bytes = ((size_t)tiles * 8 + 255) & ~(size_t)255;
-    const size_t tr_bytes = ((size_t)max_chunks * CS_CHUNK * 8 + 255) & ~(size_t)255;
+    const size_t tr_bytes = ((size_t)((max_chunks + 63) & ~(int64_t)63) * CS_CHUNK * 8 + 255) & ~(size_t)255;   // whole blocks of 64 chunks
     void *scr;
     const size_t act_bytes = ((size_t)max_chunks + 255) & ~(size_t)255;
     const size_t list_bytes = ((size_t)max_chunks * 4 + 255) & ~(size_t)255;
@@ -574,7 +582,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
         double *t_lam = (double *)(base + 3 * st_bytes + cnt_bytes + tr_bytes);
         unsigned char *active = (unsigned char *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes);
         int *list = (int *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes);
-        const dim3 pg((unsigned)fmk_ceil_div(chunks, 64), CS_CHUNK / CS_PREP_TJ);
+        const dim3 pg((unsigned)fmk_ceil_div(chunks, CS_PREP_TK), CS_CHUNK / CS_PREP_TJ);
         k_cusum_prep<<<pg, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, t_ret,
                                                  t_lam);
         FMK_LAUNCH_CHECK(ctx);
