@@ -212,12 +212,14 @@ __device__ __forceinline__ int64_t cs_tr_index(int64_t k, int j) { return (((k >
 __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                     const double *__restrict__ sigma, int64_t n, int64_t first,
                                                     int64_t m, int64_t chunks, double sigma_floor, double sigma_mult,
-                                                    double *__restrict__ t_ret, double *__restrict__ t_lam)
+                                                    double *__restrict__ t_ret, double *__restrict__ t_lam,
+                                                    unsigned long long *nan_flag /* null: sigma has been forward filled */)
 {
     __shared__ double s_r[CS_PREP_TK][CS_PREP_TJ + 1];
     __shared__ double s_l[CS_PREP_TK][CS_PREP_TJ + 1];
     const int64_t k0 = (int64_t)blockIdx.x * CS_PREP_TK;
     const int j0 = (int)blockIdx.y * CS_PREP_TJ;
+    bool nan_sigma = false;
     {
         const int col = threadIdx.x & (CS_PREP_TJ - 1), row4 = threadIdx.x / CS_PREP_TJ;
         constexpr int RP = 256 / CS_PREP_TJ;                            // rows per pass
@@ -230,8 +232,10 @@ __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ 
                 const int64_t i = first + 1 + t;
                 r = fmk_log_ratio(price[i], price[i - 1]);
                 const bool block = i + 1 < n && ts[i] == ts[i + 1];
+                const double sg = sigma[i];
+                nan_sigma |= sg != sg;
                 if (!block) {
-                    lam = sigma_mult * sigma[i];
+                    lam = sigma_mult * sg;
                     lam = sigma_floor > lam ? sigma_floor : lam;         // max(lam, floor): a NaN lam stays NaN
                 }
             }
@@ -239,6 +243,9 @@ __global__ __launch_bounds__(256) void k_cusum_prep(const int64_t *__restrict__ 
             s_l[row][col] = lam;
         }
     }
+    // sigma read as it is (not forward filled): a NaN after its first valid index makes the caller fill it and start over
+    if (nan_flag && __builtin_amdgcn_ballot_w64(nan_sigma) != 0 && fmk_lane() == 0 && __atomic_load_n(nan_flag, __ATOMIC_RELAXED) == 0)
+        atomicOr(nan_flag, 1ULL);
     __syncthreads();
     {
         const int col = threadIdx.x & (CS_PREP_TK - 1), jr8 = threadIdx.x / CS_PREP_TK;
@@ -561,18 +568,23 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
         int nan_seen = 0;
         FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out, capacity,
                                      &total, &rounds, &chain_done, filled ? nullptr : &nan_seen));
-        if (!filled && !chain_done) {                             // sigma was read as it is: fill it now
+        if (!filled && !chain_done && nan_seen) {                 // the walk stopped for a NaN in sigma: fill it, once more
             FMK_TRY(full_fill());
-            if (nan_seen)                                         // ... the walk stopped for that NaN alone: once more
-                FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out,
-                                             capacity, &total, &rounds, &chain_done, nullptr));
+            FMK_TRY(fmk_cusum_chain_tier(ctx, d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, d_out,
+                                         capacity, &total, &rounds, &chain_done, nullptr));
         }
     } else if (!filled) FMK_TRY(full_fill());
     if (chain_done) {
         if (d_out && capacity < total + 1)
             return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(total + 1),
                                  (long long)capacity);
-    } else if (chunks > 0) {
+    } else if (chunks > 0) for (;;) {
+        // (sigma may still be unfilled: the prep pass then reports a NaN after the first valid index, and this block runs again)
+        const bool check_nan = !filled;
+        bool redo = false;
+        unsigned long long *d_nan = (unsigned long long *)(ctx->d_mail + 5);
+        if (check_nan) FMK_HIP(ctx, hipMemsetAsync(d_nan, 0, 8, ctx->stream));
+        ctx->h_mail[5] = 0;
         rounds = 0;
         FMK_TRY(fmk_scratch(ctx, scan_bytes + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes + list_bytes, &scr));
         char *base = (char *)scr + scan_bytes;
@@ -584,7 +596,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
         int *list = (int *)(base + 3 * st_bytes + cnt_bytes + 2 * tr_bytes + act_bytes);
         const dim3 pg((unsigned)fmk_ceil_div(chunks, CS_PREP_TK), CS_CHUNK / CS_PREP_TJ);
         k_cusum_prep<<<pg, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, t_ret,
-                                                 t_lam);
+                                                 t_lam, check_nan ? d_nan : nullptr);
         FMK_LAUNCH_CHECK(ctx);
         const unsigned blocks = (unsigned)fmk_ceil_div(chunks, CS_THREADS);
         CsState *cur = st_a, *prev = st_b;
@@ -600,7 +612,9 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
             FMK_LAUNCH_CHECK(ctx);
             ++rounds;
             FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (check_nan) FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[5], d_nan, 8, hipMemcpyDeviceToHost, ctx->stream));
             FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (check_nan && ctx->h_mail[5] != 0) { redo = true; break; }
             if (ctx->h_mail[1] == 0) break;                       // fixed point: every chunk started from the truth
             if (rounds > chunks + 2) return fmk_set_error(ctx, FMK_E_HIP, "cusum: fixed point did not converge");
             if (rounds >= 2) {
@@ -633,6 +647,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
                 break;
             }
         }
+        if (redo) { FMK_TRY(full_fill()); continue; }
         // counts -> offsets (+1 for the opening entry), total
         FMK_TRY(fmk_exclusive_scan_i64(ctx, counts, counts, chunks, true));
         FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], counts + chunks, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -646,6 +661,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
                                                                   nullptr, nullptr, nullptr, counts, d_out + 1);
             FMK_LAUNCH_CHECK(ctx);
         }
+        break;
     }
     if (d_out) {
         if (capacity < 1) return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: capacity 0");
