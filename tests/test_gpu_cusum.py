@@ -231,6 +231,28 @@ def test_cusum_chain_walk_falls_back(orc, monkeypatch):
     assert _last_tier()[0] == 0 and _last_tier()[2] == 3
 
 
+def test_cusum_chain_walk_budget_of_a_segment(orc, monkeypatch):
+    """A tape whose beginning is quiet (the estimate from the leading 2048 chunks says "walk") and whose last quarter closes
+    every few dozen ticks: the segments there exhaust their budgets of opened sub-blocks + events, the tier reports it
+    (status 1) and the fixed point answers -- same indices."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
+    n = 6_000_000
+    ts, _ = _stream(orc, n, 29, vol=1e-6, same_ts=0.25)
+    rng = np.random.default_rng(29)
+    lr = rng.normal(0, 1e-6, n)
+    lr[4_500_000:] = rng.normal(0, 3e-4, n - 4_500_000)            # the last quarter: a threshold's worth every few ticks
+    px = 100.0 * np.exp(np.cumsum(lr))
+    sigma = np.full(n, 1e-7)
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    assert len(want) > 100_000
+    got = _cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    tier, opened, status = _last_tier()
+    print(f"{len(want) - 1} closes, tier {tier}, opened {opened}, status {status}, later segments {_last_segments()}")
+    assert (tier, status) == (0, 1) and _last_segments() > 0
+    np.testing.assert_array_equal(got, want)
+
+
 def test_cusum_chain_walk_positive_close_hides_negative(orc, monkeypatch):
     """`if s_pos >= lam ... elif s_neg <= -lam` (logic.py:214-219): inside a same-timestamp block the price falls by 3.5
     thresholds and recovers 2.2 of them on the block's last tick -- both sides are beyond their threshold there, only the
