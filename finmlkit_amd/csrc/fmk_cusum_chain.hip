@@ -1,4 +1,4 @@
-// fmk_cusum_chain.hip -- _cusum_bar_indexer (finmlkit/bar/logic.py:152-221) when the thresholds are RARELY reached.
+// fmk_cusum_chain.hip -- _cusum_bar_indexer (finmlkit/bar/logic.py:152-221) unless the thresholds are reached every few hundred ticks.
 //
 // The reference's default sigma_floor (5e-4) on a quiet tape closes a bar once per ~1e5 ticks.  The parallel-in-time fixed
 // point of fmk_cusum.hip then needs as many rounds as the state remembers chunks (0.32 s at 1e9 ticks).  This tier uses
@@ -9,26 +9,31 @@
 //     "does it close?"    max(P, s + Q) >= 0    P = max_i (S_i - min_{k<=i} S_k - lam_i),  Q = max_i (S_i - lam_i)
 // over the ticks i that may close (lam_i = max(mult * sigma_i, floor); not inside a same-timestamp block, logic.py:207-211).
 // Blocks compose associatively, so
-//   k_cc_summary : one wave per 2048-tick chunk reduces its ticks to {B, A+, P+, Q+, A-, P-, Q-, U = max |S_i|}
-//                  (coalesced loads, 8 consecutive ticks per lane through LDS, an ordered tree over the lanes): a stream pass;
-//   k_cc_walk    : one wave follows a chain: 64 chunk summaries per step (a scan of the exit maps gives every chunk its
-//                  incoming state, a ballot the first chunk that may close), and only such a chunk is opened: its ticks are
-//                  recomputed from the columns (by the four waves of the workgroup), the walking wave takes 32 of them per
-//                  lane, runs the reference's own operations over them from the state the lane scan hands it, the first
-//                  event is emitted and the side that closed restarts from 0 at the next tick.
-//                  ONLY the side that closed resets (logic.py:214-219), so each side is a chain of its own: workgroup 0
-//                  walks the positive side, workgroup 1 the negative side, k_cc_merge interleaves the two lists.  The sides
-//                  couple in one place -- a positive close hides a negative one on the same tick (`if / elif`) -- so if the
-//                  lists share a tick the joint walk (both sides in one wave, `if / elif` as written) answers instead.
+//   k_cc_summary : one wave per 2048-tick chunk reduces its ticks to {B, A+, P+, Q+, A-, P-, Q-, U = max |S_i|}, per chunk and
+//                  per 512-tick sub-block (8 consecutive ticks per lane by 16-byte loads, the lanes composed in order by a DPP
+//                  scan): a stream pass, 24 B/tick;
+//   k_cc_rate    : how often a side closes even from state 0 in the leading sub-blocks -- the estimate that picks this tier;
+//   k_cc_sync / k_cc_pick / k_cc_ranges : chunk boundaries from which a side's state provably does not depend on the past
+//                  (see k_cc_sync) cut each side's chain into up to 512 segments;
+//   k_cc_walk    : one wave follows a segment: 64 chunk summaries per step (a scan of the exit maps gives every chunk its
+//                  incoming state, a ballot the first chunk that may close); the same step over that chunk's four sub-block
+//                  summaries names the first sub-block that may close, and only that is opened: its ticks are recomputed from
+//                  the columns (by the workgroup's two waves), the walking wave takes 8 of them per lane, runs the reference's
+//                  own operations over them from the state the lane scan hands it, the first event is emitted and the side
+//                  that closed restarts from 0 at the next tick.
+//                  ONLY the side that closed resets (logic.py:214-219), so each side is a chain of its own; k_cc_gather strings
+//                  a side's segments together, k_cc_merge interleaves the two sides.  The sides couple in one place -- a
+//                  positive close hides a negative one on the same tick (`if / elif`) -- so if the lists share a tick the
+//                  joint walk (both sides in one wave, `if / elif` as written, one piece) answers instead.
 // Arithmetic.  The block sums are not the reference's sequential float64 sum from the last reset, so every decision
 // carries a margin: (ticks since that side's reset + 4096) * 2^-50 * (largest magnitude the side's state or a block
 // prefix has reached since) -- 4x the worst-case distance between two float64 evaluation orders of the same recurrence plus
 // a 1-ulp difference in log().  A chunk is skipped only when it stays below the threshold by more than the margin, a close is
-// accepted only when it exceeds it by more than the margin; anything in between ends the tier (status UNCERTAIN) and the
-// caller runs the fixed point of fmk_cusum.hip, which is the reference's loop operation for operation.  Non-finite returns
-// (a price <= 0) are outside the algebra: status BAD, same fallback.  Expected uncertain decisions at 1e9 ticks: ~1e-2.
-// Cost: the summary pass (24 B/tick, 7 ms per 1e9 ticks) + ~6 us per close (profiles/r02_cusum_chain.txt); the caller tries the first 2^22 ticks
-// with a small budget of opened chunks first, so a tape whose thresholds are reached often never pays for this tier.
+// accepted only when it exceeds it by more than the margin; anything in between is settled by cc_replay: the side has been
+// exactly 0.0 since its last reset, so the reference's own sequence of operations from there gives its state bit for bit.
+// Non-finite returns (a price <= 0) are outside the algebra: status BAD, and the caller runs the fixed point of fmk_cusum.hip,
+// which is the reference's loop operation for operation; so do an exhausted budget and a replay longer than 2^21 ticks.
+// Cost: the summary pass (24 B/tick, 5 ms per 1e9 ticks) + ~8 ns per opened sub-block or event (profiles/r02_cusum_chain.txt).
 #include <math.h>
 #include <stdlib.h>
 
