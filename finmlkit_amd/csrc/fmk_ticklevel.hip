@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "fmk_common.h"
+#include "fmk_dpp.h"
 
 // ---------------------------------------------------------------------------------------
 // comp_lagged_returns
@@ -342,17 +343,27 @@ __device__ __forceinline__ EwMap ew_shfl_up(const EwMap &m, int d)
     return r;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ EwMap ew_dpp(const EwMap &m)
+{
+    return EwMap{fmk_dpp<CTRL, ROW_MASK>(1.0, m.a), fmk_dpp<CTRL, ROW_MASK>(1.0, m.a2), fmk_dpp<CTRL, ROW_MASK>(0.0, m.bV),
+                 fmk_dpp<CTRL, ROW_MASK>(0.0, m.bV2), fmk_dpp<CTRL, ROW_MASK>(0.0, m.bSy), fmk_dpp<CTRL, ROW_MASK>(0.0, m.bSyy)};
+}
+
 // inclusive scan of maps across the 256 threads of a block (thread order = tick order);
 // returns the EXCLUSIVE prefix for this thread, *block_total = composition of all threads
 __device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *lds /*[4]*/, EwMap *block_total)
 {
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
     EwMap inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        EwMap o = ew_shfl_up(inc, d);
-        if (lane >= d) inc = ew_compose(o, inc);
-    }
+    // ordered scan over the lanes on the DPP path (the order of fmk_dpp_iscan; lanes without a source compose with the identity,
+    // which is exact).  The shuffle version cost 84 ds_bpermute per 512 ticks.
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_SHR(1), 0xF>(inc), inc);
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_SHR(2), 0xF>(inc), inc);
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_SHR(4), 0xF>(inc), inc);
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_SHR(8), 0xF>(inc), inc);
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_BCAST15, 0xA>(inc), inc);
+    inc = ew_compose(ew_dpp<FMK_DPP_ROW_BCAST31, 0xC>(inc), inc);
     if (lane == 63) lds[w] = inc;
     __syncthreads();
     EwMap pre = ew_identity();
