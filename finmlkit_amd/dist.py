@@ -60,6 +60,27 @@ def plan_edges(first_ts: Sequence[int], n_edges: int, e0: int, d: int) -> List[E
     return plans
 
 
+def sharded_tick_bar_index(offset: int, n_local: int, threshold: int):
+    """Tick bars on a shard ("trivially, closed form in the global tick index", no communication): the
+    GLOBAL close indices of `_tick_bar_indexer` (finmlkit/bar/logic.py:54-84) that fall into the ticks [offset, offset + n_local)
+    of the stream, as an int64 array; the opening entry 0 belongs to the shard that holds tick 0.  The reference counts the
+    first tick as 1 and resets to 0 at a close, so closes sit at every global index g >= 1 with (g + 1) % threshold == 0
+    (every g >= 1 when threshold <= 1).  Concatenated over the shards in order this is the un-sharded result."""
+    import numpy as np
+    offset, n_local, threshold = int(offset), int(n_local), int(threshold)
+    if n_local <= 0:                                               # an empty shard owns nothing, not even the opening entry
+        return np.zeros(0, np.int64)
+    lo, hi = max(offset, 1), offset + n_local                      # candidate closes: lo <= g < hi
+    if threshold <= 1:
+        closes = np.arange(lo, hi, dtype=np.int64)
+    else:
+        first = ((lo + 1 + threshold - 1) // threshold) * threshold - 1       # smallest g >= lo with (g + 1) % threshold == 0
+        closes = np.arange(first, hi, threshold, dtype=np.int64)
+    if offset == 0:
+        closes = np.concatenate([np.zeros(1, np.int64), closes])
+    return closes
+
+
 class Comm:
     """One rank's handle on the node's ranks: `fmk_comm_*` of libfmk_hip.so (csrc/fmk_comm.hip) -- librccl's
     ncclSend/ncclRecv on the communicator's own HIP stream (transport "rccl"), or host-staged through the rendezvous

@@ -126,3 +126,17 @@ def test_self_loop_and_errors(tmp_path):
         Comm(None, 3, 2, str(tmp_path / "bad"), "host")
     with pytest.raises(ValueError, match="needs a context"):
         Comm(None, 0, 1, str(tmp_path / "bad2"), "rccl")
+
+
+@pytest.mark.parametrize("n,thr", [(1000, 7), (1000, 1), (1000, 0), (1, 5), (64, 64), (65, 64), (10_000, 2), (999, 1000), (5, 2)])
+def test_sharded_tick_bars_concatenate_to_the_reference(orc, n, thr):
+    """tick bars shard without communication -- the closes of a shard are a closed form of its global tick
+    range; concatenated they are `_tick_bar_indexer`'s (logic.py:54-84), whatever the cut points."""
+    from finmlkit_amd.dist import sharded_tick_bar_index
+    want = orc._tick_bar_indexer(np.arange(n, dtype=np.int64), thr)
+    rng = np.random.default_rng(n * 31 + thr)
+    for world in (1, 2, 3, 8):
+        cuts = np.sort(rng.integers(0, n + 1, size=world - 1)) if world > 1 else np.zeros(0, np.int64)
+        edges = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+        got = np.concatenate([sharded_tick_bar_index(edges[r], edges[r + 1] - edges[r], thr) for r in range(world)])
+        np.testing.assert_array_equal(got, want, err_msg=f"world {world} cuts {cuts}")
