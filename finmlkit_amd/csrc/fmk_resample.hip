@@ -121,8 +121,23 @@ __global__ __launch_bounds__(256) void k_resample(const int64_t *__restrict__ se
         }
         const double cutoff = (double)tr * 0.5;                  // cum_w[-1] * 0.5 (integers in float64: exact)
         uint64_t ans = kmin;
-        if (e > s && cutoff > 0.0) {
-            const bool small = e - s <= 64;
+        if (e > s && e - s <= 64 && cutoff > 0.0) {
+            // the group fits the wave (one row per lane): W(size <= my size) for every lane at once -- a wave-uniform loop over
+            // the rows, no cross-lane reduction inside -- and the answer is the smallest key whose W reaches the cutoff.  (The
+            // bisection below costs 64 rounds of a masked wave sum: 5e7 one-second rows -> 1-minute bars 5.2 -> 3.0 ms.)
+            const int cnt = (int)(e - s);
+            int64_t wle = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const uint64_t kj = (uint64_t)fmk_readlane((int64_t)my_key, j);
+                const int64_t wj = fmk_readlane(my_w, j);
+                wle += kj <= my_key ? wj : 0;
+            }
+            uint64_t cand = (lane < cnt && (double)wle >= cutoff) ? my_key : ~0ULL;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const uint64_t b = __shfl_xor(cand, o, 64); cand = b < cand ? b : cand; }
+            ans = cand;
+        } else if (e > s && cutoff > 0.0) {
+            const bool small = false;
             uint64_t lo_k = 0, hi_k = ~0ULL;
             while (lo_k < hi_k) {
                 const uint64_t mid = lo_k + ((hi_k - lo_k) >> 1);
