@@ -25,10 +25,11 @@ __device__ __forceinline__ bool mg_coarse_head(const int64_t *ts, const uint8_t 
     return ibm && (ibm[i] != 0) != (ibm[i - 1] != 0);
 }
 
-// flags[i] = 1 iff trade i starts a merged trade
+// flags[i] = 1 iff trade i starts a merged trade (one byte per trade; every entry is written exactly once: a coarse head by its
+// own thread, its followers by that thread too)
 __global__ __launch_bounds__(256) void k_merge_flags(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                      const uint8_t *__restrict__ ibm, int64_t n,
-                                                     int64_t *__restrict__ flags)
+                                                     uint8_t *__restrict__ flags)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !mg_coarse_head(ts, ibm, i)) return;
@@ -41,23 +42,71 @@ __global__ __launch_bounds__(256) void k_merge_flags(const int64_t *__restrict__
     }
 }
 
-// pos = exclusive scan of the flags (pos[n] = number of merged trades)
+// Output slots.  The first version kept the flags as int64 and ran the generic device scan over them: 8 B/tick written, 24 B/tick
+// through the scan, 16 B/tick read back by the emit pass -- more than the 42 B/tick of columns in and out (17.7 ms per 1e9
+// ticks).  Now: one byte per flag, heads counted per 2048-tick tile (k_merge_count), the tile counts scanned by one block
+// (fmk_scan.h), and the emit pass ranks the heads inside its tile itself.
+#define MG_ITEMS 8
+#define MG_TILE (256 * MG_ITEMS)
+__device__ __forceinline__ uint64_t mg_load_flags(const uint8_t *__restrict__ flags, int64_t i0, int64_t n)
+{
+    if (i0 + MG_ITEMS <= n) return *(const uint64_t *)(flags + i0);          // (the flag array is 256-byte aligned, i0 a multiple of 8)
+    uint64_t v = 0;
+    for (int k = 0; k < MG_ITEMS; ++k)
+        if (i0 + k < n) v |= (uint64_t)flags[i0 + k] << (8 * k);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_merge_count(const uint8_t *__restrict__ flags, int64_t n, int64_t *__restrict__ tile_cnt)
+{
+    __shared__ int sw[4];
+    const int64_t i0 = (int64_t)blockIdx.x * MG_TILE + (int64_t)threadIdx.x * MG_ITEMS;
+    int c = i0 < n ? __builtin_popcountll(mg_load_flags(flags, i0, n)) : 0;      // flags are 0 / 1 bytes
+    c = fmk_wave_sum(c);
+    if (fmk_lane() == 0) sw[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+// tile_off = exclusive scan of the tile counts.  Thread t takes the tile's trades t, t + 256, ...: coalesced column loads and
+// (nearly) coalesced stores; a head's slot = tile offset + heads in the rows before + heads before it in its row (ballots).
+// (With eight CONSECUTIVE trades per thread the column loads sat 64 bytes apart across the lanes: 45 ms per 1e9 ticks.)
 __global__ __launch_bounds__(256) void k_merge_emit(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                     const float *__restrict__ amount, const uint8_t *__restrict__ ibm,
-                                                    int64_t n, const int64_t *__restrict__ pos,
+                                                    int64_t n, const uint8_t *__restrict__ flags,
+                                                    const int64_t *__restrict__ tile_off,
                                                     int64_t *__restrict__ o_ts, double *__restrict__ o_price,
                                                     float *__restrict__ o_amount, int8_t *__restrict__ o_side)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t p = pos[i];
-    if (pos[i + 1] == p) return;                                  // not a head
-    float acc = amount[i];
-    for (int64_t j = i + 1; j < n && pos[j + 1] == pos[j]; ++j) acc += amount[j];     // utils.py:307 (float32 +=)
-    o_ts[p] = ts[i];
-    o_price[p] = price[i];
-    o_amount[p] = acc;
-    if (o_side) o_side[p] = ibm[i] ? -1 : 1;                      // utils.py:296, 316
+    __shared__ int sw[MG_ITEMS][4];
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * MG_TILE;
+    bool head[MG_ITEMS];
+    int before[MG_ITEMS];                                         // heads before mine in my wave's 64 trades of the row
+#pragma unroll
+    for (int k = 0; k < MG_ITEMS; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        head[k] = i < n && flags[i] != 0;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(head[k]);
+        before[k] = __builtin_popcountll(b & ((1ULL << lane) - 1));
+        if (lane == 0) sw[k][w] = __builtin_popcountll(b);
+    }
+    __syncthreads();
+    int64_t row_off = tile_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < MG_ITEMS; ++k) {
+        int in_row = 0;
+        for (int q = 0; q < w; ++q) in_row += sw[k][q];
+        if (head[k]) {
+            const int64_t i = base + k * 256 + threadIdx.x, p = row_off + in_row + before[k];
+            float acc = amount[i];
+            for (int64_t j = i + 1; j < n && flags[j] == 0; ++j) acc += amount[j];     // utils.py:307 (float32 +=)
+            o_ts[p] = ts[i];
+            o_price[p] = price[i];
+            o_amount[p] = acc;
+            if (o_side) o_side[p] = ibm[i] ? -1 : 1;              // utils.py:296, 316
+        }
+        row_off += sw[k][0] + sw[k][1] + sw[k][2] + sw[k][3];
+    }
 }
 
 extern "C" int fmk_merge_split_trades_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price,
@@ -67,16 +116,20 @@ extern "C" int fmk_merge_split_trades_dev(fmk_ctx *ctx, const int64_t *d_ts, con
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "merge_split_trades: empty input");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    // scratch: [scan tile sums | pos[n+1]]
-    const size_t scan_bytes = (((size_t)fmk_ceil_div(n, FMK_SCAN_TILE) + 1) * 8 + 255) & ~(size_t)255;
+    // scratch: [tile offsets + total | flags[n]]
+    const int64_t tiles = fmk_ceil_div(n, MG_TILE);
+    const size_t off_bytes = (((size_t)tiles + 1) * 8 + 255) & ~(size_t)255;
     void *scr;
-    FMK_TRY(fmk_scratch(ctx, scan_bytes + (size_t)(n + 1) * 8, &scr));
-    int64_t *pos = (int64_t *)((char *)scr + scan_bytes);
-    const unsigned blocks = (unsigned)fmk_ceil_div(n, 256);
-    k_merge_flags<<<blocks, 256, 0, ctx->stream>>>(d_ts, d_price, d_is_buyer_maker, n, pos);
+    FMK_TRY(fmk_scratch(ctx, off_bytes + (size_t)n + 256, &scr));
+    int64_t *tile_off = (int64_t *)scr;
+    uint8_t *flags = (uint8_t *)scr + off_bytes;
+    k_merge_flags<<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_ts, d_price, d_is_buyer_maker, n, flags);
     FMK_LAUNCH_CHECK(ctx);
-    FMK_TRY(fmk_exclusive_scan_i64(ctx, pos, pos, n, true));
-    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], pos + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    k_merge_count<<<(unsigned)tiles, 256, 0, ctx->stream>>>(flags, n, tile_off);
+    FMK_LAUNCH_CHECK(ctx);
+    k_scan_tile_scan<<<1, 1024, 0, ctx->stream>>>(tile_off, tiles, tile_off + tiles);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], tile_off + tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t m = ctx->h_mail[0];
     if (n_merged) *n_merged = m;
@@ -86,8 +139,8 @@ extern "C" int fmk_merge_split_trades_dev(fmk_ctx *ctx, const int64_t *d_ts, con
                              (long long)capacity);
     if (d_out_side && !d_is_buyer_maker)
         return fmk_set_error(ctx, FMK_E_ARG, "merge_split_trades: side output needs is_buyer_maker");
-    k_merge_emit<<<blocks, 256, 0, ctx->stream>>>(d_ts, d_price, d_amount, d_is_buyer_maker, n, pos, d_out_ts, d_out_price,
-                                                 d_out_amount, d_out_side);
+    k_merge_emit<<<(unsigned)tiles, 256, 0, ctx->stream>>>(d_ts, d_price, d_amount, d_is_buyer_maker, n, flags, tile_off, d_out_ts,
+                                                          d_out_price, d_out_amount, d_out_side);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
