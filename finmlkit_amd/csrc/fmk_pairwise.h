@@ -17,11 +17,15 @@ __device__ __forceinline__ auto fmk_pw_leaf(F load, int off, int n, int lane) ->
         return r;
     }
     const int nm = n - (n & 7);
-    T r = 0;
-    if (lane < 8) {
-        r = load(off + lane);
-        for (int i = 8 + lane; i < nm; i += 8) r += load(off + i);
-    }
+    // The eight accumulators r_i = ((x_i + x_{8+i}) + x_{16+i}) + ... live in lanes 0..7.  All 64 lanes fetch (and transform)
+    // the leaf's <= 128 elements with two coalesced loads; the chains then take their terms from the other lanes' registers in
+    // NumPy's order.  (A first version let lanes 0..7 load their 16 elements one after the other: sixteen dependent global
+    // loads per leaf, 24.6 ms per 1e9 ticks for comp_bar_trade_size_features on 1 200-tick bars.)
+    const T v0 = lane < nm ? load(off + lane) : (T)0;
+    const T v1 = 64 + lane < nm ? load(off + 64 + lane) : (T)0;
+    const int i8 = lane & 7;
+    T r = __shfl(v0, i8, 64);
+    for (int k = 1; 8 * k < nm; ++k) r += k < 8 ? __shfl(v0, 8 * k + i8, 64) : __shfl(v1, 8 * (k - 8) + i8, 64);
     T t = r + __shfl_down(r, 1, 64);         // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
     T u = t + __shfl_down(t, 2, 64);         // lanes 0,4
     T res = __shfl(u, 0, 64) + __shfl(u, 4, 64);
@@ -79,3 +83,89 @@ __device__ __forceinline__ auto fmk_pairwise(F load, int n, int lane, int *stk) 
 template <class F>
 __device__ __forceinline__ float fmk_pairwise_f32(F load, int n, int lane, int *stk) { return fmk_pairwise(load, n, lane, stk); }
 
+
+// The same sum without walking the tree node by node.  fmk_pairwise visits the nodes one after the other -- every visit a few
+// dependent LDS round trips, every leaf waiting for its own loads: 16 leaves + 15 inner nodes for 1 200 elements cost ~50 000
+// cycles, 6 ms per 1e9 ticks of 1 200-tick bars and sum.  The tree's shape depends on n alone, so here
+//   * the list of leaves is built level by level: lane l owns entry l = (off, len); in each of six rounds the entries longer than
+//     128 split into (off, n2) and (off + n2, len - n2), n2 = len / 2 rounded down to a multiple of 8, and a ballot gives every
+//     entry its new place (order preserved); the six ballots are kept;
+//   * groups of eight lanes take a leaf each, eight leaves at a time: lane i of a group is NumPy's accumulator r_i, adds its
+//     elements 8k + i in order, the group folds ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) and adds the tail;
+//   * the rounds are undone in reverse: an entry that had split becomes left + right (two shuffles), others keep their value.
+// Bit-identical by construction: every addition has the operands and the order of the recursion.  128 < n <= FMK_PW_PAR_MAX_N
+// (leaves hold at least 64 elements, so at most 64 entries); other sizes go to fmk_pairwise.  stk: FMK_PW_PAR_STK ints of LDS.
+#define FMK_PW_PAR_MAX_N 4096
+#define FMK_PW_PAR_ROUNDS 6                                   // 4096 -> 128 takes five
+#define FMK_PW_PAR_STK (80 + 128 + 128)
+template <class F>
+__device__ __forceinline__ auto fmk_pairwise_par(F load, int n, int lane, int *stk) -> decltype(load(0))
+{
+    typedef decltype(load(0)) T;
+    if (n <= 128 || n > FMK_PW_PAR_MAX_N) return fmk_pairwise(load, n, lane, stk);
+    int *l_off = stk + 80, *l_len = stk + 144;
+    T *l_sum = (T *)(stk + 208);
+    // ---- the leaves, level by level
+    int off = 0, len = lane == 0 ? n : 0;                     // len == 0: no entry in this lane
+    unsigned long long split_mask[FMK_PW_PAR_ROUNDS];
+    const unsigned long long lt = (1ULL << lane) - 1;
+#pragma unroll
+    for (int d = 0; d < FMK_PW_PAR_ROUNDS; ++d) {
+        const bool split = len > 128;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(split);
+        split_mask[d] = m;
+        if (m == 0) continue;                                 // (wave-uniform)
+        const int pos = lane + __builtin_popcountll(m & lt);
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        __builtin_amdgcn_wave_barrier();
+        l_len[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (len > 0) {
+            l_off[pos] = off; l_len[pos] = split ? n2 : len;
+            if (split) { l_off[pos + 1] = off + n2; l_len[pos + 1] = len - n2; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        off = l_off[lane]; len = l_len[lane];
+    }
+    const int n_leaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(len > 0));
+    __builtin_amdgcn_wave_barrier();
+    l_off[lane] = off; l_len[lane] = len;
+    __builtin_amdgcn_wave_barrier();
+    // ---- the leaf sums, eight leaves per round
+    const int grp = lane >> 3, i8 = lane & 7;
+    for (int l0 = 0; l0 < n_leaf; l0 += 8) {
+        const int l = l0 + grp;
+        const bool on = l < n_leaf;
+        const int lo = on ? l_off[l] : 0, ll = on ? l_len[l] : 0;
+        const int nm = ll - (ll & 7);                        // >= 64 for every leaf of a tree with n > 128
+        T x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = 8 * k < nm ? load(lo + 8 * k + i8) : (T)0;
+        T r = x[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (8 * k < nm) r += x[k];
+        T t = r + __shfl_down(r, 1, 64);                      // lanes 0,2,4,6 of the group: r0+r1, r2+r3, r4+r5, r6+r7
+        T u = t + __shfl_down(t, 2, 64);                      // lanes 0,4
+        T res = __shfl(u, grp * 8, 64) + __shfl(u, grp * 8 + 4, 64);
+        for (int q = nm; q < ll; ++q) res += load(lo + q);
+        if (on && i8 == 0) l_sum[l] = res;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- back up the levels: lane l holds the value of entry l
+    T val = lane < n_leaf ? l_sum[lane] : (T)0;
+#pragma unroll
+    for (int d = FMK_PW_PAR_ROUNDS - 1; d >= 0; --d) {
+        const unsigned long long m = split_mask[d];
+        if (m == 0) continue;
+        const int pos = lane + __builtin_popcountll(m & lt);
+        const T a = __shfl(val, pos & 63, 64), b = __shfl(val, (pos + 1) & 63, 64);
+        val = ((m >> lane) & 1) ? a + b : a;                  // left + right, as the recursion returns it
+    }
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), 0));
+    else {
+        const int64_t b = __builtin_bit_cast(int64_t, val);
+        return __builtin_bit_cast(T, fmk_readlane(b, 0));
+    }
+}
