@@ -196,6 +196,13 @@ def other_configs(trades, ctx, args):
         clock1, ci1 = trades.time_bar_index(1.0)
         out["directional_1s_bars_ms"] = timed(lambda: trades.bar_directional(ci1))
         del clock1, ci1
+        # comp_bar_trade_size_features on the 1-minute bars, theta = each bar's median trade size (what the kits pass)
+        o60 = trades.bar_ohlcv(ci)
+        keys4 = [DeviceArray(ctx, int(ci.n) - 1, np.float32) for _ in range(4)]
+        out["trade_size_features_ms"] = timed(lambda: ctx.call(
+            "fmk_comp_bar_trade_size_dev", trades.amount.p, C.c_int(trades.amount_is_f64), c_i64(n), o60["median_trade_size"].p,
+            ci.p, c_i64(ci.n), C.c_double(5.0), *[k.p for k in keys4]))
+        del o60, keys4
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only
