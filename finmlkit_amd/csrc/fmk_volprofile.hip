@@ -29,35 +29,32 @@ __device__ __forceinline__ int64_t vp_upper(const int64_t *a, int64_t n, int64_t
     return lo;
 }
 
-// window of bar i and its level range; uniform results
-__device__ __forceinline__ void vp_window(const int64_t *ts, const double *highs, const double *lows, int64_t nb, int64_t i,
-                                          int64_t window_ns, double tick, int lane, int64_t &s, int64_t &e,
-                                          int64_t &minl, int64_t &maxl)
+// The windows of all bars, ONE LANE per bar: start / end by bisection of the bar timestamps, level range from the window's lows
+// and highs -> win[4 * (i - first)] = {s, e, minl, maxl}, and the widest window (sizes the histograms).  The first version did
+// this with one WAVE per bar (20 + 20 dependent loads of the two bisections with 63 lanes idle) and then once more in the main
+// kernel: 12.4 ms per 8.3e5 bars with 30-bar windows.
+__global__ __launch_bounds__(256) void k_vp_windows(const int64_t *__restrict__ ts, const double *__restrict__ highs,
+                                                    const double *__restrict__ lows, int64_t nb, int64_t first,
+                                                    int64_t window_ns, double tick, int64_t *__restrict__ win,
+                                                    unsigned long long *max_levels)
 {
-    const int64_t end_ts = ts[i];
-    s = vp_lower(ts, nb, end_ts - window_ns);
-    e = vp_upper(ts, nb, end_ts);
-    if (s == e) s = s - 1 > 0 ? s - 1 : 0;                       // volume.py:164-166
-    double mn = INFINITY, mx = -INFINITY;
-    for (int64_t t = s + lane; t < e; t += 64) { mn = fmin(mn, lows[t]); mx = fmax(mx, highs[t]); }
-    mn = fmk_dpp_reduce(mn, (double)INFINITY, FmkOpMin());
-    mx = fmk_dpp_reduce(mx, (double)-INFINITY, FmkOpMax());
-    minl = (int64_t)rint(mn / tick);                             // int(round(x / price_tick)), half-even
-    maxl = (int64_t)rint(mx / tick);
-}
-
-__global__ __launch_bounds__(256) void k_vp_max_levels(const int64_t *__restrict__ ts, const double *__restrict__ highs,
-                                                       const double *__restrict__ lows, int64_t nb, int64_t first,
-                                                       int64_t window_ns, double tick, unsigned long long *max_levels)
-{
-    const int lane = fmk_lane();
-    const int64_t i = first + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nb) return;
-    int64_t s, e, minl, maxl;
-    vp_window(ts, highs, lows, nb, i, window_ns, tick, lane, s, e, minl, maxl);
-    const int64_t L = maxl - minl + 1;
+    const int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t L = 0;
+    if (i < nb) {
+        const int64_t end_ts = ts[i];
+        int64_t s = vp_lower(ts, nb, end_ts - window_ns);
+        const int64_t e = vp_upper(ts, nb, end_ts);
+        if (s == e) s = s - 1 > 0 ? s - 1 : 0;                   // volume.py:164-166
+        double mn = INFINITY, mx = -INFINITY;
+        for (int64_t t = s; t < e; ++t) { mn = fmin(mn, lows[t]); mx = fmax(mx, highs[t]); }
+        const int64_t minl = (int64_t)rint(mn / tick), maxl = (int64_t)rint(mx / tick);   // int(round(x / price_tick)), half-even
+        int64_t *w = win + 4 * (i - first);
+        w[0] = s; w[1] = e; w[2] = minl; w[3] = maxl;
+        L = maxl - minl + 1;
+    }
     // attempted only when it would raise the value: one same-address atomic per BAR serialises at ~10 ns each (8 ms for 8e5 bars)
-    if (lane == 0 && L > 0 && (unsigned long long)L > __atomic_load_n(max_levels, __ATOMIC_RELAXED))
+    L = fmk_dpp_reduce(L, (int64_t)0, FmkOpMax());
+    if (fmk_lane() == 0 && L > 0 && (unsigned long long)L > __atomic_load_n(max_levels, __ATOMIC_RELAXED))
         atomicMax(max_levels, (unsigned long long)L);
 }
 
@@ -75,7 +72,7 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
                                                         double tick, double va_pct, int cap, int32_t *__restrict__ poc,
                                                         int32_t *__restrict__ hva, int32_t *__restrict__ lva,
                                                         float *__restrict__ pct, unsigned int *status,
-                                                        unsigned char *gscratch)
+                                                        unsigned char *gscratch, const int64_t *__restrict__ win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
@@ -90,8 +87,8 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
     int *stk = (int *)(as + (cap + 8));                           // 64 ints (pairwise-sum stack)
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     for (int64_t i = first + (int64_t)blockIdx.x * wpb + wib; i < nb; i += nwaves) {
-        int64_t s, e, minl, maxl;
-        vp_window(ts, highs, lows, nb, i, window_ns, tick, lane, s, e, minl, maxl);
+        const int64_t *wi = win + 4 * (i - first);
+        const int64_t s = fmk_uniform(wi[0]), e = fmk_uniform(wi[1]), minl = fmk_uniform(wi[2]), maxl = fmk_uniform(wi[3]);
         const int64_t Ll = maxl - minl + 1;
         if (Ll < 1 || Ll > cap) { if (lane == 0) atomicOr(status, VP_BAD_LEVEL); continue; }
         const int L = (int)Ll;
@@ -99,15 +96,38 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
         __builtin_amdgcn_wave_barrier();
         // ---- aggregate_footprint: bars in order, lanes across the (distinct) levels of a bar
         bool bad = false;
-        for (int64_t t = s; t < e; ++t) {
-            const int64_t r0 = fmk_uniform(off[t]), r1 = fmk_uniform(off[t + 1]);
-            for (int64_t r = r0 + lane; r < r1; r += 64) {
-                const int64_t idx = (int64_t)levels[r] - minl;
-                if (idx < 0 || idx >= L) { bad = true; continue; }
-                ab[idx] += buy[r];                                // float32 += float32, one add per level per bar
-                as[idx] += sell[r];
+        // (the CSR offsets of up to 63 bars by one coalesced load, a bar's first 64 levels fetched while the previous bar is added)
+        for (int64_t t0 = s; t0 < e; t0 += 63) {
+            const int nbar = (int)(e - t0 < 63 ? e - t0 : 63);
+            const int64_t my_off = lane <= nbar ? off[t0 + lane] : 0;
+            int64_t r0 = fmk_readlane(my_off, 0), r1 = fmk_readlane(my_off, 1);
+            int lv = 0;
+            float bv = 0.f, sv = 0.f;
+            bool has = r0 + lane < r1;
+            if (has) { lv = levels[r0 + lane]; bv = buy[r0 + lane]; sv = sell[r0 + lane]; }
+            for (int q = 0; q < nbar; ++q) {
+                const int64_t c0 = r0, c1 = r1;
+                const int clv = lv;
+                const float cbv = bv, csv = sv;
+                const bool chas = has;
+                if (q + 1 < nbar) {                               // the next bar's first rows, in flight during the adds below
+                    r0 = r1; r1 = fmk_readlane(my_off, q + 2);
+                    has = r0 + lane < r1;
+                    if (has) { lv = levels[r0 + lane]; bv = buy[r0 + lane]; sv = sell[r0 + lane]; }
+                }
+                if (chas) {
+                    const int64_t idx = (int64_t)clv - minl;
+                    if (idx < 0 || idx >= L) bad = true;
+                    else { ab[idx] += cbv; as[idx] += csv; }      // float32 += float32, one add per level per bar
+                }
+                for (int64_t r = c0 + 64 + lane; r < c1; r += 64) {
+                    const int64_t idx = (int64_t)levels[r] - minl;
+                    if (idx < 0 || idx >= L) { bad = true; continue; }
+                    ab[idx] += buy[r];
+                    as[idx] += sell[r];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         if (__ballot(bad) != 0 && lane == 0) atomicOr(status, VP_BAD_LEVEL);
         for (int k = lane; k < L; k += 64) ab[k] = ab[k] + as[k];  // total_volumes = buy + sell (float32)
@@ -222,8 +242,12 @@ extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar
     unsigned int *d_status = (unsigned int *)(d_max + 1);
     FMK_HIP(ctx, hipMemsetAsync(d_max, 0, 16, ctx->stream));
     const int64_t work = n_bars - first_bar;
-    k_vp_max_levels<<<(unsigned)fmk_ceil_div(work, 4), 256, 0, ctx->stream>>>(d_bar_ts, d_highs, d_lows, n_bars, first_bar,
-                                                                             window_ns, price_tick, d_max);
+    void *win_v = nullptr;
+    FMK_TRY(fmk_alloc(ctx, (size_t)work * 32, &win_v));
+    int64_t *d_win = (int64_t *)win_v;
+    struct WinGuard { fmk_ctx *c; void *p; ~WinGuard() { (void)fmk_free(c, p); } } win_guard{ctx, win_v};
+    k_vp_windows<<<(unsigned)fmk_ceil_div(work, 256), 256, 0, ctx->stream>>>(d_bar_ts, d_highs, d_lows, n_bars, first_bar,
+                                                                            window_ns, price_tick, d_win, d_max);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -256,11 +280,11 @@ extern "C" int fmk_volume_profile_rolling_dev(fmk_ctx *ctx, const int64_t *d_bar
     if (gscratch)
         k_volume_profile<true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(
             d_bar_ts, d_highs, d_lows, d_level_offsets, d_price_levels, d_buy_volumes, d_sell_volumes, n_bars, first_bar,
-            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, gscratch);
+            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, gscratch, d_win);
     else
         k_volume_profile<false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(
             d_bar_ts, d_highs, d_lows, d_level_offsets, d_price_levels, d_buy_volumes, d_sell_volumes, n_bars, first_bar,
-            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, nullptr);
+            window_ns, n_bins, price_tick, va_pct, cap, d_poc, d_hva, d_lva, d_pct, d_status, nullptr, d_win);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
