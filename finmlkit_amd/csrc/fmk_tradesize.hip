@@ -19,12 +19,25 @@
 
 template <bool AF64, int NREG>
 __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t start, int64_t cnt, int lane,
-                                                  typename MedKey<AF64>::K *buf)
+                                                  typename MedKey<AF64>::K *buf, double thr = 0.0, double *block_out = nullptr)
 {
     typedef MedKey<AF64> MK;
     MedBar<AF64, NREG, false> bar;
     bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
     bar.load_all();
+    if constexpr (NREG > 0 && !AF64) {
+        // float32 bars held in registers: the block volume (amounts above the threshold; a float64 sum of float32 values is
+        // exact in any order) comes from the same registers -- no separate pass over the bar (2.8 of 9.4 ms per 1e9 ticks)
+        if (block_out) {
+            double bl = 0.0;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const double a = bar.key[r] != MK::MAXK ? MK::value(bar.key[r]) : 0.0;
+                bl += a > thr ? a : 0.0;
+            }
+            *block_out = fmk_wave_sum(bl);
+        }
+    }
     // NumPy 'linear' method: virtual index (n-1)*q IN THE ARRAY'S DTYPE, neighbours floor and floor+1 (clipped), _lerp
     const double vidx = AF64 ? (double)(cnt - 1) * 0.95 : (double)((float)(cnt - 1) * (95.0f / 100.0f));
     const double fl = floor(vidx);
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
                     }
                 }
                 sum = fmk_wave_sum(sum);
-            } else {
+            } else if (!(cnt <= 64 * 32 && cnt <= FMK_PW_MAX_N)) {      // (else: `sum` is the pairwise total, `block` comes with the percentile)
                 for (int64_t j = lane; j < cnt; j += 64) {
                     const double a = fmk_amt<AF64>(amount, start + j);
                     sum += a;
@@ -138,11 +151,12 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             mean_rel = (float)log1p(mean / thr);
             const int nreg = (int)((cnt + 63) >> 6);
             double p95;
+            double *bo = (!AF64 && np_rule) ? &block : nullptr;
             if (cnt > 64 * 32) p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
-            else if (nreg <= 4) p95 = ts_percentile95<AF64, 4>(amount, start, cnt, lane, buf);
-            else if (nreg <= 12) p95 = ts_percentile95<AF64, 12>(amount, start, cnt, lane, buf);
-            else if (nreg <= 20) p95 = ts_percentile95<AF64, 20>(amount, start, cnt, lane, buf);
-            else if constexpr (!AF64) p95 = ts_percentile95<AF64, 32>(amount, start, cnt, lane, buf);
+            else if (nreg <= 4) p95 = ts_percentile95<AF64, 4>(amount, start, cnt, lane, buf, thr, bo);
+            else if (nreg <= 12) p95 = ts_percentile95<AF64, 12>(amount, start, cnt, lane, buf, thr, bo);
+            else if (nreg <= 20) p95 = ts_percentile95<AF64, 20>(amount, start, cnt, lane, buf, thr, bo);
+            else if constexpr (!AF64) p95 = ts_percentile95<AF64, 32>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 24) p95 = ts_percentile95<AF64, 24>(amount, start, cnt, lane, buf);
             else p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
             p95_rel = (float)log1p(p95 / thr);
