@@ -19,6 +19,97 @@
 // Traffic: amount column once (4 or 8 B/tick) + 8 B/bar.
 #include "fmk_median.h"
 
+// Bars beyond the register classes (more than 2048 float32 / 1536 float64 ticks: 2-minute bars and up on the bench tape).  The first
+// version ran the same value-range bisection with ONE wave re-reading its bar at every step: 20 ms per 1e9 ticks at 2 400-tick
+// bars, 0.31 s at hourly bars, 13.7 s at daily bars (580 waves on the whole chip).  Now a WORKGROUP takes such a bar and
+// selects the two middle ranks by radix: BITS / 8 passes over the bar, 256-bin histograms of the current digit in LDS for the
+// keys that share the prefix found so far (one histogram while both ranks still share it), a block scan picks the digit.
+// The bars are found like in k_bar_median's leftover pass: 64 close indices per coalesced load.
+#define ML_MIN(F64) ((F64) ? 64 * 24 : 64 * 32)
+template <bool AF64>
+__global__ __launch_bounds__(256) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
+                                                         int64_t nb, const int *__restrict__ go, double *__restrict__ o_median)
+{
+    if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
+    typedef MedKey<AF64> MK;
+    typedef typename MK::K K;
+    constexpr int D = MK::BITS / 8;
+    __shared__ unsigned hist[2][256];
+    __shared__ K s_prefix[2];
+    __shared__ int64_t s_rank[2], s_se[64][2];
+    __shared__ unsigned s_wsum[2][4];
+    __shared__ int s_nan, s_nlong;
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    const int64_t ngroups = (nb + 63) >> 6;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        if (w == 0) {                                    // the group's long bars -> s_se[0 .. s_nlong)
+            const int64_t bl = g * 64 + lane;
+            int64_t s_l = 0, e_l = 0;
+            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
+            const bool is_long = bl < nb && e_l - s_l > ML_MIN(AF64);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(is_long);
+            if (is_long) {
+                const int pos = __builtin_popcountll(m & ((1ULL << lane) - 1));
+                s_se[pos][0] = bl; s_se[pos][1] = s_l;
+            }
+            if (lane == 0) s_nlong = __builtin_popcountll(m);
+        }
+        __syncthreads();
+        const int nlong = s_nlong;
+        for (int q = 0; q < nlong; ++q) {
+            const int64_t b = s_se[q][0], s = s_se[q][1], e = ci[b + 1];
+            const int64_t cnt = e - s, start = s + 1;
+            if (tid == 0) { s_prefix[0] = 0; s_prefix[1] = 0; s_rank[0] = (cnt - 1) >> 1; s_rank[1] = cnt >> 1; s_nan = 0; }
+            bool nan = false;
+#pragma unroll 1
+            for (int p = 0; p < D; ++p) {
+                hist[0][tid] = 0; hist[1][tid] = 0;
+                __syncthreads();
+                const K pre0 = s_prefix[0], pre1 = s_prefix[1];
+                const int64_t rk0 = s_rank[0], rk1 = s_rank[1];
+                const bool same = pre0 == pre1;
+                const int shift = MK::BITS - 8 * (p + 1);
+                for (int64_t j = tid; j < cnt; j += 256) {
+                    const K k = MK::load(amount, start + j);
+                    if (p == 0) nan |= k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF;
+                    const K hi = p == 0 ? (K)0 : (K)(k >> (shift + 8));
+                    const unsigned d = (unsigned)((k >> shift) & 255);
+                    if (hi == pre0) atomicAdd(&hist[0][d], 1u);
+                    if (!same && hi == pre1) atomicAdd(&hist[1][d], 1u);
+                }
+                __syncthreads();
+                // bin `tid` of each histogram: inclusive prefix over the 256 bins, then the bin that holds the rank
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned h = hist[same ? 0 : t][tid];
+                    unsigned inc = h;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+                    if (lane == 63) s_wsum[t][w] = inc;
+                    __syncthreads();
+                    unsigned base = 0;
+                    for (int k2 = 0; k2 < w; ++k2) base += s_wsum[t][k2];
+                    const int64_t cum = (int64_t)base + inc, rk = t == 0 ? rk0 : rk1;
+                    if (cum > rk && cum - h <= rk) {     // exactly one bin
+                        s_prefix[t] = (K)(((t == 0 ? pre0 : pre1) << 8) | (K)tid);
+                        s_rank[t] = rk - (cum - h);
+                    }
+                }
+                __syncthreads();
+            }
+            if (nan) s_nan = 1;
+            __syncthreads();
+            if (tid == 0) {
+                const double v1 = MK::value(s_prefix[0]), v2 = MK::value(s_prefix[1]);
+                // np.median: mean of the two middle elements == (a + b) / 2.0 ; odd count: the middle one; NaN if any NaN
+                o_median[b] = s_nan ? (double)NAN : (cnt & 1) ? v1 : (v1 + v2) / 2.0;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amount,
                                                     const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt,
@@ -39,7 +130,7 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
         if (cnt > 0) {
             const int64_t start = s + 1;
             const int nreg = (int)((cnt + 63) >> 6);
-            if (cnt > 64 * 32) m = med_select<AF64, 0>(amount, start, cnt, lane, buf);
+            if (cnt > ML_MIN(AF64)) return;                   // k_bar_median_long
             else if (nreg <= 1) m = med_select<AF64, 1>(amount, start, cnt, lane, buf);
             else if (nreg <= 4) m = med_select<AF64, 4>(amount, start, cnt, lane, buf);
             else if (nreg <= 8) m = med_select<AF64, 8>(amount, start, cnt, lane, buf);
@@ -48,7 +139,6 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
             else if (nreg <= 20) m = med_select<AF64, 20>(amount, start, cnt, lane, buf);
             else if (nreg <= 24) m = med_select<AF64, 24>(amount, start, cnt, lane, buf);
             else if constexpr (!AF64) m = med_select<AF64, 32>(amount, start, cnt, lane, buf);
-            else m = med_select<AF64, 0>(amount, start, cnt, lane, buf);
         }
         if (lane == 0) o_median[b] = m;
     };
@@ -84,6 +174,14 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
         k_bar_median<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
     else
         k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
+    FMK_LAUNCH_CHECK(ctx);
+    // bars beyond the register classes: a workgroup per bar (grid: the 64-bar groups, at most 16 workgroups per CU)
+    int64_t lblocks = fmk_ceil_div(nb, 64);
+    if (lblocks > (int64_t)ctx->n_cu * 16) lblocks = (int64_t)ctx->n_cu * 16;
+    if (amount_is_f64)
+        k_bar_median_long<true><<<(unsigned)lblocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
+    else
+        k_bar_median_long<false><<<(unsigned)lblocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
