@@ -26,8 +26,9 @@
 // keys that share the prefix found so far (one histogram while both ranks still share it), a block scan picks the digit.
 // The bars are found like in k_bar_median's leftover pass: 64 close indices per coalesced load.
 #define ML_MIN(F64) ((F64) ? 64 * 24 : 64 * 32)
+#define ML_THREADS 1024                  // threads per bar (bins 0..255 of the scans are the first 256)
 template <bool AF64>
-__global__ __launch_bounds__(256) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
+__global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
                                                          int64_t nb, const int *__restrict__ go, double *__restrict__ o_median)
 {
     if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(256) void k_bar_median_long(const void *__restrict_
             bool nan = false;
 #pragma unroll 1
             for (int p = 0; p < D; ++p) {
-                hist[0][tid] = 0; hist[1][tid] = 0;
+                if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
                 __syncthreads();
                 const K pre0 = s_prefix[0], pre1 = s_prefix[1];
                 const int64_t rk0 = s_rank[0], rk1 = s_rank[1];
                 const bool same = pre0 == pre1;
                 const int shift = MK::BITS - 8 * (p + 1);
-                for (int64_t j = tid; j < cnt; j += 256) {
+                for (int64_t j = tid; j < cnt; j += ML_THREADS) {
                     const K k = MK::load(amount, start + j);
                     if (p == 0) nan |= k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF;
                     const K hi = p == 0 ? (K)0 : (K)(k >> (shift + 8));
@@ -81,16 +82,16 @@ __global__ __launch_bounds__(256) void k_bar_median_long(const void *__restrict_
                 // bin `tid` of each histogram: inclusive prefix over the 256 bins, then the bin that holds the rank
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const unsigned h = hist[same ? 0 : t][tid];
+                    const unsigned h = tid < 256 ? hist[same ? 0 : t][tid] : 0u;
                     unsigned inc = h;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-                    if (lane == 63) s_wsum[t][w] = inc;
+                    if (lane == 63 && w < 4) s_wsum[t][w] = inc;
                     __syncthreads();
                     unsigned base = 0;
-                    for (int k2 = 0; k2 < w; ++k2) base += s_wsum[t][k2];
+                    for (int k2 = 0; k2 < w && k2 < 4; ++k2) base += s_wsum[t][k2];
                     const int64_t cum = (int64_t)base + inc, rk = t == 0 ? rk0 : rk1;
-                    if (cum > rk && cum - h <= rk) {     // exactly one bin
+                    if (tid < 256 && cum > rk && cum - h <= rk) {     // exactly one bin
                         s_prefix[t] = (K)(((t == 0 ? pre0 : pre1) << 8) | (K)tid);
                         s_rank[t] = rk - (cum - h);
                     }
@@ -177,11 +178,11 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
     FMK_LAUNCH_CHECK(ctx);
     // bars beyond the register classes: a workgroup per bar (grid: the 64-bar groups, at most 16 workgroups per CU)
     int64_t lblocks = fmk_ceil_div(nb, 64);
-    if (lblocks > (int64_t)ctx->n_cu * 16) lblocks = (int64_t)ctx->n_cu * 16;
+    if (lblocks > (int64_t)ctx->n_cu * 8) lblocks = (int64_t)ctx->n_cu * 8;
     if (amount_is_f64)
-        k_bar_median_long<true><<<(unsigned)lblocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
+        k_bar_median_long<true><<<(unsigned)lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
     else
-        k_bar_median_long<false><<<(unsigned)lblocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
+        k_bar_median_long<false><<<(unsigned)lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
