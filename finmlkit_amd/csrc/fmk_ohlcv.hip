@@ -61,12 +61,12 @@ __device__ __forceinline__ void ohlcv_empty(const OhlcvOut &o, int64_t b, const 
 template <bool AF64>
 __device__ __forceinline__ void ohlcv_finish(const OhlcvOut &o, int64_t b, const double *price, int64_t start,
                                              int64_t e, double hi, double lo, double tv, double td, int lane,
-                                             bool sums_done = false)
+                                             bool reduced = false)
 {
     // DPP reductions (fmk_dpp.h): the four 6-step xor butterflies that stood here were 48 ds_bpermute round trips per bar
-    hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
-    lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
-    if (!sums_done) {
+    if (!reduced) {
+        hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+        lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
         tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
         td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
     }
@@ -122,6 +122,74 @@ __global__ __launch_bounds__(256) void k_bar_vol_redo(const double *__restrict__
     }
 }
 
+// Bars of more than OH_WIDE_MIN ticks (hourly and daily bars): a WORKGROUP of 1024 threads per bar instead of one wave -- with a
+// wave per bar 580 daily bars kept 580 waves busy on the whole chip: 241 ms per 1e9 ticks (10.7 ms for hourly bars).  Same
+// quantities; the float64 sums are block-reduced (wave DPP trees, then the 16 wave totals in order), which the contract
+// allows: volume is exact in any order for float32 amounts (ties of float64 amounts go to k_bar_vol_redo as before), vwap is
+// a reassociated sum (<= 1e-9).  The bars are found like in the leftover pass above: 64 close indices per coalesced load.
+#define OH_WIDE_MIN 16384
+#define OH_WIDE_THREADS 1024
+template <bool AF64>
+__global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double *__restrict__ price, const void *__restrict__ amount,
+                                                                   const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                   const int *__restrict__ go, OhlcvOut o)
+{
+    if (go && *go == 0) return;
+    __shared__ double s_red[4][OH_WIDE_THREADS / 64];
+    __shared__ int64_t s_se[64][2];
+    __shared__ int s_nwide;
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    const int64_t ngroups = (nb + 63) >> 6;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        if (w == 0) {
+            const int64_t bl = g * 64 + lane;
+            int64_t s_l = 0, e_l = 0;
+            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
+            const bool wide = bl < nb && e_l - s_l > OH_WIDE_MIN;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(wide);
+            if (wide) {
+                const int pos = __builtin_popcountll(m & ((1ULL << lane) - 1));
+                s_se[pos][0] = bl; s_se[pos][1] = s_l;
+            }
+            if (lane == 0) s_nwide = __builtin_popcountll(m);
+        }
+        __syncthreads();
+        const int nwide = s_nwide;
+        for (int q = 0; q < nwide; ++q) {
+            const int64_t b = s_se[q][0], s = s_se[q][1], e = ci[b + 1], start = s + 1;
+            double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+            for (int64_t j = start + tid; j <= e; j += OH_WIDE_THREADS) {
+                const double p0 = price[j], a0 = fmk_amt<AF64>(amount, j);
+                hi = fmax(hi, p0);
+                lo = fmin(lo, p0);
+                tv += a0; td += p0 * a0;
+            }
+            hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+            lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
+            tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
+            td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+            if (lane == 0) { s_red[0][w] = hi; s_red[1][w] = lo; s_red[2][w] = tv; s_red[3][w] = td; }
+            __syncthreads();
+            if (w == 0) {
+                hi = s_red[0][0]; lo = s_red[1][0]; tv = s_red[2][0]; td = s_red[3][0];
+                for (int k = 1; k < OH_WIDE_THREADS / 64; ++k) {
+                    hi = fmax(hi, s_red[0][k]); lo = fmin(lo, s_red[1][k]); tv += s_red[2][k]; td += s_red[3][k];
+                }
+                ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane, true);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+static inline unsigned oh_wide_grid(fmk_ctx *ctx, int64_t nb)
+{
+    int64_t g = fmk_ceil_div(nb, 64);
+    if (g > (int64_t)ctx->n_cu * 8) g = (int64_t)ctx->n_cu * 8;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ price,
                                                    const void *__restrict__ amount,
@@ -138,6 +206,7 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
             if (lane == 0) ohlcv_empty(o, b, price, e, n);
             return;
         }
+        if (e - s > OH_WIDE_MIN) return;                      // k_bar_ohlcv_wide: a workgroup per bar
         const int64_t start = s + 1;
         double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
         int64_t j = start + lane;
@@ -644,6 +713,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);
         FMK_LAUNCH_CHECK(ctx);
         if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
+        k_bar_ohlcv_wide<AF64><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, nullptr, o);
+        FMK_LAUNCH_CHECK(ctx);
         if (AF64) {
             k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
             FMK_LAUNCH_CHECK(ctx);
@@ -694,6 +765,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
     // long bars (if any): the generic kernels exit at once when the flag is clear
     k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o);
+    k_bar_ohlcv_wide<AF64><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (AF64) {
         k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
@@ -710,8 +782,13 @@ int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int 
 {
     OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, nullptr, nullptr};
     const unsigned grid = ohlcv_grid(ctx, nb);
-    if (amount_is_f64) k_bar_ohlcv<true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
-    else k_bar_ohlcv<false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
+    if (amount_is_f64) {
+        k_bar_ohlcv<true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
+        k_bar_ohlcv_wide<true><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, go, o);
+    } else {
+        k_bar_ohlcv<false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
+        k_bar_ohlcv_wide<false><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, go, o);
+    }
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
