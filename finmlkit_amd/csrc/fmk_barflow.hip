@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_dir(const double *__restri
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median);
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -860,7 +860,7 @@ extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const
         FMK_LAUNCH_CHECK(ctx);
         FMK_TRY(fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, 8192, any_long, d_open, d_high, d_low,
                                           d_close, d_volume, d_vwap, d_trades));
-        if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median));
+        if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n));
     } else {
         FMK_HIP(ctx, hipSetDevice(ctx->device));
         const int64_t nb = n_idx - 1;
@@ -888,7 +888,7 @@ extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const
         const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
         k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
         FMK_LAUNCH_CHECK(ctx);
-        if (d_median) FMK_TRY(fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, (int64_t)BF_MED_TILES * 512, saw_long, d_median));
+        if (d_median) FMK_TRY(fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, (int64_t)BF_MED_TILES * 512, saw_long, d_median, n));
     }
     return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
                                             max_levels);

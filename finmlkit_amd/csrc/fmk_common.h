@@ -58,7 +58,13 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
 int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,
                               int64_t n, int64_t min_cnt, const int *go, double *d_open, double *d_high, double *d_low,
                               double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades);
-int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median);
+int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median,
+                            int64_t n_ticks);
+// fmk_median.hip: the bars of more than `min_cnt` ticks as a list ([0] = how many, then the bar numbers, any order) in a block of
+// the context's pool (*list; the caller gives it back with fmk_free after queueing its kernels) -- the workgroup-per-bar
+// kernels take their bars from it, so that a handful of very long bars spread over the whole chip
+int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
+                      int64_t **list);
 
 #define FMK_HIP(ctx, expr)                                                                   \
     do {                                                                                     \

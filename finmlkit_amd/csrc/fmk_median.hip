@@ -29,7 +29,8 @@
 #define ML_THREADS 1024                  // threads per bar (bins 0..255 of the scans are the first 256)
 template <bool AF64>
 __global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
-                                                         int64_t nb, const int *__restrict__ go, double *__restrict__ o_median)
+                                                         const int64_t *__restrict__ list, const int *__restrict__ go,
+                                                         double *__restrict__ o_median)
 {
     if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
     typedef MedKey<AF64> MK;
@@ -37,28 +38,14 @@ __global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__re
     constexpr int D = MK::BITS / 8;
     __shared__ unsigned hist[2][256];
     __shared__ K s_prefix[2];
-    __shared__ int64_t s_rank[2], s_se[64][2];
+    __shared__ int64_t s_rank[2];
     __shared__ unsigned s_wsum[2][4];
-    __shared__ int s_nan, s_nlong;
+    __shared__ int s_nan;
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
-    const int64_t ngroups = (nb + 63) >> 6;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        if (w == 0) {                                    // the group's long bars -> s_se[0 .. s_nlong)
-            const int64_t bl = g * 64 + lane;
-            int64_t s_l = 0, e_l = 0;
-            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
-            const bool is_long = bl < nb && e_l - s_l > ML_MIN(AF64);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(is_long);
-            if (is_long) {
-                const int pos = __builtin_popcountll(m & ((1ULL << lane) - 1));
-                s_se[pos][0] = bl; s_se[pos][1] = s_l;
-            }
-            if (lane == 0) s_nlong = __builtin_popcountll(m);
-        }
-        __syncthreads();
-        const int nlong = s_nlong;
-        for (int q = 0; q < nlong; ++q) {
-            const int64_t b = s_se[q][0], s = s_se[q][1], e = ci[b + 1];
+    const int64_t n_list = list[0];
+    {
+        for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+            const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
             const int64_t cnt = e - s, start = s + 1;
             if (tid == 0) { s_prefix[0] = 0; s_prefix[1] = 0; s_rank[0] = (cnt - 1) >> 1; s_rank[1] = cnt >> 1; s_nan = 0; }
             bool nan = false;
@@ -107,8 +94,38 @@ __global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__re
             }
             __syncthreads();
         }
-        __syncthreads();
     }
+}
+
+// bars of more than min_cnt ticks -> list (one thread per bar, one atomic per wave)
+__global__ __launch_bounds__(256) void k_long_bar_list(const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt,
+                                                       const int *__restrict__ go, int64_t *__restrict__ list, int64_t cap)
+{
+    if (go && *go == 0) return;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is_long = b < nb && ci[b + 1] - ci[b] > min_cnt;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(is_long);
+    if (m == 0) return;
+    const int lane = fmk_lane();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd((unsigned long long *)list, (unsigned long long)__builtin_popcountll(m));
+    base = (unsigned long long)fmk_uniform((int64_t)base);
+    const int64_t pos = (int64_t)base + __builtin_popcountll(m & ((1ULL << lane) - 1));
+    if (is_long && pos < cap) list[1 + pos] = b;
+}
+
+int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
+                      int64_t **list)
+{
+    int64_t cap = n / (min_cnt > 0 ? min_cnt : 1) + 2;               // bars of more than min_cnt ticks: fewer than n / min_cnt
+    if (cap > nb) cap = nb;
+    void *p = nullptr;
+    FMK_TRY(fmk_alloc(ctx, (size_t)(cap + 1) * 8, &p));
+    *list = (int64_t *)p;
+    FMK_HIP(ctx, hipMemsetAsync(p, 0, 8, ctx->stream));
+    k_long_bar_list<<<(unsigned)fmk_ceil_div(nb, 256), 256, 0, ctx->stream>>>(d_close_idx, nb, min_cnt, d_go, *list, cap);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
 }
 
 template <bool AF64>
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median)
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
@@ -176,23 +193,25 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
     else
         k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
     FMK_LAUNCH_CHECK(ctx);
-    // bars beyond the register classes: a workgroup per bar (grid: the 64-bar groups, at most 16 workgroups per CU)
-    int64_t lblocks = fmk_ceil_div(nb, 64);
-    if (lblocks > (int64_t)ctx->n_cu * 8) lblocks = (int64_t)ctx->n_cu * 8;
+    // bars beyond the register classes: a workgroup per bar, the bars from a list (two workgroups of 1024 threads per CU)
+    int64_t *list = nullptr;
+    FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MIN(amount_is_f64), d_go, &list));
+    const unsigned lblocks = (unsigned)(ctx->n_cu * 2);
     if (amount_is_f64)
-        k_bar_median_long<true><<<(unsigned)lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
+        k_bar_median_long<true><<<lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list, d_go, d_median);
     else
-        k_bar_median_long<false><<<(unsigned)lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, nb, d_go, d_median);
-    FMK_LAUNCH_CHECK(ctx);
+        k_bar_median_long<false><<<lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list, d_go, d_median);
+    const hipError_t le = hipGetLastError();
+    FMK_TRY(fmk_free(ctx, list));
+    FMK_HIP(ctx, le);
     return FMK_OK;
 }
 
 extern "C" int fmk_comp_bar_median_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
                                        const int64_t *d_close_idx, int64_t n_idx, double *d_median)
 {
-    (void)n;
     if (n_idx < 2)
         return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    return fmk_median_launch(ctx, d_amount, amount_is_f64, d_close_idx, n_idx - 1, 0, nullptr, d_median);
+    return fmk_median_launch(ctx, d_amount, amount_is_f64, d_close_idx, n_idx - 1, 0, nullptr, d_median, n);
 }

@@ -36,7 +36,7 @@
                                         // at 60 ticks 9.8 vs 12.6 ms for the wave-per-bar kernel, at 80 ticks 18.6 vs 12.0 (1e9 ticks)
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median);
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
 
 struct OhlcvOut {
     double *open, *high, *low, *close;
@@ -131,63 +131,64 @@ __global__ __launch_bounds__(256) void k_bar_vol_redo(const double *__restrict__
 #define OH_WIDE_THREADS 1024
 template <bool AF64>
 __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double *__restrict__ price, const void *__restrict__ amount,
-                                                                   const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                   const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
                                                                    const int *__restrict__ go, OhlcvOut o)
 {
     if (go && *go == 0) return;
     __shared__ double s_red[4][OH_WIDE_THREADS / 64];
-    __shared__ int64_t s_se[64][2];
-    __shared__ int s_nwide;
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
-    const int64_t ngroups = (nb + 63) >> 6;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        if (w == 0) {
-            const int64_t bl = g * 64 + lane;
-            int64_t s_l = 0, e_l = 0;
-            if (bl < nb) { s_l = ci[bl]; e_l = ci[bl + 1]; }
-            const bool wide = bl < nb && e_l - s_l > OH_WIDE_MIN;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(wide);
-            if (wide) {
-                const int pos = __builtin_popcountll(m & ((1ULL << lane) - 1));
-                s_se[pos][0] = bl; s_se[pos][1] = s_l;
-            }
-            if (lane == 0) s_nwide = __builtin_popcountll(m);
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1], start = s + 1;
+        double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+        int64_t j = start + tid;
+        for (; j + 3 * OH_WIDE_THREADS <= e; j += 4 * OH_WIDE_THREADS) {       // four loads of each column in flight
+            const double p0 = price[j], p1 = price[j + OH_WIDE_THREADS], p2 = price[j + 2 * OH_WIDE_THREADS],
+                         p3 = price[j + 3 * OH_WIDE_THREADS];
+            const double a0 = fmk_amt<AF64>(amount, j), a1 = fmk_amt<AF64>(amount, j + OH_WIDE_THREADS),
+                         a2 = fmk_amt<AF64>(amount, j + 2 * OH_WIDE_THREADS), a3 = fmk_amt<AF64>(amount, j + 3 * OH_WIDE_THREADS);
+            hi = fmax(fmax(hi, p0), fmax(p1, fmax(p2, p3)));
+            lo = fmin(fmin(lo, p0), fmin(p1, fmin(p2, p3)));
+            tv += a0; td += p0 * a0;
+            tv += a1; td += p1 * a1;
+            tv += a2; td += p2 * a2;
+            tv += a3; td += p3 * a3;
         }
+        for (; j <= e; j += OH_WIDE_THREADS) {
+            const double p0 = price[j], a0 = fmk_amt<AF64>(amount, j);
+            hi = fmax(hi, p0);
+            lo = fmin(lo, p0);
+            tv += a0; td += p0 * a0;
+        }
+        hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+        lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
+        tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
+        td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+        if (lane == 0) { s_red[0][w] = hi; s_red[1][w] = lo; s_red[2][w] = tv; s_red[3][w] = td; }
         __syncthreads();
-        const int nwide = s_nwide;
-        for (int q = 0; q < nwide; ++q) {
-            const int64_t b = s_se[q][0], s = s_se[q][1], e = ci[b + 1], start = s + 1;
-            double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
-            for (int64_t j = start + tid; j <= e; j += OH_WIDE_THREADS) {
-                const double p0 = price[j], a0 = fmk_amt<AF64>(amount, j);
-                hi = fmax(hi, p0);
-                lo = fmin(lo, p0);
-                tv += a0; td += p0 * a0;
+        if (w == 0) {
+            hi = s_red[0][0]; lo = s_red[1][0]; tv = s_red[2][0]; td = s_red[3][0];
+            for (int k = 1; k < OH_WIDE_THREADS / 64; ++k) {
+                hi = fmax(hi, s_red[0][k]); lo = fmin(lo, s_red[1][k]); tv += s_red[2][k]; td += s_red[3][k];
             }
-            hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
-            lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
-            tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
-            td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
-            if (lane == 0) { s_red[0][w] = hi; s_red[1][w] = lo; s_red[2][w] = tv; s_red[3][w] = td; }
-            __syncthreads();
-            if (w == 0) {
-                hi = s_red[0][0]; lo = s_red[1][0]; tv = s_red[2][0]; td = s_red[3][0];
-                for (int k = 1; k < OH_WIDE_THREADS / 64; ++k) {
-                    hi = fmax(hi, s_red[0][k]); lo = fmin(lo, s_red[1][k]); tv += s_red[2][k]; td += s_red[3][k];
-                }
-                ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane, true);
-            }
-            __syncthreads();
+            ohlcv_finish<AF64>(o, b, price, start, e, hi, lo, tv, td, lane, true);
         }
         __syncthreads();
     }
 }
 
-static inline unsigned oh_wide_grid(fmk_ctx *ctx, int64_t nb)
+// the wide bars of a call: list them, a workgroup per listed bar (two workgroups of 1024 threads per CU)
+template <bool AF64>
+static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n, const int *go,
+                          const OhlcvOut &o)
 {
-    int64_t g = fmk_ceil_div(nb, 64);
-    if (g > (int64_t)ctx->n_cu * 8) g = (int64_t)ctx->n_cu * 8;
-    return (unsigned)(g < 1 ? 1 : g);
+    int64_t *list = nullptr;
+    FMK_TRY(fmk_long_bar_list(ctx, ci, nb, n, OH_WIDE_MIN, go, &list));
+    k_bar_ohlcv_wide<AF64><<<(unsigned)(ctx->n_cu * 2), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, list, go, o);
+    const hipError_t le = hipGetLastError();
+    FMK_TRY(fmk_free(ctx, list));
+    FMK_HIP(ctx, le);
+    return FMK_OK;
 }
 
 template <bool AF64>
@@ -446,7 +447,8 @@ __global__ __launch_bounds__(256) void k_bar_median_small(const float *__restric
 }
 
 // median trade size of every bar, float32 amounts: the small-bar kernel + k_bar_median for the bars beyond its classes
-int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median)
+int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median,
+                            int64_t n_ticks)
 {
     int *saw_long = (int *)(ctx->d_mail + 16);
     FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
@@ -456,7 +458,7 @@ int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *
     if (blocks < 1) blocks = 1;
     k_bar_median_small<<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, saw_long, d_median);
     FMK_LAUNCH_CHECK(ctx);
-    return fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, 64 * FMK_SMALL_NCH, saw_long, d_median);
+    return fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, 64 * FMK_SMALL_NCH, saw_long, d_median, n_ticks);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -713,13 +715,12 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);
         FMK_LAUNCH_CHECK(ctx);
         if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
-        k_bar_ohlcv_wide<AF64><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, nullptr, o);
-        FMK_LAUNCH_CHECK(ctx);
+        FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, nullptr, o));
         if (AF64) {
             k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
             FMK_LAUNCH_CHECK(ctx);
         }
-        if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, nullptr, o.median);
+        if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, nullptr, o.median, n);
         return FMK_OK;
     }
     // small bars: all loads up front (+ fused median); long bars: generic kernels on the rest
@@ -765,13 +766,13 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
     // long bars (if any): the generic kernels exit at once when the flag is clear
     k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o);
-    k_bar_ohlcv_wide<AF64><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
+    FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o));
     FMK_LAUNCH_CHECK(ctx);
     if (AF64) {
         k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
         FMK_LAUNCH_CHECK(ctx);
     }
-    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median);
+    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n);
     return FMK_OK;
 }
 
@@ -784,10 +785,10 @@ int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int 
     const unsigned grid = ohlcv_grid(ctx, nb);
     if (amount_is_f64) {
         k_bar_ohlcv<true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
-        k_bar_ohlcv_wide<true><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, go, o);
+        FMK_TRY(oh_wide_launch<true>(ctx, p, a, ci, nb, n, go, o));
     } else {
         k_bar_ohlcv<false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, min_cnt, go, o);
-        k_bar_ohlcv_wide<false><<<oh_wide_grid(ctx, nb), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, nb, n, go, o);
+        FMK_TRY(oh_wide_launch<false>(ctx, p, a, ci, nb, n, go, o));
     }
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
