@@ -64,7 +64,7 @@ int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *
 // the context's pool (*list; the caller gives it back with fmk_free after queueing its kernels) -- the workgroup-per-bar
 // kernels take their bars from it, so that a handful of very long bars spread over the whole chip
 int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
-                      int64_t **list);
+                      int64_t **list, int64_t max_cnt = INT64_MAX /* bars of min_cnt < ticks <= max_cnt */);
 
 #define FMK_HIP(ctx, expr)                                                                   \
     do {                                                                                     \

@@ -26,9 +26,10 @@
 // keys that share the prefix found so far (one histogram while both ranks still share it), a block scan picks the digit.
 // The bars are found like in k_bar_median's leftover pass: 64 close indices per coalesced load.
 #define ML_MIN(F64) ((F64) ? 64 * 24 : 64 * 32)
-#define ML_THREADS 1024                  // threads per bar (bins 0..255 of the scans are the first 256)
-template <bool AF64>
-__global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
+#define ML_THREADS 1024                  // threads per bar beyond ML_MID_MAX ticks (bins 0..255 of the scans are the first 256)
+#define ML_MID_MAX 8192
+template <bool AF64, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bar_median_long(const void *__restrict__ amount, const int64_t *__restrict__ ci,
                                                          const int64_t *__restrict__ list, const int *__restrict__ go,
                                                          double *__restrict__ o_median)
 {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__re
                 const int64_t rk0 = s_rank[0], rk1 = s_rank[1];
                 const bool same = pre0 == pre1;
                 const int shift = MK::BITS - 8 * (p + 1);
-                for (int64_t j = tid; j < cnt; j += ML_THREADS) {
+                for (int64_t j = tid; j < cnt; j += THREADS) {
                     const K k = MK::load(amount, start + j);
                     if (p == 0) nan |= k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF;
                     const K hi = p == 0 ? (K)0 : (K)(k >> (shift + 8));
@@ -98,12 +99,13 @@ __global__ __launch_bounds__(ML_THREADS) void k_bar_median_long(const void *__re
 }
 
 // bars of more than min_cnt ticks -> list (one thread per bar, one atomic per wave)
-__global__ __launch_bounds__(256) void k_long_bar_list(const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt,
+__global__ __launch_bounds__(256) void k_long_bar_list(const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt, int64_t max_cnt,
                                                        const int *__restrict__ go, int64_t *__restrict__ list, int64_t cap)
 {
     if (go && *go == 0) return;
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool is_long = b < nb && ci[b + 1] - ci[b] > min_cnt;
+    const int64_t cnt = b < nb ? ci[b + 1] - ci[b] : 0;
+    const bool is_long = cnt > min_cnt && cnt <= max_cnt;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(is_long);
     if (m == 0) return;
     const int lane = fmk_lane();
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void k_long_bar_list(const int64_t *__restrict
 }
 
 int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
-                      int64_t **list)
+                      int64_t **list, int64_t max_cnt)
 {
     int64_t cap = n / (min_cnt > 0 ? min_cnt : 1) + 2;               // bars of more than min_cnt ticks: fewer than n / min_cnt
     if (cap > nb) cap = nb;
@@ -123,7 +125,7 @@ int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int6
     FMK_TRY(fmk_alloc(ctx, (size_t)(cap + 1) * 8, &p));
     *list = (int64_t *)p;
     FMK_HIP(ctx, hipMemsetAsync(p, 0, 8, ctx->stream));
-    k_long_bar_list<<<(unsigned)fmk_ceil_div(nb, 256), 256, 0, ctx->stream>>>(d_close_idx, nb, min_cnt, d_go, *list, cap);
+    k_long_bar_list<<<(unsigned)fmk_ceil_div(nb, 256), 256, 0, ctx->stream>>>(d_close_idx, nb, min_cnt, max_cnt, d_go, *list, cap);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -193,16 +195,26 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
     else
         k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
     FMK_LAUNCH_CHECK(ctx);
-    // bars beyond the register classes: a workgroup per bar, the bars from a list (two workgroups of 1024 threads per CU)
-    int64_t *list = nullptr;
-    FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MIN(amount_is_f64), d_go, &list));
-    const unsigned lblocks = (unsigned)(ctx->n_cu * 2);
-    if (amount_is_f64)
-        k_bar_median_long<true><<<lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list, d_go, d_median);
-    else
-        k_bar_median_long<false><<<lblocks, ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list, d_go, d_median);
+    // bars beyond the register classes: a workgroup per bar, the bars from lists -- 256 threads for bars up to ML_MID_MAX ticks (eight
+    // workgroups per CU: at 2 400-tick bars 1024 threads per bar left most of them waiting at the barriers, 12.9 ms per 1e9 ticks),
+    // 1024 threads beyond (two per CU)
+    const int64_t lo_cnt = ML_MIN(amount_is_f64);
+    int64_t *list_mid = nullptr, *list_long = nullptr;
+    FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, lo_cnt, d_go, &list_mid, ML_MID_MAX));
+    int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MID_MAX, d_go, &list_long);
+    if (rc == FMK_OK) {
+        if (amount_is_f64) {
+            k_bar_median_long<true, 256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(d_amount, d_close_idx, list_mid, d_go, d_median);
+            k_bar_median_long<true, ML_THREADS><<<(unsigned)(ctx->n_cu * 2), ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list_long, d_go, d_median);
+        } else {
+            k_bar_median_long<false, 256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(d_amount, d_close_idx, list_mid, d_go, d_median);
+            k_bar_median_long<false, ML_THREADS><<<(unsigned)(ctx->n_cu * 2), ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, list_long, d_go, d_median);
+        }
+    }
     const hipError_t le = hipGetLastError();
-    FMK_TRY(fmk_free(ctx, list));
+    (void)fmk_free(ctx, list_mid);
+    if (list_long) (void)fmk_free(ctx, list_long);
+    FMK_TRY(rc);
     FMK_HIP(ctx, le);
     return FMK_OK;
 }
