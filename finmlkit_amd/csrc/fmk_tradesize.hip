@@ -139,12 +139,12 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             if (np_rule) {
                 if constexpr (!AF64) {
                     const float *af = (const float *)amount + start;
-                    tf = fmk_pairwise_par([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
+                    tf = fmk_pairwise_big([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
                     mean = (double)(tf / (float)cnt);
                     sum = (double)tf;
                 } else {
                     const double *ad = (const double *)amount + start;
-                    sum = fmk_pairwise_par([ad](int i) { return ad[i]; }, (int)cnt, lane, s_stk[wib]);
+                    sum = fmk_pairwise_big([ad](int i) { return ad[i]; }, (int)cnt, lane, s_stk[wib]);
                     mean = sum / (double)cnt;
                 }
             }
@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
                     // 1 - sum((a / total)^2) with float32 quotients, squares and pairwise sum (base.py:609)
                     const float *af = (const float *)amount + start;
                     const float t32 = tf;
-                    gini = 1.0f - fmk_pairwise_par([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
+                    gini = 1.0f - fmk_pairwise_big([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
                                                s_stk[wib]);
                 } else if (np_rule) {
                     const double *ad = (const double *)amount + start;
                     const double td = sum;
-                    gini = (float)(1.0 - fmk_pairwise_par([ad, td](int i) { const double q = ad[i] / td; return q * q; }, (int)cnt, lane,
+                    gini = (float)(1.0 - fmk_pairwise_big([ad, td](int i) { const double q = ad[i] / td; return q * q; }, (int)cnt, lane,
                                                        s_stk[wib]));
                 } else {
                     double sq = 0.0;
