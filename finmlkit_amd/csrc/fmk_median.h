@@ -244,3 +244,65 @@ __device__ __forceinline__ double med_select(const void *amount, int64_t start, 
     bar.load_all();
     return med_search<AF64, NREG, false>(bar, buf);
 }
+
+// Exact order statistics of ranks rk0 <= rk1 (0-based) of a bar by a whole WORKGROUP (THREADS threads, all of them call): radix
+// select on 8-bit digits, most significant first -- BITS / 8 passes over the bar, 256-bin LDS histograms of the current digit for
+// the keys that share the prefix found so far (one histogram while both ranks still share it), a block scan picks the digit.
+// k1 / k2 / any_nan are valid in every thread afterwards (any_nan: a key outside [-inf, +inf]).
+template <bool AF64, int THREADS>
+__device__ __forceinline__ void med_block_select(const void *__restrict__ amount, int64_t start, int64_t cnt, int64_t rank0,
+                                                 int64_t rank1, typename MedKey<AF64>::K &k1, typename MedKey<AF64>::K &k2,
+                                                 bool &any_nan)
+{
+    typedef MedKey<AF64> MK;
+    typedef typename MK::K K;
+    constexpr int D = MK::BITS / 8;
+    __shared__ unsigned hist[2][256];
+    __shared__ K s_prefix[2];
+    __shared__ int64_t s_rank[2];
+    __shared__ unsigned s_wsum[2][4];
+    __shared__ int s_nan;
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    __syncthreads();                                     // (the previous bar's results have been read)
+    if (tid == 0) { s_prefix[0] = 0; s_prefix[1] = 0; s_rank[0] = rank0; s_rank[1] = rank1; s_nan = 0; }
+    bool nan = false;
+#pragma unroll 1
+    for (int p = 0; p < D; ++p) {
+        if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
+        __syncthreads();
+        const K pre0 = s_prefix[0], pre1 = s_prefix[1];
+        const int64_t rk0 = s_rank[0], rk1 = s_rank[1];
+        const bool same = pre0 == pre1;
+        const int shift = MK::BITS - 8 * (p + 1);
+        for (int64_t j = tid; j < cnt; j += THREADS) {
+            const K k = MK::load(amount, start + j);
+            if (p == 0) nan |= k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF;
+            const K hi = p == 0 ? (K)0 : (K)(k >> (shift + 8));
+            const unsigned d = (unsigned)((k >> shift) & 255);
+            if (hi == pre0) atomicAdd(&hist[0][d], 1u);
+            if (!same && hi == pre1) atomicAdd(&hist[1][d], 1u);
+        }
+        __syncthreads();
+        // bin `tid` of each histogram: inclusive prefix over the 256 bins, then the bin that holds the rank
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned h = tid < 256 ? hist[same ? 0 : t][tid] : 0u;
+            unsigned inc = h;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+            if (lane == 63 && w < 4) s_wsum[t][w] = inc;
+            __syncthreads();
+            unsigned base = 0;
+            for (int k = 0; k < w && k < 4; ++k) base += s_wsum[t][k];
+            const int64_t cum = (int64_t)base + inc, rk = t == 0 ? rk0 : rk1;
+            if (tid < 256 && cum > rk && cum - h <= rk) {     // exactly one bin
+                s_prefix[t] = (K)(((t == 0 ? pre0 : pre1) << 8) | (K)tid);
+                s_rank[t] = rk - (cum - h);
+            }
+        }
+        __syncthreads();
+    }
+    if (nan) s_nan = 1;
+    __syncthreads();
+    k1 = s_prefix[0]; k2 = s_prefix[1]; any_nan = s_nan != 0;
+}

@@ -35,65 +35,17 @@ __global__ __launch_bounds__(THREADS) void k_bar_median_long(const void *__restr
 {
     if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
     typedef MedKey<AF64> MK;
-    typedef typename MK::K K;
-    constexpr int D = MK::BITS / 8;
-    __shared__ unsigned hist[2][256];
-    __shared__ K s_prefix[2];
-    __shared__ int64_t s_rank[2];
-    __shared__ unsigned s_wsum[2][4];
-    __shared__ int s_nan;
-    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
     const int64_t n_list = list[0];
-    {
-        for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
-            const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
-            const int64_t cnt = e - s, start = s + 1;
-            if (tid == 0) { s_prefix[0] = 0; s_prefix[1] = 0; s_rank[0] = (cnt - 1) >> 1; s_rank[1] = cnt >> 1; s_nan = 0; }
-            bool nan = false;
-#pragma unroll 1
-            for (int p = 0; p < D; ++p) {
-                if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
-                __syncthreads();
-                const K pre0 = s_prefix[0], pre1 = s_prefix[1];
-                const int64_t rk0 = s_rank[0], rk1 = s_rank[1];
-                const bool same = pre0 == pre1;
-                const int shift = MK::BITS - 8 * (p + 1);
-                for (int64_t j = tid; j < cnt; j += THREADS) {
-                    const K k = MK::load(amount, start + j);
-                    if (p == 0) nan |= k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF;
-                    const K hi = p == 0 ? (K)0 : (K)(k >> (shift + 8));
-                    const unsigned d = (unsigned)((k >> shift) & 255);
-                    if (hi == pre0) atomicAdd(&hist[0][d], 1u);
-                    if (!same && hi == pre1) atomicAdd(&hist[1][d], 1u);
-                }
-                __syncthreads();
-                // bin `tid` of each histogram: inclusive prefix over the 256 bins, then the bin that holds the rank
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned h = tid < 256 ? hist[same ? 0 : t][tid] : 0u;
-                    unsigned inc = h;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-                    if (lane == 63 && w < 4) s_wsum[t][w] = inc;
-                    __syncthreads();
-                    unsigned base = 0;
-                    for (int k2 = 0; k2 < w && k2 < 4; ++k2) base += s_wsum[t][k2];
-                    const int64_t cum = (int64_t)base + inc, rk = t == 0 ? rk0 : rk1;
-                    if (tid < 256 && cum > rk && cum - h <= rk) {     // exactly one bin
-                        s_prefix[t] = (K)(((t == 0 ? pre0 : pre1) << 8) | (K)tid);
-                        s_rank[t] = rk - (cum - h);
-                    }
-                }
-                __syncthreads();
-            }
-            if (nan) s_nan = 1;
-            __syncthreads();
-            if (tid == 0) {
-                const double v1 = MK::value(s_prefix[0]), v2 = MK::value(s_prefix[1]);
-                // np.median: mean of the two middle elements == (a + b) / 2.0 ; odd count: the middle one; NaN if any NaN
-                o_median[b] = s_nan ? (double)NAN : (cnt & 1) ? v1 : (v1 + v2) / 2.0;
-            }
-            __syncthreads();
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
+        const int64_t cnt = e - s, start = s + 1;
+        typename MK::K k1, k2;
+        bool any_nan;
+        med_block_select<AF64, THREADS>(amount, start, cnt, (cnt - 1) >> 1, cnt >> 1, k1, k2, any_nan);
+        if (threadIdx.x == 0) {
+            const double v1 = MK::value(k1), v2 = MK::value(k2);
+            // np.median: mean of the two middle elements == (a + b) / 2.0 ; odd count: the middle one; NaN if any NaN
+            o_median[b] = any_nan ? (double)NAN : (cnt & 1) ? v1 : (v1 + v2) / 2.0;
         }
     }
 }

@@ -67,12 +67,50 @@ __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t st
     return r;
 }
 
+// np.percentile(., 95) of float32 bars beyond the register classes (more than 2048 ticks), by a workgroup per bar (med_block_select:
+// radix select of the two ranks) in a pass of its own: the value is exactly a float32 (NumPy interpolates in the array's dtype),
+// so it travels in o_p95[b] and k_bar_trade_size turns it into size_95_rel.  One wave bisecting the value range with a re-read of
+// the bar per step took 35 / 57 / 383 ms per 1e9 ticks at 10-minute / hourly / daily bars.  Bars with irregular close indices
+// (below -1 or beyond the array: Python slice semantics) stay with the old path.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_ts_p95_long(const float *__restrict__ amount, const int64_t *__restrict__ ci,
+                                                         const int64_t *__restrict__ list, int64_t n, float *__restrict__ o_p95)
+{
+    typedef MedKey<false> MK;
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
+        if (!(s >= -1 && e <= n - 1)) continue;
+        const int64_t cnt = e - s, start = s + 1;
+        const float q32 = 95.0f / 100.0f;
+        const float vi = (float)(cnt - 1) * q32;             // the virtual index in the array's dtype (ts_percentile95)
+        const double fl = floor((double)vi);
+        const int64_t k1 = (int64_t)fl < cnt - 1 ? (int64_t)fl : cnt - 1;
+        const int64_t k2 = k1 + 1 < cnt ? k1 + 1 : cnt - 1;
+        MK::K v1, v2;
+        bool any_nan;
+        med_block_select<false, THREADS>(amount, start, cnt, k1, k2, v1, v2, any_nan);
+        if (threadIdx.x == 0) {
+            const float a32 = (float)MK::value(v1), b32 = (float)MK::value(v2);
+            float r32;
+            if (any_nan) r32 = NAN;
+            else if (vi >= (float)(cnt - 1)) r32 = b32;
+            else {
+                const float t32 = vi - floorf(vi), d32 = b32 - a32;
+                r32 = a32 + d32 * t32;
+                if (t32 >= 0.5f) r32 = b32 - d32 * (1.0f - t32);
+            }
+            o_p95[b] = r32;
+        }
+    }
+}
+
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__ amount,
                                                         const double *__restrict__ theta,
                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                         double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
-                                                        float *__restrict__ o_pct, float *__restrict__ o_gini)
+                                                        float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done)
 {
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
@@ -152,7 +190,10 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             const int nreg = (int)((cnt + 63) >> 6);
             double p95;
             double *bo = (!AF64 && np_rule) ? &block : nullptr;
-            if (cnt > 64 * 32) p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
+            if (cnt > 64 * 32) {
+                if (!AF64 && p95_done && s >= -1 && e_raw <= n - 1) p95 = (double)o_p95[b];      // k_ts_p95_long
+                else p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
+            }
             else if (nreg <= 4) p95 = ts_percentile95<AF64, 4>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 12) p95 = ts_percentile95<AF64, 12>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 20) p95 = ts_percentile95<AF64, 20>(amount, start, cnt, lane, buf, thr, bo);
@@ -201,14 +242,30 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     const int64_t cap = (int64_t)ctx->n_cu * 64;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (amount_is_f64)
+    if (amount_is_f64) {
         k_bar_trade_size<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                           theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                          d_pct_block, d_size_gini);
-    else
+                                                                          d_pct_block, d_size_gini, 0);
+        FMK_LAUNCH_CHECK(ctx);
+        return FMK_OK;
+    }
+    // float32 amounts: the percentile of the bars beyond the register classes first (256 threads per bar up to 8192 ticks, 1024 beyond)
+    int64_t *list_mid = nullptr, *list_long = nullptr;
+    FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n, 64 * 32, nullptr, &list_mid, 8192));
+    int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n, 8192, nullptr, &list_long);
+    if (rc == FMK_OK) {
+        k_ts_p95_long<256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_mid, n,
+                                                                            d_size_95_rel);
+        k_ts_p95_long<1024><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_long, n,
+                                                                             d_size_95_rel);
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                           d_pct_block, d_size_gini);
-    FMK_LAUNCH_CHECK(ctx);
+                                                                           d_pct_block, d_size_gini, 1);
+    }
+    const hipError_t le = hipGetLastError();
+    (void)fmk_free(ctx, list_mid);
+    if (list_long) (void)fmk_free(ctx, list_long);
+    FMK_TRY(rc);
+    FMK_HIP(ctx, le);
     return FMK_OK;
 }

@@ -40,6 +40,28 @@ def test_trade_size_vs_oracle(orc, n, interval):
         np.testing.assert_array_equal(g, w, err_msg=k)
 
 
+@pytest.mark.parametrize("interval", [150.0, 300.0, 1800.0, 12000.0])
+def test_trade_size_long_float32_bars(orc, interval):
+    """float32 bars beyond the register classes (more than 2048 ticks): the percentile comes from the workgroup-per-bar radix
+    select (k_ts_p95_long, 256 threads up to 8192 ticks, 1024 beyond), the two pairwise sums from fmk_pairwise_big -- lognormal
+    sizes (every key distinct), a NaN in one bar, one bar whose close index lies beyond the array (Python slice semantics: the
+    old path), against the oracle bit for bit."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    n = 700_000
+    ts, px, am, sd = orc.synth(23, 0, n)
+    am32 = np.random.default_rng(5).lognormal(-1, 1.2, n).astype(np.float32)
+    _, ci = orc._time_bar_indexer(ts, interval)
+    ci = ci.copy()
+    assert len(ci) >= 3 and np.diff(ci).max() > 2048
+    am32[int(ci[1]) + 7] = np.nan
+    ci[-1] = n + 5                                               # amounts[start:end + 1] clamps
+    theta = np.full(len(ci) - 1, float(np.nanmedian(am32)))
+    want = orc.comp_bar_trade_size_features(am32, theta, ci, 5.0)
+    got = comp_bar_trade_size_features(am32, theta, ci, 5.0)
+    for k, g, w in zip(KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=f"{k} iv={interval}")
+
+
 def test_trade_size_kit_and_errors(orc):
     import pandas as pd
     from finmlkit_amd.bar.base import comp_bar_trade_size_features
