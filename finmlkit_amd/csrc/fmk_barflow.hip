@@ -160,6 +160,7 @@ __device__ __forceinline__ void bf_dir_sequential(const FlowDirOut &o, int64_t b
     double pprev = e >= start ? price[fmk_wrap(start - 1, n)] : 0.0;
     double p = 0.0, v = 0.0;
     int sd = 0;
+    bool started = false;                               // a signed tick has been met (wave-uniform)
     if (start + lane <= e) { p = price[start + lane]; v = (double)amount[start + lane]; sd = side[start + lane]; }
     for (int64_t j0 = start; j0 <= e; j0 += 64) {
         const bool valid = j0 + lane <= e;
@@ -185,14 +186,28 @@ __device__ __forceinline__ void bf_dir_sequential(const FlowDirOut &o, int64_t b
         __builtin_amdgcn_wave_barrier();
         if (lane < 7) {
             const double *row = rows + lane * BF_SEQ_ROW;
+            if (started) {
+                // A signed tick lies behind: the running sums of rows 5 / 6 (the only rows whose extrema are used) do not
+                // move on the other ticks -- their terms are 0.0 -- so every tick's value may enter the extrema: three
+                // instructions per tick instead of five plus the mask arithmetic (this loop is what a redone hourly or daily
+                // bar costs: profiles/r02_long_bars.txt)
 #pragma unroll 16
-            for (int k = 0; k < 64; ++k) {
-                acc += row[k];
-                const double cand = (flow >> k) & 1 ? acc : NAN;     // fmin / fmax ignore NaN: no update on side 0
-                mn = fmin(mn, cand);
-                mx = fmax(mx, cand);
+                for (int k = 0; k < 64; ++k) {
+                    acc += row[k];
+                    mn = fmin(mn, acc);
+                    mx = fmax(mx, acc);
+                }
+            } else {
+#pragma unroll 16
+                for (int k = 0; k < 64; ++k) {
+                    acc += row[k];
+                    const double cand = (flow >> k) & 1 ? acc : NAN;     // fmin / fmax ignore NaN: no update on side 0
+                    mn = fmin(mn, cand);
+                    mx = fmax(mx, cand);
+                }
             }
         }
+        started = started || flow != 0;
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) o.volume_buy[b] = (float)acc;

@@ -173,7 +173,9 @@ __device__ __forceinline__ auto fmk_pairwise_par(F load, int n, int lane, int *s
 // ... and for n beyond FMK_PW_PAR_MAX_N: the TOP of the tree is walked node by node (fmk_pairwise's explicit stack), but a node of
 // at most FMK_PW_PAR_MAX_N elements is a sub-tree of exactly the shape fmk_pairwise_par evaluates -- the recursion does not know
 // where it started -- so it is handed over whole.  A 12 000-element bar is 4 hand-overs and 3 inner nodes instead of ~190 visits.
-// stk: FMK_PW_PAR_STK ints (the walk uses the first 80, the sub-trees the rest).
+// stk: FMK_PW_PAR_STK ints (the walk uses the first 80, the sub-trees the rest).  n <= FMK_PW_BIG_MAX_N: the walk's 16 frames then
+// reach from the root down to the sub-trees of 4096 elements.
+#define FMK_PW_BIG_MAX_N (FMK_PW_PAR_MAX_N << 14)
 template <class F>
 __device__ __forceinline__ auto fmk_pairwise_big(F load, int n, int lane, int *stk) -> decltype(load(0))
 {

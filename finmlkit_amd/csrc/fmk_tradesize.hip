@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             // orc_pairwise_f32, 0 ulp against the reference's kit frames).  `sum` then is that rounded total.
             // float64 amounts: the same trees in float64 (np.mean / .sum() of a float64 slice are pairwise too).
             float tf = 0.f;
-            const bool np_rule = cnt <= FMK_PW_MAX_N;       // longer bars than the explicit stack holds: tree-ordered sums
+            const bool np_rule = cnt <= FMK_PW_BIG_MAX_N;   // longer bars than the explicit stack holds: tree-ordered sums
             const bool f32_rule = !AF64 && np_rule;
             if (np_rule) {
                 if constexpr (!AF64) {
