@@ -21,15 +21,15 @@ __device__ __forceinline__ auto fmk_pw_leaf(F load, int off, int n, int lane) ->
     // the leaf's <= 128 elements with two coalesced loads; the chains then take their terms from the other lanes' registers in
     // NumPy's order.  (A first version let lanes 0..7 load their 16 elements one after the other: sixteen dependent global
     // loads per leaf, 24.6 ms per 1e9 ticks for comp_bar_trade_size_features on 1 200-tick bars.)
-    const T v0 = lane < nm ? load(off + lane) : (T)0;
-    const T v1 = 64 + lane < nm ? load(off + 64 + lane) : (T)0;
+    const T v0 = lane < n ? load(off + lane) : (T)0;                   // (the n % 8 tail elements too: no dependent loads below)
+    const T v1 = 64 + lane < n ? load(off + 64 + lane) : (T)0;
     const int i8 = lane & 7;
     T r = __shfl(v0, i8, 64);
     for (int k = 1; 8 * k < nm; ++k) r += k < 8 ? __shfl(v0, 8 * k + i8, 64) : __shfl(v1, 8 * (k - 8) + i8, 64);
     T t = r + __shfl_down(r, 1, 64);         // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
     T u = t + __shfl_down(t, 2, 64);         // lanes 0,4
     T res = __shfl(u, 0, 64) + __shfl(u, 4, 64);
-    for (int i = nm; i < n; ++i) res += load(off + i);
+    for (int i = nm; i < n; ++i) res += i < 64 ? __shfl(v0, i, 64) : __shfl(v1, i - 64, 64);
     return res;
 }
 
@@ -139,9 +139,11 @@ __device__ __forceinline__ auto fmk_pairwise_par(F load, int n, int lane, int *s
         const bool on = l < n_leaf;
         const int lo = on ? l_off[l] : 0, ll = on ? l_len[l] : 0;
         const int nm = ll - (ll & 7);                        // >= 64 for every leaf of a tree with n > 128
-        T x[16];
+        T x[16], tl[7];
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = 8 * k < nm ? load(lo + 8 * k + i8) : (T)0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) tl[q] = nm + q < ll ? load(lo + nm + q) : (T)0;     // the tail, in flight with the rest
         T r = x[0];
 #pragma unroll
         for (int k = 1; k < 16; ++k)
@@ -149,7 +151,9 @@ __device__ __forceinline__ auto fmk_pairwise_par(F load, int n, int lane, int *s
         T t = r + __shfl_down(r, 1, 64);                      // lanes 0,2,4,6 of the group: r0+r1, r2+r3, r4+r5, r6+r7
         T u = t + __shfl_down(t, 2, 64);                      // lanes 0,4
         T res = __shfl(u, grp * 8, 64) + __shfl(u, grp * 8 + 4, 64);
-        for (int q = nm; q < ll; ++q) res += load(lo + q);
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+            if (nm + q < ll) res += tl[q];
         if (on && i8 == 0) l_sum[l] = res;
     }
     __builtin_amdgcn_wave_barrier();
