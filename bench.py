@@ -6,8 +6,10 @@ device, resident in HBM) -> `TimeBarKit(period=60s).build_ohlcv()` semantics: ba
 indices (_time_bar_indexer), OHLC/volume/VWAP/trade count (comp_bar_ohlcv) and the median trade
 size.  One "step" = one full pass of that path over the resident columns; outputs stay on the device.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU; only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are
-read from the environment -- PyTorch is never imported): rank r holds ticks [r*n, (r+1)*n) of ONE global stream (weak
+N > 1, one rank per GPU, no launcher needed: `python3 bench.py --gpus N` makes this process rank 0 and starts ranks
+1..N-1 as children of itself (RANK / LOCAL_RANK / WORLD_SIZE and the rendezvous path handed down in the environment).
+Started by a launcher that already set WORLD_SIZE (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in
+the environment), every process is simply its rank.  Rank r holds ticks [r*n, (r+1)*n) of ONE global stream (weak
 scaling); the bar that straddles a shard boundary is stitched by a single neighbour send/recv of the trailing partial
 bar's raw ticks per step: ncclSend/ncclRecv of librccl behind the C ABI (fmk_comm_*, csrc/fmk_comm.hip), on its own
 stream, ordered against the compute stream by events -- no host synchronisation inside a step (finmlkit_amd/dist.py).
@@ -20,6 +22,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -210,18 +213,86 @@ def other_configs(trades, ctx, args):
     return out
 
 
+def _proc_start_ticks(pid):
+    """Start time of a process (clock ticks since boot, /proc/<pid>/stat field 22): with the pid it names ONE process instance."""
+    try:
+        with open(f"/proc/{pid}/stat") as fh:
+            return fh.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
+def rendezvous_path(world):
+    """The same string on every rank of THIS job and on no other job: handed down by the self-spawning rank 0
+    (FMK_BENCH_RDV), or -- under a launcher -- built from what the ranks share: the launcher's pid, its start time (a pid
+    is reused, a (pid, start time) pair is not) and MASTER_PORT."""
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    if os.environ.get("FMK_BENCH_RDV"):
+        return os.environ["FMK_BENCH_RDV"]
+    owner = os.getppid() if world > 1 else os.getpid()
+    return os.path.join(base, f"fmk_comm_{os.environ.get('MASTER_PORT', '0')}_{owner}_{_proc_start_ticks(owner)}")
+
+
+def spawn_ranks(args):
+    """`--gpus N` (N > 1) with no launcher: this process is rank 0; ranks 1..N-1 are children running this same file with the
+    same arguments.  -> list of Popen (rank 0 waits for them at the end and turns a failed child into its own rc)."""
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    rdv = os.path.join(base, f"fmk_comm_self_{os.getpid()}_{_proc_start_ticks(os.getpid())}_{os.urandom(4).hex()}")
+    common = {"WORLD_SIZE": str(args.gpus), "FMK_BENCH_RDV": rdv, "FMK_BENCH_SPAWNED": "1"}
+    os.environ.update(common, RANK="0", LOCAL_RANK="0")
+    kids = []
+    for r in range(1, args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r))
+        # a child's stdout goes to OUR stderr: the one JSON line on stdout is rank 0's
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=sys.stderr))
+    return kids
+
+
+def reap(kids, grace_s=60.0):
+    """Wait for the child ranks; -> worst return code (a child that does not finish in `grace_s` is killed: rc 124)."""
+    worst = 0
+    deadline = time.time() + grace_s
+    for k in kids:
+        try:
+            rc = k.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            k.kill()
+            k.wait()
+            rc = 124
+        worst = worst or rc
+    return worst
+
+
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL's P2P between processes needs it on this driver
+    kids = []
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        kids = spawn_ranks(args)
+    try:
+        rc = run(args)
+    except BaseException:
+        for k in kids:                                           # exactly the processes started above
+            if k.poll() is None:
+                k.kill()
+        raise
+    rc = rc or reap(kids)
+    sys.exit(rc)
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    # developer switch for boxes with ONE GPU: every rank on device 0 (RCCL then refuses the communicator, all ranks agree on
-    # that in the rendezvous and the step runs over the host-staged transport) -- exercises the N > 1 flow end to end
-    os.environ["FMK_DEVICE"] = "0" if os.environ.get("FMK_BENCH_ONE_DEVICE") else str(local_rank)
+    args.gpus = world
+    # developer switch for boxes with ONE GPU: every rank on device 0.  RCCL refuses a communicator with two ranks on one
+    # device, so this switch ASKS for the host-staged transport (config.transport says so) -- it exercises the N > 1 flow end
+    # to end (spawn, rendezvous, plan, exchange, boundary bar, gathers), not xGMI
+    one_device = bool(os.environ.get("FMK_BENCH_ONE_DEVICE")) or bool(os.environ.get("FMK_BENCH_SAME_DEVICE_RCCL"))
+    if os.environ.get("FMK_BENCH_ONE_DEVICE") and world > 1:
+        args.transport = "host"
+    # (FMK_BENCH_SAME_DEVICE_RCCL: every rank on device 0 but RCCL still asked for -- the test of the rc-3 fallback rule)
+    os.environ["FMK_DEVICE"] = "0" if one_device else str(local_rank)
 
     comm = None
     use_dist = world > 1 or args.force_dist
@@ -243,23 +314,24 @@ def main():
     ctx.sync()
 
     transport_note = None
+    transport = "none"
+    fell_back = False
     if use_dist:
         from finmlkit_amd.dist import Comm, ShardedTimeBars
-        # the ranks of this node meet in a shared-memory file named after the launcher (same parent pid + port on every
-        # rank); rank 0 creates it, it is unlinked as soon as every rank has attached
-        base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
-        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}_" \
-              f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
-        path = os.path.join(base, f"fmk_comm_{key}")
+        # the ranks of this node meet in a shared-memory file; rank 0 creates it, it is unlinked as soon as every rank
+        # has attached
+        path = rendezvous_path(world)
         transport = args.transport
         try:
             comm = Comm(ctx, rank, world, path, transport, self_loop=(world == 1))
         except _ffi.FmkError as e:
             if transport != "rccl":
                 raise
-            # RCCL could not initialise (every rank learns it in the rendezvous): the same step over the host-staged
-            # transport -- correct, slower, and SAID in the JSON line
+            # RCCL could not initialise (every rank learns it in the rendezvous).  The same step over the host-staged
+            # transport is correct but says nothing about xGMI: the run goes on so that the reason and the numbers are
+            # on record (stderr), and ends with rc 3 -- a scaling curve must not silently be a host-staged one
             transport_note = f"host-staged fallback: {e}"
+            fell_back = True
             print(f"[bench] rank {rank}: {transport_note}", file=sys.stderr)
             comm = Comm(ctx, rank, world, path + ".host", "host", self_loop=(world == 1))
             transport = "host"
@@ -306,14 +378,17 @@ def main():
         return ne - 1
 
     def barrier():
+        if comm:
+            comm.sync()          # first: this wait has a deadline (a dead neighbour is an error here, not a hang in ctx.sync)
         ctx.sync()
         if comm:
-            comm.sync()
             comm.barrier()
 
     for _ in range(args.warmup):
         step()
     ctx.call("fmk_profile_enable", C.c_int(1))      # HIP-event pair around every dominant-kernel launch
+    if comm:
+        comm.profile_enable(True)                   # ... and around every halo exchange, on the communicator's stream
     barrier()
     t_start = time.perf_counter()
     for k in range(args.steps):
@@ -325,15 +400,23 @@ def main():
     ctx.call("fmk_profile_read", kms, C.c_int(64), C.byref(kn))
     ctx.call("fmk_profile_enable", C.c_int(0))
 
+    k_ms = [kms[i] for i in range(kn.value)]
+    avg_k_ms = sum(k_ms) / len(k_ms)
+    per_rank = None
     if comm:
-        elapsed = max(x[0] for x in comm.all_gather_f64([elapsed]))      # MAX over ranks
+        x_ms = comm.profile_read()
+        comm.profile_enable(False)
+        # per rank: its own wall time of the K steps, the average of its dominant kernel, the average of its exchange
+        rows = comm.all_gather_f64([elapsed, avg_k_ms, sum(x_ms) / len(x_ms) if x_ms else float("nan")])
+        elapsed = max(r[0] for r in rows)                                 # MAX over ranks
+        per_rank = {"ms_per_step": [r[0] / args.steps * 1e3 for r in rows],
+                    "kernel_ms": [r[1] for r in rows],
+                    "exchange_ms": [r[2] for r in rows]}
         nb_all = comm.all_gather_i64([state["n_bars"]])
         n_bars_total = sum(x[0] for x in nb_all)
     else:
         n_bars_total = state["n_bars"]
 
-    k_ms = [kms[i] for i in range(kn.value)]
-    avg_k_ms = sum(k_ms) / len(k_ms)
     nb = state["n_bars"]
     # algorithmic bytes of ONE launch of the dominant kernel: price f64 + amount f32 read once per tick,
     # close_idx read once and 60 (+8 with the median) B written per bar (DESIGN.md "roofline")
@@ -364,6 +447,10 @@ def main():
                 "parallelism": (f"time-range shards x{world}, 1 neighbour halo exchange per step "
                                 f"({'ncclSend/ncclRecv of librccl' if transport == 'rccl' else 'host-staged'} behind the "
                                 f"C ABI, no PyTorch{'; self-loop diagnostic' if world == 1 else ''})") if use_dist else "1 GPU",
+                # ALWAYS present: "none" (one GPU, no exchange), "rccl" (ncclSend/ncclRecv over xGMI) or "host" (staged
+                # through shared memory: asked for with --transport host / FMK_BENCH_ONE_DEVICE, or -- rc 3 -- a fallback)
+                "transport": transport,
+                "launcher": ("self-spawned ranks" if os.environ.get("FMK_BENCH_SPAWNED") else "external launcher") if world > 1 else "none",
             },
             "roofline": {"bound": "hbm",
                          "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
@@ -376,8 +463,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
                          "launches_timed": len(k_ms)},
         }
+        if per_rank:
+            ms = per_rank["ms_per_step"]
+            line["per_rank"] = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step": ms,
+                                "dominant_kernel_ms": per_rank["kernel_ms"],
+                                "exchange_ms": per_rank["exchange_ms"],
+                                "exchange_note": ("HIP events on the communicator's stream around the ncclGroup of each step "
+                                                  "(device time of the send/recv alone; it overlaps the interior bars)"
+                                                  if transport == "rccl" else "wall clock of the host-staged copy")}
         if transport_note:
             line["config"]["transport_note"] = transport_note
+            line["valid"] = False
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
             if not args.no_extras:
@@ -386,10 +482,12 @@ def main():
             C.CDLL(None).fflush(None)        # RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer: keep the
         except OSError:                      # JSON line the LAST line of stdout
             pass
-        print(json.dumps(line), flush=True)
+        # a fallback run is NOT a result: its line goes to stderr and the process ends with rc 3
+        print(json.dumps(line), flush=True, file=sys.stderr if fell_back else sys.stdout)
     if comm:
         comm.barrier()
         comm.close()
+    return 3 if fell_back else 0
 
 
 if __name__ == "__main__":

@@ -13,8 +13,11 @@
 //                  bench.py reports when RCCL cannot initialise.
 // Ranks of one node meet in a shared-memory segment (a file the caller names; rank 0 creates it and unlinks it once
 // every rank has attached).  It carries the ncclUniqueId, the small host all-gathers of the set-up phase (timestamps,
-// halo lengths, timings) and the ring buffers of the host transport.  Every wait has a deadline: a missing peer is an
-// error code (FMK_E_COMM), never a hang.
+// halo lengths, timings) and the ring buffers of the host transport.  Every wait has a deadline -- set-up, the all-gathers,
+// the host ring, and the host waits for the communicator's stream (fmk_comm_sync / _destroy poll hipStreamQuery): a missing
+// peer is an error code (FMK_E_COMM), never a hang.  What cannot be bounded from here is a wait INSIDE the device queue:
+// after fmk_comm_wait_dev the context's stream is ordered behind the exchange, so fmk_ctx_sync on it waits as long as the
+// exchange does -- callers that must survive a dead peer call fmk_comm_sync (deadline) BEFORE fmk_ctx_sync.
 #include <dlfcn.h>
 #include <errno.h>
 #include <stdarg.h>
@@ -33,7 +36,7 @@
 
 namespace {
 
-constexpr uint64_t SEG_MAGIC = 0x464d4b434f4d4d32ULL;       // "FMKCOMM2"
+constexpr uint64_t SEG_MAGIC = 0x464d4b434f4d4d33ULL;       // "FMKCOMM3"
 constexpr size_t GATHER_MAX = 4096;                         // bytes per rank and all-gather
 constexpr int MAX_WORLD = 64;
 
@@ -48,8 +51,27 @@ struct alignas(64) RankSlot {
 struct SegHeader {
     uint64_t magic;                                         // written last by rank 0
     uint64_t world, ring_bytes, total_bytes;
+    uint64_t creator_pid, creator_start;                    // rank 0's pid and start time (/proc/<pid>/stat field 22): ONE process
     RankSlot slot[MAX_WORLD];
 };
+
+// start time of a process in clock ticks since boot; 0 when it does not exist (or /proc is not there)
+static uint64_t proc_start_ticks(long pid)
+{
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const size_t k = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[k] = 0;
+    const char *p = strrchr(buf, ')');                      // the command name may contain anything, it ends at the LAST ')'
+    if (!p) return 0;
+    int field = 2;
+    for (++p; *p; ++p)
+        if (*p == ' ' && ++field == 22) return strtoull(p + 1, nullptr, 10);
+    return 0;
+}
 
 static inline size_t gather_off(int world, int parity, int rank)
 {
@@ -83,6 +105,7 @@ struct Rccl {
     int (*GetUniqueId)(nccl_unique_id *) = nullptr;
     int (*CommInitRank)(nccl_comm *, int, nccl_unique_id, int) = nullptr;
     int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*CommAbort)(nccl_comm) = nullptr;               // optional: tear-down without waiting for the peers
     int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -125,6 +148,7 @@ static const char *rccl_load()
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
     g_rccl.so = so;
     return nullptr;
 }
@@ -142,6 +166,11 @@ struct fmk_comm {
     hipStream_t stream;             // RCCL launches go here
     hipEvent_t ev_ready, ev_done;   // ctx stream -> comm stream, comm stream -> ctx stream
     int exchange_pending;
+    // per-exchange timing (fmk_comm_profile_enable): RCCL = event pair on the communicator's stream around the ncclGroup,
+    // HOST = wall clock of the staged copy
+    int profile_on, profile_n;
+    hipEvent_t xev[64][2];
+    double host_ms[64];
     char err[512];
 };
 
@@ -171,30 +200,38 @@ inline SegHeader *hdr(fmk_comm *c) { return (SegHeader *)c->seg; }
         if (e__ != hipSuccess) return comm_error((c), FMK_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));       \
     } while (0)
 
-int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
+int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes, double deadline = 0.0)
 {
     const int world = c->world;
     const size_t total = ring_off(world, ring_bytes, world);
-    const double deadline = now_s() + c->timeout_s;
+    if (deadline == 0.0) deadline = now_s() + c->timeout_s;
     int fd = -1;
+    size_t map_bytes = total;
     if (c->rank == 0) {
-        fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
-        if (fd < 0 && errno == EEXIST) {                    // a leftover of a run that died: replace it
-            unlink(path);
-            fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
-        }
-        if (fd < 0) return comm_error(c, FMK_E_COMM, "rendezvous %s: %s", path, strerror(errno));
+        // created and sized under a temporary name, then rename()d into place: a peer can never open a half-made file, and a
+        // leftover of a run that died is REPLACED (its inode stays with whoever still has it open -- see the check below)
+        char tmp[512];
+        snprintf(tmp, sizeof tmp, "%s.%ld.tmp", path, (long)getpid());
+        unlink(tmp);
+        fd = open(tmp, O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        if (fd < 0) return comm_error(c, FMK_E_COMM, "rendezvous %s: %s", tmp, strerror(errno));
         if (ftruncate(fd, (off_t)total) != 0) {
             close(fd);
+            unlink(tmp);
             return comm_error(c, FMK_E_COMM, "rendezvous %s: ftruncate(%zu): %s", path, total, strerror(errno));
+        }
+        if (rename(tmp, path) != 0) {
+            close(fd);
+            unlink(tmp);
+            return comm_error(c, FMK_E_COMM, "rendezvous %s: rename: %s", path, strerror(errno));
         }
     } else {
         int spins = 0;
         for (;;) {
-            fd = open(path, O_RDWR);
+            fd = open(path, O_RDWR | O_NOFOLLOW);
             if (fd >= 0) {
                 struct stat st;
-                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SegHeader)) break;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= total) break;
                 close(fd);
                 fd = -1;
             }
@@ -204,24 +241,10 @@ int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
             relax(spins);
         }
     }
-    size_t map_bytes = total;
-    if (c->rank != 0) {                                     // the creator's size wins (it is validated below)
-        struct stat st;
-        fstat(fd, &st);
-        if ((size_t)st.st_size < total) {
-            // the file exists but rank 0 has not sized it yet: wait for the full size
-            int spins = 0;
-            while ((size_t)st.st_size < total) {
-                if (now_s() > deadline) {
-                    close(fd);
-                    return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s has %zu bytes, expected %zu", c->rank, path,
-                                      (size_t)st.st_size, total);
-                }
-                relax(spins);
-                fstat(fd, &st);
-            }
-        }
-    }
+    struct stat sfd;
+    fstat(fd, &sfd);
+    const ino_t ino = sfd.st_ino;
+    const dev_t dev = sfd.st_dev;
     void *m = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return comm_error(c, FMK_E_COMM, "mmap(%s): %s", path, strerror(errno));
@@ -233,6 +256,8 @@ int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
         h->world = (uint64_t)world;
         h->ring_bytes = ring_bytes;
         h->total_bytes = total;
+        h->creator_pid = (uint64_t)getpid();
+        h->creator_start = proc_start_ticks((long)getpid());
         __atomic_store_n(&h->magic, SEG_MAGIC, __ATOMIC_RELEASE);
     } else {
         int spins = 0;
@@ -244,6 +269,24 @@ int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
         if (h->world != (uint64_t)world || h->ring_bytes != ring_bytes)
             return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s belongs to another job (world %llu, ring %llu)",
                               c->rank, path, (unsigned long long)h->world, (unsigned long long)h->ring_bytes);
+        // a leftover of a dead run carries a valid header too (and old gather generations: a rank attached to it would pass
+        // its first all-gather on the dead run's data).  Two checks: rank 0 unlinks the name only after EVERY rank has
+        // attached, and this rank has not yet -- so the name must still lead to the inode mapped here (a rank 0 that came
+        // later has replaced it); and the process that made the file must still be running (pid + start time name one
+        // process instance) -- the creator of a leftover is gone.  Either fails: wait for this job's rank 0 and re-attach.
+        struct stat sp;
+        const uint64_t st0 = proc_start_ticks((long)h->creator_pid);
+        const bool have_proc = proc_start_ticks((long)getpid()) != 0;
+        if (stat(path, &sp) != 0 || sp.st_ino != ino || sp.st_dev != dev || (have_proc && st0 != h->creator_start)) {
+            munmap(c->seg, c->seg_bytes);
+            c->seg = nullptr;
+            if (now_s() > deadline)
+                return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s is a leftover of another run and was not replaced "
+                                  "within %.0f s", c->rank, path, c->timeout_s);
+            timespec nap{0, 2000000};
+            nanosleep(&nap, nullptr);
+            return seg_attach(c, path, ring_bytes, deadline);
+        }
     }
     __atomic_store_n(&h->slot[c->rank].attached, 1, __ATOMIC_RELEASE);
     return FMK_OK;
@@ -368,14 +411,26 @@ int rccl_exchange(fmk_comm *c, int n_cols, const void *const *send_ptrs, const s
     // boundary kernel still reads the receive buffers) -- an event, not a host wait
     COMM_HIP(c, hipEventRecord(c->ev_ready, ctx->stream));
     COMM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    const int slot = (c->profile_on && c->profile_n < 64) ? c->profile_n : -1;
+    if (slot >= 0) COMM_HIP(c, hipEventRecord(c->xev[slot][0], c->stream));
     NCCL_TRY(c, g_rccl.GroupStart());
+    // an error between GroupStart and GroupEnd must not leave the group open for every later call: remember it, close the
+    // group, then report
+    int r = 0;
+    const char *what = "";
     if (to >= 0)
-        for (int i = 0; i < n_cols; ++i)
-            if (send_bytes[i]) NCCL_TRY(c, g_rccl.Send(send_ptrs[i], send_bytes[i], /*ncclInt8*/ 0, to, c->nccl, c->stream));
+        for (int i = 0; i < n_cols && !r; ++i)
+            if (send_bytes[i]) { r = g_rccl.Send(send_ptrs[i], send_bytes[i], /*ncclInt8*/ 0, to, c->nccl, c->stream); what = "ncclSend"; }
     if (from >= 0)
-        for (int i = 0; i < n_cols; ++i)
-            if (recv_bytes[i]) NCCL_TRY(c, g_rccl.Recv(recv_ptrs[i], recv_bytes[i], /*ncclInt8*/ 0, from, c->nccl, c->stream));
-    NCCL_TRY(c, g_rccl.GroupEnd());
+        for (int i = 0; i < n_cols && !r; ++i)
+            if (recv_bytes[i]) { r = g_rccl.Recv(recv_ptrs[i], recv_bytes[i], /*ncclInt8*/ 0, from, c->nccl, c->stream); what = "ncclRecv"; }
+    const int r2 = g_rccl.GroupEnd();
+    if (r) return comm_error(c, FMK_E_COMM, "%s: %s", what, g_rccl.GetErrorString(r));
+    if (r2) return comm_error(c, FMK_E_COMM, "ncclGroupEnd: %s", g_rccl.GetErrorString(r2));
+    if (slot >= 0) {
+        COMM_HIP(c, hipEventRecord(c->xev[slot][1], c->stream));
+        c->profile_n = slot + 1;
+    }
     COMM_HIP(c, hipEventRecord(c->ev_done, c->stream));
     return FMK_OK;
 }
@@ -532,18 +587,43 @@ int fmk_comm_create(fmk_ctx *ctx, int transport, const char *rendezvous_path, in
     return FMK_OK;
 }
 
+// Host wait for the communicator's stream with the communicator's deadline: a peer that died after set-up leaves an
+// ncclRecv that never completes, and hipStreamSynchronize on it would hang the survivor for good.
+static int comm_stream_wait(fmk_comm *c)
+{
+    if (!c->stream) return FMK_OK;
+    const double deadline = now_s() + c->timeout_s;
+    int spins = 0;
+    hipError_t q;
+    while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady) {
+        if (now_s() > deadline) return FMK_E_COMM;
+        relax(spins);
+    }
+    return q == hipSuccess ? FMK_OK : FMK_E_HIP;
+}
+
 int fmk_comm_destroy(fmk_comm *c)
 {
     if (!c) return FMK_OK;
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+    int stuck = 0;
+    if (c->stream && comm_stream_wait(c) == FMK_E_COMM) stuck = 1;
+    if (c->nccl) {
+        // a communicator with an exchange that will never complete is aborted (does not wait for the peers) or, when this
+        // librccl has no ncclCommAbort, left behind -- ncclCommDestroy would block on the dead neighbour
+        if (!stuck) (void)g_rccl.CommDestroy(c->nccl);
+        else if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->nccl);
+    }
+    for (int i = 0; i < 64; ++i) {
+        if (c->xev[i][0]) (void)hipEventDestroy(c->xev[i][0]);
+        if (c->xev[i][1]) (void)hipEventDestroy(c->xev[i][1]);
+    }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && !stuck) (void)hipStreamDestroy(c->stream);     // a stuck stream is abandoned, not waited for
     if (c->seg) munmap(c->seg, c->seg_bytes);
     free(c);
-    return FMK_OK;
+    return stuck ? FMK_E_COMM : FMK_OK;
 }
 
 int fmk_comm_allgather(fmk_comm *c, const void *send, size_t bytes, void *recv) { return gather(c, send, bytes, recv); }
@@ -558,8 +638,12 @@ int fmk_comm_halo_exchange_dev(fmk_comm *c, int n_cols, const void *const *send_
     const int to = loop ? 0 : (c->rank + 1 < c->world ? c->rank + 1 : -1);
     const int from = loop ? 0 : (c->rank > 0 ? c->rank - 1 : -1);
     if (to < 0 && from < 0) return FMK_OK;
-    if (c->transport == FMK_COMM_HOST)
-        return host_exchange(c, n_cols, send_ptrs, send_bytes, recv_ptrs, recv_bytes, to, from);
+    if (c->transport == FMK_COMM_HOST) {
+        const double t0 = now_s();
+        FMK_TRY(host_exchange(c, n_cols, send_ptrs, send_bytes, recv_ptrs, recv_bytes, to, from));
+        if (c->profile_on && c->profile_n < 64) c->host_ms[c->profile_n++] = (now_s() - t0) * 1e3;
+        return FMK_OK;
+    }
     FMK_TRY(rccl_exchange(c, n_cols, send_ptrs, send_bytes, recv_ptrs, recv_bytes, to, from));
     c->exchange_pending = 1;
     return FMK_OK;
@@ -578,8 +662,44 @@ int fmk_comm_sync(fmk_comm *c)
 {
     if (c->stream) {
         COMM_HIP(c, hipSetDevice(c->ctx->device));
-        COMM_HIP(c, hipStreamSynchronize(c->stream));
+        const int rc = comm_stream_wait(c);
+        if (rc == FMK_E_COMM)
+            return comm_error(c, FMK_E_COMM, "rank %d: the halo exchange did not complete within %.0f s (neighbour gone?)",
+                              c->rank, c->timeout_s);
+        if (rc != FMK_OK) return comm_error(c, FMK_E_HIP, "communicator stream: %s", hipGetErrorString(hipGetLastError()));
     }
+    return FMK_OK;
+}
+
+int fmk_comm_profile_enable(fmk_comm *c, int on)
+{
+    if (on && c->transport == FMK_COMM_RCCL && !c->xev[0][0]) {
+        COMM_HIP(c, hipSetDevice(c->ctx->device));
+        for (int i = 0; i < 64; ++i) {
+            COMM_HIP(c, hipEventCreate(&c->xev[i][0]));
+            COMM_HIP(c, hipEventCreate(&c->xev[i][1]));
+        }
+    }
+    c->profile_on = on ? 1 : 0;
+    c->profile_n = 0;
+    return FMK_OK;
+}
+
+int fmk_comm_profile_read(fmk_comm *c, double *ms, int capacity, int *count)
+{
+    int n = c->profile_n < 64 ? c->profile_n : 64;
+    if (n > capacity) n = capacity;
+    if (c->transport == FMK_COMM_RCCL) {
+        FMK_TRY(fmk_comm_sync(c));
+        for (int i = 0; i < n; ++i) {
+            float t = 0.f;
+            COMM_HIP(c, hipEventElapsedTime(&t, c->xev[i][0], c->xev[i][1]));
+            ms[i] = (double)t;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) ms[i] = c->host_ms[i];
+    }
+    *count = n;
     return FMK_OK;
 }
 

@@ -151,7 +151,18 @@ class Comm:
         self._call("fmk_comm_wait_dev")
 
     def sync(self):
+        """Host wait for the communicator's stream, bounded by the communicator's timeout (FmkError when a peer is gone)."""
         self._call("fmk_comm_sync")
+
+    def profile_enable(self, on: bool = True):
+        """Time the next (up to 64) exchanges on their own: RCCL = event pair around the ncclGroup, host = wall clock."""
+        self._call("fmk_comm_profile_enable", self._C.c_int(1 if on else 0))
+
+    def profile_read(self) -> List[float]:
+        C = self._C
+        ms, n = (C.c_double * 64)(), C.c_int()
+        self._call("fmk_comm_profile_read", ms, C.c_int(64), C.byref(n))
+        return [ms[i] for i in range(n.value)]
 
     def close(self):
         if self._h:

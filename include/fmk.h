@@ -366,7 +366,12 @@ int fmk_comm_barrier(fmk_comm *comm);
 int fmk_comm_halo_exchange_dev(fmk_comm *comm, int n_cols, const void *const *send_ptrs, const size_t *send_bytes,
                                void *const *recv_ptrs, const size_t *recv_bytes);
 int fmk_comm_wait_dev(fmk_comm *comm);
-int fmk_comm_sync(fmk_comm *comm); /* host wait for the communicator's stream (tear-down, tests) */
+int fmk_comm_sync(fmk_comm *comm); /* host wait for the communicator's stream, bounded by timeout_s: FMK_E_COMM when the
+                                      exchange has not completed by then (call it BEFORE fmk_ctx_sync when a peer may be gone) */
+/* Per-exchange timing: the next <= 64 exchanges are timed on their own -- RCCL: a HIP event pair on the communicator's
+ * stream around the ncclGroup (device time of the send/recv alone); HOST: wall clock of the staged copy. */
+int fmk_comm_profile_enable(fmk_comm *comm, int on);
+int fmk_comm_profile_read(fmk_comm *comm, double *ms, int capacity, int *count);
 /* Up to 8 small device column slices copied by one launch on the context's stream (boundary-bar assembly). */
 int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *const *dst, const size_t *bytes);
 

@@ -140,3 +140,74 @@ def test_sharded_tick_bars_concatenate_to_the_reference(orc, n, thr):
         edges = np.concatenate([[0], cuts, [n]]).astype(np.int64)
         got = np.concatenate([sharded_tick_bar_index(edges[r], edges[r + 1] - edges[r], thr) for r in range(world)])
         np.testing.assert_array_equal(got, want, err_msg=f"world {world} cuts {cuts}")
+
+
+def _stale_worker(rank, world, path, delay):
+    import time
+    from finmlkit_amd.dist import Comm
+    time.sleep(delay)
+    comm = Comm(None, rank, world, path, "host", ring_bytes=4096, timeout_s=30.0)
+    got = comm.all_gather_i64([100 + rank])
+    assert [g[0] for g in got] == [100 + r for r in range(world)], got
+    comm.profile_enable(True)
+    a = np.arange(3000, dtype=np.int64) + rank
+    b = np.zeros_like(a)
+    comm.exchange([(a.ctypes.data, a.nbytes)], [(b.ctypes.data, b.nbytes)])
+    if rank > 0:
+        np.testing.assert_array_equal(b, np.arange(3000, dtype=np.int64) + rank - 1)
+    ms = comm.profile_read()
+    assert len(ms) == 1 and ms[0] >= 0.0
+    comm.barrier()
+    comm.close()
+
+
+def test_leftover_rendezvous_of_a_dead_run_is_replaced(tmp_path):
+    """A run that died before its ranks had all attached leaves its segment behind -- valid magic, same world and ring size, old
+    gather generations.  Rank 1 of the NEXT run finds it first (rank 0 starts later): it must not pass its first all-gather on
+    the dead run's data; rank 0 replaces the file (new inode, rename into place) and rank 1 re-attaches to the new one."""
+    from finmlkit_amd.dist import Comm
+    path = str(tmp_path / "rdv")
+    # the dead run: rank 0 of world 2 creates the segment, publishes a gather generation, and is never joined
+    ctx = mp.get_context("spawn")
+    dead = ctx.Process(target=_dead_rank0, args=(path,))
+    dead.start()
+    dead.join(60)
+    assert dead.exitcode == 0 and os.path.exists(path)
+    _spawn_delayed(_stale_worker, 2, path, delays=[1.0, 0.0])             # rank 1 first, rank 0 a second later
+    assert not os.path.exists(path)
+
+
+def _dead_rank0(path):
+    from finmlkit_amd import _ffi
+    from finmlkit_amd.dist import Comm
+    try:
+        Comm(None, 0, 2, path, "host", ring_bytes=4096, timeout_s=0.3)   # nobody joins: set-up times out, the file stays
+    except _ffi.FmkError:
+        pass
+    os._exit(0)
+
+
+def _spawn_delayed(target, world, path, delays):
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=target, args=(r, world, path, delays[r])) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("worker hung")
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+
+
+def test_rendezvous_does_not_follow_symlinks(tmp_path):
+    from finmlkit_amd import _ffi
+    from finmlkit_amd.dist import Comm
+    target = tmp_path / "victim"
+    target.write_bytes(b"\0" * (1 << 20))
+    link = tmp_path / "rdv"
+    os.symlink(target, link)
+    with pytest.raises(_ffi.FmkError):                                    # rank 1 opens with O_NOFOLLOW
+        Comm(None, 1, 2, str(link), "host", ring_bytes=4096, timeout_s=0.5)
+    assert target.read_bytes() == b"\0" * (1 << 20)

@@ -258,3 +258,68 @@ def test_rccl_two_ranks_on_one_device_agree_on_the_outcome(tmp_path):
     outcomes = [open(tmp_path / f"outcome{r}.txt").read() for r in range(2)]
     print("outcomes:", outcomes)
     assert outcomes[0].startswith("ok") == outcomes[1].startswith("ok")
+
+
+def _run_bench(extra, env_extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "FMK_BENCH_RDV", "FMK_DEVICE")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r, lines, json
+
+
+def test_plain_bench_two_ranks_spawns_itself(tmp_path):
+    """`python3 bench.py --gpus 2` with NO launcher: the process becomes rank 0, starts rank 1 itself, the
+    two meet in the rendezvous file and run the sharded step; rc 0 and exactly ONE JSON line on stdout, with the transport,
+    the per-rank step times and the exchange's own time in it.  FMK_BENCH_ONE_DEVICE puts both ranks on the box's single GPU,
+    which asks for the host-staged transport (RCCL refuses two ranks on one device)."""
+    r, lines, json = _run_bench(["--gpus", "2", "--ticks", "20000000", "--steps", "3", "--warmup", "1"],
+                                {"FMK_BENCH_ONE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["transport"] == "host" and line["config"]["launcher"] == "self-spawned ranks"
+    assert "valid" not in line
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["exchange_ms"]) == 2 and len(pr["dominant_kernel_ms"]) == 2
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] == max(pr["ms_per_step"])
+    assert abs(line["ms_per_step"] - pr["ms_per_step_max"]) < 1e-9
+    assert line["value"] == pytest.approx(2 * 20_000_000 * 3 / (line["ms_per_step"] * 3e-3), rel=1e-6)
+    assert "cpu_baseline" not in line                                     # rank 0 at N = 1 only
+
+
+def test_bench_rccl_fallback_is_not_a_result(tmp_path):
+    """Two ranks on ONE device asking for RCCL (developer switch FMK_BENCH_SAME_DEVICE_RCCL): librccl refuses the communicator,
+    every rank learns it, the step still runs host-staged -- but the run ends with rc 3 and NOTHING on stdout: a scaling curve
+    cannot silently be a host-staged one."""
+    r, lines, json = _run_bench(["--gpus", "2", "--ticks", "5000000", "--steps", "2", "--warmup", "1"],
+                                {"FMK_BENCH_SAME_DEVICE_RCCL": "1"})
+    if r.returncode == 0:                                                 # this librccl accepted two ranks on one device
+        assert json.loads(lines[0])["config"]["transport"] == "rccl"
+        return
+    assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
+    assert lines == []
+    assert "host-staged fallback" in r.stderr and '"valid": false' in r.stderr
+
+
+def test_bench_force_dist_reports_transport_and_exchange_time():
+    r, lines, json = _run_bench(["--ticks", "20000000", "--steps", "3", "--warmup", "1", "--force-dist", "--no-extras",
+                                 "--cpu-sample", "0"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(lines[-1])
+    assert line["config"]["transport"] == "rccl" and line["n_gpus"] == 1
+    assert len(line["per_rank"]["exchange_ms"]) == 1 and line["per_rank"]["exchange_ms"][0] > 0.0
+
+
+def test_bench_single_gpu_line_has_transport_none():
+    r, lines, json = _run_bench(["--ticks", "20000000", "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-sample", "0"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["config"]["transport"] == "none" and line["n_gpus"] == 1 and "per_rank" not in line
