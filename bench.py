@@ -266,6 +266,7 @@ def reap(kids, grace_s=60.0):
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL's P2P between processes needs it on this driver
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # librccl's banner / warnings: not on stdout, that is the JSON line's
     kids = []
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         kids = spawn_ranks(args)

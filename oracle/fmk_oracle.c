@@ -375,6 +375,16 @@ int64_t orc_cusum_bar_indexer(const int64_t *ts, const double *prices, double *s
 /* ------------------------------------------------------------------ */
 static inline int64_t orc_wrap(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
 
+/* ORC_THREADS > 1 in the environment: the per-bar loops of rows 5-7 run as OpenMP parallel-for over BARS.  Bars are
+ * independent in the reference (comp_bar_ohlcv / directional are numba.prange loops, base.py:349, 468; comp_bar_footprints
+ * is a serial loop over independent bars, base.py:682) and the arithmetic inside a bar is untouched, so results do not
+ * depend on the thread count (tests/test_oracle_golden.py runs the goldens with 1 and 4 threads). */
+static int orc_threads(void)
+{
+    const char *e = getenv("ORC_THREADS");
+    return (e && atoi(e) > 1) ? atoi(e) : 1;
+}
+
 int orc_comp_bar_ohlcv(const double *prices, const void *volumes, int is_f64, int64_t n,
                        const int64_t *close_idx, int64_t n_idx,
                        double *o, double *h, double *l, double *c, float *vol,
@@ -392,8 +402,7 @@ int orc_comp_bar_ohlcv(const double *prices, const void *volumes, int is_f64, in
     /* Bars are independent (the reference runs them under numba.prange, base.py:349): with ORC_THREADS > 1 in the
      * environment the bar loop is an OpenMP parallel-for -- the arithmetic inside a bar is untouched, so results do
      * not depend on the thread count.  Used by bench.py's cpu_baseline on all host cores. */
-    int nthreads = 1;
-    { const char *e = getenv("ORC_THREADS"); if (e && atoi(e) > 1) nthreads = atoi(e); }
+    int nthreads = orc_threads();
     double *scratch_all = median ? (double *)malloc(sizeof(double) * (size_t)maxcnt * (size_t)nthreads) : NULL;
     if (median && !scratch_all) return ORC_E_NOMEM;
 #ifdef _OPENMP
@@ -458,6 +467,11 @@ int orc_comp_bar_directional(const double *prices, const void *volumes, int is_f
     const double *vd = (const double *)volumes;
     int64_t nb = n_idx - 1;
     int rc = ORC_OK;
+    const int nthreads = orc_threads();
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(min : rc)
+#endif
     for (int64_t i = 0; i < nb; ++i) {
         int64_t start = close_idx[i] + 1, end = close_idx[i + 1];
         int64_t tb = 0, tsell = 0, ct = 0;
@@ -494,7 +508,7 @@ int orc_comp_bar_directional(const double *prices, const void *volumes, int is_f
         volume_buy[i] = (float)vb; volume_sell[i] = (float)vs;
         dollars_buy[i] = (float)db; dollars_sell[i] = (float)ds;
         max_spread[i] = (float)mxs;
-        if (tb + tsell == 0) { mean_spread[i] = NAN; rc = ORC_E_ZERODIV; }   /* base.py:536 */
+        if (tb + tsell == 0) { mean_spread[i] = NAN; if (ORC_E_ZERODIV < rc) rc = ORC_E_ZERODIV; }   /* base.py:536 (codes < 0) */
         else mean_spread[i] = (float)(cs / (double)(tb + tsell));
         cum_ticks_min[i] = ctmin; cum_ticks_max[i] = ctmax;
         cum_volumes_min[i] = (float)cvmin; cum_volumes_max[i] = (float)cvmax;
@@ -675,10 +689,23 @@ int orc_comp_bar_footprints(const double *prices, const void *amounts, int is_f6
     }
     level_offsets[nb] = off;
     if (!price_levels) return ORC_OK;
-    float *tf = (float *)malloc(sizeof(float) * (size_t)maxL);
-    double *td = (double *)malloc(sizeof(double) * (size_t)maxL);
-    if (!tf || !td) { free(tf); free(td); return ORC_E_NOMEM; }
+    const int nthreads = orc_threads();
+    float *tf_all = (float *)malloc(sizeof(float) * (size_t)maxL * (size_t)nthreads);
+    double *td_all = (double *)malloc(sizeof(double) * (size_t)maxL * (size_t)nthreads);
+    if (!tf_all || !td_all) { free(tf_all); free(td_all); return ORC_E_NOMEM; }
+    int bad_level = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(| : bad_level)
+#endif
     for (int64_t i = 0; i < nb; ++i) {
+#ifdef _OPENMP
+        float *tf = tf_all + (size_t)omp_get_thread_num() * (size_t)maxL;
+        double *td = td_all + (size_t)omp_get_thread_num() * (size_t)maxL;
+#else
+        float *tf = tf_all;
+        double *td = td_all;
+#endif
+        int bar_bad = 0;
         int64_t start = close_idx[i] + 1, end = close_idx[i + 1];
         int64_t low = (int64_t)nearbyint(bar_lows[i] / price_tick_size);
         int64_t base = level_offsets[i], L = level_offsets[i + 1] - base;
@@ -689,7 +716,7 @@ int orc_comp_bar_footprints(const double *prices, const void *amounts, int is_f6
         }
         for (int64_t j = start; j <= end; ++j) {                    /* base.py:700-719 */
             int64_t lvl = (int64_t)nearbyint(prices[j] / price_tick_size) - low;
-            if (lvl < 0 || lvl >= L) { free(tf); free(td); return ORC_E_LEVEL; }
+            if (lvl < 0 || lvl >= L) { bar_bad = 1; break; }             /* base.py:719 raises: reported after the loop */
             int sd = sides[j];
             if (sd == 1) {
                 /* float32 element += amount: rounded to float32 on every add */
@@ -702,6 +729,7 @@ int orc_comp_bar_footprints(const double *prices, const void *amounts, int is_f6
                 sell_ticks[base + lvl] += 1;
             }
         }
+        if (bar_bad) { bad_level |= 1; continue; }
         if (L <= 0) {   /* cannot happen with consistent highs/lows */
             buy_imb_sum[i] = sell_imb_sum[i] = 0; cot[i] = 0; max_run[i] = 0;
             vp_skew[i] = vp_gini[i] = 0.0;
@@ -716,8 +744,8 @@ int orc_comp_bar_footprints(const double *prices, const void *amounts, int is_f6
         buy_imb_sum[i] = (uint16_t)bs; sell_imb_sum[i] = (uint16_t)ss;   /* base.py:738-739 */
         cot[i] = c; max_run[i] = (int16_t)run; vp_skew[i] = sk; vp_gini[i] = gi;
     }
-    free(tf); free(td);
-    return ORC_OK;
+    free(tf_all); free(td_all);
+    return bad_level ? ORC_E_LEVEL : ORC_OK;
 }
 
 /* ------------------------------------------------------------------ */

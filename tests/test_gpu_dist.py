@@ -304,7 +304,7 @@ def test_bench_rccl_fallback_is_not_a_result(tmp_path):
         assert json.loads(lines[0])["config"]["transport"] == "rccl"
         return
     assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
-    assert lines == []
+    assert not [ln for ln in lines if ln.lstrip().startswith("{")], lines      # (librccl's version banner may be there)
     assert "host-staged fallback" in r.stderr and '"valid": false' in r.stderr
 
 

@@ -1,6 +1,9 @@
-"""GPU, BASELINE.json sizes (1e9 ticks per GPU): size-independent properties + prefix parity.
+"""GPU, BASELINE.json sizes (1e9 ticks per GPU): ALL-bar parity with the threaded oracle, size-independent properties, prefix parity.
 
-The CPU oracle cannot process 1e9 ticks in seconds, so at full size the HIP path is checked through
+`test_all_bars_*` compare EVERY bar of the 1e9-tick run with the C oracle, whose per-bar loops run as OpenMP parallel-for over bars
+on the GPU box's host cores (ORC_THREADS; ~2e8 ticks/s on 256 cores, so cfg 2 and cfg 4 take seconds each; the columns are copied
+back from the device -- the device generator equals orc.synth bit for bit, tests/test_gpu_core.py).  When host memory is short the
+comparison covers the longest prefix that fits.  The older tests below check the same runs through
   * causality / prefix parity: every bar that closes inside the first P ticks must equal the oracle's bar
     computed from those P ticks alone (bars depend only on their own ticks; threshold-bar closes only on
     earlier ticks) -- the full-size run is compared with the oracle on the prefix, bit for bit;
@@ -386,3 +389,106 @@ def test_cfg4_first_half_lane_schedule_full_size(big, prefix, orc):
             G.assert_f64_close(o[key][:k], w, what="vwap")
         else:
             np.testing.assert_array_equal(o[key][:k], w, err_msg=key)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# every bar of the full-size run against the threaded oracle (VERDICT r2 next #2a)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _mem_available_bytes():
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16 << 30
+
+
+@pytest.fixture(scope="module")
+def host_cols(big):
+    """The device columns on the host: all n ticks, or the longest prefix for which columns + oracle outputs + HIP outputs fit in
+    a third of the available host memory (~60 B/tick all told)."""
+    engine, t, n = big
+    m = min(n, int(_mem_available_bytes() / 3 // 60))
+    cores = len(os.sched_getaffinity(0))
+    os.environ["ORC_THREADS"] = str(cores)
+    cols = tuple(None if c is None else c.view(0, m).to_host() for c in (t.ts, t.price, t.amount, t.side))
+    yield cols, m
+    os.environ.pop("ORC_THREADS", None)
+
+
+def _bars_inside(cih, m, n):
+    """Number of leading bars whose ticks all lie inside the first m ticks (all of them when m == n)."""
+    return len(cih) - 1 if m == n else int(np.searchsorted(cih, m - 1, side="left")) - 1
+
+
+def test_all_bars_cfg2_against_threaded_oracle(big, host_cols, orc):
+    import time
+    engine, t, n = big
+    (ts, px, am, sd), m = host_cols
+    clock, ci = t.time_bar_index(60.0)
+    cih, clk = ci.to_host(), clock.to_host()
+    t0 = time.perf_counter()
+    oclk, oci = orc._time_bar_indexer(ts, 60.0)
+    k = _bars_inside(cih, m, n)
+    assert k > 1000 and (m < n or k == len(oci) - 1)
+    np.testing.assert_array_equal(cih[:k + 1], oci[:k + 1])
+    np.testing.assert_array_equal(clk[:k + 1], oclk[:k + 1])
+    want = orc.comp_bar_ohlcv(px, am, oci[:k + 1])
+    dt = time.perf_counter() - t0
+    o = engine.to_host(t.bar_ohlcv(ci))
+    for key, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], want):
+        assert o[key].dtype == w.dtype, key
+        if key == "vwap":
+            G.assert_f64_close(o[key][:k], w, rtol=1e-9, what="vwap")
+        else:
+            np.testing.assert_array_equal(o[key][:k], w, err_msg=key)
+    print(f"cfg 2: {k} of {len(cih) - 1} bars ({m:.3g} of {n:.3g} ticks) equal the oracle's; oracle {dt:.1f} s on "
+          f"{os.environ['ORC_THREADS']} threads")
+    # cfg 3 on the same columns: the reference's sequential loops (one thread, ~1 ns/tick) against the exact default mode
+    vthr, dthr = 1728.5, 17_285_000.0
+    for kind, got, w in (("volume", t.volume_bar_index(vthr).to_host(), orc._volume_bar_indexer(am, vthr)),
+                         ("dollar", t.dollar_bar_index(dthr).to_host(), orc._dollar_bar_indexer(px, am, dthr))):
+        kk = len(got) if m == n else int(np.searchsorted(got, m, side="left"))
+        np.testing.assert_array_equal(got[:kk], w[:kk] if m == n else w, err_msg=kind)
+        assert m < n or len(got) == len(w)
+        print(f"cfg 3 {kind}: {kk} closes equal the sequential loop's")
+
+
+def test_all_bars_cfg4_against_threaded_oracle(big, host_cols, orc):
+    import time
+    engine, t, n = big
+    (ts, px, am, sd), m = host_cols
+    _, ci = t.time_bar_index(60.0)
+    cih = ci.to_host()
+    k = _bars_inside(cih, m, n)
+    oci = cih[:k + 1]
+    o, d, nz, off, flat, bar, bad = t.bars_fused(ci, 0.01, 3.0, want_median=True)
+    assert int(bad.to_host()[0]) == 0 and int(nz.to_host()[0]) == 0
+    t0 = time.perf_counter()
+    want_d = orc.comp_bar_directional_features(px, am, oci, sd)
+    oo = orc.comp_bar_ohlcv(px, am, oci, want_median=True)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, oci, sd, 0.01, oo[2], oo[1], 3.0)
+    dt = time.perf_counter() - t0
+    lo = 0 if m == n else 1        # bar 0's spread uses prices[-1] = the last tick of the array passed (base.py:485-500)
+    for key, w in zip(G.DIR_KEYS, want_d):
+        got = d[key].to_host()
+        assert got.dtype == w.dtype, key
+        a = lo if key in ("mean_spread", "max_spread") else 0
+        np.testing.assert_array_equal(got[a:k], w[a:], err_msg=key)
+    for key, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], oo):
+        got = o[key].to_host()
+        if key == "vwap":
+            G.assert_f64_close(got[:k], w, rtol=1e-9, what="vwap")
+        else:
+            np.testing.assert_array_equal(got[:k], w, err_msg=key)
+    offh = off.to_host()
+    np.testing.assert_array_equal(offh[:k + 1], woff)
+    nl = int(woff[-1])
+    for key in G.FP_LIST_KEYS:
+        np.testing.assert_array_equal(flat[key].view(0, nl).to_host().astype(wflat[key].dtype), wflat[key], err_msg=key)
+    for key in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
+        np.testing.assert_array_equal(bar[key].to_host()[:k], wbar[key], err_msg=key)
+    np.testing.assert_allclose(bar["vp_skew"].to_host()[:k], wbar["vp_skew"], atol=1e-6)
+    print(f"cfg 4: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")

@@ -254,3 +254,26 @@ def test_tick_level_chain_reference_vectors(orc):
     np.testing.assert_allclose(r[::97], d["tl_returns_97"], rtol=1e-15, atol=0, equal_nan=True)
     np.testing.assert_allclose(sg[::97], d["tl_sigma_97"], rtol=1e-12, atol=0, equal_nan=True)
     np.testing.assert_array_equal(orc._cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), d["tl_cusum_close_indices"])
+
+
+def test_oracle_bar_loops_do_not_depend_on_the_thread_count(orc, monkeypatch):
+    """ORC_THREADS only splits the BAR loop (rows 5-7 are loops over independent bars in the reference); the arithmetic inside
+    a bar is untouched, so 1 and 4 threads give the same bits -- the full-size GPU parity tests and bench.py's cpu_baseline run
+    the oracle on all host cores."""
+    ts, px, am, sd = orc.synth(42, 0, 300_000)
+    am2 = (am * np.float32(1.2345678)).astype(np.float32)                 # inexact float32 sums as well
+    _, ci = orc._time_bar_indexer(ts, 60.0)
+    outs = []
+    for threads in ("1", "4"):
+        monkeypatch.setenv("ORC_THREADS", threads)
+        res = []
+        for a in (am, am2):
+            o = orc.comp_bar_ohlcv(px, a, ci)
+            d = orc.comp_bar_directional_features(px, a, ci, sd)
+            off, flat, bar = orc.comp_bar_footprints_csr(px, a, ci, sd, 0.01, o[2], o[1], 3.0)
+            res += list(o) + list(d) + [off] + list(flat.values()) + list(bar.values())
+        outs.append(res)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):                                       # base.py:719 through the threaded loop as well
+        orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2] + 0.05, o[1], 3.0)
