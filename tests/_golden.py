@@ -61,3 +61,68 @@ def lognormal_tape(d):
     lam = rng.lognormal(-1.0, 1.2, m)
     lpx = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=m)), 0.01)
     return lam, lpx
+
+
+def f32_amounts(d):
+    """The float32 NON-dyadic amount column of f32_amounts_reference.npz (oracle/gen_f32amounts.py: same draws), checked against
+    the stored sample so that a NumPy whose generator changed fails here and not in a parity assertion."""
+    am = np.random.default_rng(int(d["seed"])).lognormal(-1.0, 1.2, int(d["n"])).astype(np.float32)
+    np.testing.assert_array_equal(am[::9973], d["amount_check"])
+    return am
+
+
+def check_f32_amount_vectors(d, prefix, n, ci_key, ohlcv, directional, footprints, trade_size32, *, what):
+    """Compare one implementation's outputs (dicts of host arrays; `footprints` = (n_levels, flat dict, bar dict)) with the
+    reference-made vectors of f32_amounts_reference.npz (`prefix` "" = one-minute bars of 1e6 ticks, "s1_" = one-second bars of
+    1e5 ticks).  -> number of imbalance flags that differ (float32 vs float64 product, see oracle/gen_f32amounts.py)."""
+    nb = len(d[ci_key]) - 1
+    for key in ("open", "high", "low", "close", "volume", "trades", "median_trade_size"):
+        want = d[prefix + "ohlcv_col_" + key]
+        got = ohlcv[key][:nb]
+        assert got.dtype == want.dtype, (what, key, got.dtype, want.dtype)
+        np.testing.assert_array_equal(got, want, err_msg=f"{what}: {key}")
+    assert_f64_close(ohlcv["vwap"][:nb], d[prefix + "ohlcv_col_vwap"], rtol=1e-9, what=f"{what}: vwap")
+    if directional is not None:
+        for name in (str(c) for c in d[prefix + "dir_columns"]):
+            mine = {"cum_volume_min": "cum_volumes_min", "cum_volume_max": "cum_volumes_max"}.get(name, name)
+            got, want = directional[mine][:nb], d[prefix + "dir_col_" + name]
+            assert got.dtype == want.dtype, (what, name)
+            if name in ("mean_spread", "max_spread"):                       # bar 0: wrap-around tick prices[-1]: the array's last
+                got, want = got[1:], want[1:]
+            if got.dtype == np.float32:
+                # float64 sums rounded ONCE to float32: a reassociated float64 sum differs from the sequential one by ~1e-16
+                # relative, which moves the float32 rounding only on a tie -- bit-identical in practice, and asserted so
+                np.testing.assert_array_equal(got, want, err_msg=f"{what}: {name}")
+            else:
+                np.testing.assert_array_equal(got, want, err_msg=f"{what}: {name}")
+    n_flag_diff = 0
+    if footprints is not None:
+        nlev, flat, bar = footprints
+        np.testing.assert_array_equal(nlev[:nb], d[prefix + "fp_n_levels"], err_msg=f"{what}: levels per bar")
+        nl = int(d[prefix + "fp_n_levels"].sum())
+        for key in ("price_levels", "buy_volumes", "sell_volumes", "buy_ticks", "sell_ticks"):
+            want = d[prefix + "fp_" + key]
+            np.testing.assert_array_equal(flat[key][:nl].astype(want.dtype), want, err_msg=f"{what}: {key}")
+        for key in ("buy_imbalances", "sell_imbalances"):
+            n_flag_diff += int((flat[key][:nl].astype(bool) != d[prefix + "fp_" + key].astype(bool)).sum())
+        np.testing.assert_array_equal(bar["cot_price_levels"][:nb], d[prefix + "fp_cot_price_levels"], err_msg=f"{what}: cot")
+        np.testing.assert_array_equal(bar["vp_gini"][:nb], d[prefix + "fp_vp_gini"], err_msg=f"{what}: vp_gini")
+        np.testing.assert_allclose(bar["vp_skew"][:nb], d[prefix + "fp_vp_skew"], atol=1e-6, err_msg=f"{what}: vp_skew")
+        if n_flag_diff == 0:
+            for key in ("buy_imbalances_sum", "sell_imbalances_sum", "imb_max_run_signed"):
+                np.testing.assert_array_equal(bar[key][:nb], d[prefix + "fp_" + key], err_msg=f"{what}: {key}")
+    if trade_size32 is not None:
+        for key in ("mean_size_rel", "size_95_rel", "pct_block", "size_gini"):
+            want = d[prefix + "ts32_" + key]
+            got = trade_size32[key][:nb]
+            assert got.dtype == want.dtype == np.float32, (what, key)
+            if key == "pct_block":
+                # base.py:599-603 `block_volume = 0.0; block_volume += amount` is a float32 running sum in the recorded mode
+                # (python float + np.float32 -> np.float32, NEP 50) and a float64 one under Numba's typing, which the build
+                # follows for every scalar accumulator (DESIGN.md section 5, typed-vs-recorded table): a float32 sequential sum
+                # over ~1200 sizes carries ~sqrt(n) * 6e-8 relative error, hence a tolerance HERE and only here; the float64
+                # carrier run below pins the float64 accumulation itself
+                np.testing.assert_allclose(got, want, rtol=4e-6, atol=0, equal_nan=True, err_msg=f"{what}: trade-size {key}")
+            else:
+                np.testing.assert_array_equal(got, want, err_msg=f"{what}: trade-size {key}")
+    return n_flag_diff

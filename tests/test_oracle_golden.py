@@ -277,3 +277,32 @@ def test_oracle_bar_loops_do_not_depend_on_the_thread_count(orc, monkeypatch):
         np.testing.assert_array_equal(a, b)
     with pytest.raises(ValueError):                                       # base.py:719 through the threaded loop as well
         orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2] + 0.05, o[1], 3.0)
+
+
+@pytest.mark.parametrize("prefix,ci_key,n_key", [("", "close_indices", "n"), ("s1_", "s1_close_indices", "s1_n")])
+def test_oracle_on_float32_non_dyadic_amounts_against_reference_vectors(orc, prefix, ci_key, n_key):
+    """The input class real data belongs to (float32 sizes whose sums round): vectors the REFERENCE made from float64 carriers of
+    the float32 values -- its accumulators are then float64 as under Numba's typing (oracle/gen_f32amounts.py) -- against the
+    oracle fed the float32 column itself."""
+    d = G.load("f32_amounts_reference")
+    n = int(d[n_key])
+    ts, px, _, sd = orc.synth(42, 0, n)
+    am = G.f32_amounts(d)[:n]
+    assert am.dtype == np.float32
+    _, ci = orc._time_bar_indexer(ts, 60.0 if prefix == "" else 1.0)
+    np.testing.assert_array_equal(ci, d[ci_key])
+    o = dict(zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], orc.comp_bar_ohlcv(px, am, ci)))
+    dd = dict(zip(G.DIR_KEYS, orc.comp_bar_directional_features(px, am, ci, sd))) if prefix == "" else None
+    off, flat, bar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o["low"], o["high"], 3.0)
+    theta = d[prefix + "theta"] if prefix else d["theta"]
+    np.testing.assert_array_equal(theta, o["median_trade_size"])
+    t32 = dict(zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], orc.comp_bar_trade_size_features(am, theta, ci, 5.0)))
+    nd = G.check_f32_amount_vectors(d, prefix, n, ci_key, o, dd, (np.diff(off), flat, bar), t32, what=f"oracle {prefix or '1min'}")
+    print(f"{prefix or '1min'}: imbalance flags differing between the float64 product (oracle, Numba typing) and the recorded "
+          f"float32 product: {nd}")
+    assert nd <= 2
+    if prefix == "":
+        # the float64 carrier through the trade-size reducer (NumPy float64 reductions on both sides)
+        t64 = orc.comp_bar_trade_size_features(am.astype(np.float64), theta, ci, 5.0)
+        for key, got in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], t64):
+            np.testing.assert_array_equal(got, d["ts64_col_" + key], err_msg=key)
