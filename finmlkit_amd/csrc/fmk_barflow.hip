@@ -819,12 +819,50 @@ extern "C" int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, cons
 
 // cfg 4 in two passes over the ticks (26 B/tick): this call = OHLCV (+ median) + order-flow features from ONE read, then the
 // CSR level counts; fmk_comp_bar_footprints_fill_dev is the second pass.  float64 amounts take the separate kernels.
+static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
+                          const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                          double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                          double *d_vwap, int64_t *d_trades, double *d_median, const fmk_directional_out *d_dir,
+                          int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
+                          int64_t *max_levels, int *median_deferred);
+
 extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
                                       const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
                                       double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
                                       double *d_vwap, int64_t *d_trades, double *d_median, const fmk_directional_out *d_dir,
                                       int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
                                       int64_t *max_levels)
+{
+    return bars_flow_size(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, price_tick_size, d_open, d_high,
+                          d_low, d_close, d_volume, d_vwap, d_trades, d_median, d_dir, d_n_zero_div, d_level_offsets,
+                          total_levels, max_levels, nullptr);
+}
+
+// The same pass, but the median trade size may be LEFT to the footprint sweep (cfg 4 at 26 B/tick): on streams of 600..2048-tick
+// bars with float32 amounts nothing is computed for d_median here and *median_deferred comes back 1 -- the caller then hands
+// d_median to fmk_comp_bar_footprints_fill_median_dev, whose waves hold every amount of their bar anyway.  Otherwise the
+// median is complete on return (*median_deferred = 0) and the plain fill call follows.
+extern "C" int fmk_bars_flow_size_defer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
+                                            double price_tick_size, double *d_open, double *d_high, double *d_low,
+                                            double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades,
+                                            double *d_median, const fmk_directional_out *d_dir, int64_t *d_n_zero_div,
+                                            int64_t *d_level_offsets, int64_t *total_levels, int64_t *max_levels,
+                                            int *median_deferred)
+{
+    if (!median_deferred) return fmk_set_error(ctx, FMK_E_ARG, "bars_flow: median_deferred must not be NULL");
+    *median_deferred = 0;
+    return bars_flow_size(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, price_tick_size, d_open, d_high,
+                          d_low, d_close, d_volume, d_vwap, d_trades, d_median, d_dir, d_n_zero_div, d_level_offsets,
+                          total_levels, max_levels, median_deferred);
+}
+
+static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
+                          const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                          double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                          double *d_vwap, int64_t *d_trades, double *d_median, const fmk_directional_out *d_dir,
+                          int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
+                          int64_t *max_levels, int *median_deferred)
 {
     if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     if (n <= 0 || !d_side || !d_dir) return fmk_set_error(ctx, FMK_E_ARG, "bars_flow: bad arguments");
@@ -875,7 +913,14 @@ extern "C" int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const
         FMK_LAUNCH_CHECK(ctx);
         FMK_TRY(fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, 8192, any_long, d_open, d_high, d_low,
                                           d_close, d_volume, d_vwap, d_trades));
-        if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n));
+        // FMK_FLOW_MEDIAN_DEFER=1 leaves the median to the footprint sweep (26 B/tick in all).  OFF by default: measured slower --
+        // the sweep is latency-bound, the bracket bookkeeping and the per-bar selection add ~46 VALU instructions per 64 ticks
+        // and cost it two of its seven waves per SIMD: 9.35 / 10.4 ms against 7.96 / 9.0 ms with the amounts-only median pass
+        // (profiles/r03_cfg4.txt).  The path stays (exact, tested: tests/test_gpu_fused.py) for streams where it may pay.
+        const char *dv = getenv("FMK_FLOW_MEDIAN_DEFER");
+        const int defer_ok = dv ? atoi(dv) : 0;
+        if (d_median && median_deferred && defer_ok) *median_deferred = 1;
+        else if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n));
     } else {
         FMK_HIP(ctx, hipSetDevice(ctx->device));
         const int64_t nb = n_idx - 1;

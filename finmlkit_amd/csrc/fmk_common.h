@@ -52,7 +52,10 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
-                                int64_t n_ticks /* 0: unknown */);
+                                int64_t n_ticks /* 0: unknown */,
+                                double *d_median = nullptr /* float32 amounts: the median trade size from the same sweep */);
+int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
 
 // fmk_ohlcv.hip: pieces of comp_bar_ohlcv for cfg 4's first half (fmk_barflow.hip)
 int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,

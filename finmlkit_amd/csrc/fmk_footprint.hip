@@ -34,7 +34,34 @@
 // tick on a volatile hour: 10^4-10^5 levels) run the same code with the histogram in a per-wave slice of global
 // scratch instead of LDS (generic pointers; slow but unlimited up to 2^24 levels).
 #include "fmk_footprint.h"
+#include "fmk_median.h"
 #include "fmk_scan.h"
+
+// cfg 4 at 26 B/tick (round 3): the wave that sweeps a bar for its footprint has every amount of the bar in hand, so the median
+// trade size (base.py:401-404) is taken HERE instead of by a pass of its own over the amount column (k_bar_median_small, 4 B/tick,
+// 1.35 ms per 1e9 ticks).  Holding the bar's 1 200 keys for a search after the sweep was built first and measured SLOWER (5.4 KB of
+// LDS per wave or 21 more VGPRs: the sweep is latency-bound and lost its occupancy, 7.8 -> 8.6 ms, profiles/r03_cfg4.txt).  What the
+// sweep does instead costs ~10 instructions per 64 ticks and 1 KB of LDS:
+//   * the wave carries a BRACKET [blo, bhi] of order-preserving keys from its previous bar -- the keys at the ranks R below and R
+//     above that bar's middle (R ~ 2.4 sqrt(ticks): the middle ranks of the next bar of a slowly changing size distribution land
+//     inside with probability > 0.999);
+//   * per chunk it counts the keys below the bracket and appends the keys inside it to a candidate list in LDS (<= 256);
+//   * after the sweep, if the two middle ranks fall inside the candidates, they are selected there EXACTLY (fmk_median.h's
+//     bisection + cross-lane sort on four registers per lane) and the bracket moves to the candidates' ranks -R / +R;
+//   * otherwise (first bar of a wave, a jump in the distribution, more than 256 candidates) the bar's amounts are re-read and
+//     searched by the generic selection (L2 hits: the sweep has just streamed them), which also re-seeds the bracket.  A heavy tie
+//     at the median (a size that most trades share) gives the degenerate bracket blo == bhi, which needs no list at all.
+// The result is np.median's bits in every case -- the bracket only decides how much work it takes.  Bars of more than
+// FP_MED_MAX_TICKS ticks are flagged for the long-bar median kernels (fmk_median_launch), as after k_bar_median_small.
+#define FP_MED_MAX_TICKS 2048
+#define FP_MED_CAP 256
+struct FpMed {
+    uint32_t *cand;            // [FP_MED_CAP] in the wave's LDS slice
+    uint32_t blo, bhi;         // bracket (keys), wave-uniform
+    int have;                  // bracket valid
+    int below, ncand;          // this sweep: keys < blo, keys in [blo, bhi]
+    uint32_t kmin, kmax;       // per lane: smallest / largest key seen (NaN detection)
+};
 
 // ---------------------------------------------------------------------------------------
 // phase 1: level counts per bar -> exclusive scan
@@ -200,7 +227,7 @@ template <bool AF64, bool EXACT>
 __device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__ price, const void *__restrict__ amount,
                                                       const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low,
                                                       int L, double tick, double inv_tick, int lane, float *vol, int *cnt,
-                                                      int q)
+                                                      int q, FpMed *med = nullptr)
 {
     typedef typename std::conditional<AF64, double, float>::type AmtT;
     unsigned *units = (unsigned *)vol;
@@ -208,6 +235,10 @@ __device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__
     double atot = 0.0;
     bool bad = false, units_ok = true;
     const int ilow = (int)low;
+    const bool med_on = !AF64 && med != nullptr && med->have;
+    uint32_t m_lo = 0, m_hi = 0, m_kmin = 0xFFFFFFFFu, m_kmax = 0;
+    int m_below = 0, m_n = 0;
+    if (med_on) { m_lo = med->blo; m_hi = med->bhi; }
     const double *pp = price + (s + 1);
     const AmtT *ap = (const AmtT *)amount + (s + 1);
     const int8_t *sp = side + (s + 1);
@@ -223,6 +254,19 @@ __device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__
         const int sd = sd_n;
         if (j + 64 < total) { p_n = pp[j + 64]; a_n = ap[j + 64]; sd_n = sp[j + 64]; }
         const bool in_bar = j < total;
+        if constexpr (!AF64) {
+            if (med_on) {       // the median's bracket: every tick of the bar, signed or not, inside the level range or not
+                const uint32_t k = MedKey<false>::tokey(__float_as_uint(a));
+                m_kmin = (in_bar && k < m_kmin) ? k : m_kmin;
+                m_kmax = (in_bar && k > m_kmax) ? k : m_kmax;
+                m_below += __popcll(__ballot(in_bar && k < m_lo));
+                const bool inb = in_bar && k >= m_lo && k <= m_hi;
+                const uint64_t bm = __ballot(inb);
+                const int pos = m_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0));
+                if (inb && pos < FP_MED_CAP) med->cand[pos] = k;
+                m_n += __popcll(bm);
+            }
+        }
         // level = int(round(price / tick)) - low (base.py:700-707): one multiply; the exact division decides the (rare) products
         // within 1e-15 of a half-integer -- as a wave-uniform branch
         const double qq = p * inv_tick;
@@ -275,6 +319,7 @@ __device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__
             }
         }
     }
+    if (med_on) { med->below = m_below; med->ncand = m_n; med->kmin = m_kmin; med->kmax = m_kmax; }
     FpStats st;
     st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
     st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
@@ -282,6 +327,72 @@ __device__ __forceinline__ FpStats fp_accumulate_lean(const double *__restrict__
     st.bad = __ballot(bad) != 0;
     __builtin_amdgcn_wave_barrier();
     return st;
+}
+
+// np.median of the bar's n_t (1 .. FP_MED_MAX_TICKS) float32 amounts after the sweep (see the head of this file); moves the bracket.
+// The bracket is kept as [v1 - w, v2 + w] in key units around the bar's middle keys; its half-width w follows the candidate count
+// (the aim: 2R + 2 candidates, R ~ 2.4 sqrt(ticks)), so the accepting path needs ONE selection on four registers per lane.
+__device__ __forceinline__ double fp_median_finish(FpMed &med, uint32_t &width, int &n_fallback, const float *__restrict__ amount,
+                                                   int64_t start, int64_t n_t, int lane, uint32_t *buf)
+{
+    typedef MedKey<false> MK;
+    const int64_t k1 = (n_t - 1) >> 1, k2 = n_t >> 1;
+    int R = (int)(2.4f * sqrtf((float)n_t));
+    R = R < 32 ? 32 : (R > 100 ? 100 : R);
+    uint32_t v1 = 0, v2 = 0;
+    bool ok = false, isnan = false;
+    if (med.have) {
+        const uint32_t kmin = med_wave_umin<uint32_t>(med.kmin), kmax = med_wave_umax<uint32_t>(med.kmax);
+        isnan = kmin < MK::KEY_NEG_INF || kmax > MK::KEY_POS_INF;
+        const int64_t below = med.below, nc = med.ncand;
+        if (isnan) ok = true;                                         // np.median: NaN; the bracket stays
+        else if (below <= k1 && k2 < below + nc) {
+            if (med.blo == med.bhi) { v1 = v2 = med.blo; ok = true; }  // every candidate is the same key: no list needed
+            else if (nc <= FP_MED_CAP) {
+                MedBar<false, FP_MED_CAP / 64, false> cb;
+#pragma unroll
+                for (int r = 0; r < FP_MED_CAP / 64; ++r) {
+                    const int j = r * 64 + lane;
+                    cb.key[r] = j < (int)nc ? med.cand[j] : MK::MAXK;
+                }
+                cb.amount = nullptr; cb.start = 0; cb.cnt = nc; cb.lane = lane;
+                (void)med_rank_pair<false, FP_MED_CAP / 64, false>(cb, buf, k1 - below, k2 - below, v1, v2);
+                v1 = (uint32_t)fmk_uniform((int)v1);
+                v2 = (uint32_t)fmk_uniform((int)v2);
+                // too many candidates: narrower next time; too few (the middle came close to an end): wider
+                const int aim = 2 * R + 2;
+                if (nc > aim + aim / 4) width -= width >> 2;
+                else if (nc < aim - aim / 4) width += (width >> 2) + 1;
+                med.blo = v1 > width ? v1 - width : 0;
+                med.bhi = v2 < 0xFFFFFFFFu - width ? v2 + width : 0xFFFFFFFFu;
+                ok = true;
+            }
+        }
+    }
+    if (!ok) {
+        // generic selection on the amounts themselves (re-read on every pass: L2 hits), then the bracket for the next bar
+        ++n_fallback;
+        MedBar<false, 0, false> gb;
+        gb.amount = amount; gb.start = start; gb.cnt = n_t; gb.lane = lane;
+        if (!med_rank_pair<false, 0, false>(gb, buf, k1, k2, v1, v2)) { isnan = true; med.have = 0; }
+        else {
+            const int64_t ra = k1 - R > 0 ? k1 - R : 0, rb = k2 + R < n_t - 1 ? k2 + R : n_t - 1;
+            uint32_t nlo, nhi, t;
+            (void)med_rank_pair<false, 0, false>(gb, buf, ra, ra, nlo, t);
+            (void)med_rank_pair<false, 0, false>(gb, buf, rb, rb, nhi, t);
+            const int64_t inside = gb.count_le(nhi) - (nlo > 0 ? gb.count_le(nlo - 1) : 0);
+            if (inside > FP_MED_CAP) { nlo = v1; nhi = v2; }             // ties: the (possibly degenerate) bracket of the middle keys
+            med.blo = (uint32_t)fmk_uniform((int)nlo);
+            med.bhi = (uint32_t)fmk_uniform((int)nhi);
+            v1 = (uint32_t)fmk_uniform((int)v1);
+            v2 = (uint32_t)fmk_uniform((int)v2);
+            const uint32_t wl = v1 - med.blo, wh = med.bhi - v2;
+            width = wl > wh ? wl : wh;
+            med.have = 1;
+        }
+    }
+    if (isnan) return NAN;
+    return (n_t & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;   // np.median: mean of the two middle elements
 }
 
 // Are same-address LDS atomics with return applied in ascending lane order?  (They are on gfx950; the tick-ordered sweep above
@@ -339,7 +450,7 @@ static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
 // ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
-template <bool AF64, bool GLOBAL>
+template <bool AF64, bool GLOBAL, bool MED = false>
 __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict__ price,
                                                         const void *__restrict__ amount,
                                                         const int8_t *__restrict__ side,
@@ -348,13 +459,16 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         const int64_t *__restrict__ off, int lmin, int lmax,
                                                         FpOut o, unsigned long long *n_bad, int force_ordered,
                                                         unsigned char *gscratch, int lean,
-                                                        const unsigned long long *only = nullptr)
+                                                        const unsigned long long *only = nullptr,
+                                                        double *__restrict__ o_median = nullptr,
+                                                        int *__restrict__ saw_long = nullptr)
 {
+    static_assert(!(MED && AF64), "the in-sweep median serves float32 amounts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
-    const size_t per_wave = (size_t)lmax * 24 + 256;
+    const size_t per_wave = (size_t)lmax * 24 + 256 + ((MED && !GLOBAL) ? (size_t)FP_MED_CAP * 4 : 0);
     // the wave's histogram: LDS for the three narrow classes (LDS-typed pointers: ds_add / ds_read), a slice of global
     // scratch for bars wider than 2048 levels (same code; a wave's own stores are visible to its later loads)
     unsigned char *mine;
@@ -364,6 +478,14 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     int *cnt = (int *)(mine + (size_t)lmax * 8);                  // [2*lmax]
     float *aux = (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
     int *stk = (int *)(mine + (size_t)lmax * 24);                 // 64 ints
+    // the median's bracket and candidate list (LDS classes with the straight-line sweep only; otherwise every bar takes the
+    // generic selection on its re-read amounts)
+    FpMed med;
+    med.cand = (MED && !GLOBAL) ? (uint32_t *)(mine + (size_t)lmax * 24 + 256) : nullptr;
+    med.blo = med.bhi = 0; med.have = 0; med.below = med.ncand = 0; med.kmin = 0xFFFFFFFFu; med.kmax = 0;
+    FpMed *medp = (MED && !GLOBAL && lean) ? &med : nullptr;
+    uint32_t med_width = 0;
+    int med_fallbacks = 0;
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     const double inv_tick = 1.0 / tick;
@@ -387,7 +509,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (!force_ordered && wq != FP_Q_UNKNOWN) {
             bool did = false;
             if constexpr (!GLOBAL) {
-                if (lean) { st = fp_accumulate_lean<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq); did = true; }
+                if (lean) { st = fp_accumulate_lean<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq, medp); did = true; }
             }
             if (!did) st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
             done = fp_certified_units(st);
@@ -405,7 +527,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (!done) {
             bool did = false;
             if constexpr (!GLOBAL) {
-                if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0); did = true; }
+                if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0, medp); did = true; }
             }
             if (!did) st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
             // remember a usable quantum for the next bar (if this bar would have certified)
@@ -418,6 +540,26 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         __builtin_amdgcn_wave_barrier();
 
         fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk);
+        if constexpr (MED) {
+            // np.median of the bar's trade sizes (base.py:401-404); an empty bar has median 0 (base.py:352-361)
+            const int64_t n_t = e - s;
+            __builtin_amdgcn_wave_barrier();
+            double m = 0.0;
+            if (n_t > FP_MED_MAX_TICKS) {
+                if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                med.have = medp ? med.have : 0;
+                continue;
+            } else if (n_t > 0) {
+                if (!medp) med.have = 0;                                  // nothing was collected: generic selection
+                m = fp_median_finish(med, med_width, med_fallbacks, (const float *)amount, s + 1, n_t, lane, (uint32_t *)stk);
+            }
+            if (lane == 0) o_median[b] = m;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if constexpr (MED) {
+        if (lane == 0 && med_fallbacks) atomicAdd(saw_long + 1, med_fallbacks);     // diagnostics (fmk_diag_fp_median_fallbacks)
     }
 }
 
@@ -659,11 +801,13 @@ __global__ __launch_bounds__(256) void k_fl_compact(const unsigned long long *__
 template <bool AF64>
 static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t *sd, const int64_t *ci, int64_t nb,
                      double tick, const double *lows, double imb_mult, const int64_t *off, int lmin, int lmax, int wpb,
-                     const FpOut &o, unsigned long long *n_bad, const unsigned long long *only = nullptr)
+                     const FpOut &o, unsigned long long *n_bad, const unsigned long long *only = nullptr,
+                     double *d_median = nullptr, int *saw_long = nullptr)
 {
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
-    size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256);
+    const bool med = d_median != nullptr && !AF64;
+    size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
     int64_t blocks = fmk_ceil_div(nb, wpb);
     int64_t cap = (int64_t)ctx->n_cu * 64;
     unsigned char *gscratch = nullptr;
@@ -681,6 +825,37 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     }
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    if constexpr (!AF64) {
+        if (med) {
+            if (gscratch)
+                k_bar_footprints<false, true, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(
+                    p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, gscratch, 0, only, d_median,
+                    saw_long);
+            else {
+                // the bracket lives in a wave from bar to bar and every wave's FIRST bar takes the generic selection: as many
+                // workgroups as are resident at once (grid-stride over the bars), not 64 per CU
+                static int occ[3] = {0, 0, 0};
+                const int slot = lmax <= 128 ? 0 : (lmax <= 512 ? 1 : 2);
+                if (!occ[slot]) {
+                    int nblk = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_bar_footprints<false, false, true>, wpb * 64, smem) !=
+                            hipSuccess || nblk < 1)
+                        nblk = 2;
+                    occ[slot] = nblk;
+                }
+                int64_t resident = (int64_t)ctx->n_cu * occ[slot];
+                if (const char *v = getenv("FMK_FP_MED_BLOCKS")) {      // developer knob (tests: few waves, many bars per wave)
+                    if (atoi(v) > 0) resident = atoi(v);
+                }
+                if (blocks > resident) blocks = resident;
+                k_bar_footprints<false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(
+                    p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, nullptr,
+                    fp_lds_atomics_in_lane_order(ctx), only, d_median, saw_long);
+            }
+            FMK_LAUNCH_CHECK(ctx);
+            return FMK_OK;
+        }
+    }
     if (gscratch)
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
@@ -711,13 +886,14 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
-                                       max_levels, d_out, d_n_bad_level, n);
+                                       max_levels, d_out, d_n_bad_level, n, nullptr);
 }
 
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
-                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level, int64_t n_ticks)
+                                int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level, int64_t n_ticks,
+                                double *d_median)
 {
     // imb_mult stays float64: array(float32) * float64 is float64 under Numba typing (the production path); NumPy 2 / NEP 50
     // would round the product to float32 -- they differ only for inexact products (decimal lots), see oracle/fmk_oracle.c
@@ -735,6 +911,12 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         const int mode = lv ? atoi(lv) : 1;
         const bool ok = !amount_is_f64 && lmin_start == 0 && ((uintptr_t)d_amount & 7) == 0 && ((uintptr_t)d_side & 3) == 0;
         const bool fit = n_ticks > 0 && nb >= (int64_t)ctx->n_cu * 64 * 4 && n_ticks / nb <= 64;
+        if (d_median && ok && mode != 0 && (fit || mode == 2)) {
+            // the lane-per-bar schedule does not carry the median: the amounts-only pass serves it, the classes below then run
+            // without it
+            FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n_ticks));
+            d_median = nullptr;
+        }
         if (ok && mode != 0 && (fit || mode == 2)) {
             const int64_t groups = fmk_ceil_div(nb, 64);
             unsigned long long *grp_mask = nullptr;
@@ -763,6 +945,15 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         }
     }
     int lmin = 0, rc = FMK_OK;
+    int *saw_long = (int *)(ctx->d_mail + 16);
+    if (d_median && amount_is_f64) {      // float64 amounts: the in-sweep median is a float32 schedule
+        if (rest) (void)fmk_free(ctx, rest);
+        return fmk_set_error(ctx, FMK_E_ARG, "footprints with the median trade size: float32 amounts only");
+    }
+    if (d_median) {
+        const hipError_t e = hipMemsetAsync(saw_long, 0, 2 * sizeof(int), ctx->stream);   // [0] long bars seen, [1] generic selections
+        if (e != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, e); }
+    }
     for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         if (LMAX[k] > lmin_start) {
@@ -770,10 +961,44 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                      ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest)
                      : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest);
+                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, d_median, saw_long);
         }
         lmin = LMAX[k];
     }
     if (rest) (void)fmk_free(ctx, rest);                               // stream-ordered: the launches above are queued before it
+    // bars of more than FP_MED_MAX_TICKS ticks: the long-bar median kernels, when a sweep flagged one
+    if (rc == FMK_OK && d_median) rc = fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, FP_MED_MAX_TICKS, saw_long, d_median, n_ticks);
     return rc;
+}
+
+extern "C" int fmk_comp_bar_footprints_fill_median_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
+                                                       int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                                                       int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                                                       const double *d_bar_lows, double imbalance_factor,
+                                                       const int64_t *d_level_offsets, int64_t max_levels,
+                                                       const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
+                                                       double *d_median)
+{
+    if (n_idx == 1) return FMK_OK;   // zero bars: nothing to fill
+    if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
+    if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_footprints: bad arguments");
+    if (max_levels > FP_MAX_LEVELS_GLOBAL)
+        return fmk_set_error(ctx, FMK_E_CAPACITY,
+                             "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
+                             (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
+                                       price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
+                                       max_levels, d_out, d_n_bad_level, n, d_median);
+}
+
+// diagnostics: how many bars of the last fmk_comp_bar_footprints_fill_median_dev call took the generic selection (bracket miss)
+extern "C" int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count)
+{
+    int v[2] = {0, 0};
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipMemcpyAsync(v, ctx->d_mail + 16, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v[1];
+    return FMK_OK;
 }

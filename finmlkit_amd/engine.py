@@ -199,7 +199,7 @@ class DeviceTrades:
     def bars_fused(self, close_idx: DeviceArray, price_tick_size: float, imbalance_factor: float = 3.0,
                    want_median: bool = True):
         """cfg 4: build_ohlcv + build_directional_features + build_footprints semantics in two passes over the ticks
-        (13 B/tick each: OHLCV incl. median + order-flow in one kernel, then the footprints).
+        (13 B/tick each: OHLCV + order-flow in one kernel, then the footprints, whose sweep also takes the median trade size).
 
         -> (ohlcv, directional, n_zero_div, level_offsets, flat, per_bar, n_bad), all device-resident."""
         nb = close_idx.n - 1
@@ -211,18 +211,21 @@ class DeviceTrades:
         dst = DirectionalOut(**{k: d[k].ptr for k in d})
         cnts = DeviceArray(self.ctx, 2, np.int64)
         cnts.zero()
-        # pass 1: OHLCV (+ median) and the order-flow features from ONE read of price / amount / side, then the level counts
-        self.ctx.call("fmk_bars_flow_size_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64), c_i64(self.n),
+        # pass 1: OHLCV and the order-flow features from ONE read of price / amount / side, then the level counts.  The median
+        # trade size is left to pass 2 when the library says so (float32 amounts, 600..2048-tick bars): 26 B/tick in all
+        deferred = C.c_int(0)
+        self.ctx.call("fmk_bars_flow_size_defer_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64), c_i64(self.n),
                       close_idx.p, c_i64(close_idx.n), self.side.p, c_f64(price_tick_size), o["open"].p, o["high"].p,
                       o["low"].p, o["close"].p, o["volume"].p, o["vwap"].p, o["trades"].p, med, C.byref(dst),
-                      cnts.view(0, 1).p, off.p, C.byref(tot), C.byref(mx))
+                      cnts.view(0, 1).p, off.p, C.byref(tot), C.byref(mx), C.byref(deferred))
         flat = {k: DeviceArray(self.ctx, tot.value, dt) for k, dt in FOOTPRINT_FLAT_FIELDS}
         bar = {k: DeviceArray(self.ctx, nb, dt) for k, dt in FOOTPRINT_BAR_FIELDS}
         fst = FootprintOut(**{k: v.ptr for k, v in {**flat, **bar}.items()})
-        # pass 2: the footprints
-        self.ctx.call("fmk_comp_bar_footprints_fill_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64),
+        # pass 2: the footprints (+ the median of the amounts each wave has just swept)
+        self.ctx.call("fmk_comp_bar_footprints_fill_median_dev", self.price.p, self.amount.p, C.c_int(self.amount_is_f64),
                       c_i64(self.n), close_idx.p, c_i64(close_idx.n), self.side.p, c_f64(price_tick_size), o["low"].p,
-                      c_f64(imbalance_factor), off.p, c_i64(mx.value), C.byref(fst), cnts.view(1, 1).p)
+                      c_f64(imbalance_factor), off.p, c_i64(mx.value), C.byref(fst), cnts.view(1, 1).p,
+                      med if deferred.value else None)
         return o, d, cnts.view(0, 1), off, flat, bar, cnts.view(1, 1)
 
     # ------------------------------------------------------------------ tick-level features

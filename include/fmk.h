@@ -242,6 +242,23 @@ int fmk_bars_flow_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_am
                            double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume, double *d_vwap,
                            int64_t *d_trades, double *d_median /* may be NULL */, const fmk_directional_out *d_dir,
                            int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels, int64_t *max_levels);
+/* cfg 4 at 26 B/tick (round 3): the same first pass, but the median trade size of comp_bar_ohlcv (base.py:401-404) may be left
+ * to the footprint sweep, whose waves hold every amount of their bar anyway -- no pass of its own over the amount column.
+ * *median_deferred = 1: nothing was written to d_median, the caller passes it to fmk_comp_bar_footprints_fill_median_dev;
+ * 0: d_median is complete (float64 amounts, very short / very long bars) and the plain fill call follows. */
+int fmk_bars_flow_size_defer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n,
+                                 const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side, double price_tick_size,
+                                 double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                                 double *d_vwap, int64_t *d_trades, double *d_median, const fmk_directional_out *d_dir,
+                                 int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels, int64_t *max_levels,
+                                 int *median_deferred);
+/* comp_bar_footprints' fill phase (as fmk_comp_bar_footprints_fill_dev) that ALSO writes the per-bar median trade size
+ * (float32 amounts only; d_median NULL = the plain fill). */
+int fmk_comp_bar_footprints_fill_median_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
+                                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
+                                            double price_tick_size, const double *d_bar_lows, double imbalance_factor,
+                                            const int64_t *d_level_offsets, int64_t max_levels,
+                                            const fmk_footprint_out *d_out, int64_t *d_n_bad_level, double *d_median);
 
 /* ---- tick-level feature loops: finmlkit/feature/core ---------------------------------- */
 /* comp_lagged_returns (core/utils.py:12-64). */
@@ -399,6 +416,8 @@ int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t str
  * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
  * 3 non-finite return, -1 not tried).  Not used by any product path. */
 int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
+/* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
+int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
 /* ... and into how many LATER segments that walk split the two sides' chains (0: each side walked in one piece); a segment
  * starts at a chunk boundary from which the side's state provably does not depend on earlier ticks (k_cc_sync).  *rate: the
  * estimate the tier was chosen by (512-tick sub-blocks per chunk and side of the leading chunks with a certain close; -1: none). */

@@ -119,3 +119,48 @@ def test_fused_bad_level_and_errors(orc):
     assert bad == 0
     woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.05, o["low"], o["high"], 3.0)
     _check_fp(off, flat, bar, woff, wflat, wbar, "tick 0.05")
+
+
+@pytest.mark.parametrize("n,interval,amounts", [
+    (400_000, 60.0, "dyadic"), (300_000, 60.0, "lognormal32"),
+    (300_000, 60.0, "ties"),        # a size most trades share: the degenerate bracket (blo == bhi, no candidate list)
+    (300_000, 60.0, "two_values"),  # the two middle ranks straddle two heavy ties
+    (300_000, 60.0, "drift"),       # the size distribution doubles every few bars: bracket misses -> generic selection
+    (200_000, 60.0, "nan"),         # NaN sizes: np.median is NaN for those bars
+    (300_000, 150.0, "dyadic"),     # 3 000-tick bars: beyond the in-sweep limit, flagged for the long-bar median kernels
+    (60_000, 13.0, "lognormal32"),  # 260-tick bars
+])
+def test_fused_median_taken_by_the_footprint_sweep(orc, monkeypatch, n, interval, amounts):
+    """FMK_FLOW_MEDIAN_DEFER=1 (off by default, profiles/r03_cfg4.txt): pass 1 leaves the median trade size to the footprint sweep
+    (fmk_bars_flow_size_defer_dev -> fmk_comp_bar_footprints_fill_median_dev), which brackets the middle ranks from the wave's
+    previous bar and selects them exactly among the candidates -- np.median's bits whatever the bracket does."""
+    monkeypatch.setenv("FMK_FLOW_LANES", "2")
+    monkeypatch.setenv("FMK_FLOW_MEDIAN_DEFER", "1")
+    monkeypatch.setenv("FMK_FP_MED_BLOCKS", "2")        # 8 waves: every wave carries its bracket over ~30 bars
+    ts, px, am, sd = orc.synth(23, 0, n)
+    rng = np.random.default_rng(5)
+    if amounts == "lognormal32":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    elif amounts == "ties":
+        am = np.where(rng.random(n) < 0.7, np.float32(0.001), rng.lognormal(-3, 2.0, n)).astype(np.float32)
+    elif amounts == "two_values":
+        am = np.where(rng.random(n) < 0.5, np.float32(0.25), np.float32(0.5)).astype(np.float32)
+    elif amounts == "drift":
+        am = (rng.lognormal(-1, 0.3, n) * 2.0 ** (np.arange(n) // 9_000 % 7)).astype(np.float32)
+    elif amounts == "nan":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+        am[rng.integers(0, n, 40)] = np.nan
+    _, ci = orc._time_bar_indexer(ts, interval)
+    from finmlkit_amd import _ffi
+    from finmlkit_amd._ffi import c_i64
+    import ctypes as C
+    t, cid, o, d, nz, off, flat, bar, bad = _fused(px, am, sd, ci)
+    want = orc.comp_bar_ohlcv(px, am, ci)
+    np.testing.assert_array_equal(o["median_trade_size"], want[7])          # NaN positions included
+    fb = c_i64()
+    t.ctx.call("fmk_diag_fp_median_fallbacks", C.byref(fb))
+    print(f"{amounts} @ {interval:g} s: {fb.value} of {len(ci) - 1} bars took the generic selection")
+    if amounts in ("dyadic", "lognormal32", "ties") and interval == 60.0:
+        assert fb.value <= 8 + (len(ci) - 1) // 20              # the bracket is accepted after each wave's first bar
+    if amounts != "nan":
+        _check_all(orc, px, am, sd, ci, f"deferred median {amounts}")

@@ -18,4 +18,7 @@ for name, tr in (("dyadic amounts", t), ("full-mantissa amounts", t2)):
     for _ in range(5):
         ctx.sync(); t0 = time.perf_counter(); r = tr.bars_fused(ci, 0.01, 3.0); ctx.sync()
         best = min(best, (time.perf_counter() - t0) * 1e3); del r
-    print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms (separate={os.environ.get('FMK_FLOW_SEPARATE', '0')})", flush=True)
+    fb = c_i64()
+    ctx.call("fmk_diag_fp_median_fallbacks", C.byref(fb))
+    print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms (separate={os.environ.get('FMK_FLOW_SEPARATE', '0')}, "
+          f"median deferred to the footprint sweep={os.environ.get('FMK_FLOW_MEDIAN_DEFER', '0')}, bracket misses {fb.value} of {ci.n - 1} bars)", flush=True)
