@@ -206,6 +206,21 @@ def other_configs(trades, ctx, args):
             "fmk_comp_bar_trade_size_dev", trades.amount.p, C.c_int(trades.amount_is_f64), c_i64(n), o60["median_trade_size"].p,
             ci.p, c_i64(ci.n), C.c_double(5.0), *[k.p for k in keys4]))
         del o60, keys4
+        # the reference's ONE published benchmark through this build's API, host-resident NumPy columns, H2D copy included
+        # (examples/PerformanceTest.ipynb cells 12-14: 39 171 929 trades -> 44 640 one-minute bars, 0.1728 s warm with Numba)
+        try:
+            from tools import apibench
+            ab = apibench.run(reps=3, ctx=ctx)
+            out["api_39M_build_ohlcv_ms"] = ab["warm_ms"]
+            out["api_39M_build_ohlcv_cold_ms"] = ab["cold_ms"]
+            out["h2d_GBps"] = ab["h2d_GBps"]
+            out["h2d_box_GBps"] = ab["box_h2d_GBps"]
+            out["api_39M_note"] = ("TimeBarKit(trades, 1 min).build_ohlcv() from host NumPy columns (float32 amounts), wall time incl. "
+                                   f"the upload of {ab['upload_bytes'] / 1e6:.0f} MB (timestamp, price, amount) and the DataFrame; "
+                                   "reference published 172.8 ms warm / 1896 ms cold (Numba, its author's machine): context, not a "
+                                   "same-host comparison")
+        except Exception as e:                                           # noqa: BLE001
+            out["api_39M_error"] = f"{type(e).__name__}: {e}"
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only

@@ -221,6 +221,19 @@ class DeviceArray:
             pass
 
 
+def upload_columns(ctx: Context, arrays):
+    """Host arrays -> new DeviceArrays by ONE fmk_h2d_columns call (worker threads, pinned staging: csrc/fmk_upload.hip)."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    dev = [DeviceArray(ctx, a.size, a.dtype) for a in arrays]
+    n = len(arrays)
+    if n:
+        dst = (c_vp * n)(*[d.ptr for d in dev])
+        src = (c_vp * n)(*[a.ctypes.data for a in arrays])
+        nb = (C.c_size_t * n)(*[a.nbytes for a in arrays])
+        ctx.call("fmk_h2d_columns", C.c_int(n), dst, src, nb)
+    return dev
+
+
 _default_ctx = None
 
 

@@ -56,9 +56,11 @@ class BarBuilderBase(ABC):
         if self._dev is None:
             from ..engine import DeviceTrades
             df = self.trades_df
-            side = df["side"].values.astype(np.int8) if "side" in df.columns else None
-            self._dev = DeviceTrades.from_numpy(df["timestamp"].astype(np.int64).values, df["price"].values,
-                                                df["amount"].values, side)
+            # .values of a frame column is a view; from_numpy converts only what is not already int64 / float64 / float32 / int8
+            side = df["side"].values if "side" in df.columns else None
+            # the side column travels when a builder first needs it: build_ohlcv (the reference's published benchmark) does not
+            self._dev = DeviceTrades.from_numpy(df["timestamp"].values, df["price"].values, df["amount"].values, side,
+                                                lazy_side=True)
         return self._dev
 
     @abstractmethod

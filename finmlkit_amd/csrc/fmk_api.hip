@@ -93,6 +93,7 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     fmk_volume_trim(ctx);
     fmk_dollar_trim(ctx);
     fmk_threshold_trim(ctx);
+    fmk_upload_trim(ctx);
     (void)hipFree(ctx->d_mail);
     (void)hipHostFree(ctx->h_mail);
     (void)hipEventDestroy(ctx->ev0);
@@ -111,6 +112,7 @@ int fmk_ctx_trim(fmk_ctx *ctx)
     fmk_volume_trim(ctx);
     fmk_dollar_trim(ctx);
     fmk_threshold_trim(ctx);
+    fmk_upload_trim(ctx);
     return FMK_OK;
 }
 

@@ -38,6 +38,8 @@ struct fmk_ctx {
     // cache is marked stale, so a later allocation that recycles the address for other data cannot hit it
     const void *idx_key[3][2];
     int idx_stale[3];
+    // pinned staging buffers / streams of fmk_h2d_columns (fmk_upload.hip), made on first use
+    void *upload;
 };
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);
@@ -46,6 +48,7 @@ int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out);
 void fmk_volume_trim(fmk_ctx *ctx);
 void fmk_dollar_trim(fmk_ctx *ctx);
 void fmk_threshold_trim(fmk_ctx *ctx);
+void fmk_upload_trim(fmk_ctx *ctx);
 
 // fmk_footprint.hip: footprint fill launches for the level classes wider than `lmin_start` (0: all bars)
 int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,

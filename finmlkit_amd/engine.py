@@ -29,20 +29,39 @@ class DeviceTrades:
 
     def __init__(self, ctx: Context, ts: DeviceArray, price: DeviceArray, amount: DeviceArray,
                  side: Optional[DeviceArray]):
-        self.ctx, self.ts, self.price, self.amount, self.side = ctx, ts, price, amount, side
+        self.ctx, self.ts, self.price, self.amount, self._side = ctx, ts, price, amount, side
+        self._side_host = None
         self.n = price.n
         self.amount_is_f64 = int(amount.dtype == np.float64)
 
+    @property
+    def side(self) -> Optional[DeviceArray]:
+        """The side column; with from_numpy(..., lazy_side=True) it is uploaded when something first asks for it (build_ohlcv,
+        the threshold indexers and the tick-level features never do)."""
+        if self._side is None and self._side_host is not None:
+            self._side = DeviceArray.from_host(self.ctx, self._side_host)
+            self._side_host = None
+        return self._side
+
+    @side.setter
+    def side(self, v):
+        self._side, self._side_host = v, None
+
     # ------------------------------------------------------------------ constructors
     @classmethod
-    def from_numpy(cls, ts, price, amount, side=None, ctx: Optional[Context] = None) -> "DeviceTrades":
+    def from_numpy(cls, ts, price, amount, side=None, ctx: Optional[Context] = None, lazy_side: bool = False) -> "DeviceTrades":
         ctx = ctx or _ffi.default_context()
         am, _ = _ffi.amount_array(amount)
-        return cls(ctx,
-                   DeviceArray.from_host(ctx, np.ascontiguousarray(ts, dtype=np.int64)),
-                   DeviceArray.from_host(ctx, np.ascontiguousarray(price, dtype=np.float64)),
-                   DeviceArray.from_host(ctx, am),
-                   None if side is None else DeviceArray.from_host(ctx, np.ascontiguousarray(side, dtype=np.int8)))
+        # np.ascontiguousarray / asarray copy only when the dtype or the layout differs (a frame's columns arrive as they are)
+        host = [np.ascontiguousarray(ts, dtype=np.int64), np.ascontiguousarray(price, dtype=np.float64), am]
+        sd = None if side is None else np.ascontiguousarray(side, dtype=np.int8)
+        if sd is not None and not lazy_side:
+            host.append(sd)
+        dev = _ffi.upload_columns(ctx, host)      # ONE call for the frame (csrc/fmk_upload.hip)
+        t = cls(ctx, dev[0], dev[1], dev[2], dev[3] if len(dev) > 3 else None)
+        if sd is not None and lazy_side:
+            t._side_host = sd                     # a reference to the caller's column (or its int8 copy); uploaded on first use
+        return t
 
     @classmethod
     def synth(cls, n: int, seed: int = 42, first: int = 0, gap_mod: int = DENSE_GAP_MOD,

@@ -72,6 +72,11 @@ int fmk_free(fmk_ctx *ctx, void *dptr);
 int fmk_memset(fmk_ctx *ctx, void *dptr, int value, size_t bytes);
 int fmk_h2d(fmk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* sync */
 int fmk_d2h(fmk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* sync */
+/* Several host columns to the device by one call (a TradesData frame -> HBM), complete on return.  Default: each column through
+ * the runtime's own pageable copy (56 GB/s = 98 % of the pinned rate on the MI355X boxes, profiles/r03_apibench.txt);
+ * FMK_UPLOAD_THREADS=n in the environment: n worker threads stage 4 MiB chunks through their own pinned double buffers and
+ * streams instead (for hosts whose runtime copies pageable memory through one bounce buffer). */
+int fmk_h2d_columns(fmk_ctx *ctx, int n_cols, void *const *dst_dev, const void *const *src_host, const size_t *bytes);
 int fmk_d2d(fmk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* async */
 int fmk_mem_info(fmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 
@@ -415,6 +420,9 @@ int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t str
 /* Which tier the last fmk_cusum_bar_indexer[_dev] call of this process took (tests): *tier 1 = the chain walk of
  * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
  * 3 non-finite return, -1 not tried).  Not used by any product path. */
+/* host-to-device rate of this box for one buffer, GB/s, best of three: mode 1 = hipMemcpy from pinned memory (the link's ceiling),
+ * 0 = hipMemcpy from pageable memory, 2 = fmk_h2d_columns from pageable memory */
+int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps);
 int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
 /* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
 int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
