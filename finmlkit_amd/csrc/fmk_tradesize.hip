@@ -14,8 +14,12 @@
 // tolerance in tests/test_gpu_next.py).
 #include <math.h>
 
+#include <utility>
+
 #include "fmk_median.h"
 #include "fmk_pairwise.h"
+#include "fmk_dpp.h"
+#include "fmk_scan.h"
 
 template <bool AF64, int NREG>
 __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t start, int64_t cnt, int lane,
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
                                                         const double *__restrict__ theta,
                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                         double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
-                                                        float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done)
+                                                        float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done,
+                                                        const unsigned long long *__restrict__ only = nullptr)
 {
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
@@ -121,7 +126,10 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     K *buf = sbuf[wib];
-    for (int64_t b = wave0; b < nb; b += nwaves) {
+    // `only` (list mode: [0] = count, [32...] = bar numbers): the bars the lane-per-bar / row-per-bar schedules left to this one
+    const int64_t todo = only ? (int64_t)only[0] : nb;
+    for (int64_t it = wave0; it < todo; it += nwaves) {
+        const int64_t b = only ? fmk_uniform((int64_t)only[32 + it]) : it;
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e_raw = fmk_uniform(ci[b + 1]);
         // The reference takes the bar as a SLICE, amounts[start:end + 1] (base.py:590): an end index past the array is
@@ -229,6 +237,509 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE LANE PER BAR (round 3, float32 amounts): streams of very short bars -- the reference's other caller builds 1-second bars
+// (bar/io.py:484-485: ~20 ticks).  The wave-per-bar kernel above spends a wave, three passes, a cross-lane selection and the
+// pairwise-tree machinery on 20 numbers: 91 ms per 1e9 ticks of 1-second bars (profiles/r02_next_rows.txt).  Here a wave takes
+// the next <= 64 whole bars whose amounts fit its LDS tile (coalesced fill, 4 B/tick -- the loader of k_bar_ohlcv_lanes) and lane l
+// runs the reference's statements for bar l on its own registers:
+//   * np.sum / np.mean of the float32 slice: NumPy's pairwise sum of n <= 64 elements IS its leaf -- the plain loop for n < 8,
+//     eight accumulators over the elements 8k + i folded ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the n % 8 tail otherwise --
+//     which one lane evaluates in NumPy's order; the same for sum((a / total)^2) (base.py:609);
+//   * block volume: float64 sum of the float32 sizes above the threshold (exact in any order; base.py:599-603 with the typed
+//     float64 accumulator);
+//   * np.percentile(., 95): the lane's keys through the fixed sorting network of fmk_ohlcv.hip's lane kernel (lb_sort), the two
+//     order statistics picked by index, NumPy's float32 lerp as in ts_percentile95.
+// Bars of more than 64 ticks, with irregular close indices (below -1 / beyond the column: Python slice semantics) or not fitting
+// the tile go on a list for the wave-per-bar kernel (list mode).
+// ---------------------------------------------------------------------------------------------------------------------
+#define TSL_TILE 2048
+#define TSL_WAVES 2
+
+// bitonic sorting network on N registers of ONE lane (every index a template constant: the keys stay in VGPRs)
+template <int I, int J, int K, int N>
+__device__ __forceinline__ void tsl_ce(uint32_t (&r)[N])
+{
+    constexpr int l = I ^ J;
+    if constexpr (l > I) {
+        const uint32_t a = r[I], b = r[l];
+        const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+        if constexpr ((I & K) == 0) { r[I] = mn; r[l] = mx; }
+        else { r[I] = mx; r[l] = mn; }
+    }
+}
+template <int J, int K, int N, int... I>
+__device__ __forceinline__ void tsl_stage(uint32_t (&r)[N], std::integer_sequence<int, I...>) { (tsl_ce<I, J, K, N>(r), ...); }
+template <int J, int K, int N>
+__device__ __forceinline__ void tsl_js(uint32_t (&r)[N])
+{
+    tsl_stage<J, K, N>(r, std::make_integer_sequence<int, N>{});
+    if constexpr (J > 1) tsl_js<J / 2, K, N>(r);
+}
+template <int K, int N>
+__device__ __forceinline__ void tsl_ks(uint32_t (&r)[N])
+{
+    tsl_js<K / 2, K, N>(r);
+    if constexpr (K < N) tsl_ks<K * 2, N>(r);
+}
+template <int N>
+__device__ __forceinline__ void tsl_sort(uint32_t (&r)[N]) { tsl_ks<2, N>(r); }
+template <int N, int... I>
+__device__ __forceinline__ uint32_t tsl_pick_seq(const uint32_t (&r)[N], int idx, std::integer_sequence<int, I...>)
+{
+    uint32_t v = r[0];
+    ((v = idx == I ? r[I] : v), ...);
+    return v;
+}
+template <int N>
+__device__ __forceinline__ uint32_t tsl_pick(const uint32_t (&r)[N], int idx) { return tsl_pick_seq<N>(r, idx, std::make_integer_sequence<int, N>{}); }
+
+// NumPy's pairwise leaf of f(a[0..L)) for one lane, L <= N: blocks of eight elements, all lanes in lockstep up to the wave's
+// longest bar (Lmax, wave-uniform); `at(i)` gives element i of the lane's bar (LDS), idle slots are not touched
+template <int N, class F>
+__device__ __forceinline__ float tsl_leaf(F val, int L, int Lmax)
+{
+    const int nm = L - (L & 7);
+    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float small = 0.f;                                                 // n < 8: res = 0; res += a[i]
+#pragma unroll
+    for (int K = 0; K < N / 8; ++K) {
+        if (8 * K < Lmax) {                                            // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = 8 * K + q;
+                const bool in_tree = i < nm;
+                const float v = i < L ? val(i) : 0.f;
+                if (K == 0) { r[q] = in_tree ? v : r[q]; if (L < 8 && i < L) small += v; }
+                else r[q] = in_tree ? r[q] + v : r[q];
+            }
+        }
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    if (L < 8) return small;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {                                      // the n % 8 tail, in order
+        const int i = nm + q;
+        if (i < L) res += val(i);
+    }
+    return res;
+}
+
+template <int N>
+__device__ __forceinline__ void tsl_bar(const uint32_t *ta, int off, int L, double thr, float &mean_rel, float &p95_rel, float &pct,
+                                        float &gini)
+{
+    typedef MedKey<false> MK;
+    const int Lmax = fmk_dpp_reduce(L, 0, FmkOpMax());
+    const float *fa = (const float *)ta + off;
+    // ---- total (np.sum of the float32 slice), block volume, keys
+    const float tf = tsl_leaf<N>([fa](int i) { return fa[i]; }, L, Lmax);
+    uint32_t r[N];
+    double block = 0.0;
+#pragma unroll
+    for (int K = 0; K < N / 8; ++K) {
+        if (8 * K < Lmax) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = 8 * K + q;
+                const uint32_t raw = i < L ? ta[off + i] : 0u;
+                r[i] = i < L ? MK::tokey(raw) : MK::MAXK;
+                const double a = (double)__uint_as_float(raw);
+                block += (i < L && a > thr) ? a : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[8 * K + q] = MK::MAXK;
+        }
+    }
+    const double mean = (double)(tf / (float)L);                       // np.mean of a float32 slice divides in float32
+    const double sum = (double)tf;
+    mean_rel = (float)log1p(mean / thr);
+    // ---- np.percentile(., 95), every step in float32 (ts_percentile95)
+    tsl_sort<N>(r);
+    const float vi = (float)(L - 1) * (95.0f / 100.0f);
+    const int fl = (int)floorf(vi);
+    const int k1 = fl < L - 1 ? fl : L - 1;
+    const int k2 = k1 + 1 < L ? k1 + 1 : L - 1;
+    const uint32_t v1 = tsl_pick<N>(r, k1), v2 = tsl_pick<N>(r, k2);
+    const uint32_t kmx = tsl_pick<N>(r, L > 0 ? L - 1 : 0), kmn = r[0];
+    double p95;
+    if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) p95 = NAN;     // a NaN size: np.percentile is NaN
+    else {
+        const float a32 = (float)MK::value(v1), b32 = (float)MK::value(v2);
+        if (vi >= (float)(L - 1)) p95 = (double)b32;
+        else {
+            const float t32 = vi - floorf(vi), d32 = b32 - a32;
+            float r32 = a32 + d32 * t32;
+            if (t32 >= 0.5f) r32 = b32 - d32 * (1.0f - t32);
+            p95 = (double)r32;
+        }
+    }
+    p95_rel = (float)log1p(p95 / thr);
+    // ---- pct_block, size_gini (base.py:597-609)
+    pct = NAN; gini = NAN;
+    const bool have_total = sum != 0.0;
+    const float g = tsl_leaf<N>([fa, tf](int i) { const float q = fa[i] / tf; return q * q; }, L, Lmax);
+    if (have_total) {
+        pct = (float)(block / sum);
+        gini = L == 1 ? 0.f : 1.0f - g;
+    }
+}
+
+__global__ __launch_bounds__(64 * TSL_WAVES) void k_bar_trade_size_lanes(const float *__restrict__ amount,
+                                                                       const double *__restrict__ theta,
+                                                                       const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                       double theta_mult, float *__restrict__ o_mean,
+                                                                       float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                       float *__restrict__ o_gini,
+                                                                       unsigned long long *__restrict__ grp_mask,
+                                                                       int64_t *__restrict__ grp_cnt)
+{
+    __shared__ uint32_t s_a[TSL_WAVES][TSL_TILE + 2];
+    __shared__ int64_t s_ci[TSL_WAVES][66];
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    uint32_t *ta = s_a[w];
+    const int64_t ngroups = (nb + 63) >> 6;
+    const int64_t nwaves = (int64_t)gridDim.x * TSL_WAVES;
+    for (int64_t g = (int64_t)blockIdx.x * TSL_WAVES + w; g < ngroups; g += nwaves) {
+        const int64_t B0 = g * 64;
+        const int nbg = (int)(nb - B0 < 64 ? nb - B0 : 64);
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= nbg) s_ci[w][lane] = ci[B0 + lane];
+        if (lane == 0 && nbg == 64) s_ci[w][64] = ci[B0 + 64];
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long rest = 0;                                   // bars of this group left to the wave-per-bar kernel
+        // a group whose close indices are not an ascending run inside the column goes to the wave kernel whole
+        {
+            const bool valid = lane < nbg;
+            const int64_t s_l = valid ? s_ci[w][lane] : 0, e_l = valid ? s_ci[w][lane + 1] : 0;
+            const bool bad = valid && !(s_l >= -1 && e_l >= s_l && e_l <= n - 1);
+            if (__ballot(bad) != 0) {
+                rest = nbg == 64 ? ~0ULL : ((1ULL << nbg) - 1);
+                if (lane == 0) { grp_mask[g] = rest; grp_cnt[g] = __popcll(rest); }
+                continue;
+            }
+        }
+        int bl = 0;
+        while (bl < nbg) {
+            const int64_t s0 = s_ci[w][bl];
+            const int idx = bl + 1 + lane;
+            const bool valid = idx <= nbg;
+            const int64_t e_l = valid ? s_ci[w][idx] : INT64_MAX;
+            const int64_t s_l = valid ? s_ci[w][idx - 1] : 0;
+            const int m = __popcll(__ballot(valid && e_l - s0 <= TSL_TILE));    // closes ascend: a prefix of the lanes
+            if (m == 0) { rest |= 1ULL << bl; bl += 1; continue; }              // one bar longer than the tile
+            const int ntick = (int)(s_ci[w][bl + m] - s0);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t *ga = (const uint32_t *)amount + s0 + 1;
+#pragma unroll 4
+            for (int j = lane; j < ntick; j += 64) ta[j] = ga[j];
+            __builtin_amdgcn_wave_barrier();
+            const bool owner = lane < m;
+            const int L = owner ? (int)(e_l - s_l) : 0;
+            const int64_t b = B0 + bl + lane;
+            const double th = owner ? theta[b] : 0.0;
+            const bool mine = owner && L > 0 && L <= 64;
+            const uint64_t longer = __ballot(owner && L > 64);
+            rest |= (unsigned long long)longer << bl;
+            const int off = mine ? (int)(s_l - s0) : 0;
+            const int Lw = mine ? L : 0;
+            const double thr = th * theta_mult;
+            float mean_rel = NAN, p95_rel = NAN, pct = NAN, gini = NAN;          // base.py:576-579
+            if (__ballot(Lw > 32) != 0) tsl_bar<64>(ta, off, Lw, thr, mean_rel, p95_rel, pct, gini);
+            else if (__ballot(Lw > 16) != 0) tsl_bar<32>(ta, off, Lw, thr, mean_rel, p95_rel, pct, gini);
+            else tsl_bar<16>(ta, off, Lw, thr, mean_rel, p95_rel, pct, gini);
+            if (owner && L <= 64) {
+                const bool live = L > 0 && th != 0.0;                            // base.py:584-587: empty bar / theta == 0 -> NaN row
+                o_mean[b] = live ? mean_rel : NAN;
+                o_p95[b] = live ? p95_rel : NAN;
+                o_pct[b] = live ? pct : NAN;
+                o_gini[b] = live ? gini : NAN;
+            }
+            bl += m;
+        }
+        if (lane == 0) { grp_mask[g] = rest; grp_cnt[g] = __popcll(rest); }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SIXTEEN LANES PER BAR (round 3, float32 amounts): bars of up to 256 ticks (10-second bars: ~200 ticks), four bars per wave.
+// The wave-per-bar kernel needs ~34 000 cycles for such a bar (three passes, the tree walk of fmk_pairwise_big, a 64-lane
+// selection): 17.5 ms per 1e9 ticks of 10-second bars.  A row of 16 lanes is exactly what NumPy's tree of a <= 256-element sum needs:
+//   * n <= 128 is ONE leaf -- eight accumulators r_i over the elements 8k + i: lanes 0..7 of the row are the accumulators, each adds
+//     its <= 16 elements in order, the fold ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is three DPP butterflies (quad_perm, quad_perm,
+//     row_half_mirror: a + b in either operand order is the same float), the n % 8 tail follows;
+//   * 128 < n <= 256 is TWO leaves (n2 = n/2 rounded down to a multiple of 8, and the rest): lanes 8..15 take the right one,
+//     left + right by one more butterfly (row_mirror);
+//   * the 95th percentile: the row holds the bar's keys, 16 per lane; a bisection on the key VALUE with row-wide counts
+//     (16 compares + four DPP adds per step) finds the smallest key v with count(key <= v) > k1, one more pass gives its successor;
+//   * block volume: float64 sum of float32 sizes, exact in any order.
+// The four bars of a wave are consecutive, so their amounts are one contiguous range: a coalesced fill of the wave's LDS tile.
+// Bars of more than 256 ticks, groups that do not fit the tile, irregular close indices: the leftover list (wave per bar).
+// ---------------------------------------------------------------------------------------------------------------------
+#define TSR_WAVES 4
+#define DPP_XOR1 0xB1            // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E            // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141    // lane i <-> 7 - i inside each half row
+#define DPP_MIRROR 0x140         // lane i <-> 15 - i inside each row
+
+__device__ __forceinline__ float tsr_dpp_f(float v, int which)
+{
+    const int x = __float_as_int(v);
+    int y;
+    switch (which) {
+    case 1: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR1, 0xF, 0xF, false); break;
+    case 2: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR2, 0xF, 0xF, false); break;
+    case 4: y = __builtin_amdgcn_update_dpp(x, x, DPP_HALF_MIRROR, 0xF, 0xF, false); break;
+    default: y = __builtin_amdgcn_update_dpp(x, x, DPP_MIRROR, 0xF, 0xF, false); break;
+    }
+    return __int_as_float(y);
+}
+__device__ __forceinline__ int tsr_row_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR2, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_HALF_MIRROR, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_MIRROR, 0xF, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t tsr_row_umin(uint32_t v)
+{
+    uint32_t w;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
+    return v;
+}
+__device__ __forceinline__ uint32_t tsr_row_umax(uint32_t v)
+{
+    uint32_t w;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
+    return v;
+}
+__device__ __forceinline__ double tsr_row_sum(double v)
+{
+    v += fmk_dpp<DPP_XOR1, 0xF>(v, v);
+    v += fmk_dpp<DPP_XOR2, 0xF>(v, v);
+    v += fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v);
+    v += fmk_dpp<DPP_MIRROR, 0xF>(v, v);
+    return v;
+}
+
+// NumPy's pairwise sum of f(a[0..L)), L <= 256, by one row (result in every lane of the row).  steps: wave-uniform bound of the
+// accumulator chains (ceil(longest leaf / 8)).
+template <class F>
+__device__ __forceinline__ float tsr_pairwise(F val, int L, int ri, int steps)
+{
+    // the row's (<= 2) leaves
+    int n2 = L / 2;
+    n2 -= n2 % 8;
+    const bool two = L > 128;
+    const int half = ri >> 3, j = ri & 7;
+    const int hoff = (two && half) ? n2 : 0;
+    const int hlen = two ? (half ? L - n2 : n2) : (half ? 0 : L);
+    const int nm = hlen - (hlen & 7);
+    float r = j < nm ? val(hoff + j) : 0.f;
+    for (int k = 1; k < steps; ++k) {
+        const int i = 8 * k + j;
+        if (i < nm) r += val(hoff + i);
+    }
+    float res = r + tsr_dpp_f(r, 1);
+    res = res + tsr_dpp_f(res, 2);
+    res = res + tsr_dpp_f(res, 4);
+    if (hlen < 8) {                                                    // n < 8: res = 0; res += a[i]
+        res = 0.f;
+        for (int i = 0; i < 7; ++i)
+            if (i < hlen) res += val(hoff + i);
+    } else {
+        for (int q = 0; q < 7; ++q)                                    // the n % 8 tail, in order
+            if (nm + q < hlen) res += val(hoff + nm + q);
+    }
+    const float other = tsr_dpp_f(res, 8);                             // the other half row's leaf
+    const float left = half ? other : res, right = half ? res : other;
+    return two ? left + right : left;
+}
+
+__global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const float *__restrict__ amount,
+                                                                      const double *__restrict__ theta,
+                                                                      const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                      double theta_mult, float *__restrict__ o_mean,
+                                                                      float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                      float *__restrict__ o_gini,
+                                                                      const unsigned long long *__restrict__ only,
+                                                                      unsigned long long *__restrict__ rest_out)
+{
+    typedef MedKey<false> MK;
+    __shared__ uint32_t s_a[TSR_WAVES][4][256];                        // a row's bar
+    __shared__ unsigned long long s_left[TSR_WAVES][64];               // bars this wave leaves to the wave-per-bar kernel
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int row = lane >> 4, ri = lane & 15;
+    uint32_t *ta = s_a[w][row];
+    const float *fb = (const float *)ta;
+    unsigned long long *left = s_left[w];
+    int n_left = 0;                                                    // wave-uniform
+    // `only` (list mode: [0] = count, [32...] = bar numbers): the bars the lane-per-bar schedule left over
+    const int64_t todo = only ? (int64_t)only[0] : nb;
+    const int64_t niter = (todo + 3) >> 2;
+    const int64_t nwaves = (int64_t)gridDim.x * TSR_WAVES;
+    auto flush = [&]() {
+        if (n_left == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(rest_out, (unsigned long long)n_left);
+        base = (unsigned long long)fmk_uniform((int64_t)base);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_left) rest_out[32 + base + lane] = left[lane];
+        __builtin_amdgcn_wave_barrier();
+        n_left = 0;
+    };
+    for (int64_t it = (int64_t)blockIdx.x * TSR_WAVES + w; it < niter; it += nwaves) {
+        const int64_t q = 4 * it + row;                                // four bars per wave, one per row of 16 lanes
+        const bool have = q < todo;
+        const int64_t b = have ? (only ? (int64_t)only[32 + q] : q) : 0;
+        const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
+        const bool regular = s_b >= -1 && e_b >= s_b && e_b <= n - 1;
+        const int64_t len_b = e_b - s_b;
+        const bool mine = have && regular && len_b <= 256;             // (an empty bar too: its NaN row)
+        // ---- the others: remembered, handed on in blocks of up to 64
+        {
+            const uint64_t lo = __ballot(have && !mine && ri == 0);    // lanes 0, 16, 32, 48 speak for their rows
+            if (lo) {
+                const int pos = n_left + __popcll(lo & ((1ULL << lane) - 1));
+                if (have && !mine && ri == 0) left[pos] = (unsigned long long)b;
+                n_left += __popcll(lo);
+                __builtin_amdgcn_wave_barrier();
+                if (n_left > 60) flush();
+            }
+        }
+        if (__ballot(mine) == 0) continue;
+        const int L = mine ? (int)len_b : 0;
+        // ---- the row's bar into its quarter of the tile (16 lanes, 64 B segments)
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint32_t *ga = (const uint32_t *)amount + s_b + 1;
+            const int Lmax = fmk_dpp_reduce(L, 0, FmkOpMax());
+            for (int i0 = 0; i0 < Lmax; i0 += 16)
+                if (i0 + ri < L) ta[i0 + ri] = ga[i0 + ri];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double th = have ? theta[b] : 0.0;
+        const double thr = th * theta_mult;
+        // chains: the longest leaf of the wave, in steps of eight
+        const int leaf = L > 128 ? L - (L / 2 - (L / 2) % 8) : L;
+        const int steps = (fmk_dpp_reduce(leaf, 0, FmkOpMax()) + 7) >> 3;
+        const float tf = tsr_pairwise([fb](int i) { return fb[i]; }, L, ri, steps);
+        // ---- keys (16 per lane: element r * 16 + ri in key[r]), block volume
+        uint32_t key[16];
+        double block = 0.0;
+        uint32_t kmn = MK::MAXK, kmx = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = r * 16 + ri;
+            const uint32_t raw = i < L ? ta[i] : 0u;
+            key[r] = i < L ? MK::tokey(raw) : MK::MAXK;
+            const double a = (double)__uint_as_float(raw);
+            block += (i < L && a > thr) ? a : 0.0;
+            kmn = key[r] < kmn ? key[r] : kmn;
+            kmx = (i < L && key[r] > kmx) ? key[r] : kmx;
+        }
+        block = tsr_row_sum(block);
+        kmn = tsr_row_umin(kmn);
+        kmx = tsr_row_umax(kmx);
+        // ---- the two order statistics of np.percentile(., 95)
+        const float vi = (float)(L - 1) * (95.0f / 100.0f);
+        const int fl = (int)floorf(vi);
+        const int k1 = fl < L - 1 ? fl : L - 1;
+        const int k2 = k1 + 1 < L ? k1 + 1 : L - 1;
+        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + 15) >> 4;  // registers that hold keys anywhere in the wave
+        // smallest v in [kmn, kmx] with count(key <= v) > k1: invariant c_lo = count(<= lo) <= k1 < count(<= hi) = c_hi.  Once
+        // exactly ONE key is left in (lo, hi] it is the answer (a masked maximum) -- ~log2(L) + 2 steps instead of the ~26 a
+        // bisection of the key range down to one value takes; only a tied target runs the bisection to its end
+        uint32_t lo = kmn - 1, hi = kmx;                               // (lo = kmn - 1 counts 0 keys; a wrap at kmn == 0 is a NaN bar)
+        int c_lo = 0, c_hi = L;
+        for (int step = 0; step < 32; ++step) {
+            const bool open = L > 0 && hi - lo > 1 && c_hi - c_lo > 1;
+            if (__ballot(open) == 0) break;
+            const uint32_t pivot = lo + ((hi - lo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r < nreg) c += key[r] <= pivot ? 1 : 0;
+            c = tsr_row_sum(c);
+            if (open) { if (c > k1) { hi = pivot; c_hi = c; } else { lo = pivot; c_lo = c; } }
+        }
+        if (L > 0 && hi - lo > 1) {                                    // one key in (lo, hi]: find it
+            uint32_t only_key = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) only_key = (key[r] > lo && key[r] <= hi && key[r] > only_key) ? key[r] : only_key;
+            hi = tsr_row_umax(only_key);
+        }
+        const uint32_t v1 = hi;
+        int c1 = 0;
+        uint32_t nxt = MK::MAXK;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            c1 += key[r] <= v1 ? 1 : 0;
+            nxt = (key[r] > v1 && key[r] < nxt) ? key[r] : nxt;
+        }
+        c1 = tsr_row_sum(c1);
+        nxt = tsr_row_umin(nxt);
+        const uint32_t v2 = (c1 > k2 || k2 == k1) ? v1 : nxt;
+        double p95;
+        if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) p95 = NAN;   // a NaN size
+        else {
+            const float a32 = (float)MK::value(v1), b32 = (float)MK::value(v2);
+            if (vi >= (float)(L - 1)) p95 = (double)b32;
+            else {
+                const float t32 = vi - floorf(vi), d32 = b32 - a32;
+                float r32 = a32 + d32 * t32;
+                if (t32 >= 0.5f) r32 = b32 - d32 * (1.0f - t32);
+                p95 = (double)r32;
+            }
+        }
+        // ---- results (base.py:591-609)
+        const double mean = (double)(tf / (float)L), sum = (double)tf;
+        const float gsum = tsr_pairwise([fb, tf](int i) { const float qq = fb[i] / tf; return qq * qq; }, L, ri, steps);
+        // ONE log1p evaluation serves both columns: lane 0 of the row takes the mean, lane 1 the percentile
+        const float lg = (float)log1p((ri == 0 ? mean : p95) / thr);
+        const bool live = L > 0 && th != 0.0;
+        if (mine && ri == 0) {
+            float pct = NAN, gini = NAN;
+            if (live && sum != 0.0) {
+                pct = (float)(block / sum);
+                gini = L == 1 ? 0.f : 1.0f - gsum;
+            }
+            o_mean[b] = live ? lg : NAN; o_pct[b] = pct; o_gini[b] = gini;
+        }
+        if (mine && ri == 1) o_p95[b] = live ? lg : NAN;
+    }
+    flush();
+}
+
+// list of the bars the lane kernel left over: rest[0] = count (from the scan's total), rest[32 + pos[g] + k] = the k-th set bit of group g
+static __global__ __launch_bounds__(256) void k_tsl_compact(const unsigned long long *__restrict__ grp_mask,
+                                                            const int64_t *__restrict__ pos, int64_t groups,
+                                                            unsigned long long *__restrict__ rest)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) rest[0] = (unsigned long long)pos[groups];
+    if (g >= groups) return;
+    unsigned long long m = grp_mask[g];
+    int64_t at = 32 + pos[g];
+    while (m) {
+        const int bit = __builtin_ctzll(m);
+        rest[at++] = (unsigned long long)(g * 64 + bit);
+        m &= m - 1;
+    }
+}
+
 extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
                                            const double *d_theta, const int64_t *d_close_idx, int64_t n_idx,
                                            double theta_mult, float *d_mean_size_rel, float *d_size_95_rel,
@@ -248,6 +759,58 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
                                                                           d_pct_block, d_size_gini, 0);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
+    }
+    // Streams of short bars: one lane per bar (bars up to 64 ticks) and / or sixteen lanes per bar (up to 256 ticks) first, each
+    // handing the bars it cannot take to the next schedule through a list; the wave-per-bar kernel sees what is left.
+    // Developer knob FMK_TS_LANES: 0 never, 2 lanes -> rows -> waves whenever the layout allows, 3 rows -> waves.
+    {
+        const char *lv = getenv("FMK_TS_LANES");
+        const int mode = lv ? atoi(lv) : 1;
+        const bool many = nb >= (int64_t)ctx->n_cu * 64;
+        const bool use_lanes = mode == 2 || (mode == 1 && many && n / nb <= 56);
+        const bool use_rows = use_lanes || mode == 3 || (mode == 1 && many && n / nb <= 224);
+        if (mode != 0 && ((uintptr_t)d_amount & 3) == 0 && use_rows) {
+            const int64_t groups = fmk_ceil_div(nb, 64);
+            unsigned long long *rest = nullptr, *rest2 = nullptr, *grp_mask = nullptr;
+            int64_t *grp_cnt = nullptr;
+            int arc = fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest2);
+            if (arc == FMK_OK && use_lanes) arc = fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest);
+            if (arc == FMK_OK && use_lanes) arc = fmk_alloc(ctx, (size_t)groups * 8, (void **)&grp_mask);
+            if (arc == FMK_OK && use_lanes) arc = fmk_alloc(ctx, (size_t)(groups + 1) * 8, (void **)&grp_cnt);
+            hipError_t le = hipSuccess;
+            if (arc == FMK_OK) le = hipMemsetAsync(rest2, 0, 8, ctx->stream);
+            if (arc == FMK_OK && le == hipSuccess && use_lanes) {
+                int64_t lb = fmk_ceil_div(groups, TSL_WAVES);
+                const int64_t lcap = (int64_t)ctx->n_cu * 32;
+                if (lb > lcap) lb = lcap;
+                k_bar_trade_size_lanes<<<(unsigned)lb, 64 * TSL_WAVES, 0, ctx->stream>>>(
+                    (const float *)d_amount, d_theta, d_close_idx, nb, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
+                    d_size_gini, grp_mask, grp_cnt);
+                arc = fmk_exclusive_scan_i64(ctx, grp_cnt, grp_cnt, groups, true);
+                if (arc == FMK_OK)
+                    k_tsl_compact<<<(unsigned)fmk_ceil_div(groups, 256), 256, 0, ctx->stream>>>(grp_mask, grp_cnt, groups, rest);
+            }
+            if (arc == FMK_OK && le == hipSuccess) {
+                int64_t rb = use_lanes ? (int64_t)ctx->n_cu * 8 : fmk_ceil_div(fmk_ceil_div(nb, 4), TSR_WAVES);
+                if (rb > (int64_t)ctx->n_cu * 16) rb = (int64_t)ctx->n_cu * 16;
+                if (rb < 1) rb = 1;
+                k_bar_trade_size_rows<<<(unsigned)rb, 64 * TSR_WAVES, 0, ctx->stream>>>(
+                    (const float *)d_amount, d_theta, d_close_idx, nb, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
+                    d_size_gini, use_lanes ? rest : nullptr, rest2);
+                // what is left: wave per bar (their percentile by the in-kernel search; a long bar re-reads itself per step)
+                k_bar_trade_size<false><<<(unsigned)(ctx->n_cu * 16), 256, 0, ctx->stream>>>(
+                    d_amount, d_theta, d_close_idx, nb, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini, 0,
+                    rest2);
+            }
+            if (le == hipSuccess) le = hipGetLastError();
+            if (rest) (void)fmk_free(ctx, rest);
+            if (rest2) (void)fmk_free(ctx, rest2);
+            if (grp_mask) (void)fmk_free(ctx, grp_mask);
+            if (grp_cnt) (void)fmk_free(ctx, grp_cnt);
+            FMK_TRY(arc);
+            FMK_HIP(ctx, le);
+            return FMK_OK;
+        }
     }
     // float32 amounts: the percentile of the bars beyond the register classes first (256 threads per bar up to 8192 ticks, 1024 beyond)
     int64_t *list_mid = nullptr, *list_long = nullptr;

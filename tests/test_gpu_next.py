@@ -82,3 +82,47 @@ def test_trade_size_kit_and_errors(orc):
         comp_bar_trade_size_features(am64, theta[:-1], ci, 3.0)
     with pytest.raises(ValueError, match="Theta should match"):
         kit.build_trade_size_features(theta[:-1])
+
+
+@pytest.mark.parametrize("interval,amounts", [(1.0, "dyadic"), (1.0, "lognormal32"), (2.5, "lognormal32"), (0.3, "lognormal32"),
+                                              (1.0, "nan"), (400.0, "ties"), (10.0, "lognormal32"), (10.0, "nan"),
+                                              (7.0, "dyadic")])
+@pytest.mark.parametrize("mode", ["2", "0", "3"])
+def test_trade_size_one_lane_per_bar(orc, monkeypatch, interval, amounts, mode):
+    """Short float32 bars through the lane-per-bar schedule (FMK_TS_LANES=2 forces it whatever the number of bars; 3 = sixteen
+    lanes per bar, bars up to 256 ticks; 0 = the wave-per-bar kernel alone): NumPy's pairwise leaf, float32 percentile and the float64 block sum evaluated by ONE lane per bar
+    give the oracle's bits -- bars of 0 .. 64 ticks, longer ones and irregular close indices through the leftover list, theta == 0
+    rows, NaN sizes, heavy ties; and the two schedules agree with each other."""
+    from finmlkit_amd import engine
+    monkeypatch.setenv("FMK_TS_LANES", mode)
+    n = 120_000
+    ts, px, am, sd = orc.synth(29, 0, n, orc.SPARSE_GAP_MOD if interval == 400.0 else orc.DENSE_GAP_MOD)
+    rng = np.random.default_rng(11)
+    if amounts != "dyadic":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    if amounts == "nan":
+        am[rng.integers(0, n, 300)] = np.nan
+    if amounts == "ties":
+        am = np.where(rng.random(n) < 0.6, np.float32(0.001), am).astype(np.float32)
+    _, ci = orc._time_bar_indexer(ts, interval)
+    ci = ci.copy()
+    nb = len(ci) - 1
+    # a few long bars inside the stream (merge neighbours), an end index past the column (slice clamp)
+    keep = np.ones(len(ci), bool)
+    keep[200:215] = False
+    keep[100:130] = False
+    keep[1000:1002] = False
+    if interval == 400.0:
+        keep[300:360] = False
+    ci = ci[keep]
+    ci[-1] = n + 3
+    nb = len(ci) - 1
+    theta = np.full(nb, float(np.nanmedian(am)))
+    theta[::97] = 0.0
+    want = orc.comp_bar_trade_size_features(am, theta, ci, 5.0)
+    t = engine.DeviceTrades.from_numpy(ts, px, am, sd)
+    got = t.bar_trade_size(engine.DeviceArray.from_host(t.ctx, ci), theta, 5.0)
+    for k, w in zip(KEYS, want):
+        np.testing.assert_array_equal(got[k], w, err_msg=f"{k} iv={interval} {amounts} mode={mode}")
+    assert np.diff(ci).max() > 64 and np.median(np.diff(ci)) < 256
+    assert interval != 400.0 or (np.diff(ci) == 0).any()
