@@ -91,3 +91,76 @@ __device__ __forceinline__ T fmk_dpp_shift_up1(T v, T first)
 {
     return fmk_dpp<FMK_DPP_WAVE_SHR1, 0xF>(first, v);
 }
+
+// ---- reductions inside a ROW of 16 lanes (four independent rows per wave), result in every lane of the row: xor butterflies on the
+// DPP data path -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (lane i <-> 7 - i: by then the quads are uniform),
+// row_mirror (i <-> 15 - i).  For a sum this is the balanced binary tree over the row's 16 values in lane order (a + b and b + a
+// are the same float), i.e. what fmk_dpp_reduce computes inside each row.
+#define DPP_XOR1 0xB1            // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E            // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141    // lane i <-> 7 - i inside each half row
+#define DPP_MIRROR 0x140         // lane i <-> 15 - i inside each row
+
+__device__ __forceinline__ float fmk_row_xor_f32(float v, int which)
+{
+    const int x = __float_as_int(v);
+    int y;
+    switch (which) {
+    case 1: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR1, 0xF, 0xF, false); break;
+    case 2: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR2, 0xF, 0xF, false); break;
+    case 4: y = __builtin_amdgcn_update_dpp(x, x, DPP_HALF_MIRROR, 0xF, 0xF, false); break;
+    default: y = __builtin_amdgcn_update_dpp(x, x, DPP_MIRROR, 0xF, 0xF, false); break;
+    }
+    return __int_as_float(y);
+}
+__device__ __forceinline__ int fmk_row_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR2, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_HALF_MIRROR, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_MIRROR, 0xF, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t fmk_row_umin(uint32_t v)
+{
+    uint32_t w;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
+    return v;
+}
+__device__ __forceinline__ uint32_t fmk_row_umax(uint32_t v)
+{
+    uint32_t w;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
+    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
+    return v;
+}
+__device__ __forceinline__ double fmk_row_sum(double v)
+{
+    v += fmk_dpp<DPP_XOR1, 0xF>(v, v);
+    v += fmk_dpp<DPP_XOR2, 0xF>(v, v);
+    v += fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v);
+    v += fmk_dpp<DPP_MIRROR, 0xF>(v, v);
+    return v;
+}
+
+__device__ __forceinline__ double fmk_row_max(double v)
+{
+    v = fmax(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_MIRROR, 0xF>(v, v));
+    return v;
+}
+__device__ __forceinline__ double fmk_row_min(double v)
+{
+    v = fmin(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_MIRROR, 0xF>(v, v));
+    return v;
+}

@@ -687,6 +687,137 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SIXTEEN LANES PER BAR (round 3, float32 amounts): streams of 33 .. 256-tick bars (2-second to 10-second bars), four bars per wave.
+// One wave per such bar leaves 44 of 64 lanes idle on a 20-tick chunk and pays a 64-lane reduction tree and a 64-lane selection per
+// bar; one LANE per bar (k_bar_ohlcv_lanes) needs a 64-key sorting network in registers: comp_bar_ohlcv with the median took 6.5 /
+// 9.4 / 8.1 / 6.6 ms per 1e9 ticks at 40 / 60 / 80 / 100-tick bars against 2.4 ms at 1 200 (profiles/r03_median_humps.txt).
+// Here a row of 16 lanes takes a bar: element i sits in lane i % 16, register i / 16 (sixteen coalesced loads per row and column,
+// all in flight together).  Sums keep the association of every other schedule -- the 64 "virtual lanes" v = i % 64 each add their
+// elements in chunk order, then the balanced tree over v (fmk_dpp_reduce): lane ri carries the virtual lanes ri, ri + 16, ri + 32,
+// ri + 48 as four accumulators, fmk_row_sum is the tree inside each virtual row, (T0 + T1) + (T2 + T3) its top -- so a bar gets the
+// same bits whichever schedule serves it (a sharded run equals the un-sharded one).  The median: bisection on the key VALUE with
+// row-wide counts until ONE key is left in the bracket (~log2(L) + 2 steps), as in k_bar_trade_size_rows.
+// Bars of more than 256 ticks are flagged for the generic kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+#define OHR_WAVES 4
+template <bool MEDIAN>
+__global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double *__restrict__ price, const float *__restrict__ amount,
+                                                                 const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                 int *__restrict__ saw_long, OhlcvOut o)
+{
+    typedef MedKey<false> MK;
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int row = lane >> 4, ri = lane & 15;
+    const int64_t niter = (nb + 3) >> 2;
+    const int64_t nwaves = (int64_t)gridDim.x * OHR_WAVES;
+    for (int64_t it = (int64_t)blockIdx.x * OHR_WAVES + w; it < niter; it += nwaves) {
+        const int64_t b = 4 * it + row;
+        const bool have = b < nb;
+        const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
+        const int64_t len_b = e_b - s_b;
+        const bool is_long = have && len_b > 256;
+        if (__ballot(is_long) != 0 && lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = have && len_b >= 1 && len_b <= 256;
+        if (have && len_b <= 0 && ri == 0) ohlcv_empty(o, b, price, e_b, n);          // base.py:352-361
+        if (__ballot(mine) == 0) continue;
+        const int L = mine ? (int)len_b : 0;
+        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + 15) >> 4;               // wave-uniform
+        const double *pb = price + (mine ? s_b + 1 : 0);
+        const uint32_t *ab = (const uint32_t *)amount + (mine ? s_b + 1 : 0);
+        // ---- every load of the four bars
+        double p[16];
+        uint32_t araw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = 0.0; araw[r] = 0u;
+            if (r < nreg) {
+                const int i = r * 16 + ri;
+                if (i < L) { p[r] = pb[i]; araw[r] = ab[i]; }
+            }
+        }
+        const double first = mine ? pb[0] : 0.0, lastp = mine ? pb[L - 1] : 0.0;      // (lines fetched anyway)
+        // ---- accumulation: virtual lane v = 16 * (r % 4) + ri, chunk r / 4
+        double hi = -INFINITY, lo = INFINITY, tv[4] = {0.0, 0.0, 0.0, 0.0}, td[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t key[MEDIAN ? 16 : 1];
+        uint32_t kmn = MK::MAXK, kmx = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < nreg) {
+                const bool valid = r * 16 + ri < L;
+                const double a = (double)__uint_as_float(araw[r]);
+                hi = valid ? fmax(hi, p[r]) : hi;
+                lo = valid ? fmin(lo, p[r]) : lo;
+                tv[r & 3] += valid ? a : 0.0;
+                td[r & 3] += valid ? p[r] * a : 0.0;
+                if constexpr (MEDIAN) {
+                    key[r] = valid ? MK::tokey(araw[r]) : MK::MAXK;
+                    kmn = key[r] < kmn ? key[r] : kmn;
+                    kmx = (valid && key[r] > kmx) ? key[r] : kmx;
+                }
+            } else if constexpr (MEDIAN) key[r] = MK::MAXK;
+        }
+        hi = fmk_row_max(hi);
+        lo = fmk_row_min(lo);
+        double T[4], D[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { T[k] = fmk_row_sum(tv[k]); D[k] = fmk_row_sum(td[k]); }
+        const double tvs = (T[0] + T[1]) + (T[2] + T[3]), tds = (D[0] + D[1]) + (D[2] + D[3]);
+        double med = 0.0;
+        if constexpr (MEDIAN) {
+            kmn = fmk_row_umin(kmn);
+            kmx = fmk_row_umax(kmx);
+            const int k1 = (L - 1) >> 1, k2 = L >> 1;
+            // smallest v with count(key <= v) > k1: invariant c_lo = count(<= lo) <= k1 < count(<= hi) = c_hi
+            uint32_t blo = kmn - 1, bhi = kmx;
+            int c_lo = 0, c_hi = L;
+            for (int step = 0; step < 32; ++step) {
+                const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > 1;
+                if (__ballot(open) == 0) break;
+                const uint32_t pivot = blo + ((bhi - blo) >> 1);
+                int c = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nreg) c += key[r] <= pivot ? 1 : 0;
+                c = fmk_row_sum(c);
+                if (open) { if (c > k1) { bhi = pivot; c_hi = c; } else { blo = pivot; c_lo = c; } }
+            }
+            if (L > 0 && bhi - blo > 1) {                                    // one key in (blo, bhi]: find it
+                uint32_t only_key = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) only_key = (key[r] > blo && key[r] <= bhi && key[r] > only_key) ? key[r] : only_key;
+                bhi = fmk_row_umax(only_key);
+            }
+            const uint32_t v1 = bhi;
+            int c1 = 0;
+            uint32_t nxt = MK::MAXK;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c1 += key[r] <= v1 ? 1 : 0;
+                nxt = (key[r] > v1 && key[r] < nxt) ? key[r] : nxt;
+            }
+            c1 = fmk_row_sum(c1);
+            nxt = fmk_row_umin(nxt);
+            const uint32_t v2 = (c1 > k2 || k2 == k1) ? v1 : nxt;
+            if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
+            else med = (L & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
+        }
+        if (mine && ri == 0) {
+            o.open[b] = first;
+            o.close[b] = lastp;
+            o.high[b] = first != first ? first : hi;                         // base.py:371-382: a NaN FIRST price never loses
+            o.low[b] = first != first ? first : lo;
+            o.vol[b] = (float)tvs;
+            o.vwap[b] = tvs > 0.0 ? tds / tvs : 0.0;                         // base.py:398
+            o.trades[b] = L;
+            if constexpr (MEDIAN) o.median[b] = med;
+        }
+    }
+}
+
 static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
@@ -737,13 +868,27 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     if (mid_max < 0) { const char *v = getenv("FMK_OHLCV_MID_MAX_MEAN"); mid_max = v ? atoi(v) : 210; }
     static int mid2_max = -1;                // FMK_OHLCV_MID2_MAX_MEAN: ... served by the <= 640-tick instantiation
     if (mid2_max < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2_max = v ? atoi(v) : 600; }
-    if (!AF64 && nb >= 64 && n / nb <= packed_max) {
+    const char *rv = getenv("FMK_OHLCV_ROWS");            // developer knob: 0 = without the sixteen-lanes-per-bar schedule
+    const int rows_on = rv ? atoi(rv) : 1;
+    static int rows_min = -1;                // FMK_OHLCV_ROWS_MIN_MEAN: mean ticks per bar from which rows replace the lane schedule
+    if (rows_min < 0) { const char *v = getenv("FMK_OHLCV_ROWS_MIN_MEAN"); rows_min = v ? atoi(v) : 65; }
+    if (!AF64 && nb >= 64 && n / nb <= packed_max && !(rows_on && n / nb >= rows_min)) {
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
         if (!o.median) k_bar_ohlcv_lanes<false, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_lanes<true, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         long_min = 64;
+    } else if (!AF64 && rows_on && nb >= 64 && n / nb <= mid_max) {
+        // streams of 65..256-tick bars (float32 amounts): sixteen lanes per bar, four bars per wave; longer bars are left
+        if constexpr (!AF64) {
+            int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 4), OHR_WAVES);
+            const int64_t cap = (int64_t)ctx->n_cu * 32;
+            if (blocks > cap) blocks = cap;
+            if (!o.median) k_bar_ohlcv_rows<false><<<(unsigned)blocks, 64 * OHR_WAVES, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+            else k_bar_ohlcv_rows<true><<<(unsigned)blocks, 64 * OHR_WAVES, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        }
+        long_min = 256;
     } else if (n / nb <= mid_max) {
         // streams of 65..256-tick bars: the instantiation without the long classes (eight waves per SIMD); longer bars are left
         int64_t blocks = fmk_ceil_div(nb, 4);

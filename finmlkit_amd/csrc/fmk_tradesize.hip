@@ -481,58 +481,6 @@ __global__ __launch_bounds__(64 * TSL_WAVES) void k_bar_trade_size_lanes(const f
 // Bars of more than 256 ticks, groups that do not fit the tile, irregular close indices: the leftover list (wave per bar).
 // ---------------------------------------------------------------------------------------------------------------------
 #define TSR_WAVES 4
-#define DPP_XOR1 0xB1            // quad_perm [1,0,3,2]
-#define DPP_XOR2 0x4E            // quad_perm [2,3,0,1]
-#define DPP_HALF_MIRROR 0x141    // lane i <-> 7 - i inside each half row
-#define DPP_MIRROR 0x140         // lane i <-> 15 - i inside each row
-
-__device__ __forceinline__ float tsr_dpp_f(float v, int which)
-{
-    const int x = __float_as_int(v);
-    int y;
-    switch (which) {
-    case 1: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR1, 0xF, 0xF, false); break;
-    case 2: y = __builtin_amdgcn_update_dpp(x, x, DPP_XOR2, 0xF, 0xF, false); break;
-    case 4: y = __builtin_amdgcn_update_dpp(x, x, DPP_HALF_MIRROR, 0xF, 0xF, false); break;
-    default: y = __builtin_amdgcn_update_dpp(x, x, DPP_MIRROR, 0xF, 0xF, false); break;
-    }
-    return __int_as_float(y);
-}
-__device__ __forceinline__ int tsr_row_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR1, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR2, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_HALF_MIRROR, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_MIRROR, 0xF, 0xF, false);
-    return v;
-}
-__device__ __forceinline__ uint32_t tsr_row_umin(uint32_t v)
-{
-    uint32_t w;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w < v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w < v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w < v ? w : v;
-    return v;
-}
-__device__ __forceinline__ uint32_t tsr_row_umax(uint32_t v)
-{
-    uint32_t w;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = w > v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = w > v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
-    w = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = w > v ? w : v;
-    return v;
-}
-__device__ __forceinline__ double tsr_row_sum(double v)
-{
-    v += fmk_dpp<DPP_XOR1, 0xF>(v, v);
-    v += fmk_dpp<DPP_XOR2, 0xF>(v, v);
-    v += fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v);
-    v += fmk_dpp<DPP_MIRROR, 0xF>(v, v);
-    return v;
-}
-
 // NumPy's pairwise sum of f(a[0..L)), L <= 256, by one row (result in every lane of the row).  steps: wave-uniform bound of the
 // accumulator chains (ceil(longest leaf / 8)).
 template <class F>
@@ -551,9 +499,9 @@ __device__ __forceinline__ float tsr_pairwise(F val, int L, int ri, int steps)
         const int i = 8 * k + j;
         if (i < nm) r += val(hoff + i);
     }
-    float res = r + tsr_dpp_f(r, 1);
-    res = res + tsr_dpp_f(res, 2);
-    res = res + tsr_dpp_f(res, 4);
+    float res = r + fmk_row_xor_f32(r, 1);
+    res = res + fmk_row_xor_f32(res, 2);
+    res = res + fmk_row_xor_f32(res, 4);
     if (hlen < 8) {                                                    // n < 8: res = 0; res += a[i]
         res = 0.f;
         for (int i = 0; i < 7; ++i)
@@ -562,7 +510,7 @@ __device__ __forceinline__ float tsr_pairwise(F val, int L, int ri, int steps)
         for (int q = 0; q < 7; ++q)                                    // the n % 8 tail, in order
             if (nm + q < hlen) res += val(hoff + nm + q);
     }
-    const float other = tsr_dpp_f(res, 8);                             // the other half row's leaf
+    const float other = fmk_row_xor_f32(res, 8);                             // the other half row's leaf
     const float left = half ? other : res, right = half ? res : other;
     return two ? left + right : left;
 }
@@ -650,9 +598,9 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
             kmn = key[r] < kmn ? key[r] : kmn;
             kmx = (i < L && key[r] > kmx) ? key[r] : kmx;
         }
-        block = tsr_row_sum(block);
-        kmn = tsr_row_umin(kmn);
-        kmx = tsr_row_umax(kmx);
+        block = fmk_row_sum(block);
+        kmn = fmk_row_umin(kmn);
+        kmx = fmk_row_umax(kmx);
         // ---- the two order statistics of np.percentile(., 95)
         const float vi = (float)(L - 1) * (95.0f / 100.0f);
         const int fl = (int)floorf(vi);
@@ -672,14 +620,14 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (r < nreg) c += key[r] <= pivot ? 1 : 0;
-            c = tsr_row_sum(c);
+            c = fmk_row_sum(c);
             if (open) { if (c > k1) { hi = pivot; c_hi = c; } else { lo = pivot; c_lo = c; } }
         }
         if (L > 0 && hi - lo > 1) {                                    // one key in (lo, hi]: find it
             uint32_t only_key = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) only_key = (key[r] > lo && key[r] <= hi && key[r] > only_key) ? key[r] : only_key;
-            hi = tsr_row_umax(only_key);
+            hi = fmk_row_umax(only_key);
         }
         const uint32_t v1 = hi;
         int c1 = 0;
@@ -689,8 +637,8 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
             c1 += key[r] <= v1 ? 1 : 0;
             nxt = (key[r] > v1 && key[r] < nxt) ? key[r] : nxt;
         }
-        c1 = tsr_row_sum(c1);
-        nxt = tsr_row_umin(nxt);
+        c1 = fmk_row_sum(c1);
+        nxt = fmk_row_umin(nxt);
         const uint32_t v2 = (c1 > k2 || k2 == k1) ? v1 : nxt;
         double p95;
         if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) p95 = NAN;   // a NaN size
