@@ -740,9 +740,6 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_dir(const double *__restri
     }
 }
 
-int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
-
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------

@@ -57,8 +57,10 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
                                 int64_t n_ticks /* 0: unknown */,
                                 double *d_median = nullptr /* float32 amounts: the median trade size from the same sweep */);
+// median of the bars of more than min_cnt ticks (flag d_go), except those of skip_lo < ticks <= skip_hi (served by k_bar_ohlcv_mid)
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo = 0,
+                      int64_t skip_hi = 0);
 
 // fmk_ohlcv.hip: pieces of comp_bar_ohlcv for cfg 4's first half (fmk_barflow.hip)
 int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,

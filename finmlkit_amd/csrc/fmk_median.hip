@@ -85,7 +85,8 @@ int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int6
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amount,
                                                     const int64_t *__restrict__ ci, int64_t nb, int64_t min_cnt,
-                                                    const int *__restrict__ go, double *__restrict__ o_median)
+                                                    const int *__restrict__ go, double *__restrict__ o_median,
+                                                    int64_t skip_lo = 0, int64_t skip_hi = 0)
 {
     if (go && *go == 0) return;                          // the fused small-bar kernel saw no long bar
     typedef typename MedKey<AF64>::K K;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
             const int64_t start = s + 1;
             const int nreg = (int)((cnt + 63) >> 6);
             if (cnt > ML_MIN(AF64)) return;                   // k_bar_median_long
+            if (cnt > skip_lo && cnt <= skip_hi) return;      // k_bar_ohlcv_mid wrote it
             else if (nreg <= 1) m = med_select<AF64, 1>(amount, start, cnt, lane, buf);
             else if (nreg <= 4) m = med_select<AF64, 4>(amount, start, cnt, lane, buf);
             else if (nreg <= 8) m = med_select<AF64, 8>(amount, start, cnt, lane, buf);
@@ -136,21 +138,22 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks)
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo, int64_t skip_hi)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (amount_is_f64)
-        k_bar_median<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
+        k_bar_median<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median, skip_lo, skip_hi);
     else
-        k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median);
+        k_bar_median<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_close_idx, nb, min_cnt, d_go, d_median, skip_lo, skip_hi);
     FMK_LAUNCH_CHECK(ctx);
     // bars beyond the register classes: a workgroup per bar, the bars from lists -- 256 threads for bars up to ML_MID_MAX ticks (eight
     // workgroups per CU: at 2 400-tick bars 1024 threads per bar left most of them waiting at the barriers, 12.9 ms per 1e9 ticks),
     // 1024 threads beyond (two per CU)
-    const int64_t lo_cnt = ML_MIN(amount_is_f64);
+    int64_t lo_cnt = ML_MIN(amount_is_f64);
+    if (skip_hi > lo_cnt && skip_lo <= lo_cnt) lo_cnt = skip_hi;      // the skipped range covers the start of the mid list
     int64_t *list_mid = nullptr, *list_long = nullptr;
     FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, lo_cnt, d_go, &list_mid, ML_MID_MAX));
     int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MID_MAX, d_go, &list_long);

@@ -35,9 +35,6 @@
 #define FMK_PACKED_MAX_MEAN 64          // mean ticks per bar up to which the lane-per-bar schedule is used (float32 amounts):
                                         // at 60 ticks 9.8 vs 12.6 ms for the wave-per-bar kernel, at 80 ticks 18.6 vs 12.0 (1e9 ticks)
 
-int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks);
-
 struct OhlcvOut {
     double *open, *high, *low, *close;
     float *vol;
@@ -195,7 +192,8 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ price,
                                                    const void *__restrict__ amount,
                                                    const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                   int64_t min_cnt, const int *__restrict__ go, OhlcvOut o)
+                                                   int64_t min_cnt, const int *__restrict__ go, OhlcvOut o,
+                                                   int64_t skip_lo = 0, int64_t skip_hi = 0)
 {
     if (go && *go == 0) return;                              // the small-bar kernel saw no long bar
     const int lane = fmk_lane();
@@ -208,6 +206,7 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv(const double *__restrict__ pr
             return;
         }
         if (e - s > OH_WIDE_MIN) return;                      // k_bar_ohlcv_wide: a workgroup per bar
+        if (e - s > skip_lo && e - s <= skip_hi) return;      // k_bar_ohlcv_mid: a workgroup per bar, median included
         const int64_t start = s + 1;
         double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
         int64_t j = start + lane;
@@ -818,6 +817,254 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bars of 1 345 .. 8 192 ticks (float32 amounts; round 3): ONE pass by a workgroup of 256 threads -- comp_bar_ohlcv AND the median.
+// Such bars (75-second, 2-minute, 5-minute bars on the bench tape) used to cost two to three passes: the generic streaming kernel
+// for open / high / low / close / volume / vwap, then k_bar_median's wave-per-bar register classes (<= 2 048 ticks) or
+// k_bar_median_long's three radix passes with LDS-atomic histograms -- 5.5 .. 7.7 ms per 1e9 ticks against 2.4 ms at 1 200-tick
+// bars (profiles/r03_median_humps.txt).  Here every thread keeps the keys of its <= 32 ticks in registers while the sums go by, and
+// the two middle ranks come from a bisection on the key VALUE range with block-wide counts (a ballot popcount per register and
+// wave, the four wave counts through LDS: one barrier per step) down to <= 64 candidates, which one wave sorts.
+// Sums: thread t adds its elements t, t + 256, ... in order, wave DPP trees, then the four wave totals in order -- volume is exact
+// in any order for float32 amounts, vwap a reassociated sum (<= 1e-9), like k_bar_ohlcv_wide.  The bars come from a list made from
+// their own lengths, so a bar takes this path whatever stream it is part of (a sharded run equals the un-sharded one).
+// ---------------------------------------------------------------------------------------------------------------------
+#define OHM_MIN (64 * FMK_SMALL_NCH)
+#define OHM_MAX 8192
+#define OHM_THREADS 256
+struct OhmShared {
+    double red[4][4];
+    uint32_t kmn[4], kmx[4];
+    int cnt[2][4];
+    uint32_t below[2][4], above[2][4];
+    int ncand[4];
+    uint32_t buf[64];
+};
+
+template <bool MEDIAN, int NREG>
+__device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const float *__restrict__ amount, int64_t b, int64_t s,
+                                        int64_t e, const OhlcvOut &o, OhmShared &sh)
+{
+    typedef MedKey<false> MK;
+    const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
+    const int64_t start = s + 1;
+    const int cnt = (int)(e - s);
+    const double *pb = price + start;
+    const uint32_t *ab = (const uint32_t *)amount + start;
+    const unsigned last = (unsigned)(cnt - 1);
+    double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+    uint32_t key[MEDIAN ? NREG : 1];
+    uint32_t kmn = MK::MAXK, kmx = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < NREG; r0 += 4) {                           // four loads of each column in flight
+        double p[4];
+        uint32_t araw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned idx = (unsigned)((r0 + q) * OHM_THREADS + tid);
+            idx = idx < last ? idx : last;
+            p[q] = pb[idx];
+            araw[q] = ab[idx];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool valid = (unsigned)((r0 + q) * OHM_THREADS + tid) <= last;
+            const double a = (double)__uint_as_float(araw[q]);
+            hi = fmax(hi, p[q]);                                     // clamped duplicates cannot change max / min
+            lo = fmin(lo, p[q]);
+            tv += valid ? a : 0.0;
+            td += valid ? p[q] * a : 0.0;
+            if constexpr (MEDIAN) {
+                const uint32_t k = valid ? MK::tokey(araw[q]) : MK::MAXK;
+                key[r0 + q] = k;
+                kmn = k < kmn ? k : kmn;
+                kmx = (valid && k > kmx) ? k : kmx;
+            }
+        }
+    }
+    hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
+    lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
+    tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
+    td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+    if constexpr (MEDIAN) { kmn = med_wave_umin<uint32_t>(kmn); kmx = med_wave_umax<uint32_t>(kmx); }
+    __syncthreads();                                                 // (the previous bar's shared values have been read)
+    if (lane == 0) {
+        sh.red[0][w] = hi; sh.red[1][w] = lo; sh.red[2][w] = tv; sh.red[3][w] = td;
+        if constexpr (MEDIAN) { sh.kmn[w] = kmn; sh.kmx[w] = kmx; }
+    }
+    __syncthreads();
+    if (w == 0) {
+        hi = fmax(fmax(sh.red[0][0], sh.red[0][1]), fmax(sh.red[0][2], sh.red[0][3]));
+        lo = fmin(fmin(sh.red[1][0], sh.red[1][1]), fmin(sh.red[1][2], sh.red[1][3]));
+        tv = ((sh.red[2][0] + sh.red[2][1]) + sh.red[2][2]) + sh.red[2][3];
+        td = ((sh.red[3][0] + sh.red[3][1]) + sh.red[3][2]) + sh.red[3][3];
+        ohlcv_finish<false>(o, b, price, start, e, hi, lo, tv, td, lane, true);
+    }
+    if constexpr (MEDIAN) {
+        // ---- the two middle ranks: every thread walks the same (block-uniform) bisection
+        uint32_t mn = sh.kmn[0], mx = sh.kmx[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { mn = sh.kmn[k] < mn ? sh.kmn[k] : mn; mx = sh.kmx[k] > mx ? sh.kmx[k] : mx; }
+        const int k1 = (cnt - 1) >> 1, k2 = cnt >> 1;
+        uint32_t v1 = 0, v2 = 0;
+        const bool isnan = mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF;
+        if (!isnan) {
+            // invariant: count(key <= blo) = clo <= k1  and  count(key <= bhi) = chi > k2
+            uint32_t blo = mn - 1, bhi = mx;
+            int clo = 0, chi = cnt, par = 0;
+            bool done = false;
+            while (!done) {
+                if (chi - clo <= 64) {
+                    // <= 64 candidates in (blo, bhi]: wave by wave into the line, one wave sorts
+                    int mine = 0;
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) mine += med_popc(key[r] > blo && key[r] <= bhi);
+                    if (lane == 0) sh.ncand[w] = mine;
+                    if (tid < 64) sh.buf[tid] = MK::MAXK;
+                    __syncthreads();
+                    int base = 0;
+                    for (int k = 0; k < w; ++k) base += sh.ncand[k];
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        const bool in = key[r] > blo && key[r] <= bhi;
+                        const uint64_t m = __ballot(in);
+                        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        if (in) sh.buf[pos] = key[r];
+                        base += __popcll(m);
+                    }
+                    __syncthreads();
+                    if (w == 0) {
+                        const uint32_t v = med_bitonic64<uint32_t>(sh.buf[lane], lane);
+                        v1 = __shfl(v, k1 - clo, 64);
+                        v2 = __shfl(v, k2 - clo, 64);
+                    }
+                    done = true;
+                } else if (bhi - blo == 1) { v1 = v2 = bhi; done = true; }       // all candidates are the same key
+                else {
+                    const uint32_t pivot = blo + ((bhi - blo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) c += med_popc(key[r] <= pivot);
+                    if (lane == 0) sh.cnt[par][w] = c;
+                    __syncthreads();
+                    c = (sh.cnt[par][0] + sh.cnt[par][1]) + (sh.cnt[par][2] + sh.cnt[par][3]);
+                    par ^= 1;
+                    if (c > k2) { bhi = pivot; chi = c; }
+                    else if (c <= k1) { blo = pivot; clo = c; }
+                    else {
+                        // k1 < c <= k2: the pivot separates the two ranks -- largest key <= pivot, smallest key > pivot
+                        uint32_t a = 0, bb = MK::MAXK;
+#pragma unroll
+                        for (int r = 0; r < NREG; ++r) {
+                            const uint32_t k = key[r];
+                            a = (k <= pivot && k > a) ? k : a;
+                            bb = (k > pivot && k < bb) ? k : bb;
+                        }
+                        a = med_wave_umax<uint32_t>(a);
+                        bb = med_wave_umin<uint32_t>(bb);
+                        if (lane == 0) { sh.below[0][w] = a; sh.above[0][w] = bb; }
+                        __syncthreads();
+                        v1 = sh.below[0][0]; v2 = sh.above[0][0];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) {
+                            v1 = sh.below[0][k] > v1 ? sh.below[0][k] : v1;
+                            v2 = sh.above[0][k] < v2 ? sh.above[0][k] : v2;
+                        }
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (tid == 0) o.median[b] = isnan ? (double)NAN : (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
+    }
+}
+
+template <bool MEDIAN>
+__global__ __launch_bounds__(OHM_THREADS) void k_bar_ohlcv_mid(const double *__restrict__ price, const float *__restrict__ amount,
+                                                              const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                              const int *__restrict__ go, OhlcvOut o)
+{
+    if (go && *go == 0) return;
+    __shared__ OhmShared sh;
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
+        const int64_t cnt = e - s;
+        if (cnt <= 2048) ohm_bar<MEDIAN, 8>(price, amount, b, s, e, o, sh);
+        else if (cnt <= 4096) ohm_bar<MEDIAN, 16>(price, amount, b, s, e, o, sh);
+        else ohm_bar<MEDIAN, 32>(price, amount, b, s, e, o, sh);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bars of 1 345 .. 4 096 ticks (float32 amounts; round 3): still ONE WAVE per bar and one pass, the keys of the whole bar in
+// registers (32 or 64 per lane), the loads in phases of 16 chunks so that the price registers are reused.  k_bar_ohlcv_small stops
+// at 21 chunks (its up-front loads hold the 1-minute kernel at four waves per SIMD); beyond it the bars took the generic streaming
+// kernel plus a median kernel of their own -- 75-second bars 6.1 ms per 1e9 ticks against 2.4 ms for 60-second bars.  The
+// workgroup-per-bar kernel above pays ~15 000 cycles of barriers and reductions per bar, which only bars beyond ~4 000 ticks
+// amortise (profiles/r03_median_humps.txt).  Same per-lane order and tree as every wave-per-bar schedule: identical bits.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool MEDIAN, int NKEY, int PH>
+__global__ __launch_bounds__(256) void k_bar_ohlcv_phased(const double *__restrict__ price, const float *__restrict__ amount,
+                                                          const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                          const int *__restrict__ go, OhlcvOut o)
+{
+    if (go && *go == 0) return;
+    typedef MedKey<false> MK;
+    __shared__ uint32_t sbuf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    uint32_t *buf = sbuf[wib];
+    const int64_t n_list = list[0];
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wib; q < n_list; q += nwaves) {
+        const int64_t b = fmk_uniform(list[1 + q]);
+        const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
+        const int64_t start = s + 1, cnt = e - s;
+        const int nch = (int)((cnt + 63) >> 6);
+        const double *pb = price + start;
+        const uint32_t *ab = (const uint32_t *)amount + start;
+        const unsigned last = (unsigned)(cnt - 1);
+        double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+        MedBar<false, (MEDIAN ? NKEY : 1), false> bar;
+#pragma unroll
+        for (int ph = 0; ph < NKEY / PH; ++ph) {
+            if (ph * PH < nch) {                                       // wave-uniform
+                double p[PH];
+                uint32_t araw[PH];
+#pragma unroll
+                for (int c = 0; c < PH; ++c) {
+                    unsigned idx = (unsigned)((ph * PH + c) * 64 + lane);
+                    idx = idx < last ? idx : last;
+                    p[c] = pb[idx];
+                    araw[c] = ab[idx];
+                }
+#pragma unroll
+                for (int c = 0; c < PH; ++c) {
+                    const bool valid = (unsigned)((ph * PH + c) * 64 + lane) <= last;
+                    const double a = (double)__uint_as_float(araw[c]);
+                    hi = fmax(hi, p[c]);                               // clamped duplicates cannot change max / min
+                    lo = fmin(lo, p[c]);
+                    tv += valid ? a : 0.0;
+                    td += valid ? p[c] * a : 0.0;
+                    if constexpr (MEDIAN) bar.key[ph * PH + c] = valid ? MK::tokey(araw[c]) : MK::MAXK;
+                }
+            } else if constexpr (MEDIAN) {
+#pragma unroll
+                for (int c = 0; c < PH; ++c) bar.key[ph * PH + c] = MK::MAXK;
+            }
+        }
+        ohlcv_finish<false>(o, b, price, start, e, hi, lo, tv, td, lane);
+        if constexpr (MEDIAN) {
+            bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
+            const double m = med_search<false, NKEY, false>(bar, buf);
+            if (lane == 0) o.median[b] = m;
+        }
+    }
+}
+
 static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
@@ -909,15 +1156,54 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
-    // long bars (if any): the generic kernels exit at once when the flag is clear
-    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o);
+    // long bars (if any): the generic kernels exit at once when the flag is clear.  float32 bars of 1 345 .. 8 192 ticks: one pass by
+    // a workgroup each, median included (developer knob FMK_OHLCV_MID=0: the generic kernels + the median kernels as before)
+    int64_t skip_lo = 0, skip_hi = 0;
+    if constexpr (!AF64) {
+        const char *mv = getenv("FMK_OHLCV_MID");
+        if (!mv || atoi(mv)) {
+            skip_lo = OHM_MIN;
+            skip_hi = OHM_MAX;
+            // 1 345 .. 2 048, .. 3 072, .. 4 096, .. 6 144 ticks: a wave per bar with 32 / 48 / 64 / 96 key registers; 6 145 .. 8 192: a workgroup per bar
+            int64_t *list[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const int64_t edge[6] = {OHM_MIN, 2048, 3072, 4096, 6144, OHM_MAX};
+            int rc = FMK_OK;
+            for (int k = 0; k < 5 && rc == FMK_OK; ++k) rc = fmk_long_bar_list(ctx, ci, nb, n, edge[k], saw_long, &list[k], edge[k + 1]);
+            // measured per 1e9 ticks, ohlcv + median (profiles/r03_median_humps.txt): 4 400 / 5 200 / 6 000-tick bars 3.6 / 3.4 / 3.1 ms
+            // with 96 key registers per lane against 5.1 / 4.5 / 4.0 ms by the workgroup kernel; 7 000 / 8 000-tick bars 5.5 / 5.2 ms
+            // with 128 key registers (spills) against 3.6 / 3.3 ms by the workgroup kernel
+            if (rc == FMK_OK) {
+                const float *af = (const float *)a;
+                const unsigned g = (unsigned)(ctx->n_cu * 8);
+                if (o.median) {
+                    k_bar_ohlcv_phased<true, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
+                    k_bar_ohlcv_phased<true, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
+                    k_bar_ohlcv_phased<true, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
+                    k_bar_ohlcv_phased<true, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
+                    k_bar_ohlcv_mid<true><<<g, OHM_THREADS, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                } else {
+                    k_bar_ohlcv_phased<false, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
+                    k_bar_ohlcv_phased<false, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
+                    k_bar_ohlcv_phased<false, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
+                    k_bar_ohlcv_phased<false, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
+                    k_bar_ohlcv_mid<false><<<g, OHM_THREADS, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                }
+            }
+            const hipError_t le = hipGetLastError();
+            for (int k = 0; k < 5; ++k)
+                if (list[k]) (void)fmk_free(ctx, list[k]);
+            FMK_TRY(rc);
+            FMK_HIP(ctx, le);
+        }
+    }
+    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o, skip_lo, skip_hi);
     FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o));
     FMK_LAUNCH_CHECK(ctx);
     if (AF64) {
         k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
         FMK_LAUNCH_CHECK(ctx);
     }
-    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n);
+    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n, skip_lo, skip_hi);
     return FMK_OK;
 }
 
