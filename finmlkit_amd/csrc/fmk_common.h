@@ -60,7 +60,9 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
 // median of the bars of more than min_cnt ticks (flag d_go), except those of skip_lo < ticks <= skip_hi (served by k_bar_ohlcv_mid)
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo = 0,
-                      int64_t skip_hi = 0);
+                      int64_t skip_hi = 0, int64_t skip_above = INT64_MAX /* bars of more ticks were served elsewhere */);
+// the workgroup radix select (k_bar_median_long, 1024 threads) on a given list ([0] = count, then bar numbers), float32 amounts
+int fmk_median_long_list_launch(fmk_ctx *ctx, const void *d_amount, const int64_t *d_close_idx, const int64_t *d_list, double *d_median);
 
 // fmk_ohlcv.hip: pieces of comp_bar_ohlcv for cfg 4's first half (fmk_barflow.hip)
 int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int amount_is_f64, const int64_t *ci, int64_t nb,

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_bar_median(const void *__restrict__ amo
 }
 
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
-                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo, int64_t skip_hi)
+                      int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo, int64_t skip_hi,
+                      int64_t skip_above)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
     const int64_t cap = (int64_t)ctx->n_cu * 64;
@@ -156,7 +157,7 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
     if (skip_hi > lo_cnt && skip_lo <= lo_cnt) lo_cnt = skip_hi;      // the skipped range covers the start of the mid list
     int64_t *list_mid = nullptr, *list_long = nullptr;
     FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, lo_cnt, d_go, &list_mid, ML_MID_MAX));
-    int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MID_MAX, d_go, &list_long);
+    int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, ML_MID_MAX > lo_cnt ? ML_MID_MAX : lo_cnt, d_go, &list_long, skip_above);
     if (rc == FMK_OK) {
         if (amount_is_f64) {
             k_bar_median_long<true, 256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(d_amount, d_close_idx, list_mid, d_go, d_median);
@@ -171,6 +172,14 @@ int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, con
     if (list_long) (void)fmk_free(ctx, list_long);
     FMK_TRY(rc);
     FMK_HIP(ctx, le);
+    return FMK_OK;
+}
+
+int fmk_median_long_list_launch(fmk_ctx *ctx, const void *d_amount, const int64_t *d_close_idx, const int64_t *d_list, double *d_median)
+{
+    k_bar_median_long<false, ML_THREADS><<<(unsigned)(ctx->n_cu * 2), ML_THREADS, 0, ctx->stream>>>(d_amount, d_close_idx, d_list, nullptr,
+                                                                                              d_median);
+    FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
 

@@ -126,18 +126,56 @@ __global__ __launch_bounds__(256) void k_bar_vol_redo(const double *__restrict__
 // a reassociated sum (<= 1e-9).  The bars are found like in the leftover pass above: 64 close indices per coalesced load.
 #define OH_WIDE_MIN 16384
 #define OH_WIDE_THREADS 1024
-template <bool AF64>
+struct OhlBracket;
+struct OhlCount;
+template <bool AF64, bool MED = false>
 __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double *__restrict__ price, const void *__restrict__ amount,
                                                                    const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
-                                                                   const int *__restrict__ go, OhlcvOut o)
+                                                                   const int *__restrict__ go, OhlcvOut o,
+                                                                   const uint32_t *__restrict__ brk = nullptr /* OhlBracket[] */,
+                                                                   uint32_t *__restrict__ cand = nullptr,
+                                                                   int64_t *__restrict__ res = nullptr /* OhlCount[] */)
 {
     if (go && *go == 0) return;
     __shared__ double s_red[4][OH_WIDE_THREADS / 64];
+    __shared__ int s_ncand;
+    __shared__ int64_t s_below[OH_WIDE_THREADS / 64];
+    __shared__ int s_nan;
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
     const int64_t n_list = list[0];
     for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
         const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1], start = s + 1;
         double hi = -INFINITY, lo = INFINITY, tv = 0.0, td = 0.0;
+        // MED: the sizes inside the bracket go to the bar's candidate slots, the keys below it are counted (float32 amounts)
+        uint32_t blo = 0, bhi = 0;
+        int64_t below = 0;
+        bool nan = false;
+        uint32_t *mycand = nullptr;
+        int cap = 0;
+        if constexpr (MED) {
+            blo = brk[4 * q]; bhi = brk[4 * q + 1];
+            mycand = cand + (start >> 2);
+            cap = (int)((e - s) >> 2);
+            if (tid == 0) { s_ncand = 0; s_nan = 0; }
+            __syncthreads();
+        }
+        auto med_tick = [&](int64_t jj, bool in_bar) {
+            if constexpr (MED) {
+                const uint32_t raw = in_bar ? ((const uint32_t *)amount)[jj] : 0u;
+                const uint32_t k = MedKey<false>::tokey(raw);
+                nan |= in_bar && (k < MedKey<false>::KEY_NEG_INF || k > MedKey<false>::KEY_POS_INF);
+                below += (in_bar && k < blo) ? 1 : 0;
+                const bool inb = in_bar && k >= blo && k <= bhi;
+                const uint64_t m = __ballot(inb);
+                if (m) {
+                    int base = 0;
+                    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&s_ncand, (int)__popcll(m));
+                    base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(m));
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (inb && pos < cap) mycand[pos] = raw;
+                }
+            }
+        };
         int64_t j = start + tid;
         for (; j + 3 * OH_WIDE_THREADS <= e; j += 4 * OH_WIDE_THREADS) {       // four loads of each column in flight
             const double p0 = price[j], p1 = price[j + OH_WIDE_THREADS], p2 = price[j + 2 * OH_WIDE_THREADS],
@@ -150,19 +188,36 @@ __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double
             tv += a1; td += p1 * a1;
             tv += a2; td += p2 * a2;
             tv += a3; td += p3 * a3;
+            med_tick(j, true); med_tick(j + OH_WIDE_THREADS, true); med_tick(j + 2 * OH_WIDE_THREADS, true);
+            med_tick(j + 3 * OH_WIDE_THREADS, true);
         }
-        for (; j <= e; j += OH_WIDE_THREADS) {
-            const double p0 = price[j], a0 = fmk_amt<AF64>(amount, j);
+        for (; j - tid <= e; j += OH_WIDE_THREADS) {                           // (whole waves: the ballots of med_tick)
+            const bool in_bar = j <= e;
+            const int64_t jc = in_bar ? j : e;
+            const double p0 = price[jc], a0 = in_bar ? fmk_amt<AF64>(amount, jc) : 0.0;
             hi = fmax(hi, p0);
             lo = fmin(lo, p0);
-            tv += a0; td += p0 * a0;
+            tv += a0; td += in_bar ? p0 * a0 : 0.0;
+            med_tick(jc, in_bar);
         }
         hi = fmk_dpp_reduce(hi, (double)-INFINITY, FmkOpMax());
         lo = fmk_dpp_reduce(lo, (double)INFINITY, FmkOpMin());
         tv = fmk_dpp_reduce(tv, 0.0, FmkOpAdd());
         td = fmk_dpp_reduce(td, 0.0, FmkOpAdd());
+        if constexpr (MED) {
+            below = fmk_dpp_reduce(below, (int64_t)0, FmkOpAdd());
+            if (lane == 0) s_below[w] = below;
+            if (__ballot(nan) != 0 && lane == 0) s_nan = 1;
+        }
         if (lane == 0) { s_red[0][w] = hi; s_red[1][w] = lo; s_red[2][w] = tv; s_red[3][w] = td; }
         __syncthreads();
+        if constexpr (MED) {
+            if (tid == 0) {
+                int64_t bl = 0;
+                for (int k = 0; k < OH_WIDE_THREADS / 64; ++k) bl += s_below[k];
+                res[3 * q] = bl; res[3 * q + 1] = s_ncand; res[3 * q + 2] = s_nan;
+            }
+        }
         if (w == 0) {
             hi = s_red[0][0]; lo = s_red[1][0]; tv = s_red[2][0]; td = s_red[3][0];
             for (int k = 1; k < OH_WIDE_THREADS / 64; ++k) {
@@ -174,13 +229,122 @@ __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double
     }
 }
 
-// the wide bars of a call: list them, a workgroup per listed bar (two workgroups of 1024 threads per CU)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bars of more than 16 384 ticks (float32 amounts; round 3): the median from the SAME pass as open / high / low / close / volume /
+// vwap.  k_bar_median_long selects the two middle ranks by radix -- three passes over the bar with 2048-bin LDS-atomic histograms:
+// hourly bars 5.4 ms, daily bars 8.6 ms per 1e9 ticks against 2.0 / 2.5 ms without the median.  Here:
+//   1. k_bar_med_sample: a systematic sample of the bar (every 16th / 64th / 256th size: it covers the whole bar evenly, whatever
+//      the time of day does to the sizes) -> the keys at the sample ranks s/2 -+ g, g = 1.9 sqrt(s) + 4: a bracket [blo, bhi] that
+//      holds the bar's middle ranks with probability > 0.9998 and 3.8 / sqrt(s) of its ticks (12 % at 16 385 ticks, 2 % for a day);
+//   2. k_bar_ohlcv_wide<MED>: the one pass -- besides the sums it counts the keys below the bracket and appends the sizes inside it
+//      to the bar's candidate buffer (wave-aggregated, one LDS atomic per wave and chunk);
+//   3. k_bar_med_finish: if the middle ranks fall among the candidates they are selected there exactly (the same radix select, on a
+//      few per cent of the bar); otherwise the bar goes on a list for k_bar_median_long.  np.median's bits either way.
+// Scratch: sample slots [start / 16, ...) and candidate slots [start / 4, ...) of two arrays indexed by the bar's own tick range
+// (bars are disjoint, so no offsets have to be computed).
+// ---------------------------------------------------------------------------------------------------------------------
+struct OhlBracket { uint32_t blo, bhi; int ok; int pad; };
+struct OhlCount { int64_t below; int64_t ncand; int64_t nan; };
+
+__device__ __forceinline__ int ohl_stride(int64_t cnt) { return cnt <= 65536 ? 16 : (cnt <= ((int64_t)1 << 21) ? 64 : 256); }
+
+__global__ __launch_bounds__(256) void k_bar_med_sample(const float *__restrict__ amount, const int64_t *__restrict__ ci,
+                                                        const int64_t *__restrict__ list, const int *__restrict__ go,
+                                                        float *__restrict__ samp, OhlBracket *__restrict__ brk, float g_scale)
+{
+    if (go && *go == 0) return;
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s0 = ci[b], e = ci[b + 1], start = s0 + 1, cnt = e - s0;
+        const int stride = ohl_stride(cnt);
+        const int64_t ns = cnt / stride;                              // >= 1024
+        float *mine = samp + (start >> 4);
+        for (int64_t j = threadIdx.x; j < ns; j += 256) mine[j] = amount[start + j * stride];
+        __syncthreads();
+        const int g = (int)(1.9f * g_scale * sqrtf((float)ns)) + 4;
+        const int64_t r_lo = ns / 2 - g > 0 ? ns / 2 - g : 0, r_hi = ns / 2 + g < ns - 1 ? ns / 2 + g : ns - 1;
+        uint32_t klo, khi;
+        bool any_nan;
+        med_block_select<false, 256>(mine, 0, ns, r_lo, r_hi, klo, khi, any_nan);
+        if (threadIdx.x == 0) brk[q] = OhlBracket{klo, khi, any_nan ? 0 : 1, 0};
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bar_med_finish(const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                        const int *__restrict__ go, const uint32_t *__restrict__ cand,
+                                                        const OhlCount *__restrict__ res, int64_t *__restrict__ fallback,
+                                                        double *__restrict__ o_median)
+{
+    if (go && *go == 0) return;
+    typedef MedKey<false> MK;
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s0 = ci[b], e = ci[b + 1], start = s0 + 1, cnt = e - s0;
+        const OhlCount r = res[q];
+        const int64_t k1 = (cnt - 1) >> 1, k2 = cnt >> 1, cap = cnt >> 2;
+        if (r.nan) { if (threadIdx.x == 0) o_median[b] = NAN; continue; }             // np.median of a bar with a NaN size
+        if (!(r.below <= k1 && k2 < r.below + r.ncand && r.ncand <= cap)) {             // bracket missed: the full radix select
+            if (threadIdx.x == 0) fallback[1 + atomicAdd((unsigned long long *)fallback, 1ULL)] = b;
+            continue;
+        }
+        uint32_t v1, v2;
+        bool any_nan;
+        med_block_select<false, 256>(cand + (start >> 2), 0, r.ncand, k1 - r.below, k2 - r.below, v1, v2, any_nan);
+        if (threadIdx.x == 0) o_median[b] = (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
+        __syncthreads();
+    }
+}
+
+// the wide bars of a call: list them, a workgroup per listed bar (two workgroups of 1024 threads per CU).  *median_done = 1 when the
+// median of these bars was taken by the same pass (float32 amounts: sample bracket, see above) -- fmk_median_launch then skips them.
+int fmk_median_long_list_launch(fmk_ctx *ctx, const void *d_amount, const int64_t *d_close_idx, const int64_t *d_list, double *d_median);
+
 template <bool AF64>
 static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n, const int *go,
-                          const OhlcvOut &o)
+                          const OhlcvOut &o, int *median_done = nullptr, int64_t wide_min = OH_WIDE_MIN)
 {
     int64_t *list = nullptr;
-    FMK_TRY(fmk_long_bar_list(ctx, ci, nb, n, OH_WIDE_MIN, go, &list));
+    FMK_TRY(fmk_long_bar_list(ctx, ci, nb, n, wide_min, go, &list));
+    if constexpr (!AF64) {
+        const char *fv = getenv("FMK_OHLCV_WIDE_MED");            // developer knob: 0 = the radix-select median kernels as before
+        if (o.median && median_done && (!fv || atoi(fv))) {
+            const int64_t cap = n / wide_min + 2;                  // (the list's capacity: fmk_long_bar_list)
+            float *samp = nullptr;
+            uint32_t *cand = nullptr;
+            OhlBracket *brk = nullptr;
+            int64_t *res = nullptr, *fallback = nullptr;
+            int rc = fmk_alloc(ctx, (size_t)((n >> 4) + 64) * 4, (void **)&samp);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)((n >> 2) + 64) * 4, (void **)&cand);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)cap * sizeof(OhlBracket), (void **)&brk);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)cap * 3 * 8, (void **)&res);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)(cap + 1) * 8, (void **)&fallback);
+            hipError_t le = hipSuccess;
+            if (rc == FMK_OK) le = hipMemsetAsync(fallback, 0, 8, ctx->stream);
+            if (rc == FMK_OK && le == hipSuccess) {
+                const char *gv = getenv("FMK_WIDE_MED_GSCALE");      // developer knob (tests): 0 = brackets that usually miss
+                k_bar_med_sample<<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>((const float *)a, ci, list, go, samp, brk,
+                                                                                   gv ? (float)atof(gv) : 1.0f);
+                k_bar_ohlcv_wide<false, true><<<(unsigned)(ctx->n_cu * 2), OH_WIDE_THREADS, 0, ctx->stream>>>(
+                    p, a, ci, list, go, o, (const uint32_t *)brk, cand, res);
+                k_bar_med_finish<<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>(ci, list, go, cand, (const OhlCount *)res, fallback,
+                                                                                   o.median);
+                le = hipGetLastError();
+                if (le == hipSuccess) rc = fmk_median_long_list_launch(ctx, a, ci, fallback, o.median);
+            }
+            if (samp) (void)fmk_free(ctx, samp);
+            if (cand) (void)fmk_free(ctx, cand);
+            if (brk) (void)fmk_free(ctx, brk);
+            if (res) (void)fmk_free(ctx, res);
+            if (fallback) (void)fmk_free(ctx, fallback);
+            (void)fmk_free(ctx, list);
+            FMK_TRY(rc);
+            FMK_HIP(ctx, le);
+            *median_done = 1;
+            return FMK_OK;
+        }
+    }
     k_bar_ohlcv_wide<AF64><<<(unsigned)(ctx->n_cu * 2), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, list, go, o);
     const hipError_t le = hipGetLastError();
     FMK_TRY(fmk_free(ctx, list));
@@ -831,21 +995,23 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
 // their own lengths, so a bar takes this path whatever stream it is part of (a sharded run equals the un-sharded one).
 // ---------------------------------------------------------------------------------------------------------------------
 #define OHM_MIN (64 * FMK_SMALL_NCH)
-#define OHM_MAX 8192
-#define OHM_THREADS 256
+#define OHM_MAX 16384                   // beyond: the one-pass wide kernel with the sample-bracket median (1024-thread workgroups
+                                        // holding 32 / 64 keys per thread were measured for 16 385 .. 65 536 ticks: 6.0 .. 9.1 ms)
+template <int NW>
 struct OhmShared {
-    double red[4][4];
-    uint32_t kmn[4], kmx[4];
-    int cnt[2][4];
-    uint32_t below[2][4], above[2][4];
-    int ncand[4];
+    double red[4][NW];
+    uint32_t kmn[NW], kmx[NW];
+    int cnt[2][NW];
+    uint32_t below[NW], above[NW];
+    int ncand[NW];
     uint32_t buf[64];
 };
 
-template <bool MEDIAN, int NREG>
+template <bool MEDIAN, int NREG, int THREADS>
 __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const float *__restrict__ amount, int64_t b, int64_t s,
-                                        int64_t e, const OhlcvOut &o, OhmShared &sh)
+                                        int64_t e, const OhlcvOut &o, OhmShared<THREADS / 64> &sh)
 {
+    constexpr int NW = THREADS / 64;
     typedef MedKey<false> MK;
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
     const int64_t start = s + 1;
@@ -862,14 +1028,14 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
         uint32_t araw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned idx = (unsigned)((r0 + q) * OHM_THREADS + tid);
+            unsigned idx = (unsigned)((r0 + q) * THREADS + tid);
             idx = idx < last ? idx : last;
             p[q] = pb[idx];
             araw[q] = ab[idx];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool valid = (unsigned)((r0 + q) * OHM_THREADS + tid) <= last;
+            const bool valid = (unsigned)((r0 + q) * THREADS + tid) <= last;
             const double a = (double)__uint_as_float(araw[q]);
             hi = fmax(hi, p[q]);                                     // clamped duplicates cannot change max / min
             lo = fmin(lo, p[q]);
@@ -895,17 +1061,18 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
     }
     __syncthreads();
     if (w == 0) {
-        hi = fmax(fmax(sh.red[0][0], sh.red[0][1]), fmax(sh.red[0][2], sh.red[0][3]));
-        lo = fmin(fmin(sh.red[1][0], sh.red[1][1]), fmin(sh.red[1][2], sh.red[1][3]));
-        tv = ((sh.red[2][0] + sh.red[2][1]) + sh.red[2][2]) + sh.red[2][3];
-        td = ((sh.red[3][0] + sh.red[3][1]) + sh.red[3][2]) + sh.red[3][3];
+        hi = sh.red[0][0]; lo = sh.red[1][0]; tv = sh.red[2][0]; td = sh.red[3][0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) {                                   // the wave totals in order
+            hi = fmax(hi, sh.red[0][k]); lo = fmin(lo, sh.red[1][k]); tv += sh.red[2][k]; td += sh.red[3][k];
+        }
         ohlcv_finish<false>(o, b, price, start, e, hi, lo, tv, td, lane, true);
     }
     if constexpr (MEDIAN) {
         // ---- the two middle ranks: every thread walks the same (block-uniform) bisection
         uint32_t mn = sh.kmn[0], mx = sh.kmx[0];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { mn = sh.kmn[k] < mn ? sh.kmn[k] : mn; mx = sh.kmx[k] > mx ? sh.kmx[k] : mx; }
+        for (int k = 1; k < NW; ++k) { mn = sh.kmn[k] < mn ? sh.kmn[k] : mn; mx = sh.kmx[k] > mx ? sh.kmx[k] : mx; }
         const int k1 = (cnt - 1) >> 1, k2 = cnt >> 1;
         uint32_t v1 = 0, v2 = 0;
         const bool isnan = mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF;
@@ -948,7 +1115,9 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
                     for (int r = 0; r < NREG; ++r) c += med_popc(key[r] <= pivot);
                     if (lane == 0) sh.cnt[par][w] = c;
                     __syncthreads();
-                    c = (sh.cnt[par][0] + sh.cnt[par][1]) + (sh.cnt[par][2] + sh.cnt[par][3]);
+                    c = 0;
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) c += sh.cnt[par][k];
                     par ^= 1;
                     if (c > k2) { bhi = pivot; chi = c; }
                     else if (c <= k1) { blo = pivot; clo = c; }
@@ -963,13 +1132,13 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
                         }
                         a = med_wave_umax<uint32_t>(a);
                         bb = med_wave_umin<uint32_t>(bb);
-                        if (lane == 0) { sh.below[0][w] = a; sh.above[0][w] = bb; }
+                        if (lane == 0) { sh.below[w] = a; sh.above[w] = bb; }
                         __syncthreads();
-                        v1 = sh.below[0][0]; v2 = sh.above[0][0];
+                        v1 = sh.below[0]; v2 = sh.above[0];
 #pragma unroll
-                        for (int k = 1; k < 4; ++k) {
-                            v1 = sh.below[0][k] > v1 ? sh.below[0][k] : v1;
-                            v2 = sh.above[0][k] < v2 ? sh.above[0][k] : v2;
+                        for (int k = 1; k < NW; ++k) {
+                            v1 = sh.below[k] > v1 ? sh.below[k] : v1;
+                            v2 = sh.above[k] < v2 ? sh.above[k] : v2;
                         }
                         done = true;
                     }
@@ -980,23 +1149,19 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
     }
 }
 
-template <bool MEDIAN>
-__global__ __launch_bounds__(OHM_THREADS) void k_bar_ohlcv_mid(const double *__restrict__ price, const float *__restrict__ amount,
-                                                              const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
-                                                              const int *__restrict__ go, OhlcvOut o)
+template <bool MEDIAN, int NREG, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bar_ohlcv_mid(const double *__restrict__ price, const float *__restrict__ amount,
+                                                          const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                          const int *__restrict__ go, OhlcvOut o)
 {
     if (go && *go == 0) return;
-    __shared__ OhmShared sh;
+    __shared__ OhmShared<THREADS / 64> sh;
     const int64_t n_list = list[0];
     for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
         const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
-        const int64_t cnt = e - s;
-        if (cnt <= 2048) ohm_bar<MEDIAN, 8>(price, amount, b, s, e, o, sh);
-        else if (cnt <= 4096) ohm_bar<MEDIAN, 16>(price, amount, b, s, e, o, sh);
-        else ohm_bar<MEDIAN, 32>(price, amount, b, s, e, o, sh);
+        ohm_bar<MEDIAN, NREG, THREADS>(price, amount, b, s, e, o, sh);
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Bars of 1 345 .. 4 096 ticks (float32 amounts; round 3): still ONE WAVE per bar and one pass, the keys of the whole bar in
@@ -1165,10 +1330,11 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
             skip_lo = OHM_MIN;
             skip_hi = OHM_MAX;
             // 1 345 .. 2 048, .. 3 072, .. 4 096, .. 6 144 ticks: a wave per bar with 32 / 48 / 64 / 96 key registers; 6 145 .. 8 192: a workgroup per bar
-            int64_t *list[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-            static const int64_t edge[6] = {OHM_MIN, 2048, 3072, 4096, 6144, OHM_MAX};
+            constexpr int NL = 6;
+            int64_t *list[NL] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const int64_t edge[NL + 1] = {OHM_MIN, 2048, 3072, 4096, 6144, 8192, OHM_MAX};
             int rc = FMK_OK;
-            for (int k = 0; k < 5 && rc == FMK_OK; ++k) rc = fmk_long_bar_list(ctx, ci, nb, n, edge[k], saw_long, &list[k], edge[k + 1]);
+            for (int k = 0; k < NL && rc == FMK_OK; ++k) rc = fmk_long_bar_list(ctx, ci, nb, n, edge[k], saw_long, &list[k], edge[k + 1]);
             // measured per 1e9 ticks, ohlcv + median (profiles/r03_median_humps.txt): 4 400 / 5 200 / 6 000-tick bars 3.6 / 3.4 / 3.1 ms
             // with 96 key registers per lane against 5.1 / 4.5 / 4.0 ms by the workgroup kernel; 7 000 / 8 000-tick bars 5.5 / 5.2 ms
             // with 128 key registers (spills) against 3.6 / 3.3 ms by the workgroup kernel
@@ -1180,30 +1346,36 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
                     k_bar_ohlcv_phased<true, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
                     k_bar_ohlcv_phased<true, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
                     k_bar_ohlcv_phased<true, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
-                    k_bar_ohlcv_mid<true><<<g, OHM_THREADS, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<true, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<true, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
                 } else {
                     k_bar_ohlcv_phased<false, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
                     k_bar_ohlcv_phased<false, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
                     k_bar_ohlcv_phased<false, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
                     k_bar_ohlcv_phased<false, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
-                    k_bar_ohlcv_mid<false><<<g, OHM_THREADS, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<false, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<false, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
                 }
             }
             const hipError_t le = hipGetLastError();
-            for (int k = 0; k < 5; ++k)
+            for (int k = 0; k < NL; ++k)
                 if (list[k]) (void)fmk_free(ctx, list[k]);
             FMK_TRY(rc);
             FMK_HIP(ctx, le);
         }
     }
     k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o, skip_lo, skip_hi);
-    FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o));
+    int wide_median_done = 0;
+    const int64_t wide_min = skip_hi > OH_WIDE_MIN ? skip_hi : OH_WIDE_MIN;       // the workgroup classes reach further than the generic kernel
+    FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o, &wide_median_done, wide_min));
     FMK_LAUNCH_CHECK(ctx);
     if (AF64) {
         k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
         FMK_LAUNCH_CHECK(ctx);
     }
-    if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n, skip_lo, skip_hi);
+    if (o.median)
+        return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n, skip_lo, skip_hi,
+                                 wide_median_done ? wide_min : INT64_MAX);
     return FMK_OK;
 }
 
