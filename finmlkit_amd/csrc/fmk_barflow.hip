@@ -23,6 +23,30 @@
 #include "fmk_f32tie.h"
 #include "fmk_median.h"
 
+// developer knob FMK_DIR_FORCE_REDO=1 (tests): every bar of the wave-per-bar / workgroup-per-bar kernels goes on the redo list
+__device__ int bf_force_redo = 0;
+// diagnostics of the tick-order redo (fmk_diag_dir_redo): (bar, column) pairs redone, 512-term tiles, tiles added term by term
+__device__ unsigned long long bf_redo_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [3 + r]: pairs of row r
+// developer knob -DBF_REDO_TIMING: 100 MHz wall-clock ticks spent in the phases of k_bar_dir_redo_par (wave 0), read through
+// fmk_diag_dir_redo's slots 3 .. 7 instead of the per-column pair counts
+#ifdef BF_REDO_TIMING
+#define BF_T(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&bf_redo_stats[slot], now_ - t_last_); t_last_ = now_; } } while (0)
+#else
+#define BF_T(slot) do { } while (0)
+#endif
+static int bf_sync_force_redo(fmk_ctx *ctx)
+{
+    static int current = 0;
+    const char *v = getenv("FMK_DIR_FORCE_REDO");
+    const int want = v ? (atoi(v) != 0) : 0;
+    if (want != current) {
+        FMK_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(bf_force_redo), &want, sizeof(int), 0, hipMemcpyHostToDevice, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        current = want;
+    }
+    return FMK_OK;
+}
+
 struct FlowDirOut {
     int64_t *ticks_buy, *ticks_sell;
     float *volume_buy, *volume_sell, *dollars_buy, *dollars_sell;
@@ -40,6 +64,10 @@ struct FlowDir {                        // per-lane accumulators of one bar
     double vb, vs, db, ds, cs, mxs;
     double vmin, vmax, dmin, dmax;
     int tmin, tmax, nbuy, nsell;
+    // ticks from the bar's start to the END of the tile in which each float extremum was last improved (an upper bound of its
+    // position: the rounding-noise bound of a running sum's extremum grows with the number of additions behind it)
+    int64_t kvmin, kvmax, kdmin, kdmax;
+    int64_t tiles_end;               // wave-uniform: ticks from the bar's start to the end of the current tile
     // wave-uniform
     int carry_t;
     double carry_v, carry_d;
@@ -53,6 +81,8 @@ __device__ __forceinline__ void bf_dir_init(FlowDir &d)
     d.vmin = d.dmin = 1e9; d.vmax = d.dmax = -1e9;       // base.py:461-464
     d.tmin = BF_INIT_MIN; d.tmax = BF_INIT_MAX;
     d.nbuy = d.nsell = 0;
+    d.kvmin = d.kvmax = d.kdmin = d.kdmax = 0;
+    d.tiles_end = 0;
     d.carry_t = 0; d.carry_v = d.carry_d = 0.0;
     d.prev_price = 0.0; d.prev_side = 0;
 }
@@ -130,9 +160,15 @@ __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const doub
         const double bv = d.carry_v + ev, bd = d.carry_d + ed;
         d.tmin = bt + ltmin < d.tmin ? bt + ltmin : d.tmin;
         d.tmax = bt + ltmax > d.tmax ? bt + ltmax : d.tmax;
+        const int64_t te = d.tiles_end + tn;
+        if (bv + lvmin < d.vmin) d.kvmin = te;
+        if (bv + lvmax > d.vmax) d.kvmax = te;
+        if (bd + ldmin < d.dmin) d.kdmin = te;
+        if (bd + ldmax > d.dmax) d.kdmax = te;
         d.vmin = fmin(d.vmin, bv + lvmin); d.vmax = fmax(d.vmax, bv + lvmax);
         d.dmin = fmin(d.dmin, bd + ldmin); d.dmax = fmax(d.dmax, bd + ldmax);
     }
+    d.tiles_end += tn;
     d.carry_t += fmk_last_lane(it);
     d.carry_v += fmk_last_lane(iv);
     d.carry_d += fmk_last_lane(id);
@@ -219,33 +255,79 @@ __device__ __forceinline__ void bf_dir_sequential(const FlowDirOut &o, int64_t b
     if (lane == 6) { o.cum_dollars_min[b] = (float)mn; o.cum_dollars_max[b] = (float)mx; }
 }
 
-// fold the lanes and write the 14 per-bar outputs
-template <typename AmtT>
-__device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int lane, const FlowDir &d,
-                                            unsigned long long *n_zero_div, int64_t start, int64_t e,
-                                            unsigned long long *redo)
+// the bar's (or a bar segment's) accumulators folded over the wave: wave-uniform
+struct FlowTotals {
+    double vb, vs, db, ds, cs, mxs;
+    double vmin, vmax, dmin, dmax;
+    int tb, tsell, tmin, tmax;
+    int64_t kvmin, kvmax, kdmin, kdmax;      // upper bounds of the extrema's positions (ticks from the bar's start)
+};
+
+// position bound of a reduced extremum: the largest bound among the lanes that hold the reduced value
+__device__ __forceinline__ int64_t bf_pos_of(double lane_val, double reduced, int64_t lane_pos)
 {
-    const double vb = fmk_dpp_reduce(d.vb, 0.0, FmkOpAdd()), vs = fmk_dpp_reduce(d.vs, 0.0, FmkOpAdd());
-    const double db = fmk_dpp_reduce(d.db, 0.0, FmkOpAdd()), ds = fmk_dpp_reduce(d.ds, 0.0, FmkOpAdd());
-    const double cs = fmk_dpp_reduce(d.cs, 0.0, FmkOpAdd()), mxs = fmk_dpp_reduce(d.mxs, 0.0, FmkOpMax());
-    const int tb = fmk_dpp_reduce(d.nbuy, 0, FmkOpAdd()), tsell = fmk_dpp_reduce(d.nsell, 0, FmkOpAdd());
-    const int tmin = fmk_dpp_reduce(d.tmin, BF_INIT_MIN, FmkOpMin());
-    const int tmax = fmk_dpp_reduce(d.tmax, BF_INIT_MAX, FmkOpMax());
-    const double vmin = fmk_dpp_reduce(d.vmin, 1e9, FmkOpMin()), vmax = fmk_dpp_reduce(d.vmax, -1e9, FmkOpMax());
-    const double dmin = fmk_dpp_reduce(d.dmin, 1e9, FmkOpMin()), dmax = fmk_dpp_reduce(d.dmax, -1e9, FmkOpMax());
+    return fmk_dpp_reduce(lane_val == reduced ? lane_pos : (int64_t)0, (int64_t)0, FmkOpMax());
+}
+
+__device__ __forceinline__ FlowTotals bf_dir_fold(const FlowDir &d)
+{
+    FlowTotals t;
+    t.vb = fmk_dpp_reduce(d.vb, 0.0, FmkOpAdd()); t.vs = fmk_dpp_reduce(d.vs, 0.0, FmkOpAdd());
+    t.db = fmk_dpp_reduce(d.db, 0.0, FmkOpAdd()); t.ds = fmk_dpp_reduce(d.ds, 0.0, FmkOpAdd());
+    t.cs = fmk_dpp_reduce(d.cs, 0.0, FmkOpAdd()); t.mxs = fmk_dpp_reduce(d.mxs, 0.0, FmkOpMax());
+    t.tb = fmk_dpp_reduce(d.nbuy, 0, FmkOpAdd()); t.tsell = fmk_dpp_reduce(d.nsell, 0, FmkOpAdd());
+    t.tmin = fmk_dpp_reduce(d.tmin, BF_INIT_MIN, FmkOpMin());
+    t.tmax = fmk_dpp_reduce(d.tmax, BF_INIT_MAX, FmkOpMax());
+    t.vmin = fmk_dpp_reduce(d.vmin, 1e9, FmkOpMin()); t.vmax = fmk_dpp_reduce(d.vmax, -1e9, FmkOpMax());
+    t.dmin = fmk_dpp_reduce(d.dmin, 1e9, FmkOpMin()); t.dmax = fmk_dpp_reduce(d.dmax, -1e9, FmkOpMax());
+    t.kvmin = bf_pos_of(d.vmin, t.vmin, d.kvmin); t.kvmax = bf_pos_of(d.vmax, t.vmax, d.kvmax);
+    t.kdmin = bf_pos_of(d.dmin, t.dmin, d.kdmin); t.kdmax = bf_pos_of(d.dmax, t.dmax, d.kdmax);
+    return t;
+}
+
+// write the 14 per-bar outputs (lane 0) and put the bar on the redo list when a float32 output could round the other way
+template <typename AmtT>
+__device__ __forceinline__ void bf_dir_write(const FlowDirOut &o, int64_t b, int lane, const FlowTotals &t,
+                                             unsigned long long *n_zero_div, int64_t start, int64_t e,
+                                             unsigned long long *redo)
+{
+    const double vb = t.vb, vs = t.vs, db = t.db, ds = t.ds, cs = t.cs, mxs = t.mxs;
+    const int tb = t.tb, tsell = t.tsell, tmin = t.tmin, tmax = t.tmax;
+    const double vmin = t.vmin, vmax = t.vmax, dmin = t.dmin, dmax = t.dmax;
     if (lane == 0 && tb + tsell == 0 && n_zero_div) atomicAdd(n_zero_div, 1ULL);   // reference: ZeroDivisionError (base.py:536)
-    // The sums above are float64 in (lane, tree) order, the reference's in tick order: they differ by at most
-    // ~len * 2^-53 * sum|terms|.  float32 outputs can only differ when a sum sits that close to a float32 rounding
-    // boundary -- those bars (exact ties are common with grid prices x dyadic amounts: 6148 of the benchmark's 833323 bars, 0.74 %)
-    // are appended to the redo list (redo[0]: count, redo[32...]: bar numbers) and walked in tick order by
-    // k_bar_dir_redo.  All operands are wave-uniform, so the decision is too.
-    const double eps = 4.6e-16 * (double)(e - start + 2);                    // 2 x len x 2^-52, a safe over-estimate
+    // The sums above are float64 in (lane, tree[, wave]) order, the reference's in tick order.  float32 outputs can only differ when
+    // a sum sits within the two orders' rounding noise of a float32 rounding boundary; those bars go on the redo list (redo[0]:
+    // count, redo[32...]: bar number | column mask << 48) and k_bar_dir_redo_par adds the flagged columns in tick order.
+    //   * one-signed sums (buy / sell volume and dollars, spread): recursive summation of len terms errs by at most (len - 1) u S
+    //     (u = 2^-53, S the sum), the lane-sequential / tree / tile-carry order here by at most (len / 64 + len / 512 + 22) u S:
+    //     together below 1.05 (len + 64) u S.
+    //   * extrema of the running SIGNED sums: every partial sum -- in either order -- has magnitude at most M = max(|min|, |max|)
+    //     (+ the deviation itself), and running error analysis bounds the recursive sum's error at tick k by u (|s_2| + ... + |s_k|)
+    //     <= len u M; a value of the parallel order is reached through at most d = len / 512 + 16 additions of partial sums over
+    //     contiguous ranges, each below 2 M: d u 2 M (d taken as len / 512 + 32).  Round 2 bounded these by len u (buy + sell): for a daily bar that is 7 units
+    //     against a float32 spacing of 1 at M ~ 1e7 -- EVERY long bar was redone, ~20 ms of one wave each.
+    //   * float32 amounts: the volume sums and the running signed volume are float64 sums of 24-bit terms -- exact in any order
+    //     (amounts of a bar spanning less than 2^29 in magnitude, the assumption of every kernel here): they cannot tie.
+    // All operands are wave-uniform, so the decision is too.
+    const double len = (double)(e - start + 65);
+    const double eps = 1.17e-16 * len;
     const double mean = tb + tsell == 0 ? 0.0 : cs / (double)(tb + tsell);
-    const bool tie = fmk_near_f32_tie(vb, eps * vb) || fmk_near_f32_tie(vs, eps * vs) || fmk_near_f32_tie(db, eps * db) ||
-                     fmk_near_f32_tie(ds, eps * ds) || fmk_near_f32_tie(mean, 2.0 * eps * mean) ||
-                     fmk_near_f32_tie(vmin, eps * (vb + vs)) || fmk_near_f32_tie(vmax, eps * (vb + vs)) ||
-                     fmk_near_f32_tie(dmin, eps * (db + ds)) || fmk_near_f32_tie(dmax, eps * (db + ds));
-    if (tie && lane == 0) redo[32 + atomicAdd(redo, 1ULL)] = (unsigned long long)b;
+    const double mv = fmax(fabs(vmin), fabs(vmax)), md = fmax(fabs(dmin), fabs(dmax));
+    // ... an extremum reached after k ticks has only k additions behind it in the reference's order: len -> k (+ a tile, the
+    // granularity the position is known at).  Most extrema of small magnitude -- fine float32 spacing -- are early ones.
+    auto eps_at = [](int64_t k) { const double kk = (double)(k + 64); return 1.13e-16 * (kk + 2.0 * (kk / 512.0 + 32.0)); };
+    unsigned mask = 0;
+    if (fmk_near_f32_tie(db, eps * db)) mask |= 1u << 2;
+    if (fmk_near_f32_tie(ds, eps * ds)) mask |= 1u << 3;
+    if (fmk_near_f32_tie(mean, (eps + 1.2e-16) * mean)) mask |= 1u << 4;
+    if (tb + tsell > 0 && (fmk_near_f32_tie(dmin, eps_at(t.kdmin) * md) || fmk_near_f32_tie(dmax, eps_at(t.kdmax) * md))) mask |= 1u << 6;
+    if constexpr (sizeof(AmtT) == 8) {
+        if (fmk_near_f32_tie(vb, eps * vb)) mask |= 1u << 0;
+        if (fmk_near_f32_tie(vs, eps * vs)) mask |= 1u << 1;
+        if (tb + tsell > 0 && (fmk_near_f32_tie(vmin, eps_at(t.kvmin) * mv) || fmk_near_f32_tie(vmax, eps_at(t.kvmax) * mv))) mask |= 1u << 5;
+    }
+    if (bf_force_redo != 0) mask = 0x7F;                               // (tests: every bar through the tick-order redo)
+    if (mask && lane == 0) redo[32 + atomicAdd(redo, 1ULL)] = (unsigned long long)b | ((unsigned long long)mask << 48);
     if (lane == 0) {
         o.ticks_buy[b] = tb; o.ticks_sell[b] = tsell;
         o.volume_buy[b] = (float)vb; o.volume_sell[b] = (float)vs;
@@ -258,6 +340,16 @@ __device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int 
     }
 }
 
+// fold the lanes and write the 14 per-bar outputs
+template <typename AmtT>
+__device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int lane, const FlowDir &d,
+                                            unsigned long long *n_zero_div, int64_t start, int64_t e,
+                                            unsigned long long *redo)
+{
+    const FlowTotals t = bf_dir_fold(d);
+    bf_dir_write<AmtT>(o, b, lane, t, n_zero_div, start, e, redo);
+}
+
 // ---------------------------------------------------------------------------------------
 // directional only: one wave per bar
 // ---------------------------------------------------------------------------------------
@@ -265,7 +357,8 @@ template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ price, const void *__restrict__ amount,
                                                  const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                  int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
-                                                 unsigned long long *redo, const unsigned long long *only = nullptr)
+                                                 unsigned long long *redo, const unsigned long long *only = nullptr,
+                                                 int64_t skip_above = INT64_MAX /* longer bars: k_bar_dir_wide */)
 {
     typedef typename std::conditional<AF64, double, float>::type AmtT;
     __shared__ double s_p[4][BF_SLOTS];
@@ -286,6 +379,7 @@ __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ pric
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
         const int64_t start = s + 1;
+        if (e - s > skip_above) continue;
         FlowDir d;
         bf_dir_init(d);
         if (e > s) {
@@ -330,6 +424,115 @@ __global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ pric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Bars of more than BFW_MIN ticks (hourly, daily bars): a WORKGROUP per bar (round 3).  With one wave per bar 580 daily bars are 580
+// waves on 1024 SIMDs, each alone with its load latency: 10 ms per 1e9 ticks before any redo.  The order-flow quantities compose
+// over contiguous segments -- sums add, and the extrema of the running signed sums are  min over segments of (sum of the earlier
+// segments + the segment's own extremum)  -- so eight waves take an eighth of the bar each (whole 512-tick tiles; the tick before
+// a segment comes from memory) and wave 0 combines the eight results in order.  Same tie test and redo list as k_bar_dir.
+// ---------------------------------------------------------------------------------------
+#define BFW_MIN 16384
+#define BFW_WAVES 8
+struct FlowSeg {                     // one wave's segment, wave-uniform values
+    FlowTotals t;
+    int net_t;
+    double net_v, net_d;
+};
+
+template <bool AF64>
+__global__ __launch_bounds__(64 * BFW_WAVES) void k_bar_dir_wide(const double *__restrict__ price, const void *__restrict__ amount,
+                                                               const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                               const int64_t *__restrict__ list, int64_t n, FlowDirOut o,
+                                                               unsigned long long *n_zero_div, unsigned long long *redo)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    __shared__ double s_p[BFW_WAVES][BF_SLOTS];
+    __shared__ AmtT s_a[BFW_WAVES][BF_SLOTS];
+    __shared__ int8_t s_s[BFW_WAVES][640];
+    __shared__ FlowSeg s_seg[BFW_WAVES];
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    double *sP = s_p[w];
+    AmtT *sA = s_a[w];
+    int8_t *sS = s_s[w];
+    const AmtT *am = (const AmtT *)amount;
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1], start = s + 1, cnt = e - s;
+        int64_t seg = (cnt + BFW_WAVES - 1) / BFW_WAVES;
+        seg = (seg + 511) & ~(int64_t)511;                           // whole tiles
+        const int64_t j_lo = start + (int64_t)w * seg;
+        const int64_t j_hi = j_lo + seg - 1 < e ? j_lo + seg - 1 : e;   // inclusive
+        FlowDir d;
+        bf_dir_init(d);
+        d.tiles_end = (int64_t)w * seg;                              // positions count from the bar's start
+        if (j_lo <= e) {
+            d.prev_price = price[fmk_wrap(j_lo - 1, n)];
+            // base.py:485-488: the bar's first tick compares with the tick before the bar (wrapped), except in a one-tick bar
+            d.prev_side = (w > 0 || cnt > 1) ? (int)side[fmk_wrap(j_lo - 1, n)] : 0;
+        }
+        int64_t j0 = j_lo, rem = j_hi - j_lo + 1;
+        while (rem > 0) {
+            int lr, tn;
+            bf_shape(rem, lr, tn);
+            const double *pb = price + j0;
+            const AmtT *ab = am + j0;
+            const int8_t *sb = side + j0;
+            double pr[8];
+            AmtT ar[8];
+            int sr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pr[c] = 0.0; ar[c] = 0; sr[c] = 0;
+                const int t = c * 64 + lane;
+                if (c < (1 << lr) && t < tn) { pr[c] = pb[t]; ar[c] = ab[t]; sr[c] = sb[t]; }
+            }
+            const int slot0 = bf_slot(lane, lr);
+            const int cstride = (64 >> lr) * ((1 << lr) + 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < (1 << lr)) {
+                    const int sl = slot0 + c * cstride;
+                    sP[sl] = pr[c]; sA[sl] = ar[c]; sS[sl] = (int8_t)sr[c];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf_dir_tile<AmtT>(lane, lr, tn, sP, sA, sS, d);
+            __builtin_amdgcn_wave_barrier();
+            j0 += tn;
+            rem -= tn;
+        }
+        const FlowTotals t = bf_dir_fold(d);
+        __syncthreads();                                             // (the previous bar's segments have been read)
+        if (lane == 0) { s_seg[w].t = t; s_seg[w].net_t = d.carry_t; s_seg[w].net_v = d.carry_v; s_seg[w].net_d = d.carry_d; }
+        __syncthreads();
+        if (w == 0) {
+            FlowTotals a = s_seg[0].t;
+            int ct = s_seg[0].net_t;
+            double cv = s_seg[0].net_v, cd = s_seg[0].net_d;
+            for (int k = 1; k < BFW_WAVES; ++k) {
+                const FlowTotals &x = s_seg[k].t;
+                a.vb += x.vb; a.vs += x.vs; a.db += x.db; a.ds += x.ds; a.cs += x.cs;
+                a.mxs = fmax(a.mxs, x.mxs);
+                a.tb += x.tb; a.tsell += x.tsell;
+                if (x.tmin != BF_INIT_MIN) {                         // the segment met a signed tick: its extrema count
+                    a.tmin = ct + x.tmin < a.tmin ? ct + x.tmin : a.tmin;
+                    a.tmax = ct + x.tmax > a.tmax ? ct + x.tmax : a.tmax;
+                    if (cv + x.vmin < a.vmin) a.kvmin = x.kvmin;
+                    if (cv + x.vmax > a.vmax) a.kvmax = x.kvmax;
+                    if (cd + x.dmin < a.dmin) a.kdmin = x.kdmin;
+                    if (cd + x.dmax > a.dmax) a.kdmax = x.kdmax;
+                    a.vmin = fmin(a.vmin, cv + x.vmin); a.vmax = fmax(a.vmax, cv + x.vmax);
+                    a.dmin = fmin(a.dmin, cd + x.dmin); a.dmax = fmax(a.dmax, cd + x.dmax);
+                }
+                ct += s_seg[k].net_t; cv += s_seg[k].net_v; cd += s_seg[k].net_d;
+            }
+            bf_dir_write<AmtT>(o, b, lane, a, n_zero_div, start, e, redo);
+        }
+    }
+}
+
 // the bars k_bar_dir put on the redo list, one wave each, in tick order
 template <bool AF64>
 __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__ price, const void *__restrict__ amount,
@@ -342,11 +545,423 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
     const int64_t count = (int64_t)redo[0];
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t i = (int64_t)blockIdx.x * 4 + fmk_uniform((int)(threadIdx.x >> 6)); i < count; i += nwaves) {
-        const int64_t b = fmk_uniform((int64_t)redo[32 + i]);
+        const int64_t b = fmk_uniform((int64_t)(redo[32 + i] & 0xFFFFFFFFFFFFULL));
         const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
         bf_dir_sequential<AmtT>(o, b, lane, s_rows[threadIdx.x >> 6], price, (const AmtT *)amount, side, s + 1, e, n);
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// The reference's SEQUENTIAL float64 sums of a redone bar, in parallel (round 3).  A recursive sum cannot be re-associated -- but
+// while the running sum s stays inside one binade [2^e, 2^(e+1)) every addition is  s <- s + rnd_g(x)  with rnd_g = rounding to the
+// grid g = 2^(e-52) of that binade, and rnd_g(x) does not depend on s unless x lies exactly half way between two grid points (then
+// round-to-even looks at the parity of s / g).  So for a chunk of 64 terms:
+//     y_k = (C + x_k) - C,  C = 1.5 * 2^e        (the machine's own rounding to the grid; exact: Fast2Sum with |x_k| < C)
+//     r_k = x_k - y_k                           (exact remainder; |r_k| == g / 2  <=>  a tie)
+//     S_k = s + (y_1 + ... + y_k)               (multiples of g below 2^53 g: EXACT in any order -> a DPP scan)
+// and if no term ties, every |x_k| < 2^(e-5) (so that all subset sums of the y stay below 2^53 g) and every S_k lies strictly inside
+// the binade, then S_1 .. S_64 ARE the reference's partial sums, bit for bit (induction over k).  Signed sums work on |s| with the
+// terms' signs flipped along.  The BINADE of the running sum is known in advance from an approximate (re-associated) prefix sum
+// whenever the sum is not within rounding noise of a power of two.  So, per super-block of 512 chunks (32 768 ticks):
+//   A. all waves, chunk by chunk: the approximate start value S~ of the chunk (a scan of the chunks' plain totals) gives its
+//      binade e; the 64 terms are rounded to that binade's grid and the chunk is GOOD if no term ties, every |x| < 2^(e-5) and
+//      S~ + (y_1 + .. + y_k) stays inside the binade by a margin that covers S~'s own error.  A good chunk is reduced to three
+//      EXACT numbers: its total T = sum y and the extrema minP / maxP of its inclusive prefixes.  Sixteen consecutive good chunks of
+//      one binade and sign fold into a GROUP record the same way (total, extrema of  total of the chunks before + the chunk's
+//      extrema);
+//   B. one wave walks the group records in order: a group whose actual start s has the predicted binade and sign and whose partial
+//      sums stay strictly inside it is  s <- s + T  -- exact, and the reference's 1024 roundings in one step -- with extrema
+//      s + minP / s + maxP; any other group is walked chunk by chunk with the same test, and a chunk that fails it term by term.
+//      (Exactness of a group's numbers: they are sums of multiples of g; as long as the true running sum stays inside the binade
+//      every partial result is below 2^53 g and the additions are exact; the first partial result that leaves the binade -- exact
+//      or rounded, rounding is monotone -- fails the range test, and the test sees the minimum and maximum over ALL of them.)
+// About 1 % of the chunks of a daily bar take the slow road.  A workgroup takes one (bar, column) pair at a time -- the seven
+// columns (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars) are independent sums.
+// ---------------------------------------------------------------------------------------
+#define RS_CH 512
+#define RS_WAVES 8                    // 512 threads: 256 VGPRs per lane (two raw tiles, the terms and their prefixes live at once)
+#define RS_POOL 240                   // chunks whose terms wait in LDS for the term-by-term walk
+#define RS_UNROLL 4
+#define RS_GRP 16                     // chunks per group record
+#define RS_NONE ((int)0x80000000)
+struct RsRec {
+    double T, minP, maxP;
+    int e;                            // binade of |s| the record was computed for; RS_NONE: not usable
+    int neg;                          // sign of s it was computed for
+};
+
+// the row's terms of one chunk (64 ticks from j0, lane = tick; 0.0 where the reference skips the update) with unconditional loads
+// (clamped into the bar): the compiler batches them.  `flow`: the tick is a signed one.
+template <typename AmtT>
+__device__ __forceinline__ double rs_chunk_term(int row, int64_t j0, int lane, int64_t start, int64_t e_bar, int64_t n,
+                                                const double *__restrict__ price, const AmtT *__restrict__ am,
+                                                const int8_t *__restrict__ side, bool &flow)
+{
+    const int64_t j = j0 + lane;
+    const bool valid = j <= e_bar;
+    const int64_t jc = valid ? j : e_bar;
+    const int64_t jp = fmk_wrap(jc - 1, n);
+    const double p = price[jc], pprev = price[jp];
+    const double v = (double)am[jc];
+    const int sd = side[jc];
+    int sprev = side[jp];
+    if (jc == start && !(e_bar > start)) sprev = 0;                      // base.py:485-488: a one-tick bar
+    const bool buy = valid && sd == 1, sell = valid && sd == -1;
+    flow = buy || sell;
+    const double pv = p * v;
+    switch (row) {                                                       // (wave-uniform)
+    case 0: return buy ? v : 0.0;
+    case 1: return sell ? v : 0.0;
+    case 2: return buy ? pv : 0.0;
+    case 3: return sell ? pv : 0.0;
+    case 4: return valid && sd != sprev ? fabs(p - pprev) : 0.0;       // base.py:485-500: |price change| where the side changes
+    case 5: return buy ? v : sell ? -v : 0.0;
+    default: return buy ? pv : sell ? -pv : 0.0;
+    }
+}
+
+// a tile of eight chunks as loaded (lane = tick of the chunk) plus the tick before the tile
+template <typename AmtT>
+struct RsRaw {
+    double p[8];
+    AmtT v[8];
+    int sd[8];
+    double pp;
+    int ps;
+};
+
+template <bool AF64>
+__global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double *__restrict__ price, const void *__restrict__ amount,
+                                                                  const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                                  int64_t n, FlowDirOut o, const unsigned long long *__restrict__ redo)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    const AmtT *am = (const AmtT *)amount;
+    __shared__ RsRec s_rec[RS_CH];
+    __shared__ RsRec s_grp[RS_CH / RS_GRP];
+    __shared__ double s_tot[RS_CH], s_abs[RS_CH], s_cabs[RS_CH];
+    __shared__ double s_x[64];
+    // per-wave tiles while the records are made; afterwards the POOL: the terms of the chunks that will be added term by term
+    __shared__ double s_stage[RS_POOL * 64];
+    __shared__ unsigned long long s_flow[RS_CH];
+    __shared__ double s_carry[4];                                        // s, mn, mx, started (wave 0 -> all)
+    __shared__ long long s_nflow;
+    __shared__ int s_npool;
+    constexpr int POOL_N = RS_POOL;
+    static_assert(RS_POOL * 64 >= RS_WAVES * BF_SLOTS, "the tiles are staged in the pool's memory");
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t count = (int64_t)redo[0];
+    // item = column * count + list entry: the flagged columns of ONE bar land on different workgroups
+    for (int64_t item = blockIdx.x; item < count * 7; item += gridDim.x) {
+        const int row = (int)(item / count);
+        const unsigned long long entry = redo[32 + item % count];
+        if (!((entry >> (48 + row)) & 1)) continue;                      // this column is not near a float32 tie (block-uniform)
+        const int64_t b = (int64_t)(entry & 0xFFFFFFFFFFFFULL);
+        const int64_t start = ci[b] + 1, e_bar = ci[b + 1];
+        const int64_t n_ch = (e_bar - start + 64) >> 6;
+        const bool extrema = row >= 5;
+        __syncthreads();
+        if (threadIdx.x == 0) { s_carry[0] = 0.0; s_carry[1] = 1e9; s_carry[2] = -1e9; s_carry[3] = 0.0; s_nflow = 0; }   // base.py:461-464
+        __syncthreads();
+#ifdef BF_REDO_TIMING
+        unsigned long long t_last_ = wall_clock64();
+#endif
+        for (int64_t c0 = 0; c0 < n_ch; c0 += RS_CH) {
+            const int nc = (int)(n_ch - c0 < RS_CH ? n_ch - c0 : RS_CH);
+            // A wave takes TILES of eight chunks: the terms are computed in tick order across the lanes (coalesced loads, the next
+            // tile's in flight while this one is worked on) and turned through LDS so that lane l owns the eight consecutive terms
+            // 8 l .. 8 l + 7 -- a chunk is then eight lanes (half a DPP row): three butterfly steps per reduction instead of six
+            // scan steps per chunk, eight chunks at a time.
+            const int nt = (nc + 7) >> 3;
+            double *stage = s_stage + w * BF_SLOTS;
+            const int my_chunk = lane >> 3;                                  // chunk of the tile this lane's terms belong to
+            auto load_raw = [&](int tile, RsRaw<AmtT> &r) {
+                const int64_t tb = start + (c0 + (int64_t)tile * 8) * 64;
+                if (tb + 511 <= e_bar) {                                     // (wave-uniform) one address per column, immediate offsets
+                    const double *pb = price + tb + lane;
+                    const AmtT *ab = am + tb + lane;
+                    const int8_t *sb = side + tb + lane;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { r.p[c] = pb[c * 64]; r.v[c] = ab[c * 64]; r.sd[c] = sb[c * 64]; }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        int64_t j = tb + c * 64 + lane;
+                        j = j <= e_bar ? j : e_bar;
+                        r.p[c] = price[j]; r.v[c] = am[j]; r.sd[c] = side[j];
+                    }
+                }
+                const int64_t jp = fmk_wrap((tb <= e_bar ? tb : e_bar) - 1, n);
+                r.pp = price[jp]; r.ps = side[jp];
+            };
+            auto terms = [&](int tile, const RsRaw<AmtT> &r, double (&x)[8]) -> unsigned {
+                const int64_t tb = start + (c0 + (int64_t)tile * 8) * 64;
+                unsigned fb = 0;
+                double carry_p = r.pp;
+                int carry_s = (tb == start && !(e_bar > start)) ? 0 : r.ps;     // base.py:485-488: a one-tick bar
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool valid = tb + c * 64 + lane <= e_bar;
+                    const double p = r.p[c], v = (double)r.v[c];
+                    const int sd = r.sd[c];
+                    const bool buy = valid && sd == 1, sell = valid && sd == -1;
+                    const double pv = p * v;
+                    double t;
+                    switch (row) {                                           // (block-uniform)
+                    case 0: t = buy ? v : 0.0; break;
+                    case 1: t = sell ? v : 0.0; break;
+                    case 2: t = buy ? pv : 0.0; break;
+                    case 3: t = sell ? pv : 0.0; break;
+                    case 4: {                                                // base.py:485-500: |price change| where the side changes
+                        const double pprev = fmk_dpp_shift_up1(p, carry_p);
+                        const int sprev = fmk_dpp_shift_up1(sd, carry_s);
+                        carry_p = fmk_last_lane(p); carry_s = fmk_last_lane(sd);
+                        t = valid && sd != sprev ? fabs(p - pprev) : 0.0;
+                        break;
+                    }
+                    case 5: t = buy ? v : sell ? -v : 0.0; break;
+                    default: t = buy ? pv : sell ? -pv : 0.0; break;
+                    }
+                    x[c] = t;
+                    fb |= (buy || sell) ? 1u << c : 0u;
+                }
+                return fb;
+            };
+            auto turn = [&](const double (&x)[8], double (&q)[8]) {          // tick order across lanes -> eight consecutive per lane
+#pragma unroll
+                for (int c = 0; c < 8; ++c) stage[(c * 8 + (lane >> 3)) * 9 + (lane & 7)] = x[c];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = stage[lane * 9 + i];
+                __builtin_amdgcn_wave_barrier();
+            };
+            // ---- A1: plain chunk totals (any order), sum of magnitudes, which ticks are signed
+            {
+                RsRaw<AmtT> rn;
+                if (w < nt) load_raw(w, rn);
+                for (int tile = w; tile < nt; tile += RS_WAVES) {
+                    double x[8], q[8];
+                    const unsigned fb = terms(tile, rn, x);
+                    if (tile + RS_WAVES < nt) load_raw(tile + RS_WAVES, rn);
+                    turn(x, q);
+                    double lt = 0.0, la = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { lt += q[i]; la += fabs(q[i]); }
+                    const double t = fmk_half_sum(lt), ta = fmk_half_sum(la);
+                    const int c = tile * 8 + my_chunk;
+                    if ((lane & 7) == 0 && c < nc) { s_tot[c] = t; s_abs[c] = ta; s_cabs[c] = ta; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint64_t fm = __ballot((fb >> k) & 1);
+                        if (lane == 0 && tile * 8 + k < nc) s_flow[tile * 8 + k] = fm;
+                    }
+                }
+            }
+            __syncthreads();
+            BF_T(3);
+            // ---- A2: exclusive prefix of the totals (approximate), total magnitude of the block: wave 0, RS_CH / 64 entries per lane
+            if (w == 0) {
+                double loc[RS_CH / 64], acc = 0.0, aabs = 0.0;
+                long long nf = 0;
+#pragma unroll
+                for (int k = 0; k < RS_CH / 64; ++k) {
+                    const int c = lane * (RS_CH / 64) + k;
+                    loc[k] = acc;
+                    acc += c < nc ? s_tot[c] : 0.0;
+                    aabs += c < nc ? s_abs[c] : 0.0;
+                    nf += c < nc ? __popcll(s_flow[c]) : 0;
+                }
+                const double incl = fmk_dpp_iscan(acc, 0.0, FmkOpAdd());
+                const double off = incl - acc;
+                const double tabs = fmk_dpp_reduce(aabs, 0.0, FmkOpAdd());
+                const int64_t nft = fmk_dpp_reduce((int64_t)nf, (int64_t)0, FmkOpAdd());
+                if (lane == 0) { s_nflow += nft; s_npool = 0; }
+#pragma unroll
+                for (int k = 0; k < RS_CH / 64; ++k) {
+                    const int c = lane * (RS_CH / 64) + k;
+                    if (c < nc) { s_tot[c] = off + loc[k]; s_abs[c] = tabs; }
+                }
+            }
+            __syncthreads();
+            BF_T(4);
+            // ---- A3: the chunk records (same tiles, now from L2; lane l holds terms 8 l .. 8 l + 7 of the tile, its chunk is its half row)
+            const double s0 = s_carry[0];
+            auto pow2 = [](int k) { return __longlong_as_double((long long)(k + 1023) << 52); };
+            {
+                RsRaw<AmtT> rn;
+                if (w < nt) load_raw(w, rn);
+                for (int tile = w; tile < nt; tile += RS_WAVES) {
+                    double x[8], q[8];
+                    terms(tile, rn, x);
+                    if (tile + RS_WAVES < nt) load_raw(tile + RS_WAVES, rn);
+                    turn(x, q);
+                    const int c = tile * 8 + my_chunk;
+                    const int cc = c < nc ? c : nc - 1;
+                    const double Sa = s0 + s_tot[cc];                        // approximate start value of the chunk
+                    const double margin = (fabs(s0) + s_abs[cc]) * 9.1e-13;  // 2^-40 (|s0| + sum |x|): >> the prefix's rounding error
+                    const double as = fabs(Sa);
+                    const bool neg = Sa < 0.0;
+                    const bool usable = as > margin && as >= 2.3e-308 && as < INFINITY;
+                    int e = (int)((__double_as_longlong(as) >> 52) & 0x7FF) - 1023;
+                    const bool e_ok = e > -900 && e < 1000;
+                    e = e_ok ? e : 0;
+                    const double lo2 = pow2(e), hi2 = pow2(e + 1), lim = pow2(e - 1), half_g = pow2(e - 53);
+                    const double C = 1.5 * lo2;
+                    bool bad = false;
+                    double acc = 0.0, pq[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const double xs = neg ? -q[i] : q[i];
+                        const double y = (C + xs) - C;                       // |xs| < 2^(e-1): C + xs stays in C's binade -> y = rnd_g(xs)
+                        const double rr = xs - y;
+                        bad |= !(fabs(xs) < lim) || fabs(rr) == half_g;
+                        acc += y;
+                        pq[i] = acc;
+                    }
+                    // sum |y| <= sum |x| + 64 g / 2 < 2^(e+1) = 2^53 g (tested below): the lane's partial sums and the scan are exact.
+                    // (A bound on the SUM, not 64 x the largest term: signed rows hover within a few hundred terms of zero.)
+                    const double incl = fmk_half_iscan_add(acc, lane);
+                    const double base = incl - acc;
+                    double pmin = INFINITY, pmax = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const double P = base + pq[i]; pmin = bf_min(pmin, P); pmax = bf_max(pmax, P); }
+                    const double rmin = fmk_half_min(pmin), rmax = fmk_half_max(pmax);
+                    const double T = fmk_half_sum(acc);                      // (multiples of g: exact in any order)
+                    const uint64_t bb = __ballot(bad);
+                    const bool seg_bad = ((bb >> (lane & ~7)) & 0xFF) != 0;
+                    // the inclusive prefixes stay inside the binade by a margin that covers the approximate base
+                    const bool good = usable && e_ok && !seg_bad && s_cabs[cc] < hi2 * 0.999999999 &&
+                                      as + rmin > lo2 + margin && as + rmax < hi2 - margin && as > lo2 + margin && as < hi2 - margin;
+                    if ((lane & 7) == 0 && c < nc) {
+                        RsRec r;
+                        r.T = good ? T : -1.0; r.minP = good ? rmin : 0.0; r.maxP = good ? rmax : 0.0;
+                        r.e = good ? e : RS_NONE; r.neg = neg;
+                        s_rec[c] = r;
+                    }
+                }
+            }
+            __syncthreads();
+            BF_T(5);
+            // ---- A4: group records (a thread per group of RS_GRP chunks); a pool slot for every chunk without a record (T = slot, or -1)
+            const int ng = (nc + RS_GRP - 1) / RS_GRP;
+            if ((int)threadIdx.x < ng) {
+                const int g0 = (int)threadIdx.x * RS_GRP;
+                RsRec g;
+                g.T = 0.0; g.minP = INFINITY; g.maxP = -INFINITY; g.e = s_rec[g0].e; g.neg = s_rec[g0].neg;
+                for (int k = 0; k < RS_GRP && g0 + k < nc; ++k) {
+                    const RsRec r = s_rec[g0 + k];
+                    if (r.e == RS_NONE || r.e != g.e || r.neg != g.neg) { g.e = RS_NONE; break; }
+                    g.minP = fmin(g.minP, g.T + r.minP);
+                    g.maxP = fmax(g.maxP, g.T + r.maxP);
+                    g.T += r.T;
+                }
+                s_grp[threadIdx.x] = g;
+            }
+            __syncthreads();
+            for (int c = (int)threadIdx.x; c < nc; c += 64 * RS_WAVES) {
+                if (s_rec[c].e == RS_NONE) {
+                    const int slot = atomicAdd(&s_npool, 1);
+                    s_rec[c].T = slot < POOL_N ? (double)slot : -1.0;
+                }
+            }
+            __syncthreads();
+            // ---- A5: the pool (all waves): the terms of those chunks, in tick order
+            for (int c = w; c < nc; c += RS_WAVES) {
+                if (s_rec[c].e != RS_NONE || s_rec[c].T < 0.0) continue;    // (wave-uniform)
+                bool fl;
+                s_stage[(int)s_rec[c].T * 64 + lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
+            }
+            __syncthreads();
+            BF_T(6);
+            // ---- B: the walk, in order (wave 0; every lane carries the same values)
+            if (w == 0) {
+                double s = s_carry[0], mn = s_carry[1], mx = s_carry[2];
+                bool started = s_carry[3] != 0.0;
+                // one record (a chunk's or a group's): true when s, mn, mx have been advanced over it
+                auto step = [&](const RsRec &r) -> bool {
+                    const double as = fabs(s);
+                    if (!((started || !extrema) && r.e != RS_NONE && as >= 2.3e-308 && (s < 0.0) == (r.neg != 0))) return false;
+                    const int e = (int)((__double_as_longlong(as) >> 52) & 0x7FF) - 1023;
+                    const double lo2 = pow2(r.e), hi2 = pow2(r.e + 1);
+                    const double lo_v = as + r.minP, hi_v = as + r.maxP;     // exact when inside the binade
+                    if (!(e == r.e && lo_v > lo2 && hi_v < hi2)) return false;
+                    mn = fmin(mn, s < 0.0 ? -hi_v : lo_v);
+                    mx = fmax(mx, s < 0.0 ? -lo_v : hi_v);
+                    s = s < 0.0 ? -(as + r.T) : as + r.T;
+                    return true;
+                };
+                for (int g = 0; g < ng; ++g) {
+                    if (step(s_grp[g])) continue;
+                    const int c_end = (g + 1) * RS_GRP < nc ? (g + 1) * RS_GRP : nc;
+                    for (int c = g * RS_GRP; c < c_end; ++c) {
+                        const RsRec r = s_rec[c];
+                        if (step(r)) continue;
+                        // term by term: EVERY lane adds all 64 terms (broadcast LDS reads): one to three instructions per term, no
+                        // cross-lane traffic inside the dependent chain.  The terms wait in the pool; a chunk whose record did not
+                        // fit the actual s (or that found the pool full) fetches them now.
+                        const double *xs = s_x;
+                        if (r.e == RS_NONE && r.T >= 0.0) xs = s_stage + (int)r.T * 64;
+                        else {
+                            bool fl;
+                            s_x[lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
+                        }
+                        const uint64_t fm = s_flow[c];
+                        __builtin_amdgcn_wave_barrier();
+                        if (!extrema) {
+#pragma unroll 16
+                            for (int k = 0; k < 64; ++k) s += xs[k];
+                        } else if (started) {
+#pragma unroll 16
+                            for (int k = 0; k < 64; ++k) { s += xs[k]; mn = bf_min(mn, s); mx = bf_max(mx, s); }
+                        } else {
+                            for (int k = 0; k < 64; ++k) {
+                                s += xs[k];
+                                started = started || ((fm >> k) & 1);
+                                if (started) { mn = fmin(mn, s); mx = fmax(mx, s); }
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) atomicAdd(&bf_redo_stats[2], 1ULL);
+                    }
+                }
+                if (lane == 0) { s_carry[0] = s; s_carry[1] = mn; s_carry[2] = mx; s_carry[3] = started ? 1.0 : 0.0; }
+            }
+            __syncthreads();
+            BF_T(7);
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd(&bf_redo_stats[0], 1ULL);
+            atomicAdd(&bf_redo_stats[1], (unsigned long long)n_ch);
+#ifndef BF_REDO_TIMING
+            atomicAdd(&bf_redo_stats[3 + row], 1ULL);
+#endif
+            const double sum = s_carry[0];
+            switch (row) {
+            case 0: o.volume_buy[b] = (float)sum; break;
+            case 1: o.volume_sell[b] = (float)sum; break;
+            case 2: o.dollars_buy[b] = (float)sum; break;
+            case 3: o.dollars_sell[b] = (float)sum; break;
+            case 4: o.mean_spread[b] = s_nflow == 0 ? NAN : (float)(sum / (double)s_nflow); break;
+            case 5: o.cum_volumes_min[b] = (float)s_carry[1]; o.cum_volumes_max[b] = (float)s_carry[2]; break;
+            default: o.cum_dollars_min[b] = (float)s_carry[1]; o.cum_dollars_max[b] = (float)s_carry[2]; break;
+            }
+        }
+    }
+}
+
+// redo launch: the chunk-record kernel (developer knob FMK_DIR_REDO_ROWS=0: one wave per bar, seven lanes adding term by term)
+template <bool AF64>
+static void bf_redo_launch(fmk_ctx *ctx, unsigned rblocks, const double *d_price, const void *d_amount, const int8_t *d_side,
+                           const int64_t *d_close_idx, int64_t n, const FlowDirOut &o, const unsigned long long *redo)
+{
+    const char *rv = getenv("FMK_DIR_REDO_ROWS");
+    if (!rv || atoi(rv))
+        k_bar_dir_redo_par<AF64><<<(unsigned)(ctx->n_cu * 2), 64 * RS_WAVES, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+    else
+        k_bar_dir_redo<AF64><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+}
+
 
 // ---------------------------------------------------------------------------------------
 // directional only, ONE LANE PER BAR (round 2, float32 amounts): the schedule for streams of many moderate bars.
@@ -752,6 +1367,7 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     if (n_idx < 1) return fmk_set_error(ctx, FMK_E_ARG, "negative dimensions are not allowed");
     if (n <= 0 || !d_side || !d_out) return fmk_set_error(ctx, FMK_E_ARG, "comp_bar_directional: bad arguments");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_TRY(bf_sync_force_redo(ctx));
     const int64_t nb = n_idx - 1;
     FlowDirOut o;
     memcpy(&o, d_out, sizeof(o));
@@ -763,6 +1379,25 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 16, (void **)&redo));
     FMK_HIP(ctx, hipMemsetAsync(redo, 0, 8, ctx->stream));
     const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
+    // bars of more than BFW_MIN ticks: a workgroup per bar, from a list (developer knob FMK_DIR_WIDE=0: one wave per bar as before)
+    const char *wv = getenv("FMK_DIR_WIDE");
+    const bool wide_on = !wv || atoi(wv);
+    const int64_t skip_above = wide_on ? BFW_MIN : INT64_MAX;
+    auto wide = [&]() -> int {
+        if (!wide_on) return FMK_OK;
+        int64_t *wl = nullptr;
+        FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n, BFW_MIN, nullptr, &wl));
+        if (amount_is_f64)
+            k_bar_dir_wide<true><<<(unsigned)(ctx->n_cu * 2), 64 * BFW_WAVES, 0, ctx->stream>>>(
+                d_price, d_amount, d_side, d_close_idx, wl, n, o, (unsigned long long *)d_n_zero_div, redo);
+        else
+            k_bar_dir_wide<false><<<(unsigned)(ctx->n_cu * 2), 64 * BFW_WAVES, 0, ctx->stream>>>(
+                d_price, d_amount, d_side, d_close_idx, wl, n, o, (unsigned long long *)d_n_zero_div, redo);
+        const hipError_t le = hipGetLastError();
+        FMK_TRY(fmk_free(ctx, wl));
+        FMK_HIP(ctx, le);
+        return FMK_OK;
+    };
     // One lane per bar when there are enough moderate bars to fill the chip with 64-bar waves (developer knob
     // FMK_DIR_LANES: 0 never, 2 whenever the layout allows it); float32 amounts, 8- / 4-byte aligned amount / side columns.
     const char *lv = getenv("FMK_DIR_LANES");
@@ -784,19 +1419,25 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
                                                                                     8192, DlOhlcOut{});
         FMK_LAUNCH_CHECK(ctx);
         k_bar_dir<false><<<(unsigned)(blocks < 2048 ? blocks : 2048), 256, 0, ctx->stream>>>(
-            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, redo, long_list);
-        k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+            d_price, d_amount, d_side, d_close_idx, nb, n, o, (unsigned long long *)d_n_zero_div, redo, long_list, skip_above);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_TRY(wide());
+        bf_redo_launch<false>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }
     if (amount_is_f64) {
         k_bar_dir<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
-                                                                 (unsigned long long *)d_n_zero_div, redo);
-        k_bar_dir_redo<true><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+                                                                 (unsigned long long *)d_n_zero_div, redo, nullptr, skip_above);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_TRY(wide());
+        bf_redo_launch<true>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
     } else {
         k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
-                                                                  (unsigned long long *)d_n_zero_div, redo);
-        k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+                                                                  (unsigned long long *)d_n_zero_div, redo, nullptr, skip_above);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_TRY(wide());
+        bf_redo_launch<false>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
     }
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
@@ -871,7 +1512,10 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
     const bool short_bars = n / (n_idx - 1) < 600;
     const char *flv = getenv("FMK_FLOW_LANES");
     const int flow_lanes = flv ? atoi(flv) : 1;
-    if (amount_is_f64 || separate || short_bars) {
+    // long bars (hourly, daily): comp_bar_ohlcv and the order-flow features each have workgroup-per-bar schedules of their own
+    // (fmk_ohlcv.hip: k_bar_ohlcv_mid / _wide, here: k_bar_dir_wide); the fused wave-per-bar kernel below is for the middle
+    const bool long_bars = n / (n_idx - 1) > 8192;
+    if (amount_is_f64 || separate || short_bars || long_bars) {
         FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
                                        d_close, d_volume, d_vwap, d_trades, d_median));
         FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
@@ -906,7 +1550,7 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         if (blocks > 2048) blocks = 2048;
         k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                    (unsigned long long *)d_n_zero_div, redo, long_list);
-        k_bar_dir_redo<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+        bf_redo_launch<false>(ctx, (unsigned)blocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
         FMK_LAUNCH_CHECK(ctx);
         FMK_TRY(fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, 8192, any_long, d_open, d_high, d_low,
                                           d_close, d_volume, d_vwap, d_trades));
@@ -943,7 +1587,7 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
                                                                             saw_long);
         FMK_LAUNCH_CHECK(ctx);
         const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
-        k_bar_dir_redo<false><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
+        bf_redo_launch<false>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
         FMK_LAUNCH_CHECK(ctx);
         if (d_median) FMK_TRY(fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, (int64_t)BF_MED_TILES * 512, saw_long, d_median, n));
     }
@@ -975,4 +1619,19 @@ extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, cons
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
                                        max_levels, d_fp, d_n_bad_level, n);
+}
+
+// diagnostics since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
+// pairs of row 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)}
+extern "C" int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10)
+{
+    unsigned long long v[10], z[10];
+    memset(v, 0, sizeof v);
+    memset(z, 0, sizeof z);
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FMK_HIP(ctx, hipMemcpyFromSymbol(v, HIP_SYMBOL(bf_redo_stats), sizeof v));
+    FMK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(bf_redo_stats), z, sizeof z));
+    for (int i = 0; i < 10; ++i) out10[i] = (int64_t)v[i];
+    return FMK_OK;
 }

@@ -164,3 +164,36 @@ __device__ __forceinline__ double fmk_row_min(double v)
     v = fmin(v, fmk_dpp<DPP_MIRROR, 0xF>(v, v));
     return v;
 }
+
+// ---- the same inside a HALF ROW of 8 lanes (eight independent segments per wave): three butterfly steps; and the inclusive scan of
+// a half row (row_shr:1 / 2 / 4; a lane whose source lies in the other half keeps its value)
+__device__ __forceinline__ double fmk_half_sum(double v)
+{
+    v += fmk_dpp<DPP_XOR1, 0xF>(v, v);
+    v += fmk_dpp<DPP_XOR2, 0xF>(v, v);
+    v += fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v);
+    return v;
+}
+__device__ __forceinline__ double fmk_half_max(double v)
+{
+    v = fmax(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    return v;
+}
+__device__ __forceinline__ double fmk_half_min(double v)
+{
+    v = fmin(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    return v;
+}
+__device__ __forceinline__ double fmk_half_iscan_add(double v, int lane)
+{
+    const int k = lane & 7;
+    double t;
+    t = fmk_dpp<FMK_DPP_ROW_SHR(1), 0xF>(0.0, v); v += k >= 1 ? t : 0.0;
+    t = fmk_dpp<FMK_DPP_ROW_SHR(2), 0xF>(0.0, v); v += k >= 2 ? t : 0.0;
+    t = fmk_dpp<FMK_DPP_ROW_SHR(4), 0xF>(0.0, v); v += k >= 4 ? t : 0.0;
+    return v;
+}

@@ -423,6 +423,9 @@ int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t str
 /* host-to-device rate of this box for one buffer, GB/s, best of three: mode 1 = hipMemcpy from pinned memory (the link's ceiling),
  * 0 = hipMemcpy from pageable memory, 2 = fmk_h2d_columns from pageable memory */
 int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps);
+/* order-flow redo since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
+ * pairs of column 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)} */
+int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10);
 int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
 /* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
 int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);

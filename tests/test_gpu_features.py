@@ -206,3 +206,40 @@ def test_imbalance_flags_compare_in_float64(orc):
     np.testing.assert_array_equal(got[1], want[1])
     assert list(got[1]) == [True, False, True, False]                   # sell[l] > buy[l+1] * 3: levels 0 and 2 are the 0.3 vs 0.1 pairs
     assert got[2] == want[2] and got[3] == want[3]
+
+
+@pytest.mark.parametrize("amounts", ["dyadic", "lognormal32", "f64", "ties", "signflip", "huge_then_small"])
+@pytest.mark.parametrize("rows", ["1", "0"])
+def test_order_flow_redo_in_tick_order(orc, monkeypatch, amounts, rows):
+    """Every bar forced onto the redo list (FMK_DIR_FORCE_REDO=1) and redone in tick order: by the row-per-wave kernel, which adds
+    64 terms per step with the machine's own rounding to the running sum's grid (exact unless a term ties or the sum leaves its
+    binade -- then term by term), and by the old lane walkers (FMK_DIR_REDO_ROWS=0).  Both must give the oracle's sequential sums
+    bit for bit: short bars (the sum climbs through many binades), long bars, signed running sums that cross zero, exact ties
+    (terms that are half a grid step: dyadic prices), a huge first term followed by tiny ones, float64 amounts."""
+    from finmlkit_amd import engine
+    monkeypatch.setenv("FMK_DIR_FORCE_REDO", "1")
+    monkeypatch.setenv("FMK_DIR_REDO_ROWS", rows)
+    monkeypatch.setenv("FMK_DIR_LANES", "0")
+    n = 400_000
+    ts, px, am, sd = orc.synth(31, 0, n)
+    rng = np.random.default_rng(17)
+    if amounts == "lognormal32":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    elif amounts == "f64":
+        am = rng.lognormal(-1, 1.2, n)
+    elif amounts == "ties":
+        px = np.round(px * 4) / 4 + 64.0                                  # dyadic prices: products with few bits -> exact half steps
+        am = (rng.integers(1, 1 << 20, n) * 2.0 ** -12).astype(np.float64)
+    elif amounts == "signflip":
+        sd = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int8)       # the signed sums hover around zero
+        am = rng.lognormal(-1, 0.2, n).astype(np.float32)
+    elif amounts == "huge_then_small":
+        am = rng.lognormal(-8, 1.0, n).astype(np.float64)
+        am[::50_000] = 1e9
+    ci = np.concatenate([[-1], np.sort(rng.choice(n - 1, 60, replace=False)), [n - 1]]).astype(np.int64)   # 61 bars, 1 .. 30 000 ticks
+    t = engine.DeviceTrades.from_numpy(ts, px, am, sd)
+    d, nz = t.bar_directional(engine.DeviceArray.from_host(t.ctx, ci))
+    want = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    got = engine.to_host(d)
+    for k, w in zip(G.DIR_KEYS, want):
+        np.testing.assert_array_equal(got[k], w, err_msg=f"{k} ({amounts}, rows={rows})")
