@@ -100,6 +100,30 @@ __device__ __forceinline__ bool fp_certified(const FpStats &st, int q)
     return st.units_ok && q <= st.lbmin && q >= -149 && q <= 100 && st.atot < ldexp(1.0, 24 + q);
 }
 
+// The same per (level, side) KEY (round 3): the reference's float32 sums are per key, so what must stay below 2^24 units is every
+// key's total, not the bar's (a bar of more than 8192 ticks of ~2^11 units each fails the bar-level test whatever its levels look
+// like).  Non-negative whole units, the bar's total below 2^32 (no 32-bit counter has wrapped), every key below 2^24: every partial
+// sum of every key is exactly representable.  Wave-level: all lanes call, the result is uniform.
+__device__ __forceinline__ bool fp_certified_units_per_key(const FpStats &st, const unsigned *units, int nkeys, int lane)
+{
+    if (!(st.units_ok && st.atot < 4294967296.0)) return false;
+    unsigned m = 0;
+    for (int k = lane; k < nkeys; k += 64) m = units[k] > m ? units[k] : m;
+    return (unsigned)fmk_dpp_reduce((int)(m >> 1), 0, FmkOpMax()) < (16777216u >> 1);     // (m >> 1: compared as signed ints)
+}
+// ... and after a tick-ordered sweep, whose vol[] holds the (rounded) float32 key sums: rounding is monotone and 2^(24+q) is a
+// float32, so a rounded sum below it means a true sum below it.  All terms are non-negative multiples of 2^q (lbmin, units_ok).
+__device__ __forceinline__ bool fp_certified_per_key(const FpStats &st, int q, const float *vol, int nkeys, int lane)
+{
+    if (st.lbmin == FP_Q_UNKNOWN) return true;
+    if (!(st.units_ok && q <= st.lbmin && q >= -149 && q <= 100 && st.atot < ldexp(1.0, 32 + q))) return false;
+    float m = 0.f;
+    bool neg = false;
+    for (int k = lane; k < nkeys; k += 64) { const float v = vol[k]; neg |= !(v >= 0.f); m = v > m ? v : m; }
+    const double mm = fmk_dpp_reduce((double)m, 0.0, FmkOpMax());
+    return __ballot(neg) == 0 && mm < ldexp(1.0, 24 + q);
+}
+
 // Level rows + comp_footprint_features (base.py:755-850) of ONE bar from the wave's LDS histogram:
 //   vol[2L] float32 (buy = 2l, sell = 2l+1), cnt[2L], aux[2*lmax] scratch, stk[64] ints.  `base` = CSR row offset.
 __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t base, int L, int64_t low, int lmax,

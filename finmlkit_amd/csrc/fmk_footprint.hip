@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                                                         unsigned char *gscratch, int lean,
                                                         const unsigned long long *only = nullptr,
                                                         double *__restrict__ o_median = nullptr,
-                                                        int *__restrict__ saw_long = nullptr)
+                                                        int *__restrict__ saw_long = nullptr,
+                                                        int64_t skip_above = INT64_MAX, int skip_lmax = 0 /* longer bars of <= skip_lmax levels: k_bar_footprints_wide */)
 {
     static_assert(!(MED && AF64), "the in-sweep median serves float32 amounts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -499,6 +500,13 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (L <= lmin || L > lmax) continue;          // handled by another launch (or L == 0)
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
+        if (e - s > skip_above && L <= skip_lmax) {                // a workgroup has taken this bar (k_bar_footprints_wide)
+            if constexpr (MED) {                                       // ... and its median is the long-bar kernels'
+                if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
         const int64_t low = fp_level(lows[b], tick);
         for (int k = lane; k < 2 * L; k += 64) { vol[k] = 0.f; cnt[k] = 0; }
         __builtin_amdgcn_wave_barrier();
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
                 if (lean) { st = fp_accumulate_lean<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq, medp); did = true; }
             }
             if (!did) st = fp_accumulate<AF64, true>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, wq);
-            done = fp_certified_units(st);
+            done = fp_certified_units(st) || fp_certified_units_per_key(st, (const unsigned *)vol, 2 * L, lane);
             if (done) {       // units -> float32 (exact)
                 unsigned *units = (unsigned *)vol;
                 const int qq = wq;
@@ -533,7 +541,8 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             // remember a usable quantum for the next bar (if this bar would have certified)
             FpStats probe = st;
             probe.units_ok = true;
-            const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 && fp_certified(probe, st.lbmin);
+            const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 &&
+                                (fp_certified(probe, st.lbmin) || fp_certified_per_key(probe, st.lbmin, vol, 2 * L, lane));
             wq = usable ? st.lbmin : FP_Q_UNKNOWN;
         }
         if (st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
@@ -560,6 +569,177 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     }
     if constexpr (MED) {
         if (lane == 0 && med_fallbacks) atomicAdd(saw_long + 1, med_fallbacks);     // diagnostics (fmk_diag_fp_median_fallbacks)
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Bars of more than FPW_MIN ticks and at most FPW_MAX_LEVELS levels (hourly, daily bars; the histogram takes 24 B of LDS per level:
+// up to 147 KB of the CU's 160): a WORKGROUP per bar on ONE LDS histogram
+// (round 3).  With a wave per bar the 580 daily bars of a 1e9-tick tape are 580 waves streaming 1.7e6 ticks each: 73 ms.  The
+// integer-unit sweep is order-free, so sixteen waves take a sixteenth of the bar each and add into the shared histogram with LDS
+// atomics; the certificate is the per-key one (fp_certified_units_per_key: a daily bar's TOTAL is far beyond 2^24 units, its
+// levels are not).  The quantum 2^q travels from bar to bar as in the wave kernel; without one (first bar of the workgroup, or
+// the last one failed) a statistics pass over the bar finds it.  A bar that does not certify -- amounts with full mantissas,
+// negative or non-finite amounts -- is swept in tick order by wave 0 alone, as before.  Level rows and features: wave 0
+// (fp_emit_bar), while the second workgroup of the CU sweeps.
+// ---------------------------------------------------------------------------------------
+#define FPW_MIN 8192
+#define FPW_WAVES 16
+#define FPW_MAX_LEVELS 6144
+
+// lowest-bit / magnitude statistics of the pending ticks (signed side, inside the level range) of (s, e]: what the tick-ordered
+// sweep reports, without a histogram
+template <bool AF64>
+__device__ __forceinline__ FpStats fp_stats_lean(const double *__restrict__ price, const void *__restrict__ amount,
+                                                 const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low, int L,
+                                                 double tick, double inv_tick, int lane)
+{
+    typedef typename std::conditional<AF64, double, float>::type AmtT;
+    int lbmin = FP_Q_UNKNOWN;
+    double atot = 0.0;
+    bool bad = false;
+    const int ilow = (int)low;
+    const double *pp = price + (s + 1);
+    const AmtT *ap = (const AmtT *)amount + (s + 1);
+    const int8_t *sp = side + (s + 1);
+    const int total = (int)(e - s);
+    for (int j0 = 0; j0 < total; j0 += 256) {
+        double p[4];
+        AmtT a[4];
+        int sd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const int jc = j < total ? j : total - 1;
+            p[u] = pp[jc]; a[u] = ap[jc]; sd[u] = sp[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in_bar = j0 + u * 64 + lane < total;
+            const int lvl = fp_level32(p[u], tick, inv_tick) - ilow;
+            const bool inside = (unsigned)lvl < (unsigned)L;
+            bad |= in_bar && !inside;
+            if (in_bar && inside && (sd[u] == 1 || sd[u] == -1)) {
+                const int lb = fp_lowbit_exp(a[u]);
+                lbmin = lb < lbmin ? lb : lbmin;
+                atot += fabs((double)a[u]);
+            }
+        }
+    }
+    FpStats st;
+    st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
+    st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    st.units_ok = true;
+    st.bad = __ballot(bad) != 0;
+    return st;
+}
+
+template <bool AF64>
+__global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const double *__restrict__ price, const void *__restrict__ amount,
+                                                                      const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
+                                                                      const int64_t *__restrict__ list, double tick,
+                                                                      const double *__restrict__ lows, double imb_mult,
+                                                                      const int64_t *__restrict__ off, FpOut o,
+                                                                      unsigned long long *n_bad, int force_ordered, int lean,
+                                                                      int lmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *vol = (float *)smem;                                        // [2 * lmax]  buy = 2l, sell = 2l + 1
+    int *cnt = (int *)(smem + (size_t)lmax * 8);
+    float *aux = (float *)(smem + (size_t)lmax * 16);
+    int *stk = (int *)(smem + (size_t)lmax * 24);                      // 64 ints
+    __shared__ double s_atot[FPW_WAVES];
+    __shared__ int s_lb[FPW_WAVES], s_flag[FPW_WAVES];                 // s_flag: bit 0 units not ok, bit 1 bad level
+    __shared__ unsigned s_umax[FPW_WAVES];
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const double inv_tick = 1.0 / tick;
+    unsigned *units = (unsigned *)vol;
+    int wq = FP_Q_UNKNOWN;                                             // (block-uniform) the quantum the previous bar certified with
+    const int64_t n_list = list[0];
+    for (int64_t it = blockIdx.x; it < n_list; it += gridDim.x) {
+        const int64_t b = list[1 + it];
+        const int64_t base = off[b];
+        const int L = (int)(off[b + 1] - base);
+        if (L <= 0 || L > lmax) continue;                              // no rows / the global-scratch class of the wave kernel
+        const int64_t s = ci[b], e = ci[b + 1];
+        const int64_t low = fp_level(lows[b], tick);
+        int64_t seg = (e - s + FPW_WAVES - 1) / FPW_WAVES;
+        seg = (seg + 63) & ~(int64_t)63;
+        const int64_t s_w = s + (int64_t)w * seg < e ? s + (int64_t)w * seg : e;
+        const int64_t e_w = s_w + seg < e ? s_w + seg : e;
+        auto zero = [&]() {
+            __syncthreads();
+            for (int k = (int)threadIdx.x; k < 2 * L; k += 64 * FPW_WAVES) { vol[k] = 0.f; cnt[k] = 0; }
+            __syncthreads();
+        };
+        // all waves: combine the per-wave statistics (block-uniform result)
+        auto combine = [&](const FpStats &mine) -> FpStats {
+            if (lane == 0) { s_atot[w] = mine.atot; s_lb[w] = mine.lbmin; s_flag[w] = (mine.units_ok ? 0 : 1) | (mine.bad ? 2 : 0); }
+            __syncthreads();
+            FpStats t;
+            t.atot = 0.0; t.lbmin = FP_Q_UNKNOWN; t.units_ok = true; t.bad = false;
+            for (int k = 0; k < FPW_WAVES; ++k) {
+                t.atot += s_atot[k];
+                t.lbmin = s_lb[k] < t.lbmin ? s_lb[k] : t.lbmin;
+                t.units_ok = t.units_ok && !(s_flag[k] & 1);
+                t.bad = t.bad || (s_flag[k] & 2);
+            }
+            __syncthreads();
+            return t;
+        };
+        // the integer-unit sweep with quantum 2^q by all waves: true when every float32 add of the reference is certified exact
+        bool bad_level = false;
+        auto attempt = [&](int q) -> bool {
+            zero();
+            const FpStats mine = fp_accumulate_lean<AF64, true>(price, amount, side, s_w, e_w, low, L, tick, inv_tick, lane, vol, cnt, q);
+            const FpStats t = combine(mine);
+            bad_level = t.bad;
+            if (!t.units_ok || !(t.atot < 4294967296.0)) return false;  // (no 32-bit counter can have wrapped)
+            if (t.atot < 16777216.0) return true;
+            unsigned m = 0;
+            for (int k = (int)threadIdx.x; k < 2 * L; k += 64 * FPW_WAVES) m = units[k] > m ? units[k] : m;
+            m = (unsigned)fmk_dpp_reduce((int)(m >> 1), 0, FmkOpMax());   // (halved: compared as signed ints)
+            if (lane == 0) s_umax[w] = m;
+            __syncthreads();
+            unsigned mm = 0;
+            for (int k = 0; k < FPW_WAVES; ++k) mm = s_umax[k] > mm ? s_umax[k] : mm;
+            __syncthreads();
+            return mm < (16777216u >> 1);
+        };
+        bool done = false;
+        int q_used = wq;
+        if (!force_ordered) {
+            if (wq != FP_Q_UNKNOWN) done = attempt(wq);
+            if (!done) {
+                const FpStats t = combine(fp_stats_lean<AF64>(price, amount, side, s_w, e_w, low, L, tick, inv_tick, lane));
+                const int q2 = t.lbmin == FP_Q_UNKNOWN ? 0 : t.lbmin;      // only zeros: any quantum
+                if (t.lbmin != (int)0x80000000 && q2 >= -149 && q2 <= 100 && q2 != wq) {
+                    done = attempt(q2);
+                    q_used = q2;
+                }
+            }
+        }
+        if (done) {
+            wq = q_used;
+            for (int k = (int)threadIdx.x; k < 2 * L; k += 64 * FPW_WAVES) vol[k] = ldexpf((float)units[k], q_used);
+        } else {
+            // tick order: one wave (the float32 level sums round on every add, base.py:713-717)
+            zero();
+            wq = FP_Q_UNKNOWN;
+            if (w == 0) {
+                FpStats st;
+                if (lean) st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
+                else st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
+                bad_level = st.bad;
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            if (bad_level && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
+            fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk);
+        }
+        __syncthreads();
     }
 }
 
@@ -802,7 +982,7 @@ template <bool AF64>
 static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t *sd, const int64_t *ci, int64_t nb,
                      double tick, const double *lows, double imb_mult, const int64_t *off, int lmin, int lmax, int wpb,
                      const FpOut &o, unsigned long long *n_bad, const unsigned long long *only = nullptr,
-                     double *d_median = nullptr, int *saw_long = nullptr)
+                     double *d_median = nullptr, int *saw_long = nullptr, int64_t skip_above = INT64_MAX, int skip_lmax = 0)
 {
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
@@ -830,7 +1010,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
             if (gscratch)
                 k_bar_footprints<false, true, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(
                     p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, gscratch, 0, only, d_median,
-                    saw_long);
+                    saw_long, skip_above, skip_lmax);
             else {
                 // the bracket lives in a wave from bar to bar and every wave's FIRST bar takes the generic selection: as many
                 // workgroups as are resident at once (grid-stride over the bars), not 64 per CU
@@ -850,7 +1030,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
                 if (blocks > resident) blocks = resident;
                 k_bar_footprints<false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(
                     p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, nullptr,
-                    fp_lds_atomics_in_lane_order(ctx), only, d_median, saw_long);
+                    fp_lds_atomics_in_lane_order(ctx), only, d_median, saw_long, skip_above, skip_lmax);
             }
             FMK_LAUNCH_CHECK(ctx);
             return FMK_OK;
@@ -859,12 +1039,13 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if (gscratch)
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
-                                                                                   gscratch, 0, only);
+                                                                                   gscratch, 0, only, nullptr, nullptr, skip_above, skip_lmax);
     else
         k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
-                                                                                       fp_lds_atomics_in_lane_order(ctx), only);
+                                                                                       fp_lds_atomics_in_lane_order(ctx), only,
+                                                                                       nullptr, nullptr, skip_above, skip_lmax);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -954,14 +1135,50 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         const hipError_t e = hipMemsetAsync(saw_long, 0, 2 * sizeof(int), ctx->stream);   // [0] long bars seen, [1] generic selections
         if (e != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, e); }
     }
+    // bars of more than FPW_MIN ticks (and at most FP_MAX_LEVELS levels): a workgroup per bar, from a list; the wave-per-bar classes
+    // below skip them (developer knob FMK_FP_WIDE=0: one wave per bar as before)
+    int64_t skip_above = INT64_MAX;
+    int skip_lmax = 0;
+    {
+        const char *wv = getenv("FMK_FP_WIDE");
+        if ((!wv || atoi(wv)) && lmin_start == 0 && n_ticks > FPW_MIN) {
+            const char *fo = getenv("FMK_FP_ORDERED");
+            int64_t *wl = nullptr;
+            rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, FPW_MIN, nullptr, &wl);
+            if (rc == FMK_OK) {
+                // the widest bar of the call bounds the histogram (one workgroup per CU beyond ~3 000 levels, two below)
+                const int wl_max = (int)(max_levels < 64 ? 64 : (max_levels > FPW_MAX_LEVELS ? FPW_MAX_LEVELS : max_levels));
+                const size_t smem = (size_t)wl_max * 24 + 256;
+                if (smem > 48 * 1024) {
+                    (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                }
+                const unsigned grid = (unsigned)(ctx->n_cu * 2);
+                const int lean = fp_lds_atomics_in_lane_order(ctx);
+                if (amount_is_f64)
+                    k_bar_footprints_wide<true><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
+                        d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
+                        fo ? atoi(fo) : 0, lean, wl_max);
+                else
+                    k_bar_footprints_wide<false><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
+                        d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
+                        fo ? atoi(fo) : 0, lean, wl_max);
+                const hipError_t le = hipGetLastError();
+                (void)fmk_free(ctx, wl);
+                if (le != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, le); }
+                skip_above = FPW_MIN;
+                skip_lmax = wl_max;
+            }
+        }
+    }
     for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         if (LMAX[k] > lmin_start) {
             rc = amount_is_f64
                      ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                       imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest)
+                                       imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, nullptr, nullptr, skip_above, skip_lmax)
                      : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, d_median, saw_long);
+                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, d_median, saw_long, skip_above, skip_lmax);
         }
         lmin = LMAX[k];
     }

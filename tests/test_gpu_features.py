@@ -243,3 +243,52 @@ def test_order_flow_redo_in_tick_order(orc, monkeypatch, amounts, rows):
     got = engine.to_host(d)
     for k, w in zip(G.DIR_KEYS, want):
         np.testing.assert_array_equal(got[k], w, err_msg=f"{k} ({amounts}, rows={rows})")
+
+
+@pytest.mark.parametrize("amounts", ["dyadic", "dyadic_heavy", "lognormal32", "f64_dyadic", "f64", "negative", "nan", "zeros",
+                                     "quantum_changes"])
+def test_footprints_long_bars_workgroup_per_bar(orc, amounts):
+    """Bars of more than 8 192 ticks (k_bar_footprints_wide: sixteen waves on one LDS histogram, integer units, certified per
+    (level, side) key) next to short ones in one call: dyadic amounts whose BAR total is far beyond 2^24 units while every key
+    stays below it (exact, order-free); amounts heavy enough that a key passes 2^24 units (the float32 sums round: tick order);
+    full-mantissa float32 and float64 amounts (tick order); a negative and a NaN amount inside a long bar; all-zero amounts; a
+    stream whose quantum changes from bar to bar (the statistics pass); unsigned ticks; a bar of more than 2 048 levels among
+    the long ones (stays with the wave kernel's global-scratch class)."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    n = 700_000
+    ts, px, am, sd = orc.synth(37, 0, n)
+    rng = np.random.default_rng(12)
+    sd = sd.copy()
+    sd[rng.random(n) < 0.02] = 0
+    if amounts == "dyadic_heavy":
+        am = (rng.integers(1, 1 << 16, n) * 2.0 ** -4).astype(np.float32)
+    elif amounts == "lognormal32":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    elif amounts == "f64_dyadic":
+        am = (rng.integers(1, 4096, n) * 2.0 ** -10).astype(np.float64)
+    elif amounts == "f64":
+        am = rng.lognormal(-1, 1.2, n)
+    elif amounts == "negative":
+        am = am.copy(); am[123_456] = -0.5
+    elif amounts == "nan":
+        am = am.copy(); am[223_456] = np.nan
+    elif amounts == "zeros":
+        am = np.zeros(n, np.float32)
+    elif amounts == "quantum_changes":
+        am = am.copy()
+        am[100_000:300_000] = (rng.integers(1, 64, 200_000) * 2.0 ** -3).astype(np.float32)
+        am[300_000:420_000] = (rng.integers(1, 1 << 12, 120_000) * 2.0 ** -14).astype(np.float32)
+    # bars: 9 000 .. 150 000 ticks, a few short ones and an empty one in between
+    cuts = [-1, 50, 9_100, 9_100, 60_000, 61_000, 210_000, 225_000, 420_000, 430_000, 520_000, 690_000, n - 1]
+    ci = np.array(cuts, dtype=np.int64)
+    tick = 0.01
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, amounts)
+    if amounts == "dyadic":
+        # a fine tick: the longest bars span more than 2 048 levels and stay with the global-scratch class
+        woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.0005, o[2], o[1], 3.0)
+        assert np.diff(woff).max() > 2048
+        off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.0005, o[2], o[1], 3.0)
+        _check_fp(off, flat, bar, woff, wflat, wbar, "dyadic, fine tick")
