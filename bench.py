@@ -42,6 +42,17 @@ def _traffic_constants():
         return None
 
 
+def kernel_source_sha256():
+    """Identity of the dominant kernel's code: SHA-256 over the sources k_bar_ohlcv_small is compiled from.  The traffic constants
+    carry the value they were measured at (tools/pmc_summarize.py); a different value here means `traffic` describes older code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fmk_ohlcv.hip", "fmk_median.h", "fmk_dpp.h", "fmk_common.h", "fmk_pairwise.h", "fmk_f32tie.h", "Makefile"):
+        with open(os.path.join(ROOT, "finmlkit_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -441,6 +452,7 @@ def run(args):
 
     tc = _traffic_constants()
     tc_ok = bool(tc) and want_median and args.interval == 60.0 and tc.get("write_bytes_per_bar") is not None
+    tc_stale = bool(tc_ok) and tc.get("kernel_source_sha256") != kernel_source_sha256()
     if rank == 0:
         total_ticks = n * world
         line = {
@@ -472,8 +484,11 @@ def run(args):
                          "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) if tc_ok else None,
-                         "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at commit "
-                                            f"{tc['commit']} (profiles/traffic_constants.json: FETCH_SIZE x{tc['fetch_size_correction']}, "
+                         # true when the kernel's sources have changed since the counters were read (SHA-256 in the constants)
+                         "traffic_stale": tc_stale if tc_ok else None,
+                         "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (sources "
+                                            f"sha256 {str(tc.get('kernel_source_sha256'))[:12]}, commit "
+                                            f"{tc['commit']}; profiles/traffic_constants.json: FETCH_SIZE x{tc['fetch_size_correction']}, "
                                             f"WRITE_SIZE x{tc['write_size_correction']}, calibrated on known byte counts in the same passes), "
                                             f"scaled to this run's ticks and bars; not collected in this run") if tc_ok else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,

@@ -103,9 +103,17 @@ class CUSUMBarKit(BarBuilderBase):
         args = (dev.ts.p, dev.price.p, d_sigma.p, c_i64(n), c_f64(self.sigma_floor), c_f64(self.lambda_mult))
         d_all = DeviceArray(dev.ctx, n, np.int64)                   # at most one close per tick: one pass, no count phase
         dev.ctx.call("fmk_cusum_bar_indexer_dev", *args, d_all.p, c_i64(n), C.byref(m), None)
-        d_idx = d_all.view(0, m.value)
+        # the m closes move to a buffer of their own: a view would keep all n slots (8 B per tick) alive with the builder
+        d_idx = DeviceArray(dev.ctx, m.value, np.int64)
+        if m.value:
+            dev.ctx.call("fmk_d2d", d_idx.p, d_all.p, C.c_size_t(m.value * 8))
+        dev.ctx.sync()
+        d_all.free()
+        filled = d_sigma.to_host()
         if sigma.flags["WRITEABLE"]:
-            sigma[...] = d_sigma.to_host()                          # the in-place forward fill, visible to the caller
+            sigma[...] = filled                                     # the in-place forward fill, visible to the caller
+        else:
+            self._sigma = filled                                    # read-only input: the builder keeps the filled copy (get_sigma)
         self._d_close_idx = d_idx
         return dev.gather_ts(d_idx).to_host(), d_idx.to_host()      # timestamps[close_indices] (kit.py:172-174)
 

@@ -211,10 +211,10 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
                 } else break;                                      // the reference's "stuck in loop" exit
             }
             float p = 0.f;
-            if (total > 0.f) {                                     // calc_volume_percentage_above_poc
+            if (!(total <= 0.f)) {                                 // calc_volume_percentage_above_poc (volume.py:378: `<= 0`, so a NaN total goes on)
                 double above = 0.0;
                 for (int k = 0; k < n; ++k) if (pl(k) > poc_price) above += (double)vol[k];
-                if (above > 0.0) p = (float)(above / (double)total);
+                if (!(above <= 0.0)) p = (float)(above / (double)total);
             }
             poc[i] = poc_price; hva[i] = hv; lva[i] = lv; pct[i] = p;
         }
@@ -308,11 +308,11 @@ __global__ __launch_bounds__(64) void k_pct_above_poc(const int32_t *__restrict_
     const float total = fmk_pairwise_f32([&](int i) { return vol[i]; }, n, lane, stk);
     if (lane == 0) {
         double r = 0.0;
-        if (total > 0.f) {
+        if (!(total <= 0.f)) {                                     // volume.py:378-379: `<= 0` -- a NaN total is not caught, NaN comes out
             double above = 0.0;
             for (int k = 0; k < n; ++k)
                 if (levels[k] > poc_price) above += (double)vol[k];
-            if (above > 0.0) r = above / (double)total;
+            if (!(above <= 0.0)) r = above / (double)total;                // :387-388
         }
         *out = r;
     }

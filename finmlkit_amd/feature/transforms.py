@@ -141,8 +141,10 @@ class Compose(SISOTransform):
         self._validate_input(x)
         if self.output_name in x.columns:
             return x[self.output_name]
-        if len(x) and not any(t.produces[0] in x.columns or (i and t.requires[0] in x.columns)
-                              for i, t in enumerate(self.transforms)):
+        # (only when every step has a device form of its own: a nested Compose or a user-defined SISOTransform takes the
+        # generic loop below)
+        if len(x) and all(type(t)._dev is not SISOTransform._dev for t in self.transforms) and \
+                not any(t.produces[0] in x.columns or (i and t.requires[0] in x.columns) for i, t in enumerate(self.transforms)):
             # the chain stays in HBM: timestamps and the input column go up once, every intermediate series is a device
             # buffer handed to the next kernel, only the last one comes back (the reference round-trips pandas objects)
             ctx = _ffi.default_context()

@@ -1032,10 +1032,10 @@ static void orc_poc_hva_lva(const int32_t *pl, const float *vol, int64_t n, doub
     }
     *poc = poc_price; *hva = hv; *lva = lv;
     float p = 0.0f;
-    if (total > 0.0f) {
+    if (!(total <= 0.0f)) {                                         /* volume.py:378: `<= 0` lets a NaN total through */
         double above = 0.0;
         for (int64_t k = 0; k < n; ++k) if (pl[k] > poc_price) above += vol[k];
-        if (above > 0.0) p = (float)(above / (double)total);
+        if (!(above <= 0.0)) p = (float)(above / (double)total);
     }
     *pct = p;
 }
@@ -1109,10 +1109,10 @@ int orc_volume_profile_rolling(const int64_t *ts, const double *highs, const dou
 double orc_calc_volume_percentage_above_poc(const int32_t *pl, const float *vol, int64_t n, int32_t poc_price)
 {
     float total = orc_pairwise_f32(vol, n);                       /* volume.py:377 np.sum(volumes) */
-    if (!(total > 0.f)) return 0.0;                               /* :378-379 */
+    if (total <= 0.f) return 0.0;                                  /* :378-379 (a NaN total is not caught) */
     double above = 0.0;
     for (int64_t k = 0; k < n; ++k) if (pl[k] > poc_price) above += vol[k];   /* :381-384 */
-    if (!(above > 0.0)) return 0.0;                               /* :387-388 */
+    if (above <= 0.0) return 0.0;                                  /* :387-388 */
     return above / (double)total;                                 /* :390 */
 }
 

@@ -16,7 +16,10 @@ against it on the CPU (tests/test_oracle_golden.py), the 10^9-tick HIP run's fir
 The stream's amounts are float32 multiples of 2^-10 whose per-bar sums are exact in float32, so the reference's
 pure-Python accumulation (float32 under NEP 50) and its Numba-typed one (float64) are the same numbers.
 
-    python oracle/gen_cfg1.py            # ~2 min; rewrites tests/golden/cfg1_reference_timebars.npz
+(The tick-level chain lagged returns -> ewmst -> CUSUM has a generator of its own, oracle/gen_ticklevel_chain.py: the reference's
+pure-Python loops need ~10 minutes per 10^6 ticks there, and a generator nobody re-runs stops being a pin.)
+
+    python oracle/gen_cfg1.py            # ~3 min; rewrites tests/golden/cfg1_reference_timebars.npz
 """
 import os
 import sys
@@ -111,21 +114,6 @@ def main():
     print(f"volume / dollar indexers: {len(d['cfg3_volume_close_indices']) - 1} / {len(d['cfg3_dollar_close_indices']) - 1} bars on "
           f"{N_OHLCV} ticks, {len(d['cfg3_logn_volume_close_indices']) - 1} / {len(d['cfg3_logn_dollar_close_indices']) - 1} on the "
           f"lognormal tape, in {time.time() - t0:.0f} s")
-
-    # ---- the tick-level chain at 10^6 ticks through the reference's own loops: comp_lagged_returns (core/utils.py:12-64) ->
-    #      ewmst (core/volatility.py:139-219) -> _cusum_bar_indexer (bar/logic.py:152-221).  Every 97th value of the two
-    #      series (and their NaN counts) and all CUSUM close indices are stored.
-    from finmlkit.feature.core import utils as FU
-    from finmlkit.feature.core import volatility as FV
-    t0 = time.time()
-    ts, px, am, sd = orc.synth(42, 0, N_FLOW)
-    r = FU.comp_lagged_returns(ts, px, 5.0, True)
-    sg = FV.ewmst(ts, r, 60.0)
-    ci = np.array(LG._cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), dtype=np.int64)
-    d["tl_returns_97"], d["tl_sigma_97"] = r[::97].copy(), sg[::97].copy()
-    d["tl_returns_nan"], d["tl_sigma_nan"] = np.int64(np.isnan(r).sum()), np.int64(np.isnan(sg).sum())
-    d["tl_cusum_close_indices"] = ci
-    print(f"lagged returns -> ewmst -> CUSUM on {N_FLOW} ticks: {len(ci) - 1} bars, in {time.time() - t0:.0f} s")
 
     path = os.path.join(ROOT, "tests", "golden", "cfg1_reference_timebars.npz")
     np.savez_compressed(path, **d)

@@ -146,20 +146,22 @@ def test_ewmst_one_pass_kernel_matches_two_pass(monkeypatch):
 
 
 def test_tick_level_chain_reference_vectors(orc):
-    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer at 10^6 ticks against vectors made by the reference's own loops
-    (oracle/gen_cfg1.py): returns and sigma at every 97th tick within the north-star tolerance, NaN counts equal, and the
-    CUSUM closes -- an integer result fed by the device's own sigma -- identical."""
+    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer against vectors made by the reference's own loops
+    (oracle/gen_ticklevel_chain.py): returns and sigma at every sampled tick within the north-star tolerance, NaN counts equal,
+    and the CUSUM closes -- an integer result fed by the device's own sigma -- identical."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
     from finmlkit_amd.feature.core.utils import comp_lagged_returns
     from finmlkit_amd.feature.core.volatility import ewmst
-    d = G.load("cfg1_reference_timebars")
-    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n_flow"]))
-    r = comp_lagged_returns(ts, px, 5.0, True)
-    sg = ewmst(ts, r, 60.0)
-    assert int(np.isnan(r).sum()) == int(d["tl_returns_nan"]) and int(np.isnan(sg).sum()) == int(d["tl_sigma_nan"])
-    G.assert_f64_close(r[::97], d["tl_returns_97"], rtol=1e-12, what="returns")
-    G.assert_f64_close(sg[::97], d["tl_sigma_97"], rtol=RTOL, what="sigma")
-    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), d["tl_cusum_close_indices"])
+    d = G.load("ticklevel_chain_reference")
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n"]))
+    k = int(d["step"])
+    r = comp_lagged_returns(ts, px, float(d["return_window_sec"]), True)
+    sg = ewmst(ts, r, float(d["half_life_sec"]))
+    assert int(np.isnan(r).sum()) == int(d["returns_nan"]) and int(np.isnan(sg).sum()) == int(d["sigma_nan"])
+    G.assert_f64_close(r[::k], d["returns_sampled"], rtol=1e-12, what="returns")
+    G.assert_f64_close(sg[::k], d["sigma_sampled"], rtol=RTOL, what="sigma")
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, sg.copy(), float(d["sigma_floor"]), float(d["lambda_mult"])),
+                                  d["cusum_close_indices"])
 
 
 @pytest.mark.parametrize("hl", [0.05, 5.0, 600.0])

@@ -81,3 +81,17 @@ def test_volumepro_on_kit_output_and_errors(orc):
         volume_profile_rolling_csr(fp.bar_timestamps, bars.high.values, bars.low.values, fp.level_offsets,
                                    fp.flat["price_levels"], fp.flat["buy_volumes"], fp.flat["sell_volumes"], 1200.0, 0,
                                    0.01)
+
+
+def test_pct_above_poc_nan_total_propagates(orc):
+    """volume.py:378 guards with `total_volume <= 0`, which a NaN total does not trip: NaN comes out (not 0.0); an all-zero
+    profile and a profile with nothing above the POC give 0.0."""
+    from finmlkit_amd.feature.core import volume
+    pl = np.array([1, 2, 3, 4], np.int32)
+    v = np.array([1.0, np.nan, 2.0, 1.0], np.float32)
+    assert np.isnan(orc.calc_volume_percentage_above_poc(pl, v, 2))
+    assert np.isnan(volume.calc_volume_percentage_above_poc(pl, v, 2))
+    z = np.zeros(4, np.float32)
+    assert volume.calc_volume_percentage_above_poc(pl, z, 2) == 0.0 == orc.calc_volume_percentage_above_poc(pl, z, 2)
+    w = np.array([1.0, 2.0, 0.0, 0.0], np.float32)
+    assert volume.calc_volume_percentage_above_poc(pl, w, 2) == 0.0 == orc.calc_volume_percentage_above_poc(pl, w, 2)

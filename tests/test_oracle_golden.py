@@ -243,17 +243,19 @@ def test_cfg3_reference_threshold_indexers(orc):
 
 
 def test_tick_level_chain_reference_vectors(orc):
-    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer at 10^6 ticks, made by the reference's own loops (oracle/gen_cfg1.py):
+    """comp_lagged_returns -> ewmst -> _cusum_bar_indexer made by the reference's own loops (oracle/gen_ticklevel_chain.py):
     returns bit-exact (one IEEE division / log), sigma to 1e-12 (libm exp), the CUSUM closes computed from the ORACLE's sigma
     identical."""
-    d = G.load("cfg1_reference_timebars")
-    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n_flow"]))
-    r = orc.comp_lagged_returns(ts, px, 5.0, True)
-    sg = orc.ewmst(ts, r, 60.0)
-    assert int(np.isnan(r).sum()) == int(d["tl_returns_nan"]) and int(np.isnan(sg).sum()) == int(d["tl_sigma_nan"])
-    np.testing.assert_allclose(r[::97], d["tl_returns_97"], rtol=1e-15, atol=0, equal_nan=True)
-    np.testing.assert_allclose(sg[::97], d["tl_sigma_97"], rtol=1e-12, atol=0, equal_nan=True)
-    np.testing.assert_array_equal(orc._cusum_bar_indexer(ts, px, sg.copy(), 1e-5, 2.0), d["tl_cusum_close_indices"])
+    d = G.load("ticklevel_chain_reference")
+    ts, px, am, sd = orc.synth(int(d["seed"]), 0, int(d["n"]))
+    k = int(d["step"])
+    r = orc.comp_lagged_returns(ts, px, float(d["return_window_sec"]), True)
+    sg = orc.ewmst(ts, r, float(d["half_life_sec"]))
+    assert int(np.isnan(r).sum()) == int(d["returns_nan"]) and int(np.isnan(sg).sum()) == int(d["sigma_nan"])
+    np.testing.assert_allclose(r[::k], d["returns_sampled"], rtol=1e-15, atol=0, equal_nan=True)
+    np.testing.assert_allclose(sg[::k], d["sigma_sampled"], rtol=1e-12, atol=0, equal_nan=True)
+    np.testing.assert_array_equal(orc._cusum_bar_indexer(ts, px, sg.copy(), float(d["sigma_floor"]), float(d["lambda_mult"])),
+                                  d["cusum_close_indices"])
 
 
 def test_oracle_bar_loops_do_not_depend_on_the_thread_count(orc, monkeypatch):
@@ -306,3 +308,10 @@ def test_oracle_on_float32_non_dyadic_amounts_against_reference_vectors(orc, pre
         t64 = orc.comp_bar_trade_size_features(am.astype(np.float64), theta, ci, 5.0)
         for key, got in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], t64):
             np.testing.assert_array_equal(got, d["ts64_col_" + key], err_msg=key)
+
+
+def test_pct_above_poc_nan_total(orc):
+    """volume.py:378 `total_volume <= 0` does not catch a NaN total: the quotient (NaN) is returned."""
+    pl = np.array([1, 2, 3, 4], np.int32)
+    assert np.isnan(orc.calc_volume_percentage_above_poc(pl, np.array([1.0, np.nan, 2.0, 1.0], np.float32), 2))
+    assert orc.calc_volume_percentage_above_poc(pl, np.zeros(4, np.float32), 2) == 0.0

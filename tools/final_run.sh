@@ -22,3 +22,9 @@ except Exception as e:
 PY
 done
 head -8 gpurun_out/final/bench_kernel_stats.csv | cut -c1-140
+# the two counter passes of the dominant kernel at THIS code (roofline.traffic): gpurun_out/final/traffic_constants.json is what
+# goes to profiles/ afterwards
+bash tools/pmc_calibrate.sh > gpurun_out/final/pmc_calibrate.log 2>&1
+python tools/pmc_summarize.py > gpurun_out/final/pmc_summarize.log 2>&1 || tail -5 gpurun_out/final/pmc_summarize.log
+rm -rf gpurun_out/pmc_r02_FETCH_SIZE gpurun_out/pmc_r02_WRITE_SIZE
+python -c "import json; d = json.load(open('gpurun_out/final/traffic_constants.json')); print('traffic: read B/tick', d['read_bytes_per_tick'], 'write B/bar', d['write_bytes_per_bar'], d['kernel_source_sha256'][:12])"
