@@ -78,13 +78,14 @@ __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t st
 // (below -1 or beyond the array: Python slice semantics) stay with the old path.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_ts_p95_long(const float *__restrict__ amount, const int64_t *__restrict__ ci,
-                                                         const int64_t *__restrict__ list, int64_t n, float *__restrict__ o_p95)
+                                                         const int64_t *__restrict__ list, int64_t n, float *__restrict__ o_p95,
+                                                         int64_t skip_lo = INT64_MAX, int64_t skip_hi = 0 /* bars of skip_lo < ticks <= skip_hi: k_bar_trade_size_wide selects itself */)
 {
     typedef MedKey<false> MK;
     const int64_t n_list = list[0];
     for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
         const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
-        if (!(s >= -1 && e <= n - 1)) continue;
+        if (!(s >= -1 && e <= n - 1) || (e - s > skip_lo && e - s <= skip_hi)) continue;
         const int64_t cnt = e - s, start = s + 1;
         const float q32 = 95.0f / 100.0f;
         const float vi = (float)(cnt - 1) * q32;             // the virtual index in the array's dtype (ts_percentile95)
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                         double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
                                                         float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done,
-                                                        const unsigned long long *__restrict__ only = nullptr)
+                                                        const unsigned long long *__restrict__ only = nullptr,
+                                                        int64_t skip_above = INT64_MAX /* longer regular bars: k_bar_trade_size_wide */)
 {
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
         // a zero total -> the same all-NaN row.
         // Python slice bounds: a negative start / stop wraps by n once and is then clamped to [0, n] -- a close index below -1
         // must not become a read in front of the column (it selects the reference's wrapped, usually empty, slice)
+        if (!AF64 && e_raw - s > skip_above && e_raw - s <= FMK_PW_BIG_MAX_N && s >= -1 && e_raw <= n - 1) continue;
         int64_t start = s + 1, stop = e_raw + 1;
         start = start < 0 ? (start + n > 0 ? start + n : 0) : (start < n ? start : n);
         stop = stop < 0 ? (stop + n > 0 ? stop + n : 0) : (stop < n ? stop : n);
@@ -237,6 +240,220 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bars of more than TSW_MIN = 32 768 ticks (hourly, daily bars), float32 amounts, regular close indices: a WORKGROUP per bar (round 3).
+// One wave per bar walks a daily bar's NumPy trees alone -- 33.6 ms per 1e9 ticks of daily bars, 10 ms of hourly ones.  The tree
+// of np.sum is a function of n only (halves of n / 2 rounded down to a multiple of 8), so its TOP is cut level by level into 33 ..
+// 128 sub-trees of at most G elements (a ballot per level gives every node its place, as in fmk_pairwise_par), the sixteen waves
+// evaluate the sub-trees in parallel with the wave-level routine (fmk_pairwise_big: the recursion does not know where it started)
+// and the levels are undone in reverse: a node that had split becomes left + right.  Twice: the float32 total and sum((a / total)^2); the block
+// volume is a float64 sum of float32 values, exact in any order: a plain sweep.  Same bits as the wave kernel: every addition has
+// the recursion's operands and order.
+// np.percentile(., 95) of bars beyond 65 536 ticks rides on that sweep (k_ts_p95_long's radix select is three more passes over
+// the bar: 3.4 / 6.0 ms per 1e9 ticks at hourly / daily bars): like the long-bar median of fmk_ohlcv.hip, a systematic sample of the
+// bar (every 64th / 256th size) gives a bracket of keys around the sample's 95 % rank (-+ 3.8 standard deviations of that rank), the sweep counts
+// the keys below the bracket and appends the sizes inside it to the bar's candidate slots, and the two ranks are selected among
+// the candidates exactly; a bracket that misses (or overflows: heavy ties) falls back to the radix select of the whole bar.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TSW_MIN 32768                  // (10-minute bars, 12 000 ticks: a workgroup's fixed cost per bar outweighs its sixteen waves)
+#define TSW_WAVES 16
+#define TSW_MAXSUB 128
+#define TSW_ROUNDS 10
+#define TSW_SAMPLE_MIN 65536           // shorter bars: the radix select on the (L2-resident) bar itself -- its fixed cost decides
+__global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const float *__restrict__ amount, const double *__restrict__ theta,
+                                                                      const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                                      int64_t n, double theta_mult, float *__restrict__ o_mean,
+                                                                      float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                      float *__restrict__ o_gini, float *__restrict__ samp,
+                                                                      uint32_t *__restrict__ cand)
+{
+    typedef MedKey<false> MK;
+    // the cut of the tree's top, level by level (entry = a node (off, len) of the current level, in order): round d keeps for
+    // every entry where its first child stands in round d + 1 and whether it split
+    __shared__ int e_off[2][TSW_MAXSUB], e_len[2][TSW_MAXSUB];
+    __shared__ unsigned short e_pos[TSW_ROUNDS][TSW_MAXSUB];
+    __shared__ int e_n[TSW_ROUNDS + 1];
+    __shared__ float s_val[2][TSW_MAXSUB];
+    __shared__ int s_wcnt[TSW_MAXSUB / 64];
+    __shared__ __attribute__((aligned(8))) int s_stk[TSW_WAVES][FMK_PW_PAR_STK];
+    __shared__ double s_blk[TSW_WAVES];
+    __shared__ float s_p95;
+    __shared__ int s_ncand, s_nan;
+    __shared__ int64_t s_below[TSW_WAVES];
+    const int tid = (int)threadIdx.x;
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
+        const int64_t cnt64 = e - s;
+        if (!(s >= -1 && e <= n - 1) || cnt64 <= TSW_MIN || cnt64 > FMK_PW_BIG_MAX_N) continue;     // the wave kernel's (same test there)
+        const int cnt = (int)cnt64;
+        const float *af = amount + (s + 1);
+        const double th = theta[b];
+        if (th == 0.0) {                                                  // base.py:586-587
+            if (tid == 0) { o_mean[b] = NAN; o_p95[b] = NAN; o_pct[b] = NAN; o_gini[b] = NAN; }
+            continue;
+        }
+        const double thr = th * theta_mult;
+        // ---- the cut: nodes longer than G split into (off, n2) and (off + n2, len - n2), n2 = len / 2 rounded down to a multiple of
+        //      8 (NumPy's rule), until none is: 33 .. 128 sub-trees, two to eight per wave
+        int G = 256;
+        while (cnt / G > 64) G *= 2;
+        __syncthreads();
+        if (tid == 0) { e_off[0][0] = 0; e_len[0][0] = cnt; e_n[0] = 1; s_ncand = 0; s_nan = 0; }
+        __syncthreads();
+        int depth = 0;
+        for (;; ++depth) {
+            const int cur = depth & 1, ne = e_n[depth];
+            const bool mine = tid < ne;
+            const int off = mine ? e_off[cur][tid] : 0, len = mine ? e_len[cur][tid] : 0;
+            const bool split = mine && len > G;
+            const uint64_t m = __ballot(split);
+            if (tid < TSW_MAXSUB && lane == 0) s_wcnt[w] = (int)__popcll(m);
+            __syncthreads();
+            int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)), total = 0;
+            for (int k = 0; k < TSW_MAXSUB / 64; ++k) { if (k < w) before += s_wcnt[k]; total += s_wcnt[k]; }
+            if (total == 0 || depth == TSW_ROUNDS) break;                  // (block-uniform; the cap cannot be met: <= 8 rounds)
+            if (mine) {
+                const int at = tid + before;
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                e_pos[depth][tid] = (unsigned short)(at | (split ? 0x8000 : 0));
+                if (split) { e_off[cur ^ 1][at] = off; e_len[cur ^ 1][at] = n2; e_off[cur ^ 1][at + 1] = off + n2; e_len[cur ^ 1][at + 1] = len - n2; }
+                else { e_off[cur ^ 1][at] = off; e_len[cur ^ 1][at] = len; }
+            }
+            if (tid == 0) e_n[depth + 1] = ne + total;
+            __syncthreads();
+        }
+        const int fin = depth & 1, nsub = e_n[depth];
+        // the sub-trees' sums (s_val[depth & 1]) -> the root's, undoing the rounds: left + right as the recursion returns it
+        auto combine = [&]() -> float {
+            for (int d = depth - 1; d >= 0; --d) {
+                __syncthreads();
+                if (tid < e_n[d]) {
+                    const unsigned p = e_pos[d][tid];
+                    const float *nx = s_val[(d + 1) & 1];
+                    s_val[d & 1][tid] = (p & 0x8000) ? nx[p & 0x7FFF] + nx[(p & 0x7FFF) + 1] : nx[p & 0x7FFF];
+                }
+            }
+            __syncthreads();
+            return s_val[0][0];
+        };
+        // ---- np.percentile(., 95)
+        const float q32 = 95.0f / 100.0f;
+        const float vi = (float)(cnt - 1) * q32;                          // the virtual index in the array's dtype (ts_percentile95)
+        const double vfl = floor((double)vi);
+        const int64_t k1 = (int64_t)vfl < cnt - 1 ? (int64_t)vfl : cnt - 1;
+        const int64_t k2 = k1 + 1 < cnt ? k1 + 1 : cnt - 1;
+        const bool sampled = cnt > TSW_SAMPLE_MIN;
+        uint32_t *mycand = cand + ((s + 1) >> 2);
+        const int cap = cnt >> 2;
+        MK::K klo = 0, khi = 0;
+        if (sampled) {
+            // the bracket from a systematic sample
+            const int stride = cnt <= (1 << 21) ? 64 : 256;
+            const int64_t nsamp = cnt / stride;                           // >= 1024
+            float *mine = samp + ((s + 1) >> 4);
+            for (int64_t j = tid; j < nsamp; j += 64 * TSW_WAVES) mine[j] = af[j * stride];
+            __syncthreads();
+            // the rank of a sample quantile scatters with sqrt(ns p (1 - p)) = 0.218 sqrt(ns) at p = 0.95
+            const int g = (int)(0.83f * sqrtf((float)nsamp)) + 4;
+            const int64_t c = (int64_t)((double)k1 / (double)(cnt - 1) * (double)(nsamp - 1));
+            const int64_t r_lo = c - g > 0 ? c - g : 0, r_hi = c + g + 1 < nsamp - 1 ? c + g + 1 : nsamp - 1;
+            bool sn;
+            med_block_select<false, 64 * TSW_WAVES>(mine, 0, nsamp, r_lo, r_hi, klo, khi, sn);
+            __syncthreads();
+        }
+        // ---- np.sum of the float32 slice (pairwise)
+        for (int k = w; k < nsub; k += TSW_WAVES) {
+            const float *a0 = af + e_off[fin][k];
+            const float r = fmk_pairwise_big([a0](int i) { return a0[i]; }, e_len[fin][k], lane, s_stk[w]);
+            if (lane == 0) s_val[fin][k] = r;
+        }
+        // ---- the block volume (base.py:599-603: a float64 sum of float32 values) by a plain sweep; with it the percentile's counts
+        double blk = 0.0;
+        int64_t below = 0;
+        bool nan = false;
+        for (int j0 = 0; j0 < cnt; j0 += 64 * TSW_WAVES) {                // (whole waves: the ballots)
+            const int j = j0 + tid;
+            const bool in_bar = j < cnt;
+            const float af_j = in_bar ? af[j] : 0.f;
+            const double a = (double)af_j;
+            blk += a > thr ? a : 0.0;
+            if (sampled) {
+                const uint32_t raw = __float_as_uint(af_j);
+                const uint32_t k = MK::tokey(raw);
+                nan |= in_bar && (k < MK::KEY_NEG_INF || k > MK::KEY_POS_INF);
+                below += (in_bar && k < klo) ? 1 : 0;
+                const bool inb = in_bar && k >= klo && k <= khi;
+                const uint64_t m = __ballot(inb);
+                if (m) {
+                    int base = 0;
+                    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&s_ncand, (int)__popcll(m));
+                    base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(m));
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (inb && pos < cap) mycand[pos] = raw;
+                }
+            }
+        }
+        blk = fmk_wave_sum(blk);
+        below = fmk_dpp_reduce(below, (int64_t)0, FmkOpAdd());
+        if (lane == 0) { s_blk[w] = blk; s_below[w] = below; }
+        if (__ballot(nan) != 0 && lane == 0) s_nan = 1;
+        const float tf = combine();                                        // (its barriers also publish s_blk / s_below / the candidates)
+        {
+            int64_t bl = 0;
+            for (int k = 0; k < TSW_WAVES; ++k) bl += s_below[k];
+            const int64_t nc = s_ncand;
+            MK::K v1 = 0, v2 = 0;
+            bool any_nan = s_nan != 0;
+            if (!any_nan) {                                                // (block-uniform)
+                if (sampled && bl <= k1 && k2 < bl + nc && nc <= cap)
+                    med_block_select<false, 64 * TSW_WAVES>(mycand, 0, nc, k1 - bl, k2 - bl, v1, v2, any_nan);
+                else
+                    med_block_select<false, 64 * TSW_WAVES>(af, 0, cnt, k1, k2, v1, v2, any_nan);     // short bar / bracket missed or overflowed
+            }
+            if (tid == 0) {
+                const float a32 = (float)MK::value(v1), b32 = (float)MK::value(v2);
+                float r32;
+                if (any_nan) r32 = NAN;
+                else if (vi >= (float)(cnt - 1)) r32 = b32;
+                else {
+                    const float t32 = vi - floorf(vi), d32 = b32 - a32;
+                    r32 = a32 + d32 * t32;
+                    if (t32 >= 0.5f) r32 = b32 - d32 * (1.0f - t32);
+                }
+                s_p95 = r32;
+            }
+        }
+        // ---- sum((a / total)^2): float32 quotients, squares and pairwise sum (base.py:609)
+        __syncthreads();
+        if (tf != 0.f) {
+            for (int k = w; k < nsub; k += TSW_WAVES) {
+                const float *a0 = af + e_off[fin][k];
+                const float r = fmk_pairwise_big([a0, tf](int i) { const float x = a0[i] / tf; return x * x; }, e_len[fin][k], lane, s_stk[w]);
+                if (lane == 0) s_val[fin][k] = r;
+            }
+        }
+        const float sq = tf != 0.f ? combine() : 0.f;                      // (block-uniform)
+        if (tid == 0) {
+            double block = 0.0;
+            for (int k = 0; k < TSW_WAVES; ++k) block += s_blk[k];
+            const double sum = (double)tf, mean = (double)(tf / (float)cnt);       // np.mean divides in float32
+            float pct = NAN, gini = NAN;
+            if (sum != 0.0) {                                             // base.py:597-598
+                pct = (float)(block / sum);
+                gini = 1.0f - sq;
+            }
+            o_mean[b] = (float)log1p(mean / thr);
+            o_p95[b] = (float)log1p((double)s_p95 / thr);
+            o_pct[b] = pct;
+            o_gini[b] = gini;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ONE LANE PER BAR (round 3, float32 amounts): streams of very short bars -- the reference's other caller builds 1-second bars
@@ -767,11 +984,30 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     if (rc == FMK_OK) {
         k_ts_p95_long<256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_mid, n,
                                                                             d_size_95_rel);
+        // bars beyond TSW_MIN ticks: a workgroup per bar, percentile included (developer knob FMK_TS_WIDE=0: one wave per bar and the
+        // radix-select percentile as before); scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
+        const char *wv = getenv("FMK_TS_WIDE");
+        bool wide_on = (!wv || atoi(wv)) && n > TSW_MIN;
+        float *samp = nullptr;
+        uint32_t *cand = nullptr;
+        if (wide_on) {
+            rc = fmk_alloc(ctx, (size_t)((n >> 4) + 64) * 4, (void **)&samp);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)((n >> 2) + 64) * 4, (void **)&cand);
+        }
+        if (rc == FMK_OK) {
         k_ts_p95_long<1024><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_long, n,
-                                                                             d_size_95_rel);
+                                                                             d_size_95_rel, wide_on ? (int64_t)TSW_MIN : INT64_MAX, (int64_t)FMK_PW_BIG_MAX_N);
+        if (wide_on)
+            k_bar_trade_size_wide<<<(unsigned)(ctx->n_cu * 2), 64 * TSW_WAVES, 0, ctx->stream>>>(
+                (const float *)d_amount, d_theta, d_close_idx, list_long, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
+                d_size_gini, samp, cand);
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                           d_pct_block, d_size_gini, 1);
+                                                                           d_pct_block, d_size_gini, 1, nullptr,
+                                                                           wide_on ? (int64_t)TSW_MIN : INT64_MAX);
+        }
+        if (samp) (void)fmk_free(ctx, samp);
+        if (cand) (void)fmk_free(ctx, cand);
     }
     const hipError_t le = hipGetLastError();
     (void)fmk_free(ctx, list_mid);

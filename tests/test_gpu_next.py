@@ -126,3 +126,35 @@ def test_trade_size_one_lane_per_bar(orc, monkeypatch, interval, amounts, mode):
         np.testing.assert_array_equal(got[k], w, err_msg=f"{k} iv={interval} {amounts} mode={mode}")
     assert np.diff(ci).max() > 64 and np.median(np.diff(ci)) < 256
     assert interval != 400.0 or (np.diff(ci) == 0).any()
+
+
+@pytest.mark.parametrize("case", ["edges", "huge", "zeros", "theta0", "dyadic"])
+def test_trade_size_workgroup_per_bar(orc, case):
+    """Bars of more than 32 768 ticks, float32 amounts (k_bar_trade_size_wide: the top of NumPy's pairwise tree cut into sub-trees
+    that sixteen waves evaluate, added in the recursion's order; the percentile by radix select up to 65 536 ticks, from a sample
+    bracket beyond): bars of 32 768 (still the wave kernel) / 32 769 / 40 000 / 65 536 / 65 537 / 100 003 ticks next to short
+    ones; a bar of 2.3e6 ticks (sub-trees of 65 536 elements); all-zero amounts (total 0: pct and gini stay NaN); a zero theta;
+    dyadic amounts (4 096 distinct sizes: heavy ties around the bracket).  Against the oracle bit for bit."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    rng = np.random.default_rng(41)
+    if case == "huge":
+        n = 2_600_000
+        cuts = [-1, 2_300_000, 2_300_100, n - 1]
+    else:
+        lens = [100, 8192, 8193, 32_768, 3, 32_769, 65_537, 0, 100_003, 40_000, 65_536]
+        cuts = [int(c) for c in np.cumsum([-1] + lens)]
+        n = cuts[-1] + 50
+    am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    if case == "zeros":
+        am[cuts[5] + 1:cuts[6] + 1] = 0.0
+    if case == "dyadic":
+        am = (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32)
+    ci = np.array(cuts, dtype=np.int64)
+    theta = np.full(len(ci) - 1, float(np.median(am)))
+    if case == "theta0":
+        theta[2] = 0.0
+        theta[6] = 0.0
+    want = orc.comp_bar_trade_size_features(am, theta, ci, 5.0)
+    got = comp_bar_trade_size_features(am, theta, ci, 5.0)
+    for k, g, w in zip(KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=f"{k} ({case})")

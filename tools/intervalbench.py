@@ -36,6 +36,7 @@ for iv in ivs:
                                  ci.p, c_i64(ci.n), c_f64(5.0), *[k.p for k in keys]))
     ms_f = best(lambda: t.bar_footprints(ci, o["low"], o["high"], 0.01), reps=2)
     ms_c = best(lambda: t.bars_fused(ci, 0.01, 3.0), reps=2)
-    print(f"interval {iv:8.0f} s: {nb:9d} bars of {n // max(nb, 1):8d} ticks | ohlcv+median {ms_o:7.2f} ms | order flow {ms_d:7.2f} ms (redo: {st[0]} bars, {st[2]} of {st[1]} tiles term by term; per column {list(st[3:10])}) | "
-          f"trade size {ms_t:7.2f} ms | footprints (size + fill + allocation) {ms_f:7.2f} ms | cfg 4 (bars_fused) {ms_c:7.2f} ms", flush=True)
+    print(f"interval {iv:8.0f} s: {nb:9d} bars of {n // max(nb, 1):8d} ticks | ohlcv+median {ms_o:6.2f} | order flow {ms_d:6.2f} | "
+          f"trade size {ms_t:6.2f} | footprints (size + fill + allocation) {ms_f:6.2f} | cfg 4 (bars_fused) {ms_c:6.2f} ms", flush=True)
+    print(f"      order-flow redo: {st[0]} (bar, column) pairs, {st[2]} of {st[1]} chunks term by term; per column {list(st[3:10])}", flush=True)
     del o, keys, clock, ci
