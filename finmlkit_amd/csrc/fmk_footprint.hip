@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
 // negative or non-finite amounts -- is swept in tick order by wave 0 alone, as before.  Level rows and features: wave 0
 // (fp_emit_bar), while the second workgroup of the CU sweeps.
 // ---------------------------------------------------------------------------------------
-#define FPW_MIN 8192
+#define FPW_MIN 16384
 #define FPW_WAVES 16
 #define FPW_MAX_LEVELS 6144
 
@@ -634,6 +634,102 @@ __device__ __forceinline__ FpStats fp_stats_lean(const double *__restrict__ pric
     return st;
 }
 
+// (level, side) key of one tick as the sweeps compute it (base.py:700-707: level = int(round(price / tick)) - low, one multiply, the
+// exact division deciding the products within 1e-15 of a half-integer as a wave-uniform branch); -1: not pending (outside the bar,
+// unsigned tick, outside the level range -- the latter sets `bad`, base.py:719).  All lanes of the wave call.
+__device__ __forceinline__ int fp_key_lean(double p, int sd, bool in_bar, double tick, double inv_tick, int ilow, int L, bool &bad)
+{
+    const double qq = p * inv_tick;
+    double r = rint(qq);
+    if (__ballot(in_bar && 0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) != 0) {
+        if (0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) r = rint(p / tick);
+    }
+    const int lvl = (int)r - ilow;
+    const bool inside = (unsigned)lvl < (unsigned)L;
+    bad |= in_bar && !inside;
+    return (in_bar && inside && (sd == 1 || sd == -1)) ? lvl * 2 + (sd < 0 ? 1 : 0) : -1;
+}
+
+// ticks per (level, side) key of (s, e] into cnt[] (LDS atomics: any order), and the statistics of the pending float32 amounts that
+// pick the quantum (what fp_stats_lean reports); st.bad: a tick fell outside the level range.  Per-lane partial statistics are
+// ACCUMULATED into lb / at (the caller reduces them once).
+__device__ __forceinline__ bool fp_count_lean(const double *__restrict__ price, const float *__restrict__ amount,
+                                              const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low, int L, double tick,
+                                              double inv_tick, int lane, int *cnt, int &lb, double &at)
+{
+    bool bad = false;
+    const int ilow = (int)low;
+    const double *pp = price + (s + 1);
+    const float *ap = amount + (s + 1);
+    const int8_t *sp = side + (s + 1);
+    const int total = (int)(e - s);
+    for (int j0 = 0; j0 < total; j0 += 256) {
+        double p[4];
+        float a[4];
+        int sd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const int jc = j < total ? j : total - 1;
+            p[u] = pp[jc]; a[u] = ap[jc]; sd[u] = sp[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = fp_key_lean(p[u], sd[u], j0 + u * 64 + lane < total, tick, inv_tick, ilow, L, bad);
+            if (key >= 0) {
+                atomicAdd(&cnt[key], 1);
+                const int l2 = fp_lowbit_exp(a[u]);
+                lb = l2 < lb ? l2 : lb;
+                at += fabs((double)a[u]);
+            }
+        }
+    }
+    return __ballot(bad) != 0;
+}
+
+// The float32 amounts of (s, e] moved to sorted[] in (key, tick) order: cursor[key] starts at the key's first slot (exclusive scan
+// of the counts).  ONE wave, chunk after chunk: an LDS atomic with return hands out its old values in ascending lane order
+// (fp_lds_atomics_in_lane_order) and a wave's LDS instructions complete in the order they were issued, so a key's slots are filled
+// in tick order.  Four chunks are in flight: their atomics are issued back to back.
+__device__ __forceinline__ void fp_scatter_lean(const double *__restrict__ price, const float *__restrict__ amount,
+                                                const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low, int L, double tick,
+                                                double inv_tick, int lane, int *cursor, float *__restrict__ sorted)
+{
+    bool bad = false;
+    const int ilow = (int)low;
+    const double *pp = price + (s + 1);
+    const float *ap = amount + (s + 1);
+    const int8_t *sp = side + (s + 1);
+    const int total = (int)(e - s);
+    double pn[4];
+    float an[4];
+    int sn[4];
+    auto load = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const int jc = j < total ? j : total - 1;
+            pn[u] = pp[jc]; an[u] = ap[jc]; sn[u] = sp[jc];
+        }
+    };
+    if (total > 0) load(0);
+    for (int j0 = 0; j0 < total; j0 += 256) {
+        double p[4];
+        float a[4];
+        int sd[4], key[4], pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p[u] = pn[u]; a[u] = an[u]; sd[u] = sn[u]; }
+        if (j0 + 256 < total) load(j0 + 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = fp_key_lean(p[u], sd[u], j0 + u * 64 + lane < total, tick, inv_tick, ilow, L, bad);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pos[u] = key[u] >= 0 ? atomicAdd(&cursor[key[u]], 1) : 0;     // chunk u before chunk u + 1
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (key[u] >= 0) sorted[pos[u]] = a[u];
+    }
+}
+
 template <bool AF64>
 __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const double *__restrict__ price, const void *__restrict__ amount,
                                                                       const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
@@ -641,7 +737,8 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
                                                                       const double *__restrict__ lows, double imb_mult,
                                                                       const int64_t *__restrict__ off, FpOut o,
                                                                       unsigned long long *n_bad, int force_ordered, int lean,
-                                                                      int lmax)
+                                                                      int lmax, float *__restrict__ sorted_all,
+                                                                      unsigned long long *__restrict__ defer, int nseg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *vol = (float *)smem;                                        // [2 * lmax]  buy = 2l, sell = 2l + 1
@@ -709,29 +806,112 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
         };
         bool done = false;
         int q_used = wq;
-        if (!force_ordered) {
-            if (wq != FP_Q_UNKNOWN) done = attempt(wq);
-            if (!done) {
-                const FpStats t = combine(fp_stats_lean<AF64>(price, amount, side, s_w, e_w, low, L, tick, inv_tick, lane));
-                const int q2 = t.lbmin == FP_Q_UNKNOWN ? 0 : t.lbmin;      // only zeros: any quantum
-                if (t.lbmin != (int)0x80000000 && q2 >= -149 && q2 <= 100 && q2 != wq) {
-                    done = attempt(q2);
-                    q_used = q2;
+        bool parallel_ok = false;                                          // the tick-ordered path of this kernel can take the bar
+        if constexpr (!AF64) parallel_ok = lean && sorted_all != nullptr;
+        // could a sweep with quantum 2^q certify?  (whole units below 2^32 in all: otherwise not even the per-key test can pass)
+        auto hopeful = [&](const FpStats &t, int q) {
+            return t.lbmin != (int)0x80000000 && q >= -149 && q <= 100 && q != wq && t.atot < ldexp(1.0, 32 + q);
+        };
+        if (!force_ordered && wq != FP_Q_UNKNOWN) done = attempt(wq);
+        // the counts per (segment, key) of the tick-ordered path and the statistics that pick a quantum come from ONE sweep
+        const int K = 2 * L;
+        int *segc = nseg > 1 ? (int *)(smem + (size_t)lmax * 24 + 256) : (int *)aux;      // [nseg][2 * lmax]
+        const int sstride = 2 * lmax;
+        int64_t gseg = (e - s + nseg - 1) / nseg;
+        gseg = (gseg + 63) & ~(int64_t)63;
+        if (!done && parallel_ok) {
+            if constexpr (!AF64) {
+                __syncthreads();
+                for (int k = (int)threadIdx.x; k < K; k += 64 * FPW_WAVES)
+                    for (int g = 0; g < nseg; ++g) segc[g * sstride + k] = 0;
+                __syncthreads();
+                // wave w takes a sixteenth of the ticks; where its range straddles two segments it counts the parts separately
+                FpStats mine;
+                mine.lbmin = FP_Q_UNKNOWN; mine.atot = 0.0; mine.units_ok = true; mine.bad = false;
+                for (int g = 0; g < nseg; ++g) {
+                    const int64_t g_lo = s + (int64_t)g * gseg, g_hi = g_lo + gseg < e ? g_lo + gseg : e;     // (g_lo, g_hi]
+                    const int64_t lo = s_w > g_lo ? s_w : g_lo, hi = e_w < g_hi ? e_w : g_hi;
+                    if (hi > lo)
+                        mine.bad |= fp_count_lean(price, (const float *)amount, side, lo, hi, low, L, tick, inv_tick, lane,
+                                                  segc + g * sstride, mine.lbmin, mine.atot);
                 }
+                mine.lbmin = fmk_dpp_reduce(mine.lbmin, FP_Q_UNKNOWN, FmkOpMin());
+                mine.atot = fmk_dpp_reduce(mine.atot, 0.0, FmkOpAdd());
+                const FpStats t = combine(mine);
+                bad_level = t.bad;
+                const int q2 = t.lbmin == FP_Q_UNKNOWN ? 0 : t.lbmin;      // only zeros: any quantum
+                if (!force_ordered && hopeful(t, q2)) { done = attempt(q2); q_used = q2; }
             }
+        } else if (!done && !force_ordered) {
+            const FpStats t = combine(fp_stats_lean<AF64>(price, amount, side, s_w, e_w, low, L, tick, inv_tick, lane));
+            const int q2 = t.lbmin == FP_Q_UNKNOWN ? 0 : t.lbmin;
+            if (hopeful(t, q2)) { done = attempt(q2); q_used = q2; }
         }
         if (done) {
             wq = q_used;
             for (int k = (int)threadIdx.x; k < 2 * L; k += 64 * FPW_WAVES) vol[k] = ldexpf((float)units[k], q_used);
         } else {
-            // tick order: one wave (the float32 level sums round on every add, base.py:713-717)
-            zero();
+            // Tick order: the float32 level sums round on every add (base.py:713-717) -- what real sizes (full float32 mantissas) always
+            // take.  One wave walking the bar chunk by chunk (fp_accumulate_lean) needs ~2.7 us per 64 ticks: 73 ms per 1e9 ticks of
+            // daily bars, and inside this kernel it left fifteen waves idle.  Instead the bar's amounts are SORTED by (key, tick) --
+            // counts per key by all waves, an exclusive scan, a stable scatter by one wave whose per-chunk cost is one LDS atomic and
+            // one store (fp_scatter_lean) -- and every key's float32 sum is then a plain sequential loop of ONE lane over its own
+            // contiguous slice: all keys in parallel, each in the reference's order.
             wq = FP_Q_UNKNOWN;
-            if (w == 0) {
-                FpStats st;
-                if (lean) st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
-                else st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
-                bad_level = st.bad;
+            if (!parallel_ok) {
+                // float64 amounts (f32 element += f64 value) / no lane-ordered LDS atomics: the wave-per-bar kernel takes the bar
+                if (threadIdx.x == 0) defer[32 + atomicAdd(defer, 1ULL)] = (unsigned long long)b;
+                continue;
+            }
+            if constexpr (!AF64) {
+                // The scatter is the serial part, so the bar is cut into `nseg` SEGMENTS of ticks (as many as the LDS left by the
+                // histogram holds counter arrays for: 16 up to ~600 levels, 1 beyond ~5 000) that scatter concurrently, one wave each:
+                // segment g's slots of a key start where the segments before it end -- counts per (segment, key) first.
+                __syncthreads();
+                // totals per key -> cnt[]; their exclusive scan; cursors per (segment, key).  Thread t owns the keys t * per .. + per - 1
+                const int per = (K + 64 * FPW_WAVES - 1) / (64 * FPW_WAVES);
+                const int k0 = (int)threadIdx.x * per;
+                int tot = 0;
+                for (int k = k0; k < k0 + per && k < K; ++k) {
+                    int c = 0;
+                    for (int g = 0; g < nseg; ++g) c += segc[g * sstride + k];
+                    cnt[k] = c;
+                    tot += c;
+                }
+                int inc = tot;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+                if (lane == 63) s_umax[w] = (unsigned)inc;
+                __syncthreads();
+                int base0 = inc - tot;
+                for (int k = 0; k < w; ++k) base0 += (int)s_umax[k];
+                for (int k = k0; k < k0 + per && k < K; ++k) {
+                    for (int g = 0; g < nseg; ++g) { const int c = segc[g * sstride + k]; segc[g * sstride + k] = base0; base0 += c; }
+                }
+                __syncthreads();
+                float *sorted = sorted_all + (s + 1);
+                if (w < nseg) {
+                    const int64_t g_lo = s + (int64_t)w * gseg, g_hi = g_lo + gseg < e ? g_lo + gseg : e;
+                    if (g_hi > g_lo)
+                        fp_scatter_lean(price, (const float *)amount, side, g_lo, g_hi, low, L, tick, inv_tick, lane, segc + w * sstride,
+                                        sorted);
+                }
+                __syncthreads();
+                // the last segment's cursor is now the END of the key's slice
+                const int *cursor = segc + (nseg - 1) * sstride;
+                for (int k = (int)threadIdx.x; k < K; k += 64 * FPW_WAVES) {
+                    const int end = cursor[k], c = cnt[k];
+                    const float *src = sorted + (end - c);
+                    float v = 0.f;
+                    int i = 0;
+                    for (; i + 8 <= c; i += 8) {
+                        const float x0 = src[i], x1 = src[i + 1], x2 = src[i + 2], x3 = src[i + 3], x4 = src[i + 4], x5 = src[i + 5],
+                                    x6 = src[i + 6], x7 = src[i + 7];
+                        v += x0; v += x1; v += x2; v += x3; v += x4; v += x5; v += x6; v += x7;
+                    }
+                    for (; i < c; ++i) v += src[i];
+                    vol[k] = v;
+                }
             }
         }
         __syncthreads();
@@ -1139,16 +1319,31 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     // below skip them (developer knob FMK_FP_WIDE=0: one wave per bar as before)
     int64_t skip_above = INT64_MAX;
     int skip_lmax = 0;
+    float *wide_sorted = nullptr;
+    unsigned long long *wide_defer = nullptr;
     {
         const char *wv = getenv("FMK_FP_WIDE");
         if ((!wv || atoi(wv)) && lmin_start == 0 && n_ticks > FPW_MIN) {
             const char *fo = getenv("FMK_FP_ORDERED");
             int64_t *wl = nullptr;
             rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, FPW_MIN, nullptr, &wl);
+            // scratch of the tick-ordered path: the bars' amounts sorted by (key, tick), in the slots of the bar's own tick range;
+            // the list of the bars handed back to the wave-per-bar kernel (at most n_ticks / FPW_MIN of them)
+            if (rc == FMK_OK && !amount_is_f64) (void)fmk_alloc(ctx, (size_t)(n_ticks + 64) * 4, (void **)&wide_sorted);   // (none: those bars are deferred)
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)(n_ticks / FPW_MIN + 2 + 32) * 8, (void **)&wide_defer);
+            if (rc == FMK_OK) {
+                const hipError_t me = hipMemsetAsync(wide_defer, 0, 8, ctx->stream);
+                if (me != hipSuccess) rc = fmk_set_error(ctx, FMK_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(me));
+            }
             if (rc == FMK_OK) {
                 // the widest bar of the call bounds the histogram (one workgroup per CU beyond ~3 000 levels, two below)
                 const int wl_max = (int)(max_levels < 64 ? 64 : (max_levels > FPW_MAX_LEVELS ? FPW_MAX_LEVELS : max_levels));
-                const size_t smem = (size_t)wl_max * 24 + 256;
+                // ... plus the counter arrays of the tick-ordered path's segments (8 B per level and segment) in what is left of 158 KB
+                const size_t hist = (size_t)wl_max * 24 + 256, avail = (size_t)158 * 1024;
+                int nseg = (int)((avail - hist) / ((size_t)wl_max * 8));
+                nseg = nseg > 16 ? 16 : nseg;
+                if (nseg < 2) nseg = 1;                            // one segment: its cursors live in the aux area
+                const size_t smem = hist + (nseg > 1 ? (size_t)nseg * wl_max * 8 : 0);
                 if (smem > 48 * 1024) {
                     (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
                     (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1158,11 +1353,11 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                 if (amount_is_f64)
                     k_bar_footprints_wide<true><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
                         d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
-                        fo ? atoi(fo) : 0, lean, wl_max);
+                        fo ? atoi(fo) : 0, lean, wl_max, wide_sorted, wide_defer, nseg);
                 else
                     k_bar_footprints_wide<false><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
                         d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
-                        fo ? atoi(fo) : 0, lean, wl_max);
+                        fo ? atoi(fo) : 0, lean, wl_max, wide_sorted, wide_defer, nseg);
                 const hipError_t le = hipGetLastError();
                 (void)fmk_free(ctx, wl);
                 if (le != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, le); }
@@ -1182,6 +1377,21 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         }
         lmin = LMAX[k];
     }
+    // the long bars the workgroup kernel handed back (float64 amounts in tick order): the same classes once more, in list mode
+    if (wide_defer && rc == FMK_OK) {
+        lmin = 0;
+        for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
+            if (k > 0 && max_levels <= LMAX[k - 1]) break;
+            rc = amount_is_f64
+                     ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                       d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, wide_defer)
+                     : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                        d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, wide_defer);
+            lmin = LMAX[k];
+        }
+    }
+    if (wide_sorted) (void)fmk_free(ctx, wide_sorted);
+    if (wide_defer) (void)fmk_free(ctx, wide_defer);
     if (rest) (void)fmk_free(ctx, rest);                               // stream-ordered: the launches above are queued before it
     // bars of more than FP_MED_MAX_TICKS ticks: the long-bar median kernels, when a sweep flagged one
     if (rc == FMK_OK && d_median) rc = fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, FP_MED_MAX_TICKS, saw_long, d_median, n_ticks);
