@@ -155,6 +155,8 @@ def other_configs(trades, ctx, args):
         out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr))
         out["cfg3_volume_uncertified"] = int(trades.last_uncertified)
         out["cfg3_n_volume_bars"] = int(trades.volume_bar_index(vthr).n)
+        # SURVEY 8(d)'s unit for cfg 3 -- indexer AND reducer, 12 algorithmic B/tick: close indices, then OHLCV + median over them
+        out["cfg3_volume_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.volume_bar_index(vthr), want_median=True))
         # dollar bars, default (exact) mode as well: closed form + exact tier (csrc/fmk_dollar_exact.hip: the reference's
         # float64 running sum reconstructed at every bar start, fragile bars replayed) -- n_uncertified comes back 0.  The
         # closed form alone (fmk_ctx_set_fast_threshold(1)) is timed next to it with the count of decisions it cannot certify
@@ -163,6 +165,7 @@ def other_configs(trades, ctx, args):
         out["cfg3_dollar_exact"] = out["cfg3_dollar_uncertified"] == 0
         exact_idx = trades.dollar_bar_index(dthr)
         out["cfg3_n_dollar_bars"] = int(exact_idx.n - 1)
+        out["cfg3_dollar_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.dollar_bar_index(dthr), want_median=True))
         ctx.set_fast_threshold(True)
         try:
             out["cfg3_dollar_closed_form_only_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
@@ -183,6 +186,12 @@ def other_configs(trades, ctx, args):
         ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(args.seed), c_i64(n), am2.p)
         t2 = engine.DeviceTrades(ctx, trades.ts, trades.price, am2, trades.side)
         out["cfg4_full_mantissa_amounts_ms"] = timed(lambda: t2.bars_fused(ci, 0.01, 3.0))
+        # cfg 4 at the ends of the bar-length axis (hourly / daily bars: a workgroup per bar; tools/intervalbench.py has every length)
+        for label, iv in (("hourly", 3600.0), ("daily", 86400.0)):
+            _, ci_l = trades.time_bar_index(iv)
+            out[f"cfg4_{label}_bars_ms"] = timed(lambda: trades.bars_fused(ci_l, 0.01, 3.0), reps=2)
+            out[f"cfg4_{label}_bars_full_mantissa_ms"] = timed(lambda: t2.bars_fused(ci_l, 0.01, 3.0), reps=2)
+            del ci_l
         del t2, am2
         # TimeBarReader._resample: 1-second bars of the same stream (built here, not timed) -> 1-minute bars
         clock1, ci1 = trades.time_bar_index(1.0)

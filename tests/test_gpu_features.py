@@ -278,17 +278,21 @@ def test_footprints_long_bars_workgroup_per_bar(orc, amounts):
         am = am.copy()
         am[100_000:300_000] = (rng.integers(1, 64, 200_000) * 2.0 ** -3).astype(np.float32)
         am[300_000:420_000] = (rng.integers(1, 1 << 12, 120_000) * 2.0 ** -14).astype(np.float32)
-    # bars: 9 000 .. 150 000 ticks, a few short ones and an empty one in between
-    cuts = [-1, 50, 9_100, 9_100, 60_000, 61_000, 210_000, 225_000, 420_000, 430_000, 520_000, 690_000, n - 1]
+    # bars: 9 000 .. 160 000 ticks (16 384 and 16 385 among them: the last wave-kernel length and the first workgroup one), a few
+    # short ones and an empty one in between
+    cuts = [-1, 50, 9_100, 9_100, 25_484, 25_484 + 16_385, 61_000, 210_000, 225_000, 420_000, 430_000, 520_000, 690_000, n - 1]
     ci = np.array(cuts, dtype=np.int64)
     tick = 0.01
     o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
     woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
     off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, tick, o[2], o[1], 3.0)
     _check_fp(off, flat, bar, woff, wflat, wbar, amounts)
-    if amounts == "dyadic":
-        # a fine tick: the longest bars span more than 2 048 levels and stay with the global-scratch class
-        woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.0005, o[2], o[1], 3.0)
-        assert np.diff(woff).max() > 2048
-        off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.0005, o[2], o[1], 3.0)
-        _check_fp(off, flat, bar, woff, wflat, wbar, "dyadic, fine tick")
+    if amounts in ("dyadic", "lognormal32", "f64"):
+        # finer ticks: the widest bar decides how many tick segments the tick-ordered path can scatter concurrently (16 counter arrays
+        # fit the LDS up to ~600 levels, 1 beyond ~5 000) and beyond 6 144 levels a long bar stays with the wave kernel's
+        # global-scratch class
+        for fine in (0.002, 0.0005, 0.0002):
+            woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, fine, o[2], o[1], 3.0)
+            off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, fine, o[2], o[1], 3.0)
+            _check_fp(off, flat, bar, woff, wflat, wbar, f"{amounts}, tick {fine}: widest bar {np.diff(woff).max()} levels")
+        assert np.diff(woff).max() > 6144
