@@ -94,9 +94,10 @@ extern "C" int fmk_h2d_columns(fmk_ctx *ctx, int n_cols, void *const *dst_dev, c
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int T = up_threads();
     if (total < 2 * UP_CHUNK || T == 0) {                        // the runtime's copy (default; measured at 98 % of the pinned rate)
+        // the BLOCKING call: on some boxes hipMemcpyAsync from pageable memory on a stream takes the runtime's single staging
+        // buffer (29.9 GB/s measured where hipMemcpy of the same buffer reaches 56.6); the context's stream is idle here anyway
         for (int c = 0; c < n_cols; ++c)
-            if (bytes[c]) FMK_HIP(ctx, hipMemcpyAsync(dst_dev[c], src_host[c], bytes[c], hipMemcpyHostToDevice, ctx->stream));
-        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (bytes[c]) FMK_HIP(ctx, hipMemcpy(dst_dev[c], src_host[c], bytes[c], hipMemcpyHostToDevice));
         return FMK_OK;
     }
     std::vector<UpItem> items;
