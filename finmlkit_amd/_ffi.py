@@ -140,6 +140,11 @@ class Context:
         each may differ from the reference by one tick); False (default) = such inputs are redone by the exact loop."""
         self.call("fmk_ctx_set_fast_threshold", C.c_int(1 if on else 0))
 
+    def set_enqueue_only(self, on: bool):
+        """True: calls never wait for the device where they have the choice (comp_bar_ohlcv then enqueues the launches that serve
+        long bars without looking whether there are any) -- for the sharded step, which overlaps its calls with the halo exchange."""
+        self.call("fmk_ctx_set_enqueue_only", C.c_int(1 if on else 0))
+
     def sync(self):
         self.call("fmk_ctx_sync")
 

@@ -353,6 +353,12 @@ int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on)
     return FMK_OK;
 }
 
+int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on)
+{
+    ctx->enqueue_only = on ? 1 : 0;
+    return FMK_OK;
+}
+
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count)
 {
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -28,6 +28,8 @@ struct fmk_ctx {
     // threshold indexers: 0 (default) = inputs with uncertified decisions are redone by the exact sequential loop;
     // 1 = return the parallel result with its n_uncertified (fmk_ctx_set_fast_threshold)
     int fast_threshold;
+    // 1 = calls never wait for the device where they have the choice (fmk_ctx_set_enqueue_only)
+    int enqueue_only;
     hipEvent_t kev[64][2];
     // stream-ordered caching allocator behind fmk_alloc / fmk_free (fmk_api.hip): freed blocks are kept and handed
     // out again to later requests of (almost) the same size -- no hipMalloc / hipFree / synchronisation per call

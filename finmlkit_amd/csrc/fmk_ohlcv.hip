@@ -1321,6 +1321,21 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][1], ctx->stream));
+    // Everything below serves the bars the first kernel left behind -- six list kernels, six size classes, the generic kernel, the
+    // workgroup kernels and their median passes: ~36 launches that exit at once when there is no such bar, ~0.25 ms per call at
+    // ~7 us each (10 % of the 1-minute headline pass, rocprofv3 of bench.py at the end of round 3).  So the flag is read back first:
+    // one 4-byte copy and a wait for the kernel that is the call's work anyway.  fmk_ctx_set_enqueue_only(ctx, 1) (the sharded
+    // step: two waits per step cost it 0.9 ms) or the developer knob FMK_OHLCV_CENSUS_SYNC=0: enqueue everything without looking.
+    if constexpr (!AF64) {
+        static int census_sync = -1;
+        if (census_sync < 0) { const char *v = getenv("FMK_OHLCV_CENSUS_SYNC"); census_sync = v ? atoi(v) : 1; }
+        if (census_sync && !ctx->enqueue_only) {
+            int *h_saw = (int *)(ctx->h_mail + 12);
+            FMK_HIP(ctx, hipMemcpyAsync(h_saw, saw_long, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (*h_saw == 0) return FMK_OK;
+        }
+    }
     // long bars (if any): the generic kernels exit at once when the flag is clear.  float32 bars of 1 345 .. 8 192 ticks: one pass by
     // a workgroup each, median included (developer knob FMK_OHLCV_MID=0: the generic kernels + the median kernels as before)
     int64_t skip_lo = 0, skip_hi = 0;

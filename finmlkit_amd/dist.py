@@ -313,10 +313,16 @@ class ShardedTimeBars:
         return self.plan.n_bars
 
     def step(self, comm: "Comm") -> int:
-        comm.exchange(self.send_slices(), self.recv_slices())    # enqueued on the communicator's stream
-        self.enqueue_interior()                                   # overlaps the exchange
-        comm.wait()                                               # event: context stream after the exchange
-        return self.enqueue_boundary()
+        # enqueue only: comp_bar_ohlcv must not wait for its first kernel here (it would, to skip the launches that serve long bars
+        # when there are none) -- two host waits per step cost 0.9 ms against the 0.25 ms of launches they save
+        self.ctx.set_enqueue_only(True)
+        try:
+            comm.exchange(self.send_slices(), self.recv_slices())    # enqueued on the communicator's stream
+            self.enqueue_interior()                                   # overlaps the exchange
+            comm.wait()                                               # event: context stream after the exchange
+            return self.enqueue_boundary()
+        finally:
+            self.ctx.set_enqueue_only(False)
 
     def features(self, price_tick_size: float, imbalance_factor: float = 3.0):
         """cfg 4 on the shard (after a step with with_side=True): order-flow + footprints of this rank's bars through

@@ -102,6 +102,12 @@ int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms)
  * on = 1: the parallel result is returned as is, each uncertified decision may differ from the reference by one tick
  * (resident pipelines of 1e9 ticks). */
 int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on);
+/* Enqueue-only mode.  on = 0 (default): fmk_comp_bar_ohlcv_dev waits for its first kernel and reads back whether any bar was left
+ * for the long-bar schedules; when none was -- streams of 1-minute bars and the like -- the ~36 launches that serve such bars are not
+ * issued at all (they would exit at once, ~0.25 ms per call).  on = 1: the call never waits; everything is enqueued unconditionally
+ * and it returns before its kernels have run -- for callers that overlap the call with other streams' work and must not block
+ * (the sharded step of finmlkit_amd/dist.py between its halo exchange and its boundary bar). */
+int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on);
 int fmk_profile_enable(fmk_ctx *ctx, int on);
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count);
 

@@ -13,6 +13,15 @@ def test_fuzz_parity_fixed_seed(orc):
     assert not fails, "\n".join(fails[:10])
 
 
+def test_fuzz_long_bars_fixed_seed(orc):
+    """tools/fuzz_longbars.py: the four bar reducers on bars around every threshold of the workgroup-per-bar schedules (8 192 ..
+    65 536 ticks -+ 1) mixed with short, empty and very long ones; dyadic, full-mantissa float32 and float64 amounts, a NaN or a
+    negative size now and then, coarse to fine price grids (240 cases over two seeds were run when the schedules were built)."""
+    from tools.fuzz_longbars import campaign
+    fails = campaign(16, 20260929, orc, verbose=False)
+    assert not fails, "\n".join(fails[:5])
+
+
 def test_fuzz_sharded_fixed_seed():
     """tools/fuzz_sharded.py: random world sizes (2..8 virtual ranks), ticks per rank, stream density and bar interval; the
     concatenated per-rank outputs of the sharded time-bar step equal the un-sharded run bit for bit (60 configurations of

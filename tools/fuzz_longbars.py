@@ -64,23 +64,30 @@ def case(rng, orc, pkg, k):
             else: np.testing.assert_allclose(g, w, rtol=2e-6, equal_nan=True, err_msg=f"{what}: trade size {key}")
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    from oracle import oracle as orc
+def campaign(cases, seed, orc, verbose=True):
+    """-> list of failure messages"""
     from finmlkit_amd.bar import base
-    orc.build()
     pkg = {"base": base}
     rng = np.random.default_rng(seed)
-    fails = 0
+    fails = []
     for k in range(cases):
         try:
             case(rng, orc, pkg, k)
         except Exception as e:      # noqa: BLE001
-            fails += 1
-            print(f"FAIL seed {seed} {str(e)[:1500]}", flush=True)
-            if not isinstance(e, AssertionError): traceback.print_exc()
-    print(f"{cases} long-bar cases, seed {seed}: {fails} failures")
+            fails.append(f"seed {seed} {str(e)[:1500]}")
+            if verbose:
+                print(f"FAIL {fails[-1]}", flush=True)
+                if not isinstance(e, AssertionError): traceback.print_exc()
+    return fails
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    from oracle import oracle as orc
+    orc.build()
+    fails = campaign(cases, seed, orc)
+    print(f"{cases} long-bar cases, seed {seed}: {len(fails)} failures")
     sys.exit(1 if fails else 0)
 
 
