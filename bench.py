@@ -186,6 +186,15 @@ def other_configs(trades, ctx, args):
         ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(args.seed), c_i64(n), am2.p)
         t2 = engine.DeviceTrades(ctx, trades.ts, trades.price, am2, trades.side)
         out["cfg4_full_mantissa_amounts_ms"] = timed(lambda: t2.bars_fused(ci, 0.01, 3.0))
+        # cfg 4 on bars of HEAVY-TAILED lengths (lognormal, mean 1 200 ticks, sigma 1: what real one-minute bars look like;
+        # profiles/r03_real_bar_lengths.txt) -- the synthetic clock's own bars are all ~1 200 ticks long
+        rng = np.random.default_rng(7)
+        lens = np.maximum(1, rng.lognormal(np.log(1200.0) - 0.5, 1.0, int(n / 1200 * 1.3)).astype(np.int64))
+        ci_h = np.concatenate([[-1], np.cumsum(lens) - 1])
+        ci_r = DeviceArray.from_host(ctx, ci_h[ci_h <= n - 1].astype(np.int64))
+        out["cfg4_lognormal_bar_lengths_ms"] = timed(lambda: trades.bars_fused(ci_r, 0.01, 3.0), reps=2)
+        out["cfg4_lognormal_bar_lengths_full_mantissa_ms"] = timed(lambda: t2.bars_fused(ci_r, 0.01, 3.0), reps=2)
+        del ci_r
         # cfg 4 at the ends of the bar-length axis (hourly / daily bars: a workgroup per bar; tools/intervalbench.py has every length)
         for label, iv in (("hourly", 3600.0), ("daily", 86400.0)):
             _, ci_l = trades.time_bar_index(iv)

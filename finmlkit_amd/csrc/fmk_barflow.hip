@@ -1009,7 +1009,21 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
         const bool has = b < nb;
         const int64_t s = has ? ci[b] : 0, e = has ? ci[b + 1] : 0;
         const int64_t len = e - s;
-        const bool is_long = has && len > max_len;
+        // A lane walks ITS bar; the wave is done when its longest bar is.  That pays while the 64 bars are about equally long -- the
+        // schedule spends ~39 VALU instructions per tick ROW against the ~55 per 64 ticks of the wave-per-bar kernel, so it needs
+        // ~70 % of its lanes busy.  Real one-minute bars are not like that (lognormal lengths, sigma ~1: a quiet minute of 100 ticks
+        // next to a busy one of 8 000): a wave whose bars fill less than 70 % of (64 x its longest bar) keeps only its short bars
+        // (<= 192 ticks: a wave per bar is the worse deal for those) and lists the others for k_bar_dir.  Measured on 1e9 ticks in
+        // lognormal bars of sigma 1 (tools/realbars.py): 8.3 ms with every bar on a lane, 3.9 ms with a wave per bar.
+        int64_t thr_w = max_len;
+        {
+            const bool cand = has && len > 0 && len <= max_len;
+            const int64_t wsum = fmk_dpp_reduce(cand ? len : (int64_t)0, (int64_t)0, FmkOpAdd());
+            const int64_t wmax = fmk_dpp_reduce(cand ? len : (int64_t)0, (int64_t)0, FmkOpMax());
+            const int nact = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand));
+            if (wmax > 192 && (double)wsum < 0.7 * (double)wmax * (double)nact) thr_w = 192;
+        }
+        const bool is_long = has && len > thr_w;
         const unsigned long long lb = __builtin_amdgcn_ballot_w64(is_long);
         if (lb) {
             unsigned long long base = 0;
@@ -1552,6 +1566,19 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
                                                                    (unsigned long long *)d_n_zero_div, redo, long_list);
         bf_redo_launch<false>(ctx, (unsigned)blocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
         FMK_LAUNCH_CHECK(ctx);
+        // How many bars did the lane kernel hand on?  On a stream of about equally long bars none, and their OHLC is done.  On real
+        // one-minute bars (lognormal lengths) most waves keep only their short bars (k_bar_dir_lanes: the 70 % rule): the bars that
+        // carry most of the ticks are then better served by comp_bar_ohlcv's own size classes (one pass, median included) than by
+        // the generic leftover kernel plus the stand-alone median kernels -- measured at sigma 1: 20.0 ms for this call against
+        // 14.3 ms for the three functions apart (tools/realcfg4.py).  One 8-byte read-back; the call waits for its sizing pass anyway.
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[13], long_list, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_mail[13] > nb / 50) {
+            FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, 0, n, d_close_idx, n_idx, d_open, d_high, d_low, d_close, d_volume,
+                                           d_vwap, d_trades, d_median));
+            return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
+                                                    max_levels);
+        }
         FMK_TRY(fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, 8192, any_long, d_open, d_high, d_low,
                                           d_close, d_volume, d_vwap, d_trades));
         // FMK_FLOW_MEDIAN_DEFER=1 leaves the median to the footprint sweep (26 B/tick in all).  OFF by default: measured slower --

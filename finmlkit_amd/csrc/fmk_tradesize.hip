@@ -256,17 +256,18 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
 // the keys below the bracket and appends the sizes inside it to the bar's candidate slots, and the two ranks are selected among
 // the candidates exactly; a bracket that misses (or overflows: heavy ties) falls back to the radix select of the whole bar.
 // ---------------------------------------------------------------------------------------------------------------------
-#define TSW_MIN 32768                  // (10-minute bars, 12 000 ticks: a workgroup's fixed cost per bar outweighs its sixteen waves)
-#define TSW_WAVES 16
+#define TSW_MIN 32768                  // sixteen waves per bar beyond, four from TSW_MID_MIN (a workgroup's fixed cost per bar -- the
+#define TSW_MID_MIN 4096               // barriers of the cut, the scans and the selections -- grows with its waves)
 #define TSW_MAXSUB 128
 #define TSW_ROUNDS 10
 #define TSW_SAMPLE_MIN 65536           // shorter bars: the radix select on the (L2-resident) bar itself -- its fixed cost decides
+template <int TSW_WAVES>
 __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const float *__restrict__ amount, const double *__restrict__ theta,
                                                                       const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
                                                                       int64_t n, double theta_mult, float *__restrict__ o_mean,
                                                                       float *__restrict__ o_p95, float *__restrict__ o_pct,
                                                                       float *__restrict__ o_gini, float *__restrict__ samp,
-                                                                      uint32_t *__restrict__ cand)
+                                                                      uint32_t *__restrict__ cand, int64_t min_cnt, int64_t max_cnt)
 {
     typedef MedKey<false> MK;
     // the cut of the tree's top, level by level (entry = a node (off, len) of the current level, in order): round d keeps for
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
     for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
         const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
         const int64_t cnt64 = e - s;
-        if (!(s >= -1 && e <= n - 1) || cnt64 <= TSW_MIN || cnt64 > FMK_PW_BIG_MAX_N) continue;     // the wave kernel's (same test there)
+        if (!(s >= -1 && e <= n - 1) || cnt64 <= min_cnt || cnt64 > max_cnt) continue;     // another launch's (or the wave kernel's: same test there)
         const int cnt = (int)cnt64;
         const float *af = amount + (s + 1);
         const double th = theta[b];
@@ -298,9 +299,9 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
         }
         const double thr = th * theta_mult;
         // ---- the cut: nodes longer than G split into (off, n2) and (off + n2, len - n2), n2 = len / 2 rounded down to a multiple of
-        //      8 (NumPy's rule), until none is: 33 .. 128 sub-trees, two to eight per wave
+        //      8 (NumPy's rule), until none is: two to eight sub-trees per wave
         int G = 256;
-        while (cnt / G > 64) G *= 2;
+        while (cnt / G > 4 * TSW_WAVES) G *= 2;
         __syncthreads();
         if (tid == 0) { e_off[0][0] = 0; e_len[0][0] = cnt; e_n[0] = 1; s_ncand = 0; s_nan = 0; }
         __syncthreads();
@@ -981,13 +982,18 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     int64_t *list_mid = nullptr, *list_long = nullptr;
     FMK_TRY(fmk_long_bar_list(ctx, d_close_idx, nb, n, 64 * 32, nullptr, &list_mid, 8192));
     int rc = fmk_long_bar_list(ctx, d_close_idx, nb, n, 8192, nullptr, &list_long);
+    int64_t *list_w = nullptr;                                     // the bars a workgroup may take
+    if (rc == FMK_OK) rc = fmk_long_bar_list(ctx, d_close_idx, nb, n, 2048, nullptr, &list_w);
     if (rc == FMK_OK) {
-        k_ts_p95_long<256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_mid, n,
-                                                                            d_size_95_rel);
-        // bars beyond TSW_MIN ticks: a workgroup per bar, percentile included (developer knob FMK_TS_WIDE=0: one wave per bar and the
-        // radix-select percentile as before); scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
+        // bars beyond TSW_MID_MIN ticks: a workgroup per bar, percentile included (developer knob FMK_TS_WIDE=0: one wave per bar and
+        // the radix-select percentile as before); scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
         const char *wv = getenv("FMK_TS_WIDE");
-        bool wide_on = (!wv || atoi(wv)) && n > TSW_MIN;
+        bool wide_on = (!wv || atoi(wv)) && n > TSW_MID_MIN;
+        const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) a workgroup takes
+        const int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : TSW_MID_MIN;
+        k_ts_p95_long<256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_mid, n,
+                                                                            d_size_95_rel, wide_on ? wide_min : INT64_MAX,
+                                                                            (int64_t)FMK_PW_BIG_MAX_N);
         float *samp = nullptr;
         uint32_t *cand = nullptr;
         if (wide_on) {
@@ -996,15 +1002,21 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         }
         if (rc == FMK_OK) {
         k_ts_p95_long<1024><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_long, n,
-                                                                             d_size_95_rel, wide_on ? (int64_t)TSW_MIN : INT64_MAX, (int64_t)FMK_PW_BIG_MAX_N);
-        if (wide_on)
-            k_bar_trade_size_wide<<<(unsigned)(ctx->n_cu * 2), 64 * TSW_WAVES, 0, ctx->stream>>>(
-                (const float *)d_amount, d_theta, d_close_idx, list_long, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
-                d_size_gini, samp, cand);
+                                                                             d_size_95_rel, wide_on ? wide_min : INT64_MAX, (int64_t)FMK_PW_BIG_MAX_N);
+        if (wide_on) {
+            const int64_t split = wide_min > TSW_MIN ? wide_min : TSW_MIN;
+            if (wide_min < split)
+                k_bar_trade_size_wide<4><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(
+                    (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
+                    d_size_gini, samp, cand, wide_min, split);
+            k_bar_trade_size_wide<16><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>(
+                (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
+                d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N);
+        }
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
                                                                            d_pct_block, d_size_gini, 1, nullptr,
-                                                                           wide_on ? (int64_t)TSW_MIN : INT64_MAX);
+                                                                           wide_on ? wide_min : INT64_MAX);
         }
         if (samp) (void)fmk_free(ctx, samp);
         if (cand) (void)fmk_free(ctx, cand);
@@ -1012,6 +1024,7 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     const hipError_t le = hipGetLastError();
     (void)fmk_free(ctx, list_mid);
     if (list_long) (void)fmk_free(ctx, list_long);
+    if (list_w) (void)fmk_free(ctx, list_w);
     FMK_TRY(rc);
     FMK_HIP(ctx, le);
     return FMK_OK;
