@@ -1194,8 +1194,8 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
             else {
                 // the bracket lives in a wave from bar to bar and every wave's FIRST bar takes the generic selection: as many
                 // workgroups as are resident at once (grid-stride over the bars), not 64 per CU
-                static int occ[3] = {0, 0, 0};
-                const int slot = lmax <= 128 ? 0 : (lmax <= 512 ? 1 : 2);
+                static int occ[4] = {0, 0, 0, 0};
+                const int slot = lmax <= 128 ? 0 : (lmax <= 256 ? 1 : (lmax <= 512 ? 2 : 3));
                 if (!occ[slot]) {
                     int nblk = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_bar_footprints<false, false, true>, wpb * 64, smem) !=
@@ -1261,8 +1261,11 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     FpOut o;
     memcpy(&o, d_out, sizeof(o));
     unsigned long long *bad = (unsigned long long *)d_n_bad_level;
-    const int LMAX[4] = {128, 512, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
-    static const int WPB[4] = {4, 4, 1, 1};
+    // (the 256-level class: on bars of unequal length the longer ones -- more levels -- ran in the 512 class at 50 KB of LDS per
+    // workgroup, three workgroups per CU: profiles/r03_real_bar_lengths.txt)
+    constexpr int NCLS = 5;
+    const int LMAX[NCLS] = {128, 256, 512, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
+    static const int WPB[NCLS] = {4, 4, 4, 1, 1};
     // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
     // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
     // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
@@ -1366,7 +1369,7 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
             }
         }
     }
-    for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
+    for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         if (LMAX[k] > lmin_start) {
             rc = amount_is_f64
@@ -1380,7 +1383,7 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     // the long bars the workgroup kernel handed back (float64 amounts in tick order): the same classes once more, in list mode
     if (wide_defer && rc == FMK_OK) {
         lmin = 0;
-        for (int k = 0; k < 4 && rc == FMK_OK; ++k) {
+        for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
             if (k > 0 && max_levels <= LMAX[k - 1]) break;
             rc = amount_is_f64
                      ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,

@@ -19,6 +19,12 @@ nb0 = n // 1200
 lens = np.maximum(1, rng.lognormal(np.log(1200.0) - sg * sg / 2, sg, int(nb0 * 1.3)).astype(np.int64)) if sg > 0 else np.full(nb0, 1200, np.int64)
 ci_h = np.concatenate([[-1], np.cumsum(lens) - 1]); ci_h = ci_h[ci_h <= n - 1].astype(np.int64)
 ci = DeviceArray.from_host(ctx, ci_h)
+import os
+if os.environ.get("ONLY_FP"):
+    o = t.bar_ohlcv(ci, want_median=True)
+    for _ in range(2):
+        ctx.sync(); s0 = time.perf_counter(); r = t.bar_footprints(ci, o["low"], o["high"], 0.01); ctx.sync(); print(f"footprints: {(time.perf_counter() - s0) * 1e3:.2f} ms"); del r
+    sys.exit(0)
 all_ms = []
 for _ in range(6):
     ctx.sync(); s = time.perf_counter(); r = t.bars_fused(ci, 0.01, 3.0); ctx.sync(); all_ms.append(round((time.perf_counter() - s) * 1e3, 2)); del r
