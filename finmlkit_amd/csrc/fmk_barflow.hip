@@ -833,6 +833,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                     // the inclusive prefixes stay inside the binade by a margin that covers the approximate base
                     const bool good = usable && e_ok && !seg_bad && s_cabs[cc] < hi2 * 0.999999999 &&
                                       as + rmin > lo2 + margin && as + rmax < hi2 - margin && as > lo2 + margin && as < hi2 - margin;
+#ifdef BF_REDO_WHY
+                    constexpr bool getenv_why_by_row = BF_REDO_WHY == 2;      // -DBF_REDO_WHY=2: chunks with a tie / a large term, per column
+                    if ((lane & 7) == 0 && c < nc && !good) {                // developer knob: why a chunk has no record (slots 3 ..)
+                        const int why = !usable || !e_ok ? 0 : (seg_bad ? 1 : (!(s_cabs[cc] < hi2 * 0.999999999) ? 2 :
+                                        (!(as + rmin > lo2 + margin) ? 3 : (!(as + rmax < hi2 - margin) ? 4 : 5))));
+                        if (getenv_why_by_row) { if (why == 1) atomicAdd(&bf_redo_stats[3 + row], 1ULL); }
+                        else atomicAdd(&bf_redo_stats[3 + why], 1ULL);
+                    }
+#endif
                     if ((lane & 7) == 0 && c < nc) {
                         RsRec r;
                         r.T = good ? T : -1.0; r.minP = good ? rmin : 0.0; r.maxP = good ? rmax : 0.0;
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
         if (threadIdx.x == 0) {
             atomicAdd(&bf_redo_stats[0], 1ULL);
             atomicAdd(&bf_redo_stats[1], (unsigned long long)n_ch);
-#ifndef BF_REDO_TIMING
+#if !defined(BF_REDO_TIMING) && !defined(BF_REDO_WHY)
             atomicAdd(&bf_redo_stats[3 + row], 1ULL);
 #endif
             const double sum = s_carry[0];

@@ -8,6 +8,12 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 ivs = [float(x) for x in sys.argv[2:]] or [3600.0, 14400.0, 86400.0]
 ctx = _ffi.default_context()
 t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
+if os.environ.get("FMK_FULL_MANTISSA"):                            # sizes with 24 random mantissa bits (what real sizes look like)
+    import ctypes as C
+    import numpy as np
+    am2 = _ffi.DeviceArray(ctx, n, np.float32)
+    ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(42), c_i64(n), am2.p)
+    t = engine.DeviceTrades(ctx, t.ts, t.price, am2, t.side)
 for iv in ivs:
     clock, ci = t.time_bar_index(iv)
     best = 1e9
