@@ -75,6 +75,10 @@ int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *
 // fmk_median.hip: the bars of more than `min_cnt` ticks as a list ([0] = how many, then the bar numbers, any order) in a block of
 // the context's pool (*list; the caller gives it back with fmk_free after queueing its kernels) -- the workgroup-per-bar
 // kernels take their bars from it, so that a handful of very long bars spread over the whole chip
+#define FMK_MAX_BAR_LISTS 8
+// K lists in one pass and one allocation: list k = bars of edge[k] < ticks <= edge[k + 1]; free lists[0] (fmk_median.hip)
+int fmk_long_bar_lists(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int k, const int64_t *edge, const int *d_go,
+                       int64_t **lists);
 int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
                       int64_t **list, int64_t max_cnt = INT64_MAX /* bars of min_cnt < ticks <= max_cnt */);
 

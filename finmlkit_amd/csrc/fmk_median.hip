@@ -68,6 +68,53 @@ __global__ __launch_bounds__(256) void k_long_bar_list(const int64_t *__restrict
     if (is_long && pos < cap) list[1 + pos] = b;
 }
 
+// K lists at once -- list k holds the bars of edge[k] < ticks <= edge[k + 1] -- from ONE pass over the close indices into ONE
+// allocation (free lists[0]): the six size classes of comp_bar_ohlcv's middle range used to cost six memsets and six launches.
+struct LongBarEdges { int64_t edge[FMK_MAX_BAR_LISTS + 1]; int64_t *list[FMK_MAX_BAR_LISTS]; int64_t cap[FMK_MAX_BAR_LISTS]; int k; };
+__global__ __launch_bounds__(256) void k_long_bar_lists(const int64_t *__restrict__ ci, int64_t nb, LongBarEdges L, const int *__restrict__ go)
+{
+    if (go && *go == 0) return;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cnt = b < nb ? ci[b + 1] - ci[b] : 0;
+    if (__builtin_amdgcn_ballot_w64(cnt > L.edge[0] && cnt <= L.edge[L.k]) == 0) return;
+    const int lane = fmk_lane();
+    for (int k = 0; k < L.k; ++k) {
+        const bool in = cnt > L.edge[k] && cnt <= L.edge[k + 1];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long *)L.list[k], (unsigned long long)__builtin_popcountll(m));
+        base = (unsigned long long)fmk_uniform((int64_t)base);
+        const int64_t pos = (int64_t)base + __builtin_popcountll(m & ((1ULL << lane) - 1));
+        if (in && pos < L.cap[k]) L.list[k][1 + pos] = b;
+    }
+}
+
+int fmk_long_bar_lists(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int k, const int64_t *edge, const int *d_go,
+                       int64_t **lists)
+{
+    if (k < 1 || k > FMK_MAX_BAR_LISTS) return fmk_set_error(ctx, FMK_E_ARG, "fmk_long_bar_lists: %d lists", k);
+    LongBarEdges L;
+    L.k = k;
+    size_t total = 0;
+    for (int q = 0; q <= k; ++q) L.edge[q] = edge[q];
+    for (int q = 0; q < k; ++q) {
+        int64_t cap = n / (edge[q] > 0 ? edge[q] : 1) + 2;          // bars of more than edge[q] ticks: fewer than n / edge[q]
+        if (cap > nb) cap = nb;
+        L.cap[q] = cap;
+        total += (size_t)(cap + 1);
+    }
+    void *p = nullptr;
+    FMK_TRY(fmk_alloc(ctx, total * 8, &p));
+    int64_t *at = (int64_t *)p;
+    for (int q = 0; q < k; ++q) { L.list[q] = at; lists[q] = at; at += L.cap[q] + 1; }
+    // the counters sit at the heads of the lists: one memset over the block (a few MB at most) instead of one per list
+    FMK_HIP(ctx, hipMemsetAsync(p, 0, total * 8, ctx->stream));
+    k_long_bar_lists<<<(unsigned)fmk_ceil_div(nb, 256), 256, 0, ctx->stream>>>(d_close_idx, nb, L, d_go);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
 int fmk_long_bar_list(fmk_ctx *ctx, const int64_t *d_close_idx, int64_t nb, int64_t n, int64_t min_cnt, const int *d_go,
                       int64_t **list, int64_t max_cnt)
 {

@@ -1348,8 +1348,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
             constexpr int NL = 6;
             int64_t *list[NL] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             static const int64_t edge[NL + 1] = {OHM_MIN, 2048, 3072, 4096, 6144, 8192, OHM_MAX};
-            int rc = FMK_OK;
-            for (int k = 0; k < NL && rc == FMK_OK; ++k) rc = fmk_long_bar_list(ctx, ci, nb, n, edge[k], saw_long, &list[k], edge[k + 1]);
+            int rc = fmk_long_bar_lists(ctx, ci, nb, n, NL, edge, saw_long, list);      // (one pass, one allocation: list[0] owns it)
             // measured per 1e9 ticks, ohlcv + median (profiles/r03_median_humps.txt): 4 400 / 5 200 / 6 000-tick bars 3.6 / 3.4 / 3.1 ms
             // with 96 key registers per lane against 5.1 / 4.5 / 4.0 ms by the workgroup kernel; 7 000 / 8 000-tick bars 5.5 / 5.2 ms
             // with 128 key registers (spills) against 3.6 / 3.3 ms by the workgroup kernel
@@ -1373,8 +1372,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
                 }
             }
             const hipError_t le = hipGetLastError();
-            for (int k = 0; k < NL; ++k)
-                if (list[k]) (void)fmk_free(ctx, list[k]);
+            if (list[0]) (void)fmk_free(ctx, list[0]);
             FMK_TRY(rc);
             FMK_HIP(ctx, le);
         }

@@ -20,7 +20,9 @@ lens = np.maximum(1, rng.lognormal(np.log(1200.0) - sg * sg / 2, sg, int(nb0 * 1
 ci_h = np.concatenate([[-1], np.cumsum(lens) - 1]); ci_h = ci_h[ci_h <= n - 1].astype(np.int64)
 ci = DeviceArray.from_host(ctx, ci_h)
 import os
-if os.environ.get("ONLY_FP"):
+if os.environ.get("ONLY_FP_IV"):
+    clock, ci = t.time_bar_index(float(os.environ["ONLY_FP_IV"]))
+if os.environ.get("ONLY_FP") or os.environ.get("ONLY_FP_IV"):
     o = t.bar_ohlcv(ci, want_median=True)
     for _ in range(2):
         ctx.sync(); s0 = time.perf_counter(); r = t.bar_footprints(ci, o["low"], o["high"], 0.01); ctx.sync(); print(f"footprints: {(time.perf_counter() - s0) * 1e3:.2f} ms"); del r
