@@ -815,32 +815,45 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
         if (!force_ordered && wq != FP_Q_UNKNOWN) done = attempt(wq);
         // the counts per (segment, key) of the tick-ordered path and the statistics that pick a quantum come from ONE sweep
         const int K = 2 * L;
-        int *segc = nseg > 1 ? (int *)(smem + (size_t)lmax * 24 + 256) : (int *)aux;      // [nseg][2 * lmax]
+        // the counter arrays of the segments: nseg - 2 in the LDS behind the histogram, then the aux and the vol areas of the
+        // histogram itself (both idle until the key sums are written; an integer attempt in between overwrites vol: recount)
         const int sstride = 2 * lmax;
+        auto seg_arr = [&](int g) -> int * {
+            return g < nseg - 2 ? (int *)(smem + (size_t)lmax * 24 + 256) + (size_t)g * sstride : (g == nseg - 2 ? (int *)aux : (int *)vol);
+        };
         int64_t gseg = (e - s + nseg - 1) / nseg;
         gseg = (gseg + 63) & ~(int64_t)63;
         if (!done && parallel_ok) {
             if constexpr (!AF64) {
-                __syncthreads();
-                for (int k = (int)threadIdx.x; k < K; k += 64 * FPW_WAVES)
-                    for (int g = 0; g < nseg; ++g) segc[g * sstride + k] = 0;
-                __syncthreads();
-                // wave w takes a sixteenth of the ticks; where its range straddles two segments it counts the parts separately
-                FpStats mine;
-                mine.lbmin = FP_Q_UNKNOWN; mine.atot = 0.0; mine.units_ok = true; mine.bad = false;
-                for (int g = 0; g < nseg; ++g) {
-                    const int64_t g_lo = s + (int64_t)g * gseg, g_hi = g_lo + gseg < e ? g_lo + gseg : e;     // (g_lo, g_hi]
-                    const int64_t lo = s_w > g_lo ? s_w : g_lo, hi = e_w < g_hi ? e_w : g_hi;
-                    if (hi > lo)
-                        mine.bad |= fp_count_lean(price, (const float *)amount, side, lo, hi, low, L, tick, inv_tick, lane,
-                                                  segc + g * sstride, mine.lbmin, mine.atot);
-                }
-                mine.lbmin = fmk_dpp_reduce(mine.lbmin, FP_Q_UNKNOWN, FmkOpMin());
-                mine.atot = fmk_dpp_reduce(mine.atot, 0.0, FmkOpAdd());
-                const FpStats t = combine(mine);
+                auto count_sweep = [&]() -> FpStats {
+                    __syncthreads();
+                    for (int g = 0; g < nseg; ++g) {
+                        int *sc = seg_arr(g);
+                        for (int k = (int)threadIdx.x; k < K; k += 64 * FPW_WAVES) sc[k] = 0;
+                    }
+                    __syncthreads();
+                    // wave w takes a sixteenth of the ticks; where its range straddles two segments it counts the parts separately
+                    FpStats mine;
+                    mine.lbmin = FP_Q_UNKNOWN; mine.atot = 0.0; mine.units_ok = true; mine.bad = false;
+                    for (int g = 0; g < nseg; ++g) {
+                        const int64_t g_lo = s + (int64_t)g * gseg, g_hi = g_lo + gseg < e ? g_lo + gseg : e;     // (g_lo, g_hi]
+                        const int64_t lo = s_w > g_lo ? s_w : g_lo, hi = e_w < g_hi ? e_w : g_hi;
+                        if (hi > lo)
+                            mine.bad |= fp_count_lean(price, (const float *)amount, side, lo, hi, low, L, tick, inv_tick, lane, seg_arr(g),
+                                                      mine.lbmin, mine.atot);
+                    }
+                    mine.lbmin = fmk_dpp_reduce(mine.lbmin, FP_Q_UNKNOWN, FmkOpMin());
+                    mine.atot = fmk_dpp_reduce(mine.atot, 0.0, FmkOpAdd());
+                    return combine(mine);
+                };
+                const FpStats t = count_sweep();
                 bad_level = t.bad;
                 const int q2 = t.lbmin == FP_Q_UNKNOWN ? 0 : t.lbmin;      // only zeros: any quantum
-                if (!force_ordered && hopeful(t, q2)) { done = attempt(q2); q_used = q2; }
+                if (!force_ordered && hopeful(t, q2)) {
+                    done = attempt(q2);
+                    q_used = q2;
+                    if (!done) bad_level = count_sweep().bad;              // (the attempt used vol: the last segment's counters)
+                }
             }
         } else if (!done && !force_ordered) {
             const FpStats t = combine(fp_stats_lean<AF64>(price, amount, side, s_w, e_w, low, L, tick, inv_tick, lane));
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
                 int tot = 0;
                 for (int k = k0; k < k0 + per && k < K; ++k) {
                     int c = 0;
-                    for (int g = 0; g < nseg; ++g) c += segc[g * sstride + k];
+                    for (int g = 0; g < nseg; ++g) c += seg_arr(g)[k];
                     cnt[k] = c;
                     tot += c;
                 }
@@ -886,19 +899,18 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
                 int base0 = inc - tot;
                 for (int k = 0; k < w; ++k) base0 += (int)s_umax[k];
                 for (int k = k0; k < k0 + per && k < K; ++k) {
-                    for (int g = 0; g < nseg; ++g) { const int c = segc[g * sstride + k]; segc[g * sstride + k] = base0; base0 += c; }
+                    for (int g = 0; g < nseg; ++g) { int *sc = seg_arr(g); const int c = sc[k]; sc[k] = base0; base0 += c; }
                 }
                 __syncthreads();
                 float *sorted = sorted_all + (s + 1);
                 if (w < nseg) {
                     const int64_t g_lo = s + (int64_t)w * gseg, g_hi = g_lo + gseg < e ? g_lo + gseg : e;
                     if (g_hi > g_lo)
-                        fp_scatter_lean(price, (const float *)amount, side, g_lo, g_hi, low, L, tick, inv_tick, lane, segc + w * sstride,
-                                        sorted);
+                        fp_scatter_lean(price, (const float *)amount, side, g_lo, g_hi, low, L, tick, inv_tick, lane, seg_arr(w), sorted);
                 }
                 __syncthreads();
                 // the last segment's cursor is now the END of the key's slice
-                const int *cursor = segc + (nseg - 1) * sstride;
+                const int *cursor = seg_arr(nseg - 1);                   // (the vol area: thread k reads its end, then writes its sum there)
                 for (int k = (int)threadIdx.x; k < K; k += 64 * FPW_WAVES) {
                     const int end = cursor[k], c = cnt[k];
                     const float *src = sorted + (end - c);
@@ -1343,10 +1355,10 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                 const int wl_max = (int)(max_levels < 64 ? 64 : (max_levels > FPW_MAX_LEVELS ? FPW_MAX_LEVELS : max_levels));
                 // ... plus the counter arrays of the tick-ordered path's segments (8 B per level and segment) in what is left of 158 KB
                 const size_t hist = (size_t)wl_max * 24 + 256, avail = (size_t)158 * 1024;
-                int nseg = (int)((avail - hist) / ((size_t)wl_max * 8));
-                nseg = nseg > 16 ? 16 : nseg;
-                if (nseg < 2) nseg = 1;                            // one segment: its cursors live in the aux area
-                const size_t smem = hist + (nseg > 1 ? (size_t)nseg * wl_max * 8 : 0);
+                int nlds = (int)((avail - hist) / ((size_t)wl_max * 8));
+                nlds = nlds > 14 ? 14 : nlds;
+                const int nseg = nlds + 2;                         // ... plus the histogram's own aux and vol areas
+                const size_t smem = hist + (size_t)nlds * wl_max * 8;
                 if (smem > 48 * 1024) {
                     (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
                     (void)hipFuncSetAttribute((const void *)k_bar_footprints_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
