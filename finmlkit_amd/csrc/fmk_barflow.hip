@@ -580,14 +580,22 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
 // ---------------------------------------------------------------------------------------
 #define RS_CH 512
 #define RS_WAVES 8                    // 512 threads: 256 VGPRs per lane (two raw tiles, the terms and their prefixes live at once)
-#define RS_POOL 240                   // chunks whose terms wait in LDS for the term-by-term walk
+#define RS_POOL 200                   // chunks whose terms wait in LDS for the term-by-term walk
 #define RS_UNROLL 4
 #define RS_GRP 16                     // chunks per group record
 #define RS_NONE ((int)0x80000000)
+// TIES.  A term that lies exactly half way between two grid points rounds to even, i.e. by the PARITY of the running sum's last
+// bit -- and ties are not rare: 4 % of the prices on a 0.01 grid are multiples of 0.25, their product with a 24-bit size is exact,
+// and its lowest set bit is half a grid step for ~1 % of the terms of a daily bar's dollar sums (every second chunk holds one:
+// profiles/r03_long_bars.txt).  With S = |s| / g and a tie x = (m + 1/2) g:  S <- S + m + ((S + m) & 1), which is EVEN afterwards
+// whatever S was.  So only a chunk's FIRST tie depends on the incoming parity, and a record carries two variants -- index 0 / 1 =
+// the parity of S at the chunk's start -- which differ by one grid step from that tie on.  `pout`: the parity after the chunk
+// (absolute when the chunk holds a tie, otherwise the parity of its total, to be xor-ed onto the incoming one).
 struct RsRec {
-    double T, minP, maxP;
+    double T[2], minP[2], maxP[2];
     int e;                            // binade of |s| the record was computed for; RS_NONE: not usable
-    int neg;                          // sign of s it was computed for
+    short neg;                        // sign of s it was computed for
+    unsigned char has_tie, pout;
 };
 
 // the row's terms of one chunk (64 ticks from j0, lane = tick; 0.0 where the reference skips the update) with unconditional loads
@@ -640,9 +648,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
     __shared__ RsRec s_rec[RS_CH];
     __shared__ RsRec s_grp[RS_CH / RS_GRP];
     __shared__ double s_tot[RS_CH], s_abs[RS_CH], s_cabs[RS_CH];
-    __shared__ double s_x[64];
     // per-wave tiles while the records are made; afterwards the POOL: the terms of the chunks that will be added term by term
-    __shared__ double s_stage[RS_POOL * 64];
+    __shared__ double s_stage[(RS_POOL + 1) * 64];                       // (+ one slot for a chunk fetched during the walk)
     __shared__ unsigned long long s_flow[RS_CH];
     __shared__ double s_carry[4];                                        // s, mn, mx, started (wave 0 -> all)
     __shared__ long long s_nflow;
@@ -810,24 +817,80 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                     const double C = 1.5 * lo2;
                     bool bad = false;
                     double acc = 0.0, pq[8];
+                    unsigned tie_byte = 0, par_byte = 0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const double xs = neg ? -q[i] : q[i];
                         const double y = (C + xs) - C;                       // |xs| < 2^(e-1): C + xs stays in C's binade -> y = rnd_g(xs)
                         const double rr = xs - y;
-                        bad |= !(fabs(xs) < lim) || fabs(rr) == half_g;
-                        acc += y;
+                        const bool tie = fabs(rr) == half_g;
+                        const double yf = tie ? xs - half_g : y;             // a tie counts as its LOWER grid point m g (exact)
+                        bad |= !(fabs(xs) < lim);
+                        tie_byte |= tie ? 1u << i : 0u;
+                        // parity of yf / g: C / g is even and C + yf is exact, so it is the last mantissa bit of C + yf
+                        par_byte |= (unsigned)(__double_as_longlong(C + yf) & 1) << i;
+                        acc += yf;
                         pq[i] = acc;
                     }
-                    // sum |y| <= sum |x| + 64 g / 2 < 2^(e+1) = 2^53 g (tested below): the lane's partial sums and the scan are exact.
+                    // sum |y| <= sum |x| + 64 g < 2^(e+1) = 2^53 g (tested below): the lane's partial sums and the scan are exact.
                     // (A bound on the SUM, not 64 x the largest term: signed rows hover within a few hundred terms of zero.)
                     const double incl = fmk_half_iscan_add(acc, lane);
                     const double base = incl - acc;
-                    double pmin = INFINITY, pmax = -INFINITY;
+                    const double Tf = fmk_half_sum(acc);                     // (multiples of g: exact in any order)
+                    double rmin0, rmax0, rmin1, rmax1, T0, T1;
+                    int pout;
+                    uint64_t TM = 0;
+                    if (__ballot(tie_byte != 0) == 0) {                      // (no tie in the wave's eight chunks: the common case)
+                        double pmin = INFINITY, pmax = -INFINITY;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { const double P = base + pq[i]; pmin = bf_min(pmin, P); pmax = bf_max(pmax, P); }
-                    const double rmin = fmk_half_min(pmin), rmax = fmk_half_max(pmax);
-                    const double T = fmk_half_sum(acc);                      // (multiples of g: exact in any order)
+                        for (int i = 0; i < 8; ++i) { const double P = base + pq[i]; pmin = bf_min(pmin, P); pmax = bf_max(pmax, P); }
+                        rmin0 = rmin1 = fmk_half_min(pmin); rmax0 = rmax1 = fmk_half_max(pmax);
+                        T0 = T1 = Tf;
+                        int lp = (int)(__builtin_popcount(par_byte) & 1);    // parity of the chunk's total: xor over the half row
+                        lp ^= __builtin_amdgcn_update_dpp(lp, lp, DPP_XOR1, 0xF, 0xF, false);
+                        lp ^= __builtin_amdgcn_update_dpp(lp, lp, DPP_XOR2, 0xF, 0xF, false);
+                        lp ^= __builtin_amdgcn_update_dpp(lp, lp, DPP_HALF_MIRROR, 0xF, 0xF, false);
+                        pout = lp & 1;
+                    } else {
+                        // the chunk's ties, resolved in order for incoming parity 0 (cm0: the ties that round UP); parity 1 flips the first
+                        const int sh = 8 * (lane & 7);
+                        TM = fmk_half_or((uint64_t)tie_byte << sh);
+                        const uint64_t AM = fmk_half_or((uint64_t)par_byte << sh);
+                        uint64_t cm0 = 0, first_bit = 0;
+                        {
+                            uint64_t rest = TM;
+                            int prev = -1, par = 0;
+                            while (rest) {                                   // (uniform inside the half row; a handful of ties at most)
+                                const int t = __builtin_ctzll(rest);
+                                rest &= rest - 1;
+                                const uint64_t between = AM & (((1ULL << t) - 1) & ~(prev >= 0 ? ((2ULL << prev) - 1) : 0ULL));
+                                par ^= (int)(__builtin_popcountll(between) & 1);
+                                const int c1 = par ^ (int)((AM >> t) & 1);   // (S + m) & 1
+                                if (c1) cm0 |= 1ULL << t;
+                                if (prev < 0) first_bit = 1ULL << t;
+                                par = 0;                                     // even after a tie
+                                prev = t;
+                            }
+                            const uint64_t after = AM & ~(prev >= 0 ? ((2ULL << prev) - 1) : 0ULL);
+                            // with a tie: the parity after the chunk; without: the parity of the chunk's total (prev < 0: all of AM)
+                            pout = (int)(__builtin_popcountll(after) & 1);
+                        }
+                        const uint64_t cm1 = cm0 ^ first_bit;
+                        const double g1 = 2.0 * half_g;
+                        double pmin0 = INFINITY, pmax0 = -INFINITY, pmin1 = INFINITY, pmax1 = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint64_t upto = (2ULL << (sh + i)) - 1;    // the ticks of the chunk up to this one
+                            const double P = base + pq[i];
+                            const double P0 = P + g1 * (double)__builtin_popcountll(cm0 & upto), P1 = P + g1 * (double)__builtin_popcountll(cm1 & upto);
+                            pmin0 = bf_min(pmin0, P0); pmax0 = bf_max(pmax0, P0);
+                            pmin1 = bf_min(pmin1, P1); pmax1 = bf_max(pmax1, P1);
+                        }
+                        rmin0 = fmk_half_min(pmin0); rmax0 = fmk_half_max(pmax0);
+                        rmin1 = fmk_half_min(pmin1); rmax1 = fmk_half_max(pmax1);
+                        T0 = Tf + g1 * (double)__builtin_popcountll(cm0); T1 = Tf + g1 * (double)__builtin_popcountll(cm1);
+                    }
+                    const double rmin = bf_min(rmin0, rmin1), rmax = bf_max(rmax0, rmax1);
                     const uint64_t bb = __ballot(bad);
                     const bool seg_bad = ((bb >> (lane & ~7)) & 0xFF) != 0;
                     // the inclusive prefixes stay inside the binade by a margin that covers the approximate base
@@ -844,8 +907,11 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
 #endif
                     if ((lane & 7) == 0 && c < nc) {
                         RsRec r;
-                        r.T = good ? T : -1.0; r.minP = good ? rmin : 0.0; r.maxP = good ? rmax : 0.0;
-                        r.e = good ? e : RS_NONE; r.neg = neg;
+                        r.T[0] = good ? T0 : -1.0; r.T[1] = good ? T1 : -1.0;
+                        r.minP[0] = good ? rmin0 : 0.0; r.minP[1] = good ? rmin1 : 0.0;
+                        r.maxP[0] = good ? rmax0 : 0.0; r.maxP[1] = good ? rmax1 : 0.0;
+                        r.e = good ? e : RS_NONE; r.neg = (short)neg;
+                        r.has_tie = TM != 0; r.pout = (unsigned char)pout;
                         s_rec[c] = r;
                     }
                 }
@@ -857,13 +923,22 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
             if ((int)threadIdx.x < ng) {
                 const int g0 = (int)threadIdx.x * RS_GRP;
                 RsRec g;
-                g.T = 0.0; g.minP = INFINITY; g.maxP = -INFINITY; g.e = s_rec[g0].e; g.neg = s_rec[g0].neg;
+                g.e = s_rec[g0].e; g.neg = s_rec[g0].neg; g.has_tie = 0; g.pout = 0;
+                int qv[2] = {0, 1};                                      // running parity for the two incoming parities
+#pragma unroll
+                for (int v = 0; v < 2; ++v) { g.T[v] = 0.0; g.minP[v] = INFINITY; g.maxP[v] = -INFINITY; }
                 for (int k = 0; k < RS_GRP && g0 + k < nc; ++k) {
                     const RsRec r = s_rec[g0 + k];
                     if (r.e == RS_NONE || r.e != g.e || r.neg != g.neg) { g.e = RS_NONE; break; }
-                    g.minP = fmin(g.minP, g.T + r.minP);
-                    g.maxP = fmax(g.maxP, g.T + r.maxP);
-                    g.T += r.T;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int u = qv[v];
+                        const double rmn = u ? r.minP[1] : r.minP[0], rmx = u ? r.maxP[1] : r.maxP[0], rt = u ? r.T[1] : r.T[0];
+                        g.minP[v] = fmin(g.minP[v], g.T[v] + rmn);
+                        g.maxP[v] = fmax(g.maxP[v], g.T[v] + rmx);
+                        g.T[v] += rt;
+                        qv[v] = r.has_tie ? (int)r.pout : (u ^ (int)r.pout);
+                    }
                 }
                 s_grp[threadIdx.x] = g;
             }
@@ -871,15 +946,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
             for (int c = (int)threadIdx.x; c < nc; c += 64 * RS_WAVES) {
                 if (s_rec[c].e == RS_NONE) {
                     const int slot = atomicAdd(&s_npool, 1);
-                    s_rec[c].T = slot < POOL_N ? (double)slot : -1.0;
+                    s_rec[c].T[0] = slot < POOL_N ? (double)slot : -1.0;
                 }
             }
             __syncthreads();
             // ---- A5: the pool (all waves): the terms of those chunks, in tick order
             for (int c = w; c < nc; c += RS_WAVES) {
-                if (s_rec[c].e != RS_NONE || s_rec[c].T < 0.0) continue;    // (wave-uniform)
+                if (s_rec[c].e != RS_NONE || s_rec[c].T[0] < 0.0) continue;    // (wave-uniform)
                 bool fl;
-                s_stage[(int)s_rec[c].T * 64 + lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
+                s_stage[(int)s_rec[c].T[0] * 64 + lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
             }
             __syncthreads();
             BF_T(6);
@@ -892,16 +967,21 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                     const double as = fabs(s);
                     if (!((started || !extrema) && r.e != RS_NONE && as >= 2.3e-308 && (s < 0.0) == (r.neg != 0))) return false;
                     const int e = (int)((__double_as_longlong(as) >> 52) & 0x7FF) - 1023;
+                    const int v = (int)(__double_as_longlong(as) & 1);       // parity of |s| / g when |s| is in the record's binade
                     const double lo2 = pow2(r.e), hi2 = pow2(r.e + 1);
-                    const double lo_v = as + r.minP, hi_v = as + r.maxP;     // exact when inside the binade
+                    const double lo_v = as + (v ? r.minP[1] : r.minP[0]), hi_v = as + (v ? r.maxP[1] : r.maxP[0]);     // exact inside the binade
                     if (!(e == r.e && lo_v > lo2 && hi_v < hi2)) return false;
                     mn = fmin(mn, s < 0.0 ? -hi_v : lo_v);
                     mx = fmax(mx, s < 0.0 ? -lo_v : hi_v);
-                    s = s < 0.0 ? -(as + r.T) : as + r.T;
+                    const double rt = v ? r.T[1] : r.T[0];
+                    s = s < 0.0 ? -(as + rt) : as + rt;
                     return true;
                 };
                 for (int g = 0; g < ng; ++g) {
                     if (step(s_grp[g])) continue;
+#ifdef BF_REDO_TIMING
+                    if (lane == 0) atomicAdd(&bf_redo_stats[8], 1ULL);       // groups walked chunk by chunk
+#endif
                     const int c_end = (g + 1) * RS_GRP < nc ? (g + 1) * RS_GRP : nc;
                     for (int c = g * RS_GRP; c < c_end; ++c) {
                         const RsRec r = s_rec[c];
@@ -909,23 +989,35 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                         // term by term: EVERY lane adds all 64 terms (broadcast LDS reads): one to three instructions per term, no
                         // cross-lane traffic inside the dependent chain.  The terms wait in the pool; a chunk whose record did not
                         // fit the actual s (or that found the pool full) fetches them now.
-                        const double *xs = s_x;
-                        if (r.e == RS_NONE && r.T >= 0.0) xs = s_stage + (int)r.T * 64;
+                        int slot = RS_POOL;
+                        if (r.e == RS_NONE && r.T[0] >= 0.0) slot = (int)r.T[0];
                         else {
                             bool fl;
-                            s_x[lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
+                            s_stage[RS_POOL * 64 + lane] = rs_chunk_term<AmtT>(row, start + (c0 + c) * 64, lane, start, e_bar, n, price, am, side, fl);
+#ifdef BF_REDO_TIMING
+                            if (lane == 0) atomicAdd(&bf_redo_stats[9], 1ULL);   // chunks fetched during the walk (record did not fit s / pool full)
+#endif
                         }
                         const uint64_t fm = s_flow[c];
                         __builtin_amdgcn_wave_barrier();
+                        // all 64 terms into registers first (batched ds_read_b128 of one LDS array: through a pointer that could be
+                        // either of two arrays every read was a flat load the adds waited for, 2.9 us per chunk), then the chain
+                        double xv[64];
+                        {
+                            const double *xs = s_stage + slot * 64;
+#pragma unroll
+                            for (int k = 0; k < 64; ++k) xv[k] = xs[k];
+                        }
                         if (!extrema) {
-#pragma unroll 16
-                            for (int k = 0; k < 64; ++k) s += xs[k];
+#pragma unroll
+                            for (int k = 0; k < 64; ++k) s += xv[k];
                         } else if (started) {
-#pragma unroll 16
-                            for (int k = 0; k < 64; ++k) { s += xs[k]; mn = bf_min(mn, s); mx = bf_max(mx, s); }
+#pragma unroll
+                            for (int k = 0; k < 64; ++k) { s += xv[k]; mn = bf_min(mn, s); mx = bf_max(mx, s); }
                         } else {
+#pragma unroll
                             for (int k = 0; k < 64; ++k) {
-                                s += xs[k];
+                                s += xv[k];
                                 started = started || ((fm >> k) & 1);
                                 if (started) { mn = fmin(mn, s); mx = fmax(mx, s); }
                             }

@@ -197,3 +197,12 @@ __device__ __forceinline__ double fmk_half_iscan_add(double v, int lane)
     t = fmk_dpp<FMK_DPP_ROW_SHR(4), 0xF>(0.0, v); v += k >= 4 ? t : 0.0;
     return v;
 }
+
+// bitwise OR over the eight lanes of a half row (result in every lane of it)
+__device__ __forceinline__ uint64_t fmk_half_or(uint64_t v)
+{
+    v |= (uint64_t)fmk_dpp<DPP_XOR1, 0xF>((int64_t)v, (int64_t)v);
+    v |= (uint64_t)fmk_dpp<DPP_XOR2, 0xF>((int64_t)v, (int64_t)v);
+    v |= (uint64_t)fmk_dpp<DPP_HALF_MIRROR, 0xF>((int64_t)v, (int64_t)v);
+    return v;
+}

@@ -144,7 +144,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         o.sell_ticks[base + l] = sc;
         const float t = bv + sv;                                     // base.py:822
         tot[l] = t;
-        if (t > best) { best = t; best_i = l; }                      // first argmax within my lanes
+        // first argmax within my lanes; np.argmax treats a NaN as the maximum: the FIRST NaN wins and is never replaced
+        if (t > best || (t != t && best == best)) { best = t; best_i = l; }
         num += (double)(low + l) * (double)t;
     }
     // first argmax across lanes (ties -> lowest index)
@@ -152,9 +153,11 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     for (int x = 32; x > 0; x >>= 1) {
         float ob = __shfl_xor(best, x, 64);
         int oi = __shfl_xor(best_i, x, 64);
-        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+        const bool on = ob != ob, bn = best != best;
+        const bool take = on ? (!bn || oi < best_i) : (!bn && (ob > best || (ob == best && oi < best_i)));
+        if (take) { best = ob; best_i = oi; }
     }
-    if (best_i == 0x7FFFFFFF) best_i = 0;      // all-NaN / empty guard: np.argmax -> 0
+    if (best_i == 0x7FFFFFFF) best_i = 0;      // empty guard: np.argmax -> 0
     num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
     const float total = fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()

@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(64 * FL_WAVES) void k_bar_footprints_lanes(const do
                 o.buy_ticks[base + l] = hc[2 * l];
                 o.sell_ticks[base + l] = hc[2 * l + 1];
                 tot[l] = bv[l] + sv[l];                                    // base.py:822
-                if (tot[l] > best) { best = tot[l]; best_i = l; }          // np.argmax: the first maximum
+                if (tot[l] > best || (tot[l] != tot[l] && best == best)) { best = tot[l]; best_i = l; }   // np.argmax: the first maximum, a NaN being one
                 num += (double)(ilow + l) * (double)tot[l];
             }
         }

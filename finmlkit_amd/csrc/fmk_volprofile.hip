@@ -161,15 +161,17 @@ __global__ __launch_bounds__(256) void k_volume_profile(const int64_t *__restric
         int best_i = 0x7FFFFFFF;
         for (int k = lane; k < np_; k += 64) {
             const float v = vol[k];
-            if (v > best) { best = v; best_i = k; }
+            if (v > best || (v != v && best == best)) { best = v; best_i = k; }       // (np.argmax: the first NaN is the maximum)
         }
 #pragma unroll
         for (int x = 32; x > 0; x >>= 1) {
             const float ob = __shfl_xor(best, x, 64);
             const int oi = __shfl_xor(best_i, x, 64);
-            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+            const bool on = ob != ob, bn = best != best;
+            const bool take = on ? (!bn || oi < best_i) : (!bn && (ob > best || (ob == best && oi < best_i)));
+            if (take) { best = ob; best_i = oi; }
         }
-        if (best_i == 0x7FFFFFFF) best_i = 0;                     // all-NaN guard: np.argmax -> 0
+        if (best_i == 0x7FFFFFFF) best_i = 0;                     // empty guard: np.argmax -> 0
         if (lane == 0) {
             const int n = np_;
             auto pl = [&](int k) -> int32_t {

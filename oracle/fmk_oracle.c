@@ -621,8 +621,8 @@ static void orc_footprint_features(const int32_t *levels, const float *buy, cons
     *max_run_signed = max_run * max_sign;
     for (int64_t k = 0; k < L; ++k) tmpf[k] = buy[k] + sell[k];     /* base.py:822 */
     float total = orc_pairwise_f32(tmpf, L);
-    int64_t arg = 0;                                                /* first argmax */
-    for (int64_t k = 1; k < L; ++k) if (tmpf[k] > tmpf[arg]) arg = k;
+    int64_t arg = 0;                                                /* np.argmax: first maximum; the first NaN counts as one */
+    for (int64_t k = 1; k < L; ++k) if (tmpf[k] > tmpf[arg] || (tmpf[k] != tmpf[k] && tmpf[arg] == tmpf[arg])) arg = k;
     *cot = levels[arg];
     *skew = 0.0; *gini = 0.0;
     if (total > 0 && L > 0) {                                       /* base.py:836-848 */
@@ -997,7 +997,7 @@ static void orc_poc_hva_lva(const int32_t *pl, const float *vol, int64_t n, doub
 {
     float total = orc_pairwise_f32(vol, n);                       /* np.sum(float32 array) */
     int64_t pi = 0;
-    for (int64_t k = 1; k < n; ++k) if (vol[k] > vol[pi]) pi = k; /* first argmax */
+    for (int64_t k = 1; k < n; ++k) if (vol[k] > vol[pi] || (vol[k] != vol[k] && vol[pi] == vol[pi])) pi = k; /* np.argmax (first NaN = max) */
     int32_t poc_price = pl[pi];
     double va_thrs = (double)total * (va_pct / 100.0);
     double cum = vol[pi];

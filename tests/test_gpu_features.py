@@ -296,3 +296,27 @@ def test_footprints_long_bars_workgroup_per_bar(orc, amounts):
             off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, fine, o[2], o[1], 3.0)
             _check_fp(off, flat, bar, woff, wflat, wbar, f"{amounts}, tick {fine}: widest bar {np.diff(woff).max()} levels")
         assert np.diff(woff).max() > 6144
+
+
+@pytest.mark.parametrize("long_bars", [False, True])
+def test_cot_with_nan_level_sums(orc, long_bars):
+    """np.argmax takes the FIRST NaN as the maximum (base.py:829): a NaN size on a middle level moves the centre of trades there --
+    wave-per-bar and workgroup-per-bar kernels, and the lane-per-bar kernel on short bars."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    rng = np.random.default_rng(3)
+    n = 60_000 if long_bars else 6000
+    px = 100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, n))
+    sd = rng.choice(np.array([-1, 1], np.int8), n)
+    am = rng.lognormal(-1, 1, n).astype(np.float32)
+    am[[n // 3, n // 2 + 5]] = np.nan
+    if long_bars:
+        ci = np.array([-1, 20_000, 45_000, n - 1], np.int64)
+    else:
+        ci = np.concatenate([[-1], np.arange(19, n, 20)]).astype(np.int64)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, f"nan levels, long={long_bars}")
+    b = int(np.searchsorted(ci, n // 3, side="left")) - 1
+    tv = wflat["buy_volumes"][woff[b]:woff[b + 1]] + wflat["sell_volumes"][woff[b]:woff[b + 1]]
+    assert np.isnan(tv).any() and wbar["cot_price_levels"][b] == wflat["price_levels"][woff[b]:woff[b + 1]][np.argmax(tv)]

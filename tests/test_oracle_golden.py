@@ -315,3 +315,23 @@ def test_pct_above_poc_nan_total(orc):
     pl = np.array([1, 2, 3, 4], np.int32)
     assert np.isnan(orc.calc_volume_percentage_above_poc(pl, np.array([1.0, np.nan, 2.0, 1.0], np.float32), 2))
     assert orc.calc_volume_percentage_above_poc(pl, np.zeros(4, np.float32), 2) == 0.0
+
+
+def test_cot_is_numpy_argmax_with_nan_levels(orc):
+    """base.py:829 `np.argmax(total_volumes)`: NumPy treats a NaN as the maximum and returns the FIRST one (a NaN size makes its
+    level's sum NaN).  The oracle's loop is checked against np.argmax itself on its own level sums: NaN on the lowest level, on a
+    middle one, on two levels, and none."""
+    rng = np.random.default_rng(3)
+    n = 4000
+    px = 100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, n))
+    sd = rng.choice(np.array([-1, 1], np.int8), n)
+    ci = np.array([-1, 1999, n - 1], np.int64)
+    for nan_at in ([], [17], [17, 2500], [0]):
+        am = rng.lognormal(-1, 1, n).astype(np.float32)
+        am[nan_at] = np.nan
+        o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+        off, flat, bar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+        for b in range(2):
+            lv = flat["price_levels"][off[b]:off[b + 1]]
+            tv = flat["buy_volumes"][off[b]:off[b + 1]] + flat["sell_volumes"][off[b]:off[b + 1]]
+            assert bar["cot_price_levels"][b] == lv[np.argmax(tv)], (nan_at, b)
