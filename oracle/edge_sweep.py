@@ -115,6 +115,19 @@ def cases():
                             "buy only": ([1, 2, 3], [1, 5, 1], [0, 0, 0]), "ties for the POC": ([1, 2, 3], [2, 2, 2], [1, 1, 1]),
                             "no levels": ([], [], [])}.items():
         add("comp_footprint_features", np.array(lv, np.int32), np.array(b, np.float32), np.array(s, np.float32), 1.5, label=lab)
+    # NaN sizes (round 3: tools/fuzz_longbars.py met one): a level's sum becomes NaN and np.argmax takes the FIRST NaN as the maximum
+    # (base.py:829, volume.py:296) -- on the lowest level, a middle one, two levels; np.median / np.percentile of the bar are NaN
+    amn = am6.copy(); amn[1] = NAN
+    add("comp_bar_footprints", px6, amn, i64(-1, 2, 5), sd6, 0.5, lo, hi, 1.5, label="NaN size, first bar")
+    amn2 = am6.copy(); amn2[4] = NAN
+    add("comp_bar_footprints", px6, amn2, i64(-1, 5), sd6, 0.5, f64(99.5), f64(101.0), 1.5, label="NaN size on a middle level")
+    add("comp_footprint_features", np.array([1, 2, 3, 4], np.int32), np.array([1, NAN, 5, NAN], np.float32),
+        np.array([1, 1, 1, 1], np.float32), 1.5, label="two NaN levels")
+    add("comp_footprint_features", np.array([1, 2, 3], np.int32), np.array([NAN, 9, 1], np.float32), np.array([1, 1, 1], np.float32), 1.5,
+        label="NaN on the lowest level")
+    add("comp_bar_ohlcv", px6, amn, i64(-1, 2, 5), label="NaN size")
+    add("comp_bar_directional_features", px6, amn, i64(-1, 2, 5), sd6, label="NaN size")
+    add("comp_bar_trade_size_features", amn, f64(2.0, 2.0), i64(-1, 2, 5), 1.5, label="NaN size")
     # ---- preprocessing (bar/utils.py)
     add("comp_trade_side_vector", f64(), label="no ticks")
     add("comp_trade_side_vector", f64(100.0), label="one tick")
