@@ -1000,26 +1000,27 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                         }
                         const uint64_t fm = s_flow[c];
                         __builtin_amdgcn_wave_barrier();
-                        // all 64 terms into registers first (batched ds_read_b128 of one LDS array: through a pointer that could be
-                        // either of two arrays every read was a flat load the adds waited for, 2.9 us per chunk), then the chain
-                        double xv[64];
-                        {
-                            const double *xs = s_stage + slot * 64;
+                        // the terms into registers in batches (ds_read_b128 of ONE LDS array: through a pointer that could be either of
+                        // two arrays every read was a flat load the adds waited for), then the chain
+                        const double *xs = s_stage + slot * 64;
+#pragma unroll 1
+                        for (int h = 0; h < 64; h += 16) {                   // sixteen terms at a time: 32 VGPRs (all 64: spills)
+                            double xv[16];
 #pragma unroll
-                            for (int k = 0; k < 64; ++k) xv[k] = xs[k];
-                        }
-                        if (!extrema) {
+                            for (int k = 0; k < 16; ++k) xv[k] = xs[h + k];
+                            if (!extrema) {
 #pragma unroll
-                            for (int k = 0; k < 64; ++k) s += xv[k];
-                        } else if (started) {
+                                for (int k = 0; k < 16; ++k) s += xv[k];
+                            } else if (started) {
 #pragma unroll
-                            for (int k = 0; k < 64; ++k) { s += xv[k]; mn = bf_min(mn, s); mx = bf_max(mx, s); }
-                        } else {
+                                for (int k = 0; k < 16; ++k) { s += xv[k]; mn = bf_min(mn, s); mx = bf_max(mx, s); }
+                            } else {
 #pragma unroll
-                            for (int k = 0; k < 64; ++k) {
-                                s += xv[k];
-                                started = started || ((fm >> k) & 1);
-                                if (started) { mn = fmin(mn, s); mx = fmax(mx, s); }
+                                for (int k = 0; k < 16; ++k) {
+                                    s += xv[k];
+                                    started = started || ((fm >> (h + k)) & 1);
+                                    if (started) { mn = fmin(mn, s); mx = fmax(mx, s); }
+                                }
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
