@@ -580,9 +580,10 @@ __global__ __launch_bounds__(256) void k_bar_dir_redo(const double *__restrict__
 // ---------------------------------------------------------------------------------------
 #define RS_CH 512
 #define RS_WAVES 8                    // 512 threads: 256 VGPRs per lane (two raw tiles, the terms and their prefixes live at once)
-#define RS_POOL 200                   // chunks whose terms wait in LDS for the term-by-term walk
+#define RS_POOL 186                   // chunks whose terms wait in LDS for the term-by-term walk
 #define RS_UNROLL 4
 #define RS_GRP 16                     // chunks per group record
+#define RS_SUB 4                      // chunks per sub-group record (what a group that does not fit the actual sum falls back to)
 #define RS_NONE ((int)0x80000000)
 // TIES.  A term that lies exactly half way between two grid points rounds to even, i.e. by the PARITY of the running sum's last
 // bit -- and ties are not rare: 4 % of the prices on a 0.01 grid are multiples of 0.25, their product with a 24-bit size is exact,
@@ -597,6 +598,35 @@ struct RsRec {
     short neg;                        // sign of s it was computed for
     unsigned char has_tie, pout;
 };
+
+// `count` consecutive records folded into one (chunks into a sub-group, sub-groups into a group): totals add, the extrema are
+// (total of the records before) + the record's own, each for the two incoming parities; a record without a usable part, or parts
+// of different binades / signs, gives RS_NONE.  The parity map of the fold is again "absolute" or "xor": the two incoming parities
+// end up equal exactly when some part on the way made them so.
+__device__ __forceinline__ RsRec rs_compose(const RsRec *r0, int count)
+{
+    RsRec g;
+    g.e = r0[0].e; g.neg = r0[0].neg; g.has_tie = 0; g.pout = 0;
+    int qv[2] = {0, 1};
+#pragma unroll
+    for (int v = 0; v < 2; ++v) { g.T[v] = 0.0; g.minP[v] = INFINITY; g.maxP[v] = -INFINITY; }
+    for (int k = 0; k < count; ++k) {
+        const RsRec r = r0[k];
+        if (r.e == RS_NONE || r.e != g.e || r.neg != g.neg) { g.e = RS_NONE; break; }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int u = qv[v];
+            const double rmn = u ? r.minP[1] : r.minP[0], rmx = u ? r.maxP[1] : r.maxP[0], rt = u ? r.T[1] : r.T[0];
+            g.minP[v] = fmin(g.minP[v], g.T[v] + rmn);
+            g.maxP[v] = fmax(g.maxP[v], g.T[v] + rmx);
+            g.T[v] += rt;
+            qv[v] = r.has_tie ? (int)r.pout : (u ^ (int)r.pout);
+        }
+    }
+    g.has_tie = qv[0] == qv[1];
+    g.pout = (unsigned char)qv[0];
+    return g;
+}
 
 // the row's terms of one chunk (64 ticks from j0, lane = tick; 0.0 where the reference skips the update) with unconditional loads
 // (clamped into the bar): the compiler batches them.  `flow`: the tick is a signed one.
@@ -647,6 +677,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
     const AmtT *am = (const AmtT *)amount;
     __shared__ RsRec s_rec[RS_CH];
     __shared__ RsRec s_grp[RS_CH / RS_GRP];
+    __shared__ RsRec s_sub[RS_CH / RS_SUB];
     __shared__ double s_tot[RS_CH], s_abs[RS_CH], s_cabs[RS_CH];
     // per-wave tiles while the records are made; afterwards the POOL: the terms of the chunks that will be added term by term
     __shared__ double s_stage[(RS_POOL + 1) * 64];                       // (+ one slot for a chunk fetched during the walk)
@@ -919,28 +950,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
             __syncthreads();
             BF_T(5);
             // ---- A4: group records (a thread per group of RS_GRP chunks); a pool slot for every chunk without a record (T = slot, or -1)
-            const int ng = (nc + RS_GRP - 1) / RS_GRP;
+            const int ng = (nc + RS_GRP - 1) / RS_GRP, nsb = (nc + RS_SUB - 1) / RS_SUB;
+            if ((int)threadIdx.x < nsb) {
+                const int c0s = (int)threadIdx.x * RS_SUB;
+                s_sub[threadIdx.x] = rs_compose(s_rec + c0s, nc - c0s < RS_SUB ? nc - c0s : RS_SUB);
+            }
+            __syncthreads();
             if ((int)threadIdx.x < ng) {
-                const int g0 = (int)threadIdx.x * RS_GRP;
-                RsRec g;
-                g.e = s_rec[g0].e; g.neg = s_rec[g0].neg; g.has_tie = 0; g.pout = 0;
-                int qv[2] = {0, 1};                                      // running parity for the two incoming parities
-#pragma unroll
-                for (int v = 0; v < 2; ++v) { g.T[v] = 0.0; g.minP[v] = INFINITY; g.maxP[v] = -INFINITY; }
-                for (int k = 0; k < RS_GRP && g0 + k < nc; ++k) {
-                    const RsRec r = s_rec[g0 + k];
-                    if (r.e == RS_NONE || r.e != g.e || r.neg != g.neg) { g.e = RS_NONE; break; }
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int u = qv[v];
-                        const double rmn = u ? r.minP[1] : r.minP[0], rmx = u ? r.maxP[1] : r.maxP[0], rt = u ? r.T[1] : r.T[0];
-                        g.minP[v] = fmin(g.minP[v], g.T[v] + rmn);
-                        g.maxP[v] = fmax(g.maxP[v], g.T[v] + rmx);
-                        g.T[v] += rt;
-                        qv[v] = r.has_tie ? (int)r.pout : (u ^ (int)r.pout);
-                    }
-                }
-                s_grp[threadIdx.x] = g;
+                const int b0 = (int)threadIdx.x * (RS_GRP / RS_SUB);
+                s_grp[threadIdx.x] = rs_compose(s_sub + b0, nsb - b0 < RS_GRP / RS_SUB ? nsb - b0 : RS_GRP / RS_SUB);
             }
             __syncthreads();
             for (int c = (int)threadIdx.x; c < nc; c += 64 * RS_WAVES) {
@@ -980,10 +998,12 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
                 for (int g = 0; g < ng; ++g) {
                     if (step(s_grp[g])) continue;
 #ifdef BF_REDO_TIMING
-                    if (lane == 0) atomicAdd(&bf_redo_stats[8], 1ULL);       // groups walked chunk by chunk
+                    if (lane == 0) atomicAdd(&bf_redo_stats[8], 1ULL);       // groups walked part by part
 #endif
                     const int c_end = (g + 1) * RS_GRP < nc ? (g + 1) * RS_GRP : nc;
                     for (int c = g * RS_GRP; c < c_end; ++c) {
+                        // at a sub-group's first chunk: the four chunks in one step when they fit
+                        if ((c & (RS_SUB - 1)) == 0 && step(s_sub[c / RS_SUB])) { c += RS_SUB - 1; continue; }
                         const RsRec r = s_rec[c];
                         if (step(r)) continue;
                         // term by term: EVERY lane adds all 64 terms (broadcast LDS reads): one to three instructions per term, no
