@@ -1375,10 +1375,17 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                         fo ? atoi(fo) : 0, lean, wl_max, wide_sorted, wide_defer, nseg);
                 const hipError_t le = hipGetLastError();
                 (void)fmk_free(ctx, wl);
-                if (le != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, le); }
+                wl = nullptr;
+                if (le != hipSuccess) {
+                    if (rest) (void)fmk_free(ctx, rest);
+                    if (wide_sorted) (void)fmk_free(ctx, wide_sorted);
+                    if (wide_defer) (void)fmk_free(ctx, wide_defer);
+                    FMK_HIP(ctx, le);
+                }
                 skip_above = FPW_MIN;
                 skip_lmax = wl_max;
             }
+            if (wl) (void)fmk_free(ctx, wl);                       // (an allocation above failed: rc says so)
         }
     }
     for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
