@@ -110,15 +110,19 @@ __global__ __launch_bounds__(THREADS) void k_ts_p95_long(const float *__restrict
     }
 }
 
-template <bool AF64>
-__global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__ amount,
+// SMALL: the instantiation for bars of at most 20 x 64 ticks only (float32): without the 32-key class the kernel needs fewer registers
+// and a fourth wave fits the SIMD; the full instantiation then serves the longer bars (`cnt_lo`: it skips the others).
+template <bool AF64, bool SMALL = false>
+__global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const void *__restrict__ amount,
                                                         const double *__restrict__ theta,
                                                         const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                         double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
                                                         float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done,
                                                         const unsigned long long *__restrict__ only = nullptr,
-                                                        int64_t skip_above = INT64_MAX /* longer regular bars: k_bar_trade_size_wide */)
+                                                        int64_t skip_above = INT64_MAX /* longer regular bars: k_bar_trade_size_wide */,
+                                                        int64_t cnt_lo = -1 /* bars of at most this many ticks: another launch's */)
 {
+    static_assert(!(SMALL && AF64), "the small-bar instantiation serves float32 amounts");
     typedef typename MedKey<AF64>::K K;
     __shared__ K sbuf[4][64];
     __shared__ __attribute__((aligned(8))) int s_stk[4][FMK_PW_PAR_STK];      // scratch of the pairwise sums
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
         // Python slice bounds: a negative start / stop wraps by n once and is then clamped to [0, n] -- a close index below -1
         // must not become a read in front of the column (it selects the reference's wrapped, usually empty, slice)
         if (!AF64 && e_raw - s > skip_above && e_raw - s <= FMK_PW_BIG_MAX_N && s >= -1 && e_raw <= n - 1) continue;
+        if (SMALL ? e_raw - s > 64 * 20 : e_raw - s <= cnt_lo) continue;
         int64_t start = s + 1, stop = e_raw + 1;
         start = start < 0 ? (start + n > 0 ? start + n : 0) : (start < n ? start : n);
         stop = stop < 0 ? (stop + n > 0 ? stop + n : 0) : (stop < n ? stop : n);
@@ -201,13 +206,14 @@ __global__ __launch_bounds__(256) void k_bar_trade_size(const void *__restrict__
             const int nreg = (int)((cnt + 63) >> 6);
             double p95;
             double *bo = (!AF64 && np_rule) ? &block : nullptr;
-            if (cnt > 64 * 32) {
+            if (!SMALL && cnt > 64 * 32) {
                 if (!AF64 && p95_done && s >= -1 && e_raw <= n - 1) p95 = (double)o_p95[b];      // k_ts_p95_long
                 else p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
             }
             else if (nreg <= 4) p95 = ts_percentile95<AF64, 4>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 12) p95 = ts_percentile95<AF64, 12>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 20) p95 = ts_percentile95<AF64, 20>(amount, start, cnt, lane, buf, thr, bo);
+            else if constexpr (SMALL) p95 = NAN;                         // (not reached: longer bars are skipped above)
             else if constexpr (!AF64) p95 = ts_percentile95<AF64, 32>(amount, start, cnt, lane, buf, thr, bo);
             else if (nreg <= 24) p95 = ts_percentile95<AF64, 24>(amount, start, cnt, lane, buf);
             else p95 = ts_percentile95<AF64, 0>(amount, start, cnt, lane, buf);
@@ -1013,10 +1019,14 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
                 (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
                 d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N);
         }
+        // the bars of at most 1 280 ticks by the instantiation without the 32-key class, the others by the full one
+        k_bar_trade_size<false, true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
+                                                                                 theta_mult, d_mean_size_rel, d_size_95_rel,
+                                                                                 d_pct_block, d_size_gini, 1, nullptr, INT64_MAX);
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
                                                                            d_pct_block, d_size_gini, 1, nullptr,
-                                                                           wide_on ? wide_min : INT64_MAX);
+                                                                           wide_on ? wide_min : INT64_MAX, (int64_t)64 * 20);
         }
         if (samp) (void)fmk_free(ctx, samp);
         if (cand) (void)fmk_free(ctx, cand);
