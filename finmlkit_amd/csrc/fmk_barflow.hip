@@ -441,7 +441,7 @@ struct FlowSeg {                     // one wave's segment, wave-uniform values
 };
 
 template <bool AF64>
-__global__ __launch_bounds__(64 * BFW_WAVES) void k_bar_dir_wide(const double *__restrict__ price, const void *__restrict__ amount,
+__global__ __launch_bounds__(64 * BFW_WAVES, 4) void k_bar_dir_wide(const double *__restrict__ price, const void *__restrict__ amount,
                                                                const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                                const int64_t *__restrict__ list, int64_t n, FlowDirOut o,
                                                                unsigned long long *n_zero_div, unsigned long long *redo)
