@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
                                                         float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done,
                                                         const unsigned long long *__restrict__ only = nullptr,
                                                         int64_t skip_above = INT64_MAX /* longer regular bars: k_bar_trade_size_wide */,
-                                                        int64_t cnt_lo = -1 /* bars of at most this many ticks: another launch's */)
+                                                        int64_t cnt_lo = INT64_MIN /* bars of at most this many ticks: another launch's */)
 {
     static_assert(!(SMALL && AF64), "the small-bar instantiation serves float32 amounts");
     typedef typename MedKey<AF64>::K K;
