@@ -219,3 +219,27 @@ def test_packed_short_bars(orc, seed, mean_len, with_nan):
                 np.testing.assert_allclose(got[k], w, rtol=1e-9, equal_nan=True, err_msg=k)
             else:
                 np.testing.assert_array_equal(got[k], w, err_msg=f"{k} (median={med})")
+
+
+@pytest.mark.parametrize("interval", [60.0, 1800.0])
+def test_ohlcv_enqueue_only_mode_gives_the_same_bars(orc, interval):
+    """fmk_ctx_set_enqueue_only(1): comp_bar_ohlcv issues the launches of its long-bar schedules without first reading back whether
+    any bar was left for them (the sharded step needs a call that never waits).  Same outputs with and without long bars."""
+    from finmlkit_amd import engine
+    n = 400_000
+    t = engine.DeviceTrades.synth(n, seed=11)
+    ts, px, am, sd = t.to_numpy()
+    clock, ci = t.time_bar_index(interval)
+    want = orc.comp_bar_ohlcv(px, am, ci.to_host())
+    keys = ["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"]
+    for mode in (False, True):
+        t.ctx.set_enqueue_only(mode)
+        try:
+            got = engine.to_host(t.bar_ohlcv(ci))
+        finally:
+            t.ctx.set_enqueue_only(False)
+        for k, w in zip(keys, want):
+            if k == "vwap":
+                np.testing.assert_allclose(got[k], w, rtol=1e-9, err_msg=f"{k} enqueue_only={mode}")
+            else:
+                np.testing.assert_array_equal(got[k], w, err_msg=f"{k} enqueue_only={mode}")
