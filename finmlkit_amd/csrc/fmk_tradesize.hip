@@ -248,6 +248,374 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Bars of 129 .. 1 920 ticks (1-minute bars of a liquid tape), float32 amounts, regular close indices: one wave per bar that reads
+// the bar ONCE (round 3).  k_bar_trade_size walks the bar three times (np.sum's tree, the order-statistic search, the tree of the
+// squared shares), builds the tree's shape twice through LDS and divides by the total with the IEEE macro: ~4 000 wave instructions
+// per 1 200-tick bar, 5.1 ms per 1e9 ticks.  Here
+//   * np.sum's tree over n <= 1 928 elements has at most four levels of splits, so a leaf is the end of a 4-bit PATH from the root
+//     (tsm_leaf: the split rule n2 = n / 2 rounded down to a multiple of 8 applied along the path, no LDS); groups of eight lanes
+//     take a leaf each -- lane i of a group is NumPy's accumulator r_i -- in two rounds of eight leaves, and the bar's sizes STAY
+//     in those registers (x[round][k]: element 8k + i of the leaf; t[round]: the leaf's tail element i, one per lane);
+//   * both trees (the float32 total, then sum((a / total)^2)) fold inside the row by DPP shifts -- ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+//     the tail added element by element from the neighbours' registers -- and the sixteen leaf values are combined up the four levels
+//     by sixteen lanes of one row, left + right where the node had split: every addition has the recursion's operands and order;
+//   * a / total is formed as float(double(a) * (1 / double(total))): the product is within 2^-52 of the quotient, a quotient of two
+//     float32 is at least 2^-49 (relative) away from every rounding boundary of float32, so the result is the correctly rounded
+//     float32 quotient whenever it is a normal number; a bar with a subnormal quotient (v_cmp_class) repeats with the division;
+//   * np.percentile's two ranks are searched on the same registers in the FLOAT domain (count of x <= pivot by ballots, the pivot
+//     bisecting the order-preserving integer image of the value range); once at most 64 candidates are left they are compacted into
+//     one register through LDS and the bisection goes on there until it separates the two ranks (no cross-lane sort);
+//   * a NaN size makes the total NaN (the slots that hold no element are NaN too and are never added), so NaN bars are found there.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TSM_MIN 128
+#define TSM_MAX 1920                   // (np.sum's tree needs a fifth level from 1 929 elements)
+#define FMK_DPP_ROW_SHL(n) (0x100 + (n))
+
+template <int CTRL>
+__device__ __forceinline__ float tsm_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// order-preserving signed image of a float's bits (-0 < +0; every non-NaN value in [tsm_key(-inf), tsm_key(+inf)]) and back
+// (an opaque copy: keeps the compiler from carrying the dozens of lane masks derived from a leaf's length across the whole bar)
+__device__ __forceinline__ int tsm_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float tsm_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int tsm_key(float x) { const int b = __float_as_int(x); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float tsm_val(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+// The node of np.sum's tree over n elements at the end of the 4-bit path `path` (most significant bit first: 0 = left half):
+// [off, off + len).  alive: the path ends in a leaf of its own (a leaf reached before the path is used up belongs to the path whose
+// remaining bits are zero; len = 0 otherwise).  sp bit l: the node at level l of the path had split.
+__device__ __forceinline__ void tsm_leaf(int n, int path, int &off, int &len, unsigned &sp)
+{
+    off = 0; len = n; sp = 0;
+    bool alive = true;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const bool bit = (path >> (3 - l)) & 1;
+        const bool split = len > 128;
+        const int n2 = (len >> 1) & ~7;
+        sp |= split ? 1u << l : 0u;
+        alive = alive && (split || !bit);
+        off += split && bit ? n2 : 0;
+        len = split ? (bit ? len - n2 : n2) : len;
+    }
+    len = alive ? len : 0;
+}
+
+// One of the bar's two trees: f maps a size to the summand.  Round R holds the leaves of the paths 2 * group + R (one round: a tree
+// without a split at level 3).  The slots without an element hold +0.0 and are added like elements: x + 0 is x unless x is -0, and a
+// partial sum is -0 only if every element so far was -0 -- so only a total of zero can differ (in its sign), and the caller repeats
+// such a bar with PRED (the slots skipped, as the recursion does).
+template <int KMAX, int ROUNDS, bool PRED, class F>
+__device__ __forceinline__ float tsm_tree(const float (&x)[ROUNDS][KMAX], const float (&t)[ROUNDS], const int (&len)[ROUNDS],
+                                          unsigned sp_slot, F f, int lane, float *slots)
+{
+    const int i8 = lane & 7, grp = lane >> 3;
+#pragma unroll
+    for (int R = 0; R < ROUNDS; ++R) {
+        const int lenR = PRED ? tsm_opaque(len[R]) : 0;
+        const int nm = lenR & ~7;
+        float r = f(x[R][0]);
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
+            const float y = f(x[R][k]);
+            if constexpr (PRED) r = 8 * k < nm ? r + y : r;
+            else r += y;
+        }
+        const float a = r + tsm_dpp<FMK_DPP_ROW_SHL(1)>(r);            // lanes 0, 2, 4, 6 of the group: r0+r1, r2+r3, r4+r5, r6+r7
+        const float u = a + tsm_dpp<FMK_DPP_ROW_SHL(2)>(a);            // lanes 0, 4
+        float res = u + tsm_dpp<FMK_DPP_ROW_SHL(4)>(u);                // lane 0
+        const float ty = f(t[R]);
+        if constexpr (PRED) {
+            res = nm + 0 < lenR ? res + ty : res;
+            res = nm + 1 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(1)>(ty) : res;
+            res = nm + 2 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(2)>(ty) : res;
+            res = nm + 3 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(3)>(ty) : res;
+            res = nm + 4 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(4)>(ty) : res;
+            res = nm + 5 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(5)>(ty) : res;
+            res = nm + 6 < lenR ? res + tsm_dpp<FMK_DPP_ROW_SHL(6)>(ty) : res;
+        } else {
+            res += ty;
+            res += tsm_dpp<FMK_DPP_ROW_SHL(1)>(ty);
+            res += tsm_dpp<FMK_DPP_ROW_SHL(2)>(ty);
+            res += tsm_dpp<FMK_DPP_ROW_SHL(3)>(ty);
+            res += tsm_dpp<FMK_DPP_ROW_SHL(4)>(ty);
+            res += tsm_dpp<FMK_DPP_ROW_SHL(5)>(ty);
+            res += tsm_dpp<FMK_DPP_ROW_SHL(6)>(ty);
+        }
+        if (i8 == 0) slots[2 * grp + R] = res;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float v = slots[lane & 15];
+    __builtin_amdgcn_wave_barrier();
+    // up the levels: slot g is the leftmost slot of its node at level l iff its low 4 - l bits are zero; the right child starts 2^(3-l) slots on
+    float w;
+    if constexpr (ROUNDS == 2) { w = v + tsm_dpp<FMK_DPP_ROW_SHL(1)>(v); v = ((sp_slot >> 3) & 1) && (lane & 1) == 0 ? w : v; }
+    w = v + tsm_dpp<FMK_DPP_ROW_SHL(2)>(v); v = ((sp_slot >> 2) & 1) && (lane & 3) == 0 ? w : v;
+    w = v + tsm_dpp<FMK_DPP_ROW_SHL(4)>(v); v = ((sp_slot >> 1) & 1) && (lane & 7) == 0 ? w : v;
+    w = v + tsm_dpp<FMK_DPP_ROW_SHL(8)>(v); v = (sp_slot & 1) && (lane & 15) == 0 ? w : v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+
+// one bar -> the arguments of the two log1p columns (evaluated for 32 bars at a time by the caller), pct_block, size_gini
+template <int KMAX, int ROUNDS>
+__device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, const int (&off2)[2], const int (&len2)[2], unsigned sp_slot,
+                                        double th, double theta_mult, int lane, float *slots, float *cbuf, double &mean_arg,
+                                        double &p95_arg, float &pct, float &gini)
+{
+    const int i8 = lane & 7;
+    float x[ROUNDS][KMAX], t[ROUNDS];
+    int len[ROUNDS];
+    // ---- the bar's sizes: element 8k + i of the lane's leaf, and the leaf's tail element i; +0.0 where there is none
+#pragma unroll
+    for (int R = 0; R < ROUNDS; ++R) {
+        len[R] = len2[R];
+        const int nm = len[R] & ~7;
+        const float *p = a + off2[R] + i8;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) x[R][k] = 8 * k < nm ? p[8 * k] : 0.f;
+        t[R] = (i8 < 7 && nm + i8 < len[R]) ? p[nm] : 0.f;
+    }
+    constexpr int npad_all = 64 * ROUNDS * (KMAX + 1);
+    const int npad = npad_all - cnt;
+    const double thr = th * theta_mult;
+    // ---- np.sum / np.mean of the float32 slice
+    float tf = tsm_tree<KMAX, ROUNDS, false>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots);
+    if (tf == 0.f) tf = tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots);   // (the sign of a zero total)
+    const double mean = (double)(tf / (float)cnt), sum = (double)tf;
+    mean_arg = mean / thr;
+    // ---- smallest and largest size (the empty slots count as sizes of 0 here: a wider bracket is still a bracket)
+    float mnl = x[0][0], mxl = x[0][0];
+#pragma unroll
+    for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { mnl = __builtin_fminf(mnl, x[R][k]); mxl = __builtin_fmaxf(mxl, x[R][k]); }
+        mnl = __builtin_fminf(mnl, t[R]); mxl = __builtin_fmaxf(mxl, t[R]);
+    }
+    const int kmn = fmk_dpp_reduce(tsm_key(mnl), 0x7FFFFFFF, FmkOpMin());
+    const int kmx = fmk_dpp_reduce(tsm_key(mxl), (int)0x80000000, FmkOpMax());
+    // ---- block volume: (double)a > thr  <=>  a > the largest float32 not above thr
+    float thr_f = (float)thr;
+    if ((double)thr_f > thr) thr_f = tsm_val(tsm_key(thr_f) - 1);
+    double block = 0.0;
+    if (tsm_val(kmx) > thr_f || tf != tf) {                           // (the largest size of a bar with a NaN may be one)
+        double bl = 0.0;
+#pragma unroll
+        for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) bl += (double)(x[R][k] > thr_f ? x[R][k] : 0.f);
+            bl += (double)(t[R] > thr_f ? t[R] : 0.f);
+        }
+        block = fmk_dpp_reduce(bl, 0.0, FmkOpAdd());
+    }
+    // ---- np.percentile(., 95), NumPy 2.2's float32 arithmetic (ts_percentile95)
+    float p95 = NAN;
+    bool has_nan = false;
+    if (tf != tf) {                                                    // a NaN size, or +inf and -inf: look
+        bool nn = false;
+#pragma unroll
+        for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) nn |= x[R][k] != x[R][k];
+            nn |= t[R] != t[R];
+        }
+        has_nan = __builtin_amdgcn_ballot_w64(nn) != 0;
+    }
+    if (!has_nan) {
+        const float q32 = 95.0f / 100.0f;
+        const float vi = (float)(cnt - 1) * q32;
+        const int fl = (int)floorf(vi);
+        const int k1 = fl < cnt - 1 ? fl : cnt - 1;
+        const int k2 = k1 + 1 < cnt ? k1 + 1 : cnt - 1;
+        // invariant: count(x <= val(lo)) = clo <= k1 and count(x <= val(hi)) = chi > k2, counts of the bar's sizes (the empty slots
+        // are taken off: they are <= the pivot iff 0 is); float compares: -0 and +0 count alike, so the image of -0 is never used
+        // as the lower end below the smallest size
+        int lo = kmn - 1, hi = kmx, clo = 0, chi = cnt;
+        if (lo == -1) lo = -2;
+        float v1 = 0.f, v2 = 0.f;
+        bool done = false;
+        // is the element of slot (R, k) / the tail slot of round R a size of the bar?
+        int olen[ROUNDS];
+        auto real_x = [&](int R, int k) { return 8 * k < (olen[R] & ~7); };
+        auto real_t = [&](int R) { return i8 < 7 && (olen[R] & ~7) + i8 < olen[R]; };
+        while (chi - clo > 64) {
+            if ((unsigned)hi - (unsigned)lo == 1u) { v1 = v2 = tsm_val(hi); done = true; break; }
+            const int pivot = lo + (int)(((unsigned)hi - (unsigned)lo) >> 1);
+            const float pf = tsm_val(pivot);
+            int c = 0.f <= pf ? -npad : 0;
+#pragma unroll
+            for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x[R][k] <= pf));
+                c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t[R] <= pf));
+            }
+            if (c > k2) { hi = pivot; chi = c; }
+            else if (c <= k1) { lo = pivot; clo = c; }
+            else {
+                float bel = -INFINITY, abv = INFINITY;
+#pragma unroll
+                for (int R = 0; R < ROUNDS; ++R) olen[R] = tsm_opaque(len[R]);
+#pragma unroll
+                for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        bel = real_x(R, k) && x[R][k] <= pf ? __builtin_fmaxf(bel, x[R][k]) : bel;
+                        abv = real_x(R, k) && x[R][k] > pf ? __builtin_fminf(abv, x[R][k]) : abv;
+                    }
+                    bel = real_t(R) && t[R] <= pf ? __builtin_fmaxf(bel, t[R]) : bel;
+                    abv = real_t(R) && t[R] > pf ? __builtin_fminf(abv, t[R]) : abv;
+                }
+                v1 = tsm_val(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax()));
+                v2 = tsm_val(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin()));
+                done = true;
+                break;
+            }
+        }
+        if (!done) {
+            // at most 64 candidates in (val(lo), val(hi)]: one per lane, and on with the bisection
+            const float vlo = tsm_val(lo), vhi = tsm_val(hi);
+            __builtin_amdgcn_wave_barrier();
+            cbuf[lane] = NAN;
+            __builtin_amdgcn_wave_barrier();
+            int base = 0;
+            auto put = [&](float v, bool real) {
+                const bool in = real && v > vlo && v <= vhi;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
+                if (in) cbuf[pos] = v;
+                base += __builtin_popcountll(m);
+            };
+            if (vlo < 0.f && 0.f <= vhi) {                             // the empty slots are inside: leave them out by their place
+#pragma unroll
+                for (int R = 0; R < ROUNDS; ++R) olen[R] = tsm_opaque(len[R]);
+#pragma unroll
+                for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) put(x[R][k], real_x(R, k));
+                    put(t[R], real_t(R));
+                }
+            } else {
+#pragma unroll
+                for (int R = 0; R < ROUNDS; ++R) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) put(x[R][k], true);
+                    put(t[R], true);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float cv = cbuf[lane];
+            const int cbase = clo;
+            for (;;) {
+                if ((unsigned)hi - (unsigned)lo == 1u) { v1 = v2 = tsm_val(hi); break; }
+                const int pivot = lo + (int)(((unsigned)hi - (unsigned)lo) >> 1);
+                const float pf = tsm_val(pivot);
+                const int c = cbase + __builtin_popcountll(__builtin_amdgcn_ballot_w64(cv <= pf));
+                if (c > k2) { hi = pivot; chi = c; }
+                else if (c <= k1) { lo = pivot; clo = c; }
+                else {
+                    const float bel = cv <= pf ? cv : -INFINITY, abv = cv > pf ? cv : INFINITY;
+                    v1 = tsm_val(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax()));
+                    v2 = tsm_val(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin()));
+                    break;
+                }
+            }
+        }
+        if (vi >= (float)(cnt - 1)) p95 = v2;
+        else {
+            const float t32 = vi - floorf(vi), d32 = v2 - v1;
+            p95 = v1 + d32 * t32;
+            if (t32 >= 0.5f) p95 = v2 - d32 * (1.0f - t32);
+        }
+    }
+    p95_arg = (double)p95 / thr;
+    // ---- pct_block and size_gini = 1 - sum((a / total)^2), float32 quotients, squares and pairwise sum (base.py:597-609)
+    pct = NAN; gini = NAN;
+    if (sum != 0.0) {
+        pct = (float)(block / sum);
+        const double rinv = 1.0 / (double)tf;
+        bool sub = false;
+        float g = tsm_tree<KMAX, ROUNDS, false>(x, t, len, sp_slot, [rinv, &sub](float v) {
+            const float q = (float)((double)tsm_opaque(v) * rinv);      // (opaque: or the float64 images of all sizes are kept from the block volume on)
+            sub |= __builtin_isfpclass(q, 0x0090);                     // a subnormal quotient: not covered by the argument above
+            return q * q; }, lane, slots);
+        if (__builtin_amdgcn_ballot_w64(sub) != 0)
+            g = tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [tf](float v) { const float q = v / tf; return q * q; }, lane, slots);
+        gini = 1.0f - g;
+    }
+}
+
+// (a call, so that the constants of log1p do not occupy registers across the bar loop)
+static __device__ __attribute__((noinline)) float tsm_log1p(double v) { return (float)log1p(v); }
+
+// `rest` (a list in k_bar_trade_size's format: [0] = count, [32 ...] = bar numbers): the bars this kernel does not take
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const float *__restrict__ amount, const double *__restrict__ theta,
+                                                                      const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                      double theta_mult, float *__restrict__ o_mean,
+                                                                      float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                      float *__restrict__ o_gini, unsigned long long *__restrict__ rest)
+{
+    __shared__ float s_slots[WAVES][16];
+    __shared__ unsigned s_sp[WAVES][16];
+    __shared__ float s_cbuf[WAVES][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    // mean_size_rel and size_95_rel are log1p(. / threshold) in float64: the arguments of up to 32 bars wait in the lanes (2j: the
+    // mean of the j-th waiting bar, 2j + 1: its percentile) and are evaluated together -- one log1p per 32 bars instead of two per bar
+    double parg = 0.0;
+    int64_t pbar = 0;
+    int npend = 0;
+    auto flush = [&]() {
+        const float lg = tsm_log1p(parg);
+        if (lane < 2 * npend) ((lane & 1) ? o_p95 : o_mean)[pbar] = lg;
+        npend = 0;
+    };
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
+        if (!(e - s > TSM_MIN && e - s <= TSM_MAX && s >= -1 && e <= n - 1)) {                // another launch's
+            if (lane == 0) rest[32 + atomicAdd(rest, 1ULL)] = (unsigned long long)b;
+            continue;
+        }
+        const int cnt = (int)(e - s);
+        const double th = theta[b];
+        double mean_arg = NAN, p95_arg = NAN;
+        float pct = NAN, gini = NAN;                                         // base.py:576-579
+        if (th != 0.0) {                                                     // base.py:586-587
+            // the leaves of this lane's group in the two rounds (paths 2g and 2g + 1), and what the tree's shape says about the
+            // instantiation: no split at level 3 (no odd path ends in a leaf) -> one round; leaves of at most 95 elements (every bar
+            // of 1 025 .. 1 296 ticks, most bars of up to 760) -> eleven accumulator terms per lane
+            int off2[2], len2[2]; unsigned sp2[2];
+            const int grp = lane >> 3;
+            tsm_leaf(cnt, 2 * grp, off2[0], len2[0], sp2[0]);
+            tsm_leaf(cnt, 2 * grp + 1, off2[1], len2[1], sp2[1]);
+            const bool one_round = __builtin_amdgcn_ballot_w64(len2[1] > 0) == 0;
+            const bool small_leaves = __builtin_amdgcn_ballot_w64(len2[0] > 95 || len2[1] > 95) == 0;
+            float *sl = s_slots[wib], *cb = s_cbuf[wib];
+            // the split flags of path g for lane g < 16 (the lanes that combine the leaf values)
+            if ((lane & 7) == 0) { s_sp[wib][2 * grp] = sp2[0]; s_sp[wib][2 * grp + 1] = sp2[1]; }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned sp_slot = s_sp[wib][lane & 15];
+            __builtin_amdgcn_wave_barrier();
+            const float *a = amount + s + 1;
+            if (one_round) {
+                if (small_leaves) tsm_bar<11, 1>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+                else tsm_bar<16, 1>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+            } else {
+                if (small_leaves) tsm_bar<11, 2>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+                else tsm_bar<16, 2>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+            }
+        }
+        if (lane == 0) { o_pct[b] = pct; o_gini[b] = gini; }
+        if ((lane >> 1) == npend) { parg = (lane & 1) ? p95_arg : mean_arg; pbar = b; }
+        if (++npend == 32) flush();
+    }
+    if (npend > 0) flush();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Bars of more than TSW_MIN = 32 768 ticks (hourly, daily bars), float32 amounts, regular close indices: a WORKGROUP per bar (round 3).
 // One wave per bar walks a daily bar's NumPy trees alone -- 33.6 ms per 1e9 ticks of daily bars, 10 ms of hourly ones.  The tree
 // of np.sum is a function of n only (halves of n / 2 rounded down to a multiple of 8), so its TOP is cut level by level into 33 ..
@@ -1019,14 +1387,30 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
                 (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
                 d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N);
         }
-        // the bars of at most 1 280 ticks by the instantiation without the 32-key class, the others by the full one
+        // regular bars of 129 .. 1 920 ticks: the one-read wave kernel, which lists the bars it leaves to the three-pass ones
+        // (developer knob FMK_TS_MID=0: everything by the three-pass kernels)
+        const char *mv = getenv("FMK_TS_MID");
+        const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
+        unsigned long long *rest = nullptr;
+        if (mid_on) {
+            rc = fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest);
+            if (rc == FMK_OK && hipMemsetAsync(rest, 0, 8, ctx->stream) != hipSuccess) rc = FMK_E_HIP;
+            if (rc == FMK_OK)
+                k_bar_trade_size_mid<4><<<(unsigned)blocks, 256, 0, ctx->stream>>>((const float *)d_amount, d_theta, d_close_idx, nb, n,
+                                                                                   theta_mult, d_mean_size_rel, d_size_95_rel,
+                                                                                   d_pct_block, d_size_gini, rest);
+        }
+        // the other bars of at most 1 280 ticks by the instantiation without the 32-key class, the rest by the full one
+        if (rc == FMK_OK) {
         k_bar_trade_size<false, true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                                  theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                                 d_pct_block, d_size_gini, 1, nullptr, INT64_MAX);
+                                                                                 d_pct_block, d_size_gini, 1, rest, INT64_MAX);
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                           d_pct_block, d_size_gini, 1, nullptr,
+                                                                           d_pct_block, d_size_gini, 1, rest,
                                                                            wide_on ? wide_min : INT64_MAX, (int64_t)64 * 20);
+        }
+        if (rest) (void)fmk_free(ctx, rest);
         }
         if (samp) (void)fmk_free(ctx, samp);
         if (cand) (void)fmk_free(ctx, cand);

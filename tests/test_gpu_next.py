@@ -158,3 +158,54 @@ def test_trade_size_workgroup_per_bar(orc, case):
     got = comp_bar_trade_size_features(am, theta, ci, 5.0)
     for k, g, w in zip(KEYS, got, want):
         np.testing.assert_array_equal(g, w, err_msg=f"{k} ({case})")
+
+
+@pytest.mark.parametrize("case", ["lognormal", "dyadic", "constant", "nan", "inf", "signed", "zeros", "tiny", "theta0", "few_values"])
+def test_trade_size_one_read_wave_kernel(orc, case):
+    """Regular float32 bars of 129 .. 1 920 ticks (k_bar_trade_size_mid: the bar read once into the registers of np.sum's leaf
+    accumulators, both pairwise trees folded by DPP shifts, the share a / total as a float64 product, the percentile searched in the
+    float domain and finished on a compacted register): every bar length around the kernel's ends (128 / 129, 1 920 / 1 921), the
+    sizes where the tree changes shape (1 024 / 1 025: a ninth leaf; 1 296 / 1 297: leaves beyond 95 elements = the sixteen-term
+    instantiation; 1 928 / 1 929 stay with the three-pass kernel) and random lengths between; sizes with heavy ties, all equal, NaN,
+    +-inf, both signs, zeros of both signs, tiny sizes next to a large one (subnormal shares: the division fallback), two distinct
+    values only.  Against the oracle bit for bit."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    rng = np.random.default_rng(77)
+    lens = [128, 129, 130, 136, 137, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1031, 1200, 1279, 1280, 1281, 1295, 1296, 1297,
+            1344, 1500, 1919, 1920, 1921, 1928, 1929, 64, 1, 0] + [int(v) for v in rng.integers(129, 1921, 120)]
+    cuts = np.cumsum([-1] + lens)
+    n = int(cuts[-1]) + 10
+    am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    if case == "dyadic":
+        am = (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32)
+    elif case == "constant":
+        am[:] = np.float32(0.37)
+    elif case == "few_values":
+        am = rng.choice(np.array([0.001, 2.5], dtype=np.float32), n)
+    elif case == "nan":
+        am[rng.integers(0, n, 25)] = np.nan
+    elif case == "inf":
+        am[rng.integers(0, n, 12)] = np.inf
+        am[rng.integers(0, n, 12)] = -np.inf
+    elif case == "signed":
+        am *= rng.choice(np.array([-1.0, 1.0], dtype=np.float32), n)
+    elif case == "zeros":
+        z = rng.random(n)
+        am[z < 0.5] = 0.0
+        am[z < 0.2] = -0.0
+        am[cuts[5] + 1:cuts[6] + 1] = 0.0
+        am[cuts[7] + 1:cuts[8] + 1] = -0.0
+    elif case == "tiny":
+        am = (am * np.float32(1e-30)).astype(np.float32)
+        am[rng.integers(0, n, 200)] = np.float32(3e12)
+        am[rng.integers(0, n, 200)] = np.float32(1e-44)
+    ci = cuts.astype(np.int64)
+    theta = np.full(len(ci) - 1, float(np.nanmedian(np.abs(am[np.isfinite(am)]))) or 1.0)
+    if case == "theta0":
+        theta[::7] = 0.0
+        theta[3] = np.nan
+    with np.errstate(all="ignore"):
+        want = orc.comp_bar_trade_size_features(am, theta, ci, 5.0)
+    got = comp_bar_trade_size_features(am, theta, ci, 5.0)
+    for k, g, w in zip(KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=f"{k} ({case})")
