@@ -119,8 +119,9 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
                                                         double theta_mult, float *__restrict__ o_mean, float *__restrict__ o_p95,
                                                         float *__restrict__ o_pct, float *__restrict__ o_gini, int p95_done,
                                                         const unsigned long long *__restrict__ only = nullptr,
-                                                        int64_t skip_above = INT64_MAX /* longer regular bars: k_bar_trade_size_wide */,
-                                                        int64_t cnt_lo = INT64_MIN /* bars of at most this many ticks: another launch's */)
+                                                        int64_t skip_above = INT64_MAX /* longer regular bars: the workgroup kernels' */,
+                                                        int64_t cnt_lo = INT64_MIN /* bars of at most this many ticks: another launch's */,
+                                                        int64_t skip_hi = FMK_PW_BIG_MAX_N /* ... up to this many ticks */)
 {
     static_assert(!(SMALL && AF64), "the small-bar instantiation serves float32 amounts");
     typedef typename MedKey<AF64>::K K;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
         // a zero total -> the same all-NaN row.
         // Python slice bounds: a negative start / stop wraps by n once and is then clamped to [0, n] -- a close index below -1
         // must not become a read in front of the column (it selects the reference's wrapped, usually empty, slice)
-        if (!AF64 && e_raw - s > skip_above && e_raw - s <= FMK_PW_BIG_MAX_N && s >= -1 && e_raw <= n - 1) continue;
+        if (!AF64 && e_raw - s > skip_above && e_raw - s <= skip_hi && s >= -1 && e_raw <= n - 1) continue;
         if (SMALL ? e_raw - s > 64 * 20 : e_raw - s <= cnt_lo) continue;
         int64_t start = s + 1, stop = e_raw + 1;
         start = start < 0 ? (start + n > 0 ? start + n : 0) : (start < n ? start : n);
@@ -358,16 +359,79 @@ __device__ __forceinline__ float tsm_tree(const float (&x)[ROUNDS][KMAX], const 
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
 }
 
-// one bar -> the arguments of the two log1p columns (evaluated for 32 bars at a time by the caller), pct_block, size_gini
-template <int KMAX, int ROUNDS>
-__device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, const int (&off2)[2], const int (&len2)[2], unsigned sp_slot,
-                                        double th, double theta_mult, int lane, float *slots, float *cbuf, double &mean_arg,
-                                        double &p95_arg, float &pct, float &gini)
+// ---- W waves per bar (W = 2, 4, 8, 16: bars of up to 1 912 * W ticks): the top log2(W) levels of np.sum's tree cut the bar into W
+// sub-trees of at most 1 928 elements, wave w takes the sub-tree at the end of the path w and does with it what the one-wave kernel
+// does with a bar; what the bar needs as a whole goes through LDS, one workgroup barrier per exchange (two buffers in turn: a wave
+// can be one exchange ahead of the slowest, never two):
+//   the sub-trees' values, combined left + right up the top levels (both trees); the block volume; smallest and largest size;
+//   every count of the percentile search (each wave counts its own registers; all waves follow the same search); the candidates,
+//   compacted per wave and collected by wave 0, which finishes the search alone while the others go on with the shares.
+struct TsmX {                          // the exchange buffers of a workgroup (W > 1)
+    float f[2][16];
+    int i[2][16];
+    double d[2][16];
+    float cand[16][64];
+};
+template <int W>
+struct TsmWg {
+    TsmX *x;
+    int wib, lane, par;
+    // every wave contributes a wave-uniform value and receives all W of them
+    template <class T, class G>
+    __device__ __forceinline__ void all(T (*buf)[16], T v, G got)
+    {
+        if (lane == 0) buf[par][wib] = v;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < W; ++q) got(q, buf[par][q]);
+        par ^= 1;
+    }
+    __device__ __forceinline__ float tree(float v)               // left + right up the top levels
+    {
+        if constexpr (W == 1) return v;
+        else {
+            float p[W];
+            all(x->f, v, [&](int q, float u) { p[q] = u; });
+#pragma unroll
+            for (int st = 1; st < W; st <<= 1)
+#pragma unroll
+                for (int q = 0; q < W; q += 2 * st) p[q] = p[q] + p[q + st];
+            return p[0];
+        }
+    }
+    __device__ __forceinline__ int sum(int v)
+    {
+        if constexpr (W == 1) return v;
+        else { int r = 0; all(x->i, v, [&](int, int u) { r += u; }); return r; }
+    }
+    __device__ __forceinline__ int imin(int v)
+    {
+        if constexpr (W == 1) return v;
+        else { int r = 0x7FFFFFFF; all(x->i, v, [&](int, int u) { r = u < r ? u : r; }); return r; }
+    }
+    __device__ __forceinline__ int imax(int v)
+    {
+        if constexpr (W == 1) return v;
+        else { int r = (int)0x80000000; all(x->i, v, [&](int, int u) { r = u > r ? u : r; }); return r; }
+    }
+    __device__ __forceinline__ double dsum(double v)
+    {
+        if constexpr (W == 1) return v;
+        else { double r = 0.0; all(x->d, v, [&](int, double u) { r += u; }); return r; }
+    }
+};
+
+// One bar (W == 1) or one wave's sub-tree [a, a + wcnt) of a bar of cnt sizes (W > 1) -> the arguments of the two log1p columns
+// (evaluated for 32 bars at a time by the caller), pct_block, size_gini; with W > 1 the results are wave 0's.
+template <int KMAX, int ROUNDS, int W>
+__device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int wcnt, int cnt, const int (&off2)[2], const int (&len2)[2],
+                                        unsigned sp_slot, double th, double theta_mult, int lane, float *slots, float *cbuf,
+                                        TsmWg<W> &wg, double &mean_arg, double &p95_arg, float &pct, float &gini)
 {
     const int i8 = lane & 7;
     float x[ROUNDS][KMAX], t[ROUNDS];
     int len[ROUNDS];
-    // ---- the bar's sizes: element 8k + i of the lane's leaf, and the leaf's tail element i; +0.0 where there is none
+    // ---- the sizes: element 8k + i of the lane's leaf, and the leaf's tail element i; +0.0 where there is none
 #pragma unroll
     for (int R = 0; R < ROUNDS; ++R) {
         len[R] = len2[R];
@@ -378,11 +442,11 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
         t[R] = (i8 < 7 && nm + i8 < len[R]) ? p[nm] : 0.f;
     }
     constexpr int npad_all = 64 * ROUNDS * (KMAX + 1);
-    const int npad = npad_all - cnt;
+    const int npad = npad_all - wcnt;
     const double thr = th * theta_mult;
     // ---- np.sum / np.mean of the float32 slice
-    float tf = tsm_tree<KMAX, ROUNDS, false>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots);
-    if (tf == 0.f) tf = tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots);   // (the sign of a zero total)
+    float tf = wg.tree(tsm_tree<KMAX, ROUNDS, false>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots));
+    if (tf == 0.f) tf = wg.tree(tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [](float v) { return v; }, lane, slots));   // (the sign of a zero total)
     const double mean = (double)(tf / (float)cnt), sum = (double)tf;
     mean_arg = mean / thr;
     // ---- smallest and largest size (the empty slots count as sizes of 0 here: a wider bracket is still a bracket)
@@ -393,8 +457,8 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
         for (int k = 0; k < KMAX; ++k) { mnl = __builtin_fminf(mnl, x[R][k]); mxl = __builtin_fmaxf(mxl, x[R][k]); }
         mnl = __builtin_fminf(mnl, t[R]); mxl = __builtin_fmaxf(mxl, t[R]);
     }
-    const int kmn = fmk_dpp_reduce(tsm_key(mnl), 0x7FFFFFFF, FmkOpMin());
-    const int kmx = fmk_dpp_reduce(tsm_key(mxl), (int)0x80000000, FmkOpMax());
+    const int kmn = wg.imin(fmk_dpp_reduce(tsm_key(mnl), 0x7FFFFFFF, FmkOpMin()));
+    const int kmx = wg.imax(fmk_dpp_reduce(tsm_key(mxl), (int)0x80000000, FmkOpMax()));
     // ---- block volume: (double)a > thr  <=>  a > the largest float32 not above thr
     float thr_f = (float)thr;
     if ((double)thr_f > thr) thr_f = tsm_val(tsm_key(thr_f) - 1);
@@ -407,7 +471,7 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
             for (int k = 0; k < KMAX; ++k) bl += (double)(x[R][k] > thr_f ? x[R][k] : 0.f);
             bl += (double)(t[R] > thr_f ? t[R] : 0.f);
         }
-        block = fmk_dpp_reduce(bl, 0.0, FmkOpAdd());
+        block = wg.dsum(fmk_dpp_reduce(bl, 0.0, FmkOpAdd()));
     }
     // ---- np.percentile(., 95), NumPy 2.2's float32 arithmetic (ts_percentile95)
     float p95 = NAN;
@@ -420,7 +484,7 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
             for (int k = 0; k < KMAX; ++k) nn |= x[R][k] != x[R][k];
             nn |= t[R] != t[R];
         }
-        has_nan = __builtin_amdgcn_ballot_w64(nn) != 0;
+        has_nan = wg.sum(__builtin_amdgcn_ballot_w64(nn) != 0 ? 1 : 0) != 0;
     }
     if (!has_nan) {
         const float q32 = 95.0f / 100.0f;
@@ -450,6 +514,7 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
                 for (int k = 0; k < KMAX; ++k) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x[R][k] <= pf));
                 c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t[R] <= pf));
             }
+            c = wg.sum(c);
             if (c > k2) { hi = pivot; chi = c; }
             else if (c <= k1) { lo = pivot; clo = c; }
             else {
@@ -466,14 +531,14 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
                     bel = real_t(R) && t[R] <= pf ? __builtin_fmaxf(bel, t[R]) : bel;
                     abv = real_t(R) && t[R] > pf ? __builtin_fminf(abv, t[R]) : abv;
                 }
-                v1 = tsm_val(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax()));
-                v2 = tsm_val(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin()));
+                v1 = tsm_val(wg.imax(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax())));
+                v2 = tsm_val(wg.imin(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin())));
                 done = true;
                 break;
             }
         }
         if (!done) {
-            // at most 64 candidates in (val(lo), val(hi)]: one per lane, and on with the bisection
+            // at most 64 candidates in (val(lo), val(hi)]: one per lane (of wave 0), and on with the bisection
             const float vlo = tsm_val(lo), vhi = tsm_val(hi);
             __builtin_amdgcn_wave_barrier();
             cbuf[lane] = NAN;
@@ -504,20 +569,32 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const float cv = cbuf[lane];
-            const int cbase = clo;
-            for (;;) {
-                if ((unsigned)hi - (unsigned)lo == 1u) { v1 = v2 = tsm_val(hi); break; }
-                const int pivot = lo + (int)(((unsigned)hi - (unsigned)lo) >> 1);
-                const float pf = tsm_val(pivot);
-                const int c = cbase + __builtin_popcountll(__builtin_amdgcn_ballot_w64(cv <= pf));
-                if (c > k2) { hi = pivot; chi = c; }
-                else if (c <= k1) { lo = pivot; clo = c; }
-                else {
-                    const float bel = cv <= pf ? cv : -INFINITY, abv = cv > pf ? cv : INFINITY;
-                    v1 = tsm_val(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax()));
-                    v2 = tsm_val(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin()));
-                    break;
+            float cv = cbuf[lane];
+            if constexpr (W > 1) {
+                // wave 0 collects: lane l takes the l-th candidate in wave order
+                int src_w = 0, src_at = lane, before = 0;
+                bool found = false;
+                wg.all(wg.x->i, base, [&](int q, int m) {
+                    if (!found && lane < before + m) { src_w = q; src_at = lane - before; found = true; }
+                    before += m;
+                });
+                cv = found ? wg.x->cand[src_w][src_at] : NAN;
+            }
+            if (W == 1 || wg.wib == 0) {
+                const int cbase = clo;
+                for (;;) {
+                    if ((unsigned)hi - (unsigned)lo == 1u) { v1 = v2 = tsm_val(hi); break; }
+                    const int pivot = lo + (int)(((unsigned)hi - (unsigned)lo) >> 1);
+                    const float pf = tsm_val(pivot);
+                    const int c = cbase + __builtin_popcountll(__builtin_amdgcn_ballot_w64(cv <= pf));
+                    if (c > k2) { hi = pivot; chi = c; }
+                    else if (c <= k1) { lo = pivot; clo = c; }
+                    else {
+                        const float bel = cv <= pf ? cv : -INFINITY, abv = cv > pf ? cv : INFINITY;
+                        v1 = tsm_val(fmk_dpp_reduce(tsm_key(bel), (int)0x80000000, FmkOpMax()));
+                        v2 = tsm_val(fmk_dpp_reduce(tsm_key(abv), 0x7FFFFFFF, FmkOpMin()));
+                        break;
+                    }
                 }
             }
         }
@@ -539,22 +616,24 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int cnt, co
             const float q = (float)((double)tsm_opaque(v) * rinv);      // (opaque: or the float64 images of all sizes are kept from the block volume on)
             sub |= __builtin_isfpclass(q, 0x0090);                     // a subnormal quotient: not covered by the argument above
             return q * q; }, lane, slots);
-        if (__builtin_amdgcn_ballot_w64(sub) != 0)
+        if (wg.sum(__builtin_amdgcn_ballot_w64(sub) != 0 ? 1 : 0) != 0)
             g = tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [tf](float v) { const float q = v / tf; return q * q; }, lane, slots);
-        gini = 1.0f - g;
+        gini = 1.0f - wg.tree(g);
     }
 }
 
 // (a call, so that the constants of log1p do not occupy registers across the bar loop)
 static __device__ __attribute__((noinline)) float tsm_log1p(double v) { return (float)log1p(v); }
 
-// `rest` (a list in k_bar_trade_size's format: [0] = count, [32 ...] = bar numbers): the bars this kernel does not take
+// `rest` (a list in k_bar_trade_size's format: [0] = count, [32 ...] = bar numbers): the bars neither this kernel nor the
+// workgroup kernels (regular bars of TSM_MAX < ticks <= wg_hi) take
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const float *__restrict__ amount, const double *__restrict__ theta,
                                                                       const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                                       double theta_mult, float *__restrict__ o_mean,
                                                                       float *__restrict__ o_p95, float *__restrict__ o_pct,
-                                                                      float *__restrict__ o_gini, unsigned long long *__restrict__ rest)
+                                                                      float *__restrict__ o_gini, unsigned long long *__restrict__ rest,
+                                                                      int64_t wg_hi)
 {
     __shared__ float s_slots[WAVES][16];
     __shared__ unsigned s_sp[WAVES][16];
@@ -563,6 +642,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    TsmWg<1> wg{nullptr, wib, lane, 0};
     // mean_size_rel and size_95_rel are log1p(. / threshold) in float64: the arguments of up to 32 bars wait in the lanes (2j: the
     // mean of the j-th waiting bar, 2j + 1: its percentile) and are evaluated together -- one log1p per 32 bars instead of two per bar
     double parg = 0.0;
@@ -575,8 +655,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     };
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
-        if (!(e - s > TSM_MIN && e - s <= TSM_MAX && s >= -1 && e <= n - 1)) {                // another launch's
-            if (lane == 0) rest[32 + atomicAdd(rest, 1ULL)] = (unsigned long long)b;
+        const bool regular = s >= -1 && e <= n - 1;
+        if (!(e - s > TSM_MIN && e - s <= TSM_MAX && regular)) {                                  // another launch's
+            if (lane == 0 && !(regular && e - s > TSM_MAX && e - s <= wg_hi)) rest[32 + atomicAdd(rest, 1ULL)] = (unsigned long long)b;
             continue;
         }
         const int cnt = (int)(e - s);
@@ -601,11 +682,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
             __builtin_amdgcn_wave_barrier();
             const float *a = amount + s + 1;
             if (one_round) {
-                if (small_leaves) tsm_bar<11, 1>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
-                else tsm_bar<16, 1>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+                if (small_leaves) tsm_bar<11, 1, 1>(a, cnt, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, wg, mean_arg, p95_arg, pct, gini);
+                else tsm_bar<16, 1, 1>(a, cnt, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, wg, mean_arg, p95_arg, pct, gini);
             } else {
-                if (small_leaves) tsm_bar<11, 2>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
-                else tsm_bar<16, 2>(a, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, mean_arg, p95_arg, pct, gini);
+                if (small_leaves) tsm_bar<11, 2, 1>(a, cnt, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, wg, mean_arg, p95_arg, pct, gini);
+                else tsm_bar<16, 2, 1>(a, cnt, cnt, off2, len2, sp_slot, th, theta_mult, lane, sl, cb, wg, mean_arg, p95_arg, pct, gini);
             }
         }
         if (lane == 0) { o_pct[b] = pct; o_gini[b] = gini; }
@@ -613,6 +694,82 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
         if (++npend == 32) flush();
     }
     if (npend > 0) flush();
+}
+
+// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 912 * W / 2 < ticks <= 1 912 * W).
+#define TSM_WG_PER_WAVE 1912
+template <int W>
+__global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__restrict__ amount, const double *__restrict__ theta,
+                                                                  const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                                  int64_t n, double theta_mult, float *__restrict__ o_mean,
+                                                                  float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                  float *__restrict__ o_gini)
+{
+    constexpr int LW = W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4;
+    static_assert((1 << LW) == W, "2, 4, 8 or 16 waves per bar");
+    __shared__ TsmX sx;
+    __shared__ float s_slots[W][16];
+    __shared__ unsigned s_sp[W][16];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    TsmWg<W> wg{&sx, wib, lane, 0};
+    double parg = 0.0;                                                       // (wave 0: the waiting log1p arguments, as above)
+    int64_t pbar = 0;
+    int npend = 0;
+    auto flush = [&]() {
+        const float lg = tsm_log1p(parg);
+        if (lane < 2 * npend) ((lane & 1) ? o_p95 : o_mean)[pbar] = lg;
+        npend = 0;
+    };
+    const int64_t n_list = list[0];
+    for (int64_t q = blockIdx.x; q < n_list; q += gridDim.x) {
+        const int64_t b = fmk_uniform(list[1 + q]);
+        const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
+        if (!(s >= -1 && e <= n - 1)) continue;                              // (irregular close indices: the three-pass kernel's)
+        const int cnt = (int)(e - s);
+        // the wave's sub-tree: the split rule along the bits of the wave number; the right-most sub-tree is the longest
+        int woff = 0, wlen = cnt, rlen = cnt;
+#pragma unroll
+        for (int l = 0; l < LW; ++l) {
+            const int n2 = (wlen >> 1) & ~7;
+            if ((wib >> (LW - 1 - l)) & 1) { woff += n2; wlen -= n2; }
+            else wlen = n2;
+            rlen -= (rlen >> 1) & ~7;
+        }
+        if (rlen > TSM_MAX + 8) continue;                                    // (never: the list's upper edge)
+        // eleven accumulator terms per lane are enough if every leaf of the bar's tree has at most 95 elements: the nodes of a level
+        // lie between the left-most (shortest) and the right-most (longest) one; decided from the bar's length alone, the same in every wave
+        int nlo = cnt, nhi = cnt;
+        bool small_leaves = true;
+        while (nhi > 128) {
+            small_leaves = small_leaves && nlo > 128;                        // (a leaf next to a node that still splits: up to 128 elements)
+            nlo = (nlo >> 1) & ~7;
+            nhi -= (nhi >> 1) & ~7;
+        }
+        small_leaves = small_leaves && nhi <= 95;
+        const double th = theta[b];
+        double mean_arg = NAN, p95_arg = NAN;
+        float pct = NAN, gini = NAN;
+        if (th != 0.0) {
+            int off2[2], len2[2]; unsigned sp2[2];
+            const int grp = lane >> 3;
+            tsm_leaf(wlen, 2 * grp, off2[0], len2[0], sp2[0]);
+            tsm_leaf(wlen, 2 * grp + 1, off2[1], len2[1], sp2[1]);
+            if ((lane & 7) == 0) { s_sp[wib][2 * grp] = sp2[0]; s_sp[wib][2 * grp + 1] = sp2[1]; }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned sp_slot = s_sp[wib][lane & 15];
+            __builtin_amdgcn_wave_barrier();
+            const float *a = amount + s + 1 + woff;
+            if (small_leaves) tsm_bar<11, 2, W>(a, wlen, cnt, off2, len2, sp_slot, th, theta_mult, lane, s_slots[wib], sx.cand[wib], wg, mean_arg, p95_arg, pct, gini);
+            else tsm_bar<16, 2, W>(a, wlen, cnt, off2, len2, sp_slot, th, theta_mult, lane, s_slots[wib], sx.cand[wib], wg, mean_arg, p95_arg, pct, gini);
+        }
+        if (wib == 0) {
+            if (lane == 0) { o_pct[b] = pct; o_gini[b] = gini; }
+            if ((lane >> 1) == npend) { parg = (lane & 1) ? p95_arg : mean_arg; pbar = b; }
+            if (++npend == 32) flush();
+        }
+    }
+    if (wib == 0 && npend > 0) flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1363,20 +1520,35 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         // the radix-select percentile as before); scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
         const char *wv = getenv("FMK_TS_WIDE");
         bool wide_on = (!wv || atoi(wv)) && n > TSW_MID_MIN;
-        const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) a workgroup takes
-        const int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : TSW_MID_MIN;
+        // regular bars of 129 .. 1 920 ticks: the one-read wave kernel; up to 1 912 x 16 ticks: 2 .. 16 waves of it per bar
+        // (developer knob FMK_TS_MID=0: the three-pass kernels, and a workgroup per bar from TSW_MID_MIN ticks)
+        const char *mv = getenv("FMK_TS_MID");
+        const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
+        const int64_t wg_top = (int64_t)TSM_WG_PER_WAVE * 16;
+        const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) k_bar_trade_size_wide takes
+        int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : (mid_on ? wg_top : (int64_t)TSW_MID_MIN);
+        if (mid_on && wide_min > wg_top) wide_min = wg_top;
+        const int64_t wg_upper = mid_on ? (wide_on ? wide_min : wg_top) : 0;
+        // regular bars of cov_lo < ticks <= cov_hi are taken by the workgroup kernels (their percentile included)
+        const int64_t cov_lo = mid_on ? (int64_t)TSM_MAX : (wide_on ? wide_min : INT64_MAX);
+        const int64_t cov_hi = wide_on ? (int64_t)FMK_PW_BIG_MAX_N : wg_upper;
         k_ts_p95_long<256><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_mid, n,
-                                                                            d_size_95_rel, wide_on ? wide_min : INT64_MAX,
-                                                                            (int64_t)FMK_PW_BIG_MAX_N);
+                                                                            d_size_95_rel, cov_lo, cov_hi);
         float *samp = nullptr;
         uint32_t *cand = nullptr;
         if (wide_on) {
             rc = fmk_alloc(ctx, (size_t)((n >> 4) + 64) * 4, (void **)&samp);
             if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)((n >> 2) + 64) * 4, (void **)&cand);
         }
+        int64_t *wg_lists[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (rc == FMK_OK && mid_on) {
+            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, 8 * TSM_WG_PER_WAVE, 16 * TSM_WG_PER_WAVE};
+            for (int q = 0; q < 5; ++q) if (edge[q] > wg_upper) edge[q] = wg_upper;
+            rc = fmk_long_bar_lists(ctx, d_close_idx, nb, n, 4, edge, nullptr, wg_lists);
+        }
         if (rc == FMK_OK) {
         k_ts_p95_long<1024><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>((const float *)d_amount, d_close_idx, list_long, n,
-                                                                             d_size_95_rel, wide_on ? wide_min : INT64_MAX, (int64_t)FMK_PW_BIG_MAX_N);
+                                                                             d_size_95_rel, cov_lo, cov_hi);
         if (wide_on) {
             const int64_t split = wide_min > TSW_MIN ? wide_min : TSW_MIN;
             if (wide_min < split)
@@ -1387,18 +1559,23 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
                 (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
                 d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N);
         }
-        // regular bars of 129 .. 1 920 ticks: the one-read wave kernel, which lists the bars it leaves to the three-pass ones
-        // (developer knob FMK_TS_MID=0: everything by the three-pass kernels)
-        const char *mv = getenv("FMK_TS_MID");
-        const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
-        unsigned long long *rest = nullptr;
+        unsigned long long *rest = nullptr;                           // the bars the one-read kernels leave to the three-pass ones
         if (mid_on) {
+            const float *af = (const float *)d_amount;
+            k_bar_trade_size_wg<2><<<(unsigned)(ctx->n_cu * 16), 128, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[0], n, theta_mult,
+                                                                                    d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
+            k_bar_trade_size_wg<4><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[1], n, theta_mult,
+                                                                                   d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
+            k_bar_trade_size_wg<8><<<(unsigned)(ctx->n_cu * 4), 512, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[2], n, theta_mult,
+                                                                                   d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
+            k_bar_trade_size_wg<16><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[3], n, theta_mult,
+                                                                                     d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
             rc = fmk_alloc(ctx, (size_t)(nb + 32) * 8, (void **)&rest);
             if (rc == FMK_OK && hipMemsetAsync(rest, 0, 8, ctx->stream) != hipSuccess) rc = FMK_E_HIP;
             if (rc == FMK_OK)
-                k_bar_trade_size_mid<4><<<(unsigned)blocks, 256, 0, ctx->stream>>>((const float *)d_amount, d_theta, d_close_idx, nb, n,
-                                                                                   theta_mult, d_mean_size_rel, d_size_95_rel,
-                                                                                   d_pct_block, d_size_gini, rest);
+                k_bar_trade_size_mid<4><<<(unsigned)blocks, 256, 0, ctx->stream>>>(af, d_theta, d_close_idx, nb, n, theta_mult,
+                                                                                   d_mean_size_rel, d_size_95_rel, d_pct_block,
+                                                                                   d_size_gini, rest, cov_hi);
         }
         // the other bars of at most 1 280 ticks by the instantiation without the 32-key class, the rest by the full one
         if (rc == FMK_OK) {
@@ -1408,10 +1585,11 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         k_bar_trade_size<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_amount, d_theta, d_close_idx, nb, n,
                                                                            theta_mult, d_mean_size_rel, d_size_95_rel,
                                                                            d_pct_block, d_size_gini, 1, rest,
-                                                                           wide_on ? wide_min : INT64_MAX, (int64_t)64 * 20);
+                                                                           cov_lo, (int64_t)64 * 20, cov_hi);
         }
         if (rest) (void)fmk_free(ctx, rest);
         }
+        if (wg_lists[0]) (void)fmk_free(ctx, wg_lists[0]);
         if (samp) (void)fmk_free(ctx, samp);
         if (cand) (void)fmk_free(ctx, cand);
     }
