@@ -22,6 +22,15 @@ def test_fuzz_long_bars_fixed_seed(orc):
     assert not fails, "\n".join(fails[:5])
 
 
+@pytest.mark.gpu
+def test_fuzz_mid_length_bars_fixed_seed(orc):
+    """... and on the lengths between the two ends (128 .. 40 000 ticks: every register class of the medians and footprints, the
+    one-read trade-size kernels with 1, 2, 4, 8 and 16 waves per bar -+ 1 tick around each of their edges)."""
+    from tools.fuzz_longbars import campaign
+    fails = campaign(24, 20260930, orc, verbose=False, mid=True)
+    assert not fails, "\n".join(fails[:5])
+
+
 def test_fuzz_sharded_fixed_seed():
     """tools/fuzz_sharded.py: random world sizes (2..8 virtual ranks), ticks per rank, stream density and bar interval; the
     concatenated per-rank outputs of the sharded time-bar step equal the un-sharded run bit for bit (60 configurations of

@@ -10,13 +10,22 @@ import numpy as np
 from tests import _golden as G
 
 EDGE = [8191, 8192, 8193, 16383, 16384, 16385, 32767, 32768, 32769, 65535, 65536, 65537]
+# mid=True: the bar lengths between the schedules of the short and the long end (the one-read trade-size kernels: one wave up to
+# 1 920 ticks, 2 / 4 / 8 / 16 waves up to 3 824 / 7 648 / 15 296 / 30 592; the register classes of the medians and the footprints)
+EDGE_MID = [128, 129, 256, 257, 1024, 1025, 1296, 1297, 1344, 1345, 1920, 1921, 2048, 2049, 3824, 3825, 4096, 4097, 7648, 7649, 15296,
+            15297, 30592, 30593]
 
 
-def case(rng, orc, pkg, k):
+def case(rng, orc, pkg, k, mid=False):
     lens = []
-    for _ in range(int(rng.integers(2, 9))):
+    for _ in range(int(rng.integers(2, 9)) if not mid else int(rng.integers(4, 24))):
         u = rng.random()
-        if u < 0.45: lens.append(int(rng.choice(EDGE)))
+        if mid:
+            if u < 0.3: lens.append(int(rng.choice(EDGE_MID)))
+            elif u < 0.4: lens.append(int(rng.integers(0, 300)))
+            elif u < 0.8: lens.append(int(rng.integers(300, 8000)))
+            else: lens.append(int(rng.integers(8000, 40_000)))
+        elif u < 0.45: lens.append(int(rng.choice(EDGE)))
         elif u < 0.6: lens.append(int(rng.integers(0, 300)))
         elif u < 0.9: lens.append(int(rng.integers(8000, 140_000)))
         else: lens.append(int(rng.integers(140_000, 600_000)))
@@ -64,7 +73,7 @@ def case(rng, orc, pkg, k):
             else: np.testing.assert_allclose(g, w, rtol=2e-6, equal_nan=True, err_msg=f"{what}: trade size {key}")
 
 
-def campaign(cases, seed, orc, verbose=True):
+def campaign(cases, seed, orc, verbose=True, mid=False):
     """-> list of failure messages"""
     from finmlkit_amd.bar import base
     pkg = {"base": base}
@@ -72,7 +81,7 @@ def campaign(cases, seed, orc, verbose=True):
     fails = []
     for k in range(cases):
         try:
-            case(rng, orc, pkg, k)
+            case(rng, orc, pkg, k, mid)
         except Exception as e:      # noqa: BLE001
             fails.append(f"seed {seed} {str(e)[:1500]}")
             if verbose:
@@ -86,8 +95,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     from oracle import oracle as orc
     orc.build()
-    fails = campaign(cases, seed, orc)
-    print(f"{cases} long-bar cases, seed {seed}: {len(fails)} failures")
+    mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
+    fails = campaign(cases, seed, orc, mid=mid)
+    print(f"{cases} {'mid-length' if mid else 'long'}-bar cases, seed {seed}: {len(fails)} failures")
     sys.exit(1 if fails else 0)
 
 
