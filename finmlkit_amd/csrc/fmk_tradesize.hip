@@ -1319,12 +1319,16 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         if (__ballot(mine) == 0) continue;
         const int L = mine ? (int)len_b : 0;
         // ---- the row's bar into its quarter of the tile (16 lanes, 64 B segments)
+        // (all sixteen loads of a lane in flight at once -- element r * 16 + ri is also key r of the lane --, then the tile; a loop of
+        // load -> store rounds waited for HBM seven times per 100-tick bar)
         __builtin_amdgcn_wave_barrier();
+        uint32_t raw[16];
         {
             const uint32_t *ga = (const uint32_t *)amount + s_b + 1;
-            const int Lmax = fmk_dpp_reduce(L, 0, FmkOpMax());
-            for (int i0 = 0; i0 < Lmax; i0 += 16)
-                if (i0 + ri < L) ta[i0 + ri] = ga[i0 + ri];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) raw[r] = r * 16 + ri < L ? ga[r * 16 + ri] : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ta[r * 16 + ri] = raw[r];
         }
         __builtin_amdgcn_wave_barrier();
         const double th = have ? theta[b] : 0.0;
@@ -1340,9 +1344,8 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = r * 16 + ri;
-            const uint32_t raw = i < L ? ta[i] : 0u;
-            key[r] = i < L ? MK::tokey(raw) : MK::MAXK;
-            const double a = (double)__uint_as_float(raw);
+            key[r] = i < L ? MK::tokey(raw[r]) : MK::MAXK;
+            const double a = (double)__uint_as_float(raw[r]);
             block += (i < L && a > thr) ? a : 0.0;
             kmn = key[r] < kmn ? key[r] : kmn;
             kmx = (i < L && key[r] > kmx) ? key[r] : kmx;
