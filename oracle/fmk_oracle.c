@@ -114,9 +114,14 @@ static double orc_npy_floor_divide(double a, double b)
     return fd;
 }
 
-/* np.sum over a contiguous float32 array: pairwise summation with the
- * 8-accumulator leaf (numpy/_core/src/umath/loops_utils.h.src). */
-static float orc_pairwise_f32(const float *a, int64_t n)
+/* np.sum over a contiguous float32 / float64 array.  Two layers (numpy 2.2):
+ *  - the ufunc reduction hands the inner loop at most NPY_BUFSIZE = 8192 elements at a time, buffered or not, and adds the
+ *    chunks' results one after the other: ((c0 + c1) + c2) + ...   (found in round 3 when reference-made vectors for bars of more
+ *    than 8192 ticks were added: np.mean of a float32 slice of 12 000 elements differs from the whole-array tree in ~30 % of the
+ *    bars by one ulp; oracle/gen_tradesize_lengths.py, tests/golden/trade_size_lengths_reference.npz);
+ *  - inside a chunk: pairwise summation with the 8-accumulator leaf (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum). */
+#define ORC_NP_BUFSIZE 8192
+static float orc_pairwise_tree_f32(const float *a, int64_t n)
 {
     if (n < 8) {
         float r = 0.f;
@@ -134,11 +139,19 @@ static float orc_pairwise_f32(const float *a, int64_t n)
     } else {
         int64_t n2 = n / 2;
         n2 -= n2 % 8;
-        return orc_pairwise_f32(a, n2) + orc_pairwise_f32(a + n2, n - n2);
+        return orc_pairwise_tree_f32(a, n2) + orc_pairwise_tree_f32(a + n2, n - n2);
     }
 }
+static float orc_pairwise_f32(const float *a, int64_t n)
+{
+    if (n <= ORC_NP_BUFSIZE) return orc_pairwise_tree_f32(a, n);
+    float r = orc_pairwise_tree_f32(a, ORC_NP_BUFSIZE);
+    for (int64_t i = ORC_NP_BUFSIZE; i < n; i += ORC_NP_BUFSIZE)
+        r += orc_pairwise_tree_f32(a + i, n - i < ORC_NP_BUFSIZE ? n - i : ORC_NP_BUFSIZE);
+    return r;
+}
 
-static double orc_pairwise_f64(const double *a, int64_t n)
+static double orc_pairwise_tree_f64(const double *a, int64_t n)
 {
     if (n < 8) {
         double r = 0.;
@@ -156,8 +169,16 @@ static double orc_pairwise_f64(const double *a, int64_t n)
     } else {
         int64_t n2 = n / 2;
         n2 -= n2 % 8;
-        return orc_pairwise_f64(a, n2) + orc_pairwise_f64(a + n2, n - n2);
+        return orc_pairwise_tree_f64(a, n2) + orc_pairwise_tree_f64(a + n2, n - n2);
     }
+}
+static double orc_pairwise_f64(const double *a, int64_t n)
+{
+    if (n <= ORC_NP_BUFSIZE) return orc_pairwise_tree_f64(a, n);
+    double r = orc_pairwise_tree_f64(a, ORC_NP_BUFSIZE);
+    for (int64_t i = ORC_NP_BUFSIZE; i < n; i += ORC_NP_BUFSIZE)
+        r += orc_pairwise_tree_f64(a + i, n - i < ORC_NP_BUFSIZE ? n - i : ORC_NP_BUFSIZE);
+    return r;
 }
 
 static int orc_cmp_f64(const void *x, const void *y)

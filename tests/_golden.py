@@ -126,3 +126,38 @@ def check_f32_amount_vectors(d, prefix, n, ci_key, ohlcv, directional, footprint
             else:
                 np.testing.assert_array_equal(got, want, err_msg=f"{what}: trade-size {key}")
     return n_flag_diff
+
+
+# ---- trade-size features over the bar-length axis (oracle/gen_tradesize_lengths.py made the expected columns with the reference) ----
+TS_LENGTH_KINDS = ["lognormal", "lots", "dyadic"]
+TS_KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
+# both sides of every edge between the schedules of the HIP path (64 / 65 lanes -> rows, 128 / 129 rows -> one wave, the tree shapes at
+# 1 024 / 1 025 and 1 296 / 1 297, 1 920 / 1 921 one wave -> two, 3 824 / 3 825, 7 648 / 7 649, 15 296 / 15 297, 30 592 / 30 593 -> the
+# sub-tree workgroup, 32 768 / 32 769 four -> sixteen waves of it, 65 536 / 65 537 its sample-bracket percentile) and lengths between
+TS_LENGTHS = [1, 7, 8, 20, 63, 64, 65, 100, 128, 129, 200, 256, 257, 300, 600, 1023, 1024, 1025, 1200, 1296, 1297, 1800, 1920, 1921,
+              2400, 3000, 3824, 3825, 5000, 7648, 7649, 12000, 15296, 15297, 24000, 30592, 30593, 32768, 32769, 50000, 65536, 65537,
+              0, 90000, 1343, 1344, 1345, 2047, 2048, 2049, 4096, 4097, 8192, 8193]
+
+
+def tradesize_lengths_inputs(kind):
+    """-> (float32 amounts, theta float64[B], close indices int64[B+1]) of the `kind` stream; deterministic"""
+    seed = {"lognormal": 11, "lots": 12, "dyadic": 13}[kind]
+    rng = np.random.default_rng(seed)
+    lens = list(TS_LENGTHS)
+    rng.shuffle(lens)
+    ci = np.cumsum([-1] + lens).astype(np.int64)
+    n = int(ci[-1]) + 1
+    if kind == "lognormal":
+        am = rng.lognormal(-1.0, 1.2, n).astype(np.float32)
+    elif kind == "lots":            # decimal lot sizes: heavy ties, none of them a dyadic number
+        am = (np.round(rng.lognormal(-1.0, 1.5, n), 2) + 0.01).astype(np.float32)
+    else:
+        am = (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32)
+    nb = len(lens)
+    theta = np.full(nb, float(np.median(am)))
+    theta[3] = 0.0                                           # base.py:586-587: a NaN row
+    j = int(np.argmax(np.array(lens) == 3000))               # one NaN size in the 3 000-tick bar, an all-zero 600-tick bar
+    am[int(ci[j]) + 11] = np.nan
+    z = int(np.argmax(np.array(lens) == 600))
+    am[int(ci[z]) + 1:int(ci[z + 1]) + 1] = 0.0
+    return am, theta, ci

@@ -215,3 +215,24 @@ def test_trade_size_one_read_wave_kernel(orc, case, span):
     got = comp_bar_trade_size_features(am, theta, ci, 5.0)
     for k, g, w in zip(KEYS, got, want):
         np.testing.assert_array_equal(g, w, err_msg=f"{k} ({case})")
+
+
+@pytest.mark.parametrize("kind", G.TS_LENGTH_KINDS)
+def test_trade_size_over_bar_lengths_against_reference_vectors(kind):
+    """The HIP path against the REFERENCE's own outputs (tests/golden/trade_size_lengths_reference.npz, made by
+    oracle/gen_tradesize_lengths.py with finmlkit's comp_bar_trade_size_features): float32 sizes, bars on both sides of every edge
+    between the seven schedules (one lane / sixteen lanes / one wave reading the bar once / 2, 4, 8, 16 waves / the sub-tree
+    workgroup with 4 and 16 waves, radix-select and sample-bracket percentile), bit for bit."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    d = G.load("trade_size_lengths_reference")
+    am, theta, ci = G.tradesize_lengths_inputs(kind)
+    np.testing.assert_array_equal(am[::997], d[kind + "_amount_check"])
+    got = comp_bar_trade_size_features(am, theta, ci, 5.0)
+    for k, g in zip(G.TS_KEYS, got):
+        if k == "pct_block":
+            # `block_volume = 0.0; block_volume += amount` (base.py:599-603) is a float32 running sum in the recorded (pure-Python)
+            # mode and a float64 one under Numba's typing, which the build follows (DESIGN.md section 5, row T1): a sequential float32
+            # sum over up to 90 000 sizes -- hence a tolerance for this column, here and in tests/_golden.py only
+            np.testing.assert_allclose(g, d[kind + "_" + k], rtol=2e-5, atol=0, equal_nan=True, err_msg=f"{kind} {k}")
+        else:
+            np.testing.assert_array_equal(g, d[kind + "_" + k], err_msg=f"{kind} {k}")

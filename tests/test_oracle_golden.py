@@ -335,3 +335,24 @@ def test_cot_is_numpy_argmax_with_nan_levels(orc):
             lv = flat["price_levels"][off[b]:off[b + 1]]
             tv = flat["buy_volumes"][off[b]:off[b + 1]] + flat["sell_volumes"][off[b]:off[b + 1]]
             assert bar["cot_price_levels"][b] == lv[np.argmax(tv)], (nan_at, b)
+
+
+@pytest.mark.parametrize("kind", G.TS_LENGTH_KINDS)
+def test_trade_size_over_bar_lengths_against_reference_vectors(orc, kind):
+    """oracle/gen_tradesize_lengths.py: the reference's comp_bar_trade_size_features (base.py:549-612) on float32 sizes, bars of 0 ..
+    90 000 ticks on both sides of every schedule edge of the HIP path, lognormal / decimal-lot / dyadic sizes with a NaN size, a zero
+    theta, an all-zero bar.  The oracle reproduces every column bit for bit."""
+    d = G.load("trade_size_lengths_reference")
+    am, theta, ci = G.tradesize_lengths_inputs(kind)
+    np.testing.assert_array_equal(am[::997], d[kind + "_amount_check"])
+    np.testing.assert_array_equal(ci, d[kind + "_close_indices"])
+    np.testing.assert_array_equal(theta, d[kind + "_theta"])
+    got = orc.comp_bar_trade_size_features(am, theta, ci, 5.0)
+    for k, g in zip(G.TS_KEYS, got):
+        if k == "pct_block":
+            # `block_volume = 0.0; block_volume += amount` (base.py:599-603) is a float32 running sum in the recorded (pure-Python)
+            # mode and a float64 one under Numba's typing, which the build follows (DESIGN.md section 5, row T1): a sequential float32
+            # sum over up to 90 000 sizes -- hence a tolerance for this column, here and in tests/_golden.py only
+            np.testing.assert_allclose(g, d[kind + "_" + k], rtol=2e-5, atol=0, equal_nan=True, err_msg=f"{kind} {k}")
+        else:
+            np.testing.assert_array_equal(g, d[kind + "_" + k], err_msg=f"{kind} {k}")
