@@ -81,7 +81,17 @@ __device__ __forceinline__ auto fmk_pairwise(F load, int n, int lane, int *stk) 
 }
 
 template <class F>
-__device__ __forceinline__ float fmk_pairwise_f32(F load, int n, int lane, int *stk) { return fmk_pairwise(load, n, lane, stk); }
+__device__ __forceinline__ float fmk_pairwise_f32(F load, int n, int lane, int *stk)
+{
+    // np.sum(float32 array): chunks of NPY_BUFSIZE = 8192 elements one after the other, the tree inside a chunk (see fmk_np_sum below)
+    if (n <= 8192) return fmk_pairwise(load, n, lane, stk);
+    float r = fmk_pairwise(load, 8192, lane, stk);
+    for (int i = 8192; i < n; i += 8192) {
+        const int len = n - i < 8192 ? n - i : 8192;
+        r = r + fmk_pairwise([&load, i](int k) { return load(i + k); }, len, lane, stk);
+    }
+    return r;
+}
 
 
 // The same sum without walking the tree node by node.  fmk_pairwise visits the nodes one after the other -- every visit a few
@@ -219,4 +229,23 @@ __device__ __forceinline__ auto fmk_pairwise_big(F load, int n, int lane, int *s
         __builtin_amdgcn_wave_barrier();
     }
     return ret;
+}
+
+// np.sum of a contiguous array as NumPy 2.2 evaluates it: the ufunc reduction hands pairwise_sum at most NPY_BUFSIZE = 8192
+// elements at a time and adds the chunks' results one after the other, ((c0 + c1) + c2) + ... -- so the tree above is the sum of
+// an array of up to 8 192 elements only (found in round 3 with reference-made vectors for bars of more than 8 192 ticks,
+// tests/golden/trade_size_lengths_reference.npz; oracle: orc_pairwise_f32).  TREE: the wave-level tree routine for one chunk.
+#define FMK_NP_BUFSIZE 8192
+template <class F>
+__device__ __forceinline__ auto fmk_np_sum(F load, int64_t n, int lane, int *stk) -> decltype(load(0))
+{
+    typedef decltype(load(0)) T;
+    if (n <= FMK_NP_BUFSIZE) return fmk_pairwise_big(load, (int)n, lane, stk);
+    T r = fmk_pairwise_big(load, FMK_NP_BUFSIZE, lane, stk);
+    for (int64_t i = FMK_NP_BUFSIZE; i < n; i += FMK_NP_BUFSIZE) {
+        const int len = n - i < FMK_NP_BUFSIZE ? (int)(n - i) : FMK_NP_BUFSIZE;
+        const int base = (int)i;
+        r = r + fmk_pairwise_big([&load, base](int k) { return load(base + k); }, len, lane, stk);
+    }
+    return r;
 }

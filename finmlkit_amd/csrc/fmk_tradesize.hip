@@ -194,12 +194,12 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
             if (np_rule) {
                 if constexpr (!AF64) {
                     const float *af = (const float *)amount + start;
-                    tf = fmk_pairwise_big([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
+                    tf = fmk_np_sum([af](int i) { return af[i]; }, (int)cnt, lane, s_stk[wib]);
                     mean = (double)(tf / (float)cnt);
                     sum = (double)tf;
                 } else {
                     const double *ad = (const double *)amount + start;
-                    sum = fmk_pairwise_big([ad](int i) { return ad[i]; }, (int)cnt, lane, s_stk[wib]);
+                    sum = fmk_np_sum([ad](int i) { return ad[i]; }, (int)cnt, lane, s_stk[wib]);
                     mean = sum / (double)cnt;
                 }
             }
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
                     // 1 - sum((a / total)^2) with float32 quotients, squares and pairwise sum (base.py:609)
                     const float *af = (const float *)amount + start;
                     const float t32 = tf;
-                    gini = 1.0f - fmk_pairwise_big([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
+                    gini = 1.0f - fmk_np_sum([af, t32](int i) { const float q = af[i] / t32; return q * q; }, (int)cnt, lane,
                                                s_stk[wib]);
                 } else if (np_rule) {
                     const double *ad = (const double *)amount + start;
                     const double td = sum;
-                    gini = (float)(1.0 - fmk_pairwise_big([ad, td](int i) { const double q = ad[i] / td; return q * q; }, (int)cnt, lane,
+                    gini = (float)(1.0 - fmk_np_sum([ad, td](int i) { const double q = ad[i] / td; return q * q; }, (int)cnt, lane,
                                                        s_stk[wib]));
                 } else {
                     double sq = 0.0;
@@ -376,6 +376,7 @@ template <int W>
 struct TsmWg {
     TsmX *x;
     int wib, lane, par;
+    int nw1;                           // W == 16 (a bar of two np.sum chunks): waves 8 .. 8 + nw1 - 1 hold the second chunk's sub-trees
     // every wave contributes a wave-uniform value and receives all W of them
     template <class T, class G>
     __device__ __forceinline__ void all(T (*buf)[16], T v, G got)
@@ -386,17 +387,28 @@ struct TsmWg {
         for (int q = 0; q < W; ++q) got(q, buf[par][q]);
         par ^= 1;
     }
-    __device__ __forceinline__ float tree(float v)               // left + right up the top levels
+    // left + right up the top levels of a chunk's tree; sixteen waves: two chunks -- waves 0 .. 7 the eight sub-trees of the first
+    // 8 192 elements, waves 8 .. 8 + nw1 - 1 those of the rest -- and np.sum adds the chunks one after the other
+    __device__ __forceinline__ float tree(float v)
     {
         if constexpr (W == 1) return v;
         else {
             float p[W];
             all(x->f, v, [&](int q, float u) { p[q] = u; });
+            if constexpr (W == 16) {
 #pragma unroll
-            for (int st = 1; st < W; st <<= 1)
+                for (int st = 1; st < 8; st <<= 1)
 #pragma unroll
-                for (int q = 0; q < W; q += 2 * st) p[q] = p[q] + p[q + st];
-            return p[0];
+                    for (int q = 0; q < 16; q += 2 * st)
+                        if (q < 8 || st < nw1) p[q] = p[q] + p[q + st];
+                return p[0] + p[8];
+            } else {
+#pragma unroll
+                for (int st = 1; st < W; st <<= 1)
+#pragma unroll
+                    for (int q = 0; q < W; q += 2 * st) p[q] = p[q] + p[q + st];
+                return p[0];
+            }
         }
     }
     __device__ __forceinline__ int sum(int v)
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES;
-    TsmWg<1> wg{nullptr, wib, lane, 0};
+    TsmWg<1> wg{nullptr, wib, lane, 0, 0};
     // mean_size_rel and size_95_rel are log1p(. / threshold) in float64: the arguments of up to 32 bars wait in the lanes (2j: the
     // mean of the j-th waiting bar, 2j + 1: its percentile) and are evaluated together -- one log1p per 32 bars instead of two per bar
     double parg = 0.0;
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     if (npend > 0) flush();
 }
 
-// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 912 * W / 2 < ticks <= 1 912 * W).
+// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 8 192 < ticks <= 3 824 / 7 648 / 8 192 / 16 384 for 2 / 4 / 8 / 16 waves).
 #define TSM_WG_PER_WAVE 1912
 template <int W>
 __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__restrict__ amount, const double *__restrict__ theta,
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
     __shared__ unsigned s_sp[W][16];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
-    TsmWg<W> wg{&sx, wib, lane, 0};
+    TsmWg<W> wg{&sx, wib, lane, 0, 0};
     double parg = 0.0;                                                       // (wave 0: the waiting log1p arguments, as above)
     int64_t pbar = 0;
     int npend = 0;
@@ -727,26 +739,50 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
         const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
         if (!(s >= -1 && e <= n - 1)) continue;                              // (irregular close indices: the three-pass kernel's)
         const int cnt = (int)(e - s);
-        // the wave's sub-tree: the split rule along the bits of the wave number; the right-most sub-tree is the longest
+        // the wave's sub-tree.  np.sum adds a bar of more than 8 192 ticks in chunks of 8 192 (fmk_np_sum): up to 8 192 ticks the bar
+        // is ONE tree and the W waves follow the split rule along the bits of the wave number; sixteen waves take a bar of two
+        // chunks -- the first is eight sub-trees of exactly 1 024 elements (waves 0 .. 7), the rest (m ticks) 1, 2, 4 or 8 sub-trees
+        // (waves 8 ...; the others hold nothing)
         int woff = 0, wlen = cnt, rlen = cnt;
-#pragma unroll
-        for (int l = 0; l < LW; ++l) {
-            const int n2 = (wlen >> 1) & ~7;
-            if ((wib >> (LW - 1 - l)) & 1) { woff += n2; wlen -= n2; }
-            else wlen = n2;
-            rlen -= (rlen >> 1) & ~7;
-        }
-        if (rlen > TSM_MAX + 8) continue;                                    // (never: the list's upper edge)
-        // eleven accumulator terms per lane are enough if every leaf of the bar's tree has at most 95 elements: the nodes of a level
-        // lie between the left-most (shortest) and the right-most (longest) one; decided from the bar's length alone, the same in every wave
-        int nlo = cnt, nhi = cnt;
         bool small_leaves = true;
-        while (nhi > 128) {
-            small_leaves = small_leaves && nlo > 128;                        // (a leaf next to a node that still splits: up to 128 elements)
-            nlo = (nlo >> 1) & ~7;
-            nhi -= (nhi >> 1) & ~7;
+        if constexpr (W == 16) {
+            const int m = cnt - FMK_NP_BUFSIZE;
+            if (m <= 0 || m > FMK_NP_BUFSIZE) continue;                     // (never: the list's edges)
+            const int j1 = m <= TSM_WG_PER_WAVE ? 0 : m <= 2 * TSM_WG_PER_WAVE ? 1 : m <= 4 * TSM_WG_PER_WAVE ? 2 : 3;
+            wg.nw1 = 1 << j1;
+            if (wib < 8) { woff = 1024 * wib; wlen = 1024; }
+            else {
+                const int pth = wib - 8;
+                woff = FMK_NP_BUFSIZE; wlen = pth < (1 << j1) ? m : 0;
+                for (int l = 0; l < j1; ++l) {
+                    const int n2 = (wlen >> 1) & ~7;
+                    if ((pth >> (j1 - 1 - l)) & 1) { woff += n2; wlen -= n2; }
+                    else wlen = n2;
+                }
+                if (pth >= (1 << j1)) wlen = 0;
+            }
+            small_leaves = false;                                            // (the first chunk's leaves hold 128 elements)
+        } else {
+            if (cnt > FMK_NP_BUFSIZE) continue;                              // (never: the list's edges)
+#pragma unroll
+            for (int l = 0; l < LW; ++l) {
+                const int n2 = (wlen >> 1) & ~7;
+                if ((wib >> (LW - 1 - l)) & 1) { woff += n2; wlen -= n2; }
+                else wlen = n2;
+                rlen -= (rlen >> 1) & ~7;
+            }
+            if (rlen > TSM_MAX + 8) continue;                                // (never: the list's upper edge)
+            // eleven accumulator terms per lane are enough if every leaf of the bar's tree has at most 95 elements: the nodes of a
+            // level lie between the left-most (shortest) and the right-most (longest) one; decided from the bar's length alone, the
+            // same in every wave
+            int nlo = cnt, nhi = cnt;
+            while (nhi > 128) {
+                small_leaves = small_leaves && nlo > 128;                    // (a leaf next to a node that still splits: up to 128 elements)
+                nlo = (nlo >> 1) & ~7;
+                nhi -= (nhi >> 1) & ~7;
+            }
+            small_leaves = small_leaves && nhi <= 95;
         }
-        small_leaves = small_leaves && nhi <= 95;
         const double th = theta[b];
         double mean_arg = NAN, p95_arg = NAN;
         float pct = NAN, gini = NAN;
@@ -801,13 +837,7 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
                                                                       uint32_t *__restrict__ cand, int64_t min_cnt, int64_t max_cnt)
 {
     typedef MedKey<false> MK;
-    // the cut of the tree's top, level by level (entry = a node (off, len) of the current level, in order): round d keeps for
-    // every entry where its first child stands in round d + 1 and whether it split
-    __shared__ int e_off[2][TSW_MAXSUB], e_len[2][TSW_MAXSUB];
-    __shared__ unsigned short e_pos[TSW_ROUNDS][TSW_MAXSUB];
-    __shared__ int e_n[TSW_ROUNDS + 1];
-    __shared__ float s_val[2][TSW_MAXSUB];
-    __shared__ int s_wcnt[TSW_MAXSUB / 64];
+    __shared__ float s_tot;
     __shared__ __attribute__((aligned(8))) int s_stk[TSW_WAVES][FMK_PW_PAR_STK];
     __shared__ double s_blk[TSW_WAVES];
     __shared__ float s_p95;
@@ -829,49 +859,45 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
             continue;
         }
         const double thr = th * theta_mult;
-        // ---- the cut: nodes longer than G split into (off, n2) and (off + n2, len - n2), n2 = len / 2 rounded down to a multiple of
-        //      8 (NumPy's rule), until none is: two to eight sub-trees per wave
-        int G = 256;
-        while (cnt / G > 4 * TSW_WAVES) G *= 2;
-        __syncthreads();
-        if (tid == 0) { e_off[0][0] = 0; e_len[0][0] = cnt; e_n[0] = 1; s_ncand = 0; s_nan = 0; }
-        __syncthreads();
-        int depth = 0;
-        for (;; ++depth) {
-            const int cur = depth & 1, ne = e_n[depth];
-            const bool mine = tid < ne;
-            const int off = mine ? e_off[cur][tid] : 0, len = mine ? e_len[cur][tid] : 0;
-            const bool split = mine && len > G;
-            const uint64_t m = __ballot(split);
-            if (tid < TSW_MAXSUB && lane == 0) s_wcnt[w] = (int)__popcll(m);
-            __syncthreads();
-            int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)), total = 0;
-            for (int k = 0; k < TSW_MAXSUB / 64; ++k) { if (k < w) before += s_wcnt[k]; total += s_wcnt[k]; }
-            if (total == 0 || depth == TSW_ROUNDS) break;                  // (block-uniform; the cap cannot be met: <= 8 rounds)
-            if (mine) {
-                const int at = tid + before;
-                int n2 = len / 2;
-                n2 -= n2 % 8;
-                e_pos[depth][tid] = (unsigned short)(at | (split ? 0x8000 : 0));
-                if (split) { e_off[cur ^ 1][at] = off; e_len[cur ^ 1][at] = n2; e_off[cur ^ 1][at + 1] = off + n2; e_len[cur ^ 1][at + 1] = len - n2; }
-                else { e_off[cur ^ 1][at] = off; e_len[cur ^ 1][at] = len; }
+        // ---- np.sum's structure (fmk_np_sum): chunks of 8 192 elements added one after the other, the pairwise tree inside a chunk.
+        //      Work items: a chunk of at least 2 048 elements is the eight sub-trees at the ends of the 3-bit paths through the top
+        //      of its tree (all of those nodes split: they hold more than 128 elements), a shorter last chunk is one item.  The waves
+        //      take the items in turn (fmk_pairwise_big: the recursion does not know where it started), the values meet in the bar's
+        //      own scratch (behind its sample slots), a thread per chunk folds ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)) and one thread adds
+        //      the chunks in order.
+        const int nchunk = (cnt + FMK_NP_BUFSIZE - 1) / FMK_NP_BUFSIZE, nitem = 8 * nchunk;
+        float *gv = samp + ((s + 1) >> 4) + (cnt >> 5);
+        auto item = [&](int k, int &off, int &len) {
+            const int c = k >> 3, sub = k & 7;
+            off = c * FMK_NP_BUFSIZE;
+            len = cnt - off < FMK_NP_BUFSIZE ? cnt - off : FMK_NP_BUFSIZE;
+            if (len < 2048) { len = sub == 0 ? len : 0; return; }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int n2 = (len >> 1) & ~7;
+                if ((sub >> (2 - l)) & 1) { off += n2; len -= n2; }
+                else len = n2;
             }
-            if (tid == 0) e_n[depth + 1] = ne + total;
-            __syncthreads();
-        }
-        const int fin = depth & 1, nsub = e_n[depth];
-        // the sub-trees' sums (s_val[depth & 1]) -> the root's, undoing the rounds: left + right as the recursion returns it
+        };
+        __syncthreads();
+        if (tid == 0) { s_ncand = 0; s_nan = 0; }
+        __syncthreads();
+        // the items' values (gv) -> the bar's: chunk by chunk
         auto combine = [&]() -> float {
-            for (int d = depth - 1; d >= 0; --d) {
-                __syncthreads();
-                if (tid < e_n[d]) {
-                    const unsigned p = e_pos[d][tid];
-                    const float *nx = s_val[(d + 1) & 1];
-                    s_val[d & 1][tid] = (p & 0x8000) ? nx[p & 0x7FFF] + nx[(p & 0x7FFF) + 1] : nx[p & 0x7FFF];
-                }
+            __syncthreads();
+            for (int c = tid; c < nchunk; c += 64 * TSW_WAVES) {
+                const int clen = cnt - c * FMK_NP_BUFSIZE < FMK_NP_BUFSIZE ? cnt - c * FMK_NP_BUFSIZE : FMK_NP_BUFSIZE;
+                const float *g = gv + 8 * c;
+                if (clen >= 2048) gv[8 * c] = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
             }
             __syncthreads();
-            return s_val[0][0];
+            if (tid == 0) {
+                float acc = gv[0];
+                for (int c = 1; c < nchunk; ++c) acc = acc + gv[8 * c];
+                s_tot = acc;
+            }
+            __syncthreads();
+            return s_tot;
         };
         // ---- np.percentile(., 95)
         const float q32 = 95.0f / 100.0f;
@@ -899,10 +925,13 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
             __syncthreads();
         }
         // ---- np.sum of the float32 slice (pairwise)
-        for (int k = w; k < nsub; k += TSW_WAVES) {
-            const float *a0 = af + e_off[fin][k];
-            const float r = fmk_pairwise_big([a0](int i) { return a0[i]; }, e_len[fin][k], lane, s_stk[w]);
-            if (lane == 0) s_val[fin][k] = r;
+        for (int k = w; k < nitem; k += TSW_WAVES) {
+            int ioff, ilen;
+            item(k, ioff, ilen);
+            if (ilen == 0) continue;
+            const float *a0 = af + ioff;
+            const float r = fmk_pairwise_big([a0](int i) { return a0[i]; }, ilen, lane, s_stk[w]);
+            if (lane == 0) gv[k] = r;
         }
         // ---- the block volume (base.py:599-603: a float64 sum of float32 values) by a plain sweep; with it the percentile's counts
         double blk = 0.0;
@@ -963,10 +992,13 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
         // ---- sum((a / total)^2): float32 quotients, squares and pairwise sum (base.py:609)
         __syncthreads();
         if (tf != 0.f) {
-            for (int k = w; k < nsub; k += TSW_WAVES) {
-                const float *a0 = af + e_off[fin][k];
-                const float r = fmk_pairwise_big([a0, tf](int i) { const float x = a0[i] / tf; return x * x; }, e_len[fin][k], lane, s_stk[w]);
-                if (lane == 0) s_val[fin][k] = r;
+            for (int k = w; k < nitem; k += TSW_WAVES) {
+                int ioff, ilen;
+                item(k, ioff, ilen);
+                if (ilen == 0) continue;
+                const float *a0 = af + ioff;
+                const float r = fmk_pairwise_big([a0, tf](int i) { const float x = a0[i] / tf; return x * x; }, ilen, lane, s_stk[w]);
+                if (lane == 0) gv[k] = r;
             }
         }
         const float sq = tf != 0.f ? combine() : 0.f;                      // (block-uniform)
@@ -1527,7 +1559,7 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         // (developer knob FMK_TS_MID=0: the three-pass kernels, and a workgroup per bar from TSW_MID_MIN ticks)
         const char *mv = getenv("FMK_TS_MID");
         const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
-        const int64_t wg_top = (int64_t)TSM_WG_PER_WAVE * 16;
+        const int64_t wg_top = 2 * (int64_t)FMK_NP_BUFSIZE;          // (sixteen waves hold two of np.sum's chunks)
         const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) k_bar_trade_size_wide takes
         int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : (mid_on ? wg_top : (int64_t)TSW_MID_MIN);
         if (mid_on && wide_min > wg_top) wide_min = wg_top;
@@ -1545,7 +1577,7 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         }
         int64_t *wg_lists[4] = {nullptr, nullptr, nullptr, nullptr};
         if (rc == FMK_OK && mid_on) {
-            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, 8 * TSM_WG_PER_WAVE, 16 * TSM_WG_PER_WAVE};
+            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, FMK_NP_BUFSIZE, 2 * FMK_NP_BUFSIZE};
             for (int q = 0; q < 5; ++q) if (edge[q] > wg_upper) edge[q] = wg_upper;
             rc = fmk_long_bar_lists(ctx, d_close_idx, nb, n, 4, edge, nullptr, wg_lists);
         }
