@@ -376,7 +376,7 @@ template <int W>
 struct TsmWg {
     TsmX *x;
     int wib, lane, par;
-    int nw1;                           // W == 16 (a bar of two np.sum chunks): waves 8 .. 8 + nw1 - 1 hold the second chunk's sub-trees
+    int nw1;                           // > 0: a bar of two np.sum chunks, waves W / 2 .. W / 2 + nw1 - 1 hold the second chunk's sub-trees
     // every wave contributes a wave-uniform value and receives all W of them
     template <class T, class G>
     __device__ __forceinline__ void all(T (*buf)[16], T v, G got)
@@ -387,21 +387,23 @@ struct TsmWg {
         for (int q = 0; q < W; ++q) got(q, buf[par][q]);
         par ^= 1;
     }
-    // left + right up the top levels of a chunk's tree; sixteen waves: two chunks -- waves 0 .. 7 the eight sub-trees of the first
-    // 8 192 elements, waves 8 .. 8 + nw1 - 1 those of the rest -- and np.sum adds the chunks one after the other
+    // left + right up the top levels of a chunk's tree.  A bar of two chunks (nw1 > 0; eight or sixteen waves): the first half of
+    // the waves holds the W / 2 sub-trees of the first 8 192 elements, waves W / 2 .. W / 2 + nw1 - 1 those of the rest, and np.sum
+    // adds the chunks one after the other
     __device__ __forceinline__ float tree(float v)
     {
         if constexpr (W == 1) return v;
         else {
             float p[W];
             all(x->f, v, [&](int q, float u) { p[q] = u; });
-            if constexpr (W == 16) {
+            if (W >= 8 && nw1 > 0) {
+                constexpr int H = W / 2;
 #pragma unroll
-                for (int st = 1; st < 8; st <<= 1)
+                for (int st = 1; st < H; st <<= 1)
 #pragma unroll
-                    for (int q = 0; q < 16; q += 2 * st)
-                        if (q < 8 || st < nw1) p[q] = p[q] + p[q + st];
-                return p[0] + p[8];
+                    for (int q = 0; q < W; q += 2 * st)
+                        if (q < H || st < nw1) p[q] = p[q] + p[q + st];
+                return p[0] + p[H];
             } else {
 #pragma unroll
                 for (int st = 1; st < W; st <<= 1)
@@ -708,7 +710,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     if (npend > 0) flush();
 }
 
-// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 8 192 < ticks <= 3 824 / 7 648 / 8 192 / 16 384 for 2 / 4 / 8 / 16 waves).
+// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 15 840 < ticks <= 3 824 / 7 648 / 15 840 / 16 384 for 2 / 4 / 8 / 16 waves;
+// beyond 8 192 ticks a bar is two of np.sum's chunks: half of the waves for the first, the others for the rest).
 #define TSM_WG_PER_WAVE 1912
 template <int W>
 __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__restrict__ amount, const double *__restrict__ theta,
@@ -740,20 +743,22 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
         if (!(s >= -1 && e <= n - 1)) continue;                              // (irregular close indices: the three-pass kernel's)
         const int cnt = (int)(e - s);
         // the wave's sub-tree.  np.sum adds a bar of more than 8 192 ticks in chunks of 8 192 (fmk_np_sum): up to 8 192 ticks the bar
-        // is ONE tree and the W waves follow the split rule along the bits of the wave number; sixteen waves take a bar of two
-        // chunks -- the first is eight sub-trees of exactly 1 024 elements (waves 0 .. 7), the rest (m ticks) 1, 2, 4 or 8 sub-trees
-        // (waves 8 ...; the others hold nothing)
+        // is ONE tree and the W waves follow the split rule along the bits of the wave number; eight or sixteen waves also take a bar
+        // of two chunks -- the first is W / 2 sub-trees of exactly 2 048 / 1 024 elements (waves 0 .. W / 2 - 1; a 2 048-element tree
+        // splits evenly: four levels), the rest (m ticks) 1, 2, 4 (or 8) sub-trees of at most 1 928 (waves W / 2 ...; the others hold nothing)
         int woff = 0, wlen = cnt, rlen = cnt;
         bool small_leaves = true;
-        if constexpr (W == 16) {
+        wg.nw1 = 0;
+        if (W >= 8 && cnt > FMK_NP_BUFSIZE) {
+            constexpr int H = W / 2, LH = LW - 1, SUB0 = FMK_NP_BUFSIZE / H;    // the first chunk: H sub-trees of exactly SUB0 = 2 048 / 1 024 elements
             const int m = cnt - FMK_NP_BUFSIZE;
-            if (m <= 0 || m > FMK_NP_BUFSIZE) continue;                     // (never: the list's edges)
             const int j1 = m <= TSM_WG_PER_WAVE ? 0 : m <= 2 * TSM_WG_PER_WAVE ? 1 : m <= 4 * TSM_WG_PER_WAVE ? 2 : 3;
+            if (m > FMK_NP_BUFSIZE || j1 > LH) continue;                     // (never: the list's edges)
             wg.nw1 = 1 << j1;
-            if (wib < 8) { woff = 1024 * wib; wlen = 1024; }
+            if (wib < H) { woff = SUB0 * wib; wlen = SUB0; }
             else {
-                const int pth = wib - 8;
-                woff = FMK_NP_BUFSIZE; wlen = pth < (1 << j1) ? m : 0;
+                const int pth = wib - H;
+                woff = FMK_NP_BUFSIZE; wlen = m;
                 for (int l = 0; l < j1; ++l) {
                     const int n2 = (wlen >> 1) & ~7;
                     if ((pth >> (j1 - 1 - l)) & 1) { woff += n2; wlen -= n2; }
@@ -1577,7 +1582,7 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         }
         int64_t *wg_lists[4] = {nullptr, nullptr, nullptr, nullptr};
         if (rc == FMK_OK && mid_on) {
-            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, FMK_NP_BUFSIZE, 2 * FMK_NP_BUFSIZE};
+            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE, 2 * FMK_NP_BUFSIZE};
             for (int q = 0; q < 5; ++q) if (edge[q] > wg_upper) edge[q] = wg_upper;
             rc = fmk_long_bar_lists(ctx, d_close_idx, nb, n, 4, edge, nullptr, wg_lists);
         }
