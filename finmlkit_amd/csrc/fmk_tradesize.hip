@@ -815,13 +815,14 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Bars of more than TSW_MIN = 32 768 ticks (hourly, daily bars), float32 amounts, regular close indices: a WORKGROUP per bar (round 3).
-// One wave per bar walks a daily bar's NumPy trees alone -- 33.6 ms per 1e9 ticks of daily bars, 10 ms of hourly ones.  The tree
-// of np.sum is a function of n only (halves of n / 2 rounded down to a multiple of 8), so its TOP is cut level by level into 33 ..
-// 128 sub-trees of at most G elements (a ballot per level gives every node its place, as in fmk_pairwise_par), the sixteen waves
-// evaluate the sub-trees in parallel with the wave-level routine (fmk_pairwise_big: the recursion does not know where it started)
-// and the levels are undone in reverse: a node that had split becomes left + right.  Twice: the float32 total and sum((a / total)^2); the block
-// volume is a float64 sum of float32 values, exact in any order: a plain sweep.  Same bits as the wave kernel: every addition has
-// the recursion's operands and order.
+// One wave per bar walks a daily bar's NumPy trees alone -- 33.6 ms per 1e9 ticks of daily bars, 10 ms of hourly ones.  np.sum
+// adds the bar in chunks of 8 192 elements, the pairwise tree inside a chunk (fmk_np_sum); the tree of a chunk is a function of
+// its length only (halves of n / 2 rounded down to a multiple of 8), so a chunk is eight sub-trees at the ends of the 3-bit paths
+// through its top, the waves evaluate the sub-trees of all chunks in turn with the wave-level routine (fmk_pairwise_big: the
+// recursion does not know where it started), a thread per chunk folds its eight values left + right and one thread adds the
+// chunks in order.  Twice: the float32 total and sum((a / total)^2); the block volume is a float64 sum of float32 values, exact
+// in any order: a plain sweep.  Same bits as the wave kernel: every addition has NumPy's operands and order.  (Until the chunks
+// were found -- DESIGN.md section 5 -- the top of ONE tree over the whole bar was cut level by level into 33 .. 128 sub-trees.)
 // np.percentile(., 95) of bars beyond 65 536 ticks rides on that sweep (k_ts_p95_long's radix select is three more passes over
 // the bar: 3.4 / 6.0 ms per 1e9 ticks at hourly / daily bars): like the long-bar median of fmk_ohlcv.hip, a systematic sample of the
 // bar (every 64th / 256th size) gives a bracket of keys around the sample's 95 % rank (-+ 3.8 standard deviations of that rank), the sweep counts
