@@ -169,16 +169,17 @@ def test_trade_size_one_read_wave_kernel(orc, case, span):
     sizes where the tree changes shape (1 024 / 1 025: a ninth leaf; 1 296 / 1 297: leaves beyond 95 elements = the sixteen-term
     instantiation; 1 928 / 1 929 stay with the three-pass kernel) and random lengths between; sizes with heavy ties, all equal, NaN,
     +-inf, both signs, zeros of both signs, tiny sizes next to a large one (subnormal shares: the division fallback), two distinct
-    values only.  span "workgroup": bars of 1 921 .. 30 592 ticks (k_bar_trade_size_wg: 2, 4, 8 or 16 waves per bar, each on the
-    sub-tree at the end of its path through the top of np.sum's tree, the bar-wide values exchanged through LDS) around every
-    edge between the wave counts (3 824 / 3 825, 7 648 / 7 649, 15 296 / 15 297, 30 592 / 30 593).  Against the oracle bit for bit."""
+    values only.  span "workgroup": bars of 1 921 .. 16 384 ticks (k_bar_trade_size_wg: 2, 4, 8 or 16 waves per bar, each on the
+    sub-tree at the end of its path through the top of np.sum's tree -- of each of its two 8 192-element chunks beyond 8 192 ticks --,
+    the bar-wide values exchanged through LDS) around every edge between the wave counts (3 824 / 3 825, 7 648 / 7 649, 8 192 / 8 193,
+    15 840 / 15 841, 16 384 / 16 385).  Against the oracle bit for bit."""
     from finmlkit_amd.bar.base import comp_bar_trade_size_features
     rng = np.random.default_rng(77)
     lens = [128, 129, 130, 136, 137, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1031, 1200, 1279, 1280, 1281, 1295, 1296, 1297,
             1344, 1500, 1919, 1920, 1921, 1928, 1929, 64, 1, 0] + [int(v) for v in rng.integers(129, 1921, 120)]
     if span == "workgroup":
-        lens = [1921, 1929, 2000, 2048, 2049, 2400, 3600, 3823, 3824, 3825, 4096, 5000, 7648, 7649, 8192, 12000, 15296, 15297, 20000,
-                30592, 30593, 32768, 100, 0] + [int(v) for v in rng.integers(1921, 30593, 14)]
+        lens = [1921, 1929, 2000, 2048, 2049, 2400, 3600, 3823, 3824, 3825, 4096, 5000, 7648, 7649, 8192, 8193, 8200, 10105, 12000, 15840,
+                15841, 16000, 16384, 16385, 20000, 32768, 100, 0] + [int(v) for v in rng.integers(1921, 16385, 14)]
     cuts = np.cumsum([-1] + lens)
     n = int(cuts[-1]) + 10
     am = rng.lognormal(-1, 1.2, n).astype(np.float32)

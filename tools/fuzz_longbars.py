@@ -11,9 +11,10 @@ from tests import _golden as G
 
 EDGE = [8191, 8192, 8193, 16383, 16384, 16385, 32767, 32768, 32769, 65535, 65536, 65537]
 # mid=True: the bar lengths between the schedules of the short and the long end (the one-read trade-size kernels: one wave up to
-# 1 920 ticks, 2 / 4 / 8 / 16 waves up to 3 824 / 7 648 / 15 296 / 30 592; the register classes of the medians and the footprints)
-EDGE_MID = [128, 129, 256, 257, 1024, 1025, 1296, 1297, 1344, 1345, 1920, 1921, 2048, 2049, 3824, 3825, 4096, 4097, 7648, 7649, 15296,
-            15297, 30592, 30593]
+# 1 920 ticks, 2 / 4 / 8 / 16 waves up to 3 824 / 7 648 / 15 840 / 16 384 -- two of np.sum's 8 192-element chunks beyond 8 192; the
+# register classes of the medians and the footprints)
+EDGE_MID = [128, 129, 256, 257, 1024, 1025, 1296, 1297, 1344, 1345, 1920, 1921, 2048, 2049, 3824, 3825, 4096, 4097, 7648, 7649, 8192,
+            8193, 15840, 15841, 16384, 16385, 32768, 32769]
 
 
 def case(rng, orc, pkg, k, mid=False):
