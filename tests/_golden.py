@@ -161,3 +161,12 @@ def tradesize_lengths_inputs(kind):
     z = int(np.argmax(np.array(lens) == 600))
     am[int(ci[z]) + 1:int(ci[z + 1]) + 1] = 0.0
     return am, theta, ci
+
+
+# ---- the four bar reducers on long bars (oracle/gen_longbars.py made the expected columns with the reference) ----
+LONG_BARS_N = 420_000
+LONG_BARS_CUTS = [-1, 70_000, 70_100, 200_000, 200_001, 216_500, 225_000, 419_999]
+
+
+def long_bars_amounts():
+    return np.random.default_rng(4242).lognormal(-1.0, 1.2, LONG_BARS_N).astype(np.float32)

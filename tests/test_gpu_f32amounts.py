@@ -57,3 +57,32 @@ def test_one_minute_bars_float32_amounts_vs_reference(orc, fused):
 @pytest.mark.parametrize("fused", [False, True])
 def test_one_second_bars_float32_amounts_vs_reference(orc, fused):
     _run(orc, "s1_", "s1_close_indices", "s1_n", 1.0, fused)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_long_bars_float32_amounts_vs_reference(orc, fused):
+    """Bars of 70 001 / 100 / 129 900 / 1 / 16 499 / 8 500 / 194 999 ticks (tests/golden/long_bars_reference.npz, made by
+    oracle/gen_longbars.py with the reference's own four reducers): the workgroup-per-bar schedules -- OHLCV + median, order flow
+    with its tick-order redo, footprints on one LDS histogram, trade-size features by chunks of np.sum -- against the REFERENCE."""
+    from finmlkit_amd import engine
+    d = G.load("long_bars_reference")
+    n = int(d["lb_n"])
+    ts, px, _, sd = orc.synth(42, 0, n)
+    am = G.long_bars_amounts()
+    t = engine.DeviceTrades.from_numpy(ts, px, am, sd)
+    assert not t.amount_is_f64
+    ci = engine.DeviceArray.from_host(t.ctx, d["lb_close_indices"])
+    if fused:
+        o, dd, nz, off, flat, bar, bad = t.bars_fused(ci, 0.01, 3.0, want_median=True)
+    else:
+        o = t.bar_ohlcv(ci)
+        dd, nz = t.bar_directional(ci)
+        off, flat, bar, bad = t.bar_footprints(ci, o["low"], o["high"], 0.01, 3.0)
+    assert int(bad.to_host()[0]) == 0
+    o, flat, bar, dd = engine.to_host(o), engine.to_host(flat), engine.to_host(bar), engine.to_host(dd)
+    theta = d["lb_theta"]
+    np.testing.assert_array_equal(o["median_trade_size"], theta)
+    t32 = t.bar_trade_size(ci, theta, 5.0)
+    nd = G.check_f32_amount_vectors(d, "lb_", n, "lb_close_indices", o, dd, (np.diff(off.to_host()), flat, bar), t32,
+                                    what=f"HIP {'fused' if fused else 'separate'} long bars")
+    assert nd <= 2, nd

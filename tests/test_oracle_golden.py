@@ -356,3 +356,23 @@ def test_trade_size_over_bar_lengths_against_reference_vectors(orc, kind):
             np.testing.assert_allclose(g, d[kind + "_" + k], rtol=2e-5, atol=0, equal_nan=True, err_msg=f"{kind} {k}")
         else:
             np.testing.assert_array_equal(g, d[kind + "_" + k], err_msg=f"{kind} {k}")
+
+
+def test_oracle_on_long_bars_against_reference_vectors(orc):
+    """oracle/gen_longbars.py: the reference's four bar reducers on bars of 70 001 / 100 / 129 900 / 1 / 16 499 / 8 500 / 194 999 ticks
+    (float32 lognormal sizes, float64 carriers where Numba's typing makes the accumulators float64) -- the lengths only the workgroup
+    schedules of the HIP path serve, which until round 3 were pinned to the oracle alone."""
+    d = G.load("long_bars_reference")
+    n = int(d["lb_n"])
+    ts, px, _, sd = orc.synth(42, 0, n)
+    am = G.long_bars_amounts()
+    np.testing.assert_array_equal(am[::9973], d["lb_amount_check"])
+    ci = d["lb_close_indices"]
+    o = dict(zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], orc.comp_bar_ohlcv(px, am, ci)))
+    dd = dict(zip(G.DIR_KEYS, orc.comp_bar_directional_features(px, am, ci, sd)))
+    off, flat, bar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o["low"], o["high"], 3.0)
+    theta = d["lb_theta"]
+    np.testing.assert_array_equal(theta, o["median_trade_size"])
+    t32 = dict(zip(G.TS_KEYS, orc.comp_bar_trade_size_features(am, theta, ci, 5.0)))
+    nd = G.check_f32_amount_vectors(d, "lb_", n, "lb_close_indices", o, dd, (np.diff(off), flat, bar), t32, what="oracle long bars")
+    assert nd <= 2
