@@ -21,6 +21,9 @@
 #include "fmk_dpp.h"
 #include "fmk_scan.h"
 
+// (float)log1p(v) as a call: its constants do not occupy registers across a kernel's bar loop (defined with the one-read kernels)
+static __device__ __attribute__((noinline)) float tsm_log1p(double v);
+
 template <bool AF64, int NREG>
 __device__ __forceinline__ double ts_percentile95(const void *amount, int64_t start, int64_t cnt, int lane,
                                                   typename MedKey<AF64>::K *buf, double thr = 0.0, double *block_out = nullptr)
@@ -1335,6 +1338,15 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         __builtin_amdgcn_wave_barrier();
         n_left = 0;
     };
+    double parg = 0.0;
+    int64_t pbar = -1;
+    int npend = 0;
+    auto flush_log = [&]() {
+        if (npend == 0) return;
+        const float lg = tsm_log1p(parg);
+        if ((ri >> 1) < npend && pbar >= 0) ((ri & 1) ? o_p95 : o_mean)[pbar] = lg;
+        npend = 0;
+    };
     for (int64_t it = (int64_t)blockIdx.x * TSR_WAVES + w; it < niter; it += nwaves) {
         const int64_t q = 4 * it + row;                                // four bars per wave, one per row of 16 lanes
         const bool have = q < todo;
@@ -1377,20 +1389,29 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         const float tf = tsr_pairwise([fb](int i) { return fb[i]; }, L, ri, steps);
         // ---- keys (16 per lane: element r * 16 + ri in key[r]), block volume
         uint32_t key[16];
-        double block = 0.0;
         uint32_t kmn = MK::MAXK, kmx = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = r * 16 + ri;
             key[r] = i < L ? MK::tokey(raw[r]) : MK::MAXK;
-            const double a = (double)__uint_as_float(raw[r]);
-            block += (i < L && a > thr) ? a : 0.0;
             kmn = key[r] < kmn ? key[r] : kmn;
             kmx = (i < L && key[r] > kmx) ? key[r] : kmx;
         }
-        block = fmk_row_sum(block);
         kmn = fmk_row_umin(kmn);
         kmx = fmk_row_umax(kmx);
+        // block volume: (double)a > thr  <=>  a > the largest float32 not above thr; skipped when no size of the wave's bars is
+        double block = 0.0;
+        float thr_f = (float)thr;
+        if ((double)thr_f > thr) thr_f = tsm_val(tsm_key(thr_f) - 1);
+        const bool nan_bar = kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF;
+        if (__ballot(L > 0 && (nan_bar || (float)MK::value(kmx) > thr_f)) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = __uint_as_float(raw[r]);
+                block += (double)((r * 16 + ri < L && a > thr_f) ? a : 0.f);
+            }
+            block = fmk_row_sum(block);
+        }
         // ---- the two order statistics of np.percentile(., 95)
         const float vi = (float)(L - 1) * (95.0f / 100.0f);
         const int fl = (int)floorf(vi);
@@ -1444,9 +1465,16 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         }
         // ---- results (base.py:591-609)
         const double mean = (double)(tf / (float)L), sum = (double)tf;
-        const float gsum = tsr_pairwise([fb, tf](int i) { const float qq = fb[i] / tf; return qq * qq; }, L, ri, steps);
-        // ONE log1p evaluation serves both columns: lane 0 of the row takes the mean, lane 1 the percentile
-        const float lg = (float)log1p((ri == 0 ? mean : p95) / thr);
+        // the shares a / total as float64 products (k_bar_trade_size_mid explains why that is the correctly rounded float32 quotient
+        // unless it is subnormal: then the wave repeats with the division)
+        const double rinv = 1.0 / (double)tf;
+        bool sub = false;
+        float gsum = tsr_pairwise([fb, rinv, &sub](int i) {
+            const float qq = (float)((double)fb[i] * rinv);
+            sub |= __builtin_isfpclass(qq, 0x0090);
+            return qq * qq; }, L, ri, steps);
+        if (__ballot(sub && L > 0 && tf != 0.f) != 0)
+            gsum = tsr_pairwise([fb, tf](int i) { const float qq = fb[i] / tf; return qq * qq; }, L, ri, steps);
         const bool live = L > 0 && th != 0.0;
         if (mine && ri == 0) {
             float pct = NAN, gini = NAN;
@@ -1454,10 +1482,14 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
                 pct = (float)(block / sum);
                 gini = L == 1 ? 0.f : 1.0f - gsum;
             }
-            o_mean[b] = live ? lg : NAN; o_pct[b] = pct; o_gini[b] = gini;
+            o_pct[b] = pct; o_gini[b] = gini;
         }
-        if (mine && ri == 1) o_p95[b] = live ? lg : NAN;
+        // mean_size_rel and size_95_rel = log1p(. / threshold) in float64: the arguments of a row's last eight bars wait in its lanes
+        // (2j: the mean of the j-th, 2j + 1: its percentile) and are evaluated together
+        if ((ri >> 1) == npend) { parg = live ? (ri & 1 ? p95 : mean) / thr : NAN; pbar = mine ? b : -1; }
+        if (++npend == 8) flush_log();
     }
+    flush_log();
     flush();
 }
 
