@@ -86,7 +86,7 @@ def test_trade_size_kit_and_errors(orc):
 
 @pytest.mark.parametrize("interval,amounts", [(1.0, "dyadic"), (1.0, "lognormal32"), (2.5, "lognormal32"), (0.3, "lognormal32"),
                                               (1.0, "nan"), (400.0, "ties"), (10.0, "lognormal32"), (10.0, "nan"),
-                                              (7.0, "dyadic")])
+                                              (7.0, "dyadic"), (5.0, "tiny"), (10.0, "blocks")])
 @pytest.mark.parametrize("mode", ["2", "0", "3"])
 def test_trade_size_one_lane_per_bar(orc, monkeypatch, interval, amounts, mode):
     """Short float32 bars through the lane-per-bar schedule (FMK_TS_LANES=2 forces it whatever the number of bars; 3 = sixteen
@@ -104,6 +104,12 @@ def test_trade_size_one_lane_per_bar(orc, monkeypatch, interval, amounts, mode):
         am[rng.integers(0, n, 300)] = np.nan
     if amounts == "ties":
         am = np.where(rng.random(n) < 0.6, np.float32(0.001), am).astype(np.float32)
+    if amounts == "tiny":           # subnormal shares a / total (the sixteen-lane kernel's float64-product shares fall back to the division)
+        am = (am * np.float32(1e-30)).astype(np.float32)
+        am[rng.integers(0, n, 2000)] = np.float32(3e12)
+        am[rng.integers(0, n, 2000)] = np.float32(1e-44)
+    if amounts == "blocks":         # sizes above the block threshold in some bars only
+        am[rng.integers(0, n, 400)] *= np.float32(300.0)
     _, ci = orc._time_bar_indexer(ts, interval)
     ci = ci.copy()
     nb = len(ci) - 1
