@@ -129,7 +129,7 @@ def check_f32_amount_vectors(d, prefix, n, ci_key, ohlcv, directional, footprint
 
 
 # ---- trade-size features over the bar-length axis (oracle/gen_tradesize_lengths.py made the expected columns with the reference) ----
-TS_LENGTH_KINDS = ["lognormal", "lots", "dyadic"]
+TS_LENGTH_KINDS = ["lognormal", "lots", "dyadic", "lognormal64"]
 TS_KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
 # both sides of every edge between the schedules of the HIP path (64 / 65 lanes -> rows, 128 / 129 rows -> one wave, the tree shapes at
 # 1 024 / 1 025 and 1 296 / 1 297, 1 920 / 1 921 one wave -> two, 3 824 / 3 825, 7 648 / 7 649, 15 296 / 15 297, 30 592 / 30 593 -> the
@@ -140,14 +140,16 @@ TS_LENGTHS = [1, 7, 8, 20, 63, 64, 65, 100, 128, 129, 200, 256, 257, 300, 600, 1
 
 
 def tradesize_lengths_inputs(kind):
-    """-> (float32 amounts, theta float64[B], close indices int64[B+1]) of the `kind` stream; deterministic"""
-    seed = {"lognormal": 11, "lots": 12, "dyadic": 13}[kind]
+    """-> (amounts: float32, float64 for "lognormal64"; theta float64[B]; close indices int64[B+1]) of the `kind` stream; deterministic"""
+    seed = {"lognormal": 11, "lots": 12, "dyadic": 13, "lognormal64": 14}[kind]
     rng = np.random.default_rng(seed)
     lens = list(TS_LENGTHS)
     rng.shuffle(lens)
     ci = np.cumsum([-1] + lens).astype(np.int64)
     n = int(ci[-1]) + 1
-    if kind == "lognormal":
+    if kind == "lognormal64":       # float64 sizes: np.sum's chunks and trees in float64, the block volume added in tick order
+        am = rng.lognormal(-1.0, 1.2, n)
+    elif kind == "lognormal":
         am = rng.lognormal(-1.0, 1.2, n).astype(np.float32)
     elif kind == "lots":            # decimal lot sizes: heavy ties, none of them a dyadic number
         am = (np.round(rng.lognormal(-1.0, 1.5, n), 2) + 0.01).astype(np.float32)
