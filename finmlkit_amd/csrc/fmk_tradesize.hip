@@ -287,16 +287,17 @@ __device__ __forceinline__ float tsm_opaque(float v) { asm volatile("" : "+v"(v)
 __device__ __forceinline__ int tsm_key(float x) { const int b = __float_as_int(x); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float tsm_val(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-// The node of np.sum's tree over n elements at the end of the 4-bit path `path` (most significant bit first: 0 = left half):
+// The node of np.sum's tree over n elements at the end of the D-bit path `path` (most significant bit first: 0 = left half):
 // [off, off + len).  alive: the path ends in a leaf of its own (a leaf reached before the path is used up belongs to the path whose
 // remaining bits are zero; len = 0 otherwise).  sp bit l: the node at level l of the path had split.
+template <int D = 4>
 __device__ __forceinline__ void tsm_leaf(int n, int path, int &off, int &len, unsigned &sp)
 {
     off = 0; len = n; sp = 0;
     bool alive = true;
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const bool bit = (path >> (3 - l)) & 1;
+    for (int l = 0; l < D; ++l) {
+        const bool bit = (path >> (D - 1 - l)) & 1;
         const bool split = len > 128;
         const int n2 = (len >> 1) & ~7;
         sp |= split ? 1u << l : 0u;
@@ -348,11 +349,23 @@ __device__ __forceinline__ float tsm_tree(const float (&x)[ROUNDS][KMAX], const 
             res += tsm_dpp<FMK_DPP_ROW_SHL(5)>(ty);
             res += tsm_dpp<FMK_DPP_ROW_SHL(6)>(ty);
         }
-        if (i8 == 0) slots[2 * grp + R] = res;
+        if (i8 == 0) slots[(ROUNDS == 4 ? 4 : 2) * grp + R] = res;
     }
     __builtin_amdgcn_wave_barrier();
-    float v = slots[lane & 15];
+    float v = slots[lane & (ROUNDS == 4 ? 31 : 15)];
     __builtin_amdgcn_wave_barrier();
+    if constexpr (ROUNDS == 4) {
+        // five levels of splits (bars of up to 3 848 ticks): 32 slots in the lanes of two rows; the root's halves meet across them
+        float w5;
+        w5 = v + tsm_dpp<FMK_DPP_ROW_SHL(1)>(v); v = ((sp_slot >> 4) & 1) && (lane & 1) == 0 ? w5 : v;
+        w5 = v + tsm_dpp<FMK_DPP_ROW_SHL(2)>(v); v = ((sp_slot >> 3) & 1) && (lane & 3) == 0 ? w5 : v;
+        w5 = v + tsm_dpp<FMK_DPP_ROW_SHL(4)>(v); v = ((sp_slot >> 2) & 1) && (lane & 7) == 0 ? w5 : v;
+        w5 = v + tsm_dpp<FMK_DPP_ROW_SHL(8)>(v); v = ((sp_slot >> 1) & 1) && (lane & 15) == 0 ? w5 : v;
+        const float left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        const float right = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const unsigned sp0 = (unsigned)__builtin_amdgcn_readlane((int)sp_slot, 0);
+        return (sp0 & 1) ? left + right : left;
+    }
     // up the levels: slot g is the leftmost slot of its node at level l iff its low 4 - l bits are zero; the right child starts 2^(3-l) slots on
     float w;
     if constexpr (ROUNDS == 2) { w = v + tsm_dpp<FMK_DPP_ROW_SHL(1)>(v); v = ((sp_slot >> 3) & 1) && (lane & 1) == 0 ? w : v; }
@@ -441,7 +454,8 @@ struct TsmWg {
 // One bar (W == 1) or one wave's sub-tree [a, a + wcnt) of a bar of cnt sizes (W > 1) -> the arguments of the two log1p columns
 // (evaluated for 32 bars at a time by the caller), pct_block, size_gini; with W > 1 the results are wave 0's.
 template <int KMAX, int ROUNDS, int W>
-__device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int wcnt, int cnt, const int (&off2)[2], const int (&len2)[2],
+__device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int wcnt, int cnt, const int (&off2)[ROUNDS < 2 ? 2 : ROUNDS],
+                                        const int (&len2)[ROUNDS < 2 ? 2 : ROUNDS],
                                         unsigned sp_slot, double th, double theta_mult, int lane, float *slots, float *cbuf,
                                         TsmWg<W> &wg, double &mean_arg, double &p95_arg, float &pct, float &gini)
 {
@@ -642,6 +656,26 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int wcnt, i
 // (a call, so that the constants of log1p do not occupy registers across the bar loop)
 static __device__ __attribute__((noinline)) float tsm_log1p(double v) { return (float)log1p(v); }
 
+// A bar of TSM_MAX < n <= TSM_MAX5 ticks whose tree has five levels of splits and leaves of at most 95 elements everywhere (decided
+// from n alone: the nodes of a level lie between the left-most -- shortest -- and the right-most one) fits ONE wave: four rounds of
+// eight leaves, eleven accumulator terms per lane, 48 size registers.  Two waves per bar cost twice the time per tick of one (the
+// exchanges), so the one-wave kernel takes these bars -- 2-minute bars of the bench tape: 2 400 ticks, 32 leaves of 75 -- and the
+// two-wave kernel skips them (the same test in both).
+#define TSM_MAX5 3848                  // (a sixth level from 3 849 elements)
+__device__ __forceinline__ bool tsm_one_wave5(int n)
+{
+    if (n <= TSM_MAX || n > TSM_MAX5) return false;
+    int nlo = n, nhi = n, depth = 0;
+    bool same_depth = true;
+    while (nhi > 128) {
+        same_depth = same_depth && nlo > 128;
+        nlo = (nlo >> 1) & ~7;
+        nhi -= (nhi >> 1) & ~7;
+        ++depth;
+    }
+    return same_depth && depth == 5 && nhi <= 95;
+}
+
 // `rest` (a list in k_bar_trade_size's format: [0] = count, [32 ...] = bar numbers): the bars neither this kernel nor the
 // workgroup kernels (regular bars of TSM_MAX < ticks <= wg_hi) take
 template <int WAVES>
@@ -713,6 +747,62 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     if (npend > 0) flush();
 }
 
+// One wave per bar, five levels: the bars of `list` (1 920 < ticks <= 3 824) that pass tsm_one_wave5.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 3) void k_bar_trade_size_mid5(const float *__restrict__ amount, const double *__restrict__ theta,
+                                                                       const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
+                                                                       int64_t n, double theta_mult, float *__restrict__ o_mean,
+                                                                       float *__restrict__ o_p95, float *__restrict__ o_pct,
+                                                                       float *__restrict__ o_gini)
+{
+    __shared__ float s_slots[WAVES][32];
+    __shared__ unsigned s_sp[WAVES][32];
+    __shared__ float s_cbuf[WAVES][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    TsmWg<1> wg{nullptr, wib, lane, 0, 0};
+    double parg = 0.0;                                                       // (the waiting log1p arguments, as in k_bar_trade_size_mid)
+    int64_t pbar = 0;
+    int npend = 0;
+    auto flush = [&]() {
+        const float lg = tsm_log1p(parg);
+        if (lane < 2 * npend) ((lane & 1) ? o_p95 : o_mean)[pbar] = lg;
+        npend = 0;
+    };
+    const int64_t n_list = list[0];
+    for (int64_t q = wave0; q < n_list; q += nwaves) {
+        const int64_t b = fmk_uniform(list[1 + q]);
+        const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
+        if (!(s >= -1 && e <= n - 1) || !tsm_one_wave5((int)(e - s))) continue;          // (the two-wave kernel's, or the three-pass one's)
+        const int cnt = (int)(e - s);
+        const double th = theta[b];
+        double mean_arg = NAN, p95_arg = NAN;
+        float pct = NAN, gini = NAN;
+        if (th != 0.0) {
+            // the leaves at the ends of the paths 4g .. 4g + 3
+            int off4[4], len4[4]; unsigned sp4[4];
+            const int grp = lane >> 3;
+#pragma unroll
+            for (int R = 0; R < 4; ++R) tsm_leaf<5>(cnt, 4 * grp + R, off4[R], len4[R], sp4[R]);
+            if ((lane & 7) == 0) {
+#pragma unroll
+                for (int R = 0; R < 4; ++R) s_sp[wib][4 * grp + R] = sp4[R];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned sp_slot = s_sp[wib][lane & 31];
+            __builtin_amdgcn_wave_barrier();
+            tsm_bar<11, 4, 1>(amount + s + 1, cnt, cnt, off4, len4, sp_slot, th, theta_mult, lane, s_slots[wib], s_cbuf[wib], wg, mean_arg,
+                              p95_arg, pct, gini);
+        }
+        if (lane == 0) { o_pct[b] = pct; o_gini[b] = gini; }
+        if ((lane >> 1) == npend) { parg = (lane & 1) ? p95_arg : mean_arg; pbar = b; }
+        if (++npend == 32) flush();
+    }
+    if (npend > 0) flush();
+}
+
 // W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 15 840 < ticks <= 3 824 / 7 648 / 15 840 / 16 384 for 2 / 4 / 8 / 16 waves;
 // beyond 8 192 ticks a bar is two of np.sum's chunks: half of the waves for the first, the others for the rest).
 #define TSM_WG_PER_WAVE 1912
@@ -745,6 +835,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
         const int64_t s = fmk_uniform(ci[b]), e = fmk_uniform(ci[b + 1]);
         if (!(s >= -1 && e <= n - 1)) continue;                              // (irregular close indices: the three-pass kernel's)
         const int cnt = (int)(e - s);
+        if (W == 2 && tsm_one_wave5(cnt)) continue;                          // (the one-wave kernel's: five levels, small leaves)
         // the wave's sub-tree.  np.sum adds a bar of more than 8 192 ticks in chunks of 8 192 (fmk_np_sum): up to 8 192 ticks the bar
         // is ONE tree and the W waves follow the split rule along the bits of the wave number; eight or sixteen waves also take a bar
         // of two chunks -- the first is W / 2 sub-trees of exactly 2 048 / 1 024 elements (waves 0 .. W / 2 - 1; a 2 048-element tree
@@ -1635,6 +1726,8 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         unsigned long long *rest = nullptr;                           // the bars the one-read kernels leave to the three-pass ones
         if (mid_on) {
             const float *af = (const float *)d_amount;
+            k_bar_trade_size_mid5<4><<<(unsigned)(ctx->n_cu * 16), 256, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[0], n, theta_mult,
+                                                                                      d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
             k_bar_trade_size_wg<2><<<(unsigned)(ctx->n_cu * 16), 128, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[0], n, theta_mult,
                                                                                     d_mean_size_rel, d_size_95_rel, d_pct_block, d_size_gini);
             k_bar_trade_size_wg<4><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(af, d_theta, d_close_idx, wg_lists[1], n, theta_mult,
