@@ -235,6 +235,16 @@ def other_configs(trades, ctx, args):
             "fmk_comp_bar_trade_size_dev", trades.amount.p, C.c_int(trades.amount_is_f64), c_i64(n), o60["median_trade_size"].p,
             ci.p, c_i64(ci.n), C.c_double(5.0), *[k.p for k in keys4]))
         del o60, keys4
+        # ... and on 2-minute / 10-minute / hourly bars (2 400 / 12 000 / 72 000 ticks: one wave with five tree levels, eight waves on two
+        # of np.sum's chunks, the sub-tree workgroup -- profiles/r03_trade_size.txt)
+        for tag, iv in (("2min", 120.0), ("10min", 600.0), ("hourly", 3600.0)):
+            _, civ = trades.time_bar_index(iv)
+            ov = trades.bar_ohlcv(civ)
+            kv = [DeviceArray(ctx, int(civ.n) - 1, np.float32) for _ in range(4)]
+            out[f"trade_size_{tag}_bars_ms"] = timed(lambda: ctx.call(
+                "fmk_comp_bar_trade_size_dev", trades.amount.p, C.c_int(trades.amount_is_f64), c_i64(n), ov["median_trade_size"].p,
+                civ.p, c_i64(civ.n), C.c_double(5.0), *[k.p for k in kv]))
+            del civ, ov, kv
         # the reference's ONE published benchmark through this build's API, host-resident NumPy columns, H2D copy included
         # (examples/PerformanceTest.ipynb cells 12-14: 39 171 929 trades -> 44 640 one-minute bars, 0.1728 s warm with Numba)
         try:

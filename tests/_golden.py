@@ -131,9 +131,10 @@ def check_f32_amount_vectors(d, prefix, n, ci_key, ohlcv, directional, footprint
 # ---- trade-size features over the bar-length axis (oracle/gen_tradesize_lengths.py made the expected columns with the reference) ----
 TS_LENGTH_KINDS = ["lognormal", "lots", "dyadic", "lognormal64"]
 TS_KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
-# both sides of every edge between the schedules of the HIP path (64 / 65 lanes -> rows, 128 / 129 rows -> one wave, the tree shapes at
-# 1 024 / 1 025 and 1 296 / 1 297, 1 920 / 1 921 one wave -> two, 3 824 / 3 825, 7 648 / 7 649, 15 296 / 15 297, 30 592 / 30 593 -> the
-# sub-tree workgroup, 32 768 / 32 769 four -> sixteen waves of it, 65 536 / 65 537 its sample-bracket percentile) and lengths between
+# both sides of every edge between the schedules of the HIP path -- as they stood when the fixture was first made and as they are now
+# (64 / 65 lanes -> rows, 128 / 129 rows -> one wave, the tree shapes at 1 024 / 1 025 and 1 296 / 1 297, 1 920 / 1 921 one wave -> two
+# or one with five levels, 3 824 / 3 825, 7 648 / 7 649, 8 192 / 8 193 np.sum's second chunk, 15 840 / 15 841, 16 384 / 16 385 -> the
+# sub-tree workgroup, 32 768 / 32 769 its sample-bracket percentile, 65 536 / 65 537) and lengths between
 TS_LENGTHS = [1, 7, 8, 20, 63, 64, 65, 100, 128, 129, 200, 256, 257, 300, 600, 1023, 1024, 1025, 1200, 1296, 1297, 1800, 1920, 1921,
               2400, 3000, 3824, 3825, 5000, 7648, 7649, 12000, 15296, 15297, 24000, 30592, 30593, 32768, 32769, 50000, 65536, 65537,
               0, 90000, 1343, 1344, 1345, 2047, 2048, 2049, 4096, 4097, 8192, 8193, 8400, 15840, 15841, 16384, 16385]
