@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Bars of 129 .. 1 920 ticks (1-minute bars of a liquid tape), float32 amounts, regular close indices: one wave per bar that reads
+// Bars of 1 .. 1 920 ticks (1-minute bars of a liquid tape), float32 amounts, regular close indices: one wave per bar that reads
 // the bar ONCE (round 3).  k_bar_trade_size walks the bar three times (np.sum's tree, the order-statistic search, the tree of the
 // squared shares), builds the tree's shape twice through LDS and divides by the total with the IEEE macro: ~4 000 wave instructions
 // per 1 200-tick bar, 5.1 ms per 1e9 ticks.  Here
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void k_bar_trade_size(const voi
 //     one register through LDS and the bisection goes on there until it separates the two ranks (no cross-lane sort);
 //   * a NaN size makes the total NaN (the slots that hold no element are NaN too and are never added), so NaN bars are found there.
 // ---------------------------------------------------------------------------------------------------------------------
-#define TSM_MIN 128
+#define TSM_MIN 0                      // (bars of up to 128 ticks are one leaf: eight lanes busy -- still one read instead of three passes)
 #define TSM_MAX 1920                   // (np.sum's tree needs a fifth level from 1 929 elements)
 #define FMK_DPP_ROW_SHL(n) (0x100 + (n))
 
@@ -649,7 +649,7 @@ __device__ __forceinline__ void tsm_bar(const float *__restrict__ a, int wcnt, i
             return q * q; }, lane, slots);
         if (wg.sum(__builtin_amdgcn_ballot_w64(sub) != 0 ? 1 : 0) != 0)
             g = tsm_tree<KMAX, ROUNDS, true>(x, t, len, sp_slot, [tf](float v) { const float q = v / tf; return q * q; }, lane, slots);
-        gini = 1.0f - wg.tree(g);
+        gini = cnt == 1 ? 0.f : 1.0f - wg.tree(g);                           // (base.py:606-607: a bar of one tick)
     }
 }
 
