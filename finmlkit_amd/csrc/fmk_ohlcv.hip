@@ -937,9 +937,26 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
             // smallest v with count(key <= v) > k1: invariant c_lo = count(<= lo) <= k1 < count(<= hi) = c_hi
             uint32_t blo = kmn - 1, bhi = kmx;
             int c_lo = 0, c_hi = L;
-            for (int step = 0; step < 32; ++step) {
+            for (int step = 0; step < 40; ++step) {
                 const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > 1;
                 if (__ballot(open) == 0) break;
+                if (step == 10 || step == 15 || step == 20) {
+                    // still open after ~log2(L) + 3 halvings: the target key is TIED (decimal lot sizes) and the count never falls to
+                    // one -- the bracket then goes on halving an empty key range down to one value, 27 steps.  Snap it to the
+                    // smallest and largest key actually inside (the counts at both ends stay what they are); all equal: done
+                    uint32_t mn_in = MK::MAXK, mx_in = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r < nreg) {
+                            const bool in = key[r] > blo && key[r] <= bhi;
+                            mn_in = (in && key[r] < mn_in) ? key[r] : mn_in;
+                            mx_in = (in && key[r] > mx_in) ? key[r] : mx_in;
+                        }
+                    mn_in = fmk_row_umin(mn_in);
+                    mx_in = fmk_row_umax(mx_in);
+                    if (open) { bhi = mx_in; blo = (mn_in == mx_in ? mx_in : mn_in) - 1; }
+                    continue;
+                }
                 const uint32_t pivot = blo + ((bhi - blo) >> 1);
                 int c = 0;
 #pragma unroll

@@ -1514,9 +1514,25 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         // bisection of the key range down to one value takes; only a tied target runs the bisection to its end
         uint32_t lo = kmn - 1, hi = kmx;                               // (lo = kmn - 1 counts 0 keys; a wrap at kmn == 0 is a NaN bar)
         int c_lo = 0, c_hi = L;
-        for (int step = 0; step < 32; ++step) {
+        for (int step = 0; step < 40; ++step) {
             const bool open = L > 0 && hi - lo > 1 && c_hi - c_lo > 1;
             if (__ballot(open) == 0) break;
+            if (step == 10 || step == 15 || step == 20) {
+                // a TIED target (decimal lots) never leaves one key in the bracket: snap the bracket to the smallest and largest key
+                // inside it (k_bar_ohlcv_rows explains); all equal: done
+                uint32_t mn_in = MK::MAXK, mx_in = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nreg) {
+                        const bool in = key[r] > lo && key[r] <= hi;
+                        mn_in = (in && key[r] < mn_in) ? key[r] : mn_in;
+                        mx_in = (in && key[r] > mx_in) ? key[r] : mx_in;
+                    }
+                mn_in = fmk_row_umin(mn_in);
+                mx_in = fmk_row_umax(mx_in);
+                if (open) { hi = mx_in; lo = (mn_in == mx_in ? mx_in : mn_in) - 1; }
+                continue;
+            }
             const uint32_t pivot = lo + ((hi - lo) >> 1);
             int c = 0;
 #pragma unroll
