@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
         if (!isnan) {
             // invariant: count(key <= blo) = clo <= k1  and  count(key <= bhi) = chi > k2
             uint32_t blo = mn - 1, bhi = mx;
-            int clo = 0, chi = cnt, par = 0;
+            int clo = 0, chi = cnt, par = 0, nstep = 0;
             bool done = false;
             while (!done) {
                 if (chi - clo <= 64) {
@@ -1126,6 +1126,35 @@ __device__ __forceinline__ void ohm_bar(const double *__restrict__ price, const 
                     done = true;
                 } else if (bhi - blo == 1) { v1 = v2 = bhi; done = true; }       // all candidates are the same key
                 else {
+                    if (nstep == 10 || nstep == 16 || nstep == 22) {
+                        // more than 64 keys left after this many halvings: the middle ranks sit in a TIE (decimal lot sizes) and the
+                        // bracket would go on halving an empty key range down to one value (27 steps).  Snap it to the smallest
+                        // and largest key inside (the counts at its ends stay what they are); all equal: one more round ends it
+                        uint32_t a = MK::MAXK, bb = 0;
+#pragma unroll
+                        for (int r = 0; r < NREG; ++r) {
+                            const uint32_t k = key[r];
+                            const bool in = k > blo && k <= bhi;
+                            a = (in && k < a) ? k : a;
+                            bb = (in && k > bb) ? k : bb;
+                        }
+                        a = med_wave_umin<uint32_t>(a);
+                        bb = med_wave_umax<uint32_t>(bb);
+                        if (lane == 0) { sh.below[w] = a; sh.above[w] = bb; }
+                        __syncthreads();
+                        uint32_t mn_in = sh.below[0], mx_in = sh.above[0];
+#pragma unroll
+                        for (int k = 1; k < NW; ++k) {
+                            mn_in = sh.below[k] < mn_in ? sh.below[k] : mn_in;
+                            mx_in = sh.above[k] > mx_in ? sh.above[k] : mx_in;
+                        }
+                        __syncthreads();
+                        bhi = mx_in;
+                        blo = (mn_in == mx_in ? mx_in : mn_in) - 1;
+                        ++nstep;
+                        continue;
+                    }
+                    ++nstep;
                     const uint32_t pivot = blo + ((bhi - blo) >> 1);
                     int c = 0;
 #pragma unroll
