@@ -152,6 +152,20 @@ struct MedBar {
         below = med_wave_umax<K>(a);
         above = med_wave_umin<K>(b);
     }
+    // smallest and largest key in (lo, hi] (register classes)
+    __device__ __forceinline__ void inside_minmax(K lo, K hi, K &mn, K &mx)
+    {
+        K a = MK::MAXK, b = 0;
+#pragma unroll
+        for (int r = 0; r < (NREG > 0 ? NREG : 1); ++r) {
+            const K k = key[r];
+            const bool in = k > lo && k <= hi;
+            a = (in && k < a) ? k : a;
+            b = (in && k > b) ? k : b;
+        }
+        mn = med_wave_umin<K>(a);
+        mx = med_wave_umax<K>(b);
+    }
     // write the keys in (lo, hi] (at most 64 of them) to buf[0..m), one slot each
     __device__ __forceinline__ void compact(K lo, K hi, K *buf)
     {
@@ -182,7 +196,10 @@ struct MedBar {
 
 // Exact order statistics of ranks k1 <= k2 <= k1+1 (0-based) of the bar's keys; bar.key[] (register
 // path) must already hold the keys.  Returns false when the bar contains a NaN (keys outside [-inf, +inf]).
-template <bool AF64, int NREG, bool EXACT>
+// SNAP (register classes): more than 64 keys left after 10 / 16 / 22 halvings means the ranks sit in a TIE (decimal lot sizes) and the
+// bracket would go on halving an empty key range down to one value; it is then set to the smallest and largest key inside it
+// (the counts at its ends stay what they are).  Off where the instantiation's register budget is tuned (the fused small-bar kernel).
+template <bool AF64, int NREG, bool EXACT, bool SNAP = false>
 __device__ __forceinline__ bool med_rank_pair(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf,
                                               int64_t k1, int64_t k2, typename MedKey<AF64>::K &v1,
                                               typename MedKey<AF64>::K &v2)
@@ -197,7 +214,16 @@ __device__ __forceinline__ bool med_rank_pair(MedBar<AF64, NREG, EXACT> &bar, ty
     // invariant: count(key <= lo) = clo <= k1  and  count(key <= hi) = chi > k2
     K lo = mn - 1, hi = mx;
     int64_t clo = 0, chi = cnt;
-    for (;;) {
+    for (int nstep = 0;; ++nstep) {
+        if constexpr (SNAP && NREG > 0) {
+            if (chi - clo > 64 && hi - lo > 1 && (nstep == 10 || nstep == 16 || nstep == 22)) {
+                K mn_in, mx_in;
+                bar.inside_minmax(lo, hi, mn_in, mx_in);
+                hi = mx_in;
+                lo = (mn_in == mx_in ? mx_in : mn_in) - 1;
+                continue;
+            }
+        }
         if (chi - clo <= 64) {
             // <= 64 candidates in (lo, hi]: compact -> sort across lanes -> read the ranks
             buf[lane] = MK::MAXK;
@@ -224,13 +250,13 @@ __device__ __forceinline__ bool med_rank_pair(MedBar<AF64, NREG, EXACT> &bar, ty
 }
 
 // np.median of the bar's amounts (NaN if any amount is NaN, like NumPy).
-template <bool AF64, int NREG, bool EXACT>
+template <bool AF64, int NREG, bool EXACT, bool SNAP = false>
 __device__ __forceinline__ double med_search(MedBar<AF64, NREG, EXACT> &bar, typename MedKey<AF64>::K *buf)
 {
     typedef MedKey<AF64> MK;
     typename MK::K v1, v2;
     const int64_t cnt = bar.cnt;
-    if (!med_rank_pair<AF64, NREG, EXACT>(bar, buf, (cnt - 1) >> 1, cnt >> 1, v1, v2)) return NAN;
+    if (!med_rank_pair<AF64, NREG, EXACT, SNAP>(bar, buf, (cnt - 1) >> 1, cnt >> 1, v1, v2)) return NAN;
     // np.median: mean of the two middle elements == (a + b) / 2.0 ; odd count: the middle one
     return (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
 }

@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv_phased(const double *__restri
         ohlcv_finish<false>(o, b, price, start, e, hi, lo, tv, td, lane);
         if constexpr (MEDIAN) {
             bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
-            const double m = med_search<false, NKEY, false>(bar, buf);
+            const double m = med_search<false, NKEY, false, true>(bar, buf);
             if (lane == 0) o.median[b] = m;
         }
     }
