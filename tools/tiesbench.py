@@ -39,5 +39,6 @@ for iv in ivs:
         keys = [DeviceArray(ctx, nb, np.float32) for _ in range(4)]
         c = best(lambda: ctx.call("fmk_comp_bar_trade_size_dev", tt.amount.p, C.c_int(tt.amount_is_f64), c_i64(tt.n), theta.p, ci.p,
                                   c_i64(ci.n), c_f64(5.0), *[k.p for k in keys]))
-        row.append(f"{name}: ohlcv {a:6.2f}  + median {b:6.2f}  trade size {c:6.2f} ms |")
+        d = best(lambda: tt.bars_fused(ci, 0.01, 3.0, want_median=True)) if os.environ.get("TIES_CFG4") else float("nan")
+        row.append(f"{name}: ohlcv {a:6.2f}  + median {b:6.2f}  trade size {c:6.2f}  cfg 4 {d:6.2f} ms |")
     print(" ".join(row), flush=True)
