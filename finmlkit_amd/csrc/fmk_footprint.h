@@ -126,9 +126,15 @@ __device__ __forceinline__ bool fp_certified_per_key(const FpStats &st, int q, c
 
 // Level rows + comp_footprint_features (base.py:755-850) of ONE bar from the wave's LDS histogram:
 //   vol[2L] float32 (buy = 2l, sell = 2l+1), cnt[2L], aux[2*lmax] scratch, stk[64] ints.  `base` = CSR row offset.
+// fast_sum (histograms in LDS with lmax >= 512): the two np.sum over the levels by the parallel tree routine (fmk_np_sum ->
+// fmk_pairwise_par), its tables in the idle second half of aux.  The node-by-node walk of fmk_pairwise costs ~50 000 cycles per
+// sum over 1 500 levels -- bars that cover many levels in few ticks (a fine price_tick_size on a fast market) spent most of their
+// time there (tools/widebench.py: 19.6 ms per 2e8 ticks at 1 500 levels per bar against 0.9 ms at 40).
 __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t base, int L, int64_t low, int lmax,
-                                            double imb_mult, int lane, float *vol, int *cnt, float *aux, int *stk)
+                                            double imb_mult, int lane, float *vol, int *cnt, float *aux, int *stk,
+                                            bool fast_sum = false)
 {
+    int *pstk = (int *)(aux + lmax);
     // ---- pass A: write the level rows, total[l] = buy + sell (float32), argmax, vwap numerator
     float *tot = aux;
     float best = -INFINITY;
@@ -160,7 +166,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     if (best_i == 0x7FFFFFFF) best_i = 0;      // empty guard: np.argmax -> 0
     num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
-    const float total = fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()
+    const float total = fast_sum ? fmk_np_sum([tot](int i) { return tot[i]; }, L, lane, pstk)
+                                 : fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()
     const bool stats = total > 0.f && L > 0;                         // base.py:836
     const double vwap = stats ? num / (double)total : 0.0;
 
@@ -192,7 +199,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     skew = fmk_dpp_reduce(skew, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
     double gini = 0.0;
-    if (stats) gini = (double)(1.0f - fp_pairwise_f32(q2, L, lane, stk));   // base.py:847-848 (float32)
+    if (stats) gini = (double)(1.0f - (fast_sum ? fmk_np_sum([q2](int i) { return q2[i]; }, L, lane, pstk)
+                                               : fp_pairwise_f32(q2, L, lane, stk)));   // base.py:847-848 (float32)
     // ---- longest signed run (base.py:801-819).  The reference scans the levels once; here every lane scans a
     //      contiguous segment (prefix run, first-longest run inside, run state at its end) and the 64 summaries
     //      are folded in segment order -- same result, incl. "the FIRST run of maximal length wins".

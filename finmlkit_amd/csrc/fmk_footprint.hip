@@ -450,7 +450,8 @@ static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
 // ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
-template <bool AF64, bool GLOBAL, bool MED = false>
+// FAST: the classes of 512 levels and more (fp_emit_bar's fast_sum; a template flag so that the 128 / 256-level instantiations keep their code)
+template <bool AF64, bool GLOBAL, bool MED = false, bool FAST = false>
 __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict__ price,
                                                         const void *__restrict__ amount,
                                                         const int8_t *__restrict__ side,
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
         __builtin_amdgcn_wave_barrier();
 
-        fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk);
+        fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk, FAST);
         if constexpr (MED) {
             // np.median of the bar's trade sizes (base.py:401-404); an empty bar has median 0 (base.py:352-361)
             const int64_t n_t = e - s;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(64 * FPW_WAVES) void k_bar_footprints_wide(const do
         __syncthreads();
         if (w == 0) {
             if (bad_level && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
-            fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk);
+            fp_emit_bar(o, b, base, L, low, lmax, imb_mult, lane, vol, cnt, aux, stk, lmax >= 512);
         }
         __syncthreads();
     }
@@ -1232,6 +1233,12 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
                                                                                    gscratch, 0, only, nullptr, nullptr, skip_above, skip_lmax);
+    else if (lmax >= 512)
+        k_bar_footprints<AF64, false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
+                                                                                       off, lmin, lmax, o, n_bad,
+                                                                                       force_ordered, nullptr,
+                                                                                       fp_lds_atomics_in_lane_order(ctx), only,
+                                                                                       nullptr, nullptr, skip_above, skip_lmax);
     else
         k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
