@@ -1207,8 +1207,8 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
             else {
                 // the bracket lives in a wave from bar to bar and every wave's FIRST bar takes the generic selection: as many
                 // workgroups as are resident at once (grid-stride over the bars), not 64 per CU
-                static int occ[4] = {0, 0, 0, 0};
-                const int slot = lmax <= 128 ? 0 : (lmax <= 256 ? 1 : (lmax <= 512 ? 2 : 3));
+                static int occ[5] = {0, 0, 0, 0, 0};
+                const int slot = lmax <= 128 ? 0 : (lmax <= 256 ? 1 : (lmax <= 512 ? 2 : (lmax <= 1024 ? 3 : 4)));
                 if (!occ[slot]) {
                     int nblk = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_bar_footprints<false, false, true>, wpb * 64, smem) !=
@@ -1282,9 +1282,11 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     unsigned long long *bad = (unsigned long long *)d_n_bad_level;
     // (the 256-level class: on bars of unequal length the longer ones -- more levels -- ran in the 512 class at 50 KB of LDS per
     // workgroup, three workgroups per CU: profiles/r03_real_bar_lengths.txt)
-    constexpr int NCLS = 5;
-    const int LMAX[NCLS] = {128, 256, 512, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
-    static const int WPB[NCLS] = {4, 4, 4, 1, 1};
+    // (the 1 024-level class, two waves per workgroup: bars of 513 .. 1 024 levels ran with ONE wave per workgroup at 49 KB of LDS,
+    // three waves per CU: tools/widebench.py)
+    constexpr int NCLS = 6;
+    const int LMAX[NCLS] = {128, 256, 512, 1024, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
+    static const int WPB[NCLS] = {4, 4, 4, 2, 1, 1};
     // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
     // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
     // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
