@@ -320,3 +320,31 @@ def test_cot_with_nan_level_sums(orc, long_bars):
     b = int(np.searchsorted(ci, n // 3, side="left")) - 1
     tv = wflat["buy_volumes"][woff[b]:woff[b + 1]] + wflat["sell_volumes"][woff[b]:woff[b + 1]]
     assert np.isnan(tv).any() and wbar["cot_price_levels"][b] == wflat["price_levels"][woff[b]:woff[b + 1]][np.argmax(tv)]
+
+
+@pytest.mark.parametrize("w,amounts", [(8, "dyadic"), (25, "dyadic"), (25, "full"), (70, "dyadic")])
+def test_footprints_bars_of_many_levels(orc, w, amounts):
+    """Bars of ~1 200 ticks whose price path covers hundreds to thousands of levels (steps of up to w ticks: a fine price_tick_size on a
+    fast market): the level classes beyond 256 -- 512, the two-wave 1 024 class, 2 048, the global-scratch class -- with the two
+    np.sum over the levels by the parallel tree routine (fp_emit_bar's fast_sum); dyadic sizes (integer-unit path) and full-mantissa
+    ones (tick order).  Every array against the oracle."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr, comp_bar_ohlcv
+    rng = np.random.default_rng(100 + w)
+    n = 90_000
+    px = np.round(np.maximum(60000.0 + 0.01 * np.cumsum(rng.integers(-w, w + 1, n)), 1.0), 2)
+    am = (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32) if amounts == "dyadic" else rng.lognormal(-1, 1.2, n).astype(np.float32)
+    sd = rng.choice(np.array([-1, 1], dtype=np.int8), n)
+    lens = [int(v) for v in rng.integers(600, 2400, 60)]
+    ci = np.cumsum([-1] + lens).astype(np.int64)
+    ci = ci[ci <= n - 1]
+    o = orc.comp_bar_ohlcv(px, am, ci)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    lev = np.diff(woff)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, f"w={w} {amounts}: levels per bar {int(lev.min())}..{int(lev.max())}")
+    if w == 8:
+        assert lev.max() > 256 and lev.min() < 512
+    if w == 25:
+        assert (lev > 1024).any() and (lev <= 1024).any() and (lev > 512).any()
+    if w == 70:
+        assert (lev > 2048).any()
