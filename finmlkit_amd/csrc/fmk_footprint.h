@@ -24,7 +24,8 @@ struct FpOut {
 };
 static_assert(sizeof(FpOut) == sizeof(fmk_footprint_out), "ABI struct mismatch");
 
-#define FP_MAX_LEVELS 2048                 // widest bar whose histogram lives in LDS
+#define FP_MAX_LEVELS 2048                 // widest bar whose histogram lives in LDS with the 24 B / level layout
+#define FP_MAX_LEVELS_LDS 4096             // ... with the 16 B / level layout of the classes from 512 levels (one wave per CU there)
 #define FP_MAX_LEVELS_GLOBAL (1 << 24)     // wider bars: histogram in global scratch (one wave per bar)
 #define FP_Q_UNKNOWN 0x7FFFFFFF
 
@@ -134,7 +135,9 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
                                             double imb_mult, int lane, float *vol, int *cnt, float *aux, int *stk,
                                             bool fast_sum = false)
 {
-    int *pstk = (int *)(aux + lmax);
+    // aux == nullptr (the wave kernel's classes of 512 levels and more): no copy of the level totals -- buy + sell is formed again
+    // where it is needed -- and the tree routine's tables in stk (FMK_PW_PAR_STK ints there): 16 instead of 24 B of LDS per level
+    int *pstk = aux ? (int *)(aux + lmax) : stk;
     // ---- pass A: write the level rows, total[l] = buy + sell (float32), argmax, vwap numerator
     float *tot = aux;
     float best = -INFINITY;
@@ -149,7 +152,7 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         o.buy_ticks[base + l] = bc;
         o.sell_ticks[base + l] = sc;
         const float t = bv + sv;                                     // base.py:822
-        tot[l] = t;
+        if (aux) tot[l] = t;
         // first argmax within my lanes; np.argmax treats a NaN as the maximum: the FIRST NaN wins and is never replaced
         if (t > best || (t != t && best == best)) { best = t; best_i = l; }
         num += (double)(low + l) * (double)t;
@@ -166,7 +169,8 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     if (best_i == 0x7FFFFFFF) best_i = 0;      // empty guard: np.argmax -> 0
     num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
-    const float total = fast_sum ? fmk_np_sum([tot](int i) { return tot[i]; }, L, lane, pstk)
+    const float total = fast_sum ? (aux ? fmk_np_sum([tot](int i) { return tot[i]; }, L, lane, pstk)
+                                        : fmk_np_sum([vol](int i) { return vol[2 * i] + vol[2 * i + 1]; }, L, lane, pstk))
                                  : fp_pairwise_f32(tot, L, lane, stk);          // total_volumes.sum()
     const bool stats = total > 0.f && L > 0;                         // base.py:836
     const double vwap = stats ? num / (double)total : 0.0;
@@ -186,7 +190,7 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
             o.buy_imbalances[base + l] = bi;
             o.sell_imbalances[base + l] = si;
             sign[l] = bi ? 1 : (si ? -1 : 0);
-            const float t = tot[l];
+            const float t = aux ? tot[l] : bv + sv;
             if (stats) {
                 skew += ((double)(low + l) - vwap) * (double)t;
                 const float q = t / total;

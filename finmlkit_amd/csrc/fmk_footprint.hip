@@ -470,7 +470,9 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
-    const size_t per_wave = (size_t)lmax * 24 + 256 + ((MED && !GLOBAL) ? (size_t)FP_MED_CAP * 4 : 0);
+    // FAST: 16 B per level (no aux area) + the tree routine's tables
+    const size_t per_wave = FAST ? (size_t)lmax * 16 + FMK_PW_PAR_STK * 4
+                                 : (size_t)lmax * 24 + 256 + ((MED && !GLOBAL) ? (size_t)FP_MED_CAP * 4 : 0);
     // the wave's histogram: LDS for the three narrow classes (LDS-typed pointers: ds_add / ds_read), a slice of global
     // scratch for bars wider than 2048 levels (same code; a wave's own stores are visible to its later loads)
     unsigned char *mine;
@@ -478,8 +480,8 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     else mine = smem + (size_t)wib * per_wave;
     float *vol = (float *)mine;                                   // [2*lmax]  buy = 2l, sell = 2l+1
     int *cnt = (int *)(mine + (size_t)lmax * 8);                  // [2*lmax]
-    float *aux = (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
-    int *stk = (int *)(mine + (size_t)lmax * 24);                 // 64 ints
+    float *aux = FAST ? nullptr : (float *)(mine + (size_t)lmax * 16);             // [2*lmax]  tot[], later q2[]
+    int *stk = (int *)(mine + (size_t)lmax * (FAST ? 16 : 24));   // 64 ints (FAST: FMK_PW_PAR_STK)
     // the median's bracket and candidate list (LDS classes with the straight-line sweep only; otherwise every bar takes the
     // generic selection on its re-read amounts)
     FpMed med;
@@ -1180,11 +1182,13 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
     const bool med = d_median != nullptr && !AF64;
-    size_t smem = (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
+    const bool fast = !med && lmax >= 512 && lmax <= FP_MAX_LEVELS_LDS;          // the 16 B / level layout (k_bar_footprints<.., FAST>)
+    size_t smem = fast ? (size_t)wpb * ((size_t)lmax * 16 + FMK_PW_PAR_STK * 4)
+                       : (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
     int64_t blocks = fmk_ceil_div(nb, wpb);
     int64_t cap = (int64_t)ctx->n_cu * 64;
     unsigned char *gscratch = nullptr;
-    if (lmax > FP_MAX_LEVELS) {
+    if (lmax > (med ? FP_MAX_LEVELS : FP_MAX_LEVELS_LDS)) {
         // wide bars: one wave per workgroup, histogram in global scratch (<= 8 GB in total, >= 16 waves)
         const size_t per_wave = (size_t)lmax * 24 + 256;
         cap = (int64_t)(((size_t)8 << 30) / per_wave);
@@ -1233,13 +1237,15 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
         k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
                                                                                    gscratch, 0, only, nullptr, nullptr, skip_above, skip_lmax);
-    else if (lmax >= 512)
+    else if (fast) {
+        if (smem > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_bar_footprints<AF64, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         k_bar_footprints<AF64, false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
                                                                                        fp_lds_atomics_in_lane_order(ctx), only,
                                                                                        nullptr, nullptr, skip_above, skip_lmax);
-    else
+    } else
         k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
@@ -1284,9 +1290,12 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     // workgroup, three workgroups per CU: profiles/r03_real_bar_lengths.txt)
     // (the 1 024-level class, two waves per workgroup: bars of 513 .. 1 024 levels ran with ONE wave per workgroup at 49 KB of LDS,
     // three waves per CU: tools/widebench.py)
-    constexpr int NCLS = 6;
-    const int LMAX[NCLS] = {128, 256, 512, 1024, FP_MAX_LEVELS, (int)max_levels};    // last class: global-scratch histogram
-    static const int WPB[NCLS] = {4, 4, 4, 2, 1, 1};
+    // ... and classes of 4 096 / 6 144 levels on LDS (16 B per level: 67 / 100 KB per wave) instead of a histogram in global scratch
+    constexpr int NCLS = 8;
+    const bool lds_wide = !d_median;                                    // (the in-sweep median keeps the 24 B layout: up to 2 048 levels)
+    const int LMAX[NCLS] = {128, 256, 512, 1024, FP_MAX_LEVELS, lds_wide ? 4096 : FP_MAX_LEVELS, lds_wide ? FP_MAX_LEVELS_LDS : FP_MAX_LEVELS,
+                            (int)max_levels};                           // last class: global-scratch histogram
+    static const int WPB[NCLS] = {4, 4, 4, 2, 1, 1, 1, 1};
     // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
     // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
     // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
@@ -1399,12 +1408,14 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     }
     for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
-        if (LMAX[k] > lmin_start) {
+        // (the widest class of a call needs no more LDS than the call's widest bar)
+        const int lm = (k >= 3 && max_levels < LMAX[k]) ? (int)max_levels : LMAX[k];
+        if (LMAX[k] > lmin_start && LMAX[k] > lmin) {
             rc = amount_is_f64
                      ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                       imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, nullptr, nullptr, skip_above, skip_lmax)
+                                       imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, nullptr, nullptr, skip_above, skip_lmax)
                      : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                        imb_mult, d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, rest, d_median, saw_long, skip_above, skip_lmax);
+                                        imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, d_median, saw_long, skip_above, skip_lmax);
         }
         lmin = LMAX[k];
     }
@@ -1413,11 +1424,13 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         lmin = 0;
         for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
             if (k > 0 && max_levels <= LMAX[k - 1]) break;
-            rc = amount_is_f64
-                     ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
-                                       d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, wide_defer)
-                     : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
-                                        d_level_offsets, lmin, LMAX[k], WPB[k], o, bad, wide_defer);
+            const int lm = (k >= 3 && max_levels < LMAX[k]) ? (int)max_levels : LMAX[k];
+            if (LMAX[k] > lmin)
+                rc = amount_is_f64
+                         ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                           d_level_offsets, lmin, lm, WPB[k], o, bad, wide_defer)
+                         : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                            d_level_offsets, lmin, lm, WPB[k], o, bad, wide_defer);
             lmin = LMAX[k];
         }
     }
