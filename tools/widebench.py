@@ -11,6 +11,12 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
 ws = [int(v) for v in sys.argv[2:]] or [0, 5, 15, 50]
 ctx = _ffi.default_context()
 t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
+if os.environ.get("WIDE_FULL_MANTISSA"):      # full-mantissa float32 sizes: every bar takes the tick-ordered path
+    import ctypes as C
+    from finmlkit_amd._ffi import c_i64
+    am2 = DeviceArray(ctx, n, np.float32)
+    ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(42), c_i64(n), am2.p)
+    t = engine.DeviceTrades(ctx, t.ts, t.price, am2, t.side)
 clock, ci = t.time_bar_index(60.0)
 nb = ci.n - 1
 rng = np.random.default_rng(2)
