@@ -342,6 +342,14 @@ def test_footprints_bars_of_many_levels(orc, w, amounts):
     lev = np.diff(woff)
     off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
     _check_fp(off, flat, bar, woff, wflat, wbar, f"w={w} {amounts}: levels per bar {int(lev.min())}..{int(lev.max())}")
+    if w == 25 and amounts == "full":
+        # ... and through the fused cfg-4 call (same fill, its own size pass)
+        from finmlkit_amd import engine
+        ts = 1_700_000_000_000_000_000 + np.arange(n, dtype=np.int64) * 50_000_000
+        t = engine.DeviceTrades.from_numpy(ts, px, am, sd)
+        o2, dd, nz, off2, flat2, bar2, bad = t.bars_fused(engine.DeviceArray.from_host(t.ctx, ci), 0.01, 3.0, want_median=True)
+        assert int(bad.to_host()[0]) == 0
+        _check_fp(off2.to_host(), engine.to_host(flat2), engine.to_host(bar2), woff, wflat, wbar, "fused, many levels")
     if w == 8:
         assert lev.max() > 256 and lev.min() < 512
     if w == 25:
