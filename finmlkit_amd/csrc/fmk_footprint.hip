@@ -1291,11 +1291,13 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     // (the 1 024-level class, two waves per workgroup: bars of 513 .. 1 024 levels ran with ONE wave per workgroup at 49 KB of LDS,
     // three waves per CU: tools/widebench.py)
     // ... and classes of 4 096 / 6 144 levels on LDS (16 B per level: 67 / 100 KB per wave) instead of a histogram in global scratch
-    constexpr int NCLS = 8;
+    // (half-step classes from 512 levels: a bar of 1 100 levels in the 1 536 class leaves room for six waves per CU, in the 2 048 class for four)
+    constexpr int NCLS = 10;
     const bool lds_wide = !d_median;                                    // (the in-sweep median keeps the 24 B layout: up to 2 048 levels)
-    const int LMAX[NCLS] = {128, 256, 512, 1024, FP_MAX_LEVELS, lds_wide ? 4096 : FP_MAX_LEVELS, lds_wide ? FP_MAX_LEVELS_LDS : FP_MAX_LEVELS,
+    const int LMAX[NCLS] = {128, 256, 512, lds_wide ? 768 : 1024, 1024, lds_wide ? 1536 : FP_MAX_LEVELS, FP_MAX_LEVELS,
+                            lds_wide ? 3072 : FP_MAX_LEVELS, lds_wide ? FP_MAX_LEVELS_LDS : FP_MAX_LEVELS,
                             (int)max_levels};                           // last class: global-scratch histogram
-    static const int WPB[NCLS] = {4, 4, 4, 2, 1, 1, 1, 1};
+    static const int WPB[NCLS] = {4, 4, 4, 2, 2, 1, 1, 1, 1, 1};
     // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
     // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
     // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
