@@ -1193,7 +1193,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
         const size_t per_wave = (size_t)lmax * 24 + 256;
         cap = (int64_t)(((size_t)8 << 30) / per_wave);
         if (cap < 16) cap = 16;
-        if (cap > (int64_t)ctx->n_cu * 8) cap = (int64_t)ctx->n_cu * 8;
+        if (cap > (int64_t)ctx->n_cu * 32) cap = (int64_t)ctx->n_cu * 32;     // (every wave slot of the chip: 65 -> 47 ms per 2e8 ticks of 6 000-level bars against n_cu * 8)
         if (blocks > cap) blocks = cap;
         void *scr;
         FMK_TRY(fmk_scratch(ctx, per_wave * (size_t)blocks + 256, &scr));
