@@ -1445,7 +1445,10 @@ __global__ __launch_bounds__(64 * TSR_WAVES) void k_bar_trade_size_rows(const fl
         const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
         const bool regular = s_b >= -1 && e_b >= s_b && e_b <= n - 1;
         const int64_t len_b = e_b - s_b;
-        const bool mine = have && regular && len_b <= 256;             // (an empty bar too: its NaN row)
+        // (an empty bar too: its NaN row.  Not the bars of 249 .. 255 ticks: their right half -- n - (n / 2 rounded down to a multiple of
+        // 8) = 129 .. 135 elements -- splits once more in NumPy's tree, three leaves; found by the fuzzer late in round 3, the row
+        // schedule had summed it as ONE leaf: an ulp in mean_size_rel / pct_block of such bars)
+        const bool mine = have && regular && len_b <= 256 && len_b - ((len_b >> 1) & ~(int64_t)7) <= 128;
         // ---- the others: remembered, handed on in blocks of up to 64
         {
             const uint64_t lo = __ballot(have && !mine && ri == 0);    // lanes 0, 16, 32, 48 speak for their rows

@@ -243,3 +243,23 @@ def test_trade_size_over_bar_lengths_against_reference_vectors(kind):
             np.testing.assert_allclose(g, d[kind + "_" + k], rtol=2e-5, atol=0, equal_nan=True, err_msg=f"{kind} {k}")
         else:
             np.testing.assert_array_equal(g, d[kind + "_" + k], err_msg=f"{kind} {k}")
+
+
+@pytest.mark.parametrize("mode", ["3", "2"])
+def test_trade_size_rows_schedule_leaves_three_leaf_bars(orc, monkeypatch, mode):
+    """Bars of 249 .. 255 ticks have THREE leaves in NumPy's tree (the right half, 129 .. 135 elements, splits once more): the
+    sixteen-lanes-per-bar schedule (two leaves at most) must hand them on.  tools/fuzz_parity.py seed 42001 case 11160 found them
+    summed as two leaves (an ulp in mean_size_rel and pct_block); every length from 240 to 260 here, bit for bit."""
+    from finmlkit_amd.bar.base import comp_bar_trade_size_features
+    monkeypatch.setenv("FMK_TS_LANES", mode)
+    rng = np.random.default_rng(42001)
+    lens = list(range(240, 261)) * 6 + [int(v) for v in rng.integers(1, 300, 200)]
+    rng.shuffle(lens)
+    ci = np.cumsum([-1] + lens).astype(np.int64)
+    n = int(ci[-1]) + 1
+    am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    theta = np.full(len(lens), float(np.median(am)))
+    want = orc.comp_bar_trade_size_features(am, theta, ci, 3.0)
+    got = comp_bar_trade_size_features(am, theta, ci, 3.0)
+    for k, g, w in zip(KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=f"{k} mode={mode}")
