@@ -31,6 +31,15 @@ def test_fuzz_mid_length_bars_fixed_seed(orc):
     assert not fails, "\n".join(fails[:5])
 
 
+def test_fuzz_short_bar_streams_fixed_seed(orc):
+    """... and on STREAMS of 17 000 .. 40 000 short bars (geometric lengths around 12 .. 200 ticks with the schedules' edges mixed in:
+    64 / 65, 128 / 129, 248 / 249 .. 255 / 256 / 257): what selects the lane-per-bar and sixteen-lanes-per-bar schedules and their
+    hand-over lists, for all four reducers (460 cases over two seeds were run when the mode was added)."""
+    from tools.fuzz_longbars import campaign
+    fails = campaign(8, 20261001, orc, verbose=False, mid="short")
+    assert not fails, "\n".join(fails[:5])
+
+
 def test_fuzz_sharded_fixed_seed():
     """tools/fuzz_sharded.py: random world sizes (2..8 virtual ranks), ticks per rank, stream density and bar interval; the
     concatenated per-rank outputs of the sharded time-bar step equal the un-sharded run bit for bit (60 configurations of

@@ -17,9 +17,22 @@ EDGE_MID = [128, 129, 256, 257, 1024, 1025, 1296, 1297, 1344, 1345, 1920, 1921, 
             8193, 15840, 15841, 16384, 16385, 32768, 32769]
 
 
+# mid="short": STREAMS of 17 000 .. 40 000 short bars -- what selects the lane-per-bar and sixteen-lanes-per-bar schedules and their
+# hand-over lists (bars of 0 .. 64 / 65 .. 256 ticks, longer ones in between; the three-leaf lengths 249 .. 255 of NumPy's tree)
+EDGE_SHORT = [0, 1, 7, 8, 9, 32, 33, 63, 64, 65, 127, 128, 129, 192, 193, 240, 248, 249, 250, 255, 256, 257, 300, 1344, 1345, 2048]
+
+
 def case(rng, orc, pkg, k, mid=False):
     lens = []
-    for _ in range(int(rng.integers(2, 9)) if not mid else int(rng.integers(4, 24))):
+    if mid == "short":
+        nbars = int(rng.integers(17_000, 40_000))
+        mean = float(rng.choice([12.0, 30.0, 60.0, 110.0, 200.0]))
+        lens = np.minimum(rng.geometric(1.0 / mean, nbars) - 1, 3000).astype(np.int64)
+        where = rng.integers(0, nbars, nbars // 50)
+        lens[where] = rng.choice(EDGE_SHORT, len(where))
+        if rng.random() < 0.6: lens = np.maximum(lens, 1)     # (no empty bar: the order-flow features are then defined for every bar and get compared)
+        lens = [int(v) for v in lens]
+    for _ in range(0 if mid == "short" else (int(rng.integers(2, 9)) if not mid else int(rng.integers(4, 24)))):
         u = rng.random()
         if mid:
             if u < 0.3: lens.append(int(rng.choice(EDGE_MID)))
@@ -45,7 +58,7 @@ def case(rng, orc, pkg, k, mid=False):
     if rng.random() < 0.1: am[int(rng.integers(0, n))] = -am[int(rng.integers(0, n))]
     sd = rng.choice(np.array([-1, 1, 1, -1, 0], dtype=np.int8), size=n)
     tick = float(rng.choice([step, step / 5, step * 4]))
-    what = f"case {k}: lens {lens}, first {first}, step {step}, tick {tick}, amounts kind {kind} ({am.dtype})"
+    what = f"case {k}: lens {lens if len(lens) < 40 else str(lens[:12]) + ' ... ' + str(len(lens)) + ' bars'}, first {first}, step {step}, tick {tick}, amounts kind {kind} ({am.dtype})"
     o = orc.comp_bar_ohlcv(px, am, ci)
     got = pkg["base"].comp_bar_ohlcv(px, am, ci)
     for key, g, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median"], got, o):
@@ -96,9 +109,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     from oracle import oracle as orc
     orc.build()
-    mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
+    mid = (sys.argv[3] if sys.argv[3] == "short" else sys.argv[3] == "mid") if len(sys.argv) > 3 else False
     fails = campaign(cases, seed, orc, mid=mid)
-    print(f"{cases} {'mid-length' if mid else 'long'}-bar cases, seed {seed}: {len(fails)} failures")
+    print(f"{cases} {'short-bar-stream' if mid == 'short' else 'mid-length-bar' if mid else 'long-bar'} cases, seed {seed}: {len(fails)} failures")
     sys.exit(1 if fails else 0)
 
 
