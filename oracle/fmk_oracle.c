@@ -40,7 +40,7 @@
  *     (oracle/gen_longbars.py).  Building (4) found that np.sum adds an array in chunks of 8 192 elements (orc_pairwise_f32 below):
  *     this file had used one pairwise tree, right up to 8 192 elements and an ulp off in ~30 % of the longer bars.
  * (5) live, in the build container: tools/fuzz_reference.py runs tools/fuzz_parity.py's random cases with the reference's modules
- *     in the package's place (tests/test_reference_live.py: 600 fixed-seed cases; campaigns of 7 500 more were clean).
+ *     in the package's place (tests/test_reference_live.py: 600 fixed-seed cases; campaigns of 11 500 more were clean).
  *
  * Citations are relative to /root/reference/.
  */
