@@ -356,3 +356,40 @@ def test_footprints_bars_of_many_levels(orc, w, amounts):
         assert (lev > 1024).any() and (lev <= 1024).any() and (lev > 512).any()
     if w == 70:
         assert (lev > 2048).any()
+
+
+@pytest.mark.parametrize("amounts", ["dyadic", "full"])
+def test_footprints_exact_level_class_edges(orc, amounts):
+    """Bars whose level count sits exactly on and one beyond every class edge of the wave kernel (128, 256, 512, 768, 1 024, 1 536,
+    2 048, 3 072, 4 096: the 24 B / 16 B per level layouts, two and one wave per workgroup, LDS and global scratch), bars of 300 .. 5 000
+    ticks in random order.  Every array against the oracle."""
+    from finmlkit_amd.bar.base import comp_bar_footprints_csr
+    rng = np.random.default_rng(77)
+    edges = [127, 128, 129, 255, 256, 257, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2048, 2049, 3071,
+             3072, 3073, 4095, 4096, 4097, 5000, 1, 2]
+    rng.shuffle(edges)
+    px_parts, lens = [], []
+    for L in edges:
+        m = int(rng.integers(max(300, L // 2), 5000)) if L > 2 else int(rng.integers(1, 50))
+        lv = rng.integers(0, L, m)
+        lv[rng.integers(0, m)] = 0
+        if m > 1:
+            j = int(rng.integers(0, m))
+            lv[j if lv[j] != 0 or L == 1 else (j + 1) % m] = L - 1
+            if not (lv == 0).any(): lv[0] = 0
+            if not (lv == L - 1).any(): lv[-1] = L - 1
+        else:
+            lv[0] = 0
+        px_parts.append(1000.0 + 0.01 * lv)
+        lens.append(m)
+    px = np.round(np.concatenate(px_parts), 2)
+    n = len(px)
+    am = (rng.integers(1, 4097, n) * 2.0 ** -10).astype(np.float32) if amounts == "dyadic" else rng.lognormal(-1, 1.2, n).astype(np.float32)
+    sd = rng.choice(np.array([-1, 1], dtype=np.int8), n)
+    ci = np.cumsum([-1] + lens).astype(np.int64)
+    o = orc.comp_bar_ohlcv(px, am, ci)
+    woff, wflat, wbar = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    lev = np.diff(woff)
+    assert set(int(v) for v in lev) >= {128, 129, 512, 513, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 3072, 3073, 4096, 4097}, sorted(lev)
+    off, flat, bar = comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    _check_fp(off, flat, bar, woff, wflat, wbar, f"exact level edges, {amounts}")
