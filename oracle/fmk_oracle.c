@@ -562,11 +562,25 @@ int orc_comp_bar_trade_size(const void *amounts, int is_f64, int64_t n, const do
         int64_t cnt = close_idx[i + 1] - close_idx[i];
         if (cnt > maxcnt) maxcnt = cnt;
     }
-    double *sd = (double *)malloc(sizeof(double) * (size_t)maxcnt);
-    float *sf = (float *)malloc(sizeof(float) * (size_t)maxcnt);
-    double *sq = (double *)malloc(sizeof(double) * (size_t)maxcnt);
-    if (!sd || !sf || !sq) { free(sd); free(sf); free(sq); return ORC_E_NOMEM; }
+    /* bars are independent (numba.prange in the reference, base.py:581): with ORC_THREADS > 1 the bar loop is an OpenMP parallel-for
+     * with per-thread scratch, the arithmetic inside a bar untouched (the full-size parity test runs it on all host cores) */
+    int nthreads = orc_threads();
+    double *sd_all = (double *)malloc(sizeof(double) * (size_t)maxcnt * (size_t)nthreads);
+    float *sf_all = (float *)malloc(sizeof(float) * (size_t)maxcnt * (size_t)nthreads);
+    double *sq_all = (double *)malloc(sizeof(double) * (size_t)maxcnt * (size_t)nthreads);
+    if (!sd_all || !sf_all || !sq_all) { free(sd_all); free(sf_all); free(sq_all); return ORC_E_NOMEM; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
     for (int64_t i = 0; i < nb; ++i) {
+#ifdef _OPENMP
+        const size_t tnum = (size_t)omp_get_thread_num();
+#else
+        const size_t tnum = 0;
+#endif
+        double *sd = sd_all + tnum * (size_t)maxcnt;
+        float *sf = sf_all + tnum * (size_t)maxcnt;
+        double *sq = sq_all + tnum * (size_t)maxcnt;
         mean_size_rel[i] = size_95_rel[i] = pct_block[i] = size_gini[i] = NAN;
         int64_t start = close_idx[i] + 1, end = close_idx[i + 1];
         if (start > end) continue;                   /* base.py:584, on the raw indices */
@@ -615,7 +629,7 @@ int orc_comp_bar_trade_size(const void *amounts, int is_f64, int64_t n, const do
             size_gini[i] = 1.0f - orc_pairwise_f32(sf, cnt);
         }
     }
-    free(sd); free(sf); free(sq);
+    free(sd_all); free(sf_all); free(sq_all);
     return ORC_OK;
 }
 

@@ -492,3 +492,26 @@ def test_all_bars_cfg4_against_threaded_oracle(big, host_cols, orc):
         np.testing.assert_array_equal(bar[key].to_host()[:k], wbar[key], err_msg=key)
     np.testing.assert_allclose(bar["vp_skew"].to_host()[:k], wbar["vp_skew"], atol=1e-6)
     print(f"cfg 4: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")
+
+
+@pytest.mark.parametrize("interval", [60.0, 150.0, 600.0, 3600.0])
+def test_all_bars_trade_size_against_threaded_oracle(big, host_cols, orc, interval):
+    """comp_bar_trade_size_features of ALL bars at full size against the oracle (its bar loop on all host cores): 1-minute bars (one
+    wave reading the bar once), 150-second bars (one wave with five tree levels / two waves), 10-minute bars (eight waves on two of
+    np.sum's chunks), hourly bars (the sub-tree workgroup, sample-bracket percentile) -- every column bit for bit."""
+    import time
+    engine, t, n = big
+    (ts, px, am, sd), m = host_cols
+    _, ci = t.time_bar_index(interval)
+    cih = ci.to_host()
+    k = _bars_inside(cih, m, n)
+    assert k >= 100
+    theta_d = t.bar_ohlcv(ci)["median_trade_size"]
+    theta = theta_d.to_host()
+    got = t.bar_trade_size(ci, theta, 5.0)
+    t0 = time.perf_counter()
+    want = orc.comp_bar_trade_size_features(am, theta[:k], cih[:k + 1], 5.0)
+    dt = time.perf_counter() - t0
+    for key, w in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], want):
+        np.testing.assert_array_equal(got[key][:k], w, err_msg=f"{key} interval {interval}")
+    print(f"trade size, {interval:.0f} s bars: {k} bars equal the oracle's; oracle {dt:.1f} s")
