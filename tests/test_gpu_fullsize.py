@@ -457,10 +457,21 @@ def test_all_bars_cfg2_against_threaded_oracle(big, host_cols, orc):
 
 
 def test_all_bars_cfg4_against_threaded_oracle(big, host_cols, orc):
+    _cfg4_all_bars(big, host_cols, orc, 60.0)
+
+
+@pytest.mark.parametrize("interval", [3600.0, 86400.0])
+def test_all_long_bars_cfg4_against_threaded_oracle(big, host_cols, orc, interval):
+    """... and on hourly / daily bars: the workgroup-per-bar schedules (order flow with its tick-order redo, footprints on one LDS
+    histogram, OHLCV + sample-bracket median) on ALL bars of the full-size run."""
+    _cfg4_all_bars(big, host_cols, orc, interval)
+
+
+def _cfg4_all_bars(big, host_cols, orc, interval):
     import time
     engine, t, n = big
     (ts, px, am, sd), m = host_cols
-    _, ci = t.time_bar_index(60.0)
+    _, ci = t.time_bar_index(interval)
     cih = ci.to_host()
     k = _bars_inside(cih, m, n)
     oci = cih[:k + 1]
@@ -491,7 +502,7 @@ def test_all_bars_cfg4_against_threaded_oracle(big, host_cols, orc):
     for key in ("buy_imbalances_sum", "sell_imbalances_sum", "cot_price_levels", "imb_max_run_signed", "vp_gini"):
         np.testing.assert_array_equal(bar[key].to_host()[:k], wbar[key], err_msg=key)
     np.testing.assert_allclose(bar["vp_skew"].to_host()[:k], wbar["vp_skew"], atol=1e-6)
-    print(f"cfg 4: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")
+    print(f"cfg 4, {interval:.0f} s bars: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")
 
 
 @pytest.mark.parametrize("interval", [60.0, 150.0, 600.0, 3600.0])
