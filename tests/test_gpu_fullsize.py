@@ -467,6 +467,20 @@ def test_all_long_bars_cfg4_against_threaded_oracle(big, host_cols, orc, interva
     _cfg4_all_bars(big, host_cols, orc, interval)
 
 
+@pytest.mark.parametrize("interval", [60.0, 3600.0])
+def test_all_bars_cfg4_full_mantissa_sizes_against_threaded_oracle(big, host_cols, orc, interval):
+    """... and with FULL-MANTISSA float32 sizes (what real trade sizes are): every footprint bar then takes the tick-ordered path and
+    the order-flow sums sit in the float32 tie zone far more often -- all bars of the full-size run again."""
+    import ctypes as C
+    engine, t, n = big
+    from finmlkit_amd._ffi import DeviceArray, c_i64
+    am2 = DeviceArray(t.ctx, n, np.float32)
+    t.ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(42), c_i64(n), am2.p)
+    t2 = engine.DeviceTrades(t.ctx, t.ts, t.price, am2, t.side)
+    (ts, px, am, sd), m = host_cols
+    _cfg4_all_bars((engine, t2, n), ((ts, px, am2.view(0, m).to_host(), sd), m), orc, interval)
+
+
 def _cfg4_all_bars(big, host_cols, orc, interval):
     import time
     engine, t, n = big
