@@ -392,7 +392,7 @@ template <int W>
 struct TsmWg {
     TsmX *x;
     int wib, lane, par;
-    int nw1;                           // > 0: a bar of two np.sum chunks, waves W / 2 .. W / 2 + nw1 - 1 hold the second chunk's sub-trees
+    int nchunk, nwl;                   // nchunk > 1: a bar of several np.sum chunks, four waves per chunk; nwl: the last chunk's sub-trees
     // every wave contributes a wave-uniform value and receives all W of them
     template <class T, class G>
     __device__ __forceinline__ void all(T (*buf)[16], T v, G got)
@@ -403,23 +403,26 @@ struct TsmWg {
         for (int q = 0; q < W; ++q) got(q, buf[par][q]);
         par ^= 1;
     }
-    // left + right up the top levels of a chunk's tree.  A bar of two chunks (nw1 > 0; eight or sixteen waves): the first half of
-    // the waves holds the W / 2 sub-trees of the first 8 192 elements, waves W / 2 .. W / 2 + nw1 - 1 those of the rest, and np.sum
-    // adds the chunks one after the other
+    // left + right up the top levels of a chunk's tree.  A bar of several chunks (eight waves: two, sixteen: up to four): waves
+    // 4c .. 4c + 3 hold the sub-trees of chunk c -- four of exactly 2 048 elements for a full chunk, nwl of at most 1 928 for the
+    // last --, and np.sum adds the chunks one after the other
     __device__ __forceinline__ float tree(float v)
     {
         if constexpr (W == 1) return v;
         else {
             float p[W];
             all(x->f, v, [&](int q, float u) { p[q] = u; });
-            if (W >= 8 && nw1 > 0) {
-                constexpr int H = W / 2;
+            if (W >= 8 && nchunk > 1) {
 #pragma unroll
-                for (int st = 1; st < H; st <<= 1)
+                for (int st = 1; st < 4; st <<= 1)
 #pragma unroll
                     for (int q = 0; q < W; q += 2 * st)
-                        if (q < H || st < nw1) p[q] = p[q] + p[q + st];
-                return p[0] + p[H];
+                        if ((q >> 2) < nchunk - 1 || st < nwl) p[q] = p[q] + p[q + st];
+                float tot = p[0];
+#pragma unroll
+                for (int c = 1; c < W / 4; ++c)
+                    if (c < nchunk) tot = tot + p[4 * c];
+                return tot;
             } else {
 #pragma unroll
                 for (int st = 1; st < W; st <<= 1)
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_bar_trade_size_mid(const floa
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES;
-    TsmWg<1> wg{nullptr, wib, lane, 0, 0};
+    TsmWg<1> wg{nullptr, wib, lane, 0, 1, 0};
     // mean_size_rel and size_95_rel are log1p(. / threshold) in float64: the arguments of up to 32 bars wait in the lanes (2j: the
     // mean of the j-th waiting bar, 2j + 1: its percentile) and are evaluated together -- one log1p per 32 bars instead of two per bar
     double parg = 0.0;
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void k_bar_trade_size_mid5(const flo
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES + wib;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES;
-    TsmWg<1> wg{nullptr, wib, lane, 0, 0};
+    TsmWg<1> wg{nullptr, wib, lane, 0, 1, 0};
     double parg = 0.0;                                                       // (the waiting log1p arguments, as in k_bar_trade_size_mid)
     int64_t pbar = 0;
     int npend = 0;
@@ -803,9 +806,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void k_bar_trade_size_mid5(const flo
     if (npend > 0) flush();
 }
 
-// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 15 840 < ticks <= 3 824 / 7 648 / 15 840 / 16 384 for 2 / 4 / 8 / 16 waves;
-// beyond 8 192 ticks a bar is two of np.sum's chunks: half of the waves for the first, the others for the rest).
 #define TSM_WG_PER_WAVE 1912
+// Sixteen waves hold a bar of up to four of np.sum's chunks, four waves per chunk -- if its LAST chunk (m elements) fits four sub-trees
+// of at most 1 928 elements (m <= 4 * 1 912) or is a full one; the other bars of 15 841 .. 32 768 ticks stay with k_bar_trade_size_wide
+// (the same test in both kernels).
+__device__ __forceinline__ bool tsm_quad16_fits(int64_t n)
+{
+    if (n <= FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE || n > 4 * FMK_NP_BUFSIZE) return false;
+    const int64_t m = n - ((n + FMK_NP_BUFSIZE - 1) / FMK_NP_BUFSIZE - 1) * FMK_NP_BUFSIZE;
+    return m <= 4 * TSM_WG_PER_WAVE || m == FMK_NP_BUFSIZE;
+}
+
+// W waves per bar: the regular bars of `list` (fmk_long_bar_lists: 1 920 / 3 824 / 7 648 / 15 840 < ticks <= 3 824 / 7 648 / 15 840 / 32 768 for 2 / 4 / 8 / 16 waves;
+// beyond 8 192 ticks a bar is several of np.sum's chunks, four waves per chunk).
 template <int W>
 __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__restrict__ amount, const double *__restrict__ theta,
                                                                   const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
     __shared__ unsigned s_sp[W][16];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
-    TsmWg<W> wg{&sx, wib, lane, 0, 0};
+    TsmWg<W> wg{&sx, wib, lane, 0, 1, 0};
     double parg = 0.0;                                                       // (wave 0: the waiting log1p arguments, as above)
     int64_t pbar = 0;
     int npend = 0;
@@ -838,29 +851,28 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
         if (W == 2 && tsm_one_wave5(cnt)) continue;                          // (the one-wave kernel's: five levels, small leaves)
         // the wave's sub-tree.  np.sum adds a bar of more than 8 192 ticks in chunks of 8 192 (fmk_np_sum): up to 8 192 ticks the bar
         // is ONE tree and the W waves follow the split rule along the bits of the wave number; eight or sixteen waves also take a bar
-        // of two chunks -- the first is W / 2 sub-trees of exactly 2 048 / 1 024 elements (waves 0 .. W / 2 - 1; a 2 048-element tree
-        // splits evenly: four levels), the rest (m ticks) 1, 2, 4 (or 8) sub-trees of at most 1 928 (waves W / 2 ...; the others hold nothing)
+        // of two .. four chunks, four waves per chunk -- a full chunk is four sub-trees of exactly 2 048 elements (a 2 048-element
+        // tree splits evenly: four levels), the last one (m ticks) 1, 2 or 4 sub-trees of at most 1 928 (the other waves hold nothing)
         int woff = 0, wlen = cnt, rlen = cnt;
         bool small_leaves = true;
-        wg.nw1 = 0;
+        wg.nchunk = 1; wg.nwl = 0;
         if (W >= 8 && cnt > FMK_NP_BUFSIZE) {
-            constexpr int H = W / 2, LH = LW - 1, SUB0 = FMK_NP_BUFSIZE / H;    // the first chunk: H sub-trees of exactly SUB0 = 2 048 / 1 024 elements
-            const int m = cnt - FMK_NP_BUFSIZE;
-            const int j1 = m <= TSM_WG_PER_WAVE ? 0 : m <= 2 * TSM_WG_PER_WAVE ? 1 : m <= 4 * TSM_WG_PER_WAVE ? 2 : 3;
-            if (m > FMK_NP_BUFSIZE || j1 > LH) continue;                     // (never: the list's edges)
-            wg.nw1 = 1 << j1;
-            if (wib < H) { woff = SUB0 * wib; wlen = SUB0; }
-            else {
-                const int pth = wib - H;
-                woff = FMK_NP_BUFSIZE; wlen = m;
+            const int nchunk = (cnt + FMK_NP_BUFSIZE - 1) / FMK_NP_BUFSIZE;
+            const int m = cnt - (nchunk - 1) * FMK_NP_BUFSIZE;               // the last chunk: 1 .. 8 192 elements
+            const int j1 = m <= TSM_WG_PER_WAVE ? 0 : m <= 2 * TSM_WG_PER_WAVE ? 1 : (m <= 4 * TSM_WG_PER_WAVE || m == FMK_NP_BUFSIZE) ? 2 : 3;
+            if (nchunk > W / 4 || j1 == 3) continue;                         // (k_bar_trade_size_wide's: tsm_quad16_fits)
+            wg.nchunk = nchunk; wg.nwl = 1 << j1;
+            const int chunk = wib >> 2, pth = wib & 3;
+            if (chunk < nchunk - 1) { woff = chunk * FMK_NP_BUFSIZE + 2048 * pth; wlen = 2048; }     // (8 192 splits evenly: 4 x 2 048)
+            else if (chunk == nchunk - 1 && pth < (1 << j1)) {
+                woff = chunk * FMK_NP_BUFSIZE; wlen = m;
                 for (int l = 0; l < j1; ++l) {
                     const int n2 = (wlen >> 1) & ~7;
                     if ((pth >> (j1 - 1 - l)) & 1) { woff += n2; wlen -= n2; }
                     else wlen = n2;
                 }
-                if (pth >= (1 << j1)) wlen = 0;
-            }
-            small_leaves = false;                                            // (the first chunk's leaves hold 128 elements)
+            } else { woff = 0; wlen = 0; }
+            small_leaves = false;                                            // (a full chunk's leaves hold 128 elements)
         } else {
             if (cnt > FMK_NP_BUFSIZE) continue;                              // (never: the list's edges)
 #pragma unroll
@@ -934,7 +946,8 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
                                                                       int64_t n, double theta_mult, float *__restrict__ o_mean,
                                                                       float *__restrict__ o_p95, float *__restrict__ o_pct,
                                                                       float *__restrict__ o_gini, float *__restrict__ samp,
-                                                                      uint32_t *__restrict__ cand, int64_t min_cnt, int64_t max_cnt)
+                                                                      uint32_t *__restrict__ cand, int64_t min_cnt, int64_t max_cnt,
+                                                                      int skip_quad16 = 0 /* the bars k_bar_trade_size_wg<16> takes */)
 {
     typedef MedKey<false> MK;
     __shared__ float s_tot;
@@ -951,6 +964,7 @@ __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const fl
         const int64_t b = list[1 + q], s = ci[b], e = ci[b + 1];
         const int64_t cnt64 = e - s;
         if (!(s >= -1 && e <= n - 1) || cnt64 <= min_cnt || cnt64 > max_cnt) continue;     // another launch's (or the wave kernel's: same test there)
+        if (skip_quad16 && tsm_quad16_fits(cnt64)) continue;
         const int cnt = (int)cnt64;
         const float *af = amount + (s + 1);
         const double th = theta[b];
@@ -1707,11 +1721,14 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         // (developer knob FMK_TS_MID=0: the three-pass kernels, and a workgroup per bar from TSW_MID_MIN ticks)
         const char *mv = getenv("FMK_TS_MID");
         const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
-        const int64_t wg_top = 2 * (int64_t)FMK_NP_BUFSIZE;          // (sixteen waves hold two of np.sum's chunks)
+        // eight waves hold two of np.sum's chunks (8 192 + 4 x 1 912 ticks), sixteen up to four -- those whose last chunk fits four
+        // sub-trees (tsm_quad16_fits); the others of 15 841 .. 32 768 ticks are k_bar_trade_size_wide's, which skips the ones that fit
+        const int64_t wg8_top = (int64_t)FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE;
         const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) k_bar_trade_size_wide takes
-        int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : (mid_on ? wg_top : (int64_t)TSW_MID_MIN);
-        if (mid_on && wide_min > wg_top) wide_min = wg_top;
-        const int64_t wg_upper = mid_on ? (wide_on ? wide_min : wg_top) : 0;
+        int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : (mid_on ? wg8_top : (int64_t)TSW_MID_MIN);
+        if (mid_on && wide_min > wg8_top) wide_min = wg8_top;
+        const bool quad16 = mid_on && wide_on && wide_min == wg8_top;
+        const int64_t wg_upper = mid_on ? (quad16 ? 4 * (int64_t)FMK_NP_BUFSIZE : (wide_on ? wide_min : wg8_top)) : 0;
         // regular bars of cov_lo < ticks <= cov_hi are taken by the workgroup kernels (their percentile included)
         const int64_t cov_lo = mid_on ? (int64_t)TSM_MAX : (wide_on ? wide_min : INT64_MAX);
         const int64_t cov_hi = wide_on ? (int64_t)FMK_PW_BIG_MAX_N : wg_upper;
@@ -1725,7 +1742,7 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
         }
         int64_t *wg_lists[4] = {nullptr, nullptr, nullptr, nullptr};
         if (rc == FMK_OK && mid_on) {
-            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE, 2 * FMK_NP_BUFSIZE};
+            int64_t edge[5] = {TSM_MAX, 2 * TSM_WG_PER_WAVE, 4 * TSM_WG_PER_WAVE, FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE, 4 * FMK_NP_BUFSIZE};
             for (int q = 0; q < 5; ++q) if (edge[q] > wg_upper) edge[q] = wg_upper;
             rc = fmk_long_bar_lists(ctx, d_close_idx, nb, n, 4, edge, nullptr, wg_lists);
         }
@@ -1737,10 +1754,10 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
             if (wide_min < split)
                 k_bar_trade_size_wide<4><<<(unsigned)(ctx->n_cu * 8), 256, 0, ctx->stream>>>(
                     (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
-                    d_size_gini, samp, cand, wide_min, split);
+                    d_size_gini, samp, cand, wide_min, split, quad16 ? 1 : 0);
             k_bar_trade_size_wide<16><<<(unsigned)(ctx->n_cu * 2), 1024, 0, ctx->stream>>>(
                 (const float *)d_amount, d_theta, d_close_idx, list_w, n, theta_mult, d_mean_size_rel, d_size_95_rel, d_pct_block,
-                d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N);
+                d_size_gini, samp, cand, split, (int64_t)FMK_PW_BIG_MAX_N, quad16 ? 1 : 0);
         }
         unsigned long long *rest = nullptr;                           // the bars the one-read kernels leave to the three-pass ones
         if (mid_on) {

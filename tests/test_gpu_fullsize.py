@@ -519,11 +519,12 @@ def _cfg4_all_bars(big, host_cols, orc, interval):
     print(f"cfg 4, {interval:.0f} s bars: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")
 
 
-@pytest.mark.parametrize("interval", [60.0, 150.0, 600.0, 3600.0])
+@pytest.mark.parametrize("interval", [60.0, 150.0, 600.0, 1200.0, 1500.0, 3600.0])
 def test_all_bars_trade_size_against_threaded_oracle(big, host_cols, orc, interval):
     """comp_bar_trade_size_features of ALL bars at full size against the oracle (its bar loop on all host cores): 1-minute bars (one
     wave reading the bar once), 150-second bars (one wave with five tree levels / two waves), 10-minute bars (eight waves on two of
-    np.sum's chunks), hourly bars (the sub-tree workgroup, sample-bracket percentile) -- every column bit for bit."""
+    np.sum's chunks), 20- and 25-minute bars (sixteen waves on three / four chunks, or the sub-tree workgroup where the last chunk does
+    not fit), hourly bars (the sub-tree workgroup, sample-bracket percentile) -- every column bit for bit."""
     import time
     engine, t, n = big
     (ts, px, am, sd), m = host_cols
