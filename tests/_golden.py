@@ -137,7 +137,8 @@ TS_KEYS = ["mean_size_rel", "size_95_rel", "pct_block", "size_gini"]
 # sub-tree workgroup, 32 768 / 32 769 its sample-bracket percentile, 65 536 / 65 537) and lengths between
 TS_LENGTHS = [1, 7, 8, 20, 63, 64, 65, 100, 128, 129, 200, 256, 257, 300, 600, 1023, 1024, 1025, 1200, 1296, 1297, 1800, 1920, 1921,
               2400, 3000, 3824, 3825, 5000, 7648, 7649, 12000, 15296, 15297, 24000, 30592, 30593, 32768, 32769, 50000, 65536, 65537,
-              0, 90000, 1343, 1344, 1345, 2047, 2048, 2049, 4096, 4097, 8192, 8193, 8400, 15840, 15841, 16384, 16385]
+              0, 90000, 1343, 1344, 1345, 2047, 2048, 2049, 4096, 4097, 8192, 8193, 8400, 15840, 15841, 16384, 16385, 24032, 24033, 24576,
+              24577, 32224, 32225]
 
 
 def tradesize_lengths_inputs(kind):

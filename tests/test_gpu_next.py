@@ -185,7 +185,7 @@ def test_trade_size_one_read_wave_kernel(orc, case, span):
             1344, 1500, 1919, 1920, 1921, 1928, 1929, 64, 1, 0] + [int(v) for v in rng.integers(129, 1921, 120)]
     if span == "workgroup":
         lens = [1921, 1929, 2000, 2048, 2049, 2400, 3600, 3823, 3824, 3825, 4096, 5000, 7648, 7649, 8192, 8193, 8200, 10105, 12000, 15840,
-                15841, 16000, 16384, 16385, 20000, 32768, 100, 0] + [int(v) for v in rng.integers(1921, 16385, 14)]
+                15841, 16000, 16384, 16385, 20000, 24032, 24033, 24576, 24577, 32224, 32225, 32768, 32769, 100, 0] + [int(v) for v in rng.integers(1921, 32769, 14)]
     cuts = np.cumsum([-1] + lens)
     n = int(cuts[-1]) + 10
     am = rng.lognormal(-1, 1.2, n).astype(np.float32)

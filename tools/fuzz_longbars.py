@@ -14,7 +14,7 @@ EDGE = [8191, 8192, 8193, 16383, 16384, 16385, 32767, 32768, 32769, 65535, 65536
 # 1 920 ticks, 2 / 4 / 8 / 16 waves up to 3 824 / 7 648 / 15 840 / 16 384 -- two of np.sum's 8 192-element chunks beyond 8 192; the
 # register classes of the medians and the footprints)
 EDGE_MID = [128, 129, 256, 257, 1024, 1025, 1296, 1297, 1344, 1345, 1920, 1921, 2048, 2049, 3824, 3825, 4096, 4097, 7648, 7649, 8192,
-            8193, 15840, 15841, 16384, 16385, 32768, 32769]
+            8193, 15840, 15841, 16384, 16385, 24032, 24033, 24576, 24577, 32224, 32225, 32768, 32769]
 
 
 # mid="short": STREAMS of 17 000 .. 40 000 short bars -- what selects the lane-per-bar and sixteen-lanes-per-bar schedules and their
