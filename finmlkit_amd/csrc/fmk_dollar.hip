@@ -109,7 +109,8 @@ template <bool AF64>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__restrict__ price,
                                                              const void *__restrict__ amount, int64_t n,
                                                              DD *__restrict__ tile_sum, int *__restrict__ bad,
-                                                             unsigned long long *__restrict__ dmax_bits)
+                                                             unsigned long long *__restrict__ dmax_bits, double thr,
+                                                             double *__restrict__ whale_sum)
 {
     __shared__ DD lds[4];
     // the tile's sum does not depend on the order of its terms (double-double: ~2^-104 relative), so the loads are COALESCED
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
         const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
         if (fmk_lane() == 0 && !neg && mb > __hip_atomic_load(dmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(dmax_bits, mb);
+        // ... and the sum of the increments that reach the threshold by themselves (whale trades): the reference's running sum then
+        // stays ABOVE thr for a while -- one close per tick until the backlog is gone -- and its adds round at that magnitude, which
+        // the drift bound of the decisions must know (dl_run)
+        if (m >= thr) {                                             // (wave-uniform: m is the wave's maximum)
+            double wsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < DL_ITEMS; ++k) wsum += d[k] >= thr ? d[k] : 0.0;
+            wsum = fmk_wave_sum(wsum);
+            if (fmk_lane() == 0 && !neg) atomicAdd(whale_sum, wsum);
+        }
     }
     DD tot;
     (void)dl_block_exclusive(s, lds, &tot);
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_scan_dd(DD *__restrict__ t_al
 template <bool AF64>
 __device__ __forceinline__ int dl_thread_G(const double *price, const void *amount, int64_t n, double thr,
                                            const DD *tile_base, const DD *seg_base, DD *lds, int64_t (&G)[DL_ITEMS],
-                                           double *rem = nullptr)
+                                           double *rem = nullptr, double extra = 0.0 /* see dl_run: the backlog term of the drift */)
 {
     // The thread owns 8 CONSECUTIVE ticks (the prefix runs in tick order) and loads them itself, 16 bytes per instruction (price
     // 4 x double2, amount 2 x float4 / 4 x double2).  History: eight 8-byte loads per array made every instruction touch 64
@@ -246,7 +257,7 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
                 if (r >= thr) { r -= thr; M += 1; }      // d < thr: at most one step per tick
                 if (rem) rem[k] = r;
                 G[k] = i == 0 ? 0 : M - i;
-                const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16) * thr;
+                const double tol = fmax(1e-11, ((double)(i + 1) + extra) * 2.3e-16) * thr;
                 frag += (i > 0 && fmin(r, thr - r) <= tol);
             }
         }
@@ -262,7 +273,7 @@ __device__ __forceinline__ int dl_thread_G(const double *price, const void *amou
                 const int64_t Mk = dd_floor_div(D, thr, &fd, &rr);
                 if (rem) rem[k] = rr;
                 G[k] = i == 0 ? 0 : Mk - i;
-                const double tol = fmax(1e-11, (double)(i + 1) * 2.3e-16);
+                const double tol = fmax(1e-11, ((double)(i + 1) + extra) * 2.3e-16);
                 frag += (i > 0 && fd <= tol);
             }
         }
@@ -354,13 +365,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
                                                         const int64_t *__restrict__ seg_premin,
                                                         int64_t *__restrict__ out, int64_t cap,
                                                         unsigned long long *n_frag, int64_t *__restrict__ carry_k,
-                                                        double inv_ulp, int simple, int64_t *__restrict__ last_M)
+                                                        double inv_ulp, int simple, int64_t *__restrict__ last_M, double extra)
 {
     __shared__ DD lds[4];
     __shared__ int64_t wmin[4];
     int64_t G[DL_ITEMS];
     double rem[DL_ITEMS];
-    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G, rem);
+    const int frag = dl_thread_G<AF64>(price, amount, n, thr, tile_base, seg_base, lds, G, rem, extra);
     // exclusive prefix-min over the block in tick order: thread-local then across threads
     int64_t tmin = G[0];
 #pragma unroll
@@ -460,19 +471,29 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     int64_t *d_res = ctx->d_mail + 24;
     int *d_bad = (int *)(ctx->d_mail + 26);
     unsigned long long *d_dmax = (unsigned long long *)(ctx->d_mail + 27);
-    FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 16, ctx->stream));
-    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax);
+    double *d_whale = (double *)(ctx->d_mail + 28);
+    FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 24, ctx->stream));
+    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax, thr, d_whale);
     FMK_LAUNCH_CHECK(ctx);
     k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
     DD *d_total = (DD *)(ctx->d_mail + 44);                            // sum of all increments (double-double)
     k_dl_scan_dd<<<1, DL_THREADS, 0, ctx->stream>>>(segb, gdd, gdd, d_total);
     FMK_LAUNCH_CHECK(ctx);
     // what pass 1 learned: negative / NaN increments (-> serial walk), the largest increment, the total
-    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_bad, 24, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 4, d_total, 16, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((int)ctx->h_mail[1] != 0) return 1;
     memcpy(&c.dmax, &ctx->h_mail[2], 8);
+    // The drift bound of a decision.  Without whales every add of the reference happens below 2 thr: <= (i + 1) * 2^-52 * thr after i
+    // ticks.  An increment w >= thr leaves a backlog -- cum falls from ~w to below thr by one threshold per tick -- and the adds of
+    // those ~w / thr ticks round at the magnitude of cum: their errors sum to <= 2^-53 * w^2 / (2 thr) ... for ALL whales together
+    // (a second one may arrive before the first is worked off) <= 2^-53 * W^2 / thr, W their sum.  In units of 2.3e-16 * thr that is
+    // `extra` = (W / thr)^2 more "ticks".  (Found by tools/fuzz_volume.py seed 81003, dollar cases 792 / 1143, late in round 3: with
+    // the tick count alone two closes right after a whale were certified and wrong by one tick.)
+    double whale = 0.0;
+    memcpy(&whale, &ctx->h_mail[3], 8);
+    const double extra = (whale / thr) * (whale / thr);
     static int force_minpass = -1;       // developer knob: FMK_DL_MIN_PASS=1 keeps the prefix-min pass for every input
     if (force_minpass < 0) { const char *v = getenv("FMK_DL_MIN_PASS"); force_minpass = v ? atoi(v) : 0; }
     const int simple = (c.dmax < thr && !force_minpass) ? 1 : 0;
@@ -516,7 +537,7 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     FMK_HIP(ctx, hipMemsetAsync(d_res, 0xFF, 8, ctx->stream));
     k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf,
                                                                      simple ? c.cap : c.count, d_frag, c.carry,
-                                                                     ldexp(1.0, 53 - ex), simple, d_res);
+                                                                     ldexp(1.0, 53 - ex), simple, d_res, extra);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -306,3 +306,32 @@ def test_dollar_exact_tier_end_of_stream(orc, monkeypatch):
                 t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, am)
                 np.testing.assert_array_equal(t.dollar_bar_index(thr).to_host(), orc._dollar_bar_indexer(px, am, thr))
                 assert t.last_uncertified == 0
+
+
+@pytest.mark.parametrize("whale", [3e5, 1e6])
+def test_dollar_bars_after_a_whale_are_not_certified_by_the_tick_count_alone(orc, whale):
+    """An increment of `whale` thresholds leaves a backlog: the reference closes a bar per tick while its running sum falls from
+    ~whale * thr, and those adds round at THAT magnitude -- the drift of the later decisions is (whale)^2 ticks' worth, not the tick
+    count's.  tools/fuzz_volume.py (seed 81003, dollar cases 792 / 1143) found closes right after a whale certified and wrong by one
+    tick.  The default mode equals the reference's loop; the parallel mode must REPORT decisions now (it counted none before)."""
+    from finmlkit_amd import _ffi, engine
+    rng = np.random.default_rng(792)
+    n = 600_000
+    px = np.maximum(100.0 + 0.01 * np.cumsum(rng.integers(-2, 3, size=n)), 0.01)
+    am = rng.integers(1, 20, n).astype(np.float32)
+    am[150_000] *= np.float32(whale * 3.6)
+    thr = 3594.9535145178074
+    want = orc._dollar_bar_indexer(px, am, thr)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, am)
+    got = t.dollar_bar_index(thr).to_host()
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    ctx = _ffi.default_context()
+    ctx.set_fast_threshold(True)
+    try:
+        fast = t.dollar_bar_index(thr).to_host()
+        unc = t.last_uncertified
+    finally:
+        ctx.set_fast_threshold(False)
+    assert unc > 0, "the parallel mode certified every decision of a stream with a backlog"
+    assert abs(len(fast) - len(want)) <= unc
