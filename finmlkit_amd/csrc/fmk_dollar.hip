@@ -23,7 +23,8 @@
 // The float64-drift replay that makes the result exact (default mode) lives in fmk_dollar_exact.hip.
 //
 // Exact arithmetic vs the reference's float64 running sum: the reference's `cum` carries its own
-// rounding drift (<= (i+1)*2^-52*thr after i adds, the carry never resets it).  A decision is
+// rounding drift (<= (i+1)*2^-52*thr after i adds, the carry never resets it -- plus 2^-53 * W^2 / thr where increments of W in
+// all reach the threshold by themselves: the backlog they leave is worked off at the magnitude of cum, see dl_run).  A decision is
 // reported in n_uncertified when the exact cum lies within that bound (or 1e-11*thr) of the threshold;
 // 0 means the close indices are provably the reference's.
 #include <math.h>
