@@ -937,8 +937,6 @@ __global__ __launch_bounds__(64 * W, 4) void k_bar_trade_size_wg(const float *__
 // ---------------------------------------------------------------------------------------------------------------------
 #define TSW_MIN 16384                  // sixteen waves per bar beyond, four from TSW_MID_MIN (a workgroup's fixed cost per bar -- the
 #define TSW_MID_MIN 4096               // barriers of the cut, the scans and the selections -- grows with its waves)
-#define TSW_MAXSUB 128
-#define TSW_ROUNDS 10
 #define TSW_SAMPLE_MIN 32768           // shorter bars: the radix select on the (L2-resident) bar itself -- its fixed cost decides
 template <int TSW_WAVES>
 __global__ __launch_bounds__(64 * TSW_WAVES) void k_bar_trade_size_wide(const float *__restrict__ amount, const double *__restrict__ theta,
