@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
     m = 1;
     double cin = 0.0;                            // cum carried into the chunk
     const double tol = 1e-11 * fabs(thr);
+    double cerr = 0.0;                           // bound on what the chunked sums have put into cin since it was last reset
     double cur[TH_ITEMS], nxt[TH_ITEMS];
     th_load<AF64, DOLLAR>(price, amount, n, (int64_t)lane * TH_ITEMS, cur);
     for (int64_t base = 0; base < n; base += TH_CHUNK) {
@@ -68,6 +69,16 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
         double ex = __shfl_up(inc, 1, 64);
         if (lane == 0) ex = 0.0;
         const double chunk_total = __shfl(inc, 63, 64);
+        // The chunk's sums are differences of chunk-wide prefixes: next to an increment of 1e12 every later tick of the chunk
+        // carries an error of ulp(1e12), whatever the threshold (tools/fuzz_volume.py seed 97015 case 2356: decisions off by
+        // a tick and not reported).  ~24 roundings at the magnitude of the chunk's absolute sum bound it; a NaN increment
+        // is left out of that sum (the ticks before it still decide), an infinite one makes every decision of the chunk fragile.
+        double la = 0.0;
+#pragma unroll
+        for (int k = 0; k < TH_ITEMS; ++k) { const double v = fabs(cur[k]); la += v == v ? v : 0.0; }
+        const double cherr = 7.2e-15 * (fmk_wave_sum(la) + (cin == cin ? fabs(cin) : 0.0));
+        const double btol = tol + cerr + cherr;
+        bool closed_here = false;
         const int64_t i0 = base + (int64_t)lane * TH_ITEMS;
         double off = 0.0;                         // chunk-prefix value at the last close in this chunk
         int64_t last_close = base == 0 ? 0 : base - 1;   // ticks <= last_close cannot close (tick 0 never does)
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
                 const double c = cin + ((ex + s[k]) - off);
                 const bool live = i > last_close && i < n;
                 if (live && c >= thr) { kk = k; ck = c; }
-                frag |= live && fabs(c - thr) <= tol;
+                frag |= live && fabs(c - thr) <= btol;
             }
             const uint64_t hit = __ballot(kk < TH_ITEMS);
             if (hit == 0) {
@@ -103,8 +114,11 @@ __global__ __launch_bounds__(64) void k_threshold_index(const double *__restrict
             off = __shfl(pk, l0, 64);
             cin = DOLLAR ? c0 - thr : 0.0;        // logic.py:147 carry / logic.py:113 reset
             last_close = ic;
+            closed_here = true;
         }
+        if (!(cherr < INFINITY)) ++unc;           // an infinite increment: inf - inf in the re-based sums
         cin = cin + (chunk_total - off);
+        cerr = (DOLLAR || !closed_here) ? cerr + cherr : cherr;     // (the dollar carry is never reset)
 #pragma unroll
         for (int k = 0; k < TH_ITEMS; ++k) cur[k] = nxt[k];
     }

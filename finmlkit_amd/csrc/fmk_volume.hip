@@ -902,7 +902,11 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
         const double over = s_at - thr;
         double under = INFINITY;
         if (mclose - 1 >= lo) under = thr - (off + l_before);       // mclose - 1 >= lo >= block start: inside this block
-        if (lane == 0 && ((over > 0.0 && over <= tol) || under <= tol || (ties && over == 0.0))) vol_list_append(list, cnt);
+        else if (mclose - 1 > c && mclose - 1 >= 1) under = thr - off;   // first tick of its block: the sum up to the block before
+        // over < 0: the close forced onto the block's last tick above (the double-double block test says "crosses", the plain
+        // sum stays below -- tools/fuzz_volume.py seed 97015 case 2997: a threshold equal to the correctly rounded total)
+        if (lane == 0 && (over < 0.0 || (over > 0.0 && over <= tol) || under <= tol || (ties && over == 0.0)))
+            vol_list_append(list, cnt);
         if (cnt < cap && lane == 0) closes[cnt] = mclose;
         ++cnt;
         long_bars = bstar - bc >= 64;      // beyond one 64-block window; the next bar is probably as long as this one

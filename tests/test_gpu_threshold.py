@@ -1,4 +1,6 @@
 """GPU parity: _volume_bar_indexer / _dollar_bar_indexer close indices, bit-exact vs goldens and oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -335,3 +337,74 @@ def test_dollar_bars_after_a_whale_are_not_certified_by_the_tick_count_alone(orc
         ctx.set_fast_threshold(False)
     assert unc > 0, "the parallel mode certified every decision of a stream with a backlog"
     assert abs(len(fast) - len(want)) <= unc
+
+
+def _fast_mode(t, thr):
+    from finmlkit_amd import _ffi
+    ctx = _ffi.default_context()
+    ctx.set_fast_threshold(True)
+    try:
+        fast = t.volume_bar_index(thr).to_host()
+        return fast, t.last_uncertified
+    finally:
+        ctx.set_fast_threshold(False)
+
+
+def test_volume_chain_walk_reports_a_close_forced_onto_the_last_tick_of_a_block(orc):
+    """tools/fuzz_volume.py seed 97015 case 2997 (the stream is the fixture: 36 689 lognormal float64 amounts, threshold = their
+    correctly rounded total, which the reference's sequential sum stays one part in 1e15 below: no bar).  The chain walk picks the
+    crossing block by double-double block totals and, when the plain in-block sums do not cross, closes on the block's last tick --
+    without listing the decision: the parallel mode answered one bar and reported nothing."""
+    from finmlkit_amd import engine
+    d = np.load(os.path.join(G.GOLDEN_DIR, "volume_total_tie_case.npz"))
+    a, thr = d["a"], float(d["thr"])
+    n = len(a)
+    want = orc._volume_bar_indexer(a, thr)
+    assert len(want) == 1
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), a)
+    got = t.volume_bar_index(thr).to_host()
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    fast, unc = _fast_mode(t, thr)
+    assert np.array_equal(fast, want) or unc > 0, "the parallel mode differs from the reference and reports no fragile decision"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_volume_threshold_at_the_rounded_total(orc, seed):
+    """The same situation from seeds: thresholds at NumPy's (pairwise) total of the stream, where the exact sum, the pairwise sum and
+    the reference's sequential sum disagree in the last bits; lengths that put the stream on the chain walk and on the global tables."""
+    from finmlkit_amd import engine
+    rng = np.random.default_rng(9700 + seed)
+    n = int(rng.choice([5_000, 36_689, 70_001, 200_000]))
+    a = rng.lognormal(0.0, float(rng.choice([0.1, 1.0])), n)
+    k = int(rng.choice([1, 1, 2, 7]))                                # the total, or the sum of the first n / k ticks
+    thr = float(a[: n // k].sum())
+    want = orc._volume_bar_indexer(a, thr)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), a)
+    got = t.volume_bar_index(thr).to_host()
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    fast, unc = _fast_mode(t, thr)
+    assert np.array_equal(fast, want) or unc > 0
+
+
+@pytest.mark.parametrize("big", [1e9, 1e12])
+def test_volume_fast_walk_next_to_an_amount_that_dwarfs_the_threshold(orc, big):
+    """tools/fuzz_volume.py seed 97015 case 2356: a NaN amount sends the parallel mode to the chunked walk of fmk_threshold.hip, whose
+    in-chunk sums are differences of chunk-wide prefixes -- after an amount of 1e12 the other ticks of that chunk (and the carry into the
+    next one) are good to ulp(1e12) = 1e-4, with a threshold of 25.  Those decisions were off by a tick and not reported."""
+    from finmlkit_amd import engine
+    rng = np.random.default_rng(2356)
+    n = 300_000
+    a = rng.lognormal(0.0, 1.0, n).astype(np.float32).astype(np.float64)
+    a[rng.integers(0, n, 6)] *= big
+    a[int(0.8 * n)] = np.nan
+    thr = 25.0
+    want = orc._volume_bar_indexer(a, thr)
+    t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), np.ones(n), a)
+    got = t.volume_bar_index(thr).to_host()
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    fast, unc = _fast_mode(t, thr)
+    assert np.array_equal(fast, want) or unc > 0
+    assert unc < len(want) // 4, "the magnitude term must stay local to the chunks next to the large amounts"
