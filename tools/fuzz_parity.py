@@ -44,6 +44,17 @@ def tape(rng, n):
         am = rng.lognormal(-1, 1.2, size=n).astype(np.float32)
     else:
         am = rng.lognormal(-1, 1.2, size=n)
+    if os.environ.get("FUZZ_EXOTIC") and rng.random() < 0.6:
+        # sizes a feed can hold and the tape above never does (only drawn with FUZZ_EXOTIC set, so the seeds of the recorded
+        # campaigns keep their streams): zero sizes (a few, a third, most), block trades, one size nine decades above the rest
+        am = am.copy()
+        r = rng.random()
+        if r < 0.4:
+            am[rng.random(n) < float(rng.choice([0.02, 0.3, 0.9]))] = 0
+        elif r < 0.75:
+            am[rng.integers(0, n, max(1, n // 500))] *= am.dtype.type(rng.choice([1e3, 1e5]))
+        else:
+            am[rng.integers(0, n, max(1, n // 2000))] *= am.dtype.type(1e9)
     sd = rng.choice(np.array([-1, 1, 1, -1, 0], dtype=np.int8), size=n)
     return ts, px.astype(np.float64), am, sd
 
