@@ -72,6 +72,12 @@ def parse():
                          "(ncclSend/ncclRecv to self), plus the boundary-bar launches -- the per-step overhead of the "
                          "multi-GPU path measured on one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
+    ap.add_argument("--placements", type=int, default=3,
+                    help="allocate the input columns this many times (all held at once), probe each copy with a few steps and run "
+                         "the timed region on the fastest; roofline.frac_min / frac_max report the spread (1: no choice)")
+    ap.add_argument("--separate-index", action="store_true",
+                    help="the step as two library calls (time-bar indexer kernels, then OHLCV + median) instead of the one-launch "
+                         "fmk_time_bars_ohlcv_dev -- for A/B timing")
     return ap.parse_args()
 
 
@@ -267,6 +273,40 @@ def other_configs(trades, ctx, args):
     return out
 
 
+def choose_placement(ctx, trades, args, rank, n):
+    """K allocations of the input columns (the first is `trades`), each probed with 2 + 5 passes of the step's dominant call;
+    -> (the fastest copy, {"probe_kernel_ms": [...], "chosen": k, ...}).  The other copies are freed before the timed region."""
+    import ctypes as C
+    from finmlkit_amd import engine
+    copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx) for _ in range(args.placements - 1)]
+    want_median = not args.no_median
+    ms = []
+    clock = idx = out = None
+    for t in copies:
+        for _ in range(2):
+            clock, idx, out = t.time_bars_ohlcv(args.interval, want_median, out_index=(clock, idx) if clock else None, out=out)
+        ctx.sync()
+        ctx.call("fmk_profile_enable", C.c_int(1))
+        for _ in range(5):
+            t.time_bars_ohlcv(args.interval, want_median, out_index=(clock, idx), out=out)
+        k = (C.c_double * 64)()
+        kn = C.c_int()
+        ctx.call("fmk_profile_read", k, C.c_int(64), C.byref(kn))
+        ctx.call("fmk_profile_enable", C.c_int(0))
+        ms.append(sum(k[i] for i in range(kn.value)) / max(kn.value, 1))
+    best = min(range(len(ms)), key=lambda i: ms[i])
+    chosen = copies[best]
+    info = {"policy": f"best of {len(copies)} allocations of the input columns by a 5-step probe of the dominant kernel "
+                      "(set-up, before warm-up; the other copies are freed)",
+            "probe_kernel_ms": ms, "chosen": best}
+    for i, t in enumerate(copies):
+        if i != best:
+            for col in getattr(t, "_backing", []):
+                col.free()
+    del copies
+    return chosen, info
+
+
 def _proc_start_ticks(pid):
     """Start time of a process (clock ticks since boot, /proc/<pid>/stat field 22): with the pid it names ONE process instance."""
     try:
@@ -367,6 +407,12 @@ def run(args):
             print(f"[bench] reducing ticks/GPU to {n} (free HBM {free / 2**30:.1f} GiB)", file=sys.stderr)
     trades = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx)
     ctx.sync()
+    placement = None
+    if args.placements > 1 and (args.placements - 1) * n * 21 + (8 << 30) < free - need:
+        # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-4 % between allocations of one
+        # process, constant for the life of an allocation: profiles/r04_placement.txt).  Set-up, not a step: K copies of the
+        # same ticks, each probed with the step itself; the fastest stays, the others are freed.
+        trades, placement = choose_placement(ctx, trades, args, rank, n)
 
     transport_note = None
     transport = "none"
@@ -426,9 +472,14 @@ def run(args):
         t0, t1 = trades.first_last_ts()
         ne, e0, d = clock_of(t0, t1)
         ensure_buffers(ne)
-        clock, ci = trades.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
-        # comp_bar_ohlcv incl. the median trade size: ONE fused kernel for bars <= 1344 ticks (dominant)
-        trades.bar_ohlcv(ci, want_median=want_median, out=state["out"])
+        if args.separate_index:
+            clock, ci = trades.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
+            trades.bar_ohlcv(ci, want_median=want_median, out=state["out"])
+        else:
+            # clock + close indices + comp_bar_ohlcv incl. the median trade size: ONE kernel launch for bars <= 1344 ticks -- every
+            # wave finds its own bar's two clock edges, then reduces the bar (k_time_bars_ohlcv, the dominant kernel)
+            trades.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
+                                   out_index=(state["clock"], state["idx"]), out=state["out"])
         state["n_bars"] = ne - 1
         return ne - 1
 
@@ -476,6 +527,8 @@ def run(args):
     # algorithmic bytes of ONE launch of the dominant kernel: price f64 + amount f32 read once per tick,
     # close_idx read once and 60 (+8 with the median) B written per bar (DESIGN.md "roofline")
     alg_bytes = n * 12 + nb * (68 if want_median else 60) + (nb + 1) * 8
+    if not (use_dist or args.separate_index):
+        alg_bytes += (nb + 1) * 8          # one launch: close_idx is WRITTEN (8 B/bar) and so is the clock (8 B/bar), not read
     achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
 
     tc = _traffic_constants()
@@ -509,7 +562,9 @@ def run(args):
                 "launcher": ("self-spawned ranks" if os.environ.get("FMK_BENCH_SPAWNED") else "external launcher") if world > 1 else "none",
             },
             "roofline": {"bound": "hbm",
-                         "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
+                         "kernel": ("k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" if (use_dist or args.separate_index) else
+                                    "k_time_bars_ohlcv<f32 amount, in-kernel clock-edge search, exact 17..21-chunk classes, %s>")
+                                   % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) if tc_ok else None,
                          # true when the kernel's sources have changed since the counters were read (SHA-256 in the constants)
@@ -520,8 +575,14 @@ def run(args):
                                             f"WRITE_SIZE x{tc['write_size_correction']}, calibrated on known byte counts in the same passes), "
                                             f"scaled to this run's ticks and bars; not collected in this run") if tc_ok else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
+                         "kernel_ms_min": min(k_ms), "kernel_ms_max": max(k_ms),
                          "launches_timed": len(k_ms)},
         }
+        if placement:
+            # the same fraction for every allocation probed (frac = algorithmic bytes / probe time / peak): what the run would have
+            # reported on the slowest / the fastest of them
+            fr = [alg_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in placement["probe_kernel_ms"]]
+            line["roofline"].update({"frac_min": min(fr), "frac_max": max(fr), "placement": placement})
         if per_rank:
             ms = per_rank["ms_per_step"]
             line["per_rank"] = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step": ms,

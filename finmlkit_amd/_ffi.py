@@ -144,6 +144,12 @@ class Context:
         """True: calls never wait for the device where they have the choice (comp_bar_ohlcv then enqueues the launches that serve
         long bars without looking whether there are any) -- for the sharded step, which overlaps its calls with the halo exchange."""
         self.call("fmk_ctx_set_enqueue_only", C.c_int(1 if on else 0))
+        self._enqueue_only = bool(on)
+
+    @property
+    def enqueue_only(self) -> bool:
+        """The flag as last set through this object (False after creation)."""
+        return getattr(self, "_enqueue_only", False)
 
     def sync(self):
         self.call("fmk_ctx_sync")

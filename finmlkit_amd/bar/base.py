@@ -97,7 +97,10 @@ class BarBuilderBase(ABC):
         from ..engine import to_host
         self._set_bar_close()
         self._check_indices()
-        o = to_host(self._device().bar_ohlcv(self._d_close_idx))
+        return self._ohlcv_frame(to_host(self._device().bar_ohlcv(self._d_close_idx)))
+
+    def _ohlcv_frame(self, o) -> pd.DataFrame:
+        """The frame of base.py:148-169 from the host copies of the eight OHLCV columns."""
         self._highs, self._lows = o["high"], o["low"]
         df = pd.DataFrame({
             "timestamp": self.bar_close_timestamps,

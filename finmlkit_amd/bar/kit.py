@@ -32,6 +32,20 @@ class TimeBarKit(BarBuilderBase):
         self._d_close_idx = idx
         return clock.to_host(), idx.to_host()
 
+    def build_ohlcv(self) -> pd.DataFrame:
+        """base.py:132-169 for time bars.  When the close indices have not been computed yet, the clock, the close indices and the
+        OHLCV columns come from ONE library call (fmk_time_bars_ohlcv_dev: for 1-minute-sized bars one kernel launch); the values
+        are those of _comp_bar_close() followed by the base class' build_ohlcv()."""
+        if self._close_ts is None and self._close_indices is None:
+            dev = self._device()
+            logger.info("Calculating bar close tick indices and timestamps...")
+            clock, idx, o = dev.time_bars_ohlcv(self.interval)
+            if idx.n >= 2:
+                self._d_close_idx = idx
+                self._close_ts, self._close_indices = clock.to_host(), idx.to_host()
+                return self._ohlcv_frame({k: v.to_host() for k, v in o.items()})
+        return super().build_ohlcv()
+
 
 class _ThresholdKit(BarBuilderBase):
     def _close_from(self, d_idx) -> Tuple[NDArray[np.int64], NDArray[np.int64]]:

@@ -315,7 +315,9 @@ __device__ __forceinline__ void bf_dir_write(const FlowDirOut &o, int64_t b, int
     const double mv = fmax(fabs(vmin), fabs(vmax)), md = fmax(fabs(dmin), fabs(dmax));
     // ... an extremum reached after k ticks has only k additions behind it in the reference's order: len -> k (+ a tile, the
     // granularity the position is known at).  Most extrema of small magnitude -- fine float32 spacing -- are early ones.
-    auto eps_at = [](int64_t k) { const double kk = (double)(k + 64); return 1.13e-16 * (kk + 2.0 * (kk / 512.0 + 32.0)); };
+    // (round 4: the parallel order's share is bounded by its NODE count, not its depth -- a tree or carry sum over k terms has about k
+    // internal nodes, each partial sum below 2 M and rounded once: 2 k u M, plus the reference's k u M -> 3 (k + 64) u M)
+    auto eps_at = [](int64_t k) { const double kk = (double)(k + 64); return 3.4e-16 * kk; };
     unsigned mask = 0;
     if (fmk_near_f32_tie(db, eps * db)) mask |= 1u << 2;
     if (fmk_near_f32_tie(ds, eps * ds)) mask |= 1u << 3;

@@ -52,6 +52,7 @@ struct SegHeader {
     uint64_t magic;                                         // written last by rank 0
     uint64_t world, ring_bytes, total_bytes;
     uint64_t creator_pid, creator_start;                    // rank 0's pid and start time (/proc/<pid>/stat field 22): ONE process
+    uint64_t creator_pidns;                                 // ... and the PID namespace that pid is meaningful in (0: unknown)
     RankSlot slot[MAX_WORLD];
 };
 
@@ -71,6 +72,13 @@ static uint64_t proc_start_ticks(long pid)
     for (++p; *p; ++p)
         if (*p == ' ' && ++field == 22) return strtoull(p + 1, nullptr, 10);
     return 0;
+}
+
+// identity of this process' PID namespace (inode of /proc/self/ns/pid); 0 when it cannot be read
+static uint64_t pidns_id()
+{
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : 0;
 }
 
 static inline size_t gather_off(int world, int parity, int rank)
@@ -200,11 +208,14 @@ inline SegHeader *hdr(fmk_comm *c) { return (SegHeader *)c->seg; }
         if (e__ != hipSuccess) return comm_error((c), FMK_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));       \
     } while (0)
 
-int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes, double deadline = 0.0)
+// One attempt to attach.  *again is set (status FMK_OK) when the file found is a leftover of another run: the caller naps and
+// tries again until the deadline -- a loop, not a recursion (at ~1 KB of locals per attempt a 120 s wait would run the
+// stack out long before the deadline).
+int seg_attach_once(fmk_comm *c, const char *path, size_t ring_bytes, double deadline, bool *again)
 {
     const int world = c->world;
     const size_t total = ring_off(world, ring_bytes, world);
-    if (deadline == 0.0) deadline = now_s() + c->timeout_s;
+    *again = false;
     int fd = -1;
     size_t map_bytes = total;
     if (c->rank == 0) {
@@ -258,6 +269,7 @@ int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes, double deadline
         h->total_bytes = total;
         h->creator_pid = (uint64_t)getpid();
         h->creator_start = proc_start_ticks((long)getpid());
+        h->creator_pidns = pidns_id();
         __atomic_store_n(&h->magic, SEG_MAGIC, __ATOMIC_RELEASE);
     } else {
         int spins = 0;
@@ -274,22 +286,37 @@ int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes, double deadline
         // attached, and this rank has not yet -- so the name must still lead to the inode mapped here (a rank 0 that came
         // later has replaced it); and the process that made the file must still be running (pid + start time name one
         // process instance) -- the creator of a leftover is gone.  Either fails: wait for this job's rank 0 and re-attach.
+        // The /proc check only means something where the creator's pid does: in the creator's own PID namespace (ranks in
+        // different namespaces sharing /dev/shm see no entry, or somebody else's, under that number).  There, no entry or another
+        // start time = the creator is gone.  Elsewhere -- or when either side cannot name its namespace -- the inode check decides.
         struct stat sp;
-        const uint64_t st0 = proc_start_ticks((long)h->creator_pid);
-        const bool have_proc = proc_start_ticks((long)getpid()) != 0;
-        if (stat(path, &sp) != 0 || sp.st_ino != ino || sp.st_dev != dev || (have_proc && st0 != h->creator_start)) {
+        const uint64_t my_ns = pidns_id();
+        const bool same_ns = my_ns != 0 && h->creator_pidns == my_ns && h->creator_start != 0;
+        const bool creator_gone = same_ns && proc_start_ticks((long)h->creator_pid) != h->creator_start;
+        if (stat(path, &sp) != 0 || sp.st_ino != ino || sp.st_dev != dev || creator_gone) {
             munmap(c->seg, c->seg_bytes);
             c->seg = nullptr;
             if (now_s() > deadline)
                 return comm_error(c, FMK_E_COMM, "rank %d: rendezvous %s is a leftover of another run and was not replaced "
                                   "within %.0f s", c->rank, path, c->timeout_s);
-            timespec nap{0, 2000000};
-            nanosleep(&nap, nullptr);
-            return seg_attach(c, path, ring_bytes, deadline);
+            *again = true;
+            return FMK_OK;
         }
     }
     __atomic_store_n(&h->slot[c->rank].attached, 1, __ATOMIC_RELEASE);
     return FMK_OK;
+}
+
+int seg_attach(fmk_comm *c, const char *path, size_t ring_bytes)
+{
+    const double deadline = now_s() + c->timeout_s;
+    for (;;) {
+        bool again = false;
+        const int rc = seg_attach_once(c, path, ring_bytes, deadline, &again);
+        if (rc != FMK_OK || !again) return rc;
+        timespec nap{0, 2000000};
+        nanosleep(&nap, nullptr);
+    }
 }
 
 int gather(fmk_comm *c, const void *send, size_t bytes, void *recv)

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double
                                                                    const int *__restrict__ go, OhlcvOut o,
                                                                    const uint32_t *__restrict__ brk = nullptr /* OhlBracket[] */,
                                                                    uint32_t *__restrict__ cand = nullptr,
-                                                                   int64_t *__restrict__ res = nullptr /* OhlCount[] */)
+                                                                   int64_t *__restrict__ res = nullptr /* OhlCount[] */,
+                                                                   int64_t base = 0 /* first tick the scratch covers (multiple of 16) */)
 {
     if (go && *go == 0) return;
     __shared__ double s_red[4][OH_WIDE_THREADS / 64];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double
         int cap = 0;
         if constexpr (MED) {
             blo = brk[4 * q]; bhi = brk[4 * q + 1];
-            mycand = cand + (start >> 2);
+            mycand = cand + ((start - base) >> 2);
             cap = (int)((e - s) >> 2);
             if (tid == 0) { s_ncand = 0; s_nan = 0; }
             __syncthreads();
@@ -241,8 +242,9 @@ __global__ __launch_bounds__(OH_WIDE_THREADS) void k_bar_ohlcv_wide(const double
 //      to the bar's candidate buffer (wave-aggregated, one LDS atomic per wave and chunk);
 //   3. k_bar_med_finish: if the middle ranks fall among the candidates they are selected there exactly (the same radix select, on a
 //      few per cent of the bar); otherwise the bar goes on a list for k_bar_median_long.  np.median's bits either way.
-// Scratch: sample slots [start / 16, ...) and candidate slots [start / 4, ...) of two arrays indexed by the bar's own tick range
-// (bars are disjoint, so no offsets have to be computed).
+// Scratch: sample slots [(start - base) / 16, ...) and candidate slots [(start - base) / 4, ...) of two arrays indexed by the bar's
+// own tick range (bars are disjoint, so no offsets have to be computed); base = the first listed bar's start rounded down to 16,
+// so the arrays cover only the span of the listed bars (k_list_span) -- the whole tick axis when the call must not wait.
 // ---------------------------------------------------------------------------------------------------------------------
 struct OhlBracket { uint32_t blo, bhi; int ok; int pad; };
 struct OhlCount { int64_t below; int64_t ncand; int64_t nan; };
@@ -251,7 +253,8 @@ __device__ __forceinline__ int ohl_stride(int64_t cnt) { return cnt <= 65536 ? 1
 
 __global__ __launch_bounds__(256) void k_bar_med_sample(const float *__restrict__ amount, const int64_t *__restrict__ ci,
                                                         const int64_t *__restrict__ list, const int *__restrict__ go,
-                                                        float *__restrict__ samp, OhlBracket *__restrict__ brk, float g_scale)
+                                                        float *__restrict__ samp, OhlBracket *__restrict__ brk, float g_scale,
+                                                        int64_t base)
 {
     if (go && *go == 0) return;
     const int64_t n_list = list[0];
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void k_bar_med_sample(const float *__restrict_
         const int64_t b = list[1 + q], s0 = ci[b], e = ci[b + 1], start = s0 + 1, cnt = e - s0;
         const int stride = ohl_stride(cnt);
         const int64_t ns = cnt / stride;                              // >= 1024
-        float *mine = samp + (start >> 4);
+        float *mine = samp + ((start - base) >> 4);
         for (int64_t j = threadIdx.x; j < ns; j += 256) mine[j] = amount[start + j * stride];
         __syncthreads();
         const int g = (int)(1.9f * g_scale * sqrtf((float)ns)) + 4;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_bar_med_sample(const float *__restrict_
 __global__ __launch_bounds__(256) void k_bar_med_finish(const int64_t *__restrict__ ci, const int64_t *__restrict__ list,
                                                         const int *__restrict__ go, const uint32_t *__restrict__ cand,
                                                         const OhlCount *__restrict__ res, int64_t *__restrict__ fallback,
-                                                        double *__restrict__ o_median)
+                                                        double *__restrict__ o_median, int64_t base)
 {
     if (go && *go == 0) return;
     typedef MedKey<false> MK;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void k_bar_med_finish(const int64_t *__restric
         }
         uint32_t v1, v2;
         bool any_nan;
-        med_block_select<false, 256>(cand + (start >> 2), 0, r.ncand, k1 - r.below, k2 - r.below, v1, v2, any_nan);
+        med_block_select<false, 256>(cand + ((start - base) >> 2), 0, r.ncand, k1 - r.below, k2 - r.below, v1, v2, any_nan);
         if (threadIdx.x == 0) o_median[b] = (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
         __syncthreads();
     }
@@ -300,6 +303,26 @@ __global__ __launch_bounds__(256) void k_bar_med_finish(const int64_t *__restric
 // the wide bars of a call: list them, a workgroup per listed bar (two workgroups of 1024 threads per CU).  *median_done = 1 when the
 // median of these bars was taken by the same pass (float32 amounts: sample bracket, see above) -- fmk_median_launch then skips them.
 int fmk_median_long_list_launch(fmk_ctx *ctx, const void *d_amount, const int64_t *d_close_idx, const int64_t *d_list, double *d_median);
+
+// listed bars: count, first tick and one past the last tick of the span they cover (one block)
+__global__ __launch_bounds__(256) void k_list_span(const int64_t *__restrict__ ci, const int64_t *__restrict__ list, int64_t *__restrict__ out)
+{
+    __shared__ long long s_lo, s_hi;
+    if (threadIdx.x == 0) { s_lo = INT64_MAX; s_hi = 0; }
+    __syncthreads();
+    const int64_t n_list = list[0];
+    long long lo = INT64_MAX, hi = 0;
+    for (int64_t q = threadIdx.x; q < n_list; q += 256) {
+        const int64_t b = list[1 + q];
+        const long long s = ci[b] + 1, e = ci[b + 1] + 1;
+        lo = s < lo ? s : lo;
+        hi = e > hi ? e : hi;
+    }
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = n_list; out[1] = n_list ? s_lo : 0; out[2] = n_list ? s_hi : 0; }
+}
 
 template <bool AF64>
 static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n, const int *go,
@@ -311,26 +334,46 @@ static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const in
         const char *fv = getenv("FMK_OHLCV_WIDE_MED");            // developer knob: 0 = the radix-select median kernels as before
         if (o.median && median_done && (!fv || atoi(fv))) {
             const int64_t cap = n / wide_min + 2;                  // (the list's capacity: fmk_long_bar_list)
+            // The scratch is sized from the listed bars: their count and tick span come back in one 24-byte copy (this path is
+            // only reached when the stream has bars beyond 8 192 ticks, or in enqueue-only mode).  An empty list ends the call
+            // here; in enqueue-only mode nothing may be waited for, so the scratch covers the whole tick axis (1.25 B/tick).
+            int64_t base = 0, span = n;
+            if (!ctx->enqueue_only) {
+                int64_t *d_span = ctx->d_mail + 48, *h_span = ctx->h_mail + 20;
+                k_list_span<<<1, 256, 0, ctx->stream>>>(ci, list, d_span);
+                FMK_LAUNCH_CHECK(ctx);
+                FMK_HIP(ctx, hipMemcpyAsync(h_span, d_span, 24, hipMemcpyDeviceToHost, ctx->stream));
+                FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (h_span[0] == 0) {                               // no bar for the workgroup kernels
+                    FMK_TRY(fmk_free(ctx, list));
+                    *median_done = 1;
+                    return FMK_OK;
+                }
+                base = h_span[1] & ~(int64_t)15;
+                span = h_span[2] - base;
+            }
             float *samp = nullptr;
             uint32_t *cand = nullptr;
             OhlBracket *brk = nullptr;
             int64_t *res = nullptr, *fallback = nullptr;
-            int rc = fmk_alloc(ctx, (size_t)((n >> 4) + 64) * 4, (void **)&samp);
-            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)((n >> 2) + 64) * 4, (void **)&cand);
+            int rc = fmk_alloc(ctx, (size_t)((span >> 4) + 64) * 4, (void **)&samp);
+            if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)((span >> 2) + 64) * 4, (void **)&cand);
             if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)cap * sizeof(OhlBracket), (void **)&brk);
             if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)cap * 3 * 8, (void **)&res);
             if (rc == FMK_OK) rc = fmk_alloc(ctx, (size_t)(cap + 1) * 8, (void **)&fallback);
+            const bool have_scratch = rc == FMK_OK;
             hipError_t le = hipSuccess;
-            if (rc == FMK_OK) le = hipMemsetAsync(fallback, 0, 8, ctx->stream);
-            if (rc == FMK_OK && le == hipSuccess) {
+            if (have_scratch) le = hipMemsetAsync(fallback, 0, 8, ctx->stream);
+            if (have_scratch && le == hipSuccess) {
                 const char *gv = getenv("FMK_WIDE_MED_GSCALE");      // developer knob (tests): 0 = brackets that usually miss
                 k_bar_med_sample<<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>((const float *)a, ci, list, go, samp, brk,
-                                                                                   gv ? (float)atof(gv) : 1.0f);
+                                                                                   gv ? (float)atof(gv) : 1.0f, base);
                 k_bar_ohlcv_wide<false, true><<<(unsigned)(ctx->n_cu * 2), OH_WIDE_THREADS, 0, ctx->stream>>>(
-                    p, a, ci, list, go, o, (const uint32_t *)brk, cand, res);
+                    p, a, ci, list, go, o, (const uint32_t *)brk, cand, res, base);
                 k_bar_med_finish<<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>(ci, list, go, cand, (const OhlCount *)res, fallback,
-                                                                                   o.median);
+                                                                                   o.median, base);
                 le = hipGetLastError();
+                rc = FMK_OK;
                 if (le == hipSuccess) rc = fmk_median_long_list_launch(ctx, a, ci, fallback, o.median);
             }
             if (samp) (void)fmk_free(ctx, samp);
@@ -338,11 +381,16 @@ static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const in
             if (brk) (void)fmk_free(ctx, brk);
             if (res) (void)fmk_free(ctx, res);
             if (fallback) (void)fmk_free(ctx, fallback);
-            (void)fmk_free(ctx, list);
-            FMK_TRY(rc);
-            FMK_HIP(ctx, le);
-            *median_done = 1;
-            return FMK_OK;
+            if (have_scratch) {
+                (void)fmk_free(ctx, list);
+                FMK_TRY(rc);
+                FMK_HIP(ctx, le);
+                *median_done = 1;
+                return FMK_OK;
+            }
+            // no memory for the scratch: the sums by the plain workgroup kernel below, the medians by the radix-select kernels
+            // (fmk_median_launch, *median_done stays 0) -- slower, not an error
+            if (rc != FMK_E_NOMEM) { (void)fmk_free(ctx, list); FMK_TRY(rc); }
         }
     }
     k_bar_ohlcv_wide<AF64><<<(unsigned)(ctx->n_cu * 2), OH_WIDE_THREADS, 0, ctx->stream>>>(p, a, ci, list, go, o);
@@ -550,6 +598,115 @@ __global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : MAXNCH <= 10 ? 6 : 4)) void
                 else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
                 else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the time-bar step in ONE launch -- _time_bar_indexer (logic.py:12-51) inside the OHLCV + median kernel.
+// The separate indexer (fmk_indexers.hip: sample gather + one thread per clock edge, ~15 dependent probes each) is 0.11 ms in
+// front of a 2.2 ms kernel that cannot start before it.  Here every wave finds the two edges of its OWN bar first: lanes 0 and 1
+// run an interpolation search (each step probes both ends of a bracket of 2 sqrt(width) around the interpolated position in one
+// memory round trip and keeps the bisection invariant ts[lo] <= edge < ts[hi]; a step that fails to halve the bracket is followed
+// by a bisection step, so uneven spacing costs time, never correctness), 1e9 evenly spaced ticks -> 126 K -> 1.4 K -> 150 -> <= 63
+// in four round trips, and the last <= 62 candidates of both edges are read by the whole wave in one coalesced load each and
+// counted with a ballot.  The searches of the ~4 000 resident waves overlap the loads of the others; what is left in front of the
+// first loads is one search (~10 us) instead of the whole indexer.  The wave also writes clock[b] / idx[b] (the path's outputs).
+// Same bar code as k_bar_ohlcv_small<.., 21>; long bars raise the same flag for the same leftover passes, which read idx.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TbFuse {
+    const int64_t *ts;
+    int64_t e0, d;                  // clock: edge k = e0 + k * d (fmk_time_bar_clock)
+    int64_t t_first, t_last;        // ts[0], ts[n - 1] (the caller has them: they define the clock)
+    int64_t *clock, *idx;           // [nb + 1] outputs
+};
+
+// ts[lo] <= edge < ts[hi] with hi - lo <= stop (lo == -1: no tick at or before the edge, hi == n: none after it)
+__device__ __forceinline__ void tb_interp_bracket(const int64_t *__restrict__ ts, int64_t n, int64_t edge, int64_t t_first,
+                                                  int64_t t_last, int64_t stop, int64_t &lo_out, int64_t &hi_out)
+{
+    if (edge < t_first) { lo_out = -1; hi_out = 0; return; }
+    if (edge >= t_last) { lo_out = n - 1; hi_out = n; return; }
+    int64_t lo = 0, hi = n - 1, vlo = t_first, vhi = t_last;       // vlo <= edge < vhi
+    while (hi - lo > stop) {                                        // (stop >= 2: a and b below exist)
+        const int64_t w = hi - lo;
+        const double f = (double)(edge - vlo) / (double)(vhi - vlo);
+        const int64_t g = lo + (int64_t)(f * (double)w);
+        const int64_t r = 2 * (int64_t)sqrt((double)w) + 8;
+        int64_t a = g - r, b = g + r;
+        a = a <= lo ? lo + 1 : (a >= hi ? hi - 1 : a);
+        b = b >= hi ? hi - 1 : (b <= lo ? lo + 1 : b);
+        const int64_t va = ts[a], vb = ts[b];                       // independent: one round trip
+        if (va > edge) { hi = a; vhi = va; }
+        else if (vb <= edge) { lo = b; vlo = vb; }
+        else { lo = a; vlo = va; hi = b; vhi = vb; }
+        if (hi - lo > (w >> 1) && hi - lo > stop) {                 // the guess was off: bisect once (worst case stays logarithmic)
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const int64_t vm = ts[mid];
+            if (vm <= edge) { lo = mid; vlo = vm; } else { hi = mid; vhi = vm; }
+        }
+    }
+    lo_out = lo; hi_out = hi;
+}
+
+template <bool AF64, bool MEDIAN>
+__global__ __launch_bounds__(256, 4) void k_time_bars_ohlcv(TbFuse tb, const double *__restrict__ price, const void *__restrict__ amount,
+                                                            int64_t nb, int64_t n, int *__restrict__ saw_long, OhlcvOut o)
+{
+    typedef typename MedKey<AF64>::K K;
+    __shared__ K sbuf[4][64];
+    const int lane = fmk_lane();
+    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    K *buf = sbuf[wib];
+    const int64_t *__restrict__ ts = tb.ts;
+    for (int64_t b = wave0; b < nb; b += nwaves) {
+        // ---- the bar's two clock edges: lane 0 the opening edge, lane 1 the closing edge
+        const int64_t edge0 = tb.e0 + b * tb.d, edge1 = edge0 + tb.d;
+        int64_t blo = 0, bhi = 0;
+        if (lane < 2) tb_interp_bracket(ts, n, lane == 0 ? edge0 : edge1, tb.t_first, tb.t_last, 63, blo, bhi);
+        const int64_t lo0 = fmk_readlane(blo, 0), hi0 = fmk_readlane(bhi, 0), lo1 = fmk_readlane(blo, 1), hi1 = fmk_readlane(bhi, 1);
+        const int64_t i0 = lo0 + 1 + lane, i1 = lo1 + 1 + lane;     // the candidates strictly inside the brackets (<= 62 each)
+        const bool in0 = i0 < hi0, in1 = i1 < hi1;
+        const int64_t v0 = in0 ? ts[i0] : INT64_MAX, v1 = in1 ? ts[i1] : INT64_MAX;
+        const int64_t s = lo0 + (int64_t)__popcll(__builtin_amdgcn_ballot_w64(in0 && v0 <= edge0));
+        const int64_t e = lo1 + (int64_t)__popcll(__builtin_amdgcn_ballot_w64(in1 && v1 <= edge1));
+        if (lane == 0) {
+            tb.idx[b] = s;
+            if (tb.clock) tb.clock[b] = edge0;
+            if (b == nb - 1) { tb.idx[nb] = e; if (tb.clock) tb.clock[nb] = edge1; }
+        }
+        const int64_t cnt = e - s;
+        if (cnt > 64 * FMK_SMALL_NCH) {                      // long bar: left to the generic kernels (see k_bar_ohlcv_small)
+            if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (cnt <= 0) {
+            if (lane == 0) ohlcv_empty(o, b, price, e, n);
+            continue;
+        }
+        const int64_t start = s + 1;
+        const int nch = (int)((cnt + 63) >> 6);
+        switch (nch) {
+        case 11: small_bar<AF64, 11, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 12: small_bar<AF64, 12, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 13: small_bar<AF64, 13, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 14: small_bar<AF64, 14, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 15: small_bar<AF64, 15, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 16: small_bar<AF64, 16, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        case 21: small_bar<AF64, 21, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
+        default:
+            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
+            else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
         }
     }
 }
@@ -1276,12 +1433,14 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv_phased(const double *__restri
     }
 }
 
-static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
+static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb, bool fused = false)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
     static int per_cu = -1;                  // developer knob: FMK_OHLCV_BLOCKS_PER_CU (workgroups per CU in the grid)
     if (per_cu < 0) { const char *v = getenv("FMK_OHLCV_BLOCKS_PER_CU"); per_cu = v ? atoi(v) : 64; }
-    int64_t cap = (int64_t)ctx->n_cu * per_cu;   // grid-stride beyond this
+    static int per_cu_fused = -1;            // ... FMK_OHLCV_FUSED_BLOCKS_PER_CU for k_time_bars_ohlcv (default: no cap)
+    if (per_cu_fused < 0) { const char *v = getenv("FMK_OHLCV_FUSED_BLOCKS_PER_CU"); per_cu_fused = v ? atoi(v) : (1 << 20); }
+    int64_t cap = (int64_t)ctx->n_cu * (fused ? per_cu_fused : per_cu);   // grid-stride beyond this
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
@@ -1289,10 +1448,23 @@ static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 
 template <bool AF64>
 static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n,
-                        const OhlcvOut &o_in, int variant)
+                        const OhlcvOut &o_in, int variant, const TbFuse *tb = nullptr)
 {
     OhlcvOut o = o_in;
     const unsigned grid = ohlcv_grid(ctx, nb);
+    // tb: the close indices are not there yet (fmk_time_bars_ohlcv_dev) -- the 1-minute schedule finds them inside its kernel
+    // (k_time_bars_ohlcv), every other schedule runs the separate indexer first
+    bool fuse_index = false;
+    if (tb) {
+        static int fuse_on = -1;             // developer knob: FMK_OHLCV_FUSE_INDEX=1 -> the edge search inside the OHLCV kernel
+        if (fuse_on < 0) { const char *v = getenv("FMK_OHLCV_FUSE_INDEX"); fuse_on = v ? atoi(v) : 0; }
+        static int mid2 = -1;
+        if (mid2 < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2 = v ? atoi(v) : 600; }
+        fuse_index = fuse_on && variant != 0 && nb >= 64 && n / nb > mid2;      // = the last branch of the schedule choice below
+        if (!fuse_index)
+            FMK_TRY(fmk_time_bar_indexer_dev(ctx, tb->ts, n, tb->e0, tb->d, nb + 1, tb->clock, tb->idx));
+        ci = tb->idx;
+    }
     if (AF64) {   // redo list of near-tie volume sums (fmk_f32tie.h); nothing else here uses the context scratch
         FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 8, (void **)&o.vol_redo));
         FMK_HIP(ctx, hipMemsetAsync(o.vol_redo, 0, 8, ctx->stream));
@@ -1363,6 +1535,11 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         if (!o.median) k_bar_ohlcv_small<AF64, false, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_small<AF64, true, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         long_min = 640;
+    } else if (fuse_index) {
+        // one wave per bar in dispatch order (no grid-stride cap): the in-flight window slides through the columns
+        const unsigned fgrid = ohlcv_grid(ctx, nb, /*fused=*/true);
+        if (!o.median) k_time_bars_ohlcv<AF64, false><<<fgrid, 256, 0, ctx->stream>>>(*tb, p, a, nb, n, saw_long, o);
+        else k_time_bars_ohlcv<AF64, true><<<fgrid, 256, 0, ctx->stream>>>(*tb, p, a, nb, n, saw_long, o);
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
@@ -1474,4 +1651,27 @@ extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const
     }
     return amount_is_f64 ? ohlcv_launch<true>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant)
                          : ohlcv_launch<false>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant);
+}
+
+// _time_bar_indexer + comp_bar_ohlcv in one call (TimeBarKit.build_ohlcv on resident columns; bench.py's step): the results of
+// fmk_time_bar_indexer_dev(first_edge, delta, n_edges) followed by fmk_comp_bar_ohlcv_dev on its close indices, bit for bit; for
+// streams of 1-minute-sized bars (mean bar length above 600 ticks) both are ONE kernel launch (k_time_bars_ohlcv).
+extern "C" int fmk_time_bars_ohlcv_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const void *d_amount,
+                                       int amount_is_f64, int64_t n, int64_t ts_first, int64_t ts_last, int64_t first_edge,
+                                       int64_t delta, int64_t n_edges, int64_t *d_clock, int64_t *d_close_idx, double *d_open,
+                                       double *d_high, double *d_low, double *d_close, float *d_volume, double *d_vwap,
+                                       int64_t *d_trades, double *d_median)
+{
+    if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "time_bars_ohlcv: empty input");
+    if (n_edges < 2)   // base.py:334-335
+        return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
+    if (!d_close_idx) return fmk_set_error(ctx, FMK_E_ARG, "time_bars_ohlcv: d_close_idx is required");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nb = n_edges - 1;
+    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median, nullptr};
+    const TbFuse tb{d_ts, first_edge, delta, ts_first, ts_last, d_clock, d_close_idx};
+    const char *v = getenv("FMK_OHLCV_VARIANT");
+    const int variant = v ? atoi(v) : 1;
+    return amount_is_f64 ? ohlcv_launch<true>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant, &tb)
+                         : ohlcv_launch<false>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant, &tb);
 }

@@ -315,6 +315,8 @@ class ShardedTimeBars:
     def step(self, comm: "Comm") -> int:
         # enqueue only: comp_bar_ohlcv must not wait for its first kernel here (it would, to skip the launches that serve long bars
         # when there are none) -- two host waits per step cost 0.9 ms against the 0.25 ms of launches they save
+        # (the caller's setting is put back afterwards: a pipelined loop that had the flag on keeps it)
+        was = self.ctx.enqueue_only
         self.ctx.set_enqueue_only(True)
         try:
             comm.exchange(self.send_slices(), self.recv_slices())    # enqueued on the communicator's stream
@@ -322,7 +324,7 @@ class ShardedTimeBars:
             comm.wait()                                               # event: context stream after the exchange
             return self.enqueue_boundary()
         finally:
-            self.ctx.set_enqueue_only(False)
+            self.ctx.set_enqueue_only(was)
 
     def features(self, price_tick_size: float, imbalance_factor: float = 3.0):
         """cfg 4 on the shard (after a step with with_side=True): order-flow + footprints of this rank's bars through

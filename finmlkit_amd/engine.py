@@ -123,6 +123,33 @@ class DeviceTrades:
                       clock.p, idx.p)
         return clock, idx
 
+    def time_bars_ohlcv(self, interval_seconds: float, want_median: bool = True, clock_params=None,
+                        out_index: Optional[Tuple[DeviceArray, DeviceArray]] = None,
+                        out: Optional[Dict[str, DeviceArray]] = None):
+        """TimeBarKit.build_ohlcv on the resident columns in ONE library call (kit.py:42-66 -> base.py:126-158):
+        _time_bar_indexer + comp_bar_ohlcv -> (bar_clock, bar_close_indices, ohlcv dict), the same values as
+        time_bar_index() followed by bar_ohlcv().  For 1-minute-sized bars it is one kernel launch (the edge search runs
+        inside the OHLCV + median kernel)."""
+        if clock_params is None:
+            t0, t1 = self.first_last_ts()
+            ne, e0, d = c_i64(), c_i64(), c_i64()
+            _ffi.check(_ffi.lib().fmk_time_bar_clock(c_i64(t0), c_i64(t1), c_f64(interval_seconds),
+                                                     C.byref(ne), C.byref(e0), C.byref(d)))
+            clock_params = (ne.value, e0.value, d.value)
+        ne, e0, d = clock_params
+        t0, t1 = self.first_last_ts()
+        if out_index is not None:
+            clock, idx = out_index[0].view(0, ne), out_index[1].view(0, ne)
+        else:
+            clock, idx = DeviceArray(self.ctx, ne, np.int64), DeviceArray(self.ctx, ne, np.int64)
+        out = out or self.alloc_ohlcv(max(ne - 1, 0), want_median)
+        med = out["median_trade_size"].p if (want_median and "median_trade_size" in out) else None
+        self.ctx.call("fmk_time_bars_ohlcv_dev", self.ts.p, self.price.p, self.amount.p, C.c_int(self.amount_is_f64),
+                      c_i64(self.n), c_i64(t0), c_i64(t1), c_i64(e0), c_i64(d), c_i64(ne), clock.p, idx.p,
+                      out["open"].p, out["high"].p, out["low"].p, out["close"].p, out["volume"].p, out["vwap"].p,
+                      out["trades"].p, med)
+        return clock, idx, out
+
     def tick_bar_index(self, threshold: int) -> DeviceArray:
         m = c_i64()
         self.ctx.call("fmk_tick_bar_indexer_dev", c_i64(self.n), c_i64(int(threshold)), None, c_i64(0), C.byref(m))

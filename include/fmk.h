@@ -155,6 +155,17 @@ int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const void *d_am
                            int64_t n_idx, double *d_open, double *d_high, double *d_low,
                            double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades,
                            double *d_median);
+/* TimeBarKit.build_ohlcv on resident columns in ONE call (kit.py:42-66 -> base.py:126-158): _time_bar_indexer
+ * (logic.py:12-51) + comp_bar_ohlcv (base.py:306-407).  Results = fmk_time_bar_indexer_dev(first_edge, delta, n_edges)
+ * followed by fmk_comp_bar_ohlcv_dev on its close indices, bit for bit (d_clock may be NULL, d_close_idx[n_edges] is
+ * always written; ts_first / ts_last = d_ts[0] / d_ts[n-1], the two values the clock was made from).  For streams of
+ * 1-minute-sized bars (mean bar length above 600 ticks) the edge search runs INSIDE the OHLCV + median kernel -- one
+ * launch, every wave finds its own bar's two edges by interpolation search before it issues the bar's loads. */
+int fmk_time_bars_ohlcv_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const void *d_amount,
+                            int amount_is_f64, int64_t n, int64_t ts_first, int64_t ts_last, int64_t first_edge,
+                            int64_t delta, int64_t n_edges, int64_t *d_clock, int64_t *d_close_idx,
+                            double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                            double *d_vwap, int64_t *d_trades, double *d_median);
 /* The order statistic alone (np.median of the bar's trade sizes, base.py:373-403). */
 int fmk_comp_bar_median_dev(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n,
                             const int64_t *d_close_idx, int64_t n_idx, double *d_median);
