@@ -476,8 +476,9 @@ def run(args):
             clock, ci = trades.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
             trades.bar_ohlcv(ci, want_median=want_median, out=state["out"])
         else:
-            # clock + close indices + comp_bar_ohlcv incl. the median trade size: ONE kernel launch for bars <= 1344 ticks -- every
-            # wave finds its own bar's two clock edges, then reduces the bar (k_time_bars_ohlcv, the dominant kernel)
+            # clock + close indices + comp_bar_ohlcv incl. the median trade size in ONE library call (fmk_time_bars_ohlcv_dev): the
+            # indexer kernels, then the dominant kernel k_bar_ohlcv_small (the in-kernel edge search k_time_bars_ohlcv exists
+            # behind FMK_OHLCV_FUSE_INDEX=1 and measured slower: profiles/r04_indexer.txt)
             trades.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
                                    out_index=(state["clock"], state["idx"]), out=state["out"])
         state["n_bars"] = ne - 1
@@ -527,7 +528,8 @@ def run(args):
     # algorithmic bytes of ONE launch of the dominant kernel: price f64 + amount f32 read once per tick,
     # close_idx read once and 60 (+8 with the median) B written per bar (DESIGN.md "roofline")
     alg_bytes = n * 12 + nb * (68 if want_median else 60) + (nb + 1) * 8
-    if not (use_dist or args.separate_index):
+    fused_index = bool(int(os.environ.get("FMK_OHLCV_FUSE_INDEX", "0"))) and not (use_dist or args.separate_index)
+    if fused_index:
         alg_bytes += (nb + 1) * 8          # one launch: close_idx is WRITTEN (8 B/bar) and so is the clock (8 B/bar), not read
     achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
 
@@ -562,8 +564,8 @@ def run(args):
                 "launcher": ("self-spawned ranks" if os.environ.get("FMK_BENCH_SPAWNED") else "external launcher") if world > 1 else "none",
             },
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" if (use_dist or args.separate_index) else
-                                    "k_time_bars_ohlcv<f32 amount, in-kernel clock-edge search, exact 17..21-chunk classes, %s>")
+                         "kernel": ("k_time_bars_ohlcv<f32 amount, in-kernel clock-edge search, exact 17..21-chunk classes, %s>" if fused_index else
+                                    "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>")
                                    % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) if tc_ok else None,

@@ -73,6 +73,26 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_diag = None
+DIAG_PROBES = ("fmk_diag_read_bandwidth", "fmk_diag_fill_amounts_dev", "fmk_diag_read_two_streams", "fmk_diag_hop_latency",
+               "fmk_diag_h2d_rate")
+
+
+def diag_lib() -> C.CDLL:
+    """libfmk_diag.so: the bandwidth / latency probes and the full-mantissa size generator that tests, tools and bench.py use
+    (include/fmk_diag.h).  Not part of the product: nothing in finmlkit_amd calls it."""
+    global _diag
+    if _diag is None:
+        lib()                                                    # the probes take the product library's context type
+        path = os.path.join(os.path.dirname(LIB_PATH), "libfmk_diag.so")
+        if not os.path.exists(path):
+            path = os.path.join(_HERE, "lib", "libfmk_diag.so")
+        if not os.path.exists(path):
+            raise FmkError(f"{path} not found: build it with `python __graft_entry__.py build`")
+        _diag = C.CDLL(path)
+    return _diag
+
+
 def check(rc: int, ctx=None, allow=()):
     """Map a C status to the exception type the reference raises for the same condition."""
     if rc == OK or rc in allow:
@@ -129,7 +149,8 @@ class Context:
             pass
 
     def call(self, name, *args, allow=()):
-        return check(getattr(lib(), name)(self._h, *args), self._h, allow=allow)
+        l = diag_lib() if name in DIAG_PROBES else lib()
+        return check(getattr(l, name)(self._h, *args), self._h, allow=allow)
 
     def trim(self):
         """Give back everything the context caches between calls (scratch, allocator free lists, indexer buffers)."""

@@ -140,41 +140,3 @@ extern "C" int fmk_h2d_columns(fmk_ctx *ctx, int n_cols, void *const *dst_dev, c
     if (err.load()) return fmk_set_error(ctx, FMK_E_HIP, "fmk_h2d_columns: %s", hipGetErrorString((hipError_t)err.load()));
     return FMK_OK;
 }
-
-// Diagnostics: the box's host-to-device rate for one buffer of `bytes` -- pinned = 1: from hipHostMalloc memory (the link's
-// ceiling), 0: plain hipMemcpy from malloc'ed memory (what a caller's NumPy array gets without fmk_h2d_columns), 2: fmk_h2d_columns
-// from malloc'ed memory.  Best of three, GB/s.
-extern "C" int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps)
-{
-    *gbps = 0.0;
-    if (bytes == 0) return FMK_OK;
-    FMK_HIP(ctx, hipSetDevice(ctx->device));
-    void *d = nullptr, *h = nullptr;
-    FMK_HIP(ctx, hipMalloc(&d, bytes));
-    hipError_t e = hipSuccess;
-    if (mode == 1) e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
-    else h = malloc(bytes);
-    if (e != hipSuccess || !h) { (void)hipFree(d); return fmk_set_error(ctx, FMK_E_NOMEM, "fmk_diag_h2d_rate: host buffer"); }
-    memset(h, 1, bytes);
-    double best = 0.0;
-    int rc = FMK_OK;
-    for (int r = 0; r < 4 && rc == FMK_OK; ++r) {
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        if (mode == 2) {
-            void *dd[1] = {d};
-            const void *ss[1] = {h};
-            rc = fmk_h2d_columns(ctx, 1, dd, ss, &bytes);
-        } else {
-            e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = fmk_set_error(ctx, FMK_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-        }
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        const double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-        if (r > 0 && s > 0 && (double)bytes / s / 1e9 > best) best = (double)bytes / s / 1e9;
-    }
-    if (mode == 1) (void)hipHostFree(h); else free(h);
-    (void)hipFree(d);
-    *gbps = best;
-    return rc;
-}

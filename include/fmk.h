@@ -414,42 +414,7 @@ int fmk_comm_profile_read(fmk_comm *comm, double *ms, int capacity, int *count);
 /* Up to 8 small device column slices copied by one launch on the context's stream (boundary-bar assembly). */
 int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *const *dst, const size_t *bytes);
 
-/* ---- diagnostics ------------------------------------------------------------------------ */
-/* Read-only streaming bandwidth probe (tools/readbw.py): calibrates the HBM ceiling quoted in DESIGN.md.
- * variant 0: 16 B loads per lane, 1: 8 B loads per lane, 2: 4 B loads per lane, 3: 8 B STORES per lane (the buffer is
- * overwritten) -- the last three calibrate FETCH_SIZE / WRITE_SIZE for the access widths the reducers use
- * (tools/pmc_calibrate.py).  Not used by any product path. */
-int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int variant, int blocks_per_cu,
-                            double *elapsed_ms);
-/* float32 amounts with a full random 24-bit mantissa in [2^-7, 2) (sums inexact in every order, like real trade sizes): the
- * second cfg-4 timing of bench.py.  Not used by any product path. */
-int fmk_diag_fill_amounts_dev(fmk_ctx *ctx, uint64_t seed, int64_t n, float *d_amount);
-/* Two columns read in lock-step (tools/placement.py): 8 B elements of d_a8 and 4 B elements of d_b4 at the same index.
- * pattern 0: flat grid-stride; 1: each wave streams `seg` contiguous elements of both, then jumps by the number of waves
- * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only.  Not used by any product path. */
-int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
-                              int blocks_per_cu, double *elapsed_ms);
-/* Dependent-access latency of one wave (tools/hoplat.py): `hops` hops of `loads` coalesced 512 B rows, the next address
- * depending on the data read; shader cycles per hop.  Not used by any product path. */
-int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t stride, int loads, int hops,
-                         double *cycles_per_hop, double *elapsed_ms);
-
-/* Which tier the last fmk_cusum_bar_indexer[_dev] call of this process took (tests): *tier 1 = the chain walk of
- * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
- * 3 non-finite return, -1 not tried).  Not used by any product path. */
-/* host-to-device rate of this box for one buffer, GB/s, best of three: mode 1 = hipMemcpy from pinned memory (the link's ceiling),
- * 0 = hipMemcpy from pageable memory, 2 = fmk_h2d_columns from pageable memory */
-int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps);
-/* order-flow redo since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
- * pairs of column 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)} */
-int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10);
-int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
-/* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
-int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
-/* ... and into how many LATER segments that walk split the two sides' chains (0: each side walked in one piece); a segment
- * starts at a chunk boundary from which the side's state provably does not depend on earlier ticks (k_cc_sync).  *rate: the
- * estimate the tier was chosen by (512-tick sub-blocks per chunk and side of the leading chunks with a certain close; -1: none). */
-int fmk_diag_cusum_segments(int64_t *segments, double *rate);
+/* Diagnostics (bandwidth / latency probes, counters read by tests and tools) are NOT part of this ABI: include/fmk_diag.h. */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """The full-size parity tests say how many bars / closes / levels they compared: printed after the dots (also with -q) and
+    written to gpu_parity_counts.json (tests/_counts.py)."""
+    from tests import _counts
+    c = _counts.dump()
+    if c:
+        terminalreporter.write_line("gpu_parity_counts (also in gpu_parity_counts.json):")
+        for k in sorted(c):
+            terminalreporter.write_line("  %s: %s" % (k, ", ".join("%s=%s" % kv for kv in sorted(c[k].items()))))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """A fresh checkout has no finmlkit_amd/lib/libfmk_hip.so (build products are git-ignored): build it once

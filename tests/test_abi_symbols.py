@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "fmk.h")).read()
+def declared_symbols(header="fmk.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(fmk_[a-z0-9_]+)\s*\(", txt)))
 
@@ -30,6 +30,21 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in include/fmk.h but not exported: {missing}"
     assert lib.fmk_abi_version() == 1
+
+
+def test_diagnostics_are_not_in_the_drop_in_abi():
+    """include/fmk.h declares no probe / counter; include/fmk_diag.h declares them all, the probes are exported by libfmk_diag.so
+    (and NOT by the product library), the counters of the last call by libfmk_hip.so."""
+    from finmlkit_amd import _ffi
+    assert not [s for s in declared_symbols() if s.startswith("fmk_diag_")]
+    diag = [s for s in declared_symbols("fmk_diag.h") if s.startswith("fmk_diag_")]
+    assert len(diag) >= 9
+    for s in diag:
+        if s in _ffi.DIAG_PROBES:
+            assert hasattr(_ffi.diag_lib(), s), s
+            assert not hasattr(_ffi.lib(), s), f"{s} is still exported by the product library"
+        else:
+            assert hasattr(_ffi.lib(), s), s
 
 
 def test_no_cpu_fallback_without_device():

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from tests import _golden as G
+from tests._counts import record
 
 pytestmark = pytest.mark.gpu
 
@@ -407,10 +408,14 @@ def _mem_available_bytes():
 
 @pytest.fixture(scope="module")
 def host_cols(big):
-    """The device columns on the host: all n ticks, or the longest prefix for which columns + oracle outputs + HIP outputs fit in
-    a third of the available host memory (~60 B/tick all told)."""
+    """The device columns on the host: ALL n ticks.  A host too small for columns + oracle outputs + HIP outputs (~60 B/tick all
+    told, in a third of the available memory) FAILS the all-bars tests instead of silently comparing a prefix; FMK_FULLSIZE_ALLOW_PREFIX=1
+    (developer boxes) brings the prefix comparison back, and gpu_parity_counts.json says how much was compared either way."""
     engine, t, n = big
     m = min(n, int(_mem_available_bytes() / 3 // 60))
+    if m < n and not os.environ.get("FMK_FULLSIZE_ALLOW_PREFIX"):
+        pytest.fail(f"host memory holds {m:.3g} of the {n:.3g} ticks: the all-bars tests would compare a prefix only "
+                    "(FMK_FULLSIZE_ALLOW_PREFIX=1 to allow that)")
     cores = len(os.sched_getaffinity(0))
     os.environ["ORC_THREADS"] = str(cores)
     cols = tuple(None if c is None else c.view(0, m).to_host() for c in (t.ts, t.price, t.amount, t.side))
@@ -446,6 +451,8 @@ def test_all_bars_cfg2_against_threaded_oracle(big, host_cols, orc):
             np.testing.assert_array_equal(o[key][:k], w, err_msg=key)
     print(f"cfg 2: {k} of {len(cih) - 1} bars ({m:.3g} of {n:.3g} ticks) equal the oracle's; oracle {dt:.1f} s on "
           f"{os.environ['ORC_THREADS']} threads")
+    record("cfg2_time_bars_ohlcv_median", ticks_compared=m, ticks_total=n, bars_compared=k, bars_total=len(cih) - 1,
+           edges_compared=k + 1)
     # cfg 3 on the same columns: the reference's sequential loops (one thread, ~1 ns/tick) against the exact default mode
     vthr, dthr = 1728.5, 17_285_000.0
     for kind, got, w in (("volume", t.volume_bar_index(vthr).to_host(), orc._volume_bar_indexer(am, vthr)),
@@ -454,6 +461,7 @@ def test_all_bars_cfg2_against_threaded_oracle(big, host_cols, orc):
         np.testing.assert_array_equal(got[:kk], w[:kk] if m == n else w, err_msg=kind)
         assert m < n or len(got) == len(w)
         print(f"cfg 3 {kind}: {kk} closes equal the sequential loop's")
+        record(f"cfg3_{kind}_bar_closes", ticks_compared=m, ticks_total=n, closes_compared=kk, closes_total=len(got))
 
 
 def test_all_bars_cfg4_against_threaded_oracle(big, host_cols, orc):
@@ -478,10 +486,10 @@ def test_all_bars_cfg4_full_mantissa_sizes_against_threaded_oracle(big, host_col
     t.ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(42), c_i64(n), am2.p)
     t2 = engine.DeviceTrades(t.ctx, t.ts, t.price, am2, t.side)
     (ts, px, am, sd), m = host_cols
-    _cfg4_all_bars((engine, t2, n), ((ts, px, am2.view(0, m).to_host(), sd), m), orc, interval)
+    _cfg4_all_bars((engine, t2, n), ((ts, px, am2.view(0, m).to_host(), sd), m), orc, interval, tag="full_mantissa_sizes")
 
 
-def _cfg4_all_bars(big, host_cols, orc, interval):
+def _cfg4_all_bars(big, host_cols, orc, interval, tag="dyadic_sizes"):
     import time
     engine, t, n = big
     (ts, px, am, sd), m = host_cols
@@ -517,6 +525,8 @@ def _cfg4_all_bars(big, host_cols, orc, interval):
         np.testing.assert_array_equal(bar[key].to_host()[:k], wbar[key], err_msg=key)
     np.testing.assert_allclose(bar["vp_skew"].to_host()[:k], wbar["vp_skew"], atol=1e-6)
     print(f"cfg 4, {interval:.0f} s bars: {k} bars, {nl} footprint levels equal the oracle's; oracle {dt:.1f} s")
+    record(f"cfg4_{tag}_{interval:.0f}s_bars", ticks_compared=m, ticks_total=n, bars_compared=k, bars_total=len(cih) - 1,
+           footprint_levels_compared=nl)
 
 
 @pytest.mark.parametrize("interval", [60.0, 150.0, 600.0, 1200.0, 1500.0, 3600.0])
@@ -541,3 +551,4 @@ def test_all_bars_trade_size_against_threaded_oracle(big, host_cols, orc, interv
     for key, w in zip(["mean_size_rel", "size_95_rel", "pct_block", "size_gini"], want):
         np.testing.assert_array_equal(got[key][:k], w, err_msg=f"{key} interval {interval}")
     print(f"trade size, {interval:.0f} s bars: {k} bars equal the oracle's; oracle {dt:.1f} s")
+    record(f"trade_size_{interval:.0f}s_bars", ticks_compared=m, ticks_total=n, bars_compared=k, bars_total=len(cih) - 1)

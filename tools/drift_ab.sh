@@ -1,7 +1,8 @@
 #!/bin/bash
 # Headline drift: on ONE box, interleave R runs each of the round-1, round-2 and round-3 end
 # libraries (built from 2349744^, 80570ca^ and bee7b92^ into finmlkit_amd/lib/ab/) and the current library, each run a
-# fresh process that allocates its own inputs:  bench.py --no-extras --cpu-sample 0 --steps 20 --warmup 5.
+# fresh process that allocates its own inputs:  bench.py --no-extras --cpu-sample 0 --steps 20 --warmup 5 --separate-index
+# --placements 1 (the two-call step every library has; ONE allocation of the inputs, no choice).
 # Prints one line per run: library, ms_per_step, avg dominant-kernel ms, roofline fraction.
 R=${1:-6}
 OUT=${2:-gpurun_out/r04_drift.txt}
@@ -12,7 +13,7 @@ for r in $(seq 1 $R); do
   for l in $LIBS; do
     if [ $l = head ]; then lib=finmlkit_amd/lib/libfmk_hip.so; else lib=finmlkit_amd/lib/ab/libfmk_hip_$l.so; fi
     [ -f $lib ] || continue
-    line=$(timeout 300 python tools/ab_lib.py $lib bench.py --no-extras --cpu-sample 0 --steps 20 --warmup 5 2>/dev/null | tail -1)
+    line=$(timeout 300 python tools/ab_lib.py $lib bench.py --no-extras --cpu-sample 0 --steps 20 --warmup 5 --separate-index --placements 1 2>/dev/null | tail -1)
     echo "$line" | python -c "
 import json,sys
 try:
