@@ -273,37 +273,51 @@ def other_configs(trades, ctx, args):
     return out
 
 
-def choose_placement(ctx, trades, args, rank, n):
-    """K allocations of the input columns (the first is `trades`), each probed with 2 + 5 passes of the step's dominant call;
-    -> (the fastest copy, {"probe_kernel_ms": [...], "chosen": k, ...}).  The other copies are freed before the timed region."""
+def _probe_step_kernel_ms(ctx, fn, steps):
+    """Kernel time per step (ms) of `steps` calls of fn: the library's HIP-event pairs around every launch of the dominant kernel,
+    summed per step (the pipelined step launches it twice)."""
     import ctypes as C
+    ctx.sync()
+    ctx.call("fmk_profile_enable", C.c_int(1))
+    for _ in range(steps):
+        fn()
+    k = (C.c_double * 256)()
+    kn = C.c_int()
+    ctx.call("fmk_profile_read", k, C.c_int(256), C.byref(kn))
+    ctx.call("fmk_profile_enable", C.c_int(0))
+    return sum(k[i] for i in range(kn.value)) / steps
+
+
+def choose_placement(ctx, trades, args, rank, n, step_of):
+    """K allocations of the input columns (the first is `trades`), all held at once; each is probed with the bench's own step (3 untimed
+    + 8 timed passes, kernel time by HIP events), the fastest stays and the others are freed.  Then the chosen copy is run until its level
+    has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before; at most 40 steps): the first passes over a new
+    allocation run up to 10 % slower than the level it settles at (profiles/r04_step_timeline.txt).  All of it is set-up, before the
+    warm-up; -> (the chosen copy, {"probe_kernel_ms": [...], "chosen": k, "settle_kernel_ms": [...]})."""
     from finmlkit_amd import engine
     copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx) for _ in range(args.placements - 1)]
-    want_median = not args.no_median
     ms = []
-    clock = idx = out = None
     for t in copies:
-        for _ in range(2):
-            clock, idx, out = t.time_bars_ohlcv(args.interval, want_median, out_index=(clock, idx) if clock else None, out=out)
-        ctx.sync()
-        ctx.call("fmk_profile_enable", C.c_int(1))
-        for _ in range(5):
-            t.time_bars_ohlcv(args.interval, want_median, out_index=(clock, idx), out=out)
-        k = (C.c_double * 64)()
-        kn = C.c_int()
-        ctx.call("fmk_profile_read", k, C.c_int(64), C.byref(kn))
-        ctx.call("fmk_profile_enable", C.c_int(0))
-        ms.append(sum(k[i] for i in range(kn.value)) / max(kn.value, 1))
+        fn = step_of(t)
+        for _ in range(3):
+            fn()
+        ms.append(_probe_step_kernel_ms(ctx, fn, 8))
     best = min(range(len(ms)), key=lambda i: ms[i])
     chosen = copies[best]
-    info = {"policy": f"best of {len(copies)} allocations of the input columns by a 5-step probe of the dominant kernel "
-                      "(set-up, before warm-up; the other copies are freed)",
-            "probe_kernel_ms": ms, "chosen": best}
     for i, t in enumerate(copies):
         if i != best:
             for col in getattr(t, "_backing", []):
                 col.free()
     del copies
+    fn = step_of(chosen)
+    settle = [_probe_step_kernel_ms(ctx, fn, 5)]
+    while len(settle) < 8:
+        settle.append(_probe_step_kernel_ms(ctx, fn, 5))
+        if settle[-1] > settle[-2] * 0.995:
+            break
+    info = {"policy": f"best of {len(ms)} allocations of the input columns by an 8-step probe of the step's dominant kernel, then run "
+                      "until its level settles (set-up, before the warm-up; the other copies are freed)",
+            "probe_kernel_ms": ms, "chosen": best, "settle_kernel_ms": settle}
     return chosen, info
 
 
@@ -408,11 +422,6 @@ def run(args):
     trades = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx)
     ctx.sync()
     placement = None
-    if args.placements > 1 and (args.placements - 1) * n * 21 + (8 << 30) < free - need:
-        # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-4 % between allocations of one
-        # process, constant for the life of an allocation: profiles/r04_placement.txt).  Set-up, not a step: K copies of the
-        # same ticks, each probed with the step itself; the fastest stays, the others are freed.
-        trades, placement = choose_placement(ctx, trades, args, rank, n)
 
     transport_note = None
     transport = "none"
@@ -453,6 +462,25 @@ def run(args):
             state["clock"] = DeviceArray(ctx, cap, np.int64)
             state["idx"] = DeviceArray(ctx, cap, np.int64)
             state["out"] = trades.alloc_ohlcv(cap, want_median)
+
+    if args.placements > 1 and not use_dist and (args.placements - 1) * n * 21 + (8 << 30) < free - need:
+        # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-5 % between allocations of one
+        # process, constant for the life of an allocation: profiles/r04_placement.txt, r04_drift.txt).  Set-up, not a step: K
+        # copies of the same ticks, each probed with the step itself; the fastest stays, the others are freed.
+        def step_of(t):
+            t0, t1 = t.first_last_ts()
+            ne, e0, d = clock_of(t0, t1)
+            ensure_buffers(ne)
+            if args.separate_index:
+                def fn():
+                    clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
+                    t.bar_ohlcv(ci, want_median=want_median, out=state["out"])
+            else:
+                def fn():
+                    t.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
+                                      out_index=(state["clock"], state["idx"]), out=state["out"])
+            return fn
+        trades, placement = choose_placement(ctx, trades, args, rank, n, step_of)
 
     if use_dist:
         # SET-UP, not a step: the plan (global clock, edge partition, halo lengths, boundary buffers) is a function of
@@ -502,12 +530,17 @@ def run(args):
         step()
     barrier()
     elapsed = time.perf_counter() - t_start
-    kms = (C.c_double * 64)()
+    kms = (C.c_double * 256)()
     kn = C.c_int()
-    ctx.call("fmk_profile_read", kms, C.c_int(64), C.byref(kn))
+    ctx.call("fmk_profile_read", kms, C.c_int(256), C.byref(kn))
     ctx.call("fmk_profile_enable", C.c_int(0))
 
     k_ms = [kms[i] for i in range(kn.value)]
+    # the pipelined time-bar step launches the dominant kernel TWICE per step (the first eighth of the bars, then the rest): the
+    # kernel time of a step is the sum of its launches, each timed on its own (the bubble between them is not kernel time)
+    lps = max(1, round(len(k_ms) / args.steps)) if len(k_ms) % args.steps == 0 else 1
+    if lps > 1:
+        k_ms = [sum(k_ms[i * lps:(i + 1) * lps]) for i in range(len(k_ms) // lps)]
     avg_k_ms = sum(k_ms) / len(k_ms)
     per_rank = None
     if comm:
@@ -576,9 +609,14 @@ def run(args):
                                             f"{tc['commit']}; profiles/traffic_constants.json: FETCH_SIZE x{tc['fetch_size_correction']}, "
                                             f"WRITE_SIZE x{tc['write_size_correction']}, calibrated on known byte counts in the same passes), "
                                             f"scaled to this run's ticks and bars; not collected in this run") if tc_ok else None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes / lps, "avg_kernel_ms": avg_k_ms,
+                         "avg_launch_ms": avg_k_ms / lps, "launches_per_step": lps,
+                         "launches_note": (None if lps == 1 else
+                                           f"{lps} launches of the kernel per step over disjoint bar ranges (pipelined time-bar step): "
+                                           "achieved = bytes of a step / summed duration of its launches = bytes per launch / average "
+                                           "launch duration (avg_launch_ms is what a rocprofv3 kernel summary averages)"),
                          "kernel_ms_min": min(k_ms), "kernel_ms_max": max(k_ms),
-                         "launches_timed": len(k_ms)},
+                         "launches_timed": len(k_ms) * lps},
         }
         if placement:
             # the same fraction for every allocation probed (frac = algorithmic bytes / probe time / peak): what the run would have

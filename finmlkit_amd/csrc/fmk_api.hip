@@ -98,6 +98,13 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     (void)hipHostFree(ctx->h_mail);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    if (ctx->kev[0][0])
+        for (int i = 0; i < FMK_PROFILE_SLOTS; ++i) { (void)hipEventDestroy(ctx->kev[i][0]); (void)hipEventDestroy(ctx->kev[i][1]); }
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->aev[i]);
+        (void)hipStreamDestroy(ctx->aux);
+    }
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
     return FMK_OK;
@@ -338,7 +345,7 @@ int fmk_profile_enable(fmk_ctx *ctx, int on)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     if (on && !ctx->kev[0][0])
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < FMK_PROFILE_SLOTS; ++i) {
             FMK_HIP(ctx, hipEventCreate(&ctx->kev[i][0]));
             FMK_HIP(ctx, hipEventCreate(&ctx->kev[i][1]));
         }
@@ -362,7 +369,7 @@ int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on)
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count)
 {
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int n = ctx->profile_n < 64 ? ctx->profile_n : 64;
+    int n = ctx->profile_n < FMK_PROFILE_SLOTS ? ctx->profile_n : FMK_PROFILE_SLOTS;
     if (n > capacity) n = capacity;
     for (int i = 0; i < n; ++i) {
         float t = 0.f;
@@ -389,3 +396,21 @@ int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out)
     *out = ctx->scratch;
     return FMK_OK;
 }
+
+// the auxiliary stream of the pipelined time-bar step and its events (timing disabled: they only order the two streams)
+int fmk_ctx_aux(fmk_ctx *ctx)
+{
+    if (ctx->aux) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st;
+    // lowest priority: its kernels run beside a launch of the context's stream and must not take that launch's wave slots
+    int plo = 0, phi = 0;
+    FMK_HIP(ctx, hipDeviceGetStreamPriorityRange(&plo, &phi));
+    const char *pv = getenv("FMK_AUX_PRIORITY");                 // developer knob: 0 = default priority
+    if (pv && atoi(pv) == 0) FMK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    else FMK_HIP(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, plo));
+    for (int i = 0; i < 4; ++i) FMK_HIP(ctx, hipEventCreateWithFlags(&ctx->aev[i], hipEventDisableTiming));
+    ctx->aux = st;
+    return FMK_OK;
+}
+

@@ -10,6 +10,7 @@
 #include "../../include/fmk.h"
 
 #define FMK_WAVE 64
+#define FMK_PROFILE_SLOTS 256              // launches fmk_profile_* can time between enable and read
 
 struct fmk_ctx {
     int device;
@@ -30,7 +31,7 @@ struct fmk_ctx {
     int fast_threshold;
     // 1 = calls never wait for the device where they have the choice (fmk_ctx_set_enqueue_only)
     int enqueue_only;
-    hipEvent_t kev[64][2];
+    hipEvent_t kev[FMK_PROFILE_SLOTS][2];
     // stream-ordered caching allocator behind fmk_alloc / fmk_free (fmk_api.hip): freed blocks are kept and handed
     // out again to later requests of (almost) the same size -- no hipMalloc / hipFree / synchronisation per call
     void *pool;
@@ -42,7 +43,16 @@ struct fmk_ctx {
     int idx_stale[3];
     // pinned staging buffers / streams of fmk_h2d_columns (fmk_upload.hip), made on first use
     void *upload;
+    // auxiliary stream + events of the pipelined time-bar step (fmk_ohlcv.hip), made on first use (fmk_ctx_aux)
+    hipStream_t aux;
+    hipEvent_t aev[4];
 };
+int fmk_ctx_aux(fmk_ctx *ctx);
+// fmk_indexers.hip: the time-bar indexer in stages (sample table, then edges [k0, k1) on a given stream, with the long-bar census)
+int fmk_time_bar_coarse_launch(fmk_ctx *ctx, const int64_t *d_ts, int64_t n, const int64_t **coarse, int64_t *m_out, int *clear);
+int fmk_time_bar_index_stage(fmk_ctx *ctx, hipStream_t st, const int64_t *d_ts, int64_t n, int64_t e0, int64_t d, int64_t ne,
+                             const int64_t *coarse, int64_t m, int64_t k0, int64_t k1, int64_t *d_clock, int64_t *d_idx,
+                             int *saw_long, int64_t long_min, int64_t max_blocks /* 0: one workgroup per 256 edges */);
 
 int fmk_set_error(fmk_ctx *ctx, int code, const char *fmt, ...);
 int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out);

@@ -58,9 +58,10 @@ extern "C" int fmk_time_bar_clock(int64_t ts_first, int64_t ts_last, double inte
 #define TB_COARSE_SHIFT 12
 
 __global__ __launch_bounds__(256) void k_time_bar_coarse(const int64_t *__restrict__ ts, int64_t n,
-                                                         int64_t *__restrict__ coarse, int64_t m)
+                                                         int64_t *__restrict__ coarse, int64_t m, int *__restrict__ clear = nullptr)
 {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (clear && j == 0) *clear = 0;                                   // (a flag word the next launches raise: saves a memset node)
     if (j < m) coarse[j] = ts[j << TB_COARSE_SHIFT];
 }
 
@@ -112,6 +113,82 @@ __global__ __launch_bounds__(256) void k_time_bar_index(const int64_t *__restric
     const int64_t hi = hi_real ? (j + 1) << TB_COARSE_SHIFT : n;
     const int64_t vlo = coarse[j], vhi = hi_real ? coarse[j + 1] : 0;
     idx[k] = tb_last_le([ts](int64_t i) { return ts[i]; }, lo, hi, vlo, vhi, hi_real, edge, 48);
+}
+
+// searchsorted(ts, edge, side='right') - 1 through the sample table (the body of k_time_bar_index)
+__device__ __forceinline__ int64_t tb_index_of(const int64_t *__restrict__ ts, int64_t n, const int64_t *__restrict__ coarse, int64_t m,
+                                               int64_t edge)
+{
+    const int64_t c_first = coarse[0], c_last = coarse[m - 1];
+    if (edge < c_first) return -1;
+    const int64_t j = edge >= c_last ? m - 1
+                                     : tb_last_le([coarse](int64_t i) { return coarse[i]; }, 0, m - 1, c_first, c_last, true, edge, 8);
+    const int64_t lo = j << TB_COARSE_SHIFT;
+    const bool hi_real = j + 1 < m;
+    const int64_t hi = hi_real ? (j + 1) << TB_COARSE_SHIFT : n;
+    const int64_t vlo = coarse[j], vhi = hi_real ? coarse[j + 1] : 0;
+    return tb_last_le([ts](int64_t i) { return ts[i]; }, lo, hi, vlo, vhi, hi_real, edge, 48);
+}
+
+// Edges [k0, k1) of the clock -- one STAGE of the pipelined time-bar step (fmk_time_bars_ohlcv_dev, fmk_ohlcv.hip): the first stage
+// is short and runs in front of the first OHLCV launch, the second runs on the context's auxiliary stream beside it.  The stage also
+// answers the question the OHLCV call otherwise has to wait for its main kernel to ask: is any bar longer than `long_min` ticks?
+// (bar k = ticks idx[k]+1 .. idx[k+1]: neighbours meet in LDS, the last thread of a workgroup searches edge k+1 itself) -- so the
+// host learns it ~2 ms before the main kernel ends and the call returns without waiting for the device.
+__global__ __launch_bounds__(256) void k_time_bar_index_stage(const int64_t *__restrict__ ts, int64_t n, int64_t e0, int64_t d,
+                                                              int64_t ne, const int64_t *__restrict__ coarse, int64_t m,
+                                                              int64_t k0, int64_t k1, int64_t *__restrict__ clock,
+                                                              int64_t *__restrict__ idx, int *__restrict__ saw_long, int64_t long_min)
+{
+    __shared__ int64_t sidx[256];
+    // grid-stride over groups of 256 edges: the stage that runs BESIDE an OHLCV launch is given a small grid, so that it does not
+    // take the wave slots of the launch it is meant to hide behind
+    for (int64_t g = k0 + (int64_t)blockIdx.x * 256; g < k1; g += (int64_t)gridDim.x * 256) {
+        const int64_t k = g + threadIdx.x;
+        const bool live = k < k1;
+        int64_t me = 0;
+        if (live) {
+            const int64_t edge = e0 + k * d;
+            me = tb_index_of(ts, n, coarse, m, edge);
+            if (clock) clock[k] = edge;
+            idx[k] = me;
+        }
+        __syncthreads();                                                 // (the previous group's readers are done)
+        sidx[threadIdx.x] = me;
+        __syncthreads();
+        if (live && k + 1 < ne) {
+            const int64_t nx = (threadIdx.x + 1 < 256 && k + 1 < k1) ? sidx[threadIdx.x + 1]
+                                                                      : tb_index_of(ts, n, coarse, m, e0 + (k + 1) * d);
+            if (nx - me > long_min && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the sample table of a column in the context's scratch, on the context's stream (-> *coarse, *m)
+int fmk_time_bar_coarse_launch(fmk_ctx *ctx, const int64_t *d_ts, int64_t n, const int64_t **coarse, int64_t *m_out, int *clear)
+{
+    const int64_t m = fmk_ceil_div(n, (int64_t)1 << TB_COARSE_SHIFT);
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, (size_t)m * 8, &scr));
+    k_time_bar_coarse<<<(unsigned)fmk_ceil_div(m, 256), 256, 0, ctx->stream>>>(d_ts, n, (int64_t *)scr, m, clear);
+    FMK_LAUNCH_CHECK(ctx);
+    *coarse = (const int64_t *)scr;
+    *m_out = m;
+    return FMK_OK;
+}
+
+int fmk_time_bar_index_stage(fmk_ctx *ctx, hipStream_t st, const int64_t *d_ts, int64_t n, int64_t e0, int64_t d, int64_t ne,
+                             const int64_t *coarse, int64_t m, int64_t k0, int64_t k1, int64_t *d_clock, int64_t *d_idx,
+                             int *saw_long, int64_t long_min, int64_t max_blocks)
+{
+    if (k1 <= k0) return FMK_OK;
+    int64_t blocks = fmk_ceil_div(k1 - k0, 256);
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    k_time_bar_index_stage<<<(unsigned)blocks, 256, 0, st>>>(d_ts, n, e0, d, ne, coarse, m, k0, k1, d_clock,
+                                                                                  d_idx, saw_long, long_min);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
 }
 
 // Round 4 experiment (off by default, see the knob below): interpolation search straight on the column, no sample table (one launch

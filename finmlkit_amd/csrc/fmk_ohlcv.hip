@@ -1446,6 +1446,67 @@ static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb, bool fused = false)
     return (unsigned)blocks;
 }
 
+// What the first kernel of a comp_bar_ohlcv call left behind (bars longer than `long_min` ticks; `saw_long`: its flag)
+template <bool AF64>
+static int ohlcv_leftovers(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n,
+                           const OhlcvOut &o, int *saw_long, int64_t long_min, unsigned grid)
+{
+    // long bars (if any): the generic kernels exit at once when the flag is clear.  float32 bars of 1 345 .. 8 192 ticks: one pass by
+    // a workgroup each, median included (developer knob FMK_OHLCV_MID=0: the generic kernels + the median kernels as before)
+    int64_t skip_lo = 0, skip_hi = 0;
+    if constexpr (!AF64) {
+        const char *mv = getenv("FMK_OHLCV_MID");
+        if (!mv || atoi(mv)) {
+            skip_lo = OHM_MIN;
+            skip_hi = OHM_MAX;
+            // 1 345 .. 2 048, .. 3 072, .. 4 096, .. 6 144 ticks: a wave per bar with 32 / 48 / 64 / 96 key registers; 6 145 .. 8 192: a workgroup per bar
+            constexpr int NL = 6;
+            int64_t *list[NL] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const int64_t edge[NL + 1] = {OHM_MIN, 2048, 3072, 4096, 6144, 8192, OHM_MAX};
+            int rc = fmk_long_bar_lists(ctx, ci, nb, n, NL, edge, saw_long, list);      // (one pass, one allocation: list[0] owns it)
+            // measured per 1e9 ticks, ohlcv + median (profiles/r03_median_humps.txt): 4 400 / 5 200 / 6 000-tick bars 3.6 / 3.4 / 3.1 ms
+            // with 96 key registers per lane against 5.1 / 4.5 / 4.0 ms by the workgroup kernel; 7 000 / 8 000-tick bars 5.5 / 5.2 ms
+            // with 128 key registers (spills) against 3.6 / 3.3 ms by the workgroup kernel
+            if (rc == FMK_OK) {
+                const float *af = (const float *)a;
+                const unsigned g = (unsigned)(ctx->n_cu * 8);
+                if (o.median) {
+                    k_bar_ohlcv_phased<true, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
+                    k_bar_ohlcv_phased<true, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
+                    k_bar_ohlcv_phased<true, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
+                    k_bar_ohlcv_phased<true, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
+                    k_bar_ohlcv_mid<true, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<true, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
+                } else {
+                    k_bar_ohlcv_phased<false, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
+                    k_bar_ohlcv_phased<false, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
+                    k_bar_ohlcv_phased<false, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
+                    k_bar_ohlcv_phased<false, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
+                    k_bar_ohlcv_mid<false, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
+                    k_bar_ohlcv_mid<false, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
+                }
+            }
+            const hipError_t le = hipGetLastError();
+            if (list[0]) (void)fmk_free(ctx, list[0]);
+            FMK_TRY(rc);
+            FMK_HIP(ctx, le);
+        }
+    }
+    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o, skip_lo, skip_hi);
+    int wide_median_done = 0;
+    const int64_t wide_min = skip_hi > OH_WIDE_MIN ? skip_hi : OH_WIDE_MIN;       // the workgroup classes reach further than the generic kernel
+    FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o, &wide_median_done, wide_min));
+    FMK_LAUNCH_CHECK(ctx);
+    if (AF64) {
+        k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    if (o.median)
+        return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n, skip_lo, skip_hi,
+                                 wide_median_done ? wide_min : INT64_MAX);
+    return FMK_OK;
+}
+
 template <bool AF64>
 static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int64_t *ci, int64_t nb, int64_t n,
                         const OhlcvOut &o_in, int variant, const TbFuse *tb = nullptr)
@@ -1455,13 +1516,21 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     // tb: the close indices are not there yet (fmk_time_bars_ohlcv_dev) -- the 1-minute schedule finds them inside its kernel
     // (k_time_bars_ohlcv), every other schedule runs the separate indexer first
     bool fuse_index = false;
+    int64_t pipe_ka = 0;                     // > 0: bars [0, pipe_ka) are the first stage of the pipelined time-bar step
     if (tb) {
         static int fuse_on = -1;             // developer knob: FMK_OHLCV_FUSE_INDEX=1 -> the edge search inside the OHLCV kernel
         if (fuse_on < 0) { const char *v = getenv("FMK_OHLCV_FUSE_INDEX"); fuse_on = v ? atoi(v) : 0; }
         static int mid2 = -1;
         if (mid2 < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2 = v ? atoi(v) : 600; }
         fuse_index = fuse_on && variant != 0 && nb >= 64 && n / nb > mid2;      // = the last branch of the schedule choice below
-        if (!fuse_index)
+        // PIPELINED time-bar step (the default for the 1-minute schedule, float32 amounts): the indexer in two stages -- see below
+        static int split = -1;               // developer knob: FMK_TB_PIPE_SPLIT = 1 / share of the bars in the first stage (0: off)
+        if (split < 0) { const char *v = getenv("FMK_TB_PIPE_SPLIT"); split = v ? atoi(v) : 8; }
+        const char *msv = getenv("FMK_TB_PIPE_MIN_STAGE");            // developer knob (tests): bars in the first stage from which the
+        const int64_t min_stage = msv ? atoll(msv) : 4096;            // step is pipelined (read on every call)
+        if (!AF64 && !fuse_index && split >= 2 && variant != 0 && n / nb > mid2 && nb / split >= min_stage && min_stage >= 256) {
+            pipe_ka = (nb / split) & ~(int64_t)255;
+        } else if (!fuse_index)
             FMK_TRY(fmk_time_bar_indexer_dev(ctx, tb->ts, n, tb->e0, tb->d, nb + 1, tb->clock, tb->idx));
         ci = tb->idx;
     }
@@ -1470,7 +1539,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         FMK_HIP(ctx, hipMemsetAsync(o.vol_redo, 0, 8, ctx->stream));
     }
     // time the dominant launch only (the one-bar boundary launch of a sharded step is not it)
-    const int slot = (ctx->profile_on && nb >= 64) ? (ctx->profile_n++ & 63) : -1;
+    const int slot = (ctx->profile_on && nb >= 64 && pipe_ka == 0) ? (ctx->profile_n++ & (FMK_PROFILE_SLOTS - 1)) : -1;
     if (slot >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[slot][0], ctx->stream));
     if (variant == 0) {   // generic streaming kernel only (+ stand-alone median)
         k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, 0, nullptr, o);
@@ -1483,6 +1552,57 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         }
         if (o.median) return fmk_median_launch(ctx, a, AF64, ci, nb, 0, nullptr, o.median, n);
         return FMK_OK;
+    }
+    if constexpr (!AF64) {
+        if (pipe_ka > 0) {
+            // ---- the pipelined time-bar step (round 4).  The indexer (0.13 ms: sample table + one search per clock edge, bound by
+            // random line fetches) used to stand in front of a 2.2 ms kernel that cannot start without it, and the call ended with a
+            // read-back of the long-bar flag (memset + copy + host wait + the host's way back into the next call: another 0.05 ms
+            // of idle device per step; rocprofv3 timeline in profiles/r04_step_timeline.txt).  Now: sample table and the edges of
+            // the first 1/8 of the bars on the context's stream (~25 us), OHLCV + median of those bars, and BESIDE that launch the
+            // remaining edges on the auxiliary stream; the second OHLCV launch waits for them by event.  Both index stages also take
+            // the census (is any bar longer than 1 344 ticks?), so the flag reaches the host while the first OHLCV launch is still
+            // running: the call decides about the leftover passes and returns without ever waiting for a kernel it launched.
+            FMK_TRY(fmk_ctx_aux(ctx));
+            static int idx_bpc = -1;         // developer knob: FMK_TB_PIPE_IDX_BPC = workgroups per CU of the second index stage (0: no cap)
+            if (idx_bpc < 0) { const char *v = getenv("FMK_TB_PIPE_IDX_BPC"); idx_bpc = v ? atoi(v) : 2; }
+            int *saw_long = (int *)(ctx->d_mail + 16);
+            const int64_t *coarse = nullptr;
+            int64_t m = 0;
+            const int64_t ne = nb + 1, long_min = 64 * FMK_SMALL_NCH;
+            FMK_TRY(fmk_time_bar_coarse_launch(ctx, tb->ts, n, &coarse, &m, saw_long));          // (also clears the flag)
+            FMK_TRY(fmk_time_bar_index_stage(ctx, ctx->stream, tb->ts, n, tb->e0, tb->d, ne, coarse, m, 0, pipe_ka + 1, tb->clock,
+                                             tb->idx, saw_long, long_min, 0));
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[0], ctx->stream));
+            FMK_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->aev[0], 0));
+            FMK_TRY(fmk_time_bar_index_stage(ctx, ctx->aux, tb->ts, n, tb->e0, tb->d, ne, coarse, m, pipe_ka + 1, ne, tb->clock,
+                                             tb->idx, saw_long, long_min, (int64_t)ctx->n_cu * idx_bpc));
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[1], ctx->aux));
+            int *h_saw = (int *)(ctx->h_mail + 50);
+            if (!ctx->enqueue_only) {
+                FMK_HIP(ctx, hipMemcpyAsync(h_saw, saw_long, sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
+                FMK_HIP(ctx, hipEventRecord(ctx->aev[2], ctx->aux));
+            }
+            for (int stage = 0; stage < 2; ++stage) {
+                const int64_t b0 = stage ? pipe_ka : 0, cnt = stage ? nb - pipe_ka : pipe_ka;
+                OhlcvOut q = o;
+                q.open += b0; q.high += b0; q.low += b0; q.close += b0; q.vol += b0; q.vwap += b0; q.trades += b0;
+                if (q.median) q.median += b0;
+                if (stage) FMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aev[1], 0));
+                const int sl = (ctx->profile_on) ? (ctx->profile_n++ & (FMK_PROFILE_SLOTS - 1)) : -1;      // each launch of the dominant kernel on its own
+                if (sl >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[sl][0], ctx->stream));
+                const unsigned g = ohlcv_grid(ctx, cnt);
+                if (!o.median) k_bar_ohlcv_small<AF64, false><<<g, 256, 0, ctx->stream>>>(p, a, ci + b0, cnt, n, saw_long, q);
+                else k_bar_ohlcv_small<AF64, true><<<g, 256, 0, ctx->stream>>>(p, a, ci + b0, cnt, n, saw_long, q);
+                FMK_LAUNCH_CHECK(ctx);
+                if (sl >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[sl][1], ctx->stream));
+            }
+            if (!ctx->enqueue_only) {
+                FMK_HIP(ctx, hipEventSynchronize(ctx->aev[2]));          // the index stages' census: long before the kernels end
+                if (*h_saw == 0) return FMK_OK;
+            }
+            return ohlcv_leftovers<AF64>(ctx, p, a, ci, nb, n, o, saw_long, 64 * FMK_SMALL_NCH, grid);
+        }
     }
     // small bars: all loads up front (+ fused median); long bars: generic kernels on the rest
     // launch bounds measured on MI355X: forcing >4 waves/SIMD on the fused-median kernel makes the compiler
@@ -1559,60 +1679,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
             if (*h_saw == 0) return FMK_OK;
         }
     }
-    // long bars (if any): the generic kernels exit at once when the flag is clear.  float32 bars of 1 345 .. 8 192 ticks: one pass by
-    // a workgroup each, median included (developer knob FMK_OHLCV_MID=0: the generic kernels + the median kernels as before)
-    int64_t skip_lo = 0, skip_hi = 0;
-    if constexpr (!AF64) {
-        const char *mv = getenv("FMK_OHLCV_MID");
-        if (!mv || atoi(mv)) {
-            skip_lo = OHM_MIN;
-            skip_hi = OHM_MAX;
-            // 1 345 .. 2 048, .. 3 072, .. 4 096, .. 6 144 ticks: a wave per bar with 32 / 48 / 64 / 96 key registers; 6 145 .. 8 192: a workgroup per bar
-            constexpr int NL = 6;
-            int64_t *list[NL] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            static const int64_t edge[NL + 1] = {OHM_MIN, 2048, 3072, 4096, 6144, 8192, OHM_MAX};
-            int rc = fmk_long_bar_lists(ctx, ci, nb, n, NL, edge, saw_long, list);      // (one pass, one allocation: list[0] owns it)
-            // measured per 1e9 ticks, ohlcv + median (profiles/r03_median_humps.txt): 4 400 / 5 200 / 6 000-tick bars 3.6 / 3.4 / 3.1 ms
-            // with 96 key registers per lane against 5.1 / 4.5 / 4.0 ms by the workgroup kernel; 7 000 / 8 000-tick bars 5.5 / 5.2 ms
-            // with 128 key registers (spills) against 3.6 / 3.3 ms by the workgroup kernel
-            if (rc == FMK_OK) {
-                const float *af = (const float *)a;
-                const unsigned g = (unsigned)(ctx->n_cu * 8);
-                if (o.median) {
-                    k_bar_ohlcv_phased<true, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
-                    k_bar_ohlcv_phased<true, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
-                    k_bar_ohlcv_phased<true, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
-                    k_bar_ohlcv_phased<true, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
-                    k_bar_ohlcv_mid<true, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
-                    k_bar_ohlcv_mid<true, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
-                } else {
-                    k_bar_ohlcv_phased<false, 32, 16><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[0], saw_long, o);
-                    k_bar_ohlcv_phased<false, 48, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[1], saw_long, o);
-                    k_bar_ohlcv_phased<false, 64, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[2], saw_long, o);
-                    k_bar_ohlcv_phased<false, 96, 8><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[3], saw_long, o);
-                    k_bar_ohlcv_mid<false, 32, 256><<<g, 256, 0, ctx->stream>>>(p, af, ci, list[4], saw_long, o);
-                    k_bar_ohlcv_mid<false, 32, 512><<<g / 2, 512, 0, ctx->stream>>>(p, af, ci, list[5], saw_long, o);
-                }
-            }
-            const hipError_t le = hipGetLastError();
-            if (list[0]) (void)fmk_free(ctx, list[0]);
-            FMK_TRY(rc);
-            FMK_HIP(ctx, le);
-        }
-    }
-    k_bar_ohlcv<AF64><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, long_min, saw_long, o, skip_lo, skip_hi);
-    int wide_median_done = 0;
-    const int64_t wide_min = skip_hi > OH_WIDE_MIN ? skip_hi : OH_WIDE_MIN;       // the workgroup classes reach further than the generic kernel
-    FMK_TRY(oh_wide_launch<AF64>(ctx, p, a, ci, nb, n, saw_long, o, &wide_median_done, wide_min));
-    FMK_LAUNCH_CHECK(ctx);
-    if (AF64) {
-        k_bar_vol_redo<<<grid < 4096 ? grid : 4096, 256, 0, ctx->stream>>>((const double *)a, ci, o.vol, o.vol_redo);
-        FMK_LAUNCH_CHECK(ctx);
-    }
-    if (o.median)
-        return fmk_median_launch(ctx, a, AF64, ci, nb, long_min, saw_long, o.median, n, skip_lo, skip_hi,
-                                 wide_median_done ? wide_min : INT64_MAX);
-    return FMK_OK;
+    return ohlcv_leftovers<AF64>(ctx, p, a, ci, nb, n, o, saw_long, long_min, grid);
 }
 
 // comp_bar_ohlcv (without the median) for the bars longer than min_cnt that another kernel left behind (`go`: its flag)

@@ -529,6 +529,8 @@ void fmk_volume_trim(fmk_ctx *ctx)
 
 static int vol_certify(fmk_ctx *ctx, const void *a, int is_f64, int64_t n, double thr, VolCache &c);
 
+#include "fmk_volume_exact.h"     // the exact-sum tier (round 4): k_vx_level0, k_vx_emit, vx_run
+
 // returns FMK_OK, 1 (the next tier), 2 (negative / NaN amounts), 3 (a replayed decision disagrees: serial walk) or an error
 template <bool AF64, int S>
 static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c)
@@ -1602,7 +1604,20 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         if (rcs && rcs != 2) return rcs;
         const double est_len = est_total > 0.0 ? (double)ns * threshold / est_total : 1e300;
         int rc = 1;
-        if (est_len < 1800.0)
+        // the exact-sum tier first (fmk_volume_exact.h): every window certifies that its float64 sums are exact, so there is no
+        // tie zone to replay; entry tables for the first 1024 / 2048 ticks of 4096-tick blocks.  A window that does not certify or
+        // a bar beyond the table span hands the call to the tiers below (developer knob FMK_VOL_EXACT_TIER=0: skip it)
+        static int vx_on = -1;
+        if (vx_on < 0) { const char *v = getenv("FMK_VOL_EXACT_TIER"); vx_on = v ? atoi(v) : 1; }
+        if (vx_on && est_len < 1500.0) {
+            if (est_len < 640.0 && vx_on != 2)
+                rc = amount_is_f64 ? vx_run<true, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c)
+                                   : vx_run<false, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c);
+            if (rc == 1)
+                rc = amount_is_f64 ? vx_run<true, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c)
+                                   : vx_run<false, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c);
+        }
+        if (rc == 1 && est_len < 1800.0)
             rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)
                                : vol_run<false, 2048>(ctx, d_amount, n, threshold, c);
         if (rc == 1) {

@@ -91,7 +91,7 @@ int fmk_event_record(fmk_ctx *ctx, void *event);
 int fmk_event_elapsed(fmk_ctx *ctx, void *start, void *stop, double *elapsed_ms);
 /* Per-launch timing of the dominant kernel (k_bar_ohlcv_small / k_bar_ohlcv of comp_bar_ohlcv):
  * while enabled, every fmk_comp_bar_ohlcv_dev call brackets that ONE kernel launch with a HIP event
- * pair on the context stream (ring of 64).  fmk_profile_read synchronises and returns the durations. */
+ * pair on the context stream (ring of 256).  fmk_profile_read synchronises and returns the durations. */
 /* Volume / dollar bar indexers: the parallel algorithms work on exactly computed sums and count the decisions that
  * land within the rounding drift of the reference's float64 running sum (n_uncertified).  on = 0 (default):
  * volume bars -- fragile decisions are settled by replaying their bar with the reference's sequential sum (every

@@ -1,7 +1,10 @@
 """GPU parity of fmk_time_bars_ohlcv_dev (round 4): _time_bar_indexer (logic.py:12-51) + comp_bar_ohlcv (base.py:306-407) in one
-call -- for 1-minute-sized bars ONE kernel launch whose waves find their own bar's edges by interpolation search.  Checked against
-the CPU oracle (clock, close indices, all eight OHLCV columns) on even, bursty, tied and degenerate timestamp spacings: the search
-keeps the bisection invariant, so the spacing may only change its speed."""
+call.  For streams of 1-minute-sized bars (float32 amounts) the call is PIPELINED: the clock edges of the first eighth of the bars,
+then OHLCV + median of those bars while the remaining edges are searched on a second stream; both index stages take the long-bar
+census, so the call never waits for a kernel it launched (csrc/fmk_ohlcv.hip).  FMK_TB_PIPE_MIN_STAGE lowers the size from which that
+happens so that the small cases here take it; FMK_OHLCV_FUSE_INDEX=1 (the in-kernel edge search, measured slower) keeps its cases.
+Checked against the CPU oracle (clock, close indices, all eight OHLCV columns) on even, bursty, tied and degenerate timestamp
+spacings."""
 import numpy as np
 import pytest
 
@@ -12,6 +15,13 @@ pytestmark = pytest.mark.gpu
 def eng():
     from finmlkit_amd import engine
     return engine
+
+
+@pytest.fixture(autouse=True, params=["pipelined", "plain"])
+def _stage_size(request, monkeypatch):
+    """Every case twice: with the pipelined step from 256 bars per first stage, and with the plain two-launch order."""
+    monkeypatch.setenv("FMK_TB_PIPE_MIN_STAGE", "256" if request.param == "pipelined" else "1000000000")
+    yield
 
 
 def _check(eng, orc, ts, px, am, interval, f64=False, what=""):
@@ -126,3 +136,51 @@ def test_kit_build_ohlcv_uses_the_fused_call(eng, orc):
     want = orc.comp_bar_ohlcv(px, am, oci)
     np.testing.assert_array_equal(df["trades"].values, want[6])
     np.testing.assert_array_equal(df["median_trade_size"].values, want[7])
+
+
+def test_pipelined_step_with_long_bars_and_enqueue_only(eng, orc, monkeypatch):
+    """The census of the index stages: a stream with a few bars beyond 1 344 ticks (the leftover passes must run), the same in
+    enqueue-only mode (no read-back at all), and a stream without any (the call returns after the two launches)."""
+    monkeypatch.setenv("FMK_TB_PIPE_MIN_STAGE", "256")
+    rng = np.random.default_rng(12)
+    n = 3_000_000
+    gaps = rng.integers(1, 100_000_000, n)
+    for a in (400_000, 1_700_000, 2_900_000):                       # three dense stretches: bars of ~20 000 ticks
+        gaps[a:a + 60_000] = rng.integers(1, 3_000_000, 60_000)
+    ts = 1_700_000_000_000_000_000 + np.cumsum(gaps)
+    px = 100.0 + np.cumsum(rng.integers(-1, 2, n)) * 0.01
+    am = (rng.integers(1, 4096, n) / 1024.0).astype(np.float32)
+    nb = _check(eng, orc, ts, px, am, 60.0, what="long bars in a 1-minute stream")
+    assert nb / 8 >= 256
+    from finmlkit_amd import _ffi
+    ctx = _ffi.default_context()
+    ctx.set_enqueue_only(True)
+    try:
+        _check(eng, orc, ts, px, am, 60.0, what="long bars, enqueue-only")
+    finally:
+        ctx.set_enqueue_only(False)
+
+
+def test_pipelined_step_at_its_default_size(eng, orc):
+    """6e7 device-generated ticks (50 000 one-minute bars: the first stage has 6 144 of them without any knob): the pipelined call
+    against the two separate calls on every bar, and against the oracle on the bars of the first 3e6 ticks."""
+    n = 60_000_000
+    t = eng.DeviceTrades.synth(n, seed=42)
+    clock, idx, o = t.time_bars_ohlcv(60.0)
+    c2, i2 = t.time_bar_index(60.0)
+    np.testing.assert_array_equal(idx.to_host(), i2.to_host())
+    np.testing.assert_array_equal(clock.to_host(), c2.to_host())
+    got, o2 = eng.to_host(o), eng.to_host(t.bar_ohlcv(i2))
+    for k in o2:
+        np.testing.assert_array_equal(got[k], o2[k], err_msg=k)
+    m = 3_000_000
+    ts, px, am, sd = orc.synth(42, 0, m)
+    oclock, oci = orc._time_bar_indexer(ts, 60.0)
+    kb = len(oci) - 2                                               # the last bar of the prefix is cut short
+    np.testing.assert_array_equal(idx.to_host()[:kb + 1], oci[:kb + 1])
+    want = orc.comp_bar_ohlcv(px, am, oci[:kb + 1])
+    for k, w in zip(["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"], want):
+        if k == "vwap":
+            np.testing.assert_allclose(got[k][:kb], w, rtol=1e-9)
+        else:
+            np.testing.assert_array_equal(got[k][:kb], w, err_msg=k)
