@@ -1610,12 +1610,18 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         static int vx_on = -1;
         if (vx_on < 0) { const char *v = getenv("FMK_VOL_EXACT_TIER"); vx_on = v ? atoi(v) : 1; }
         if (vx_on && est_len < 1500.0) {
+            // table span W >= the longest bar; the estimate is the MEAN length of the head of the stream, so each class leaves room
+            // (x 1.6 / x 1.3) and a bar that is longer after all sends the call to the next class (flag, then one more attempt)
             if (est_len < 640.0 && vx_on != 2)
                 rc = amount_is_f64 ? vx_run<true, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c);
+            if (rc == 1 && est_len < 1150.0 && vx_on != 3)
+                rc = amount_is_f64 ? vx_run<true, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c)
+                                   : vx_run<false, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c);
             if (rc == 1)
                 rc = amount_is_f64 ? vx_run<true, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c);
+            if (rc == 4) rc = 1;                                    // does not certify: the tiers below
         }
         if (rc == 1 && est_len < 1800.0)
             rc = amount_is_f64 ? vol_run<true, 2048>(ctx, d_amount, n, threshold, c)

@@ -20,19 +20,9 @@
 //
 // Traffic: 4 (1 + W/S) B/tick read, 2 + 8 W/S B/tick written: 9 (W = 1024) or 12 (W = 2048) B/tick against 21.
 #pragma once
+#include "fmk_dpp.h"
 
 #define VX_NONE 0xFFFFu
-
-// lowest set bit of a positive finite double as a power of two (its exponent); INT_MAX for 0
-__device__ __forceinline__ int vx_lsb_exp(double v)
-{
-    if (!(v > 0.0)) return 0x7fffffff;
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int e = (int)((b >> 52) & 0x7ff);
-    if (e == 0) return -100000;                                          // subnormal double: never certifies
-    const unsigned long long mant = (b & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-    return e - 1075 + (int)__builtin_ctzll(mant);
-}
 
 template <bool AF64, int S, int W, int THREADS, bool PAD>
 __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ amount, int64_t n, double thr,
@@ -51,8 +41,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
     double *Lp = (double *)vx_smem;
     uint16_t *nx = (uint16_t *)(vx_smem + (size_t)LPN * 8);
-    double *wtot = (double *)(nx + S);                 // [NW] wave totals, then [NW] wave maxima
-    int *wlsb = (int *)(wtot + 2 * NW);
+    double *wtot = (double *)(nx + S);                 // [NW] wave totals, [NW] wave maxima, [NW] wave minima
     // a window elsewhere already failed its certificate (or met a bad amount): the call is going to the older tier anyway
     // (asked by the whole workgroup at once: waves that saw the flag at different moments must not part at a barrier)
     if (__syncthreads_or(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (VOL_ST_INEXACT | VOL_ST_BAD))) return;
@@ -62,8 +51,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     const int mmax = (int)(remain < T ? remain : T);   // Lp[0..mmax] are valid
     // ---- the thread's PER consecutive amounts, 16 bytes per load
     double loc[PER];
-    double run = 0.0, amax = 0.0;
-    int lsb = 0x7fffffff;
+    double run = 0.0, amax = 0.0, amin = 1.7e308;     // amin: the smallest POSITIVE amount
     bool bad = false;
     {
         const int64_t jb = bs + (int64_t)tid * PER;
@@ -85,28 +73,25 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
 #pragma unroll
             for (int k = 0; k < PER; ++k) vv[k] = jb + k < n ? fmk_amt<AF64>(amount, jb + k) : 0.0;
         }
+        // (ticks beyond n are 0.0: neutral for all four)
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const double v = vv[k];
-            if (jb + k < n) {
-                bad |= !(v >= 0.0) || v > 1.7e308;
-                const int l = vx_lsb_exp(v);
-                lsb = l < lsb ? l : lsb;
-                amax = fmax(amax, v);
-            }
+            bad |= !(v >= 0.0) || v > 1.7e308;
+            amax = fmax(amax, v);
+            amin = fmin(amin, v > 0.0 ? v : 1.7e308);
             run += v;
             loc[k] = run;
         }
     }
-    const double inc = fmk_wave_iscan(run);
-    amax = fmk_wave_max(amax);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(lsb, o, 64); lsb = x < lsb ? x : lsb; }
+    // DPP scans / reductions (fmk_dpp.h): no LDS round trips
+    const double inc = fmk_dpp_iscan(run, 0.0, FmkOpAdd());
+    amax = fmk_dpp_reduce(amax, 0.0, FmkOpMax());
+    amin = fmk_dpp_reduce(amin, 1.7e308, FmkOpMin());
     if (lane == 63) wtot[w] = inc;
-    if (lane == 0) { wtot[NW + w] = amax; wlsb[w] = lsb; }
+    if (lane == 0) { wtot[NW + w] = amax; wtot[2 * NW + w] = amin; }
     const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    double pre = __shfl_up(inc, 1, 64);
-    if (lane == 0) pre = 0.0;
+    double pre = fmk_dpp_shift_up1(inc, 0.0);          // exclusive prefix of the thread totals inside the wave
     double total = 0.0;
     {
         double wp = 0.0;
@@ -114,15 +99,19 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
             if (q == w) pre += wp;
             wp += wtot[q];
             amax = fmax(amax, wtot[NW + q]);
-            lsb = wlsb[q] < lsb ? wlsb[q] : lsb;
+            amin = fmin(amin, wtot[2 * NW + q]);
         }
         total = wp;
     }
     if (any_bad) { if (tid == 0) atomicOr(status, VOL_ST_BAD); return; }
-    // ---- the certificate of this window: every amount a multiple of q = 2^lsb, block total and thr + max amount below 2^53 q
-    if (lsb != 0x7fffffff) {
-        const double lim = ldexp(1.0, lsb + 52);                        // 2^52 q: thr and amax each below it -> their sum below 2^53 q
-        const bool exact = lsb > -1000 && total < 2.0 * lim && thr < lim && amax < lim;
+    // ---- the certificate of this window.  Every amount is a multiple of q = ulp(smallest positive amount) -- of its own ulp, which is
+    //      a power-of-two multiple of q -- (float32 sizes: ulp = 2^(e - 23), float64: 2^(e - 52)); block total and thr + max amount
+    //      below 2^53 q.  (A first version took q from the lowest SET mantissa bit of every amount -- more tapes certify, e.g. decimal
+    //      lots next to one tiny trade do not here -- at fifteen 64-bit instructions per amount in a kernel that is bound by VALU issue.)
+    if (amin < 1.7e308) {
+        const int e = (int)((__double_as_longlong(amin) >> 52) & 0x7ff) - 1023;          // amin >= 2^e (float32 subnormals arrive normal)
+        const double lim = ldexp(1.0, e - (AF64 ? 52 : 23) + 52);                        // 2^52 q
+        const bool exact = e > -1000 && total < 2.0 * lim && thr < lim && amax < lim;
         if (!exact) { if (tid == 0) vol_flag(status, VOL_ST_INEXACT); return; }
     }
 #pragma unroll
@@ -130,35 +119,52 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     if (tid == 0) VXP(0) = 0.0;
     __syncthreads();
     // ---- nxt(j) for the block's S ticks: smallest m > i + 1 with Lp[m] - Lp[i + 1] >= thr (an exact difference, an exact compare).
-    //      A thread owns EPT consecutive ticks: one bisection, then forward walks (nxt is non-decreasing)
-    int carry_lo = 0;
+    //      A thread owns EPT consecutive ticks; nxt is non-decreasing, so their answers lie in a narrow run of prefixes.  The kernel
+    //      is bound by DEPENDENT LDS round trips (first version: a 12-step bisection, then a read-compare-advance walk per tick and one
+    //      hop at a time per entry row -- ~50 round trips per thread, 7.1 ms per 1e9 ticks at 16 waves per CU, no faster than the
+    //      level 0 it replaces although it moves half the bytes).  Hence: the first tick by an 8-ary search (8 independent reads per
+    //      round: 4 rounds for 2048), then the run of prefixes behind its answer is fetched in batches of 8 independent reads and the
+    //      EPT ticks are resolved against the batch in registers (a merge of two sorted runs).
     bool ovf = false;
-#pragma unroll 1
-    for (int q = 0; q < EPT; ++q) {
-        const int i = tid * EPT + q;
-        unsigned off = VX_NONE;
-        if (i < remain) {
-            const double base = VXP(i + 1);
-            int lo = i + 2, hi = i + 1 + W;
+    {
+        const int i0 = tid * EPT;
+        // -- first tick of the thread: 8-ary search in (i0 + 1, min(i0 + 1 + W, mmax)]
+        int m0 = -1;                                                     // answer for tick i0 (index into Lp), -1: none
+        if (i0 < remain) {
+            const double base = VXP(i0 + 1);
+            int lo = i0 + 2, hi = i0 + 1 + W;
             if (hi > mmax) hi = mmax;
             if (lo <= hi && VXP(hi) - base >= thr) {
-                if (q > 0 && carry_lo >= lo) {
-                    lo = carry_lo;
-                    while (lo < hi && VXP(lo) - base < thr) ++lo;
-                } else {
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (VXP(mid) - base >= thr) hi = mid; else lo = mid + 1;
-                    }
+                while (lo < hi) {                                        // (an 8-ary search with 8 independent reads per round was
+                    const int mid = (lo + hi) >> 1;                      //  tried: 4 round trips instead of 11, but ~290 instead of ~90
+                    if (VXP(mid) - base >= thr) hi = mid; else lo = mid + 1;   // instructions, and the kernel is bound by VALU issue)
                 }
-                carry_lo = lo;
-                off = (unsigned)(lo - 1 - i);                            // close tick bs + lo - 1, offset 1 .. W
-            } else {
-                if (i + 1 + W <= mmax) ovf = true;                       // no close within W ticks although data remains
-                carry_lo = 0;
-            }
+                m0 = lo;
+            } else if (i0 + 1 + W <= mmax) ovf = true;                   // no close within W ticks although data remains
         }
-        nx[i] = (uint16_t)off;
+        nx[i0] = (uint16_t)(m0 >= 0 ? (unsigned)(m0 - 1 - i0) : VX_NONE);
+        // -- the other EPT - 1 ticks walk forward from the previous answer (nxt is non-decreasing)
+        int cur = m0;
+#pragma unroll 1
+        for (int q = 1; q < EPT; ++q) {
+            const int i = i0 + q;
+            unsigned off = VX_NONE;
+            if (i < remain) {
+                int hi = i + 1 + W;
+                if (hi > mmax) hi = mmax;
+                const double base = VXP(i + 1);
+                int lo = cur > i + 2 ? cur : i + 2;
+                if (cur >= 0 && lo <= hi && VXP(hi) - base >= thr) {
+                    while (lo < hi && VXP(lo) - base < thr) ++lo;
+                    cur = lo;
+                    off = (unsigned)(lo - 1 - i);
+                } else {
+                    if (i + 1 + W <= mmax) ovf = true;
+                    cur = -1;
+                }
+            }
+            nx[i] = (uint16_t)off;
+        }
     }
     if (__ballot(ovf) != 0 && lane == 0) vol_flag(status, VOL_ST_OVERFLOW);
     // first bar (block 0): tick 0 is counted but cannot close -> first j >= 1 with P_j >= thr (cum = volumes[0], logic.py:107)
@@ -183,21 +189,43 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
         const int i = q * THREADS + tid;
         if (bs + i < n) nxt16[bs + i] = nx[i];
     }
-    for (int i = tid; i < W; i += THREADS) {
-        uint32_t E = VOL_END, C = 0;
-        if (i < remain) {
-            int e = i;
-            C = 1;
-            for (;;) {
-                const unsigned o = nx[e];
-                if (o == VX_NONE) break;
-                e += (int)o;
-                if (e >= S) { E = (uint32_t)(bs + e); break; }
-                ++C;
+    {   // W / THREADS rows per thread, walked TOGETHER: one LDS round trip advances all of them by a hop
+        constexpr int ROWS = (W + THREADS - 1) / THREADS;
+        int e[ROWS];
+        uint32_t C[ROWS];
+        bool open[ROWS];
+        uint32_t E[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int i = tid + r * THREADS;
+            e[r] = i; E[r] = VOL_END;
+            open[r] = i < W && i < remain;
+            C[r] = open[r] ? 1u : 0u;
+        }
+        for (;;) {
+            bool any = false;
+            unsigned o[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) o[r] = open[r] ? (unsigned)nx[e[r]] : VX_NONE;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                if (!open[r]) continue;
+                if (o[r] == VX_NONE) { open[r] = false; continue; }
+                e[r] += (int)o[r];
+                if (e[r] >= S) { E[r] = (uint32_t)(bs + e[r]); open[r] = false; continue; }
+                ++C[r];
+                any = true;
+            }
+            if (!any) break;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int i = tid + r * THREADS;
+            if (i < W) {
+                E0[(int64_t)blockIdx.x * W + i] = E[r];
+                C0[(int64_t)blockIdx.x * W + i] = C[r];
             }
         }
-        E0[(int64_t)blockIdx.x * W + i] = E;
-        C0[(int64_t)blockIdx.x * W + i] = C;
     }
 #undef VXP
 }
@@ -221,12 +249,62 @@ __global__ __launch_bounds__(256) void k_vx_emit(int64_t S, const uint32_t *__re
     }
 }
 
-// returns FMK_OK, 1 (the next tier: a window that does not certify, or a bar beyond W ticks), 2 (negative / NaN amounts) or an error
+// k_vol_level_up4 / k_vol_descend4 for tables of W rows per block, W any number (theirs is a power of two): level q + 1 composes
+// `radix` blocks of level q over the W entry ticks of the first of them
+__global__ __launch_bounds__(256) void k_vx_level_up(int W, const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
+                                                     int64_t nblk_prev, int64_t span_prev, uint32_t *__restrict__ Ek,
+                                                     uint32_t *__restrict__ Ck, int64_t nblk, int *__restrict__ status, int radix)
+{
+    const int64_t b = blockIdx.x;
+    const int i = (int)(blockIdx.y * blockDim.x + threadIdx.x);
+    if (i >= W || b >= nblk) return;
+    const int64_t c0 = (int64_t)radix * b;
+    uint32_t x = Ep[c0 * W + i];
+    uint32_t c = Cp[c0 * W + i];
+    for (int j = 1; j < radix; ++j) {
+        const int64_t child = c0 + j;
+        if (x == VOL_END || child >= nblk_prev) break;
+        const int64_t i2 = (int64_t)x - child * span_prev;           // the chain enters the next child in its first W ticks
+        if (i2 < 0 || i2 >= W) { vol_flag(status, VOL_ST_OVERFLOW); x = VOL_END; break; }
+        c += Cp[child * W + i2];
+        x = Ep[child * W + i2];
+    }
+    Ek[b * W + i] = x;
+    Ck[b * W + i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_vx_descend(int W, const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
+                                                    int64_t nblk_k, int64_t span_prev, const uint32_t *__restrict__ Ep,
+                                                    const uint32_t *__restrict__ Cp, int64_t nblk_prev,
+                                                    uint32_t *__restrict__ ent_p, int64_t *__restrict__ off_p, int radix)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk_k) return;
+    uint32_t e = ent_k[b];
+    int64_t o = off_k[b];
+    const int64_t c0 = (int64_t)radix * b;
+    ent_p[c0] = e;
+    off_p[c0] = o;
+    for (int j = 1; j < radix; ++j) {
+        const int64_t child = c0 + j;
+        if (child >= nblk_prev) break;
+        if (e != VOL_END) {
+            const int64_t i = (int64_t)e - (child - 1) * span_prev;  // the entry lies in the previous child's first W ticks
+            if (i >= 0 && i < W) {
+                o += Cp[(child - 1) * W + i];
+                e = Ep[(child - 1) * W + i];
+            }
+        }
+        ent_p[child] = e;
+        off_p[child] = o;
+    }
+}
+
+// returns FMK_OK, 1 (a bar beyond W ticks: the next class), 4 (a window that does not certify: the older tier), 2 (negative / NaN
+// amounts) or an error
 template <bool AF64, int S, int W, int THREADS, bool PAD>
 static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c)
 {
-    int LS = 0;
-    while ((1 << LS) < W) ++LS;
     const int64_t nblk0 = fmk_ceil_div(n, S);
     static int RAD = 0;
     if (!RAD) { const char *v = getenv("FMK_VOL_RADIX"); RAD = v ? atoi(v) : VOL_RADIX; if (RAD < 2 || RAD > 64) RAD = VOL_RADIX; }
@@ -264,7 +342,7 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 32, ctx->stream));
     {
         constexpr int T = S + W;
-        constexpr size_t lds = (size_t)(PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2) * 8 + (size_t)S * 2 + (size_t)(THREADS / 64) * 20 + 64;
+        constexpr size_t lds = (size_t)(PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2) * 8 + (size_t)S * 2 + (size_t)(THREADS / 64) * 24 + 64;
         if (lds > 64 * 1024)
             FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vx_level0<AF64, S, W, THREADS, PAD>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -274,9 +352,8 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     FMK_LAUNCH_CHECK(ctx);
     // the status is known after level 0; the level-ups are cheap (N W / (S RAD) entries and less) and run regardless
     for (int k = 1; k <= K; ++k) {
-        const int64_t tot = nblk[k] * W;
-        k_vol_level_up4<<<(unsigned)fmk_ceil_div(tot, 256), 256, 0, ctx->stream>>>(
-            LS, E[k - 1], C[k - 1], nblk[k - 1], spanq[k - 1], E[k], C[k], nblk[k], d_status, RAD);
+        k_vx_level_up<<<dim3((unsigned)nblk[k], (unsigned)fmk_ceil_div(W, 256)), 256, 0, ctx->stream>>>(
+            W, E[k - 1], C[k - 1], nblk[k - 1], spanq[k - 1], E[k], C[k], nblk[k], d_status, RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 32, 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -284,7 +361,8 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     const int status = (int)(ctx->h_mail[0] & 0xFFFFFFFF);
     const uint32_t root = (uint32_t)(ctx->h_mail[1] & 0xFFFFFFFFu);
     if (status & VOL_ST_BAD) return 2;
-    if (status & (VOL_ST_OVERFLOW | VOL_ST_INEXACT)) return 1;
+    if (status & VOL_ST_INEXACT) return 4;                          // no class of this tier will serve the stream
+    if (status & VOL_ST_OVERFLOW) return 1;
     int64_t closes = 0;
     if (root != VOL_END) {
         if ((int64_t)root >= W) return 1;
@@ -300,8 +378,8 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int k = K; k >= 1; --k) {
-        k_vol_descend4<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
-            LS, ent[k], off[k], nblk[k], spanq[k - 1], E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1], RAD);
+        k_vx_descend<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+            W, ent[k], off[k], nblk[k], spanq[k - 1], E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1], RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     k_vx_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(S, ent[0], off[0], nblk0, nxt16, c.dbuf, c.cap);
