@@ -355,25 +355,25 @@ __device__ __forceinline__ void bf_dir_emit(const FlowDirOut &o, int64_t b, int 
 // ---------------------------------------------------------------------------------------
 // directional only: one wave per bar
 // ---------------------------------------------------------------------------------------
-template <bool AF64>
-__global__ __launch_bounds__(256) void k_bar_dir(const double *__restrict__ price, const void *__restrict__ amount,
+template <bool AF64, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_bar_dir(const double *__restrict__ price, const void *__restrict__ amount,
                                                  const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                  int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
                                                  unsigned long long *redo, const unsigned long long *only = nullptr,
                                                  int64_t skip_above = INT64_MAX /* longer bars: k_bar_dir_wide */)
 {
     typedef typename std::conditional<AF64, double, float>::type AmtT;
-    __shared__ double s_p[4][BF_SLOTS];
-    __shared__ AmtT s_a[4][BF_SLOTS];
-    __shared__ int8_t s_s[4][640];
+    __shared__ double s_p[WPB][BF_SLOTS];
+    __shared__ AmtT s_a[WPB][BF_SLOTS];
+    __shared__ int8_t s_s[WPB][640];
     const int lane = fmk_lane();
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     double *sP = s_p[wib];
     AmtT *sA = s_a[wib];
     int8_t *sS = s_s[wib];
     const AmtT *am = (const AmtT *)amount;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
     // `only` (list mode: [0] = count, [32...] = bar numbers): the bars k_bar_dir_lanes left to this schedule
     const int64_t todo = only ? (int64_t)only[0] : nb;
     for (int64_t it = wave0; it < todo; it += nwaves) {
@@ -1571,6 +1571,12 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
         FMK_TRY(wide());
         bf_redo_launch<true>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
     } else {
+        static int dwpb = -1;                // developer knob: FMK_DIR_WPB=1 -> one-wave workgroups (see fp_launch, fmk_footprint.hip)
+        if (dwpb < 0) { const char *v = getenv("FMK_DIR_WPB"); dwpb = v ? atoi(v) : 4; }
+        if (dwpb == 1)
+            k_bar_dir<false, 1><<<(unsigned)(blocks * 4), 64, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                                              (unsigned long long *)d_n_zero_div, redo, nullptr, skip_above);
+        else
         k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                   (unsigned long long *)d_n_zero_div, redo, nullptr, skip_above);
         FMK_LAUNCH_CHECK(ctx);
@@ -1686,6 +1692,12 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         FMK_LAUNCH_CHECK(ctx);
         int64_t blocks = fmk_ceil_div(nb, 4);
         if (blocks > 2048) blocks = 2048;
+        static int dwpb = -1;
+        if (dwpb < 0) { const char *v = getenv("FMK_DIR_WPB"); dwpb = v ? atoi(v) : 4; }
+        if (dwpb == 1)
+            k_bar_dir<false, 1><<<(unsigned)(blocks * 4), 64, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                                              (unsigned long long *)d_n_zero_div, redo, long_list);
+        else
         k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                    (unsigned long long *)d_n_zero_div, redo, long_list);
         bf_redo_launch<false>(ctx, (unsigned)blocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);

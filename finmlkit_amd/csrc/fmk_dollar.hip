@@ -120,6 +120,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
     const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x;
     DD s = dd_make(0.0);
     bool neg = false;
+    double wave_whale = 0.0;
     double d[DL_ITEMS];
 #pragma unroll
     for (int k = 0; k < DL_ITEMS; ++k) d[k] = i0 + k * DL_THREADS < n ? dl_d<AF64>(price, amount, i0 + k * DL_THREADS) : 0.0;
@@ -146,12 +147,36 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
 #pragma unroll
             for (int k = 0; k < DL_ITEMS; ++k) wsum += d[k] >= thr ? d[k] : 0.0;
             wsum = fmk_wave_sum(wsum);
-            if (fmk_lane() == 0 && !neg) atomicAdd(whale_sum, wsum);
+            wave_whale = wsum;
         }
+    }
+    // the tile's share of that sum: a plain store per tile, added up by k_dl_whale_total.  (An atomicAdd per wave on ONE address cost
+    // ~50 ns each, serialised: with 0.01 % block trades one wave in twenty has one -- k_dl_tile_sums 2.2 -> 7.4 ms per 1e9 ticks.)
+    {
+        __shared__ double s_wh[4];
+        if (fmk_lane() == 0) s_wh[threadIdx.x >> 6] = neg ? 0.0 : wave_whale;
+        __syncthreads();
+        if (threadIdx.x == 0) whale_sum[blockIdx.x] = (s_wh[0] + s_wh[1]) + (s_wh[2] + s_wh[3]);
     }
     DD tot;
     (void)dl_block_exclusive(s, lds, &tot);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+// W / thr (rounded up): the per-tile sums of the increments >= thr added up by one block
+__global__ __launch_bounds__(1024) void k_dl_whale_total(const double *__restrict__ part, int64_t tiles, double thr, double *__restrict__ out)
+{
+    __shared__ double ws[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < tiles; i += 1024) acc += part[i];
+    acc = fmk_wave_sum(acc);
+    if (fmk_lane() == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += ws[q];
+        *out = t / thr * (1.0 + 1e-9);
+    }
 }
 
 // exclusive scan in place (one block; every thread owns 8 consecutive records per round, so the block-wide scan and
@@ -366,7 +391,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
                                                         const int64_t *__restrict__ seg_premin,
                                                         int64_t *__restrict__ out, int64_t cap,
                                                         unsigned long long *n_frag, int64_t *__restrict__ carry_k,
-                                                        double inv_ulp, int simple, int64_t *__restrict__ last_M, double extra)
+                                                        double inv_ulp, int simple, int64_t *__restrict__ last_M, double extra,
+                                                        unsigned long long *__restrict__ area_out)
 {
     __shared__ DD lds[4];
     __shared__ int64_t wmin[4];
@@ -407,17 +433,24 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
     if (lane == 0) prev = INT64_MAX;
     int64_t mex = prev < pre ? prev : pre;           // min_{j < first tick of this thread} G_j
     const int64_t i0 = (int64_t)blockIdx.x * DL_TILE + (int64_t)threadIdx.x * DL_ITEMS;
+    int64_t area = 0;                                // sum over this thread's ticks of the backlog M_i - K_i (in thresholds)
 #pragma unroll
     for (int k = 0; k < DL_ITEMS; ++k) {
         const int64_t i = i0 + k;
         if (i < n) {
+            if (!simple && i >= 1 && G[k] > mex) area += G[k] - mex;
             if (i >= 1 && G[k] >= mex) {             // close: K_i = i + mex is its slot
                 const int64_t slot = i + mex;
                 if (slot < cap) {
                     out[slot] = i;
                     // exact-arithmetic carry after this close in units of ulp(thr) (D_i - M_i*thr: with d_max < thr there is
                     // no backlog, M_i == K_i) -- the start state of the next bar's simulation in fmk_dollar_exact.hip
-                    carry_k[slot] = llrint(rem[k] * inv_ulp);
+                    // With a backlog (an increment >= thr behind it: M_i > K_i) the state is (M_i - K_i) thresholds higher:
+                    // M_i - K_i = G_i - min_{j<i} G_j.  Beyond 500 thresholds the unit count leaves int64's comfortable range: -1 (no
+                    // exact tier for this stream).
+                    const int64_t back = G[k] - mex;
+                    carry_k[slot] = back == 0 ? llrint(rem[k] * inv_ulp)
+                                              : (back <= 500 ? llrint(rem[k] * inv_ulp) + back * llrint(thr * inv_ulp) : -1);
                 }
             }
             mex = G[k] < mex ? G[k] : mex;
@@ -427,6 +460,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_emit(const double *__restrict
     if (i0 == 0 && cap > 0) out[0] = 0;              // logic.py:138
     int f = (int)fmk_wave_sum(frag);
     if (lane == 0 && f) atomicAdd(n_frag, (unsigned long long)f);
+    if (!simple) {
+        // The backlog AREA of the stream, sum_i (M_i - K_i): the reference's add at tick i happens at a magnitude of at most
+        // (M_i - K_i + 2) thr, so the rounding drift its backlogs add to the per-tick bound is 2^-52 thr x area / 2.  (The bound
+        // the closed form certifies with, (W / thr)^2, assumes ALL increments >= thr pile into one backlog: at 1e5 block trades
+        // of 1.2 thr each that is 1.3e10 tick equivalents where the area is 1e5; the exact tier flags its bars with the area.)
+        area = fmk_wave_sum(area);
+        if (lane == 0 && area) atomicAdd(area_out, (unsigned long long)area);
+    }
 }
 
 struct DlCache {
@@ -441,6 +482,8 @@ struct DlCache {
     int64_t *carry;      // carry_k per close, same capacity
     int64_t cap;
     double dmax;
+    double extra;        // the backlog term of the drift bound, in ticks ((W / thr)^2, W the sum of the increments >= thr)
+    double area;         // ... and its tight form: the backlog area sum_i (M_i - K_i) (k_dl_emit), what the exact tier flags with
 };
 static DlCache &dl_cache(fmk_ctx *ctx)       // one per context (slot 1), created on first use
 {
@@ -464,17 +507,19 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     const int64_t tiles = fmk_ceil_div(n, DL_TILE);
     void *scr;
     const int64_t gdd = fmk_ceil_div(tiles, (int64_t)1 << DL_SEG_SHIFT), gmn = fmk_ceil_div(tiles, (int64_t)1 << DL_SEGM_SHIFT);
-    FMK_TRY(fmk_scratch(ctx, (size_t)tiles * (sizeof(DD) + 8) + (size_t)gdd * sizeof(DD) + (size_t)gmn * 8 + 64, &scr));
+    FMK_TRY(fmk_scratch(ctx, (size_t)tiles * (sizeof(DD) + 8 + 8) + (size_t)gdd * sizeof(DD) + (size_t)gmn * 8 + 64, &scr));
     DD *tsum = (DD *)scr;
     DD *segb = tsum + tiles;
     int64_t *tmin = (int64_t *)(segb + gdd);
     int64_t *segm = tmin + tiles;
+    double *wpart = (double *)(segm + gmn + 1);                        // per-tile sums of the increments >= thr
     int64_t *d_res = ctx->d_mail + 24;
     int *d_bad = (int *)(ctx->d_mail + 26);
     unsigned long long *d_dmax = (unsigned long long *)(ctx->d_mail + 27);
     double *d_whale = (double *)(ctx->d_mail + 28);
     FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 24, ctx->stream));
-    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax, thr, d_whale);
+    k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax, thr, wpart);
+    k_dl_whale_total<<<1, 1024, 0, ctx->stream>>>(wpart, tiles, thr, d_whale);
     FMK_LAUNCH_CHECK(ctx);
     k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
     DD *d_total = (DD *)(ctx->d_mail + 44);                            // sum of all increments (double-double)
@@ -492,9 +537,10 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     // (a second one may arrive before the first is worked off) <= 2^-53 * W^2 / thr, W their sum.  In units of 2.3e-16 * thr that is
     // `extra` = (W / thr)^2 more "ticks".  (Found by tools/fuzz_volume.py seed 81003, dollar cases 792 / 1143, late in round 3: with
     // the tick count alone two closes right after a whale were certified and wrong by one tick.)
-    double whale = 0.0;
-    memcpy(&whale, &ctx->h_mail[3], 8);
-    const double extra = (whale / thr) * (whale / thr);
+    double whale_thr = 0.0;                                           // W / thr (k_dl_whale_total)
+    memcpy(&whale_thr, &ctx->h_mail[3], 8);
+    const double extra = whale_thr * whale_thr;
+    c.extra = extra;
     static int force_minpass = -1;       // developer knob: FMK_DL_MIN_PASS=1 keeps the prefix-min pass for every input
     if (force_minpass < 0) { const char *v = getenv("FMK_DL_MIN_PASS"); force_minpass = v ? atoi(v) : 0; }
     const int simple = (c.dmax < thr && !force_minpass) ? 1 : 0;
@@ -532,18 +578,22 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
         FMK_HIP(ctx, hipMalloc((void **)&c.carry, (size_t)c.cap * 8));
     }
     unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 25);
+    unsigned long long *d_area = (unsigned long long *)(ctx->d_mail + 46);     // [d_frag + 1 would be d_bad: keep the area apart]
     FMK_HIP(ctx, hipMemsetAsync(d_frag, 0, 8, ctx->stream));
+    FMK_HIP(ctx, hipMemsetAsync(d_area, 0, 8, ctx->stream));
     int ex;
     (void)frexp(thr, &ex);                                            // thr = m * 2^ex, m in [0.5, 1): ulp(thr) = 2^(ex - 53)
     FMK_HIP(ctx, hipMemsetAsync(d_res, 0xFF, 8, ctx->stream));
     k_dl_emit<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin, segm, c.dbuf,
                                                                      simple ? c.cap : c.count, d_frag, c.carry,
-                                                                     ldexp(1.0, 53 - ex), simple, d_res, extra);
+                                                                     ldexp(1.0, 53 - ex), simple, d_res, extra, d_area);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_frag, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 1, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 2, d_area, 8, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     c.unc = ctx->h_mail[0];
+    c.area = (double)ctx->h_mail[2];
     if (simple && ctx->h_mail[1] + 1 != c.count) {
         // the device's D_{n-1} (segment base + tile base + in-tile prefix) and the host's total are the same sum in two
         // association orders: they can only disagree about floor(D / thr) when D is within ~2^-100 of a multiple of thr
@@ -562,7 +612,17 @@ int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const 
 // closed form got wrong in `close_idx` (capacity: count + DL_EXTRA).  *status: 0 = done (now exact), 1 = not applicable /
 // gave up (caller takes the serial walk).
 int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
-                     int64_t *d_close_idx, const int64_t *d_carry_k, int64_t *count, int *status);
+                     int64_t *d_close_idx, const int64_t *d_carry_k, int64_t *count, int *status, double extra_ticks, int whales);
+
+// which path answered the last fmk_dollar_bar_indexer[_dev] call of this process (tests; include/fmk_diag.h): 0 the closed form alone
+// (every decision certain), 1 closed form + exact tier, 2 closed form + exact tier on a stream with increments >= thr (stretch walk),
+// 3 the serial walk (the fill half of a count-then-fill pair answers from the cache and leaves the value alone)
+static int g_dl_last_path = -1;
+extern "C" int fmk_diag_dollar_last(int64_t *path)
+{
+    *path = g_dl_last_path;
+    return FMK_OK;
+}
 
 extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
                                           int amount_is_f64, int64_t n, double threshold, int64_t *d_close_idx,
@@ -570,9 +630,11 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "threshold indexer: empty input");
     // the closed form needs thr > 0 and non-negative increments; anything else takes the serial walk
-    if (!(threshold > 0.0) || getenv("FMK_THRESHOLD_SERIAL"))
+    if (!(threshold > 0.0) || getenv("FMK_THRESHOLD_SERIAL")) {
+        g_dl_last_path = 3;
         return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                     n_idx, n_uncertified);
+    }
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     DlCache &c = dl_cache(ctx);
     const bool hit = c.ctx == ctx && !ctx->idx_stale[1] && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
@@ -580,10 +642,13 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
     if (!hit) {
         int rc = amount_is_f64 ? dl_run<true>(ctx, d_price, d_amount, n, threshold, c)
                                : dl_run<false>(ctx, d_price, d_amount, n, threshold, c);
-        if (rc == 1)
+        if (rc == 1) {
+            g_dl_last_path = 3;
             return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity,
                                         n_idx, n_uncertified);
+        }
         if (rc) return rc;
+        g_dl_last_path = 0;
         c.ctx = ctx; c.amount = d_amount; c.price = d_price; c.n = n; c.thr = threshold; c.is_f64 = amount_is_f64;
         ctx->idx_key[1][0] = d_amount; ctx->idx_key[1][1] = d_price; ctx->idx_stale[1] = 0;
     }
@@ -596,15 +661,19 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         // are a function of the bar's own ticks and of the carried state modulo 4 ulp(thr)) and replays the few fragile bars
         // from it; streams it does not cover (an increment >= thr) take the serial walk (fmk_threshold.hip)
         int status = 1;
-        if (c.dmax < threshold && !hit) {
-            int rc = fmk_dollar_exact(ctx, d_price, d_amount, amount_is_f64, n, threshold, c.dbuf, c.carry, &c.count, &status);
+        static int whale_tier = -1;          // developer knob: FMK_DL_WHALE_TIER=0 -> streams with an increment >= thr take the serial walk
+        if (whale_tier < 0) { const char *v = getenv("FMK_DL_WHALE_TIER"); whale_tier = v ? atoi(v) : 1; }
+        if ((c.dmax < threshold || whale_tier) && !hit) {
+            int rc = fmk_dollar_exact(ctx, d_price, d_amount, amount_is_f64, n, threshold, c.dbuf, c.carry, &c.count, &status,
+                                      c.dmax >= threshold ? c.area : 0.0, c.dmax >= threshold ? 1 : 0);
             if (rc) { c.ctx = nullptr; return rc; }
-            if (status == 0) c.unc = 0;
+            if (status == 0) { c.unc = 0; g_dl_last_path = c.dmax >= threshold ? 2 : 1; }
         } else if (hit) {
             status = c.unc == 0 ? 0 : 1;
         }
         if (status != 0) {
             c.ctx = nullptr;
+            g_dl_last_path = 3;
             return fmk_threshold_serial(ctx, 1, d_price, d_amount, amount_is_f64, n, threshold, d_close_idx, capacity, n_idx,
                                         n_uncertified);
         }

@@ -40,6 +40,9 @@
 struct DlxFn {                           // f(k) = kap[(k - base) & 3] + ((k - base) & ~3), or the constant kap[0]
     int64_t base;
     int64_t kap[4];
+    // >= 0: the composition STARTS behind stretch bar `seg` (round 4, streams with increments >= thr): its input is that bar's
+    // output state sval[seg], whatever came before; -1: an ordinary function of the incoming state
+    int64_t seg;
 };
 
 struct DlxRes {                          // state of one flagged bar between rounds
@@ -51,18 +54,24 @@ struct DlxRes {                          // state of one flagged bar between rou
     int64_t close[DLX_MAXC];
 };
 
-__device__ __forceinline__ int64_t dlx_eval(const DlxFn &f, int64_t k)
+__device__ __forceinline__ int64_t dlx_eval(const DlxFn &f, int64_t k)      // (the part behind f.seg, if any)
 {
     if (f.base == DLX_CONST) return f.kap[0];
     const int64_t t = k - f.base, r = t & 3;
     return f.kap[r] + (t - r);
 }
+// ... with the reset: the state behind bar f.seg comes from the walk over the stretch bars (k_dlx_walk)
+__device__ __forceinline__ int64_t dlx_apply(const DlxFn &f, int64_t k, const int64_t *__restrict__ sval)
+{
+    return dlx_eval(f, f.seg >= 0 ? sval[f.seg] : k);
+}
 
 // first f, then g
 __device__ __forceinline__ DlxFn dlx_compose(const DlxFn &f, const DlxFn &g)
 {
-    if (g.base == DLX_CONST) return g;
+    if (g.seg >= 0 || g.base == DLX_CONST) return g;              // g does not look at its input
     DlxFn h;
+    h.seg = f.seg;
     if (f.base == DLX_CONST) {
         h.base = DLX_CONST;
         h.kap[0] = dlx_eval(g, f.kap[0]);
@@ -73,6 +82,37 @@ __device__ __forceinline__ DlxFn dlx_compose(const DlxFn &f, const DlxFn &g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) h.kap[j] = dlx_eval(g, f.kap[j]);
     return h;
+}
+
+// ---- stretch bars (round 4).  An increment w >= thr closes its bar on the spot and leaves a backlog: the next ~w / thr ticks each
+// close a one-tick bar while cum works its way down.  Those adds happen in binades ABOVE thr's, where the rounding depends on
+// more low bits of the incoming state than the four trajectories of k_dlx_bars cover (f(k + 4) = f(k) + 4 no longer holds), so
+// such bars have no composable function: they are STRETCH bars, and the state behind each is computed from the true state in front
+// of it -- two float64 operations (the reference's closing add and its carry) by one lane walking them in order (k_dlx_walk), the
+// ordinary bars between two of them composed in parallel as before.
+//   type 1 (backlog): the bar starts at or above thr (certainly): one tick, cum = k u + d, cum - thr.
+//   type 2 (whale close): an ordinary start, then a closing add that lands beyond the binade above thr's.  The adds BEFORE it are
+//          ordinary (period 4 in k): fn.kap[] holds the four trajectories' float64 values in front of the closing add (as bit
+//          patterns), C_r; the true value is C_r + (k - base - r) u exactly (point (2) of the header); then + d, - thr.
+#define DLX_T_BACKLOG 1
+#define DLX_T_WHALE 2
+__device__ __forceinline__ int64_t dlx_stretch_op(int type, const DlxFn &f, double dlast, int64_t k, double thr, double u, double inv_u)
+{
+    double c;
+    if (type == DLX_T_BACKLOG) c = (double)k * u;
+    else {
+        const int64_t t = k - f.base, r = t & 3;
+        c = __longlong_as_double(f.kap[r]) + (double)(t - r) * u;
+    }
+    c += dlast;                                                      // logic.py:143
+    c = c - thr;                                                     // logic.py:147 (exact: Sterbenz or a coarser grid than u)
+    return llrint(c * inv_u);
+}
+
+__device__ __forceinline__ void vol_giveup(unsigned long long *w)    // (one store, not one atomic per bar)
+{
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ULL)
+        __hip_atomic_store(w, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool AF64>
@@ -100,7 +140,9 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
                                                   const int64_t *__restrict__ carry_k, DlxFn *__restrict__ fn,
                                                   int32_t *__restrict__ fidx, int32_t *__restrict__ owner,
                                                   int64_t *__restrict__ flist, unsigned long long *__restrict__ n_flag,
-                                                  int bars_per_lane)
+                                                  int bars_per_lane, int whales, double m_extra /* backlog term of the drift */,
+                                                  int64_t tu /* thr in units of u */, double top /* 2 x the power of two above thr */,
+                                                  unsigned char *__restrict__ btype, double *__restrict__ dlast)
 {
     __shared__ double rows[2][64][DLX_T + 1];               // 2 waves x 16.9 KB
     __shared__ int64_t s_pos[2][64], s_end[2][64];
@@ -110,7 +152,8 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
     int r = 0;
     int64_t b = bar0, pos = 0, end = -1, kb = 0;
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, m = 0;
-    bool tail = false, flag = false, active = false;
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, dcl = 0;           // a whale close: the trajectories in front of the closing add, its increment
+    bool tail = false, flag = false, active = false, wclose = false;
     auto open_bar = [&]() {                          // next bar of this lane, or none
         for (;;) {
             active = r < bars_per_lane && b <= nb;
@@ -120,20 +163,32 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
             end = tail ? n - 1 : ci[b + 1];
             // how far the reference's state can be from a simulated trajectory at the end of this bar: its drift against
             // exact arithmetic (3), the rounding of the exact carry to k~, the spread of the trajectories, their parity wiggle
-            m = (double)(end + 2) * m_rel + m_abs;
+            m = ((double)(end + 2) + m_extra) * m_rel + m_abs;
             flag = false;
+            wclose = false;
             kb = 0;
+            bool backlog = false;
             if (b == 0) {
                 c0 = c1 = c2 = c3 = dlx_d<AF64>(price, amount, 0);   // cum = prices[0] * volumes[0] (logic.py:140): exact
             } else {
-                kb = carry_k[b] - 1;
+                const int64_t kc = carry_k[b];
+                if (kc < 0) { vol_giveup(n_flag + 2); kb = 0; }      // a backlog of more than 500 thresholds: no exact tier
+                else kb = kc - 1;
                 if (kb < 0) kb = 0;
+                // the bar STARTS at or above the threshold for every state the reference can be in: a backlog bar (type 1)
+                backlog = whales && !tail && (double)kc * u - m >= thr && pos <= end;
                 c0 = (double)kb * u; c1 = (double)(kb + 1) * u; c2 = (double)(kb + 2) * u; c3 = (double)(kb + 3) * u;
             }
-            if (pos <= end) return;
-            // an empty tail: nothing can close behind the last close
+            if (btype) btype[b] = 0;
+            if (pos <= end && !backlog) return;
+            // an empty tail (nothing can close behind the last close), or a backlog bar: no trajectories
             DlxFn f;
-            f.base = kb; f.kap[0] = kb; f.kap[1] = kb + 1; f.kap[2] = kb + 2; f.kap[3] = kb + 3;
+            f.base = kb; f.kap[0] = kb; f.kap[1] = kb + 1; f.kap[2] = kb + 2; f.kap[3] = kb + 3; f.seg = -1;
+            if (backlog) {
+                if (pos != end) vol_giveup(n_flag + 2);              // (its first add closes it: the closed form says so too)
+                btype[b] = DLX_T_BACKLOG;
+                dlast[b] = dlx_d<AF64>(price, amount, pos);
+            }
             fn[b] = f; owner[b] = (int32_t)b; fidx[b] = -1;
             ++r; b += 64;
         }
@@ -166,12 +221,19 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
         for (int j = 0; j < DLX_T; ++j) {
             if (j < cnt) {
                 const double d = rows[w][lane][(o + j) & (DLX_T - 1)];
+                const bool closing = closes_here && j == cnt - 1;
+                if (closing) { p0 = c0; p1 = c1; p2 = c2; p3 = c3; dcl = d; }
                 c0 += d; c1 += d; c2 += d; c3 += d;
                 const double lo = c0 - m, hi = c3 + m;
-                bool bad = dlx_binade(lo) != dlx_binade(hi);     // the add must land in one binade for every possible state
-                if (closes_here && j == cnt - 1) bad |= !(lo >= thr);   // the closing add reaches the threshold for every state
-                else bad |= hi >= thr;                           // every other add stays below it
-                flag |= bad;
+                if (closing && whales && hi >= top) {
+                    wclose = true;                               // lands (or may land) beyond the binade above thr's: a whale close (type 2)
+                    flag |= !(lo >= thr);
+                } else {
+                    bool bad = dlx_binade(lo) != dlx_binade(hi); // the add must land in one binade for every possible state
+                    if (closing) bad |= !(lo >= thr);            // the closing add reaches the threshold for every state
+                    else bad |= hi >= thr;                       // every other add stays below it
+                    flag |= bad;
+                }
             }
         }
         pos += cnt;
@@ -180,7 +242,13 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
         if (finished) {
             DlxFn f;
             f.base = kb;
-            if (!tail) {
+            f.seg = -1;
+            if (wclose) {
+                f.kap[0] = __double_as_longlong(p0); f.kap[1] = __double_as_longlong(p1);
+                f.kap[2] = __double_as_longlong(p2); f.kap[3] = __double_as_longlong(p3);
+                btype[b] = DLX_T_WHALE;
+                dlast[b] = dcl;
+            } else if (!tail) {
                 f.kap[0] = llrint((c0 - thr) * inv_u);           // cum - thr is exact and a multiple of u (1)
                 f.kap[1] = llrint((c1 - thr) * inv_u);
                 f.kap[2] = llrint((c2 - thr) * inv_u);
@@ -211,7 +279,7 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
 
 // the function bar x contributes to the scan in this round
 __device__ __forceinline__ DlxFn dlx_effective(int64_t x, const DlxFn *fn, const int32_t *fidx, const int32_t *owner,
-                                               const DlxRes *res)
+                                               const DlxRes *res, const unsigned char *btype)
 {
     const int32_t o = owner[x];
     const int32_t f = fidx[o];
@@ -220,27 +288,45 @@ __device__ __forceinline__ DlxFn dlx_effective(int64_t x, const DlxFn *fn, const
         c.base = DLX_CONST;
         c.kap[0] = res[f].kout;
         c.kap[1] = c.kap[2] = c.kap[3] = 0;
+        c.seg = -1;
+        return c;
+    }
+    if (btype[x]) {                                  // a stretch bar: what follows it starts from ITS output (identity behind a reset)
+        DlxFn c;
+        c.base = 0; c.kap[0] = 0; c.kap[1] = 1; c.kap[2] = 2; c.kap[3] = 3;
+        c.seg = x;
         return c;
     }
     return fn[x];
 }
+__device__ __forceinline__ bool dlx_is_stretch(int64_t x, const int32_t *fidx, const int32_t *owner, const DlxRes *res,
+                                               const unsigned char *btype)
+{
+    if (!btype[x]) return false;
+    const int32_t f = fidx[owner[x]];
+    return !(f >= 0 && res && res[f].mode == 1);     // (a constant, or absorbed by one, is no longer a stretch bar)
+}
 
-// phase 0: blk[block] = composition of the block's 1024 bars.  phase 1: kin[x] = state at the start of bar x.
+// phase 0: blk[block] = composition of the block's 1024 bars, and for every stretch bar the composition of the bars of its block IN
+// FRONT of it (spre: what k_dlx_walk applies to the block's incoming state, or to the previous stretch bar's output, to get the
+// state in front of the bar).  phase 1: kin[x] = state at the start of bar x.
 __global__ __launch_bounds__(256) void k_dlx_scan(const DlxFn *__restrict__ fn, const int32_t *__restrict__ fidx,
                                                   const int32_t *__restrict__ owner, const DlxRes *__restrict__ res,
                                                   int64_t nbar, int phase, DlxFn *__restrict__ blk,
-                                                  const int64_t *__restrict__ blk_in, int64_t *__restrict__ kin)
+                                                  const int64_t *__restrict__ blk_in, int64_t *__restrict__ kin,
+                                                  const unsigned char *__restrict__ btype, DlxFn *__restrict__ spre,
+                                                  const int64_t *__restrict__ sval, int *__restrict__ scount = nullptr)
 {
     __shared__ DlxFn buf[2][256];
     const int t = threadIdx.x;
     const int64_t x0 = (int64_t)blockIdx.x * DLX_BLOCK_BARS + (int64_t)t * 4;
     DlxFn mine[4];
     DlxFn acc;
-    acc.base = 0; acc.kap[0] = 0; acc.kap[1] = 1; acc.kap[2] = 2; acc.kap[3] = 3;      // identity
+    acc.base = 0; acc.kap[0] = 0; acc.kap[1] = 1; acc.kap[2] = 2; acc.kap[3] = 3; acc.seg = -1;      // identity
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (x0 + j < nbar) {
-            mine[j] = dlx_effective(x0 + j, fn, fidx, owner, res);
+            mine[j] = dlx_effective(x0 + j, fn, fidx, owner, res, btype);
             acc = dlx_compose(acc, mine[j]);
         }
     }
@@ -254,22 +340,41 @@ __global__ __launch_bounds__(256) void k_dlx_scan(const DlxFn *__restrict__ fn, 
         __syncthreads();
         cur ^= 1;
     }
+    // the composition of the block's bars in front of this thread's first bar
+    DlxFn ex;
+    ex.base = 0; ex.kap[0] = 0; ex.kap[1] = 1; ex.kap[2] = 2; ex.kap[3] = 3; ex.seg = -1;
+    if (t > 0) ex = buf[cur][t - 1];
     if (phase == 0) {
         if (t == 255) blk[blockIdx.x] = buf[cur][255];
+        int mystretch = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (x0 + j < nbar) {
+                if (mine[j].seg == x0 + j) { spre[x0 + j] = ex; ++mystretch; }   // (mine[j].seg == its own index: an effective stretch bar)
+                ex = dlx_compose(ex, mine[j]);
+            }
+        }
+        if (scount) {
+            __shared__ int s_cnt;
+            if (t == 0) s_cnt = 0;
+            __syncthreads();
+            if (mystretch) atomicAdd(&s_cnt, mystretch);
+            __syncthreads();
+            if (t == 0) scount[blockIdx.x] = s_cnt;
+        }
         return;
     }
-    int64_t k = blk_in[blockIdx.x];
-    if (t > 0) k = dlx_eval(buf[cur][t - 1], k);
+    const int64_t kb = blk_in[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (x0 + j < nbar) {
-            kin[x0 + j] = k;
-            k = dlx_eval(mine[j], k);
+            kin[x0 + j] = dlx_apply(ex, kb, sval);
+            ex = dlx_compose(ex, mine[j]);
         }
     }
 }
 
-// one wave: the lanes fetch 64 block aggregates, lane 0 applies them in order
+// one wave: the lanes fetch 64 block aggregates, lane 0 applies them in order (streams without stretch bars)
 __global__ __launch_bounds__(64) void k_dlx_blocks(const DlxFn *__restrict__ blk, int64_t nblk, int64_t *__restrict__ blk_in)
 {
     __shared__ DlxFn s[64];
@@ -289,6 +394,186 @@ __global__ __launch_bounds__(64) void k_dlx_blocks(const DlxFn *__restrict__ blk
     }
 }
 
+// Streams WITH stretch bars.  The states behind them are a strictly serial chain (nothing composes across a stretch bar), so the chain
+// is made as short as it can be: an ordered list of EVENTS -- every stretch bar, and the end of every scan block -- each with the
+// function that leads from the state behind the previous event to its own result, prepared for all events in parallel:
+//   c(S) = Cc[r] + ((S / u - base) - r) u,  r = (S / u - base) mod 4          (a constant Cc[0] when the function is one)
+//   block end       : the state is c(S)                       (Cc[r] = kap[r] u of the block's composition since its last stretch bar)
+//   stretch, general: the state is (c(S) + d) - thr           (Cc[r] = the float64 value in front of the bar's closing add for the
+//                     incoming state base + r: the bars since the last event composed with the bar's own four trajectories)
+//   stretch, light  : the state is (S + d) - thr              (a backlog bar right behind another stretch bar: nothing in between)
+// and ONE wave walks them: 64 events per coalesced load (the next loads in flight), the state in real units (the reference's own
+// float64 cum) in a register.  ~12 instructions per light event, ~32 per general one.  First version (the walk fetching type,
+// pre-function, trajectories and increment per bar, a chain of dependent loads per 64 bars, integer states): 30 ms per 1e9 ticks
+// with 1e5 block trades; this one: see profiles/r04_dollar_block_trades.txt.
+struct DlxEvent {
+    double base;                         // of the function since the last event, in units of u
+    double cc[4];
+    double d;                            // the closing increment (stretch events)
+    int32_t flags;                       // DLX_EV_*
+    int32_t idx;                         // bar (stretch) or scan block (block end)
+};
+#define DLX_EV_STRETCH 1
+#define DLX_EV_LIGHT 2
+#define DLX_EV_CONST 4
+
+// exclusive scan of (stretch bars + 1) over the scan blocks: where each block's events start; total -> off[nblk]
+__global__ __launch_bounds__(1024) void k_dlx_evoff(const int *__restrict__ scount, int64_t nblk, int64_t *__restrict__ off)
+{
+    __shared__ int64_t ws[16];
+    __shared__ int64_t run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    for (int64_t b0 = 0; b0 < nblk; b0 += 1024) {
+        const int64_t b = b0 + threadIdx.x;
+        const int64_t v = b < nblk ? (int64_t)scount[b] + 1 : 0;
+        const int64_t inc = fmk_wave_iscan(v);
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        int64_t pre = run;
+        for (int q = 0; q < w; ++q) pre += ws[q];
+        if (b < nblk) off[b] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) run = pre + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nblk] = run;
+}
+
+__device__ __forceinline__ void dlx_event_fn(DlxEvent &e, const DlxFn &g, double u)      // block end / backlog bar: c(S) = g(S / u) u
+{
+    e.base = (double)g.base;
+    if (g.base == DLX_CONST) {
+        e.flags |= DLX_EV_CONST;
+        e.base = 0.0;
+        e.cc[0] = (double)g.kap[0] * u; e.cc[1] = e.cc[2] = e.cc[3] = 0.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e.cc[r] = (double)g.kap[r] * u;
+    }
+}
+
+// the events of one scan block, in order (same bar ownership as k_dlx_scan: thread t has bars 4t .. 4t + 3 of the block)
+__global__ __launch_bounds__(256) void k_dlx_events(const DlxFn *__restrict__ fn, const int32_t *__restrict__ fidx,
+                                                    const int32_t *__restrict__ owner, const DlxRes *__restrict__ res,
+                                                    const unsigned char *__restrict__ btype, const DlxFn *__restrict__ spre,
+                                                    const double *__restrict__ dlast, const DlxFn *__restrict__ blk,
+                                                    const int64_t *__restrict__ off, int64_t nbar, double u,
+                                                    DlxEvent *__restrict__ ev)
+{
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = fmk_lane(), w = t >> 6;
+    const int64_t x0 = (int64_t)blockIdx.x * DLX_BLOCK_BARS + (int64_t)t * 4;
+    bool st[4];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st[j] = x0 + j < nbar && dlx_is_stretch(x0 + j, fidx, owner, res, btype);
+        mine += st[j] ? 1 : 0;
+    }
+    const int inc = fmk_wave_iscan(mine);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int rank = inc - mine;
+    for (int q = 0; q < w; ++q) rank += wsum[q];
+    const int64_t o = off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!st[j]) continue;
+        const int64_t x = x0 + j;
+        const DlxFn pre = spre[x];
+        const int type = btype[x];
+        DlxEvent e;
+        e.flags = DLX_EV_STRETCH;
+        e.idx = (int32_t)x;
+        e.d = dlast[x];
+        const bool ident = pre.base == 0 && pre.kap[0] == 0 && pre.kap[1] == 1 && pre.kap[2] == 2 && pre.kap[3] == 3;
+        if (type == DLX_T_BACKLOG) {
+            if (ident) { e.flags |= DLX_EV_LIGHT; e.base = 0.0; e.cc[0] = e.cc[1] = e.cc[2] = e.cc[3] = 0.0; }
+            else dlx_event_fn(e, pre, u);
+        } else {
+            // the bars since the last event, then the whale bar's own trajectories in front of its closing add
+            const DlxFn f = fn[x];
+            if (pre.base == DLX_CONST) {
+                const int64_t t2 = pre.kap[0] - f.base, r2 = t2 & 3;
+                e.flags |= DLX_EV_CONST;
+                e.base = 0.0;
+                e.cc[0] = __longlong_as_double(f.kap[r2]) + (double)(t2 - r2) * u;
+                e.cc[1] = e.cc[2] = e.cc[3] = 0.0;
+            } else {
+                e.base = (double)pre.base;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t t2 = pre.kap[r] - f.base, r2 = t2 & 3;
+                    e.cc[r] = __longlong_as_double(f.kap[r2]) + (double)(t2 - r2) * u;
+                }
+            }
+        }
+        ev[o + rank] = e;
+        ++rank;
+    }
+    if (t == 255) {                                  // (its running rank is the block's count)
+        DlxEvent e;
+        e.flags = 0;
+        e.idx = (int32_t)blockIdx.x;
+        e.d = 0.0;
+        dlx_event_fn(e, blk[blockIdx.x], u);
+        ev[o + rank] = e;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dlx_walk(const DlxEvent *__restrict__ ev, const int64_t *__restrict__ off, int64_t nblk,
+                                                 double thr, double u, double inv_u, double *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t nev = off[nblk];
+    double S = 0.0;                                  // the reference's cum behind the last event (bar 0 is a constant: the start never matters)
+    DlxEvent cur, nxt;
+    cur.flags = 0; cur.base = 0; cur.d = 0; cur.cc[0] = cur.cc[1] = cur.cc[2] = cur.cc[3] = 0; cur.idx = 0;
+    if (lane < nev) cur = ev[lane];
+    for (int64_t e0 = 0; e0 < nev; e0 += 64) {
+        nxt = cur;
+        if (e0 + 64 + lane < nev) nxt = ev[e0 + 64 + lane];          // in flight while this group is walked
+        const int lim = (int)(nev - e0 < 64 ? nev - e0 : 64);
+        double mine = 0.0;
+        for (int j = 0; j < lim; ++j) {
+            const int fl = __builtin_amdgcn_readlane(cur.flags, j);
+            const double d = __longlong_as_double(fmk_readlane((int64_t)__double_as_longlong(cur.d), j));
+            double c;
+            if (fl & DLX_EV_LIGHT) c = S;
+            else {
+                const double base = __longlong_as_double(fmk_readlane((int64_t)__double_as_longlong(cur.base), j));
+                const double tt = S * inv_u - base;                   // exact: both integers (in units of u), the difference small
+                const double r = tt - 4.0 * floor(tt * 0.25);         // tt mod 4, in [0, 4)
+                const int ri = (fl & DLX_EV_CONST) ? 0 : (int)r;
+                const double sel = ri == 0 ? cur.cc[0] : (ri == 1 ? cur.cc[1] : (ri == 2 ? cur.cc[2] : cur.cc[3]));   // (every lane, on its own record)
+                const double cc = __longlong_as_double(fmk_readlane((int64_t)__double_as_longlong(sel), j));
+                c = (fl & DLX_EV_CONST) ? cc : cc + (tt - r) * u;
+            }
+            if (fl & DLX_EV_STRETCH) { c += d; c = c - thr; }         // logic.py:143, 147
+            S = c;
+            if (lane == j) mine = S;
+        }
+        if (lane < lim) out[e0 + lane] = mine;
+        cur = nxt;
+    }
+}
+
+// the walk's results back where the scans read them: sval[bar] (units of u) for the stretch bars, blk_in[block] for the blocks
+__global__ __launch_bounds__(256) void k_dlx_evout(const DlxEvent *__restrict__ ev, const double *__restrict__ out,
+                                                   const int64_t *__restrict__ off, int64_t nblk, double inv_u,
+                                                   int64_t *__restrict__ sval, int64_t *__restrict__ blk_in)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) blk_in[0] = 0;
+    if (e >= off[nblk]) return;
+    const int32_t fl = ev[e].flags, idx = ev[e].idx;
+    const int64_t k = llrint(out[e] * inv_u);
+    if (fl & DLX_EV_STRETCH) sval[idx] = k;
+    else if (idx + 1 < nblk) blk_in[idx + 1] = k;
+}
+
 template <bool AF64>
 __global__ __launch_bounds__(64) void k_dlx_resolve(const double *__restrict__ price, const void *__restrict__ amount,
                                                     int64_t n, double thr, double u, double inv_u,
@@ -296,7 +581,8 @@ __global__ __launch_bounds__(64) void k_dlx_resolve(const double *__restrict__ p
                                                     const DlxFn *__restrict__ fn, const int64_t *__restrict__ kin,
                                                     const int64_t *__restrict__ flist, int64_t n_flag,
                                                     int32_t *owner, DlxRes *res, unsigned long long *changed,
-                                                    unsigned long long *giveup)
+                                                    unsigned long long *giveup, const unsigned char *__restrict__ btype,
+                                                    const int64_t *__restrict__ sval)
 {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_flag) return;
@@ -339,7 +625,7 @@ __global__ __launch_bounds__(64) void k_dlx_resolve(const double *__restrict__ p
     bool same;
     if (old.mode == 0) {
         if (b == nb) same = r.to_end && q == 0;
-        else same = synced && q == 1 && r.kout == dlx_eval(fn[b], kin[b]);
+        else same = synced && q == 1 && r.kout == (btype[b] ? sval[b] : dlx_eval(fn[b], kin[b]));   // (a stretch bar: the walk's output)
         if (same) return;
     } else {
         same = old.span == r.span && old.nclose == r.nclose && old.to_end == r.to_end && old.kout == r.kout;
@@ -384,7 +670,7 @@ __global__ __launch_bounds__(64) void k_dlx_commit(const int64_t *__restrict__ f
     } while (0)
 
 int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, int is_f64, int64_t n, double thr,
-                     int64_t *d_close_idx, const int64_t *d_carry_k, int64_t *count, int *status)
+                     int64_t *d_close_idx, const int64_t *d_carry_k, int64_t *count, int *status, double extra_ticks, int whales)
 {
     *status = 1;
     const int64_t nb = *count - 1;                   // closes of the closed form
@@ -401,7 +687,10 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     const int64_t nbar = nb + 1;                     // + the tail
     const int64_t nblk = fmk_ceil_div(nbar, DLX_BLOCK_BARS);
     void *p_fn = nullptr, *p_fidx = nullptr, *p_owner = nullptr, *p_flist = nullptr, *p_kin = nullptr, *p_blk = nullptr,
-         *p_blkin = nullptr, *p_res = nullptr, *p_cnt = nullptr;
+         *p_blkin = nullptr, *p_res = nullptr, *p_cnt = nullptr, *p_btype = nullptr, *p_dlast = nullptr, *p_spre = nullptr,
+         *p_sval = nullptr, *p_scount = nullptr, *p_off = nullptr, *p_ev = nullptr, *p_out = nullptr;
+    const int64_t tu = llrint(thr * inv_u);          // thr in units of u: an integer in [2^52, 2^53)
+    const double top = ldexp(1.0, ex + 1);           // thr in [2^(ex-1), 2^ex): closing sums from here on are whale closes
     int rc = FMK_OK;
     unsigned long long *cnt;
     int64_t n_flag = 0;
@@ -417,18 +706,31 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     DLX_TRY(fmk_alloc(ctx, (size_t)nblk * sizeof(DlxFn), &p_blk));
     DLX_TRY(fmk_alloc(ctx, (size_t)nblk * 8, &p_blkin));
     DLX_TRY(fmk_alloc(ctx, 64, &p_cnt));
+    DLX_TRY(fmk_alloc(ctx, (size_t)nbar, &p_btype));
+    DLX_TRY(fmk_alloc(ctx, (size_t)nbar * 8, &p_dlast));
+    if (whales) {
+        DLX_TRY(fmk_alloc(ctx, (size_t)nbar * sizeof(DlxFn), &p_spre));
+        DLX_TRY(fmk_alloc(ctx, (size_t)nbar * 8, &p_sval));
+        DLX_TRY(fmk_alloc(ctx, (size_t)nblk * 4, &p_scount));
+        DLX_TRY(fmk_alloc(ctx, (size_t)(nblk + 1) * 8, &p_off));
+        DLX_TRY(fmk_alloc(ctx, (size_t)(nbar + nblk) * sizeof(DlxEvent), &p_ev));
+        DLX_TRY(fmk_alloc(ctx, (size_t)(nbar + nblk) * 8, &p_out));
+    }
     cnt = (unsigned long long *)p_cnt;               // [0] flagged bars, [1] changed, [2] gave up, [3] new count
     DLX_HIP(hipMemsetAsync(cnt, 0, 64, ctx->stream));
     if (is_f64)
         k_dlx_bars<true><<<gb, 128, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
-                                                      (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl);
+                                                      (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl,
+                                                      whales, extra_ticks, tu, top, (unsigned char *)p_btype, (double *)p_dlast);
     else
         k_dlx_bars<false><<<gb, 128, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, m_rel, m_abs, d_close_idx, nb, d_carry_k,
-                                                       (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl);
+                                                       (DlxFn *)p_fn, (int32_t *)p_fidx, (int32_t *)p_owner, (int64_t *)p_flist, cnt, bpl,
+                                                       whales, extra_ticks, tu, top, (unsigned char *)p_btype, (double *)p_dlast);
     DLX_HIP(hipGetLastError());
-    DLX_HIP(hipMemcpyAsync(ctx->h_mail, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DLX_HIP(hipMemcpyAsync(ctx->h_mail, cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
     DLX_HIP(hipStreamSynchronize(ctx->stream));
     n_flag = ctx->h_mail[0];
+    if (ctx->h_mail[2] != 0) goto done;              // a backlog beyond 500 thresholds (or a bar the closed form and the states disagree about)
     if (n_flag == 0) { *status = 0; goto done; }     // no bar needs a replay: every decision of the closed form is certain
     DLX_TRY(fmk_alloc(ctx, (size_t)n_flag * sizeof(DlxRes), &p_res));
     DLX_HIP(hipMemsetAsync(p_res, 0, (size_t)n_flag * sizeof(DlxRes), ctx->stream));
@@ -437,19 +739,35 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
         for (rounds = 0; rounds < 64; ++rounds) {
             DLX_HIP(hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
             k_dlx_scan<<<(unsigned)nblk, 256, 0, ctx->stream>>>((const DlxFn *)p_fn, (const int32_t *)p_fidx, (const int32_t *)p_owner,
-                                                                (const DlxRes *)p_res, nbar, 0, (DlxFn *)p_blk, nullptr, nullptr);
-            k_dlx_blocks<<<1, 64, 0, ctx->stream>>>((const DlxFn *)p_blk, nblk, (int64_t *)p_blkin);
+                                                                (const DlxRes *)p_res, nbar, 0, (DlxFn *)p_blk, nullptr, nullptr,
+                                                                (const unsigned char *)p_btype, (DlxFn *)p_spre, nullptr, (int *)p_scount);
+            if (whales) {
+                k_dlx_evoff<<<1, 1024, 0, ctx->stream>>>((const int *)p_scount, nblk, (int64_t *)p_off);
+                k_dlx_events<<<(unsigned)nblk, 256, 0, ctx->stream>>>((const DlxFn *)p_fn, (const int32_t *)p_fidx, (const int32_t *)p_owner,
+                                                                      (const DlxRes *)p_res, (const unsigned char *)p_btype,
+                                                                      (const DlxFn *)p_spre, (const double *)p_dlast, (const DlxFn *)p_blk,
+                                                                      (const int64_t *)p_off, nbar, u, (DlxEvent *)p_ev);
+                k_dlx_walk<<<1, 64, 0, ctx->stream>>>((const DlxEvent *)p_ev, (const int64_t *)p_off, nblk, thr, u, inv_u, (double *)p_out);
+                k_dlx_evout<<<(unsigned)fmk_ceil_div(nbar + nblk, 256), 256, 0, ctx->stream>>>((const DlxEvent *)p_ev, (const double *)p_out,
+                                                                                                (const int64_t *)p_off, nblk, inv_u,
+                                                                                                (int64_t *)p_sval, (int64_t *)p_blkin);
+            }
+            else
+                k_dlx_blocks<<<1, 64, 0, ctx->stream>>>((const DlxFn *)p_blk, nblk, (int64_t *)p_blkin);
             k_dlx_scan<<<(unsigned)nblk, 256, 0, ctx->stream>>>((const DlxFn *)p_fn, (const int32_t *)p_fidx, (const int32_t *)p_owner,
                                                                 (const DlxRes *)p_res, nbar, 1, nullptr, (const int64_t *)p_blkin,
-                                                                (int64_t *)p_kin);
+                                                                (int64_t *)p_kin, (const unsigned char *)p_btype, nullptr,
+                                                                (const int64_t *)p_sval);
             if (is_f64)
                 k_dlx_resolve<true><<<gf, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
                                                                 (const int64_t *)p_kin, (const int64_t *)p_flist, n_flag,
-                                                                (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2);
+                                                                (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2,
+                                                                (const unsigned char *)p_btype, (const int64_t *)p_sval);
             else
                 k_dlx_resolve<false><<<gf, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
                                                                  (const int64_t *)p_kin, (const int64_t *)p_flist, n_flag,
-                                                                 (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2);
+                                                                 (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2,
+                                                                 (const unsigned char *)p_btype, (const int64_t *)p_sval);
             DLX_HIP(hipGetLastError());
             DLX_HIP(hipMemcpyAsync(ctx->h_mail, cnt + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
             DLX_HIP(hipStreamSynchronize(ctx->stream));
@@ -473,6 +791,14 @@ done:
             fprintf(stderr, "[fmk_dollar_exact] n=%lld bars=%lld flagged=%lld rounds=%d status=%d rc=%d\n", (long long)n,
                     (long long)nb, (long long)n_flag, rounds + 1, *status, rc);
     }
+    if (p_out) fmk_free(ctx, p_out);
+    if (p_ev) fmk_free(ctx, p_ev);
+    if (p_off) fmk_free(ctx, p_off);
+    if (p_scount) fmk_free(ctx, p_scount);
+    if (p_sval) fmk_free(ctx, p_sval);
+    if (p_spre) fmk_free(ctx, p_spre);
+    if (p_dlast) fmk_free(ctx, p_dlast);
+    if (p_btype) fmk_free(ctx, p_btype);
     if (p_res) fmk_free(ctx, p_res);
     if (p_cnt) fmk_free(ctx, p_cnt);
     if (p_blkin) fmk_free(ctx, p_blkin);

@@ -1183,10 +1183,19 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
     const bool med = d_median != nullptr && !AF64;
     const bool fast = !med && lmax >= 512 && lmax <= FP_MAX_LEVELS_LDS;          // the 16 B / level layout (k_bar_footprints<.., FAST>)
+    // waves per workgroup.  A workgroup keeps its wave slots until its SLOWEST wave has finished its bars; on bars of unequal length
+    // (lognormal one-minute bars) that idles the slots of the others, so streams of many bars take one-wave workgroups: the
+    // dispatcher then balances per wave (FMK_FP_WPB overrides: developer knob)
+    const int wpb_in = wpb;
+    {
+        static int wpb_env = -1;
+        if (wpb_env < 0) { const char *v = getenv("FMK_FP_WPB"); wpb_env = v ? atoi(v) : 0; }
+        if (wpb_env > 0 && wpb_env <= wpb) wpb = wpb_env;
+    }
     size_t smem = fast ? (size_t)wpb * ((size_t)lmax * 16 + FMK_PW_PAR_STK * 4)
                        : (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
     int64_t blocks = fmk_ceil_div(nb, wpb);
-    int64_t cap = (int64_t)ctx->n_cu * 64;
+    int64_t cap = (int64_t)ctx->n_cu * 64 * (wpb_in / wpb);                        // (the same number of waves in the grid)
     unsigned char *gscratch = nullptr;
     if (lmax > (med ? FP_MAX_LEVELS : FP_MAX_LEVELS_LDS)) {
         // wide bars: one wave per workgroup, histogram in global scratch (<= 8 GB in total, >= 16 waves)

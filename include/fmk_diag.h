@@ -43,6 +43,10 @@ int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps);
  * fmk_cusum_chain.hip, 0 = the fixed point; chunks the walk opened; its status (0 done, 1 budget, 2 uncertain decision,
  * 3 non-finite return, -1 not tried).  Not used by any product path. */
 int fmk_diag_cusum_last(int64_t *tier, int64_t *opened, int64_t *status);
+/* Which path answered the last fmk_dollar_bar_indexer[_dev] call of this process: 0 the closed form alone (every decision certain),
+ * 1 closed form + exact tier, 2 the same on a stream with increments >= threshold (block trades: the stretch walk of
+ * fmk_dollar_exact.hip), 3 the serial walk, 4 a cached result. */
+int fmk_diag_dollar_last(int64_t *path);
 /* order-flow redo since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
  * pairs of column 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)} */
 int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10);

@@ -408,3 +408,36 @@ def test_volume_fast_walk_next_to_an_amount_that_dwarfs_the_threshold(orc, big):
     fast, unc = _fast_mode(t, thr)
     assert np.array_equal(fast, want) or unc > 0
     assert unc < len(want) // 4, "the magnitude term must stay local to the chunks next to the large amounts"
+
+
+def _dollar_path():
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    p = C.c_int64()
+    _ffi.lib().fmk_diag_dollar_last(C.byref(p))
+    return p.value
+
+
+@pytest.mark.parametrize("n,share,factor", [(100_000_000, 1e-4, 1000.0), (20_000_000, 1e-3, 8000.0)])
+def test_dollar_bars_with_block_trades_stay_on_the_parallel_path(orc, monkeypatch, n, share, factor):
+    """a tape with block trades (increments >= the threshold) used to leave the exact tier -- one fragile decision
+    then cost the serial walk, ~20 s per 1e9 ticks.  1e8 synthetic ticks with 0.01 % of the sizes x 1000 (each ~1.2 thresholds: a
+    backlog of one or two closes), and 2e7 ticks with 0.1 % x 8000 (backlogs of ~9 closes, overlapping now and then): the closes of the
+    default exact mode against the sequential oracle, n_uncertified 0, answered by the exact tier's stretch walk (path 2)."""
+    from finmlkit_amd import _ffi, engine
+    from finmlkit_amd._ffi import DeviceArray
+    monkeypatch.setenv("FMK_DL_FORCE_EXACT_TIER", "1")
+    ctx = _ffi.default_context()
+    t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
+    am = t.amount.to_host()
+    idx = np.random.default_rng(5).integers(0, n, int(n * share))
+    am[idx] *= np.float32(factor)
+    px = t.price.to_host()
+    t2 = engine.DeviceTrades(ctx, t.ts, t.price, DeviceArray.from_host(ctx, am), t.side)
+    thr = float((am[:2_000_000].astype(np.float64) * px[:2_000_000]).mean()) * 865.0 / (1 + share * factor)
+    assert float((am[idx].astype(np.float64) * px[idx]).max()) >= thr          # the tape does hold block trades
+    got = t2.dollar_bar_index(thr).to_host()
+    assert t2.last_uncertified == 0
+    assert _dollar_path() == 2
+    want = orc._dollar_bar_indexer(px, am, thr)
+    np.testing.assert_array_equal(got, want)
