@@ -315,18 +315,27 @@ __device__ __forceinline__ void bf_dir_write(const FlowDirOut &o, int64_t b, int
     const double mv = fmax(fabs(vmin), fabs(vmax)), md = fmax(fabs(dmin), fabs(dmax));
     // ... an extremum reached after k ticks has only k additions behind it in the reference's order: len -> k (+ a tile, the
     // granularity the position is known at).  Most extrema of small magnitude -- fine float32 spacing -- are early ones.
-    // (round 4: the parallel order's share is bounded by its NODE count, not its depth -- a tree or carry sum over k terms has about k
-    // internal nodes, each partial sum below 2 M and rounded once: 2 k u M, plus the reference's k u M -> 3 (k + 64) u M)
-    auto eps_at = [](int64_t k) { const double kk = (double)(k + 64); return 3.4e-16 * kk; };
+    // Absolute error bound of an extremum reached after k ticks, M = the largest magnitude a running sum takes, A = the sum of the
+    // terms' magnitudes (buy + sell).  The reference's recursive sum: one rounding per tick, each at most u M: k u M.  The parallel
+    // order: every NODE of its dependency tree rounds once, by at most u |node|; the nodes of one level are sums over disjoint tick
+    // ranges, so their magnitudes add up to at most A -- (levels) u A with <= 24 levels (8 ticks in a lane, 6 scan steps, the
+    // composition of up to 16 waves, slack) -- and the carry from tile to tile is a chain of k / 512 nodes below 2 M each.
+    // (History: round 3 charged the parallel order 2 M per LEVEL, which counts one node per level -- not a bound; the first repair in
+    // round 4 charged 2 M per NODE, 3 (k + 64) u M in all -- a bound, but three times the reference's own term: daily bars were
+    // redone three times as often, order flow on them 6.6 -> 17.9 ms per 1e9 ticks.  This one is a bound and costs what round 3 did.)
+    auto eps_at = [](int64_t k, double M, double A) {
+        const double kk = (double)(k + 64);
+        return 1.13e-16 * ((kk + 4.0 * (kk / 512.0 + 2.0)) * M + 24.0 * A);
+    };
     unsigned mask = 0;
     if (fmk_near_f32_tie(db, eps * db)) mask |= 1u << 2;
     if (fmk_near_f32_tie(ds, eps * ds)) mask |= 1u << 3;
     if (fmk_near_f32_tie(mean, (eps + 1.2e-16) * mean)) mask |= 1u << 4;
-    if (tb + tsell > 0 && (fmk_near_f32_tie(dmin, eps_at(t.kdmin) * md) || fmk_near_f32_tie(dmax, eps_at(t.kdmax) * md))) mask |= 1u << 6;
+    if (tb + tsell > 0 && (fmk_near_f32_tie(dmin, eps_at(t.kdmin, md, db + ds)) || fmk_near_f32_tie(dmax, eps_at(t.kdmax, md, db + ds)))) mask |= 1u << 6;
     if constexpr (sizeof(AmtT) == 8) {
         if (fmk_near_f32_tie(vb, eps * vb)) mask |= 1u << 0;
         if (fmk_near_f32_tie(vs, eps * vs)) mask |= 1u << 1;
-        if (tb + tsell > 0 && (fmk_near_f32_tie(vmin, eps_at(t.kvmin) * mv) || fmk_near_f32_tie(vmax, eps_at(t.kvmax) * mv))) mask |= 1u << 5;
+        if (tb + tsell > 0 && (fmk_near_f32_tie(vmin, eps_at(t.kvmin, mv, vb + vs)) || fmk_near_f32_tie(vmax, eps_at(t.kvmax, mv, vb + vs)))) mask |= 1u << 5;
     }
     if (bf_force_redo != 0) mask = 0x7F;                               // (tests: every bar through the tick-order redo)
     if (mask && lane == 0) redo[32 + atomicAdd(redo, 1ULL)] = (unsigned long long)b | ((unsigned long long)mask << 48);
