@@ -468,10 +468,42 @@ __device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], co
     return m;
 }
 
+// the thread's 8 consecutive doubles as four 16-byte accesses
+__device__ __forceinline__ void ew_store8(double *__restrict__ dst, int64_t i0, int64_t n, const double (&v)[EW_ITEMS])
+{
+    if (i0 + EW_ITEMS <= n) {
+        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
+        ew_d2s *q = (ew_d2s *)(dst + i0);
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { ew_d2s t; t.x = v[2 * k]; t.y = v[2 * k + 1]; q[k] = t; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k)
+            if (i0 + k < n) dst[i0 + k] = v[k];
+    }
+}
+__device__ __forceinline__ void ew_load8(const double *__restrict__ src, int64_t i0, int64_t n, double (&v)[EW_ITEMS])
+{
+    if (i0 + EW_ITEMS <= n) {
+        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
+        const ew_d2s *q = (const ew_d2s *)(src + i0);
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_d2s t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0.0;
+    }
+}
+
+// alpha_out (may be null; round 4): the tick's alpha is ALSO stored -- into the caller's output array, which the apply pass reads it
+// back from before it overwrites it with sigma (the same thread owns the same 8 elements in both passes).  The apply pass then
+// needs neither the timestamps nor a second exp per tick: it reads alpha (8 B) instead of ts (8 B), so the only extra traffic is
+// this pass's 8 B/tick of stores.
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__restrict__ ts,
                                                              const double *__restrict__ y, int64_t n,
-                                                             EwHl half_life, EwMap *__restrict__ tile_map)
+                                                             EwHl half_life, EwMap *__restrict__ tile_map,
+                                                             double *__restrict__ alpha_out = nullptr)
 {
     __shared__ EwMap lds[4];
     int64_t tl[EW_ITEMS], tprev0;
@@ -479,9 +511,24 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__re
     ew_load_direct(ts, y, n, tl, yl, &tprev0);
     double al[EW_ITEMS];
     EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
+    if (alpha_out) ew_store8(alpha_out, (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS, n, al);
     EwMap tot;
     (void)ew_block_exclusive(m, lds, &tot);
     if (threadIdx.x == 0) tile_map[blockIdx.x] = tot;
+}
+
+// the thread's map from GIVEN alphas (the apply pass after a map pass that stored them): the same compositions, no exp
+template <int MODE>
+__device__ __forceinline__ EwMap ew_thread_map_given(const double (&yl)[EW_ITEMS], int64_t n, const double (&al)[EW_ITEMS])
+{
+    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    EwMap m = ew_identity();
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        if (i >= 1 && i < n) m = ew_compose(m, ew_tick_alpha<MODE>(al[k], yl[k]));
+    }
+    return m;
 }
 
 // Hierarchical exclusive scan (composition) of an array of maps, in place:
@@ -533,14 +580,23 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
                                                          int64_t n, EwHl half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
                                                          const double *__restrict__ state_in,
-                                                         double *__restrict__ out)
+                                                         double *__restrict__ out, int alpha_in_out = 0)
 {
     __shared__ EwMap lds[4];
-    int64_t tl[EW_ITEMS], tprev0;
     double yl[EW_ITEMS];
-    ew_load_direct(ts, y, n, tl, yl, &tprev0);
     double al[EW_ITEMS];
-    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
+    EwMap m;
+    if (MODE != 2 && alpha_in_out) {
+        // `out` holds the alphas of the map pass: 8 B/tick of alpha instead of 8 B/tick of timestamps, and no second exp
+        const int64_t i0a = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+        ew_load8(y, i0a, n, yl);
+        ew_load8(out, i0a, n, al);
+        m = ew_thread_map_given<MODE>(yl, n, al);
+    } else {
+        int64_t tl[EW_ITEMS], tprev0;
+        ew_load_direct(ts, y, n, tl, yl, &tprev0);
+        m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
+    }
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     ex = ew_compose(tile_pre[blockIdx.x], ex);
@@ -562,17 +618,7 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
         ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
         res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
     }
-    // the thread's 8 results as four 16-byte stores
-    if (i0 + EW_ITEMS <= n) {
-        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
-        ew_d2s *q = (ew_d2s *)(out + i0);
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) { ew_d2s v; v.x = res[2 * k]; v.y = res[2 * k + 1]; q[k] = v; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k)
-            if (i0 + k < n) out[i0 + k] = res[k];
-    }
+    ew_store8(out, i0, n, res);                                    // the thread's 8 results as four 16-byte stores
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -822,7 +868,15 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     FMK_TRY(fmk_scratch(ctx, (size_t)(tiles + work_maps + 2) * sizeof(EwMap), &scr));
     EwMap *tm = (EwMap *)scr;
     EwMap *work = tm + tiles;
-    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, tm);
+    // FMK_EW_STORE_ALPHA=1 (developer knob, OFF by default): the map pass leaves its alphas in d_out for the apply pass.  Measured at 1e9
+    // ticks (profiles/r04_ewmst.txt): k_ew_apply 6.6 -> 4.7 ms without its exp, k_ew_tile_maps 2.7 -> 4.9 ms with its 8 GB of stores: 9.65
+    // against 9.79 ms end to end -- what exp saves the stores cost.  Same bits either way (the alphas are the same doubles);
+    // d_out must not alias the inputs for that
+    static int store_alpha = -1;
+    if (store_alpha < 0) { const char *v = getenv("FMK_EW_STORE_ALPHA"); store_alpha = v ? atoi(v) : 0; }
+    const int via_out = (MODE != 2 && store_alpha && d_out && !d_map_out && (const void *)d_out != (const void *)d_y &&
+                         (const void *)d_out != (const void *)d_ts) ? 1 : 0;
+    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, tm, via_out ? d_out : nullptr);
     FMK_LAUNCH_CHECK(ctx);
     if (d_map_out) {
         k_ew_total<<<1, EW_THREADS, 0, ctx->stream>>>(tm, tiles, d_map_out);
@@ -831,7 +885,7 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     }
     FMK_TRY(ew_scan_maps(ctx, tm, tiles, work));
     k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, tm, d_state_in,
-                                                                     d_out);
+                                                                     d_out, via_out);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
