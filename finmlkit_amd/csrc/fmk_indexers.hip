@@ -92,32 +92,42 @@ __device__ __forceinline__ int64_t tb_last_le(F at, int64_t lo, int64_t hi, int6
     return lo;
 }
 
-// one thread per clock edge: close_idx[k] = searchsorted(ts, edge_k, side='right') - 1
-__global__ __launch_bounds__(256) void k_time_bar_index(const int64_t *__restrict__ ts, int64_t n, int64_t e0,
-                                                        int64_t d, int64_t ne, const int64_t *__restrict__ coarse,
-                                                        int64_t m, int64_t *__restrict__ clock,
-                                                        int64_t *__restrict__ idx)
+// The window search of the two-level indexer with fewer LINES: the indexer is bound by random 64-byte line fetches (~6 per edge with
+// tb_last_le's bracket of +-48 around the interpolated position and the bisection inside it).  Here: ONE probe at the interpolated
+// position g; the residual (edge - ts[g]) divided by the window's mean gap moves the guess to within a few ticks (the window's own
+// drift is gone, what is left is the noise of ~|residual| gaps); both ends of a bracket of +-6 around that are probed (one or two
+// neighbouring lines) and the bisection finishes inside it.  Every probe keeps ts[lo] <= edge < ts[hi], so a guess that is off only
+// costs probes.  ~3 lines per edge instead of ~6.
+template <class F>
+__device__ __forceinline__ int64_t tb_last_le_secant(F at, int64_t lo, int64_t hi, int64_t vlo, int64_t vhi, bool hi_real, int64_t edge)
 {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ne) return;
-    const int64_t edge = e0 + k * d;
-    if (clock) clock[k] = edge;
-    const int64_t c_first = coarse[0], c_last = coarse[m - 1];        // (the same two words for every thread)
-    if (edge < c_first) { idx[k] = -1; return; }                      // before the first tick
-    // the last sample point <= edge: 18 dependent probes by bisection (243 K samples at 1e9 ticks), ~6 this way
-    const int64_t j = edge >= c_last ? m - 1
-                                     : tb_last_le([coarse](int64_t i) { return coarse[i]; }, 0, m - 1, c_first, c_last, true, edge, 8);
-    // ts[j * 4096] <= edge < ts[(j + 1) * 4096]: the answer lies in that window, whose two ends are the samples
-    const int64_t lo = j << TB_COARSE_SHIFT;
-    const bool hi_real = j + 1 < m;
-    const int64_t hi = hi_real ? (j + 1) << TB_COARSE_SHIFT : n;
-    const int64_t vlo = coarse[j], vhi = hi_real ? coarse[j + 1] : 0;
-    idx[k] = tb_last_le([ts](int64_t i) { return ts[i]; }, lo, hi, vlo, vhi, hi_real, edge, 48);
+    if (hi_real && hi - lo > 32 && vhi > vlo) {
+        const double gap = (double)(vhi - vlo) / (double)(hi - lo);
+        int64_t g = lo + (int64_t)((double)(edge - vlo) / gap);
+        g = g <= lo ? lo + 1 : (g >= hi ? hi - 1 : g);
+        const int64_t vg = at(g);
+        int64_t g2 = g + (int64_t)floor((double)(edge - vg) / gap);
+        if (vg <= edge) lo = g; else hi = g;
+        int64_t a = g2 - 6, b = g2 + 6;
+        a = a <= lo ? lo + 1 : (a >= hi ? hi - 1 : a);
+        b = b >= hi ? hi - 1 : (b <= lo ? lo + 1 : b);
+        if (hi - lo > 2) {
+            const int64_t va = at(a), vb = at(b);
+            if (va > edge) hi = a;
+            else if (vb <= edge) lo = b;
+            else { lo = a; hi = b; }
+        }
+    }
+    while (hi - lo > 1) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (at(mid) <= edge) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // searchsorted(ts, edge, side='right') - 1 through the sample table (the body of k_time_bar_index)
 __device__ __forceinline__ int64_t tb_index_of(const int64_t *__restrict__ ts, int64_t n, const int64_t *__restrict__ coarse, int64_t m,
-                                               int64_t edge)
+                                               int64_t edge, int secant)
 {
     const int64_t c_first = coarse[0], c_last = coarse[m - 1];
     if (edge < c_first) return -1;
@@ -127,7 +137,21 @@ __device__ __forceinline__ int64_t tb_index_of(const int64_t *__restrict__ ts, i
     const bool hi_real = j + 1 < m;
     const int64_t hi = hi_real ? (j + 1) << TB_COARSE_SHIFT : n;
     const int64_t vlo = coarse[j], vhi = hi_real ? coarse[j + 1] : 0;
+    if (secant) return tb_last_le_secant([ts](int64_t i) { return ts[i]; }, lo, hi, vlo, vhi, hi_real, edge);
     return tb_last_le([ts](int64_t i) { return ts[i]; }, lo, hi, vlo, vhi, hi_real, edge, 48);
+}
+
+// one thread per clock edge: close_idx[k] = searchsorted(ts, edge_k, side='right') - 1
+__global__ __launch_bounds__(256) void k_time_bar_index(const int64_t *__restrict__ ts, int64_t n, int64_t e0,
+                                                        int64_t d, int64_t ne, const int64_t *__restrict__ coarse,
+                                                        int64_t m, int64_t *__restrict__ clock,
+                                                        int64_t *__restrict__ idx, int secant)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ne) return;
+    const int64_t edge = e0 + k * d;
+    if (clock) clock[k] = edge;
+    idx[k] = tb_index_of(ts, n, coarse, m, edge, secant);
 }
 
 // Edges [k0, k1) of the clock -- one STAGE of the pipelined time-bar step (fmk_time_bars_ohlcv_dev, fmk_ohlcv.hip): the first stage
@@ -138,7 +162,8 @@ __device__ __forceinline__ int64_t tb_index_of(const int64_t *__restrict__ ts, i
 __global__ __launch_bounds__(256) void k_time_bar_index_stage(const int64_t *__restrict__ ts, int64_t n, int64_t e0, int64_t d,
                                                               int64_t ne, const int64_t *__restrict__ coarse, int64_t m,
                                                               int64_t k0, int64_t k1, int64_t *__restrict__ clock,
-                                                              int64_t *__restrict__ idx, int *__restrict__ saw_long, int64_t long_min)
+                                                              int64_t *__restrict__ idx, int *__restrict__ saw_long, int64_t long_min,
+                                                              int secant)
 {
     __shared__ int64_t sidx[256];
     // grid-stride over groups of 256 edges: the stage that runs BESIDE an OHLCV launch is given a small grid, so that it does not
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(256) void k_time_bar_index_stage(const int64_t *__r
         int64_t me = 0;
         if (live) {
             const int64_t edge = e0 + k * d;
-            me = tb_index_of(ts, n, coarse, m, edge);
+            me = tb_index_of(ts, n, coarse, m, edge, secant);
             if (clock) clock[k] = edge;
             idx[k] = me;
         }
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(256) void k_time_bar_index_stage(const int64_t *__r
         __syncthreads();
         if (live && k + 1 < ne) {
             const int64_t nx = (threadIdx.x + 1 < 256 && k + 1 < k1) ? sidx[threadIdx.x + 1]
-                                                                      : tb_index_of(ts, n, coarse, m, e0 + (k + 1) * d);
+                                                                      : tb_index_of(ts, n, coarse, m, e0 + (k + 1) * d, secant);
             if (nx - me > long_min && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -185,8 +210,10 @@ int fmk_time_bar_index_stage(fmk_ctx *ctx, hipStream_t st, const int64_t *d_ts, 
     if (k1 <= k0) return FMK_OK;
     int64_t blocks = fmk_ceil_div(k1 - k0, 256);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    static int secant = -1;                  // developer knob: FMK_TIME_INDEX_SECANT=0 -> the bracket-of-48 window search
+    if (secant < 0) { const char *v = getenv("FMK_TIME_INDEX_SECANT"); secant = v ? atoi(v) : 1; }
     k_time_bar_index_stage<<<(unsigned)blocks, 256, 0, st>>>(d_ts, n, e0, d, ne, coarse, m, k0, k1, d_clock,
-                                                                                  d_idx, saw_long, long_min);
+                                                                                  d_idx, saw_long, long_min, secant);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
@@ -263,9 +290,11 @@ extern "C" int fmk_time_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, int64
     int64_t *coarse = (int64_t *)scr;
     k_time_bar_coarse<<<(unsigned)fmk_ceil_div(m, 256), 256, 0, ctx->stream>>>(d_ts, n, coarse, m);
     FMK_LAUNCH_CHECK(ctx);
+    static int secant = -1;                  // developer knob: FMK_TIME_INDEX_SECANT=0 -> the bracket-of-48 window search
+    if (secant < 0) { const char *v = getenv("FMK_TIME_INDEX_SECANT"); secant = v ? atoi(v) : 1; }
     k_time_bar_index<<<(unsigned)fmk_ceil_div(n_edges, 256), 256, 0, ctx->stream>>>(d_ts, n, first_edge, delta,
                                                                                    n_edges, coarse, m, d_clock,
-                                                                                   d_close_idx);
+                                                                                   d_close_idx, secant);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }
