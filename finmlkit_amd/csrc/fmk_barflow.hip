@@ -22,6 +22,7 @@
 #include "fmk_footprint.h"
 #include "fmk_f32tie.h"
 #include "fmk_median.h"
+#include "fmk_scan.h"
 
 // developer knob FMK_DIR_FORCE_REDO=1 (tests): every bar of the wave-per-bar / workgroup-per-bar kernels goes on the redo list
 __device__ int bf_force_redo = 0;
@@ -1097,6 +1098,110 @@ static void bf_redo_launch(fmk_ctx *ctx, unsigned rblocks, const double *d_price
 
 
 // ---------------------------------------------------------------------------------------
+// Bars ordered by length (round 4).  The lane-per-bar schedule below is done with a wave when its LONGEST bar is:
+// on bars of unequal length (real one-minute bars: lognormal, sigma ~1) most lanes idle.  A counting sort by quarter-octave length
+// class (the four values of the two bits under the leading one: bars of a class differ by < 19 %), longest class first, gives every
+// wave 64 bars of about the same length; inside a class the bars keep the order of their 1 024-bar blocks (locality).
+//   k_bs_hist: per block of 1 024 bars, the count of every class -> hist[class][block]     (exclusive scan: fmk_scan.h)
+//   k_bs_scatter: perm[offset[class][block] + rank inside (block, class)] = bar
+// ---------------------------------------------------------------------------------------
+#define BS_CLASSES 128
+#define BS_BLOCK 1024
+__device__ __forceinline__ int bs_class(int64_t len)            // 0: the longest ... 127: empty / negative
+{
+    if (len <= 0) return BS_CLASSES - 1;
+    const int e = 63 - __builtin_clzll((unsigned long long)len);
+    const int q = e >= 2 ? (int)((len >> (e - 2)) & 3) : (int)((len << (2 - e)) & 3);
+    int c = 4 * e + q;                                           // grows with the length; < 126 for len < 2^31
+    if (c > BS_CLASSES - 2) c = BS_CLASSES - 2;
+    return BS_CLASSES - 2 - c;
+}
+__global__ __launch_bounds__(256) void k_bs_hist(const int64_t *__restrict__ ci, int64_t nb, int64_t nblk, int64_t *__restrict__ hist)
+{
+    __shared__ int cnt[BS_CLASSES];
+    if (threadIdx.x < BS_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = 0; r < BS_BLOCK / 256; ++r) {
+        const int64_t b = (int64_t)blockIdx.x * BS_BLOCK + r * 256 + threadIdx.x;
+        if (b < nb) atomicAdd(&cnt[bs_class(ci[b + 1] - ci[b])], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < BS_CLASSES) hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_bs_scatter(const int64_t *__restrict__ ci, int64_t nb, int64_t nblk,
+                                                    const int64_t *__restrict__ off, int64_t *__restrict__ perm)
+{
+    __shared__ int cnt[BS_CLASSES];
+    __shared__ int64_t base[BS_CLASSES];
+    if (threadIdx.x < BS_CLASSES) { cnt[threadIdx.x] = 0; base[threadIdx.x] = off[(int64_t)threadIdx.x * nblk + blockIdx.x]; }
+    __syncthreads();
+    for (int r = 0; r < BS_BLOCK / 256; ++r) {
+        const int64_t b = (int64_t)blockIdx.x * BS_BLOCK + r * 256 + threadIdx.x;
+        if (b < nb) {
+            const int c = bs_class(ci[b + 1] - ci[b]);
+            perm[base[c] + atomicAdd(&cnt[c], 1)] = b;
+        }
+    }
+}
+// per class, the number of bars: tot[c] = sum over the blocks of hist[c][.]
+__global__ __launch_bounds__(256) void k_bs_totals(const int64_t *__restrict__ hist, int64_t nblk, int64_t *__restrict__ tot)
+{
+    __shared__ int64_t ws[4];
+    const int c = blockIdx.x;
+    int64_t acc = 0;
+    for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += hist[(int64_t)c * nblk + b];
+    acc = fmk_wave_sum(acc);
+    if (fmk_lane() == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tot[c] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// The census: hist (*hist_out: a block of the context's pool, BS_CLASSES x nblk counts + the class totals behind them) and, on the
+// host, whether the bars are of UNEQUAL length: fewer than 80 % of them inside the best window of five adjacent classes (a factor
+// 2.4 in length).  One small read-back; it replaces the one the lane schedule used to make after the fact.
+static int bf_bar_census(fmk_ctx *ctx, const int64_t *d_ci, int64_t nb, int64_t **hist_out, bool *uneven)
+{
+    *hist_out = nullptr;
+    *uneven = false;
+    const int64_t nblk = fmk_ceil_div(nb, BS_BLOCK);
+    void *p_hist = nullptr;
+    FMK_TRY(fmk_alloc(ctx, (size_t)(BS_CLASSES * nblk + BS_CLASSES + 1) * 8, &p_hist));
+    int64_t *hist = (int64_t *)p_hist, *tot = hist + BS_CLASSES * nblk + 1;
+    k_bs_hist<<<(unsigned)nblk, 256, 0, ctx->stream>>>(d_ci, nb, nblk, hist);
+    k_bs_totals<<<BS_CLASSES, 256, 0, ctx->stream>>>(hist, nblk, tot);
+    int64_t h[BS_CLASSES];
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, tot, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)fmk_free(ctx, p_hist); return fmk_set_error(ctx, FMK_E_HIP, "bar census: %s", hipGetErrorString(e)); }
+    int64_t best = 0, run = 0;
+    for (int c = 0; c < BS_CLASSES - 1; ++c) {                       // (class 127: empty bars -- they cost nothing anywhere)
+        run += h[c];
+        if (c >= 5) run -= h[c - 5];
+        best = run > best ? run : best;
+    }
+    *uneven = (double)best < 0.8 * (double)(nb - h[BS_CLASSES - 1]);
+    *hist_out = hist;
+    return FMK_OK;
+}
+// the bars in order of their class (longest first) from the census' counts -> *perm_out: a block of the context's pool (the caller
+// frees it after queueing its kernels); `hist` is consumed (scanned in place)
+static int bf_sort_bars(fmk_ctx *ctx, const int64_t *d_ci, int64_t nb, int64_t *hist, int64_t **perm_out)
+{
+    *perm_out = nullptr;
+    const int64_t nblk = fmk_ceil_div(nb, BS_BLOCK);
+    void *p_perm = nullptr;
+    FMK_TRY(fmk_alloc(ctx, (size_t)nb * 8, &p_perm));
+    int rc = fmk_exclusive_scan_i64(ctx, hist, hist, BS_CLASSES * nblk, false);
+    if (rc == FMK_OK) {
+        k_bs_scatter<<<(unsigned)nblk, 256, 0, ctx->stream>>>(d_ci, nb, nblk, hist, (int64_t *)p_perm);
+        if (hipGetLastError() != hipSuccess) rc = fmk_set_error(ctx, FMK_E_HIP, "bf_sort_bars: launch failed");
+    }
+    if (rc != FMK_OK) { (void)fmk_free(ctx, p_perm); return rc; }
+    *perm_out = (int64_t *)p_perm;
+    return FMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // directional only, ONE LANE PER BAR (round 2, float32 amounts): the schedule for streams of many moderate bars.
 // A wave takes 64 consecutive bars; lane l walks bar l tick by tick with the reference's own loop (base.py:476-546: same
 // operations, same order, float64 accumulators), so
@@ -1123,7 +1228,8 @@ template <bool OHLC>
 __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *__restrict__ price, const float *__restrict__ amount,
                                                        const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
                                                        int64_t nb, int64_t n, FlowDirOut o, unsigned long long *n_zero_div,
-                                                       unsigned long long *long_list, int64_t max_len, DlOhlcOut oo)
+                                                       unsigned long long *long_list, int64_t max_len, DlOhlcOut oo,
+                                                       const int64_t *__restrict__ perm = nullptr)
 {
     __shared__ double s_p[DL_WAVES][64 * DL_ROW];
     __shared__ float s_a[DL_WAVES][64 * DL_ROW];
@@ -1138,8 +1244,9 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
     int64_t *sB = s_blk[wib];
     const int64_t nwaves = (int64_t)gridDim.x * DL_WAVES;
     for (int64_t w = (int64_t)blockIdx.x * DL_WAVES + wib; w * 64 < nb; w += nwaves) {
-        const int64_t b = w * 64 + lane;
-        const bool has = b < nb;
+        // perm (may be null): the bars ordered by length, longest first (bf_sort_bars) -- a wave's 64 bars then are about equally long
+        const bool has = w * 64 + lane < nb;
+        const int64_t b = has ? (perm ? perm[w * 64 + lane] : w * 64 + lane) : nb;
         const int64_t s = has ? ci[b] : 0, e = has ? ci[b + 1] : 0;
         const int64_t len = e - s;
         // A lane walks ITS bar; the wave is done when its longest bar is.  That pays while the 64 bars are about equally long -- the
@@ -1154,7 +1261,9 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
             const int64_t wsum = fmk_dpp_reduce(cand ? len : (int64_t)0, (int64_t)0, FmkOpAdd());
             const int64_t wmax = fmk_dpp_reduce(cand ? len : (int64_t)0, (int64_t)0, FmkOpMax());
             const int nact = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand));
-            if (wmax > 192 && (double)wsum < 0.7 * (double)wmax * (double)nact) thr_w = 192;
+            // (bars in order of length -- perm -- fill their waves by construction, and the caller then relies on every bar up to
+            //  max_len having been walked here)
+            if (!perm && wmax > 192 && (double)wsum < 0.7 * (double)wmax * (double)nact) thr_w = 192;
         }
         const bool is_long = has && len > thr_w;
         const unsigned long long lb = __builtin_amdgcn_ballot_w64(is_long);
@@ -1683,6 +1792,22 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         const int64_t nb = n_idx - 1;
         FlowDirOut o;
         memcpy(&o, d_dir, sizeof(o));
+        // Bars of UNEQUAL length (real one-minute bars: lognormal, sigma ~1; round 4): a census of the lengths by quarter-octave class
+        // first -- when fewer than 80 % of the bars lie within a factor 2.4 of each other, the lanes take the bars in order of their
+        // length (bf_sort_bars), so that a wave's 64 lanes finish together instead of waiting for its longest bar.  FMK_FLOW_SORT:
+        // 0 never, 1 always, unset: by the census.  (Before the scratch below is taken: the sort's scan uses the context scratch.)
+        const char *sv = getenv("FMK_FLOW_SORT");
+        int sort_mode = sv ? atoi(sv) : -1;
+        int64_t *perm = nullptr;
+        if (sort_mode != 0 && d_median) {
+            int64_t *hist = nullptr;
+            bool uneven = false;
+            FMK_TRY(bf_bar_census(ctx, d_close_idx, nb, &hist, &uneven));
+            if (sort_mode < 0) sort_mode = uneven ? 1 : 0;
+            int rc = sort_mode ? bf_sort_bars(ctx, d_close_idx, nb, hist, &perm) : FMK_OK;
+            (void)fmk_free(ctx, hist);
+            FMK_TRY(rc);
+        } else sort_mode = 0;
         unsigned long long *redo;
         FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 16, (void **)&redo));
         unsigned long long *long_list = redo + nb + 32;
@@ -1697,8 +1822,12 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         k_bar_dir_lanes<true><<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side,
                                                                                    d_close_idx, nb, n, o,
                                                                                    (unsigned long long *)d_n_zero_div, long_list,
-                                                                                   8192, oo);
-        FMK_LAUNCH_CHECK(ctx);
+                                                                                   8192, oo, perm);
+        {
+            const hipError_t le = hipGetLastError();
+            if (perm) (void)fmk_free(ctx, perm);
+            FMK_HIP(ctx, le);
+        }
         int64_t blocks = fmk_ceil_div(nb, 4);
         if (blocks > 2048) blocks = 2048;
         static int dwpb = -1;
@@ -1718,6 +1847,14 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         // 14.3 ms for the three functions apart (tools/realcfg4.py).  One 8-byte read-back; the call waits for its sizing pass anyway.
         FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[13], long_list, 8, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (sort_mode && d_median) {
+            // bars in order of length: the lanes have served every bar up to 8 192 ticks; the longer ones (listed) got their order flow from
+            // k_bar_dir above; medians (and open .. trades of the bars beyond 1 344 ticks) by comp_bar_ohlcv's size classes
+            FMK_TRY(fmk_median_small_ohlcv_long_launch(ctx, d_price, (const float *)d_amount, d_close_idx, nb, n, d_open, d_high, d_low,
+                                                       d_close, d_volume, d_vwap, d_trades, d_median));
+            return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
+                                                    max_levels);
+        }
         if (ctx->h_mail[13] > nb / 50) {
             FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, 0, n, d_close_idx, n_idx, d_open, d_high, d_low, d_close, d_volume,
                                            d_vwap, d_trades, d_median));

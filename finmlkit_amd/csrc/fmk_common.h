@@ -82,6 +82,9 @@ int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int 
                               double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades);
 int fmk_median_small_launch(fmk_ctx *ctx, const float *d_amount, const int64_t *d_close_idx, int64_t nb, double *d_median,
                             int64_t n_ticks);
+int fmk_median_small_ohlcv_long_launch(fmk_ctx *ctx, const double *p, const float *a, const int64_t *ci, int64_t nb, int64_t n,
+                                       double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                                       double *d_vwap, int64_t *d_trades, double *d_median);
 // fmk_median.hip: the bars of more than `min_cnt` ticks as a list ([0] = how many, then the bar numbers, any order) in a block of
 // the context's pool (*list; the caller gives it back with fmk_free after queueing its kernels) -- the workgroup-per-bar
 // kernels take their bars from it, so that a handful of very long bars spread over the whole chip

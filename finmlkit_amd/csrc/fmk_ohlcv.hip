@@ -1700,6 +1700,27 @@ int fmk_ohlcv_leftover_launch(fmk_ctx *ctx, const double *p, const void *a, int 
     return FMK_OK;
 }
 
+// cfg 4's first half on bars of unequal length (fmk_barflow.hip, float32 amounts): the lane-per-bar order-flow kernel has written
+// open .. trades of the bars it walked; the MEDIAN of a bar of <= 1 344 ticks comes from the amounts alone (k_bar_median_small), and
+// the bars beyond that take comp_bar_ohlcv's own size classes -- one pass each over price and amount, the median fused (their open ..
+// trades are written again, in this file's summation order: the values comp_bar_ohlcv itself gives).  The stand-alone median kernels
+// that served those bars before cost 3.0 ms per 1e9 ticks of lognormal bars, the classes 2.0 (profiles/r04_cfg4.txt).
+int fmk_median_small_ohlcv_long_launch(fmk_ctx *ctx, const double *p, const float *a, const int64_t *ci, int64_t nb, int64_t n,
+                                       double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
+                                       double *d_vwap, int64_t *d_trades, double *d_median)
+{
+    int *saw_long = (int *)(ctx->d_mail + 16);
+    FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 64;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    k_bar_median_small<<<(unsigned)blocks, 256, 0, ctx->stream>>>(a, ci, nb, saw_long, d_median);
+    FMK_LAUNCH_CHECK(ctx);
+    OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median, nullptr};
+    return ohlcv_leftovers<false>(ctx, p, a, ci, nb, n, o, saw_long, 64 * FMK_SMALL_NCH, ohlcv_grid(ctx, nb));
+}
+
 extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount,
                                       int amount_is_f64, int64_t n, const int64_t *d_close_idx, int64_t n_idx,
                                       double *d_open, double *d_high, double *d_low, double *d_close,

@@ -164,3 +164,27 @@ def test_fused_median_taken_by_the_footprint_sweep(orc, monkeypatch, n, interval
         assert fb.value <= 8 + (len(ci) - 1) // 20              # the bracket is accepted after each wave's first bar
     if amounts != "nan":
         _check_all(orc, px, am, sd, ci, f"deferred median {amounts}")
+
+
+@pytest.mark.parametrize("sort", ["0", "1", "census"])
+@pytest.mark.parametrize("amounts", ["dyadic", "lognormal32"])
+def test_fused_on_lognormal_bar_lengths_sorted_lanes(orc, monkeypatch, sort, amounts):
+    """cfg 4 on bars of UNEQUAL length (lognormal, sigma 1, mean ~900 ticks: what real one-minute bars look like), with and without the
+    length-ordered lane schedule (FMK_FLOW_SORT=1: a counting sort of the bars by quarter-octave length class, longest first, feeds
+    k_bar_dir_lanes) -- every output against the oracle; FMK_FLOW_LANES=2 forces the lane-per-bar first half at this size."""
+    if sort == "census":
+        monkeypatch.delenv("FMK_FLOW_SORT", raising=False)       # the library decides from its census of the bar lengths (here: sort)
+    else:
+        monkeypatch.setenv("FMK_FLOW_SORT", sort)
+    monkeypatch.setenv("FMK_FLOW_LANES", "2")
+    rng = np.random.default_rng(77)
+    n = 1_500_000
+    lens = np.maximum(1, rng.lognormal(np.log(900.0) - 0.5, 1.0, int(n / 900 * 1.4)).astype(np.int64))
+    lens[rng.integers(0, len(lens), 12)] = 0                              # a few empty bars
+    lens[rng.integers(0, len(lens), 3)] = rng.integers(8193, 20000, 3)    # and some beyond the lane schedule's reach
+    ci = np.concatenate([[-1], np.cumsum(lens) - 1])
+    ci = ci[ci <= n - 1].astype(np.int64)
+    px = np.round(100.0 + np.cumsum(rng.integers(-1, 2, n)) * 0.01, 2)
+    sd = rng.choice(np.array([-1, 1], np.int8), n)
+    am = (rng.integers(1, 4097, n) / 1024.0).astype(np.float32) if amounts == "dyadic" else rng.lognormal(-1, 1.2, n).astype(np.float32)
+    _check_all(orc, px, am, sd, ci, f"lognormal lengths, sort {sort}, {amounts}")
