@@ -1177,8 +1177,10 @@ template <bool AF64>
 static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t *sd, const int64_t *ci, int64_t nb,
                      double tick, const double *lows, double imb_mult, const int64_t *off, int lmin, int lmax, int wpb,
                      const FpOut &o, unsigned long long *n_bad, const unsigned long long *only = nullptr,
-                     double *d_median = nullptr, int *saw_long = nullptr, int64_t skip_above = INT64_MAX, int skip_lmax = 0)
+                     double *d_median = nullptr, int *saw_long = nullptr, int64_t skip_above = INT64_MAX, int skip_lmax = 0,
+                     hipStream_t st = nullptr /* the context's stream when null */)
 {
+    if (!st) st = ctx->stream;
     static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
     if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
     const bool med = d_median != nullptr && !AF64;
@@ -1205,6 +1207,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
         if (cap > (int64_t)ctx->n_cu * 32) cap = (int64_t)ctx->n_cu * 32;     // (every wave slot of the chip: 65 -> 47 ms per 2e8 ticks of 6 000-level bars against n_cu * 8)
         if (blocks > cap) blocks = cap;
         void *scr;
+        st = ctx->stream;                                            // (the context scratch is ordered on the context's stream)
         FMK_TRY(fmk_scratch(ctx, per_wave * (size_t)blocks + 256, &scr));
         gscratch = (unsigned char *)scr;
         smem = 0;
@@ -1214,7 +1217,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     if constexpr (!AF64) {
         if (med) {
             if (gscratch)
-                k_bar_footprints<false, true, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(
+                k_bar_footprints<false, true, true><<<(unsigned)blocks, wpb * 64, 0, st>>>(
                     p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, gscratch, 0, only, d_median,
                     saw_long, skip_above, skip_lmax);
             else {
@@ -1234,7 +1237,7 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
                     if (atoi(v) > 0) resident = atoi(v);
                 }
                 if (blocks > resident) blocks = resident;
-                k_bar_footprints<false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(
+                k_bar_footprints<false, false, true><<<(unsigned)blocks, wpb * 64, smem, st>>>(
                     p, a, sd, ci, nb, tick, lows, imb_mult, off, lmin, lmax, o, n_bad, force_ordered, nullptr,
                     fp_lds_atomics_in_lane_order(ctx), only, d_median, saw_long, skip_above, skip_lmax);
             }
@@ -1243,19 +1246,19 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
         }
     }
     if (gscratch)
-        k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
+        k_bar_footprints<AF64, true><<<(unsigned)blocks, wpb * 64, 0, st>>>(p, a, sd, ci, nb, tick, lows, imb_mult, off,
                                                                                    lmin, lmax, o, n_bad, force_ordered,
                                                                                    gscratch, 0, only, nullptr, nullptr, skip_above, skip_lmax);
     else if (fast) {
         if (smem > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_bar_footprints<AF64, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        k_bar_footprints<AF64, false, false, true><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
+        k_bar_footprints<AF64, false, false, true><<<(unsigned)blocks, wpb * 64, smem, st>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
                                                                                        fp_lds_atomics_in_lane_order(ctx), only,
                                                                                        nullptr, nullptr, skip_above, skip_lmax);
     } else
-        k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, ctx->stream>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
+        k_bar_footprints<AF64, false><<<(unsigned)blocks, wpb * 64, smem, st>>>(p, a, sd, ci, nb, tick, lows, imb_mult,
                                                                                        off, lmin, lmax, o, n_bad,
                                                                                        force_ordered, nullptr,
                                                                                        fp_lds_atomics_in_lane_order(ctx), only,
@@ -1417,18 +1420,38 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
             if (wl) (void)fmk_free(ctx, wl);                       // (an allocation above failed: rc says so)
         }
     }
+    // The classes take disjoint bars, and on a tape whose bars differ in length the first class (<= 128 levels) does nearly all the
+    // work while each wider one walks a few long bars with little parallelism (lognormal one-minute bars: 5.4 ms + six launches of
+    // 0.15 .. 0.36 ms one after the other).  So the wider LDS classes run BESIDE the first one, on the context's auxiliary stream
+    // (round 4; developer knob FMK_FP_SIDE_STREAM=0: one after the other as before).
+    hipStream_t side = nullptr;
+    {
+        const char *sv = getenv("FMK_FP_SIDE_STREAM");
+        if ((!sv || atoi(sv)) && max_levels > LMAX[0] && lmin_start == 0 && fmk_ctx_aux(ctx) == FMK_OK) {
+            side = ctx->aux;
+            hipError_t e = hipEventRecord(ctx->aev[3], ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ctx->aev[3], 0);
+            if (e != hipSuccess) side = nullptr;
+        }
+    }
     for (int k = 0; k < NCLS && rc == FMK_OK; ++k) {
         if (k > 0 && max_levels <= LMAX[k - 1]) break;
         // (the widest class of a call needs no more LDS than the call's widest bar)
         const int lm = (k >= 3 && max_levels < LMAX[k]) ? (int)max_levels : LMAX[k];
         if (LMAX[k] > lmin_start && LMAX[k] > lmin) {
+            hipStream_t st = (k > 0 && side) ? side : nullptr;
             rc = amount_is_f64
                      ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                       imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, nullptr, nullptr, skip_above, skip_lmax)
+                                       imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, nullptr, nullptr, skip_above, skip_lmax, st)
                      : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows,
-                                        imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, d_median, saw_long, skip_above, skip_lmax);
+                                        imb_mult, d_level_offsets, lmin, lm, WPB[k], o, bad, rest, d_median, saw_long, skip_above, skip_lmax, st);
         }
         lmin = LMAX[k];
+    }
+    if (side) {                                                     // join: everything behind this point sees every class' results
+        hipError_t e = hipEventRecord(ctx->aev[3], side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->aev[3], 0);
+        if (e != hipSuccess && rc == FMK_OK) rc = fmk_set_error(ctx, FMK_E_HIP, "footprints: joining the side stream: %s", hipGetErrorString(e));
     }
     // the long bars the workgroup kernel handed back (float64 amounts in tick order): the same classes once more, in list mode
     if (wide_defer && rc == FMK_OK) {
