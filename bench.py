@@ -601,7 +601,8 @@ def run(args):
                                     "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>")
                                    % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) if tc_ok else None,
+                         # per launch, like `achieved` (a step's launches cover disjoint bar ranges: bytes of the step / launches)
+                         "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) / lps if tc_ok else None,
                          # true when the kernel's sources have changed since the counters were read (SHA-256 in the constants)
                          "traffic_stale": tc_stale if tc_ok else None,
                          "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (sources "
