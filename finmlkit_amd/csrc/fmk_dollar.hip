@@ -163,19 +163,19 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
 }
 
-// W / thr (rounded up): the per-tile sums of the increments >= thr added up by one block
-__global__ __launch_bounds__(1024) void k_dl_whale_total(const double *__restrict__ part, int64_t tiles, double thr, double *__restrict__ out)
+// W / thr (rounded up): the per-tile sums of the increments >= thr, added up by a few hundred workgroups (one block walking the
+// 488 K tile records of 1e9 ticks took 0.21 ms -- on every dollar call, whales or not), one atomic each; *out is zeroed by the caller
+__global__ __launch_bounds__(256) void k_dl_whale_total(const double *__restrict__ part, int64_t tiles, double thr, double *__restrict__ out)
 {
-    __shared__ double ws[16];
+    __shared__ double ws[4];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < tiles; i += 1024) acc += part[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tiles; i += (int64_t)gridDim.x * 256) acc += part[i];
     acc = fmk_wave_sum(acc);
     if (fmk_lane() == 0) ws[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += ws[q];
-        *out = t / thr * (1.0 + 1e-9);
+        const double t = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        if (t > 0.0) atomicAdd(out, t / thr * (1.0 + 1e-9));
     }
 }
 
@@ -519,7 +519,7 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     double *d_whale = (double *)(ctx->d_mail + 28);
     FMK_HIP(ctx, hipMemsetAsync(d_bad, 0, 24, ctx->stream));
     k_dl_tile_sums<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, tsum, d_bad, d_dmax, thr, wpart);
-    k_dl_whale_total<<<1, 1024, 0, ctx->stream>>>(wpart, tiles, thr, d_whale);
+    k_dl_whale_total<<<(unsigned)(tiles < 512 * 256 ? fmk_ceil_div(tiles, 256) : 512), 256, 0, ctx->stream>>>(wpart, tiles, thr, d_whale);
     FMK_LAUNCH_CHECK(ctx);
     k_dl_scan_dd<<<(unsigned)gdd, DL_THREADS, 0, ctx->stream>>>(tsum, tiles, (int64_t)1 << DL_SEG_SHIFT, segb);
     DD *d_total = (DD *)(ctx->d_mail + 44);                            // sum of all increments (double-double)
