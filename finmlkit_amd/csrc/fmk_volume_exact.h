@@ -42,9 +42,10 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     double *Lp = (double *)vx_smem;
     uint16_t *nx = (uint16_t *)(vx_smem + (size_t)LPN * 8);
     double *wtot = (double *)(nx + S);                 // [NW] wave totals, [NW] wave maxima, [NW] wave minima
-    // a window elsewhere already failed its certificate (or met a bad amount): the call is going to the older tier anyway
+    // a window elsewhere already failed its certificate (or met a bad amount, or a bar beyond W ticks): the call is going to another
+    // class or tier anyway
     // (asked by the whole workgroup at once: waves that saw the flag at different moments must not part at a barrier)
-    if (__syncthreads_or(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (VOL_ST_INEXACT | VOL_ST_BAD))) return;
+    if (__syncthreads_or(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (VOL_ST_INEXACT | VOL_ST_BAD | VOL_ST_OVERFLOW))) return;
     const int64_t bs = (int64_t)blockIdx.x * S;
     const int tid = threadIdx.x, lane = fmk_lane(), w = tid >> 6;
     const int64_t remain = n - bs;
