@@ -1626,6 +1626,15 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
+        // bars of 45 .. 64 ticks fill a 1 024-tick tile with 16 .. 22 bars only: a 2 048-tick tile for those -- 50 / 60-tick bars 7.4 / 9.5 ->
+        // 6.7 / 8.9 ms per 1e9 ticks, 34 / 40-tick bars are better off with the small tile (7.0 / 6.6 against 7.9 / 7.4) (developer knob
+        // FMK_OHLCV_LANES_TILE=1024: the small tile at every length; profiles/r04_short_bars.txt)
+        static int big_tile = -1;
+        if (big_tile < 0) { const char *v = getenv("FMK_OHLCV_LANES_TILE"); big_tile = (v ? atoi(v) : 2048) >= 2048 ? 1 : 0; }
+        if (big_tile && n / nb > 44) {
+            if (!o.median) k_bar_ohlcv_lanes<false, 2048><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+            else k_bar_ohlcv_lanes<true, 2048><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        } else
         if (!o.median) k_bar_ohlcv_lanes<false, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_lanes<true, 1024><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         long_min = 64;
