@@ -158,6 +158,21 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         num += (double)(low + l) * (double)t;
     }
     // first argmax across lanes (ties -> lowest index)
+    const bool narrow = L <= 64;               // (wave-uniform) one level per lane: the common case -- ~40 levels per one-minute bar
+    if (narrow) {
+        // ONE max-reduction of a packed key on the DPP path (round 4): the value as an order-preserving 32-bit pattern (NaN above
+        // everything: np.argmax keeps the first NaN), then the lowest index -- instead of six butterflies of two ds_bpermute each
+        long long key = -1;
+        if (best_i != 0x7FFFFFFF) {
+            const float tz = best + 0.0f;                                 // (-0.0 and +0.0 are equal to np.argmax)
+            unsigned u = __float_as_uint(tz);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            if (best != best) u = 0xFFFFFFFFu;
+            key = (long long)(((unsigned long long)u << 31) | (unsigned long long)(0x7FFFFFFF - best_i));
+        }
+        key = (long long)fmk_dpp_reduce((int64_t)key, (int64_t)-1, FmkOpMax());
+        best_i = key < 0 ? 0 : 0x7FFFFFFF - (int)(key & 0x7FFFFFFF);      // empty guard: np.argmax -> 0
+    } else {
 #pragma unroll
     for (int x = 32; x > 0; x >>= 1) {
         float ob = __shfl_xor(best, x, 64);
@@ -167,6 +182,7 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         if (take) { best = ob; best_i = oi; }
     }
     if (best_i == 0x7FFFFFFF) best_i = 0;      // empty guard: np.argmax -> 0
+    }
     num = fmk_dpp_reduce(num, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
     const float total = fast_sum ? (aux ? fmk_np_sum([tot](int i) { return tot[i]; }, L, lane, pstk)
@@ -180,6 +196,7 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     float *q2 = (float *)(cnt + lmax);
     unsigned bsum = 0, ssum = 0;
     double skew = 0.0;
+    unsigned long long mask_p = 0, mask_n = 0;                       // narrow bars: the levels whose run sign is +1 / -1
     for (int l0 = 0; l0 < L; l0 += 64) {
         const int l = l0 + lane;
         bool bi = false, si = false;
@@ -197,8 +214,11 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
                 q2[l] = q * q;
             }
         }
-        bsum += __popcll(__ballot(bi));
-        ssum += __popcll(__ballot(si));
+        const unsigned long long bb = __ballot(bi), sb = __ballot(si);
+        bsum += __popcll(bb);
+        ssum += __popcll(sb);
+        mask_p = bb;                                                 // (meaningful when L <= 64: one iteration)
+        mask_n = sb & ~bb;                                           // buy wins where both are set (base.py:807)
     }
     skew = fmk_dpp_reduce(skew, 0.0, FmkOpAdd());
     __builtin_amdgcn_wave_barrier();
@@ -208,6 +228,18 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
     // ---- longest signed run (base.py:801-819).  The reference scans the levels once; here every lane scans a
     //      contiguous segment (prefix run, first-longest run inside, run state at its end) and the 64 summaries
     //      are folded in segment order -- same result, incl. "the FIRST run of maximal length wins".
+    int max_run = 0, max_sign = 0;
+    if (narrow) {
+        // Narrow bars (round 4): the runs of equal sign are runs of set bits in two 64-bit masks.  m &= m >> 1 leaves, after k steps,
+        // the STARTS of the runs of length > k: the last non-empty mask names the longest runs, its lowest bit the first of them.
+        // The reference keeps the run that REACHES the maximal length first (run > max_run, strictly): start + length - 1, i.e. --
+        // at equal length -- the lower start.  A dozen scalar instructions instead of a 16-step loop on every lane and a fold.
+        int kp = 0, kn = 0, sp = 0, sn = 0;
+        for (unsigned long long m = mask_p; m; m &= m >> 1) { ++kp; sp = (int)__builtin_ctzll(m); }
+        for (unsigned long long m = mask_n; m; m &= m >> 1) { ++kn; sn = (int)__builtin_ctzll(m); }
+        if (kp > kn || (kp == kn && kp > 0 && sp < sn)) { max_run = kp; max_sign = 1; }
+        else if (kn > 0) { max_run = kn; max_sign = -1; }
+    } else {
     int p_len = 0, p_sign = 0, s_len = 0, s_sign = 0, b_len = 0, b_sign = 0, n_seg = 0;
     {
         int seg = (L + 63) / 64;
@@ -231,7 +263,6 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
         }
         s_len = run; s_sign = rs;
     }
-    int max_run = 0, max_sign = 0;
     {
         int run = 0, run_sign = 0;
         for (int k = 0; k < 64; ++k) {
@@ -252,6 +283,7 @@ __device__ __forceinline__ void fp_emit_bar(const FpOut &o, int64_t b, int64_t b
                 run_sign = __builtin_amdgcn_readlane(s_sign, k);
             }
         }
+    }
     }
     if (lane == 0) {
         o.buy_imbalances_sum[b] = (uint16_t)bsum;
