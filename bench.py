@@ -72,7 +72,7 @@ def parse():
                          "(ncclSend/ncclRecv to self), plus the boundary-bar launches -- the per-step overhead of the "
                          "multi-GPU path measured on one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
-    ap.add_argument("--placements", type=int, default=3,
+    ap.add_argument("--placements", type=int, default=6,
                     help="allocate the input columns this many times (all held at once), probe each copy with a few steps and run "
                          "the timed region on the fastest; roofline.frac_min / frac_max report the spread (1: no choice)")
     ap.add_argument("--separate-index", action="store_true",
@@ -463,10 +463,14 @@ def run(args):
             state["idx"] = DeviceArray(ctx, cap, np.int64)
             state["out"] = trades.alloc_ohlcv(cap, want_median)
 
-    if args.placements > 1 and not use_dist and (args.placements - 1) * n * 21 + (8 << 30) < free - need:
+    # (as many of the requested copies as fit beside 8 GiB of working memory)
+    args.placements = max(1, min(args.placements, 1 + int((free - need - (8 << 30)) // (n * 21))))
+    if args.placements > 1:
         # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-5 % between allocations of one
         # process, constant for the life of an allocation: profiles/r04_placement.txt, r04_drift.txt).  Set-up, not a step: K
-        # copies of the same ticks, each probed with the step itself; the fastest stays, the others are freed.
+        # copies of the same ticks, each probed with the step itself; the fastest stays, the others are freed.  Every rank of a
+        # sharded run does the same for its own shard (the probe is the shard's bars without the exchange: the same kernel over
+        # the same columns) -- the job's step is the MAX over ranks, so one rank on a slow allocation would set it.
         def step_of(t):
             t0, t1 = t.first_last_ts()
             ne, e0, d = clock_of(t0, t1)

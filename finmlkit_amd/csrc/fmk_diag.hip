@@ -106,6 +106,30 @@ __global__ __launch_bounds__(256) void k_diag_read2(const uint2 *__restrict__ a,
             const uint2 v = a[i];
             acc ^= v.x ^ v.y ^ b[i];
         }
+    } else if (PATTERN == 3) {
+        // the reducers' own issue order: a wave asks for up to 16 rows of BOTH columns of its segment before it looks at any of them
+        const int lane = threadIdx.x & 63;
+        const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+        const int64_t nseg = n / seg;
+        for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+            const int64_t base = s * seg;
+            for (int j0 = 0; j0 < seg; j0 += 1024) {
+                uint2 v[16];
+                unsigned u[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int j = j0 + k * 64 + lane;
+                    v[k] = j < seg ? a[base + j] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int j = j0 + k * 64 + lane;
+                    u[k] = j < seg ? b[base + j] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc ^= v[k].x ^ v[k].y ^ u[k];
+            }
+        }
     } else {
         const int lane = threadIdx.x & 63;
         const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -125,13 +149,14 @@ __global__ __launch_bounds__(256) void k_diag_read2(const uint2 *__restrict__ a,
 extern "C" int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
                                          int blocks_per_cu, double *elapsed_ms)
 {
-    if (n <= 0 || seg <= 0 || pattern < 0 || pattern > 2) return fmk_set_error(ctx, FMK_E_ARG, "diag: bad arguments");
+    if (n <= 0 || seg <= 0 || pattern < 0 || pattern > 3) return fmk_set_error(ctx, FMK_E_ARG, "diag: bad arguments");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const unsigned blocks = (unsigned)(ctx->n_cu * (blocks_per_cu > 0 ? blocks_per_cu : 8));
     unsigned long long *sink = (unsigned long long *)(ctx->d_mail + 60);
     FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (pattern == 0) k_diag_read2<0><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
     else if (pattern == 1) k_diag_read2<1><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
+    else if (pattern == 3) k_diag_read2<3><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
     else k_diag_read2<2><<<blocks, 256, 0, ctx->stream>>>((const uint2 *)d_a8, (const unsigned *)d_b4, n, seg, sink);
     FMK_LAUNCH_CHECK(ctx);
     FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

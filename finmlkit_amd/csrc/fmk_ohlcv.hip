@@ -1578,11 +1578,11 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
             FMK_TRY(fmk_time_bar_index_stage(ctx, ctx->aux, tb->ts, n, tb->e0, tb->d, ne, coarse, m, pipe_ka + 1, ne, tb->clock,
                                              tb->idx, saw_long, long_min, (int64_t)ctx->n_cu * idx_bpc));
             FMK_HIP(ctx, hipEventRecord(ctx->aev[1], ctx->aux));
+            // (also in enqueue-only mode: this wait ends when the index stages do, ~0.1 ms into a 2 ms launch -- the device never idles
+            //  for it, and it saves the ~36 empty launches of the leftover passes, 0.25 ms per step of the sharded path)
             int *h_saw = (int *)(ctx->h_mail + 50);
-            if (!ctx->enqueue_only) {
-                FMK_HIP(ctx, hipMemcpyAsync(h_saw, saw_long, sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
-                FMK_HIP(ctx, hipEventRecord(ctx->aev[2], ctx->aux));
-            }
+            FMK_HIP(ctx, hipMemcpyAsync(h_saw, saw_long, sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[2], ctx->aux));
             for (int stage = 0; stage < 2; ++stage) {
                 const int64_t b0 = stage ? pipe_ka : 0, cnt = stage ? nb - pipe_ka : pipe_ka;
                 OhlcvOut q = o;
@@ -1597,7 +1597,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
                 FMK_LAUNCH_CHECK(ctx);
                 if (sl >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[sl][1], ctx->stream));
             }
-            if (!ctx->enqueue_only) {
+            static const int eo_census = []{ const char *v = getenv("FMK_TB_PIPE_EO_CENSUS"); return v ? atoi(v) : 1; }();
+            if (!ctx->enqueue_only || eo_census) {
                 FMK_HIP(ctx, hipEventSynchronize(ctx->aev[2]));          // the index stages' census: long before the kernels end
                 if (*h_saw == 0) return FMK_OK;
             }
@@ -1679,6 +1680,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     // one 4-byte copy and a wait for the kernel that is the call's work anyway.  fmk_ctx_set_enqueue_only(ctx, 1) (the sharded
     // step: two waits per step cost it 0.9 ms) or the developer knob FMK_OHLCV_CENSUS_SYNC=0: enqueue everything without looking.
     if constexpr (!AF64) {
+        if (n <= long_min) return FMK_OK;                          // no bar is longer than the tick array (the sharded step's boundary bar)
         static int census_sync = -1;
         if (census_sync < 0) { const char *v = getenv("FMK_OHLCV_CENSUS_SYNC"); census_sync = v ? atoi(v) : 1; }
         if (census_sync && !ctx->enqueue_only) {

@@ -18,6 +18,7 @@ against the compute stream by events only.  No PyTorch, no all-reduce, no ring.
 The planning arithmetic is plain Python integers (exact); nothing here computes bar values.
 """
 from __future__ import annotations
+import os
 
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
@@ -205,6 +206,8 @@ class ShardedTimeBars:
         from ._ffi import DeviceArray
         self.t, self.rank, self.world = trades, rank, world
         self.interval, self.want_median = float(interval_seconds), want_median
+        # interior bars through the pipelined one-call entry (1) or the separate indexer + comp_bar_ohlcv (0): developer switch
+        self.one_call = os.environ.get("FMK_DIST_ONE_CALL", "1") != "0"
         self.with_side = with_side and trades.side is not None
         self.self_loop = self_loop and world == 1
         self.ctx = trades.ctx
@@ -292,13 +295,23 @@ class ShardedTimeBars:
                                                      out=(self._clock, self._idx))
 
     def enqueue_interior(self):
-        self._index()
-        # bars that need no halo: all of them on rank 0, bars 1.. elsewhere (their ticks are local)
-        if self.rank == 0:
-            self.t.bar_ohlcv(self.idx, want_median=self.want_median, out=self.out)
-        elif self.n_edges > 2:
-            self.t.bar_ohlcv(self.idx.view(1), want_median=self.want_median,
-                             out={k: v.view(1) for k, v in self.out.items()})
+        # The shard's clock edges and its bars in ONE pipelined call (fmk_time_bars_ohlcv_dev, round 4: index stage 1 -> OHLCV launch 1 ||
+        # index stage 2 -> OHLCV launch 2; the long-bar census comes from the index stages, so nothing waits for a kernel).  Bars that
+        # need no halo: all of them on rank 0, bars 1.. elsewhere.  On the other ranks bar 0 is computed here from the local ticks alone
+        # -- a partial bar -- and OVERWRITTEN by the boundary launch that follows on the same stream (enqueue_boundary).
+        if not self.one_call:
+            self._index()
+            if self.rank == 0:
+                self.t.bar_ohlcv(self.idx, want_median=self.want_median, out=self.out)
+            elif self.n_edges > 2:
+                self.t.bar_ohlcv(self.idx.view(1), want_median=self.want_median,
+                                 out={k: v.view(1) for k, v in self.out.items()})
+        elif self.n_edges > 2 or self.rank == 0:
+            self.clock, self.idx, _ = self.t.time_bars_ohlcv(self.interval, self.want_median,
+                                                             clock_params=(self.n_edges, self.e_lo, self.gclock[2]),
+                                                             out_index=(self._clock, self._idx), out=self.out)
+        else:
+            self._index()
 
     def enqueue_boundary(self) -> int:
         import ctypes as C

@@ -26,7 +26,7 @@ int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int v
 int fmk_diag_fill_amounts_dev(fmk_ctx *ctx, uint64_t seed, int64_t n, float *d_amount);
 /* Two columns read in lock-step (tools/placement.py): 8 B elements of d_a8 and 4 B elements of d_b4 at the same index.
  * pattern 0: flat grid-stride; 1: each wave streams `seg` contiguous elements of both, then jumps by the number of waves
- * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only.  Not used by any product path. */
+ * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only; 3: as 1, up to 16 rows of both columns requested before any is used.  Not used by any product path. */
 int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, int64_t n, int pattern, int seg,
                               int blocks_per_cu, double *elapsed_ms);
 /* Dependent-access latency of one wave (tools/hoplat.py): `hops` hops of `loads` coalesced 512 B rows, the next address

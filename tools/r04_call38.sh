@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out/c38
+for v in "1 1" "1 0" "0 1"; do set -- $v
+  FMK_DIST_ONE_CALL=$1 FMK_TB_PIPE_EO_CENSUS=$2 timeout 200 python tools/distab.py 1e9 20 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tee -a gpurun_out/c38/distab.txt
+done
