@@ -72,9 +72,10 @@ def parse():
                          "(ncclSend/ncclRecv to self), plus the boundary-bar launches -- the per-step overhead of the "
                          "multi-GPU path measured on one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
-    ap.add_argument("--placements", type=int, default=6,
-                    help="allocate the input columns this many times (all held at once), probe each copy with a few steps and run "
-                         "the timed region on the fastest; roofline.frac_min / frac_max report the spread (1: no choice)")
+    ap.add_argument("--placements", type=int, default=7,
+                    help="probe the input columns at this many places of device memory (as first allocated + N-1 positions of one large "
+                         "allocation) with a few steps each and run the timed region on the fastest; roofline.frac_min / frac_max report "
+                         "the spread (1: no choice)")
     ap.add_argument("--separate-index", action="store_true",
                     help="the step as two library calls (time-bar indexer kernels, then OHLCV + median) instead of the one-launch "
                          "fmk_time_bars_ohlcv_dev -- for A/B timing")
@@ -288,14 +289,26 @@ def _probe_step_kernel_ms(ctx, fn, steps):
     return sum(k[i] for i in range(kn.value)) / steps
 
 
+def placement_span(n):
+    """Bytes one set of columns takes inside the placement slab (ts, price, amount, side on 2 MiB boundaries, rounded up to 1 GiB)."""
+    return (21 * n + (8 << 20) + (1 << 30) - 1) // (1 << 30) * (1 << 30)
+
+
 def choose_placement(ctx, trades, args, rank, n, step_of):
-    """K allocations of the input columns (the first is `trades`), all held at once; each is probed with the bench's own step (3 untimed
-    + 8 timed passes, kernel time by HIP events), the fastest stays and the others are freed.  Then the chosen copy is run until its level
-    has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before; at most 40 steps): the first passes over a new
-    allocation run up to 10 % slower than the level it settles at (profiles/r04_step_timeline.txt).  All of it is set-up, before the
-    warm-up; -> (the chosen copy, {"probe_kernel_ms": [...], "chosen": k, "settle_kernel_ms": [...]})."""
+    """WHERE the input columns lie in device memory sets the level of the dominant kernel: whole physical blocks of 16 .. 128 GiB are 8 .. 10 %
+    "slow" for it, and small separate allocations land in them more often than one large one does (profiles/r04_placement_regions.txt).  So:
+    ONE slab of K x 20 GiB, the same ticks synthesised at K positions of it; every position (and the separately allocated columns the run
+    started with) is probed with the bench's own step (3 untimed + 8 timed passes, kernel time by HIP events); the fastest stays.  Then the
+    chosen copy is run until its level has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before; at most 40 steps):
+    the first passes over new memory run up to 10 % slower than the level they settle at (profiles/r04_step_timeline.txt).  All of it is
+    set-up, before the warm-up; -> (the chosen copy, {"probe_kernel_ms": [...], "chosen": k, "settle_kernel_ms": [...]})."""
+    import numpy as np
     from finmlkit_amd import engine
-    copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx) for _ in range(args.placements - 1)]
+    from finmlkit_amd._ffi import DeviceArray
+    k_pos = args.placements - 1
+    span = placement_span(n)
+    slab = DeviceArray(ctx, k_pos * span, np.uint8)
+    copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, k * span)) for k in range(k_pos)]
     ms = []
     for t in copies:
         fn = step_of(t)
@@ -304,10 +317,12 @@ def choose_placement(ctx, trades, args, rank, n, step_of):
         ms.append(_probe_step_kernel_ms(ctx, fn, 8))
     best = min(range(len(ms)), key=lambda i: ms[i])
     chosen = copies[best]
-    for i, t in enumerate(copies):
-        if i != best:
-            for col in getattr(t, "_backing", []):
-                col.free()
+    if best != 0:
+        for col in getattr(trades, "_backing", []):
+            col.free()
+    else:
+        slab.free()
+    chosen._placement_slab = slab                       # (the slab lives as long as the columns carved out of it)
     del copies
     fn = step_of(chosen)
     settle = [_probe_step_kernel_ms(ctx, fn, 5)]
@@ -315,8 +330,9 @@ def choose_placement(ctx, trades, args, rank, n, step_of):
         settle.append(_probe_step_kernel_ms(ctx, fn, 5))
         if settle[-1] > settle[-2] * 0.995:
             break
-    info = {"policy": f"best of {len(ms)} allocations of the input columns by an 8-step probe of the step's dominant kernel, then run "
-                      "until its level settles (set-up, before the warm-up; the other copies are freed)",
+    info = {"policy": f"the columns as first allocated (probe 0) and at {k_pos} positions of one {k_pos * span >> 30} GiB allocation, each probed by "
+                      "8 steps of the step's dominant kernel; the fastest stays and is run until its level settles (set-up, before the "
+                      "warm-up)",
             "probe_kernel_ms": ms, "chosen": best, "settle_kernel_ms": settle}
     return chosen, info
 
@@ -463,8 +479,8 @@ def run(args):
             state["idx"] = DeviceArray(ctx, cap, np.int64)
             state["out"] = trades.alloc_ohlcv(cap, want_median)
 
-    # (as many of the requested copies as fit beside 8 GiB of working memory)
-    args.placements = max(1, min(args.placements, 1 + int((free - need - (8 << 30)) // (n * 21))))
+    # (as many of the requested positions as fit beside 8 GiB of working memory)
+    args.placements = max(1, min(args.placements, 1 + int((free - need - (8 << 30)) // placement_span(n))))
     if args.placements > 1:
         # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-5 % between allocations of one
         # process, constant for the life of an allocation: profiles/r04_placement.txt, r04_drift.txt).  Set-up, not a step: K

@@ -65,17 +65,28 @@ class DeviceTrades:
 
     @classmethod
     def synth(cls, n: int, seed: int = 42, first: int = 0, gap_mod: int = DENSE_GAP_MOD,
-              ctx: Optional[Context] = None, headroom: int = 0) -> "DeviceTrades":
+              ctx: Optional[Context] = None, headroom: int = 0, into=None) -> "DeviceTrades":
         """Ticks [first, first+n) of the synthetic stream, generated on the device.
 
         `headroom` reserves that many elements *in front* of every column (multi-GPU halo)."""
         ctx = ctx or _ffi.default_context()
-        cols = [DeviceArray(ctx, n + headroom, dt) for dt in (np.int64, np.float64, np.float32, np.int8)]
+        if into is not None:
+            # the four columns carved out of ONE caller-owned allocation at byte offset `into[1]` (each column on a 2 MiB boundary):
+            # bench.py's placement probe -- the level of the reducers depends on where in device memory the columns lie
+            slab, off = into
+            cols, at = [], int(off)
+            for dt in (np.int64, np.float64, np.float32, np.int8):
+                nb = (n + headroom) * np.dtype(dt).itemsize
+                assert at + nb <= slab.nbytes, "DeviceTrades.synth(into=...): the slab is too small"
+                cols.append(DeviceArray(ctx, n + headroom, dt, slab.ptr + at, owner=slab))
+                at += (nb + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        else:
+            cols = [DeviceArray(ctx, n + headroom, dt) for dt in (np.int64, np.float64, np.float32, np.int8)]
         v = [c.view(headroom, n) for c in cols]
         ctx.call("fmk_synth_trades_dev", C.c_uint64(seed), c_i64(first), c_i64(n), C.c_uint64(gap_mod),
                  v[0].p, v[1].p, v[2].p, v[3].p)
         t = cls(ctx, *v)
-        t._backing = cols
+        t._backing = cols if into is None else []
         t._headroom = headroom
         return t
 
