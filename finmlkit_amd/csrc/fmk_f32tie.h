@@ -19,7 +19,10 @@ __device__ __forceinline__ bool fmk_near_f32_tie(double s, double bound)
     const double up = ldexp(1.0, ex - 23);                       // float32 spacing above |f|
     const double down = af == ldexp(1.0, ex) ? 0.5 * up : up;    // ... and below (a power of two sits on a binade edge)
     const double half = 0.5 * (fabs(s) >= af ? up : down);
-    return half - fabs(fabs(s) - af) <= bound;
+    // (written so that an UNDEFINED bound -- a NaN among the terms it was computed from, e.g. a NaN amount elsewhere in the bar while this
+    //  extremum was reached before it -- says "near": the bar then takes the tick-order redo.  `<= bound` said "not near" and the bar kept
+    //  the parallel order's last bit: tools/fuzz_longbars.py 150 361, case 70, cum_dollars_max 2.7e-12 below a boundary)
+    return !(half - fabs(fabs(s) - af) > bound);
 }
 
 __device__ __forceinline__ double fmk_f32tie_eps(int64_t len) { return 4.6e-16 * (double)(len + 1); }   // > 2 len 2^-52

@@ -1022,12 +1022,14 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
 // Bars of more than 256 ticks are flagged for the generic kernels.
 // ---------------------------------------------------------------------------------------------------------------------
 #define OHR_WAVES 4
+#define OHR_CAND 16                     // keys left in the median bracket when the row sorts them (k_bar_ohlcv_rows)
 template <bool MEDIAN>
 __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double *__restrict__ price, const float *__restrict__ amount,
                                                                  const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                                  int *__restrict__ saw_long, OhlcvOut o)
 {
     typedef MedKey<false> MK;
+    __shared__ uint32_t s_cand[OHR_WAVES][64];
     const int lane = fmk_lane();
     const int w = fmk_uniform((int)(threadIdx.x >> 6));
     const int row = lane >> 4, ri = lane & 15;
@@ -1095,7 +1097,7 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
             uint32_t blo = kmn - 1, bhi = kmx;
             int c_lo = 0, c_hi = L;
             for (int step = 0; step < 40; ++step) {
-                const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > 1;
+                const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > OHR_CAND;
                 if (__ballot(open) == 0) break;
                 if (step == 10 || step == 15 || step == 20) {
                     // still open after ~log2(L) + 3 halvings: the target key is TIED (decimal lot sizes) and the count never falls to
@@ -1122,11 +1124,48 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
                 c = fmk_row_sum(c);
                 if (open) { if (c > k1) { bhi = pivot; c_hi = c; } else { blo = pivot; c_lo = c; } }
             }
-            if (L > 0 && bhi - blo > 1) {                                    // one key in (blo, bhi]: find it
-                uint32_t only_key = 0;
+            const bool few = L > 0 && bhi - blo > 1;                         // <= OHR_CAND keys left in (blo, bhi]
+            if (__ballot(few) != 0) {
+                // The bisection on the key VALUE used to run until ONE key was left: ~22 steps of ~25 instructions for the 80 keys of a
+                // bar whose sizes span twelve binades.  Now it stops at <= 16 candidates (~6 steps); the row packs them into its sixteen
+                // lanes through LDS and sorts them with a ten-step network on the DPP data path; rank k1 - c_lo of the sorted row is v1.
+                int mcnt = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) only_key = (key[r] > blo && key[r] <= bhi && key[r] > only_key) ? key[r] : only_key;
-                bhi = fmk_row_umax(only_key);
+                for (int r = 0; r < 16; ++r)
+                    if (r < nreg) mcnt += (key[r] > blo && key[r] <= bhi) ? 1 : 0;
+                int pos = mcnt;
+                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(1), 0xF>(0, pos);
+                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(2), 0xF>(0, pos);
+                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(4), 0xF>(0, pos);
+                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(8), 0xF>(0, pos);
+                pos -= mcnt;                                                  // keys of the row's lower lanes that are in the bracket
+                s_cand[w][lane] = MK::MAXK;
+                __builtin_amdgcn_wave_barrier();
+                if (few) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r < nreg && key[r] > blo && key[r] <= bhi) s_cand[w][(row << 4) + (pos++ & 15)] = key[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t v = s_cand[w][lane];
+                __builtin_amdgcn_wave_barrier();
+                // sorting network over the 16 lanes of a row, every exchange ascending: merge of size 2, 4, 8, 16 = one "flip" (i <-> size-1-i)
+                // and then half-cleaners at distance size/4 .. 1
+#define OHR_CE(PARTNER, LOWER) { const uint32_t q_ = (uint32_t)(PARTNER); const uint32_t mn_ = q_ < v ? q_ : v, mx_ = q_ < v ? v : q_; v = (LOWER) ? mn_ : mx_; }
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, 0x1B /* quad_perm [3,2,1,0] */, 0xF, 0xF, false), (ri & 2) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false), (ri & 4) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false), (ri & 8) == 0)
+                OHR_CE(__shfl_xor((int)v, 4, 64), (ri & 4) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
+                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+#undef OHR_CE
+                const int want = few ? k1 - c_lo : 0;                         // 0 <= k1 - c_lo < c_hi - c_lo <= 16
+                const uint32_t got = (uint32_t)__shfl((int)v, (row << 4) + (want & 15), 64);
+                if (few) bhi = got;
             }
             const uint32_t v1 = bhi;
             int c1 = 0;

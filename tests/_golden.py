@@ -174,3 +174,13 @@ LONG_BARS_CUTS = [-1, 70_000, 70_100, 200_000, 200_001, 216_500, 225_000, 419_99
 
 def long_bars_amounts():
     return np.random.default_rng(4242).lognormal(-1.0, 1.2, LONG_BARS_N).astype(np.float32)
+
+
+def nan_tie_longbar():
+    """-> (prices, amounts float32, close_idx, sides, the oracle's 14 order-flow columns) of tests/golden/nan_tie_longbar.npz"""
+    d = load("nan_tie_longbar")
+    px = np.maximum(100.0 + 0.05 * np.cumsum(d["steps"].astype(np.int64)), 0.05)
+    units = d["units"].astype(np.int64)
+    am = (units * 2.0 ** -10).astype(np.float32)
+    am[units == 0] = np.nan
+    return px, am, d["close_idx"], d["sides"], tuple(d[f"want_{k}"] for k in DIR_KEYS)

@@ -245,6 +245,17 @@ def test_order_flow_redo_in_tick_order(orc, monkeypatch, amounts, rows):
         np.testing.assert_array_equal(got[k], w, err_msg=f"{k} ({amounts}, rows={rows})")
 
 
+def test_order_flow_extremum_near_tie_with_nan_elsewhere_in_the_bar(orc):
+    """tools/fuzz_longbars.py seed 361, case 70 (tests/golden/nan_tie_longbar.npz, tools/gen_nan_tie_fixture.py): a 65 537-tick bar whose running
+    signed dollar sum peaks 2.7e-12 below a float32 rounding boundary at tick 488 and holds a NaN amount at tick 554.  The NaN made the
+    error bound of the tie test NaN (it contains the bar's dollar total), `distance <= NaN` said "not near", and the bar kept the
+    parallel order's last bit: cum_dollars_max 6534.9214 against the reference's 6534.921.  An undefined bound now means redo."""
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    px, am, ci, sd, want = G.nan_tie_longbar()
+    got = comp_bar_directional_features(px, am, ci, sd)
+    _check_dir(got, want, "nan_tie_longbar")
+
+
 @pytest.mark.parametrize("amounts", ["dyadic", "dyadic_heavy", "lognormal32", "f64_dyadic", "f64", "negative", "nan", "zeros",
                                      "quantum_changes"])
 def test_footprints_long_bars_workgroup_per_bar(orc, amounts):

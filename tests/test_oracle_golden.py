@@ -376,3 +376,12 @@ def test_oracle_on_long_bars_against_reference_vectors(orc):
     t32 = dict(zip(G.TS_KEYS, orc.comp_bar_trade_size_features(am, theta, ci, 5.0)))
     nd = G.check_f32_amount_vectors(d, "lb_", n, "lb_close_indices", o, dd, (np.diff(off), flat, bar), t32, what="oracle long bars")
     assert nd <= 2
+
+
+def test_oracle_order_flow_near_tie_bar_with_a_nan_against_reference_vectors(orc):
+    """tests/golden/nan_tie_longbar.npz (tools/gen_nan_tie_fixture.py): the reference's own order-flow columns of a 65 537-tick bar whose
+    running dollar sum peaks 2.7e-12 below a float32 rounding boundary, with a NaN size later in the bar."""
+    px, am, ci, sd, want = G.nan_tie_longbar()
+    got = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    for k, g, w in zip(G.DIR_KEYS, got, want):
+        np.testing.assert_array_equal(g, w, err_msg=k)
