@@ -1023,53 +1023,47 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
 // ---------------------------------------------------------------------------------------------------------------------
 #define OHR_WAVES 4
 #define OHR_CAND 16                     // keys left in the median bracket when the row sorts them (k_bar_ohlcv_rows)
-template <bool MEDIAN>
-__global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double *__restrict__ price, const float *__restrict__ amount,
-                                                                 const int64_t *__restrict__ ci, int64_t nb, int64_t n,
-                                                                 int *__restrict__ saw_long, OhlcvOut o)
+// The body of k_bar_ohlcv_rows for a wave whose longest bar takes NR registers per lane (NR * 16 >= its ticks): every loop over the
+// registers has a compile-time trip count.  With one body for all lengths (loops to 16 guarded by the wave's register count) the kernel
+// issued 1 341 VALU instructions per four 80-tick bars, 490 without the median, and is bound by exactly that (rocprofv3 SQ counters:
+// 4.19e9 VALU instructions x 4 cycles / 1 024 SIMDs = the 6.5 ms it took; profiles/r04_short_bars.txt).
+template <bool MEDIAN, int NR>
+__device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const float *__restrict__ amount, int64_t s_b, int L, bool mine,
+                                         int64_t b, int row, int ri, int lane, int w, uint32_t (*s_cand)[64], const OhlcvOut &o, int nreg)
 {
     typedef MedKey<false> MK;
-    __shared__ uint32_t s_cand[OHR_WAVES][64];
-    const int lane = fmk_lane();
-    const int w = fmk_uniform((int)(threadIdx.x >> 6));
-    const int row = lane >> 4, ri = lane & 15;
-    const int64_t niter = (nb + 3) >> 2;
-    const int64_t nwaves = (int64_t)gridDim.x * OHR_WAVES;
-    for (int64_t it = (int64_t)blockIdx.x * OHR_WAVES + w; it < niter; it += nwaves) {
-        const int64_t b = 4 * it + row;
-        const bool have = b < nb;
-        const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
-        const int64_t len_b = e_b - s_b;
-        const bool is_long = have && len_b > 256;
-        if (__ballot(is_long) != 0 && lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool mine = have && len_b >= 1 && len_b <= 256;
-        if (have && len_b <= 0 && ri == 0) ohlcv_empty(o, b, price, e_b, n);          // base.py:352-361
-        if (__ballot(mine) == 0) continue;
-        const int L = mine ? (int)len_b : 0;
-        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + 15) >> 4;               // wave-uniform
+#define OHR_LIVE(r_) (NR < 16 || (r_) < nreg)      /* NR == 16: the generic body, loops guarded by the wave's register count */
         const double *pb = price + (mine ? s_b + 1 : 0);
         const uint32_t *ab = (const uint32_t *)amount + (mine ? s_b + 1 : 0);
         // ---- every load of the four bars
-        double p[16];
-        uint32_t araw[16];
+        double p[NR];
+        uint32_t araw[NR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NR; ++r) {
             p[r] = 0.0; araw[r] = 0u;
-            if (r < nreg) {
+            if (OHR_LIVE(r)) {
                 const int i = r * 16 + ri;
                 if (i < L) { p[r] = pb[i]; araw[r] = ab[i]; }
             }
         }
         const double first = mine ? pb[0] : 0.0, lastp = mine ? pb[L - 1] : 0.0;      // (lines fetched anyway)
+        // (without the median the sizes are only used as doubles, and the compiler sinks the conversion into each register's guarded load
+        //  block: load, wait, convert, sixteen times -- 4.4 against 3.0 ms at 80-tick bars.  Each raw word is pinned where it is used, in
+        //  the accumulation loop behind the last load, so every load is in flight before the first wait.  With the median the pins
+        //  stand together right here -- all loads complete, then all arithmetic: 4.56 against 5.32 ms at 80-tick bars, measured)
+        if constexpr (MEDIAN) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(araw[r]));
+        }
         // ---- accumulation: virtual lane v = 16 * (r % 4) + ri, chunk r / 4
         double hi = -INFINITY, lo = INFINITY, tv[4] = {0.0, 0.0, 0.0, 0.0}, td[4] = {0.0, 0.0, 0.0, 0.0};
-        uint32_t key[MEDIAN ? 16 : 1];
+        uint32_t key[MEDIAN ? NR : 1];
         uint32_t kmn = MK::MAXK, kmx = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r < nreg) {
+        for (int r = 0; r < NR; ++r) {
+            if (OHR_LIVE(r)) {
                 const bool valid = r * 16 + ri < L;
+                if constexpr (!MEDIAN) asm volatile("" : "+v"(araw[r]));
                 const double a = (double)__uint_as_float(araw[r]);
                 hi = valid ? fmax(hi, p[r]) : hi;
                 lo = valid ? fmin(lo, p[r]) : lo;
@@ -1105,8 +1099,8 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
                     // smallest and largest key actually inside (the counts at both ends stay what they are); all equal: done
                     uint32_t mn_in = MK::MAXK, mx_in = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (r < nreg) {
+                    for (int r = 0; r < NR; ++r)
+                        if (OHR_LIVE(r)) {
                             const bool in = key[r] > blo && key[r] <= bhi;
                             mn_in = (in && key[r] < mn_in) ? key[r] : mn_in;
                             mx_in = (in && key[r] > mx_in) ? key[r] : mx_in;
@@ -1119,20 +1113,22 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
                 const uint32_t pivot = blo + ((bhi - blo) >> 1);
                 int c = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r < nreg) c += key[r] <= pivot ? 1 : 0;
+                for (int r = 0; r < NR; ++r)
+                    if (OHR_LIVE(r)) c += key[r] <= pivot ? 1 : 0;
                 c = fmk_row_sum(c);
                 if (open) { if (c > k1) { bhi = pivot; c_hi = c; } else { blo = pivot; c_lo = c; } }
             }
             const bool few = L > 0 && bhi - blo > 1;                         // <= OHR_CAND keys left in (blo, bhi]
+            const uint32_t bhi_in = bhi;                                     // (count(key <= bhi_in) == c_hi)
+            uint32_t v2_sorted = 0;
             if (__ballot(few) != 0) {
                 // The bisection on the key VALUE used to run until ONE key was left: ~22 steps of ~25 instructions for the 80 keys of a
                 // bar whose sizes span twelve binades.  Now it stops at <= 16 candidates (~6 steps); the row packs them into its sixteen
                 // lanes through LDS and sorts them with a ten-step network on the DPP data path; rank k1 - c_lo of the sorted row is v1.
                 int mcnt = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r < nreg) mcnt += (key[r] > blo && key[r] <= bhi) ? 1 : 0;
+                for (int r = 0; r < NR; ++r)
+                    if (OHR_LIVE(r)) mcnt += (key[r] > blo && key[r] <= bhi) ? 1 : 0;
                 int pos = mcnt;
                 pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(1), 0xF>(0, pos);
                 pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(2), 0xF>(0, pos);
@@ -1143,8 +1139,8 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
                 __builtin_amdgcn_wave_barrier();
                 if (few) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (r < nreg && key[r] > blo && key[r] <= bhi) s_cand[w][(row << 4) + (pos++ & 15)] = key[r];
+                    for (int r = 0; r < NR; ++r)
+                        if (OHR_LIVE(r) && key[r] > blo && key[r] <= bhi) s_cand[w][(row << 4) + (pos++ & 15)] = key[r];
                 }
                 __builtin_amdgcn_wave_barrier();
                 uint32_t v = s_cand[w][lane];
@@ -1165,19 +1161,24 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
 #undef OHR_CE
                 const int want = few ? k1 - c_lo : 0;                         // 0 <= k1 - c_lo < c_hi - c_lo <= 16
                 const uint32_t got = (uint32_t)__shfl((int)v, (row << 4) + (want & 15), 64);
+                v2_sorted = (uint32_t)__shfl((int)v, (row << 4) + ((want + 1) & 15), 64);      // rank k1 + 1, used when it is inside the bracket
                 if (few) bhi = got;
             }
             const uint32_t v1 = bhi;
-            int c1 = 0;
-            uint32_t nxt = MK::MAXK;
+            // rank k2 (= k1 or k1 + 1): inside the bracket it is the sorted row's next entry (or the same tied key); only when k1 was
+            // the bracket's LAST rank is it the smallest key above the bracket -- a scan over the registers, taken by the whole wave
+            // when one of its four bars needs it
+            uint32_t v2 = v1;
+            const bool beyond = L > 0 && k2 != k1 && k2 >= c_hi;
+            if (L > 0 && k2 != k1 && !beyond && few) v2 = v2_sorted;
+            if (__ballot(beyond) != 0) {
+                uint32_t nxt = MK::MAXK;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                c1 += key[r] <= v1 ? 1 : 0;
-                nxt = (key[r] > v1 && key[r] < nxt) ? key[r] : nxt;
+                for (int r = 0; r < NR; ++r)
+                    if (OHR_LIVE(r)) nxt = (key[r] > bhi_in && key[r] < nxt) ? key[r] : nxt;
+                nxt = fmk_row_umin(nxt);
+                if (beyond) v2 = nxt;
             }
-            c1 = fmk_row_sum(c1);
-            nxt = fmk_row_umin(nxt);
-            const uint32_t v2 = (c1 > k2 || k2 == k1) ? v1 : nxt;
             if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
             else med = (L & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;
         }
@@ -1191,6 +1192,43 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
             o.trades[b] = L;
             if constexpr (MEDIAN) o.median[b] = med;
         }
+#undef OHR_LIVE
+}
+
+template <bool MEDIAN>
+__global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double *__restrict__ price, const float *__restrict__ amount,
+                                                                 const int64_t *__restrict__ ci, int64_t nb, int64_t n,
+                                                                 int *__restrict__ saw_long, OhlcvOut o)
+{
+    typedef MedKey<false> MK;
+    __shared__ uint32_t s_cand[OHR_WAVES][64];
+    const int lane = fmk_lane();
+    const int w = fmk_uniform((int)(threadIdx.x >> 6));
+    const int row = lane >> 4, ri = lane & 15;
+    const int64_t niter = (nb + 3) >> 2;
+    const int64_t nwaves = (int64_t)gridDim.x * OHR_WAVES;
+    for (int64_t it = (int64_t)blockIdx.x * OHR_WAVES + w; it < niter; it += nwaves) {
+        const int64_t b = 4 * it + row;
+        const bool have = b < nb;
+        const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
+        const int64_t len_b = e_b - s_b;
+        const bool is_long = have && len_b > 256;
+        if (__ballot(is_long) != 0 && lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = have && len_b >= 1 && len_b <= 256;
+        if (have && len_b <= 0 && ri == 0) ohlcv_empty(o, b, price, e_b, n);          // base.py:352-361
+        if (__ballot(mine) == 0) continue;
+        const int L = mine ? (int)len_b : 0;
+        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + 15) >> 4;               // wave-uniform
+        // ---- the body specialised for the register count of the wave's longest bar
+        // (without the median the one generic body is the faster kernel -- 3.0 against 4.2 ms at 80-tick bars with nine bodies: the reducer alone
+        //  is not bound by VALU issue, and the code of nine bodies does not stay in the instruction cache)
+        if constexpr (MEDIAN) {
+#define OHR_CASE(NR_) if (nreg <= NR_) { ohr_bars<MEDIAN, NR_>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg); continue; }
+            OHR_CASE(4) OHR_CASE(5) OHR_CASE(6) OHR_CASE(7) OHR_CASE(8) OHR_CASE(10) OHR_CASE(12)
+#undef OHR_CASE
+        }
+        ohr_bars<MEDIAN, 16>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg);
     }
 }
 
@@ -1661,7 +1699,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     const char *rv = getenv("FMK_OHLCV_ROWS");            // developer knob: 0 = without the sixteen-lanes-per-bar schedule
     const int rows_on = rv ? atoi(rv) : 1;
     static int rows_min = -1;                // FMK_OHLCV_ROWS_MIN_MEAN: mean ticks per bar from which rows replace the lane schedule
-    if (rows_min < 0) { const char *v = getenv("FMK_OHLCV_ROWS_MIN_MEAN"); rows_min = v ? atoi(v) : 65; }
+    if (rows_min < 0) { const char *v = getenv("FMK_OHLCV_ROWS_MIN_MEAN"); rows_min = v ? atoi(v) : 57; }
     if (!AF64 && nb >= 64 && n / nb <= packed_max && !(rows_on && n / nb >= rows_min)) {
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
