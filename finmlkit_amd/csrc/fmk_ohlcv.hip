@@ -1027,11 +1027,67 @@ __global__ __launch_bounds__(128) void k_bar_ohlcv_lanes(const double *__restric
 // registers has a compile-time trip count.  With one body for all lengths (loops to 16 guarded by the wave's register count) the kernel
 // issued 1 341 VALU instructions per four 80-tick bars, 490 without the median, and is bound by exactly that (rocprofv3 SQ counters:
 // 4.19e9 VALU instructions x 4 cycles / 1 024 SIMDs = the 6.5 ms it took; profiles/r04_short_bars.txt).
-template <bool MEDIAN, int NR>
+// LPB lanes per bar: 16 (a DPP row, four bars per wave, <= 256 ticks) or 8 (a half row, eight bars per wave, <= 128 ticks: streams of 33 .. 46
+// ticks per bar, where a row leaves half its lanes idle and the lane-per-bar schedule pays a 64-key network per bar).  The sums keep the
+// association of every other schedule in both layouts: element i belongs to virtual lane i % 64 = LPB * (r % NA) + ri with NA = 64 / LPB
+// accumulators per lane, added in chunk order; the tree over the virtual lanes is the butterfly inside the LPB lanes, then the balanced
+// tree over the NA partial sums.
+template <int LPB> __device__ __forceinline__ double ohr_sum(double v)
+{
+    v += fmk_dpp<DPP_XOR1, 0xF>(v, v);
+    v += fmk_dpp<DPP_XOR2, 0xF>(v, v);
+    if constexpr (LPB >= 8) v += fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v);
+    if constexpr (LPB == 16) v += fmk_dpp<DPP_MIRROR, 0xF>(v, v);
+    return v;
+}
+template <int LPB> __device__ __forceinline__ double ohr_max(double v)
+{
+    v = fmax(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmax(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    if constexpr (LPB >= 8) v = fmax(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    if constexpr (LPB == 16) v = fmax(v, fmk_dpp<DPP_MIRROR, 0xF>(v, v));
+    return v;
+}
+template <int LPB> __device__ __forceinline__ double ohr_min(double v)
+{
+    v = fmin(v, fmk_dpp<DPP_XOR1, 0xF>(v, v));
+    v = fmin(v, fmk_dpp<DPP_XOR2, 0xF>(v, v));
+    if constexpr (LPB >= 8) v = fmin(v, fmk_dpp<DPP_HALF_MIRROR, 0xF>(v, v));
+    if constexpr (LPB == 16) v = fmin(v, fmk_dpp<DPP_MIRROR, 0xF>(v, v));
+    return v;
+}
+template <int LPB> __device__ __forceinline__ int ohr_isum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, DPP_XOR2, 0xF, 0xF, false);
+    if constexpr (LPB >= 8) v += __builtin_amdgcn_update_dpp(v, v, DPP_HALF_MIRROR, 0xF, 0xF, false);
+    if constexpr (LPB == 16) v += __builtin_amdgcn_update_dpp(v, v, DPP_MIRROR, 0xF, 0xF, false);
+    return v;
+}
+template <int LPB> __device__ __forceinline__ uint32_t ohr_umin(uint32_t v)
+{
+    uint32_t q;
+    q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = q < v ? q : v;
+    q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = q < v ? q : v;
+    if constexpr (LPB >= 8) { q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = q < v ? q : v; }
+    if constexpr (LPB == 16) { q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = q < v ? q : v; }
+    return v;
+}
+template <int LPB> __device__ __forceinline__ uint32_t ohr_umax(uint32_t v)
+{
+    uint32_t q;
+    q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false); v = q > v ? q : v;
+    q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false); v = q > v ? q : v;
+    if constexpr (LPB >= 8) { q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false); v = q > v ? q : v; }
+    if constexpr (LPB == 16) { q = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false); v = q > v ? q : v; }
+    return v;
+}
+template <bool MEDIAN, int NR, int LPB = 16>
 __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const float *__restrict__ amount, int64_t s_b, int L, bool mine,
                                          int64_t b, int row, int ri, int lane, int w, uint32_t (*s_cand)[64], const OhlcvOut &o, int nreg)
 {
     typedef MedKey<false> MK;
+    constexpr int NA = 64 / LPB;                  // accumulators per lane = virtual lanes per lane
 #define OHR_LIVE(r_) (NR < 16 || (r_) < nreg)      /* NR == 16: the generic body, loops guarded by the wave's register count */
         const double *pb = price + (mine ? s_b + 1 : 0);
         const uint32_t *ab = (const uint32_t *)amount + (mine ? s_b + 1 : 0);
@@ -1042,7 +1098,7 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
         for (int r = 0; r < NR; ++r) {
             p[r] = 0.0; araw[r] = 0u;
             if (OHR_LIVE(r)) {
-                const int i = r * 16 + ri;
+                const int i = r * LPB + ri;
                 if (i < L) { p[r] = pb[i]; araw[r] = ab[i]; }
             }
         }
@@ -1055,20 +1111,22 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
 #pragma unroll
             for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(araw[r]));
         }
-        // ---- accumulation: virtual lane v = 16 * (r % 4) + ri, chunk r / 4
-        double hi = -INFINITY, lo = INFINITY, tv[4] = {0.0, 0.0, 0.0, 0.0}, td[4] = {0.0, 0.0, 0.0, 0.0};
+        // ---- accumulation: virtual lane v = LPB * (r % NA) + ri, chunk r / NA
+        double hi = -INFINITY, lo = INFINITY, tv[NA], td[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) { tv[k] = 0.0; td[k] = 0.0; }
         uint32_t key[MEDIAN ? NR : 1];
         uint32_t kmn = MK::MAXK, kmx = 0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (OHR_LIVE(r)) {
-                const bool valid = r * 16 + ri < L;
+                const bool valid = r * LPB + ri < L;
                 if constexpr (!MEDIAN) asm volatile("" : "+v"(araw[r]));
                 const double a = (double)__uint_as_float(araw[r]);
                 hi = valid ? fmax(hi, p[r]) : hi;
                 lo = valid ? fmin(lo, p[r]) : lo;
-                tv[r & 3] += valid ? a : 0.0;
-                td[r & 3] += valid ? p[r] * a : 0.0;
+                tv[r % NA] += valid ? a : 0.0;
+                td[r % NA] += valid ? p[r] * a : 0.0;
                 if constexpr (MEDIAN) {
                     key[r] = valid ? MK::tokey(araw[r]) : MK::MAXK;
                     kmn = key[r] < kmn ? key[r] : kmn;
@@ -1076,22 +1134,29 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
                 }
             } else if constexpr (MEDIAN) key[r] = MK::MAXK;
         }
-        hi = fmk_row_max(hi);
-        lo = fmk_row_min(lo);
-        double T[4], D[4];
+        hi = ohr_max<LPB>(hi);
+        lo = ohr_min<LPB>(lo);
+        double T[NA], D[NA];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { T[k] = fmk_row_sum(tv[k]); D[k] = fmk_row_sum(td[k]); }
-        const double tvs = (T[0] + T[1]) + (T[2] + T[3]), tds = (D[0] + D[1]) + (D[2] + D[3]);
+        for (int k = 0; k < NA; ++k) { T[k] = ohr_sum<LPB>(tv[k]); D[k] = ohr_sum<LPB>(td[k]); }
+        double tvs, tds;
+        {                                                                // the balanced tree over the NA partial sums
+#pragma unroll
+            for (int h = 1; h < NA; h <<= 1)
+#pragma unroll
+                for (int k = 0; k < NA; k += 2 * h) { T[k] += T[k + h]; D[k] += D[k + h]; }
+            tvs = T[0]; tds = D[0];
+        }
         double med = 0.0;
         if constexpr (MEDIAN) {
-            kmn = fmk_row_umin(kmn);
-            kmx = fmk_row_umax(kmx);
+            kmn = ohr_umin<LPB>(kmn);
+            kmx = ohr_umax<LPB>(kmx);
             const int k1 = (L - 1) >> 1, k2 = L >> 1;
             // smallest v with count(key <= v) > k1: invariant c_lo = count(<= lo) <= k1 < count(<= hi) = c_hi
             uint32_t blo = kmn - 1, bhi = kmx;
             int c_lo = 0, c_hi = L;
             for (int step = 0; step < 40; ++step) {
-                const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > OHR_CAND;
+                const bool open = L > 0 && bhi - blo > 1 && c_hi - c_lo > LPB;
                 if (__ballot(open) == 0) break;
                 if (step == 10 || step == 15 || step == 20) {
                     // still open after ~log2(L) + 3 halvings: the target key is TIED (decimal lot sizes) and the count never falls to
@@ -1105,8 +1170,8 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
                             mn_in = (in && key[r] < mn_in) ? key[r] : mn_in;
                             mx_in = (in && key[r] > mx_in) ? key[r] : mx_in;
                         }
-                    mn_in = fmk_row_umin(mn_in);
-                    mx_in = fmk_row_umax(mx_in);
+                    mn_in = ohr_umin<LPB>(mn_in);
+                    mx_in = ohr_umax<LPB>(mx_in);
                     if (open) { bhi = mx_in; blo = (mn_in == mx_in ? mx_in : mn_in) - 1; }
                     continue;
                 }
@@ -1115,10 +1180,10 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
                     if (OHR_LIVE(r)) c += key[r] <= pivot ? 1 : 0;
-                c = fmk_row_sum(c);
+                c = ohr_isum<LPB>(c);
                 if (open) { if (c > k1) { bhi = pivot; c_hi = c; } else { blo = pivot; c_lo = c; } }
             }
-            const bool few = L > 0 && bhi - blo > 1;                         // <= OHR_CAND keys left in (blo, bhi]
+            const bool few = L > 0 && bhi - blo > 1;                         // <= LPB keys left in (blo, bhi]
             const uint32_t bhi_in = bhi;                                     // (count(key <= bhi_in) == c_hi)
             uint32_t v2_sorted = 0;
             if (__ballot(few) != 0) {
@@ -1130,17 +1195,24 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
                 for (int r = 0; r < NR; ++r)
                     if (OHR_LIVE(r)) mcnt += (key[r] > blo && key[r] <= bhi) ? 1 : 0;
                 int pos = mcnt;
-                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(1), 0xF>(0, pos);
-                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(2), 0xF>(0, pos);
-                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(4), 0xF>(0, pos);
-                pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(8), 0xF>(0, pos);
+                if constexpr (LPB == 16) {
+                    pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(1), 0xF>(0, pos);
+                    pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(2), 0xF>(0, pos);
+                    pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(4), 0xF>(0, pos);
+                    pos += fmk_dpp_i32<FMK_DPP_ROW_SHR(8), 0xF>(0, pos);
+                } else {                                                      // (a source lane in the other half row contributes nothing)
+                    int t_;
+                    t_ = fmk_dpp_i32<FMK_DPP_ROW_SHR(1), 0xF>(0, pos); pos += ri >= 1 ? t_ : 0;
+                    t_ = fmk_dpp_i32<FMK_DPP_ROW_SHR(2), 0xF>(0, pos); pos += ri >= 2 ? t_ : 0;
+                    if constexpr (LPB == 8) { t_ = fmk_dpp_i32<FMK_DPP_ROW_SHR(4), 0xF>(0, pos); pos += ri >= 4 ? t_ : 0; }
+                }
                 pos -= mcnt;                                                  // keys of the row's lower lanes that are in the bracket
                 s_cand[w][lane] = MK::MAXK;
                 __builtin_amdgcn_wave_barrier();
                 if (few) {
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
-                        if (OHR_LIVE(r) && key[r] > blo && key[r] <= bhi) s_cand[w][(row << 4) + (pos++ & 15)] = key[r];
+                        if (OHR_LIVE(r) && key[r] > blo && key[r] <= bhi) s_cand[w][row * LPB + (pos++ & (LPB - 1))] = key[r];
                 }
                 __builtin_amdgcn_wave_barrier();
                 uint32_t v = s_cand[w][lane];
@@ -1151,17 +1223,21 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
                 OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
                 OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, 0x1B /* quad_perm [3,2,1,0] */, 0xF, 0xF, false), (ri & 2) == 0)
                 OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false), (ri & 4) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false), (ri & 8) == 0)
-                OHR_CE(__shfl_xor((int)v, 4, 64), (ri & 4) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
-                OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                if constexpr (LPB >= 8) {
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_HALF_MIRROR, 0xF, 0xF, false), (ri & 4) == 0)
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                }
+                if constexpr (LPB == 16) {
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_MIRROR, 0xF, 0xF, false), (ri & 8) == 0)
+                    OHR_CE(__shfl_xor((int)v, 4, 64), (ri & 4) == 0)
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR2, 0xF, 0xF, false), (ri & 2) == 0)
+                    OHR_CE(__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_XOR1, 0xF, 0xF, false), (ri & 1) == 0)
+                }
 #undef OHR_CE
-                const int want = few ? k1 - c_lo : 0;                         // 0 <= k1 - c_lo < c_hi - c_lo <= 16
-                const uint32_t got = (uint32_t)__shfl((int)v, (row << 4) + (want & 15), 64);
-                v2_sorted = (uint32_t)__shfl((int)v, (row << 4) + ((want + 1) & 15), 64);      // rank k1 + 1, used when it is inside the bracket
+                const int want = few ? k1 - c_lo : 0;                         // 0 <= k1 - c_lo < c_hi - c_lo <= LPB
+                const uint32_t got = (uint32_t)__shfl((int)v, row * LPB + (want & (LPB - 1)), 64);
+                v2_sorted = (uint32_t)__shfl((int)v, row * LPB + ((want + 1) & (LPB - 1)), 64);      // rank k1 + 1, used when it is inside the bracket
                 if (few) bhi = got;
             }
             const uint32_t v1 = bhi;
@@ -1176,7 +1252,7 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
                     if (OHR_LIVE(r)) nxt = (key[r] > bhi_in && key[r] < nxt) ? key[r] : nxt;
-                nxt = fmk_row_umin(nxt);
+                nxt = ohr_umin<LPB>(nxt);
                 if (beyond) v2 = nxt;
             }
             if (kmn < MK::KEY_NEG_INF || kmx > MK::KEY_POS_INF) med = NAN;   // a NaN amount: np.median is NaN
@@ -1195,7 +1271,7 @@ __device__ __forceinline__ void ohr_bars(const double *__restrict__ price, const
 #undef OHR_LIVE
 }
 
-template <bool MEDIAN>
+template <bool MEDIAN, int LPB = 16>
 __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double *__restrict__ price, const float *__restrict__ amount,
                                                                  const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                                  int *__restrict__ saw_long, OhlcvOut o)
@@ -1204,31 +1280,32 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
     __shared__ uint32_t s_cand[OHR_WAVES][64];
     const int lane = fmk_lane();
     const int w = fmk_uniform((int)(threadIdx.x >> 6));
-    const int row = lane >> 4, ri = lane & 15;
-    const int64_t niter = (nb + 3) >> 2;
+    const int row = lane / LPB, ri = lane % LPB;
+    constexpr int BPW = 64 / LPB, LMAX = 16 * LPB;      // bars per wave, longest bar served
+    const int64_t niter = (nb + BPW - 1) / BPW;
     const int64_t nwaves = (int64_t)gridDim.x * OHR_WAVES;
     for (int64_t it = (int64_t)blockIdx.x * OHR_WAVES + w; it < niter; it += nwaves) {
-        const int64_t b = 4 * it + row;
+        const int64_t b = BPW * it + row;
         const bool have = b < nb;
         const int64_t s_b = have ? ci[b] : 0, e_b = have ? ci[b + 1] : 0;
         const int64_t len_b = e_b - s_b;
-        const bool is_long = have && len_b > 256;
+        const bool is_long = have && len_b > LMAX;
         if (__ballot(is_long) != 0 && lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool mine = have && len_b >= 1 && len_b <= 256;
+        const bool mine = have && len_b >= 1 && len_b <= LMAX;
         if (have && len_b <= 0 && ri == 0) ohlcv_empty(o, b, price, e_b, n);          // base.py:352-361
         if (__ballot(mine) == 0) continue;
         const int L = mine ? (int)len_b : 0;
-        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + 15) >> 4;               // wave-uniform
+        const int nreg = (fmk_dpp_reduce(L, 0, FmkOpMax()) + LPB - 1) / LPB;               // wave-uniform
         // ---- the body specialised for the register count of the wave's longest bar
         // (without the median the one generic body is the faster kernel -- 3.0 against 4.2 ms at 80-tick bars with nine bodies: the reducer alone
         //  is not bound by VALU issue, and the code of nine bodies does not stay in the instruction cache)
         if constexpr (MEDIAN) {
-#define OHR_CASE(NR_) if (nreg <= NR_) { ohr_bars<MEDIAN, NR_>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg); continue; }
+#define OHR_CASE(NR_) if (nreg <= NR_) { ohr_bars<MEDIAN, NR_, LPB>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg); continue; }
             OHR_CASE(4) OHR_CASE(5) OHR_CASE(6) OHR_CASE(7) OHR_CASE(8) OHR_CASE(10) OHR_CASE(12)
 #undef OHR_CASE
         }
-        ohr_bars<MEDIAN, 16>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg);
+        ohr_bars<MEDIAN, 16, LPB>(price, amount, s_b, L, mine, b, row, ri, lane, w, s_cand, o, nreg);
     }
 }
 
@@ -1700,7 +1777,23 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     const int rows_on = rv ? atoi(rv) : 1;
     static int rows_min = -1;                // FMK_OHLCV_ROWS_MIN_MEAN: mean ticks per bar from which rows replace the lane schedule
     if (rows_min < 0) { const char *v = getenv("FMK_OHLCV_ROWS_MIN_MEAN"); rows_min = v ? atoi(v) : 57; }
-    if (!AF64 && nb >= 64 && n / nb <= packed_max && !(rows_on && n / nb >= rows_min)) {
+    // With the median: eight lanes per bar (bars of <= 128 ticks) serve streams of 33 .. 63 ticks per bar (FMK_OHLCV_HALF_MIN_MEAN, 0 = off),
+    // sixteen lanes per bar from 64 (profiles/r04_short_bars.txt: 5.8 / 5.3 / 4.9 / 4.3 ms at 34 / 40 / 46 / 60 ticks against the lane
+    // schedule's 7.0 / 6.6 / 7.0 / 8.9; the half rows are ahead of the rows up to ~100 ticks on equal bars, but a stream's longer bars
+    // -- twice its mean -- must still fit the schedule: 63 x 2 <= 128).  Without the median the lane schedule stays ahead up to 56.
+    // (Four lanes per bar, sixteen bars per wave, was measured too: 6.9 / 6.2 / 5.4 ms at 20 / 26 / 34 ticks -- behind; not dispatched.)
+    static int half_min = -1;
+    if (half_min < 0) { const char *v = getenv("FMK_OHLCV_HALF_MIN_MEAN"); half_min = v ? atoi(v) : 33; }
+    const int64_t rows_from = (o.median && !getenv("FMK_OHLCV_ROWS_MIN_MEAN")) ? 64 : rows_min;
+    if (!AF64 && rows_on && o.median && half_min > 0 && nb >= 64 && n / nb >= half_min && n / nb < rows_from) {
+        if constexpr (!AF64) {
+            int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 8), OHR_WAVES);
+            const int64_t cap = (int64_t)ctx->n_cu * 32;
+            if (blocks > cap) blocks = cap;
+            k_bar_ohlcv_rows<true, 8><<<(unsigned)blocks, 64 * OHR_WAVES, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
+        }
+        long_min = 128;
+    } else if (!AF64 && nb >= 64 && n / nb <= packed_max && !(rows_on && n / nb >= rows_from)) {
         int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 64), 2);
         const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
