@@ -317,12 +317,9 @@ def choose_placement(ctx, trades, args, rank, n, step_of):
         ms.append(_probe_step_kernel_ms(ctx, fn, 8))
     best = min(range(len(ms)), key=lambda i: ms[i])
     chosen = copies[best]
-    if best != 0:
-        for col in getattr(trades, "_backing", []):
-            col.free()
-    else:
-        slab.free()
-    chosen._placement_slab = slab                       # (the slab lives as long as the columns carved out of it)
+    # Nothing is freed: releasing the 120 GiB slab after the probes moved the level of the OTHER allocation from 2.135 to 2.19 ms in one run
+    # (profiles/r04_sharded_step.txt) -- the state the probes saw is the state the run keeps.  (~150 GB of 288 held; the extras need < 40.)
+    chosen._placement_keep = (slab, trades)
     del copies
     fn = step_of(chosen)
     settle = [_probe_step_kernel_ms(ctx, fn, 5)]
@@ -479,6 +476,15 @@ def run(args):
             state["idx"] = DeviceArray(ctx, cap, np.int64)
             state["out"] = trades.alloc_ohlcv(cap, want_median)
 
+    if use_dist:
+        # Before the placement probes: everything a sharded run allocates later -- RCCL's point-to-point channels (built by the first
+        # exchange), the plan's index / output / boundary buffers -- is allocated once now.  Measured without this: the columns probed
+        # at 2.13 ms and ran at 2.31 ms in the sharded step after those allocations (profiles/r04_sharded_step.txt).
+        from finmlkit_amd.dist import ShardedTimeBars as _STB
+        _pre = _STB(trades, rank, world, args.interval, want_median, self_loop=(world == 1)).setup(comm)
+        _pre.step(comm)
+        ctx.sync()
+        comm.sync()
     # (as many of the requested positions as fit beside 8 GiB of working memory)
     args.placements = max(1, min(args.placements, 1 + int((free - need - (8 << 30)) // placement_span(n))))
     if args.placements > 1:
