@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "fmk_common.h"
+#include <type_traits>
 
 #define DLX_MAXC 6                       // closes one replay may record before it has to be back on the closed form
 #define DLX_CONST INT64_MIN              // DlxFn.base of a constant function
@@ -203,15 +204,26 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
         __builtin_amdgcn_wave_barrier();
         constexpr int SPI = 64 / DLX_T;                              // segments per load instruction
         const int half = lane / DLX_T, j32 = lane & (DLX_T - 1);
+        // All loads of the round in flight together -- which the loop above this comment used to SAY and not do: with the product and its
+        // LDS store inside each guarded block the compiler waited for every pair of loads before it issued the next (LLWW x 16 in the
+        // ISA: sixteen memory round trips per round, and with 4 waves per SIMD that latency WAS the kernel: 3.8 ms per 1e9 ticks).
+        // Now: the raw words of all sixteen segments into registers, pinned behind the last load, then the products.
+        typedef typename std::conditional<AF64, double, float>::type DlxAmt;
+        double lp[64 / SPI];
+        DlxAmt la[64 / SPI];
 #pragma unroll
-        for (int sgm = 0; sgm < 64; sgm += SPI) {           // all loads of the round in flight together
-            const int seg = sgm + half;
+        for (int q = 0; q < 64 / SPI; ++q) {
+            const int seg = q * SPI + half;
             const int64_t p0 = s_pos[w][seg], e0 = s_end[w][seg];
             const int64_t tick = p0 + j32;
-            double v = 0.0;
-            if (p0 >= 0 && tick <= e0) v = dlx_d<AF64>(price, amount, tick);
-            rows[w][seg][j32] = v;
+            lp[q] = 0.0; la[q] = (DlxAmt)0;
+            if (p0 >= 0 && tick <= e0) { lp[q] = price[tick]; la[q] = ((const DlxAmt *)amount)[tick]; }
         }
+#pragma unroll
+        for (int q = 0; q < 64 / SPI; ++q) { asm volatile("" : "+v"(lp[q])); asm volatile("" : "+v"(la[q])); }
+#pragma unroll
+        for (int q = 0; q < 64 / SPI; ++q)
+            rows[w][q * SPI + half][j32] = lp[q] * (double)la[q];   // rounded once, like prices[i] * volumes[i] (logic.py:143): dlx_d
         __builtin_amdgcn_wave_barrier();
         int cnt = 0;
         const int o = (int)(pos & (DLX_T - 1));                     // my first tick inside the window
