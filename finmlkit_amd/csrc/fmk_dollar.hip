@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "fmk_common.h"
+#include <type_traits>
 
 struct DD { double hi, lo; };
 
@@ -122,8 +123,23 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_tile_sums(const double *__res
     bool neg = false;
     double wave_whale = 0.0;
     double d[DL_ITEMS];
+    {
+        // the sixteen loads of the thread in flight together: with the product inside the guard the compiler waited for each pair
+        // (tools/isa_loadwaits.py); the raw words are pinned behind the last load, then multiplied (rounded once: dl_d)
+        typedef typename std::conditional<AF64, double, float>::type DlAmt;
+        double lp[DL_ITEMS];
+        DlAmt la[DL_ITEMS];
 #pragma unroll
-    for (int k = 0; k < DL_ITEMS; ++k) d[k] = i0 + k * DL_THREADS < n ? dl_d<AF64>(price, amount, i0 + k * DL_THREADS) : 0.0;
+        for (int k = 0; k < DL_ITEMS; ++k) {
+            const int64_t i = i0 + k * DL_THREADS;
+            lp[k] = 0.0; la[k] = (DlAmt)0;
+            if (i < n) { lp[k] = price[i]; la[k] = ((const DlAmt *)amount)[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < DL_ITEMS; ++k) { asm volatile("" : "+v"(lp[k])); asm volatile("" : "+v"(la[k])); }
+#pragma unroll
+        for (int k = 0; k < DL_ITEMS; ++k) d[k] = lp[k] * (double)la[k];
+    }
 #pragma unroll
     for (int k = 0; k < DL_ITEMS; ++k) {
         neg |= !(d[k] >= 0.0);                       // negative or NaN increment: outside the closed form

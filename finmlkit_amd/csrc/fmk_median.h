@@ -88,10 +88,21 @@ struct MedBar {
     __device__ __forceinline__ void load_all()
     {
         if constexpr (NREG > 0) {
+            // raw words first, keys afterwards: with the key conversion inside each guarded load the compiler waits for every load
+            // before it issues the next (LW x NREG in the ISA, tools/isa_loadwaits.py) -- the words are pinned behind the last load
+            K raw[NREG];
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
-                int64_t j = (int64_t)r * 64 + lane;
-                key[r] = j < cnt ? MK::load(amount, start + j) : MK::MAXK;
+                const int64_t j = (int64_t)r * 64 + lane;
+                raw[r] = 0;
+                if (j < cnt) raw[r] = ((const K *)amount)[start + j];
+            }
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) asm volatile("" : "+v"(raw[r]));
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const int64_t j = (int64_t)r * 64 + lane;
+                key[r] = j < cnt ? MK::tokey(raw[r]) : MK::MAXK;
             }
         }
     }
