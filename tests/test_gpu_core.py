@@ -138,6 +138,13 @@ def test_context_trim_releases_cached_memory():
     free1, _ = ctx.mem_info()                # cached blocks count as free; the indexer's work buffers do not
     ctx.trim()
     free2, _ = ctx.mem_info()
+    # (the driver may report a block it has just been handed back a moment later: seen once in ~40 runs of the suite, 160 MB short)
+    import time
+    deadline = time.time() + 5.0
+    while not (free2 >= free1 and free2 >= free0 - (64 << 20)) and time.time() < deadline:
+        time.sleep(0.05)
+        ctx.sync()
+        free2, _ = ctx.mem_info()
     assert free2 >= free1 and free2 >= free0 - (64 << 20)
     np.testing.assert_array_equal(t.volume_bar_index(500.0).to_host(), ci.to_host())     # still works after a trim
 
