@@ -307,7 +307,15 @@ def choose_placement(ctx, trades, args, rank, n, step_of):
     from finmlkit_amd._ffi import DeviceArray
     k_pos = args.placements - 1
     span = placement_span(n)
-    slab = DeviceArray(ctx, k_pos * span, np.uint8)
+    slab = None
+    while k_pos > 0 and slab is None:                       # (a refused allocation is not an error here: fewer positions, or none)
+        try:
+            slab = DeviceArray(ctx, k_pos * span, np.uint8)
+        except Exception as e:                              # noqa: BLE001
+            print(f"[bench] rank {rank}: no {k_pos * span >> 30} GiB for the placement probes ({e}); trying fewer", file=sys.stderr)
+            k_pos -= 2
+    if slab is None:
+        return trades, None
     copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, k * span)) for k in range(k_pos)]
     ms = []
     for t in copies:
