@@ -106,7 +106,10 @@ int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on);
  * for the long-bar schedules; when none was -- streams of 1-minute bars and the like -- the ~36 launches that serve such bars are not
  * issued at all (they would exit at once, ~0.25 ms per call).  on = 1: the call never waits; everything is enqueued unconditionally
  * and it returns before its kernels have run -- for callers that overlap the call with other streams' work and must not block
- * (the sharded step of finmlkit_amd/dist.py between its halo exchange and its boundary bar). */
+ * (the sharded step of finmlkit_amd/dist.py between its halo exchange and its boundary bar).  One wait remains in this mode:
+ * fmk_time_bars_ohlcv_dev takes the long-bar census from its INDEX stages (~0.1 ms into the call, while its first OHLCV launch runs:
+ * the device never idles for it) instead of enqueuing the ~36 launches blindly -- 0.25 ms per sharded step (FMK_TB_PIPE_EO_CENSUS=0
+ * restores the blind enqueue).  A call whose tick array is no longer than the first kernel's reach enqueues nothing more either way. */
 int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on);
 int fmk_profile_enable(fmk_ctx *ctx, int on);
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count);
