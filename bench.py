@@ -297,8 +297,8 @@ def placement_span(n):
 def choose_placement(ctx, trades, args, rank, n, step_of):
     """WHERE the input columns lie in device memory sets the level of the dominant kernel: whole physical blocks of 16 .. 128 GiB are 8 .. 10 %
     "slow" for it, and small separate allocations land in them more often than one large one does (profiles/r04_placement_regions.txt).  So:
-    ONE slab of K x 20 GiB, the same ticks synthesised at K positions of it; every position (and the separately allocated columns the run
-    started with) is probed with the bench's own step (3 untimed + 8 timed passes, kernel time by HIP events); the fastest stays.  Then the
+    ONE slab of K x 20 GiB, the same ticks synthesised at positions of it (every 4 GiB); every position (and the separately allocated columns
+    the run started with) is probed with the bench's own step (3 untimed + 8 timed passes, kernel time by HIP events); the fastest stays.  Then the
     chosen copy is run until its level has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before; at most 40 steps):
     the first passes over new memory run up to 10 % slower than the level they settle at (profiles/r04_step_timeline.txt).  All of it is
     set-up, before the warm-up; -> (the chosen copy, {"probe_kernel_ms": [...], "chosen": k, "settle_kernel_ms": [...]})."""
@@ -316,29 +316,37 @@ def choose_placement(ctx, trades, args, rank, n, step_of):
             k_pos -= 2
     if slab is None:
         return trades, None
-    copies = [trades] + [engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, k * span)) for k in range(k_pos)]
+    # positions every 4 GiB of the slab (they overlap: the ticks are synthesised at one position, probed, then at the next; the best position
+    # is synthesised again at the end) -- the slow stretches are 16 GiB and more wide and begin at any multiple of 16 GiB from the slab's start,
+    # so a 20 GiB set of columns that must avoid them needs a finer grid than its own length
+    stride = 4 << 30
+    offsets = list(range(0, k_pos * span - span + 1, stride))
     ms = []
-    for t in copies:
+    fn = step_of(trades)
+    for _ in range(3):
+        fn()
+    ms.append(_probe_step_kernel_ms(ctx, fn, 8))
+    for off in offsets:
+        t = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, off))
         fn = step_of(t)
         for _ in range(3):
             fn()
         ms.append(_probe_step_kernel_ms(ctx, fn, 8))
     best = min(range(len(ms)), key=lambda i: ms[i])
-    chosen = copies[best]
+    chosen = trades if best == 0 else engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, offsets[best - 1]))
     # Nothing is freed: releasing the 120 GiB slab after the probes moved the level of the OTHER allocation from 2.135 to 2.19 ms in one run
     # (profiles/r04_sharded_step.txt) -- the state the probes saw is the state the run keeps.  (~150 GB of 288 held; the extras need < 40.)
     chosen._placement_keep = (slab, trades)
-    del copies
     fn = step_of(chosen)
     settle = [_probe_step_kernel_ms(ctx, fn, 5)]
     while len(settle) < 8:
         settle.append(_probe_step_kernel_ms(ctx, fn, 5))
         if settle[-1] > settle[-2] * 0.995:
             break
-    info = {"policy": f"the columns as first allocated (probe 0) and at {k_pos} positions of one {k_pos * span >> 30} GiB allocation, each probed by "
-                      "8 steps of the step's dominant kernel; the fastest stays and is run until its level settles (set-up, before the "
-                      "warm-up)",
-            "probe_kernel_ms": ms, "chosen": best, "settle_kernel_ms": settle}
+    info = {"policy": f"the columns as first allocated (probe 0) and at {len(offsets)} positions, every 4 GiB, of one {k_pos * span >> 30} GiB "
+                      "allocation, each probed by 8 steps of the step's dominant kernel; the fastest stays and is run until its level settles "
+                      "(set-up, before the warm-up)",
+            "probe_kernel_ms": ms, "probe_offset_gib": [None] + [o >> 30 for o in offsets], "chosen": best, "settle_kernel_ms": settle}
     return chosen, info
 
 
