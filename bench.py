@@ -73,9 +73,9 @@ def parse():
                          "multi-GPU path measured on one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
     ap.add_argument("--placements", type=int, default=7,
-                    help="probe the input columns at this many places of device memory (as first allocated + N-1 positions of one large "
-                         "allocation) with a few steps each and run the timed region on the fastest; roofline.frac_min / frac_max report "
-                         "the spread (1: no choice)")
+                    help="size of the placement probe: the input columns as first allocated + every 4 GiB of ONE allocation that would hold "
+                         "N-1 copies of them (7: 120 GiB, 26 positions), each probed with a few steps; the timed region runs on the fastest; "
+                         "roofline.frac_min / frac_max report the spread (1: no choice)")
     ap.add_argument("--separate-index", action="store_true",
                     help="the step as two library calls (time-bar indexer kernels, then OHLCV + median) instead of the one-launch "
                          "fmk_time_bars_ohlcv_dev -- for A/B timing")
