@@ -1223,7 +1223,8 @@ static int bf_sort_bars(fmk_ctx *ctx, const int64_t *d_ci, int64_t nb, int64_t *
 // OHLC: comp_bar_ohlcv's open / high / low / close / volume / vwap / trades (base.py:352-400) ride along -- the lane already holds
 // the tick's price and amount; six more instructions per tick, the reference's own sequential sums.  (Not the median trade size:
 // fmk_median_small_launch.)  Bars left on the list get theirs from k_bar_ohlcv (`any_long` is its go flag).
-struct DlOhlcOut { double *open, *high, *low, *close; float *vol; double *vwap; int64_t *trades; int *any_long; };
+struct DlOhlcOut { double *open, *high, *low, *close; float *vol; double *vwap; int64_t *trades; int *any_long;
+                   int64_t ohlc_max = INT64_MAX; /* bars longer than this get open .. trades from another launch (cfg 4, sorted bars) */ };
 template <bool OHLC>
 __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *__restrict__ price, const float *__restrict__ amount,
                                                        const int8_t *__restrict__ side, const int64_t *__restrict__ ci,
@@ -1453,7 +1454,9 @@ __global__ __launch_bounds__(64 * DL_WAVES) void k_bar_dir_lanes(const double *_
             o.cum_volumes_min[b] = (float)vmin; o.cum_volumes_max[b] = (float)vmax;
             o.cum_dollars_min[b] = (float)dmin; o.cum_dollars_max[b] = (float)dmax;
             if constexpr (OHLC) {
-                if (len > 0) {
+                if (len > oo.ohlc_max) {
+                    // (written by comp_bar_ohlcv's size classes on the auxiliary stream, beside this kernel)
+                } else if (len > 0) {
                     oo.open[b] = b_first; oo.close[b] = pp;            // pp: the price of the bar's last tick
                     oo.high[b] = b_hi; oo.low[b] = b_lo;
                     oo.vol[b] = (float)b_tv;
@@ -1818,14 +1821,41 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         int64_t lblocks = fmk_ceil_div(fmk_ceil_div(nb, 64), DL_WAVES);
         const int64_t lcap = (int64_t)ctx->n_cu * 40;
         if (lblocks > lcap) lblocks = lcap;
+        // Sorted bars with the median (round 4, late): the medians and the open .. trades of the bars beyond 1 344 ticks come from comp_bar_ohlcv's
+        // size classes -- kernels that share nothing with the order-flow kernels but the input columns.  They run on the context's auxiliary
+        // stream BESIDE the lane kernel, the long-bar order flow and the redo (the lane kernel then leaves open .. trades of those bars alone:
+        // two writers of one value in two association orders would race); the footprint sizing waits for both.  FMK_FLOW_SIDE_OHLCV=0: one
+        // after the other on the context's stream, as before.
+        static int side_knob = -1;
+        if (side_knob < 0) { const char *v = getenv("FMK_FLOW_SIDE_OHLCV"); side_knob = v ? atoi(v) : 1; }
+        const bool side_ohlcv = sort_mode && d_median && side_knob != 0;
         DlOhlcOut oo{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, any_long};
+        // (bars of about equal length -- no sort: the lane kernel writes open .. trades of every bar it serves, and only the MEDIANS, an
+        //  amounts-only pass, run beside it)
+        const char *dv0 = getenv("FMK_FLOW_MEDIAN_DEFER");
+        const bool side_median = !sort_mode && d_median && side_knob != 0 && !(median_deferred && dv0 && atoi(dv0));
+        if (side_ohlcv || side_median) {
+            if (side_ohlcv) oo.ohlc_max = 1344;                                  // 64 * FMK_SMALL_NCH: the reach of k_bar_median_small's class
+            FMK_TRY(fmk_ctx_aux(ctx));
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[0], ctx->stream));              // (the close indices may come from a launch still in flight)
+            FMK_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->aev[0], 0));
+        }
+        if (side_median) {
+            hipStream_t keep = ctx->stream;
+            ctx->stream = ctx->aux;
+            const int rc = fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n);
+            ctx->stream = keep;
+            FMK_TRY(rc);
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[1], ctx->aux));
+        }
         k_bar_dir_lanes<true><<<(unsigned)lblocks, 64 * DL_WAVES, 0, ctx->stream>>>(d_price, (const float *)d_amount, d_side,
                                                                                    d_close_idx, nb, n, o,
                                                                                    (unsigned long long *)d_n_zero_div, long_list,
                                                                                    8192, oo, perm);
         {
             const hipError_t le = hipGetLastError();
-            if (perm) (void)fmk_free(ctx, perm);
+            if (perm && !side_ohlcv) { (void)fmk_free(ctx, perm); perm = nullptr; }   // (side_ohlcv: freed behind the auxiliary stream's allocations)
+            if (le != hipSuccess && perm) { (void)fmk_free(ctx, perm); perm = nullptr; }
             FMK_HIP(ctx, le);
         }
         int64_t blocks = fmk_ceil_div(nb, 4);
@@ -1839,7 +1869,24 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         k_bar_dir<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                    (unsigned long long *)d_n_zero_div, redo, long_list);
         bf_redo_launch<false>(ctx, (unsigned)blocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
-        FMK_LAUNCH_CHECK(ctx);
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess && perm) { (void)fmk_free(ctx, perm); perm = nullptr; }
+            FMK_HIP(ctx, le);
+        }
+        if (side_ohlcv) {
+            hipStream_t keep = ctx->stream;
+            ctx->stream = ctx->aux;                                              // every launch, wait and allocation of the call below: the auxiliary stream
+            int rc = fmk_median_small_ohlcv_long_launch(ctx, d_price, (const float *)d_amount, d_close_idx, nb, n, d_open, d_high, d_low,
+                                                        d_close, d_volume, d_vwap, d_trades, d_median);
+            ctx->stream = keep;
+            if (perm) { (void)fmk_free(ctx, perm); perm = nullptr; }
+            FMK_TRY(rc);
+            FMK_HIP(ctx, hipEventRecord(ctx->aev[1], ctx->aux));
+            FMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aev[1], 0));
+            return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
+                                                    max_levels);
+        }
         // How many bars did the lane kernel hand on?  On a stream of about equally long bars none, and their OHLC is done.  On real
         // one-minute bars (lognormal lengths) most waves keep only their short bars (k_bar_dir_lanes: the 70 % rule): the bars that
         // carry most of the ticks are then better served by comp_bar_ohlcv's own size classes (one pass, median included) than by
@@ -1855,6 +1902,7 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
             return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets, total_levels,
                                                     max_levels);
         }
+        if (side_median) FMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aev[1], 0));    // the medians of the auxiliary stream
         if (ctx->h_mail[13] > nb / 50) {
             FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, 0, n, d_close_idx, n_idx, d_open, d_high, d_low, d_close, d_volume,
                                            d_vwap, d_trades, d_median));
@@ -1870,7 +1918,7 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         const char *dv = getenv("FMK_FLOW_MEDIAN_DEFER");
         const int defer_ok = dv ? atoi(dv) : 0;
         if (d_median && median_deferred && defer_ok) *median_deferred = 1;
-        else if (d_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n));
+        else if (d_median && !side_median) FMK_TRY(fmk_median_small_launch(ctx, (const float *)d_amount, d_close_idx, nb, d_median, n));
     } else {
         FMK_HIP(ctx, hipSetDevice(ctx->device));
         const int64_t nb = n_idx - 1;
