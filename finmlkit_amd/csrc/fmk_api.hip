@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <vector>
 #include <unordered_map>
 
 #include "fmk_common.h"
@@ -158,6 +159,10 @@ struct FmkPool {
     std::unordered_map<void *, size_t> live;        // block -> size (everything handed out)
     size_t cached_bytes = 0;
     bool enabled = true;
+    // While a call runs launches on the context's stream AND on its auxiliary stream, a block freed by one side must not be handed to the
+    // other (the free list is ordered by ONE stream's launch order): frees are parked here until the call has joined the streams.
+    bool defer = false;
+    std::vector<void *> deferred;
 };
 
 static FmkPool *fmk_pool(fmk_ctx *ctx)
@@ -228,6 +233,14 @@ int fmk_free(fmk_ctx *ctx, void *dptr)
     if (!dptr) return FMK_OK;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FmkPool *p = fmk_pool(ctx);
+    if (p->defer) {
+        if (p->live.find(dptr) == p->live.end())
+            return fmk_set_error(ctx, FMK_E_ARG, "fmk_free: %p is not a live block of this context (double free?)", dptr);
+        for (void *q : p->deferred)
+            if (q == dptr) return fmk_set_error(ctx, FMK_E_ARG, "fmk_free: %p freed twice", dptr);
+        p->deferred.push_back(dptr);
+        return FMK_OK;
+    }
     auto it = p->live.find(dptr);
     if (it == p->live.end())                         // not handed out by fmk_alloc, or freed twice: a raw hipFree here
         return fmk_set_error(ctx, FMK_E_ARG,         // could release a block that sits in the free list (use after free)
@@ -396,6 +409,20 @@ int fmk_scratch(fmk_ctx *ctx, size_t bytes, void **out)
     *out = ctx->scratch;
     return FMK_OK;
 }
+
+// on = 1: park every fmk_free until on = 0 (then they are carried out in order).  For calls that launch on two streams at once.
+int fmk_pool_defer(fmk_ctx *ctx, int on)
+{
+    FmkPool *p = fmk_pool(ctx);
+    if (on) { p->defer = true; return FMK_OK; }
+    p->defer = false;
+    int rc = FMK_OK;
+    std::vector<void *> todo;
+    todo.swap(p->deferred);
+    for (void *q : todo) { const int r = fmk_free(ctx, q); if (r != FMK_OK) rc = r; }
+    return rc;
+}
+
 
 // the auxiliary stream of the pipelined time-bar step and its events (timing disabled: they only order the two streams)
 int fmk_ctx_aux(fmk_ctx *ctx)

@@ -48,6 +48,7 @@ struct fmk_ctx {
     hipEvent_t aev[4];
 };
 int fmk_ctx_aux(fmk_ctx *ctx);
+int fmk_pool_defer(fmk_ctx *ctx, int on);   // park fmk_free while a call launches on two streams (fmk_api.hip)
 // fmk_indexers.hip: the time-bar indexer in stages (sample table, then edges [k0, k1) on a given stream, with the long-bar census)
 int fmk_time_bar_coarse_launch(fmk_ctx *ctx, const int64_t *d_ts, int64_t n, const int64_t **coarse, int64_t *m_out, int *clear);
 int fmk_time_bar_index_stage(fmk_ctx *ctx, hipStream_t st, const int64_t *d_ts, int64_t n, int64_t e0, int64_t d, int64_t ne,

@@ -1276,7 +1276,6 @@ __global__ __launch_bounds__(64 * OHR_WAVES) void k_bar_ohlcv_rows(const double 
                                                                  const int64_t *__restrict__ ci, int64_t nb, int64_t n,
                                                                  int *__restrict__ saw_long, OhlcvOut o)
 {
-    typedef MedKey<false> MK;
     __shared__ uint32_t s_cand[OHR_WAVES][64];
     const int lane = fmk_lane();
     const int w = fmk_uniform((int)(threadIdx.x >> 6));
