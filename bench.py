@@ -492,6 +492,7 @@ def run(args):
             state["idx"] = DeviceArray(ctx, cap, np.int64)
             state["out"] = trades.alloc_ohlcv(cap, want_median)
 
+    _pre = None
     if use_dist:
         # Before the placement probes: everything a sharded run allocates later -- RCCL's point-to-point channels (built by the first
         # exchange), the plan's index / output / boundary buffers -- is allocated once now.  Measured without this: the columns probed
@@ -528,6 +529,12 @@ def run(args):
         # SET-UP, not a step: the plan (global clock, edge partition, halo lengths, boundary buffers) is a function of
         # the immutable columns -- two host all-gathers, once.  The first exchange also builds RCCL's point-to-point
         # channels (seconds, once).
+        # (the set-up made before the placement probes goes first: its index / output / boundary buffers return to the allocator's free
+        #  list and come back, same sizes, to the set-up below -- no allocation is made or released after the probes.  With both alive the
+        #  run's kernel took 2.30 ms where the probes had said 2.13: end-of-round run, profiles/r04_sharded_step.txt)
+        _pre = None
+        import gc
+        gc.collect()
         shard = ShardedTimeBars(trades, rank, world, args.interval, want_median, self_loop=(world == 1)).setup(comm)
         shard.step(comm)
         ctx.sync()
