@@ -245,6 +245,25 @@ def test_order_flow_redo_in_tick_order(orc, monkeypatch, amounts, rows):
         np.testing.assert_array_equal(got[k], w, err_msg=f"{k} ({amounts}, rows={rows})")
 
 
+def test_order_flow_on_negative_prices(orc):
+    """A tape whose prices are NEGATIVE (spreads, some futures): the dollar sums are negative, and the tie test of the wave-per-bar
+    kernel bounded the two orders' difference by eps * sum -- a negative bound: no bar was ever redone and ~0.3 % of the bars kept the
+    parallel order's last float32 bit (tools/fuzz_fused.py seed 7707, case 9).  The bound takes magnitudes now."""
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    rng = np.random.default_rng(7707)
+    n = 3_000_000
+    px = np.round(-40.0 + np.cumsum(rng.integers(-1, 2, n)) * 0.0005, 4)
+    assert px.max() < 0
+    am = (rng.integers(1, 4097, n) / 1024.0).astype(np.float32)
+    sd = rng.choice(np.array([-1, 1], np.int8), n)
+    lens = np.maximum(1, rng.normal(900, 45, int(n / 900 * 1.2)).astype(np.int64))
+    ci = np.concatenate([[-1], np.cumsum(lens) - 1])
+    ci = ci[ci <= n - 1].astype(np.int64)
+    got = comp_bar_directional_features(px, am, ci, sd)
+    want = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    _check_dir(got, want, "negative prices")
+
+
 def test_order_flow_extremum_near_tie_with_nan_elsewhere_in_the_bar(orc):
     """tools/fuzz_longbars.py seed 361, case 70 (tests/golden/nan_tie_longbar.npz, tools/gen_nan_tie_fixture.py): a 65 537-tick bar whose running
     signed dollar sum peaks 2.7e-12 below a float32 rounding boundary at tick 488 and holds a NaN amount at tick 554.  The NaN made the
