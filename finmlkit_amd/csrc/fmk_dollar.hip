@@ -622,6 +622,113 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     return FMK_OK;
 }
 
+#include "fmk_dollar_onepass.h"
+
+// The one-pass closed form (fmk_dollar_onepass.h).  -> FMK_OK (c.count / c.unc / c.dbuf / c.carry filled like dl_run does),
+// 1 (not served: an increment outside [0, thr), a threshold outside the fixed-point range, a look-back that gave up -- the caller
+// runs dl_run), or an error.
+template <bool AF64>
+static int dl1_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, double thr, DlCache &c)
+{
+    static int enabled = -1;             // developer knob: FMK_DL_ONEPASS=0 -> the reduce-then-scan kernels for every input
+    if (enabled < 0) { const char *v = getenv("FMK_DL_ONEPASS"); enabled = v ? atoi(v) : 1; }
+    int ex;
+    (void)frexp(thr, &ex);               // thr = m * 2^ex, m in [0.5, 1): ulp(thr) = 2^(ex - 53)
+    if (!enabled || !(thr > 0.0) || !isfinite(thr) || ex < -900 || ex > 900 || n < 2) return 1;
+    Dl1Params P;
+    P.scale = ldexp(1.0, DL1_F + 53 - ex);
+    P.T = (uint64_t)(thr * P.scale);     // exact: thr / ulp(thr) is an integer in [2^52, 2^53)
+    P.inv_t = 1.0 / (double)P.T;
+    memcpy(&P.thr_bits, &thr, 8);
+    P.tol_a = 1e-11 * (double)P.T;
+    P.tol_b = 2.31e-16 * (double)P.T;    // the reference's drift per add (2.3e-16 thr, dl_run) + the truncation of the fixed point (2^-60 thr)
+    // tile geometry: 512 threads x 16 ticks (8 192-tick tiles).  A tile waits ~5 us for its look-back with its ticks in registers and
+    // loads nothing meanwhile, and a poll costs what a cache line of ticks costs, so few large tiles win: 256 x 8 / 256 x 16 / 512 x 8
+    // / 512 x 16 / 1024 x 16 ran 3.9 / 3.1 / 3.3 / 2.7 / 3.2 ms per 1e9 ticks (profiles/r05_cfg3.txt).  Developer knob
+    // FMK_DL1_GEOMETRY=1: 256 x 8 (small tiles: more of them in a short stream, used by the tests to cross many tile borders)
+    static int geometry = -1;
+    if (geometry < 0) { const char *v = getenv("FMK_DL1_GEOMETRY"); geometry = v ? atoi(v) : 0; }
+    const int threads = geometry == 1 ? 256 : 512, items = geometry == 1 ? 8 : 16;
+    const int64_t tiles = fmk_ceil_div(n, (int64_t)threads * items);
+    const int64_t groups = (tiles + DL1_W1 - 1) / DL1_W1;
+    const size_t desc_bytes = (size_t)tiles * 16 + (size_t)groups * DL1_W1 * 16;      // A[tiles][2], B[W1][groups][2] (fmk_dollar_onepass.h)
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, desc_bytes + (size_t)tiles * 32 + 64, &scr));            // (+ the time stamps of a -DDL1_TIMING build)
+    unsigned long long *desc = (unsigned long long *)scr;
+    int64_t *d_last = ctx->d_mail + 24;
+    unsigned long long *d_frag = (unsigned long long *)(ctx->d_mail + 25);
+    int *d_flags = (int *)(ctx->d_mail + 26);
+    double *d_sum = (double *)(ctx->d_mail + 27);
+    if (!c.dbuf || c.cap <= 0) {
+        // no close buffers yet: their capacity from a strided sample of the products (x 1.3 + slack).  Only a guess -- the pass
+        // itself reports the true count, and a guess that was too small costs one more pass with the exact capacity.
+        const int64_t m = n < 65536 ? n : 65536, stride = n / m;
+        FMK_HIP(ctx, hipMemsetAsync(d_sum, 0, 8, ctx->stream));
+        k_dl1_sample<AF64><<<(unsigned)fmk_ceil_div(m, 256), 256, 0, ctx->stream>>>(p, a, n, stride, m, d_sum);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double ssum;
+        memcpy(&ssum, &ctx->h_mail[0], 8);
+        double est = ssum / (double)m * (double)n / thr;
+        if (!(est >= 0.0) || est > (double)n) est = (double)n;
+        c.cap = (int64_t)(est * 1.3) + 65536 + DL_EXTRA;
+        if (c.cap > n + 1 + DL_EXTRA) c.cap = n + 1 + DL_EXTRA;
+        if (c.dbuf) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
+        if (c.carry) { FMK_HIP(ctx, hipFree(c.carry)); c.carry = nullptr; }
+        FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.cap * 8));
+        FMK_HIP(ctx, hipMalloc((void **)&c.carry, (size_t)c.cap * 8));
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        FMK_HIP(ctx, hipMemsetAsync(desc, 0, desc_bytes, ctx->stream));
+        FMK_HIP(ctx, hipMemsetAsync(d_last, 0, 24, ctx->stream));
+        unsigned long long *dB = desc + 2 * tiles;
+        if (geometry == 1)
+            k_dl1<AF64, 8, 256><<<(unsigned)tiles, 256, 0, ctx->stream>>>(p, a, n, P, desc, dB, c.dbuf, c.carry, c.cap, d_last, d_frag, d_flags);
+        else
+            k_dl1<AF64, 16, 512><<<(unsigned)tiles, 512, 0, ctx->stream>>>(p, a, n, P, desc, dB, c.dbuf, c.carry, c.cap, d_last, d_frag, d_flags);
+        FMK_LAUNCH_CHECK(ctx);
+        FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_last, 24, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef DL1_TIMING
+        {
+            unsigned long long *tt = (unsigned long long *)malloc((size_t)tiles * 32);
+            (void)hipMemcpy(tt, (char *)desc + desc_bytes, (size_t)tiles * 32, hipMemcpyDeviceToHost);
+            double s_load = 0, s_lb = 0, s_cmp = 0, s_polls = 0; int64_t cnt = 0;
+            unsigned long long t_min = ~0ULL, t_max = 0;
+            for (int64_t t = 1; t < tiles - 1; ++t) {
+                unsigned long long *q = tt + 4 * t;
+                { const unsigned long long np = (0ULL - (q[0] >> 56)) & 0xFF; s_polls += (double)np; q[0] += np << 56; }
+                s_load += (double)(q[1] - q[0]); s_lb += (double)(q[2] - q[1]); s_cmp += (double)(q[3] - q[2]);
+                if (q[0] < t_min) t_min = q[0];
+                if (q[3] > t_max) t_max = q[3];
+                ++cnt;
+            }
+            fprintf(stderr, "[dl1] tiles %lld: start->sum %.2f us, look-back %.2f us, rest %.2f us, %.2f polls; kernel span %.3f ms\n",
+                    (long long)tiles, s_load / cnt * 0.01, s_lb / cnt * 0.01, s_cmp / cnt * 0.01, s_polls / cnt, (double)(t_max - t_min) * 1e-5);
+            free(tt);
+        }
+#endif
+        if ((int)(ctx->h_mail[2] & 0xFFFFFFFF) != 0) return 1;
+        const int64_t count = ctx->h_mail[0] + 1;                    // M_{n-1} closes + the leading 0
+        if (count + DL_EXTRA <= c.cap) {
+            c.count = count;
+            c.unc = ctx->h_mail[1];
+            c.dmax = nextafter(thr, 0.0);                             // all the callers ask is whether an increment reached thr
+            c.extra = 0.0;
+            c.area = 0.0;
+            return FMK_OK;
+        }
+        FMK_HIP(ctx, hipFree(c.dbuf));
+        FMK_HIP(ctx, hipFree(c.carry));
+        c.dbuf = c.carry = nullptr;
+        c.cap = count + DL_EXTRA;
+        FMK_HIP(ctx, hipMalloc((void **)&c.dbuf, (size_t)c.cap * 8));
+        FMK_HIP(ctx, hipMalloc((void **)&c.carry, (size_t)c.cap * 8));
+    }
+    return fmk_set_error(ctx, FMK_E_HIP, "dollar indexer: the close count changed between two passes over the same ticks");
+}
+
 int fmk_threshold_serial(fmk_ctx *ctx, int dollar, const double *d_price, const void *d_amount, int is_f64, int64_t n,
                          double thr, int64_t *d_close_idx, int64_t capacity, int64_t *n_idx, int64_t *n_unc);
 // fmk_dollar_exact.hip: the reference's float64 state at every bar start, reconstructed in parallel; rewrites the closes the
@@ -634,6 +741,7 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
 // (every decision certain), 1 closed form + exact tier, 2 closed form + exact tier on a stream with increments >= thr (stretch walk),
 // 3 the serial walk (the fill half of a count-then-fill pair answers from the cache and leaves the value alone)
 static int g_dl_last_path = -1;
+static int g_dl_onepass = 0;           // the closed form of the last call came from the one-pass kernel (fmk_dollar_onepass.h)
 extern "C" int fmk_diag_dollar_last(int64_t *path)
 {
     *path = g_dl_last_path;
@@ -656,7 +764,11 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
     const bool hit = c.ctx == ctx && !ctx->idx_stale[1] && c.amount == d_amount && c.price == d_price && c.n == n && c.thr == threshold &&
                      c.is_f64 == amount_is_f64 && c.dbuf && d_close_idx;
     if (!hit) {
-        int rc = amount_is_f64 ? dl_run<true>(ctx, d_price, d_amount, n, threshold, c)
+        int rc = amount_is_f64 ? dl1_run<true>(ctx, d_price, d_amount, n, threshold, c)
+                               : dl1_run<false>(ctx, d_price, d_amount, n, threshold, c);
+        g_dl_onepass = rc == FMK_OK;
+        if (rc == 1)
+            rc = amount_is_f64 ? dl_run<true>(ctx, d_price, d_amount, n, threshold, c)
                                : dl_run<false>(ctx, d_price, d_amount, n, threshold, c);
         if (rc == 1) {
             g_dl_last_path = 3;

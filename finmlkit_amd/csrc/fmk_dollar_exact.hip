@@ -596,13 +596,17 @@ __global__ __launch_bounds__(64) void k_dlx_resolve(const double *__restrict__ p
                                                     unsigned long long *giveup, const unsigned char *__restrict__ btype,
                                                     const int64_t *__restrict__ sval)
 {
-    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // ONE WAVE per flagged bar (round 5; it was one thread: ~860 dependent global loads per replay, 0.7 ms per call at 1e9 ticks for
+    // ~3 500 replays).  The loads are the wave's -- 64 ticks per step, the next step's already in flight -- and every lane runs the
+    // reference's loop on the same values (readlane); lane 0 alone writes.
+    const int64_t f = blockIdx.x;
+    const int lane = threadIdx.x;
     if (f >= n_flag) return;
     const int64_t b = flist[f];
     DlxRes old = res[f];
     if (owner[b] != (int32_t)b) {
         // absorbed by the replay of an earlier bar: no state of its own.  Give back what it had claimed.
-        if (old.mode == 1) {
+        if (old.mode == 1 && lane == 0) {
             for (int64_t x = b + 1; x < b + old.span && x <= nb; ++x)
                 if (owner[x] == (int32_t)b) owner[x] = (int32_t)x;
             old.mode = 0; old.span = 1;
@@ -619,15 +623,25 @@ __global__ __launch_bounds__(64) void k_dlx_resolve(const double *__restrict__ p
     int q = 0;
     bool synced = false, lost = false;
     int64_t i = ci[b] + 1;
-    for (; i < n; ++i) {
-        c += dlx_d<AF64>(price, amount, i);
-        if (c >= thr) {
-            if (q >= DLX_MAXC) { lost = true; break; }
-            r.close[q++] = i;
-            c = c - thr;
-            if (b + q <= nb && i == ci[b + q]) { synced = true; break; }     // back on a close of the closed form
+    double dnext = i + lane < n ? dlx_d<AF64>(price, amount, i + lane) : 0.0;
+    for (bool done = false; i < n && !done; i += 64) {
+        const double dl = dnext;
+        if (i + 64 + lane < n) dnext = dlx_d<AF64>(price, amount, i + 64 + lane);
+        const int lim = (int)(n - i < 64 ? n - i : 64);
+        for (int j = 0; j < lim; ++j) {
+            c += __longlong_as_double(fmk_readlane((int64_t)__double_as_longlong(dl), j));
+            if (c >= thr) {
+                if (q >= DLX_MAXC) { lost = true; done = true; break; }
+                const int64_t at = i + j;
+#pragma unroll
+                for (int z = 0; z < DLX_MAXC; ++z) if (z == q) r.close[z] = at;
+                ++q;
+                c = c - thr;
+                if (b + q <= nb && at == ci[b + q]) { synced = true; done = true; break; }     // back on a close of the closed form
+            }
         }
     }
+    if (lane != 0) return;
     if (lost) { atomicAdd(giveup, 1ULL); return; }
     r.nclose = q;
     r.kout = llrint(c * inv_u);
@@ -695,7 +709,9 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
     const char *mv = getenv("FMK_DL_MARGIN_SCALE");
     double mscale = mv ? atof(mv) : 1.0;
     if (!(mscale >= 1.0)) mscale = 1.0;
-    const double m_rel = ldexp(thr, -52) * mscale, m_abs = 64.0 * u * mscale;   // the carry k~ is good to a few units
+    // (m_rel: the reference's drift per add, + 1/128 for the carries of the one-pass closed form, whose fixed point truncates every
+    //  product by less than ulp(thr) / 256: fmk_dollar_onepass.h)
+    const double m_rel = ldexp(thr, -52) * mscale * (1.0 + 1.0 / 128.0), m_abs = 64.0 * u * mscale;   // the carry k~ is good to a few units
     const int64_t nbar = nb + 1;                     // + the tail
     const int64_t nblk = fmk_ceil_div(nbar, DLX_BLOCK_BARS);
     void *p_fn = nullptr, *p_fidx = nullptr, *p_owner = nullptr, *p_flist = nullptr, *p_kin = nullptr, *p_blk = nullptr,
@@ -771,12 +787,12 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
                                                                 (int64_t *)p_kin, (const unsigned char *)p_btype, nullptr,
                                                                 (const int64_t *)p_sval);
             if (is_f64)
-                k_dlx_resolve<true><<<gf, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
+                k_dlx_resolve<true><<<(unsigned)n_flag, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
                                                                 (const int64_t *)p_kin, (const int64_t *)p_flist, n_flag,
                                                                 (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2,
                                                                 (const unsigned char *)p_btype, (const int64_t *)p_sval);
             else
-                k_dlx_resolve<false><<<gf, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
+                k_dlx_resolve<false><<<(unsigned)n_flag, 64, 0, ctx->stream>>>(d_price, d_amount, n, thr, u, inv_u, d_close_idx, nb, (const DlxFn *)p_fn,
                                                                  (const int64_t *)p_kin, (const int64_t *)p_flist, n_flag,
                                                                  (int32_t *)p_owner, (DlxRes *)p_res, cnt + 1, cnt + 2,
                                                                  (const unsigned char *)p_btype, (const int64_t *)p_sval);
