@@ -93,6 +93,13 @@ __device__ __forceinline__ int64_t vol_replay(const void *__restrict__ amount, i
     return -1;
 }
 
+// The decisions of the global-table and chain-walk tiers are sums of a double-double block part (exact) and block-LOCAL prefix sums
+// (512 ticks, plain doubles).  A local prefix carries the rounding of its own scan, at most a few hundred ulps of ITS magnitude --
+// which has nothing to do with the threshold's: behind a block trade of 7e11 the prefixes of the same block are good to ~1e-4,
+// and a bar of small trades that starts there had its decision "certified" with the 1e-11 * thr margin, one tick late
+// (tools/fuzz_volume.py seed 5202 case 241, round 5).  Every margin that involves a local prefix therefore adds 2^-42 of it.
+__device__ __forceinline__ double vol_prefix_slack(double local_prefix) { return 2.2737367544323206e-13 * fabs(local_prefix); }
+
 __device__ __forceinline__ void vol_flag(int *status, int bit)     // one atomic per kernel, not per wave
 {
     if (!(__atomic_load_n(status, __ATOMIC_RELAXED) & bit)) atomicOr(status, bit);
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
         if (bstar < 0) {
             // the remaining ticks do not fill a bar -- decision `cnt`, fragile when they come within the margin
             const double rest = vc_diff(Bb[nblk], Bc) - Lc;
-            if (lane == 0 && thr - rest <= (1e-11 + 2.3e-16 * (double)(n - 1 - c)) * thr) vol_list_append(list, cnt);
+            if (lane == 0 && thr - rest <= (1e-11 + 2.3e-16 * (double)(n - 1 - c)) * thr + vol_prefix_slack(Lc)) vol_list_append(list, cnt);
             break;
         }
         // request the next close's window now: it starts at bstar whatever tick of the block closes
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(64) void k_vc_chase(const double *__restrict__ Lp, 
         VC_T(t1); tB += t1 - t0; t0 = t1;
 #endif
         // ---- certification
-        const double tol = (1e-11 + 2.3e-16 * (double)(mclose - c)) * thr;
+        const double tol = (1e-11 + 2.3e-16 * (double)(mclose - c)) * thr + vol_prefix_slack(Lc) + vol_prefix_slack(l_at);
         const double over = s_at - thr;
         double under = INFINITY;
         if (mclose - 1 >= lo) under = thr - (off + l_before);       // mclose - 1 >= lo >= block start: inside this block
@@ -1100,7 +1107,7 @@ __global__ __launch_bounds__(256, 4) void k_vg_nxt(const double *__restrict__ Lp
             } else {
                 // no further close: fragile if the rest of the stream comes within the margin of the threshold
                 dblk[k] = VG_DEND;
-                const double tol = (1e-11 + 2.3e-16 * (double)(n - 1 - (j0 + k))) * thr;
+                const double tol = (1e-11 + 2.3e-16 * (double)(n - 1 - (j0 + k))) * thr + vol_prefix_slack(lpj[k]);
                 frag[k] = thr - (last - lpj[k]) <= tol ? 1 : 0;
             }
         }
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(256, 4) void k_vg_nxt(const double *__restrict__ Lp
             if (hi < nvt) {
                 iprev = hi;
                 m = ds + hi;
-                const double tol = (1e-11 + 2.3e-16 * (double)(m - j)) * thr;
+                const double tol = (1e-11 + 2.3e-16 * (double)(m - j)) * thr + vol_prefix_slack(l0) + vol_prefix_slack(VG_SLP(hi));
                 const double over = b + (VG_SLP(hi) - l0) - thr;
                 double under = INFINITY;
                 if (m - 1 > j) under = thr - (hi > 0 ? b + (VG_SLP(hi - 1) - l0) : b - l0);
@@ -1239,7 +1246,7 @@ __global__ __launch_bounds__(64) void k_vg_root(const double *__restrict__ Lp, c
         if (hi >= lo) { m = hi; fr = true; }                       // rounded just below at the block's end
         else { *root = n > 1 ? 1u : VOL_END; if (n > 1) vol_list_append(list, 1); return; }   // one-tick block 0: let the replay decide
     } else {
-        const double tol = (1e-11 + 2.3e-16 * (double)m) * thr;
+        const double tol = (1e-11 + 2.3e-16 * (double)m) * thr + vol_prefix_slack(Lp[m]);
         const double over = off + Lp[m] - thr;
         double under = INFINITY;
         if (m - 1 >= lo) under = thr - (off + Lp[m - 1]);
@@ -1616,9 +1623,14 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
                 rc = amount_is_f64 ? vx_run<true, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c);
             // (a (3840, 1280) class with 640 threads -- a third of the rows per tick -- was measured: 7.3 against 6.3 ms at 865-tick bars)
-            if (rc == 1 && est_len < 1150.0 && vx_on != 3)
+            if (rc == 1 && est_len < 1150.0 && vx_on != 3) {
+                if (vx_on == 5)          // experiment: 256 threads (twice the ticks per thread)
+                    rc = amount_is_f64 ? vx_run<true, 2560, 1536, 256, false>(ctx, d_amount, n, threshold, c)
+                                       : vx_run<false, 2560, 1536, 256, false>(ctx, d_amount, n, threshold, c);
+                else
                 rc = amount_is_f64 ? vx_run<true, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c);
+            }
             if (rc == 1)
                 rc = amount_is_f64 ? vx_run<true, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c);

@@ -26,8 +26,8 @@
 
 template <bool AF64, int S, int W, int THREADS, bool PAD>
 __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ amount, int64_t n, double thr,
-                                                       uint16_t *__restrict__ nxt16, uint32_t *__restrict__ E0,
-                                                       uint32_t *__restrict__ C0, uint32_t *__restrict__ root,
+                                                       uint16_t *__restrict__ nxt16, uint32_t *__restrict__ EC0,
+                                                       uint32_t *__restrict__ root,
                                                        int *__restrict__ status)
 {
     constexpr int T = S + W;                          // ticks whose prefix sums the block needs
@@ -53,22 +53,36 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     // ---- the thread's PER consecutive amounts, 16 bytes per load
     double loc[PER];
     double run = 0.0, amax = 0.0, amin = 1.7e308;     // amin: the smallest POSITIVE amount
+    int qexp = 4096;                                   // float64 sizes: the lowest set bit of any amount, as a power of two
     bool bad = false;
     {
         const int64_t jb = bs + (int64_t)tid * PER;
         double vv[PER];
+        bool fast32 = false;
         if (jb + PER <= n && ((uintptr_t)amount & 15) == 0) {
             if constexpr (AF64) {
                 const double2 *q = (const double2 *)((const double *)amount + jb);
 #pragma unroll
                 for (int k = 0; k < PER / 2; ++k) { const double2 t2 = q[k]; vv[2 * k] = t2.x; vv[2 * k + 1] = t2.y; }
             } else {
+                // float32 sizes: the largest, the smallest positive and "any negative / NaN / inf" from the BIT PATTERNS -- non-negative
+                // floats order like unsigned integers, everything else lies above 0x7F7FFFFF -- three 32-bit instructions per amount
+                // where the float64 compares took eight (the kernel is bound by VALU issue).  (-0.0 counts as negative here: the
+                // call then takes the serial walk, which gives the same closes.)
                 const float4 *q = (const float4 *)((const float *)amount + jb);
+                uint32_t bmax = 0, bmin1 = 0xFFFFFFFFu;
 #pragma unroll
                 for (int k = 0; k < PER / 4; ++k) {
                     const float4 t4 = q[k];
                     vv[4 * k] = (double)t4.x; vv[4 * k + 1] = (double)t4.y; vv[4 * k + 2] = (double)t4.z; vv[4 * k + 3] = (double)t4.w;
+                    const uint32_t u0 = __float_as_uint(t4.x), u1 = __float_as_uint(t4.y), u2 = __float_as_uint(t4.z), u3 = __float_as_uint(t4.w);
+                    bmax = max(max(bmax, u0), max(u1, max(u2, u3)));
+                    bmin1 = min(min(bmin1, u0 - 1u), min(u1 - 1u, min(u2 - 1u, u3 - 1u)));   // (0 - 1 wraps to the top: zeros do not count)
                 }
+                fast32 = true;
+                bad = bmax > 0x7F7FFFFFu;
+                amax = bad ? 0.0 : (double)__uint_as_float(bmax);
+                amin = bmin1 == 0xFFFFFFFFu || bad ? 1.7e308 : (double)__uint_as_float(bmin1 + 1u);
             }
         } else {
 #pragma unroll
@@ -78,9 +92,20 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const double v = vv[k];
-            bad |= !(v >= 0.0) || v > 1.7e308;
-            amax = fmax(amax, v);
-            amin = fmin(amin, v > 0.0 ? v : 1.7e308);
+            if (!fast32) {
+                bad |= !(v >= 0.0) || v > 1.7e308;
+                amax = fmax(amax, v);
+                amin = fmin(amin, v > 0.0 ? v : 1.7e308);
+            }
+            if constexpr (AF64) {
+                // the certificate's quantum for float64 sizes: q = 2^(lowest set bit of any amount) -- with q = ulp(smallest amount), as for
+                // float32, no float64 window could ever certify (2^52 ulp(a) <= a), while float64 COPIES of float32 / dyadic sizes do
+                const uint64_t bits = (uint64_t)__double_as_longlong(v);
+                const uint32_t lo32 = (uint32_t)bits, hi32 = (uint32_t)(bits >> 32);
+                const int tz = lo32 ? __builtin_ctz(lo32) : 32 + __builtin_ctz((hi32 & 0xFFFFFu) | 0x100000u);
+                const int eq = (int)((hi32 >> 20) & 0x7FFu) - 1075 + tz;
+                qexp = v > 0.0 && eq < qexp ? eq : qexp;
+            }
             run += v;
             loc[k] = run;
         }
@@ -89,7 +114,9 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     const double inc = fmk_dpp_iscan(run, 0.0, FmkOpAdd());
     amax = fmk_dpp_reduce(amax, 0.0, FmkOpMax());
     amin = fmk_dpp_reduce(amin, 1.7e308, FmkOpMin());
+    if constexpr (AF64) qexp = fmk_dpp_reduce(qexp, 4096, FmkOpMin());
     if (lane == 63) wtot[w] = inc;
+    if constexpr (AF64) amin = (double)qexp;           // (float64 sizes: from here on `amin` carries the quantum's exponent)
     if (lane == 0) { wtot[NW + w] = amax; wtot[2 * NW + w] = amin; }
     const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
     double pre = fmk_dpp_shift_up1(inc, 0.0);          // exclusive prefix of the thread totals inside the wave
@@ -100,7 +127,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
             if (q == w) pre += wp;
             wp += wtot[q];
             amax = fmax(amax, wtot[NW + q]);
-            amin = fmin(amin, wtot[2 * NW + q]);
+            amin = fmin(amin, wtot[2 * NW + q]);               // (float64 sizes: the waves' quantum exponents)
         }
         total = wp;
     }
@@ -108,11 +135,14 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     // ---- the certificate of this window.  Every amount is a multiple of q = ulp(smallest positive amount) -- of its own ulp, which is
     //      a power-of-two multiple of q -- (float32 sizes: ulp = 2^(e - 23), float64: 2^(e - 52)); block total and thr + max amount
     //      below 2^53 q.  (A first version took q from the lowest SET mantissa bit of every amount -- more tapes certify, e.g. decimal
-    //      lots next to one tiny trade do not here -- at fifteen 64-bit instructions per amount in a kernel that is bound by VALU issue.)
-    if (amin < 1.7e308) {
-        const int e = (int)((__double_as_longlong(amin) >> 52) & 0x7ff) - 1023;          // amin >= 2^e (float32 subnormals arrive normal)
-        const double lim = ldexp(1.0, e - (AF64 ? 52 : 23) + 52);                        // 2^52 q
-        const bool exact = e > -1000 && total < 2.0 * lim && thr < lim && amax < lim;
+    //      lots next to one tiny trade do not here -- at fifteen 64-bit instructions per amount in a kernel that is bound by VALU issue;
+    //      float64 sizes take it from the lowest set bit all the same: with their own ulp nothing would certify.)
+    if (AF64 ? amin < 4096.0 : amin < 1.7e308) {
+        int qe;                                                                          // q = 2^qe
+        if constexpr (AF64) qe = (int)amin;
+        else qe = (int)((__double_as_longlong(amin) >> 52) & 0x7ff) - 1023 - 23;         // amin >= 2^e (float32 subnormals arrive normal)
+        const double lim = ldexp(1.0, qe + 52);                                          // 2^52 q
+        const bool exact = qe > -1040 && total < 2.0 * lim && thr < lim && amax < lim;
         if (!exact) { if (tid == 0) vol_flag(status, VOL_ST_INEXACT); return; }
     }
 #pragma unroll
@@ -127,6 +157,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     //      round: 4 rounds for 2048), then the run of prefixes behind its answer is fetched in batches of 8 independent reads and the
     //      EPT ticks are resolved against the batch in registers (a merge of two sorted runs).
     bool ovf = false;
+    unsigned minoff = VX_NONE;                                           // the shortest link of this thread's ticks
     {
         const int i0 = tid * EPT;
         // -- first tick of the thread: 8-ary search in (i0 + 1, min(i0 + 1 + W, mmax)]
@@ -144,6 +175,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
             } else if (i0 + 1 + W <= mmax) ovf = true;                   // no close within W ticks although data remains
         }
         nx[i0] = (uint16_t)(m0 >= 0 ? (unsigned)(m0 - 1 - i0) : VX_NONE);
+        if (m0 >= 0) minoff = (unsigned)(m0 - 1 - i0);
         // -- the other EPT - 1 ticks walk forward from the previous answer (nxt is non-decreasing)
         int cur = m0;
 #pragma unroll 1
@@ -165,6 +197,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
                 }
             }
             nx[i] = (uint16_t)off;
+            minoff = off < minoff ? off : minoff;
         }
     }
     if (__ballot(ovf) != 0 && lane == 0) vol_flag(status, VOL_ST_OVERFLOW);
@@ -183,14 +216,42 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
         }
         *root = r;
     }
-    __syncthreads();
+    // (are all bars of this block at least THREADS ticks long?  then the entry rows come from a backward sweep, see below)
+    const bool long_bars = __syncthreads_and(minoff >= (unsigned)THREADS) != 0;
     // ---- the links leave as 16-bit offsets (coalesced), the entry rows by following them through LDS
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int i = q * THREADS + tid;
         if (bs + i < n) nxt16[bs + i] = nx[i];
     }
-    {   // W / THREADS rows per thread, walked TOGETHER: one LDS round trip advances all of them by a hop
+    if (long_bars) {
+        // Backward sweep (round 5).  (exit, count) of EVERY tick of the block, a chunk of THREADS ticks at a time from the block's end:
+        // tick j's chain continues at t = j + off >= j + THREADS, i.e. in a chunk that is already done, so one LDS read gives its
+        // (exit, count) and adding one node gives j's -- S ticks, one dependent round trip each, no divergence; the walk below costs
+        // W rows x ~S / L hops per row (1.8x as many LDS round trips at W = 1536, L = 865, and lanes that finish at different hops).
+        // The packed words overlay the prefix table, which is dead by now.
+        uint32_t *ec = (uint32_t *)vx_smem;
+#pragma unroll 1
+        for (int ch = EPT - 1; ch >= 0; --ch) {
+            const int j = ch * THREADS + tid;
+            uint32_t wv = 0xFFFFu;                                     // beyond the data: no node, no exit
+            if (j < remain) {
+                const unsigned o = nx[j];
+                if (o == VX_NONE) wv = (1u << 16) | 0xFFFFu;           // the chain ends in this block
+                else {
+                    const int t = j + (int)o;
+                    wv = t >= S ? ((1u << 16) | (uint32_t)(t - S)) : ec[t] + (1u << 16);
+                }
+            }
+            ec[j] = wv;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < (W + THREADS - 1) / THREADS; ++r) {
+            const int i = tid + r * THREADS;
+            if (i < W) EC0[(int64_t)blockIdx.x * W + i] = ec[i];
+        }
+    } else {   // W / THREADS rows per thread, walked TOGETHER: one LDS round trip advances all of them by a hop
         constexpr int ROWS = (W + THREADS - 1) / THREADS;
         int e[ROWS];
         uint32_t C[ROWS];
@@ -222,10 +283,9 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int i = tid + r * THREADS;
-            if (i < W) {
-                E0[(int64_t)blockIdx.x * W + i] = E[r];
-                C0[(int64_t)blockIdx.x * W + i] = C[r];
-            }
+            // one word per row: the count and where the chain leaves the block, as an offset into the next block's first W ticks
+            // (two 32-bit arrays made this table 4.8 B/tick written here and read again by the first level-up: 1.2 of 6.5 ms)
+            if (i < W) EC0[(int64_t)blockIdx.x * W + i] = (C[r] << 16) | (E[r] == VOL_END ? 0xFFFFu : E[r] - (uint32_t)(bs + S));
         }
     }
 #undef VXP
@@ -252,6 +312,14 @@ __global__ __launch_bounds__(256) void k_vx_emit(int64_t S, const uint32_t *__re
 
 // k_vol_level_up4 / k_vol_descend4 for tables of W rows per block, W any number (theirs is a power of two): level q + 1 composes
 // `radix` blocks of level q over the W entry ticks of the first of them
+// a row of the packed level-0 table: count, and the chain's exit as an absolute tick (VOL_END: none)
+__device__ __forceinline__ void vx_unpack0(uint32_t w, int64_t block, int64_t S, uint32_t *e, uint32_t *c)
+{
+    *c = w >> 16;
+    *e = (w & 0xFFFFu) == 0xFFFFu ? VOL_END : (uint32_t)((block + 1) * S + (w & 0xFFFFu));
+}
+
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_vx_level_up(int W, const uint32_t *__restrict__ Ep, const uint32_t *__restrict__ Cp,
                                                      int64_t nblk_prev, int64_t span_prev, uint32_t *__restrict__ Ek,
                                                      uint32_t *__restrict__ Ck, int64_t nblk, int *__restrict__ status, int radix)
@@ -260,20 +328,28 @@ __global__ __launch_bounds__(256) void k_vx_level_up(int W, const uint32_t *__re
     const int i = (int)(blockIdx.y * blockDim.x + threadIdx.x);
     if (i >= W || b >= nblk) return;
     const int64_t c0 = (int64_t)radix * b;
-    uint32_t x = Ep[c0 * W + i];
-    uint32_t c = Cp[c0 * W + i];
+    uint32_t x, c;
+    if constexpr (PACKED) vx_unpack0(Ep[c0 * W + i], c0, span_prev, &x, &c);
+    else { x = Ep[c0 * W + i]; c = Cp[c0 * W + i]; }
     for (int j = 1; j < radix; ++j) {
         const int64_t child = c0 + j;
         if (x == VOL_END || child >= nblk_prev) break;
         const int64_t i2 = (int64_t)x - child * span_prev;           // the chain enters the next child in its first W ticks
         if (i2 < 0 || i2 >= W) { vol_flag(status, VOL_ST_OVERFLOW); x = VOL_END; break; }
-        c += Cp[child * W + i2];
-        x = Ep[child * W + i2];
+        if constexpr (PACKED) {
+            uint32_t c2;
+            vx_unpack0(Ep[child * W + i2], child, span_prev, &x, &c2);
+            c += c2;
+        } else {
+            c += Cp[child * W + i2];
+            x = Ep[child * W + i2];
+        }
     }
     Ek[b * W + i] = x;
     Ck[b * W + i] = c;
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_vx_descend(int W, const uint32_t *__restrict__ ent_k, const int64_t *__restrict__ off_k,
                                                     int64_t nblk_k, int64_t span_prev, const uint32_t *__restrict__ Ep,
                                                     const uint32_t *__restrict__ Cp, int64_t nblk_prev,
@@ -292,8 +368,14 @@ __global__ __launch_bounds__(256) void k_vx_descend(int W, const uint32_t *__res
         if (e != VOL_END) {
             const int64_t i = (int64_t)e - (child - 1) * span_prev;  // the entry lies in the previous child's first W ticks
             if (i >= 0 && i < W) {
-                o += Cp[(child - 1) * W + i];
-                e = Ep[(child - 1) * W + i];
+                if constexpr (PACKED) {
+                    uint32_t c2;
+                    vx_unpack0(Ep[(child - 1) * W + i], child - 1, span_prev, &e, &c2);
+                    o += c2;
+                } else {
+                    o += Cp[(child - 1) * W + i];
+                    e = Ep[(child - 1) * W + i];
+                }
             }
         }
         ent_p[child] = e;
@@ -347,14 +429,17 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
         if (lds > 64 * 1024)
             FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vx_level0<AF64, S, W, THREADS, PAD>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_vx_level0<AF64, S, W, THREADS, PAD><<<(unsigned)nblk0, THREADS, lds, ctx->stream>>>(a, n, thr, nxt16, E[0], C[0], d_root,
-                                                                                             d_status);
+        k_vx_level0<AF64, S, W, THREADS, PAD><<<(unsigned)nblk0, THREADS, lds, ctx->stream>>>(a, n, thr, nxt16, E[0], d_root, d_status);
     }
     FMK_LAUNCH_CHECK(ctx);
     // the status is known after level 0; the level-ups are cheap (N W / (S RAD) entries and less) and run regardless
     for (int k = 1; k <= K; ++k) {
-        k_vx_level_up<<<dim3((unsigned)nblk[k], (unsigned)fmk_ceil_div(W, 256)), 256, 0, ctx->stream>>>(
-            W, E[k - 1], C[k - 1], nblk[k - 1], spanq[k - 1], E[k], C[k], nblk[k], d_status, RAD);
+        if (k == 1)
+            k_vx_level_up<true><<<dim3((unsigned)nblk[k], (unsigned)fmk_ceil_div(W, 256)), 256, 0, ctx->stream>>>(
+                W, E[0], nullptr, nblk[0], spanq[0], E[k], C[k], nblk[k], d_status, RAD);
+        else
+            k_vx_level_up<false><<<dim3((unsigned)nblk[k], (unsigned)fmk_ceil_div(W, 256)), 256, 0, ctx->stream>>>(
+                W, E[k - 1], C[k - 1], nblk[k - 1], spanq[k - 1], E[k], C[k], nblk[k], d_status, RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail + 32, 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -368,9 +453,9 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     if (root != VOL_END) {
         if ((int64_t)root >= W) return 1;
         uint32_t cnt = 0;
-        FMK_HIP(ctx, hipMemcpyAsync(&cnt, C[K] + root, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&cnt, (K == 0 ? E[0] : C[K]) + root, 4, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        closes = cnt;
+        closes = K == 0 ? cnt >> 16 : cnt;                           // (a single block: the packed level-0 row itself)
     }
     c.count = closes + 1;
     if (c.dbuf && c.cap < c.count) { FMK_HIP(ctx, hipFree(c.dbuf)); c.dbuf = nullptr; }
@@ -379,8 +464,12 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     FMK_HIP(ctx, hipMemcpyAsync(ent[K], &root, 4, hipMemcpyHostToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(off[K], &one, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int k = K; k >= 1; --k) {
-        k_vx_descend<<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
-            W, ent[k], off[k], nblk[k], spanq[k - 1], E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1], RAD);
+        if (k == 1)
+            k_vx_descend<true><<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+                W, ent[k], off[k], nblk[k], spanq[0], E[0], nullptr, nblk[0], ent[0], off[0], RAD);
+        else
+            k_vx_descend<false><<<(unsigned)fmk_ceil_div(nblk[k], 256), 256, 0, ctx->stream>>>(
+                W, ent[k], off[k], nblk[k], spanq[k - 1], E[k - 1], C[k - 1], nblk[k - 1], ent[k - 1], off[k - 1], RAD);
         FMK_LAUNCH_CHECK(ctx);
     }
     k_vx_emit<<<(unsigned)fmk_ceil_div(nblk0, 256), 256, 0, ctx->stream>>>(S, ent[0], off[0], nblk0, nxt16, c.dbuf, c.cap);

@@ -410,6 +410,24 @@ def test_volume_fast_walk_next_to_an_amount_that_dwarfs_the_threshold(orc, big):
     assert unc < len(want) // 4, "the magnitude term must stay local to the chunks next to the large amounts"
 
 
+def test_volume_bar_of_small_trades_right_behind_a_block_trade(orc):
+    """tools/fuzz_volume.py seed 5202 case 241 (round 5): tenth lots with a few trades of ~7e11 in 1.7e6 ticks, threshold 1000.  One
+    block trade closes its bar, and the ~2000-tick bar of tenth lots that starts right behind it -- in the same 512-tick prefix
+    block -- ends on a sum of 1000.0000055: the block-local prefixes behind 7e11 are good to 1e-4, the margin of the global-table
+    and chain-walk tiers knew only about 1e-11 x the threshold, and the close came out one tick late, certified."""
+    from finmlkit_amd import engine
+    from tools import fuzz_case
+    dist, a, px, thr = fuzz_case.regenerate(5202, 241, 3_000_000, "volume")
+    assert dist == "decimal" and a.dtype == np.float64 and len(a) == 1738199 and thr == 1000.0
+    want = orc._volume_bar_indexer(a, thr)
+    t = engine.DeviceTrades.from_numpy(np.arange(len(a), dtype=np.int64), px, a)
+    got = t.volume_bar_index(thr).to_host()
+    np.testing.assert_array_equal(got, want)
+    assert t.last_uncertified == 0
+    fast, unc = _fast_mode(t, thr)
+    assert np.array_equal(fast, want) or unc > 0
+
+
 def _dollar_path():
     import ctypes as C
     from finmlkit_amd import _ffi
