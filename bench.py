@@ -56,6 +56,49 @@ def kernel_source_sha256():
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def csrc_sha256():
+    """Identity of ALL kernel sources (the per-config traffic figures of profiles/traffic_other_configs.json carry the value they were
+    measured at; tools/cfgprof_summarize.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "finmlkit_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def _other_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_other_configs.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def config_roofline(key, kernel_ms, alg_bytes, note=None):
+    """The roofline object of one secondary config: `kernel_ms` is DEVICE time of the library call(s), a HIP-event pair on the
+    context's stream (fmk_timer_start / fmk_timer_stop: from the first enqueue to the last completion, the host round trips
+    inside a call included -- what a caller waits for, minus the Python around it); `traffic` and `dominant_kernel` come from the
+    OFFLINE rocprofv3 passes of the same call (tools/cfgprof.py: --kernel-trace --stats, and --pmc FETCH_SIZE / WRITE_SIZE in
+    their own runs), with the hash of the kernel sources they were measured at."""
+    tr = _other_traffic().get(key) or {}
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    stale = (tr.get("csrc_sha256") != csrc_sha256()) if tr else None
+    r = {"bound": "hbm", "algorithmic_bytes": alg_bytes, "kernel_ms": kernel_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "dominant_kernel": tr.get("dominant_kernel"), "dominant_kernel_ms": tr.get("dominant_kernel_ms"),
+         "kernels_ms_offline": tr.get("kernels_ms"),
+         "traffic": tr.get("traffic_bytes"), "traffic_stale": stale,
+         "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE (x2, profiles/pmc_calibration.txt) + WRITE_SIZE over the kernels of one call "
+                            f"(tools/cfgprof.py {key}; sources sha256 {str(tr.get('csrc_sha256'))[:12]}); kernel stats of the same command: "
+                            f"profiles/r05_{key}_kernel_stats.csv") if tr else None}
+    if note:
+        r["note"] = note
+    return r
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,10 +115,13 @@ def parse():
                          "(ncclSend/ncclRecv to self), plus the boundary-bar launches -- the per-step overhead of the "
                          "multi-GPU path measured on one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"], help="halo transport (host: staged, tests)")
-    ap.add_argument("--placements", type=int, default=7,
-                    help="size of the placement probe: the input columns as first allocated + every 4 GiB of ONE allocation that would hold "
-                         "N-1 copies of them (7: 120 GiB, 26 positions), each probed with a few steps; the timed region runs on the fastest; "
-                         "roofline.frac_min / frac_max report the spread (1: no choice)")
+    ap.add_argument("--placements", type=int, default=1,
+                    help="1 (default): the headline is measured on the input columns AS THE LIBRARY ALLOCATED THEM.  K > 1: the columns go through "
+                         "DeviceTrades.place() (finmlkit_amd/engine.py: K positions, one every 16 GiB of ONE allocation, probed with the step) "
+                         "BEFORE the timed region and the headline is measured on the chosen position -- a diagnostic, roofline.placement says so")
+    ap.add_argument("--placed-probe", type=int, default=7,
+                    help="after the timed region (1 GPU): the same step on columns placed by the library's opt-in DeviceTrades.place() with this many "
+                         "positions -> roofline.placed (0: skip); never part of `value` / `frac`")
     ap.add_argument("--separate-index", action="store_true",
                     help="the step as two library calls (time-bar indexer kernels, then OHLCV + median) instead of the one-launch "
                          "fmk_time_bars_ohlcv_dev -- for A/B timing")
@@ -136,17 +182,29 @@ def other_configs(trades, ctx, args):
     from finmlkit_amd._ffi import DeviceArray, c_i64
     out = {}
 
-    def timed(fn, reps=3):
+    dev_ms = {}
+
+    def timed(fn, reps=3, key=None):
+        """best-of-`reps` host wall time (ms); with `key`, also the best DEVICE time of the call -- a HIP-event pair on the context's
+        stream (fmk_timer_start / _stop) -- kept in dev_ms[key] for the config's roofline object"""
         best = None
         for _ in range(reps):
             ctx.sync()
             t0 = time.perf_counter()
+            if key:
+                ctx.timer_start()
             r = fn()
+            if key:
+                d = ctx.timer_stop()
+                dev_ms[key] = d if key not in dev_ms else min(dev_ms[key], d)
             ctx.sync()
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
             del r
         return best
+
+    def levels_of(fused):
+        return int(fused[4]["price_levels"].n)
 
     try:
         n = trades.n
@@ -159,20 +217,20 @@ def other_configs(trades, ctx, args):
         del o
         # volume bars: the library's default (exact) mode -- fragile decisions on the chain of closes are replayed with the
         # reference's sequential sum, so the count that comes back is 0 unless a replay disagreed
-        out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr))
+        out["cfg3_volume_bar_index_ms"] = timed(lambda: trades.volume_bar_index(vthr), key="cfg3_volume_index")
         out["cfg3_volume_uncertified"] = int(trades.last_uncertified)
         out["cfg3_n_volume_bars"] = int(trades.volume_bar_index(vthr).n)
         # SURVEY 8(d)'s unit for cfg 3 -- indexer AND reducer, 12 algorithmic B/tick: close indices, then OHLCV + median over them
-        out["cfg3_volume_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.volume_bar_index(vthr), want_median=True))
+        out["cfg3_volume_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.volume_bar_index(vthr), want_median=True), key="cfg3_volume_build_ohlcv")
         # dollar bars, default (exact) mode as well: closed form + exact tier (csrc/fmk_dollar_exact.hip: the reference's
         # float64 running sum reconstructed at every bar start, fragile bars replayed) -- n_uncertified comes back 0.  The
         # closed form alone (fmk_ctx_set_fast_threshold(1)) is timed next to it with the count of decisions it cannot certify
-        out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
+        out["cfg3_dollar_bar_index_ms"] = timed(lambda: trades.dollar_bar_index(dthr), key="cfg3_dollar_index")
         out["cfg3_dollar_uncertified"] = int(trades.last_uncertified)
         out["cfg3_dollar_exact"] = out["cfg3_dollar_uncertified"] == 0
         exact_idx = trades.dollar_bar_index(dthr)
         out["cfg3_n_dollar_bars"] = int(exact_idx.n - 1)
-        out["cfg3_dollar_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.dollar_bar_index(dthr), want_median=True))
+        out["cfg3_dollar_build_ohlcv_ms"] = timed(lambda: trades.bar_ohlcv(trades.dollar_bar_index(dthr), want_median=True), key="cfg3_dollar_build_ohlcv")
         ctx.set_fast_threshold(True)
         try:
             out["cfg3_dollar_closed_form_only_ms"] = timed(lambda: trades.dollar_bar_index(dthr))
@@ -184,7 +242,8 @@ def other_configs(trades, ctx, args):
         finally:
             ctx.set_fast_threshold(False)
         del exact_idx
-        out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0))
+        out["cfg4_ohlcv_directional_footprints_ms"] = timed(lambda: trades.bars_fused(ci, 0.01, 3.0), key="cfg4_equal_bars")
+        lv_eq = levels_of(trades.bars_fused(ci, 0.01, 3.0))
         out["cfg4_bytes_per_tick"] = 30      # 13 (order flow + OHLC, one lane per bar) + 4 (median of the amounts) + 13 (footprints)
         # the same pass on amounts with a full random float32 mantissa: the footprint level sums are then inexact in every
         # order and every bar takes the tick-ordered accumulation (the synthetic stream's dyadic amounts all certify for the
@@ -192,7 +251,7 @@ def other_configs(trades, ctx, args):
         am2 = DeviceArray(ctx, n, np.float32)
         ctx.call("fmk_diag_fill_amounts_dev", C.c_uint64(args.seed), c_i64(n), am2.p)
         t2 = engine.DeviceTrades(ctx, trades.ts, trades.price, am2, trades.side)
-        out["cfg4_full_mantissa_amounts_ms"] = timed(lambda: t2.bars_fused(ci, 0.01, 3.0))
+        out["cfg4_full_mantissa_amounts_ms"] = timed(lambda: t2.bars_fused(ci, 0.01, 3.0), key="cfg4_equal_bars_full_mantissa")
         # cfg 4 on bars of HEAVY-TAILED lengths (lognormal, mean 1 200 ticks, sigma 1: what real one-minute bars look like;
         # profiles/r03_real_bar_lengths.txt) -- the synthetic clock's own bars are all ~1 200 ticks long
         rng = np.random.default_rng(7)
@@ -200,7 +259,8 @@ def other_configs(trades, ctx, args):
         ci_h = np.concatenate([[-1], np.cumsum(lens) - 1])
         ci_r = DeviceArray.from_host(ctx, ci_h[ci_h <= n - 1].astype(np.int64))
         out["cfg4_lognormal_bar_lengths_ms"] = timed(lambda: trades.bars_fused(ci_r, 0.01, 3.0), reps=2)
-        out["cfg4_lognormal_bar_lengths_full_mantissa_ms"] = timed(lambda: t2.bars_fused(ci_r, 0.01, 3.0), reps=2)
+        out["cfg4_lognormal_bar_lengths_full_mantissa_ms"] = timed(lambda: t2.bars_fused(ci_r, 0.01, 3.0), reps=2, key="cfg4_lognormal_full_mantissa")
+        lv_ln, nb_ln = levels_of(t2.bars_fused(ci_r, 0.01, 3.0)), int(ci_r.n) - 1
         del ci_r
         # cfg 4 at the ends of the bar-length axis (hourly / daily bars: a workgroup per bar; tools/intervalbench.py has every length)
         for label, iv in (("hourly", 3600.0), ("daily", 86400.0)):
@@ -219,9 +279,9 @@ def other_configs(trades, ctx, args):
         # quiet tape a close per 2.4e5 ticks, served by the chain walk of fmk_cusum_chain.hip; 1e-5: a close per ~200 ticks, the
         # fixed point), and the order-flow features on the 1-second bars of io.py:484 (one lane per bar)
         ret = trades.lagged_returns(5.0, True)
-        out["lagged_returns_5s_ms"] = timed(lambda: trades.lagged_returns(5.0, True))
+        out["lagged_returns_5s_ms"] = timed(lambda: trades.lagged_returns(5.0, True), key="lagged_returns_5s")
         sig = trades.ewmst(ret, 60.0)
-        out["ewmst_60s_ms"] = timed(lambda: trades.ewmst(ret, 60.0))
+        out["ewmst_60s_ms"] = timed(lambda: trades.ewmst(ret, 60.0), key="ewmst_60s")
         del ret
         cus = DeviceArray(ctx, 8_000_000 if n >= 1_000_000_000 else max(n, 16), np.int64)
         m, rounds = c_i64(), c_i64()
@@ -267,6 +327,20 @@ def other_configs(trades, ctx, args):
                                    "same-host comparison")
         except Exception as e:                                           # noqa: BLE001
             out["api_39M_error"] = f"{type(e).__name__}: {e}"
+        # ---- roofline objects of the secondary configs (SURVEY 8(d)'s algorithmic bytes; DEVICE time by HIP events, best of the reps)
+        nb60 = int(ci.n) - 1
+        nvb, ndb = out["cfg3_n_volume_bars"] - 1, out["cfg3_n_dollar_bars"]
+        cfg4_bytes = lambda bars, levels: 21 * n + bars * (8 + 60 + 8 + 88 + 8 + 26) + levels * 22     # noqa: E731  close idx, OHLCV + median, order flow, level offsets + per-bar footprint features; 22 B per footprint level (the output dtypes of base.py:675-697)
+        alg = {"cfg3_volume_index": 4 * n + 8 * (nvb + 1), "cfg3_volume_build_ohlcv": 12 * n + (8 + 68) * nvb,
+               "cfg3_dollar_index": 12 * n + 8 * (ndb + 1), "cfg3_dollar_build_ohlcv": 12 * n + (8 + 68) * ndb,
+               "cfg4_equal_bars": cfg4_bytes(nb60, lv_eq), "cfg4_equal_bars_full_mantissa": cfg4_bytes(nb60, lv_eq),
+               "cfg4_lognormal_full_mantissa": cfg4_bytes(nb_ln, lv_ln),
+               "lagged_returns_5s": 24 * n, "ewmst_60s": 24 * n}
+        notes = {"cfg3_volume_build_ohlcv": "SURVEY 8(d): indexer + reducer fused would read amount once with price: 12 B/tick; the build makes two calls (4 + 12)",
+                 "cfg3_dollar_build_ohlcv": "SURVEY 8(d): 12 B/tick for indexer + reducer; the build makes two calls (12 x 2 + 12)",
+                 "cfg4_lognormal_full_mantissa": "the primary cfg 4 figure: bars of lognormal length (sigma 1), sizes with a full float32 mantissa",
+                 "ewmst_60s": "16 B/tick read (ts, returns) + 8 written", "lagged_returns_5s": "16 B/tick read (ts, price) + 8 written"}
+        out["roofline"] = {k: config_roofline(k, dev_ms[k], alg[k], notes.get(k)) for k in alg if k in dev_ms}
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only
@@ -289,64 +363,29 @@ def _probe_step_kernel_ms(ctx, fn, steps):
     return sum(k[i] for i in range(kn.value)) / steps
 
 
-def placement_span(n):
-    """Bytes one set of columns takes inside the placement slab (ts, price, amount, side on 2 MiB boundaries, rounded up to 1 GiB)."""
-    return (21 * n + (8 << 20) + (1 << 30) - 1) // (1 << 30) * (1 << 30)
+def choose_placement(ctx, trades, args, rank, n, step_of, positions):
+    """The library's opt-in placement (engine.DeviceTrades.place): the columns copied to `positions` - 1 places, 16 GiB apart, of ONE
+    allocation, each probed with the bench's own step (device time by HIP events); the fastest stays.  Then the chosen copy is run until
+    its level has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before): the first passes over new memory run
+    up to 10 % slower than the level they settle at (profiles/r04_step_timeline.txt).  Set-up, not a step.
+    -> (the chosen trade set, {"probe_ms": [...], "offset_gib": [...], "chosen": k, "settle_kernel_ms": [...]})."""
+    fns = {}
 
+    def probe(t):
+        if id(t) not in fns:
+            fns[id(t)] = step_of(t)
+        fns[id(t)]()
 
-def choose_placement(ctx, trades, args, rank, n, step_of):
-    """WHERE the input columns lie in device memory sets the level of the dominant kernel: whole physical blocks of 16 .. 128 GiB are 8 .. 10 %
-    "slow" for it, and small separate allocations land in them more often than one large one does (profiles/r04_placement_regions.txt).  So:
-    ONE slab of K x 20 GiB, the same ticks synthesised at positions of it (every 4 GiB); every position (and the separately allocated columns
-    the run started with) is probed with the bench's own step (3 untimed + 8 timed passes, kernel time by HIP events); the fastest stays.  Then the
-    chosen copy is run until its level has settled (blocks of 5 steps, until one is not 0.5 % faster than the one before; at most 40 steps):
-    the first passes over new memory run up to 10 % slower than the level they settle at (profiles/r04_step_timeline.txt).  All of it is
-    set-up, before the warm-up; -> (the chosen copy, {"probe_kernel_ms": [...], "chosen": k, "settle_kernel_ms": [...]})."""
-    import numpy as np
-    from finmlkit_amd import engine
-    from finmlkit_amd._ffi import DeviceArray
-    k_pos = args.placements - 1
-    span = placement_span(n)
-    slab = None
-    while k_pos > 0 and slab is None:                       # (a refused allocation is not an error here: fewer positions, or none)
-        try:
-            slab = DeviceArray(ctx, k_pos * span, np.uint8)
-        except Exception as e:                              # noqa: BLE001
-            print(f"[bench] rank {rank}: no {k_pos * span >> 30} GiB for the placement probes ({e}); trying fewer", file=sys.stderr)
-            k_pos -= 2
-    if slab is None:
-        return trades, None
-    # positions every 4 GiB of the slab (they overlap: the ticks are synthesised at one position, probed, then at the next; the best position
-    # is synthesised again at the end) -- the slow stretches are 16 GiB and more wide and begin at any multiple of 16 GiB from the slab's start,
-    # so a 20 GiB set of columns that must avoid them needs a finer grid than its own length
-    stride = 4 << 30
-    offsets = list(range(0, k_pos * span - span + 1, stride))
-    ms = []
-    fn = step_of(trades)
-    for _ in range(3):
-        fn()
-    ms.append(_probe_step_kernel_ms(ctx, fn, 8))
-    for off in offsets:
-        t = engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, off))
-        fn = step_of(t)
-        for _ in range(3):
-            fn()
-        ms.append(_probe_step_kernel_ms(ctx, fn, 8))
-    best = min(range(len(ms)), key=lambda i: ms[i])
-    chosen = trades if best == 0 else engine.DeviceTrades.synth(n, seed=args.seed, first=rank * n, ctx=ctx, into=(slab, offsets[best - 1]))
-    # Nothing is freed: releasing the 120 GiB slab after the probes moved the level of the OTHER allocation from 2.135 to 2.19 ms in one run
-    # (profiles/r04_sharded_step.txt) -- the state the probes saw is the state the run keeps.  (~150 GB of 288 held; the extras need < 40.)
-    chosen._placement_keep = (slab, trades)
+    chosen, info = trades.place(probe, positions=positions)
     fn = step_of(chosen)
     settle = [_probe_step_kernel_ms(ctx, fn, 5)]
     while len(settle) < 8:
         settle.append(_probe_step_kernel_ms(ctx, fn, 5))
         if settle[-1] > settle[-2] * 0.995:
             break
-    info = {"policy": f"the columns as first allocated (probe 0) and at {len(offsets)} positions, every 4 GiB, of one {k_pos * span >> 30} GiB "
-                      "allocation, each probed by 8 steps of the step's dominant kernel; the fastest stays and is run until its level settles "
-                      "(set-up, before the warm-up)",
-            "probe_kernel_ms": ms, "probe_offset_gib": [None] + [o >> 30 for o in offsets], "chosen": best, "settle_kernel_ms": settle}
+    info["settle_kernel_ms"] = settle
+    info["policy"] = (f"finmlkit_amd.engine.DeviceTrades.place(probe, positions={positions}): the columns as allocated (position 0) and copied to "
+                      f"{len(info['probe_ms']) - 1} places, 16 GiB apart, of one allocation; each probed with the step (HIP events), the fastest kept")
     return chosen, info
 
 
@@ -418,11 +457,48 @@ def main():
     sys.exit(rc)
 
 
+class _Tee:
+    """sys.stderr of a rank of a multi-rank run: everything also goes to the rank's own log file"""
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def write(self, x):
+        self.a.write(x)
+        self.b.write(x)
+        self.b.flush()
+        return len(x)
+
+    def flush(self):
+        self.a.flush()
+        self.b.flush()
+
+
+def rank_log(rank, world):
+    """N > 1: every rank keeps its own record -- gpurun_out/bench_rank<r>.log (what this process writes to stderr: the transport it
+    got, a fallback and its reason) and gpurun_out/bench_rank<r>.rccl.log (librccl's own NCCL_DEBUG output) -- next to the files the
+    driver pulls, so that a run that fell back or died says why (VERDICT r4 next #5).  FMK_BENCH_LOGDIR overrides the directory."""
+    if world <= 1:
+        return
+    d = os.environ.get("FMK_BENCH_LOGDIR") or os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        fh = open(os.path.join(d, f"bench_rank{rank}.log"), "w")
+    except OSError:
+        return
+    sys.stderr = _Tee(sys.stderr, fh)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    if os.environ.get("NCCL_DEBUG_FILE", "/dev/stderr") == "/dev/stderr":
+        os.environ["NCCL_DEBUG_FILE"] = os.path.join(d, f"bench_rank{rank}.rccl.log")
+    print(f"[bench] rank {rank} of {world}: pid {os.getpid()}, LOCAL_RANK {os.environ.get('LOCAL_RANK')}, "
+          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, args {sys.argv[1:]}", file=sys.stderr)
+
+
 def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    rank_log(rank, world)
     # developer switch for boxes with ONE GPU: every rank on device 0.  RCCL refuses a communicator with two ranks on one
     # device, so this switch ASKS for the host-staged transport (config.transport says so) -- it exercises the N > 1 flow end
     # to end (spawn, rendezvous, plan, exchange, boundary bar, gathers), not xGMI
@@ -463,6 +539,8 @@ def run(args):
         transport = args.transport
         try:
             comm = Comm(ctx, rank, world, path, transport, self_loop=(world == 1))
+            if world > 1:
+                print(f"[bench] rank {rank}: communicator up, transport {transport}", file=sys.stderr)
         except _ffi.FmkError as e:
             if transport != "rccl":
                 raise
@@ -502,28 +580,25 @@ def run(args):
         _pre.step(comm)
         ctx.sync()
         comm.sync()
-    # (as many of the requested positions as fit beside 8 GiB of working memory)
-    args.placements = max(1, min(args.placements, 1 + int((free - need - (8 << 30)) // placement_span(n))))
+    def step_of(t):
+        t0, t1 = t.first_last_ts()
+        ne, e0, d = clock_of(t0, t1)
+        ensure_buffers(ne)
+        if args.separate_index:
+            def fn():
+                clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
+                t.bar_ohlcv(ci, want_median=want_median, out=state["out"])
+        else:
+            def fn():
+                t.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
+                                  out_index=(state["clock"], state["idx"]), out=state["out"])
+        return fn
+
     if args.placements > 1:
-        # WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-5 % between allocations of one
-        # process, constant for the life of an allocation: profiles/r04_placement.txt, r04_drift.txt).  Set-up, not a step: K
-        # copies of the same ticks, each probed with the step itself; the fastest stays, the others are freed.  Every rank of a
-        # sharded run does the same for its own shard (the probe is the shard's bars without the exchange: the same kernel over
-        # the same columns) -- the job's step is the MAX over ranks, so one rank on a slow allocation would set it.
-        def step_of(t):
-            t0, t1 = t.first_last_ts()
-            ne, e0, d = clock_of(t0, t1)
-            ensure_buffers(ne)
-            if args.separate_index:
-                def fn():
-                    clock, ci = t.time_bar_index(args.interval, clock_params=(ne, e0, d), out=(state["clock"], state["idx"]))
-                    t.bar_ohlcv(ci, want_median=want_median, out=state["out"])
-            else:
-                def fn():
-                    t.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
-                                      out_index=(state["clock"], state["idx"]), out=state["out"])
-            return fn
-        trades, placement = choose_placement(ctx, trades, args, rank, n, step_of)
+        # opt-in diagnostic: WHERE the 21 GB of input columns land decides the level of the dominant kernel (+-5 % between allocations
+        # of one process, constant for the life of an allocation: profiles/r04_placement.txt).  The default run does NOT do this: its
+        # headline is what the library delivers on the columns as it allocated them.
+        trades, placement = choose_placement(ctx, trades, args, rank, n, step_of, args.placements)
 
     if use_dist:
         # SET-UP, not a step: the plan (global clock, edge partition, halo lengths, boundary buffers) is a function of
@@ -582,14 +657,24 @@ def run(args):
     kms = (C.c_double * 256)()
     kn = C.c_int()
     ctx.call("fmk_profile_read", kms, C.c_int(256), C.byref(kn))
+    total_launches = c_i64()
+    ctx.call("fmk_profile_count", C.byref(total_launches))
     ctx.call("fmk_profile_enable", C.c_int(0))
 
     k_ms = [kms[i] for i in range(kn.value)]
     # the pipelined time-bar step launches the dominant kernel TWICE per step (the first eighth of the bars, then the rest): the
     # kernel time of a step is the sum of its launches, each timed on its own (the bubble between them is not kernel time)
-    lps = max(1, round(len(k_ms) / args.steps)) if len(k_ms) % args.steps == 0 else 1
+    # launches per step from the library's own count (with steps x launches > 256 the ring of event pairs wraps; the
+    # ring then holds the LAST 256 launches, oldest at slot total mod 256 -- put them in order and keep whole steps)
+    total_launches = int(total_launches.value)
+    lps = total_launches // args.steps if args.steps and total_launches % args.steps == 0 and total_launches >= args.steps else 1
+    if total_launches > len(k_ms):
+        start = total_launches % len(k_ms)
+        k_ms = k_ms[start:] + k_ms[:start]
     if lps > 1:
-        k_ms = [sum(k_ms[i * lps:(i + 1) * lps]) for i in range(len(k_ms) // lps)]
+        whole = len(k_ms) // lps
+        k_ms = k_ms[len(k_ms) - whole * lps:]
+        k_ms = [sum(k_ms[i * lps:(i + 1) * lps]) for i in range(whole)]
     avg_k_ms = sum(k_ms) / len(k_ms)
     per_rank = None
     if comm:
@@ -668,11 +753,10 @@ def run(args):
                          "kernel_ms_min": min(k_ms), "kernel_ms_max": max(k_ms),
                          "launches_timed": len(k_ms) * lps},
         }
+        line["roofline"]["columns"] = ("as the library allocated them (default)" if not placement else
+                                       "placed by DeviceTrades.place() before the timed region (--placements: a diagnostic run)")
         if placement:
-            # the same fraction for every allocation probed (frac = algorithmic bytes / probe time / peak): what the run would have
-            # reported on the slowest / the fastest of them
-            fr = [alg_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in placement["probe_kernel_ms"]]
-            line["roofline"].update({"frac_min": min(fr), "frac_max": max(fr), "placement": placement})
+            line["roofline"]["placement"] = placement
         if per_rank:
             ms = per_rank["ms_per_step"]
             line["per_rank"] = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step": ms,
@@ -684,6 +768,31 @@ def run(args):
         if transport_note:
             line["config"]["transport_note"] = transport_note
             line["valid"] = False
+        if world == 1 and not use_dist and not placement and args.placed_probe > 1:
+            # AUXILIARY, after the timed region and outside `value` / `frac`: the same step on columns placed by the library's opt-in
+            # DeviceTrades.place() -- what a caller who asks for it gets (the headline above is the default: columns as allocated)
+            try:
+                placed, pinfo = choose_placement(ctx, trades, args, rank, n, step_of, args.placed_probe)
+                fnp = step_of(placed)
+                pk = _probe_step_kernel_ms(ctx, fnp, args.steps)
+                ctx.sync()
+                tp0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fnp()
+                ctx.sync()
+                p_ms = (time.perf_counter() - tp0) / args.steps * 1e3
+                fr_all = [alg_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in pinfo["probe_ms"]]
+                line["roofline"]["frac_as_allocated"] = line["roofline"]["frac"]
+                line["roofline"]["placed"] = {
+                    "entry_point": "finmlkit_amd.engine.DeviceTrades.place(probe, positions)", "frac": alg_bytes / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel_ms": pk, "ms_per_step": p_ms, "probe_step_ms": pinfo["probe_ms"], "probe_offset_gib": pinfo["offset_gib"],
+                    "chosen": pinfo["chosen"], "settle_kernel_ms": pinfo["settle_kernel_ms"],
+                    "probe_frac_of_step_ms_min_max": [min(fr_all), max(fr_all)],
+                    "note": "opt-in, set-up once per trade set (positions x one device-to-device copy of the columns + the probes); "
+                            "NOT the headline: `frac` / `value` are measured on the columns as allocated"}
+                del placed, fnp
+            except Exception as e:                                   # noqa: BLE001 -- auxiliary
+                line["roofline"]["placed"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
             if not args.no_extras:

@@ -379,6 +379,15 @@ int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on)
     return FMK_OK;
 }
 
+// launches timed since fmk_profile_enable(1): more than FMK_PROFILE_SLOTS means the ring has wrapped -- slot i then holds launch
+// number (total - FMK_PROFILE_SLOTS + ((i - total) mod FMK_PROFILE_SLOTS)), i.e. the last FMK_PROFILE_SLOTS launches, oldest at
+// slot total mod FMK_PROFILE_SLOTS
+int fmk_profile_count(fmk_ctx *ctx, int64_t *total)
+{
+    *total = ctx->profile_n;
+    return FMK_OK;
+}
+
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count)
 {
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -233,6 +233,17 @@ extern "C" int fmk_diag_fill_amounts_dev(fmk_ctx *ctx, uint64_t seed, int64_t n,
     return FMK_OK;
 }
 
+// A one-thread kernel whose name tools/cfgprof_summarize.py looks for in a rocprofv3 trace: `which` = 1 opens the measured region of
+// tools/cfgprof.py, 2 closes it (the dispatches between the two are the config's, everything else is set-up).
+__global__ void k_diag_marker(int which, int *sink) { if (sink && which < 0) *sink = which; }
+extern "C" int fmk_diag_marker_dev(fmk_ctx *ctx, int which)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    k_diag_marker<<<1, 1, 0, ctx->stream>>>(which, nullptr);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
 // Diagnostics: the box's host-to-device rate for one buffer of `bytes` -- pinned = 1: from hipHostMalloc memory (the link's
 // ceiling), 0: plain hipMemcpy from malloc'ed memory (what a caller's NumPy array gets without fmk_h2d_columns), 2: fmk_h2d_columns
 // from malloc'ed memory.  Best of three, GB/s.

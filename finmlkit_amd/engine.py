@@ -90,6 +90,72 @@ class DeviceTrades:
         t._headroom = headroom
         return t
 
+    # ------------------------------------------------------------------ placement (opt-in)
+    def place(self, probe, positions: int = 7, stride: int = 16 << 30, reps: int = 6, warm: int = 3):
+        """Opt-in: choose WHERE in device memory the columns lie.  The reducers that stream whole bars (k_bar_ohlcv_small ...) run up to
+        10 % slower when their input columns fall into certain physical blocks of HBM (profiles/r04_placement_regions.txt: whole
+        16 .. 128 GiB stretches, constant for an allocation's life; small separate allocations land in them more often than one
+        large one).  `place` makes ONE allocation that holds `positions` copies' worth of address space, copies the columns to every
+        `stride` bytes of it in turn, times `probe(trades)` -- the caller's own first call, e.g. `lambda t: t.time_bars_ohlcv(60.0)`
+        -- on each with the context's HIP-event timer (`warm` untimed + `reps` timed calls), and returns the trade set at the fastest
+        position (the original columns are left alone and also take part as position 0).
+
+        -> (DeviceTrades, info) with info = {"probe_ms": [...], "offset_gib": [None, 0, ...], "chosen": k}.  The slab stays
+        allocated for the life of the returned object (releasing it moved the level of other allocations: r04_sharded_step.txt).
+        Costs positions x (a device-to-device copy of the columns + the probes): set-up, once per trade set."""
+        ctx = self.ctx
+        cols = [c for c in (self.ts, self.price, self.amount, self.side) if c is not None]
+        span = sum((c.nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) for c in cols)
+        span = (span + (1 << 30) - 1) // (1 << 30) * (1 << 30)
+        # positions 1 .. P-1 lie every `step` bytes of ONE slab (they may overlap: one copy lives at a time, the best is copied again
+        # at the end); as many as fit beside 8 GiB of working memory
+        step = max(int(stride), 2 << 20)
+        free, _ = ctx.mem_info()
+        k = max(0, int(positions) - 1)
+        while k > 0 and (k - 1) * step + span > free - (8 << 30):
+            k -= 1
+        slab = None
+        while k > 0 and slab is None:
+            try:
+                slab = DeviceArray(ctx, (k - 1) * step + span, np.uint8)
+            except Exception:                                        # noqa: BLE001 -- a refused allocation: fewer positions
+                k -= 1
+
+        def timed(t):
+            for _ in range(warm):
+                probe(t)
+            best = None
+            for _ in range(reps):
+                ctx.timer_start()
+                probe(t)
+                ms = ctx.timer_stop()
+                best = ms if best is None else min(best, ms)
+            return best
+
+        def at(off):
+            out, o = [], int(off)
+            for c in cols:
+                out.append(DeviceArray(ctx, c.n, c.dtype, slab.ptr + o, owner=slab))
+                o += (c.nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+            for src, dst in zip(cols, out):
+                ctx.call("fmk_d2d", dst.p, src.p, C.c_size_t(src.nbytes))
+            if self.side is None:
+                out.append(None)
+            t = DeviceTrades(ctx, *out)
+            t._first_last = getattr(self, "_first_last", None)
+            return t
+
+        ms, offs = [timed(self)], [None]
+        if slab is not None:
+            for i in range(k):
+                ms.append(timed(at(i * step)))
+                offs.append(i * step)
+        best = min(range(len(ms)), key=lambda i: ms[i])
+        chosen = self if best == 0 else at(offs[best])
+        if chosen is not self:
+            chosen._placement_keep = (slab, self)
+        return chosen, {"probe_ms": ms, "offset_gib": [None if o is None else o / float(1 << 30) for o in offs], "chosen": best}
+
     def with_halo(self, k: int) -> "DeviceTrades":
         """View that also covers the k elements in front of the shard (already filled by the caller)."""
         assert k <= getattr(self, "_headroom", 0)

