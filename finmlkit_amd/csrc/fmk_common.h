@@ -193,22 +193,37 @@ __device__ __forceinline__ double fmk_amt(const void *p, int64_t j)
 __device__ __forceinline__ int64_t fmk_wrap(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
 
 // log(p / pm) for tick returns (comp_lagged_returns utils.py, _cusum_bar_indexer logic.py:198): the quotient as the reference
-// rounds it, then its logarithm.  Prices a few ticks apart give x = p / pm within 2^-6 of 1, where f = x - 1 is exact and
-// log1p(f) = f + f^2 (-1/2 + f/3 - ... - f^10/12) needs twelve instructions: the last step adds a correction of at most
-// f / 128 to an exact f, so the result is within 0.51 ulp -- tools/logratio_check.c: the same double as glibc's log in all
-// but 4 of a million such quotients, and as often the correctly rounded value as glibc's.  The library log costs ~150
-// instructions per call, which made every kernel that takes tick returns VALU-bound (k_cc_summary 7.0 ms per 1e9 ticks for
-// a 24 B/tick read).  Anything else -- larger moves, zero, negative, non-finite -- goes to the library function.
+// rounds it, then its logarithm -- THE SAME DOUBLE AS THE HOST'S log(), which is what the oracle (and Numba's compiled code) calls.
+// Prices a few ticks apart give x = p / pm next to 1, and for x in [1 - 2^-4, 1 + 0x1.09p-4) glibc's log (2.28 and later:
+// sysdeps/ieee754/dbl-64/e_log.c, the ARM optimized-routines algorithm) does not use its table: r = x - 1, a degree-11 polynomial
+// in r whose leading terms r - r^2 / 2 are formed in double-double, 0.507 ulp.  That branch is restated here operation by
+// operation, with the FMA contractions GCC makes in the `fma` build of libm that x86-64 hosts with FMA3 select (ifunc) --
+// tools/logratio_check.c holds the same restatement in C and compares it with the host's log(): 0 differences on 2e7 price
+// quotients and on a sweep of 5.7e7 arguments across the interval (the non-FMA build of the same source differs from the FMA build
+// in ~8 of 1e6 arguments: the contract is pinned to the FMA build, the one on this image's hosts).  Round 4's own 12-term
+// polynomial differed from glibc in ~4 of 1e6 quotients, which moved CUSUM closes on knife-edge streams (7 of 8 000 fuzz cases).
+// Anything outside the interval -- moves of more than 6 %, zero, negative, non-finite -- goes to the device library's log, which
+// may differ from glibc's table branch in the last bit.
 __device__ __noinline__ static double fmk_log_far(double x) { return log(x); }   // (not inlined: ~150 instructions, rarely run)
+__device__ __forceinline__ double fmk_log_near1(double x)
+{
+    const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+    double q = fma(r3, -0x1.5521375d145cdp-4, fma(r2, 0x1.78182f7afd085p-4, fma(r, -0x1.999eb43b068ffp-4, 0x1.c7184282ad6cap-4)));
+    q = fma(r3, q, fma(r2, -0x1.fffffa4423d65p-4, fma(r, 0x1.24924a344de3p-3, -0x1.55555556745a7p-3)));
+    q = fma(r3, q, fma(r2, 0x1.999999995dd0cp-3, fma(r, -0x1.ffffffffffdcbp-3, 0x1.5555555555577p-2)));
+    double w = r * 0x1p27;
+    const double rhi = r + w - w, rlo = r - rhi;                     // r = rhi + rlo, rhi on 26 bits: rhi * rhi is exact
+    w = rhi * rhi * -0.5;
+    const double hi = r + w;
+    double lo = r - hi + w;
+    lo = fma(-0.5 * rlo, rhi + r, lo);
+    return fma(r3, q, lo) + hi;
+}
 __device__ __forceinline__ double fmk_log_ratio(double p, double pm)
 {
-    const double x = p / pm, f = x - 1.0;
-    if (!(fabs(f) <= 0.015625)) return fmk_log_far(x);
-    double q = -1.0 / 12.0;
-    q = fma(f, q, 1.0 / 11.0); q = fma(f, q, -1.0 / 10.0); q = fma(f, q, 1.0 / 9.0); q = fma(f, q, -1.0 / 8.0);
-    q = fma(f, q, 1.0 / 7.0); q = fma(f, q, -1.0 / 6.0); q = fma(f, q, 1.0 / 5.0); q = fma(f, q, -1.0 / 4.0);
-    q = fma(f, q, 1.0 / 3.0); q = fma(f, q, -0.5);
-    return fma(f * f, q, f);
+    const double x = p / pm;
+    if (!(x >= 0.9375 && x < 0x1.109p+0)) return fmk_log_far(x);     // [1 - 2^-4, 1 + 0x1.09p-4): glibc's table-free branch
+    return fmk_log_near1(x);
 }
 
 // splitmix64-style counter hash shared with oracle/fmk_oracle.c (orc_mix64)

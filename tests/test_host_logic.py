@@ -143,3 +143,23 @@ def test_close_indices_out_of_range_are_refused_before_any_device_work():
             base.comp_bar_directional_features(px, am, ci, sd)
         with pytest.raises(IndexError, match="out of bounds"):
             base.comp_bar_footprints(px, am, ci, sd, 0.5, px[:len(ci) - 1], px[:len(ci) - 1], 3.0)
+
+
+def test_device_logarithm_is_the_hosts_logarithm(tmp_path):
+    """The logarithm of tick returns on the device (fmk_log_near1, csrc/fmk_common.h) is an operation-by-operation restatement of the
+    table-free branch of glibc's log in libm's FMA build; tools/logratio_check.c holds the same sequence in C and compares it with THIS
+    host's log() -- the function the oracle calls -- on 2e6 price quotients and a sweep of the interval: no difference allowed.  (A host
+    without FMA3 runs libm's generic build, which differs from the FMA build on ~6 arguments in 1e5: the contract is the FMA build.)"""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("host without FMA3: its libm runs the generic build of log")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "logratio_check")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", os.path.join(root, "tools", "logratio_check.c"), "-o", exe, "-lm"])
+    r = subprocess.run([exe, "2000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "0 of" in r.stdout
