@@ -632,43 +632,111 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
 // tile a workgroup waits for belongs to a resident workgroup that only ever waits for EARLIER tiles.  Spins are bounded: a
 // tile that never shows up raises a sticky error word in pinned host memory (reported by the next fmk_ctx_sync / fmk_d2h)
 // instead of hanging the device.
-typedef __attribute__((address_space(1))) unsigned long long ew_gu64;
-#define EW_GRAN 12                       // 6 doubles = 12 words
 #define EW_SPIN_LIMIT (1u << 22)
+#define EW_W1 64                         // tiles one R record covers
 
-__device__ __forceinline__ void ew_publish(unsigned long long *g, const EwMap &m, int lane)
+// Round 5: the look-back in TWO memory round trips whatever the number of tiles in flight (the scheme of fmk_dollar_onepass.h, for maps
+// instead of sums).  Round 2's version walked back one tile per dependent cross-XCD round trip: 25.9 ms per 1e9 ticks against 16.0 for
+// the two passes.  Per tile three records of six doubles, each written ONCE, each with its own tag word in a compact tag array (a poll
+// reads 64 consecutive tags, not 64 records):
+//   A[t]  the tile's own map                      R[t]  the composition of A over the 64 tiles in front of t
+//   P[t]  the composition of A over ALL tiles in front of t (its exclusive prefix)
+// Writer: the record's granules, then the tag, all relaxed.  Reader: the tag (polled), then the granules until each is valid.
+// Lane l of the look-back waits for A[t - 1 - l] and, at the same time, for P or R of tile u_l = t - 64 (l + 1); R(u_l) covers the tiles
+// [u_l - 64, u_l), so prefix(t) = P(u_f) then R(u_{f-1}) ... R(u_0) then R(t), f the nearest lane whose tile already has its prefix.
+// R and P lie residue-major (slot = (t mod 64) * groups + t / 64): the 64 tags one look-back polls are consecutive.
+struct EwDesc {
+    unsigned long long *tagA, *tagR, *tagP;
+    unsigned long long *A, *R, *P;       // [tiles][12] granules (R, P: by slot)
+    int64_t groups;
+};
+__device__ __forceinline__ int64_t ew_slot(int64_t t, int64_t groups) { return (t & (EW_W1 - 1)) * groups + t / EW_W1; }
+
+// A record is twelve {valid, 32-bit word} granules (the data IS the flag: no fence -- a release / acquire fence at agent scope writes
+// back / invalidates the whole L2, which cost this kernel 59 ms per 1e9 ticks when every tile did two of each); the compact tag only
+// says "worth reading now".
+__device__ __forceinline__ void ew_publish(unsigned long long *rec, unsigned long long *tag, const EwMap &m, int lane)
 {
-    if (lane < EW_GRAN) {
-        const double d = lane < 2 ? m.a : lane < 4 ? m.a2 : lane < 6 ? m.bV : lane < 8 ? m.bV2 : lane < 10 ? m.bSy : m.bSyy;
+    if (lane < 12) {
+        const int f = lane >> 1;
+        const double d = f == 0 ? m.a : f == 1 ? m.a2 : f == 2 ? m.bV : f == 3 ? m.bV2 : f == 4 ? m.bSy : m.bSyy;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
         const unsigned word = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-        __hip_atomic_store((ew_gu64 *)(g + lane), (1ULL << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + lane, (1ULL << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (lane == 0) __hip_atomic_store(tag, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one sweep over the twelve granules: true when all tags are set; m (wave-uniform) is then the published map
-__device__ __forceinline__ bool ew_sweep(unsigned long long *g, EwMap &m, int lane)
+// this lane's record (the tag said it is there): read until every granule is valid
+__device__ __forceinline__ EwMap ew_fetch(const unsigned long long *rec)
 {
-    unsigned long long x = 1ULL << 32;
-    if (lane < EW_GRAN) x = __hip_atomic_load((ew_gu64 *)(g + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__ballot((x >> 32) != 1ULL) != 0) return false;
-    const unsigned w = (unsigned)x;
-    double d[6];
+    unsigned long long g[12];
+    for (;;) {
+        bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)w, 2 * k);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)w, 2 * k + 1);
-        d[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        for (int k = 0; k < 12; ++k) {
+            g[k] = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (g[k] >> 32) == 1ULL;
+        }
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    m.a = d[0]; m.a2 = d[1]; m.bV = d[2]; m.bV2 = d[3]; m.bSy = d[4]; m.bSyy = d[5];
-    return true;
+    auto dbl = [&](int f) { return __longlong_as_double((long long)((g[2 * f + 1] << 32) | (g[2 * f] & 0xFFFFFFFFULL))); };
+    return EwMap{dbl(0), dbl(1), dbl(2), dbl(3), dbl(4), dbl(5)};
+}
+// lane 0 holds the NEWEST map, lane 63 the oldest: the composition oldest first, wave-uniform
+__device__ __forceinline__ EwMap ew_wave_compose_newest_first(EwMap x)
+{
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_SHR(1), 0xF>(x));
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_SHR(2), 0xF>(x));
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_SHR(4), 0xF>(x));
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_SHR(8), 0xF>(x));
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_BCAST15, 0xA>(x));
+    x = ew_compose(x, ew_dpp<FMK_DPP_ROW_BCAST31, 0xC>(x));
+    return EwMap{fmk_last_lane(x.a), fmk_last_lane(x.a2), fmk_last_lane(x.bV), fmk_last_lane(x.bV2), fmk_last_lane(x.bSy), fmk_last_lane(x.bSyy)};
+}
+
+// wave 0 of tile `tile` > 0, after its own map went out: the exclusive prefix map of the tile; false: a wait gave up
+__device__ __forceinline__ bool ew_lookback(const EwDesc &D, int64_t tile, int lane, EwMap *out)
+{
+    const int64_t ia = tile - 1 - lane, ib = tile - EW_W1 * ((int64_t)lane + 1);
+    bool have_a = ia < 0, have_p = ib <= 0 || tile <= EW_W1, have_r = false;     // nothing there: the identity
+    bool published = false;
+    EwMap r = ew_identity();
+    for (unsigned polls = 1;; ++polls) {
+        if (!have_a) have_a = __hip_atomic_load(D.tagA + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (!have_p) {
+            const int64_t sl = ew_slot(ib, D.groups);
+            have_p = __hip_atomic_load(D.tagP + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (!have_p && !have_r) have_r = __hip_atomic_load(D.tagR + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        if (!published && __ballot(!have_a) == 0) {
+            r = ew_wave_compose_newest_first(ia >= 0 ? ew_fetch(D.A + 12 * ia) : ew_identity());    // R(tile)
+            published = true;
+            if (tile > EW_W1) ew_publish(D.R + 12 * ew_slot(tile, D.groups), D.tagR + ew_slot(tile, D.groups), r, lane);
+        }
+        if (published) {
+            if (tile <= EW_W1) { *out = r; return true; }            // the window reached tile 0: R is the prefix
+            const uint64_t based = __ballot(have_p), missing = __ballot(!have_p && !have_r);
+            if (based != 0) {
+                const int first = __builtin_ctzll(based);             // the nearest tile that has its prefix
+                if ((missing & ((1ULL << first) - 1)) == 0) {
+                    EwMap x = ew_identity();
+                    if (lane <= first && ib > 0) x = ew_fetch((lane == first ? D.P : D.R) + 12 * ew_slot(ib, D.groups));
+                    *out = ew_compose(ew_wave_compose_newest_first(x), r);
+                    return true;
+                }
+            }
+        }
+        if (polls > EW_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__restrict__ ts, const double *__restrict__ y,
                                                            int64_t n, EwHl half_life, double sigma_floor,
                                                            const double *__restrict__ state_in, double *__restrict__ out,
-                                                           unsigned long long *gran /*[tiles][2][EW_GRAN]*/, int64_t tiles,
-                                                           int64_t *err_word)
+                                                           EwDesc D, int64_t tiles, int64_t *err_word)
 {
     __shared__ EwMap lds[4];
     __shared__ EwMap s_excl;
@@ -727,25 +795,14 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__rest
         EwMap tot;
         EwMap ex = ew_block_exclusive(m, lds, &tot);
         // ---- publish the aggregate, look back, publish the inclusive prefix (wave 0)
-        unsigned long long *g_agg = gran + (size_t)tile * 2 * EW_GRAN, *g_pre = g_agg + EW_GRAN;
         if (threadIdx.x < 64) {
             EwMap excl = ew_identity();
-            if (tile > 0) {
-                ew_publish(g_agg, tot, lane);
-                unsigned spins = 0;
-                for (int64_t j = tile - 1; j >= 0;) {
-                    unsigned long long *pj = gran + (size_t)j * 2 * EW_GRAN;
-                    EwMap got;
-                    if (ew_sweep(pj + EW_GRAN, got, lane)) { excl = ew_compose(got, excl); break; }     // inclusive prefix of j
-                    if (ew_sweep(pj, got, lane)) { excl = ew_compose(got, excl); --j; spins = 0; continue; }   // its aggregate
-                    if (++spins > EW_SPIN_LIMIT) {                           // never: report, do not hang
-                        if (lane == 0) *err_word = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+            ew_publish(D.A + 12 * tile, D.tagA + tile, tot, lane);
+            if (tile > 0 && !ew_lookback(D, tile, lane, &excl)) {
+                if (lane == 0) *err_word = 1;                          // never: report, do not hang
+                excl = ew_identity();
             }
-            ew_publish(g_pre, ew_compose(excl, tot), lane);
+            ew_publish(D.P + 12 * ew_slot(tile, D.groups), D.tagP + ew_slot(tile, D.groups), excl, lane);
             if (lane == 0) s_excl = excl;
         }
         __syncthreads();
@@ -799,6 +856,61 @@ __global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__rest
     }
 }
 
+// The one-pass kernel, second form (round 5): ONE TILE PER WORKGROUP in dispatch order instead of a persistent grid, the tile's ticks by
+// direct 16-byte loads (no LDS staging: six waves per SIMD instead of four).  With the persistent grid every workgroup reaches its
+// look-back at the same moment and the whole device waits out the two round trips, generation after generation (18.7 ms per 1e9
+// ticks); here the workgroups of a CU are at different points of their tiles and the SIMDs stay busy with the others' arithmetic
+// while one waits.  Forward progress: workgroups are dispatched in index order, so the lowest unfinished tile is always resident;
+// a wait that gives up all the same raises the sticky error word instead of hanging.
+template <int MODE, int OCC>
+__global__ __launch_bounds__(EW_THREADS, OCC) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
+                                                                EwHl half_life, double sigma_floor, const double *__restrict__ state_in,
+                                                                double *__restrict__ out, EwDesc D, int64_t *err_word)
+{
+    __shared__ EwMap lds[4];
+    __shared__ EwMap s_excl;
+    const int lane = fmk_lane();
+    const int64_t tile = blockIdx.x;
+    double yl[EW_ITEMS], al[EW_ITEMS];
+    EwMap m;
+    {
+        int64_t tl[EW_ITEMS], tprev0;
+        ew_load_direct(ts, y, n, tl, yl, &tprev0);
+        m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
+    }
+    EwMap tot;
+    EwMap ex = ew_block_exclusive(m, lds, &tot);
+    if (threadIdx.x < 64) {
+        EwMap excl = ew_identity();
+        ew_publish(D.A + 12 * tile, D.tagA + tile, tot, lane);
+        if (tile > 0 && !ew_lookback(D, tile, lane, &excl)) {
+            if (lane == 0) *err_word = 1;
+            excl = ew_identity();
+        }
+        ew_publish(D.P + 12 * ew_slot(tile, D.groups), D.tagP + ew_slot(tile, D.groups), excl, lane);
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    ex = ew_compose(s_excl, ex);
+    double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
+    if (state_in) {
+        V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
+        Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
+    }
+    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    double res[EW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        res[k] = NAN;                                              // volatility.py:174 (out[0])
+        if (i >= n) continue;
+        if (MODE != 2 && i == 0) continue;
+        ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
+        res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
+    }
+    ew_store8(out, i0, n, res);
+}
+
 // composition of all tile maps in order (ONE block): the map of the whole series, x -> a*x + b per state
 __global__ __launch_bounds__(EW_THREADS) void k_ew_total(const EwMap *__restrict__ maps, int64_t m, double *out6)
 {
@@ -848,20 +960,35 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     // The two-pass scan therefore stays the default; FMK_EW_ONE_PASS=1 (read per call) selects this kernel.
     const char *opv = getenv("FMK_EW_ONE_PASS");
     if (!d_map_out && opv && atoi(opv)) {
-        // one pass: persistent grid, decoupled look-back over {tag, word} granules (zeroed before every launch)
-        const size_t gbytes = (size_t)tiles * 2 * EW_GRAN * 8;
-        FMK_TRY(fmk_scratch(ctx, gbytes, &scr));
-        FMK_HIP(ctx, hipMemsetAsync(scr, 0, gbytes, ctx->stream));
-        static int per_cu = 0;
-        if (!per_cu) {
-            int nbk = 0;
-            FMK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)k_ew_onepass<MODE>, EW_THREADS, 0));
-            per_cu = nbk > 0 ? nbk : 1;
-        }
-        int64_t grid = (int64_t)ctx->n_cu * per_cu;  // every workgroup resident at once: the look-back cannot starve
-        if (grid > tiles) grid = tiles;
-        k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out,
-                                                                          (unsigned long long *)scr, tiles, ctx->h_mail + 40);
+        // one pass: persistent grid, two-level look-back over tagged records (the tags are zeroed before every launch)
+        const int64_t groups = fmk_ceil_div(tiles, EW_W1), slots = groups * EW_W1;
+        const size_t tag_bytes = (size_t)(tiles + 2 * slots) * 8, rec_bytes = (size_t)(tiles + 2 * slots) * 96;
+        FMK_TRY(fmk_scratch(ctx, tag_bytes + rec_bytes + 64, &scr));
+        FMK_HIP(ctx, hipMemsetAsync(scr, 0, tag_bytes + rec_bytes, ctx->stream));     // tags AND granules
+        EwDesc D;
+        D.tagA = (unsigned long long *)scr; D.tagR = D.tagA + tiles; D.tagP = D.tagR + slots;
+        D.A = D.tagP + slots; D.R = D.A + 12 * tiles; D.P = D.R + 12 * slots;
+        D.groups = groups;
+        if (atoi(opv) == 2) {                                       // the persistent-grid form (round 2's schedule)
+            static int per_cu = 0;
+            if (!per_cu) {
+                int nbk = 0;
+                FMK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)k_ew_onepass<MODE>, EW_THREADS, 0));
+                per_cu = nbk > 0 ? nbk : 1;
+            }
+            int64_t grid = (int64_t)ctx->n_cu * per_cu;  // every workgroup resident at once: the look-back cannot starve
+            if (grid > tiles) grid = tiles;
+            k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out,
+                                                                              D, tiles, ctx->h_mail + 40);
+        } else if (atoi(opv) == 4)
+            k_ew_onepass_d<MODE, 4><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
+                                                                                    ctx->h_mail + 40);
+        else if (atoi(opv) == 5)
+            k_ew_onepass_d<MODE, 5><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
+                                                                                    ctx->h_mail + 40);
+        else
+            k_ew_onepass_d<MODE, 6><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
+                                                                                    ctx->h_mail + 40);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }

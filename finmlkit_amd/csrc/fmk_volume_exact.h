@@ -36,8 +36,13 @@ __global__ __launch_bounds__(THREADS) void k_vx_level0(const void *__restrict__ 
     constexpr int NW = THREADS / 64;
     static_assert(T % THREADS == 0 && S % THREADS == 0 && PER % (AF64 ? 2 : 4) == 0, "tile shape");
     static_assert(W <= 0xFFFE, "16-bit link offsets");
-#define VXP(i) Lp[PAD ? (i) + ((i) >> 3) : (i)]
-    constexpr int LPN = PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2;
+    // The prefix table is padded: the prefix phase writes element 8 t + k from lane t -- a stride of 16 banks, four bank pairs for 32
+    // lanes, an 8-way conflict on every one of its eight stores, and with them 54 % of the kernel's LDS cycles were conflict cycles
+    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_cfg3.txt; the kernel's time did not move when a fifth of its VALU
+    // instructions went away: it waits for LDS).  PAD: one slot per 8 (the 4096-tick class, which has the room); otherwise one per
+    // 32 -- 3 % more LDS, still four workgroups per CU -- which makes lane t's slot 8 t + k + t / 4: 32 distinct bank pairs.
+#define VXP(i) Lp[PAD ? (i) + ((i) >> 3) : (i) + ((i) >> 5)]
+    constexpr int LPN = PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2 + (T + 2) / 32 + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
     double *Lp = (double *)vx_smem;
     uint16_t *nx = (uint16_t *)(vx_smem + (size_t)LPN * 8);
@@ -425,7 +430,7 @@ static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &
     FMK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 32, 0, 32, ctx->stream));
     {
         constexpr int T = S + W;
-        constexpr size_t lds = (size_t)(PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2) * 8 + (size_t)S * 2 + (size_t)(THREADS / 64) * 24 + 64;
+        constexpr size_t lds = (size_t)(PAD ? T + 1 + (T + 1) / 8 + 1 : T + 2 + (T + 2) / 32 + 1) * 8 + (size_t)S * 2 + (size_t)(THREADS / 64) * 24 + 64;
         if (lds > 64 * 1024)
             FMK_HIP(ctx, hipFuncSetAttribute((const void *)k_vx_level0<AF64, S, W, THREADS, PAD>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
