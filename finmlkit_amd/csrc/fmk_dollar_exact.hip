@@ -135,7 +135,7 @@ __device__ __forceinline__ int64_t dlx_binade(double x) { return __double_as_lon
 // the 64 segments with coalesced loads (a quarter wave per 128-byte segment), forms the rounded products and parks them in LDS,
 // one padded row per lane; then every lane walks its own row.
 template <bool AF64>
-__global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ price, const void *__restrict__ amount, int64_t n,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dlx_bars(const double *__restrict__ price, const void *__restrict__ amount, int64_t n,
                                                   double thr, double u, double inv_u, double m_rel, double m_abs,
                                                   const int64_t *__restrict__ ci, int64_t nb,
                                                   const int64_t *__restrict__ carry_k, DlxFn *__restrict__ fn,
@@ -146,8 +146,12 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
                                                   unsigned char *__restrict__ btype, double *__restrict__ dlast)
 {
     __shared__ double rows[2][64][DLX_T + 1];               // 2 waves x 16.9 KB
-    __shared__ int64_t s_pos[2][64], s_end[2][64];
+    __shared__ int64_t s_pos[2][64], s_end[2][64], s_prev[2][64];
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
+    float keep[64 / (64 / DLX_T)];                            // (float32 amounts) the second half of the amount line of each segment this lane loads for
+#pragma unroll
+    for (int q = 0; q < 64 / (64 / DLX_T); ++q) keep[q] = 0.f;
+    s_prev[w][lane] = -1;
     const int64_t wave = (int64_t)blockIdx.x * 2 + w;
     const int64_t bar0 = wave * (64 * (int64_t)bars_per_lane) + lane;
     int r = 0;
@@ -211,20 +215,35 @@ __global__ __launch_bounds__(128) void k_dlx_bars(const double *__restrict__ pri
         typedef typename std::conditional<AF64, double, float>::type DlxAmt;
         double lp[64 / SPI];
         DlxAmt la[64 / SPI];
+        // float32 amounts: a window of 16 ticks is HALF a 128-byte line of amounts, and the other half was asked for a round later --
+        // by then L2 had turned over and the line came from memory again (16 GB fetched for the kernel's 12).
+        // Round 5: a window that starts a line also fetches the line's second half (the same lane serves the same segment and tick
+        // offset in the next round) and keeps it in a register; s_prev says whether this round continues the last one's window.
 #pragma unroll
         for (int q = 0; q < 64 / SPI; ++q) {
             const int seg = q * SPI + half;
             const int64_t p0 = s_pos[w][seg], e0 = s_end[w][seg];
             const int64_t tick = p0 + j32;
             lp[q] = 0.0; la[q] = (DlxAmt)0;
-            if (p0 >= 0 && tick <= e0) { lp[q] = price[tick]; la[q] = ((const DlxAmt *)amount)[tick]; }
+            if constexpr (AF64) {
+                if (p0 >= 0 && tick <= e0) { lp[q] = price[tick]; la[q] = ((const DlxAmt *)amount)[tick]; }
+            } else {
+                const bool second = (p0 & DLX_T) != 0;
+                const bool reuse = second && p0 >= 0 && s_prev[w][seg] == p0 - DLX_T;
+                if (p0 >= 0 && tick <= e0) { lp[q] = price[tick]; la[q] = reuse ? keep[q] : ((const DlxAmt *)amount)[tick]; }
+                if (p0 >= 0 && !second && tick + DLX_T < n) keep[q] = ((const DlxAmt *)amount)[tick + DLX_T];
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 64 / SPI; ++q) { asm volatile("" : "+v"(lp[q])); asm volatile("" : "+v"(la[q])); }
+        for (int q = 0; q < 64 / SPI; ++q) {
+            asm volatile("" : "+v"(lp[q])); asm volatile("" : "+v"(la[q]));
+            if constexpr (!AF64) asm volatile("" : "+v"(keep[q]));
+        }
 #pragma unroll
         for (int q = 0; q < 64 / SPI; ++q)
             rows[w][q * SPI + half][j32] = lp[q] * (double)la[q];   // rounded once, like prices[i] * volumes[i] (logic.py:143): dlx_d
         __builtin_amdgcn_wave_barrier();
+        s_prev[w][lane] = active ? (pos & ~(int64_t)(DLX_T - 1)) : -1;   // (read by the loaders of the NEXT round, behind its barrier)
         int cnt = 0;
         const int o = (int)(pos & (DLX_T - 1));                     // my first tick inside the window
         if (active) cnt = (int)(end - pos + 1 < DLX_T - o ? end - pos + 1 : DLX_T - o);
