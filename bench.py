@@ -444,17 +444,53 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL's P2P between processes needs it on this driver
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # librccl's banner / warnings: not on stdout, that is the JSON line's
     kids = []
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        kids = spawn_ranks(args)
-    try:
-        rc = run(args)
-    except BaseException:
-        for k in kids:                                           # exactly the processes started above
-            if k.poll() is None:
-                k.kill()
-        raise
-    rc = rc or reap(kids)
+    with _StdoutIsTheJsonLine():
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            kids = spawn_ranks(args)                                 # (each is a `python bench.py` of its own and guards its own fd 1)
+        try:
+            rc = run(args)
+        except BaseException:
+            for k in kids:                                           # exactly the processes started above
+                if k.poll() is None:
+                    k.kill()
+            raise
+        rc = rc or reap(kids)
     sys.exit(rc)
+
+
+class _StdoutIsTheJsonLine:
+    """fd 1 carries the ONE JSON line and nothing else.  librccl prints its version banner with printf when the first communicator
+    comes up (NCCL_DEBUG_FILE does not move it), and any other library may do the same: for the length of the run fd 1 points at
+    stderr, and the line is written to a saved copy of the real stdout by `emit`."""
+    saved = None
+
+    def __enter__(self):
+        sys.stdout.flush()
+        _StdoutIsTheJsonLine.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    @staticmethod
+    def emit(text):
+        fd = _StdoutIsTheJsonLine.saved
+        if fd is None:                                  # (run() called without the guard: tests that import bench)
+            print(text, flush=True)
+            return
+        data = (text + "\n").encode()
+        while data:
+            data = data[os.write(fd, data):]
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes as C
+            C.CDLL(None).fflush(None)                   # C stdio buffers of fd 1 (the banner) go where fd 1 points NOW: stderr
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.dup2(_StdoutIsTheJsonLine.saved, 1)
+        os.close(_StdoutIsTheJsonLine.saved)
+        _StdoutIsTheJsonLine.saved = None
+        return False
 
 
 class _Tee:
@@ -797,12 +833,11 @@ def run(args):
             line["cpu_baseline"] = cpu_baseline(args)
             if not args.no_extras:
                 line["other_configs"] = other_configs(trades, ctx, args)
-        try:
-            C.CDLL(None).fflush(None)        # RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer: keep the
-        except OSError:                      # JSON line the LAST line of stdout
-            pass
         # a fallback run is NOT a result: its line goes to stderr and the process ends with rc 3
-        print(json.dumps(line), flush=True, file=sys.stderr if fell_back else sys.stdout)
+        if fell_back:
+            print(json.dumps(line), flush=True, file=sys.stderr)
+        else:
+            _StdoutIsTheJsonLine.emit(json.dumps(line))
     if comm:
         comm.barrier()
         comm.close()
