@@ -488,6 +488,119 @@ __global__ __launch_bounds__(256) void k_cusum_walk(const int64_t *__restrict__ 
     }
 }
 
+#include "fmk_cusum_onepass.h"
+
+static int64_t g_cs1_last[4];           // last call: 1 if the one-pass form answered, fix-up launches, chunks pending after the first, chunks
+extern "C" int fmk_diag_cusum_onepass(int64_t *used, int64_t *fix_launches, int64_t *pending_first, int64_t *chunks)
+{
+    if (used) *used = g_cs1_last[0];
+    if (fix_launches) *fix_launches = g_cs1_last[1];
+    if (pending_first) *pending_first = g_cs1_last[2];
+    if (chunks) *chunks = g_cs1_last[3];
+    return FMK_OK;
+}
+
+// The one-pass form (fmk_cusum_onepass.h).  *done = 1: d_out[1..] and *total are the answer; *done = 0: nothing was written that the
+// caller may use (the tape does not forget fast enough, or the fix-up did not settle in CS1_MAX_LAUNCHES launches): run the fixed point.
+// *redo = true: sigma (not forward filled yet) has a NaN after its first valid index -- fill it and call again.
+#define CS1_MAX_LAUNCHES 24
+static int cs1_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const double *d_sigma, int64_t n, int64_t first,
+                   int64_t m, double sigma_floor, double sigma_mult, int64_t *d_out, int64_t capacity, bool check_nan,
+                   int64_t *total, int64_t *rounds, int *done, bool *redo)
+{
+    *done = 0; *redo = false;
+    const int64_t chunks = fmk_ceil_div(m, (int64_t)CS1_L);
+    g_cs1_last[0] = 0; g_cs1_last[1] = 0; g_cs1_last[2] = 0; g_cs1_last[3] = chunks;
+    const size_t scan_bytes = (((size_t)fmk_ceil_div(chunks + 1, FMK_SCAN_TILE) + 1) * 8 + 255) & ~(size_t)255;
+    const size_t st_bytes = ((size_t)chunks * sizeof(CsState) + 255) & ~(size_t)255;
+    const size_t cnt_bytes = ((size_t)(chunks + 1) * 8 + 255) & ~(size_t)255;
+    const size_t c0_bytes = ((size_t)chunks * 4 + 255) & ~(size_t)255;
+    const size_t fix_bytes = ((size_t)chunks * sizeof(Cs1Fix) + 255) & ~(size_t)255;
+    const size_t row_bytes = ((size_t)chunks * CS1_L * 2 + 255) & ~(size_t)255;
+    void *scr;
+    FMK_TRY(fmk_scratch(ctx, scan_bytes + 5 * st_bytes + cnt_bytes + c0_bytes + fix_bytes + 2 * row_bytes, &scr));
+    char *base = (char *)scr + scan_bytes;
+    CsState *S = (CsState *)base, *S_read = (CsState *)(base + st_bytes), *last_in = (CsState *)(base + 2 * st_bytes);
+    CsState *S0 = (CsState *)(base + 3 * st_bytes), *E = (CsState *)(base + 4 * st_bytes);
+    int64_t *counts = (int64_t *)(base + 5 * st_bytes);
+    int *C0 = (int *)(base + 5 * st_bytes + cnt_bytes);
+    Cs1Fix *fix = (Cs1Fix *)(base + 5 * st_bytes + cnt_bytes + c0_bytes);
+    unsigned short *staged = (unsigned short *)(base + 5 * st_bytes + cnt_bytes + c0_bytes + fix_bytes);
+    unsigned short *patch = (unsigned short *)(base + 5 * st_bytes + cnt_bytes + c0_bytes + fix_bytes + row_bytes);
+    unsigned long long *d_changed = (unsigned long long *)(ctx->d_mail + 1), *d_pending = (unsigned long long *)(ctx->d_mail + 3);
+    unsigned long long *d_nan = (unsigned long long *)(ctx->d_mail + 5);
+    if (check_nan) FMK_HIP(ctx, hipMemsetAsync(d_nan, 0, 8, ctx->stream));
+    ctx->h_mail[5] = 0;
+    FMK_HIP(ctx, hipMemsetAsync(fix, 0, fix_bytes, ctx->stream));
+    {
+        const char *v = getenv("FMK_CS1_VARIANT");                        // developer timing only (fmk_cusum_onepass.h)
+        const int variant = v ? atoi(v) : 0;
+        const unsigned g = (unsigned)fmk_ceil_div(chunks, (int64_t)CS1_TK);
+        unsigned long long *nf = check_nan ? d_nan : nullptr;
+        if (variant == 1) {
+            FMK_HIP(ctx, hipMemsetAsync(E, 0, st_bytes, ctx->stream));
+            FMK_HIP(ctx, hipMemsetAsync(C0, 0, c0_bytes, ctx->stream));
+            k_cs1_pass<1><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
+        } else if (variant == 2)
+            k_cs1_pass<2><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
+        else
+            k_cs1_pass<0><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
+        FMK_LAUNCH_CHECK(ctx);
+        if (variant == 1 || variant == 2) { FMK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return FMK_OK; }   // not a result
+    }
+    FMK_HIP(ctx, hipMemcpyAsync(S, S0, (size_t)chunks * sizeof(CsState), hipMemcpyDeviceToDevice, ctx->stream));
+    FMK_HIP(ctx, hipMemcpyAsync(last_in, E, (size_t)chunks * sizeof(CsState), hipMemcpyDeviceToDevice, ctx->stream));   // every record was made from E
+    *rounds = 1;
+    int limit = CS1_FIRST_LIMIT;
+    int64_t launches = 0;
+    if (check_nan && chunks <= 1) {
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[5], d_nan, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_mail[5] != 0) { *redo = true; return FMK_OK; }
+    }
+    while (chunks > 1) {
+        FMK_HIP(ctx, hipMemcpyAsync(S_read, S, (size_t)chunks * sizeof(CsState), hipMemcpyDeviceToDevice, ctx->stream));
+        FMK_HIP(ctx, hipMemsetAsync(d_changed, 0, 8, ctx->stream));
+        FMK_HIP(ctx, hipMemsetAsync(d_pending, 0, 8, ctx->stream));
+        k_cs1_fix<<<(unsigned)fmk_ceil_div(chunks - 1, (int64_t)4), 256, 0, ctx->stream>>>(
+            d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, S_read, S, last_in, fix, patch, limit,
+            d_changed, d_pending);
+        FMK_LAUNCH_CHECK(ctx);
+        ++launches; ++*rounds;
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], d_changed, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[3], d_pending, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (check_nan) FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[5], d_nan, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (check_nan && ctx->h_mail[5] != 0) { *redo = true; return FMK_OK; }
+        const int64_t changed = ctx->h_mail[1], pending = ctx->h_mail[3];
+        g_cs1_last[1] = launches;
+        if (launches == 1) {
+            g_cs1_last[2] = pending;
+            if (pending > chunks / 4 + 1) return FMK_OK;                  // this tape does not forget within CS1_FIRST_LIMIT ticks
+        }
+        limit = CS1_L;
+        if (changed == 0 && pending == 0) break;
+        if (launches >= CS1_MAX_LAUNCHES) return FMK_OK;
+    }
+    k_cs1_counts<<<(unsigned)fmk_ceil_div(chunks, (int64_t)256), 256, 0, ctx->stream>>>(C0, fix, chunks, counts);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_TRY(fmk_exclusive_scan_i64(ctx, counts, counts, chunks, true));
+    FMK_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[2], counts + chunks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total = ctx->h_mail[2];
+    if (d_out) {
+        if (capacity < *total + 1)
+            return fmk_set_error(ctx, FMK_E_CAPACITY, "cusum: %lld close indices, capacity %lld", (long long)(*total + 1),
+                                 (long long)capacity);
+        k_cs1_emit<<<(unsigned)fmk_ceil_div(chunks, (int64_t)4), 256, 0, ctx->stream>>>(C0, fix, staged, patch, chunks, first, counts,
+                                                                                      d_out + 1);
+        FMK_LAUNCH_CHECK(ctx);
+    }
+    g_cs1_last[0] = 1;
+    *done = 1;
+    return FMK_OK;
+}
+
 int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const double *d_sigma, int64_t n,
                          int64_t first, int64_t m, int64_t chunks, double sigma_floor, double sigma_mult, int64_t *d_out,
                          int64_t capacity, int64_t *total, int64_t *visits, int *done, int *nan_seen);
@@ -498,6 +611,7 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
 {
     if (n <= 0) return fmk_set_error(ctx, FMK_E_ARG, "Prices, timestamps, and sigma arrays must have the same length.");
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    g_cs1_last[0] = g_cs1_last[1] = g_cs1_last[2] = g_cs1_last[3] = 0;
     // ---- scratch layout: [scan tile sums | states a, b, last_in | counts | forward-fill tiles | ret^T | lam^T]
     const int64_t tiles = fmk_ceil_div(n, FF_TILE);
     const int64_t max_chunks = fmk_ceil_div(n, CS_CHUNK) + 1;
@@ -582,6 +696,17 @@ extern "C" int fmk_cusum_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, cons
         // (sigma may still be unfilled: the prep pass then reports a NaN after the first valid index, and this block runs again)
         const bool check_nan = !filled;
         bool redo = false;
+        {   // closes every few hundred ticks: one pass over the columns (fmk_cusum_onepass.h); FMK_CUSUM_ONEPASS=0: the fixed point only
+            const char *v = getenv("FMK_CUSUM_ONEPASS");
+            int one_done = 0;
+            g_cs1_last[0] = 0;
+            if (!(v && atoi(v) == 0)) {
+                FMK_TRY(cs1_run(ctx, d_ts, d_price, d_sigma, n, first, m, sigma_floor, sigma_mult, d_out, capacity, check_nan, &total,
+                                &rounds, &one_done, &redo));
+                if (redo) { FMK_TRY(full_fill()); continue; }
+                if (one_done) break;
+            }
+        }
         unsigned long long *d_nan = (unsigned long long *)(ctx->d_mail + 5);
         if (check_nan) FMK_HIP(ctx, hipMemsetAsync(d_nan, 0, 8, ctx->stream));
         ctx->h_mail[5] = 0;

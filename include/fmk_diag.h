@@ -58,6 +58,9 @@ int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
  * starts at a chunk boundary from which the side's state provably does not depend on earlier ticks (k_cc_sync).  *rate: the
  * estimate the tier was chosen by (512-tick sub-blocks per chunk and side of the leading chunks with a certain close; -1: none). */
 int fmk_diag_cusum_segments(int64_t *segments, double *rate);
+/* last CUSUM call: 1 if the one-pass form (csrc/fmk_cusum_onepass.h) answered, its fix-up launches, the chunks that had not merged
+   within the first launch's limit, the number of chunks */
+int fmk_diag_cusum_onepass(int64_t *used, int64_t *fix_launches, int64_t *pending_first, int64_t *chunks);
 
 #ifdef __cplusplus
 }

@@ -275,3 +275,62 @@ def test_cusum_chain_walk_positive_close_hides_negative(orc, monkeypatch):
     got = _cusum_bar_indexer(ts, px, sigma.copy(), 1e-3, 2.0)
     assert _last_tier()[0] == 1
     np.testing.assert_array_equal(got, want)
+
+
+def _onepass():
+    """(answered, fix-up launches, chunks pending after the first launch, chunks) of the last call (csrc/fmk_cusum_onepass.h)"""
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    from finmlkit_amd._ffi import c_i64
+    v = [c_i64() for _ in range(4)]
+    _ffi.lib().fmk_diag_cusum_onepass(*(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
+
+
+@pytest.mark.parametrize("n,vol,floor,same_ts,sigma_kind", [
+    (3_000_000, 2e-4, 2e-3, 0.25, "const"),           # a close every ~100 ticks, print blocks across chunk edges
+    (1_000_000, 2e-4, 1e-6, 0.0, "const"),            # a close on nearly every tick: staging rows almost full
+    (1_000_000, 2e-4, 1e-3, 0.5, "ewm"),              # sigma with a NaN prefix (first > 0) and a NaN hole (the lazy fill's redo)
+    (1 + 3 * 4096 - 1, 2e-4, 2e-3, 0.25, "const"),    # the stream ends one tick before / on / one tick after a chunk edge
+    (1 + 3 * 4096, 2e-4, 2e-3, 0.25, "const"),
+    (1 + 3 * 4096 + 1, 2e-4, 2e-3, 0.25, "const"),
+    (1 + 4096 + 512, 2e-4, 2e-3, 0.0, "const"),       # the second chunk is exactly one warm-up long
+    (4097, 2e-4, 2e-3, 0.0, "const"), (4098, 2e-4, 2e-3, 0.0, "const"), (700, 2e-4, 2e-3, 0.0, "const")])
+def test_cusum_onepass_vs_oracle(orc, monkeypatch, n, vol, floor, same_ts, sigma_kind):
+    """The one-pass form of the dense regime (pass A with a warm-up, lockstep fix-up, emission) against the sequential oracle
+    and against the fixed point it replaces, with the chain tier switched off so that it is the form that answers."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", "0")
+    ts, px = _stream(orc, n, 21, vol=vol, same_ts=same_ts)
+    if sigma_kind == "ewm":
+        r = orc.comp_lagged_returns(ts, px, 5.0, True)
+        sigma = orc.ewmst(ts, r, 60.0)
+        sigma[n // 2: n // 2 + 50] = np.nan
+    else:
+        sigma = np.full(n, floor / 4)
+    want, wfilled = orc._cusum_bar_indexer(ts, px, sigma.copy(), floor, 2.0, return_sigma=True)
+    s = sigma.copy()
+    got = _cusum_bar_indexer(ts, px, s, floor, 2.0)
+    used, launches, pending, chunks = _onepass()
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(s, wfilled)
+    assert used == 1 and chunks == -(-(n - 1 - int(want[0])) // 4096), (used, launches, pending, chunks)
+    monkeypatch.setenv("FMK_CUSUM_ONEPASS", "0")
+    s = sigma.copy()
+    np.testing.assert_array_equal(_cusum_bar_indexer(ts, px, s, floor, 2.0), want)
+    assert _onepass()[0] == 0
+
+
+def test_cusum_onepass_leaves_a_tape_that_does_not_forget(orc, monkeypatch):
+    """Thresholds that are never reached on a quiet tape: the clamps alone do not bring the walk from (0, 0) and the true
+    walk together within the warm-up plus the first fix-up launch, so the form gives the call to the fixed point."""
+    from finmlkit_amd.bar.logic import _cusum_bar_indexer
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", "0")
+    n = 600_000
+    ts, px = _stream(orc, n, 23, vol=1e-6, same_ts=0.1)
+    sigma = np.full(n, 1e-7)
+    want = orc._cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    got = _cusum_bar_indexer(ts, px, sigma.copy(), 5e-4, 2.0)
+    used, launches, pending, chunks = _onepass()
+    np.testing.assert_array_equal(got, want)
+    assert used == 0 and launches == 1 and pending > chunks // 4, (used, launches, pending, chunks)

@@ -28,6 +28,9 @@ for floor in floors:
         _ffi.lib().fmk_diag_cusum_last(C.byref(tier), C.byref(opened), C.byref(status))
         seg, rate = c_i64(), c_f64()
         _ffi.lib().fmk_diag_cusum_segments(C.byref(seg), C.byref(rate))
+        u, fl, pf, ch = c_i64(), c_i64(), c_i64(), c_i64()
+        _ffi.lib().fmk_diag_cusum_onepass(C.byref(u), C.byref(fl), C.byref(pf), C.byref(ch))
+        print("   one pass: used %d, fix-up launches %d, chunks pending after the first %d of %d" % (u.value, fl.value, pf.value, ch.value))
         print("sigma_floor %g: %.2f ms  rounds %d  closes %d  tier %d (walk: %d opened / events, status %d, %d later segments, rate %.3f)  checksum %d" %
               (floor, ms, rounds.value, m.value, tier.value, opened.value, status.value, seg.value, rate.value,
                int(out.view(0, m.value).to_host().sum())), flush=True)
