@@ -277,7 +277,7 @@ def other_configs(trades, ctx, args):
         del o1, clock1, ci1
         # "next" rows: the QuickStart chain lagged returns -> ewmst -> CUSUM bars (CUSUMBarKit's default sigma_floor 5e-4: on this
         # quiet tape a close per 2.4e5 ticks, served by the chain walk of fmk_cusum_chain.hip; 1e-5: a close per ~200 ticks, the
-        # fixed point), and the order-flow features on the 1-second bars of io.py:484 (one lane per bar)
+        # one-pass form of fmk_cusum_onepass.h), and the order-flow features on the 1-second bars of io.py:484 (one lane per bar)
         ret = trades.lagged_returns(5.0, True)
         out["lagged_returns_5s_ms"] = timed(lambda: trades.lagged_returns(5.0, True), key="lagged_returns_5s")
         sig = trades.ewmst(ret, 60.0)
@@ -289,7 +289,7 @@ def other_configs(trades, ctx, args):
             def run(floor=floor):
                 ctx.call("fmk_cusum_bar_indexer_dev", trades.ts.p, trades.price.p, sig.p, c_i64(n), C.c_double(floor),
                          C.c_double(2.0), cus.p, c_i64(cus.n), C.byref(m), C.byref(rounds))
-            out[key + "_ms"] = timed(run)
+            out[key + "_ms"] = timed(run, key="cusum_floor_" + key.split("_")[-1])
             out[key + "_closes"] = int(m.value) - 1
         del sig, cus
         clock1, ci1 = trades.time_bar_index(1.0)
@@ -335,10 +335,14 @@ def other_configs(trades, ctx, args):
                "cfg3_dollar_index": 12 * n + 8 * (ndb + 1), "cfg3_dollar_build_ohlcv": 12 * n + (8 + 68) * ndb,
                "cfg4_equal_bars": cfg4_bytes(nb60, lv_eq), "cfg4_equal_bars_full_mantissa": cfg4_bytes(nb60, lv_eq),
                "cfg4_lognormal_full_mantissa": cfg4_bytes(nb_ln, lv_ln),
-               "lagged_returns_5s": 24 * n, "ewmst_60s": 24 * n}
+               "lagged_returns_5s": 24 * n, "ewmst_60s": 24 * n,
+               "cusum_floor_5e-4": 24 * n + 8 * out["cusum_default_floor_5e-4_closes"],
+               "cusum_floor_1e-5": 24 * n + 8 * out["cusum_floor_1e-5_closes"]}
         notes = {"cfg3_volume_build_ohlcv": "SURVEY 8(d): indexer + reducer fused would read amount once with price: 12 B/tick; the build makes two calls (4 + 12)",
                  "cfg3_dollar_build_ohlcv": "SURVEY 8(d): 12 B/tick for indexer + reducer; the build makes two calls (12 x 2 + 12)",
                  "cfg4_lognormal_full_mantissa": "the primary cfg 4 figure: bars of lognormal length (sigma 1), sizes with a full float32 mantissa",
+                 "cusum_floor_5e-4": "24 B/tick read (ts, price, sigma) + 8 B per close; the device time spans the call's host round trips (the chain walk's launches wait for counts)",
+                 "cusum_floor_1e-5": "24 B/tick read (ts, price, sigma) + 8 B per close; one-pass form (csrc/fmk_cusum_onepass.h); the device time spans the call's host round trips",
                  "ewmst_60s": "16 B/tick read (ts, returns) + 8 written", "lagged_returns_5s": "16 B/tick read (ts, price) + 8 written"}
         out["roofline"] = {k: config_roofline(k, dev_ms[k], alg[k], notes.get(k)) for k in alg if k in dev_ms}
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "

@@ -14,7 +14,8 @@ from finmlkit_amd import _ffi, engine
 from finmlkit_amd._ffi import DeviceArray, c_i64
 
 KEYS = ("cfg3_volume_index", "cfg3_volume_build_ohlcv", "cfg3_dollar_index", "cfg3_dollar_build_ohlcv", "cfg4_equal_bars",
-        "cfg4_equal_bars_full_mantissa", "cfg4_lognormal_full_mantissa", "lagged_returns_5s", "ewmst_60s")
+        "cfg4_equal_bars_full_mantissa", "cfg4_lognormal_full_mantissa", "lagged_returns_5s", "ewmst_60s",
+        "cusum_floor_5e-4", "cusum_floor_1e-5")
 
 
 def main():
@@ -48,6 +49,17 @@ def main():
             ci_h = np.concatenate([[-1], np.cumsum(lens) - 1])
             cc = DeviceArray.from_host(ctx, ci_h[ci_h <= n - 1].astype(np.int64))
         fn = lambda: tt.bars_fused(cc, 0.01, 3.0)                    # noqa: E731
+    elif key.startswith("cusum"):
+        # bench.py's CUSUM rows: sigma = ewmst(60 s) of the 5 s lagged returns, sigma_mult 2; the floor decides the tier (5e-4: the
+        # chain walk of fmk_cusum_chain.hip; 1e-5: the one-pass form of fmk_cusum_onepass.h)
+        floor = float(key.split("_")[-1])
+        ret = t.lagged_returns(5.0, True)
+        sig = t.ewmst(ret, 60.0)
+        del ret
+        cus = DeviceArray(ctx, 8_000_000 if n >= 1_000_000_000 else max(n, 16), np.int64)
+        m, rounds = c_i64(), c_i64()
+        fn = lambda: ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sig.p, c_i64(n), C.c_double(floor), C.c_double(2.0),   # noqa: E731
+                              cus.p, c_i64(cus.n), C.byref(m), C.byref(rounds))
     else:
         ret = t.lagged_returns(5.0, True)
         fn = (lambda: t.lagged_returns(5.0, True)) if key == "lagged_returns_5s" else (lambda: t.ewmst(ret, 60.0))

@@ -4,7 +4,7 @@
 # (counters with --kernel-trace only, as gpurun requires); then tools/cfgprof_summarize.py -> gpurun_out/final/ + profiles/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-1e9}; shift
-KEYS=${@:-cfg3_volume_index cfg3_volume_build_ohlcv cfg3_dollar_index cfg3_dollar_build_ohlcv cfg4_equal_bars cfg4_equal_bars_full_mantissa cfg4_lognormal_full_mantissa lagged_returns_5s ewmst_60s}
+KEYS=${@:-cfg3_volume_index cfg3_volume_build_ohlcv cfg3_dollar_index cfg3_dollar_build_ohlcv cfg4_equal_bars cfg4_equal_bars_full_mantissa cfg4_lognormal_full_mantissa lagged_returns_5s ewmst_60s cusum_floor_5e-4 cusum_floor_1e-5}
 O=$R/gpurun_out/cfgprof; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for k in $KEYS; do
