@@ -537,11 +537,9 @@ static int cs1_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, con
         const int variant = v ? atoi(v) : 0;
         const unsigned g = (unsigned)fmk_ceil_div(chunks, (int64_t)CS1_TK);
         unsigned long long *nf = check_nan ? d_nan : nullptr;
-        if (variant == 1) {
-            FMK_HIP(ctx, hipMemsetAsync(E, 0, st_bytes, ctx->stream));
-            FMK_HIP(ctx, hipMemsetAsync(C0, 0, c0_bytes, ctx->stream));
+        if (variant == 1)
             k_cs1_pass<1><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
-        } else if (variant == 2)
+        else if (variant == 2)
             k_cs1_pass<2><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
         else
             k_cs1_pass<0><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
