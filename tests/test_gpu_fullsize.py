@@ -232,10 +232,13 @@ def _threshold_bars_full_size(engine, t, n, px, am, orc, vthr, dthr, kinds):
             assert np.all(v >= vthr - 4.0) and np.all(v < vthr + 4.0)       # reset bars: thr <= vol(+tick 0 rule) < thr + max tick
 
 
-def test_cusum_and_volume_profile_full_size(big, prefix, orc):
+def test_cusum_and_volume_profile_full_size(big, prefix, orc, monkeypatch):
     """The "next" rows at 1e9 ticks: CUSUM closes are causal (prefix parity with the sequential oracle on the same
-    sigma), the rolling volume profile satisfies its ordering invariants on 8e5 bars and equals the oracle on a prefix."""
+    sigma) and, with thresholds reached every ~200 ticks, come from the one-pass form (csrc/fmk_cusum_onepass.h) and equal the
+    fixed point's over the whole stream; the rolling volume profile satisfies its ordering invariants on 8e5 bars and equals
+    the oracle on a prefix."""
     import ctypes as C
+    from finmlkit_amd import _ffi
     from finmlkit_amd._ffi import DeviceArray, c_f64, c_i64
     engine, t, n = big
     ts, px, am, sd = prefix
@@ -250,6 +253,18 @@ def test_cusum_and_volume_profile_full_size(big, prefix, orc):
     t.ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sg.p, c_i64(n), c_f64(1e-5), c_f64(2.0), out.p,
                c_i64(m.value), C.byref(m), C.byref(rounds))
     ci = out.to_host()
+    used, launches, pending, chunks = (c_i64() for _ in range(4))
+    _ffi.lib().fmk_diag_cusum_onepass(C.byref(used), C.byref(launches), C.byref(pending), C.byref(chunks))
+    if n >= 100_000_000:
+        assert used.value == 1 and launches.value <= 8, (used.value, launches.value, pending.value, chunks.value)
+    monkeypatch.setenv("FMK_CUSUM_ONEPASS", "0")                     # the fixed point on chunk-transposed copies (rounds 1-4)
+    m2 = c_i64()
+    t.ctx.call("fmk_cusum_bar_indexer_dev", t.ts.p, t.price.p, sg.p, c_i64(n), c_f64(1e-5), c_f64(2.0), out.p,
+               c_i64(out.n), C.byref(m2), C.byref(rounds))
+    _ffi.lib().fmk_diag_cusum_onepass(C.byref(used), None, None, None)
+    assert used.value == 0 and m2.value == m.value
+    np.testing.assert_array_equal(out.to_host(), ci)
+    monkeypatch.delenv("FMK_CUSUM_ONEPASS")
     del sg, out
     assert rounds.value <= 16 and np.all(np.diff(ci) > 0) and ci[-1] < n
     want = orc._cusum_bar_indexer(ts, px, sigma_prefix, 1e-5, 2.0)
