@@ -92,12 +92,35 @@ def replay(ts, r, sig, fl, mult):
     return out
 
 
+def _onepass():
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    v = [C.c_int64() for _ in range(4)]
+    _ffi.lib().fmk_diag_cusum_onepass(*(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
+
+
+def _tier(n):
+    """which tier answered the last call (the chain walk reports itself through fmk_diag_cusum_last)"""
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    if n < 2:
+        return "none (n < 2 or an exception)"
+    t = C.c_int64()
+    _ffi.lib().fmk_diag_cusum_last(C.byref(t), None, None)
+    if _onepass()[0] == 1:
+        return "one pass"
+    return "chain walk" if t.value == 1 else "fixed point"
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     max_n = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2_000_000
     rng = np.random.default_rng(seed)
     bad = ulp = 0
+    tiers = {"chain walk": 0, "one pass": 0, "fixed point": 0, "none (n < 2 or an exception)": 0}
+    one_pass_chunks = 0
     for case in range(cases):
         n = int(np.exp(rng.uniform(np.log(1), np.log(max_n))))
         if rng.random() < 0.15:
@@ -115,6 +138,9 @@ def main():
             g_exc = None
         except Exception as e:                                      # noqa: BLE001
             got, g_exc = None, type(e).__name__
+        tiers[_tier(n if g_exc is None else 0)] += 1
+        if g_exc is None and _onepass()[0] == 1:
+            one_pass_chunks += _onepass()[3]
         if w_exc or g_exc:
             if w_exc != g_exc:
                 print("EXCEPTION", tag, "oracle", w_exc, "hip", g_exc); bad += 1
@@ -137,6 +163,7 @@ def main():
             print("MISMATCH", tag, "lens", len(got), len(want), "at", k, got[max(0, k - 1):k + 2], want[max(0, k - 1):k + 2]); bad += 1
         elif not np.array_equal(s_got, s_want, equal_nan=True):
             print("SIGMA FILL", tag); bad += 1
+    print("answered by:", ", ".join(f"{k} {v}" for k, v in tiers.items()), f"; chunks of 4096 ticks walked by the one-pass form: {one_pass_chunks}")
     print(f"{cases} cusum cases, seed {seed}, sizes up to {max_n}: {bad} failures; {ulp} cases where the last bit of a logarithm "
           f"decides a close (the reference's loop on the device's tick returns, all within one ulp of np.log's, gives the device's closes)")
     sys.exit(1 if bad else 0)
