@@ -63,6 +63,7 @@ static_assert(sizeof(FlowDirOut) == sizeof(fmk_directional_out), "ABI struct mis
 
 struct FlowDir {                        // per-lane accumulators of one bar
     double vb, vs, db, ds, cs, mxs;
+    double da, va;                   // sums of |price x amount| and (float64 amounts) |amount| over the signed ticks: see bf_dir_write
     double vmin, vmax, dmin, dmax;
     int tmin, tmax, nbuy, nsell;
     // ticks from the bar's start to the END of the tile in which each float extremum was last improved (an upper bound of its
@@ -79,6 +80,7 @@ struct FlowDir {                        // per-lane accumulators of one bar
 __device__ __forceinline__ void bf_dir_init(FlowDir &d)
 {
     d.vb = d.vs = d.db = d.ds = d.cs = d.mxs = 0.0;
+    d.da = d.va = 0.0;
     d.vmin = d.dmin = 1e9; d.vmax = d.dmax = -1e9;       // base.py:461-464
     d.tmin = BF_INIT_MIN; d.tmax = BF_INIT_MAX;
     d.nbuy = d.nsell = 0;
@@ -142,6 +144,8 @@ __device__ __forceinline__ void bf_dir_tile(int lane, int lr, int tn, const doub
         if (buy) { d.vb += av; d.db += pv; d.nbuy += 1; }
         if (sell) { d.vs += av; d.ds += pv; d.nsell += 1; }
         if (buy || sell) {                                   // base.py:518-527: signed ticks only
+            d.da += fabs(pv);
+            if constexpr (sizeof(AmtT) == 8) d.va += fabs(av);
             rt += buy ? 1 : -1;
             rv += buy ? av : -av;
             rd += buy ? pv : -pv;
@@ -259,6 +263,7 @@ __device__ __forceinline__ void bf_dir_sequential(const FlowDirOut &o, int64_t b
 // the bar's (or a bar segment's) accumulators folded over the wave: wave-uniform
 struct FlowTotals {
     double vb, vs, db, ds, cs, mxs;
+    double da, va;
     double vmin, vmax, dmin, dmax;
     int tb, tsell, tmin, tmax;
     int64_t kvmin, kvmax, kdmin, kdmax;      // upper bounds of the extrema's positions (ticks from the bar's start)
@@ -276,6 +281,7 @@ __device__ __forceinline__ FlowTotals bf_dir_fold(const FlowDir &d)
     t.vb = fmk_dpp_reduce(d.vb, 0.0, FmkOpAdd()); t.vs = fmk_dpp_reduce(d.vs, 0.0, FmkOpAdd());
     t.db = fmk_dpp_reduce(d.db, 0.0, FmkOpAdd()); t.ds = fmk_dpp_reduce(d.ds, 0.0, FmkOpAdd());
     t.cs = fmk_dpp_reduce(d.cs, 0.0, FmkOpAdd()); t.mxs = fmk_dpp_reduce(d.mxs, 0.0, FmkOpMax());
+    t.da = fmk_dpp_reduce(d.da, 0.0, FmkOpAdd()); t.va = fmk_dpp_reduce(d.va, 0.0, FmkOpAdd());
     t.tb = fmk_dpp_reduce(d.nbuy, 0, FmkOpAdd()); t.tsell = fmk_dpp_reduce(d.nsell, 0, FmkOpAdd());
     t.tmin = fmk_dpp_reduce(d.tmin, BF_INIT_MIN, FmkOpMin());
     t.tmax = fmk_dpp_reduce(d.tmax, BF_INIT_MAX, FmkOpMax());
@@ -330,17 +336,27 @@ __device__ __forceinline__ void bf_dir_write(const FlowDirOut &o, int64_t b, int
     };
     unsigned mask = 0;
     // (magnitudes: a tape of NEGATIVE prices -- tools/fuzz_fused.py drew one, seed 7707 case 9 -- has negative dollar sums; with the signed
-    //  sum as the bound the test said "not near" for every bar and five of 1 649 kept the parallel order's last bit.  A bar whose prices
-    //  change sign is still outside the bound's assumption |sum| == sum |terms|.)
+    //  sum as the bound the test said "not near" for every bar and five of 1 649 kept the parallel order's last bit.)
+    // Both bounds take |sum| for the sum of the terms' magnitudes, which holds while the terms of a bar have ONE sign.  t.da is that sum
+    // of magnitudes itself (one more addition per signed tick): a bar in which it exceeds |db| + |ds| has price x amount terms of both
+    // signs -- its sums cancel, the bounds would come out too small -- and goes to the tick-order redo with every dollar column,
+    // whatever its values.  (Below the 1e-9 the test allows for da's own rounding, A is understated by less than that factor: the 1.8 %
+    // between 1.13e-16 and 2^-53 in eps_at, and the 5 % in eps, cover it.  A NaN sum compares false and takes the tests below, as before.)
     const double adb = fabs(db), ads = fabs(ds);
-    if (fmk_near_f32_tie(db, eps * adb)) mask |= 1u << 2;
-    if (fmk_near_f32_tie(ds, eps * ads)) mask |= 1u << 3;
+    if (t.da > (adb + ads) * (1.0 + 1e-9)) mask |= (1u << 2) | (1u << 3) | (1u << 6);
+    else {
+        if (fmk_near_f32_tie(db, eps * adb)) mask |= 1u << 2;
+        if (fmk_near_f32_tie(ds, eps * ads)) mask |= 1u << 3;
+        if (tb + tsell > 0 && (fmk_near_f32_tie(dmin, eps_at(t.kdmin, md, adb + ads)) || fmk_near_f32_tie(dmax, eps_at(t.kdmax, md, adb + ads)))) mask |= 1u << 6;
+    }
     if (fmk_near_f32_tie(mean, (eps + 1.2e-16) * fabs(mean))) mask |= 1u << 4;
-    if (tb + tsell > 0 && (fmk_near_f32_tie(dmin, eps_at(t.kdmin, md, adb + ads)) || fmk_near_f32_tie(dmax, eps_at(t.kdmax, md, adb + ads)))) mask |= 1u << 6;
     if constexpr (sizeof(AmtT) == 8) {
-        if (fmk_near_f32_tie(vb, eps * fabs(vb))) mask |= 1u << 0;
-        if (fmk_near_f32_tie(vs, eps * fabs(vs))) mask |= 1u << 1;
-        if (tb + tsell > 0 && (fmk_near_f32_tie(vmin, eps_at(t.kvmin, mv, fabs(vb) + fabs(vs))) || fmk_near_f32_tie(vmax, eps_at(t.kvmax, mv, fabs(vb) + fabs(vs))))) mask |= 1u << 5;
+        if (t.va > (fabs(vb) + fabs(vs)) * (1.0 + 1e-9)) mask |= (1u << 0) | (1u << 1) | (1u << 5);       // amounts of both signs
+        else {
+            if (fmk_near_f32_tie(vb, eps * fabs(vb))) mask |= 1u << 0;
+            if (fmk_near_f32_tie(vs, eps * fabs(vs))) mask |= 1u << 1;
+            if (tb + tsell > 0 && (fmk_near_f32_tie(vmin, eps_at(t.kvmin, mv, fabs(vb) + fabs(vs))) || fmk_near_f32_tie(vmax, eps_at(t.kvmax, mv, fabs(vb) + fabs(vs))))) mask |= 1u << 5;
+        }
     }
     if (bf_force_redo != 0) mask = 0x7F;                               // (tests: every bar through the tick-order redo)
     if (mask && lane == 0) redo[32 + atomicAdd(redo, 1ULL)] = (unsigned long long)b | ((unsigned long long)mask << 48);
@@ -530,6 +546,7 @@ __global__ __launch_bounds__(64 * BFW_WAVES, 4) void k_bar_dir_wide(const double
             for (int k = 1; k < BFW_WAVES; ++k) {
                 const FlowTotals &x = s_seg[k].t;
                 a.vb += x.vb; a.vs += x.vs; a.db += x.db; a.ds += x.ds; a.cs += x.cs;
+                a.da += x.da; a.va += x.va;
                 a.mxs = fmax(a.mxs, x.mxs);
                 a.tb += x.tb; a.tsell += x.tsell;
                 if (x.tmin != BF_INIT_MIN) {                         // the segment met a signed tick: its extrema count

@@ -264,6 +264,34 @@ def test_order_flow_on_negative_prices(orc):
     _check_dir(got, want, "negative prices")
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_order_flow_on_prices_that_change_sign_inside_a_bar(orc, f64):
+    """Prices (and, with float64 amounts, sizes) of BOTH signs inside one bar: the dollar sums cancel, so |dollars_buy| + |dollars_sell|
+    is no longer the sum of the terms' magnitudes the tie bounds are built on.  The kernel carries that sum itself and sends
+    every bar in which it is larger to the tick-order redo; bars of ~900 ticks (one wave), a 40 000-tick bar (eight waves, composed) and
+    the few-tick bars between them, against the oracle on all 14 columns."""
+    from finmlkit_amd.bar.base import comp_bar_directional_features
+    rng = np.random.default_rng(7711)
+    n = 2_000_000
+    px = np.round(np.cumsum(rng.integers(-1, 2, n)) * 0.0005, 4) + rng.choice([-0.25, 0.25], n)     # hovers around zero, both signs in every bar
+    px[px == 0.0] = 0.0005
+    if f64:
+        am = rng.integers(1, 4097, n) / 1024.0 * rng.choice([1.0, 1.0, 1.0, -1.0], n)               # a quarter of the sizes negative
+        am = am + rng.random(n) * 2.0 ** -30                                                        # full float64 mantissas
+    else:
+        am = (rng.integers(1, 4097, n) / 1024.0).astype(np.float32)
+    sd = rng.choice(np.array([-1, 1], np.int8), n)
+    lens = np.maximum(1, rng.normal(900, 45, int(n / 900 * 1.2)).astype(np.int64))
+    lens[5] = 40_000
+    lens[9:12] = (1, 2, 3)
+    ci = np.concatenate([[-1], np.cumsum(lens) - 1])
+    ci = ci[ci <= n - 1].astype(np.int64)
+    assert (px[: ci[8]] > 0).any() and (px[: ci[8]] < 0).any()
+    got = comp_bar_directional_features(px, am, ci, sd)
+    want = orc.comp_bar_directional_features(px, am, ci, sd, raise_on_zero_div=False)
+    _check_dir(got, want, f"prices of both signs inside the bars, float64 amounts {f64}")
+
+
 def test_order_flow_extremum_near_tie_with_nan_elsewhere_in_the_bar(orc):
     """tools/fuzz_longbars.py seed 361, case 70 (tests/golden/nan_tie_longbar.npz, tools/gen_nan_tie_fixture.py): a 65 537-tick bar whose running
     signed dollar sum peaks 2.7e-12 below a float32 rounding boundary at tick 488 and holds a NaN amount at tick 554.  The NaN made the
