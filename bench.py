@@ -470,14 +470,27 @@ class _StdoutIsTheJsonLine:
 
     def __enter__(self):
         sys.stdout.flush()
-        _StdoutIsTheJsonLine.saved = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+            except OSError:                             # no usable stderr: leave stdout alone (the line is still its last one)
+                os.close(saved)
+                saved = None
+        except OSError:
+            saved = None
+        _StdoutIsTheJsonLine.saved = saved
         return self
 
     @staticmethod
     def emit(text):
         fd = _StdoutIsTheJsonLine.saved
-        if fd is None:                                  # (run() called without the guard: tests that import bench)
+        if fd is None:                                  # (no guard, or no usable stderr: keep the line the LAST one of stdout)
+            try:
+                import ctypes as C
+                C.CDLL(None).fflush(None)               # librccl's banner sits in the C stdio buffer
+            except OSError:
+                pass
             print(text, flush=True)
             return
         data = (text + "\n").encode()
@@ -491,9 +504,10 @@ class _StdoutIsTheJsonLine:
         except OSError:
             pass
         sys.stdout.flush()
-        os.dup2(_StdoutIsTheJsonLine.saved, 1)
-        os.close(_StdoutIsTheJsonLine.saved)
-        _StdoutIsTheJsonLine.saved = None
+        if _StdoutIsTheJsonLine.saved is not None:
+            os.dup2(_StdoutIsTheJsonLine.saved, 1)
+            os.close(_StdoutIsTheJsonLine.saved)
+            _StdoutIsTheJsonLine.saved = None
         return False
 
 
