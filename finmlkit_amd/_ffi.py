@@ -75,7 +75,7 @@ def lib() -> C.CDLL:
 
 _diag = None
 DIAG_PROBES = ("fmk_diag_read_bandwidth", "fmk_diag_fill_amounts_dev", "fmk_diag_read_two_streams", "fmk_diag_hop_latency",
-               "fmk_diag_h2d_rate", "fmk_diag_marker_dev")
+               "fmk_diag_h2d_rate", "fmk_diag_marker_dev", "fmk_diag_read_owned")
 
 
 def diag_lib() -> C.CDLL:

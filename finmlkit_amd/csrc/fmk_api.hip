@@ -90,6 +90,7 @@ int fmk_ctx_destroy(fmk_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    fmk_fused_release(ctx);
     fmk_pool_destroy(ctx);
     fmk_volume_trim(ctx);
     fmk_dollar_trim(ctx);
@@ -116,6 +117,7 @@ int fmk_ctx_trim(fmk_ctx *ctx)
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    fmk_fused_release(ctx);
     fmk_pool_flush(ctx);
     fmk_volume_trim(ctx);
     fmk_dollar_trim(ctx);

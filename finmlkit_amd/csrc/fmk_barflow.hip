@@ -1635,6 +1635,194 @@ __global__ __launch_bounds__(256, 4) void k_bar_ohlcv_dir(const double *__restri
     }
 }
 
+#include "fmk_fused.h"
+
+// ---------------------------------------------------------------------------------------
+// cfg 4 in one pass (fmk_fused.h): host side
+// ---------------------------------------------------------------------------------------
+struct FuState {                      // what the sizing call leaves for the fill call (ctx->fused)
+    void *block;                      // one allocation: staged rows [nb * FU_LV] x 4 arrays, L[nb], fp_list[nb + 32], the kernel's FuArgs
+    FuStage stg;
+    unsigned long long *fp_list;
+    int64_t nb, n_fp;
+    const int64_t *ci;                // the close indices the rows belong to (the fill call must name the same)
+};
+
+void fmk_fused_release(fmk_ctx *ctx)
+{
+    FuState *st = (FuState *)ctx->fused;
+    if (!st) return;
+    if (st->block) (void)fmk_free(ctx, st->block);
+    free(st);
+    ctx->fused = nullptr;
+}
+
+// Does the one-pass kernel serve this tape?  float32 amounts; bars of 96 .. ~1 400 ticks on average (shorter: the several-bars-per-wave
+// schedules are ahead; longer: most ticks would lie in bars beyond FU_MAXT); a sample of the amounts certifies -- whole multiples of
+// their common power of two below 2^23 of them (full-mantissa sizes never do: every bar would come back on the lists after a wasted
+// sweep).  FMK_FUSED: 0 never, 2 whenever the dtype allows (tests), unset / 1: by these rules.
+__global__ __launch_bounds__(256) void k_fu_census(const float *__restrict__ amount, int64_t n, int *__restrict__ out /* [0] min low bit, [1] max exponent, [2] bad */)
+{
+    const int64_t stride = n / 4096 > 0 ? n / 4096 : 1;
+    int lb = FP_Q_UNKNOWN, mx = -1000, bad = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < 4096; k += (int64_t)gridDim.x * blockDim.x) {
+        // 16 consecutive amounts at each of 4 096 places
+        const int64_t j0 = k * stride;
+        for (int64_t j = j0; j < j0 + 16 && j < n; ++j) {
+            const float a = amount[j];
+            const int l = fp_lowbit_exp(a);
+            if (l == (int)0x80000000 || a < 0.f) bad = 1;
+            else if (l != FP_Q_UNKNOWN) { lb = l < lb ? l : lb; int ex; (void)frexpf(a, &ex); mx = ex > mx ? ex : mx; }
+        }
+    }
+    lb = fmk_dpp_reduce(lb, (int)FP_Q_UNKNOWN, FmkOpMin());
+    mx = fmk_dpp_reduce(mx, -1000, FmkOpMax());
+    if (fmk_lane() == 0) { atomicMin(out, lb); atomicMax(out + 1, mx); if (bad) atomicOr(out + 2, 1); }
+    if (__ballot(bad != 0) != 0 && fmk_lane() == 0) atomicOr(out + 2, 1);
+}
+
+static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n, int64_t nb, bool *ok)
+{
+    *ok = false;
+    const char *fv = getenv("FMK_FUSED");
+    const int mode = fv ? atoi(fv) : 1;
+    if (mode == 0 || amount_is_f64 || nb < 1) return FMK_OK;
+    if (mode == 2) { *ok = true; return FMK_OK; }
+    const int64_t mean = n / nb;
+    if (mean < 96 || mean > 1400 || nb < (int64_t)ctx->n_cu * 8) return FMK_OK;
+    int *d = (int *)(ctx->d_mail + 44);
+    const int init[3] = {FP_Q_UNKNOWN, -1000, 0};
+    FMK_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    k_fu_census<<<16, 256, 0, ctx->stream>>>((const float *)d_amount, n, d);
+    FMK_LAUNCH_CHECK(ctx);
+    int got[3];
+    FMK_HIP(ctx, hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // largest sampled amount < 2^mx: below 2^23 units of 2^lb when mx - lb <= 23 (one binade of slack for what the sample missed)
+    *ok = got[2] == 0 && (got[0] == FP_Q_UNKNOWN || got[1] - got[0] <= 22);
+    return FMK_OK;
+}
+
+static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_amount, int64_t n, const int64_t *d_close_idx,
+                           int64_t n_idx, const int8_t *d_side, double price_tick_size, double *d_open, double *d_high, double *d_low,
+                           double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades, double *d_median,
+                           const fmk_directional_out *d_dir, int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
+                           int64_t *max_levels)
+{
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    FMK_TRY(bf_sync_force_redo(ctx));
+    fmk_fused_release(ctx);
+    const int64_t nb = n_idx - 1;
+    FlowDirOut o;
+    memcpy(&o, d_dir, sizeof(o));
+    FuState *st = (FuState *)calloc(1, sizeof(FuState));
+    if (!st) return fmk_set_error(ctx, FMK_E_NOMEM, "calloc");
+    const size_t rows = (size_t)nb * FU_LV;
+    const size_t lbytes = ((size_t)nb * 4 + 255) & ~(size_t)255, fbytes = ((size_t)(nb + 32) * 8 + 255) & ~(size_t)255;
+    const size_t bytes = rows * 16 + lbytes + fbytes + sizeof(FuArgs);
+    int rc = fmk_alloc(ctx, bytes, &st->block);
+    if (rc != FMK_OK) { free(st); return rc; }
+    unsigned char *blk = (unsigned char *)st->block;
+    st->stg.bv = (float *)blk; st->stg.sv = (float *)(blk + rows * 4);
+    st->stg.bc = (int *)(blk + rows * 8); st->stg.sc = (int *)(blk + rows * 12);
+    st->stg.L = (int *)(blk + rows * 16);
+    st->fp_list = (unsigned long long *)(blk + rows * 16 + lbytes);
+    FuArgs *d_args = (FuArgs *)(blk + rows * 16 + lbytes + fbytes);
+    st->nb = nb; st->ci = d_close_idx; st->n_fp = -1;
+    ctx->fused = st;
+    // two redo lists: the one-pass kernel's own (bars of <= FU_MAXT ticks: one wave per bar walks them, k_bar_dir_redo) and k_bar_dir's
+    // (any length: the chunk-record kernel).  On the bench tape 0.19 % of the bars are TRUE near-ties -- its prices and sizes lie on
+    // grids that put running dollar sums exactly on float32 midpoints -- and the chunk-record kernel took 0.41 ms for those 1 591 short bars
+    unsigned long long *redo;
+    rc = fmk_scratch(ctx, (size_t)(nb + 32) * 24, (void **)&redo);
+    if (rc != FMK_OK) { fmk_fused_release(ctx); return rc; }
+    unsigned long long *dir_list = redo + nb + 32, *redo_fu = redo + 2 * (nb + 32);
+    int *saw_long = (int *)(ctx->d_mail + 18);
+    FuLists li{redo_fu, dir_list, st->fp_list, saw_long};
+    auto fail = [&](int code) { fmk_fused_release(ctx); return code; };
+#define FU_HIP(expr) do { const hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(fmk_set_error(ctx, FMK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
+    FU_HIP(hipMemsetAsync(redo, 0, 8, ctx->stream));
+    FU_HIP(hipMemsetAsync(redo_fu, 0, 8, ctx->stream));
+    FU_HIP(hipMemsetAsync(dir_list, 0, 8, ctx->stream));
+    FU_HIP(hipMemsetAsync(st->fp_list, 0, 8, ctx->stream));
+    FU_HIP(hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+    FuArgs h_args;
+    h_args.oo = FuOhlcv{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median};
+    h_args.o = o; h_args.stg = st->stg; h_args.li = li;
+    FU_HIP(hipMemcpyAsync(d_args, &h_args, sizeof h_args, hipMemcpyHostToDevice, ctx->stream));   // (pageable source: copied before the call returns)
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (d_median)
+        k_fu_bars<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+    else
+        k_fu_bars<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+    FU_HIP(hipGetLastError());
+    // bars of more than FU_MAXT ticks: open .. trades and the median by comp_bar_ohlcv's leftover passes (they look at the flag on the device)
+    rc = fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, FU_MAXT, saw_long, d_open, d_high, d_low, d_close,
+                                   d_volume, d_vwap, d_trades);
+    if (rc == FMK_OK && d_median) rc = fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, FU_MAXT, saw_long, d_median, n);
+    if (rc != FMK_OK) return fail(rc);
+    // the order flow of the listed bars (outside the class: empty, long, uncertified sizes, sides other than +-1, prices <= 0), then the
+    // tick-order redo of both kernels' float32 ties
+    int64_t dblocks = fmk_ceil_div(nb, 4);
+    if (dblocks > 2048) dblocks = 2048;
+    k_bar_dir<false><<<(unsigned)dblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
+                                                               (unsigned long long *)d_n_zero_div, redo, dir_list);
+    FU_HIP(hipGetLastError());
+    bf_redo_launch<false>(ctx, (unsigned)dblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
+    FU_HIP(hipGetLastError());
+    k_bar_dir_redo<false><<<(unsigned)dblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo_fu);
+    FU_HIP(hipGetLastError());
+    FU_HIP(hipMemcpyAsync(&ctx->h_mail[14], st->fp_list, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FU_HIP(hipMemcpyAsync(&ctx->h_mail[15], dir_list, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FU_HIP(hipMemcpyAsync(&ctx->h_mail[16], redo_fu, 8, hipMemcpyDeviceToHost, ctx->stream));
+#undef FU_HIP
+    rc = fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, nb, price_tick_size, d_level_offsets, total_levels, max_levels);
+    if (rc != FMK_OK) return fail(rc);
+    st->n_fp = ctx->h_mail[14];                                      // (the sizing call has waited for the stream)
+    return FMK_OK;
+}
+
+// The fill call of a sizing call that took the one-pass kernel: the staged rows -> CSR rows + per-bar features, the listed bars by
+// the class kernels.  *handled = 0: no state for these close indices (the caller runs the ordinary fill).
+int fmk_fused_fill(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                   int64_t n_idx, const int8_t *d_side, double price_tick_size, const double *d_bar_lows, double imbalance_factor,
+                   const int64_t *d_level_offsets, int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
+                   int *handled)
+{
+    *handled = 0;
+    FuState *st = (FuState *)ctx->fused;
+    if (!st) return FMK_OK;
+    if (st->ci != d_close_idx || st->nb != n_idx - 1 || amount_is_f64 || st->n_fp < 0) { fmk_fused_release(ctx); return FMK_OK; }
+    *handled = 1;
+    const int64_t nb = st->nb;
+    FpOut o;
+    memcpy(&o, d_out, sizeof(o));
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    const int64_t cap = (int64_t)ctx->n_cu * 32;
+    if (blocks > cap) blocks = cap;
+    k_fu_emit<<<(unsigned)blocks, 256, 0, ctx->stream>>>(st->stg, d_bar_lows, price_tick_size, imbalance_factor, d_level_offsets, nb, o);
+    int rc = FMK_OK;
+    if (hipGetLastError() != hipSuccess) rc = fmk_set_error(ctx, FMK_E_HIP, "k_fu_emit: launch failed");
+    if (rc == FMK_OK && st->n_fp > 0)
+        rc = fmk_footprints_fill_classes(ctx, d_price, d_amount, 0, d_close_idx, nb, d_side, price_tick_size, d_bar_lows, imbalance_factor,
+                                         d_level_offsets, 0, max_levels, d_out, d_n_bad_level, n, nullptr, st->fp_list);
+    fmk_fused_release(ctx);                                          // (stream-ordered: the launches above are queued before the free)
+    return rc;
+}
+
+// diagnostics of the last one-pass sizing call: bars handed to the class kernels (footprints), to k_bar_dir (order flow), and the
+// (bar, columns) entries of the tick-order redo
+extern "C" int fmk_diag_fused_last(fmk_ctx *ctx, int64_t *n_fp_list, int64_t *n_dir_list, int64_t *n_redo)
+{
+    *n_fp_list = ctx->h_mail[14];
+    *n_dir_list = ctx->h_mail[15];
+    *n_redo = ctx->h_mail[16];
+    return FMK_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -1801,6 +1989,16 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
     // long bars (hourly, daily): comp_bar_ohlcv and the order-flow features each have workgroup-per-bar schedules of their own
     // (fmk_ohlcv.hip: k_bar_ohlcv_mid / _wide, here: k_bar_dir_wide); the fused wave-per-bar kernel below is for the middle
     const bool long_bars = n / (n_idx - 1) > 8192;
+    // the common class in ONE pass over the ticks (fmk_fused.h; round 6): 13 B/tick read once for all three families
+    {
+        bool fused_ok = false;
+        FMK_TRY(bars_flow_fused_ok(ctx, d_amount, amount_is_f64, n, n_idx - 1, &fused_ok));
+        if (fused_ok && !separate)
+            return bars_flow_fused(ctx, d_price, (const float *)d_amount, n, d_close_idx, n_idx, d_side, price_tick_size, d_open, d_high,
+                                   d_low, d_close, d_volume, d_vwap, d_trades, d_median, d_dir, d_n_zero_div, d_level_offsets,
+                                   total_levels, max_levels);
+        fmk_fused_release(ctx);                                          // (a stale state of an earlier call)
+    }
     if (amount_is_f64 || separate || short_bars || long_bars) {
         // Long bars (hourly, daily), float32 sizes: comp_bar_ohlcv and the order-flow features share nothing but the input columns -- the
         // first runs on the context's auxiliary stream beside the second (cfg 4 at hourly / daily bars 12.1 / 16.0 -> 11.0 / 13.9 ms per

@@ -46,7 +46,15 @@ struct fmk_ctx {
     // auxiliary stream + events of the pipelined time-bar step (fmk_ohlcv.hip), made on first use (fmk_ctx_aux)
     hipStream_t aux;
     hipEvent_t aev[4];
+    // cfg 4 in one pass (fmk_fused.h): what the sizing call leaves for the fill call -- staged level rows, the list of bars the class
+    // kernels still have to serve (fmk_barflow.hip: FuState); released by the fill call, the next sizing call, trim and destroy
+    void *fused;
 };
+void fmk_fused_release(fmk_ctx *ctx);
+int fmk_fused_fill(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64, int64_t n, const int64_t *d_close_idx,
+                   int64_t n_idx, const int8_t *d_side, double price_tick_size, const double *d_bar_lows, double imbalance_factor,
+                   const int64_t *d_level_offsets, int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
+                   int *handled);
 int fmk_ctx_aux(fmk_ctx *ctx);
 int fmk_pool_defer(fmk_ctx *ctx, int on);   // park fmk_free while a call launches on two streams (fmk_api.hip)
 // fmk_indexers.hip: the time-bar indexer in stages (sample table, then edges [k0, k1) on a given stream, with the long-bar census)
@@ -69,7 +77,8 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level,
                                 int64_t n_ticks /* 0: unknown */,
-                                double *d_median = nullptr /* float32 amounts: the median trade size from the same sweep */);
+                                double *d_median = nullptr /* float32 amounts: the median trade size from the same sweep */,
+                                const unsigned long long *only_list = nullptr /* [0] = count, bars from [32]: only these bars, by the wave-per-bar classes */);
 // median of the bars of more than min_cnt ticks (flag d_go), except those of skip_lo < ticks <= skip_hi (served by k_bar_ohlcv_mid)
 int fmk_median_launch(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, const int64_t *d_close_idx, int64_t nb,
                       int64_t min_cnt, const int *d_go, double *d_median, int64_t n_ticks, int64_t skip_lo = 0,
@@ -191,40 +200,6 @@ __device__ __forceinline__ double fmk_amt(const void *p, int64_t j)
 
 // Python negative-index wrap of the reference (prices[-1] when close_idx[0] == -1)
 __device__ __forceinline__ int64_t fmk_wrap(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
-
-// log(p / pm) for tick returns (comp_lagged_returns utils.py, _cusum_bar_indexer logic.py:198): the quotient as the reference
-// rounds it, then its logarithm -- THE SAME DOUBLE AS THE HOST'S log(), which is what the oracle (and Numba's compiled code) calls.
-// Prices a few ticks apart give x = p / pm next to 1, and for x in [1 - 2^-4, 1 + 0x1.09p-4) glibc's log (2.28 and later:
-// sysdeps/ieee754/dbl-64/e_log.c, the ARM optimized-routines algorithm) does not use its table: r = x - 1, a degree-11 polynomial
-// in r whose leading terms r - r^2 / 2 are formed in double-double, 0.507 ulp.  That branch is restated here operation by
-// operation, with the FMA contractions GCC makes in the `fma` build of libm that x86-64 hosts with FMA3 select (ifunc) --
-// tools/logratio_check.c holds the same restatement in C and compares it with the host's log(): 0 differences on 2e7 price
-// quotients and on a sweep of 5.7e7 arguments across the interval (the non-FMA build of the same source differs from the FMA build
-// in ~8 of 1e6 arguments: the contract is pinned to the FMA build, the one on this image's hosts).  Round 4's own 12-term
-// polynomial differed from glibc in ~4 of 1e6 quotients, which moved CUSUM closes on knife-edge streams (7 of 8 000 fuzz cases).
-// Anything outside the interval -- moves of more than 6 %, zero, negative, non-finite -- goes to the device library's log, which
-// may differ from glibc's table branch in the last bit.
-__device__ __noinline__ static double fmk_log_far(double x) { return log(x); }   // (not inlined: ~150 instructions, rarely run)
-__device__ __forceinline__ double fmk_log_near1(double x)
-{
-    const double r = x - 1.0, r2 = r * r, r3 = r * r2;
-    double q = fma(r3, -0x1.5521375d145cdp-4, fma(r2, 0x1.78182f7afd085p-4, fma(r, -0x1.999eb43b068ffp-4, 0x1.c7184282ad6cap-4)));
-    q = fma(r3, q, fma(r2, -0x1.fffffa4423d65p-4, fma(r, 0x1.24924a344de3p-3, -0x1.55555556745a7p-3)));
-    q = fma(r3, q, fma(r2, 0x1.999999995dd0cp-3, fma(r, -0x1.ffffffffffdcbp-3, 0x1.5555555555577p-2)));
-    double w = r * 0x1p27;
-    const double rhi = r + w - w, rlo = r - rhi;                     // r = rhi + rlo, rhi on 26 bits: rhi * rhi is exact
-    w = rhi * rhi * -0.5;
-    const double hi = r + w;
-    double lo = r - hi + w;
-    lo = fma(-0.5 * rlo, rhi + r, lo);
-    return fma(r3, q, lo) + hi;
-}
-__device__ __forceinline__ double fmk_log_ratio(double p, double pm)
-{
-    const double x = p / pm;
-    if (!(x >= 0.9375 && x < 0x1.109p+0)) return fmk_log_far(x);     // [1 - 2^-4, 1 + 0x1.09p-4): glibc's table-free branch
-    return fmk_log_near1(x);
-}
 
 // splitmix64-style counter hash shared with oracle/fmk_oracle.c (orc_mix64)
 __host__ __device__ __forceinline__ uint64_t fmk_mix64(uint64_t x)

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "fmk_common.h"
+#include "fmk_log.h"
 #include "fmk_scan.h"
 
 #define CS_CHUNK 2048          // ticks per thread

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "fmk_common.h"
+#include "fmk_log.h"
 #include "fmk_dpp.h"
 
 #define CC_CHUNK 2048

@@ -211,6 +211,116 @@ extern "C" int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, 
 
 
 
+// Three columns (price 8 B, amount 4 B, side 1 B per tick) read by one wave per `seg`-tick segment in tiles of 512 ticks, with
+// lane l owning R CONSECUTIVE ticks of every group of 64 R (tools/ownedread.py; round 6): R = 1 is the reducers' chunk layout (one
+// tick per lane and load: 24 loads per tile), R = 2 / 4 / 8 read 16-byte vectors per lane (12 / 8 / 7 loads per tile; for R >= 4 a
+// price load instruction touches every second / every line of its 2 / 4 KB span and the R / 2 loads of a lane group share lines).
+// The question: does the memory pipeline deliver the same bytes per second when lanes own consecutive ticks (a layout in which a
+// running-sum walk needs one wave scan per tile instead of one per chunk)?  Not used by any product path.
+template <int R>
+__global__ __launch_bounds__(256) void k_diag_read_owned(const double *__restrict__ price, const float *__restrict__ amount,
+                                                         const signed char *__restrict__ side, int64_t n, int seg,
+                                                         unsigned long long *sink)
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2), aligned(1)));
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nseg = n / seg;
+    unsigned acc = 0;
+    for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+        const int64_t base = s * seg;
+        const double *pb = price + base;
+        const float *ab = amount + base;
+        const signed char *sb = side + base;
+        for (int t0 = 0; t0 < seg; t0 += 512) {
+            const int last = seg - 1;
+            if constexpr (R == 1) {
+                uint2 pv[8];
+                unsigned av[8];
+                int sv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    int j = t0 + c * 64 + lane;
+                    j = j < last ? j : last;
+                    pv[c] = ((const uint2 *)pb)[j];
+                    av[c] = ((const unsigned *)ab)[j];
+                    sv[c] = sb[j];
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc ^= pv[c].x ^ pv[c].y ^ av[c] ^ (unsigned)sv[c];
+            } else if constexpr (R == 2) {
+                u4 pv[4];
+                uint2 av[4];
+                unsigned short sv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int j = t0 + g * 128 + 2 * lane;
+                    j = j < last - 1 ? j : last - 1;
+                    pv[g] = *(const u4 *)(pb + j);
+                    av[g] = *(const uint2 *)(ab + j);
+                    sv[g] = *(const unsigned short *)(sb + j);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc ^= pv[g].x ^ pv[g].y ^ pv[g].z ^ pv[g].w ^ av[g].x ^ av[g].y ^ sv[g];
+            } else if constexpr (R == 4) {
+                u4 pv[4];
+                u4 av[2];
+                unsigned sv[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    int j = t0 + g * 256 + 4 * lane;
+                    j = j < last - 3 ? j : last - 3;
+                    pv[2 * g] = *(const u4 *)(pb + j);
+                    pv[2 * g + 1] = *(const u4 *)(pb + j + 2);
+                    av[g] = *(const u4 *)(ab + j);
+                    sv[g] = *(const unsigned *)(sb + j);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc ^= pv[g].x ^ pv[g].y ^ pv[g].z ^ pv[g].w;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc ^= av[g].x ^ av[g].y ^ av[g].z ^ av[g].w ^ sv[g];
+            } else {
+                int j = t0 + 8 * lane;
+                j = j < last - 7 ? j : last - 7;
+                u4 pv[4];
+                u4 av[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pv[k] = *(const u4 *)(pb + j + 2 * k);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) av[k] = *(const u4 *)(ab + j + 4 * k);
+                const u2 sv = *(const u2 *)(sb + j);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc ^= pv[g].x ^ pv[g].y ^ pv[g].z ^ pv[g].w;
+                acc ^= av[0].x ^ av[0].y ^ av[0].z ^ av[0].w ^ av[1].x ^ av[1].y ^ av[1].z ^ av[1].w ^ sv.x ^ sv.y;
+            }
+        }
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ULL);
+}
+
+extern "C" int fmk_diag_read_owned(fmk_ctx *ctx, const double *d_price, const float *d_amount, const signed char *d_side, int64_t n,
+                                   int seg, int r, int blocks_per_cu, double *elapsed_ms)
+{
+    if (n <= 0 || seg < 16 || (r != 1 && r != 2 && r != 4 && r != 8)) return fmk_set_error(ctx, FMK_E_ARG, "diag: bad arguments");
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned blocks = (unsigned)(ctx->n_cu * (blocks_per_cu > 0 ? blocks_per_cu : 4));
+    unsigned long long *sink = (unsigned long long *)(ctx->d_mail + 60);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (r == 1) k_diag_read_owned<1><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, n, seg, sink);
+    else if (r == 2) k_diag_read_owned<2><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, n, seg, sink);
+    else if (r == 4) k_diag_read_owned<4><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, n, seg, sink);
+    else k_diag_read_owned<8><<<blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, n, seg, sink);
+    FMK_LAUNCH_CHECK(ctx);
+    FMK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FMK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return FMK_OK;
+}
+
+
 // Amounts with a full random 24-bit mantissa in [2^-7, 2): float32 sums of them are inexact in every order, like real trade
 // sizes (the synthetic stream's dyadic amounts make every footprint bar take the certified integer path).  bench.py times
 // cfg 4 on both.  Not used by any product path.

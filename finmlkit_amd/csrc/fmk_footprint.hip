@@ -1282,6 +1282,12 @@ extern "C" int fmk_comp_bar_footprints_fill_dev(fmk_ctx *ctx, const double *d_pr
                              "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
                              (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    {   // a sizing call that took the one-pass kernel left the rows staged (fmk_fused.h)
+        int handled = 0;
+        FMK_TRY(fmk_fused_fill(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, price_tick_size, d_bar_lows,
+                               imbalance_factor, d_level_offsets, max_levels, d_out, d_n_bad_level, &handled));
+        if (handled) return FMK_OK;
+    }
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
                                        max_levels, d_out, d_n_bad_level, n, nullptr);
@@ -1291,7 +1297,7 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                                 const int64_t *d_close_idx, int64_t nb, const int8_t *d_side, double price_tick_size,
                                 const double *d_bar_lows, double imb_mult, const int64_t *d_level_offsets, int lmin_start,
                                 int64_t max_levels, const fmk_footprint_out *d_out, int64_t *d_n_bad_level, int64_t n_ticks,
-                                double *d_median)
+                                double *d_median, const unsigned long long *only_list)
 {
     // imb_mult stays float64: array(float32) * float64 is float64 under Numba typing (the production path); NumPy 2 / NEP 50
     // would round the product to float32 -- they differ only for inexact products (decimal lots), see oracle/fmk_oracle.c
@@ -1310,6 +1316,22 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                             lds_wide ? 3072 : FP_MAX_LEVELS, lds_wide ? FP_MAX_LEVELS_LDS : FP_MAX_LEVELS,
                             (int)max_levels};                           // last class: global-scratch histogram
     static const int WPB[NCLS] = {4, 4, 4, 2, 2, 1, 1, 1, 1, 1};
+    if (only_list) {
+        // the bars a caller lists (cfg 4's one-pass kernel hands over the bars outside its class): the wave-per-bar classes in list mode
+        int lmin_l = 0, rc_l = FMK_OK;
+        for (int k = 0; k < NCLS && rc_l == FMK_OK; ++k) {
+            if (k > 0 && max_levels <= LMAX[k - 1]) break;
+            const int lm = (k >= 3 && max_levels < LMAX[k]) ? (int)max_levels : LMAX[k];
+            if (LMAX[k] > lmin_l)
+                rc_l = amount_is_f64
+                           ? fp_launch<true>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                             d_level_offsets, lmin_l, lm, WPB[k], o, bad, only_list)
+                           : fp_launch<false>(ctx, d_price, d_amount, d_side, d_close_idx, nb, price_tick_size, d_bar_lows, imb_mult,
+                                              d_level_offsets, lmin_l, lm, WPB[k], o, bad, only_list);
+            lmin_l = LMAX[k];
+        }
+        return rc_l;
+    }
     // Very short bars (1-second bars and the like): one lane per bar first, the wave-per-bar classes below then only see the
     // bars it listed (more than FL_MAXL levels, or long).  Developer knob FMK_FP_LANES: 0 never, 2 whenever the layout allows.
     // Measured at 1e9 ticks (profiles/r02_fp_lanes.txt).
@@ -1492,6 +1514,12 @@ extern "C" int fmk_comp_bar_footprints_fill_median_dev(fmk_ctx *ctx, const doubl
                              "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
                              (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
     FMK_HIP(ctx, hipSetDevice(ctx->device));
+    {   // a sizing call that took the one-pass kernel left the rows staged (fmk_fused.h); its medians are done
+        int handled = 0;
+        FMK_TRY(fmk_fused_fill(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, price_tick_size, d_bar_lows,
+                               imbalance_factor, d_level_offsets, max_levels, d_out, d_n_bad_level, &handled));
+        if (handled) return FMK_OK;
+    }
     return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
                                        price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
                                        max_levels, d_out, d_n_bad_level, n, d_median);

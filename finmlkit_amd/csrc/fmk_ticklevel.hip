@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "fmk_common.h"
+#include "fmk_log.h"
 #include "fmk_dpp.h"
 
 // ---------------------------------------------------------------------------------------

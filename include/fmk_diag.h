@@ -36,6 +36,11 @@ int fmk_diag_read_two_streams(fmk_ctx *ctx, const void *d_a8, const void *d_b4, 
 int fmk_diag_hop_latency(fmk_ctx *ctx, const void *d_buf, int64_t n, int64_t stride, int loads, int hops,
                          double *cycles_per_hop, double *elapsed_ms);
 
+/* Price / amount / side read by one wave per `seg`-tick segment in 512-tick tiles with lane l owning r = 1, 2, 4 or 8 CONSECUTIVE
+ * ticks (tools/ownedread.py): r = 1 is the reducers' chunk layout, the others read 16-byte vectors per lane.  Not used by any product path. */
+int fmk_diag_read_owned(fmk_ctx *ctx, const double *d_price, const float *d_amount, const signed char *d_side, int64_t n, int seg,
+                        int r, int blocks_per_cu, double *elapsed_ms);
+
 /* host-to-device rate of this box for one buffer, GB/s, best of three: mode 1 = hipMemcpy from pinned memory (the link's ceiling),
  * 0 = hipMemcpy from pageable memory, 2 = fmk_h2d_columns from pageable memory */
 int fmk_diag_h2d_rate(fmk_ctx *ctx, size_t bytes, int mode, double *gbps);
@@ -52,6 +57,9 @@ int fmk_diag_dollar_last(int64_t *path);
 /* order-flow redo since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
  * pairs of column 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)} */
 int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10);
+/* the last one-pass cfg-4 sizing call (csrc/fmk_fused.h): bars it handed to the footprint class kernels / to k_bar_dir / entries of
+ * the tick-order redo list (float32 ties of the dollar columns and mean_spread) */
+int fmk_diag_fused_last(fmk_ctx *ctx, int64_t *n_fp_list, int64_t *n_dir_list, int64_t *n_redo);
 /* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
 int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
 /* ... and into how many LATER segments that walk split the two sides' chains (0: each side walked in one piece); a segment

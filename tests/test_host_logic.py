@@ -146,10 +146,13 @@ def test_close_indices_out_of_range_are_refused_before_any_device_work():
 
 
 def test_device_logarithm_is_the_hosts_logarithm(tmp_path):
-    """The logarithm of tick returns on the device (fmk_log_near1, csrc/fmk_common.h) is an operation-by-operation restatement of the
-    table-free branch of glibc's log in libm's FMA build; tools/logratio_check.c holds the same sequence in C and compares it with THIS
-    host's log() -- the function the oracle calls -- on 2e6 price quotients and a sweep of the interval: no difference allowed.  (A host
-    without FMA3 runs libm's generic build, which differs from the FMA build on ~6 arguments in 1e5: the contract is the FMA build.)"""
+    """The logarithm of tick returns on the device (csrc/fmk_log.h) is an operation-by-operation restatement of glibc's log in libm's FMA
+    build -- BOTH branches: the table-free one around 1 and the 128-entry table (constants extracted from the host's libm by
+    tools/extract_glibc_log_table.py); the header is plain C as well, and tools/logratio_check.c runs THE SAME SOURCE against this
+    host's log() -- the function the oracle calls -- on 2e6 price quotients, a sweep of the table-free interval, quotients of prices up
+    to a factor 2^40 apart, random bit patterns over the whole double range (subnormals, negatives, NaNs), the special values and the
+    neighbours of every power of two: no difference allowed.  (A host without FMA3 runs libm's generic build, which differs from the FMA
+    build on ~6 arguments in 1e5: the contract is the FMA build.)"""
     import os
     import shutil
     import subprocess
@@ -162,4 +165,22 @@ def test_device_logarithm_is_the_hosts_logarithm(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", os.path.join(root, "tools", "logratio_check.c"), "-o", exe, "-lm"])
     r = subprocess.run([exe, "2000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    assert "0 of" in r.stdout
+    assert "whole double range: 0 of" in r.stdout
+
+
+def test_the_log_table_in_the_tree_is_the_hosts(tmp_path):
+    """csrc/fmk_logtab.h is what tools/extract_glibc_log_table.py reads from THIS host's libm.so.6 (the constants of glibc's log have not
+    changed since 2.28; a host whose libm carries other constants would make the device differ from the oracle there)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libm = "/lib/x86_64-linux-gnu/libm.so.6"
+    if not os.path.exists(libm):
+        pytest.skip("no libm.so.6 at the usual place")
+    src = open(os.path.join(root, "tools", "extract_glibc_log_table.py")).read().replace(
+        'OUT = os.path.join(', 'OUT = os.environ.get("FMK_LOGTAB_OUT") or os.path.join(')
+    out = str(tmp_path / "fmk_logtab.h")
+    subprocess.check_call([sys.executable, "-c", src, libm], env={**os.environ, "FMK_LOGTAB_OUT": out})
+    strip = lambda t: [l for l in t.splitlines() if not l.startswith("//")]
+    assert strip(open(out).read()) == strip(open(os.path.join(root, "finmlkit_amd", "csrc", "fmk_logtab.h")).read())

@@ -20,5 +20,13 @@ for name, tr in (("dyadic amounts", t), ("full-mantissa amounts", t2)):
         best = min(best, (time.perf_counter() - t0) * 1e3); del r
     fb = c_i64()
     ctx.call("fmk_diag_fp_median_fallbacks", C.byref(fb))
+    nfp, ndir, nredo = c_i64(), c_i64(), c_i64()
+    ctx.call("fmk_diag_fused_last", C.byref(nfp), C.byref(ndir), C.byref(nredo))
+    z10 = (c_i64 * 10)()
+    ctx.call("fmk_diag_dir_redo", z10)                  # (reads and clears)
+    ctx.timer_start(); r = tr.bars_fused(ci, 0.01, 3.0); dev_ms = ctx.timer_stop(); del r
+    ctx.call("fmk_diag_dir_redo", z10)
+    print("  tick-order redo of that call: pairs, tiles, term-by-term tiles, pairs of column 0..6 =", list(z10), flush=True)
+    print(f"  device time {dev_ms:.3f} ms; one-pass kernel (FMK_FUSED={os.environ.get('FMK_FUSED', 'unset')}): {nfp.value} bars to the footprint classes, {ndir.value} to k_bar_dir, {nredo.value} redo entries", flush=True)
     print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms (separate={os.environ.get('FMK_FLOW_SEPARATE', '0')}, "
           f"median deferred to the footprint sweep={os.environ.get('FMK_FLOW_MEDIAN_DEFER', '0')}, bracket misses {fb.value} of {ci.n - 1} bars)", flush=True)
