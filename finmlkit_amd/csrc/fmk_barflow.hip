@@ -1660,7 +1660,7 @@ void fmk_fused_release(fmk_ctx *ctx)
 // Does the one-pass kernel serve this tape?  float32 amounts; bars of 96 .. ~1 400 ticks on average (shorter: the several-bars-per-wave
 // schedules are ahead; longer: most ticks would lie in bars beyond FU_MAXT); a sample of the amounts certifies -- whole multiples of
 // their common power of two below 2^23 of them (full-mantissa sizes never do: every bar would come back on the lists after a wasted
-// sweep).  FMK_FUSED: 0 never, 2 whenever the dtype allows (tests), unset / 1: by these rules.
+// sweep; such tapes get the kernel without its histogram, see bars_flow_fused_ok).
 __global__ __launch_bounds__(256) void k_fu_census(const float *__restrict__ amount, int64_t n, int *__restrict__ out /* [0] min low bit, [1] max exponent, [2] bad */)
 {
     const int64_t stride = n / 4096 > 0 ? n / 4096 : 1;
@@ -1681,13 +1681,16 @@ __global__ __launch_bounds__(256) void k_fu_census(const float *__restrict__ amo
     if (__ballot(bad != 0) != 0 && fmk_lane() == 0) atomicOr(out + 2, 1);
 }
 
-static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n, int64_t nb, bool *ok)
+// -> *mode: 0 the schedules below, 1 the one-pass kernel with the footprint histogram (sizes that certify), 2 the one-pass kernel for
+// OHLCV + median + order flow only (float32 sizes that do not: full mantissas; the footprints by their own tick-ordered sweep).
+// FMK_FUSED: 0 never, 2 / 3 force mode 1 / 2 whenever the dtype allows (tests), unset / 1: by the rules above.
+static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_f64, int64_t n, int64_t nb, int *mode_out)
 {
-    *ok = false;
+    *mode_out = 0;
     const char *fv = getenv("FMK_FUSED");
     const int mode = fv ? atoi(fv) : 1;
     if (mode == 0 || amount_is_f64 || nb < 1) return FMK_OK;
-    if (mode == 2) { *ok = true; return FMK_OK; }
+    if (mode == 2 || mode == 3) { *mode_out = mode - 1; return FMK_OK; }
     const int64_t mean = n / nb;
     if (mean < 96 || mean > 1400 || nb < (int64_t)ctx->n_cu * 8) return FMK_OK;
     int *d = (int *)(ctx->d_mail + 44);
@@ -1699,7 +1702,8 @@ static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_
     FMK_HIP(ctx, hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
     FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // largest sampled amount < 2^mx: below 2^23 units of 2^lb when mx - lb <= 23 (one binade of slack for what the sample missed)
-    *ok = got[2] == 0 && (got[0] == FP_Q_UNKNOWN || got[1] - got[0] <= 22);
+    const bool certifies = got[2] == 0 && (got[0] == FP_Q_UNKNOWN || got[1] - got[0] <= 22);
+    *mode_out = certifies ? 1 : (got[2] == 0 ? 2 : 0);                // (negative / non-finite sizes in the sample: the schedules below)
     return FMK_OK;
 }
 
@@ -1707,7 +1711,7 @@ static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_a
                            int64_t n_idx, const int8_t *d_side, double price_tick_size, double *d_open, double *d_high, double *d_low,
                            double *d_close, float *d_volume, double *d_vwap, int64_t *d_trades, double *d_median,
                            const fmk_directional_out *d_dir, int64_t *d_n_zero_div, int64_t *d_level_offsets, int64_t *total_levels,
-                           int64_t *max_levels)
+                           int64_t *max_levels, bool units)
 {
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     FMK_TRY(bf_sync_force_redo(ctx));
@@ -1717,9 +1721,16 @@ static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_a
     memcpy(&o, d_dir, sizeof(o));
     FuState *st = (FuState *)calloc(1, sizeof(FuState));
     if (!st) return fmk_set_error(ctx, FMK_E_NOMEM, "calloc");
-    const size_t rows = (size_t)nb * FU_LV;
+    const size_t rows = units ? (size_t)nb * FU_LV : 0;                 // (no staging without the histogram)
     const size_t lbytes = ((size_t)nb * 4 + 255) & ~(size_t)255, fbytes = ((size_t)(nb + 32) * 8 + 255) & ~(size_t)255;
-    const size_t bytes = rows * 16 + lbytes + fbytes + sizeof(FuArgs);
+    int64_t blocks = fmk_ceil_div(nb, 4);
+    {
+        const int64_t cap = (int64_t)ctx->n_cu * 16;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+    }
+    const size_t sbytes = (size_t)blocks * 256 * 8;                      // the kernel's scrap area: 8 bytes per lane
+    const size_t bytes = rows * 16 + lbytes + fbytes + ((sizeof(FuArgs) + 255) & ~(size_t)255) + sbytes;
     int rc = fmk_alloc(ctx, bytes, &st->block);
     if (rc != FMK_OK) { free(st); return rc; }
     unsigned char *blk = (unsigned char *)st->block;
@@ -1728,6 +1739,7 @@ static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_a
     st->stg.L = (int *)(blk + rows * 16);
     st->fp_list = (unsigned long long *)(blk + rows * 16 + lbytes);
     FuArgs *d_args = (FuArgs *)(blk + rows * 16 + lbytes + fbytes);
+    unsigned long long *d_scrap = (unsigned long long *)(blk + rows * 16 + lbytes + fbytes + ((sizeof(FuArgs) + 255) & ~(size_t)255));
     st->nb = nb; st->ci = d_close_idx; st->n_fp = -1;
     ctx->fused = st;
     // two redo lists: the one-pass kernel's own (bars of <= FU_MAXT ticks: one wave per bar walks them, k_bar_dir_redo) and k_bar_dir's
@@ -1738,29 +1750,38 @@ static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_a
     if (rc != FMK_OK) { fmk_fused_release(ctx); return rc; }
     unsigned long long *dir_list = redo + nb + 32, *redo_fu = redo + 2 * (nb + 32);
     int *saw_long = (int *)(ctx->d_mail + 18);
-    FuLists li{redo_fu, dir_list, st->fp_list, saw_long};
+    FuLists li{redo_fu, redo, dir_list, st->fp_list, saw_long, saw_long + 1};
     auto fail = [&](int code) { fmk_fused_release(ctx); return code; };
 #define FU_HIP(expr) do { const hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(fmk_set_error(ctx, FMK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
     FU_HIP(hipMemsetAsync(redo, 0, 8, ctx->stream));
     FU_HIP(hipMemsetAsync(redo_fu, 0, 8, ctx->stream));
     FU_HIP(hipMemsetAsync(dir_list, 0, 8, ctx->stream));
     FU_HIP(hipMemsetAsync(st->fp_list, 0, 8, ctx->stream));
-    FU_HIP(hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
+    FU_HIP(hipMemsetAsync(saw_long, 0, 2 * sizeof(int), ctx->stream));
     FuArgs h_args;
+    h_args.amount = d_amount;
     h_args.oo = FuOhlcv{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median};
-    h_args.o = o; h_args.stg = st->stg; h_args.li = li;
+    h_args.o = o; h_args.stg = st->stg; h_args.li = li; h_args.scrap = d_scrap;
     FU_HIP(hipMemcpyAsync(d_args, &h_args, sizeof h_args, hipMemcpyHostToDevice, ctx->stream));   // (pageable source: copied before the call returns)
-    int64_t blocks = fmk_ceil_div(nb, 4);
-    const int64_t cap = (int64_t)ctx->n_cu * 16;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    if (d_median)
-        k_fu_bars<true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
-    else
-        k_fu_bars<false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+    if (units) {
+        if (d_median)
+            k_fu_bars<true, true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+        else
+            k_fu_bars<false, true><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+        FU_HIP(hipGetLastError());
+        k_fu_long<true><<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+    } else {
+        if (d_median)
+            k_fu_bars<true, false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+        else
+            k_fu_bars<false, false><<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+        FU_HIP(hipGetLastError());
+        k_fu_long<false><<<(unsigned)(ctx->n_cu * 4), 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, price_tick_size, d_args);
+    }
     FU_HIP(hipGetLastError());
-    // bars of more than FU_MAXT ticks: open .. trades and the median by comp_bar_ohlcv's leftover passes (they look at the flag on the device)
-    rc = fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, FU_MAXT, saw_long, d_open, d_high, d_low, d_close,
+    // bars of more than FU_LONGEST ticks: open .. trades by comp_bar_ohlcv's leftover pass; of more than FU_MAXT ticks: the median by
+    // the long-bar kernels (both look at their flag on the device)
+    rc = fmk_ohlcv_leftover_launch(ctx, d_price, d_amount, 0, d_close_idx, nb, n, FU_LONGEST, saw_long + 1, d_open, d_high, d_low, d_close,
                                    d_volume, d_vwap, d_trades);
     if (rc == FMK_OK && d_median) rc = fmk_median_launch(ctx, d_amount, 0, d_close_idx, nb, FU_MAXT, saw_long, d_median, n);
     if (rc != FMK_OK) return fail(rc);
@@ -1782,6 +1803,7 @@ static int bars_flow_fused(fmk_ctx *ctx, const double *d_price, const float *d_a
     rc = fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, nb, price_tick_size, d_level_offsets, total_levels, max_levels);
     if (rc != FMK_OK) return fail(rc);
     st->n_fp = ctx->h_mail[14];                                      // (the sizing call has waited for the stream)
+    if (!units) fmk_fused_release(ctx);                              // nothing staged: the fill call is the ordinary one
     return FMK_OK;
 }
 
@@ -1813,6 +1835,17 @@ int fmk_fused_fill(fmk_ctx *ctx, const double *d_price, const void *d_amount, in
     return rc;
 }
 
+#ifdef FU_TIMING
+extern "C" int fmk_diag_fused_phases(fmk_ctx *ctx, int64_t *out4)
+{
+    unsigned long long v[4], z[4] = {0, 0, 0, 0};
+    FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FMK_HIP(ctx, hipMemcpyFromSymbol(v, HIP_SYMBOL(fu_phase_cycles), sizeof v));
+    FMK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(fu_phase_cycles), z, sizeof z));
+    for (int i = 0; i < 4; ++i) out4[i] = (int64_t)v[i];
+    return FMK_OK;
+}
+#endif
 // diagnostics of the last one-pass sizing call: bars handed to the class kernels (footprints), to k_bar_dir (order flow), and the
 // (bar, columns) entries of the tick-order redo
 extern "C" int fmk_diag_fused_last(fmk_ctx *ctx, int64_t *n_fp_list, int64_t *n_dir_list, int64_t *n_redo)
@@ -1991,12 +2024,12 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
     const bool long_bars = n / (n_idx - 1) > 8192;
     // the common class in ONE pass over the ticks (fmk_fused.h; round 6): 13 B/tick read once for all three families
     {
-        bool fused_ok = false;
-        FMK_TRY(bars_flow_fused_ok(ctx, d_amount, amount_is_f64, n, n_idx - 1, &fused_ok));
-        if (fused_ok && !separate)
+        int fused_mode = 0;
+        FMK_TRY(bars_flow_fused_ok(ctx, d_amount, amount_is_f64, n, n_idx - 1, &fused_mode));
+        if (fused_mode && !separate)
             return bars_flow_fused(ctx, d_price, (const float *)d_amount, n, d_close_idx, n_idx, d_side, price_tick_size, d_open, d_high,
                                    d_low, d_close, d_volume, d_vwap, d_trades, d_median, d_dir, d_n_zero_div, d_level_offsets,
-                                   total_levels, max_levels);
+                                   total_levels, max_levels, fused_mode == 1);
         fmk_fused_release(ctx);                                          // (a stale state of an earlier call)
     }
     if (amount_is_f64 || separate || short_bars || long_bars) {
