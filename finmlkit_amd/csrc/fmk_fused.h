@@ -26,7 +26,7 @@
 
 #define FU_MAXR 24
 #define FU_MAXT (64 * FU_MAXR)
-#define FU_LONGEST 65536              // a longer bar is not walked by one wave: open .. trades, order flow and footprint by the other kernels
+#define FU_LONGEST 262144             // a longer bar is not walked by one wave: open .. trades, order flow and footprint by the other kernels
 #define FU_Q_UNKNOWN 0x7FFFFFFF
 #define FU_LV 128                      // price levels per bar the histogram and the staging rows hold (level mod FU_LV is the slot)
 
