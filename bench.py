@@ -571,6 +571,16 @@ def run(args):
     import ctypes as C
 
     ctx = _ffi.default_context()
+    if world > 1 and not os.environ.get("FMK_BENCH_NO_SELFTEST"):
+        # first contact (finmlkit_amd/dist.py: selftest): the node as this rank sees it, a 1 KiB ncclSend / ncclRecv to rank + 1 with a
+        # 10 s deadline, its content checked -- on record in gpurun_out/bench_rank<r>.log BEFORE anything is timed.  It decides
+        # nothing: the communicator of the run is made (and falls back, with rc 3) below as before.
+        from finmlkit_amd.dist import selftest
+        try:
+            selftest(rank, world, rendezvous_path(world) + ".selftest", ctx=ctx, log=sys.stderr,
+                     deadline_s=float(os.environ.get("FMK_BENCH_SELFTEST_DEADLINE", "10")))
+        except Exception as e:                                                 # noqa: BLE001 -- a report, never a reason to stop
+            print(f"[selftest] rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
     n = args.ticks
     free, total = ctx.mem_info()
     need = n * 21 + (1 << 30)

@@ -119,6 +119,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;                  // optional
 };
 static Rccl g_rccl;
 
@@ -157,6 +158,7 @@ static const char *rccl_load()
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     *(void **)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
+    *(void **)(&g_rccl.GetVersion) = dlsym(so, "ncclGetVersion");
     g_rccl.so = so;
     return nullptr;
 }
@@ -768,5 +770,70 @@ extern "C" int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *sr
     if (bx > 1024) bx = 1024;
     k_copy_cols<<<dim3((unsigned)bx, (unsigned)n_cols), 256, 0, ctx->stream>>>(c, n_cols);
     FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
+
+// First contact with a node: what this process sees of it, as text -- the devices, which of them can map each
+// other's memory (hipDeviceCanAccessPeer: what RCCL's point-to-point path over xGMI needs), the librccl this library would load and
+// its version, and the environment that decides how RCCL shares memory between processes.  No context, no communicator, no device
+// memory: it works (and says so) on a box without a GPU or without librccl.  `python -m finmlkit_amd.dist --selftest` prints it.
+extern "C" int fmk_comm_describe(char *buf, size_t cap)
+{
+    if (!buf || cap < 64) return FMK_E_ARG;
+    size_t at = 0;
+    auto put = [&](const char *fmt, ...) {
+        if (at >= cap - 1) return;
+        va_list ap;
+        va_start(ap, fmt);
+        const int k = vsnprintf(buf + at, cap - at, fmt, ap);
+        va_end(ap);
+        if (k > 0) at += (size_t)k < cap - at ? (size_t)k : cap - at - 1;
+    };
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { put("devices: hipGetDeviceCount: %s\n", hipGetErrorString(e)); n = 0; }
+    else put("devices: %d\n", n);
+    for (int i = 0; i < n && i < 16; ++i) {
+        hipDeviceProp_t pr;
+        char bus[32] = "?";
+        if (hipGetDeviceProperties(&pr, i) != hipSuccess) { put("  [%d] hipGetDeviceProperties failed\n", i); continue; }
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, i);
+        put("  [%d] %s %s, %d CUs, %.0f GiB, pci %s\n", i, pr.name, pr.gcnArchName, pr.multiProcessorCount,
+            (double)pr.totalGlobalMem / (double)(1ull << 30), bus);
+    }
+    if (n > 1) {
+        put("peer access (row can map column):\n");
+        for (int i = 0; i < n && i < 16; ++i) {
+            put("  [%d]", i);
+            for (int j = 0; j < n && j < 16; ++j) {
+                int ok = 0;
+                if (i == j) { put(" ."); continue; }
+                const hipError_t pe = hipDeviceCanAccessPeer(&ok, i, j);
+                put(pe == hipSuccess ? (ok ? " 1" : " 0") : " ?");
+            }
+            put("\n");
+        }
+    }
+    const char *why = rccl_load();
+    if (why) put("librccl: NOT LOADED: %s\n", why);
+    else {
+        Dl_info di;
+        const char *path = (dladdr((void *)g_rccl.Send, &di) && di.dli_fname) ? di.dli_fname : "?";
+        int v = 0;
+        if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == 0) put("librccl: %s, ncclGetVersion %d (%d.%d.%d)\n", path, v, v / 10000, v / 100 % 100, v % 100);
+        else put("librccl: %s (no ncclGetVersion)\n", path);
+    }
+    const char *keys[] = {"HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "NCCL_DEBUG",
+                          "NCCL_P2P_DISABLE", "NCCL_SHM_DISABLE", "NCCL_SOCKET_IFNAME", "RCCL_MSCCL_ENABLE", "FMK_RCCL_LIB", "FMK_DEVICE"};
+    put("environment:");
+    for (const char *k : keys) {
+        const char *v = getenv(k);
+        if (v) put(" %s=%s", k, v);
+    }
+    put("\n");
+    if (!getenv("HSA_ENABLE_IPC_MODE_LEGACY") || strcmp(getenv("HSA_ENABLE_IPC_MODE_LEGACY"), "0") != 0)
+        put("note: HSA_ENABLE_IPC_MODE_LEGACY is not 0 -- on hosts whose driver only supports dmabuf IPC, RCCL between processes fails with "
+            "hipIpcGetMemHandle: invalid argument\n");
     return FMK_OK;
 }

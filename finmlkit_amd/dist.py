@@ -443,3 +443,101 @@ class ShardedTickLevel:
                       C.c_int(bool(mean0)), None if st is None else st.p, out.p)
         self.ctx.sync()                                                       # `st` must outlive the kernel
         return out if self.rank == 0 else out.view(1, self.t.n)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# First contact with a node: `python -m finmlkit_amd.dist --selftest` (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
+# MASTER_PORT from the launcher as for bench.py; without them: one rank, RCCL self-loop).  bench.py calls selftest() at the top of
+# every N > 1 run, so that gpurun_out/bench_rank<r>.log says what the node looked like BEFORE anything was timed.
+# ------------------------------------------------------------------------------------------------------------------------
+def describe_node() -> str:
+    """fmk_comm_describe (include/fmk.h): devices, peer-access matrix, librccl path + version, the IPC environment."""
+    import ctypes as C
+    from . import _ffi
+    buf = C.create_string_buffer(16384)
+    _ffi.lib().fmk_comm_describe(buf, C.c_size_t(len(buf)))
+    return buf.value.decode(errors="replace")
+
+
+def selftest(rank: int, world: int, path: str, ctx=None, log=None, deadline_s: float = 10.0, payload: int = 1024) -> dict:
+    """What a first N > 1 run needs to know, in this order: the node as this process sees it; a communicator over RCCL (deadline
+    `deadline_s`); ONE exchange of `payload` bytes to rank + 1 (self-loop when world == 1) whose content is checked on arrival and
+    whose device time is read back.  A failure of the RCCL leg is reported with librccl's own message and the same exchange is
+    repeated over the host-staged transport, so that the report separates "the flow is broken" from "RCCL is broken".
+    -> {"rccl": True/False, "rccl_error": str|None, "rccl_ms": float|None, "host": True/False/None, "report": str}"""
+    import numpy as np
+    from . import _ffi
+    from ._ffi import DeviceArray
+    say = (lambda m: print(m, file=log, flush=True)) if log is not None else (lambda m: None)
+    res = {"rccl": False, "rccl_error": None, "rccl_ms": None, "host": None}
+    report = describe_node()
+    say(f"[selftest] rank {rank} of {world}: pid {os.getpid()}, LOCAL_RANK {os.environ.get('LOCAL_RANK')}, FMK_DEVICE {os.environ.get('FMK_DEVICE')}")
+    for line in report.rstrip().splitlines():
+        say("[selftest]   " + line)
+    ctx = ctx or _ffi.default_context()
+    n = payload // 8
+    pattern = (np.arange(n, dtype=np.int64) * 2654435761 + (rank + 1) * 1_000_003)
+    want_from = (rank - 1) % world if world > 1 else rank
+    expect = (np.arange(n, dtype=np.int64) * 2654435761 + (want_from + 1) * 1_000_003)
+
+    def one(transport: str, p: str):
+        comm = Comm(ctx, rank, world, p, transport, self_loop=(world == 1), timeout_s=deadline_s)
+        try:
+            send = DeviceArray.from_host(ctx, pattern)
+            recv = DeviceArray(ctx, n, np.int64)
+            recv.zero()
+            ctx.sync()
+            has_right, has_left = (world == 1 or rank + 1 < world), (world == 1 or rank > 0)
+            comm.profile_enable(True)
+            comm.exchange([(send.ptr, payload if has_right else 0)], [(recv.ptr, payload if has_left else 0)])
+            comm.wait()
+            comm.sync()
+            ctx.sync()
+            ms = comm.profile_read()
+            ok = (not has_left) or bool(np.array_equal(recv.to_host(), expect))
+            oks = comm.all_gather_i64([1 if ok else 0])
+            return all(r[0] == 1 for r in oks), (ms[-1] if ms else None)
+        finally:
+            comm.close()
+
+    try:
+        ok, ms = one("rccl", path)
+        res["rccl"], res["rccl_ms"] = ok, ms
+        say(f"[selftest] rank {rank}: RCCL exchange of {payload} B to rank + 1: {'ok' if ok else 'PAYLOAD MISMATCH on some rank'}"
+            + (f", {ms * 1e3:.1f} us on the communicator's stream" if ms is not None else ""))
+    except Exception as e:                                                     # noqa: BLE001 -- whatever librccl / the rendezvous said
+        res["rccl_error"] = f"{type(e).__name__}: {e}"
+        say(f"[selftest] rank {rank}: RCCL leg FAILED within its {deadline_s:.0f} s deadline: {res['rccl_error']}")
+    if not res["rccl"]:
+        try:
+            ok, ms = one("host", path + ".selftest_host")
+            res["host"] = ok
+            say(f"[selftest] rank {rank}: the same exchange host-staged: {'ok' if ok else 'PAYLOAD MISMATCH'} -- the flow works, RCCL does not"
+                if ok else f"[selftest] rank {rank}: the same exchange host-staged: PAYLOAD MISMATCH")
+        except Exception as e:                                                 # noqa: BLE001
+            res["host"] = False
+            say(f"[selftest] rank {rank}: host-staged leg FAILED too: {type(e).__name__}: {e}")
+    res["report"] = report
+    return res
+
+
+def _selftest_main(argv) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m finmlkit_amd.dist", description="first-contact self test of the multi-GPU path")
+    ap.add_argument("--selftest", action="store_true", required=True)
+    ap.add_argument("--deadline", type=float, default=10.0, help="seconds the RCCL leg may take")
+    ap.add_argument("--one-device", action="store_true", help="every rank on device 0 (boxes with one GPU: RCCL refuses, the report says so)")
+    a = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("FMK_DEVICE", "0" if a.one_device else os.environ.get("LOCAL_RANK", "0"))
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.environ.get("FMK_BENCH_RDV") or os.path.join(base, f"fmk_selftest_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
+    import sys
+    r = selftest(rank, world, path, log=sys.stdout, deadline_s=a.deadline)
+    print(f"SELFTEST rank {rank}/{world}: " + ("RCCL ok" if r["rccl"] else f"RCCL FAILED ({r['rccl_error']}); host-staged {'ok' if r['host'] else 'FAILED'}"), flush=True)
+    return 0 if r["rccl"] else 3
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(_selftest_main(sys.argv[1:]))

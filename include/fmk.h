@@ -432,6 +432,10 @@ int fmk_comm_sync(fmk_comm *comm); /* host wait for the communicator's stream, b
  * stream around the ncclGroup (device time of the send/recv alone); HOST: wall clock of the staged copy. */
 int fmk_comm_profile_enable(fmk_comm *comm, int on);
 int fmk_comm_profile_read(fmk_comm *comm, double *ms, int capacity, int *count);
+/* First contact with a node, as text: the devices this process sees, the peer-access matrix (hipDeviceCanAccessPeer), the librccl that
+ * would be loaded and its version, the environment that decides how RCCL shares memory between processes.  Needs no context and no
+ * GPU (`python -m finmlkit_amd.dist --selftest` prints it, bench.py logs it per rank when N > 1). */
+int fmk_comm_describe(char *buf, size_t cap);
 /* Up to 8 small device column slices copied by one launch on the context's stream (boundary-bar assembly). */
 int fmk_copy_cols_dev(fmk_ctx *ctx, int n_cols, const void *const *src, void *const *dst, const size_t *bytes);
 

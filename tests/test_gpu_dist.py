@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 KEYS = ["open", "high", "low", "close", "volume", "vwap", "trades", "median_trade_size"]
@@ -316,6 +318,7 @@ def test_plain_bench_eight_ranks_one_device(tmp_path):
     for k in range(world):
         text = (tmp_path / f"bench_rank{k}.log").read_text()
         assert f"rank {k} of {world}" in text and "communicator up, transport host" in text
+        assert f"[selftest] rank {k} of {world}" in text and "librccl: " in text          # the first-contact report comes first
 
 
 def test_bench_eight_ranks_rccl_failure_ends_every_rank(tmp_path):
@@ -361,3 +364,92 @@ def test_bench_single_gpu_line_has_transport_none():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["config"]["transport"] == "none" and line["n_gpus"] == 1 and "per_rank" not in line
+
+
+# ---- first-contact kit (finmlkit_amd/dist.py: selftest) -------------------------------------------
+def _run_selftest(env_extra, args=(), timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable, "-m", "finmlkit_amd.dist", "--selftest", *args], cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_selftest_one_rank_reports_the_node_and_talks_to_itself_over_rccl(tmp_path):
+    """`python -m finmlkit_amd.dist --selftest` with no launcher: the node report (devices, librccl path + version, the IPC
+    environment) and a 1 KiB ncclSend / ncclRecv to itself on the communicator's stream, content checked: rc 0."""
+    r = _run_selftest({"FMK_BENCH_RDV": str(tmp_path / "rdv")})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "devices: " in r.stdout and "gfx950" in r.stdout and "librccl: " in r.stdout and "ncclGetVersion" in r.stdout
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" in r.stdout
+    assert "RCCL exchange of 1024 B to rank + 1: ok" in r.stdout and "SELFTEST rank 0/1: RCCL ok" in r.stdout
+
+
+def test_selftest_two_ranks_on_one_device_say_why_rccl_fails_and_that_the_flow_works(tmp_path):
+    """Two ranks on the box's ONE device: librccl refuses the communicator -- both ranks learn it inside the deadline, say why, run the
+    same exchange host-staged and end with rc 3 (a librccl that accepts two ranks on one device ends with rc 0: also fine)."""
+    import subprocess
+    import sys
+    procs = []
+    for k in range(2):
+        env = dict(os.environ, RANK=str(k), WORLD_SIZE="2", LOCAL_RANK=str(k), FMK_BENCH_RDV=str(tmp_path / "rdv"))
+        procs.append(subprocess.Popen([sys.executable, "-m", "finmlkit_amd.dist", "--selftest", "--one-device", "--deadline", "20"],
+                                      cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    rcs = [p.returncode for p in procs]
+    assert rcs[0] == rcs[1] and rcs[0] in (0, 3), (rcs, outs[0][-2000:], outs[1][-2000:])
+    for k, out in enumerate(outs):
+        assert f"[selftest] rank {k} of 2" in out and "librccl: " in out
+        if rcs[0] == 3:
+            assert "RCCL leg FAILED" in out and "host-staged: ok" in out and f"SELFTEST rank {k}/2: RCCL FAILED" in out
+
+
+def _features_worker(rank, world, path, n, interval, out_dir):
+    os.environ["FMK_DEVICE"] = "0"
+    from finmlkit_amd import _ffi, dist, engine
+    ctx = _ffi.default_context()
+    comm = dist.Comm(ctx, rank, world, path, "host", ring_bytes=1 << 16, timeout_s=120.0)
+    t = engine.DeviceTrades.synth(n, seed=42, first=rank * n, ctx=ctx)
+    shard = dist.ShardedTimeBars(t, rank, world, interval, False, with_side=True).setup(comm)
+    shard.step(comm)
+    ctx.sync()
+    comm.sync()
+    d, lv, flat, bar = shard.features(0.01, 3.0)
+    np.savez(os.path.join(out_dir, f"feat{rank}.npz"), lv=lv, **{"d_" + k: v for k, v in d.items()},
+             **{"f_" + k: v for k, v in flat.items()}, **{"b_" + k: v for k, v in bar.items()})
+    comm.barrier()
+    comm.close()
+
+
+def test_eight_processes_cfg4_features_across_shard_boundaries(tmp_path):
+    """cfg 4 (order flow + footprints) on EIGHT real processes sharing the box's GPU, host-staged transport: every rank's bars --
+    the boundary bar stitched from [halo | head] included -- equal the un-sharded run's, bit for bit (the spread columns of the
+    stream's very first bar excepted: the reference's wrap-around tick is 'the last tick of the array at hand')."""
+    from finmlkit_amd import _ffi, engine
+    world, n, interval = 8, 150_000, 60.0
+    mpx = mp.get_context("spawn")
+    procs = [mpx.Process(target=_features_worker, args=(r, world, str(tmp_path / "rdv"), n, interval, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("worker hung")
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    parts = [dict(np.load(tmp_path / f"feat{r}.npz")) for r in range(world)]
+    ctx = _ffi.default_context()
+    whole = engine.DeviceTrades.synth(world * n, seed=42, ctx=ctx)
+    _, wci = whole.time_bar_index(interval)
+    o, d, nz, off, flat, bar, bad = whole.bars_fused(wci, 0.01, 3.0, want_median=False)
+    for k, w in engine.to_host(d).items():
+        got = np.concatenate([p["d_" + k] for p in parts])
+        if k in ("mean_spread", "max_spread"):
+            got, w = got[1:], w[1:]
+        np.testing.assert_array_equal(got, w, err_msg=k)
+    np.testing.assert_array_equal(np.concatenate([p["lv"] for p in parts]), np.diff(off.to_host()))
+    for k, w in engine.to_host(flat).items():
+        np.testing.assert_array_equal(np.concatenate([p["f_" + k] for p in parts]), w, err_msg=k)
+    for k, w in engine.to_host(bar).items():
+        np.testing.assert_array_equal(np.concatenate([p["b_" + k] for p in parts]), w, err_msg=k)
