@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the waves of the one-pass cfg-4 kernel spend their cycles (a -DFU_TIMING build: tools/fu_variants.sh timing "-DFU_TIMING"):
+"""Where the waves of the one-pass cfg-4 kernel spend their cycles (a -DFU_TIMING build: tools/ab_variant.sh timing "-DFU_TIMING"):
     python tools/ab_lib.py finmlkit_amd/lib/ab/libfmk_hip_timing.so tools/fu_phases.py [N]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
