@@ -77,7 +77,7 @@ def _other_traffic():
         return {}
 
 
-def config_roofline(key, kernel_ms, alg_bytes, note=None):
+def config_roofline(key, kernel_ms, alg_bytes, note=None, extra=None):
     """The roofline object of one secondary config: `kernel_ms` is DEVICE time of the library call(s), a HIP-event pair on the
     context's stream (fmk_timer_start / fmk_timer_stop: from the first enqueue to the last completion, the host round trips
     inside a call included -- what a caller waits for, minus the Python around it); `traffic` and `dominant_kernel` come from the
@@ -88,14 +88,17 @@ def config_roofline(key, kernel_ms, alg_bytes, note=None):
     stale = (tr.get("csrc_sha256") != csrc_sha256()) if tr else None
     r = {"bound": "hbm", "algorithmic_bytes": alg_bytes, "kernel_ms": kernel_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "dominant_kernel": tr.get("dominant_kernel"), "dominant_kernel_ms": tr.get("dominant_kernel_ms"),
+         # (summed over the launches of that kernel in one call: where launches overlap on two streams the sum can exceed kernel_ms)
+         "dominant_kernel": tr.get("dominant_kernel"), "dominant_kernel_ms_summed": tr.get("dominant_kernel_ms_summed", tr.get("dominant_kernel_ms")),
          "kernels_ms_offline": tr.get("kernels_ms"),
          "traffic": tr.get("traffic_bytes"), "traffic_stale": stale,
          "traffic_source": (f"offline rocprofv3 --pmc FETCH_SIZE (x2, profiles/pmc_calibration.txt) + WRITE_SIZE over the kernels of one call "
                             f"(tools/cfgprof.py {key}; sources sha256 {str(tr.get('csrc_sha256'))[:12]}); kernel stats of the same command: "
-                            f"profiles/r05_{key}_kernel_stats.csv") if tr else None}
+                            f"profiles/r06_{key}_kernel_stats.csv") if tr else None}
     if note:
         r["note"] = note
+    if extra:
+        r.update(extra)
     return r
 
 
@@ -338,13 +341,19 @@ def other_configs(trades, ctx, args):
                "lagged_returns_5s": 24 * n, "ewmst_60s": 24 * n,
                "cusum_floor_5e-4": 24 * n + 8 * out["cusum_default_floor_5e-4_closes"],
                "cusum_floor_1e-5": 24 * n + 8 * out["cusum_floor_1e-5_closes"]}
-        notes = {"cfg3_volume_build_ohlcv": "SURVEY 8(d): indexer + reducer fused would read amount once with price: 12 B/tick; the build makes two calls (4 + 12)",
-                 "cfg3_dollar_build_ohlcv": "SURVEY 8(d): 12 B/tick for indexer + reducer; the build makes two calls (12 x 2 + 12)",
+        notes = {"cfg3_volume_build_ohlcv": "SURVEY 8(d) prices indexer + reducer as ONE read, 12 B/tick; a threshold indexer cannot emit a close before its chain is resolved back to the tape's first tick, so the reducer's pass is a second read by construction: algorithmic_bytes_two_pass (4 + 12 B/tick) is the algorithm's own compulsory figure, frac_two_pass the fraction against it (DESIGN.md section 3)",
+                 "cfg3_dollar_build_ohlcv": "SURVEY 8(d) prices indexer + reducer as ONE read, 12 B/tick; the closes are known only when the carry chain is resolved, so the reducer's pass is a second read by construction: algorithmic_bytes_two_pass (12 + 12 B/tick), frac_two_pass (DESIGN.md section 3)",
+                 "cfg4_equal_bars": "ONE pass over the ticks (csrc/fmk_fused.h: k_fu_bars reads price + amount + side once for OHLCV + median + order flow + the footprint histogram; k_fu_emit turns the staged level rows into the CSR rows)",
+                 "cfg4_equal_bars_full_mantissa": "sizes with a full float32 mantissa do not certify as whole units: OHLCV + median + order flow from one read (k_fu_bars without its histogram), the footprints by their own tick-ordered sweep (a second read, 13 B/tick)",
                  "cfg4_lognormal_full_mantissa": "the primary cfg 4 figure: bars of lognormal length (sigma 1), sizes with a full float32 mantissa",
                  "cusum_floor_5e-4": "24 B/tick read (ts, price, sigma) + 8 B per close; the device time spans the call's host round trips (the chain walk's launches wait for counts)",
                  "cusum_floor_1e-5": "24 B/tick read (ts, price, sigma) + 8 B per close; one-pass form (csrc/fmk_cusum_onepass.h); the device time spans the call's host round trips",
                  "ewmst_60s": "16 B/tick read (ts, returns) + 8 written", "lagged_returns_5s": "16 B/tick read (ts, price) + 8 written"}
-        out["roofline"] = {k: config_roofline(k, dev_ms[k], alg[k], notes.get(k)) for k in alg if k in dev_ms}
+        two_pass = {"cfg3_volume_build_ohlcv": 4 * n + 8 * (nvb + 1) + 12 * n + (8 + 68) * nvb,
+                    "cfg3_dollar_build_ohlcv": 12 * n + 8 * (ndb + 1) + 12 * n + (8 + 68) * ndb}
+        extras = {k: {"algorithmic_bytes_two_pass": v, "frac_two_pass": v / (dev_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                  for k, v in two_pass.items() if k in dev_ms}
+        out["roofline"] = {k: config_roofline(k, dev_ms[k], alg[k], notes.get(k), extras.get(k)) for k in alg if k in dev_ms}
         out["note"] = (f"{n} ticks, 1 GPU, best of 3, host wall time; not part of `value`; cfg3: volume AND dollar in the "
                        "library's default exact mode (n_uncertified == 0: provably the reference's close indices)")
     except Exception as e:                                               # noqa: BLE001 -- informational only

@@ -3,7 +3,7 @@
     tools/cfgprof.py KEY [ticks] [reps]
 runs the same library call(s) bench.py times under KEY, `reps` times after one untimed call, between two marker kernels
 (k_diag_marker) so that tools/cfgprof_summarize.py can cut the set-up (synthesis, thresholds) out of a rocprofv3 trace.
-Under `rocprofv3 --kernel-trace --stats` -> profiles/r05_KEY_kernel_stats.csv; under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+Under `rocprofv3 --kernel-trace --stats` -> profiles/r06_KEY_kernel_stats.csv; under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
 (separate runs) -> the traffic of profiles/traffic_other_configs.json."""
 import ctypes as C
 import os

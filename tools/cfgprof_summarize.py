@@ -2,9 +2,9 @@
 """The offline half of bench.py's per-config roofline objects.  Input: what tools/cfgprof.sh left in gpurun_out/cfgprof/ for each
 KEY -- a rocpd database of `rocprofv3 --kernel-trace --stats` (KEY_trace) and the counter CSVs of two `--pmc` runs (KEY_FETCH_SIZE,
 KEY_WRITE_SIZE), each of the process `tools/cfgprof.py KEY`.  Only the dispatches between the two k_diag_marker kernels count.
-Output: profiles/r05_KEY_kernel_stats.csv (per kernel: calls per call of the config, total / average ns) and
+Output: profiles/r06_KEY_kernel_stats.csv (per kernel: calls per call of the config, total / average ns) and
 profiles/traffic_other_configs.json {KEY: {traffic_bytes (2 x FETCH_SIZE + WRITE_SIZE per call of the config, KiB counters,
-profiles/pmc_calibration.txt), dominant_kernel, dominant_kernel_ms, kernels_ms, device_ms, csrc_sha256}}."""
+profiles/pmc_calibration.txt), dominant_kernel, dominant_kernel_ms_summed, kernels_ms, device_ms, csrc_sha256}}."""
 import csv, glob, json, os, re, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -58,7 +58,7 @@ def main():
             by.setdefault(name, []).append(en - st)
         os.makedirs(os.path.join(ROOT, "gpurun_out", "final"), exist_ok=True)
         for dst in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out", "final")):
-          with open(os.path.join(dst, f"r05_{key}_kernel_stats.csv"), "w") as fh:
+          with open(os.path.join(dst, f"r06_{key}_kernel_stats.csv"), "w") as fh:
             fh.write(f'# tools/cfgprof.py {key} {m.group(2)} {reps} under rocprofv3 --kernel-trace --stats: the dispatches of {reps} calls of the config (between the k_diag_marker kernels); device time per call by HIP events in the same run: {m.group(4)} ms\n')
             fh.write('"Name","CallsPerConfigCall","TotalDurationNs","AverageNs","MsPerConfigCall"\n')
             for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
@@ -68,7 +68,7 @@ def main():
         f, w = counter(key, "FETCH_SIZE"), counter(key, "WRITE_SIZE")
         out[key] = {"traffic_bytes": 2.0 * f + w if f is not None and w is not None else None,
                     "fetch_size_bytes_raw": f, "write_size_bytes": w,
-                    "dominant_kernel": short, "dominant_kernel_ms": sum(dom[1]) / reps * 1e-6,
+                    "dominant_kernel": short, "dominant_kernel_ms_summed": sum(dom[1]) / reps * 1e-6,
                     "kernels_ms": sum(sum(v) for v in by.values()) / reps * 1e-6, "device_ms": float(m.group(4)),
                     "n_ticks": int(m.group(2)), "csrc_sha256": sha}
         print(key, json.dumps(out[key]))
