@@ -7,7 +7,7 @@
 //     double-double (every price quotient of ticks less than 6 % apart);
 //   * every other positive finite x: x = 2^k z with z in [0x1.6p-1, 0x1.6p0), the subinterval i of 128 that holds z gives c_i
 //     near its centre with 1 / c_i and log c_i tabulated (fmk_logtab.h: glibc's own table, extracted from the host's libm by
-//     tools/extract_glibc_log_table.py), r = fma(z, 1 / c_i, -1), log x = k ln2 + log c_i + log1p(r) with a degree-5 polynomial
+//     tools/extract_glibc_tables.py), r = fma(z, 1 / c_i, -1), log x = k ln2 + log c_i + log1p(r) with a degree-5 polynomial
 //     (round 5 handed these arguments to the device library's log);
 //   * subnormals are scaled by 2^52 first; +0 / -0 -> -inf, negative -> NaN, +inf -> +inf, NaN -> NaN like glibc (the sign of a NaN
 //     result is not part of the contract).

@@ -19,6 +19,7 @@
 
 #include "fmk_common.h"
 #include "fmk_log.h"
+#include "fmk_exp.h"
 #include "fmk_dpp.h"
 
 // ---------------------------------------------------------------------------------------
@@ -180,38 +181,53 @@ struct EwMap {   // x -> a*x + b for the four states (V2 decays with a2 = a*a)
 
 __device__ __forceinline__ EwMap ew_identity() { return EwMap{1.0, 1.0, 0.0, 0.0, 0.0, 0.0}; }
 
-// first `f`, then `g`
+// first `f`, then `g`.  Fused multiply-adds (round 6; the library is built with contraction off, for the reference's own expressions):
+// the reference has no such operation -- its loop applies one tick at a time, and ew_step restates THAT -- so the composition only
+// has to be accurate, and every one of these is issued per tick and pass (6 instructions instead of 10).
 __device__ __forceinline__ EwMap ew_compose(const EwMap &f, const EwMap &g)
 {
     EwMap r;
     r.a = f.a * g.a;
     r.a2 = f.a2 * g.a2;
-    r.bV = g.a * f.bV + g.bV;
-    r.bV2 = g.a2 * f.bV2 + g.bV2;
-    r.bSy = g.a * f.bSy + g.bSy;
-    r.bSyy = g.a * f.bSyy + g.bSyy;
+    r.bV = fma(g.a, f.bV, g.bV);
+    r.bV2 = fma(g.a2, f.bV2, g.bV2);
+    r.bSy = fma(g.a, f.bSy, g.bSy);
+    r.bSyy = fma(g.a, f.bSyy, g.bSyy);
     return r;
 }
 
-// the per-tick map of MODE 0 / 1 from the tick's alpha = 1 - exp(-dt / half_life)
+// The per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52).  MODE 0: ewmst (volatility.py:139-219)   1: ewmst_mean0 (:72-136)
+// 2: ewms (:9-69; fixed alpha, no timestamps -- the four states are Sw, Sw2, Sy, Sy2).  `al` is the tick's alpha = 1 - exp(-dt / half_life)
+// for MODE 0 / 1, the fixed 1 - alpha for MODE 2.  A tick that is not there (beyond n, or tick 0 of the time-stamped modes, which the
+// reference skips) is handed in as al = 0, y = 0: the map is then EXACTLY the identity and the sequential step
+// leaves the state as it is, so the per-tick code carries no range checks (ew_mask_ticks).
 template <int MODE>
-__device__ __forceinline__ EwMap ew_tick_alpha(double alpha, double y)
+__device__ __forceinline__ EwMap ew_tick_map(double al, double y)
 {
     const bool nan = isnan(y);
     EwMap m;
-    const double om = 1.0 - alpha;
+    if constexpr (MODE == 2) {
+        m.a = al;
+        m.a2 = al * al;
+        m.bV = nan ? 0.0 : 1.0;
+        m.bV2 = nan ? 0.0 : 1.0;
+        m.bSy = nan ? 0.0 : y;
+        m.bSyy = nan ? 0.0 : y * y;
+        return m;
+    }
+    const double om = 1.0 - al;
     m.a = om;
     m.a2 = om * om;
     if constexpr (MODE == 1) {
-        m.bV = nan ? 0.0 : alpha;            // V  (weights) : decays only on NaN
+        m.bV = nan ? 0.0 : al;               // V  (weights) : decays only on NaN
         m.bV2 = 0.0;
         m.bSy = 0.0;
-        m.bSyy = nan ? 0.0 : alpha * (y * y);   // U
+        m.bSyy = nan ? 0.0 : al * (y * y);   // U
     } else {
-        m.bV = alpha;
-        m.bV2 = alpha * alpha;
-        m.bSy = nan ? 0.0 : alpha * y;
-        m.bSyy = nan ? 0.0 : alpha * y * y;
+        m.bV = al;
+        m.bV2 = al * al;
+        m.bSy = nan ? 0.0 : al * y;
+        m.bSyy = nan ? 0.0 : al * y * y;
     }
     return m;
 }
@@ -229,16 +245,44 @@ __device__ __forceinline__ double ew_div(double x, double v, double r)
 // negative, non-finite, an all-ones significand -- takes the plain divisions); MODE 2: `hl` is the fixed 1 - alpha.
 struct EwHl { double hl, r; };
 
-// alpha of one tick, volatility.py:178-179: dt = (t - t_prev) / 1e9; alpha = 1 - exp(-dt / half_life) -- the reference's two
-// divisions as correctly rounded quotients (same bits), then the library exp.  Parity note: for gaps of nanoseconds against a
-// half life of seconds exp(x) is 1 - k * 2^-53 with a single-digit k and the reference's alpha carries a relative error of 1e-2
-// ... 1e-7; a MORE accurate alpha (a polynomial for -expm1 was tried: 11 instructions instead of exp's ~45) moves the outputs by
-// up to 4e-7 relative and fails the parity fuzz -- the reference's rounding is part of its result.
-__device__ __forceinline__ double ew_alpha(int64_t t_prev, int64_t t_cur, EwHl h)
+// alpha of the thread's eight ticks, volatility.py:178-179: dt = (t - t_prev) / 1e9; alpha = 1 - exp(-dt / half_life) -- the reference's two
+// divisions as correctly rounded quotients (same bits), then THE HOST's exp (csrc/fmk_exp.h: glibc's, restated; round 5 called the device
+// library's).  Parity note: for gaps of nanoseconds against a half life of seconds exp(x) is 1 - k * 2^-53 with a single-digit k and the
+// reference's alpha carries a relative error of 1e-2 ... 1e-7; a MORE accurate alpha (a polynomial for -expm1 was tried) moves the outputs
+// by up to 4e-7 relative and fails the parity fuzz -- the reference's rounding is part of its result.
+// The two data-dependent choices are taken ONCE per eight ticks, wave-uniform (round 6; they stood inside the per-tick code, and every
+// tick was its own basic block with ~60 register copies between them): the odd half life, and whether every argument of the wave lies in
+// exp's table-free range (|x| < ln2 / 256: gaps below 0.27 % of the half life -- 8 instructions per exp instead of ~45).
+#define EW_THREADS 256
+#define EW_ITEMS 8
+#define EW_TILE (EW_THREADS * EW_ITEMS)
+__device__ __forceinline__ void ew_alphas(const int64_t (&tl)[EW_ITEMS], int64_t tprev0, EwHl h, double (&al)[EW_ITEMS])
 {
-    const double dt = ew_div((double)(t_cur - t_prev), 1e9, 1e-9);        // 1e-9 == RN(1 / 1e9)
-    const double x = h.r != 0.0 ? -ew_div(dt, h.hl, h.r) : -dt / h.hl;
-    return 1.0 - exp(x);
+    double x[EW_ITEMS];
+    int64_t tp = tprev0;
+    if (h.r != 0.0) {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) {
+            x[k] = -ew_div(ew_div((double)(tl[k] - tp), 1e9, 1e-9), h.hl, h.r);       // 1e-9 == RN(1 / 1e9)
+            tp = tl[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) {
+            x[k] = -(ew_div((double)(tl[k] - tp), 1e9, 1e-9) / h.hl);
+            tp = tl[k];
+        }
+    }
+    bool general = false;
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) general |= !(fabs(x[k]) < FMK_EXP_SMALL_BELOW);
+    if (__builtin_amdgcn_ballot_w64(general) != 0) {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) al[k] = 1.0 - fmk_exp_host(x[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) al[k] = 1.0 - fmk_exp_small(x[k]);
+    }
 }
 // 1 / x for a positive normal x, correctly rounded in practice: v_rcp_f64 and two Newton steps
 __device__ __forceinline__ double ew_rcp(double x)
@@ -247,27 +291,6 @@ __device__ __forceinline__ double ew_rcp(double x)
     r = fma(r, fma(-x, r, 1.0), r);
     r = fma(r, fma(-x, r, 1.0), r);
     return r;
-}
-
-// MODE 0: ewmst (volatility.py:139-219)   1: ewmst_mean0 (:72-136)   2: ewms (:9-69; fixed alpha, no timestamps --
-// `half_life` then carries one_minus_alpha and the four states are Sw, Sw2, Sy, Sy2)
-// the reference's per-tick update as a map (volatility.py:176-201 / 110-124 / 44-52)
-template <int MODE>
-__device__ __forceinline__ EwMap ew_tick(int64_t t_prev, int64_t t_cur, double y, EwHl half_life)
-{
-    const bool nan = isnan(y);
-    EwMap m;
-    if constexpr (MODE == 2) {
-        const double om = half_life.hl;
-        m.a = om;
-        m.a2 = om * om;
-        m.bV = nan ? 0.0 : 1.0;
-        m.bV2 = nan ? 0.0 : 1.0;
-        m.bSy = nan ? 0.0 : y;
-        m.bSyy = nan ? 0.0 : y * y;
-        return m;
-    }
-    return ew_tick_alpha<MODE>(ew_alpha(t_prev, t_cur, half_life), y);
 }
 
 // sequentially apply one tick to a state, in the reference's operation order; `alpha` is the tick's alpha (MODE 2: the fixed
@@ -296,6 +319,23 @@ __device__ __forceinline__ void ew_step(double &V, double &V2, double &Sy, doubl
     }
 }
 
+// sqrt(x) for the closing expressions: the device library's correctly rounded sequence (v_rsq_f64, one coupled step for root and half
+// reciprocal root, two residual corrections) without its range scaling and special-value selects -- 10 instructions instead of 21 --
+// when every lane of the wave has x in [2^-767, 2^1000] (the library scales below 2^-767); the library's sqrt otherwise (zeros, NaN,
+// infinities, subnormal variances).  Same operations on the same operands in range: the same bits.
+__device__ __forceinline__ double ew_sqrt(double x)
+{
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-767 && x <= 0x1p+1000)) != 0) return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return g;
+}
+
 // The closing quotients use ew_div with ONE refined reciprocal per divisor (three quotients by V share it: 5 + 3 x 3 instructions
 // instead of three ~11-instruction IEEE divisions).  Correct rounding matters here: e2 - mean * mean and V - V2 / V cancel to
 // EXACTLY 0 for a window with one valid sample in the reference, and "== 0" decides between 0.0 / NaN and a 1e-13 residue.
@@ -311,11 +351,11 @@ __device__ __forceinline__ double ew_sigma(double V, double V2, double Sy, doubl
         if (!(den > 0.0)) return NAN;
         double var = ew_div((ew_div(Syy, V, rV) - mean * mean) * V, den, ew_rcp(den));
         if (!(var > 0.0)) var = isnan(var) ? var : 0.0;
-        return sqrt(var);
+        return ew_sqrt(var);
     } else if constexpr (MODE == 1) {
         double var = V > 0.0 ? ew_div(Syy, V, ew_rcp(V)) : NAN;     // volatility.py:127-133
         if (var < 0.0) var = 0.0;
-        double s = sqrt(var);
+        double s = ew_sqrt(var);
         if (s < sigma_floor) s = sigma_floor;
         return s;
     } else {
@@ -325,15 +365,12 @@ __device__ __forceinline__ double ew_sigma(double V, double V2, double Sy, doubl
         const double var_raw = e2 - mean * mean;
         const double denom = V - ew_div(V2, V, rV);
         const double var = (denom > 0.0 && var_raw > 0.0) ? var_raw * ew_div(V, denom, ew_rcp(denom)) : 0.0;
-        double s = sqrt(var);
+        double s = ew_sqrt(var);
         if (s < sigma_floor) s = sigma_floor;
         return s;
     }
 }
 
-#define EW_THREADS 256
-#define EW_ITEMS 8
-#define EW_TILE (EW_THREADS * EW_ITEMS)
 
 __device__ __forceinline__ EwMap ew_shfl_up(const EwMap &m, int d)
 {
@@ -379,157 +416,132 @@ __device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *ld
     return ew_compose(pre, prev);
 }
 
-// Coalesced tile load through LDS: thread t loads elements t + 256*r (full 2 KB wavefronts), then reads
-// back its 8 CONSECUTIVE ticks (rows padded 8 -> 9 doubles: conflict-free ds_read_b64).  tl[k] / yl[k] are
-// tick i0+k (0 beyond n); *tprev0 is ts[i0-1] (ts[0] for the very first tick).
-__device__ __forceinline__ void ew_load_tile(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
-                                             int64_t *s_ts, double *s_y, int64_t (&tl)[EW_ITEMS],
-                                             double (&yl)[EW_ITEMS], int64_t *tprev0)
-{
-    const int64_t base = (int64_t)blockIdx.x * EW_TILE;
-#pragma unroll
-    for (int r = 0; r < EW_ITEMS; ++r) {
-        const int e = r * EW_THREADS + threadIdx.x;          // element of the tile
-        const int64_t i = base + e;
-        const int slot = (e >> 3) * 9 + (e & 7);
-        s_ts[slot] = (ts && i < n) ? ts[i] : 0;
-        s_y[slot] = i < n ? y[i] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EW_ITEMS; ++k) {
-        tl[k] = s_ts[threadIdx.x * 9 + k];
-        yl[k] = s_y[threadIdx.x * 9 + k];
-    }
-    const int64_t i0 = base + (int64_t)threadIdx.x * EW_ITEMS;
-    int64_t tp = 0;
-    if (threadIdx.x > 0) tp = s_ts[(threadIdx.x - 1) * 9 + 7];
-    else if (ts && i0 >= 1 && i0 - 1 < n) tp = ts[i0 - 1];
-    *tprev0 = tp;
-}
-
 // The thread's 8 consecutive ticks straight from memory, 16 bytes per load (4 + 4 instructions; every 128-byte line is shared
-// by two lanes): no LDS.  The transposing tile of ew_load_tile costs 36.8 KB per workgroup -- four workgroups per CU -- and
+// by two lanes): no LDS.  A transposing tile in LDS (round 1) cost 36.8 KB per workgroup -- four workgroups per CU -- and
 // these kernels are bound by the work they have in flight, not by how their loads coalesce: k_ew_tile_maps 5.5 -> 2.7 ms per 1e9
 // ticks (6.0 TB/s), k_ew_apply with direct 16-byte stores as well: see profiles/r02_ewmst_direct_loads.txt.
-__device__ __forceinline__ void ew_load_direct(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
-                                               int64_t (&tl)[EW_ITEMS], double (&yl)[EW_ITEMS], int64_t *tprev0)
+// `whole`: every tick of the workgroup's tile exists and none of them is tick 0 (uniform over the workgroup: tiles 1 .. the last full one);
+// the other tiles read tick by tick with range checks (0 for what is not there).  *tprev0 is ts[i0 - 1] (0 in front of tick 0).
+typedef long long ew_l2 __attribute__((ext_vector_type(2), aligned(8)));       // 16-byte accesses on an 8-byte alignment promise:
+typedef double ew_d2 __attribute__((ext_vector_type(2), aligned(8)));          // a shard's arrays start one tick before a 64-byte boundary
+__device__ __forceinline__ bool ew_whole_tile(int64_t tile, int64_t n) { return tile > 0 && (tile + 1) * EW_TILE <= n; }
+
+__device__ __forceinline__ void ew_load8(const double *__restrict__ src, int64_t i0, int64_t n, bool whole, double (&v)[EW_ITEMS])
 {
-    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    // 16-byte accesses on an 8-byte alignment promise: a shard's arrays start one tick before a 64-byte boundary
-    typedef long long ew_l2 __attribute__((ext_vector_type(2), aligned(8)));
-    typedef double ew_d2 __attribute__((ext_vector_type(2), aligned(8)));
-    if (i0 + EW_ITEMS <= n) {
-        if (ts) {
-            const ew_l2 *q = (const ew_l2 *)(ts + i0);
+    if (whole) {
+        const ew_d2 *q = (const ew_d2 *)(src + i0);
 #pragma unroll
-            for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_l2 v = q[k]; tl[2 * k] = v.x; tl[2 * k + 1] = v.y; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < EW_ITEMS; ++k) tl[k] = 0;
-        }
-        const ew_d2 *qy = (const ew_d2 *)(y + i0);
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_d2 v = qy[k]; yl[2 * k] = v.x; yl[2 * k + 1] = v.y; }
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_d2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
     } else {
 #pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k) {
-            tl[k] = (ts && i0 + k < n) ? ts[i0 + k] : 0;
-            yl[k] = i0 + k < n ? y[i0 + k] : 0.0;
-        }
+        for (int k = 0; k < EW_ITEMS; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0.0;
     }
-    *tprev0 = (ts && i0 >= 1 && i0 - 1 < n) ? ts[i0 - 1] : 0;
 }
-
-#define EW_LDS_ELEMS (EW_THREADS * 9)
-
-// al[k]: the tick's alpha (MODE 2: the fixed 1 - alpha), kept for the apply phase
-template <int MODE>
-__device__ __forceinline__ EwMap ew_thread_map(const int64_t (&tl)[EW_ITEMS], const double (&yl)[EW_ITEMS],
-                                               int64_t tprev0, int64_t n, EwHl half_life, double (&al)[EW_ITEMS])
+__device__ __forceinline__ void ew_load_ticks(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t i0, int64_t n, bool whole,
+                                              int64_t (&tl)[EW_ITEMS], double (&yl)[EW_ITEMS], int64_t *tprev0)
 {
-    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    EwMap m = ew_identity();
-    int64_t tprev = tprev0;
+    if (!ts) {                                                      // ewms: no timestamps
 #pragma unroll
-    for (int k = 0; k < EW_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        al[k] = MODE == 2 ? half_life.hl : 0.0;
-        if (i >= (MODE == 2 ? 0 : 1) && i < n) {          // ewms has no skipped first tick
-            if constexpr (MODE == 2) m = ew_compose(m, ew_tick<MODE>(tprev, tl[k], yl[k], half_life));
-            else {
-                al[k] = ew_alpha(tprev, tl[k], half_life);
-                m = ew_compose(m, ew_tick_alpha<MODE>(al[k], yl[k]));
-            }
-            tprev = tl[k];
-        } else if (i == 0 && n > 0) {
-            tprev = tl[k];
-        }
+        for (int k = 0; k < EW_ITEMS; ++k) tl[k] = 0;
+        *tprev0 = 0;
+    } else if (whole) {
+        const ew_l2 *q = (const ew_l2 *)(ts + i0);
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_l2 v = q[k]; tl[2 * k] = v.x; tl[2 * k + 1] = v.y; }
+        *tprev0 = ts[i0 - 1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < EW_ITEMS; ++k) tl[k] = i0 + k < n ? ts[i0 + k] : 0;
+        *tprev0 = (i0 >= 1 && i0 - 1 < n) ? ts[i0 - 1] : 0;
     }
-    return m;
+    ew_load8(y, i0, n, whole, yl);
 }
-
-// the thread's 8 consecutive doubles as four 16-byte accesses
-__device__ __forceinline__ void ew_store8(double *__restrict__ dst, int64_t i0, int64_t n, const double (&v)[EW_ITEMS])
+// the thread's 8 consecutive results as four 16-byte stores
+__device__ __forceinline__ void ew_store8(double *__restrict__ dst, int64_t i0, int64_t n, bool whole, const double (&v)[EW_ITEMS])
 {
-    if (i0 + EW_ITEMS <= n) {
-        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
-        ew_d2s *q = (ew_d2s *)(dst + i0);
+    if (whole) {
+        ew_d2 *q = (ew_d2 *)(dst + i0);
 #pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) { ew_d2s t; t.x = v[2 * k]; t.y = v[2 * k + 1]; q[k] = t; }
+        for (int k = 0; k < EW_ITEMS / 2; ++k) { ew_d2 t; t.x = v[2 * k]; t.y = v[2 * k + 1]; q[k] = t; }
     } else {
 #pragma unroll
         for (int k = 0; k < EW_ITEMS; ++k)
             if (i0 + k < n) dst[i0 + k] = v[k];
     }
 }
-__device__ __forceinline__ void ew_load8(const double *__restrict__ src, int64_t i0, int64_t n, double (&v)[EW_ITEMS])
-{
-    if (i0 + EW_ITEMS <= n) {
-        typedef double ew_d2s __attribute__((ext_vector_type(2), aligned(8)));
-        const ew_d2s *q = (const ew_d2s *)(src + i0);
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS / 2; ++k) { const ew_d2s t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0.0;
-    }
-}
 
-// alpha_out (may be null; round 4): the tick's alpha is ALSO stored -- into the caller's output array, which the apply pass reads it
-// back from before it overwrites it with sigma (the same thread owns the same 8 elements in both passes).  The apply pass then
-// needs neither the timestamps nor a second exp per tick: it reads alpha (8 B) instead of ts (8 B), so the only extra traffic is
-// this pass's 8 B/tick of stores.
+// a tile that is not `whole`: the ticks that are not there become the identity (see ew_tick_map).  ewms needs none of it: it has no
+// skipped first tick and no shard entry point, so what the ticks beyond n do to the last tile's aggregate is never read.
 template <int MODE>
-__global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__restrict__ ts,
-                                                             const double *__restrict__ y, int64_t n,
-                                                             EwHl half_life, EwMap *__restrict__ tile_map,
-                                                             double *__restrict__ alpha_out = nullptr)
+__device__ __forceinline__ void ew_mask_ticks(int64_t i0, int64_t n, double (&al)[EW_ITEMS], double (&yl)[EW_ITEMS])
 {
-    __shared__ EwMap lds[4];
-    int64_t tl[EW_ITEMS], tprev0;
-    double yl[EW_ITEMS];
-    ew_load_direct(ts, y, n, tl, yl, &tprev0);
-    double al[EW_ITEMS];
-    EwMap m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
-    if (alpha_out) ew_store8(alpha_out, (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS, n, al);
-    EwMap tot;
-    (void)ew_block_exclusive(m, lds, &tot);
-    if (threadIdx.x == 0) tile_map[blockIdx.x] = tot;
-}
-
-// the thread's map from GIVEN alphas (the apply pass after a map pass that stored them): the same compositions, no exp
-template <int MODE>
-__device__ __forceinline__ EwMap ew_thread_map_given(const double (&yl)[EW_ITEMS], int64_t n, const double (&al)[EW_ITEMS])
-{
-    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    EwMap m = ew_identity();
+    if constexpr (MODE == 2) return;
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k) {
         const int64_t i = i0 + k;
-        if (i >= 1 && i < n) m = ew_compose(m, ew_tick_alpha<MODE>(al[k], yl[k]));
+        if (!(i >= 1 && i < n)) { al[k] = 0.0; yl[k] = 0.0; }
     }
+}
+
+// The thread's ticks of tile `tile`: yl[] the values, al[] the alphas (MODE 2: the fixed 1 - alpha) -- kept for the apply phase, exp is
+// evaluated once per tick and pass -- and the composition of the eight tick maps.
+template <int MODE>
+__device__ __forceinline__ EwMap ew_thread_ticks(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t tile, int64_t n,
+                                                 EwHl half_life, double (&yl)[EW_ITEMS], double (&al)[EW_ITEMS])
+{
+    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    const bool whole = ew_whole_tile(tile, n);
+    {
+        int64_t tl[EW_ITEMS], tprev0;
+        ew_load_ticks(MODE == 2 ? nullptr : ts, y, i0, n, whole, tl, yl, &tprev0);
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < EW_ITEMS; ++k) al[k] = half_life.hl;
+        } else
+            ew_alphas(tl, tprev0, half_life, al);
+    }
+    if (!whole) ew_mask_ticks<MODE>(i0, n, al, yl);
+    EwMap m = ew_tick_map<MODE>(al[0], yl[0]);
+#pragma unroll
+    for (int k = 1; k < EW_ITEMS; ++k) m = ew_compose(m, ew_tick_map<MODE>(al[k], yl[k]));
     return m;
+}
+
+// ... and the sequential pass over them from the state (V, V2, Sy, Syy) entering the thread's first tick: the reference's update in
+// its own operation order, its closing expression per tick, the results stored.  out[0] = NaN (volatility.py:174).
+template <int MODE>
+__device__ __forceinline__ void ew_thread_apply(double V, double V2, double Sy, double Syy, const double (&yl)[EW_ITEMS],
+                                                const double (&al)[EW_ITEMS], double sigma_floor, int64_t tile, int64_t n,
+                                                double *__restrict__ out)
+{
+    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
+    const bool whole = ew_whole_tile(tile, n);
+    double res[EW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        // the products of alpha and y that the tick map formed in front of the scan are formed again here (5 instructions per tick):
+        // kept, they are 80 registers live across the scan -- the compiler spilled them
+        double a = al[k], yy = yl[k];
+        if constexpr (MODE == 2) asm volatile("" : "+v"(yy));        // ewms: al[] is one constant
+        else asm volatile("" : "+v"(a), "+v"(yy));
+        ew_step<MODE>(V, V2, Sy, Syy, a, yy);
+        res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
+    }
+    if (MODE != 2 && i0 == 0) res[0] = NAN;
+    ew_store8(out, i0, n, whole, res);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EW_THREADS) void k_ew_tile_maps(const int64_t *__restrict__ ts,
+                                                             const double *__restrict__ y, int64_t n,
+                                                             EwHl half_life, EwMap *__restrict__ tile_map)
+{
+    __shared__ EwMap lds[4];
+    double yl[EW_ITEMS], al[EW_ITEMS];
+    const EwMap m = ew_thread_ticks<MODE>(ts, y, blockIdx.x, n, half_life, yl, al);
+    EwMap tot;
+    (void)ew_block_exclusive(m, lds, &tot);
+    if (threadIdx.x == 0) tile_map[blockIdx.x] = tot;
 }
 
 // Hierarchical exclusive scan (composition) of an array of maps, in place:
@@ -575,51 +587,34 @@ static int ew_scan_maps(fmk_ctx *ctx, EwMap *maps, int64_t m, EwMap *work)
     return FMK_OK;
 }
 
+// the state entering the thread's first tick: the prefix map applied to the initial state (all-zero unless this is a shard of a longer
+// series: then the state the earlier shards leave behind, fmk_ewmst_shard_*)
+__device__ __forceinline__ void ew_enter(const EwMap &ex, const double *__restrict__ state_in, double &V, double &V2, double &Sy, double &Syy)
+{
+    V = ex.bV; V2 = ex.bV2; Sy = ex.bSy; Syy = ex.bSyy;
+    if (state_in) {
+        V = fma(ex.a, state_in[0], ex.bV); V2 = fma(ex.a2, state_in[1], ex.bV2);
+        Sy = fma(ex.a, state_in[2], ex.bSy); Syy = fma(ex.a, state_in[3], ex.bSyy);
+    }
+}
+
 template <int MODE>
 // six waves per SIMD (78 VGPRs, no spill): 9.5 -> 9.4 ms; eight (64 VGPRs, 68 B of scratch): 13.2 ms
 __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
                                                          int64_t n, EwHl half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
                                                          const double *__restrict__ state_in,
-                                                         double *__restrict__ out, int alpha_in_out = 0)
+                                                         double *__restrict__ out)
 {
     __shared__ EwMap lds[4];
-    double yl[EW_ITEMS];
-    double al[EW_ITEMS];
-    EwMap m;
-    if (MODE != 2 && alpha_in_out) {
-        // `out` holds the alphas of the map pass: 8 B/tick of alpha instead of 8 B/tick of timestamps, and no second exp
-        const int64_t i0a = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-        ew_load8(y, i0a, n, yl);
-        ew_load8(out, i0a, n, al);
-        m = ew_thread_map_given<MODE>(yl, n, al);
-    } else {
-        int64_t tl[EW_ITEMS], tprev0;
-        ew_load_direct(ts, y, n, tl, yl, &tprev0);
-        m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
-    }
+    double yl[EW_ITEMS], al[EW_ITEMS];
+    const EwMap m = ew_thread_ticks<MODE>(ts, y, blockIdx.x, n, half_life, yl, al);
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     ex = ew_compose(tile_pre[blockIdx.x], ex);
-    // state entering my first tick: the prefix map applied to the initial state (all-zero unless this is a shard
-    // of a longer series: then the state the earlier shards leave behind, fmk_ewmst_shard_*)
-    double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
-    if (state_in) {
-        V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
-        Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
-    }
-    const int64_t i0 = (int64_t)blockIdx.x * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    double res[EW_ITEMS];
-#pragma unroll
-    for (int k = 0; k < EW_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        res[k] = NAN;                                              // volatility.py:174 (out[0])
-        if (i >= n) continue;
-        if (MODE != 2 && i == 0) continue;
-        ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
-        res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
-    }
-    ew_store8(out, i0, n, res);                                    // the thread's 8 results as four 16-byte stores
+    double V, V2, Sy, Syy;
+    ew_enter(ex, state_in, V, V2, Sy, Syy);
+    ew_thread_apply<MODE>(V, V2, Sy, Syy, yl, al, sigma_floor, blockIdx.x, n, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -628,11 +623,8 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
 // registers between the map phase and the apply phase).  Inter-workgroup hand-off as the CDNA4 guide prescribes (Guideline
 // 16, form R2: the data IS the flag): a tile's aggregate map and, later, its inclusive prefix map are published as twelve
 // 8-byte {tag, 32-bit word} granules each with relaxed agent-scope stores; a consumer re-reads the twelve granules until
-// every tag matches -- no fences, no flags, nothing that depends on dispatch order or XCD placement.  Forward progress: the
-// grid is PERSISTENT (as many workgroups as the device can hold at once, each looping over tiles t, t + G, ...), so every
-// tile a workgroup waits for belongs to a resident workgroup that only ever waits for EARLIER tiles.  Spins are bounded: a
-// tile that never shows up raises a sticky error word in pinned host memory (reported by the next fmk_ctx_sync / fmk_d2h)
-// instead of hanging the device.
+// every tag matches -- no fences, no flags, nothing that depends on XCD placement.  Spins are bounded: a tile that never shows up
+// raises a sticky error word in pinned host memory (reported by the next fmk_ctx_sync / fmk_d2h) instead of hanging the device.
 #define EW_SPIN_LIMIT (1u << 22)
 #define EW_W1 64                         // tiles one R record covers
 
@@ -733,138 +725,15 @@ __device__ __forceinline__ bool ew_lookback(const EwDesc &D, int64_t tile, int l
     }
 }
 
+// ONE TILE PER WORKGROUP in dispatch order, the tile's ticks by direct 16-byte loads (round 5; round 2's form was a persistent grid with
+// the tile staged in LDS: every workgroup reached its look-back at the same moment and the whole device waited out the two round trips,
+// generation after generation -- 18.7 ms per 1e9 ticks, removed in round 6).  Here the workgroups of a CU are at different points of
+// their tiles and the SIMDs stay busy with the others' arithmetic while one waits.  Forward progress: workgroups are dispatched in index
+// order, so the lowest unfinished tile is always resident; a wait that gives up all the same raises the sticky error word instead of
+// hanging.
+// Four waves per SIMD (112 .. 128 registers, no spill): 9.5 ms per 1e9 ticks; five: 13.2 ms, six: 15.6 ms (they spill).
 template <int MODE>
-__global__ __launch_bounds__(EW_THREADS) void k_ew_onepass(const int64_t *__restrict__ ts, const double *__restrict__ y,
-                                                           int64_t n, EwHl half_life, double sigma_floor,
-                                                           const double *__restrict__ state_in, double *__restrict__ out,
-                                                           EwDesc D, int64_t tiles, int64_t *err_word)
-{
-    __shared__ EwMap lds[4];
-    __shared__ EwMap s_excl;
-    __shared__ int64_t s_ts[EW_LDS_ELEMS];
-    __shared__ double s_y[EW_LDS_ELEMS];
-    const int lane = fmk_lane();
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t base = tile * EW_TILE;
-        // ---- coalesced tile load through LDS (ew_load_tile with an explicit tile index)
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < EW_ITEMS; ++r) {
-            const int e = r * EW_THREADS + threadIdx.x;
-            const int64_t i = base + e;
-            const int slot = (e >> 3) * 9 + (e & 7);
-            s_ts[slot] = (ts && i < n) ? ts[i] : 0;
-            s_y[slot] = i < n ? y[i] : 0.0;
-        }
-        __syncthreads();
-        int64_t tl[EW_ITEMS];
-        double yl[EW_ITEMS];
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k) {
-            tl[k] = s_ts[threadIdx.x * 9 + k];
-            yl[k] = s_y[threadIdx.x * 9 + k];
-        }
-        const int64_t i0 = base + (int64_t)threadIdx.x * EW_ITEMS;
-        int64_t tprev0 = 0;
-        if (threadIdx.x > 0) tprev0 = s_ts[(threadIdx.x - 1) * 9 + 7];
-        else if (ts && i0 >= 1 && i0 - 1 < n) tprev0 = ts[i0 - 1];
-        // ---- per-tick maps (the decay factor of every tick is kept for the apply phase: one exp per tick)
-        EwMap m = ew_identity();
-        double al[EW_ITEMS];                                           // alpha of every tick (MODE 2: the fixed 1 - alpha)
-        {
-            int64_t tprev = tprev0;
-#pragma unroll
-            for (int k = 0; k < EW_ITEMS; ++k) {
-                const int64_t i = i0 + k;
-                al[k] = 0.0;
-                if (i >= (MODE == 2 ? 0 : 1) && i < n) {
-                    EwMap t;
-                    if constexpr (MODE == 2) {
-                        t = ew_tick<MODE>(tprev, tl[k], yl[k], half_life);
-                        al[k] = half_life.hl;
-                    } else {
-                        al[k] = ew_alpha(tprev, tl[k], half_life);     // volatility.py:178-179, evaluated ONCE per tick
-                        t = ew_tick_alpha<MODE>(al[k], yl[k]);
-                    }
-                    m = ew_compose(m, t);
-                    tprev = tl[k];
-                } else if (i == 0 && n > 0) {
-                    tprev = tl[k];
-                }
-            }
-        }
-        EwMap tot;
-        EwMap ex = ew_block_exclusive(m, lds, &tot);
-        // ---- publish the aggregate, look back, publish the inclusive prefix (wave 0)
-        if (threadIdx.x < 64) {
-            EwMap excl = ew_identity();
-            ew_publish(D.A + 12 * tile, D.tagA + tile, tot, lane);
-            if (tile > 0 && !ew_lookback(D, tile, lane, &excl)) {
-                if (lane == 0) *err_word = 1;                          // never: report, do not hang
-                excl = ew_identity();
-            }
-            ew_publish(D.P + 12 * ew_slot(tile, D.groups), D.tagP + ew_slot(tile, D.groups), excl, lane);
-            if (lane == 0) s_excl = excl;
-        }
-        __syncthreads();
-        ex = ew_compose(s_excl, ex);
-        // ---- apply: the reference's update in its own operation order, from the state entering my first tick
-        double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
-        if (state_in) {
-            V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
-            Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
-        }
-        double res[EW_ITEMS];
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k) {
-            const int64_t i = i0 + k;
-            res[k] = NAN;                                              // volatility.py:174 (out[0])
-            if (i >= n) continue;
-            if (MODE != 2 && i == 0) continue;
-            const bool nan = isnan(yl[k]);
-            const double yy = yl[k];
-            if constexpr (MODE == 2) {
-                const double o = al[k], wgt = nan ? 0.0 : 1.0;
-                V = o * V + wgt;
-                V2 = (o * o) * V2 + wgt;
-                if (nan) { Sy = o * Sy; Syy = o * Syy; }
-                else { Sy = o * Sy + yy; Syy = o * Syy + yy * yy; }
-            } else {
-                const double alpha = al[k], o = 1.0 - alpha;           // the operations of ew_step, minus its exp
-                if constexpr (MODE == 1) {
-                    if (nan) { Syy = o * Syy; V = o * V; }
-                    else { Syy = alpha * (yy * yy) + o * Syy; V = alpha + o * V; }
-                } else {
-                    V = alpha + o * V;
-                    V2 = alpha * alpha + (o * o) * V2;
-                    if (nan) { Sy = o * Sy; Syy = o * Syy; }
-                    else { Sy = alpha * yy + o * Sy; Syy = alpha * yy * yy + o * Syy; }
-                }
-            }
-            res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
-        }
-        // ---- coalesced store through the (now free) LDS tile
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < EW_ITEMS; ++k) s_y[threadIdx.x * 9 + k] = res[k];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < EW_ITEMS; ++r) {
-            const int e = r * EW_THREADS + threadIdx.x;
-            const int64_t i = base + e;
-            if (i < n) out[i] = s_y[(e >> 3) * 9 + (e & 7)];
-        }
-    }
-}
-
-// The one-pass kernel, second form (round 5): ONE TILE PER WORKGROUP in dispatch order instead of a persistent grid, the tile's ticks by
-// direct 16-byte loads (no LDS staging: six waves per SIMD instead of four).  With the persistent grid every workgroup reaches its
-// look-back at the same moment and the whole device waits out the two round trips, generation after generation (18.7 ms per 1e9
-// ticks); here the workgroups of a CU are at different points of their tiles and the SIMDs stay busy with the others' arithmetic
-// while one waits.  Forward progress: workgroups are dispatched in index order, so the lowest unfinished tile is always resident;
-// a wait that gives up all the same raises the sticky error word instead of hanging.
-template <int MODE, int OCC>
-__global__ __launch_bounds__(EW_THREADS, OCC) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
+__global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
                                                                 EwHl half_life, double sigma_floor, const double *__restrict__ state_in,
                                                                 double *__restrict__ out, EwDesc D, int64_t *err_word)
 {
@@ -873,12 +742,7 @@ __global__ __launch_bounds__(EW_THREADS, OCC) void k_ew_onepass_d(const int64_t 
     const int lane = fmk_lane();
     const int64_t tile = blockIdx.x;
     double yl[EW_ITEMS], al[EW_ITEMS];
-    EwMap m;
-    {
-        int64_t tl[EW_ITEMS], tprev0;
-        ew_load_direct(ts, y, n, tl, yl, &tprev0);
-        m = ew_thread_map<MODE>(tl, yl, tprev0, n, half_life, al);
-    }
+    const EwMap m = ew_thread_ticks<MODE>(ts, y, tile, n, half_life, yl, al);
     EwMap tot;
     EwMap ex = ew_block_exclusive(m, lds, &tot);
     if (threadIdx.x < 64) {
@@ -893,23 +757,9 @@ __global__ __launch_bounds__(EW_THREADS, OCC) void k_ew_onepass_d(const int64_t 
     }
     __syncthreads();
     ex = ew_compose(s_excl, ex);
-    double V = ex.bV, V2 = ex.bV2, Sy = ex.bSy, Syy = ex.bSyy;
-    if (state_in) {
-        V = ex.a * state_in[0] + ex.bV; V2 = ex.a2 * state_in[1] + ex.bV2;
-        Sy = ex.a * state_in[2] + ex.bSy; Syy = ex.a * state_in[3] + ex.bSyy;
-    }
-    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    double res[EW_ITEMS];
-#pragma unroll
-    for (int k = 0; k < EW_ITEMS; ++k) {
-        const int64_t i = i0 + k;
-        res[k] = NAN;                                              // volatility.py:174 (out[0])
-        if (i >= n) continue;
-        if (MODE != 2 && i == 0) continue;
-        ew_step<MODE>(V, V2, Sy, Syy, al[k], yl[k]);
-        res[k] = ew_sigma<MODE>(V, V2, Sy, Syy, sigma_floor);
-    }
-    ew_store8(out, i0, n, res);
+    double V, V2, Sy, Syy;
+    ew_enter(ex, state_in, V, V2, Sy, Syy);
+    ew_thread_apply<MODE>(V, V2, Sy, Syy, yl, al, sigma_floor, tile, n, out);
 }
 
 // composition of all tile maps in order (ONE block): the map of the whole series, x -> a*x + b per state
@@ -952,16 +802,15 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         if (g <= 1) break;
     }
     void *scr;
-    // MEASURED (round 2, 1e9 ticks, profiles/r02_ewmst_one_pass_vs_two_pass.txt): the one-pass kernel is correct (same suite)
-    // but SLOWER than the two passes -- ewmst 25.9 vs 16.0 ms, ewms 21.8 vs 9.7 ms.  With the persistent grid every
-    // "generation" of ~1000 tiles publishes its aggregates at the same time, and a tile's look-back then walks back ~sqrt(2 k)
-    // tiles, each step a dependent cross-XCD round trip of ~1.2 us: ~54 us per generation, which is the whole run time
-    // (the frontier of finished prefixes moves at ~19 tiles/us, the two passes need the equivalent of 30).  And the two passes are not
-    // bound by their 40 B/tick anyway: exp, four float64 divisions and a sqrt per tick keep k_ew_apply at 2.3 TB/s.
-    // The two-pass scan therefore stays the default; FMK_EW_ONE_PASS=1 (read per call) selects this kernel.
+    // The one-pass kernel (16 + 8 B/tick instead of 2 x 16 + 8) is correct -- the same suite runs through it -- and SLOWER at every size
+    // measured, every round: 25.9 vs 16.0 ms (round 2, one predecessor per round trip), 9.3 vs 9.7 (round 5, two-level look-back), 9.5 vs
+    // 8.0 ms (round 6: the two passes lost more instructions than it did).  A workgroup's four waves sit out two dependent round trips
+    // between its map phase and its apply phase, and at 112 .. 128 registers only four workgroups share a CU to cover for each other;
+    // k_ew_tile_maps meanwhile runs at the HBM rate (16 GB in 2.5 ms).  profiles/r06_ewmst.txt.  The two passes stay the default;
+    // FMK_EW_ONE_PASS=1 (read per call) selects the one-pass kernel.
     const char *opv = getenv("FMK_EW_ONE_PASS");
     if (!d_map_out && opv && atoi(opv)) {
-        // one pass: persistent grid, two-level look-back over tagged records (the tags are zeroed before every launch)
+        // one pass: two-level look-back over tagged records (the tags are zeroed before every launch)
         const int64_t groups = fmk_ceil_div(tiles, EW_W1), slots = groups * EW_W1;
         const size_t tag_bytes = (size_t)(tiles + 2 * slots) * 8, rec_bytes = (size_t)(tiles + 2 * slots) * 96;
         FMK_TRY(fmk_scratch(ctx, tag_bytes + rec_bytes + 64, &scr));
@@ -970,41 +819,15 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         D.tagA = (unsigned long long *)scr; D.tagR = D.tagA + tiles; D.tagP = D.tagR + slots;
         D.A = D.tagP + slots; D.R = D.A + 12 * tiles; D.P = D.R + 12 * slots;
         D.groups = groups;
-        if (atoi(opv) == 2) {                                       // the persistent-grid form (round 2's schedule)
-            static int per_cu = 0;
-            if (!per_cu) {
-                int nbk = 0;
-                FMK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)k_ew_onepass<MODE>, EW_THREADS, 0));
-                per_cu = nbk > 0 ? nbk : 1;
-            }
-            int64_t grid = (int64_t)ctx->n_cu * per_cu;  // every workgroup resident at once: the look-back cannot starve
-            if (grid > tiles) grid = tiles;
-            k_ew_onepass<MODE><<<(unsigned)grid, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out,
-                                                                              D, tiles, ctx->h_mail + 40);
-        } else if (atoi(opv) == 4)
-            k_ew_onepass_d<MODE, 4><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
-                                                                                    ctx->h_mail + 40);
-        else if (atoi(opv) == 5)
-            k_ew_onepass_d<MODE, 5><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
-                                                                                    ctx->h_mail + 40);
-        else
-            k_ew_onepass_d<MODE, 6><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D,
-                                                                                    ctx->h_mail + 40);
+        k_ew_onepass_d<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D, ctx->h_mail + 40);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }
     FMK_TRY(fmk_scratch(ctx, (size_t)(tiles + work_maps + 2) * sizeof(EwMap), &scr));
     EwMap *tm = (EwMap *)scr;
     EwMap *work = tm + tiles;
-    // FMK_EW_STORE_ALPHA=1 (developer knob, OFF by default): the map pass leaves its alphas in d_out for the apply pass.  Measured at 1e9
-    // ticks (profiles/r04_ewmst.txt): k_ew_apply 6.6 -> 4.7 ms without its exp, k_ew_tile_maps 2.7 -> 4.9 ms with its 8 GB of stores: 9.65
-    // against 9.79 ms end to end -- what exp saves the stores cost.  Same bits either way (the alphas are the same doubles);
-    // d_out must not alias the inputs for that
-    static int store_alpha = -1;
-    if (store_alpha < 0) { const char *v = getenv("FMK_EW_STORE_ALPHA"); store_alpha = v ? atoi(v) : 0; }
-    const int via_out = (MODE != 2 && store_alpha && d_out && !d_map_out && (const void *)d_out != (const void *)d_y &&
-                         (const void *)d_out != (const void *)d_ts) ? 1 : 0;
-    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, tm, via_out ? d_out : nullptr);
+    // (round 4 tried leaving the alphas of the map pass in d_out for the apply pass: what exp saved the 8 GB of stores cost -- profiles/r04_ewmst.txt)
+    k_ew_tile_maps<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, tm);
     FMK_LAUNCH_CHECK(ctx);
     if (d_map_out) {
         k_ew_total<<<1, EW_THREADS, 0, ctx->stream>>>(tm, tiles, d_map_out);
@@ -1012,8 +835,22 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         return FMK_OK;
     }
     FMK_TRY(ew_scan_maps(ctx, tm, tiles, work));
-    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, tm, d_state_in,
-                                                                     d_out, via_out);
+    k_ew_apply<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, tm, d_state_in, d_out);
+    FMK_LAUNCH_CHECK(ctx);
+    return FMK_OK;
+}
+
+// diagnostics (include/fmk_diag.h): the device's exp over an array -- tests compare it with the host's exp() bit for bit
+__global__ void k_diag_exp(const double *__restrict__ x, int64_t n, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fmk_exp_host(x[i]);
+}
+extern "C" int fmk_diag_exp_dev(fmk_ctx *ctx, const double *d_x, int64_t n, double *d_out)
+{
+    if (n <= 0) return FMK_OK;
+    FMK_HIP(ctx, hipSetDevice(ctx->device));
+    k_diag_exp<<<(unsigned)fmk_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_x, n, d_out);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
 }

@@ -60,6 +60,8 @@ int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10);
 /* the last one-pass cfg-4 sizing call (csrc/fmk_fused.h): bars it handed to the footprint class kernels / to k_bar_dir / entries of
  * the tick-order redo list (float32 ties of the dollar columns and mean_spread) */
 int fmk_diag_fused_last(fmk_ctx *ctx, int64_t *n_fp_list, int64_t *n_dir_list, int64_t *n_redo);
+/* the device's exp (csrc/fmk_exp.h: glibc's, restated) of n doubles on the device -- tests compare it with the host's exp() */
+int fmk_diag_exp_dev(fmk_ctx *ctx, const double *d_x, int64_t n, double *d_out);
 /* bars of the last fmk_comp_bar_footprints_fill_median_dev call whose median took the generic selection (bracket miss) */
 int fmk_diag_fp_median_fallbacks(fmk_ctx *ctx, int64_t *count);
 /* ... and into how many LATER segments that walk split the two sides' chains (0: each side walked in one piece); a segment

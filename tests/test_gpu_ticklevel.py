@@ -127,8 +127,8 @@ def test_realized_vol_errors_and_transform(orc):
 
 
 def test_ewmst_one_pass_kernel_matches_two_pass(monkeypatch):
-    """k_ew_onepass (persistent grid, decoupled look-back, one exp per tick; kept behind FMK_EW_ONE_PASS because it measured
-    slower than the two-pass scan): same per-tick operations, so the outputs agree to reassociation noise of the prefix maps;
+    """k_ew_onepass_d (one tile per workgroup, two-level decoupled look-back, one exp per tick; kept behind FMK_EW_ONE_PASS because it
+    measures slower than the two-pass scan, profiles/r06_ewmst.txt): same per-tick operations, so the outputs agree to reassociation noise of the prefix maps;
     the sticky error word stays clear (no workgroup gave up waiting)."""
     from finmlkit_amd import _ffi, engine
     ctx = _ffi.default_context()
@@ -210,3 +210,32 @@ def test_device_logarithm_over_the_whole_double_range(orc):
     want = orc.comp_lagged_returns(ts, px, 1.0, True)
     assert np.isnan(got[0]) and np.isnan(want[0])
     np.testing.assert_array_equal(got, want)
+
+
+def test_device_exp_over_the_whole_double_range():
+    """ewmst's alpha = 1 - exp(-dt / half_life) (volatility.py:178-179) carries the rounding of exp in its leading digits, so the device
+    restates the HOST's exp (csrc/fmk_exp.h: glibc's algorithm with the FMA contractions of libm's FMA build, its table extracted from
+    the host's libm) -- compared here with libm's exp() bit for bit: ewmst's own arguments (the table-free form and its edge), every table
+    entry, results from the subnormals to the overflow threshold, both infinities, NaN.  The CPU suite runs the same source against the
+    host over the whole range (tests/test_host_logic.py); this is the device's turn."""
+    import ctypes as C
+    from finmlkit_amd import _ffi
+    libm = C.CDLL("libm.so.6")
+    libm.exp.restype = C.c_double
+    libm.exp.argtypes = [C.c_double]
+    rng = np.random.default_rng(20260930)
+    gaps = rng.integers(0, 100_000_000_000, 100_000).astype(np.float64)        # 0 .. 100 s in ns
+    gaps[:50_000] = rng.integers(0, 5_000_000, 50_000)
+    x = np.concatenate([
+        -((gaps / 1e9) / rng.choice([0.5, 5.0, 60.0, 3600.0], gaps.size)),
+        rng.uniform(-0.75, 0.75, 50_000), rng.uniform(-760.0, 720.0, 50_000), rng.uniform(-745.2, -708.0, 20_000),
+        rng.integers(0, 2**63, 50_000, dtype=np.int64).view(np.float64), -rng.integers(0, 2**63, 50_000, dtype=np.int64).view(np.float64),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.0**-54, -2.0**-54, 512.0, -512.0, 1024.0, -1024.0,
+                  709.782712893384, 709.7827128933841, -745.1332191019411, -745.1332191019412])])
+    ctx = _ffi.default_context()
+    dx, dout = _ffi.DeviceArray.from_host(ctx, x), _ffi.DeviceArray(ctx, x.size, np.float64)
+    ctx.call("fmk_diag_exp_dev", dx.p, C.c_int64(x.size), dout.p)
+    got = dout.to_host()
+    want = np.array([libm.exp(float(v)) for v in x])
+    same = (got.view(np.int64) == want.view(np.int64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"{(~same).sum()} of {x.size} differ, first at x = {x[~same][0]!r}: {got[~same][0]!r} against {want[~same][0]!r}"

@@ -145,10 +145,12 @@ def test_close_indices_out_of_range_are_refused_before_any_device_work():
             base.comp_bar_footprints(px, am, ci, sd, 0.5, px[:len(ci) - 1], px[:len(ci) - 1], 3.0)
 
 
-def test_device_logarithm_is_the_hosts_logarithm(tmp_path):
-    """The logarithm of tick returns on the device (csrc/fmk_log.h) is an operation-by-operation restatement of glibc's log in libm's FMA
+def test_device_logarithm_and_exp_are_the_hosts(tmp_path):
+    """(exp: csrc/fmk_exp.h restates glibc's exp the same way, for ewmst's alpha = 1 - exp(-dt / half_life), volatility.py:178-179; the
+    same program checks it on 2e6 of ewmst's own arguments, a sweep of [-0.75, 0.75), random bit patterns, results from the subnormals to
+    the overflow threshold and the special values.)  The logarithm of tick returns on the device (csrc/fmk_log.h) is an operation-by-operation restatement of glibc's log in libm's FMA
     build -- BOTH branches: the table-free one around 1 and the 128-entry table (constants extracted from the host's libm by
-    tools/extract_glibc_log_table.py); the header is plain C as well, and tools/logratio_check.c runs THE SAME SOURCE against this
+    tools/extract_glibc_tables.py); the header is plain C as well, and tools/logratio_check.c runs THE SAME SOURCE against this
     host's log() -- the function the oracle calls -- on 2e6 price quotients, a sweep of the table-free interval, quotients of prices up
     to a factor 2^40 apart, random bit patterns over the whole double range (subnormals, negatives, NaNs), the special values and the
     neighbours of every power of two: no difference allowed.  (A host without FMA3 runs libm's generic build, which differs from the FMA
@@ -166,10 +168,11 @@ def test_device_logarithm_is_the_hosts_logarithm(tmp_path):
     r = subprocess.run([exe, "2000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert "whole double range: 0 of" in r.stdout
+    assert "differ from the host's exp" in r.stdout and "exp, whole double range: 0 of" in r.stdout
 
 
-def test_the_log_table_in_the_tree_is_the_hosts(tmp_path):
-    """csrc/fmk_logtab.h is what tools/extract_glibc_log_table.py reads from THIS host's libm.so.6 (the constants of glibc's log have not
+def test_the_log_and_exp_tables_in_the_tree_are_the_hosts(tmp_path):
+    """csrc/fmk_logtab.h and csrc/fmk_exptab.h are what tools/extract_glibc_tables.py reads from THIS host's libm.so.6 (the constants of glibc's log have not
     changed since 2.28; a host whose libm carries other constants would make the device differ from the oracle there)."""
     import os
     import subprocess
@@ -178,9 +181,8 @@ def test_the_log_table_in_the_tree_is_the_hosts(tmp_path):
     libm = "/lib/x86_64-linux-gnu/libm.so.6"
     if not os.path.exists(libm):
         pytest.skip("no libm.so.6 at the usual place")
-    src = open(os.path.join(root, "tools", "extract_glibc_log_table.py")).read().replace(
-        'OUT = os.path.join(', 'OUT = os.environ.get("FMK_LOGTAB_OUT") or os.path.join(')
-    out = str(tmp_path / "fmk_logtab.h")
-    subprocess.check_call([sys.executable, "-c", src, libm], env={**os.environ, "FMK_LOGTAB_OUT": out})
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "extract_glibc_tables.py"), libm],
+                          env={**os.environ, "FMK_TABLES_OUT": str(tmp_path)})
     strip = lambda t: [l for l in t.splitlines() if not l.startswith("//")]
-    assert strip(open(out).read()) == strip(open(os.path.join(root, "finmlkit_amd", "csrc", "fmk_logtab.h")).read())
+    for name in ("fmk_logtab.h", "fmk_exptab.h"):
+        assert strip(open(str(tmp_path / name)).read()) == strip(open(os.path.join(root, "finmlkit_amd", "csrc", name)).read()), name

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the tick-level volatility loops at N ticks (HIP events, outputs preallocated by the library calls)."""
+"""Timing of the tick-level volatility loops at N ticks (HIP events, outputs preallocated by the library calls).
+   python tools/tlbench.py [N] [ew]     ew: only the exponentially weighted ones"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,9 +21,11 @@ def timed(name, fn, reps=3):
 
 
 r = t.lagged_returns(5.0, True)
-timed("lagged_returns 5s log", lambda: t.lagged_returns(5.0, True))
+only_ew = len(sys.argv) > 2 and sys.argv[2] == "ew"
+if not only_ew:
+    timed("lagged_returns 5s log", lambda: t.lagged_returns(5.0, True))
 timed("ewmst 60s", lambda: t.ewmst(r, 60.0))
 timed("ewmst_mean0 60s", lambda: t.ewmst(r, 60.0, mean0=True))
 timed("ewms span 100", lambda: t.ewms(r, 100))
-for w in (20, 64, 100, 256, 500, 1000, 2048, 4096, 100_000):
+for w in () if only_ew else (20, 64, 100, 256, 500, 1000, 2048, 4096, 100_000):
     timed(f"realized_vol window {w}", lambda: t.realized_vol(r, w, True))
