@@ -427,7 +427,7 @@ def spawn_ranks(args):
     same arguments.  -> list of Popen (rank 0 waits for them at the end and turns a failed child into its own rc)."""
     base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
     rdv = os.path.join(base, f"fmk_comm_self_{os.getpid()}_{_proc_start_ticks(os.getpid())}_{os.urandom(4).hex()}")
-    common = {"WORLD_SIZE": str(args.gpus), "FMK_BENCH_RDV": rdv, "FMK_BENCH_SPAWNED": "1"}
+    common = {"WORLD_SIZE": str(args.gpus), "FMK_BENCH_RDV": rdv}
     os.environ.update(common, RANK="0", LOCAL_RANK="0")
     kids = []
     for r in range(1, args.gpus):
@@ -580,14 +580,15 @@ def run(args):
     import ctypes as C
 
     ctx = _ffi.default_context()
-    if world > 1 and not os.environ.get("FMK_BENCH_NO_SELFTEST"):
+    selftest_deadline = float(os.environ.get("FMK_BENCH_SELFTEST_DEADLINE", "10"))      # 0: no selftest
+    if world > 1 and selftest_deadline > 0:
         # first contact (finmlkit_amd/dist.py: selftest): the node as this rank sees it, a 1 KiB ncclSend / ncclRecv to rank + 1 with a
         # 10 s deadline, its content checked -- on record in gpurun_out/bench_rank<r>.log BEFORE anything is timed.  It decides
         # nothing: the communicator of the run is made (and falls back, with rc 3) below as before.
         from finmlkit_amd.dist import selftest
         try:
             selftest(rank, world, rendezvous_path(world) + ".selftest", ctx=ctx, log=sys.stderr,
-                     deadline_s=float(os.environ.get("FMK_BENCH_SELFTEST_DEADLINE", "10")))
+                     deadline_s=selftest_deadline)
         except Exception as e:                                                 # noqa: BLE001 -- a report, never a reason to stop
             print(f"[selftest] rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
     n = args.ticks
@@ -702,8 +703,8 @@ def run(args):
             trades.bar_ohlcv(ci, want_median=want_median, out=state["out"])
         else:
             # clock + close indices + comp_bar_ohlcv incl. the median trade size in ONE library call (fmk_time_bars_ohlcv_dev): the
-            # indexer kernels, then the dominant kernel k_bar_ohlcv_small (the in-kernel edge search k_time_bars_ohlcv exists
-            # behind FMK_OHLCV_FUSE_INDEX=1 and measured slower: profiles/r04_indexer.txt)
+            # indexer kernels, then the dominant kernel k_bar_ohlcv_small (round 4's in-kernel edge search measured slower and is
+            # gone: profiles/r04_indexer.txt)
             trades.time_bars_ohlcv(args.interval, want_median, clock_params=(ne, e0, d),
                                    out_index=(state["clock"], state["idx"]), out=state["out"])
         state["n_bars"] = ne - 1
@@ -768,9 +769,6 @@ def run(args):
     # algorithmic bytes of ONE launch of the dominant kernel: price f64 + amount f32 read once per tick,
     # close_idx read once and 60 (+8 with the median) B written per bar (DESIGN.md "roofline")
     alg_bytes = n * 12 + nb * (68 if want_median else 60) + (nb + 1) * 8
-    fused_index = bool(int(os.environ.get("FMK_OHLCV_FUSE_INDEX", "0"))) and not (use_dist or args.separate_index)
-    if fused_index:
-        alg_bytes += (nb + 1) * 8          # one launch: close_idx is WRITTEN (8 B/bar) and so is the clock (8 B/bar), not read
     achieved = alg_bytes / (avg_k_ms * 1e-3) / 1e9
 
     tc = _traffic_constants()
@@ -801,12 +799,10 @@ def run(args):
                 # ALWAYS present: "none" (one GPU, no exchange), "rccl" (ncclSend/ncclRecv over xGMI) or "host" (staged
                 # through shared memory: asked for with --transport host / FMK_BENCH_ONE_DEVICE, or -- rc 3 -- a fallback)
                 "transport": transport,
-                "launcher": ("self-spawned ranks" if os.environ.get("FMK_BENCH_SPAWNED") else "external launcher") if world > 1 else "none",
+                "launcher": ("external launcher" if os.environ.get("TORCHELASTIC_RUN_ID") or not os.environ.get("FMK_BENCH_RDV") else "self-spawned ranks") if world > 1 else "none",
             },
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_time_bars_ohlcv<f32 amount, in-kernel clock-edge search, exact 17..21-chunk classes, %s>" if fused_index else
-                                    "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>")
-                                   % ("fused median" if want_median else "no median"),
+                         "kernel": "k_bar_ohlcv_small<f32 amount, exact 17..21-chunk classes, %s>" % ("fused median" if want_median else "no median"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # per launch, like `achieved` (a step's launches cover disjoint bar ranges: bytes of the step / launches)
                          "traffic": (tc["read_bytes_per_tick"] * n + tc["write_bytes_per_bar"] * nb) / lps if tc_ok else None,

@@ -101,7 +101,10 @@ class BarBuilderBase(ABC):
 
     def _ohlcv_frame(self, o) -> pd.DataFrame:
         """The frame of base.py:148-169 from the host copies of the eight OHLCV columns."""
-        self._highs, self._lows = o["high"], o["low"]
+        # the frame shares memory with these two (copy=False below; pandas 2 without copy-on-write), and build_footprints / the volume
+        # profile read them later: the kit keeps copies of its own, so an in-place edit of the returned frame changes nothing here --
+        # like the reference's frame, which is an independent copy (base.py:148-169)
+        self._highs, self._lows = o["high"].copy(), o["low"].copy()
         # (the same frame as base.py:148-169 -- columns, dtypes, a DatetimeIndex named "timestamp", its freq for time bars -- built
         #  index first and without the detour through an int64 column + to_datetime + set_index: 0.5 instead of 3 ms for 44 640 bars,
         #  a fifth of what TimeBarKit.build_ohlcv() costs on 39 M host-resident trades beyond the upload itself)

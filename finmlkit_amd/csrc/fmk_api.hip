@@ -445,12 +445,8 @@ int fmk_ctx_aux(fmk_ctx *ctx)
     // must not take that launch's wave slots) -- the capped grids of those kernels do that on their own, and a lowest-priority queue
     // holding a blocked barrier packet makes every small dispatch of the context's queue take ~45 us instead of ~5: the sharded step,
     // which enqueues ~30 of them per step with the next step already queued, went from 2.35 to 2.9..3.2 ms (profiles/r04_sharded_step.txt);
-    // the single-GPU step measures the same either way.  Developer knob: FMK_AUX_PRIORITY=1 = lowest.
-    int plo = 0, phi = 0;
-    FMK_HIP(ctx, hipDeviceGetStreamPriorityRange(&plo, &phi));
-    const char *pv = getenv("FMK_AUX_PRIORITY");
-    if (pv && atoi(pv) != 0) FMK_HIP(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, plo));
-    else FMK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // the single-GPU step measures the same either way.
+    FMK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) FMK_HIP(ctx, hipEventCreateWithFlags(&ctx->aev[i], hipEventDisableTiming));
     ctx->aux = st;
     return FMK_OK;

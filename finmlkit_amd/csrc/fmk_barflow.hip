@@ -15,7 +15,7 @@
 // k_bar_dir: one wave per bar (fmk_comp_bar_directional_dev).  The other waves of the SIMD cover the load latency
 // of a tile; a register-prefetch pipeline across tiles and bars was measured and is not faster (3.13 vs 3.05 ms at
 // 1e9 ticks): the kernel is VALU-bound (~106 VALU instructions per 64 ticks), not latency-bound.
-// The cfg-4 entry points (fmk_bars_fused_size_dev / _fill_dev) live here as well.
+// The cfg-4 entry points (fmk_bars_flow_size_dev / _defer_dev) live here as well.
 // float64 sums are combined in (lane-sequential, then tree) order; bars whose sums land within that reordering's
 // noise of a float32 rounding tie are redone in tick order (k_bar_dir_redo), so the float32 outputs are the
 // reference's bit for bit.
@@ -24,7 +24,8 @@
 #include "fmk_median.h"
 #include "fmk_scan.h"
 
-// developer knob FMK_DIR_FORCE_REDO=1 (tests): every bar of the wave-per-bar / workgroup-per-bar kernels goes on the redo list
+// developer knob FMK_DIR_FORCE_REDO=1 (tests): every bar of the wave-per-bar / workgroup-per-bar kernels goes on the redo list; =2: ... and the
+// list is served by the wave-per-bar walkers (k_bar_dir_redo, which also serve the one-pass path's short bars) instead of the chunk-record kernel
 __device__ int bf_force_redo = 0;
 // diagnostics of the tick-order redo (fmk_diag_dir_redo): (bar, column) pairs redone, 512-term tiles, tiles added term by term
 __device__ unsigned long long bf_redo_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [3 + r]: pairs of row r
@@ -1105,13 +1106,13 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_bar_dir_redo_par(const double
     }
 }
 
-// redo launch: the chunk-record kernel (developer knob FMK_DIR_REDO_ROWS=0: one wave per bar, seven lanes adding term by term)
+// redo launch: the chunk-record kernel (FMK_DIR_FORCE_REDO=2: one wave per bar, seven lanes adding term by term)
 template <bool AF64>
 static void bf_redo_launch(fmk_ctx *ctx, unsigned rblocks, const double *d_price, const void *d_amount, const int8_t *d_side,
                            const int64_t *d_close_idx, int64_t n, const FlowDirOut &o, const unsigned long long *redo)
 {
-    const char *rv = getenv("FMK_DIR_REDO_ROWS");
-    if (!rv || atoi(rv))
+    const char *rv = getenv("FMK_DIR_FORCE_REDO");
+    if (!rv || atoi(rv) != 2)
         k_bar_dir_redo_par<AF64><<<(unsigned)(ctx->n_cu * 2), 64 * RS_WAVES, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
     else
         k_bar_dir_redo<AF64><<<rblocks, 256, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, n, o, redo);
@@ -1926,9 +1927,8 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     FMK_TRY(fmk_scratch(ctx, (size_t)(nb + 32) * 16, (void **)&redo));
     FMK_HIP(ctx, hipMemsetAsync(redo, 0, 8, ctx->stream));
     const unsigned rblocks = (unsigned)(blocks < 4096 ? blocks : 4096);
-    // bars of more than BFW_MIN ticks: a workgroup per bar, from a list (developer knob FMK_DIR_WIDE=0: one wave per bar as before)
-    const char *wv = getenv("FMK_DIR_WIDE");
-    const bool wide_on = !wv || atoi(wv);
+    // bars of more than BFW_MIN ticks: a workgroup per bar, from a list
+    const bool wide_on = true;
     const int64_t skip_above = wide_on ? BFW_MIN : INT64_MAX;
     auto wide = [&]() -> int {
         if (!wide_on) return FMK_OK;
@@ -1980,8 +1980,7 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
         FMK_TRY(wide());
         bf_redo_launch<true>(ctx, rblocks, d_price, d_amount, d_side, d_close_idx, n, o, redo);
     } else {
-        static int dwpb = -1;                // developer knob: FMK_DIR_WPB=1 -> one-wave workgroups (see fp_launch, fmk_footprint.hip)
-        if (dwpb < 0) { const char *v = getenv("FMK_DIR_WPB"); dwpb = v ? atoi(v) : 4; }
+        const int dwpb = 4;                // one-wave workgroups (see fp_launch, fmk_footprint.hip)
         if (dwpb == 1)
             k_bar_dir<false, 1><<<(unsigned)(blocks * 4), 64, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                               (unsigned long long *)d_n_zero_div, redo, nullptr, skip_above);
@@ -1994,18 +1993,6 @@ extern "C" int fmk_comp_bar_directional_dev(fmk_ctx *ctx, const double *d_price,
     }
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
-}
-
-extern "C" int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
-                                       int64_t n, const int64_t *d_close_idx, int64_t n_idx, double price_tick_size,
-                                       double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
-                                       double *d_vwap, int64_t *d_trades, double *d_median, int64_t *d_level_offsets,
-                                       int64_t *total_levels, int64_t *max_levels)
-{
-    FMK_TRY(fmk_comp_bar_ohlcv_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_open, d_high, d_low,
-                                   d_close, d_volume, d_vwap, d_trades, d_median));
-    return fmk_comp_bar_footprints_size_dev(ctx, d_low, d_high, n_idx - 1, price_tick_size, d_level_offsets,
-                                            total_levels, max_levels);
 }
 
 // cfg 4 in two passes over the ticks (26 B/tick): this call = OHLCV (+ median) + order-flow features from ONE read, then the
@@ -2058,8 +2045,6 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
     if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
     if (n <= 0 || !d_side || !d_dir) return fmk_set_error(ctx, FMK_E_ARG, "bars_flow: bad arguments");
     if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
-    static int separate = -1;              // developer knob: FMK_FLOW_SEPARATE=1 keeps the OHLCV kernel apart (A/B timing)
-    if (separate < 0) { const char *v = getenv("FMK_FLOW_SEPARATE"); separate = v ? atoi(v) : 0; }
     // short bars: the fused kernel is a wave-per-bar schedule; comp_bar_ohlcv and the order-flow features each have a
     // several-bars-per-wave schedule of their own (k_bar_ohlcv_lanes, k_bar_dir_lanes)
     const bool short_bars = n / (n_idx - 1) < 600;
@@ -2072,19 +2057,18 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
     {
         int fused_mode = 0;
         FMK_TRY(bars_flow_fused_ok(ctx, d_amount, amount_is_f64, n, d_close_idx, n_idx - 1, &fused_mode));
-        if (fused_mode && !separate)
+        if (fused_mode)
             return bars_flow_fused(ctx, d_price, (const float *)d_amount, n, d_close_idx, n_idx, d_side, price_tick_size, d_open, d_high,
                                    d_low, d_close, d_volume, d_vwap, d_trades, d_median, d_dir, d_n_zero_div, d_level_offsets,
                                    total_levels, max_levels, fused_mode == 1);
         fmk_fused_release(ctx);                                          // (a stale state of an earlier call)
     }
-    if (amount_is_f64 || separate || short_bars || long_bars) {
+    if (amount_is_f64 || short_bars || long_bars) {
         // Long bars (hourly, daily), float32 sizes: comp_bar_ohlcv and the order-flow features share nothing but the input columns -- the
         // first runs on the context's auxiliary stream beside the second (cfg 4 at hourly / daily bars 12.1 / 16.0 -> 11.0 / 13.9 ms per
         // 1e9 ticks; streams of short bars gain nothing and keep the plain order).  While both streams carry launches of this call no
-        // freed block goes back to the allocator's free list (fmk_pool_defer).  FMK_FLOW_SIDE_OHLCV=0: one after the other.
-        const char *xv = getenv("FMK_FLOW_SIDE_OHLCV");
-        if (long_bars && !amount_is_f64 && !separate && !(xv && atoi(xv) == 0)) {
+        // freed block goes back to the allocator's free list (fmk_pool_defer).
+        if (long_bars && !amount_is_f64) {
             FMK_TRY(fmk_ctx_aux(ctx));
             FMK_HIP(ctx, hipEventRecord(ctx->aev[0], ctx->stream));
             FMK_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->aev[0], 0));
@@ -2147,16 +2131,13 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         // Sorted bars with the median (round 4, late): the medians and the open .. trades of the bars beyond 1 344 ticks come from comp_bar_ohlcv's
         // size classes -- kernels that share nothing with the order-flow kernels but the input columns.  They run on the context's auxiliary
         // stream BESIDE the lane kernel, the long-bar order flow and the redo (the lane kernel then leaves open .. trades of those bars alone:
-        // two writers of one value in two association orders would race); the footprint sizing waits for both.  FMK_FLOW_SIDE_OHLCV=0: one
-        // after the other on the context's stream, as before.
-        static int side_knob = -1;
-        if (side_knob < 0) { const char *v = getenv("FMK_FLOW_SIDE_OHLCV"); side_knob = v ? atoi(v) : 1; }
-        const bool side_ohlcv = sort_mode && d_median && side_knob != 0;
+        // two writers of one value in two association orders would race); the footprint sizing waits for both.
+        const bool side_ohlcv = sort_mode && d_median;
         DlOhlcOut oo{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, any_long};
         // (bars of about equal length -- no sort: the lane kernel writes open .. trades of every bar it serves, and only the MEDIANS, an
         //  amounts-only pass, run beside it)
         const char *dv0 = getenv("FMK_FLOW_MEDIAN_DEFER");
-        const bool side_median = !sort_mode && d_median && side_knob != 0 && !(median_deferred && dv0 && atoi(dv0));
+        const bool side_median = !sort_mode && d_median && !(median_deferred && dv0 && atoi(dv0));
         if (side_ohlcv || side_median) {
             if (side_ohlcv) oo.ohlc_max = 1344;                                  // 64 * FMK_SMALL_NCH: the reach of k_bar_median_small's class
             FMK_TRY(fmk_ctx_aux(ctx));
@@ -2188,8 +2169,7 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
         }
         int64_t blocks = fmk_ceil_div(nb, 4);
         if (blocks > 2048) blocks = 2048;
-        static int dwpb = -1;
-        if (dwpb < 0) { const char *v = getenv("FMK_DIR_WPB"); dwpb = v ? atoi(v) : 4; }
+        const int dwpb = 4;
         if (dwpb == 1)
             k_bar_dir<false, 1><<<(unsigned)(blocks * 4), 64, 0, ctx->stream>>>(d_price, d_amount, d_side, d_close_idx, nb, n, o,
                                                                               (unsigned long long *)d_n_zero_div, redo, long_list);
@@ -2280,32 +2260,9 @@ static int bars_flow_size(fmk_ctx *ctx, const double *d_price, const void *d_amo
                                             max_levels);
 }
 
-extern "C" int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
-                                       int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
-                                       const fmk_directional_out *d_dir, int64_t *d_n_zero_div, double price_tick_size,
-                                       const double *d_bar_lows, double imbalance_factor,
-                                       const int64_t *d_level_offsets, int64_t max_levels,
-                                       const fmk_footprint_out *d_fp, int64_t *d_n_bad_level)
-{
-    if (n_idx < 2) return fmk_set_error(ctx, FMK_E_ARG, "Bar close indices must contain at least two elements.");
-    if (n <= 0 || !d_side || !d_dir || !d_fp) return fmk_set_error(ctx, FMK_E_ARG, "bars_fused: bad arguments");
-    if (!(price_tick_size > 0)) return fmk_set_error(ctx, FMK_E_ARG, "price_tick_size must be > 0");
-    if (max_levels > FP_MAX_LEVELS_GLOBAL)
-        return fmk_set_error(ctx, FMK_E_CAPACITY,
-                             "comp_bar_footprints: a bar spans %lld price levels; this build supports <= %d per bar",
-                             (long long)max_levels, FP_MAX_LEVELS_GLOBAL);
-    // Two kernels back to back.  In-kernel fusion was built and measured twice (one wave doing both halves on a
-    // shared LDS tile: 11.2 ms; two waves per bar, one per half, on double-buffered tiles: 10.3 ms at 1e9 ticks)
-    // against 3.0 + 3.7 ms for the two kernels below: both halves are VALU-bound (~106 and ~161 VALU instructions
-    // per 64 ticks), not HBM-bound, so sharing the 13 B/tick read buys nothing while the merged register / LDS
-    // footprint halves the occupancy.  DESIGN.md section 3 has the counters.
-    FMK_TRY(fmk_comp_bar_directional_dev(ctx, d_price, d_amount, amount_is_f64, n, d_close_idx, n_idx, d_side, d_dir,
-                                         d_n_zero_div));
-    return fmk_footprints_fill_classes(ctx, d_price, d_amount, amount_is_f64, d_close_idx, n_idx - 1, d_side,
-                                       price_tick_size, d_bar_lows, imbalance_factor, d_level_offsets, 0,
-                                       max_levels, d_fp, d_n_bad_level, n);
-}
-
+// (In-kernel fusion of the order-flow and footprint halves was built and measured twice in round 1 -- one wave doing both halves on a
+// shared LDS tile: 11.2 ms; two waves per bar, one per half, on double-buffered tiles: 10.3 ms at 1e9 ticks -- against 3.0 + 3.7 ms
+// for the two kernels: both halves were VALU-bound, not HBM-bound.  Round 6's one-pass kernel, fmk_fused.h, is the form that pays.)
 // diagnostics since the last call: {(bar, column) pairs redone in tick order, 512-term tiles walked, tiles added term by term,
 // pairs of row 0 .. 6 (buy / sell volume, buy / sell dollars, spread, signed volume, signed dollars)}
 extern "C" int fmk_diag_dir_redo(fmk_ctx *ctx, int64_t *out10)

@@ -534,18 +534,10 @@ static int cs1_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, con
     ctx->h_mail[5] = 0;
     FMK_HIP(ctx, hipMemsetAsync(fix, 0, fix_bytes, ctx->stream));
     {
-        const char *v = getenv("FMK_CS1_VARIANT");                        // developer timing only (fmk_cusum_onepass.h)
-        const int variant = v ? atoi(v) : 0;
         const unsigned g = (unsigned)fmk_ceil_div(chunks, (int64_t)CS1_TK);
         unsigned long long *nf = check_nan ? d_nan : nullptr;
-        if (variant == 1)
-            k_cs1_pass<1><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
-        else if (variant == 2)
-            k_cs1_pass<2><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
-        else
-            k_cs1_pass<0><<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
+        k_cs1_pass<<<g, 256, 0, ctx->stream>>>(d_ts, d_price, d_sigma, n, first, m, chunks, sigma_floor, sigma_mult, E, S0, C0, staged, nf);
         FMK_LAUNCH_CHECK(ctx);
-        if (variant == 1 || variant == 2) { FMK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return FMK_OK; }   // not a result
     }
     FMK_HIP(ctx, hipMemcpyAsync(S, S0, (size_t)chunks * sizeof(CsState), hipMemcpyDeviceToDevice, ctx->stream));
     FMK_HIP(ctx, hipMemcpyAsync(last_in, E, (size_t)chunks * sizeof(CsState), hipMemcpyDeviceToDevice, ctx->stream));   // every record was made from E

@@ -735,9 +735,18 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     // it (k_cc_summary reports one) ends the tier with *nan_seen = 1
     *done = 0;
     if (nan_seen) *nan_seen = 0;
-    // developer knobs, read per call: FMK_CUSUM_CHAIN = 0 (never) / 1 (default) / 2 (no budget of opened chunks)
+    // developer knobs, read per call: FMK_CUSUM_CHAIN = 0 (never) / 1 (default) / 2 (no budget of opened chunks), optionally followed by
+    // ":joint=1" (the one-workgroup joint walk only), ":segments=K" (segments of the walk after the sample, k_cc_sync; 1 = one walk per
+    // side), ":sample=N" (walk N leading chunks in a launch of their own first) -- the shapes tests/test_gpu_cusum.py forces
     const char *v = getenv("FMK_CUSUM_CHAIN");
     const int mode = v ? atoi(v) : 1;
+    auto chain_opt = [&](const char *key, long long dflt) -> long long {
+        const char *e = getenv("FMK_CUSUM_CHAIN");
+        const char *q = e ? strstr(e, key) : nullptr;
+        return q ? atoll(q + strlen(key)) : dflt;
+    };
+    const bool force_joint = chain_opt(":joint=", 0) != 0;
+    const long long segments_opt = chain_opt(":segments=", 512), sample_opt = chain_opt(":sample=", 0);
     v = getenv("FMK_CUSUM_CHAIN_MIN_CHUNKS");
     const int64_t min_chunks = v ? atoll(v) : 4096;
     v = getenv("FMK_CUSUM_MARGIN_SCALE");
@@ -745,17 +754,14 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     if (!(margin_scale > 0.0)) margin_scale = 1.0;
     g_cc_last[0] = 0; g_cc_last[1] = 0; g_cc_last[2] = -1; g_cc_last[3] = 0;
     if (mode == 0 || chunks < min_chunks || chunks < 2) return FMK_OK;
-    v = getenv("FMK_CUSUM_CHAIN_JOINT");
-    const bool force_joint = v && atoi(v);                           // developer knob: the one-workgroup joint walk only
     void *scr;
     const size_t sum_bytes = (size_t)chunks * 8 * sizeof(double);
     // per-side close lists: a side that fills its list ends the tier like an exhausted budget
     const int64_t list_cap = m < ((int64_t)1 << 22) ? m : ((int64_t)1 << 22);
     const size_t list_bytes = (size_t)list_cap * 8;
     const size_t sub_bytes = sum_bytes * (CC_CHUNK / CC_SUB);
-    // segments of the walk after the sample (k_cc_sync): developer knob FMK_CUSUM_CHAIN_SEGMENTS, 1 = one walk per side
-    v = getenv("FMK_CUSUM_CHAIN_SEGMENTS");
-    int K = v ? atoi(v) : 512;
+    // segments of the walk after the sample (k_cc_sync); 1 = one walk per side
+    int K = (int)segments_opt;
     if (K > 1024) K = 1024;
     if (K < 1 || force_joint) K = 1;
     const int n_states = 2 * K + 1, JOINT = 2 * K;                    // [pos, neg, later segments of pos, of neg, joint]
@@ -778,8 +784,7 @@ int fmk_cusum_chain_tier(fmk_ctx *ctx, const int64_t *d_ts, const double *d_pric
     // leading 2048 chunks (k_cc_rate: no walk, one small launch); the visit budgets below are the safety net for tapes whose
     // beginning is not representative.
     const double max_rate = 3.0, max_certain = 1.3;
-    v = getenv("FMK_CUSUM_CHAIN_SAMPLE");                              // developer knob (tests): walk this many leading chunks
-    const int64_t sample_want = v && atoll(v) > 0 ? atoll(v) : 0;      // in a launch of their own first (the walk resumes)
+    const int64_t sample_want = sample_opt > 0 ? sample_opt : 0;       // (tests) walk this many leading chunks in a launch of their own first
     const int64_t sample = chunks < sample_want ? chunks : sample_want;
     const int64_t lead = chunks < 2048 ? chunks : 2048;
     const int bad_mask = nan_seen ? 3 : 1;

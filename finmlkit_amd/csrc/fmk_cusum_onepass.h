@@ -53,9 +53,6 @@ __device__ __forceinline__ void cs1_inputs(const int64_t *__restrict__ ts, const
     }
 }
 
-// VARIANT (developer timing, FMK_CS1_VARIANT): 0 the kernel; 1 without the walk; 2 with a subtraction for the logarithm -- 1 and 2
-// produce nothing usable, the caller falls back
-template <int VARIANT>
 __global__ __launch_bounds__(256) void k_cs1_pass(const int64_t *__restrict__ ts, const double *__restrict__ price,
                                                   const double *__restrict__ sigma, int64_t n, int64_t first, int64_t m,
                                                   int64_t chunks, double sigma_floor, double sigma_mult,
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(256) void k_cs1_pass(const int64_t *__restrict__ ts
             double r = 0.0, lam = NAN;                                   // outside the stream: a tick that changes nothing
             if ((okm >> rr) & 1u) {                                      // the expressions of k_cusum_prep, operation for operation
                 const int64_t i = first + 1 + (k0 + row) * CS1_L + j0 + col;
-                r = VARIANT == 2 ? p[rr] - pm : fmk_log_ratio(p[rr], pm);
+                r = fmk_log_ratio(p[rr], pm);
                 const bool block = i + 1 < n && tsi[rr] == tsn;
                 nan_sigma |= sg[rr] != sg[rr];
                 if (!block) {
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(256) void k_cs1_pass(const int64_t *__restrict__ ts
         }
         if (CS1_PREFETCH) fetch(j0 + CS1_TJ);                            // the next tile's loads fly while this one is walked
         __syncthreads();
-        if (VARIANT != 1 && walker && kw < chunks) {
+        if (walker && kw < chunks) {
             if (j0 == 0) { E[kw].sp = sp; E[kw].sn = sn; }
             // The loop of k_cusum_chunks (logic.py:199-219) as selects, 64 ticks in ONE basic block: the closes go into a bit mask and
             // are stored after the tile.  (With the store inside the loop every tick was its own block: LDS reads, then the chain,

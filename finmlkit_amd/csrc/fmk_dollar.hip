@@ -557,9 +557,7 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
     memcpy(&whale_thr, &ctx->h_mail[3], 8);
     const double extra = whale_thr * whale_thr;
     c.extra = extra;
-    static int force_minpass = -1;       // developer knob: FMK_DL_MIN_PASS=1 keeps the prefix-min pass for every input
-    if (force_minpass < 0) { const char *v = getenv("FMK_DL_MIN_PASS"); force_minpass = v ? atoi(v) : 0; }
-    const int simple = (c.dmax < thr && !force_minpass) ? 1 : 0;
+    const int simple = c.dmax < thr ? 1 : 0;
     if (!simple) {
         k_dl_tile_min<AF64><<<(unsigned)tiles, DL_THREADS, 0, ctx->stream>>>(p, a, n, thr, tsum, segb, tmin);
         FMK_LAUNCH_CHECK(ctx);
@@ -630,11 +628,9 @@ static int dl_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doubl
 template <bool AF64>
 static int dl1_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, double thr, DlCache &c)
 {
-    static int enabled = -1;             // developer knob: FMK_DL_ONEPASS=0 -> the reduce-then-scan kernels for every input
-    if (enabled < 0) { const char *v = getenv("FMK_DL_ONEPASS"); enabled = v ? atoi(v) : 1; }
     int ex;
     (void)frexp(thr, &ex);               // thr = m * 2^ex, m in [0.5, 1): ulp(thr) = 2^(ex - 53)
-    if (!enabled || !(thr > 0.0) || !isfinite(thr) || ex < -900 || ex > 900 || n < 2) return 1;
+    if (!(thr > 0.0) || !isfinite(thr) || ex < -900 || ex > 900 || n < 2) return 1;
     Dl1Params P;
     P.scale = ldexp(1.0, DL1_F + 53 - ex);
     P.T = (uint64_t)(thr * P.scale);     // exact: thr / ulp(thr) is an integer in [2^52, 2^53)
@@ -644,11 +640,8 @@ static int dl1_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doub
     P.tol_b = 2.31e-16 * (double)P.T;    // the reference's drift per add (2.3e-16 thr, dl_run) + the truncation of the fixed point (2^-60 thr)
     // tile geometry: 512 threads x 16 ticks (8 192-tick tiles).  A tile waits ~5 us for its look-back with its ticks in registers and
     // loads nothing meanwhile, and a poll costs what a cache line of ticks costs, so few large tiles win: 256 x 8 / 256 x 16 / 512 x 8
-    // / 512 x 16 / 1024 x 16 ran 3.9 / 3.1 / 3.3 / 2.7 / 3.2 ms per 1e9 ticks (profiles/r05_cfg3.txt).  Developer knob
-    // FMK_DL1_GEOMETRY=1: 256 x 8 (small tiles: more of them in a short stream, used by the tests to cross many tile borders)
-    static int geometry = -1;
-    if (geometry < 0) { const char *v = getenv("FMK_DL1_GEOMETRY"); geometry = v ? atoi(v) : 0; }
-    const int threads = geometry == 1 ? 256 : 512, items = geometry == 1 ? 8 : 16;
+    // / 512 x 16 / 1024 x 16 ran 3.9 / 3.1 / 3.3 / 2.7 / 3.2 ms per 1e9 ticks (profiles/r05_cfg3.txt).
+    const int threads = 512, items = 16;
     const int64_t tiles = fmk_ceil_div(n, (int64_t)threads * items);
     const int64_t groups = (tiles + DL1_W1 - 1) / DL1_W1;
     const size_t desc_bytes = (size_t)tiles * 16 + (size_t)groups * DL1_W1 * 16;      // A[tiles][2], B[W1][groups][2] (fmk_dollar_onepass.h)
@@ -681,12 +674,11 @@ static int dl1_run(fmk_ctx *ctx, const double *p, const void *a, int64_t n, doub
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         FMK_HIP(ctx, hipMemsetAsync(desc, 0, desc_bytes, ctx->stream));
+        unsigned long long *d_ticket = (unsigned long long *)((char *)desc + desc_bytes + (size_t)tiles * 32);
+        FMK_HIP(ctx, hipMemsetAsync(d_ticket, 0, 8, ctx->stream));
         FMK_HIP(ctx, hipMemsetAsync(d_last, 0, 24, ctx->stream));
         unsigned long long *dB = desc + 2 * tiles;
-        if (geometry == 1)
-            k_dl1<AF64, 8, 256><<<(unsigned)tiles, 256, 0, ctx->stream>>>(p, a, n, P, desc, dB, c.dbuf, c.carry, c.cap, d_last, d_frag, d_flags);
-        else
-            k_dl1<AF64, 16, 512><<<(unsigned)tiles, 512, 0, ctx->stream>>>(p, a, n, P, desc, dB, c.dbuf, c.carry, c.cap, d_last, d_frag, d_flags);
+        k_dl1<AF64, 16, 512><<<(unsigned)tiles, 512, 0, ctx->stream>>>(p, a, n, P, desc, dB, c.dbuf, c.carry, c.cap, d_last, d_frag, d_flags, d_ticket);
         FMK_LAUNCH_CHECK(ctx);
         FMK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, d_last, 24, hipMemcpyDeviceToHost, ctx->stream));
         FMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -789,9 +781,7 @@ extern "C" int fmk_dollar_bar_indexer_dev(fmk_ctx *ctx, const double *d_price, c
         // are a function of the bar's own ticks and of the carried state modulo 4 ulp(thr)) and replays the few fragile bars
         // from it; streams it does not cover (an increment >= thr) take the serial walk (fmk_threshold.hip)
         int status = 1;
-        static int whale_tier = -1;          // developer knob: FMK_DL_WHALE_TIER=0 -> streams with an increment >= thr take the serial walk
-        if (whale_tier < 0) { const char *v = getenv("FMK_DL_WHALE_TIER"); whale_tier = v ? atoi(v) : 1; }
-        if ((c.dmax < threshold || whale_tier) && !hit) {
+        if (!hit) {
             int rc = fmk_dollar_exact(ctx, d_price, d_amount, amount_is_f64, n, threshold, c.dbuf, c.carry, &c.count, &status,
                                       c.dmax >= threshold ? c.area : 0.0, c.dmax >= threshold ? 1 : 0);
             if (rc) { c.ctx = nullptr; return rc; }

@@ -832,12 +832,7 @@ int fmk_dollar_exact(fmk_ctx *ctx, const double *d_price, const void *d_amount, 
         *status = 0;
     }
 done:
-    {
-        const char *vv = getenv("FMK_DL_VERBOSE");
-        if (vv && atoi(vv))
-            fprintf(stderr, "[fmk_dollar_exact] n=%lld bars=%lld flagged=%lld rounds=%d status=%d rc=%d\n", (long long)n,
-                    (long long)nb, (long long)n_flag, rounds + 1, *status, rc);
-    }
+    (void)n_flag;
     if (p_out) fmk_free(ctx, p_out);
     if (p_ev) fmk_free(ctx, p_ev);
     if (p_off) fmk_free(ctx, p_off);

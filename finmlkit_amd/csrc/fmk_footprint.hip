@@ -435,8 +435,6 @@ static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
 {
     static int known = -1;
     if (known >= 0) return known;
-    const char *v = getenv("FMK_FP_BALLOT_GROUPS");                   // developer knob: 1 = use the ballot-loop sweep
-    if (v && atoi(v)) { known = 0; return known; }
     int *d = (int *)(ctx->d_mail + 30);
     if (hipMemsetAsync(d, 0, 4, ctx->stream) != hipSuccess) return 0;
     k_fp_lds_order_probe<<<64, 64, 0, ctx->stream>>>(d);
@@ -1181,19 +1179,13 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
                      hipStream_t st = nullptr /* the context's stream when null */)
 {
     if (!st) st = ctx->stream;
-    static int force_ordered = -1;    // developer knob: FMK_FP_ORDERED=1 disables the exact (integer) path
-    if (force_ordered < 0) { const char *v = getenv("FMK_FP_ORDERED"); force_ordered = v ? atoi(v) : 0; }
+    const int force_ordered = 0;    // disables the exact (integer) path
     const bool med = d_median != nullptr && !AF64;
     const bool fast = !med && lmax >= 512 && lmax <= FP_MAX_LEVELS_LDS;          // the 16 B / level layout (k_bar_footprints<.., FAST>)
     // waves per workgroup.  A workgroup keeps its wave slots until its SLOWEST wave has finished its bars; on bars of unequal length
     // (lognormal one-minute bars) that idles the slots of the others, so streams of many bars take one-wave workgroups: the
-    // dispatcher then balances per wave (FMK_FP_WPB overrides: developer knob)
+    // dispatcher then balances per wave
     const int wpb_in = wpb;
-    {
-        static int wpb_env = -1;
-        if (wpb_env < 0) { const char *v = getenv("FMK_FP_WPB"); wpb_env = v ? atoi(v) : 0; }
-        if (wpb_env > 0 && wpb_env <= wpb) wpb = wpb_env;
-    }
     size_t smem = fast ? (size_t)wpb * ((size_t)lmax * 16 + FMK_PW_PAR_STK * 4)
                        : (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
     int64_t blocks = fmk_ceil_div(nb, wpb);
@@ -1233,8 +1225,9 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
                     occ[slot] = nblk;
                 }
                 int64_t resident = (int64_t)ctx->n_cu * occ[slot];
-                if (const char *v = getenv("FMK_FP_MED_BLOCKS")) {      // developer knob (tests: few waves, many bars per wave)
-                    if (atoi(v) > 0) resident = atoi(v);
+                if (const char *v = getenv("FMK_FLOW_MEDIAN_DEFER")) {  // "1:blocks=N" (tests: few waves, many bars per wave)
+                    const char *b = strstr(v, "blocks=");
+                    if (b && atoi(b + 7) > 0) resident = atoi(b + 7);
                 }
                 if (blocks > resident) blocks = resident;
                 k_bar_footprints<false, false, true><<<(unsigned)blocks, wpb * 64, smem, st>>>(
@@ -1385,15 +1378,13 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
         if (e != hipSuccess) { if (rest) (void)fmk_free(ctx, rest); FMK_HIP(ctx, e); }
     }
     // bars of more than FPW_MIN ticks (and at most FP_MAX_LEVELS levels): a workgroup per bar, from a list; the wave-per-bar classes
-    // below skip them (developer knob FMK_FP_WIDE=0: one wave per bar as before)
+    // below skip them
     int64_t skip_above = INT64_MAX;
     int skip_lmax = 0;
     float *wide_sorted = nullptr;
     unsigned long long *wide_defer = nullptr;
     {
-        const char *wv = getenv("FMK_FP_WIDE");
-        if ((!wv || atoi(wv)) && lmin_start == 0 && n_ticks > FPW_MIN) {
-            const char *fo = getenv("FMK_FP_ORDERED");
+        if (lmin_start == 0 && n_ticks > FPW_MIN) {
             int64_t *wl = nullptr;
             rc = fmk_long_bar_list(ctx, d_close_idx, nb, n_ticks, FPW_MIN, nullptr, &wl);
             // scratch of the tick-ordered path: the bars' amounts sorted by (key, tick), in the slots of the bar's own tick range;
@@ -1422,11 +1413,11 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
                 if (amount_is_f64)
                     k_bar_footprints_wide<true><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
                         d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
-                        fo ? atoi(fo) : 0, lean, wl_max, wide_sorted, wide_defer, nseg);
+                        0, lean, wl_max, wide_sorted, wide_defer, nseg);
                 else
                     k_bar_footprints_wide<false><<<grid, 64 * FPW_WAVES, smem, ctx->stream>>>(
                         d_price, d_amount, d_side, d_close_idx, wl, price_tick_size, d_bar_lows, imb_mult, d_level_offsets, o, bad,
-                        fo ? atoi(fo) : 0, lean, wl_max, wide_sorted, wide_defer, nseg);
+                        0, lean, wl_max, wide_sorted, wide_defer, nseg);
                 const hipError_t le = hipGetLastError();
                 (void)fmk_free(ctx, wl);
                 wl = nullptr;
@@ -1445,11 +1436,10 @@ int fmk_footprints_fill_classes(fmk_ctx *ctx, const double *d_price, const void 
     // The classes take disjoint bars, and on a tape whose bars differ in length the first class (<= 128 levels) does nearly all the
     // work while each wider one walks a few long bars with little parallelism (lognormal one-minute bars: 5.4 ms + six launches of
     // 0.15 .. 0.36 ms one after the other).  So the wider LDS classes run BESIDE the first one, on the context's auxiliary stream
-    // (round 4; developer knob FMK_FP_SIDE_STREAM=0: one after the other as before).
+    // (round 4).
     hipStream_t side = nullptr;
     {
-        const char *sv = getenv("FMK_FP_SIDE_STREAM");
-        if ((!sv || atoi(sv)) && max_levels > LMAX[0] && lmin_start == 0 && fmk_ctx_aux(ctx) == FMK_OK) {
+        if (max_levels > LMAX[0] && lmin_start == 0 && fmk_ctx_aux(ctx) == FMK_OK) {
             side = ctx->aux;
             hipError_t e = hipEventRecord(ctx->aev[3], ctx->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(side, ctx->aev[3], 0);

@@ -210,60 +210,11 @@ int fmk_time_bar_index_stage(fmk_ctx *ctx, hipStream_t st, const int64_t *d_ts, 
     if (k1 <= k0) return FMK_OK;
     int64_t blocks = fmk_ceil_div(k1 - k0, 256);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    static int secant = -1;                  // developer knob: FMK_TIME_INDEX_SECANT=0 -> the bracket-of-48 window search
-    if (secant < 0) { const char *v = getenv("FMK_TIME_INDEX_SECANT"); secant = v ? atoi(v) : 1; }
+    const int secant = 1;                  // the bracket-of-48 window search
     k_time_bar_index_stage<<<(unsigned)blocks, 256, 0, st>>>(d_ts, n, e0, d, ne, coarse, m, k0, k1, d_clock,
                                                                                   d_idx, saw_long, long_min, secant);
     FMK_LAUNCH_CHECK(ctx);
     return FMK_OK;
-}
-
-// Round 4 experiment (off by default, see the knob below): interpolation search straight on the column, no sample table (one launch
-// instead of two, ~10 dependent probes instead of ~15).  Between two known points the position of an edge is guessed by
-// linear interpolation and BOTH ends of a bracket of 2 sqrt(width) + 8 around the guess are probed in one round trip; every probe
-// keeps the bisection invariant ts[lo] <= edge < ts[hi], and a step that fails to halve the bracket is followed by a bisection
-// step -- uneven spacing costs probes, never correctness.  1e9 evenly spaced ticks: 1e9 -> 126 K -> 1.4 K -> 150 -> <= 63 wide in four
-// round trips, then six bisection probes inside 512 bytes.
-__device__ __forceinline__ int64_t tb_interp_last_le(const int64_t *__restrict__ ts, int64_t n, int64_t edge, int64_t t_first,
-                                                     int64_t t_last)
-{
-    if (edge < t_first) return -1;
-    if (edge >= t_last) return n - 1;
-    int64_t lo = 0, hi = n - 1, vlo = t_first, vhi = t_last;       // vlo <= edge < vhi
-    while (hi - lo > 63) {
-        const int64_t w = hi - lo;
-        const double f = (double)(edge - vlo) / (double)(vhi - vlo);
-        const int64_t g = lo + (int64_t)(f * (double)w);
-        const int64_t r = 2 * (int64_t)sqrt((double)w) + 8;
-        int64_t a = g - r, b = g + r;
-        a = a <= lo ? lo + 1 : (a >= hi ? hi - 1 : a);
-        b = b >= hi ? hi - 1 : (b <= lo ? lo + 1 : b);
-        const int64_t va = ts[a], vb = ts[b];                       // independent: one round trip
-        if (va > edge) { hi = a; vhi = va; }
-        else if (vb <= edge) { lo = b; vlo = vb; }
-        else { lo = a; vlo = va; hi = b; vhi = vb; }
-        if (hi - lo > (w >> 1) && hi - lo > 63) {                   // the guess was off: bisect once (worst case stays logarithmic)
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            const int64_t vm = ts[mid];
-            if (vm <= edge) { lo = mid; vlo = vm; } else { hi = mid; vhi = vm; }
-        }
-    }
-    while (hi - lo > 1) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        if (ts[mid] <= edge) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(256) void k_time_bar_index_interp(const int64_t *__restrict__ ts, int64_t n, int64_t e0, int64_t d,
-                                                               int64_t ne, int64_t *__restrict__ clock, int64_t *__restrict__ idx)
-{
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ne) return;
-    const int64_t edge = e0 + k * d;
-    if (clock) clock[k] = edge;
-    const int64_t t_first = ts[0], t_last = ts[n - 1];               // (the same two words for every thread)
-    idx[k] = tb_interp_last_le(ts, n, edge, t_first, t_last);
 }
 
 extern "C" int fmk_time_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, int64_t n, int64_t first_edge,
@@ -272,26 +223,16 @@ extern "C" int fmk_time_bar_indexer_dev(fmk_ctx *ctx, const int64_t *d_ts, int64
     if (n <= 0 || n_edges < 0) return fmk_set_error(ctx, FMK_E_ARG, "time_bar_indexer: empty input");
     if (n_edges == 0) return FMK_OK;
     FMK_HIP(ctx, hipSetDevice(ctx->device));
-    // developer knob FMK_TIME_INDEX_INTERP=1: interpolation search on the column without the sample table.  Fewer dependent probes,
-    // but every one of them a random HBM line (and page): measured SLOWER -- 0.235 vs 0.124 ms for the 833 K edges of 1e9 ticks,
-    // 11.6 vs 2.6 ms for 5e7 one-second edges (profiles/r04_indexer.txt).  The indexer is bound by random line fetches, not by
-    // the length of its probe chain; the sample table keeps the first level in L2.
-    static int interp = -1;
-    if (interp < 0) { const char *v = getenv("FMK_TIME_INDEX_INTERP"); interp = v ? atoi(v) : 0; }
-    if (interp) {
-        k_time_bar_index_interp<<<(unsigned)fmk_ceil_div(n_edges, 256), 256, 0, ctx->stream>>>(d_ts, n, first_edge, delta, n_edges,
-                                                                                              d_clock, d_close_idx);
-        FMK_LAUNCH_CHECK(ctx);
-        return FMK_OK;
-    }
+    // (an interpolation search on the column without the sample table was measured SLOWER -- 0.235 vs 0.124 ms for the 833 K edges of 1e9
+    // ticks, 11.6 vs 2.6 ms for 5e7 one-second edges, profiles/r04_indexer.txt -- the indexer is bound by random line fetches, not by the
+    // length of its probe chain; the sample table keeps the first level in L2.  Removed in round 6.)
     const int64_t m = fmk_ceil_div(n, (int64_t)1 << TB_COARSE_SHIFT);
     void *scr;
     FMK_TRY(fmk_scratch(ctx, (size_t)m * 8, &scr));
     int64_t *coarse = (int64_t *)scr;
     k_time_bar_coarse<<<(unsigned)fmk_ceil_div(m, 256), 256, 0, ctx->stream>>>(d_ts, n, coarse, m);
     FMK_LAUNCH_CHECK(ctx);
-    static int secant = -1;                  // developer knob: FMK_TIME_INDEX_SECANT=0 -> the bracket-of-48 window search
-    if (secant < 0) { const char *v = getenv("FMK_TIME_INDEX_SECANT"); secant = v ? atoi(v) : 1; }
+    const int secant = 1;                  // the bracket-of-48 window search
     k_time_bar_index<<<(unsigned)fmk_ceil_div(n_edges, 256), 256, 0, ctx->stream>>>(d_ts, n, first_edge, delta,
                                                                                    n_edges, coarse, m, d_clock,
                                                                                    d_close_idx, secant);

@@ -331,8 +331,7 @@ static int oh_wide_launch(fmk_ctx *ctx, const double *p, const void *a, const in
     int64_t *list = nullptr;
     FMK_TRY(fmk_long_bar_list(ctx, ci, nb, n, wide_min, go, &list));
     if constexpr (!AF64) {
-        const char *fv = getenv("FMK_OHLCV_WIDE_MED");            // developer knob: 0 = the radix-select median kernels as before
-        if (o.median && median_done && (!fv || atoi(fv))) {
+        if (o.median && median_done) {
             const int64_t cap = n / wide_min + 2;                  // (the list's capacity: fmk_long_bar_list)
             // The scratch is sized from the listed bars: their count and tick span come back in one 24-byte copy (this path is
             // only reached when the stream has bars beyond 8 192 ticks, or in enqueue-only mode).  An empty list ends the call
@@ -603,16 +602,9 @@ __global__ __launch_bounds__(256, (MAXNCH <= 4 ? 8 : MAXNCH <= 10 ? 6 : 4)) void
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 4: the time-bar step in ONE launch -- _time_bar_indexer (logic.py:12-51) inside the OHLCV + median kernel.
-// The separate indexer (fmk_indexers.hip: sample gather + one thread per clock edge, ~15 dependent probes each) is 0.11 ms in
-// front of a 2.2 ms kernel that cannot start before it.  Here every wave finds the two edges of its OWN bar first: lanes 0 and 1
-// run an interpolation search (each step probes both ends of a bracket of 2 sqrt(width) around the interpolated position in one
-// memory round trip and keeps the bisection invariant ts[lo] <= edge < ts[hi]; a step that fails to halve the bracket is followed
-// by a bisection step, so uneven spacing costs time, never correctness), 1e9 evenly spaced ticks -> 126 K -> 1.4 K -> 150 -> <= 63
-// in four round trips, and the last <= 62 candidates of both edges are read by the whole wave in one coalesced load each and
-// counted with a ballot.  The searches of the ~4 000 resident waves overlap the loads of the others; what is left in front of the
-// first loads is one search (~10 us) instead of the whole indexer.  The wave also writes clock[b] / idx[b] (the path's outputs).
-// Same bar code as k_bar_ohlcv_small<.., 21>; long bars raise the same flag for the same leftover passes, which read idx.
+// The time-bar step in one call (fmk_time_bars_ohlcv_dev): what the indexer stages need to know.  (Round 4 also had the clock-edge
+// search INSIDE the OHLCV kernel -- k_time_bars_ohlcv, behind an environment switch -- one launch instead of two and measured
+// slower than the pipelined indexer below: profiles/r04_indexer.txt; removed in round 6.)
 // ---------------------------------------------------------------------------------------------------------------------
 struct TbFuse {
     const int64_t *ts;
@@ -621,95 +613,6 @@ struct TbFuse {
     int64_t *clock, *idx;           // [nb + 1] outputs
 };
 
-// ts[lo] <= edge < ts[hi] with hi - lo <= stop (lo == -1: no tick at or before the edge, hi == n: none after it)
-__device__ __forceinline__ void tb_interp_bracket(const int64_t *__restrict__ ts, int64_t n, int64_t edge, int64_t t_first,
-                                                  int64_t t_last, int64_t stop, int64_t &lo_out, int64_t &hi_out)
-{
-    if (edge < t_first) { lo_out = -1; hi_out = 0; return; }
-    if (edge >= t_last) { lo_out = n - 1; hi_out = n; return; }
-    int64_t lo = 0, hi = n - 1, vlo = t_first, vhi = t_last;       // vlo <= edge < vhi
-    while (hi - lo > stop) {                                        // (stop >= 2: a and b below exist)
-        const int64_t w = hi - lo;
-        const double f = (double)(edge - vlo) / (double)(vhi - vlo);
-        const int64_t g = lo + (int64_t)(f * (double)w);
-        const int64_t r = 2 * (int64_t)sqrt((double)w) + 8;
-        int64_t a = g - r, b = g + r;
-        a = a <= lo ? lo + 1 : (a >= hi ? hi - 1 : a);
-        b = b >= hi ? hi - 1 : (b <= lo ? lo + 1 : b);
-        const int64_t va = ts[a], vb = ts[b];                       // independent: one round trip
-        if (va > edge) { hi = a; vhi = va; }
-        else if (vb <= edge) { lo = b; vlo = vb; }
-        else { lo = a; vlo = va; hi = b; vhi = vb; }
-        if (hi - lo > (w >> 1) && hi - lo > stop) {                 // the guess was off: bisect once (worst case stays logarithmic)
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            const int64_t vm = ts[mid];
-            if (vm <= edge) { lo = mid; vlo = vm; } else { hi = mid; vhi = vm; }
-        }
-    }
-    lo_out = lo; hi_out = hi;
-}
-
-template <bool AF64, bool MEDIAN>
-__global__ __launch_bounds__(256, 4) void k_time_bars_ohlcv(TbFuse tb, const double *__restrict__ price, const void *__restrict__ amount,
-                                                            int64_t nb, int64_t n, int *__restrict__ saw_long, OhlcvOut o)
-{
-    typedef typename MedKey<AF64>::K K;
-    __shared__ K sbuf[4][64];
-    const int lane = fmk_lane();
-    const int wib = fmk_uniform((int)(threadIdx.x >> 6));
-    const int wpb = blockDim.x >> 6;
-    const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
-    const int64_t nwaves = (int64_t)gridDim.x * wpb;
-    K *buf = sbuf[wib];
-    const int64_t *__restrict__ ts = tb.ts;
-    for (int64_t b = wave0; b < nb; b += nwaves) {
-        // ---- the bar's two clock edges: lane 0 the opening edge, lane 1 the closing edge
-        const int64_t edge0 = tb.e0 + b * tb.d, edge1 = edge0 + tb.d;
-        int64_t blo = 0, bhi = 0;
-        if (lane < 2) tb_interp_bracket(ts, n, lane == 0 ? edge0 : edge1, tb.t_first, tb.t_last, 63, blo, bhi);
-        const int64_t lo0 = fmk_readlane(blo, 0), hi0 = fmk_readlane(bhi, 0), lo1 = fmk_readlane(blo, 1), hi1 = fmk_readlane(bhi, 1);
-        const int64_t i0 = lo0 + 1 + lane, i1 = lo1 + 1 + lane;     // the candidates strictly inside the brackets (<= 62 each)
-        const bool in0 = i0 < hi0, in1 = i1 < hi1;
-        const int64_t v0 = in0 ? ts[i0] : INT64_MAX, v1 = in1 ? ts[i1] : INT64_MAX;
-        const int64_t s = lo0 + (int64_t)__popcll(__builtin_amdgcn_ballot_w64(in0 && v0 <= edge0));
-        const int64_t e = lo1 + (int64_t)__popcll(__builtin_amdgcn_ballot_w64(in1 && v1 <= edge1));
-        if (lane == 0) {
-            tb.idx[b] = s;
-            if (tb.clock) tb.clock[b] = edge0;
-            if (b == nb - 1) { tb.idx[nb] = e; if (tb.clock) tb.clock[nb] = edge1; }
-        }
-        const int64_t cnt = e - s;
-        if (cnt > 64 * FMK_SMALL_NCH) {                      // long bar: left to the generic kernels (see k_bar_ohlcv_small)
-            if (lane == 0 && __hip_atomic_load(saw_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(saw_long, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
-        if (cnt <= 0) {
-            if (lane == 0) ohlcv_empty(o, b, price, e, n);
-            continue;
-        }
-        const int64_t start = s + 1;
-        const int nch = (int)((cnt + 63) >> 6);
-        switch (nch) {
-        case 11: small_bar<AF64, 11, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 12: small_bar<AF64, 12, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 13: small_bar<AF64, 13, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 14: small_bar<AF64, 14, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 15: small_bar<AF64, 15, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 16: small_bar<AF64, 16, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 17: small_bar<AF64, 17, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 18: small_bar<AF64, 18, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 19: small_bar<AF64, 19, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 20: small_bar<AF64, 20, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        case 21: small_bar<AF64, 21, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o); break;
-        default:
-            if (nch <= 1) small_bar<AF64, 1, true, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else if (nch <= 4) small_bar<AF64, 4, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else if (nch <= 10) small_bar<AF64, 10, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-            else small_bar<AF64, 16, false, MEDIAN>(price, amount, b, start, e, cnt, lane, buf, o);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The median trade size ALONE for bars of <= 64 * 21 ticks (float32 amounts): k_bar_ohlcv_small's amount loads, keys and
@@ -1586,14 +1489,11 @@ __global__ __launch_bounds__(256) void k_bar_ohlcv_phased(const double *__restri
     }
 }
 
-static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb, bool fused = false)
+static unsigned ohlcv_grid(fmk_ctx *ctx, int64_t nb)
 {
     int64_t blocks = fmk_ceil_div(nb, 4);
-    static int per_cu = -1;                  // developer knob: FMK_OHLCV_BLOCKS_PER_CU (workgroups per CU in the grid)
-    if (per_cu < 0) { const char *v = getenv("FMK_OHLCV_BLOCKS_PER_CU"); per_cu = v ? atoi(v) : 64; }
-    static int per_cu_fused = -1;            // ... FMK_OHLCV_FUSED_BLOCKS_PER_CU for k_time_bars_ohlcv (default: no cap)
-    if (per_cu_fused < 0) { const char *v = getenv("FMK_OHLCV_FUSED_BLOCKS_PER_CU"); per_cu_fused = v ? atoi(v) : (1 << 20); }
-    int64_t cap = (int64_t)ctx->n_cu * (fused ? per_cu_fused : per_cu);   // grid-stride beyond this
+    const int per_cu = 64;                  // workgroups per CU in the grid
+    int64_t cap = (int64_t)ctx->n_cu * per_cu;   // grid-stride beyond this
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
@@ -1605,11 +1505,10 @@ static int ohlcv_leftovers(fmk_ctx *ctx, const double *p, const void *a, const i
                            const OhlcvOut &o, int *saw_long, int64_t long_min, unsigned grid)
 {
     // long bars (if any): the generic kernels exit at once when the flag is clear.  float32 bars of 1 345 .. 8 192 ticks: one pass by
-    // a workgroup each, median included (developer knob FMK_OHLCV_MID=0: the generic kernels + the median kernels as before)
+    // a workgroup each, median included
     int64_t skip_lo = 0, skip_hi = 0;
     if constexpr (!AF64) {
-        const char *mv = getenv("FMK_OHLCV_MID");
-        if (!mv || atoi(mv)) {
+        {
             skip_lo = OHM_MIN;
             skip_hi = OHM_MAX;
             // 1 345 .. 2 048, .. 3 072, .. 4 096, .. 6 144 ticks: a wave per bar with 32 / 48 / 64 / 96 key registers; 6 145 .. 8 192: a workgroup per bar
@@ -1666,24 +1565,18 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
 {
     OhlcvOut o = o_in;
     const unsigned grid = ohlcv_grid(ctx, nb);
-    // tb: the close indices are not there yet (fmk_time_bars_ohlcv_dev) -- the 1-minute schedule finds them inside its kernel
-    // (k_time_bars_ohlcv), every other schedule runs the separate indexer first
-    bool fuse_index = false;
+    // tb: the close indices are not there yet (fmk_time_bars_ohlcv_dev) -- the 1-minute schedule pipelines the indexer with the bar
+    // kernel in two stages, every other schedule runs the separate indexer first
     int64_t pipe_ka = 0;                     // > 0: bars [0, pipe_ka) are the first stage of the pipelined time-bar step
     if (tb) {
-        static int fuse_on = -1;             // developer knob: FMK_OHLCV_FUSE_INDEX=1 -> the edge search inside the OHLCV kernel
-        if (fuse_on < 0) { const char *v = getenv("FMK_OHLCV_FUSE_INDEX"); fuse_on = v ? atoi(v) : 0; }
-        static int mid2 = -1;
-        if (mid2 < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2 = v ? atoi(v) : 600; }
-        fuse_index = fuse_on && variant != 0 && nb >= 64 && n / nb > mid2;      // = the last branch of the schedule choice below
+        const int mid2 = 600;
         // PIPELINED time-bar step (the default for the 1-minute schedule, float32 amounts): the indexer in two stages -- see below
-        static int split = -1;               // developer knob: FMK_TB_PIPE_SPLIT = 1 / share of the bars in the first stage (0: off)
-        if (split < 0) { const char *v = getenv("FMK_TB_PIPE_SPLIT"); split = v ? atoi(v) : 8; }
+        const int split = 8;               // 1 / share of the bars in the first stage (0: off)
         const char *msv = getenv("FMK_TB_PIPE_MIN_STAGE");            // developer knob (tests): bars in the first stage from which the
         const int64_t min_stage = msv ? atoll(msv) : 4096;            // step is pipelined (read on every call)
-        if (!AF64 && !fuse_index && split >= 2 && variant != 0 && n / nb > mid2 && nb / split >= min_stage && min_stage >= 256) {
+        if (!AF64 && split >= 2 && variant != 0 && n / nb > mid2 && nb / split >= min_stage && min_stage >= 256) {
             pipe_ka = (nb / split) & ~(int64_t)255;
-        } else if (!fuse_index)
+        } else
             FMK_TRY(fmk_time_bar_indexer_dev(ctx, tb->ts, n, tb->e0, tb->d, nb + 1, tb->clock, tb->idx));
         ci = tb->idx;
     }
@@ -1717,8 +1610,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
             // the census (is any bar longer than 1 344 ticks?), so the flag reaches the host while the first OHLCV launch is still
             // running: the call decides about the leftover passes and returns without ever waiting for a kernel it launched.
             FMK_TRY(fmk_ctx_aux(ctx));
-            static int idx_bpc = -1;         // developer knob: FMK_TB_PIPE_IDX_BPC = workgroups per CU of the second index stage (0: no cap)
-            if (idx_bpc < 0) { const char *v = getenv("FMK_TB_PIPE_IDX_BPC"); idx_bpc = v ? atoi(v) : 2; }
+            const int idx_bpc = 2;         // workgroups per CU of the second index stage (0: no cap)
             int *saw_long = (int *)(ctx->d_mail + 16);
             const int64_t *coarse = nullptr;
             int64_t m = 0;
@@ -1750,8 +1642,7 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
                 FMK_LAUNCH_CHECK(ctx);
                 if (sl >= 0) FMK_HIP(ctx, hipEventRecord(ctx->kev[sl][1], ctx->stream));
             }
-            static const int eo_census = []{ const char *v = getenv("FMK_TB_PIPE_EO_CENSUS"); return v ? atoi(v) : 1; }();
-            if (!ctx->enqueue_only || eo_census) {
+            {
                 FMK_HIP(ctx, hipEventSynchronize(ctx->aev[2]));          // the index stages' census: long before the kernels end
                 if (*h_saw == 0) return FMK_OK;
             }
@@ -1765,25 +1656,19 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     FMK_HIP(ctx, hipMemsetAsync(saw_long, 0, sizeof(int), ctx->stream));
     // mean bar length (the tick array's length over the bars is an upper bound) picks the schedule: several whole bars per
     // LANE below FMK_PACKED_MAX_MEAN ticks per bar (k_bar_ohlcv_lanes), one bar per wave above
-    static int packed_max = -1;              // developer knob: FMK_OHLCV_PACKED_MAX_MEAN (0 disables the packed schedule)
-    if (packed_max < 0) { const char *v = getenv("FMK_OHLCV_PACKED_MAX_MEAN"); packed_max = v ? atoi(v) : FMK_PACKED_MAX_MEAN; }
+    const int packed_max = FMK_PACKED_MAX_MEAN;              // (0 disables the packed schedule)
     int64_t long_min = 64 * FMK_SMALL_NCH;
-    static int mid_max = -1;                 // developer knob: FMK_OHLCV_MID_MAX_MEAN (0 disables the 65..256-tick instantiation)
-    if (mid_max < 0) { const char *v = getenv("FMK_OHLCV_MID_MAX_MEAN"); mid_max = v ? atoi(v) : 210; }
-    static int mid2_max = -1;                // FMK_OHLCV_MID2_MAX_MEAN: ... served by the <= 640-tick instantiation
-    if (mid2_max < 0) { const char *v = getenv("FMK_OHLCV_MID2_MAX_MEAN"); mid2_max = v ? atoi(v) : 600; }
-    const char *rv = getenv("FMK_OHLCV_ROWS");            // developer knob: 0 = without the sixteen-lanes-per-bar schedule
-    const int rows_on = rv ? atoi(rv) : 1;
-    static int rows_min = -1;                // FMK_OHLCV_ROWS_MIN_MEAN: mean ticks per bar from which rows replace the lane schedule
-    if (rows_min < 0) { const char *v = getenv("FMK_OHLCV_ROWS_MIN_MEAN"); rows_min = v ? atoi(v) : 57; }
-    // With the median: eight lanes per bar (bars of <= 128 ticks) serve streams of 33 .. 63 ticks per bar (FMK_OHLCV_HALF_MIN_MEAN, 0 = off),
+    const int mid_max = 210;                 // mean ticks per bar up to which the 65..256-tick instantiation serves the stream
+    const int mid2_max = 600;                // ... and the <= 640-tick instantiation
+    const int rows_on = 1;                   // the sixteen-lanes-per-bar schedule
+    const int rows_min = 57;                 // mean ticks per bar from which rows replace the lane schedule (without the median)
+    // With the median: eight lanes per bar (bars of <= 128 ticks) serve streams of 33 .. 63 ticks per bar,
     // sixteen lanes per bar from 64 (profiles/r04_short_bars.txt: 5.8 / 5.3 / 4.9 / 4.3 ms at 34 / 40 / 46 / 60 ticks against the lane
     // schedule's 7.0 / 6.6 / 7.0 / 8.9; the half rows are ahead of the rows up to ~100 ticks on equal bars, but a stream's longer bars
     // -- twice its mean -- must still fit the schedule: 63 x 2 <= 128).  Without the median the lane schedule stays ahead up to 56.
     // (Four lanes per bar, sixteen bars per wave, was measured too: 6.9 / 6.2 / 5.4 ms at 20 / 26 / 34 ticks -- behind; not dispatched.)
-    static int half_min = -1;
-    if (half_min < 0) { const char *v = getenv("FMK_OHLCV_HALF_MIN_MEAN"); half_min = v ? atoi(v) : 33; }
-    const int64_t rows_from = (o.median && !getenv("FMK_OHLCV_ROWS_MIN_MEAN")) ? 64 : rows_min;
+    const int half_min = 33;
+    const int64_t rows_from = o.median ? 64 : rows_min;
     if (!AF64 && rows_on && o.median && half_min > 0 && nb >= 64 && n / nb >= half_min && n / nb < rows_from) {
         if constexpr (!AF64) {
             int64_t blocks = fmk_ceil_div(fmk_ceil_div(nb, 8), OHR_WAVES);
@@ -1797,11 +1682,8 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         const int64_t cap = (int64_t)ctx->n_cu * 96;
         if (blocks > cap) blocks = cap;
         // bars of 45 .. 64 ticks fill a 1 024-tick tile with 16 .. 22 bars only: a 2 048-tick tile for those -- 50 / 60-tick bars 7.4 / 9.5 ->
-        // 6.7 / 8.9 ms per 1e9 ticks, 34 / 40-tick bars are better off with the small tile (7.0 / 6.6 against 7.9 / 7.4) (developer knob
-        // FMK_OHLCV_LANES_TILE=1024: the small tile at every length; profiles/r04_short_bars.txt)
-        static int big_tile = -1;
-        if (big_tile < 0) { const char *v = getenv("FMK_OHLCV_LANES_TILE"); big_tile = (v ? atoi(v) : 2048) >= 2048 ? 1 : 0; }
-        if (big_tile && n / nb > 44) {
+        // 6.7 / 8.9 ms per 1e9 ticks, 34 / 40-tick bars are better off with the small tile (7.0 / 6.6 against 7.9 / 7.4) (profiles/r04_short_bars.txt)
+        if (n / nb > 44) {
             if (!o.median) k_bar_ohlcv_lanes<false, 2048><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
             else k_bar_ohlcv_lanes<true, 2048><<<(unsigned)blocks, 128, 0, ctx->stream>>>(p, (const float *)a, ci, nb, n, saw_long, o);
         } else
@@ -1834,11 +1716,6 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
         if (!o.median) k_bar_ohlcv_small<AF64, false, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         else k_bar_ohlcv_small<AF64, true, 10><<<(unsigned)blocks, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
         long_min = 640;
-    } else if (fuse_index) {
-        // one wave per bar in dispatch order (no grid-stride cap): the in-flight window slides through the columns
-        const unsigned fgrid = ohlcv_grid(ctx, nb, /*fused=*/true);
-        if (!o.median) k_time_bars_ohlcv<AF64, false><<<fgrid, 256, 0, ctx->stream>>>(*tb, p, a, nb, n, saw_long, o);
-        else k_time_bars_ohlcv<AF64, true><<<fgrid, 256, 0, ctx->stream>>>(*tb, p, a, nb, n, saw_long, o);
     } else if (!o.median) k_bar_ohlcv_small<AF64, false><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     else k_bar_ohlcv_small<AF64, true><<<grid, 256, 0, ctx->stream>>>(p, a, ci, nb, n, saw_long, o);
     FMK_LAUNCH_CHECK(ctx);
@@ -1847,11 +1724,10 @@ static int ohlcv_launch(fmk_ctx *ctx, const double *p, const void *a, const int6
     // workgroup kernels and their median passes: ~36 launches that exit at once when there is no such bar, ~0.25 ms per call at
     // ~7 us each (10 % of the 1-minute headline pass, rocprofv3 of bench.py at the end of round 3).  So the flag is read back first:
     // one 4-byte copy and a wait for the kernel that is the call's work anyway.  fmk_ctx_set_enqueue_only(ctx, 1) (the sharded
-    // step: two waits per step cost it 0.9 ms) or the developer knob FMK_OHLCV_CENSUS_SYNC=0: enqueue everything without looking.
+    // step: two waits per step cost it 0.9 ms) : enqueue everything without looking.
     if constexpr (!AF64) {
         if (n <= long_min) return FMK_OK;                          // no bar is longer than the tick array (the sharded step's boundary bar)
-        static int census_sync = -1;
-        if (census_sync < 0) { const char *v = getenv("FMK_OHLCV_CENSUS_SYNC"); census_sync = v ? atoi(v) : 1; }
+        const int census_sync = 1;
         if (census_sync && !ctx->enqueue_only) {
             int *h_saw = (int *)(ctx->h_mail + 12);
             FMK_HIP(ctx, hipMemcpyAsync(h_saw, saw_long, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1912,18 +1788,14 @@ extern "C" int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const
     FMK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nb = n_idx - 1;
     OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median, nullptr};
-    static int variant = -1;   // developer knob: FMK_OHLCV_VARIANT=0 forces the generic kernels
-    if (variant < 0) {
-        const char *v = getenv("FMK_OHLCV_VARIANT");
-        variant = v ? atoi(v) : 1;
-    }
+    const int variant = 1;     // (0: the generic kernels only)
     return amount_is_f64 ? ohlcv_launch<true>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant)
                          : ohlcv_launch<false>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant);
 }
 
 // _time_bar_indexer + comp_bar_ohlcv in one call (TimeBarKit.build_ohlcv on resident columns; bench.py's step): the results of
 // fmk_time_bar_indexer_dev(first_edge, delta, n_edges) followed by fmk_comp_bar_ohlcv_dev on its close indices, bit for bit; for
-// streams of 1-minute-sized bars (mean bar length above 600 ticks) both are ONE kernel launch (k_time_bars_ohlcv).
+// streams of 1-minute-sized bars (mean bar length above 600 ticks) the indexer runs in two stages, pipelined with the bar kernel.
 extern "C" int fmk_time_bars_ohlcv_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const void *d_amount,
                                        int amount_is_f64, int64_t n, int64_t ts_first, int64_t ts_last, int64_t first_edge,
                                        int64_t delta, int64_t n_edges, int64_t *d_clock, int64_t *d_close_idx, double *d_open,
@@ -1938,8 +1810,7 @@ extern "C" int fmk_time_bars_ohlcv_dev(fmk_ctx *ctx, const int64_t *d_ts, const 
     const int64_t nb = n_edges - 1;
     OhlcvOut o{d_open, d_high, d_low, d_close, d_volume, d_vwap, d_trades, d_median, nullptr};
     const TbFuse tb{d_ts, first_edge, delta, ts_first, ts_last, d_clock, d_close_idx};
-    const char *v = getenv("FMK_OHLCV_VARIANT");
-    const int variant = v ? atoi(v) : 1;
+    const int variant = 1;
     return amount_is_f64 ? ohlcv_launch<true>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant, &tb)
                          : ohlcv_launch<false>(ctx, d_price, d_amount, d_close_idx, nb, n, o, variant, &tb);
 }

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__res
 struct EwDesc {
     unsigned long long *tagA, *tagR, *tagP;
     unsigned long long *A, *R, *P;       // [tiles][12] granules (R, P: by slot)
+    unsigned long long *ticket;          // the next tile to hand out (zeroed with the tags)
     int64_t groups;
 };
 __device__ __forceinline__ int64_t ew_slot(int64_t t, int64_t groups) { return (t & (EW_W1 - 1)) * groups + t / EW_W1; }
@@ -728,9 +729,8 @@ __device__ __forceinline__ bool ew_lookback(const EwDesc &D, int64_t tile, int l
 // ONE TILE PER WORKGROUP in dispatch order, the tile's ticks by direct 16-byte loads (round 5; round 2's form was a persistent grid with
 // the tile staged in LDS: every workgroup reached its look-back at the same moment and the whole device waited out the two round trips,
 // generation after generation -- 18.7 ms per 1e9 ticks, removed in round 6).  Here the workgroups of a CU are at different points of
-// their tiles and the SIMDs stay busy with the others' arithmetic while one waits.  Forward progress: workgroups are dispatched in index
-// order, so the lowest unfinished tile is always resident; a wait that gives up all the same raises the sticky error word instead of
-// hanging.
+// their tiles and the SIMDs stay busy with the others' arithmetic while one waits.  Forward progress: a workgroup takes its tile from an atomic ticket, so every tile it can
+// wait for has started; a wait that gives up all the same raises the sticky error word instead of hanging.
 // Four waves per SIMD (112 .. 128 registers, no spill): 9.5 ms per 1e9 ticks; five: 13.2 ms, six: 15.6 ms (they spill).
 template <int MODE>
 __global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
@@ -739,8 +739,11 @@ __global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *_
 {
     __shared__ EwMap lds[4];
     __shared__ EwMap s_excl;
+    __shared__ unsigned long long s_ticket;
     const int lane = fmk_lane();
-    const int64_t tile = blockIdx.x;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(D.ticket, 1ULL);       // a ticket, not blockIdx.x: every earlier tile has started (k_dl1)
+    __syncthreads();
+    const int64_t tile = (int64_t)s_ticket;
     double yl[EW_ITEMS], al[EW_ITEMS];
     const EwMap m = ew_thread_ticks<MODE>(ts, y, tile, n, half_life, yl, al);
     EwMap tot;
@@ -814,11 +817,12 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
         const int64_t groups = fmk_ceil_div(tiles, EW_W1), slots = groups * EW_W1;
         const size_t tag_bytes = (size_t)(tiles + 2 * slots) * 8, rec_bytes = (size_t)(tiles + 2 * slots) * 96;
         FMK_TRY(fmk_scratch(ctx, tag_bytes + rec_bytes + 64, &scr));
-        FMK_HIP(ctx, hipMemsetAsync(scr, 0, tag_bytes + rec_bytes, ctx->stream));     // tags AND granules
+        FMK_HIP(ctx, hipMemsetAsync(scr, 0, tag_bytes + rec_bytes + 8, ctx->stream)); // tags, granules, the ticket counter
         EwDesc D;
         D.tagA = (unsigned long long *)scr; D.tagR = D.tagA + tiles; D.tagP = D.tagR + slots;
         D.A = D.tagP + slots; D.R = D.A + 12 * tiles; D.P = D.R + 12 * slots;
         D.groups = groups;
+        D.ticket = (unsigned long long *)((char *)scr + tag_bytes + rec_bytes);
         k_ew_onepass_d<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D, ctx->h_mail + 40);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;

@@ -1711,19 +1711,15 @@ extern "C" int fmk_comp_bar_trade_size_dev(fmk_ctx *ctx, const void *d_amount, i
     int64_t *list_w = nullptr;                                     // the bars a workgroup may take
     if (rc == FMK_OK) rc = fmk_long_bar_list(ctx, d_close_idx, nb, n, 2048, nullptr, &list_w);
     if (rc == FMK_OK) {
-        // bars beyond TSW_MID_MIN ticks: a workgroup per bar, percentile included (developer knob FMK_TS_WIDE=0: one wave per bar and
-        // the radix-select percentile as before); scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
-        const char *wv = getenv("FMK_TS_WIDE");
-        bool wide_on = (!wv || atoi(wv)) && n > TSW_MID_MIN;
+        // bars beyond TSW_MID_MIN ticks: a workgroup per bar, percentile included; scratch: sample slots [start / 16 ...) and candidate slots [start / 4 ...) of the bars
+        bool wide_on = n > TSW_MID_MIN;
         // regular bars of 129 .. 1 920 ticks: the one-read wave kernel; up to 1 912 x 16 ticks: 2 .. 16 waves of it per bar
-        // (developer knob FMK_TS_MID=0: the three-pass kernels, and a workgroup per bar from TSW_MID_MIN ticks)
-        const char *mv = getenv("FMK_TS_MID");
-        const bool mid_on = (!mv || atoi(mv)) && ((uintptr_t)d_amount & 3) == 0;
+        // (amounts that are not 4-byte aligned: the three-pass kernels, and a workgroup per bar from TSW_MID_MIN ticks)
+        const bool mid_on = ((uintptr_t)d_amount & 3) == 0;
         // eight waves hold two of np.sum's chunks (8 192 + 4 x 1 912 ticks), sixteen up to four -- those whose last chunk fits four
         // sub-trees (tsm_quad16_fits); the others of 15 841 .. 32 768 ticks are k_bar_trade_size_wide's, which skips the ones that fit
         const int64_t wg8_top = (int64_t)FMK_NP_BUFSIZE + 4 * TSM_WG_PER_WAVE;
-        const char *wm = getenv("FMK_TS_WIDE_MIN");                // developer knob: shortest bar (ticks) k_bar_trade_size_wide takes
-        int64_t wide_min = wm && atoll(wm) >= 2048 ? atoll(wm) : (mid_on ? wg8_top : (int64_t)TSW_MID_MIN);
+        int64_t wide_min = mid_on ? wg8_top : (int64_t)TSW_MID_MIN;   // shortest bar (ticks) k_bar_trade_size_wide takes
         if (mid_on && wide_min > wg8_top) wide_min = wg8_top;
         const bool quad16 = mid_on && wide_on && wide_min == wg8_top;
         const int64_t wg_upper = mid_on ? (quad16 ? 4 * (int64_t)FMK_NP_BUFSIZE : (wide_on ? wide_min : wg8_top)) : 0;

@@ -546,8 +546,7 @@ static int vol_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache 
     static_assert(S == (1 << LS), "table span");
     const int64_t nblk0 = fmk_ceil_div(n, S);
     // levels: nblk[k] = ceil(nblk0 / R^k) until 1 (radix-R composition, k_vol_level_up4)
-    static int RAD = 0;                  // developer knob: FMK_VOL_RADIX (2..64, default VOL_RADIX)
-    if (!RAD) { const char *v = getenv("FMK_VOL_RADIX"); RAD = v ? atoi(v) : VOL_RADIX; if (RAD < 2 || RAD > 64) RAD = VOL_RADIX; }
+    const int RAD = VOL_RADIX;
     int64_t nblk[64], spanq[64];
     int K = 0;
     nblk[0] = nblk0;
@@ -1613,24 +1612,18 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
         int rc = 1;
         // the exact-sum tier first (fmk_volume_exact.h): every window certifies that its float64 sums are exact, so there is no
         // tie zone to replay; entry tables for the first 1024 / 2048 ticks of 4096-tick blocks.  A window that does not certify or
-        // a bar beyond the table span hands the call to the tiers below (developer knob FMK_VOL_EXACT_TIER=0: skip it)
-        static int vx_on = -1;
-        if (vx_on < 0) { const char *v = getenv("FMK_VOL_EXACT_TIER"); vx_on = v ? atoi(v) : 1; }
-        if (vx_on && est_len < 1500.0) {
+        // a bar beyond the table span hands the call to the tiers below
+        if (est_len < 1500.0) {
             // table span W >= the longest bar; the estimate is the MEAN length of the head of the stream, so each class leaves room
             // (x 1.6 / x 1.3) and a bar that is longer after all sends the call to the next class (flag, then one more attempt)
-            if (est_len < 640.0 && vx_on != 2)
+            if (est_len < 640.0)
                 rc = amount_is_f64 ? vx_run<true, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 3072, 1024, 512, false>(ctx, d_amount, n, threshold, c);
-            // (a (3840, 1280) class with 640 threads -- a third of the rows per tick -- was measured: 7.3 against 6.3 ms at 865-tick bars)
-            if (rc == 1 && est_len < 1150.0 && vx_on != 3) {
-                if (vx_on == 5)          // experiment: 256 threads (twice the ticks per thread)
-                    rc = amount_is_f64 ? vx_run<true, 2560, 1536, 256, false>(ctx, d_amount, n, threshold, c)
-                                       : vx_run<false, 2560, 1536, 256, false>(ctx, d_amount, n, threshold, c);
-                else
+            // (a (3840, 1280) class with 640 threads -- a third of the rows per tick -- was measured: 7.3 against 6.3 ms at 865-tick bars;
+            //  256 threads with twice the ticks per thread: no better)
+            if (rc == 1 && est_len < 1150.0)
                 rc = amount_is_f64 ? vx_run<true, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 2560, 1536, 512, false>(ctx, d_amount, n, threshold, c);
-            }
             if (rc == 1)
                 rc = amount_is_f64 ? vx_run<true, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c)
                                    : vx_run<false, 4096, 2048, 512, true>(ctx, d_amount, n, threshold, c);
@@ -1657,7 +1650,7 @@ extern "C" int fmk_volume_bar_indexer_dev(fmk_ctx *ctx, const void *d_amount, in
             }
             // bars beyond the 2048-tick LDS tables: global tables up to ~64K ticks (26 ms at 1e9 ticks whatever the length;
             // the 4096-tick LDS tables this used to try first cost 33 ms), the chain walk beyond
-            if (rc == 1 && mean_len < 65536.0 && !getenv("FMK_VOLUME_NO_GLOBAL")) {
+            if (rc == 1 && mean_len < 65536.0) {
                 if (!prefix_ok) {            // a table attempt overwrote the prefix of the total pass
                     rc2 = amount_is_f64 ? vol_chase<true>(ctx, d_amount, n, threshold, c, true, &total)
                                         : vol_chase<false>(ctx, d_amount, n, threshold, c, true, &total);

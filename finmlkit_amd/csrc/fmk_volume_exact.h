@@ -394,8 +394,7 @@ template <bool AF64, int S, int W, int THREADS, bool PAD>
 static int vx_run(fmk_ctx *ctx, const void *a, int64_t n, double thr, VolCache &c)
 {
     const int64_t nblk0 = fmk_ceil_div(n, S);
-    static int RAD = 0;
-    if (!RAD) { const char *v = getenv("FMK_VOL_RADIX"); RAD = v ? atoi(v) : VOL_RADIX; if (RAD < 2 || RAD > 64) RAD = VOL_RADIX; }
+    const int RAD = VOL_RADIX;
     int64_t nblk[64], spanq[64];
     int K = 0;
     nblk[0] = nblk0;

@@ -206,8 +206,6 @@ class ShardedTimeBars:
         from ._ffi import DeviceArray
         self.t, self.rank, self.world = trades, rank, world
         self.interval, self.want_median = float(interval_seconds), want_median
-        # interior bars through the pipelined one-call entry (1) or the separate indexer + comp_bar_ohlcv (0): developer switch
-        self.one_call = os.environ.get("FMK_DIST_ONE_CALL", "1") != "0"
         self.with_side = with_side and trades.side is not None
         self.self_loop = self_loop and world == 1
         self.ctx = trades.ctx
@@ -299,14 +297,7 @@ class ShardedTimeBars:
         # index stage 2 -> OHLCV launch 2; the long-bar census comes from the index stages, so nothing waits for a kernel).  Bars that
         # need no halo: all of them on rank 0, bars 1.. elsewhere.  On the other ranks bar 0 is computed here from the local ticks alone
         # -- a partial bar -- and OVERWRITTEN by the boundary launch that follows on the same stream (enqueue_boundary).
-        if not self.one_call:
-            self._index()
-            if self.rank == 0:
-                self.t.bar_ohlcv(self.idx, want_median=self.want_median, out=self.out)
-            elif self.n_edges > 2:
-                self.t.bar_ohlcv(self.idx.view(1), want_median=self.want_median,
-                                 out={k: v.view(1) for k, v in self.out.items()})
-        elif self.n_edges > 2 or self.rank == 0:
+        if self.n_edges > 2 or self.rank == 0:
             self.clock, self.idx, _ = self.t.time_bars_ohlcv(self.interval, self.want_median,
                                                              clock_params=(self.n_edges, self.e_lo, self.gclock[2]),
                                                              out_index=(self._clock, self._idx), out=self.out)

@@ -92,7 +92,9 @@ class DeviceTrades:
 
     # ------------------------------------------------------------------ placement (opt-in)
     def place(self, probe, positions: int = 7, stride: int = 16 << 30, reps: int = 6, warm: int = 3):
-        """Opt-in: choose WHERE in device memory the columns lie.  The reducers that stream whole bars (k_bar_ohlcv_small ...) run up to
+        """Opt-in, and it DOUBLES the device memory of the columns for the life of the returned object (the slab and the original
+        columns both stay): choose WHERE in device memory the columns lie.  A trade set with head-room in front of it (a shard made for
+        the halo exchange, `with_halo`) is refused -- place the columns before sharding.  The reducers that stream whole bars (k_bar_ohlcv_small ...) run up to
         10 % slower when their input columns fall into certain physical blocks of HBM (profiles/r04_placement_regions.txt: whole
         16 .. 128 GiB stretches, constant for an allocation's life; small separate allocations land in them more often than one
         large one).  `place` makes ONE allocation that holds `positions` copies' worth of address space, copies the columns to every
@@ -104,6 +106,9 @@ class DeviceTrades:
         allocated for the life of the returned object (releasing it moved the level of other allocations: r04_sharded_step.txt).
         Costs positions x (a device-to-device copy of the columns + the probes): set-up, once per trade set."""
         ctx = self.ctx
+        if getattr(self, "_headroom", 0):
+            raise ValueError("place(): this trade set has head-room for a halo in front of its columns (a shard); the placed copy "
+                             "would lose it -- place the columns before sharding")
         cols = [c for c in (self.ts, self.price, self.amount, self.side) if c is not None]
         span = sum((c.nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) for c in cols)
         span = (span + (1 << 30) - 1) // (1 << 30) * (1 << 30)

@@ -114,7 +114,9 @@ def bucket_price_levels(all_price_levels: NDArray[np.int32], total_volumes: NDAr
 
 
 def comp_poc_hva_lva(price_levels: NDArray[np.int32], volumes: NDArray[np.float32], va_pct: float = 68.34) -> Tuple[int, int, int]:
-    """Reference volume.py:278-365 -> (poc_price, hva_price, lva_price) in the units of `price_levels`."""
+    """Reference volume.py:278-365 -> (poc_price, hva_price, lva_price) in the units of `price_levels`.  Contract (include/fmk.h):
+    the total is NumPy's pairwise float32 np.sum (the reference's pinned pure-Python mode), the walk's scalars are float64; the
+    readings of the reference's scalars coincide unless the covered volume meets the threshold to the last float32 bit."""
     import ctypes as C
     pl = np.ascontiguousarray(price_levels, dtype=np.int32)
     v = np.ascontiguousarray(volumes, dtype=np.float32)

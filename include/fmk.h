@@ -163,8 +163,8 @@ int fmk_comp_bar_ohlcv_dev(fmk_ctx *ctx, const double *d_price, const void *d_am
  * (logic.py:12-51) + comp_bar_ohlcv (base.py:306-407).  Results = fmk_time_bar_indexer_dev(first_edge, delta, n_edges)
  * followed by fmk_comp_bar_ohlcv_dev on its close indices, bit for bit (d_clock may be NULL, d_close_idx[n_edges] is
  * always written; ts_first / ts_last = d_ts[0] / d_ts[n-1], the two values the clock was made from).  For streams of
- * 1-minute-sized bars (mean bar length above 600 ticks) the edge search runs INSIDE the OHLCV + median kernel -- one
- * launch, every wave finds its own bar's two edges by interpolation search before it issues the bar's loads. */
+ * 1-minute-sized bars (mean bar length above 600 ticks, float32 amounts) the call is pipelined: the clock edges of the first eighth of
+ * the bars, then OHLCV + median of those bars while the remaining edges are searched on a second stream (csrc/fmk_ohlcv.hip). */
 int fmk_time_bars_ohlcv_dev(fmk_ctx *ctx, const int64_t *d_ts, const double *d_price, const void *d_amount,
                             int amount_is_f64, int64_t n, int64_t ts_first, int64_t ts_last, int64_t first_edge,
                             int64_t delta, int64_t n_edges, int64_t *d_clock, int64_t *d_close_idx,
@@ -241,25 +241,11 @@ int fmk_comp_bar_trade_size(fmk_ctx *ctx, const void *amount, int amount_is_f64,
                             double theta_mult, float *mean_size_rel, float *size_95_rel,
                             float *pct_block, float *size_gini);
 
-/* ---- cfg 4: time bars + order-flow + footprints, fused ----------------------------------
- * Two phases like comp_bar_footprints (the CSR row count must reach the caller's allocator):
- *   size: comp_bar_ohlcv (incl. median when d_median != NULL) + the footprint level offsets from the
- *         lows/highs it just produced (12 B/tick);
- *   fill: comp_bar_directional_features + comp_bar_footprints + comp_footprint_features in ONE pass over
- *         price/amount/side (13 B/tick) -- base.py:409-546, 615-850.
- * Replaces BarBuilderBase.build_ohlcv + build_directional_features + build_footprints (base.py:126-300)
- * called back to back (38 B/tick as three reducers). */
-int fmk_bars_fused_size_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
-                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, double price_tick_size,
-                            double *d_open, double *d_high, double *d_low, double *d_close, float *d_volume,
-                            double *d_vwap, int64_t *d_trades, double *d_median, int64_t *d_level_offsets,
-                            int64_t *total_levels, int64_t *max_levels);
-int fmk_bars_fused_fill_dev(fmk_ctx *ctx, const double *d_price, const void *d_amount, int amount_is_f64,
-                            int64_t n, const int64_t *d_close_idx, int64_t n_idx, const int8_t *d_side,
-                            const fmk_directional_out *d_dir, int64_t *d_n_zero_div, double price_tick_size,
-                            const double *d_bar_lows, double imbalance_factor, const int64_t *d_level_offsets,
-                            int64_t max_levels, const fmk_footprint_out *d_fp, int64_t *d_n_bad_level);
-
+/* ---- cfg 4: time bars + order-flow + footprints ----------------------------------------
+ * Replaces BarBuilderBase.build_ohlcv + build_directional_features + build_footprints (base.py:126-300) called back to back (38 B/tick
+ * as three reducers).  Two phases like comp_bar_footprints (the CSR row count must reach the caller's allocator).  (Round 1's
+ * fmk_bars_fused_size_dev / _fill_dev -- comp_bar_ohlcv, then the two other reducers back to back -- were superseded by the entry
+ * points below and removed in round 6.) */
 /* cfg 4 in TWO passes over the ticks (round 2; 26 B/tick): build_ohlcv + build_directional_features semantics from one read of
  * price / amount / side (float32 amounts: one kernel; float64 amounts: the two kernels back to back), then the CSR level
  * counts.  The second pass is fmk_comp_bar_footprints_fill_dev with the offsets and lows produced here. */
@@ -346,7 +332,12 @@ int fmk_calc_volume_percentage_above_poc(fmk_ctx *ctx, const int32_t *price_leve
  * bucket_price_levels (volume.py:207-275): odd-width buckets over [min, max] of the levels, float32 sums in element order, the
  *   leftover bucket when the last level falls past the last edge.  binned_* == NULL: *n_out only.
  * comp_poc_hva_lva (volume.py:278-365): first argmax, then the value area grown two levels at a time towards the heavier side
- *   until va_pct of the (NumPy-pairwise float32) total is covered; float64 scalars (the Numba-typed function). */
+ *   until va_pct of the total is covered.  THE CONTRACT: the total is np.sum of the float32 array as NumPy computes it (pairwise
+ *   float32 -- the reference's pinned pure-Python mode; a jitted np.sum is a sequential float32 loop and can differ in the last bit),
+ *   the walk's scalars are float64 (the typed reading of the function's `0.0` literals; pure Python under NumPy 2 adds its np.float32
+ *   scalars in float32).  The readings coincide whenever the partial sums are exact, and on all 400 lognormal float32 profiles of
+ *   tests/golden/volume_profile_stages.npz (`poc_lognormal`, made by the reference itself); a knife-edge profile whose covered volume
+ *   equals the threshold to the last float32 bit can move HVA / LVA by one step between them. */
 int fmk_aggregate_footprint(fmk_ctx *ctx, const int64_t *bar_ts, const double *highs, const double *lows,
                             const int64_t *level_offsets, const int32_t *price_levels, const float *buy_volumes,
                             const float *sell_volumes, int64_t n_bars, int64_t start_ts, int64_t end_ts, double price_tick,

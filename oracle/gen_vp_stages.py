@@ -52,6 +52,16 @@ def main():
                 d[f"poc{w}_{nbins}_{va}"] = np.array(rvolume.comp_poc_hva_lva(bl, bv, va), dtype=np.int64)
         for va in (68.34, 30.0):
             d[f"poc{w}_raw_{va}"] = np.array(rvolume.comp_poc_hva_lva(lv, tot, va), dtype=np.int64)
+    # comp_poc_hva_lva on INEXACT volumes: lognormal float32 profiles, regenerated in the tests from the seed -- the
+    # reference in the same pinned pure-Python mode (NumPy's pairwise float32 np.sum; its np.float32 scalars).  Stored: the outputs.
+    rng = np.random.default_rng(20260930)
+    res = []
+    for _ in range(400):
+        m = int(rng.integers(1, 300))
+        v = rng.lognormal(0.0, 1.5, m).astype(np.float32)
+        va = float(rng.choice([68.34, 50.0, 95.0]))
+        res.append(rvolume.comp_poc_hva_lva(np.arange(m, dtype=np.int32) * 3 + 1000, v, va))
+    d["poc_lognormal"] = np.array(res, dtype=np.int64)
     d["synth"] = np.array([42, 0, n, orc.DENSE_GAP_MOD], dtype=np.int64)
     d["amount"] = am
     path = os.path.join(ROOT, "tests", "golden", "volume_profile_stages.npz")

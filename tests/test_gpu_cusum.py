@@ -118,11 +118,9 @@ def test_cusum_chain_walk_vs_oracle(orc, monkeypatch, n, vol, floor, mult, kind,
     provably no longer depends on the past (k_cc_sync) -- and as the one joint walk: the same close indices as the
     sequential loop, and the tier must be the one that answered."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
-    monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
-    monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
-    monkeypatch.setenv("FMK_CUSUM_CHAIN_SAMPLE", "50")         # two launches; the first ends inside a group of 64 chunks
+    # sample=50: two launches; the first ends inside a group of 64 chunks
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", f"2:joint={joint}:sample=50:segments={segments}")
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
-    monkeypatch.setenv("FMK_CUSUM_CHAIN_SEGMENTS", segments)
     ts, px = _stream(orc, n, 11, vol=vol, same_ts=same_ts)
     if kind == "ewm":
         r = orc.comp_lagged_returns(ts, px, 5.0, True)
@@ -154,9 +152,7 @@ def test_cusum_chain_walk_replays_what_its_margins_cannot_settle(orc, monkeypatc
     close, after which the walk has to go on as if nothing happened -- on the lattice tape of the bench round floors do it
     unaided (log-prices are multiples of a quantum: s == floor to the last bits)."""
     from finmlkit_amd.bar.logic import _cusum_bar_indexer
-    monkeypatch.setenv("FMK_CUSUM_CHAIN", "2")
-    monkeypatch.setenv("FMK_CUSUM_CHAIN_JOINT", str(joint))
-    monkeypatch.setenv("FMK_CUSUM_CHAIN_SAMPLE", "50")
+    monkeypatch.setenv("FMK_CUSUM_CHAIN", f"2:joint={joint}:sample=50")
     monkeypatch.setenv("FMK_CUSUM_CHAIN_MIN_CHUNKS", "2")
     monkeypatch.setenv("FMK_CUSUM_MARGIN_SCALE", scale)
     n = 1_000_000

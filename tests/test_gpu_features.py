@@ -209,16 +209,15 @@ def test_imbalance_flags_compare_in_float64(orc):
 
 
 @pytest.mark.parametrize("amounts", ["dyadic", "lognormal32", "f64", "ties", "signflip", "huge_then_small"])
-@pytest.mark.parametrize("rows", ["1", "0"])
+@pytest.mark.parametrize("rows", ["1", "2"])
 def test_order_flow_redo_in_tick_order(orc, monkeypatch, amounts, rows):
     """Every bar forced onto the redo list (FMK_DIR_FORCE_REDO=1) and redone in tick order: by the row-per-wave kernel, which adds
     64 terms per step with the machine's own rounding to the running sum's grid (exact unless a term ties or the sum leaves its
-    binade -- then term by term), and by the old lane walkers (FMK_DIR_REDO_ROWS=0).  Both must give the oracle's sequential sums
+    binade -- then term by term), and by the wave-per-bar lane walkers (FMK_DIR_FORCE_REDO=2).  Both must give the oracle's sequential sums
     bit for bit: short bars (the sum climbs through many binades), long bars, signed running sums that cross zero, exact ties
     (terms that are half a grid step: dyadic prices), a huge first term followed by tiny ones, float64 amounts."""
     from finmlkit_amd import engine
-    monkeypatch.setenv("FMK_DIR_FORCE_REDO", "1")
-    monkeypatch.setenv("FMK_DIR_REDO_ROWS", rows)
+    monkeypatch.setenv("FMK_DIR_FORCE_REDO", rows)
     monkeypatch.setenv("FMK_DIR_LANES", "0")
     n = 400_000
     ts, px, am, sd = orc.synth(31, 0, n)

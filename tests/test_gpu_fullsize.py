@@ -9,7 +9,8 @@ comparison covers the longest prefix that fits.  The older tests below check the
     earlier ticks) -- the full-size run is compared with the oracle on the prefix, bit for bit;
   * conservation laws over ALL bars (trade counts, exact dyadic volumes across bar granularities,
     footprint rows vs bar totals), ordering and envelope invariants.
-FMK_FULLSIZE_TICKS overrides the size (default 1e9; reduced automatically if HBM is short)."""
+FMK_FULLSIZE_TICKS overrides the size (default 1e9; reduced automatically if HBM is short); `<n>:prefix` lets a host that
+cannot hold all columns compare a prefix (host_cols)."""
 import os
 
 import numpy as np
@@ -27,7 +28,7 @@ PREFIX = 3_000_000
 def big():
     from finmlkit_amd import _ffi, engine
     ctx = _ffi.default_context()
-    n = int(float(os.environ.get("FMK_FULLSIZE_TICKS", "1e9")))
+    n = int(float(os.environ.get("FMK_FULLSIZE_TICKS", "1e9").split(":")[0]))
     free, _ = ctx.mem_info()
     n = min(n, int((free - (8 << 30)) // 60))           # columns + footprint / threshold scratch head-room
     t = engine.DeviceTrades.synth(n, seed=42, ctx=ctx)
@@ -424,13 +425,13 @@ def _mem_available_bytes():
 @pytest.fixture(scope="module")
 def host_cols(big):
     """The device columns on the host: ALL n ticks.  A host too small for columns + oracle outputs + HIP outputs (~60 B/tick all
-    told, in a third of the available memory) FAILS the all-bars tests instead of silently comparing a prefix; FMK_FULLSIZE_ALLOW_PREFIX=1
+    told, in a third of the available memory) FAILS the all-bars tests instead of silently comparing a prefix; FMK_FULLSIZE_TICKS=<n>:prefix
     (developer boxes) brings the prefix comparison back, and gpu_parity_counts.json says how much was compared either way."""
     engine, t, n = big
     m = min(n, int(_mem_available_bytes() / 3 // 60))
-    if m < n and not os.environ.get("FMK_FULLSIZE_ALLOW_PREFIX"):
+    if m < n and not os.environ.get("FMK_FULLSIZE_TICKS", "").endswith(":prefix"):
         pytest.fail(f"host memory holds {m:.3g} of the {n:.3g} ticks: the all-bars tests would compare a prefix only "
-                    "(FMK_FULLSIZE_ALLOW_PREFIX=1 to allow that)")
+                    "(FMK_FULLSIZE_TICKS=<n>:prefix to allow that)")
     cores = len(os.sched_getaffinity(0))
     os.environ["ORC_THREADS"] = str(cores)
     cols = tuple(None if c is None else c.view(0, m).to_host() for c in (t.ts, t.price, t.amount, t.side))

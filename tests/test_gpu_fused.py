@@ -1,4 +1,4 @@
-"""GPU parity of the cfg-4 fused path (fmk_bars_fused_size_dev / fmk_bars_fused_fill_dev): OHLCV, then order-flow +
+"""GPU parity of the cfg-4 fused path (fmk_bars_flow_size_defer_dev + the footprint fill): OHLCV, then order-flow +
 footprints from ONE read of price/amount/side by the two-waves-per-bar kernel.  Checked against the CPU oracle, the
 reference-generated goldens and the separate reducers (same arithmetic -> identical bits)."""
 import numpy as np
@@ -135,8 +135,7 @@ def test_fused_median_taken_by_the_footprint_sweep(orc, monkeypatch, n, interval
     (fmk_bars_flow_size_defer_dev -> fmk_comp_bar_footprints_fill_median_dev), which brackets the middle ranks from the wave's
     previous bar and selects them exactly among the candidates -- np.median's bits whatever the bracket does."""
     monkeypatch.setenv("FMK_FLOW_LANES", "2")
-    monkeypatch.setenv("FMK_FLOW_MEDIAN_DEFER", "1")
-    monkeypatch.setenv("FMK_FP_MED_BLOCKS", "2")        # 8 waves: every wave carries its bracket over ~30 bars
+    monkeypatch.setenv("FMK_FLOW_MEDIAN_DEFER", "1:blocks=2")        # 2 workgroups = 8 waves: every wave carries its bracket over ~30 bars
     ts, px, am, sd = orc.synth(23, 0, n)
     rng = np.random.default_rng(5)
     if amounts == "lognormal32":
@@ -188,3 +187,32 @@ def test_fused_on_lognormal_bar_lengths_sorted_lanes(orc, monkeypatch, sort, amo
     sd = rng.choice(np.array([-1, 1], np.int8), n)
     am = (rng.integers(1, 4097, n) / 1024.0).astype(np.float32) if amounts == "dyadic" else rng.lognormal(-1, 1.2, n).astype(np.float32)
     _check_all(orc, px, am, sd, ci, f"lognormal lengths, sort {sort}, {amounts}")
+
+
+@pytest.mark.parametrize("n,interval,amounts,zeros", [
+    (400_000, 60.0, "dyadic", False),        # ~500-tick bars, integer units certify
+    (300_000, 60.0, "lognormal32", False),   # sizes that do not certify: float64 volumes
+    (300_000, 60.0, "mixed", True),          # a few inexact sizes among dyadic ones, unsigned ticks
+    (300_000, 7.0, "dyadic", False),         # bars of a few dozen ticks: one tick per lane and fewer
+    (400_000, 900.0, "dyadic", False),       # bars of several tiles: k_fu_long
+    (130, 60.0, "dyadic", False),
+])
+@pytest.mark.parametrize("fused", ["0", "2", "3"])
+def test_one_pass_kernels_forced(orc, monkeypatch, n, interval, amounts, zeros, fused):
+    """FMK_FUSED: cfg 4 through the one-pass kernels of csrc/fmk_fused.h whatever the tape looks like -- 2: with the integer-unit
+    certificate (a tape that does not certify falls through to the two-pass form by itself), 3: with float64 volumes -- or never (0).
+    The library picks by bar count, mean bar length and a census of the bar lengths (bars_flow_fused_ok), which the small tapes of this
+    suite never pass: forced, every case must give the oracle's bits, and the separate reducers' bits (_check_all)."""
+    monkeypatch.setenv("FMK_FUSED", fused)
+    ts, px, am, sd = orc.synth(29, 0, n)
+    rng = np.random.default_rng(11)
+    if amounts == "lognormal32":
+        am = rng.lognormal(-1, 1.2, n).astype(np.float32)
+    elif amounts == "mixed":
+        am = am.copy()
+        am[rng.random(n) < 0.002] = np.float32(0.3)
+    if zeros:
+        sd = sd.copy()
+        sd[rng.random(n) < 0.1] = 0
+    _, ci = orc._time_bar_indexer(ts, interval)
+    _check_all(orc, px, am, sd, ci, f"FMK_FUSED={fused} n={n} iv={interval} {amounts}")

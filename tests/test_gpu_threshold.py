@@ -48,6 +48,26 @@ def test_threshold_vs_oracle(orc, n, f64):
                                       err_msg=f"dol {bar_ticks}")
 
 
+def test_threshold_serial_walk_forced(orc, monkeypatch):
+    """FMK_THRESHOLD_SERIAL=1: both threshold indexers skip their parallel tiers (closed form + exact tier, jump tables) and run the
+    serial walk -- the reference's loop, one wave -- on tapes the tiers would have served: the same closes, nothing uncertified."""
+    from finmlkit_amd import engine
+    from finmlkit_amd.bar.logic import _dollar_bar_indexer, _volume_bar_indexer
+    monkeypatch.setenv("FMK_THRESHOLD_SERIAL", "1")
+    n = 400_000
+    ts, px, am, sd = orc.synth(21, 0, n)
+    for am_k in (am, np.random.default_rng(2).lognormal(-1, 1.3, n)):
+        mean_v = float(np.mean(am_k))
+        for bar_ticks in (40, 1500):
+            vthr = mean_v * bar_ticks
+            np.testing.assert_array_equal(_volume_bar_indexer(am_k, vthr), orc._volume_bar_indexer(am_k, vthr))
+            dthr = vthr * float(px[0])
+            np.testing.assert_array_equal(_dollar_bar_indexer(px, am_k, dthr), orc._dollar_bar_indexer(px, am_k, dthr))
+    t = engine.DeviceTrades.from_numpy(ts, px, am)
+    t.volume_bar_index(float(np.mean(am)) * 300)
+    assert t.last_uncertified == 0
+
+
 def test_threshold_device_resident(orc):
     """Device-resident path + close_ts gather (kit.py:97-101) + OHLCV on volume bars."""
     from finmlkit_amd import engine

@@ -2,7 +2,7 @@
 call.  For streams of 1-minute-sized bars (float32 amounts) the call is PIPELINED: the clock edges of the first eighth of the bars,
 then OHLCV + median of those bars while the remaining edges are searched on a second stream; both index stages take the long-bar
 census, so the call never waits for a kernel it launched (csrc/fmk_ohlcv.hip).  FMK_TB_PIPE_MIN_STAGE lowers the size from which that
-happens so that the small cases here take it; FMK_OHLCV_FUSE_INDEX=1 (the in-kernel edge search, measured slower) keeps its cases.
+happens so that the small cases here take it.
 Checked against the CPU oracle (clock, close indices, all eight OHLCV columns) on even, bursty, tied and degenerate timestamp
 spacings."""
 import numpy as np

@@ -136,6 +136,15 @@ def test_volume_profile_stages_golden(orc):
             assert comp_poc_hva_lva(lv, tot, va) == tuple(int(x) for x in d[f"poc{w}_raw_{va}"]), (w, va)
             n_poc += 1
     assert n_agg == 6 and n_bkt >= 16 and n_poc >= 40
+    # inexact volumes (lognormal float32 profiles from the seed of oracle/gen_vp_stages.py): the reference's own answers in its pinned
+    # pure-Python mode.  The library's contract (include/fmk.h): NumPy's pairwise float32 np.sum for the total, float64 scalars for
+    # the walk -- on these 400 profiles every reading of the reference's scalars gives the same three levels.
+    rng = np.random.default_rng(20260930)
+    for want in d["poc_lognormal"]:
+        m = int(rng.integers(1, 300))
+        v = rng.lognormal(0.0, 1.5, m).astype(np.float32)
+        va = float(rng.choice([68.34, 50.0, 95.0]))
+        assert comp_poc_hva_lva(np.arange(m, dtype=np.int32) * 3 + 1000, v, va) == tuple(int(x) for x in want), (m, va)
     with pytest.raises(ZeroDivisionError):
         bucket_price_levels(np.arange(5, dtype=np.int32), np.ones(5, dtype=np.float32), 0)
     with pytest.raises(ValueError):

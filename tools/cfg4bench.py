@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """cfg 4 (bars_fused: OHLCV + order-flow + footprints) at N ticks, dyadic and full-mantissa amounts, host wall time best of 5.
-usage: cfg4bench.py [N]     (FMK_FLOW_SEPARATE=1: OHLCV kernel apart from the directional one)"""
+usage: cfg4bench.py [N]"""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,5 +28,5 @@ for name, tr in (("dyadic amounts", t), ("full-mantissa amounts", t2)):
     ctx.call("fmk_diag_dir_redo", z10)
     print("  tick-order redo of that call: pairs, tiles, term-by-term tiles, pairs of column 0..6 =", list(z10), flush=True)
     print(f"  device time {dev_ms:.3f} ms; one-pass kernel (FMK_FUSED={os.environ.get('FMK_FUSED', 'unset')}): {nfp.value} bars to the footprint classes, {ndir.value} to k_bar_dir, {nredo.value} redo entries", flush=True)
-    print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms (separate={os.environ.get('FMK_FLOW_SEPARATE', '0')}, "
+    print(f"n={n:.3g} cfg4 {name}: {best:.3f} ms ("
           f"median deferred to the footprint sweep={os.environ.get('FMK_FLOW_MEDIAN_DEFER', '0')}, bracket misses {fb.value} of {ci.n - 1} bars)", flush=True)

@@ -34,8 +34,7 @@ for floor in floors:
     want = orc._cusum_bar_indexer(ts, px, sg.copy(), floor, 2.0)
     for mode in ("0", "2"):
         for joint in ("0", "1") if mode == "2" else ("0",):
-            os.environ["FMK_CUSUM_CHAIN_JOINT"] = joint
-            got, info = dev(mode)
+            got, info = dev(mode if joint == "0" else mode + ":joint=1")
             k = min(len(got), len(want))
             bad = np.flatnonzero(got[:k] != want[:k])
             print(f"floor {floor}: mode {mode} joint {joint} tier/opened/status {info}: {len(got)} vs oracle {len(want)} closes,",

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timings of the cfg-4 reducers at N ticks: OHLCV, directional, footprint fill, fused fill.
-usage: flowbench.py [N] [inexact]   (env FMK_FLOW_VARIANT=0: first-generation per-chunk kernels)"""
+usage: flowbench.py [N] [inexact]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,11 +32,9 @@ runs = {
     "directional": lambda: ctx.call("fmk_comp_bar_directional_dev", *A, t.side.p, C.byref(dst), cn.view(0, 1).p),
     "footprint fill": lambda: ctx.call("fmk_comp_bar_footprints_fill_dev", *A, t.side.p, c_f64(0.01), o["low"].p, c_f64(3.0),
                                        off.p, c_i64(mx.value), C.byref(fst), cn.view(1, 1).p),
-    "fused fill (dir+fp)": lambda: ctx.call("fmk_bars_fused_fill_dev", *A, t.side.p, C.byref(dst), cn.view(0, 1).p, c_f64(0.01),
-                                            o["low"].p, c_f64(3.0), off.p, c_i64(mx.value), C.byref(fst), cn.view(1, 1).p),
 }
-print(f"n={n} bars={nb} levels={tot.value} max_levels={mx.value} variant={os.environ.get('FMK_FLOW_VARIANT', '1')} "
-      f"ordered={os.environ.get('FMK_FP_ORDERED', '0')} amounts={'inexact' if len(sys.argv) > 2 else 'dyadic'}")
+print(f"n={n} bars={nb} levels={tot.value} max_levels={mx.value} "
+      f"amounts={'inexact' if len(sys.argv) > 2 else 'dyadic'}")
 for name, fn in runs.items():
     fn(); ctx.sync()
     ts = []

@@ -54,7 +54,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             fails += 1
             print(f"FAIL seed {seed} {str(e)[:1200]}", flush=True)
-    print(f"{cases} fused cases (equal / lognormal / long bars in turn), seed {seed}, FMK_FLOW_SIDE_OHLCV={os.environ.get('FMK_FLOW_SIDE_OHLCV', 'default')}: {fails} failures")
+    print(f"{cases} fused cases (equal / lognormal / long bars in turn), seed {seed}: {fails} failures")
     sys.exit(1 if fails else 0)
 
 

@@ -41,17 +41,12 @@ def case(rng, max_n):
 
 
 def run(seed, cases, max_n, verbose=True):
-    """FMK_DL_FORCE_EXACT_TIER=1 (set by main) sends every case through the exact tier; FMK_DL_VERBOSE=1 makes the library say on
-    stderr how each attempt ended: the lines are collected through a pipe and counted (status 0 = the tier served the stream)."""
+    """FMK_DL_FORCE_EXACT_TIER=1 (set by main) sends every case through the exact tier; fmk_diag_dollar_last says which path answered
+    each call (1 / 2: the exact tier served the stream, 3: it handed the call to the serial walk)."""
+    import ctypes as C
     rng = np.random.default_rng(seed)
     bad = 0
     served = tried = 0
-    log = None
-    if os.environ.get("FMK_DL_VERBOSE") == "1":
-        import tempfile
-        log = tempfile.TemporaryFile(mode="w+b")
-        saved = os.dup(2)
-        os.dup2(log.fileno(), 2)
     for c in range(cases):
         kind, px, a, thr = case(rng, max_n)
         n = len(a)
@@ -59,19 +54,16 @@ def run(seed, cases, max_n, verbose=True):
         t = engine.DeviceTrades.from_numpy(np.arange(n, dtype=np.int64), px, a)
         got = t.dollar_bar_index(thr).to_host()
         unc = t.last_uncertified
+        path = C.c_int64(-1)
+        _ffi.lib().fmk_diag_dollar_last(C.byref(path))
+        tried += path.value in (1, 2, 3)
+        served += path.value in (1, 2)
         if unc != 0 or not np.array_equal(got, want):
             m = min(len(got), len(want))
             k = int(np.argmax(got[:m] != want[:m])) if m and (got[:m] != want[:m]).any() else m
             print(f"MISMATCH whales seed {seed} case {c}: {kind} {a.dtype} n={n} thr={thr!r} bars {len(want) - 1} uncertified {unc} "
                   f"lens {len(got)} {len(want)} first difference at {k}: {got[max(0, k - 1):k + 2]} vs {want[max(0, k - 1):k + 2]}")
             bad += 1
-    if log is not None:
-        os.dup2(saved, 2)
-        log.seek(0)
-        for ln in log.read().decode(errors="replace").splitlines():
-            if "[fmk_dollar_exact]" in ln:
-                tried += 1
-                served += "status=0" in ln
     if verbose:
         print(f"whales seed {seed}: {cases} cases, {bad} failures; exact tier tried {tried} times, served {served} "
               f"(the others: a backlog beyond 500 thresholds or a replay that did not re-join -> serial walk)")
@@ -83,5 +75,4 @@ if __name__ == "__main__":
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     max_n = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2_000_000
     os.environ.setdefault("FMK_DL_FORCE_EXACT_TIER", "1")
-    os.environ.setdefault("FMK_DL_VERBOSE", "1")
     sys.exit(1 if run(seed, cases, max_n) else 0)

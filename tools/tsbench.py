@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""comp_bar_trade_size_features on N resident ticks in time bars of the given intervals.  usage: tsbench.py [N] [interval_s ...]
-(FMK_TS_MID=0: without the one-read wave kernel)"""
+"""comp_bar_trade_size_features on N resident ticks in time bars of the given intervals.  usage: tsbench.py [N] [interval_s ...]"""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
