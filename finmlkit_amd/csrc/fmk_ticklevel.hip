@@ -390,7 +390,8 @@ __device__ __forceinline__ EwMap ew_dpp(const EwMap &m)
 
 // inclusive scan of maps across the 256 threads of a block (thread order = tick order);
 // returns the EXCLUSIVE prefix for this thread, *block_total = composition of all threads
-__device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *lds /*[4]*/, EwMap *block_total)
+template <int NW = 4>
+__device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *lds /*[NW]*/, EwMap *block_total)
 {
     const int lane = fmk_lane(), w = threadIdx.x >> 6;
     EwMap inc = mine;
@@ -407,7 +408,7 @@ __device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *ld
     EwMap pre = ew_identity();
     for (int k = 0; k < w; ++k) pre = ew_compose(pre, lds[k]);
     EwMap tot = lds[0];
-    for (int k = 1; k < 4; ++k) tot = ew_compose(tot, lds[k]);
+    for (int k = 1; k < NW; ++k) tot = ew_compose(tot, lds[k]);
     *block_total = tot;
     // exclusive prefix of this thread = (waves before) o (lanes before in my wave)
     EwMap prev = ew_shfl_up(inc, 1);
@@ -424,7 +425,7 @@ __device__ __forceinline__ EwMap ew_block_exclusive(const EwMap &mine, EwMap *ld
 // the other tiles read tick by tick with range checks (0 for what is not there).  *tprev0 is ts[i0 - 1] (0 in front of tick 0).
 typedef long long ew_l2 __attribute__((ext_vector_type(2), aligned(8)));       // 16-byte accesses on an 8-byte alignment promise:
 typedef double ew_d2 __attribute__((ext_vector_type(2), aligned(8)));          // a shard's arrays start one tick before a 64-byte boundary
-__device__ __forceinline__ bool ew_whole_tile(int64_t tile, int64_t n) { return tile > 0 && (tile + 1) * EW_TILE <= n; }
+__device__ __forceinline__ bool ew_whole_tile(int64_t tile, int64_t n, int tile_ticks = EW_TILE) { return tile > 0 && (tile + 1) * tile_ticks <= n; }
 
 __device__ __forceinline__ void ew_load8(const double *__restrict__ src, int64_t i0, int64_t n, bool whole, double (&v)[EW_ITEMS])
 {
@@ -485,12 +486,12 @@ __device__ __forceinline__ void ew_mask_ticks(int64_t i0, int64_t n, double (&al
 
 // The thread's ticks of tile `tile`: yl[] the values, al[] the alphas (MODE 2: the fixed 1 - alpha) -- kept for the apply phase, exp is
 // evaluated once per tick and pass -- and the composition of the eight tick maps.
-template <int MODE>
+template <int MODE, int THREADS = EW_THREADS>
 __device__ __forceinline__ EwMap ew_thread_ticks(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t tile, int64_t n,
                                                  EwHl half_life, double (&yl)[EW_ITEMS], double (&al)[EW_ITEMS])
 {
-    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    const bool whole = ew_whole_tile(tile, n);
+    const int64_t i0 = tile * (THREADS * EW_ITEMS) + (int64_t)threadIdx.x * EW_ITEMS;
+    const bool whole = ew_whole_tile(tile, n, THREADS * EW_ITEMS);
     {
         int64_t tl[EW_ITEMS], tprev0;
         ew_load_ticks(MODE == 2 ? nullptr : ts, y, i0, n, whole, tl, yl, &tprev0);
@@ -509,13 +510,13 @@ __device__ __forceinline__ EwMap ew_thread_ticks(const int64_t *__restrict__ ts,
 
 // ... and the sequential pass over them from the state (V, V2, Sy, Syy) entering the thread's first tick: the reference's update in
 // its own operation order, its closing expression per tick, the results stored.  out[0] = NaN (volatility.py:174).
-template <int MODE>
+template <int MODE, int THREADS = EW_THREADS>
 __device__ __forceinline__ void ew_thread_apply(double V, double V2, double Sy, double Syy, const double (&yl)[EW_ITEMS],
                                                 const double (&al)[EW_ITEMS], double sigma_floor, int64_t tile, int64_t n,
                                                 double *__restrict__ out)
 {
-    const int64_t i0 = tile * EW_TILE + (int64_t)threadIdx.x * EW_ITEMS;
-    const bool whole = ew_whole_tile(tile, n);
+    const int64_t i0 = tile * (THREADS * EW_ITEMS) + (int64_t)threadIdx.x * EW_ITEMS;
+    const bool whole = ew_whole_tile(tile, n, THREADS * EW_ITEMS);
     double res[EW_ITEMS];
 #pragma unroll
     for (int k = 0; k < EW_ITEMS; ++k) {
@@ -731,13 +732,14 @@ __device__ __forceinline__ bool ew_lookback(const EwDesc &D, int64_t tile, int l
 // generation after generation -- 18.7 ms per 1e9 ticks, removed in round 6).  Here the workgroups of a CU are at different points of
 // their tiles and the SIMDs stay busy with the others' arithmetic while one waits.  Forward progress: a workgroup takes its tile from an atomic ticket, so every tile it can
 // wait for has started; a wait that gives up all the same raises the sticky error word instead of hanging.
-// Four waves per SIMD (112 .. 128 registers, no spill): 9.5 ms per 1e9 ticks; five: 13.2 ms, six: 15.6 ms (they spill).
-template <int MODE>
-__global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
+// Four waves per SIMD (112 .. 128 registers, no spill): 9.5 ms per 1e9 ticks; five: 13.2 ms, six: 15.6 ms (they spill).  THREADS: the
+// workgroup = the tile (x 8 ticks); 256 is the measured optimum (64 / 128 / 512 / 1024: 24.1 / 18.7 / 12.3 / 21.9 ms).
+template <int MODE, int THREADS, int OCC>
+__global__ __launch_bounds__(THREADS, OCC) void k_ew_onepass_d(const int64_t *__restrict__ ts, const double *__restrict__ y, int64_t n,
                                                                 EwHl half_life, double sigma_floor, const double *__restrict__ state_in,
                                                                 double *__restrict__ out, EwDesc D, int64_t *err_word)
 {
-    __shared__ EwMap lds[4];
+    __shared__ EwMap lds[THREADS / 64];
     __shared__ EwMap s_excl;
     __shared__ unsigned long long s_ticket;
     const int lane = fmk_lane();
@@ -745,9 +747,9 @@ __global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *_
     __syncthreads();
     const int64_t tile = (int64_t)s_ticket;
     double yl[EW_ITEMS], al[EW_ITEMS];
-    const EwMap m = ew_thread_ticks<MODE>(ts, y, tile, n, half_life, yl, al);
+    const EwMap m = ew_thread_ticks<MODE, THREADS>(ts, y, tile, n, half_life, yl, al);
     EwMap tot;
-    EwMap ex = ew_block_exclusive(m, lds, &tot);
+    EwMap ex = ew_block_exclusive<THREADS / 64>(m, lds, &tot);
     if (threadIdx.x < 64) {
         EwMap excl = ew_identity();
         ew_publish(D.A + 12 * tile, D.tagA + tile, tot, lane);
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(EW_THREADS, 4) void k_ew_onepass_d(const int64_t *_
     ex = ew_compose(s_excl, ex);
     double V, V2, Sy, Syy;
     ew_enter(ex, state_in, V, V2, Sy, Syy);
-    ew_thread_apply<MODE>(V, V2, Sy, Syy, yl, al, sigma_floor, tile, n, out);
+    ew_thread_apply<MODE, THREADS>(V, V2, Sy, Syy, yl, al, sigma_floor, tile, n, out);
 }
 
 // composition of all tile maps in order (ONE block): the map of the whole series, x -> a*x + b per state
@@ -814,16 +816,18 @@ static int ew_run(fmk_ctx *ctx, const int64_t *d_ts, const double *d_y, int64_t 
     const char *opv = getenv("FMK_EW_ONE_PASS");
     if (!d_map_out && opv && atoi(opv)) {
         // one pass: two-level look-back over tagged records (the tags are zeroed before every launch)
-        const int64_t groups = fmk_ceil_div(tiles, EW_W1), slots = groups * EW_W1;
-        const size_t tag_bytes = (size_t)(tiles + 2 * slots) * 8, rec_bytes = (size_t)(tiles + 2 * slots) * 96;
+        // (workgroups of 64 / 128 / 512 / 1024 threads -- tiles of 512 .. 8 192 ticks -- were measured: 24.1 / 18.7 / 12.3 / 21.9 ms against 9.5)
+        const int64_t otiles = tiles;
+        const int64_t groups = fmk_ceil_div(otiles, EW_W1), slots = groups * EW_W1;
+        const size_t tag_bytes = (size_t)(otiles + 2 * slots) * 8, rec_bytes = (size_t)(otiles + 2 * slots) * 96;
         FMK_TRY(fmk_scratch(ctx, tag_bytes + rec_bytes + 64, &scr));
         FMK_HIP(ctx, hipMemsetAsync(scr, 0, tag_bytes + rec_bytes + 8, ctx->stream)); // tags, granules, the ticket counter
         EwDesc D;
-        D.tagA = (unsigned long long *)scr; D.tagR = D.tagA + tiles; D.tagP = D.tagR + slots;
-        D.A = D.tagP + slots; D.R = D.A + 12 * tiles; D.P = D.R + 12 * slots;
+        D.tagA = (unsigned long long *)scr; D.tagR = D.tagA + otiles; D.tagP = D.tagR + slots;
+        D.A = D.tagP + slots; D.R = D.A + 12 * otiles; D.P = D.R + 12 * slots;
         D.groups = groups;
         D.ticket = (unsigned long long *)((char *)scr + tag_bytes + rec_bytes);
-        k_ew_onepass_d<MODE><<<(unsigned)tiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D, ctx->h_mail + 40);
+        k_ew_onepass_d<MODE, EW_THREADS, 4><<<(unsigned)otiles, EW_THREADS, 0, ctx->stream>>>(d_ts, d_y, n, hl, sigma_floor, d_state_in, d_out, D, ctx->h_mail + 40);
         FMK_LAUNCH_CHECK(ctx);
         return FMK_OK;
     }
