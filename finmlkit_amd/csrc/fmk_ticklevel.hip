@@ -600,8 +600,8 @@ __device__ __forceinline__ void ew_enter(const EwMap &ex, const double *__restri
 }
 
 template <int MODE>
-// six waves per SIMD (78 VGPRs, no spill): 9.5 -> 9.4 ms; eight (64 VGPRs, 68 B of scratch): 13.2 ms
-__global__ __launch_bounds__(EW_THREADS, 6) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
+// five waves per SIMD (96 VGPRs, no spill): 7.47 ms per 1e9 ticks; six (80 VGPRs, 8 spill instructions): 7.6; four: 7.46 (round 6)
+__global__ __launch_bounds__(EW_THREADS, 5) void k_ew_apply(const int64_t *__restrict__ ts, const double *__restrict__ y,
                                                          int64_t n, EwHl half_life, double sigma_floor,
                                                          const EwMap *__restrict__ tile_pre,
                                                          const double *__restrict__ state_in,
