@@ -446,6 +446,156 @@ static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
 }
 
 // ---------------------------------------------------------------------------------------
+// The tick-ordered sweep for float32 amounts, SORTED (round 6).  fp_accumulate_lean's ordered path serves a 64-tick chunk in as many
+// dependent LDS read-add-write rounds as its busiest (level, side) key has ticks -- ~20 on a tape whose trades cluster on a few levels,
+// ~4 000 cycles per chunk: the footprint sweep of full-mantissa sizes (what real sizes are) was bound by that latency, not by its
+// ~110 instructions per chunk (profiles/r06_cfg4_fused.txt).  Here a SEGMENT of 256 ticks is sorted by (key, tick) first -- one LDS
+// atomic per tick gives its rank within its key in tick order (lane-ordered atomics, chunks in order), an exclusive scan over the
+// segment's key range gives every key its slice, one LDS store per tick scatters the amounts -- and then every key's float32 sum is a
+// plain sequential loop of ONE lane over its own contiguous slice, all keys in parallel, each in the reference's order
+// (base.py:713-717; what the workgroup-per-bar kernel does for a whole bar).  The level sums that come out are the same float32
+// operations on the same operands in the same order per key.  A segment whose keys span more than 256 values (a price that moves more
+// than 128 levels within 256 trades) takes the rounds.  scnt[FP_SEG] (zero on entry, left zero) and sorted[FP_SEG]: 2 KB of LDS per wave.
+// ---------------------------------------------------------------------------------------
+#define FP_SEG 256
+#define FP_SORT_BYTES (FP_SEG * 8)
+__device__ __forceinline__ FpStats fp_accumulate_sorted(const double *__restrict__ price, const float *__restrict__ amount,
+                                                        const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low, int L,
+                                                        double tick, double inv_tick, int lane, float *vol, int *cnt, int *scnt,
+                                                        float *sorted, FpMed *med)
+{
+    int lbmin = FP_Q_UNKNOWN;
+    double atot = 0.0;
+    bool bad = false;
+    const int ilow = (int)low;
+    const bool med_on = med != nullptr && med->have;
+    uint32_t m_lo = 0, m_hi = 0, m_kmin = 0xFFFFFFFFu, m_kmax = 0;
+    int m_below = 0, m_n = 0;
+    if (med_on) { m_lo = med->blo; m_hi = med->bhi; }
+    const double *pp = price + (s + 1);
+    const float *ap = amount + (s + 1);
+    const int8_t *sp = side + (s + 1);
+    const int total = (int)(e - s);                                   // ticks of the bar (<= 2^31: one wave per bar)
+    for (int j0 = 0; j0 < total; j0 += FP_SEG) {
+        double p[4];
+        float a[4];
+        int sd[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                 // the segment's loads, all in flight together
+            const int j = j0 + 64 * c + lane;
+            const bool in = j < total;
+            p[c] = in ? pp[j] : 0.0; a[c] = in ? ap[j] : 0.f; sd[c] = in ? (int)sp[j] : 0;
+        }
+        int key[4];
+        bool pend[4];
+        int kmin = 0x7FFFFFFF, kmax = -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool in_bar = j0 + 64 * c + lane < total;
+            if (med_on) {       // the median's bracket: every tick of the bar, signed or not, inside the level range or not
+                const uint32_t k = MedKey<false>::tokey(__float_as_uint(a[c]));
+                m_kmin = (in_bar && k < m_kmin) ? k : m_kmin;
+                m_kmax = (in_bar && k > m_kmax) ? k : m_kmax;
+                m_below += __popcll(__ballot(in_bar && k < m_lo));
+                const bool inb = in_bar && k >= m_lo && k <= m_hi;
+                const uint64_t bm = __ballot(inb);
+                const int pos = m_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0));
+                if (inb && pos < FP_MED_CAP) med->cand[pos] = k;
+                m_n += __popcll(bm);
+            }
+            // level = int(round(price / tick)) - low (base.py:700-707), as in fp_accumulate_lean
+            const double qq = p[c] * inv_tick;
+            double r = rint(qq);
+            if (__ballot(in_bar && 0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) != 0) {
+                if (0.5 - fabs(qq - r) <= fabs(qq) * 1e-15) r = rint(p[c] / tick);
+            }
+            const int lvl = (int)r - ilow;
+            const bool inside = (unsigned)lvl < (unsigned)L;
+            bad |= in_bar && !inside;                                 // base.py:719
+            pend[c] = in_bar && inside && (sd[c] == 1 || sd[c] == -1);
+            key[c] = pend[c] ? lvl * 2 + (sd[c] < 0 ? 1 : 0) : 0;
+            if (pend[c]) {                                            // statistics that pick the quantum of later bars
+                const int lb = fp_lowbit_exp(a[c]);
+                lbmin = lb < lbmin ? lb : lbmin;
+                atot += fabs((double)a[c]);
+                kmin = key[c] < kmin ? key[c] : kmin;
+                kmax = key[c] > kmax ? key[c] : kmax;
+            }
+        }
+        kmin = fmk_dpp_reduce(kmin, 0x7FFFFFFF, FmkOpMin());
+        kmax = fmk_dpp_reduce(kmax, -1, FmkOpMax());
+        if (kmax < 0) continue;                                       // no signed tick inside the level range
+        if (kmax - kmin >= FP_SEG) {                                  // keys too far apart for one slice table: the rounds, chunk by chunk
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                const int before = pend[c] ? cnt[key[c]] : 0;
+                __builtin_amdgcn_wave_barrier();
+                const int rank = pend[c] ? atomicAdd(&cnt[key[c]], 1) - before : -1;
+                const int rounds = fmk_dpp_reduce(rank, -1, FmkOpMax()) + 1;
+                for (int t = 0; t < rounds; ++t) {
+                    if (rank == t) vol[key[c]] = vol[key[c]] + a[c];
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            continue;
+        }
+        // rank of every tick within its key, in tick order: lane-ordered atomics, the chunks one after the other
+        int rk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rk[c] = pend[c] ? atomicAdd(&scnt[key[c] - kmin], 1) : 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // every key's slice of sorted[]: exclusive scan of the counts; the table word becomes base << 16 | count
+        {
+            int4 c4 = *(const int4 *)&scnt[4 * lane];
+            const int t = c4.x + c4.y + c4.z + c4.w;
+            const int ex = fmk_dpp_iscan(t, 0, FmkOpAdd()) - t;
+            const int b0 = ex, b1 = b0 + c4.x, b2 = b1 + c4.y, b3 = b2 + c4.z;
+            c4.x |= b0 << 16; c4.y |= b1 << 16; c4.z |= b2 << 16; c4.w |= b3 << 16;
+            __builtin_amdgcn_wave_barrier();
+            *(int4 *)&scnt[4 * lane] = c4;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (pend[c]) sorted[(scnt[key[c] - kmin] >> 16) + rk[c]] = a[c];
+        __builtin_amdgcn_wave_barrier();
+        // the sums: slot = lane + 64 r (neighbouring keys on different lanes), each a sequential float32 loop in tick order
+        const int span = kmax - kmin;
+#pragma unroll 1
+        for (int r = 0; r < 4 && 64 * r <= span; ++r) {
+            const int slot = lane + 64 * r;
+            const int w = scnt[slot];
+            const int n_k = w & 0xFFFF;
+            if (n_k) {
+                const int base = w >> 16, k = kmin + slot;
+                float sum = vol[k];
+                int i = 0;
+                for (; i + 4 <= n_k; i += 4) {
+                    const float x0 = sorted[base + i], x1 = sorted[base + i + 1], x2 = sorted[base + i + 2], x3 = sorted[base + i + 3];
+                    sum = sum + x0; sum = sum + x1; sum = sum + x2; sum = sum + x3;
+                }
+                for (; i < n_k; ++i) sum = sum + sorted[base + i];
+                vol[k] = sum;
+                cnt[k] += n_k;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        *(int4 *)&scnt[4 * lane] = make_int4(0, 0, 0, 0);             // (every word carries its base by now: the whole table)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (med_on) { med->below = m_below; med->ncand = m_n; med->kmin = m_kmin; med->kmax = m_kmax; }
+    FpStats st;
+    st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
+    st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    st.units_ok = true;
+    st.bad = __ballot(bad) != 0;
+    __builtin_amdgcn_wave_barrier();
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------
 // phase 2: one wave per bar
 // ---------------------------------------------------------------------------------------
 // FAST: the classes of 512 levels and more (fp_emit_bar's fast_sum; a template flag so that the 128 / 256-level instantiations keep their code)
@@ -469,8 +619,9 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     const int wib = fmk_uniform((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     // FAST: 16 B per level (no aux area) + the tree routine's tables
-    const size_t per_wave = FAST ? (size_t)lmax * 16 + FMK_PW_PAR_STK * 4
-                                 : (size_t)lmax * 24 + 256 + ((MED && !GLOBAL) ? (size_t)FP_MED_CAP * 4 : 0);
+    constexpr size_t sort_bytes = (!AF64 && !GLOBAL) ? (size_t)FP_SORT_BYTES : 0;     // fp_accumulate_sorted's slice table + sorted amounts
+    const size_t per_wave = (FAST ? (size_t)lmax * 16 + FMK_PW_PAR_STK * 4
+                                  : (size_t)lmax * 24 + 256 + ((MED && !GLOBAL) ? (size_t)FP_MED_CAP * 4 : 0)) + sort_bytes;
     // the wave's histogram: LDS for the three narrow classes (LDS-typed pointers: ds_add / ds_read), a slice of global
     // scratch for bars wider than 2048 levels (same code; a wave's own stores are visible to its later loads)
     unsigned char *mine;
@@ -486,6 +637,14 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     med.cand = (MED && !GLOBAL) ? (uint32_t *)(mine + (size_t)lmax * 24 + 256) : nullptr;
     med.blo = med.bhi = 0; med.have = 0; med.below = med.ncand = 0; med.kmin = 0xFFFFFFFFu; med.kmax = 0;
     FpMed *medp = (MED && !GLOBAL && lean) ? &med : nullptr;
+    int *scnt = nullptr;
+    float *sorted = nullptr;
+    if constexpr (!AF64 && !GLOBAL) {
+        scnt = (int *)(mine + per_wave - sort_bytes);
+        sorted = (float *)(scnt + FP_SEG);
+        for (int k = lane; k < FP_SEG; k += 64) scnt[k] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
     uint32_t med_width = 0;
     int med_fallbacks = 0;
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wib;
@@ -536,7 +695,9 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
         if (!done) {
             bool did = false;
             if constexpr (!GLOBAL) {
-                if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0, medp); did = true; }
+                if constexpr (!AF64) {
+                    if (lean) { st = fp_accumulate_sorted(price, (const float *)amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, scnt, sorted, medp); did = true; }
+                } else if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0, medp); did = true; }
             }
             if (!did) st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
             // remember a usable quantum for the next bar (if this bar would have certified)
@@ -1186,8 +1347,9 @@ static int fp_launch(fmk_ctx *ctx, const double *p, const void *a, const int8_t 
     // (lognormal one-minute bars) that idles the slots of the others, so streams of many bars take one-wave workgroups: the
     // dispatcher then balances per wave
     const int wpb_in = wpb;
-    size_t smem = fast ? (size_t)wpb * ((size_t)lmax * 16 + FMK_PW_PAR_STK * 4)
-                       : (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0));
+    const size_t sort_bytes = AF64 ? 0 : (size_t)FP_SORT_BYTES;
+    size_t smem = fast ? (size_t)wpb * ((size_t)lmax * 16 + FMK_PW_PAR_STK * 4 + sort_bytes)
+                       : (size_t)wpb * ((size_t)lmax * 24 + 256 + (med ? (size_t)FP_MED_CAP * 4 : 0) + sort_bytes);
     int64_t blocks = fmk_ceil_div(nb, wpb);
     int64_t cap = (int64_t)ctx->n_cu * 64 * (wpb_in / wpb);                        // (the same number of waves in the grid)
     unsigned char *gscratch = nullptr;
