@@ -459,6 +459,9 @@ static int fp_lds_atomics_in_lane_order(fmk_ctx *ctx)
 // ---------------------------------------------------------------------------------------
 #define FP_SEG 256
 #define FP_SORT_BYTES (FP_SEG * 8)
+// STATS: also measure the quantum a later bar could certify with (lowest set bit, magnitude); a wave whose bars keep failing that test
+// sweeps without (k_bar_footprints: re-probed every 32nd bar).
+template <bool STATS>
 __device__ __forceinline__ FpStats fp_accumulate_sorted(const double *__restrict__ price, const float *__restrict__ amount,
                                                         const int8_t *__restrict__ side, int64_t s, int64_t e, int64_t low, int L,
                                                         double tick, double inv_tick, int lane, float *vol, int *cnt, int *scnt,
@@ -514,10 +517,12 @@ __device__ __forceinline__ FpStats fp_accumulate_sorted(const double *__restrict
             bad |= in_bar && !inside;                                 // base.py:719
             pend[c] = in_bar && inside && (sd[c] == 1 || sd[c] == -1);
             key[c] = pend[c] ? lvl * 2 + (sd[c] < 0 ? 1 : 0) : 0;
-            if (pend[c]) {                                            // statistics that pick the quantum of later bars
-                const int lb = fp_lowbit_exp(a[c]);
-                lbmin = lb < lbmin ? lb : lbmin;
-                atot += fabs((double)a[c]);
+            if (pend[c]) {
+                if constexpr (STATS) {                                // statistics that pick the quantum of later bars
+                    const int lb = fp_lowbit_exp(a[c]);
+                    lbmin = lb < lbmin ? lb : lbmin;
+                    atot += fabs((double)a[c]);
+                }
                 kmin = key[c] < kmin ? key[c] : kmin;
                 kmax = key[c] > kmax ? key[c] : kmax;
             }
@@ -587,8 +592,12 @@ __device__ __forceinline__ FpStats fp_accumulate_sorted(const double *__restrict
     }
     if (med_on) { med->below = m_below; med->ncand = m_n; med->kmin = m_kmin; med->kmax = m_kmax; }
     FpStats st;
-    st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
-    st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    st.lbmin = FP_Q_UNKNOWN;
+    st.atot = 0.0;
+    if constexpr (STATS) {
+        st.lbmin = fmk_dpp_reduce(lbmin, FP_Q_UNKNOWN, FmkOpMin());
+        st.atot = fmk_dpp_reduce(atot, 0.0, FmkOpAdd());
+    }
     st.units_ok = true;
     st.bad = __ballot(bad) != 0;
     __builtin_amdgcn_wave_barrier();
@@ -651,6 +660,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     const double inv_tick = 1.0 / tick;
     int wq = FP_Q_UNKNOWN;        // quantum exponent the previous bar of this wave certified with
+    int no_quantum = 0;           // bars in a row whose tick-ordered sweep found no usable quantum
     // `only` (list mode: [0] = count, [32...] = bar numbers): the bars k_bar_footprints_lanes left to this schedule
     const int64_t todo = only ? (int64_t)only[0] : nb;
     for (int64_t it = wave0; it < todo; it += nwaves) {
@@ -696,7 +706,14 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             bool did = false;
             if constexpr (!GLOBAL) {
                 if constexpr (!AF64) {
-                    if (lean) { st = fp_accumulate_sorted(price, (const float *)amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, scnt, sorted, medp); did = true; }
+                    if (lean) {
+                        // full mantissas never certify: after four bars in a row without a usable quantum the wave stops measuring one
+                        // (the statistics are ~14 of the sweep's ~100 instructions per chunk), and looks again every 32nd bar
+                        const bool stats = no_quantum < 4 || (no_quantum & 31) == 0;
+                        if (stats) st = fp_accumulate_sorted<true>(price, (const float *)amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, scnt, sorted, medp);
+                        else st = fp_accumulate_sorted<false>(price, (const float *)amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, scnt, sorted, medp);
+                        did = true;
+                    }
                 } else if (lean) { st = fp_accumulate_lean<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0, medp); did = true; }
             }
             if (!did) st = fp_accumulate<AF64, false>(price, amount, side, s, e, low, L, tick, inv_tick, lane, vol, cnt, 0);
@@ -706,6 +723,7 @@ __global__ __launch_bounds__(256) void k_bar_footprints(const double *__restrict
             const bool usable = st.lbmin != FP_Q_UNKNOWN && st.lbmin != (int)0x80000000 &&
                                 (fp_certified(probe, st.lbmin) || fp_certified_per_key(probe, st.lbmin, vol, 2 * L, lane));
             wq = usable ? st.lbmin : FP_Q_UNKNOWN;
+            no_quantum = usable ? 0 : no_quantum + 1;
         }
         if (st.bad && lane == 0 && n_bad) atomicAdd(n_bad, 1ULL);
         __builtin_amdgcn_wave_barrier();

@@ -150,22 +150,7 @@ __device__ __forceinline__ void fu_load_all(const double *__restrict__ pb, const
     }
 }
 
-// ---- median trade size of a bar whose amounts sit in R registers per lane (any lane layout: only counts matter).
-// fmk_median.h's search bisects the KEY range from [min, max] -- ten-odd rounds of R compares each before 64 candidates are left, then a
-// compaction and a 21-stage cross-lane sort.  Here (the post-walk phase is most of this kernel's instructions):
-//   * the wave carries a BRACKET (lo, hi] of keys around its previous bar's middle keys, as wide as it takes to catch ~100 keys
-//     (the width adapts); consecutive bars of a tape have about the same size distribution, so ONE sweep of 2 R compares usually
-//     proves that both middle ranks lie inside;
-//   * register rounds only while more than 64 candidates are left (one or two), then the candidates go to one key per lane and the
-//     bisection continues on that single register (a compare and a ballot per round) until the ranks are pinned -- no sort;
-//   * a bracket miss (first bar of a wave, a jump in the size distribution) or an amount the walk flagged (NaN: np.median returns
-//     NaN) takes the full range [min, max] as before.
-// The result is np.median's bits in every case; the bracket only decides how much work it takes.
-struct FuMed {
-    uint32_t lo, hi;         // the bracket (lo, hi] in key units, wave-uniform
-    uint32_t width;          // half-width beyond the middle keys it was built with
-    int have;
-};
+// (the carried-bracket median of a bar whose keys sit in registers -- FuMed, fu_median -- lives in fmk_median.h: k_bar_median_small uses it too)
 
 // ---- float64 wave reductions for this kernel's fold (most of its instructions are behind the walk).  fmk_dpp_reduce is a scan: every
 // step sets up an identity for the lanes without a source (two moves), moves both halves and combines -- five to seven instructions
@@ -197,125 +182,6 @@ FU_REDUCE(fu_rmax, bf_max)
 FU_REDUCE(fu_rmin, bf_min)
 FU_REDUCE(fu_rsum, fu_op_add)
 #undef FU_REDUCE
-
-__device__ __forceinline__ uint32_t fu_wave_umin(uint32_t v)
-{
-    return (uint32_t)fmk_dpp_reduce((int)(v ^ 0x80000000u), (int)0x7FFFFFFF, FmkOpMin()) ^ 0x80000000u;
-}
-__device__ __forceinline__ uint32_t fu_wave_umax(uint32_t v)
-{
-    return (uint32_t)fmk_dpp_reduce((int)(v ^ 0x80000000u), (int)0x80000000, FmkOpMax()) ^ 0x80000000u;
-}
-
-template <int R>
-__device__ __forceinline__ double fu_median(const uint32_t (&key)[R], int cnt, int lane, bool maybe_nan, FuMed &med, uint32_t *buf)
-{
-    typedef MedKey<false> MK;
-    const int k1 = (cnt - 1) >> 1, k2 = cnt >> 1;
-    uint32_t lo = 0, hi = 0;
-    int clo = 0, chi = cnt;
-    bool inside = false;
-    if (med.have && !maybe_nan) {
-        int c1 = 0, c2 = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            c1 += med_popc(key[i] <= med.lo);
-            c2 += med_popc(key[i] <= med.hi);              // (hi < MAXK: the sentinels of the unused slots never count)
-        }
-        if (c1 <= k1 && k2 < c2) {
-            inside = true; lo = med.lo; hi = med.hi; clo = c1; chi = c2;
-            // about a hundred keys inside: wide enough for the next bar's middle ranks (sqrt(cnt) / 2 ~ 17 ranks of sampling noise on
-            // either side), narrow enough for one register round
-            const int nc = c2 - c1;
-            if (nc > 144) med.width -= med.width >> 2;
-            else if (nc < 80) med.width += (med.width >> 2) + 1;
-        }
-    }
-    if (!inside) {
-        uint32_t a = MK::MAXK, bmax = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const uint32_t k = key[i];
-            a = k < a ? k : a;
-            bmax = (k != MK::MAXK && k > bmax) ? k : bmax;
-        }
-        const uint32_t mn = fu_wave_umin(a), mx = fu_wave_umax(bmax);
-        if (mn < MK::KEY_NEG_INF || mx > MK::KEY_POS_INF) { med.have = 0; return NAN; }     // a NaN amount: np.median -> NaN
-        lo = mn - 1; hi = mx; clo = 0; chi = cnt;
-    }
-    // invariant: count(key <= lo) = clo <= k1  and  count(key <= hi) = chi > k2
-    uint32_t v1 = 0, v2 = 0;
-    bool found = false;
-    while (chi - clo > 64) {
-        if (hi - lo == 1) { v1 = v2 = hi; found = true; break; }         // a tie of more than 64 equal keys at the middle
-        const uint32_t pivot = lo + ((hi - lo) >> 1);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) c += med_popc(key[i] <= pivot);
-        if (c > k2) { hi = pivot; chi = c; }
-        else if (c <= k1) { lo = pivot; clo = c; }
-        else {                                                           // k1 < c <= k2: the pivot separates the two middle ranks
-            uint32_t a = 0, bb = MK::MAXK;
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const uint32_t k = key[i];
-                a = (k <= pivot && k > a) ? k : a;
-                bb = (k > pivot && k < bb) ? k : bb;
-            }
-            v1 = fu_wave_umax(a); v2 = fu_wave_umin(bb);
-            found = true;
-            break;
-        }
-    }
-    uint32_t cmin = 0, cmax = 0;
-    if (!found) {
-        // <= 64 candidates in (lo, hi]: one per lane
-        buf[lane] = MK::MAXK;
-        __builtin_amdgcn_wave_barrier();
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const uint32_t k = key[i];
-            const bool in = k > lo && k <= hi;
-            const uint64_t m = __ballot(in);
-            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (in) buf[pos] = k;
-            base += __popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t c0 = buf[lane];                                   // MAXK beyond the candidates
-        __builtin_amdgcn_wave_barrier();
-        if (!inside) {                                                   // (a fresh bracket takes its width from the candidates' span)
-            cmin = fu_wave_umin(c0);
-            cmax = fu_wave_umax(lane < chi - clo ? c0 : 0u);
-        }
-        // the bisection goes on over this one register (it holds every key of (lo, hi]: count(key <= pivot) = clo + the candidates <= pivot)
-        for (;;) {
-            if (hi - lo == 1) { v1 = v2 = hi; break; }
-            const uint32_t pivot = lo + ((hi - lo) >> 1);
-            const int c = clo + med_popc(c0 <= pivot);
-            if (c > k2) hi = pivot;
-            else if (c <= k1) lo = pivot;
-            else {
-                v1 = fu_wave_umax(c0 <= pivot ? c0 : 0u);
-                v2 = fu_wave_umin(c0 > pivot ? c0 : MK::MAXK);
-                break;
-            }
-        }
-    }
-    // the bracket for the wave's next bar
-    if (!inside) {
-        if (found) med.width = 64;
-        else {
-            const uint32_t wl = v1 - cmin, wh = cmax - v2;
-            med.width = wl > wh ? wl : wh;
-        }
-        med.have = 1;
-    }
-    med.lo = v1 > med.width + 1 ? v1 - med.width - 1 : 0;
-    med.hi = v2 < 0xFFFFFFFEu - med.width ? v2 + med.width : 0xFFFFFFFEu;
-    return (cnt & 1) ? MK::value(v1) : (MK::value(v1) + MK::value(v2)) / 2.0;   // np.median: mean of the two middle elements
-}
 
 __device__ __forceinline__ int fu_lowbit_min(int a, int b) { return b < a ? b : a; }
 

@@ -619,23 +619,31 @@ struct TbFuse {
 // order-statistic search without the price column (4 B/tick).  For cfg 4's first half the order-flow kernel k_bar_dir_lanes walks
 // price / amount / side anyway and takes open / high / low / close / volume / vwap along for six instructions per tick; what it cannot
 // do in one lane is the median of 1 200 amounts.  Longer bars: k_bar_median through the flag, as after k_bar_ohlcv_small.
+// Round 6: the order-statistic search is the carried-bracket one of the one-pass cfg 4 kernels (fmk_median.h: fu_median) -- the wave
+// keeps a bracket of keys around its previous bar's middle, one sweep of 2 NCH compares usually proves both middle ranks inside, the
+// candidates go to one key per lane and the bisection finishes on that register -- instead of a bisection of the whole key range and a
+// 21-stage cross-lane sort per bar: np.median's bits either way.
 template <int NCH>
 __device__ __forceinline__ void median_bar(const void *__restrict__ amount, int64_t b, int64_t start, int64_t cnt, int lane,
-                                           uint32_t *buf, double *__restrict__ o_median)
+                                           uint32_t *buf, double *__restrict__ o_median, FuMed &med)
 {
     typedef MedKey<false> MK;
     const uint32_t *ab = (const uint32_t *)amount + start;
     const unsigned last = (unsigned)(cnt - 1);
-    MedBar<false, NCH, true> bar;
+    uint32_t key[NCH];
+    bool nan = false;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         unsigned idx = (unsigned)(c * 64 + lane);
         if (c == NCH - 1) idx = idx < last ? idx : last;
         const uint32_t raw = ab[idx];
-        bar.key[c] = (c < NCH - 1 || (unsigned)(c * 64 + lane) <= last) ? MK::tokey(raw) : MK::MAXK;
+        nan |= (raw & 0x7FFFFFFFu) > 0x7F800000u;                     // (a clamped duplicate of the last tick cannot add a NaN that is not there)
+        key[c] = (c < NCH - 1 || (unsigned)(c * 64 + lane) <= last) ? MK::tokey(raw) : MK::MAXK;
     }
-    bar.amount = amount; bar.start = start; bar.cnt = cnt; bar.lane = lane;
-    const double m = med_search<false, NCH, true>(bar, buf);
+    const bool any_nan = __ballot(nan) != 0;
+    double m;
+    if (any_nan) { m = NAN; med.have = 0; }                           // np.median of a bar with a NaN amount
+    else m = fu_median<NCH>(key, (int)cnt, lane, false, med, buf);
     if (lane == 0) o_median[b] = m;
 }
 
@@ -648,6 +656,8 @@ __global__ __launch_bounds__(256) void k_bar_median_small(const float *__restric
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wib;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     uint32_t *buf = sbuf[wib];
+    FuMed med;
+    med.lo = med.hi = 0; med.width = 64; med.have = 0;
     for (int64_t b = wave0; b < nb; b += nwaves) {
         const int64_t s = fmk_uniform(ci[b]);
         const int64_t e = fmk_uniform(ci[b + 1]);
@@ -660,11 +670,11 @@ __global__ __launch_bounds__(256) void k_bar_median_small(const float *__restric
         if (cnt <= 0) { if (lane == 0) o_median[b] = 0.0; continue; }     // base.py:352-361
         const int64_t start = s + 1;
         switch ((int)((cnt + 63) >> 6)) {
-#define FMK_MB(N) case N: median_bar<N>(amount, b, start, cnt, lane, buf, o_median); break;
+#define FMK_MB(N) case N: median_bar<N>(amount, b, start, cnt, lane, buf, o_median, med); break;
             FMK_MB(1) FMK_MB(2) FMK_MB(3) FMK_MB(4) FMK_MB(5) FMK_MB(6) FMK_MB(7) FMK_MB(8) FMK_MB(9) FMK_MB(10) FMK_MB(11)
             FMK_MB(12) FMK_MB(13) FMK_MB(14) FMK_MB(15) FMK_MB(16) FMK_MB(17) FMK_MB(18) FMK_MB(19) FMK_MB(20)
 #undef FMK_MB
-        default: median_bar<21>(amount, b, start, cnt, lane, buf, o_median); break;
+        default: median_bar<21>(amount, b, start, cnt, lane, buf, o_median, med); break;
         }
     }
 }
