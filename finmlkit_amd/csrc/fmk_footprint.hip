@@ -19,10 +19,11 @@
 //         amounts are then accumulated as integer units with LDS integer atomics (ds_add_u32; the
 //         float atomic ds_add_f32 measured ~25x slower) and converted back at the end.  The certificate
 //         is evaluated from the data of the bar itself; q is remembered per wave.
-//       - ordered path (any input): per chunk the lanes are grouped by (level, side) key with a
-//         ballot loop; inside a group the running float32 value is passed from the lane of rank t-1 to
-//         rank t by a lane gather (tick order), the first lane starts from LDS and the last one stores.
-//         Distinct keys proceed in parallel, no atomics.
+//       - ordered path (any input).  float32 amounts (round 6, fp_accumulate_sorted): a segment of 256 ticks is sorted
+//         by (key, tick) -- one lane-ordered LDS atomic per tick for its rank within its key, a scan for the keys'
+//         slices, one LDS store per tick -- and one lane per key adds its slice in tick order.  float64 amounts /
+//         histograms in global scratch: per chunk the lanes are grouped by (level, side) key; inside a group the
+//         running float32 value passes from the lane of rank t-1 to rank t (tick order).
 //   * comp_footprint_features runs on the LDS histogram: diagonal imbalance flags (float32 product
 //     like NumPy: float32 array * Python float), longest signed run, first argmax (COT), and the
 //     float32 sums total / gini with NumPy's pairwise summation order reproduced exactly
