@@ -528,8 +528,11 @@ __device__ __forceinline__ FpStats fp_accumulate_sorted(const double *__restrict
                 kmax = key[c] > kmax ? key[c] : kmax;
             }
         }
-        kmin = fmk_dpp_reduce(kmin, 0x7FFFFFFF, FmkOpMin());
-        kmax = fmk_dpp_reduce(kmax, -1, FmkOpMax());
+        if (2 * L <= FP_SEG) { kmin = 0; kmax = 2 * L - 1; }          // a bar of <= 128 levels: its keys ARE the slots
+        else {
+            kmin = fmk_dpp_reduce(kmin, 0x7FFFFFFF, FmkOpMin());
+            kmax = fmk_dpp_reduce(kmax, -1, FmkOpMax());
+        }
         if (kmax < 0) continue;                                       // no signed tick inside the level range
         if (kmax - kmin >= FP_SEG) {                                  // keys too far apart for one slice table: the rounds, chunk by chunk
 #pragma unroll 1
