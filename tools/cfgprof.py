@@ -13,7 +13,7 @@ import numpy as np
 from finmlkit_amd import _ffi, engine
 from finmlkit_amd._ffi import DeviceArray, c_i64
 
-KEYS = ("cfg3_volume_index", "cfg3_volume_build_ohlcv", "cfg3_dollar_index", "cfg3_dollar_build_ohlcv", "cfg4_equal_bars",
+KEYS = ("cfg3_volume_index", "cfg3_volume_build_ohlcv", "cfg3_dollar_index", "cfg3_dollar_build_ohlcv", "cfg4_equal_bars", "cfg4_lognormal",
         "cfg4_equal_bars_full_mantissa", "cfg4_lognormal_full_mantissa", "lagged_returns_5s", "ewmst_60s",
         "cusum_floor_5e-4", "cusum_floor_1e-5")
 
