@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Is the allocation-dependent step time (tools/allocwarm.py) a property of the memory system or of the OHLCV kernel?
+"""The placement study of round 4 in one script (its siblings -- allocwarm, arenawarm, placeexp, placemap, placeprobe, placeshift, placepmc
+... -- were removed in round 6; they are in the repository's history, their results in profiles/r04_placement*.txt and
+profiles/r05_placement_counters.txt).  Is the allocation-dependent step time a property of the memory system or of the OHLCV kernel?
 One process, R rounds: free everything, give the pooled blocks back to the driver, allocate + fill the input columns, then
 on the SAME allocation time (a) the plain read probe over the price column (8 B/lane and 16 B/lane variants, 8 GB) and
 (b) 20 steps of time-bar OHLCV + median.  Prints both per round and their correlation.
