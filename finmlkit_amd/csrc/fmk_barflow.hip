@@ -1694,7 +1694,12 @@ static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_
     if (mode == 0 || amount_is_f64 || nb < 1) return FMK_OK;
     if (mode == 2 || mode == 3) { *mode_out = mode - 1; return FMK_OK; }
     const int64_t mean = n / nb;
-    if (mean < 96 || mean > 1400 || nb < (int64_t)ctx->n_cu * 8) return FMK_OK;
+    // Where the one pass wins (tools/cfg4bench.py N interval, 1e9 ticks, profiles/r06_cfg4_fused.txt): its per-bar tail (~1 200 instructions
+    // whatever the bar's length) loses to the lane schedules below ~240 ticks per bar -- 26.8 against 17.7 ms at 100, 17.8 / 13.9 at 160,
+    // 12.1 / 12.5 at 240, 10.2 / 11.2 at 300, 6.3 / 7.9 at 600, 4.9 / 7.3 at 1 200, 4.8 / 8.7 at 1 400 -- and beyond one tile per bar (1 800:
+    // 12.6 / 8.9).  Without the histogram (sizes that do not certify) it only pays where the two-pass form starts to hand bars to its
+    // long-bar classes: 7.05 / 7.33 at 1 260, 7.32 / 7.88 at 1 340, 7.45 / 8.56 at 1 400, but 9.3 / 8.2 at 600 and 14.6 / 11.9 at 300.
+    if (mean < 256 || mean > 1400 || nb < (int64_t)ctx->n_cu * 8) return FMK_OK;
     int *d = (int *)(ctx->d_mail + 44);
     const int init[3] = {FP_Q_UNKNOWN, -1000, 0};
     FMK_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
@@ -1728,7 +1733,7 @@ static int bars_flow_fused_ok(fmk_ctx *ctx, const void *d_amount, int amount_is_
     }
     // largest sampled amount < 2^mx: below 2^23 units of 2^lb when mx - lb <= 23 (one binade of slack for what the sample missed)
     const bool certifies = got[2] == 0 && (got[0] == FP_Q_UNKNOWN || got[1] - got[0] <= 22);
-    *mode_out = certifies ? 1 : (got[2] == 0 ? 2 : 0);                // (negative / non-finite sizes in the sample: the schedules below)
+    *mode_out = certifies ? 1 : ((got[2] == 0 && mean >= 1250) ? 2 : 0);   // (negative / non-finite sizes in the sample: the schedules below)
     return FMK_OK;
 }
 
